@@ -1,0 +1,226 @@
+/*
+ * phip.h -- C ABI of the MI355X-native `path_hip` integrator back end (libphip.so).
+ *
+ * This is the drop-in boundary: it is exactly what a Mitsuba 0.6
+ * integrator plugin `path_hip.so` (class PathHIP : MonteCarloIntegrator, see
+ * mitsuba_amd/plugin/path_hip.cpp and INTEGRATION.md) binds in place of the CPU
+ * per-block worker loop.  Reference interfaces replaced (file:line under /root/reference):
+ *
+ *   phip_scene_create   <- Scene::initialize + ShapeKDTree::build     src/librender/scene.cpp:322-384,
+ *                                                                      src/librender/skdtree.cpp:68-110
+ *   phip_render         <- SamplingIntegrator::render + BlockRenderer::process + renderBlock
+ *                          + MIPathTracer::Li + ImageBlock::put        src/librender/integrator.cpp:95-188,
+ *                                                                      src/integrators/path/path.cpp:119-300,
+ *                                                                      include/mitsuba/render/imageblock.h:103-204
+ *   phip_render_device  <- same, result left in device memory so the caller can RCCL-reduce it
+ *                          (replaces StreamBackend::sendWorkResult,    src/libcore/sched_remote.cpp:519-532)
+ *   phip_trace          <- ShapeKDTree::rayIntersect(ray, its) / (ray) src/librender/skdtree.cpp:112-142,207-226
+ *   phip_cancel         <- SamplingIntegrator::cancel                  src/librender/integrator.cpp:90-93
+ *   phip_develop        <- HDRFilm::develop weight normalisation       src/libcore/fmtconv.cpp:979-991
+ *
+ * Conventions: plain C, plain pointers and sizes, no exceptions cross the boundary.  Every
+ * function that can fail returns 0 on success and a negative phip_status otherwise;
+ * phip_last_error() returns a thread-local human-readable message.  All pointers passed in are
+ * borrowed for the duration of the call only (phip_scene_create deep-copies).  All arithmetic on
+ * the path is float32 / RGB (the reference's -DSINGLE_PRECISION -DSPECTRUM_SAMPLES=3 build).
+ */
+#ifndef PHIP_H
+#define PHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHIP_ABI_VERSION 1
+
+typedef enum phip_status {
+    PHIP_OK              =  0,
+    PHIP_ERR_INVALID     = -1,  /* bad argument / malformed scene description            */
+    PHIP_ERR_UNSUPPORTED = -2,  /* feature outside the path (e.g. phong microfacets)     */
+    PHIP_ERR_DEVICE      = -3,  /* HIP runtime error, no device, kernel failure          */
+    PHIP_ERR_CANCELLED   = -4,  /* phip_cancel() was called while rendering              */
+    PHIP_ERR_NOMEM       = -5
+} phip_status;
+
+/* ---- materials: src/bsdfs/{diffuse,dielectric,roughconductor,twosided}.cpp ---- */
+typedef enum phip_bsdf_type {
+    PHIP_BSDF_DIFFUSE        = 0,  /* SmoothDiffuse, diffuse.cpp:110-150                 */
+    PHIP_BSDF_DIELECTRIC     = 1,  /* SmoothDielectric, dielectric.cpp:217-387           */
+    PHIP_BSDF_ROUGHCONDUCTOR = 2,  /* RoughConductor, roughconductor.cpp:253-415         */
+    PHIP_BSDF_TWOSIDED       = 3   /* TwoSidedBRDF adapter, twosided.cpp:108-183         */
+} phip_bsdf_type;
+
+typedef enum phip_microfacet_type {   /* MicrofacetDistribution::EType, microfacet.h:47-56 */
+    PHIP_MF_BECKMANN = 0,
+    PHIP_MF_GGX      = 1
+} phip_microfacet_type;
+
+typedef struct phip_material {
+    uint32_t type;              /* phip_bsdf_type                                          */
+    uint32_t nested[2];         /* TWOSIDED: material ids of the front / back BRDF
+                                   (equal when only one was nested, twosided.cpp:87-88)  */
+    float    reflectance[3];    /* DIFFUSE: reflectance; DIELECTRIC / ROUGHCONDUCTOR:
+                                   specularReflectance                                   */
+    float    transmittance[3];  /* DIELECTRIC: specularTransmittance                     */
+    float    eta[3];            /* DIELECTRIC: eta[0] = intIOR/extIOR (dielectric.cpp:158);
+                                   ROUGHCONDUCTOR: eta/extEta as linear RGB              */
+    float    k[3];              /* ROUGHCONDUCTOR: k/extEta as linear RGB                */
+    float    alpha_u, alpha_v;  /* ROUGHCONDUCTOR roughness (clamped to >= 1e-4 inside)  */
+    uint32_t distribution;      /* phip_microfacet_type                                  */
+    uint32_t sample_visible;    /* microfacet.h:144, default true                        */
+} phip_material;
+
+/* ---- shapes: every shape is a TriMesh (analytic shapes go through Shape::createTriMesh) ---- */
+typedef struct phip_shape {
+    uint32_t first_vertex, n_vertices;   /* range in positions[] / normals[]              */
+    uint32_t first_triangle, n_triangles;/* range in indices[] (indices are GLOBAL vertex ids) */
+    uint32_t material;                   /* id into materials[]                           */
+    int32_t  emitter;                    /* id into emitters[] or -1                      */
+    uint32_t has_normals;                /* 0: shading normal = face normal (skdtree.h:393)*/
+    uint32_t reserved;
+} phip_shape;
+
+/* ---- emitters: only `area` (src/emitters/area.cpp) is on the path ---- */
+typedef struct phip_emitter {
+    float    radiance[3];
+    float    sampling_weight;            /* Emitter::getSamplingWeight, default 1         */
+    uint32_t shape;                      /* the parent shape (area.cpp:185-203)           */
+    uint32_t reserved[3];
+} phip_emitter;
+
+/* ---- sensor: `perspective` pinhole (src/sensors/perspective.cpp:126-180,271-297) ---- */
+typedef struct phip_camera {
+    float to_world[16];      /* row-major camera-to-world, no scale (perspective.cpp:116-118)  */
+    float xfov_deg;          /* horizontal field of view in degrees (sensor.cpp:244-278 resolved)*/
+    float near_clip, far_clip;
+    float reserved;
+} phip_camera;
+
+/* ---- film + reconstruction filter (films/hdrfilm.cpp, libcore/rfilter.cpp:38-57) ---- */
+#define PHIP_FILTER_RESOLUTION 31
+typedef struct phip_film {
+    int32_t width, height;               /* full film size                                */
+    int32_t crop_offset_x, crop_offset_y;
+    int32_t crop_width, crop_height;     /* the rendered window; output is crop-sized     */
+    float   filter_radius;               /* ReconstructionFilter::getRadius               */
+    float   filter_table[PHIP_FILTER_RESOLUTION + 1]; /* m_values[], last entry 0         */
+} phip_film;
+
+typedef struct phip_scene_desc {
+    uint32_t abi_version;                /* PHIP_ABI_VERSION                              */
+    uint32_t n_vertices;
+    const float    *positions;           /* 3*n_vertices, world space                     */
+    const float    *normals;             /* 3*n_vertices or NULL (then no shape has normals)*/
+    uint32_t n_triangles;
+    const uint32_t *indices;             /* 3*n_triangles, global vertex ids              */
+    uint32_t n_shapes;
+    const phip_shape    *shapes;         /* triangle ranges must tile [0,n_triangles) in order */
+    uint32_t n_materials;
+    const phip_material *materials;
+    uint32_t n_emitters;
+    const phip_emitter  *emitters;
+    phip_camera camera;
+    phip_film   film;
+} phip_scene_desc;
+
+/* ---- integrator parameters: MonteCarloIntegrator (src/librender/integrator.cpp:190-225) ---- */
+typedef enum phip_sampler_kind {
+    PHIP_SAMPLER_CTR = 0     /* counter-based (pixel, sample, dimension) stream -- the parity stream */
+} phip_sampler_kind;
+
+typedef struct phip_render_params {
+    int32_t  spp;                /* sampler sampleCount                                   */
+    int32_t  max_depth;          /* -1 = infinite (integrator.cpp:197)                    */
+    int32_t  rr_depth;           /* default 5                                             */
+    int32_t  strict_normals;     /* default 0                                             */
+    int32_t  hide_emitters;      /* default 0                                             */
+    int32_t  block_size;         /* Scene::getBlockSize, default 32 (mitsuba.cpp:144)     */
+    uint32_t sampler;            /* phip_sampler_kind                                     */
+    uint32_t seed;
+    /* block sharding: this call renders the blocks whose index in the reference's spiral order
+       (imageproc.cpp:43-78) is congruent to shard_index modulo shard_count. 0/1 = whole image. */
+    int32_t  shard_index;
+    int32_t  shard_count;
+    int32_t  device;             /* HIP device ordinal                                    */
+    int32_t  flags;              /* PHIP_FLAG_*                                           */
+    void    *stream;             /* hipStream_t to launch on, NULL = library-owned stream */
+} phip_render_params;
+
+#define PHIP_FLAG_KERNEL_TIMING 1   /* bracket the kernels with hipEvents, fill phip_stats.*_ms */
+#define PHIP_FLAG_SAMPLE_BUFFER 2   /* keep per-sample radiance for phip_get_samples (tests)    */
+
+typedef struct phip_stats {
+    uint64_t samples;            /* camera samples rendered by this call                  */
+    uint64_t closest_rays;       /* "Normal rays traced" (skdtree.cpp:46)                 */
+    uint64_t shadow_rays;        /* "Shadow rays traced" (skdtree.cpp:47)                 */
+    uint64_t path_vertices;      /* sum of path depths, "Average path length" (path.cpp:24)*/
+    uint64_t bvh_node_visits;    /* inner nodes fetched (closest + shadow)                */
+    uint64_t triangle_tests;     /* TriAccel tests (closest + shadow)                     */
+    uint64_t invalid_samples;    /* rejected by the ImageBlock::put validity check        */
+    uint32_t iterations;         /* wavefront iterations                                  */
+    uint32_t reserved;
+    double   render_ms;          /* host wall clock of the call                           */
+    double   trace_kernel_ms;    /* sum of HIP-event durations of the trace kernel        */
+    double   shade_kernel_ms;
+    double   film_kernel_ms;
+    uint32_t trace_kernel_launches;
+    uint32_t reserved2;
+    double   algorithmic_bytes;  /* SURVEY 8(d) bytes for this call, from the counters    */
+} phip_stats;
+
+typedef struct phip_ray  { float o[3]; float mint; float d[3]; float maxt; } phip_ray;
+typedef struct phip_hit  { float t, u, v; uint32_t prim; /* global triangle id, 0xFFFFFFFF = miss */ } phip_hit;
+#define PHIP_NO_HIT 0xFFFFFFFFu
+
+typedef struct phip_scene phip_scene;   /* opaque */
+
+/* number of HIP devices visible, or a negative phip_status */
+int          phip_device_count(void);
+const char  *phip_last_error(void);
+const char  *phip_version(void);
+
+/* Flattens the scene, builds the acceleration structure on the host and uploads it to `device`. */
+phip_scene  *phip_scene_create(const phip_scene_desc *desc, int device);
+void         phip_scene_destroy(phip_scene *scene);
+
+/* Renders the crop window; out_rgbaw = crop_h*crop_w*5 float32 (R,G,B,alpha,weight) on the HOST,
+   accumulated filter-weighted sums exactly like the film's ESpectrumAlphaWeight bitmap. */
+int  phip_render(phip_scene *scene, const phip_render_params *params,
+                 float *out_rgbaw, phip_stats *out_stats);
+
+/* Same, but d_out_rgbaw is DEVICE memory on params->device (e.g. a torch tensor's data_ptr());
+   the buffer is overwritten.  Completion is synchronous on return. */
+int  phip_render_device(phip_scene *scene, const phip_render_params *params,
+                        void *d_out_rgbaw, phip_stats *out_stats);
+
+/* Per-sample radiance of the last render with PHIP_FLAG_SAMPLE_BUFFER: n = crop_w*crop_h*spp
+   entries of (R,G,B,alpha) ordered [y][x][sample].  Test/diagnostic hook. */
+int  phip_get_samples(phip_scene *scene, float *out_rgba, size_t n_samples);
+
+/* Ray-cast entry (the reference's kdbench / test_kd workload): closest hit into hits[],
+   and/or any-hit into occluded[] (either may be NULL).  Host pointers. */
+int  phip_trace(phip_scene *scene, const phip_ray *rays, size_t n,
+                phip_hit *hits, uint8_t *occluded, phip_stats *out_stats);
+
+/* Thread-safe; makes a concurrent phip_render return PHIP_ERR_CANCELLED. */
+void phip_cancel(phip_scene *scene);
+
+/* RGB = sum/weight (0 where weight == 0): rgbaw[n*5] -> rgb[n*3]. Host-side helper. */
+void phip_develop(const float *rgbaw, size_t n_pixels, float *out_rgb);
+
+/* Acceleration-structure facts for DESIGN.md / bench accounting. */
+typedef struct phip_accel_info {
+    uint32_t n_nodes, n_leaves, n_triangle_refs, max_depth;
+    uint32_t node_bytes, triangle_bytes;
+    float    sah_cost;
+    float    build_ms;
+} phip_accel_info;
+int  phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHIP_H */

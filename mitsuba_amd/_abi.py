@@ -1,0 +1,120 @@
+"""ctypes mirror of include/phip.h (the C ABI of libphip.so).
+
+Field order and types must match the header exactly; tests/test_abi.py checks sizeof() of every
+struct against the values the C side reports through phip_abi_sizeof().
+"""
+import ctypes as C
+
+PHIP_ABI_VERSION = 1
+PHIP_FILTER_RESOLUTION = 31
+
+PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCELLED, PHIP_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+PHIP_BSDF_DIFFUSE, PHIP_BSDF_DIELECTRIC, PHIP_BSDF_ROUGHCONDUCTOR, PHIP_BSDF_TWOSIDED = 0, 1, 2, 3
+PHIP_MF_BECKMANN, PHIP_MF_GGX = 0, 1
+PHIP_SAMPLER_CTR = 0
+PHIP_FLAG_KERNEL_TIMING = 1
+PHIP_FLAG_SAMPLE_BUFFER = 2
+PHIP_NO_HIT = 0xFFFFFFFF
+
+
+class phip_material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("nested", C.c_uint32 * 2),
+                ("reflectance", C.c_float * 3), ("transmittance", C.c_float * 3),
+                ("eta", C.c_float * 3), ("k", C.c_float * 3),
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float),
+                ("distribution", C.c_uint32), ("sample_visible", C.c_uint32)]
+
+
+class phip_shape(C.Structure):
+    _fields_ = [("first_vertex", C.c_uint32), ("n_vertices", C.c_uint32),
+                ("first_triangle", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("material", C.c_uint32), ("emitter", C.c_int32),
+                ("has_normals", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class phip_emitter(C.Structure):
+    _fields_ = [("radiance", C.c_float * 3), ("sampling_weight", C.c_float),
+                ("shape", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class phip_camera(C.Structure):
+    _fields_ = [("to_world", C.c_float * 16), ("xfov_deg", C.c_float),
+                ("near_clip", C.c_float), ("far_clip", C.c_float), ("reserved", C.c_float)]
+
+
+class phip_film(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("crop_offset_x", C.c_int32), ("crop_offset_y", C.c_int32),
+                ("crop_width", C.c_int32), ("crop_height", C.c_int32),
+                ("filter_radius", C.c_float),
+                ("filter_table", C.c_float * (PHIP_FILTER_RESOLUTION + 1))]
+
+
+class phip_scene_desc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_vertices", C.c_uint32),
+                ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
+                ("n_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
+                ("n_shapes", C.c_uint32), ("shapes", C.POINTER(phip_shape)),
+                ("n_materials", C.c_uint32), ("materials", C.POINTER(phip_material)),
+                ("n_emitters", C.c_uint32), ("emitters", C.POINTER(phip_emitter)),
+                ("camera", phip_camera), ("film", phip_film)]
+
+
+class phip_render_params(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
+                ("strict_normals", C.c_int32), ("hide_emitters", C.c_int32), ("block_size", C.c_int32),
+                ("sampler", C.c_uint32), ("seed", C.c_uint32),
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p)]
+
+
+class phip_stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("path_vertices", C.c_uint64), ("bvh_node_visits", C.c_uint64), ("triangle_tests", C.c_uint64),
+                ("invalid_samples", C.c_uint64), ("iterations", C.c_uint32), ("reserved", C.c_uint32),
+                ("render_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("shade_kernel_ms", C.c_double),
+                ("film_kernel_ms", C.c_double), ("trace_kernel_launches", C.c_uint32), ("reserved2", C.c_uint32),
+                ("algorithmic_bytes", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
+
+
+class phip_ray(C.Structure):
+    _fields_ = [("o", C.c_float * 3), ("mint", C.c_float), ("d", C.c_float * 3), ("maxt", C.c_float)]
+
+
+class phip_hit(C.Structure):
+    _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("prim", C.c_uint32)]
+
+
+class phip_accel_info(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_triangle_refs", C.c_uint32),
+                ("max_depth", C.c_uint32), ("node_bytes", C.c_uint32), ("triangle_bytes", C.c_uint32),
+                ("sah_cost", C.c_float), ("build_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def default_render_params(**kw):
+    """MonteCarloIntegrator defaults (src/librender/integrator.cpp:190-225)."""
+    p = phip_render_params()
+    p.spp = 4
+    p.max_depth = -1
+    p.rr_depth = 5
+    p.strict_normals = 0
+    p.hide_emitters = 0
+    p.block_size = 32
+    p.sampler = PHIP_SAMPLER_CTR
+    p.seed = 0
+    p.shard_index = 0
+    p.shard_count = 1
+    p.device = 0
+    p.flags = 0
+    p.stream = None
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p

@@ -1,0 +1,127 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see o_math.h).
+ *
+ * o_path.h: MIPathTracer::Li restated from src/integrators/path/path.cpp:119-300 with the
+ * control flow, random-number consumption order and operation order of the reference.
+ * Environment emitters, subsurface and media are outside the path's scope (no environment
+ * emitter exists, so `scene->evalEnvironment` contributes 0 and a miss ends the path).
+ */
+#pragma once
+#include "o_bsdf.h"
+
+namespace orc {
+
+struct IntegratorParams {
+    int maxDepth = -1, rrDepth = 5;
+    bool strictNormals = false, hideEmitters = false;
+};
+
+inline Float miWeight(Float pdfA, Float pdfB) { /* path.cpp:296-300 */
+    pdfA *= pdfA;
+    pdfB *= pdfB;
+    return pdfA / (pdfA + pdfB);
+}
+
+/* Returns Li; alpha as set by RadianceQueryRecord::rayIntersect (records.inl:117-144). */
+inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray &r, SampleSource &smp,
+                       Float &alpha, PathCounters *pc) {
+    BSDF bsdfs(scene);
+    Intersection its;
+    Ray ray(r);
+    Spectrum Li(0.0f);
+    bool scattered = false;
+    int depth = 1;                       /* integrator.h:218-224 */
+    bool emittedRadiance = true;         /* rRec.type & EEmittedRadiance (ERadiance initially) */
+
+    scene.rayIntersect(ray, its, pc);
+    alpha = its.isValid() ? 1.0f : 0.0f;
+    ray.mint = ORC_EPSILON;
+
+    Spectrum throughput(1.0f);
+    Float eta = 1.0f;
+
+    while (depth <= ip.maxDepth || ip.maxDepth < 0) {
+        if (!its.isValid())
+            break;                       /* no environment emitter: path.cpp:136-143 adds nothing */
+
+        const Material &bsdf = scene.bsdfOf(its);
+
+        if (scene.isEmitter(its) && emittedRadiance && (!ip.hideEmitters || scattered))
+            Li += throughput * scene.Le(its, -ray.d);
+
+        if ((depth >= ip.maxDepth && ip.maxDepth > 0)
+            || (ip.strictNormals && dot(ray.d, its.geoFrame.n) * Frame::cosTheta(its.wi) >= 0))
+            break;
+
+        /* ---- direct illumination sampling, path.cpp:172-200 ---- */
+        DirectSamplingRecord dRec;
+        scene.initDirectRecord(dRec, its);
+
+        if (bsdf.smooth) {
+            Spectrum value = scene.sampleEmitterDirect(dRec, smp.emitterSample(depth), pc);
+            if (!value.isZero()) {
+                const Vec3 wo = its.toLocal(dRec.d);
+                const Spectrum bsdfVal = bsdfs.eval(bsdf, its.wi, wo);
+                if (!bsdfVal.isZero() && (!ip.strictNormals || dot(its.geoFrame.n, dRec.d) * Frame::cosTheta(wo) > 0)) {
+                    /* area emitters are on a surface and sampled w.r.t. solid angle */
+                    Float bsdfPdf = (dRec.measure == ESolidAngle) ? bsdfs.pdf(bsdf, its.wi, wo) : 0;
+                    Float weight = miWeight(dRec.pdf, bsdfPdf);
+                    Li += throughput * value * bsdfVal * weight;
+                }
+            }
+        }
+
+        /* ---- BSDF sampling, path.cpp:207-226 ---- */
+        Float bsdfPdf = 0;
+        BSDFSamplingRecord bRec;
+        bRec.wi = its.wi; bRec.eta = 1.0f; bRec.sampledDelta = false;
+        Spectrum bsdfWeight = bsdfs.sample(bsdf, bRec, bsdfPdf, smp.bsdfSample(depth));
+        if (bsdfWeight.isZero())
+            break;
+
+        scattered |= true;               /* sampledType != ENull always on this path */
+
+        const Vec3 wo = its.toWorld(bRec.wo);
+        Float woDotGeoN = dot(its.geoFrame.n, wo);
+        if (ip.strictNormals && woDotGeoN * Frame::cosTheta(bRec.wo) <= 0)
+            break;
+
+        bool hitEmitter = false;
+        Spectrum value;
+
+        ray = Ray(its.p, wo);
+        if (scene.rayIntersect(ray, its, pc)) {
+            if (scene.isEmitter(its)) {
+                value = scene.Le(its, -ray.d);
+                scene.setQuery(dRec, ray, its);
+                hitEmitter = true;
+            }
+        } else {
+            break;                       /* no environment emitter, path.cpp:233-248 */
+        }
+
+        throughput *= bsdfWeight;
+        eta *= bRec.eta;
+
+        if (hitEmitter) {
+            const Float lumPdf = (!bRec.sampledDelta) ? scene.pdfEmitterDirect(dRec) : 0;
+            Li += throughput * value * miWeight(bsdfPdf, lumPdf);
+        }
+
+        /* ---- indirect illumination, path.cpp:270-286 ---- */
+        if (!its.isValid())
+            break;
+        emittedRadiance = false;         /* rRec.type = ERadianceNoEmission */
+
+        if (depth++ >= ip.rrDepth) {
+            Float q = std::min(throughput.max() * eta * eta, (Float) 0.95f);
+            if (smp.rrSample(depth - 1) >= q)
+                break;
+            throughput /= q;
+        }
+    }
+    if (pc) { pc->pathVertices += (uint64_t) depth; pc->samples++; }
+    return Li;
+}
+
+} // namespace orc

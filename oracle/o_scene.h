@@ -1,0 +1,403 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see o_math.h).
+ *
+ * o_scene.h: scene container, intersection record, emitter sampling, sample streams.  Restates
+ * (file:line under /root/reference):
+ *   include/mitsuba/core/pmf.h:33-200            DiscreteDistribution (append/normalize/sample/sampleReuse)
+ *   src/librender/scene.cpp:375-381,828-852,949-952  emitter PDF, sampleEmitterDirect, pdfEmitterDirect
+ *   include/mitsuba/render/scene.h:848-850       pdfEmitterDiscrete
+ *   src/emitters/area.cpp:104-109,158-182        AreaLight::eval / sampleDirect / pdfDirect
+ *   src/librender/shape.cpp:102-126              Shape::sampleDirect / pdfDirect
+ *   src/librender/trimesh.cpp:358-360,388-423    pdfPosition, prepareSamplingTable, samplePosition
+ *   src/libcore/triangle.cpp:24-67               Triangle::sample / surfaceArea
+ *   include/mitsuba/render/skdtree.h:343-428     fillIntersectionRecord<true>
+ *   include/mitsuba/render/records.inl:160-178   DirectSamplingRecord(its) / setQuery
+ *   src/samplers/independent.cpp:71-103, src/librender/renderjob.cpp:58-69   per-worker SFMT streams
+ */
+#pragma once
+#include "o_kdtree.h"
+#include "o_sfmt.h"
+#include "../include/phip.h"
+#include <string>
+#include <stdexcept>
+
+namespace orc {
+
+/* pmf.h */
+struct DiscreteDistribution {
+    std::vector<Float> cdf;
+    Float sum = 0, normalization = 0;
+    bool normalized = false;
+    DiscreteDistribution() { cdf.push_back(0.0f); }
+    void append(Float v) { cdf.push_back(cdf[cdf.size() - 1] + v); }
+    size_t size() const { return cdf.size() - 1; }
+    Float operator[](size_t e) const { return cdf[e + 1] - cdf[e]; }
+    Float normalize() {
+        sum = cdf[cdf.size() - 1];
+        if (sum > 0) {
+            normalization = 1.0f / sum;
+            for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= normalization;
+            cdf[cdf.size() - 1] = 1.0f;
+            normalized = true;
+        } else {
+            normalization = 0.0f;
+        }
+        return sum;
+    }
+    size_t sample(Float sampleValue) const {
+        std::vector<Float>::const_iterator entry = std::lower_bound(cdf.begin(), cdf.end(), sampleValue);
+        size_t index = std::min(cdf.size() - 2, (size_t) std::max((ptrdiff_t) 0, entry - cdf.begin() - 1));
+        while (operator[](index) == 0 && index < cdf.size() - 1)
+            ++index;
+        return index;
+    }
+    size_t sample(Float sampleValue, Float &pdf) const { size_t i = sample(sampleValue); pdf = operator[](i); return i; }
+    size_t sampleReuse(Float &sampleValue) const {
+        size_t index = sample(sampleValue);
+        sampleValue = (sampleValue - cdf[index]) / (cdf[index + 1] - cdf[index]);
+        return index;
+    }
+    size_t sampleReuse(Float &sampleValue, Float &pdf) const {
+        size_t index = sample(sampleValue, pdf);
+        sampleValue = (sampleValue - cdf[index]) / (cdf[index + 1] - cdf[index]);
+        return index;
+    }
+};
+
+/* BSDF type bits used by the path (bsdf.h:224-283) */
+enum { EDiffuseReflection = 0x8, EGlossyReflection = 0x10, EDeltaReflection = 0x100, EDeltaTransmission = 0x400,
+       ESmoothMask = 0x8 | 0x10 | 0x20 | 0x40 | 0x4, EDeltaMask = 0x100 | 0x400 | 0x1,
+       EFrontSide = 0x20000, EBackSide = 0x40000 };
+/* (numeric values are local to the oracle; only the predicates matter) */
+
+struct Material {
+    phip_material m;
+    /* derived at configure time */
+    bool smooth;          /* getType() & ESmooth                           */
+    bool transOrBack;     /* getType() & (ETransmission | EBackSide)       */
+    Float alphaU, alphaV; /* roughconductor, after .average() and clamp    */
+};
+
+struct Shape {
+    phip_shape s;
+    DiscreteDistribution areaDistr;
+    Float surfaceArea = 0, invSurfaceArea = 0;
+};
+
+struct Intersection {
+    Float t;
+    Vec3 p;
+    Frame geoFrame, shFrame;
+    Vec2 uv;
+    Vec3 dpdu, dpdv;
+    Vec3 wi;
+    int shape;            /* -1 = invalid */
+    uint32_t primIndex;   /* global triangle id */
+    bool isValid() const { return shape >= 0; }
+    Vec3 toWorld(const Vec3 &v) const { return shFrame.toWorld(v); }
+    Vec3 toLocal(const Vec3 &v) const { return shFrame.toLocal(v); }
+};
+
+enum EMeasure { EInvalidMeasure = 0, ESolidAngle = 1, ELength = 2, EArea = 3, EDiscrete = 4 };
+
+struct DirectSamplingRecord {
+    Vec3 p, n; Vec2 uv; Float pdf; int measure; int emitter;
+    Vec3 ref, refN, d; Float dist;
+};
+
+/* Sample source: the reference consumes one sequential stream per worker (`sfmt` mode); the
+ * parity stream (`ctr`) is addressed by (pixel, sample, dimension block) so CPU and GPU see the
+ * same numbers regardless of scheduling.  Block layout (shared with the HIP kernels):
+ *   block 0              : (jitter.x, jitter.y, -, -)
+ *   block 1 + 2*(d-1)    : (emitter.x, emitter.y, bsdf.x, bsdf.y) at path depth d (d >= 1)
+ *   block 2 + 2*(d-1)    : (rr, -, -, -)
+ * word -> float exactly like Random::nextFloat (random.cpp:632-641): (u >> 9 | 0x3f800000) - 1.
+ */
+inline void pcg4d(uint32_t v[4]) {
+    /* Jarzynski & Olano, "Hash Functions for GPU Rendering", JCGT 9(3) 2020, pcg4d */
+    for (int i = 0; i < 4; ++i) v[i] = v[i] * 1664525u + 1013904223u;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+    for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+}
+inline float u32ToFloat(uint32_t u) {
+    uint32_t b = (u >> 9) | 0x3f800000u; float f; memcpy(&f, &b, 4); return f - 1.0f;
+}
+
+struct SampleSource {
+    /* ctr mode */
+    bool ctr = true;
+    uint32_t pixel = 0, sample = 0, seed = 0;
+    /* sfmt mode */
+    SFMT *rng = nullptr;
+
+    void block(uint32_t blk, float out[4]) const {
+        uint32_t v[4] = { pixel, sample, blk, seed };
+        pcg4d(v);
+        for (int i = 0; i < 4; ++i) out[i] = u32ToFloat(v[i]);
+    }
+    Vec2 cameraSample() {
+        if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
+        float f[4]; block(0, f); return Vec2(f[0], f[1]);
+    }
+    Vec2 emitterSample(int depth) {
+        if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
+        float f[4]; block(1 + 2 * (uint32_t) (depth - 1), f); return Vec2(f[0], f[1]);
+    }
+    Vec2 bsdfSample(int depth) {
+        if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
+        float f[4]; block(1 + 2 * (uint32_t) (depth - 1), f); return Vec2(f[2], f[3]);
+    }
+    Float rrSample(int depth) {
+        if (!ctr) return rng->nextFloat();
+        float f[4]; block(2 + 2 * (uint32_t) (depth - 1), f); return f[0];
+    }
+};
+
+struct PathCounters {
+    uint64_t closestRays = 0, shadowRays = 0, pathVertices = 0, samples = 0, invalidSamples = 0;
+    TraversalCounters closest, shadow;
+    void add(const PathCounters &o) {
+        closestRays += o.closestRays; shadowRays += o.shadowRays; pathVertices += o.pathVertices;
+        samples += o.samples; invalidSamples += o.invalidSamples;
+        closest.nodeVisits += o.closest.nodeVisits; closest.triTests += o.closest.triTests; closest.leafVisits += o.closest.leafVisits;
+        shadow.nodeVisits += o.shadow.nodeVisits; shadow.triTests += o.shadow.triTests; shadow.leafVisits += o.shadow.leafVisits;
+    }
+};
+
+class Scene {
+public:
+    std::vector<float> positions, normals;
+    std::vector<uint32_t> indices;
+    std::vector<uint32_t> triShape, triPrim;
+    std::vector<Shape> shapes;
+    std::vector<Material> materials;
+    std::vector<phip_emitter> emitters;
+    DiscreteDistribution emitterPDF;
+    KDTree kdtree;
+    phip_camera camera;
+    phip_film film;
+    bool haveNormals = false;
+
+    void load(const phip_scene_desc &d) {
+        if (d.abi_version != PHIP_ABI_VERSION) throw std::runtime_error("oracle: ABI version mismatch");
+        positions.assign(d.positions, d.positions + 3 * (size_t) d.n_vertices);
+        haveNormals = d.normals != nullptr;
+        if (haveNormals) normals.assign(d.normals, d.normals + 3 * (size_t) d.n_vertices);
+        indices.assign(d.indices, d.indices + 3 * (size_t) d.n_triangles);
+        camera = d.camera; film = d.film;
+        materials.resize(d.n_materials);
+        for (uint32_t i = 0; i < d.n_materials; ++i) materials[i].m = d.materials[i];
+        for (uint32_t i = 0; i < d.n_materials; ++i) configureMaterial(i);
+        emitters.assign(d.emitters, d.emitters + d.n_emitters);
+        shapes.resize(d.n_shapes);
+        triShape.resize(d.n_triangles); triPrim.resize(d.n_triangles);
+        uint32_t expect = 0;
+        for (uint32_t i = 0; i < d.n_shapes; ++i) {
+            shapes[i].s = d.shapes[i];
+            const phip_shape &s = d.shapes[i];
+            if (s.first_triangle != expect) throw std::runtime_error("oracle: shape triangle ranges must tile the index array");
+            if (s.material >= d.n_materials) throw std::runtime_error("oracle: bad material id");
+            if (s.emitter >= (int32_t) d.n_emitters) throw std::runtime_error("oracle: bad emitter id");
+            expect += s.n_triangles;
+            for (uint32_t j = 0; j < s.n_triangles; ++j) { triShape[s.first_triangle + j] = i; triPrim[s.first_triangle + j] = j; }
+        }
+        if (expect != d.n_triangles) throw std::runtime_error("oracle: shape triangle ranges do not cover the index array");
+        /* area sampling tables, trimesh.cpp:388-404 (built lazily in the reference) */
+        for (uint32_t i = 0; i < d.n_shapes; ++i) {
+            Shape &sh = shapes[i];
+            if (sh.s.emitter < 0) continue;
+            for (uint32_t j = 0; j < sh.s.n_triangles; ++j) {
+                uint32_t t = sh.s.first_triangle + j;
+                Vec3 p0 = P(t, 0), p1 = P(t, 1), p2 = P(t, 2);
+                Vec3 sideA = p1 - p0, sideB = p2 - p0;
+                sh.areaDistr.append(0.5f * cross(sideA, sideB).length());   /* triangle.cpp:61-67 */
+            }
+            sh.surfaceArea = sh.areaDistr.normalize();
+            sh.invSurfaceArea = 1.0f / sh.surfaceArea;
+        }
+        /* scene.cpp:375-381 */
+        for (uint32_t i = 0; i < d.n_emitters; ++i) emitterPDF.append(emitters[i].sampling_weight);
+        if (d.n_emitters > 0) emitterPDF.normalize();
+        kdtree.build(positions.data(), indices.data(), d.n_triangles, triShape.data(), triPrim.data());
+    }
+
+    Vec3 P(uint32_t tri, int c) const { const float *p = &positions[3 * (size_t) indices[3 * (size_t) tri + c]]; return Vec3(p[0], p[1], p[2]); }
+    Vec3 Nrm(uint32_t tri, int c) const { const float *p = &normals[3 * (size_t) indices[3 * (size_t) tri + c]]; return Vec3(p[0], p[1], p[2]); }
+
+    void configureMaterial(uint32_t i) {
+        Material &M = materials[i];
+        switch (M.m.type) {
+            case PHIP_BSDF_DIFFUSE: {
+                /* diffuse.cpp:93-103: clamp to <=1 (ensureEnergyConservation), component only if max > 0 */
+                Float mx = std::max(M.m.reflectance[0], std::max(M.m.reflectance[1], M.m.reflectance[2]));
+                M.smooth = mx > 0; M.transOrBack = false;
+            } break;
+            case PHIP_BSDF_DIELECTRIC: M.smooth = false; M.transOrBack = true; break;
+            case PHIP_BSDF_ROUGHCONDUCTOR: {
+                M.smooth = true; M.transOrBack = false;
+                /* roughconductor.cpp:275-280: alpha = texture.eval().average(); microfacet.h:113-114 clamp */
+                M.alphaU = std::max(Spectrum(M.m.alpha_u).average(), (Float) 1e-4f);
+                M.alphaV = std::max(Spectrum(M.m.alpha_v).average(), (Float) 1e-4f);
+                if (M.m.distribution > PHIP_MF_GGX) throw std::runtime_error("oracle: unsupported microfacet distribution");
+            } break;
+            case PHIP_BSDF_TWOSIDED: {
+                if (M.m.nested[0] >= materials.size() || M.m.nested[1] >= materials.size()) throw std::runtime_error("oracle: bad nested material");
+                if (M.m.nested[0] >= i || M.m.nested[1] >= i) throw std::runtime_error("oracle: nested materials must precede the twosided adapter");
+                const Material &a = materials[M.m.nested[0]], &b = materials[M.m.nested[1]];
+                if (a.m.type == PHIP_BSDF_DIELECTRIC || b.m.type == PHIP_BSDF_DIELECTRIC || a.m.type == PHIP_BSDF_TWOSIDED || b.m.type == PHIP_BSDF_TWOSIDED)
+                    throw std::runtime_error("oracle: twosided can only nest one-sided reflection models (twosided.cpp:104-106)");
+                M.smooth = a.smooth || b.smooth; M.transOrBack = true;   /* twosided.cpp:96-100: EBackSide set */
+            } break;
+            default: throw std::runtime_error("oracle: unknown material type");
+        }
+    }
+
+    /* skdtree.cpp:112-142 + skdtree.h:343-428 */
+    bool rayIntersect(const Ray &ray, Intersection &its, PathCounters *pc) const {
+        Float t, u, v; uint32_t prim;
+        its.shape = -1; its.t = std::numeric_limits<Float>::infinity();
+        if (pc) pc->closestRays++;
+        if (!kdtree.rayIntersect(ray, t, u, v, prim, pc ? &pc->closest : nullptr))
+            return false;
+        its.t = t;
+        fillIntersectionRecord(ray, prim, u, v, its);
+        return true;
+    }
+
+    bool rayIntersectShadow(const Ray &ray, PathCounters *pc) const {
+        if (pc) pc->shadowRays++;
+        return kdtree.rayIntersectShadow(ray, pc ? &pc->shadow : nullptr);
+    }
+
+    void fillIntersectionRecord(const Ray &ray, uint32_t prim, Float cu, Float cv, Intersection &its) const {
+        const uint32_t shapeIdx = triShape[prim];
+        const Shape &sh = shapes[shapeIdx];
+        const Vec3 b(1 - cu - cv, cu, cv);
+        const Vec3 p0 = P(prim, 0), p1 = P(prim, 1), p2 = P(prim, 2);
+        its.p = p0 * b.x + p1 * b.y + p2 * b.z;
+        Vec3 side1(p1 - p0), side2(p2 - p0);
+        Vec3 faceNormal(cross(side1, side2));
+        Float length = faceNormal.length();
+        if (!faceNormal.isZero())
+            faceNormal /= length;
+        its.dpdu = side1;
+        its.dpdv = side2;
+        if (sh.s.has_normals && haveNormals) {
+            const Vec3 n0 = Nrm(prim, 0), n1 = Nrm(prim, 1), n2 = Nrm(prim, 2);
+            its.shFrame.n = normalize(n0 * b.x + n1 * b.y + n2 * b.z);
+            if (dot(faceNormal, its.shFrame.n) < 0)
+                faceNormal = -faceNormal;
+        } else {
+            its.shFrame.n = faceNormal;
+        }
+        its.geoFrame = Frame(faceNormal);
+        its.uv = Vec2(b.y, b.z);
+        its.shape = (int) shapeIdx;
+        its.primIndex = prim;
+        computeShadingFrame(its.shFrame.n, its.dpdu, its.shFrame);
+        its.wi = its.toLocal(-ray.d);
+    }
+
+    const Material &bsdfOf(const Intersection &its) const { return materials[shapes[its.shape].s.material]; }
+    bool isEmitter(const Intersection &its) const { return shapes[its.shape].s.emitter >= 0; }
+
+    /* area.cpp:104-109 */
+    Spectrum Le(const Intersection &its, const Vec3 &d) const {
+        const phip_emitter &e = emitters[shapes[its.shape].s.emitter];
+        if (dot(its.shFrame.n, d) <= 0) return Spectrum(0.0f);
+        return Spectrum(e.radiance);
+    }
+
+    /* records.inl:160-164 */
+    void initDirectRecord(DirectSamplingRecord &dRec, const Intersection &refIts) const {
+        dRec.ref = refIts.p; dRec.refN = Vec3(0.0f);
+        if (!bsdfOf(refIts).transOrBack)
+            dRec.refN = refIts.shFrame.n;
+        dRec.emitter = -1; dRec.pdf = 0; dRec.measure = EInvalidMeasure;
+    }
+    /* records.inl:170-178 */
+    void setQuery(DirectSamplingRecord &dRec, const Ray &ray, const Intersection &its) const {
+        dRec.p = its.p; dRec.n = its.shFrame.n; dRec.measure = ESolidAngle; dRec.uv = its.uv;
+        dRec.emitter = shapes[its.shape].s.emitter; dRec.d = ray.d; dRec.dist = its.t;
+    }
+
+    /* trimesh.cpp:412-423 + triangle.cpp:24-59 */
+    void samplePosition(const Shape &sh, DirectSamplingRecord &dRec, const Vec2 &_sample) const {
+        Vec2 sample(_sample);
+        size_t index = sh.areaDistr.sampleReuse(sample.y);
+        uint32_t t = sh.s.first_triangle + (uint32_t) index;
+        const Vec3 p0 = P(t, 0), p1 = P(t, 1), p2 = P(t, 2);
+        Vec2 bary = squareToUniformTriangle(sample);
+        Vec3 sideA = p1 - p0, sideB = p2 - p0;
+        dRec.p = p0 + (sideA * bary.x) + (sideB * bary.y);
+        if (sh.s.has_normals && haveNormals) {
+            const Vec3 n0 = Nrm(t, 0), n1 = Nrm(t, 1), n2 = Nrm(t, 2);
+            dRec.n = normalize(n0 * (1.0f - bary.x - bary.y) + n1 * bary.x + n2 * bary.y);
+        } else {
+            dRec.n = normalize(cross(sideA, sideB));
+        }
+        dRec.uv = bary;
+        dRec.pdf = sh.invSurfaceArea;
+        dRec.measure = EArea;
+    }
+
+    /* shape.cpp:102-115 */
+    void shapeSampleDirect(const Shape &sh, DirectSamplingRecord &dRec, const Vec2 &sample) const {
+        samplePosition(sh, dRec, sample);
+        dRec.d = dRec.p - dRec.ref;
+        Float distSquared = dRec.d.lengthSquared();
+        dRec.dist = std::sqrt(distSquared);
+        dRec.d /= dRec.dist;
+        Float dp = absDot(dRec.d, dRec.n);
+        dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+        dRec.measure = ESolidAngle;
+    }
+
+    /* scene.cpp:828-852 (visibility test included), area.cpp:158-173 */
+    Spectrum sampleEmitterDirect(DirectSamplingRecord &dRec, const Vec2 &_sample, PathCounters *pc) const {
+        Vec2 sample(_sample);
+        if (emitters.empty()) { dRec.pdf = 0; return Spectrum(0.0f); }
+        Float emPdf;
+        size_t index = emitterPDF.sampleReuse(sample.x, emPdf);
+        const phip_emitter &em = emitters[index];
+        shapeSampleDirect(shapes[em.shape], dRec, sample);
+        Spectrum value;
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
+            value = Spectrum(em.radiance) / dRec.pdf;
+        } else {
+            dRec.pdf = 0.0f;
+            value = Spectrum(0.0f);
+        }
+        if (dRec.pdf != 0) {
+            Ray ray(dRec.ref, dRec.d, ORC_EPSILON, dRec.dist * (1 - ORC_SHADOW_EPSILON));
+            if (rayIntersectShadow(ray, pc))
+                return Spectrum(0.0f);
+            dRec.emitter = (int) index;
+            dRec.pdf *= emPdf;
+            value /= emPdf;
+            return value;
+        }
+        return Spectrum(0.0f);
+    }
+
+    /* scene.cpp:949-952, scene.h:848-850, area.cpp:175-182, shape.cpp:117-126 */
+    Float pdfEmitterDirect(const DirectSamplingRecord &dRec) const {
+        const phip_emitter &em = emitters[dRec.emitter];
+        Float pdf;
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+            Float pdfPos = shapes[em.shape].invSurfaceArea;
+            if (dRec.measure == ESolidAngle)
+                pdf = pdfPos * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
+            else if (dRec.measure == EArea)
+                pdf = pdfPos;
+            else
+                pdf = 0.0f;
+        } else {
+            pdf = 0.0f;
+        }
+        return pdf * (em.sampling_weight * emitterPDF.normalization);
+    }
+};
+
+} // namespace orc

@@ -1,0 +1,253 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's `path` integrator hot path (see the o_*.h headers for the
+ * file:line map).  Built by oracle/Makefile into oracle/_build/liboracle.so and loaded through
+ * ctypes by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.  It is the
+ * parity checker and the timed CPU baseline ("port"); the product (libphip.so) never links,
+ * loads or calls it.
+ *
+ * Parity status: the reference cannot be compiled in this image (Boost/Xerces/OpenEXR/SCons
+ * are absent), so this restatement is pinned only by the reference's own
+ * test vectors: SFMT19937 seed-4321 golden words (src/tests/test_random.cpp:433-473), the five
+ * Triangle::getClippedAABB known answers (src/tests/test_kd.cpp:34-84) and the chi-square
+ * sample/pdf/eval contracts of src/tests/test_chisquare.cpp and test_microfacet.cpp.  Li,
+ * TriAccel, Havran traversal, emitter sampling, the camera and ImageBlock::put have no
+ * reference vectors: for those the oracle is **parity unpinned** and is instead cross-checked
+ * against brute force / closed forms (tests/test_oracle_*.py).
+ */
+#include "o_render.h"
+#include <string>
+
+using namespace orc;
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *oracle_last_error(void) { return g_err.c_str(); }
+
+void *oracle_scene_create(const phip_scene_desc *desc) {
+    try {
+        Scene *s = new Scene();
+        s->load(*desc);
+        return s;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+void oracle_scene_destroy(void *scene) { delete static_cast<Scene *>(scene); }
+
+/* sampler_mode: 0 = ctr parity stream, 1 = per-worker SFMT19937 streams like `independent` */
+int oracle_render(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
+                  float *out_rgbaw, float *out_samples_rgba, phip_stats *stats) {
+    try {
+        const Scene &scene = *static_cast<Scene *>(scene_);
+        RenderParams rp;
+        rp.spp = p->spp; rp.blockSize = p->block_size > 0 ? p->block_size : 32; rp.threads = threads;
+        rp.ip.maxDepth = p->max_depth; rp.ip.rrDepth = p->rr_depth;
+        rp.ip.strictNormals = p->strict_normals != 0; rp.ip.hideEmitters = p->hide_emitters != 0;
+        rp.ctr = sampler_mode == 0; rp.seed = p->seed;
+        rp.shardIndex = p->shard_index; rp.shardCount = p->shard_count > 0 ? p->shard_count : 1;
+        /* integrator.cpp:219-224 */
+        if (rp.ip.rrDepth <= 0) throw std::runtime_error("'rrDepth' must be set to a value greater than zero!");
+        if (rp.ip.maxDepth <= 0 && rp.ip.maxDepth != -1) throw std::runtime_error("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
+        RenderResult rr = render(scene, rp, out_rgbaw, out_samples_rgba);
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->samples = rr.counters.samples;
+            stats->closest_rays = rr.counters.closestRays;
+            stats->shadow_rays = rr.counters.shadowRays;
+            stats->path_vertices = rr.counters.pathVertices;
+            stats->bvh_node_visits = rr.counters.closest.nodeVisits + rr.counters.shadow.nodeVisits;
+            stats->triangle_tests = rr.counters.closest.triTests + rr.counters.shadow.triTests;
+            stats->invalid_samples = rr.counters.invalidSamples;
+            stats->render_ms = rr.seconds * 1e3;
+            /* 8 B kd node, 4 B index + 48 B TriAccel, ray/hit/state/film terms */
+            stats->algorithmic_bytes =
+                8.0 * (double) stats->bvh_node_visits + 52.0 * (double) stats->triangle_tests +
+                (64.0 + 40.0 + 108.0) * (double) stats->closest_rays + (64.0 + 4.0) * (double) stats->shadow_rays +
+                104.0 * (double) stats->path_vertices + 20.0 * (double) scene.film.crop_width * scene.film.crop_height;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+int oracle_trace(void *scene_, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, phip_stats *stats) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    TraversalCounters c, cs;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r(Vec3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), Vec3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].mint, rays[i].maxt);
+        if (hits) {
+            Float t, u, v; uint32_t prim;
+            if (scene.kdtree.rayIntersect(r, t, u, v, prim, &c)) { hits[i].t = t; hits[i].u = u; hits[i].v = v; hits[i].prim = prim; }
+            else { hits[i].t = std::numeric_limits<float>::infinity(); hits[i].u = hits[i].v = 0; hits[i].prim = PHIP_NO_HIT; }
+        }
+        if (occluded) occluded[i] = scene.kdtree.rayIntersectShadow(r, &cs) ? 1 : 0;
+    }
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->closest_rays = hits ? n : 0; stats->shadow_rays = occluded ? n : 0;
+        stats->bvh_node_visits = c.nodeVisits + cs.nodeVisits; stats->triangle_tests = c.triTests + cs.triTests;
+    }
+    return 0;
+}
+
+/* brute-force closest hit over every TriAccel: the structure-independent answer */
+int oracle_trace_bruteforce(void *scene_, const phip_ray *rays, size_t n, phip_hit *hits) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    const KDTree &kd = scene.kdtree;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r(Vec3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), Vec3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].mint, rays[i].maxt);
+        Float mint = r.mint, maxt = r.maxt;
+        hits[i].t = std::numeric_limits<float>::infinity(); hits[i].u = hits[i].v = 0; hits[i].prim = PHIP_NO_HIT;
+        for (uint32_t p = 0; p < kd.primCount; ++p) {
+            Float u, v, t;
+            if (kd.triAccel[p].rayIntersect(r, mint, maxt, u, v, t)) { maxt = t; hits[i].t = t; hits[i].u = u; hits[i].v = v; hits[i].prim = p; }
+        }
+    }
+    return 0;
+}
+
+struct oracle_kd_info {
+    uint32_t n_nodes, n_indices, max_depth, retracted;
+    double exp_traversal_steps, exp_leaves_visited, exp_prims_intersected, sah_cost;
+    float aabb_min[3], aabb_max[3];
+};
+void oracle_kd_info_get(void *scene_, oracle_kd_info *o) {
+    const KDTree &kd = static_cast<Scene *>(scene_)->kdtree;
+    o->n_nodes = (uint32_t) kd.nodes.size(); o->n_indices = (uint32_t) kd.indices.size();
+    o->max_depth = kd.builtDepth; o->retracted = kd.retractedSplits;
+    o->exp_traversal_steps = kd.expTraversalSteps; o->exp_leaves_visited = kd.expLeavesVisited;
+    o->exp_prims_intersected = kd.expPrimitivesIntersected; o->sah_cost = kd.sahCost;
+    for (int i = 0; i < 3; ++i) { o->aabb_min[i] = kd.aabb.min[i]; o->aabb_max[i] = kd.aabb.max[i]; }
+}
+
+void oracle_gaussian_filter(float stddev, float *radius, float *table32) { gaussianFilterTable(stddev, *radius, table32); }
+
+/* camera ray for a crop-window sample position (tests) */
+void oracle_camera_ray(void *scene_, float sx, float sy, phip_ray *out) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    PerspectiveCamera cam; cam.configure(scene.camera, scene.film);
+    Ray r = cam.sampleRay(Vec2(sx, sy));
+    for (int i = 0; i < 3; ++i) { out->o[i] = r.o[i]; out->d[i] = r.d[i]; }
+    out->mint = r.mint; out->maxt = r.maxt;
+}
+
+/* ---- known-answer hooks ---- */
+void oracle_sfmt_words(uint64_t seed, size_t n, uint64_t *out) {
+    SFMT r(seed);
+    for (size_t i = 0; i < n; ++i) out[i] = r.nextULong();
+}
+void oracle_sfmt_floats(uint64_t seed, int clone, size_t n, float *out) {
+    SFMT parent(seed);
+    if (clone) { SFMT child; child.seedFrom(parent); for (size_t i = 0; i < n; ++i) out[i] = child.nextFloat(); }
+    else for (size_t i = 0; i < n; ++i) out[i] = parent.nextFloat();
+}
+void oracle_ctr_block(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, float *out4) {
+    SampleSource s; s.pixel = pixel; s.sample = sample; s.seed = seed; s.block(block, out4);
+}
+int oracle_clipped_aabb(const float *tri9, const float *box6, float *out6) {
+    AABB b(Vec3(box6[0], box6[1], box6[2]), Vec3(box6[3], box6[4], box6[5]));
+    AABB r = triangleClippedAABB(Vec3(tri9[0], tri9[1], tri9[2]), Vec3(tri9[3], tri9[4], tri9[5]), Vec3(tri9[6], tri9[7], tri9[8]), b);
+    for (int i = 0; i < 3; ++i) { out6[i] = r.min[i]; out6[3 + i] = r.max[i]; }
+    return r.isValid() ? 1 : 0;
+}
+
+/* ---- BSDF / microfacet hooks for the chi-square contracts ---- */
+void oracle_bsdf_sample(void *scene_, uint32_t material, size_t n, const float *wi3, const float *sample2,
+                        float *wo3, float *weight3, float *pdf, uint8_t *delta) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    BSDF b(scene);
+    for (size_t i = 0; i < n; ++i) {
+        BSDFSamplingRecord r; r.wi = Vec3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]); r.wo = Vec3(0.0f); r.eta = 1; r.sampledDelta = false;
+        Float p = 0;
+        Spectrum w = b.sample(scene.materials[material], r, p, Vec2(sample2[2 * i], sample2[2 * i + 1]));
+        if (w.isZero()) { p = 0; r.wo = Vec3(0.0f); }
+        for (int k = 0; k < 3; ++k) { wo3[3 * i + k] = r.wo[k]; weight3[3 * i + k] = w[k]; }
+        pdf[i] = p; if (delta) delta[i] = r.sampledDelta;
+    }
+}
+void oracle_bsdf_eval_pdf(void *scene_, uint32_t material, size_t n, const float *wi3, const float *wo3, float *value3, float *pdf) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    BSDF b(scene);
+    for (size_t i = 0; i < n; ++i) {
+        Vec3 wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+        Spectrum v = b.eval(scene.materials[material], wi, wo);
+        for (int k = 0; k < 3; ++k) value3[3 * i + k] = v[k];
+        pdf[i] = b.pdf(scene.materials[material], wi, wo);
+    }
+}
+void oracle_mf_sample(int type, float au, float av, int visible, size_t n, const float *wi3, const float *sample2, float *m3, float *pdf) {
+    MicrofacetDistribution d(type, au, av, visible != 0);
+    for (size_t i = 0; i < n; ++i) {
+        Float p; Vec3 m = d.sample(Vec3(wi3[0], wi3[1], wi3[2]), Vec2(sample2[2 * i], sample2[2 * i + 1]), p);
+        m3[3 * i] = m.x; m3[3 * i + 1] = m.y; m3[3 * i + 2] = m.z; pdf[i] = p;
+    }
+}
+void oracle_mf_pdf(int type, float au, float av, int visible, size_t n, const float *wi3, const float *m3, float *pdf, float *D) {
+    MicrofacetDistribution d(type, au, av, visible != 0);
+    for (size_t i = 0; i < n; ++i) {
+        Vec3 m(m3[3 * i], m3[3 * i + 1], m3[3 * i + 2]);
+        pdf[i] = d.pdf(Vec3(wi3[0], wi3[1], wi3[2]), m);
+        if (D) D[i] = d.eval(m);
+    }
+}
+
+/* emitter sampling hook: value/pdf/direction of sampleEmitterDirect (no visibility) + pdfEmitterDirect */
+void oracle_sample_emitter(void *scene_, const float *ref3, const float *refN3, size_t n, const float *sample2,
+                           float *d3, float *dist, float *pdf, float *value3, float *pdf_check) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    for (size_t i = 0; i < n; ++i) {
+        DirectSamplingRecord dRec;
+        dRec.ref = Vec3(ref3[0], ref3[1], ref3[2]); dRec.refN = Vec3(refN3[0], refN3[1], refN3[2]);
+        dRec.emitter = -1; dRec.pdf = 0; dRec.measure = EInvalidMeasure;
+        Vec2 sample(sample2[2 * i], sample2[2 * i + 1]);
+        Float emPdf;
+        size_t index = scene.emitterPDF.sampleReuse(sample.x, emPdf);
+        const phip_emitter &em = scene.emitters[index];
+        scene.shapeSampleDirect(scene.shapes[em.shape], dRec, sample);
+        Spectrum value(0.0f);
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) value = Spectrum(em.radiance) / dRec.pdf; else dRec.pdf = 0;
+        if (dRec.pdf != 0) { dRec.emitter = (int) index; dRec.pdf *= emPdf; value /= emPdf; }
+        for (int k = 0; k < 3; ++k) { d3[3 * i + k] = dRec.d[k]; value3[3 * i + k] = value[k]; }
+        dist[i] = dRec.dist; pdf[i] = dRec.pdf;
+        pdf_check[i] = dRec.pdf != 0 ? scene.pdfEmitterDirect(dRec) : 0.0f;
+    }
+}
+
+/* ---- phip_fmath.h spot checks: op 0 sin,1 cos,2 exp,3 log,4 acos,5 atan2,6 tan,7 pow,8 erf,9 erfinv,10 atan ---- */
+void oracle_fmath(int op, size_t n, const float *a, const float *b, float *out) {
+    for (size_t i = 0; i < n; ++i) {
+        float s, c;
+        switch (op) {
+            case 0: pm_sincosf(a[i], &s, &c); out[i] = s; break;
+            case 1: pm_sincosf(a[i], &s, &c); out[i] = c; break;
+            case 2: out[i] = pm_expf(a[i]); break;
+            case 3: out[i] = pm_logf(a[i]); break;
+            case 4: out[i] = pm_acosf(a[i]); break;
+            case 5: out[i] = pm_atan2f(a[i], b[i]); break;
+            case 6: out[i] = pm_tanf(a[i]); break;
+            case 7: out[i] = pm_powf(a[i], b[i]); break;
+            case 8: out[i] = mts_erf(a[i]); break;
+            case 9: out[i] = mts_erfinv(a[i]); break;
+            case 10: out[i] = pm_atanf(a[i]); break;
+            default: out[i] = 0;
+        }
+    }
+}
+
+int oracle_uses_libm(void) {
+#if defined(ORACLE_LIBM)
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+} // extern "C"
