@@ -1,0 +1,105 @@
+"""ctypes binding of libphip.so (include/phip.h) -- the only way the Python harness reaches the GPU.
+
+The library is built in-tree by `build()` (hipcc --offload-arch=gfx950) into
+mitsuba_amd/_build/libphip.so; there is no fallback: if it is missing or cannot be loaded the
+import of anything that renders raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi as A
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "_build")
+LIB = os.path.join(BUILD, "libphip.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+_lib = None
+
+
+def _sources():
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    out += [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
+    return out
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 (cross-compiles without a GPU)."""
+    os.makedirs(BUILD, exist_ok=True)
+    if not force and os.path.exists(LIB):
+        mt = os.path.getmtime(LIB)
+        if all(os.path.getmtime(s) <= mt for s in _sources()):
+            return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "phip.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    if verbose:
+        print(" ".join(cmd))
+        print(r.stderr)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise RuntimeError("libphip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "-- path_hip has no CPU fallback" % LIB)
+    L = C.CDLL(LIB)
+    fp, u8p, u32 = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_uint32
+    L.phip_last_error.restype = C.c_char_p
+    L.phip_version.restype = C.c_char_p
+    L.phip_device_count.restype = C.c_int
+    L.phip_scene_create.restype = C.c_void_p
+    L.phip_scene_create.argtypes = [C.POINTER(A.phip_scene_desc), C.c_int]
+    L.phip_scene_destroy.argtypes = [C.c_void_p]
+    L.phip_render.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), fp, C.POINTER(A.phip_stats)]
+    L.phip_render_device.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), C.c_void_p, C.POINTER(A.phip_stats)]
+    L.phip_get_samples.argtypes = [C.c_void_p, fp, C.c_size_t]
+    L.phip_trace.argtypes = [C.c_void_p, C.POINTER(A.phip_ray), C.c_size_t, C.POINTER(A.phip_hit), u8p, C.POINTER(A.phip_stats)]
+    L.phip_cancel.argtypes = [C.c_void_p]
+    L.phip_develop.argtypes = [fp, C.c_size_t, fp]
+    L.phip_scene_accel_info.argtypes = [C.c_void_p, C.POINTER(A.phip_accel_info)]
+    L.phip_gaussian_filter.argtypes = [C.c_float, fp, fp]
+    L.phip_abi_sizeof.restype = C.c_size_t
+    L.phip_abi_sizeof.argtypes = [C.c_int]
+    L.phip_debug_host_bsdf_sample.argtypes = [C.POINTER(A.phip_material), u32, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]
+    L.phip_debug_host_bsdf_eval_pdf.argtypes = [C.POINTER(A.phip_material), u32, u32, C.c_size_t, fp, fp, fp, fp]
+    L.phip_debug_host_camera_ray.argtypes = [C.POINTER(A.phip_camera), C.POINTER(A.phip_film), C.c_float, C.c_float, C.POINTER(A.phip_ray)]
+    L.phip_debug_host_ctr_block.argtypes = [u32, u32, u32, u32, fp]
+    L.phip_debug_host_build_bvh.argtypes = [fp, u32, C.POINTER(C.c_uint32), u32, C.POINTER(A.phip_accel_info), fp]
+    L.phip_debug_fmath.argtypes = [C.c_int, C.c_int, C.c_size_t, fp, fp, fp]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().phip_last_error().decode()
+
+
+class PhipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s failed (%d): %s" % (where, code, last_error()))
+
+
+def gaussian_filter(stddev=0.5):
+    """(radius, table[32]) of the reference's default `gaussian` rfilter."""
+    r = C.c_float()
+    t = (C.c_float * 32)()
+    lib().phip_gaussian_filter(stddev, C.byref(r), t)
+    return (r.value, list(t))
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))

@@ -1,0 +1,254 @@
+/*
+ * bvh.h -- host-side acceleration-structure build for path_hip.
+ *
+ * The reference answers ray queries with a SAH kd-tree (include/mitsuba/render/gkdtree.h,
+ * sahkdtree3.h); a kd-tree's pointer-chasing, duplicated references and 48-entry Havran stack
+ * are a poor fit for 64-wide wavefronts.  The MI355X design instead uses a binary BVH built
+ * with binned SAH on the host, flattened into 64-byte nodes that hold BOTH children's boxes
+ * (one node visit = four coalescable 16-byte loads, two slab tests), with triangles stored in
+ * leaf order as 48-byte Wald records (the reference's TriAccel arithmetic,
+ * include/mitsuba/render/triaccel.h:61-93, so that (t,u,v) are bit-identical to the CPU path).
+ * Closest-hit results do not depend on the structure, only on the triangle test.
+ *
+ * Node layout (4 x float4):
+ *   n0 = (l.min.x, l.min.y, l.min.z, l.max.x)
+ *   n1 = (l.max.y, l.max.z, r.min.x, r.min.y)
+ *   n2 = (r.min.z, r.max.x, r.max.y, r.max.z)
+ *   n3 = (bits(left), bits(right), 0, 0)
+ * child reference: >= 0 inner-node index; < 0 leaf: ~ref = (firstTri << 3) | (count - 1), count in 1..8.
+ * Triangle record (3 x float4): (bits(k), n_u, n_v, n_d) (a_u, a_v, b_nu, b_nv) (c_nu, c_nv, bits(globalPrim), 0)
+ */
+#pragma once
+#include <vector>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <chrono>
+
+namespace pt {
+
+struct BuildTri { float bmin[3], bmax[3], c[3]; uint32_t prim; };
+
+struct HostBVH {
+    std::vector<float> nodes;     /* 16 floats per node */
+    std::vector<float> tris;      /* 12 floats per triangle record, leaf order */
+    uint32_t nNodes = 0, nLeaves = 0, nTriRefs = 0, maxDepth = 0;
+    float sceneMin[3], sceneMax[3];       /* enlarged like gkdtree.h:1213-1220 */
+    float tightMin[3], tightMax[3];
+    float sahCost = 0, buildMs = 0;
+    int32_t rootRef = 0;
+};
+
+namespace detail {
+
+inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* TriAccel::load, triaccel.h:61-93 -- returns false for degenerate triangles (k = 3) */
+inline bool waldLoad(const float *A, const float *B, const float *C, uint32_t prim, float *out12) {
+    static const int waldModulo[4] = { 1, 2, 0, 1 };
+    float b[3] = { C[0] - A[0], C[1] - A[1], C[2] - A[2] };
+    float c[3] = { B[0] - A[0], B[1] - A[1], B[2] - A[2] };
+    float N[3] = { c[1] * b[2] - c[2] * b[1], c[2] * b[0] - c[0] * b[2], c[0] * b[1] - c[1] * b[0] };
+    uint32_t k = 0;
+    for (int j = 0; j < 3; j++)
+        if (std::fabs(N[j]) > std::fabs(N[k])) k = j;
+    uint32_t u = waldModulo[k], v = waldModulo[k + 1];
+    const float n_k = N[k], denom = b[u] * c[v] - b[v] * c[u];
+    if (denom == 0) return false;
+    out12[0] = bits2f(k);
+    out12[1] = N[u] / n_k;
+    out12[2] = N[v] / n_k;
+    out12[3] = (A[0] * N[0] + A[1] * N[1] + A[2] * N[2]) / n_k;
+    out12[4] = A[u];
+    out12[5] = A[v];
+    out12[6] = b[u] / denom;
+    out12[7] = -b[v] / denom;
+    out12[8] = c[v] / denom;
+    out12[9] = -c[u] / denom;
+    out12[10] = bits2f(prim);
+    out12[11] = 0.0f;
+    return true;
+}
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() { for (int i = 0; i < 3; ++i) { mn[i] = INFINITY; mx[i] = -INFINITY; } }
+    void grow(const float *a, const float *b) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], a[i]); mx[i] = std::max(mx[i], b[i]); } }
+    void growPt(const float *p) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], p[i]); mx[i] = std::max(mx[i], p[i]); } }
+    float area() const {
+        float d[3] = { mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2] };
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0f;
+        return 2.0f * (d[0] * d[1] + d[1] * d[2] + d[0] * d[2]);
+    }
+};
+
+struct Builder {
+    std::vector<BuildTri> &T;
+    HostBVH &out;
+    const float *positions; const uint32_t *indices;
+    static constexpr int NBINS = 32;
+    static constexpr int MAX_LEAF = 4;
+    static constexpr float C_TRAV = 1.0f, C_ISECT = 1.0f;
+    double sah = 0;
+
+    Builder(std::vector<BuildTri> &t, HostBVH &o, const float *p, const uint32_t *i) : T(t), out(o), positions(p), indices(i) {}
+
+    /* pads a box so that a hit accepted by the Wald test (which tolerates a few ulp outside the
+       exact triangle) can never be culled by the slab test */
+    static void pad(Box &b) {
+        for (int i = 0; i < 3; ++i) {
+            float e = 1e-5f * std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])) + 1e-7f * (b.mx[i] - b.mn[i]) + 1e-30f;
+            b.mn[i] -= e; b.mx[i] += e;
+        }
+    }
+
+    int32_t makeLeaf(size_t b, size_t e) {
+        uint32_t first = (uint32_t) (out.tris.size() / 12);
+        uint32_t count = 0;
+        for (size_t i = b; i < e; ++i) {
+            float rec[12];
+            const uint32_t p = T[i].prim;
+            const float *A = positions + 3 * (size_t) indices[3 * (size_t) p], *B = positions + 3 * (size_t) indices[3 * (size_t) p + 1],
+                        *C = positions + 3 * (size_t) indices[3 * (size_t) p + 2];
+            if (!waldLoad(A, B, C, p, rec)) continue;
+            out.tris.insert(out.tris.end(), rec, rec + 12);
+            ++count;
+        }
+        out.nLeaves++; out.nTriRefs += count;
+        if (count == 0) { /* keep a well-formed (never-hit) leaf: one record with k = 3 */
+            float rec[12] = { 0 }; rec[0] = bits2f(3u); rec[10] = bits2f(0xFFFFFFFFu);
+            out.tris.insert(out.tris.end(), rec, rec + 12);
+            count = 1;
+        }
+        return ~(int32_t) ((first << 3) | (count - 1));
+    }
+
+    /* returns child reference; box = bounds of the subtree */
+    int32_t build(size_t b, size_t e, Box &box, uint32_t depth) {
+        out.maxDepth = std::max(out.maxDepth, depth);
+        box.reset();
+        Box cb; cb.reset();
+        for (size_t i = b; i < e; ++i) { box.grow(T[i].bmin, T[i].bmax); cb.growPt(T[i].c); }
+        const size_t n = e - b;
+        if (n == 1) return makeLeaf(b, e);
+
+        /* binned SAH over the centroid bounds */
+        float bestCost = INFINITY; int bestAxis = -1, bestBin = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            float lo = cb.mn[axis], hi = cb.mx[axis];
+            if (!(hi > lo)) continue;
+            Box bins[NBINS]; uint32_t cnt[NBINS];
+            for (int i = 0; i < NBINS; ++i) { bins[i].reset(); cnt[i] = 0; }
+            const float scale = NBINS / (hi - lo);
+            for (size_t i = b; i < e; ++i) {
+                int k = (int) ((T[i].c[axis] - lo) * scale); k = std::min(std::max(k, 0), NBINS - 1);
+                bins[k].grow(T[i].bmin, T[i].bmax); cnt[k]++;
+            }
+            float rightArea[NBINS]; uint32_t rightCnt[NBINS];
+            Box acc; acc.reset(); uint32_t c = 0;
+            for (int i = NBINS - 1; i > 0; --i) { acc.grow(bins[i].mn, bins[i].mx); c += cnt[i]; rightArea[i] = acc.area(); rightCnt[i] = c; }
+            acc.reset(); c = 0;
+            for (int i = 0; i < NBINS - 1; ++i) {
+                acc.grow(bins[i].mn, bins[i].mx); c += cnt[i];
+                if (c == 0 || rightCnt[i + 1] == 0) continue;
+                float cost = acc.area() * c + rightArea[i + 1] * rightCnt[i + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = i; }
+            }
+        }
+        const float parentArea = box.area();
+        const float leafCost = C_ISECT * (float) n;
+        size_t mid;
+        if (bestAxis < 0) {
+            if (n <= 8) return makeLeaf(b, e);
+            mid = b + n / 2;   /* all centroids coincide: split in the middle */
+        } else {
+            float splitCost = C_TRAV + C_ISECT * bestCost / (parentArea > 0 ? parentArea : 1.0f);
+            if (n <= MAX_LEAF && splitCost >= leafCost) return makeLeaf(b, e);
+            float lo = cb.mn[bestAxis], hi = cb.mx[bestAxis];
+            const float scale = NBINS / (hi - lo);
+            BuildTri *first = &T[b], *last = &T[e];
+            BuildTri *m = std::partition(first, last, [&](const BuildTri &t) {
+                int k = (int) ((t.c[bestAxis] - lo) * scale); k = std::min(std::max(k, 0), NBINS - 1);
+                return k <= bestBin;
+            });
+            mid = b + (size_t) (m - first);
+            if (mid == b || mid == e) mid = b + n / 2;
+        }
+        const uint32_t idx = out.nNodes++;
+        out.nodes.resize((size_t) out.nNodes * 16);
+        Box lb, rb;
+        int32_t l = build(b, mid, lb, depth + 1);
+        int32_t r = build(mid, e, rb, depth + 1);
+        Box lp = lb, rp = rb; pad(lp); pad(rp);
+        float *nd = &out.nodes[(size_t) idx * 16];
+        nd[0] = lp.mn[0]; nd[1] = lp.mn[1]; nd[2] = lp.mn[2]; nd[3] = lp.mx[0];
+        nd[4] = lp.mx[1]; nd[5] = lp.mx[2]; nd[6] = rp.mn[0]; nd[7] = rp.mn[1];
+        nd[8] = rp.mn[2]; nd[9] = rp.mx[0]; nd[10] = rp.mx[1]; nd[11] = rp.mx[2];
+        nd[12] = bits2f((uint32_t) l); nd[13] = bits2f((uint32_t) r); nd[14] = 0; nd[15] = 0;
+        return (int32_t) idx;
+    }
+};
+
+} // namespace detail
+
+inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t nTris, HostBVH &out) {
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<BuildTri> T; T.reserve(nTris);
+    detail::Box tight; tight.reset();
+    for (uint32_t i = 0; i < nTris; ++i) {
+        BuildTri bt; bt.prim = i;
+        for (int a = 0; a < 3; ++a) { bt.bmin[a] = INFINITY; bt.bmax[a] = -INFINITY; }
+        for (int v = 0; v < 3; ++v) {
+            const float *p = positions + 3 * (size_t) indices[3 * (size_t) i + v];
+            for (int a = 0; a < 3; ++a) { bt.bmin[a] = std::min(bt.bmin[a], p[a]); bt.bmax[a] = std::max(bt.bmax[a], p[a]); }
+        }
+        for (int a = 0; a < 3; ++a) bt.c[a] = 0.5f * (bt.bmin[a] + bt.bmax[a]);
+        tight.grow(bt.bmin, bt.bmax);
+        T.push_back(bt);
+    }
+    out = HostBVH();
+    out.nodes.reserve((size_t) nTris * 16);
+    out.tris.reserve((size_t) nTris * 12);
+    for (int a = 0; a < 3; ++a) { out.tightMin[a] = tight.mn[a]; out.tightMax[a] = tight.mx[a]; }
+    /* scene box: tight box enlarged exactly like the reference's kd-tree root (gkdtree.h:1213-1220):
+       min -= (max-min)*eps + eps; max += (max-min_new)*eps + eps */
+    const float eps = 1e-3f;
+    for (int a = 0; a < 3; ++a) {
+        float mn = tight.mn[a], mx = tight.mx[a];
+        mn -= (mx - mn) * eps + eps;
+        mx += (mx - mn) * eps + eps;
+        out.sceneMin[a] = mn; out.sceneMax[a] = mx;
+    }
+    if (nTris == 0) {
+        /* empty scene: a single never-hit leaf */
+        float rec[12] = { 0 }; rec[0] = detail::bits2f(3u); rec[10] = detail::bits2f(0xFFFFFFFFu);
+        out.tris.assign(rec, rec + 12);
+        out.rootRef = ~(int32_t) 0;
+        for (int a = 0; a < 3; ++a) { out.sceneMin[a] = out.tightMin[a] = 0; out.sceneMax[a] = out.tightMax[a] = 0; }
+        return;
+    }
+    detail::Builder B(T, out, positions, indices);
+    detail::Box rootBox;
+    out.rootRef = B.build(0, T.size(), rootBox, 1);
+    /* SAH cost of the final tree */
+    {
+        struct It { int32_t ref; detail::Box box; };
+        std::vector<It> st; st.push_back({ out.rootRef, rootBox });
+        double cost = 0; const double rootA = rootBox.area() > 0 ? rootBox.area() : 1.0;
+        while (!st.empty()) {
+            It it = st.back(); st.pop_back();
+            if (it.ref < 0) { uint32_t r = ~(uint32_t) it.ref; cost += it.box.area() / rootA * ((r & 7) + 1); continue; }
+            cost += it.box.area() / rootA;
+            const float *nd = &out.nodes[(size_t) it.ref * 16];
+            detail::Box l, r; l.mn[0] = nd[0]; l.mn[1] = nd[1]; l.mn[2] = nd[2]; l.mx[0] = nd[3]; l.mx[1] = nd[4]; l.mx[2] = nd[5];
+            r.mn[0] = nd[6]; r.mn[1] = nd[7]; r.mn[2] = nd[8]; r.mx[0] = nd[9]; r.mx[1] = nd[10]; r.mx[2] = nd[11];
+            uint32_t lr, rr; memcpy(&lr, &nd[12], 4); memcpy(&rr, &nd[13], 4);
+            st.push_back({ (int32_t) lr, l }); st.push_back({ (int32_t) rr, r });
+        }
+        out.sahCost = (float) cost;
+    }
+    out.buildMs = (float) std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace pt

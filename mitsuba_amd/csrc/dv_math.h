@@ -1,0 +1,208 @@
+/*
+ * dv_math.h -- float3 / RGB helpers and leaf math for the path_hip kernels.
+ *
+ * Every function is __host__ __device__: the kernels use the device instantiation; the
+ * phip_debug_host_* entry points run the SAME source on the host so that CPU-only tests can
+ * compare the product's shading arithmetic with the oracle bit for bit.
+ *
+ * Operation order follows the reference (so results match the CPU `path` integrator up to the
+ * transcendental substitution of include/phip_fmath.h); the file must be compiled with
+ * -ffp-contract=off.  Reference semantics restated here (file:line under /root/reference):
+ *   include/mitsuba/core/vector.h:535-626   `v / f` multiplies by the reciprocal
+ *   include/mitsuba/core/spectrum.h:415-456 same for Spectrum / scalar
+ *   src/libcore/util.cpp:592-608            coordinateSystem, computeShadingFrame
+ *   src/libcore/util.cpp:651-681,739-761    fresnelDielectricExt, fresnelConductorExact
+ *   src/libcore/math.cpp:25-72              erfinv, erf
+ *   src/libcore/warp.cpp:43-52,76-102       cosine hemisphere, uniform triangle, concentric disk
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/phip_fmath.h"
+
+#define DV __host__ __device__ __forceinline__
+
+#define PT_EPSILON        1e-4f
+#define PT_SHADOW_EPSILON 1e-3f
+#define PT_PI             3.14159265358979323846f
+#define PT_INV_PI         0.31830988618379067154f
+
+namespace pt {
+
+/* std::max / std::min semantics (NOT fmaxf: NaN behaviour must match the CPU restatement) */
+DV float smax(float a, float b) { return (a < b) ? b : a; }
+DV float smin(float a, float b) { return (b < a) ? b : a; }
+DV float safe_sqrt(float v) { return sqrtf(smax(0.0f, v)); }
+
+struct V3 {
+    float x, y, z;
+    DV V3() {}
+    DV explicit V3(float v) : x(v), y(v), z(v) {}
+    DV V3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+    DV V3 operator+(const V3 &v) const { return V3(x + v.x, y + v.y, z + v.z); }
+    DV V3 operator-(const V3 &v) const { return V3(x - v.x, y - v.y, z - v.z); }
+    DV V3 operator*(float f) const { return V3(x * f, y * f, z * f); }
+    DV V3 operator*(const V3 &v) const { return V3(x * v.x, y * v.y, z * v.z); }   /* Spectrum * Spectrum */
+    DV V3 operator-() const { return V3(-x, -y, -z); }
+    DV V3 operator/(float f) const { float r = 1.0f / f; return V3(x * r, y * r, z * r); }
+    DV V3 div(const V3 &v) const { return V3(x / v.x, y / v.y, z / v.z); }          /* Spectrum / Spectrum */
+    DV float lengthSquared() const { return x * x + y * y + z * z; }
+    DV float length() const { return sqrtf(lengthSquared()); }
+    DV bool isZero() const { return x == 0.0f && y == 0.0f && z == 0.0f; }
+    DV float maxc() const { float r = x; r = smax(r, y); r = smax(r, z); return r; }
+    DV float average() const { float r = 0.0f; r += x; r += y; r += z; return r * (1.0f / 3); }
+    DV float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+DV V3 operator*(float f, const V3 &v) { return v * f; }
+DV float dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DV float absDot(const V3 &a, const V3 &b) { return fabsf(dot(a, b)); }
+DV V3 cross(const V3 &a, const V3 &b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DV V3 normalize(const V3 &v) { return v / v.length(); }
+DV V3 sqrt3(const V3 &v) { return V3(safe_sqrt(v.x), safe_sqrt(v.y), safe_sqrt(v.z)); }
+
+struct V2 { float x, y; DV V2() {} DV V2(float x_, float y_) : x(x_), y(y_) {} };
+
+struct Frame {
+    V3 s, t, n;
+    DV V3 toLocal(const V3 &v) const { return V3(dot(v, s), dot(v, t), dot(v, n)); }
+    DV V3 toWorld(const V3 &v) const { return s * v.x + t * v.y + n * v.z; }
+};
+DV float cosTheta(const V3 &v) { return v.z; }
+DV float tanTheta(const V3 &v) {
+    float temp = 1 - v.z * v.z;
+    if (temp <= 0.0f) return 0.0f;
+    return sqrtf(temp) / v.z;
+}
+
+/* util.cpp:592-601 */
+DV void coordinateSystem(const V3 &a, V3 &b, V3 &c) {
+    if (fabsf(a.x) > fabsf(a.y)) {
+        float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z);
+        c = V3(a.z * invLen, 0.0f, -a.x * invLen);
+    } else {
+        float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z);
+        c = V3(0.0f, a.z * invLen, -a.y * invLen);
+    }
+    b = cross(c, a);
+}
+
+/* ---- warp.cpp ---- */
+DV V2 squareToUniformDiskConcentric(const V2 &sample) {
+    float r1 = 2.0f * sample.x - 1.0f;
+    float r2 = 2.0f * sample.y - 1.0f;
+    float phi, r;
+    if (r1 == 0 && r2 == 0) {
+        r = phi = 0;
+    } else if (r1 * r1 > r2 * r2) {
+        r = r1;
+        phi = (PT_PI / 4.0f) * (r2 / r1);
+    } else {
+        r = r2;
+        phi = (PT_PI / 2.0f) - (r1 / r2) * (PT_PI / 4.0f);
+    }
+    float cosPhi, sinPhi;
+    pm_sincosf(phi, &sinPhi, &cosPhi);
+    return V2(r * cosPhi, r * sinPhi);
+}
+DV V3 squareToCosineHemisphere(const V2 &sample) {
+    V2 p = squareToUniformDiskConcentric(sample);
+    float z = safe_sqrt(1.0f - p.x * p.x - p.y * p.y);
+    if (z == 0) z = 1e-10f;
+    return V3(p.x, p.y, z);
+}
+DV V2 squareToUniformTriangle(const V2 &sample) {
+    float a = safe_sqrt(1.0f - sample.x);
+    return V2(1 - a, a * sample.y);
+}
+
+/* ---- math.cpp:25-72 ---- */
+DV float mts_erfinv(float x) {
+    float w = -pm_logf((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+DV float mts_erf(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+    float sign = copysignf(1.0f, x);
+    x = fabsf(x);
+    float t = 1.0f / (1.0f + p * x);
+    float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * pm_expf(-x * x);
+    return sign * y;
+}
+DV float hypot2(float a, float b) {
+    float r;
+    if (fabsf(a) > fabsf(b)) { r = b / a; r = fabsf(a) * sqrtf(1.0f + r * r); }
+    else if (b != 0.0f) { r = a / b; r = fabsf(b) * sqrtf(1.0f + r * r); }
+    else r = 0.0f;
+    return r;
+}
+
+/* ---- util.cpp:651-681 ---- */
+DV float fresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta) {
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    float scale = (cosThetaI_ > 0) ? 1 / eta : eta,
+          cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    float cosThetaI = fabsf(cosThetaI_);
+    float cosThetaT = sqrtf(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+
+/* ---- util.cpp:739-761 (Spectrum version) ---- */
+DV V3 fresnelConductorExact(float cosThetaI, const V3 &eta, const V3 &k) {
+    float cosThetaI2 = cosThetaI * cosThetaI,
+          sinThetaI2 = 1 - cosThetaI2,
+          sinThetaI4 = sinThetaI2 * sinThetaI2;
+    V3 temp1 = eta * eta - k * k - V3(sinThetaI2),
+       a2pb2 = sqrt3(temp1 * temp1 + k * k * eta * eta * 4),
+       a = sqrt3((a2pb2 + temp1) * 0.5f);
+    V3 term1 = a2pb2 + V3(cosThetaI2),
+       term2 = a * (2 * cosThetaI);
+    V3 Rs2 = (term1 - term2).div(term1 + term2);
+    V3 term3 = a2pb2 * cosThetaI2 + V3(sinThetaI4),
+       term4 = term2 * sinThetaI2;
+    V3 Rp2 = (Rs2 * (term3 - term4)).div(term3 + term4);
+    return 0.5f * (Rp2 + Rs2);
+}
+
+/* ---- the counter-based parity stream (phip_sampler_kind CTR), see include/phip.h ----
+ * pcg4d (Jarzynski & Olano, JCGT 9(3) 2020) keyed by (pixel, sample, block, seed); words become
+ * floats exactly like Random::nextFloat (src/libcore/random.cpp:632-641). */
+struct U4 { uint32_t x, y, z, w; };
+DV U4 pcg4d(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    U4 v;
+    v.x = a * 1664525u + 1013904223u; v.y = b * 1664525u + 1013904223u;
+    v.z = c * 1664525u + 1013904223u; v.w = d * 1664525u + 1013904223u;
+    v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+    v.x ^= v.x >> 16; v.y ^= v.y >> 16; v.z ^= v.z >> 16; v.w ^= v.w >> 16;
+    v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+    return v;
+}
+DV float u32ToFloat(uint32_t u) { return pm_from_bits((u >> 9) | 0x3f800000u) - 1.0f; }
+
+} // namespace pt

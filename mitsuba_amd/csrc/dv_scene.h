@@ -1,0 +1,503 @@
+/*
+ * dv_scene.h -- device-resident scene layout and the per-vertex shading functions of path_hip.
+ *
+ * HBM layout (all arrays are immutable after phip_scene_create):
+ *   nodes      float4[4*nNodes]    64-byte BVH2 nodes, both child boxes per node (bvh.h)
+ *   tris       float4[3*nTriRefs]  48-byte Wald triangle records in leaf order
+ *   triVerts   uint4[nTriangles]   (v0, v1, v2, shape) per GLOBAL triangle id
+ *   positions  float4[nVertices]   xyz + pad  (one 16-byte load per vertex)
+ *   normals    float4[nVertices]   xyz + pad  (or null)
+ *   shapes / materials / emitters  small tables
+ *   areaCdf    float[...]          per-emitter-shape area CDFs (pmf.h layout, n+1 entries)
+ *   emitterCdf float[nEmitters+1]
+ *
+ * Functions restate (file:line under /root/reference) -- same arithmetic as oracle/, written
+ * independently for the device:
+ *   include/mitsuba/render/skdtree.h:343-428     fillIntersectionRecord<true>
+ *   include/mitsuba/render/triaccel.h:96-158     TriAccel::rayIntersect
+ *   include/mitsuba/core/pmf.h:124-188           DiscreteDistribution::sample / sampleReuse
+ *   src/librender/scene.cpp:828-852,949-952      sampleEmitterDirect / pdfEmitterDirect
+ *   src/emitters/area.cpp:104-109,158-182        AreaLight eval / sampleDirect / pdfDirect
+ *   src/librender/shape.cpp:102-126              Shape::sampleDirect / pdfDirect
+ *   src/librender/trimesh.cpp:412-423, src/libcore/triangle.cpp:24-59   area sampling
+ *   src/bsdfs/{diffuse,dielectric,roughconductor,twosided}.cpp, microfacet.h   the BSDFs
+ *   src/sensors/perspective.cpp:271-297          sampleRayDifferential
+ */
+#pragma once
+#include "dv_math.h"
+#include "../../include/phip.h"
+
+namespace pt {
+
+struct DevShape {
+    uint32_t material; int32_t emitter; uint32_t hasNormals; uint32_t firstTri;
+    uint32_t nTris; uint32_t cdfOffset; float invSurfaceArea; uint32_t pad;
+};
+
+enum { MF_SMOOTH = 1, MF_TRANS_OR_BACK = 2 };
+struct DevMaterial {
+    uint32_t type, nested0, nested1, flags;
+    float refl[3]; float alphaU;
+    float trans[3]; float alphaV;
+    float eta[3]; uint32_t distribution;
+    float k[3]; uint32_t sampleVisible;
+};
+
+struct DevEmitter { float radiance[3]; float samplingWeight; uint32_t shape; uint32_t pad[3]; };
+
+struct DevCamera {
+    float s2c[16];      /* sampleToCamera */
+    float c2w[12];      /* camera-to-world, top 3 rows */
+    float nearClip, farClip, invResX, invResY;
+};
+
+struct DevFilm {
+    int width, height;          /* crop window size (pixel coordinates are crop-relative) */
+    int blockSize, border;
+    float radius, scaleFactor;
+    float table[PHIP_FILTER_RESOLUTION + 1];
+};
+
+struct DevScene {
+    const float4 *nodes; const float4 *tris; const uint4 *triVerts;
+    const float4 *positions; const float4 *normals;
+    const DevShape *shapes; const DevMaterial *materials; const DevEmitter *emitters;
+    const float *areaCdf; const float *emitterCdf;
+    uint32_t nEmitters; float emitterNormalization;
+    int32_t rootRef; uint32_t nTriangles;
+    float sceneMin[3], sceneMax[3];
+    DevCamera cam; DevFilm film;
+};
+
+struct Isect {
+    V3 p; Frame sh; V3 geoN; V3 wi; float t; uint32_t shape; uint32_t prim;
+};
+
+DV V3 ld3(const float4 *a, uint32_t i) { float4 v = a[i]; return V3(v.x, v.y, v.z); }
+
+/* skdtree.h:343-428 with BarycentricPos = true, no UV tangents, no texcoords */
+DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float cu, float cv, float t, Isect &its) {
+    const uint4 tv = S.triVerts[prim];
+    const DevShape &sh = S.shapes[tv.w];
+    const V3 b(1 - cu - cv, cu, cv);
+    const V3 p0 = ld3(S.positions, tv.x), p1 = ld3(S.positions, tv.y), p2 = ld3(S.positions, tv.z);
+    its.p = p0 * b.x + p1 * b.y + p2 * b.z;
+    V3 side1(p1 - p0), side2(p2 - p0);
+    V3 faceNormal(cross(side1, side2));
+    float length = faceNormal.length();
+    if (!faceNormal.isZero())
+        faceNormal = faceNormal / length;
+    V3 shN;
+    if (sh.hasNormals) {
+        const V3 n0 = ld3(S.normals, tv.x), n1 = ld3(S.normals, tv.y), n2 = ld3(S.normals, tv.z);
+        shN = normalize(n0 * b.x + n1 * b.y + n2 * b.z);
+        if (dot(faceNormal, shN) < 0)
+            faceNormal = -faceNormal;
+    } else {
+        shN = faceNormal;
+    }
+    its.geoN = faceNormal;
+    /* computeShadingFrame(n, dpdu = side1), util.cpp:603-608 */
+    its.sh.n = shN;
+    its.sh.s = normalize(side1 - shN * dot(shN, side1));
+    its.sh.t = cross(shN, its.sh.s);
+    its.wi = its.sh.toLocal(-rayD);
+    its.t = t; its.shape = tv.w; its.prim = prim;
+}
+
+/* triaccel.h:96-158 on a 48-byte record */
+DV bool waldIntersect(const float4 &a, const float4 &b, const float4 &c, const V3 &o, const V3 &d,
+                      float mint, float maxt, float &u, float &v, float &t) {
+    const uint32_t k = pm_to_bits(a.x);
+    float o_u, o_v, o_k, d_u, d_v, d_k;
+    if (k == 0) { o_u = o.y; o_v = o.z; o_k = o.x; d_u = d.y; d_v = d.z; d_k = d.x; }
+    else if (k == 1) { o_u = o.z; o_v = o.x; o_k = o.y; d_u = d.z; d_v = d.x; d_k = d.y; }
+    else if (k == 2) { o_u = o.x; o_v = o.y; o_k = o.z; d_u = d.x; d_v = d.y; d_k = d.z; }
+    else return false;
+    const float n_u = a.y, n_v = a.z, n_d = a.w;
+    t = (n_d - o_u * n_u - o_v * n_v - o_k) / (d_u * n_u + d_v * n_v + d_k);
+    if (t < mint || t > maxt)
+        return false;
+    const float hu = o_u + t * d_u - b.x;
+    const float hv = o_v + t * d_v - b.y;
+    u = hv * b.z + hu * b.w;
+    v = hu * c.x + hv * c.y;
+    return u >= 0 && v >= 0 && u + v <= 1.0f;
+}
+
+/* std::lower_bound over cdf[0..n] + DiscreteDistribution::sample, pmf.h:124-136 */
+DV uint32_t cdfSample(const float *cdf, uint32_t nEntries, float sampleValue) {
+    /* cdf has nEntries+1 values */
+    uint32_t lo = 0, len = nEntries + 1;
+    while (len > 0) {                       /* lower_bound: first element not < value */
+        uint32_t half = len >> 1, mid = lo + half;
+        if (cdf[mid] < sampleValue) { lo = mid + 1; len = len - half - 1; } else len = half;
+    }
+    long idx = (long) lo - 1;
+    if (idx < 0) idx = 0;
+    uint32_t index = (uint32_t) idx;
+    if (index > nEntries - 1) index = nEntries - 1;
+    while (index < nEntries - 1 && cdf[index + 1] - cdf[index] == 0)
+        ++index;
+    return index;
+}
+
+struct DirectRec {
+    V3 p, n, d, ref, refN; float dist, pdf; int emitter; int solidAngle;
+};
+
+/* trimesh.cpp:412-423 + triangle.cpp:24-59 + shape.cpp:102-115 */
+DV void shapeSampleDirect(const DevScene &S, const DevShape &sh, DirectRec &dRec, V2 sample) {
+    const float *cdf = S.areaCdf + sh.cdfOffset;
+    uint32_t index = cdfSample(cdf, sh.nTris, sample.y);
+    sample.y = (sample.y - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    const uint32_t tri = sh.firstTri + index;
+    const uint4 tv = S.triVerts[tri];
+    const V3 p0 = ld3(S.positions, tv.x), p1 = ld3(S.positions, tv.y), p2 = ld3(S.positions, tv.z);
+    V2 bary = squareToUniformTriangle(sample);
+    V3 sideA = p1 - p0, sideB = p2 - p0;
+    dRec.p = p0 + (sideA * bary.x) + (sideB * bary.y);
+    if (sh.hasNormals) {
+        const V3 n0 = ld3(S.normals, tv.x), n1 = ld3(S.normals, tv.y), n2 = ld3(S.normals, tv.z);
+        dRec.n = normalize(n0 * (1.0f - bary.x - bary.y) + n1 * bary.x + n2 * bary.y);
+    } else {
+        dRec.n = normalize(cross(sideA, sideB));
+    }
+    dRec.pdf = sh.invSurfaceArea;
+    dRec.d = dRec.p - dRec.ref;
+    float distSquared = dRec.d.lengthSquared();
+    dRec.dist = sqrtf(distSquared);
+    dRec.d = dRec.d / dRec.dist;
+    float dp = absDot(dRec.d, dRec.n);
+    dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    dRec.solidAngle = 1;
+}
+
+/* scene.cpp:828-852 without the visibility test (the shadow ray is traced by the wavefront),
+   area.cpp:158-173.  Returns value (radiance/pdf/emPdf); dRec.pdf == 0 means "no sample". */
+DV V3 sampleEmitterDirect(const DevScene &S, DirectRec &dRec, V2 sample) {
+    if (S.nEmitters == 0) { dRec.pdf = 0; return V3(0.0f); }
+    uint32_t index = cdfSample(S.emitterCdf, S.nEmitters, sample.x);
+    float emPdf = S.emitterCdf[index + 1] - S.emitterCdf[index];
+    sample.x = (sample.x - S.emitterCdf[index]) / (S.emitterCdf[index + 1] - S.emitterCdf[index]);
+    const DevEmitter &em = S.emitters[index];
+    shapeSampleDirect(S, S.shapes[em.shape], dRec, sample);
+    V3 value;
+    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
+        value = V3(em.radiance[0], em.radiance[1], em.radiance[2]) / dRec.pdf;
+    } else {
+        dRec.pdf = 0.0f;
+        return V3(0.0f);
+    }
+    dRec.emitter = (int) index;
+    dRec.pdf *= emPdf;
+    value = value / emPdf;
+    return value;
+}
+
+/* scene.cpp:949-952, scene.h:848-850, area.cpp:175-182, shape.cpp:117-126 (solid-angle measure) */
+DV float pdfEmitterDirect(const DevScene &S, const DirectRec &dRec) {
+    const DevEmitter &em = S.emitters[dRec.emitter];
+    float pdf;
+    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+        float pdfPos = S.shapes[em.shape].invSurfaceArea;
+        pdf = pdfPos * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
+    } else {
+        pdf = 0.0f;
+    }
+    return pdf * (em.samplingWeight * S.emitterNormalization);
+}
+
+/* ======================================================================================
+ *  BSDFs
+ * ====================================================================================== */
+struct MF {   /* MicrofacetDistribution, microfacet.h */
+    int type; float alphaU, alphaV; bool visible;
+    DV MF(const DevMaterial &M) : type((int) M.distribution), alphaU(M.alphaU), alphaV(M.alphaV), visible(M.sampleVisible != 0) {
+        alphaU = smax(alphaU, 1e-4f); alphaV = smax(alphaV, 1e-4f);
+    }
+    DV bool isIsotropic() const { return alphaU == alphaV; }
+    DV float eval(const V3 &m) const {
+        if (cosTheta(m) <= 0) return 0.0f;
+        float cosTheta2 = m.z * m.z;
+        float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
+        float result;
+        if (type == PHIP_MF_BECKMANN) {
+            result = pm_expf(-beckmannExponent) / (PT_PI * alphaU * alphaV * cosTheta2 * cosTheta2);
+        } else {
+            float root = (1.0f + beckmannExponent) * cosTheta2;
+            result = 1.0f / (PT_PI * alphaU * alphaV * root * root);
+        }
+        if (result * cosTheta(m) < 1e-20f) result = 0;
+        return result;
+    }
+    DV float projectRoughness(const V3 &v) const {
+        float invSinTheta2 = 1 / (1.0f - v.z * v.z);
+        if (isIsotropic() || invSinTheta2 <= 0) return alphaU;
+        float cosPhi2 = v.x * v.x * invSinTheta2;
+        float sinPhi2 = v.y * v.y * invSinTheta2;
+        return sqrtf(cosPhi2 * alphaU * alphaU + sinPhi2 * alphaV * alphaV);
+    }
+    DV float smithG1(const V3 &v, const V3 &m) const {
+        if (dot(v, m) * cosTheta(v) <= 0) return 0.0f;
+        float tanT = fabsf(tanTheta(v));
+        if (tanT == 0.0f) return 1.0f;
+        float alpha = projectRoughness(v);
+        if (type == PHIP_MF_BECKMANN) {
+            float a = 1.0f / (alpha * tanT);
+            if (a >= 1.6f) return 1.0f;
+            float aSqr = a * a;
+            return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+        } else {
+            float root = alpha * tanT;
+            return 2.0f / (1.0f + hypot2(1.0f, root));
+        }
+    }
+    DV float G(const V3 &wi, const V3 &wo, const V3 &m) const { return smithG1(wi, m) * smithG1(wo, m); }
+    DV float pdfVisible(const V3 &wi, const V3 &m) const {
+        if (cosTheta(wi) == 0) return 0.0f;
+        return smithG1(wi, m) * absDot(wi, m) * eval(m) / fabsf(cosTheta(wi));
+    }
+    DV float pdf(const V3 &wi, const V3 &m) const { return visible ? pdfVisible(wi, m) : eval(m) * cosTheta(m); }
+
+    DV V3 sampleAll(const V2 &sample, float &pdf) const {
+        float cosThetaM = 0.0f, sinPhiM, cosPhiM, alphaSqr;
+        if (isIsotropic()) {
+            pm_sincosf((2.0f * PT_PI) * sample.y, &sinPhiM, &cosPhiM);
+            alphaSqr = alphaU * alphaU;
+        } else {
+            float phiM = pm_atanf(alphaV / alphaU * pm_tanf(PT_PI + 2 * PT_PI * sample.y)) + PT_PI * floorf(2 * sample.y + 0.5f);
+            pm_sincosf(phiM, &sinPhiM, &cosPhiM);
+            float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
+            alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
+        }
+        if (type == PHIP_MF_BECKMANN) {
+            float tanThetaMSqr = alphaSqr * -pm_logf(1.0f - sample.x);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            pdf = (1.0f - sample.x) / (PT_PI * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
+        } else {
+            float tanThetaMSqr = alphaSqr * sample.x / (1.0f - sample.x);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            float temp = 1 + tanThetaMSqr / alphaSqr;
+            pdf = PT_INV_PI / (alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        }
+        if (pdf < 1e-20f) pdf = 0;
+        float sinThetaM = sqrtf(smax(0.0f, 1 - cosThetaM * cosThetaM));
+        return V3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+    }
+
+    DV V2 sampleVisible11(float thetaI, V2 sample) const {
+        const float SQRT_PI_INV = 1 / sqrtf(PT_PI);
+        V2 slope;
+        if (type == PHIP_MF_BECKMANN) {
+            if (thetaI < 1e-4f) {
+                float sinPhi, cosPhi;
+                float r = sqrtf(-pm_logf(1.0f - sample.x));
+                pm_sincosf(2 * PT_PI * sample.y, &sinPhi, &cosPhi);
+                return V2(r * cosPhi, r * sinPhi);
+            }
+            float tanThetaI = pm_tanf(thetaI);
+            float cotThetaI = 1 / tanThetaI;
+            float a = -1, c = mts_erf(cotThetaI);
+            float sample_x = smax(sample.x, 1e-6f);
+            float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+            float b = c - (1 + c) * pm_powf(1 - sample_x, fit);
+            float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * pm_expf(-cotThetaI * cotThetaI));
+            int it = 0;
+            while (++it < 10) {
+                if (!(b >= a && b <= c))
+                    b = 0.5f * (a + c);
+                float invErf = mts_erfinv(b);
+                float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * pm_expf(-invErf * invErf)) - sample_x;
+                float derivative = normalization * (1 - invErf * tanThetaI);
+                if (fabsf(value) < 1e-5f)
+                    break;
+                if (value > 0) c = b; else a = b;
+                b -= value / derivative;
+            }
+            slope.x = mts_erfinv(b);
+            slope.y = mts_erfinv(2.0f * smax(sample.y, 1e-6f) - 1.0f);
+        } else {
+            if (thetaI < 1e-4f) {
+                float sinPhi, cosPhi;
+                float r = safe_sqrt(sample.x / (1 - sample.x));
+                pm_sincosf(2 * PT_PI * sample.y, &sinPhi, &cosPhi);
+                return V2(r * cosPhi, r * sinPhi);
+            }
+            float tanThetaI = pm_tanf(thetaI);
+            float a = 1 / tanThetaI;
+            float G1 = 2.0f / (1.0f + safe_sqrt(1.0f + 1.0f / (a * a)));
+            float A = 2.0f * sample.x / G1 - 1.0f;
+            if (fabsf(A) == 1)
+                A -= copysignf(1.0f, A) * PT_EPSILON;
+            float tmp = 1.0f / (A * A - 1.0f);
+            float B = tanThetaI;
+            float D = safe_sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+            float slope_x_1 = B * tmp - D;
+            float slope_x_2 = B * tmp + D;
+            slope.x = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+            float Sg;
+            if (sample.y > 0.5f) { Sg = 1.0f; sample.y = 2.0f * (sample.y - 0.5f); }
+            else { Sg = -1.0f; sample.y = 2.0f * (0.5f - sample.y); }
+            float z = (sample.y * (sample.y * (sample.y * (-0.365728915865723f) + 0.790235037209296f) -
+                        0.424965825137544f) + 0.000152998850436920f) /
+                      (sample.y * (sample.y * (sample.y * (sample.y * 0.169507819808272f - 0.397203533833404f) -
+                        0.232500544458471f) + 1.0f) - 0.539825872510702f);
+            slope.y = Sg * z * sqrtf(1.0f + slope.x * slope.x);
+        }
+        return slope;
+    }
+
+    DV V3 sampleVisible(const V3 &_wi, const V2 &sample) const {
+        V3 wi = normalize(V3(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
+        float theta = 0, phi = 0;
+        if (wi.z < 0.99999f) {
+            theta = pm_acosf(wi.z);
+            phi = pm_atan2f(wi.y, wi.x);
+        }
+        float sinPhi, cosPhi;
+        pm_sincosf(phi, &sinPhi, &cosPhi);
+        V2 slope = sampleVisible11(theta, sample);
+        slope = V2(cosPhi * slope.x - sinPhi * slope.y, sinPhi * slope.x + cosPhi * slope.y);
+        slope.x *= alphaU;
+        slope.y *= alphaV;
+        float normalization = 1.0f / sqrtf(slope.x * slope.x + slope.y * slope.y + 1.0f);
+        return V3(-slope.x * normalization, -slope.y * normalization, normalization);
+    }
+    DV V3 sample(const V3 &wi, const V2 &smp, float &pdf) const {
+        V3 m;
+        if (visible) { m = sampleVisible(wi, smp); pdf = pdfVisible(wi, m); }
+        else m = sampleAll(smp, pdf);
+        return m;
+    }
+};
+
+struct BSDFSample { V3 wo; float eta; float pdf; bool delta; };
+
+DV V3 rgb(const float *p) { return V3(p[0], p[1], p[2]); }
+
+/* one-sided leaf models; wi.z sign already resolved by the twosided adapter */
+DV V3 leafEval(const DevMaterial &M, const V3 &wi, const V3 &wo) {
+    if (M.type == PHIP_BSDF_DIFFUSE) {
+        if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
+        return rgb(M.refl) * (PT_INV_PI * cosTheta(wo));
+    } else if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
+        if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
+        V3 H = normalize(wo + wi);
+        MF distr(M);
+        const float D = distr.eval(H);
+        if (D == 0) return V3(0.0f);
+        const V3 F = fresnelConductorExact(dot(wi, H), rgb(M.eta), rgb(M.k)) * rgb(M.refl);
+        const float G = distr.G(wi, wo, H);
+        float model = D * G / (4.0f * cosTheta(wi));
+        return F * model;
+    }
+    return V3(0.0f);
+}
+DV float leafPdf(const DevMaterial &M, const V3 &wi, const V3 &wo) {
+    if (M.type == PHIP_BSDF_DIFFUSE) {
+        if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0f;
+        return PT_INV_PI * cosTheta(wo);
+    } else if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
+        if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0f;
+        V3 H = normalize(wo + wi);
+        MF distr(M);
+        if (M.sampleVisible)
+            return distr.eval(H) * distr.smithG1(wi, H) / (4.0f * cosTheta(wi));
+        else
+            return distr.pdf(wi, H) / (4 * absDot(wo, H));
+    }
+    return 0.0f;
+}
+DV V3 leafSample(const DevMaterial &M, const V3 &wi, const V2 &smp, BSDFSample &bs) {
+    bs.eta = 1.0f; bs.delta = false; bs.pdf = 0.0f; bs.wo = V3(0.0f);
+    if (M.type == PHIP_BSDF_DIFFUSE) {
+        if (cosTheta(wi) <= 0) return V3(0.0f);
+        bs.wo = squareToCosineHemisphere(smp);
+        bs.pdf = PT_INV_PI * cosTheta(bs.wo);
+        return rgb(M.refl);
+    } else if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
+        if (cosTheta(wi) < 0) return V3(0.0f);
+        MF distr(M);
+        float pdf;
+        V3 m = distr.sample(wi, smp, pdf);
+        if (pdf == 0) return V3(0.0f);
+        bs.wo = 2 * dot(wi, m) * m - wi;
+        if (cosTheta(bs.wo) <= 0) return V3(0.0f);
+        V3 F = fresnelConductorExact(dot(wi, m), rgb(M.eta), rgb(M.k)) * rgb(M.refl);
+        float weight;
+        if (M.sampleVisible) weight = distr.smithG1(bs.wo, m);
+        else weight = distr.eval(m) * distr.G(wi, bs.wo, m) * dot(wi, m) / (pdf * cosTheta(wi));
+        pdf /= 4.0f * dot(bs.wo, m);
+        bs.pdf = pdf;
+        return F * weight;
+    } else if (M.type == PHIP_BSDF_DIELECTRIC) {
+        const float eta = M.eta[0], invEta = 1 / eta;
+        float cosThetaT;
+        float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, eta);
+        bs.delta = true;
+        if (smp.x <= F) {
+            bs.wo = V3(-wi.x, -wi.y, wi.z);
+            bs.eta = 1.0f; bs.pdf = F;
+            return rgb(M.refl);
+        } else {
+            float scale = -(cosThetaT < 0 ? invEta : eta);
+            bs.wo = V3(scale * wi.x, scale * wi.y, cosThetaT);
+            bs.eta = cosThetaT < 0 ? eta : invEta;
+            bs.pdf = 1 - F;
+            float factor = cosThetaT < 0 ? invEta : eta;
+            return rgb(M.trans) * (factor * factor);
+        }
+    }
+    return V3(0.0f);
+}
+
+/* dispatch incl. the twosided adapter (twosided.cpp:108-183) */
+DV V3 bsdfEval(const DevScene &S, const DevMaterial &M, V3 wi, V3 wo) {
+    if (M.type == PHIP_BSDF_TWOSIDED) {
+        if (cosTheta(wi) > 0) return leafEval(S.materials[M.nested0], wi, wo);
+        wi.z *= -1; wo.z *= -1;
+        return leafEval(S.materials[M.nested1], wi, wo);
+    }
+    return leafEval(M, wi, wo);
+}
+DV float bsdfPdf(const DevScene &S, const DevMaterial &M, V3 wi, V3 wo) {
+    if (M.type == PHIP_BSDF_TWOSIDED) {
+        if (wi.z > 0) return leafPdf(S.materials[M.nested0], wi, wo);
+        wi.z *= -1; wo.z *= -1;
+        return leafPdf(S.materials[M.nested1], wi, wo);
+    }
+    return leafPdf(M, wi, wo);
+}
+DV V3 bsdfSample(const DevScene &S, const DevMaterial &M, V3 wi, const V2 &smp, BSDFSample &bs) {
+    if (M.type == PHIP_BSDF_TWOSIDED) {
+        bool flipped = false;
+        if (cosTheta(wi) < 0) { wi.z *= -1; flipped = true; }
+        V3 result = leafSample(S.materials[flipped ? M.nested1 : M.nested0], wi, smp, bs);
+        if (flipped && !result.isZero() && bs.pdf != 0)
+            bs.wo.z *= -1;
+        return result;
+    }
+    return leafSample(M, wi, smp, bs);
+}
+
+/* perspective.cpp:271-297 */
+DV void cameraRay(const DevCamera &c, float sx, float sy, V3 &o, V3 &d, float &mint, float &maxt) {
+    const float px = sx * c.invResX, py = sy * c.invResY, pz = 0.0f;
+    const float *m = c.s2c;
+    float x = m[0] * px + m[1] * py + m[2] * pz + m[3];
+    float y = m[4] * px + m[5] * py + m[6] * pz + m[7];
+    float z = m[8] * px + m[9] * py + m[10] * pz + m[11];
+    float w = m[12] * px + m[13] * py + m[14] * pz + m[15];
+    V3 nearP = (w == 1.0f) ? V3(x, y, z) : V3(x, y, z) / w;
+    V3 dl = normalize(nearP);
+    float invZ = 1.0f / dl.z;
+    mint = c.nearClip * invZ;
+    maxt = c.farClip * invZ;
+    const float *t = c.c2w;
+    o = V3(t[0] * 0.0f + t[1] * 0.0f + t[2] * 0.0f + t[3], t[4] * 0.0f + t[5] * 0.0f + t[6] * 0.0f + t[7],
+           t[8] * 0.0f + t[9] * 0.0f + t[10] * 0.0f + t[11]);
+    d = V3(t[0] * dl.x + t[1] * dl.y + t[2] * dl.z, t[4] * dl.x + t[5] * dl.y + t[6] * dl.z, t[8] * dl.x + t[9] * dl.y + t[10] * dl.z);
+}
+
+} // namespace pt

@@ -1,0 +1,1149 @@
+/*
+ * phip.hip -- MI355X (gfx950) wavefront path tracer behind the C ABI of include/phip.h.
+ *
+ * Replaces the reference's per-block CPU loop (SamplingIntegrator::renderBlock ->
+ * MIPathTracer::Li, src/librender/integrator.cpp:140-188, src/integrators/path/path.cpp:119-300)
+ * with a slot-stable wavefront: a pool of path slots lives in HBM as SoA arrays; every iteration
+ * runs   shade -> shadow -> trace   over the pool.
+ *
+ *   k_shade   one lane per slot.  Consumes the closest-hit record of the slot's current ray:
+ *             emitter-hit MIS term, Russian roulette, then at the new vertex emission, NEE
+ *             sample (emits a self-contained shadow-queue entry), BSDF sample -> next ray.
+ *             When a path ends the SAME lane immediately regenerates a new camera path from a
+ *             global sample counter (wave-aggregated atomic), so the pool stays full until the
+ *             image runs out of samples.  Radiance is accumulated per sample in a sample buffer
+ *             L[sampleId] (float4), so a finished slot has nothing to flush.
+ *   k_shadow  any-hit traversal over the compacted shadow queue; unoccluded entries add their
+ *             contribution to L[sampleId].
+ *   k_trace   closest-hit traversal for every live slot -> hit record.
+ *   k_film    per-pixel gather of the filtered samples (ImageBlock::put semantics,
+ *             include/mitsuba/render/imageblock.h:124-204) -- no float atomics, deterministic.
+ *
+ * Traversal: BVH2 with 64-byte nodes (bvh.h), per-lane stack in LDS (interleaved so that lane i
+ * owns bank i), Wald triangle test with the reference's arithmetic.  Not MFMA work: irregular,
+ * latency/HBM bound.
+ *
+ * This file is the product; it never includes, links or calls anything under oracle/.
+ */
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+
+#include "../../include/phip.h"
+#include "dv_scene.h"
+#include "bvh.h"
+
+using namespace pt;
+
+/* ======================================================================================
+ *  error handling
+ * ====================================================================================== */
+static thread_local std::string g_err;
+static int setErr(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__));         \
+    } while (0)
+
+/* ======================================================================================
+ *  device-side state
+ * ====================================================================================== */
+#define BLOCK 256
+#define STACK_DEPTH 40          /* BVH2 depth for 1M triangles stays well below this */
+
+enum : uint32_t {
+    F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20,
+    DEPTH_MASK = 0xFFFFu
+};
+
+struct PathPool {
+    float4 *rayO;     /* o.xyz, mint */
+    float4 *rayD;     /* d.xyz, maxt */
+    float4 *hit;      /* t, u, v, bits(prim) */
+    float4 *thr;      /* throughput rgb, eta */
+    float4 *refN;     /* refN xyz, bsdfPdf */
+    uint4 *info;      /* sampleId, pixel, sampleIndex, depth|flags */
+    float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0) */
+    uint32_t capacity;
+};
+
+struct Counters {
+    unsigned long long nextId;        /* next sample id to hand out */
+    unsigned long long closestRays, shadowRays, pathVertices, nodeVisits, triTests, samplesDone;
+    uint32_t shadowCount;             /* entries in the shadow queue (reset every iteration) */
+    uint32_t aliveCount;              /* live slots after the last shade (reset every iteration) */
+};
+
+struct RenderConst {
+    unsigned long long totalIds;      /* ids in this pass = nLocalTiles * sppPass * tilePixels */
+    uint32_t sppPass, sppFirst;       /* samples in this pass, first sample index of the pass */
+    uint32_t tilePixels, tileShift;   /* blockSize^2, log2(blockSize) */
+    uint32_t nLocalTiles;
+    int maxDepth, rrDepth, strictNormals, hideEmitters;
+    uint32_t seed;
+    const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
+};
+
+/* ======================================================================================
+ *  small device helpers
+ * ====================================================================================== */
+__device__ __forceinline__ uint32_t compactBits(uint32_t x) {   /* even bits of x -> low 16 bits */
+    x &= 0x55555555u;
+    x = (x ^ (x >> 1)) & 0x33333333u;
+    x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu;
+    x = (x ^ (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t spreadBits(uint32_t x) {
+    x &= 0x0000ffffu;
+    x = (x ^ (x << 8)) & 0x00ff00ffu;
+    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+    x = (x ^ (x << 2)) & 0x33333333u;
+    x = (x ^ (x << 1)) & 0x55555555u;
+    return x;
+}
+
+/* sample id -> (local tile, sample-in-pass, pixel); ids are tile-major, then sample, then the
+   Morton index of the pixel inside the tile so that a wave covers an 8x8 pixel patch */
+__device__ __forceinline__ bool decodeId(const RenderConst &rc, const DevFilm &film, unsigned long long id,
+                                         uint32_t &px, uint32_t &py, uint32_t &k) {
+    const uint32_t m = (uint32_t) (id & (rc.tilePixels - 1));
+    const unsigned long long r = id >> (2 * rc.tileShift);
+    k = (uint32_t) (r % rc.sppPass);
+    const uint32_t tile = (uint32_t) (r / rc.sppPass);
+    const uint32_t org = rc.tileOrigin[tile];
+    px = (org & 0xFFFFu) + compactBits(m);
+    py = (org >> 16) + compactBits(m >> 1);
+    k += rc.sppFirst;
+    return px < (uint32_t) film.width && py < (uint32_t) film.height;
+}
+
+/* wave-aggregated append: returns the slot for this lane (valid when `pred`) */
+__device__ __forceinline__ uint32_t waveAppend(uint32_t *counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    const int leader = __ffsll((long long) mask) - 1;
+    if (pred && (int) lane == leader)
+        base = atomicAdd(counter, (uint32_t) __popcll(mask));
+    base = __shfl(base, leader < 0 ? 0 : leader);
+    return base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ unsigned long long waveFetchIds(unsigned long long *counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t lane = __lane_id();
+    unsigned long long base = 0;
+    const int leader = __ffsll((long long) mask) - 1;
+    if (pred && (int) lane == leader)
+        base = atomicAdd(counter, (unsigned long long) __popcll(mask));
+    base = __shfl(base, leader < 0 ? 0 : leader);   /* 64-bit shuffle */
+    return base + (unsigned long long) __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void waveAdd(unsigned long long *counter, unsigned long long v) {
+    /* wave reduction, one atomic per wave */
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    if (__lane_id() == 0 && v)
+        atomicAdd(counter, v);
+}
+
+/* ======================================================================================
+ *  BVH traversal (closest / any hit)
+ * ====================================================================================== */
+struct TravResult { float t, u, v; uint32_t prim; };
+
+/* scene-box clip + adaptive epsilon, src/librender/skdtree.cpp:112-142 (closest) / :207-226 (shadow) */
+template <bool SHADOW>
+__device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
+                                            float &mint, float &maxt) {
+    float nearT = -INFINITY, farT = INFINITY;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
+        if (dd[i] == 0) {
+            if (origin < minVal || origin > maxVal) return false;
+        } else {
+            const float rcp = 1.0f / dd[i];
+            float t1 = (minVal - origin) * rcp;
+            float t2 = (maxVal - origin) * rcp;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+            nearT = smax(t1, nearT);
+            farT = smin(t2, farT);
+            if (!(nearT <= farT)) return false;
+        }
+    }
+    mint = nearT; maxt = farT;
+    float rayMinT = rayMint;
+    if (rayMinT == PT_EPSILON) {
+        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+        if (!SHADOW) m = smax(m, PT_EPSILON);
+        rayMinT *= m;
+    }
+    if (rayMinT > mint) mint = rayMinT;
+    if (rayMaxt < maxt) maxt = rayMaxt;
+    return maxt > mint;
+}
+
+template <bool SHADOW>
+__device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
+                                         uint32_t *stack /* LDS, stride BLOCK */, TravResult &res,
+                                         uint32_t &nodeVisits, uint32_t &triTests) {
+    /* reciprocal direction for the slab tests; the Wald test below uses o,d directly */
+    const V3 rcp(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const V3 ordr(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
+    int sp = 0;
+    int32_t cur = S.rootRef;
+    bool found = false;
+    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *n = S.nodes + 4 * (size_t) cur;
+            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            ++nodeVisits;
+            /* slab tests (fmaf is fine here: box tests only need to be conservative; boxes are padded) */
+            float lx0 = fmaf(n0.x, rcp.x, -ordr.x), lx1 = fmaf(n0.w, rcp.x, -ordr.x);
+            float ly0 = fmaf(n0.y, rcp.y, -ordr.y), ly1 = fmaf(n1.x, rcp.y, -ordr.y);
+            float lz0 = fmaf(n0.z, rcp.z, -ordr.z), lz1 = fmaf(n1.y, rcp.z, -ordr.z);
+            float lnear = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), mint));
+            float lfar = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), maxt));
+            float rx0 = fmaf(n1.z, rcp.x, -ordr.x), rx1 = fmaf(n2.y, rcp.x, -ordr.x);
+            float ry0 = fmaf(n1.w, rcp.y, -ordr.y), ry1 = fmaf(n2.z, rcp.y, -ordr.y);
+            float rz0 = fmaf(n2.x, rcp.z, -ordr.z), rz1 = fmaf(n2.w, rcp.z, -ordr.z);
+            float rnear = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), mint));
+            float rfar = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), maxt));
+            const bool hl = lnear <= lfar, hr = rnear <= rfar;
+            const int32_t lref = (int32_t) pm_to_bits(n3.x), rref = (int32_t) pm_to_bits(n3.y);
+            if (hl && hr) {
+                const bool leftFirst = lnear <= rnear;
+                stack[sp * BLOCK] = (uint32_t) (leftFirst ? rref : lref);
+                ++sp;
+                cur = leftFirst ? lref : rref;
+                continue;
+            } else if (hl) { cur = lref; continue; }
+            else if (hr) { cur = rref; continue; }
+        } else {
+            const uint32_t ref = ~(uint32_t) cur;
+            const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4 *tp = S.tris + 3 * (size_t) (first + i);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                ++triTests;
+                float tu, tv, tt;
+                if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
+                    if (SHADOW) return true;
+                    maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
+                    found = true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = (int32_t) stack[sp * BLOCK];
+    }
+    return found;
+}
+
+/* ======================================================================================
+ *  kernels
+ * ====================================================================================== */
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, PathPool P, Counters *C) {
+    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
+    if (slot < P.capacity) {
+        const uint4 info = P.info[slot];
+        if (info.w & F_ALIVE) {
+            const float4 ro = P.rayO[slot], rd = P.rayD[slot];
+            const V3 o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
+            float mint, maxt;
+            TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
+            rays = 1;
+            if (clipToScene<false>(S, o, d, ro.w, rd.w, mint, maxt))
+                traverse<false>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+            P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+        }
+    }
+    waveAdd(&C->closestRays, rays);
+    waveAdd(&C->nodeVisits, nodeVisits);
+    waveAdd(&C->triTests, triTests);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene S, PathPool P, Counters *C, float4 *L) {
+    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
+    const uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t n = C->shadowCount;
+    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
+    if (idx < n) {
+        const float4 e0 = P.shadow[3 * (size_t) idx], e1 = P.shadow[3 * (size_t) idx + 1], e2 = P.shadow[3 * (size_t) idx + 2];
+        const V3 o(e0.x, e0.y, e0.z), d(e1.x, e1.y, e1.z);
+        float mint, maxt;
+        bool occluded = false;
+        TravResult r;
+        rays = 1;
+        if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt))
+            occluded = traverse<true>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+        if (!occluded) {
+            const uint32_t id = pm_to_bits(e1.w);
+            float4 l = L[id];
+            l.x += e2.x; l.y += e2.y; l.z += e2.z;
+            L[id] = l;
+        }
+    }
+    waveAdd(&C->shadowRays, rays);
+    waveAdd(&C->nodeVisits, nodeVisits);
+    waveAdd(&C->triTests, triTests);
+}
+
+__device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
+    pdfA *= pdfA; pdfB *= pdfB;
+    return pdfA / (pdfA + pdfB);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene S, PathPool P, Counters *C, RenderConst rc, float4 *L) {
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const bool inRange = slot < P.capacity;
+    uint4 info = inRange ? P.info[slot] : make_uint4(0, 0, 0, 0);
+    bool alive = inRange && (info.w & F_ALIVE);
+    bool needNew = inRange && !alive;
+    unsigned long long vertices = 0, done = 0;
+
+    if (alive) {
+        const float4 hit = P.hit[slot];
+        const uint32_t prim = pm_to_bits(hit.w);
+        const float4 ro = P.rayO[slot], rd = P.rayD[slot];
+        const V3 rayD(rd.x, rd.y, rd.z);
+        float4 thr4 = P.thr[slot];
+        V3 thr(thr4.x, thr4.y, thr4.z);
+        float eta = thr4.w;
+        uint32_t depth = info.w & DEPTH_MASK;
+        uint32_t flags = info.w & ~DEPTH_MASK;
+        const uint32_t id = info.x;
+        bool terminate = false;
+        V3 addL(0.0f); bool haveAdd = false;   /* radiance to add to L[id] (in reference order) */
+        float4 l = make_float4(0, 0, 0, 0);
+
+        if (prim == PHIP_NO_HIT) {
+            terminate = true;                   /* no environment emitter: path.cpp:136-143 / 233-248 */
+        } else {
+            Isect its;
+            fillIntersection(S, rayD, prim, hit.y, hit.z, hit.x, its);
+            const DevShape &shp = S.shapes[its.shape];
+            const DevMaterial &mat = S.materials[shp.material];
+            l = L[id];
+            if (flags & F_FIRST) {
+                l.w = 1.0f;                     /* alpha, records.inl:117-144 */
+                haveAdd = true;
+            } else {
+                /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
+                if (shp.emitter >= 0) {
+                    const DevEmitter &em = S.emitters[shp.emitter];
+                    V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em.radiance);
+                    const float4 rn = P.refN[slot];
+                    DirectRec dRec;
+                    dRec.ref = V3(ro.x, ro.y, ro.z); dRec.refN = V3(rn.x, rn.y, rn.z);
+                    dRec.p = its.p; dRec.n = its.sh.n; dRec.d = rayD; dRec.dist = its.t; dRec.emitter = shp.emitter; dRec.solidAngle = 1;
+                    const float lumPdf = (!(flags & F_PREV_DELTA)) ? pdfEmitterDirect(S, dRec) : 0;
+                    const V3 c = thr * value * miWeight(rn.w, lumPdf);
+                    l.x += c.x; l.y += c.y; l.z += c.z;
+                    haveAdd = true;
+                }
+                flags &= ~F_EMITTED;
+                if (depth++ >= (uint32_t) rc.rrDepth) {
+                    float q = smin(thr.maxc() * eta * eta, 0.95f);
+                    const U4 h = pcg4d(info.y, info.z, 2 + 2 * (depth - 2), rc.seed);
+                    if (u32ToFloat(h.x) >= q)
+                        terminate = true;
+                    else
+                        thr = thr / q;
+                }
+            }
+            flags &= ~F_FIRST;
+
+            /* ---- head of the loop for this vertex, path.cpp:135-165 ---- */
+            if (!terminate && !(depth <= (uint32_t) rc.maxDepth || rc.maxDepth < 0))
+                terminate = true;
+            if (!terminate) {
+                if (shp.emitter >= 0 && (flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
+                    const DevEmitter &em = S.emitters[shp.emitter];
+                    V3 le = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em.radiance);
+                    const V3 c = thr * le;
+                    l.x += c.x; l.y += c.y; l.z += c.z;
+                    haveAdd = true;
+                }
+                if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
+                    || (rc.strictNormals && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
+                    terminate = true;
+            }
+            bool pushShadow = false;
+            V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
+            if (!terminate) {
+                const U4 h = pcg4d(info.y, info.z, 1 + 2 * (depth - 1), rc.seed);
+                /* ---- direct illumination sampling, path.cpp:172-200 ---- */
+                DirectRec dRec;
+                dRec.ref = its.p;
+                dRec.refN = (mat.flags & MF_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
+                dRec.pdf = 0; dRec.emitter = -1;
+                if (mat.flags & MF_SMOOTH) {
+                    V3 value = sampleEmitterDirect(S, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
+                    if (dRec.pdf != 0 && !value.isZero()) {
+                        const V3 wo = its.sh.toLocal(dRec.d);
+                        const V3 bsdfVal = bsdfEval(S, mat, its.wi, wo);
+                        if (!bsdfVal.isZero() && (!rc.strictNormals || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
+                            const float bPdf = bsdfPdf(S, mat, its.wi, wo);
+                            const float weight = miWeight(dRec.pdf, bPdf);
+                            shC = thr * value * bsdfVal * weight;
+                            shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
+                            pushShadow = true;
+                        }
+                    }
+                }
+                /* ---- BSDF sampling, path.cpp:207-226 ---- */
+                BSDFSample bs;
+                const V3 bsdfWeight = bsdfSample(S, mat, its.wi, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
+                if (bsdfWeight.isZero()) {
+                    terminate = true;
+                } else {
+                    flags |= F_SCATTERED;
+                    const V3 wo = its.sh.toWorld(bs.wo);
+                    const float woDotGeoN = dot(its.geoN, wo);
+                    if (rc.strictNormals && woDotGeoN * cosTheta(bs.wo) <= 0) {
+                        terminate = true;
+                    } else {
+                        P.rayO[slot] = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
+                        P.rayD[slot] = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                        thr = thr * bsdfWeight;
+                        eta *= bs.eta;
+                        P.thr[slot] = make_float4(thr.x, thr.y, thr.z, eta);
+                        P.refN[slot] = make_float4(dRec.refN.x, dRec.refN.y, dRec.refN.z, bs.pdf);
+                        flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
+                    }
+                }
+            }
+            if (haveAdd) L[id] = l;
+            /* shadow queue entry (self-contained: survives the slot being recycled) */
+            const uint32_t sidx = waveAppend(&C->shadowCount, pushShadow);
+            if (pushShadow) {
+                P.shadow[3 * (size_t) sidx] = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
+                P.shadow[3 * (size_t) sidx + 1] = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
+                P.shadow[3 * (size_t) sidx + 2] = make_float4(shC.x, shC.y, shC.z, 0.0f);
+            }
+        }
+        if (terminate) {
+            vertices = depth; done = 1;
+            needNew = true;
+        } else {
+            info.w = flags | depth;
+            P.info[slot] = info;
+        }
+    }
+
+    /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183) ---- */
+    bool nowAlive = alive && !needNew;
+    for (;;) {
+        const bool want = needNew;
+        if (!__any(want)) break;
+        unsigned long long id = waveFetchIds(&C->nextId, want);
+        if (want) {
+            if (id >= rc.totalIds) {
+                info.w = 0; P.info[slot] = info; needNew = false;     /* out of samples: slot dies */
+            } else {
+                uint32_t px, py, k;
+                if (decodeId(rc, S.film, id, px, py, k)) {
+                    const uint32_t pixel = py * (uint32_t) S.film.width + px;
+                    const U4 h = pcg4d(pixel, k, 0, rc.seed);
+                    const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+                    V3 o, d; float mint, maxt;
+                    cameraRay(S.cam, sx, sy, o, d, mint, maxt);
+                    P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
+                    P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
+                    P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    P.refN[slot] = make_float4(0, 0, 0, 0);
+                    info = make_uint4((uint32_t) id, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST);
+                    P.info[slot] = info;
+                    needNew = false; nowAlive = true;
+                }
+                /* ids that fall outside the crop window (edge tiles) are skipped: fetch again */
+            }
+        }
+    }
+    const unsigned long long am = __ballot(nowAlive);
+    if (__lane_id() == 0 && am) atomicAdd(&C->aliveCount, (uint32_t) __popcll(am));
+    waveAdd(&C->pathVertices, vertices);
+    waveAdd(&C->samplesDone, done);
+}
+
+/* Film: one lane per crop pixel gathers every sample whose filter footprint covers it.  Restates
+ * ImageBlock::put (imageblock.h:124-204) incl. the block-local coordinate arithmetic: a sample
+ * taken in pixel (sx,sy) belongs to the render block whose origin is (sx,sy) rounded down to the
+ * block size, and its weights are computed in that block's coordinate system. */
+__global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
+                                               int tilesX, float *out, int accumulate, unsigned long long *invalidCount) {
+    const DevFilm &F = S.film;
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= F.width || y >= F.height) return;
+    /* a sample of source pixel s lands at s + jitter - 0.5 in [s-0.5, s+0.5): it can reach x iff
+       s > x - radius - 0.5 and s <= x + radius + 0.5 */
+    const int sx0 = max((int) floorf((float) x - F.radius - 0.5f) + 1, 0), sx1 = min((int) floorf((float) x + F.radius + 0.5f), F.width - 1);
+    const int sy0 = max((int) floorf((float) y - F.radius - 0.5f) + 1, 0), sy1 = min((int) floorf((float) y + F.radius + 0.5f), F.height - 1);
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    unsigned long long invalid = 0;
+    for (int sy = sy0; sy <= sy1; ++sy) {
+        for (int sx = sx0; sx <= sx1; ++sx) {
+            const int tx = sx >> rc.tileShift, ty = sy >> rc.tileShift;
+            const int32_t ts = tileSlot[ty * tilesX + tx];
+            if (ts < 0) continue;           /* that block belongs to another shard */
+            const int offX = tx << rc.tileShift, offY = ty << rc.tileShift;
+            const int bw = min(F.blockSize, F.width - offX) + 2 * F.border, bh = min(F.blockSize, F.height - offY) + 2 * F.border;
+            /* destination pixel in the source block's bitmap coordinates */
+            const int dx = x - (offX - F.border), dy = y - (offY - F.border);
+            if (dx < 0 || dy < 0 || dx >= bw || dy >= bh) continue;
+            const uint32_t m = spreadBits((uint32_t) (sx - offX)) | (spreadBits((uint32_t) (sy - offY)) << 1);
+            const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
+            for (uint32_t k = 0; k < rc.sppPass; ++k) {
+                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
+                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
+                const float posx = px - 0.5f - (float) (offX - F.border), posy = py - 0.5f - (float) (offY - F.border);
+                const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), bw - 1);
+                const int miny = max((int) ceilf(posy - F.radius), 0), maxy = min((int) floorf(posy + F.radius), bh - 1);
+                if (dx < minx || dx > maxx || dy < miny || dy > maxy) continue;
+                const unsigned long long id = (((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m;
+                const float4 v = L[id];
+                /* validity check of ImageBlock::put: reject non-finite / negative samples (imageblock.h:148-151) */
+                if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
+                    if (sx == x && sy == y) ++invalid;
+                    continue;
+                }
+                const float wx = F.table[min((int) fabsf(((float) dx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                const float wy = F.table[min((int) fabsf(((float) dy - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                const float w = wx * wy;
+                acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
+            }
+        }
+    }
+    float *o = out + ((size_t) y * F.width + x) * 5;
+    if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
+    else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
+    if (invalid) atomicAdd(invalidCount, invalid);
+}
+
+/* copy per-sample radiance out in [y][x][sample] order (tests) */
+__global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot, int tilesX,
+                                 float4 *out, uint32_t sppTotal) {
+    const DevFilm &F = S.film;
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t) F.width * F.height * rc.sppPass;
+    if (i >= n) return;
+    const uint32_t k = (uint32_t) (i % rc.sppPass);
+    const size_t p = i / rc.sppPass;
+    const int x = (int) (p % F.width), y = (int) (p / F.width);
+    const int tx = x >> rc.tileShift, ty = y >> rc.tileShift;
+    const int32_t ts = tileSlot[ty * tilesX + tx];
+    float4 v = make_float4(0, 0, 0, 0);
+    if (ts >= 0) {
+        const uint32_t m = spreadBits((uint32_t) (x - (tx << rc.tileShift))) | (spreadBits((uint32_t) (y - (ty << rc.tileShift))) << 1);
+        v = L[(((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m];
+    }
+    out[p * sppTotal + rc.sppFirst + k] = v;
+}
+
+/* standalone ray casts for phip_trace */
+__global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, Counters *C) {
+    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
+    const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t nodeVisits = 0, triTests = 0;
+    if (i < n) {
+        const phip_ray ry = rays[i];
+        const V3 o(ry.o[0], ry.o[1], ry.o[2]), d(ry.d[0], ry.d[1], ry.d[2]);
+        float mint, maxt;
+        if (hits) {
+            TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
+            if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt))
+                traverse<false>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+            phip_hit h; h.t = r.t; h.u = r.u; h.v = r.v; h.prim = r.prim;
+            hits[i] = h;
+        }
+        if (occluded) {
+            TravResult r; bool occ = false;
+            if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
+                occ = traverse<true>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+            occluded[i] = occ ? 1 : 0;
+        }
+    }
+    waveAdd(&C->nodeVisits, nodeVisits);
+    waveAdd(&C->triTests, triTests);
+}
+
+/* ======================================================================================
+ *  host side
+ * ====================================================================================== */
+namespace {
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    void alloc(size_t count) { release(); n = count; if (count) HIP_TRY(hipMalloc((void **) &p, count * sizeof(T))); }
+    void upload(const T *src, size_t count) { alloc(count); if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice)); }
+    void release() { if (p) { (void) hipFree(p); p = nullptr; } n = 0; }
+    ~DevBuf() { release(); }
+};
+
+/* 4x4 helpers for the camera set-up: perspective.cpp:126-157, transform.cpp:33-63,99-123, matrix.inl:138-193 */
+struct M4 { float m[4][4]; };
+M4 m4identity() { M4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = i == j ? 1.0f : 0.0f; return r; }
+M4 m4mul(const M4 &a, const M4 &b) {
+    M4 r;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = 0; for (int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[k][j]; r.m[i][j] = s; }
+    return r;
+}
+bool m4invert(const M4 &src, M4 &t) {
+    int indxc[4], indxr[4], ipiv[4] = { 0, 0, 0, 0 };
+    t = src;
+    for (int i = 0; i < 4; i++) {
+        int irow = -1, icol = -1; float big = 0;
+        for (int j = 0; j < 4; j++) if (ipiv[j] != 1) for (int k = 0; k < 4; k++) {
+            if (ipiv[k] == 0) { if (fabsf(t.m[j][k]) >= big) { big = fabsf(t.m[j][k]); irow = j; icol = k; } }
+            else if (ipiv[k] > 1) return false;
+        }
+        ++ipiv[icol];
+        if (irow != icol) for (int k = 0; k < 4; ++k) std::swap(t.m[irow][k], t.m[icol][k]);
+        indxr[i] = irow; indxc[i] = icol;
+        if (t.m[icol][icol] == 0) return false;
+        float pivinv = 1.f / t.m[icol][icol];
+        t.m[icol][icol] = 1.f;
+        for (int j = 0; j < 4; j++) t.m[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++) if (j != icol) {
+            float save = t.m[j][icol]; t.m[j][icol] = 0;
+            for (int k = 0; k < 4; k++) t.m[j][k] -= t.m[icol][k] * save;
+        }
+    }
+    for (int j = 3; j >= 0; j--) if (indxr[j] != indxc[j]) for (int k = 0; k < 4; k++) std::swap(t.m[k][indxr[j]], t.m[k][indxc[j]]);
+    return true;
+}
+
+void setupCamera(const phip_camera &c, const phip_film &f, DevCamera &out) {
+    const float aspect = f.width / (float) f.height;
+    const float relSizeX = (float) f.crop_width / (float) f.width, relSizeY = (float) f.crop_height / (float) f.height;
+    const float relOffX = (float) f.crop_offset_x / (float) f.width, relOffY = (float) f.crop_offset_y / (float) f.height;
+    /* inverse of scale(1/relSize) * translate(-relOffset) * scale(-0.5,-0.5*aspect,1) * translate(-1,-1/aspect,0) * perspective
+       = perspective^-1 * translate^-1 * scale^-1 * translate^-1 * scale^-1 (Transform keeps the product of inverses) */
+    M4 persp; memset(&persp, 0, sizeof(persp));
+    const float recip = 1.0f / (c.far_clip - c.near_clip);
+    const float cot = 1.0f / pm_tanf((c.xfov_deg / 2.0f) * (PT_PI / 180.0f));
+    persp.m[0][0] = cot; persp.m[1][1] = cot; persp.m[2][2] = c.far_clip * recip; persp.m[2][3] = -c.near_clip * c.far_clip * recip; persp.m[3][2] = 1;
+    M4 perspInv; m4invert(persp, perspInv);
+    M4 t2i = m4identity(); t2i.m[0][3] = -(-1.0f); t2i.m[1][3] = -(-1.0f / aspect); t2i.m[2][3] = -0.0f;   /* inverse of translate(-1,-1/aspect,0) */
+    M4 s2i = m4identity(); s2i.m[0][0] = 1.0f / -0.5f; s2i.m[1][1] = 1.0f / (-0.5f * aspect); s2i.m[2][2] = 1.0f / 1.0f;
+    M4 t1i = m4identity(); t1i.m[0][3] = -(-relOffX); t1i.m[1][3] = -(-relOffY); t1i.m[2][3] = -0.0f;
+    M4 s1i = m4identity(); s1i.m[0][0] = 1.0f / (1.0f / relSizeX); s1i.m[1][1] = 1.0f / (1.0f / relSizeY); s1i.m[2][2] = 1.0f / 1.0f;
+    /* Transform::operator* : inv = t.inv * this.inv, applied left to right over the five factors */
+    M4 inv = s1i;                 /* (scale1)^-1 */
+    inv = m4mul(t1i, inv);        /* (scale1*translate1)^-1 = translate1^-1 * scale1^-1 */
+    inv = m4mul(s2i, inv);
+    inv = m4mul(t2i, inv);
+    inv = m4mul(perspInv, inv);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out.s2c[4 * i + j] = inv.m[i][j];
+    for (int i = 0; i < 12; ++i) out.c2w[i] = c.to_world[i];
+    out.nearClip = c.near_clip; out.farClip = c.far_clip;
+    out.invResX = 1.0f / (float) f.crop_width; out.invResY = 1.0f / (float) f.crop_height;
+}
+
+/* spiral block order, src/librender/imageproc.cpp:28-78 */
+void spiralBlocks(int sizeX, int sizeY, int bs, std::vector<std::pair<int, int>> &out) {
+    const int nbx = (int) std::ceil((float) sizeX / (float) bs), nby = (int) std::ceil((float) sizeY / (float) bs);
+    const int total = nbx * nby; int generated = 0;
+    int cx = nbx / 2, cy = nby / 2, dir = 0, stepsLeft = 1, numSteps = 1;
+    out.clear();
+    while (generated < total) {
+        out.push_back({ cx, cy });
+        if (++generated == total) break;
+        do {
+            switch (dir) { case 0: ++cx; break; case 1: ++cy; break; case 2: --cx; break; case 3: --cy; break; }
+            if (--stepsLeft == 0) { dir = (dir + 1) % 4; if (dir == 2 || dir == 0) ++numSteps; stepsLeft = numSteps; }
+        } while (cx < 0 || cy < 0 || cx >= nbx || cy >= nby);
+    }
+}
+
+} // namespace
+
+struct phip_scene {
+    int device = 0;
+    phip_scene_desc descCopy;        /* scalar fields only */
+    HostBVH bvh;
+    DevBuf<float4> nodes, tris, positions, normals;
+    DevBuf<uint4> triVerts;
+    DevBuf<DevShape> shapes; DevBuf<DevMaterial> materials; DevBuf<DevEmitter> emitters;
+    DevBuf<float> areaCdf, emitterCdf;
+    DevScene dev;
+    /* render-time buffers (grown on demand, reused between calls) */
+    DevBuf<float4> rayO, rayD, hit, thr, refN, shadow, L, sampleOut;
+    DevBuf<uint4> info;
+    DevBuf<Counters> counters;
+    DevBuf<uint32_t> tileOrigin; DevBuf<int32_t> tileSlot;
+    DevBuf<float> film; DevBuf<unsigned long long> invalid;
+    uint32_t lastSpp = 0;
+    bool haveSamples = false;
+    std::atomic<int> cancel{ 0 };
+    std::mutex renderLock;
+    hipStream_t stream = nullptr;
+};
+
+static std::vector<DevMaterial> convertMaterials(const phip_material *materials, uint32_t nMaterials) {
+    if (nMaterials && !materials) throw std::runtime_error("materials is NULL");
+    std::vector<DevMaterial> mats(nMaterials);
+    for (uint32_t i = 0; i < nMaterials; ++i) {
+        const phip_material &m = materials[i];
+        DevMaterial &o = mats[i];
+        memset(&o, 0, sizeof(o));
+        o.type = m.type; o.nested0 = m.nested[0]; o.nested1 = m.nested[1];
+        for (int k = 0; k < 3; ++k) { o.refl[k] = m.reflectance[k]; o.trans[k] = m.transmittance[k]; o.eta[k] = m.eta[k]; o.k[k] = m.k[k]; }
+        o.distribution = m.distribution; o.sampleVisible = m.sample_visible ? 1 : 0;
+        switch (m.type) {
+            case PHIP_BSDF_DIFFUSE: {
+                const float mx = std::max(m.reflectance[0], std::max(m.reflectance[1], m.reflectance[2]));
+                if (mx > 1.0f) throw std::runtime_error("diffuse reflectance > 1 (ensureEnergyConservation, diffuse.cpp:95)");
+                if (mx > 0) o.flags |= MF_SMOOTH;            /* component list empty otherwise, diffuse.cpp:97-100 */
+            } break;
+            case PHIP_BSDF_DIELECTRIC:
+                if (!(m.eta[0] > 0)) throw std::runtime_error("dielectric eta must be positive");
+                o.flags |= MF_TRANS_OR_BACK; break;
+            case PHIP_BSDF_ROUGHCONDUCTOR: {
+                if (m.distribution > PHIP_MF_GGX) { g_err = "unsupported microfacet distribution"; throw std::invalid_argument("unsupported microfacet distribution (only beckmann, ggx)"); }
+                o.flags |= MF_SMOOTH;
+                /* alpha = ConstantFloatTexture.eval().average() (roughconductor.cpp:275-280), clamp microfacet.h:113-114 */
+                o.alphaU = std::max(V3(m.alpha_u).average(), 1e-4f);
+                o.alphaV = std::max(V3(m.alpha_v).average(), 1e-4f);
+            } break;
+            case PHIP_BSDF_TWOSIDED: {
+                if (m.nested[0] >= i || m.nested[1] >= i) throw std::runtime_error("twosided: nested materials must precede the adapter");
+                const DevMaterial &a = mats[m.nested[0]], &b = mats[m.nested[1]];
+                if ((a.type != PHIP_BSDF_DIFFUSE && a.type != PHIP_BSDF_ROUGHCONDUCTOR) || (b.type != PHIP_BSDF_DIFFUSE && b.type != PHIP_BSDF_ROUGHCONDUCTOR))
+                    throw std::runtime_error("twosided: only materials without a transmission component can be nested (twosided.cpp:104-106)");
+                if ((a.flags | b.flags) & MF_SMOOTH) o.flags |= MF_SMOOTH;
+                o.flags |= MF_TRANS_OR_BACK;                  /* EBackSide, twosided.cpp:96-100 */
+            } break;
+            default: throw std::runtime_error("unknown bsdf type");
+        }
+    }
+    return mats;
+}
+
+static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
+    if (d.abi_version != PHIP_ABI_VERSION) throw std::runtime_error("phip_scene_desc.abi_version mismatch");
+    if (d.n_vertices && !d.positions) throw std::runtime_error("positions is NULL");
+    if (d.n_triangles && !d.indices) throw std::runtime_error("indices is NULL");
+    if (d.film.crop_width <= 0 || d.film.crop_height <= 0 || d.film.width <= 0 || d.film.height <= 0)
+        throw std::runtime_error("invalid film size");
+    if (d.film.crop_offset_x < 0 || d.film.crop_offset_y < 0 || d.film.crop_offset_x + d.film.crop_width > d.film.width ||
+        d.film.crop_offset_y + d.film.crop_height > d.film.height)
+        throw std::runtime_error("invalid crop window");          /* film.cpp:44-48 */
+    if (!(d.film.filter_radius > 0)) throw std::runtime_error("filter radius must be > 0");
+    for (uint32_t i = 0; i < 3 * d.n_triangles; ++i)
+        if (d.indices[i] >= d.n_vertices) throw std::runtime_error("triangle index out of range");
+
+    /* shapes */
+    std::vector<DevShape> shapes(d.n_shapes);
+    std::vector<uint32_t> triShape(d.n_triangles);
+    std::vector<float> areaCdf;
+    uint32_t expect = 0;
+    for (uint32_t i = 0; i < d.n_shapes; ++i) {
+        const phip_shape &s = d.shapes[i];
+        if (s.first_triangle != expect) throw std::runtime_error("shape triangle ranges must tile the index array in order");
+        if (s.material >= d.n_materials) throw std::runtime_error("shape material id out of range");
+        if (s.emitter >= (int32_t) d.n_emitters) throw std::runtime_error("shape emitter id out of range");
+        if (s.has_normals && !d.normals) throw std::runtime_error("shape has_normals but normals is NULL");
+        expect += s.n_triangles;
+        DevShape &o = shapes[i];
+        o.material = s.material; o.emitter = s.emitter; o.hasNormals = s.has_normals ? 1 : 0;
+        o.firstTri = s.first_triangle; o.nTris = s.n_triangles; o.cdfOffset = 0; o.invSurfaceArea = 0; o.pad = 0;
+        for (uint32_t j = 0; j < s.n_triangles; ++j) triShape[s.first_triangle + j] = i;
+        if (s.emitter >= 0) {
+            /* TriMesh::prepareSamplingTable, trimesh.cpp:388-404 + DiscreteDistribution::normalize */
+            if (s.n_triangles == 0) throw std::runtime_error("area emitter on an empty mesh");
+            o.cdfOffset = (uint32_t) areaCdf.size();
+            std::vector<float> cdf(1, 0.0f);
+            for (uint32_t j = 0; j < s.n_triangles; ++j) {
+                const uint32_t *ix = d.indices + 3 * (size_t) (s.first_triangle + j);
+                const float *p0 = d.positions + 3 * (size_t) ix[0], *p1 = d.positions + 3 * (size_t) ix[1], *p2 = d.positions + 3 * (size_t) ix[2];
+                V3 a(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]), b(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]);
+                cdf.push_back(cdf.back() + 0.5f * cross(a, b).length());
+            }
+            const float sum = cdf.back();
+            if (!(sum > 0)) throw std::runtime_error("area emitter with zero surface area");
+            const float norm = 1.0f / sum;
+            for (size_t j = 1; j < cdf.size(); ++j) cdf[j] *= norm;
+            cdf.back() = 1.0f;
+            o.invSurfaceArea = 1.0f / sum;
+            areaCdf.insert(areaCdf.end(), cdf.begin(), cdf.end());
+        }
+    }
+    if (expect != d.n_triangles) throw std::runtime_error("shape triangle ranges do not cover the index array");
+
+    /* materials */
+    std::vector<DevMaterial> mats = convertMaterials(d.materials, d.n_materials);
+
+    /* emitters + selection pdf, scene.cpp:375-381 */
+    std::vector<DevEmitter> ems(d.n_emitters);
+    std::vector<float> ecdf(1, 0.0f);
+    for (uint32_t i = 0; i < d.n_emitters; ++i) {
+        const phip_emitter &e = d.emitters[i];
+        if (e.shape >= d.n_shapes || d.shapes[e.shape].emitter != (int32_t) i) throw std::runtime_error("emitter/shape back reference mismatch");
+        memset(&ems[i], 0, sizeof(DevEmitter));
+        for (int k = 0; k < 3; ++k) ems[i].radiance[k] = e.radiance[k];
+        ems[i].samplingWeight = e.sampling_weight; ems[i].shape = e.shape;
+        ecdf.push_back(ecdf.back() + e.sampling_weight);
+    }
+    float emNorm = 0;
+    if (d.n_emitters) {
+        const float sum = ecdf.back();
+        if (sum > 0) { emNorm = 1.0f / sum; for (size_t j = 1; j < ecdf.size(); ++j) ecdf[j] *= emNorm; ecdf.back() = 1.0f; }
+    }
+
+    /* acceleration structure */
+    buildBVH(d.positions, d.indices, d.n_triangles, sc->bvh);
+    if (sc->bvh.maxDepth + 2 > STACK_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
+
+    /* upload */
+    HIP_TRY(hipSetDevice(sc->device));
+    std::vector<float4> pos4(d.n_vertices), nrm4;
+    for (uint32_t i = 0; i < d.n_vertices; ++i) pos4[i] = make_float4(d.positions[3 * i], d.positions[3 * i + 1], d.positions[3 * i + 2], 0);
+    if (d.normals) { nrm4.resize(d.n_vertices); for (uint32_t i = 0; i < d.n_vertices; ++i) nrm4[i] = make_float4(d.normals[3 * i], d.normals[3 * i + 1], d.normals[3 * i + 2], 0); }
+    std::vector<uint4> tv(d.n_triangles);
+    for (uint32_t i = 0; i < d.n_triangles; ++i) tv[i] = make_uint4(d.indices[3 * i], d.indices[3 * i + 1], d.indices[3 * i + 2], triShape[i]);
+    if (sc->bvh.nodes.empty()) sc->nodes.alloc(4);
+    else sc->nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
+    sc->tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
+    sc->positions.upload(pos4.data(), pos4.size());
+    if (d.normals) sc->normals.upload(nrm4.data(), nrm4.size());
+    sc->triVerts.upload(tv.data(), tv.size());
+    sc->shapes.upload(shapes.data(), shapes.size());
+    sc->materials.upload(mats.data(), mats.size());
+    sc->emitters.upload(ems.data(), ems.size());
+    sc->areaCdf.upload(areaCdf.data(), areaCdf.size());
+    sc->emitterCdf.upload(ecdf.data(), ecdf.size());
+
+    DevScene &D = sc->dev;
+    memset(&D, 0, sizeof(D));
+    D.nodes = sc->nodes.p; D.tris = sc->tris.p; D.triVerts = sc->triVerts.p; D.positions = sc->positions.p; D.normals = sc->normals.p;
+    D.shapes = sc->shapes.p; D.materials = sc->materials.p; D.emitters = sc->emitters.p;
+    D.areaCdf = sc->areaCdf.p; D.emitterCdf = sc->emitterCdf.p;
+    D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
+    D.rootRef = sc->bvh.rootRef; D.nTriangles = d.n_triangles;
+    for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
+    setupCamera(d.camera, d.film, D.cam);
+    D.film.width = d.film.crop_width; D.film.height = d.film.crop_height;
+    D.film.radius = d.film.filter_radius;
+    D.film.scaleFactor = PHIP_FILTER_RESOLUTION / d.film.filter_radius;     /* rfilter.cpp:50 */
+    D.film.border = (int) std::ceil(d.film.filter_radius - 0.5f);           /* rfilter.cpp:51 */
+    D.film.blockSize = 32;
+    for (int i = 0; i <= PHIP_FILTER_RESOLUTION; ++i) D.film.table[i] = d.film.filter_table[i];
+
+    sc->descCopy = d;
+    sc->descCopy.positions = nullptr; sc->descCopy.normals = nullptr; sc->descCopy.indices = nullptr;
+    sc->descCopy.shapes = nullptr; sc->descCopy.materials = nullptr; sc->descCopy.emitters = nullptr;
+    sc->counters.alloc(1);
+    sc->invalid.alloc(1);
+}
+
+static double algorithmicBytes(const phip_scene *sc, const phip_stats &st) {
+    /* SURVEY 8(d) with this structure's sizes: 64-byte BVH node visits, 48-byte triangle records */
+    const double film = 20.0 * (double) sc->dev.film.width * sc->dev.film.height;
+    return 64.0 * (double) st.bvh_node_visits + 48.0 * (double) st.triangle_tests +
+           (64.0 + 40.0 + 108.0) * (double) st.closest_rays + (64.0 + 4.0) * (double) st.shadow_rays +
+           104.0 * (double) st.path_vertices + film;
+}
+
+static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /* device */, phip_stats *stats) {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    if (p->spp <= 0) throw std::invalid_argument("spp must be > 0");
+    if (p->rr_depth <= 0) throw std::invalid_argument("'rrDepth' must be set to a value greater than zero!");                       /* integrator.cpp:219-220 */
+    if (p->max_depth <= 0 && p->max_depth != -1) throw std::invalid_argument("'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); /* :222-223 */
+    if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
+    const int bs = p->block_size > 0 ? p->block_size : 32;
+    if (bs < 2 || bs > 128 || (bs & (bs - 1))) throw std::invalid_argument("block_size must be a power of two in [2,128] (mitsuba.cpp:233-239 allows 2..128)");
+    const int shardCount = p->shard_count > 0 ? p->shard_count : 1;
+    if (p->shard_index < 0 || p->shard_index >= shardCount) throw std::invalid_argument("shard_index out of range");
+    if (p->device != sc->device) throw std::invalid_argument("scene was created on a different device");
+    HIP_TRY(hipSetDevice(sc->device));
+    std::lock_guard<std::mutex> lock(sc->renderLock);
+    sc->cancel.store(0);
+
+    DevScene D = sc->dev;
+    D.film.blockSize = bs;
+    if (bs < D.film.border) throw std::invalid_argument("The block size must be larger than the image reconstruction filter radius!"); /* renderproc.cpp:175-176 */
+    const int W = D.film.width, H = D.film.height;
+    int tileShift = 0; while ((1 << tileShift) < bs) ++tileShift;
+
+    /* tile -> shard assignment in the reference's spiral order */
+    std::vector<std::pair<int, int>> spiral;
+    spiralBlocks(W, H, bs, spiral);
+    const int tilesX = (W + bs - 1) / bs, tilesY = (H + bs - 1) / bs;
+    std::vector<int32_t> tileSlot((size_t) tilesX * tilesY, -1);
+    std::vector<uint32_t> tileOrigin;
+    for (size_t i = 0; i < spiral.size(); ++i) {
+        if ((int) (i % (size_t) shardCount) != p->shard_index) continue;
+        tileSlot[(size_t) spiral[i].second * tilesX + spiral[i].first] = (int32_t) tileOrigin.size();
+        tileOrigin.push_back((uint32_t) (spiral[i].first * bs) | ((uint32_t) (spiral[i].second * bs) << 16));
+    }
+    const uint32_t nLocalTiles = (uint32_t) tileOrigin.size();
+    if (tileOrigin.empty()) sc->tileOrigin.alloc(1);
+    else sc->tileOrigin.upload(tileOrigin.data(), tileOrigin.size());
+    sc->tileSlot.upload(tileSlot.data(), tileSlot.size());
+
+    hipStream_t stream = (hipStream_t) p->stream;
+    if (!stream) { if (!sc->stream) HIP_TRY(hipStreamCreate(&sc->stream)); stream = sc->stream; }
+
+    /* passes: bound the per-sample buffer (16 B per sample id) */
+    const unsigned long long tilePixels = (unsigned long long) bs * bs;
+    const unsigned long long maxIdsPerPass = (1ull << 32) - 1;                 /* sample ids are 32-bit in the slot state */
+    const unsigned long long budgetIds = (24ull << 30) / 16;                  /* 24 GiB of sample buffer */
+    unsigned long long idsPerSpp = (unsigned long long) nLocalTiles * tilePixels;
+    uint32_t sppPerPass = (uint32_t) p->spp;
+    if (idsPerSpp > 0) {
+        unsigned long long cap = std::min(maxIdsPerPass, budgetIds) / idsPerSpp;
+        if (cap < 1) cap = 1;
+        sppPerPass = (uint32_t) std::min<unsigned long long>(cap, (unsigned long long) p->spp);
+    }
+    const bool keepSamples = (p->flags & PHIP_FLAG_SAMPLE_BUFFER) != 0;
+    if (keepSamples) { sc->sampleOut.alloc((size_t) W * H * (size_t) p->spp); HIP_TRY(hipMemsetAsync(sc->sampleOut.p, 0, sc->sampleOut.n * sizeof(float4), stream)); }
+    sc->haveSamples = keepSamples; sc->lastSpp = (uint32_t) p->spp;
+
+    /* path pool */
+    const unsigned long long idsFirstPass = idsPerSpp * sppPerPass;
+    uint32_t capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), 1u << 21);
+    capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
+    if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
+    if (sc->rayO.n < capacity) {
+        sc->rayO.alloc(capacity); sc->rayD.alloc(capacity); sc->hit.alloc(capacity); sc->thr.alloc(capacity);
+        sc->refN.alloc(capacity); sc->info.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
+    }
+    PathPool P;
+    P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.refN = sc->refN.p; P.info = sc->info.p;
+    P.shadow = sc->shadow.p; P.capacity = capacity;
+    if (sc->L.n < idsFirstPass) sc->L.alloc((size_t) idsFirstPass);
+
+    phip_stats st; memset(&st, 0, sizeof(st));
+    const bool timing = (p->flags & PHIP_FLAG_KERNEL_TIMING) != 0;
+    std::vector<hipEvent_t> evTrace, evShade, evFilm;
+    auto newEvent = [&](std::vector<hipEvent_t> &v) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); v.push_back(e); return e; };
+
+    HIP_TRY(hipMemsetAsync(sc->invalid.p, 0, sizeof(unsigned long long), stream));
+    const dim3 grid((capacity + BLOCK - 1) / BLOCK), block(BLOCK);
+    Counters hc;
+    bool cancelled = false;
+
+    for (uint32_t sppDone = 0; sppDone < (uint32_t) p->spp && !cancelled; sppDone += sppPerPass) {
+        RenderConst rc;
+        rc.sppPass = std::min(sppPerPass, (uint32_t) p->spp - sppDone); rc.sppFirst = sppDone;
+        rc.tilePixels = (uint32_t) tilePixels; rc.tileShift = (uint32_t) tileShift; rc.nLocalTiles = nLocalTiles;
+        rc.totalIds = idsPerSpp * rc.sppPass;
+        rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
+        rc.seed = p->seed; rc.tileOrigin = sc->tileOrigin.p;
+
+        HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
+        HIP_TRY(hipMemsetAsync(sc->info.p, 0, (size_t) capacity * sizeof(uint4), stream));
+        if (rc.totalIds) HIP_TRY(hipMemsetAsync(sc->L.p, 0, (size_t) rc.totalIds * sizeof(float4), stream));
+
+        uint32_t iter = 0;
+        bool done = rc.totalIds == 0;
+        while (!done) {
+            /* reset the per-iteration queue counters (shadowCount, aliveCount are adjacent) */
+            HIP_TRY(hipMemsetAsync(&sc->counters.p->shadowCount, 0, 2 * sizeof(uint32_t), stream));
+            if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
+            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, D, P, sc->counters.p, rc, sc->L.p);
+            if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
+            if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+            hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, D, P, sc->counters.p, sc->L.p);
+            hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P, sc->counters.p);
+            if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+            ++iter;
+            if ((iter & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4) {
+                HIP_TRY(hipMemcpyAsync(&hc, sc->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (hc.aliveCount == 0 && hc.nextId >= rc.totalIds) done = true;
+                if (sc->cancel.load()) { cancelled = true; done = true; }
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        st.iterations += iter;
+        /* film */
+        if (timing) HIP_TRY(hipEventRecord(newEvent(evFilm), stream));
+        {
+            const dim3 fg((W + 15) / 16, (H + 15) / 16);
+            hipLaunchKernelGGL(k_film, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
+                               sppDone > 0 ? 1 : 0, sc->invalid.p);
+        }
+        if (timing) HIP_TRY(hipEventRecord(newEvent(evFilm), stream));
+        if (keepSamples && rc.totalIds) {
+            const size_t n = (size_t) W * H * rc.sppPass;
+            hipLaunchKernelGGL(k_export_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, D, rc, (const float4 *) sc->L.p,
+                               (const int32_t *) sc->tileSlot.p, tilesX, sc->sampleOut.p, (uint32_t) p->spp);
+        }
+        HIP_TRY(hipMemcpyAsync(&hc, sc->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipGetLastError());
+        st.samples += hc.samplesDone; st.closest_rays += hc.closestRays; st.shadow_rays += hc.shadowRays;
+        st.path_vertices += hc.pathVertices; st.bvh_node_visits += hc.nodeVisits; st.triangle_tests += hc.triTests;
+    }
+    if (nLocalTiles == 0) { HIP_TRY(hipMemsetAsync(dOut, 0, (size_t) W * H * 5 * sizeof(float), stream)); HIP_TRY(hipStreamSynchronize(stream)); }
+    unsigned long long inv = 0;
+    HIP_TRY(hipMemcpy(&inv, sc->invalid.p, sizeof(inv), hipMemcpyDeviceToHost));
+    st.invalid_samples = inv;
+    auto sumPairs = [&](std::vector<hipEvent_t> &v) { double ms = 0; for (size_t i = 0; i + 1 < v.size(); i += 2) { float t = 0; (void) hipEventElapsedTime(&t, v[i], v[i + 1]); ms += t; } for (auto e : v) (void) hipEventDestroy(e); return ms; };
+    st.trace_kernel_launches = (uint32_t) (evTrace.size() / 2);
+    st.trace_kernel_ms = sumPairs(evTrace); st.shade_kernel_ms = sumPairs(evShade); st.film_kernel_ms = sumPairs(evFilm);
+    st.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    st.algorithmic_bytes = algorithmicBytes(sc, st);
+    if (stats) *stats = st;
+    if (cancelled) return setErr(PHIP_ERR_CANCELLED, "rendering was cancelled");
+    return PHIP_OK;
+}
+
+/* ======================================================================================
+ *  C ABI
+ * ====================================================================================== */
+extern "C" {
+
+const char *phip_last_error(void) { return g_err.c_str(); }
+const char *phip_version(void) { return "path_hip 0.1 (gfx950, abi 1)"; }
+
+int phip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return setErr(PHIP_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+phip_scene *phip_scene_create(const phip_scene_desc *desc, int device) {
+    if (!desc) { setErr(PHIP_ERR_INVALID, "desc is NULL"); return nullptr; }
+    int n = phip_device_count();
+    if (n <= 0) { if (n == 0) setErr(PHIP_ERR_DEVICE, "no HIP device visible: path_hip has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= n) { setErr(PHIP_ERR_INVALID, "device ordinal out of range"); return nullptr; }
+    phip_scene *sc = new (std::nothrow) phip_scene();
+    if (!sc) { setErr(PHIP_ERR_NOMEM, "out of memory"); return nullptr; }
+    sc->device = device;
+    try {
+        buildScene(sc, *desc);
+        return sc;
+    } catch (const std::invalid_argument &e) {
+        setErr(PHIP_ERR_UNSUPPORTED, e.what());
+    } catch (const std::exception &e) {
+        setErr(PHIP_ERR_INVALID, e.what());
+    }
+    delete sc;
+    return nullptr;
+}
+
+void phip_scene_destroy(phip_scene *scene) {
+    if (!scene) return;
+    (void) hipSetDevice(scene->device);
+    if (scene->stream) (void) hipStreamDestroy(scene->stream);
+    delete scene;
+}
+
+int phip_render_device(phip_scene *scene, const phip_render_params *params, void *d_out, phip_stats *out_stats) {
+    if (!scene || !params || !d_out) return setErr(PHIP_ERR_INVALID, "NULL argument");
+    try {
+        return renderImpl(scene, params, (float *) d_out, out_stats);
+    } catch (const std::invalid_argument &e) {
+        return setErr(PHIP_ERR_INVALID, e.what());
+    } catch (const std::exception &e) {
+        return setErr(PHIP_ERR_DEVICE, e.what());
+    }
+}
+
+int phip_render(phip_scene *scene, const phip_render_params *params, float *out_rgbaw, phip_stats *out_stats) {
+    if (!scene || !params || !out_rgbaw) return setErr(PHIP_ERR_INVALID, "NULL argument");
+    try {
+        HIP_TRY(hipSetDevice(scene->device));
+        const size_t n = (size_t) scene->dev.film.width * scene->dev.film.height * 5;
+        if (scene->film.n < n) scene->film.alloc(n);
+        int rc = renderImpl(scene, params, scene->film.p, out_stats);
+        if (rc != PHIP_OK) return rc;
+        HIP_TRY(hipMemcpy(out_rgbaw, scene->film.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        return PHIP_OK;
+    } catch (const std::invalid_argument &e) {
+        return setErr(PHIP_ERR_INVALID, e.what());
+    } catch (const std::exception &e) {
+        return setErr(PHIP_ERR_DEVICE, e.what());
+    }
+}
+
+int phip_get_samples(phip_scene *scene, float *out_rgba, size_t n_samples) {
+    if (!scene || !out_rgba) return setErr(PHIP_ERR_INVALID, "NULL argument");
+    if (!scene->haveSamples) return setErr(PHIP_ERR_INVALID, "last render did not set PHIP_FLAG_SAMPLE_BUFFER");
+    const size_t n = (size_t) scene->dev.film.width * scene->dev.film.height * scene->lastSpp;
+    if (n_samples != n) return setErr(PHIP_ERR_INVALID, "n_samples does not match crop_w*crop_h*spp");
+    hipError_t e = hipMemcpy(out_rgba, scene->sampleOut.p, n * sizeof(float4), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return setErr(PHIP_ERR_DEVICE, hipGetErrorString(e));
+    return PHIP_OK;
+}
+
+int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, phip_stats *out_stats) {
+    if (!scene || (!rays && n)) return setErr(PHIP_ERR_INVALID, "NULL argument");
+    try {
+        HIP_TRY(hipSetDevice(scene->device));
+        std::lock_guard<std::mutex> lock(scene->renderLock);
+        DevBuf<phip_ray> dr; DevBuf<phip_hit> dh; DevBuf<uint8_t> dz;
+        if (n) {
+            dr.upload(rays, n);
+            if (hits) dh.alloc(n);
+            if (occluded) dz.alloc(n);
+            HIP_TRY(hipMemset(scene->counters.p, 0, sizeof(Counters)));
+            hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, scene->dev, (const phip_ray *) dr.p, n, dh.p, dz.p, scene->counters.p);
+            HIP_TRY(hipEventRecord(e1, 0));
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipGetLastError());
+            float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+            if (hits) HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(phip_hit), hipMemcpyDeviceToHost));
+            if (occluded) HIP_TRY(hipMemcpy(occluded, dz.p, n, hipMemcpyDeviceToHost));
+            if (out_stats) {
+                Counters hc; HIP_TRY(hipMemcpy(&hc, scene->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
+                memset(out_stats, 0, sizeof(*out_stats));
+                out_stats->closest_rays = hits ? n : 0; out_stats->shadow_rays = occluded ? n : 0;
+                out_stats->bvh_node_visits = hc.nodeVisits; out_stats->triangle_tests = hc.triTests;
+                out_stats->trace_kernel_ms = ms; out_stats->trace_kernel_launches = 1;
+            }
+        }
+        return PHIP_OK;
+    } catch (const std::exception &e) {
+        return setErr(PHIP_ERR_DEVICE, e.what());
+    }
+}
+
+void phip_cancel(phip_scene *scene) { if (scene) scene->cancel.store(1); }
+
+void phip_develop(const float *rgbaw, size_t n_pixels, float *out_rgb) {
+    /* fmtconv.cpp:979-991: divide by the weight channel, 0 if the weight is 0 */
+    for (size_t i = 0; i < n_pixels; ++i) {
+        const float w = rgbaw[5 * i + 4];
+        const float inv = w != 0 ? 1.0f / w : 0.0f;
+        for (int k = 0; k < 3; ++k) out_rgb[3 * i + k] = rgbaw[5 * i + k] * inv;
+    }
+}
+
+int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
+    if (!scene || !out) return setErr(PHIP_ERR_INVALID, "NULL argument");
+    out->n_nodes = scene->bvh.nNodes; out->n_leaves = scene->bvh.nLeaves; out->n_triangle_refs = scene->bvh.nTriRefs;
+    out->max_depth = scene->bvh.maxDepth; out->node_bytes = 64; out->triangle_bytes = 48;
+    out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
+    return PHIP_OK;
+}
+
+} // extern "C"
+
+#include "phip_debug.inl"

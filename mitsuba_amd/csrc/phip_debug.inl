@@ -1,0 +1,162 @@
+/*
+ * phip_debug.inl -- host-side utility and unit-test entry points of libphip.so.
+ *
+ * phip_gaussian_filter is a harness utility (the Mitsuba shim copies the table from the
+ * scene's ReconstructionFilter instead).  The phip_debug_host_* functions execute the
+ * __host__ __device__ shading functions of dv_math.h / dv_scene.h ON THE HOST so that
+ * `-m "not gpu"` tests can compare the product's arithmetic with the oracle bit for bit
+ * without a GPU.  They are never reachable from phip_render*: rendering has no CPU fallback.
+ */
+extern "C" {
+
+/* rfilter.cpp:38-57 + gaussian.cpp:34-57: (radius, table[32]) of `gaussian` with the given stddev */
+void phip_gaussian_filter(float stddev, float *radius, float *table32) {
+    const float r = 4 * stddev;
+    float sum = 0.0f;
+    const float alpha = -1.0f / (2.0f * stddev * stddev);
+    for (size_t i = 0; i < PHIP_FILTER_RESOLUTION; ++i) {
+        float x = (r * i) / PHIP_FILTER_RESOLUTION;
+        float value = smax(0.0f, pm_expf(alpha * x * x) - pm_expf(alpha * r * r));
+        table32[i] = value;
+        sum += value;
+    }
+    table32[PHIP_FILTER_RESOLUTION] = 0.0f;
+    sum *= 2 * r / PHIP_FILTER_RESOLUTION;
+    const float normalization = 1.0f / sum;
+    for (size_t i = 0; i < PHIP_FILTER_RESOLUTION; ++i)
+        table32[i] *= normalization;
+    *radius = r;
+}
+
+size_t phip_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(phip_material);
+        case 1: return sizeof(phip_shape);
+        case 2: return sizeof(phip_emitter);
+        case 3: return sizeof(phip_camera);
+        case 4: return sizeof(phip_film);
+        case 5: return sizeof(phip_scene_desc);
+        case 6: return sizeof(phip_render_params);
+        case 7: return sizeof(phip_stats);
+        case 8: return sizeof(phip_ray);
+        case 9: return sizeof(phip_hit);
+        case 10: return sizeof(phip_accel_info);
+        default: return 0;
+    }
+}
+
+int phip_debug_host_bsdf_sample(const phip_material *materials, uint32_t n_materials, uint32_t material, size_t n,
+                                const float *wi3, const float *sample2, float *wo3, float *weight3, float *pdf, uint8_t *delta) {
+    try {
+        std::vector<DevMaterial> mats = convertMaterials(materials, n_materials);
+        if (material >= n_materials) return setErr(PHIP_ERR_INVALID, "material id out of range");
+        DevScene S; memset(&S, 0, sizeof(S)); S.materials = mats.data();
+        for (size_t i = 0; i < n; ++i) {
+            BSDFSample bs;
+            V3 w = bsdfSample(S, mats[material], V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), V2(sample2[2 * i], sample2[2 * i + 1]), bs);
+            if (w.isZero()) { bs.pdf = 0; bs.wo = V3(0.0f); }
+            wo3[3 * i] = bs.wo.x; wo3[3 * i + 1] = bs.wo.y; wo3[3 * i + 2] = bs.wo.z;
+            weight3[3 * i] = w.x; weight3[3 * i + 1] = w.y; weight3[3 * i + 2] = w.z;
+            pdf[i] = bs.pdf; if (delta) delta[i] = bs.delta ? 1 : 0;
+        }
+        return PHIP_OK;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_INVALID, e.what()); }
+}
+
+int phip_debug_host_bsdf_eval_pdf(const phip_material *materials, uint32_t n_materials, uint32_t material, size_t n,
+                                  const float *wi3, const float *wo3, float *value3, float *pdf) {
+    try {
+        std::vector<DevMaterial> mats = convertMaterials(materials, n_materials);
+        if (material >= n_materials) return setErr(PHIP_ERR_INVALID, "material id out of range");
+        DevScene S; memset(&S, 0, sizeof(S)); S.materials = mats.data();
+        for (size_t i = 0; i < n; ++i) {
+            V3 wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+            V3 v = bsdfEval(S, mats[material], wi, wo);
+            value3[3 * i] = v.x; value3[3 * i + 1] = v.y; value3[3 * i + 2] = v.z;
+            pdf[i] = bsdfPdf(S, mats[material], wi, wo);
+        }
+        return PHIP_OK;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_INVALID, e.what()); }
+}
+
+void phip_debug_host_camera_ray(const phip_camera *cam, const phip_film *film, float sx, float sy, phip_ray *out) {
+    DevCamera dc; setupCamera(*cam, *film, dc);
+    V3 o, d; float mint, maxt;
+    cameraRay(dc, sx, sy, o, d, mint, maxt);
+    out->o[0] = o.x; out->o[1] = o.y; out->o[2] = o.z; out->mint = mint;
+    out->d[0] = d.x; out->d[1] = d.y; out->d[2] = d.z; out->maxt = maxt;
+}
+
+void phip_debug_host_ctr_block(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, float *out4) {
+    const U4 h = pcg4d(pixel, sample, block, seed);
+    out4[0] = u32ToFloat(h.x); out4[1] = u32ToFloat(h.y); out4[2] = u32ToFloat(h.z); out4[3] = u32ToFloat(h.w);
+}
+
+/* Wald records + BVH statistics of a triangle soup, built exactly like phip_scene_create does (no GPU needed) */
+int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles,
+                              phip_accel_info *info, float *scene_box6) {
+    try {
+        for (uint32_t i = 0; i < 3 * n_triangles; ++i) if (indices[i] >= n_vertices) return setErr(PHIP_ERR_INVALID, "index out of range");
+        HostBVH bvh; buildBVH(positions, indices, n_triangles, bvh);
+        if (info) {
+            info->n_nodes = bvh.nNodes; info->n_leaves = bvh.nLeaves; info->n_triangle_refs = bvh.nTriRefs; info->max_depth = bvh.maxDepth;
+            info->node_bytes = 64; info->triangle_bytes = 48; info->sah_cost = bvh.sahCost; info->build_ms = bvh.buildMs;
+        }
+        if (scene_box6) for (int a = 0; a < 3; ++a) { scene_box6[a] = bvh.sceneMin[a]; scene_box6[3 + a] = bvh.sceneMax[a]; }
+        return PHIP_OK;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_INVALID, e.what()); }
+}
+
+} // extern "C"
+
+/* device execution of the phip_fmath.h functions (bitwise host/device agreement test) */
+__global__ void k_debug_fmath(int op, size_t n, const float *a, const float *b, float *out) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    switch (op) {
+        case 0: pm_sincosf(a[i], &s, &c); out[i] = s; break;
+        case 1: pm_sincosf(a[i], &s, &c); out[i] = c; break;
+        case 2: out[i] = pm_expf(a[i]); break;
+        case 3: out[i] = pm_logf(a[i]); break;
+        case 4: out[i] = pm_acosf(a[i]); break;
+        case 5: out[i] = pm_atan2f(a[i], b[i]); break;
+        case 6: out[i] = pm_tanf(a[i]); break;
+        case 7: out[i] = pm_powf(a[i], b[i]); break;
+        case 8: out[i] = mts_erf(a[i]); break;
+        case 9: out[i] = mts_erfinv(a[i]); break;
+        case 10: out[i] = pm_atanf(a[i]); break;
+        default: out[i] = 0;
+    }
+}
+
+extern "C" int phip_debug_fmath(int on_device, int op, size_t n, const float *a, const float *b, float *out) {
+    if (!on_device) {
+        for (size_t i = 0; i < n; ++i) {
+            float s, c;
+            switch (op) {
+                case 0: pm_sincosf(a[i], &s, &c); out[i] = s; break;
+                case 1: pm_sincosf(a[i], &s, &c); out[i] = c; break;
+                case 2: out[i] = pm_expf(a[i]); break;
+                case 3: out[i] = pm_logf(a[i]); break;
+                case 4: out[i] = pm_acosf(a[i]); break;
+                case 5: out[i] = pm_atan2f(a[i], b[i]); break;
+                case 6: out[i] = pm_tanf(a[i]); break;
+                case 7: out[i] = pm_powf(a[i], b[i]); break;
+                case 8: out[i] = mts_erf(a[i]); break;
+                case 9: out[i] = mts_erfinv(a[i]); break;
+                case 10: out[i] = pm_atanf(a[i]); break;
+                default: out[i] = 0;
+            }
+        }
+        return PHIP_OK;
+    }
+    try {
+        DevBuf<float> da, db, dout;
+        da.upload(a, n); db.upload(b ? b : a, n); dout.alloc(n);
+        hipLaunchKernelGGL(k_debug_fmath, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, op, n, (const float *) da.p, (const float *) db.p, dout.p);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        return PHIP_OK;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_DEVICE, e.what()); }
+}

@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's integrator plugin interface for the `path` hot path.
+
+Names, parameter meaning and error behaviour follow the reference so that tests read like the
+reference's own:
+
+    PathHIP(props)           <-> MIPathTracer(const Properties &)           src/integrators/path/path.cpp:109-111
+      maxDepth / rrDepth / strictNormals / hideEmitters                      src/librender/integrator.cpp:190-225
+    PathHIP.render(scene)    <-> SamplingIntegrator::render(scene, queue, job, ...) -> bool   integrator.cpp:95-129
+    PathHIP.cancel()         <-> SamplingIntegrator::cancel                  integrator.cpp:90-93
+    Scene(desc)              <-> Scene::initialize (kd-tree build -> BVH build + upload)       scene.cpp:322-384
+    HDRFilm.put / develop    <-> HDRFilm::put(const ImageBlock *) / develop  films/hdrfilm.cpp:391-393,427-475
+
+Everything below the C ABI runs on the GPU; this module only marshals arguments.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+from . import _ffi
+
+
+class Properties(dict):
+    """Minimal typed property bag (include/mitsuba/core/properties.h)."""
+
+    def __init__(self, plugin_name="", **kw):
+        super().__init__(**kw)
+        self.plugin_name = plugin_name
+
+    def getInteger(self, name, default):
+        return int(self.get(name, default))
+
+    def getBoolean(self, name, default):
+        return bool(self.get(name, default))
+
+
+class Scene:
+    """Device-resident scene: flattened meshes + BVH + emitter tables (phip_scene)."""
+
+    def __init__(self, desc, device=0):
+        self._L = _ffi.lib()
+        self.desc = desc
+        self.device = device
+        self._h = self._L.phip_scene_create(C.byref(desc), device)
+        if not self._h:
+            raise RuntimeError("phip_scene_create: " + _ffi.last_error())
+        self.width, self.height = desc.film.crop_width, desc.film.crop_height
+        self.block_size = 32          # Scene::getBlockSize default (mitsuba.cpp:144)
+
+    def setBlockSize(self, bs):
+        self.block_size = int(bs)
+
+    def accel_info(self):
+        info = A.phip_accel_info()
+        rc = self._L.phip_scene_accel_info(self._h, C.byref(info))
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_scene_accel_info")
+        return info
+
+    def rayIntersect(self, rays, closest=True, shadow=False):
+        """Batch version of ShapeKDTree::rayIntersect(ray, its) / (ray).  rays: (n,8) float32 = o, mint, d, maxt."""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(r)
+        hits = np.zeros((n, 4), np.float32) if closest else None
+        occ = np.zeros(n, np.uint8) if shadow else None
+        st = A.phip_stats()
+        rc = self._L.phip_trace(self._h, r.ctypes.data_as(C.POINTER(A.phip_ray)), n,
+                                hits.ctypes.data_as(C.POINTER(A.phip_hit)) if closest else None,
+                                occ.ctypes.data_as(C.POINTER(C.c_uint8)) if shadow else None, C.byref(st))
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_trace")
+        return hits, occ, st
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.phip_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HDRFilm:
+    """Crop-sized (R,G,B,alpha,weight) float32 accumulation buffer, like HDRFilm's m_storage."""
+
+    def __init__(self, width, height):
+        self.storage = np.zeros((height, width, 5), np.float32)
+
+    def clear(self):
+        self.storage[...] = 0
+
+    def put(self, block):
+        self.storage += block
+
+    def develop(self):
+        h, w, _ = self.storage.shape
+        out = np.zeros((h, w, 3), np.float32)
+        _ffi.lib().phip_develop(_ffi.fptr(self.storage), h * w, _ffi.fptr(out))
+        return out
+
+
+class PathHIP:
+    """`path_hip` integrator: MIPathTracer semantics, MI355X execution."""
+
+    def __init__(self, props=None, **kw):
+        props = Properties("path_hip", **(dict(props or {}) | kw))
+        self.m_rrDepth = props.getInteger("rrDepth", 5)
+        self.m_maxDepth = props.getInteger("maxDepth", -1)
+        self.m_strictNormals = props.getBoolean("strictNormals", False)
+        self.m_hideEmitters = props.getBoolean("hideEmitters", False)
+        # integrator.cpp:219-224
+        if self.m_rrDepth <= 0:
+            raise RuntimeError("'rrDepth' must be set to a value greater than zero!")
+        if self.m_maxDepth <= 0 and self.m_maxDepth != -1:
+            raise RuntimeError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!")
+        self.stats = None
+        self._scene = None
+
+    def params(self, scene, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None):
+        return A.default_render_params(spp=spp, max_depth=self.m_maxDepth, rr_depth=self.m_rrDepth,
+                                       strict_normals=int(self.m_strictNormals), hide_emitters=int(self.m_hideEmitters),
+                                       block_size=scene.block_size, seed=seed, shard_index=shard_index,
+                                       shard_count=shard_count, device=scene.device, flags=flags, stream=stream)
+
+    def render(self, scene, film, spp, seed=0, shard_index=0, shard_count=1, flags=0):
+        """Renders into `film` (film.put of one full-frame block).  Returns True on success,
+        False if cancelled (SamplingIntegrator::render returns proc->getReturnStatus() == ESuccess)."""
+        self._scene = scene
+        p = self.params(scene, spp, seed, shard_index, shard_count, flags)
+        block = np.zeros((scene.height, scene.width, 5), np.float32)
+        st = A.phip_stats()
+        rc = _ffi.lib().phip_render(scene._h, C.byref(p), _ffi.fptr(block), C.byref(st))
+        self.stats = st
+        if rc == A.PHIP_ERR_CANCELLED:
+            return False
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_render")     # Log(EError, ...) throws in the reference
+        film.put(block)
+        return True
+
+    def render_device(self, scene, d_out_ptr, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None):
+        """Renders this shard's blocks into device memory (e.g. a torch tensor) for an RCCL reduce."""
+        self._scene = scene
+        p = self.params(scene, spp, seed, shard_index, shard_count, flags, stream)
+        st = A.phip_stats()
+        rc = _ffi.lib().phip_render_device(scene._h, C.byref(p), C.c_void_p(d_out_ptr), C.byref(st))
+        self.stats = st
+        if rc == A.PHIP_ERR_CANCELLED:
+            return False
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_render_device")
+        return True
+
+    def samples(self, scene, spp):
+        """Per-sample (R,G,B,alpha) of the last render made with PHIP_FLAG_SAMPLE_BUFFER: [y][x][sample]."""
+        out = np.zeros((scene.height, scene.width, spp, 4), np.float32)
+        rc = _ffi.lib().phip_get_samples(scene._h, _ffi.fptr(out), scene.height * scene.width * spp)
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_get_samples")
+        return out
+
+    def cancel(self):
+        if self._scene is not None:
+            _ffi.lib().phip_cancel(self._scene._h)

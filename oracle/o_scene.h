@@ -47,7 +47,9 @@ struct DiscreteDistribution {
     size_t sample(Float sampleValue) const {
         std::vector<Float>::const_iterator entry = std::lower_bound(cdf.begin(), cdf.end(), sampleValue);
         size_t index = std::min(cdf.size() - 2, (size_t) std::max((ptrdiff_t) 0, entry - cdf.begin() - 1));
-        while (operator[](index) == 0 && index < cdf.size() - 1)
+        /* pmf.h:131-134 evaluates `operator[](index) == 0 && index < size-1`, which reads one entry
+           past the end when a zero-probability tail is reached; the bounds check comes first here */
+        while (index < cdf.size() - 2 && operator[](index) == 0)
             ++index;
         return index;
     }
