@@ -153,22 +153,24 @@ typedef struct phip_render_params {
 #define PHIP_FLAG_SAMPLE_BUFFER 2   /* keep per-sample radiance for phip_get_samples (tests)    */
 
 typedef struct phip_stats {
-    uint64_t samples;            /* camera samples rendered by this call                  */
-    uint64_t closest_rays;       /* "Normal rays traced" (skdtree.cpp:46)                 */
-    uint64_t shadow_rays;        /* "Shadow rays traced" (skdtree.cpp:47)                 */
-    uint64_t path_vertices;      /* sum of path depths, "Average path length" (path.cpp:24)*/
-    uint64_t bvh_node_visits;    /* inner nodes fetched (closest + shadow)                */
-    uint64_t triangle_tests;     /* TriAccel tests (closest + shadow)                     */
-    uint64_t invalid_samples;    /* rejected by the ImageBlock::put validity check        */
-    uint32_t iterations;         /* wavefront iterations                                  */
+    uint64_t samples;                /* camera samples rendered by this call                  */
+    uint64_t closest_rays;           /* "Normal rays traced" (skdtree.cpp:46)                 */
+    uint64_t shadow_rays;            /* "Shadow rays traced" (skdtree.cpp:47)                 */
+    uint64_t path_vertices;          /* sum of path depths, "Average path length" (path.cpp:24)*/
+    uint64_t closest_node_visits;    /* accel nodes fetched by closest-hit queries            */
+    uint64_t closest_triangle_tests; /* TriAccel tests by closest-hit queries                 */
+    uint64_t shadow_node_visits;     /* same for any-hit (shadow) queries                     */
+    uint64_t shadow_triangle_tests;
+    uint64_t invalid_samples;        /* rejected by the ImageBlock::put validity check        */
+    uint32_t iterations;             /* wavefront iterations = launches of each kernel        */
     uint32_t reserved;
-    double   render_ms;          /* host wall clock of the call                           */
-    double   trace_kernel_ms;    /* sum of HIP-event durations of the trace kernel        */
+    double   render_ms;              /* host wall clock of the call                           */
+    double   trace_kernel_ms;        /* sum of HIP-event durations of the closest-hit kernel  */
+    double   shadow_kernel_ms;       /* ... of the any-hit kernel                             */
     double   shade_kernel_ms;
     double   film_kernel_ms;
-    uint32_t trace_kernel_launches;
-    uint32_t reserved2;
-    double   algorithmic_bytes;  /* SURVEY 8(d) bytes for this call, from the counters    */
+    double   algorithmic_bytes;      /* SURVEY 8(d) bytes of the whole call, from the counters */
+    double   trace_kernel_bytes;     /* the closest-hit kernel's share: node + triangle + ray + hit bytes */
 } phip_stats;
 
 typedef struct phip_ray  { float o[3]; float mint; float d[3]; float maxt; } phip_ray;

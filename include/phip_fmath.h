@@ -202,7 +202,7 @@ PM_FN float pm_tanf(float xx) {
     if (j & 1) { j += 1; y += 1.0f; }
     float z = ((x - y * DP1) - y * DP2) - y * DP3;
     float zz = z * z;
-    if (zz > 1.0e-4f) {
+    if (zz > 1.0e-8f) {
         y = (((((9.38540185543e-3f * zz + 3.11992232697e-3f) * zz + 2.44301354525e-2f) * zz
                + 5.34112807005e-2f) * zz + 1.33387994085e-1f) * zz + 3.33331568548e-1f) * zz * z + z;
     } else {

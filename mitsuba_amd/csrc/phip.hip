@@ -61,7 +61,7 @@ static int setErr(int code, const std::string &msg) { g_err = msg; return code; 
 #define STACK_DEPTH 40          /* BVH2 depth for 1M triangles stays well below this */
 
 enum : uint32_t {
-    F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20,
+    F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22,
     DEPTH_MASK = 0xFFFFu
 };
 
@@ -72,15 +72,20 @@ struct PathPool {
     float4 *thr;      /* throughput rgb, eta */
     float4 *refN;     /* refN xyz, bsdfPdf */
     uint4 *info;      /* sampleId, pixel, sampleIndex, depth|flags */
-    float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0) */
-    uint32_t capacity;
+    float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0);
+                         block b's entries are compacted at [b*BLOCK, b*BLOCK + shadowCount[b]) */
+    uint32_t *shadowCount;            /* per block of BLOCK slots */
+    unsigned long long *stat;         /* ST_COUNT arrays of nWaves entries */
+    uint32_t capacity, nWaves;
 };
 
+/* Work counters are kept per wave (one owner, plain read-modify-write, no atomics: a single
+ * contended word saturates at ~88 atomics/us on MI355X) in SoA arrays stat[k][waveId] and summed
+ * by k_reduce_stats when the host wants them. */
+enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI, ST_VERTICES, ST_SAMPLES, ST_ALIVE, ST_COUNT };
+
 struct Counters {
-    unsigned long long nextId;        /* next sample id to hand out */
-    unsigned long long closestRays, shadowRays, pathVertices, nodeVisits, triTests, samplesDone;
-    uint32_t shadowCount;             /* entries in the shadow queue (reset every iteration) */
-    uint32_t aliveCount;              /* live slots after the last shade (reset every iteration) */
+    unsigned long long total[ST_COUNT];   /* written by k_reduce_stats */
 };
 
 struct RenderConst {
@@ -91,6 +96,7 @@ struct RenderConst {
     int maxDepth, rrDepth, strictNormals, hideEmitters;
     uint32_t seed;
     const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
+    uint32_t countAlive;              /* this iteration records the number of live slots */
 };
 
 /* ======================================================================================
@@ -128,35 +134,14 @@ __device__ __forceinline__ bool decodeId(const RenderConst &rc, const DevFilm &f
     return px < (uint32_t) film.width && py < (uint32_t) film.height;
 }
 
-/* wave-aggregated append: returns the slot for this lane (valid when `pred`) */
-__device__ __forceinline__ uint32_t waveAppend(uint32_t *counter, bool pred) {
-    const unsigned long long mask = __ballot(pred);
-    const uint32_t lane = __lane_id();
-    uint32_t base = 0;
-    const int leader = __ffsll((long long) mask) - 1;
-    if (pred && (int) lane == leader)
-        base = atomicAdd(counter, (uint32_t) __popcll(mask));
-    base = __shfl(base, leader < 0 ? 0 : leader);
-    return base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
-}
-
-__device__ __forceinline__ unsigned long long waveFetchIds(unsigned long long *counter, bool pred) {
-    const unsigned long long mask = __ballot(pred);
-    const uint32_t lane = __lane_id();
-    unsigned long long base = 0;
-    const int leader = __ffsll((long long) mask) - 1;
-    if (pred && (int) lane == leader)
-        base = atomicAdd(counter, (unsigned long long) __popcll(mask));
-    base = __shfl(base, leader < 0 ? 0 : leader);   /* 64-bit shuffle */
-    return base + (unsigned long long) __popcll(mask & ((1ull << lane) - 1ull));
-}
-
-__device__ __forceinline__ void waveAdd(unsigned long long *counter, unsigned long long v) {
-    /* wave reduction, one atomic per wave */
+/* per-wave statistics slot: wave-reduce v, lane 0 accumulates into stat[k][waveId] (unique owner) */
+__device__ __forceinline__ void waveStat(const PathPool &P, int k, uint32_t waveId, unsigned long long v, bool overwrite = false) {
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_down(v, off);
-    if (__lane_id() == 0 && v)
-        atomicAdd(counter, v);
+    if (__lane_id() == 0) {
+        unsigned long long *p = P.stat + (size_t) k * P.nWaves + waveId;
+        if (overwrite) *p = v; else if (v) *p += v;
+    }
 }
 
 /* ======================================================================================
@@ -259,7 +244,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
 /* ======================================================================================
  *  kernels
  * ====================================================================================== */
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, PathPool P, Counters *C) {
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, PathPool P) {
     __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
@@ -276,18 +261,19 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, PathPool P, Counter
             P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
         }
     }
-    waveAdd(&C->closestRays, rays);
-    waveAdd(&C->nodeVisits, nodeVisits);
-    waveAdd(&C->triTests, triTests);
+    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    waveStat(P, ST_CLOSEST_RAYS, waveId, rays);
+    waveStat(P, ST_NODE, waveId, nodeVisits);
+    waveStat(P, ST_TRI, waveId, triTests);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene S, PathPool P, Counters *C, float4 *L) {
+__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene S, PathPool P, float4 *L) {
     __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
-    const uint32_t idx = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t n = C->shadowCount;
+    const uint32_t n = P.shadowCount[blockIdx.x];            /* entries of this block's slots */
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    if (idx < n) {
-        const float4 e0 = P.shadow[3 * (size_t) idx], e1 = P.shadow[3 * (size_t) idx + 1], e2 = P.shadow[3 * (size_t) idx + 2];
+    if (threadIdx.x < n) {
+        const size_t idx = (size_t) blockIdx.x * BLOCK + threadIdx.x;
+        const float4 e0 = P.shadow[3 * idx], e1 = P.shadow[3 * idx + 1], e2 = P.shadow[3 * idx + 2];
         const V3 o(e0.x, e0.y, e0.z), d(e1.x, e1.y, e1.z);
         float mint, maxt;
         bool occluded = false;
@@ -302,9 +288,12 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene S, PathPool P, Counte
             L[id] = l;
         }
     }
-    waveAdd(&C->shadowRays, rays);
-    waveAdd(&C->nodeVisits, nodeVisits);
-    waveAdd(&C->triTests, triTests);
+    if ((threadIdx.x & ~63u) < n) {                          /* waves without entries have nothing to add */
+        const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+        waveStat(P, ST_SHADOW_RAYS, waveId, rays);
+        waveStat(P, ST_SH_NODE, waveId, nodeVisits);
+        waveStat(P, ST_SH_TRI, waveId, triTests);
+    }
 }
 
 __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
@@ -312,13 +301,16 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
     return pdfA / (pdfA + pdfB);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene S, PathPool P, Counters *C, RenderConst rc, float4 *L) {
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+    __shared__ uint32_t waveCnt[BLOCK / 64];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
     uint4 info = inRange ? P.info[slot] : make_uint4(0, 0, 0, 0);
     bool alive = inRange && (info.w & F_ALIVE);
-    bool needNew = inRange && !alive;
+    bool needNew = inRange && !alive && !(info.w & F_DEAD);
     unsigned long long vertices = 0, done = 0;
+    bool pushShadow = false;
+    float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0;
 
     if (alive) {
         const float4 hit = P.hit[slot];
@@ -387,7 +379,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene S, PathPool P, Counter
                     || (rc.strictNormals && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
                     terminate = true;
             }
-            bool pushShadow = false;
             V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
             if (!terminate) {
                 const U4 h = pcg4d(info.y, info.z, 1 + 2 * (depth - 1), rc.seed);
@@ -433,12 +424,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene S, PathPool P, Counter
                 }
             }
             if (haveAdd) L[id] = l;
-            /* shadow queue entry (self-contained: survives the slot being recycled) */
-            const uint32_t sidx = waveAppend(&C->shadowCount, pushShadow);
-            if (pushShadow) {
-                P.shadow[3 * (size_t) sidx] = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
-                P.shadow[3 * (size_t) sidx + 1] = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
-                P.shadow[3 * (size_t) sidx + 2] = make_float4(shC.x, shC.y, shC.z, 0.0f);
+            if (pushShadow) {   /* self-contained shadow-queue entry: survives the slot being recycled */
+                sh0 = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
+                sh1 = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
+                sh2 = make_float4(shC.x, shC.y, shC.z, 0.0f);
             }
         }
         if (terminate) {
@@ -450,39 +439,69 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene S, PathPool P, Counter
         }
     }
 
-    /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183) ---- */
+    /* ---- shadow queue: compact this block's entries to the front of its own region (no global atomics) ---- */
+    {
+        const unsigned long long m = __ballot(pushShadow);
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) base += c; total += c; }
+        if (pushShadow) {
+            const size_t sidx = (size_t) blockIdx.x * BLOCK + base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+            P.shadow[3 * sidx] = sh0; P.shadow[3 * sidx + 1] = sh1; P.shadow[3 * sidx + 2] = sh2;
+        }
+        if (threadIdx.x == 0) P.shadowCount[blockIdx.x] = total;
+    }
+
+    /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183).
+       Static schedule: slot s renders sample ids s, s + capacity, s + 2*capacity, ... -- no global counter. ---- */
     bool nowAlive = alive && !needNew;
-    for (;;) {
-        const bool want = needNew;
-        if (!__any(want)) break;
-        unsigned long long id = waveFetchIds(&C->nextId, want);
-        if (want) {
+    if (needNew) {
+        unsigned long long id = (info.w & F_FRESH) ? (unsigned long long) slot      /* first sample of this slot */
+                                                   : (unsigned long long) info.x + P.capacity;
+        for (;;) {
             if (id >= rc.totalIds) {
-                info.w = 0; P.info[slot] = info; needNew = false;     /* out of samples: slot dies */
-            } else {
-                uint32_t px, py, k;
-                if (decodeId(rc, S.film, id, px, py, k)) {
-                    const uint32_t pixel = py * (uint32_t) S.film.width + px;
-                    const U4 h = pcg4d(pixel, k, 0, rc.seed);
-                    const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
-                    V3 o, d; float mint, maxt;
-                    cameraRay(S.cam, sx, sy, o, d, mint, maxt);
-                    P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
-                    P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
-                    P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                    P.refN[slot] = make_float4(0, 0, 0, 0);
-                    info = make_uint4((uint32_t) id, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST);
-                    P.info[slot] = info;
-                    needNew = false; nowAlive = true;
-                }
-                /* ids that fall outside the crop window (edge tiles) are skipped: fetch again */
+                info = make_uint4(0, 0, 0, F_DEAD); P.info[slot] = info; break;       /* out of samples: slot dies */
             }
+            uint32_t px, py, k;
+            if (decodeId(rc, S.film, id, px, py, k)) {
+                const uint32_t pixel = py * (uint32_t) S.film.width + px;
+                const U4 h = pcg4d(pixel, k, 0, rc.seed);
+                const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+                V3 o, d; float mint, maxt;
+                cameraRay(S.cam, sx, sy, o, d, mint, maxt);
+                P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
+                P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
+                P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                P.refN[slot] = make_float4(0, 0, 0, 0);
+                info = make_uint4((uint32_t) id, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST);
+                P.info[slot] = info;
+                nowAlive = true;
+                break;
+            }
+            id += P.capacity;       /* ids outside the crop window (edge blocks) are skipped */
         }
     }
-    const unsigned long long am = __ballot(nowAlive);
-    if (__lane_id() == 0 && am) atomicAdd(&C->aliveCount, (uint32_t) __popcll(am));
-    waveAdd(&C->pathVertices, vertices);
-    waveAdd(&C->samplesDone, done);
+    const uint32_t waveId = slot >> 6;
+    if (inRange || (slot & ~63u) < P.capacity) {
+        waveStat(P, ST_VERTICES, waveId, vertices);
+        waveStat(P, ST_SAMPLES, waveId, done);
+        if (rc.countAlive) waveStat(P, ST_ALIVE, waveId, nowAlive ? 1ull : 0ull, true);
+    }
+}
+
+/* sums the per-wave statistics: one block per counter */
+__global__ void k_reduce_stats(PathPool P, Counters *C) {
+    __shared__ unsigned long long red[256];
+    const unsigned long long *src = P.stat + (size_t) blockIdx.x * P.nWaves;
+    unsigned long long v = 0;
+    for (uint32_t i = threadIdx.x; i < P.nWaves; i += 256) v += src[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int) threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) C->total[blockIdx.x] = red[0];
 }
 
 /* Film: one lane per crop pixel gathers every sample whose filter footprint covers it.  Restates
@@ -560,10 +579,10 @@ __global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, co
 }
 
 /* standalone ray casts for phip_trace */
-__global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, Counters *C) {
+__global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
     __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t nodeVisits = 0, triTests = 0;
+    uint32_t nodeVisits = 0, triTests = 0, shNodeVisits = 0, shTriTests = 0;
     if (i < n) {
         const phip_ray ry = rays[i];
         const V3 o(ry.o[0], ry.o[1], ry.o[2]), d(ry.d[0], ry.d[1], ry.d[2]);
@@ -578,12 +597,15 @@ __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *r
         if (occluded) {
             TravResult r; bool occ = false;
             if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                occ = traverse<true>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+                occ = traverse<true>(S, o, d, mint, maxt, lds + threadIdx.x, r, shNodeVisits, shTriTests);
             occluded[i] = occ ? 1 : 0;
         }
     }
-    waveAdd(&C->nodeVisits, nodeVisits);
-    waveAdd(&C->triTests, triTests);
+    const uint32_t waveId = (uint32_t) (i >> 6);
+    waveStat(P, ST_NODE, waveId, nodeVisits);
+    waveStat(P, ST_TRI, waveId, triTests);
+    waveStat(P, ST_SH_NODE, waveId, shNodeVisits);
+    waveStat(P, ST_SH_TRI, waveId, shTriTests);
 }
 
 /* ======================================================================================
@@ -690,7 +712,8 @@ struct phip_scene {
     DevBuf<float4> rayO, rayD, hit, thr, refN, shadow, L, sampleOut;
     DevBuf<uint4> info;
     DevBuf<Counters> counters;
-    DevBuf<uint32_t> tileOrigin; DevBuf<int32_t> tileSlot;
+    DevBuf<uint32_t> tileOrigin, shadowCount; DevBuf<int32_t> tileSlot;
+    DevBuf<unsigned long long> stat;
     DevBuf<float> film; DevBuf<unsigned long long> invalid;
     uint32_t lastSpp = 0;
     bool haveSamples = false;
@@ -856,12 +879,18 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     sc->invalid.alloc(1);
 }
 
-static double algorithmicBytes(const phip_scene *sc, const phip_stats &st) {
-    /* SURVEY 8(d) with this structure's sizes: 64-byte BVH node visits, 48-byte triangle records */
+static void algorithmicBytes(const phip_scene *sc, phip_stats &st) {
+    /* SURVEY 8(d) with this structure's sizes: 64-byte BVH node visits, 48-byte triangle records
+       (no separate index array: records are stored in leaf order) */
     const double film = 20.0 * (double) sc->dev.film.width * sc->dev.film.height;
-    return 64.0 * (double) st.bvh_node_visits + 48.0 * (double) st.triangle_tests +
+    st.algorithmic_bytes = 64.0 * (double) (st.closest_node_visits + st.shadow_node_visits) +
+           48.0 * (double) (st.closest_triangle_tests + st.shadow_triangle_tests) +
            (64.0 + 40.0 + 108.0) * (double) st.closest_rays + (64.0 + 4.0) * (double) st.shadow_rays +
            104.0 * (double) st.path_vertices + film;
+    /* closest-hit kernel: node + triangle fetches, ray read (32 B), hit record write (16 B) ... counted with
+       the SURVEY's read+write convention: ray 64 B, hit 40 B */
+    st.trace_kernel_bytes = 64.0 * (double) st.closest_node_visits + 48.0 * (double) st.closest_triangle_tests +
+           (64.0 + 40.0) * (double) st.closest_rays;
 }
 
 static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /* device */, phip_stats *stats) {
@@ -925,18 +954,20 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     uint32_t capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), 1u << 21);
     capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
     if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
+    const uint32_t nWaves = capacity / 64, nBlocks = capacity / BLOCK;
     if (sc->rayO.n < capacity) {
         sc->rayO.alloc(capacity); sc->rayD.alloc(capacity); sc->hit.alloc(capacity); sc->thr.alloc(capacity);
         sc->refN.alloc(capacity); sc->info.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
+        sc->shadowCount.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves);
     }
     PathPool P;
     P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.refN = sc->refN.p; P.info = sc->info.p;
-    P.shadow = sc->shadow.p; P.capacity = capacity;
+    P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.stat = sc->stat.p; P.capacity = capacity; P.nWaves = nWaves;
     if (sc->L.n < idsFirstPass) sc->L.alloc((size_t) idsFirstPass);
 
     phip_stats st; memset(&st, 0, sizeof(st));
     const bool timing = (p->flags & PHIP_FLAG_KERNEL_TIMING) != 0;
-    std::vector<hipEvent_t> evTrace, evShade, evFilm;
+    std::vector<hipEvent_t> evTrace, evShadow, evShade, evFilm;
     auto newEvent = [&](std::vector<hipEvent_t> &v) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); v.push_back(e); return e; };
 
     HIP_TRY(hipMemsetAsync(sc->invalid.p, 0, sizeof(unsigned long long), stream));
@@ -950,29 +981,34 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         rc.tilePixels = (uint32_t) tilePixels; rc.tileShift = (uint32_t) tileShift; rc.nLocalTiles = nLocalTiles;
         rc.totalIds = idsPerSpp * rc.sppPass;
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
-        rc.seed = p->seed; rc.tileOrigin = sc->tileOrigin.p;
+        rc.seed = p->seed; rc.tileOrigin = sc->tileOrigin.p; rc.countAlive = 0;
 
         HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
-        HIP_TRY(hipMemsetAsync(sc->info.p, 0, (size_t) capacity * sizeof(uint4), stream));
+        HIP_TRY(hipMemsetAsync(sc->stat.p, 0, (size_t) ST_COUNT * nWaves * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(sc->shadowCount.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) sc->info.p, (int) F_FRESH, (size_t) capacity * 4, stream));
         if (rc.totalIds) HIP_TRY(hipMemsetAsync(sc->L.p, 0, (size_t) rc.totalIds * sizeof(float4), stream));
 
         uint32_t iter = 0;
         bool done = rc.totalIds == 0;
         while (!done) {
-            /* reset the per-iteration queue counters (shadowCount, aliveCount are adjacent) */
-            HIP_TRY(hipMemsetAsync(&sc->counters.p->shadowCount, 0, 2 * sizeof(uint32_t), stream));
+            const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
+            rc.countAlive = check ? 1 : 0;
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
-            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, D, P, sc->counters.p, rc, sc->L.p);
+            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, D, P, rc, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
+            if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
+            hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, D, P, sc->L.p);
+            if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-            hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, D, P, sc->counters.p, sc->L.p);
-            hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P, sc->counters.p);
+            hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
             ++iter;
-            if ((iter & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4) {
+            if (check) {
+                hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT), dim3(256), 0, stream, P, sc->counters.p);
                 HIP_TRY(hipMemcpyAsync(&hc, sc->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
-                if (hc.aliveCount == 0 && hc.nextId >= rc.totalIds) done = true;
+                if (hc.total[ST_ALIVE] == 0) done = true;
                 if (sc->cancel.load()) { cancelled = true; done = true; }
             }
         }
@@ -991,21 +1027,23 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             hipLaunchKernelGGL(k_export_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, D, rc, (const float4 *) sc->L.p,
                                (const int32_t *) sc->tileSlot.p, tilesX, sc->sampleOut.p, (uint32_t) p->spp);
         }
+        hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT), dim3(256), 0, stream, P, sc->counters.p);
         HIP_TRY(hipMemcpyAsync(&hc, sc->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
-        st.samples += hc.samplesDone; st.closest_rays += hc.closestRays; st.shadow_rays += hc.shadowRays;
-        st.path_vertices += hc.pathVertices; st.bvh_node_visits += hc.nodeVisits; st.triangle_tests += hc.triTests;
+        st.samples += hc.total[ST_SAMPLES]; st.closest_rays += hc.total[ST_CLOSEST_RAYS]; st.shadow_rays += hc.total[ST_SHADOW_RAYS];
+        st.path_vertices += hc.total[ST_VERTICES]; st.closest_node_visits += hc.total[ST_NODE]; st.closest_triangle_tests += hc.total[ST_TRI];
+        st.shadow_node_visits += hc.total[ST_SH_NODE]; st.shadow_triangle_tests += hc.total[ST_SH_TRI];
     }
     if (nLocalTiles == 0) { HIP_TRY(hipMemsetAsync(dOut, 0, (size_t) W * H * 5 * sizeof(float), stream)); HIP_TRY(hipStreamSynchronize(stream)); }
     unsigned long long inv = 0;
     HIP_TRY(hipMemcpy(&inv, sc->invalid.p, sizeof(inv), hipMemcpyDeviceToHost));
     st.invalid_samples = inv;
     auto sumPairs = [&](std::vector<hipEvent_t> &v) { double ms = 0; for (size_t i = 0; i + 1 < v.size(); i += 2) { float t = 0; (void) hipEventElapsedTime(&t, v[i], v[i + 1]); ms += t; } for (auto e : v) (void) hipEventDestroy(e); return ms; };
-    st.trace_kernel_launches = (uint32_t) (evTrace.size() / 2);
-    st.trace_kernel_ms = sumPairs(evTrace); st.shade_kernel_ms = sumPairs(evShade); st.film_kernel_ms = sumPairs(evFilm);
+    st.trace_kernel_ms = sumPairs(evTrace); st.shadow_kernel_ms = sumPairs(evShadow);
+    st.shade_kernel_ms = sumPairs(evShade); st.film_kernel_ms = sumPairs(evFilm);
     st.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
-    st.algorithmic_bytes = algorithmicBytes(sc, st);
+    algorithmicBytes(sc, st);
     if (stats) *stats = st;
     if (cancelled) return setErr(PHIP_ERR_CANCELLED, "rendering was cancelled");
     return PHIP_OK;
@@ -1101,11 +1139,17 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             dr.upload(rays, n);
             if (hits) dh.alloc(n);
             if (occluded) dz.alloc(n);
-            HIP_TRY(hipMemset(scene->counters.p, 0, sizeof(Counters)));
+            DevBuf<unsigned long long> stat;
+            PathPool P; memset(&P, 0, sizeof(P));
+            P.nWaves = (uint32_t) ((n + 63) / 64 + BLOCK / 64);
+            stat.alloc((size_t) ST_COUNT * P.nWaves);
+            HIP_TRY(hipMemset(stat.p, 0, stat.n * sizeof(unsigned long long)));
+            P.stat = stat.p;
             hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
             HIP_TRY(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, scene->dev, (const phip_ray *) dr.p, n, dh.p, dz.p, scene->counters.p);
+            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, scene->dev, (const phip_ray *) dr.p, n, dh.p, dz.p, P);
             HIP_TRY(hipEventRecord(e1, 0));
+            hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT), dim3(256), 0, 0, P, scene->counters.p);
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipGetLastError());
             float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
@@ -1115,8 +1159,10 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
                 Counters hc; HIP_TRY(hipMemcpy(&hc, scene->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
                 memset(out_stats, 0, sizeof(*out_stats));
                 out_stats->closest_rays = hits ? n : 0; out_stats->shadow_rays = occluded ? n : 0;
-                out_stats->bvh_node_visits = hc.nodeVisits; out_stats->triangle_tests = hc.triTests;
-                out_stats->trace_kernel_ms = ms; out_stats->trace_kernel_launches = 1;
+                out_stats->closest_node_visits = hc.total[ST_NODE]; out_stats->closest_triangle_tests = hc.total[ST_TRI];
+                out_stats->shadow_node_visits = hc.total[ST_SH_NODE]; out_stats->shadow_triangle_tests = hc.total[ST_SH_TRI];
+                out_stats->trace_kernel_ms = ms; out_stats->iterations = 1;
+                algorithmicBytes(scene, *out_stats);
             }
         }
         return PHIP_OK;

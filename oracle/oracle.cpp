@@ -61,15 +61,18 @@ int oracle_render(void *scene_, const phip_render_params *p, int threads, int sa
             stats->closest_rays = rr.counters.closestRays;
             stats->shadow_rays = rr.counters.shadowRays;
             stats->path_vertices = rr.counters.pathVertices;
-            stats->bvh_node_visits = rr.counters.closest.nodeVisits + rr.counters.shadow.nodeVisits;
-            stats->triangle_tests = rr.counters.closest.triTests + rr.counters.shadow.triTests;
+            stats->closest_node_visits = rr.counters.closest.nodeVisits; stats->shadow_node_visits = rr.counters.shadow.nodeVisits;
+            stats->closest_triangle_tests = rr.counters.closest.triTests; stats->shadow_triangle_tests = rr.counters.shadow.triTests;
             stats->invalid_samples = rr.counters.invalidSamples;
             stats->render_ms = rr.seconds * 1e3;
             /* 8 B kd node, 4 B index + 48 B TriAccel, ray/hit/state/film terms */
             stats->algorithmic_bytes =
-                8.0 * (double) stats->bvh_node_visits + 52.0 * (double) stats->triangle_tests +
+                8.0 * (double) (stats->closest_node_visits + stats->shadow_node_visits) +
+                52.0 * (double) (stats->closest_triangle_tests + stats->shadow_triangle_tests) +
                 (64.0 + 40.0 + 108.0) * (double) stats->closest_rays + (64.0 + 4.0) * (double) stats->shadow_rays +
                 104.0 * (double) stats->path_vertices + 20.0 * (double) scene.film.crop_width * scene.film.crop_height;
+            stats->trace_kernel_bytes = 8.0 * (double) stats->closest_node_visits + 52.0 * (double) stats->closest_triangle_tests +
+                (64.0 + 40.0) * (double) stats->closest_rays;
         }
         return 0;
     } catch (const std::exception &e) {
@@ -93,7 +96,8 @@ int oracle_trace(void *scene_, const phip_ray *rays, size_t n, phip_hit *hits, u
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->closest_rays = hits ? n : 0; stats->shadow_rays = occluded ? n : 0;
-        stats->bvh_node_visits = c.nodeVisits + cs.nodeVisits; stats->triangle_tests = c.triTests + cs.triTests;
+        stats->closest_node_visits = c.nodeVisits; stats->shadow_node_visits = cs.nodeVisits;
+        stats->closest_triangle_tests = c.triTests; stats->shadow_triangle_tests = cs.triTests;
     }
     return 0;
 }

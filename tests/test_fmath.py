@@ -1,0 +1,96 @@
+"""include/phip_fmath.h: accuracy against libm (numpy, float64 reference) and bitwise agreement of
+the three compilations (oracle g++, product clang host, product gfx950 device)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+OPS = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "acos": 4, "atan2": 5, "tan": 6, "pow": 7, "erf": 8, "erfinv": 9, "atan": 10}
+
+
+def ulp_err(got, ref64):
+    ref32 = ref64.astype(np.float32)
+    spacing = np.spacing(np.abs(ref32)).astype(np.float64)
+    spacing = np.maximum(spacing, np.finfo(np.float32).tiny)
+    return np.abs(got.astype(np.float64) - ref64) / spacing
+
+
+def run(lib_fn, op, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b if b is not None else a, np.float32)
+    out = np.zeros_like(a)
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    lib_fn(op, len(a), fp(a), fp(b), fp(out))
+    return out
+
+
+def inputs():
+    rng = np.random.default_rng(7)
+    n = 200000
+    return {
+        "sin": (rng.uniform(-7, 7, n), None), "cos": (rng.uniform(-7, 7, n), None),
+        "exp": (rng.uniform(-80, 20, n), None), "log": (np.exp(rng.uniform(-40, 40, n)), None),
+        "acos": (rng.uniform(-1, 1, n), None), "atan2": (rng.normal(size=n), rng.normal(size=n)),
+        "tan": (rng.uniform(-1.55, 1.55, n), None), "atan": (rng.normal(size=n) * 10, None),
+        "pow": (rng.uniform(1e-6, 1, n), rng.uniform(0.2, 1.2, n)),
+    }
+
+
+REF = {"sin": np.sin, "cos": np.cos, "exp": np.exp, "log": np.log, "acos": np.arccos, "tan": np.tan, "atan": np.arctan}
+
+
+@pytest.mark.parametrize("name", ["sin", "cos", "exp", "log", "acos", "atan2", "tan", "atan", "pow"])
+def test_accuracy_vs_libm(oracle, name):
+    a, b = inputs()[name]
+    a32 = a.astype(np.float32); b32 = None if b is None else b.astype(np.float32)
+    got = run(oracle.lib().oracle_fmath, OPS[name], a32, b32)
+    if name == "atan2":
+        ref = np.arctan2(a32.astype(np.float64), b32.astype(np.float64))
+    elif name == "pow":
+        ref = np.power(a32.astype(np.float64), b32.astype(np.float64))
+    else:
+        ref = REF[name](a32.astype(np.float64))
+    err = ulp_err(got, ref)
+    if name in ("sin", "cos"):
+        # relative accuracy degrades near the zeros of sin/cos; bound the absolute error there
+        absok = np.abs(got.astype(np.float64) - ref) < 2.5e-7
+        assert (absok | (err <= 4)).all(), float(err[~absok].max())
+    elif name == "pow":
+        assert err.max() <= 64, err.max()      # exp(y*log(x)) -- only used as a Newton start value
+    else:
+        assert err.max() <= 4, (name, float(err.max()))
+
+
+@pytest.mark.parametrize("name", list(OPS))
+def test_oracle_and_product_host_builds_agree_bitwise(oracle, phip, name):
+    rng = np.random.default_rng(3)
+    n = 100000
+    if name in ("erfinv", "acos"):
+        a = rng.uniform(-1, 1, n)
+    elif name in ("log", "pow"):
+        a = rng.uniform(1e-6, 3, n)
+    else:
+        a = rng.uniform(-6, 6, n)
+    b = rng.uniform(0.1, 2, n)
+    o = run(oracle.lib().oracle_fmath, OPS[name], a, b)
+    host = run(lambda op, n_, x, y, z: phip.phip_debug_fmath(0, op, n_, x, y, z), OPS[name], a, b)
+    assert (o.view(np.uint32) == host.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(OPS))
+def test_device_and_host_agree_bitwise(phip, name):
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    if name in ("erfinv", "acos"):
+        a = rng.uniform(-1, 1, n)
+    elif name in ("log", "pow"):
+        a = rng.uniform(1e-6, 3, n)
+    elif name == "exp":
+        a = rng.uniform(-90, 30, n)
+    else:
+        a = rng.uniform(-6.5, 6.5, n)
+    b = rng.uniform(0.1, 2, n)
+    host = run(lambda op, n_, x, y, z: phip.phip_debug_fmath(0, op, n_, x, y, z), OPS[name], a, b)
+    dev = run(lambda op, n_, x, y, z: phip.phip_debug_fmath(1, op, n_, x, y, z), OPS[name], a, b)
+    assert (host.view(np.uint32) == dev.view(np.uint32)).all()
