@@ -234,3 +234,241 @@ def cornell_box(width, height, filter_table, light_scale=1.0, sb=None):
                    fov_x_deg=39.3077, near=10.0, far=2800.0)
     sb.hdrfilm(width, height, filter_table)
     return sb
+
+
+# ==========================================================================================
+#  procedural meshes
+# ==========================================================================================
+def _grid_mesh(P, nu, nv, closed_u=False):
+    """(nu x nv) vertex grid -> triangles; P has shape (nv, nu, 3)"""
+    P = _f32(P).reshape(nv, nu, 3)
+    idx = np.arange(nu * nv, dtype=np.uint32).reshape(nv, nu)
+    cols = nu if closed_u else nu - 1
+    i0 = idx[:-1, :cols]
+    i1 = np.roll(idx, -1, axis=1)[:-1, :cols]
+    i2 = np.roll(idx, -1, axis=1)[1:, :cols]
+    i3 = idx[1:, :cols]
+    tris = np.concatenate([np.stack([i0, i1, i2], -1).reshape(-1, 3), np.stack([i2, i3, i0], -1).reshape(-1, 3)])
+    return P.reshape(-1, 3), tris.astype(np.uint32)
+
+
+def _smooth_normals(P, T):
+    """area-weighted vertex normals (only used to give generated meshes a shading normal)"""
+    P64 = P.astype(np.float64)
+    fn = np.cross(P64[T[:, 1]] - P64[T[:, 0]], P64[T[:, 2]] - P64[T[:, 0]])
+    N = np.zeros_like(P64)
+    for k in range(3):
+        np.add.at(N, T[:, k], fn)
+    ln = np.linalg.norm(N, axis=1, keepdims=True)
+    N = np.where(ln > 0, N / np.maximum(ln, 1e-30), np.array([0.0, 1.0, 0.0]))
+    return N.astype(np.float32)
+
+
+def cylinder_mesh(center, radius, y0, y1, nseg, nring, flute=0.0, nflutes=12):
+    th = np.linspace(0, 2 * np.pi, nseg, endpoint=False)
+    ys = np.linspace(y0, y1, nring + 1)
+    r = radius * (1.0 - flute * (0.5 + 0.5 * np.cos(nflutes * th)))
+    P = np.zeros((nring + 1, nseg, 3))
+    P[..., 0] = center[0] + r[None, :] * np.cos(th)[None, :]
+    P[..., 2] = center[1] + r[None, :] * np.sin(th)[None, :]
+    P[..., 1] = ys[:, None]
+    return _grid_mesh(P, nseg, nring + 1, closed_u=True)
+
+
+def sphere_mesh(center, radius, nlon, nlat):
+    th = np.linspace(0, 2 * np.pi, nlon, endpoint=False)
+    ph = np.linspace(0, np.pi, nlat + 1)[1:-1]
+    P = np.zeros((nlat - 1, nlon, 3))
+    P[..., 0] = np.sin(ph)[:, None] * np.cos(th)[None, :]
+    P[..., 1] = np.cos(ph)[:, None]
+    P[..., 2] = np.sin(ph)[:, None] * np.sin(th)[None, :]
+    V, T = _grid_mesh(P, nlon, nlat - 1, closed_u=True)
+    n = len(V)
+    V = np.concatenate([V, [[0, 1, 0], [0, -1, 0]]]).astype(np.float32)
+    top = np.stack([np.full(nlon, n), (np.arange(nlon) + 1) % nlon, np.arange(nlon)], -1)
+    base = (nlat - 2) * nlon
+    bot = np.stack([np.full(nlon, n + 1), base + np.arange(nlon), base + (np.arange(nlon) + 1) % nlon], -1)
+    T = np.concatenate([T, top, bot]).astype(np.uint32)
+    N = V.copy()
+    return (V * radius + np.asarray(center, np.float32)).astype(np.float32), T, N.astype(np.float32)
+
+
+def box_mesh(lo, hi):
+    lo = np.asarray(lo, np.float32); hi = np.asarray(hi, np.float32)
+    c = np.array([[lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]],
+                  [lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]], np.float32)
+    q = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (0, 4, 7, 3)]   # outward facing
+    T = []
+    for a, b, cc, d in q:
+        T += [[a, b, cc], [cc, d, a]]
+    return c, np.array(T, np.uint32)
+
+
+CU_ETA = (0.200438, 0.924033, 1.102212)     # copper, linear RGB (what the host derives from data/ior/Cu.eta.spd)
+CU_K = (3.912949, 2.452848, 2.142188)
+
+
+# ==========================================================================================
+#  C3 / C5: "Sponza-class" procedural atrium, ~260k triangles
+# ==========================================================================================
+def atrium(width, height, filter_table, seed=1, detail=1.0, sb=None):
+    """Two-storey colonnaded atrium: tessellated fluted columns, arches, a bumpy tiled floor and
+    hanging cloth banners.  70 % of the objects are twosided diffuse (albedo ~ U[0.2,0.8]), 30 %
+    roughconductor (Cu, beckmann alpha in {0.05, 0.1, 0.3}); one large ceiling area light plus a
+    smaller 'skylight' quad.  detail scales the tessellation (1.0 -> ~260k triangles)."""
+    rng = np.random.default_rng(seed)
+    sb = sb or SceneBuilder()
+    LX, LY, LZ = 36.0, 14.0, 16.0        # room size (x: long axis)
+
+    def random_material():
+        if rng.random() < 0.3:
+            a = float(rng.choice([0.05, 0.1, 0.3]))
+            return sb.twosided(sb.roughconductor(CU_ETA, CU_K, alpha=a))
+        return sb.twosided(sb.diffuse(tuple(rng.uniform(0.2, 0.8, 3))))
+
+    wall = sb.twosided(sb.diffuse((0.62, 0.58, 0.5)))
+    # shell
+    sb.quad((0, 0, 0), (LX, 0, 0), (LX, 0, LZ), (0, 0, LZ), wall, facing=(0, 1, 0))      # ground slab (under the tiles)
+    sb.quad((0, LY, 0), (LX, LY, 0), (LX, LY, LZ), (0, LY, LZ), wall, facing=(0, -1, 0))
+    sb.quad((0, 0, 0), (0, LY, 0), (0, LY, LZ), (0, 0, LZ), wall, facing=(1, 0, 0))
+    sb.quad((LX, 0, 0), (LX, LY, 0), (LX, LY, LZ), (LX, 0, LZ), wall, facing=(-1, 0, 0))
+    sb.quad((0, 0, 0), (LX, 0, 0), (LX, LY, 0), (0, LY, 0), wall, facing=(0, 0, 1))
+    sb.quad((0, 0, LZ), (LX, 0, LZ), (LX, LY, LZ), (0, LY, LZ), wall, facing=(0, 0, -1))
+    # lights
+    sb.quad((8, LY - 0.05, 5.5), (28, LY - 0.05, 5.5), (28, LY - 0.05, 10.5), (8, LY - 0.05, 10.5), sb.diffuse((0.5, 0.5, 0.5)),
+            facing=(0, -1, 0), radiance=(18.0, 16.5, 14.0))
+    sb.quad((0.05, 8.0, 6.0), (0.05, 12.0, 6.0), (0.05, 12.0, 10.0), (0.05, 8.0, 10.0), sb.diffuse((0.5, 0.5, 0.5)),
+            facing=(1, 0, 0), radiance=(6.0, 8.0, 12.0))
+
+    # bumpy tiled floor: one mesh per 4x4 m tile
+    n = max(2, int(round(24 * detail)))
+    for ix in range(9):
+        for iz in range(4):
+            xs = np.linspace(ix * 4.0, ix * 4.0 + 3.9, n)
+            zs = np.linspace(iz * 4.0, iz * 4.0 + 3.9, n)
+            X, Z = np.meshgrid(xs, zs)
+            Y = 0.02 + 0.015 * np.sin(3.1 * X + ix) * np.cos(2.7 * Z + iz) + 0.004 * rng.standard_normal(X.shape)
+            P, T = _grid_mesh(np.stack([X, Y, Z], -1), n, n)
+            T = T[:, [0, 2, 1]]            # face up
+            sb.mesh(P, T, random_material(), normals=_smooth_normals(P, T))
+
+    # two rows of fluted columns on two storeys + arches between them
+    nseg = max(8, int(round(48 * detail))); nring = max(2, int(round(20 * detail)))
+    xs_cols = np.linspace(3.0, LX - 3.0, 9)
+    for storey, (y0, y1, rad) in enumerate([(0.0, 6.0, 0.45), (6.6, 11.5, 0.35)]):
+        for zc in (3.5, LZ - 3.5):
+            for xc in xs_cols:
+                P, T = cylinder_mesh((xc, zc), rad, y0, y1, nseg, nring, flute=0.12, nflutes=12)
+                sb.mesh(P, T, random_material(), normals=_smooth_normals(P, T))
+            # arches: half tori between neighbouring columns
+            na = max(6, int(round(28 * detail))); nt = max(6, int(round(14 * detail)))
+            for xa, xb in zip(xs_cols[:-1], xs_cols[1:]):
+                R = 0.5 * (xb - xa); cx = 0.5 * (xa + xb)
+                u = np.linspace(0, np.pi, na + 1); v = np.linspace(0, 2 * np.pi, nt, endpoint=False)
+                U, V = np.meshgrid(u, v, indexing="ij")
+                r = 0.22
+                X = cx + (R + r * np.cos(V)) * np.cos(U)
+                Yc = y1 - R * 0.0 + (R + r * np.cos(V)) * np.sin(U) * 0.55
+                Zc = zc + r * np.sin(V)
+                P, T = _grid_mesh(np.stack([X, Yc, Zc], -1), nt, na + 1, closed_u=True)
+                sb.mesh(P, T, random_material(), normals=_smooth_normals(P, T))
+        # balcony slab of the storey
+        for zlo, zhi in ((0.0, 4.2), (LZ - 4.2, LZ)):
+            P, T = box_mesh((0.0, y1, zlo), (LX, y1 + 0.5, zhi))
+            sb.mesh(P, T, wall)
+
+    # hanging cloth banners (sinusoidal sheets)
+    nc = max(8, int(round(96 * detail)))
+    for i, xc in enumerate(np.linspace(6.0, LX - 6.0, 6)):
+        u = np.linspace(-1.4, 1.4, nc); v = np.linspace(0.0, 5.5, nc)
+        U, V = np.meshgrid(u, v)
+        X = xc + 0.25 * np.sin(2.2 * V + i) * (V / 5.5)
+        Y = 12.5 - V
+        Z = LZ / 2 + U + 0.12 * np.sin(4.0 * U + 1.7 * V + i)
+        P, T = _grid_mesh(np.stack([X, Y, Z], -1), nc, nc)
+        sb.mesh(P, T, random_material(), normals=_smooth_normals(P, T))
+
+    # clutter: spheres and boxes on the floor
+    nl = max(8, int(round(40 * detail)))
+    for i in range(14):
+        c = (rng.uniform(4, LX - 4), 0.0, rng.uniform(5.5, LZ - 5.5))
+        if i % 2 == 0:
+            rad = rng.uniform(0.35, 0.8)
+            P, T, N = sphere_mesh((c[0], rad + 0.05, c[2]), rad, nl, nl // 2)
+            sb.mesh(P, T, random_material(), normals=N)
+        else:
+            s = rng.uniform(0.4, 0.9, 3)
+            P, T = box_mesh((c[0] - s[0], 0.05, c[2] - s[2]), (c[0] + s[0], 0.05 + 2 * s[1], c[2] + s[2]))
+            sb.mesh(P, T, random_material())
+
+    sb.perspective(origin=(2.5, 4.2, LZ / 2 + 0.8), target=(LX - 4.0, 5.2, LZ / 2 - 0.4), up=(0, 1, 0), fov_x_deg=70.0, near=0.05, far=200.0)
+    sb.hdrfilm(width, height, filter_table)
+    return sb
+
+
+# ==========================================================================================
+#  C4: glass-heavy room, ~150k triangles
+# ==========================================================================================
+def glass_room(width, height, filter_table, seed=2, detail=1.0, sb=None):
+    """Tiled box room with tessellated glass spheres and slabs (dielectric, intIOR 1.5) on a table,
+    two quad area lights.  Long specular chains: NEE is skipped on the delta surfaces (path.cpp:174-175)."""
+    rng = np.random.default_rng(seed)
+    sb = sb or SceneBuilder()
+    LX, LY, LZ = 8.0, 4.0, 6.0
+    tiles = [sb.diffuse(c) for c in [(0.75, 0.75, 0.72), (0.35, 0.45, 0.6), (0.7, 0.55, 0.4)]]
+    white = sb.diffuse((0.8, 0.8, 0.8))
+    glass = sb.dielectric(1.5, 1.0)
+
+    def tiled_wall(origin, du, dv, nu, nv, facing):
+        o = np.asarray(origin, np.float32); du = np.asarray(du, np.float32); dv = np.asarray(dv, np.float32)
+        for m in range(len(tiles)):
+            Ps, Ts = [], []
+            cnt = 0
+            for i in range(nu):
+                for j in range(nv):
+                    if (i * 7 + j * 3 + (i * j) % 2) % len(tiles) != m:
+                        continue
+                    p0 = o + du * (i / nu) + dv * (j / nv); p1 = o + du * ((i + 1) / nu) + dv * (j / nv)
+                    p2 = o + du * ((i + 1) / nu) + dv * ((j + 1) / nv); p3 = o + du * (i / nu) + dv * ((j + 1) / nv)
+                    quad = np.stack([p0, p1, p2, p3])
+                    nrm = np.cross(quad[1] - quad[0], quad[2] - quad[0])
+                    if np.dot(nrm, facing) < 0:
+                        quad = quad[::-1]
+                    Ps.append(quad); Ts.append(np.array([[0, 1, 2], [2, 3, 0]], np.uint32) + 4 * cnt); cnt += 1
+            if Ps:
+                sb.mesh(np.concatenate(Ps), np.concatenate(Ts), tiles[m])
+
+    nt = max(2, int(round(24 * detail)))
+    tiled_wall((0, 0, 0), (LX, 0, 0), (0, 0, LZ), nt, nt, (0, 1, 0))
+    tiled_wall((0, LY, 0), (LX, 0, 0), (0, 0, LZ), nt // 2, nt // 2, (0, -1, 0))
+    tiled_wall((0, 0, 0), (0, LY, 0), (0, 0, LZ), nt // 2, nt, (1, 0, 0))
+    tiled_wall((LX, 0, 0), (0, LY, 0), (0, 0, LZ), nt // 2, nt, (-1, 0, 0))
+    tiled_wall((0, 0, LZ), (LX, 0, 0), (0, LY, 0), nt, nt // 2, (0, 0, -1))
+    tiled_wall((0, 0, 0), (LX, 0, 0), (0, LY, 0), nt, nt // 2, (0, 0, 1))
+    # lights
+    sb.quad((2.0, LY - 0.02, 2.0), (3.6, LY - 0.02, 2.0), (3.6, LY - 0.02, 3.6), (2.0, LY - 0.02, 3.6), sb.diffuse((0.5, 0.5, 0.5)),
+            facing=(0, -1, 0), radiance=(30.0, 28.0, 24.0))
+    sb.quad((5.2, LY - 0.02, 3.0), (6.4, LY - 0.02, 3.0), (6.4, LY - 0.02, 4.4), (5.2, LY - 0.02, 4.4), sb.diffuse((0.5, 0.5, 0.5)),
+            facing=(0, -1, 0), radiance=(14.0, 18.0, 26.0))
+    # table
+    P, T = box_mesh((1.5, 0.9, 1.5), (6.5, 1.0, 4.8)); sb.mesh(P, T, white)
+    for x, z in [(1.7, 1.7), (6.3, 1.7), (1.7, 4.6), (6.3, 4.6)]:
+        P, T = box_mesh((x - 0.06, 0.0, z - 0.06), (x + 0.06, 0.9, z + 0.06)); sb.mesh(P, T, white)
+    # glass spheres on the table and floor
+    nl = max(8, int(round(80 * detail)))
+    for i in range(24):
+        r = float(rng.uniform(0.12, 0.32))
+        if i < 16:
+            c = (rng.uniform(1.9, 6.1), 1.0 + r + 0.002, rng.uniform(1.9, 4.4))
+        else:
+            c = (rng.uniform(0.8, 7.2), r + 0.002, rng.uniform(0.6, 1.2) if i % 2 else rng.uniform(5.0, 5.6))
+        P, T, N = sphere_mesh(c, r, nl, nl // 2)
+        sb.mesh(P, T, glass, normals=N)
+    # glass slabs
+    for i in range(6):
+        x = 2.0 + 0.75 * i
+        P, T = box_mesh((x, 1.002, 2.6 + 0.1 * (i % 2)), (x + 0.08, 1.9 + 0.1 * i, 3.6 + 0.1 * (i % 2)))
+        sb.mesh(P, T, glass)
+    sb.perspective(origin=(0.9, 2.2, 0.5), target=(4.6, 1.2, 3.4), up=(0, 1, 0), fov_x_deg=65.0, near=0.02, far=100.0)
+    sb.hdrfilm(width, height, filter_table)
+    return sb

@@ -220,3 +220,32 @@ def test_cancel_returns_false(gpu, gauss):
     assert ok is False                       # SamplingIntegrator::render returns false when cancelled
     film2 = HDRFilm(512, 512)
     assert integ.render(gs, film2, 1) is True   # the scene is reusable afterwards
+
+
+def test_atrium_sponza_class_matches_oracle(gpu, oracle, gauss):
+    """BASELINE.json configs[2] scene (reduced film): ~250k triangles, twosided diffuse + roughconductor, smooth normals"""
+    desc = S.atrium(240, 136, gauss).desc()
+    same, r = compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=8)
+    print("atrium: identical %.6f rel L2 %.3e" % (same, r))
+
+
+def test_glass_room_matches_oracle(gpu, oracle, gauss):
+    """BASELINE.json configs[3] scene (reduced film): dielectric chains, maxDepth=16"""
+    desc = S.glass_room(240, 136, gauss).desc()
+    same, r = compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=16)
+    print("glass_room: identical %.6f rel L2 %.3e" % (same, r))
+
+
+def test_material_zoo_matches_oracle(gpu, oracle, gauss):
+    """every BSDF variant on the path in one Cornell box: ggx / anisotropic / non-visible sampling, dielectric, twosided(front, back)"""
+    sb = S.cornell_box(128, 128, gauss)
+    cu = dict(eta=S.CU_ETA, k=S.CU_K)
+    mats = [sb.twosided(sb.roughconductor(alpha=0.2, distribution="ggx", **cu)),
+            sb.twosided(sb.roughconductor(alpha=0.05, alpha_v=0.3, **cu)),
+            sb.twosided(sb.roughconductor(alpha=0.15, sample_visible=False, **cu), sb.diffuse((0.2, 0.7, 0.3))),
+            sb.roughconductor(alpha=0.3, **cu),
+            sb.dielectric(1.33, 1.0)]
+    for i, m in enumerate(mats):
+        P, T, N = S.sphere_mesh((90 + 95 * i, 420 - 60 * (i % 2), 150 + 60 * i), 45.0, 24, 12)
+        sb.mesh(P, T, m, normals=N)
+    compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.999, maxDepth=8)

@@ -1,0 +1,25 @@
+"""Runs the BASELINE configs on the GPU (reduced spp by env) and prints throughput + counters."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mitsuba_amd import _ffi, _abi as A, scene as S
+from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
+
+ft = _ffi.gaussian_filter()
+cfgs = {"cornell": ("cornell_box", 1024, 1024, 64, -1), "atrium": ("atrium", 1920, 1080, 16, 8), "glass": ("glass_room", 1920, 1080, 32, 16)}
+for key in sys.argv[1:] or cfgs:
+    name, w, h, spp, md = cfgs[key]
+    spp = int(os.environ.get("SPP", spp))
+    sb = getattr(S, name)(w, h, ft)
+    t = time.time(); sc = Scene(sb.desc()); tb = time.time() - t
+    integ = PathHIP(maxDepth=md); film = HDRFilm(w, h)
+    integ.render(sc, film, 1)
+    t = time.time(); integ.render(sc, film, spp, flags=A.PHIP_FLAG_KERNEL_TIMING); dt = time.time() - t
+    st = integ.stats.as_dict()
+    n = w * h * spp
+    print(json.dumps({"scene": key, "tris": sb.n_triangles, "accel": sc.accel_info().as_dict(), "scene_create_s": round(tb, 3), "spp": spp, "Msamples/s": round(n / 1e6 / dt, 1),
+                      "Mrays/s": round((st["closest_rays"] + st["shadow_rays"]) / 1e6 / dt, 1), "mean_len": round(st["path_vertices"] / n, 2),
+                      "nodes/closest": round(st["closest_node_visits"] / max(st["closest_rays"], 1), 1), "tris/closest": round(st["closest_triangle_tests"] / max(st["closest_rays"], 1), 1),
+                      "nodes/shadow": round(st["shadow_node_visits"] / max(st["shadow_rays"], 1), 1),
+                      "kernel_ms": {k: round(st[k], 1) for k in ("trace_kernel_ms", "shadow_kernel_ms", "shade_kernel_ms", "film_kernel_ms")}, "wall_ms": round(dt * 1e3, 1),
+                      "iters": st["iterations"], "trace_GBs_alg": round(st["trace_kernel_bytes"] / 1e9 / (st["trace_kernel_ms"] / 1e3), 1)}))
