@@ -52,10 +52,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
+    path = os.environ.get("PHIP_LIB", LIB)     # experiment hook: alternative builds of the same sources
+    if not os.path.exists(path):
         raise RuntimeError("libphip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "-- path_hip has no CPU fallback" % LIB)
-    L = C.CDLL(LIB)
+    L = C.CDLL(path)
     fp, u8p, u32 = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_uint32
     L.phip_last_error.restype = C.c_char_p
     L.phip_version.restype = C.c_char_p

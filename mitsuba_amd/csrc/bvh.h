@@ -10,11 +10,15 @@
  * include/mitsuba/render/triaccel.h:61-93, so that (t,u,v) are bit-identical to the CPU path).
  * Closest-hit results do not depend on the structure, only on the triangle test.
  *
- * Node layout (4 x float4):
- *   n0 = (l.min.x, l.min.y, l.min.z, l.max.x)
- *   n1 = (l.max.y, l.max.z, r.min.x, r.min.y)
- *   n2 = (r.min.z, r.max.x, r.max.y, r.max.z)
- *   n3 = (bits(left), bits(right), 0, 0)
+ * The binary tree is then collapsed into a 4-wide BVH (a child that is an inner node is replaced by
+ * its two children, largest surface area first) so that one 128-byte node -- exactly one cache line,
+ * eight coalescable 16-byte loads -- yields four slab tests per dependent memory round trip.
+ *
+ * BVH4 node layout (8 x float4, children in the four lanes of each vector):
+ *   n0 = min.x[4]  n1 = min.y[4]  n2 = min.z[4]  n3 = max.x[4]  n4 = max.y[4]  n5 = max.z[4]
+ *   n6 = bits(child ref[4])   n7 = unused
+ *   empty child slots have min = +inf, max = -inf (never hit).
+ * (intermediate BVH2 node, 4 x float4: l.min.xyz l.max.x | l.max.yz r.min.xy | r.min.z r.max.xyz | refs)
  * child reference: >= 0 inner-node index; < 0 leaf: ~ref = (firstTri << 3) | (count - 1), count in 1..8.
  * Triangle record (3 x float4): (bits(k), n_u, n_v, n_d) (a_u, a_v, b_nu, b_nv) (c_nu, c_nv, bits(globalPrim), 0)
  */
@@ -25,13 +29,18 @@
 #include <cmath>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 
 namespace pt {
 
 struct BuildTri { float bmin[3], bmax[3], c[3]; uint32_t prim; };
 
 struct HostBVH {
-    std::vector<float> nodes;     /* 16 floats per node */
+    std::vector<float> nodes8;    /* 64 floats per BVH8 node: child k at [8k..8k+7] = min.xyz, max.xyz, bits(ref), 0 */
+    uint32_t nNodes8 = 0, maxDepth8 = 0; int32_t rootRef8 = 0; float sahCost8 = 0;
+    std::vector<float> nodes;     /* 32 floats per BVH4 node */
+    std::vector<float> nodes2;    /* 16 floats per intermediate BVH2 node */
+    uint32_t nNodes2 = 0;
     std::vector<float> tris;      /* 12 floats per triangle record, leaf order */
     uint32_t nNodes = 0, nLeaves = 0, nTriRefs = 0, maxDepth = 0;
     float sceneMin[3], sceneMax[3];       /* enlarged like gkdtree.h:1213-1220 */
@@ -175,13 +184,13 @@ struct Builder {
             mid = b + (size_t) (m - first);
             if (mid == b || mid == e) mid = b + n / 2;
         }
-        const uint32_t idx = out.nNodes++;
-        out.nodes.resize((size_t) out.nNodes * 16);
+        const uint32_t idx = out.nNodes2++;
+        out.nodes2.resize((size_t) out.nNodes2 * 16);
         Box lb, rb;
         int32_t l = build(b, mid, lb, depth + 1);
         int32_t r = build(mid, e, rb, depth + 1);
         Box lp = lb, rp = rb; pad(lp); pad(rp);
-        float *nd = &out.nodes[(size_t) idx * 16];
+        float *nd = &out.nodes2[(size_t) idx * 16];
         nd[0] = lp.mn[0]; nd[1] = lp.mn[1]; nd[2] = lp.mn[2]; nd[3] = lp.mx[0];
         nd[4] = lp.mx[1]; nd[5] = lp.mx[2]; nd[6] = rp.mn[0]; nd[7] = rp.mn[1];
         nd[8] = rp.mn[2]; nd[9] = rp.mx[0]; nd[10] = rp.mx[1]; nd[11] = rp.mx[2];
@@ -208,7 +217,7 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
         T.push_back(bt);
     }
     out = HostBVH();
-    out.nodes.reserve((size_t) nTris * 16);
+    out.nodes2.reserve((size_t) nTris * 16);
     out.tris.reserve((size_t) nTris * 12);
     for (int a = 0; a < 3; ++a) { out.tightMin[a] = tight.mn[a]; out.tightMax[a] = tight.mx[a]; }
     /* scene box: tight box enlarged exactly like the reference's kd-tree root (gkdtree.h:1213-1220):
@@ -230,24 +239,87 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
     }
     detail::Builder B(T, out, positions, indices);
     detail::Box rootBox;
-    out.rootRef = B.build(0, T.size(), rootBox, 1);
-    /* SAH cost of the final tree */
-    {
-        struct It { int32_t ref; detail::Box box; };
-        std::vector<It> st; st.push_back({ out.rootRef, rootBox });
-        double cost = 0; const double rootA = rootBox.area() > 0 ? rootBox.area() : 1.0;
-        while (!st.empty()) {
-            It it = st.back(); st.pop_back();
-            if (it.ref < 0) { uint32_t r = ~(uint32_t) it.ref; cost += it.box.area() / rootA * ((r & 7) + 1); continue; }
-            cost += it.box.area() / rootA;
-            const float *nd = &out.nodes[(size_t) it.ref * 16];
-            detail::Box l, r; l.mn[0] = nd[0]; l.mn[1] = nd[1]; l.mn[2] = nd[2]; l.mx[0] = nd[3]; l.mx[1] = nd[4]; l.mx[2] = nd[5];
-            r.mn[0] = nd[6]; r.mn[1] = nd[7]; r.mn[2] = nd[8]; r.mx[0] = nd[9]; r.mx[1] = nd[10]; r.mx[2] = nd[11];
-            uint32_t lr, rr; memcpy(&lr, &nd[12], 4); memcpy(&rr, &nd[13], 4);
-            st.push_back({ (int32_t) lr, l }); st.push_back({ (int32_t) rr, r });
+    const int32_t root2 = B.build(0, T.size(), rootBox, 1);
+
+    /* ---- collapse to BVH4 ---- */
+    struct Child { int32_t ref; detail::Box box; };
+    auto children2 = [&](int32_t ref, Child out2[2]) {
+        const float *nd = &out.nodes2[(size_t) ref * 16];
+        out2[0].box.mn[0] = nd[0]; out2[0].box.mn[1] = nd[1]; out2[0].box.mn[2] = nd[2]; out2[0].box.mx[0] = nd[3]; out2[0].box.mx[1] = nd[4]; out2[0].box.mx[2] = nd[5];
+        out2[1].box.mn[0] = nd[6]; out2[1].box.mn[1] = nd[7]; out2[1].box.mn[2] = nd[8]; out2[1].box.mx[0] = nd[9]; out2[1].box.mx[1] = nd[10]; out2[1].box.mx[2] = nd[11];
+        uint32_t l, r; memcpy(&l, &nd[12], 4); memcpy(&r, &nd[13], 4);
+        out2[0].ref = (int32_t) l; out2[1].ref = (int32_t) r;
+    };
+    out.maxDepth = 0;
+    double cost = 0; const double rootA = rootBox.area() > 0 ? rootBox.area() : 1.0;
+    std::function<int32_t(int32_t, uint32_t)> collapse = [&](int32_t ref2, uint32_t depth) -> int32_t {
+        out.maxDepth = std::max(out.maxDepth, depth);
+        if (ref2 < 0) return ref2;                      /* leaf reference stays */
+        Child ch[4]; int n = 2;
+        children2(ref2, ch);
+        while (n < 4) {                                 /* expand the inner child with the largest area */
+            int best = -1; float bestA = -1;
+            for (int i = 0; i < n; ++i) if (ch[i].ref >= 0 && ch[i].box.area() > bestA) { bestA = ch[i].box.area(); best = i; }
+            if (best < 0) break;
+            Child two[2]; children2(ch[best].ref, two);
+            ch[best] = two[0]; ch[n++] = two[1];
         }
-        out.sahCost = (float) cost;
-    }
+        const uint32_t idx = out.nNodes++;
+        out.nodes.resize((size_t) out.nNodes * 32);
+        int32_t refs[4];
+        for (int i = 0; i < n; ++i) {
+            refs[i] = collapse(ch[i].ref, depth + 1);
+            cost += ch[i].box.area() / rootA * (ch[i].ref < 0 ? (double) (((~(uint32_t) ch[i].ref) & 7) + 1) : 1.0);
+        }
+        float *nd = &out.nodes[(size_t) idx * 32];
+        for (int i = 0; i < 4; ++i) {
+            const bool used = i < n;
+            for (int a = 0; a < 3; ++a) {
+                nd[4 * a + i] = used ? ch[i].box.mn[a] : INFINITY;
+                nd[4 * (3 + a) + i] = used ? ch[i].box.mx[a] : -INFINITY;
+            }
+            nd[24 + i] = detail::bits2f(used ? (uint32_t) refs[i] : 0xffffffffu);   /* unused: never reached */
+            nd[28 + i] = 0.0f;
+        }
+        return (int32_t) idx;
+    };
+    out.rootRef = collapse(root2, 1);
+    out.sahCost = (float) (cost + 1.0);
+
+    /* ---- 8-wide collapse for the lane-cooperative traversal (one child box per lane) ---- */
+    double cost8 = 0;
+    std::function<int32_t(int32_t, uint32_t)> collapse8 = [&](int32_t ref2, uint32_t depth) -> int32_t {
+        out.maxDepth8 = std::max(out.maxDepth8, depth);
+        if (ref2 < 0) return ref2;
+        Child ch[8]; int n = 2;
+        children2(ref2, ch);
+        while (n < 8) {
+            int best = -1; float bestA = -1;
+            for (int i = 0; i < n; ++i) if (ch[i].ref >= 0 && ch[i].box.area() > bestA) { bestA = ch[i].box.area(); best = i; }
+            if (best < 0) break;
+            Child two[2]; children2(ch[best].ref, two);
+            ch[best] = two[0]; ch[n++] = two[1];
+        }
+        const uint32_t idx = out.nNodes8++;
+        out.nodes8.resize((size_t) out.nNodes8 * 64);
+        int32_t refs[8];
+        for (int i = 0; i < n; ++i) {
+            refs[i] = collapse8(ch[i].ref, depth + 1);
+            cost8 += ch[i].box.area() / rootA;
+        }
+        float *nd = &out.nodes8[(size_t) idx * 64];
+        for (int i = 0; i < 8; ++i) {
+            const bool used = i < n;
+            float *c = nd + 8 * i;
+            for (int a = 0; a < 3; ++a) { c[a] = used ? ch[i].box.mn[a] : INFINITY; c[3 + a] = used ? ch[i].box.mx[a] : -INFINITY; }
+            c[6] = detail::bits2f(used ? (uint32_t) refs[i] : 0xffffffffu);
+            c[7] = 0.0f;
+        }
+        return (int32_t) idx;
+    };
+    out.rootRef8 = collapse8(root2, 1);
+    out.sahCost8 = (float) (cost8 + 1.0);
+    std::vector<float>().swap(out.nodes2);
     out.buildMs = (float) std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -59,12 +59,12 @@ struct DevFilm {
 };
 
 struct DevScene {
-    const float4 *nodes; const float4 *tris; const uint4 *triVerts;
+    const float4 *nodes; const float4 *nodes8; const float4 *tris; const uint4 *triVerts;
     const float4 *positions; const float4 *normals;
     const DevShape *shapes; const DevMaterial *materials; const DevEmitter *emitters;
     const float *areaCdf; const float *emitterCdf;
     uint32_t nEmitters; float emitterNormalization;
-    int32_t rootRef; uint32_t nTriangles;
+    int32_t rootRef, rootRef8; uint32_t nTriangles;
     float sceneMin[3], sceneMax[3];
     DevCamera cam; DevFilm film;
 };

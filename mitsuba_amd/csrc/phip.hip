@@ -58,7 +58,12 @@ static int setErr(int code, const std::string &msg) { g_err = msg; return code; 
  *  device-side state
  * ====================================================================================== */
 #define BLOCK 256
-#define STACK_DEPTH 40          /* BVH2 depth for 1M triangles stays well below this */
+#ifndef STACK_DEPTH
+#define STACK_DEPTH 24          /* LDS entries per lane (96 B): 6 waves/SIMD fit in 160 KB; deeper entries spill to HBM */
+#endif
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 6           /* __launch_bounds__ second argument (waves per SIMD) for the traversal kernels */
+#endif
 
 enum : uint32_t {
     F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22,
@@ -76,6 +81,8 @@ struct PathPool {
                          block b's entries are compacted at [b*BLOCK, b*BLOCK + shadowCount[b]) */
     uint32_t *shadowCount;            /* per block of BLOCK slots */
     unsigned long long *stat;         /* ST_COUNT arrays of nWaves entries */
+    uint32_t *spill;                  /* traversal-stack overflow: SPILL_DEPTH entries per lane */
+    uint2 *spill8;                    /* group kernels: SPILL8 entries per ray group (8 groups per wave) */
     uint32_t capacity, nWaves;
 };
 
@@ -182,46 +189,81 @@ __device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, cons
     return maxt > mint;
 }
 
+/* Per-lane traversal stack: the first STACK_DEPTH entries live in LDS (interleaved: entry e of lane l at
+ * lds[e * BLOCK + l], so lane i always hits bank i), deeper entries spill to a per-lane HBM array. */
+struct TravStack {
+    uint32_t *lds;          /* lds base + threadIdx.x */
+    uint32_t *spill;        /* global: SPILL_DEPTH entries per lane */
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) {
+        if (sp < STACK_DEPTH) lds[sp * BLOCK] = v; else spill[sp - STACK_DEPTH] = v;
+        ++sp;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        --sp;
+        return sp < STACK_DEPTH ? lds[sp * BLOCK] : spill[sp - STACK_DEPTH];
+    }
+};
+#define SPILL_DEPTH 96
+
+__device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const uint32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
 template <bool SHADOW>
 __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
-                                         uint32_t *stack /* LDS, stride BLOCK */, TravResult &res,
+                                         TravStack &stack, TravResult &res,
                                          uint32_t &nodeVisits, uint32_t &triTests) {
-    /* reciprocal direction for the slab tests; the Wald test below uses o,d directly */
+    /* reciprocal direction for the slab tests (conservative: boxes are padded); the Wald test uses o,d */
     const V3 rcp(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const V3 ordr(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
-    int sp = 0;
+    stack.sp = 0;
     int32_t cur = S.rootRef;
     bool found = false;
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
     for (;;) {
         if (cur >= 0) {
-            const float4 *n = S.nodes + 4 * (size_t) cur;
-            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            const float4 *n = S.nodes + 8 * (size_t) cur;
+            const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5], chf = n[6];
             ++nodeVisits;
-            /* slab tests (fmaf is fine here: box tests only need to be conservative; boxes are padded) */
-            float lx0 = fmaf(n0.x, rcp.x, -ordr.x), lx1 = fmaf(n0.w, rcp.x, -ordr.x);
-            float ly0 = fmaf(n0.y, rcp.y, -ordr.y), ly1 = fmaf(n1.x, rcp.y, -ordr.y);
-            float lz0 = fmaf(n0.z, rcp.z, -ordr.z), lz1 = fmaf(n1.y, rcp.z, -ordr.z);
-            float lnear = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), mint));
-            float lfar = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), maxt));
-            float rx0 = fmaf(n1.z, rcp.x, -ordr.x), rx1 = fmaf(n2.y, rcp.x, -ordr.x);
-            float ry0 = fmaf(n1.w, rcp.y, -ordr.y), ry1 = fmaf(n2.z, rcp.y, -ordr.y);
-            float rz0 = fmaf(n2.x, rcp.z, -ordr.z), rz1 = fmaf(n2.w, rcp.z, -ordr.z);
-            float rnear = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), mint));
-            float rfar = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), maxt));
-            const bool hl = lnear <= lfar, hr = rnear <= rfar;
-            const int32_t lref = (int32_t) pm_to_bits(n3.x), rref = (int32_t) pm_to_bits(n3.y);
-            if (hl && hr) {
-                const bool leftFirst = lnear <= rnear;
-                stack[sp * BLOCK] = (uint32_t) (leftFirst ? rref : lref);
-                ++sp;
-                cur = leftFirst ? lref : rref;
-                continue;
-            } else if (hl) { cur = lref; continue; }
-            else if (hr) { cur = rref; continue; }
+            float key[4]; uint32_t ref[4];
+#define SLAB(K, C)                                                                                   \
+            {                                                                                        \
+                const float x0 = fmaf(mnx.C, rcp.x, -ordr.x), x1 = fmaf(mxx.C, rcp.x, -ordr.x);        \
+                const float y0 = fmaf(mny.C, rcp.y, -ordr.y), y1 = fmaf(mxy.C, rcp.y, -ordr.y);        \
+                const float z0 = fmaf(mnz.C, rcp.z, -ordr.z), z1 = fmaf(mxz.C, rcp.z, -ordr.z);        \
+                const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint)); \
+                const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt)); \
+                key[K] = (tn <= tf) ? tn : INFINITY;                                                 \
+                ref[K] = pm_to_bits(chf.C);                                                          \
+            }
+            SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)
+#undef SLAB
+            if (!SHADOW) {
+                /* sorting network: nearest child first */
+                cswap(key[0], ref[0], key[1], ref[1]); cswap(key[2], ref[2], key[3], ref[3]);
+                cswap(key[0], ref[0], key[2], ref[2]); cswap(key[1], ref[1], key[3], ref[3]);
+                cswap(key[1], ref[1], key[2], ref[2]);
+                if (key[0] < INFINITY) {
+                    if (key[3] < INFINITY) stack.push(ref[3]);
+                    if (key[2] < INFINITY) stack.push(ref[2]);
+                    if (key[1] < INFINITY) stack.push(ref[1]);
+                    cur = (int32_t) ref[0];
+                    continue;
+                }
+            } else {
+                int32_t next = 0; bool have = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (key[k] < INFINITY) { if (have) stack.push(ref[k]); else { next = (int32_t) ref[k]; have = true; } }
+                if (have) { cur = next; continue; }
+            }
         } else {
-            const uint32_t ref = ~(uint32_t) cur;
-            const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+            const uint32_t r = ~(uint32_t) cur;
+            const uint32_t first = r >> 3, count = (r & 7u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
                 const float4 *tp = S.tris + 3 * (size_t) (first + i);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -234,17 +276,205 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
                 }
             }
         }
-        if (sp == 0) break;
-        --sp;
-        cur = (int32_t) stack[sp * BLOCK];
+        if (stack.sp == 0) break;
+        cur = (int32_t) stack.pop();
     }
     return found;
 }
 
 /* ======================================================================================
+ *  Lane-cooperative traversal ("group" kernels): 8 lanes work on ONE ray over the 8-wide BVH.
+ *  Lane k of a group fetches and slab-tests child k (the group's loads cover one contiguous
+ *  256-byte node -> fully coalesced), or Wald-tests triangle k of a leaf.  A wave64 therefore
+ *  walks 8 rays at a time; trip-count divergence is 8-way instead of 64-way, the per-ray stack
+ *  (ref, tnear) lives in LDS at 1/8 of the per-lane cost, and a group that finishes its ray
+ *  immediately pulls the next of the wave's 64 rays (wave-local dynamic fetch, no atomics).
+ * ====================================================================================== */
+#define STACK8 40                       /* (ref, tnear) entries per ray in LDS; deeper ones spill to HBM */
+#define NONE_REF 0x7fffffff
+
+struct Stack8 {
+    uint2 *lds;             /* this group's STACK8 entries */
+    uint2 *spill;           /* this group's SPILL8 entries in HBM */
+    __device__ __forceinline__ void put(int i, uint2 v) { if (i < STACK8) lds[i] = v; else spill[i - STACK8] = v; }
+    __device__ __forceinline__ uint2 get(int i) const { return i < STACK8 ? lds[i] : spill[i - STACK8]; }
+};
+#define SPILL8 64
+
+template <bool SHADOW, typename Fetch, typename Commit>
+__device__ __forceinline__ void traverseWave8(const DevScene &S, uint2 *waveStack, uint2 *waveSpill, uint32_t nRays,
+                                              Fetch fetch, Commit commit, uint32_t &nodeVisits, uint32_t &triTests, uint32_t &raysTraced) {
+    const uint32_t lane = __lane_id(), sub = lane & 7u, grp = lane >> 3, grpBase = lane & ~7u;
+    Stack8 stk; stk.lds = waveStack + grp * STACK8; stk.spill = waveSpill + grp * SPILL8;
+    uint32_t nextRay = 0;                    /* wave-uniform */
+    bool needRay = true, active = false;
+    uint32_t ray = 0;
+    V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
+    float mint = 0, maxt = 0;
+    int32_t cur = NONE_REF; int sp = 0;
+    float bestT = INFINITY, bestU = 0, bestV = 0; uint32_t bestPrim = PHIP_NO_HIT;
+    bool occluded = false;
+
+    for (;;) {
+        /* ---- hand out rays to the groups that need one (wave-uniform bookkeeping) ---- */
+        const unsigned long long want = __ballot(needRay && sub == 0);
+        if (want) {
+            if (needRay) {
+                ray = nextRay + (uint32_t) __popcll(want & ((1ull << grpBase) - 1ull));
+                needRay = false;
+                if (ray < nRays) {
+                    float rmint, rmaxt;
+                    if (fetch(ray, o, d, rmint, rmaxt)) {
+                        if (sub == 0) ++raysTraced;
+                        bestT = INFINITY; bestU = bestV = 0; bestPrim = PHIP_NO_HIT; occluded = false;
+                        if (clipToScene<SHADOW>(S, o, d, rmint, rmaxt, mint, maxt)) {
+                            rcp = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
+                            cur = S.rootRef8; sp = 0; active = true;
+                        } else {
+                            if (sub == 0) commit(ray, false, bestT, bestU, bestV, bestPrim);
+                            needRay = true;
+                        }
+                    } else {
+                        needRay = true;                      /* dead slot: take the next one */
+                    }
+                }
+            }
+            nextRay += (uint32_t) __popcll(want);
+        }
+        if (!__any(active || needRay)) break;
+        if (!active) continue;
+
+        /* ---- one traversal step per group ---- */
+        bool done = false;
+        if (cur == NONE_REF) {                               /* pop (with distance culling for closest hit) */
+            if (sp == 0) done = true;
+            else {
+                --sp;
+                const uint2 e = stk.get(sp);
+                if (SHADOW || pm_from_bits(e.y) <= maxt) cur = (int32_t) e.x;
+            }
+        } else if (cur >= 0) {                               /* inner node: lane `sub` tests child `sub` */
+            const float4 *p = S.nodes8 + (size_t) cur * 16 + sub * 2;
+            const float4 a = p[0], b = p[1];
+            if (sub == 0) ++nodeVisits;
+            const float x0 = fmaf(a.x, rcp.x, -ordr.x), x1 = fmaf(a.w, rcp.x, -ordr.x);
+            const float y0 = fmaf(a.y, rcp.y, -ordr.y), y1 = fmaf(b.x, rcp.y, -ordr.y);
+            const float z0 = fmaf(a.z, rcp.z, -ordr.z), z1 = fmaf(b.y, rcp.z, -ordr.z);
+            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint));
+            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt));
+            const bool hit = tn <= tf;
+            const uint32_t ref = pm_to_bits(b.z);
+            const uint32_t hm = (uint32_t) (__ballot(hit) >> grpBase) & 0xffu;
+            const int nh = __popc(hm);
+            if (nh == 0) {
+                cur = NONE_REF;
+            } else {
+                int rank;
+                if (SHADOW) {
+                    rank = __popc(hm & ((1u << sub) - 1u));  /* any order will do */
+                } else {
+                    const float key = hit ? tn : INFINITY;
+                    rank = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        const float kj = __shfl(key, (int) (grpBase + j));
+                        rank += (kj < key || (kj == key && j < sub)) ? 1 : 0;
+                    }
+                }
+                if (hit && rank > 0) stk.put(sp + nh - 1 - rank, make_uint2(ref, pm_to_bits(tn)));
+                const uint32_t fm = (uint32_t) (__ballot(hit && rank == 0) >> grpBase) & 0xffu;
+                cur = (int32_t) __shfl(ref, (int) (grpBase + (uint32_t) (__ffs((int) fm) - 1)));
+                sp += nh - 1;
+            }
+        } else {                                             /* leaf: lane `sub` tests triangle `sub` */
+            const uint32_t r = ~(uint32_t) cur;
+            const uint32_t first = r >> 3, count = (r & 7u) + 1u;
+            bool hit = false; float tu = 0, tv = 0, tt = INFINITY; uint32_t prim = PHIP_NO_HIT;
+            if (sub < count) {
+                const float4 *tp = S.tris + 3 * (size_t) (first + sub);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                hit = waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt);
+                prim = pm_to_bits(c.z);
+            }
+            if (sub == 0) triTests += count;
+            const uint32_t hm = (uint32_t) (__ballot(hit) >> grpBase) & 0xffu;
+            if (hm) {
+                if (SHADOW) { occluded = true; done = true; }
+                else {
+                    float m = hit ? tt : INFINITY;
+                    m = fminf(m, __shfl_xor(m, 1)); m = fminf(m, __shfl_xor(m, 2)); m = fminf(m, __shfl_xor(m, 4));
+                    /* ties: the later-tested triangle wins (sahkdtree3.h:286-291 semantics, `t <= maxt`) */
+                    const uint32_t wm = (uint32_t) (__ballot(hit && tt == m) >> grpBase) & 0xffu;
+                    const int jw = (int) grpBase + (31 - __clz((int) wm));
+                    maxt = m; bestT = m;
+                    bestU = __shfl(tu, jw); bestV = __shfl(tv, jw); bestPrim = __shfl(prim, jw);
+                }
+            }
+            cur = NONE_REF;
+        }
+        if (done) {
+            if (sub == 0) commit(ray, occluded, bestT, bestU, bestV, bestPrim);
+            active = false; needRay = true;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK, 6) void k_trace8(DevScene S, PathPool P) {
+    __shared__ uint2 lds[(BLOCK / 64) * 8 * STACK8];
+    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint32_t base = waveId * 64;
+    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
+    const uint32_t n = base < P.capacity ? min(64u, P.capacity - base) : 0u;
+    traverseWave8<false>(S, lds + wave * 8 * STACK8, P.spill8 + (size_t) waveId * 8 * SPILL8, n,
+        [&](uint32_t r, V3 &o, V3 &d, float &mint, float &maxt) -> bool {
+            const uint32_t slot = base + r;
+            if (!(P.info[slot].w & F_ALIVE)) return false;
+            const float4 ro = P.rayO[slot], rd = P.rayD[slot];
+            o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
+            return true;
+        },
+        [&](uint32_t r, bool, float t, float u, float v, uint32_t prim) {
+            P.hit[base + r] = make_float4(t, u, v, pm_from_bits(prim));
+        }, nodeVisits, triTests, rays);
+    waveStat(P, ST_CLOSEST_RAYS, waveId, rays);
+    waveStat(P, ST_NODE, waveId, nodeVisits);
+    waveStat(P, ST_TRI, waveId, triTests);
+}
+
+__global__ __launch_bounds__(BLOCK, 6) void k_shadow8(DevScene S, PathPool P, float4 *L) {
+    __shared__ uint2 lds[(BLOCK / 64) * 8 * STACK8];
+    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint32_t count = P.shadowCount[blockIdx.x];
+    const uint32_t first = wave * 64;
+    if (first >= count) return;
+    const uint32_t n = min(64u, count - first);
+    const size_t base = (size_t) blockIdx.x * BLOCK + first;
+    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
+    traverseWave8<true>(S, lds + wave * 8 * STACK8, P.spill8 + (size_t) waveId * 8 * SPILL8, n,
+        [&](uint32_t r, V3 &o, V3 &d, float &mint, float &maxt) -> bool {
+            const float4 e0 = P.shadow[3 * (base + r)], e1 = P.shadow[3 * (base + r) + 1];
+            o = V3(e0.x, e0.y, e0.z); d = V3(e1.x, e1.y, e1.z); mint = PT_EPSILON; maxt = e0.w;
+            return true;
+        },
+        [&](uint32_t r, bool occluded, float, float, float, uint32_t) {
+            if (!occluded) {
+                const float4 e1 = P.shadow[3 * (base + r) + 1], e2 = P.shadow[3 * (base + r) + 2];
+                const uint32_t id = pm_to_bits(e1.w);
+                float4 l = L[id];
+                l.x += e2.x; l.y += e2.y; l.z += e2.z;
+                L[id] = l;
+            }
+        }, nodeVisits, triTests, rays);
+    waveStat(P, ST_SHADOW_RAYS, waveId, rays);
+    waveStat(P, ST_SH_NODE, waveId, nodeVisits);
+    waveStat(P, ST_SH_TRI, waveId, triTests);
+}
+
+/* ======================================================================================
  *  kernels
  * ====================================================================================== */
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, PathPool P) {
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPool P) {
     __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
@@ -257,7 +487,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, PathPool P) {
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             rays = 1;
             if (clipToScene<false>(S, o, d, ro.w, rd.w, mint, maxt))
-                traverse<false>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+                { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + (size_t) slot * SPILL_DEPTH;
+                  traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests); }
             P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
         }
     }
@@ -267,7 +498,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene S, PathPool P) {
     waveStat(P, ST_TRI, waveId, triTests);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene S, PathPool P, float4 *L) {
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathPool P, float4 *L) {
     __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const uint32_t n = P.shadowCount[blockIdx.x];            /* entries of this block's slots */
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
@@ -280,7 +511,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene S, PathPool P, float4
         TravResult r;
         rays = 1;
         if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt))
-            occluded = traverse<true>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+            { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + idx * SPILL_DEPTH;
+              occluded = traverse<true>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests); }
         if (!occluded) {
             const uint32_t id = pm_to_bits(e1.w);
             float4 l = L[id];
@@ -590,14 +822,16 @@ __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *r
         if (hits) {
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                traverse<false>(S, o, d, mint, maxt, lds + threadIdx.x, r, nodeVisits, triTests);
+                { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + i * SPILL_DEPTH;
+                  traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests); }
             phip_hit h; h.t = r.t; h.u = r.u; h.v = r.v; h.prim = r.prim;
             hits[i] = h;
         }
         if (occluded) {
             TravResult r; bool occ = false;
             if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                occ = traverse<true>(S, o, d, mint, maxt, lds + threadIdx.x, r, shNodeVisits, shTriTests);
+                { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + i * SPILL_DEPTH;
+                  occ = traverse<true>(S, o, d, mint, maxt, stk, r, shNodeVisits, shTriTests); }
             occluded[i] = occ ? 1 : 0;
         }
     }
@@ -703,7 +937,10 @@ struct phip_scene {
     int device = 0;
     phip_scene_desc descCopy;        /* scalar fields only */
     HostBVH bvh;
-    DevBuf<float4> nodes, tris, positions, normals;
+    DevBuf<float4> nodes, nodes8, tris, positions, normals;
+    DevBuf<uint2> spill8;
+    int traversal = 0;               /* 0 = one ray per lane over the BVH4 (default), 1 = 8 lanes per ray over the BVH8
+                                        (PHIP_TRAVERSAL=group; measured 2-3x slower: too few rays in flight per CU) */
     DevBuf<uint4> triVerts;
     DevBuf<DevShape> shapes; DevBuf<DevMaterial> materials; DevBuf<DevEmitter> emitters;
     DevBuf<float> areaCdf, emitterCdf;
@@ -712,7 +949,7 @@ struct phip_scene {
     DevBuf<float4> rayO, rayD, hit, thr, refN, shadow, L, sampleOut;
     DevBuf<uint4> info;
     DevBuf<Counters> counters;
-    DevBuf<uint32_t> tileOrigin, shadowCount; DevBuf<int32_t> tileSlot;
+    DevBuf<uint32_t> tileOrigin, shadowCount, spill; DevBuf<int32_t> tileSlot;
     DevBuf<unsigned long long> stat;
     DevBuf<float> film; DevBuf<unsigned long long> invalid;
     uint32_t lastSpp = 0;
@@ -835,7 +1072,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     /* acceleration structure */
     buildBVH(d.positions, d.indices, d.n_triangles, sc->bvh);
-    if (sc->bvh.maxDepth + 2 > STACK_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
+    if (3 * sc->bvh.maxDepth + 2 > STACK_DEPTH + SPILL_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
 
     /* upload */
     HIP_TRY(hipSetDevice(sc->device));
@@ -844,8 +1081,10 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (d.normals) { nrm4.resize(d.n_vertices); for (uint32_t i = 0; i < d.n_vertices; ++i) nrm4[i] = make_float4(d.normals[3 * i], d.normals[3 * i + 1], d.normals[3 * i + 2], 0); }
     std::vector<uint4> tv(d.n_triangles);
     for (uint32_t i = 0; i < d.n_triangles; ++i) tv[i] = make_uint4(d.indices[3 * i], d.indices[3 * i + 1], d.indices[3 * i + 2], triShape[i]);
-    if (sc->bvh.nodes.empty()) sc->nodes.alloc(4);
+    if (sc->bvh.nodes.empty()) sc->nodes.alloc(8);
     else sc->nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
+    if (sc->bvh.nodes8.empty()) sc->nodes8.alloc(16);
+    else sc->nodes8.upload((const float4 *) sc->bvh.nodes8.data(), sc->bvh.nodes8.size() / 4);
     sc->tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
     sc->positions.upload(pos4.data(), pos4.size());
     if (d.normals) sc->normals.upload(nrm4.data(), nrm4.size());
@@ -858,11 +1097,12 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     DevScene &D = sc->dev;
     memset(&D, 0, sizeof(D));
-    D.nodes = sc->nodes.p; D.tris = sc->tris.p; D.triVerts = sc->triVerts.p; D.positions = sc->positions.p; D.normals = sc->normals.p;
+    D.nodes = sc->nodes.p; D.nodes8 = sc->nodes8.p; D.tris = sc->tris.p; D.triVerts = sc->triVerts.p; D.positions = sc->positions.p; D.normals = sc->normals.p;
     D.shapes = sc->shapes.p; D.materials = sc->materials.p; D.emitters = sc->emitters.p;
     D.areaCdf = sc->areaCdf.p; D.emitterCdf = sc->emitterCdf.p;
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
-    D.rootRef = sc->bvh.rootRef; D.nTriangles = d.n_triangles;
+    D.rootRef = sc->bvh.rootRef; D.rootRef8 = sc->bvh.rootRef8; D.nTriangles = d.n_triangles;
+    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = (strcmp(e, "group") == 0) ? 1 : 0;
     for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
     setupCamera(d.camera, d.film, D.cam);
     D.film.width = d.film.crop_width; D.film.height = d.film.crop_height;
@@ -880,16 +1120,17 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 }
 
 static void algorithmicBytes(const phip_scene *sc, phip_stats &st) {
-    /* SURVEY 8(d) with this structure's sizes: 64-byte BVH node visits, 48-byte triangle records
+    /* SURVEY 8(d) with this structure's sizes: 128-byte BVH4 node visits, 48-byte triangle records
        (no separate index array: records are stored in leaf order) */
     const double film = 20.0 * (double) sc->dev.film.width * sc->dev.film.height;
-    st.algorithmic_bytes = 64.0 * (double) (st.closest_node_visits + st.shadow_node_visits) +
+    const double nodeBytes = sc->traversal ? 256.0 : 128.0;
+    st.algorithmic_bytes = nodeBytes * (double) (st.closest_node_visits + st.shadow_node_visits) +
            48.0 * (double) (st.closest_triangle_tests + st.shadow_triangle_tests) +
            (64.0 + 40.0 + 108.0) * (double) st.closest_rays + (64.0 + 4.0) * (double) st.shadow_rays +
            104.0 * (double) st.path_vertices + film;
     /* closest-hit kernel: node + triangle fetches, ray read (32 B), hit record write (16 B) ... counted with
        the SURVEY's read+write convention: ray 64 B, hit 40 B */
-    st.trace_kernel_bytes = 64.0 * (double) st.closest_node_visits + 48.0 * (double) st.closest_triangle_tests +
+    st.trace_kernel_bytes = nodeBytes * (double) st.closest_node_visits + 48.0 * (double) st.closest_triangle_tests +
            (64.0 + 40.0) * (double) st.closest_rays;
 }
 
@@ -958,11 +1199,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     if (sc->rayO.n < capacity) {
         sc->rayO.alloc(capacity); sc->rayD.alloc(capacity); sc->hit.alloc(capacity); sc->thr.alloc(capacity);
         sc->refN.alloc(capacity); sc->info.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
-        sc->shadowCount.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves);
+        sc->shadowCount.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
+        sc->spill8.alloc((size_t) nWaves * 8 * SPILL8);
     }
     PathPool P;
     P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.refN = sc->refN.p; P.info = sc->info.p;
-    P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.stat = sc->stat.p; P.capacity = capacity; P.nWaves = nWaves;
+    P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.stat = sc->stat.p; P.spill = sc->spill.p; P.spill8 = sc->spill8.p; P.capacity = capacity; P.nWaves = nWaves;
     if (sc->L.n < idsFirstPass) sc->L.alloc((size_t) idsFirstPass);
 
     phip_stats st; memset(&st, 0, sizeof(st));
@@ -998,10 +1240,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             hipLaunchKernelGGL(k_shade, grid, block, 0, stream, D, P, rc, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
-            hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, D, P, sc->L.p);
+            if (sc->traversal) hipLaunchKernelGGL(k_shadow8, grid, block, 0, stream, D, P, sc->L.p);
+            else hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, D, P, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-            hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P);
+            if (sc->traversal) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
+            else hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
             ++iter;
             if (check) {
@@ -1143,6 +1387,7 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             PathPool P; memset(&P, 0, sizeof(P));
             P.nWaves = (uint32_t) ((n + 63) / 64 + BLOCK / 64);
             stat.alloc((size_t) ST_COUNT * P.nWaves);
+            DevBuf<uint32_t> spill; spill.alloc(((n + BLOCK - 1) / BLOCK * BLOCK) * (size_t) SPILL_DEPTH); P.spill = spill.p;
             HIP_TRY(hipMemset(stat.p, 0, stat.n * sizeof(unsigned long long)));
             P.stat = stat.p;
             hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -1185,7 +1430,8 @@ void phip_develop(const float *rgbaw, size_t n_pixels, float *out_rgb) {
 int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
     if (!scene || !out) return setErr(PHIP_ERR_INVALID, "NULL argument");
     out->n_nodes = scene->bvh.nNodes; out->n_leaves = scene->bvh.nLeaves; out->n_triangle_refs = scene->bvh.nTriRefs;
-    out->max_depth = scene->bvh.maxDepth; out->node_bytes = 64; out->triangle_bytes = 48;
+    out->max_depth = scene->traversal ? scene->bvh.maxDepth8 : scene->bvh.maxDepth; out->node_bytes = scene->traversal ? 256 : 128; out->triangle_bytes = 48;
+    if (scene->traversal) { out->n_nodes = scene->bvh.nNodes8; out->sah_cost = scene->bvh.sahCost8; }
     out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
     return PHIP_OK;
 }

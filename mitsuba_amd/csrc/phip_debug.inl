@@ -100,7 +100,7 @@ int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const
         HostBVH bvh; buildBVH(positions, indices, n_triangles, bvh);
         if (info) {
             info->n_nodes = bvh.nNodes; info->n_leaves = bvh.nLeaves; info->n_triangle_refs = bvh.nTriRefs; info->max_depth = bvh.maxDepth;
-            info->node_bytes = 64; info->triangle_bytes = 48; info->sah_cost = bvh.sahCost; info->build_ms = bvh.buildMs;
+            info->node_bytes = 128; info->triangle_bytes = 48; info->sah_cost = bvh.sahCost; info->build_ms = bvh.buildMs;
         }
         if (scene_box6) for (int a = 0; a < 3; ++a) { scene_box6[a] = bvh.sceneMin[a]; scene_box6[3 + a] = bvh.sceneMax[a]; }
         return PHIP_OK;
