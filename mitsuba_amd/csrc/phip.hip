@@ -283,6 +283,194 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
 }
 
 /* ======================================================================================
+ *  Persistent per-lane traversal: a fixed grid of resident waves walks the whole ray pool.
+ *  A lane that finishes its ray (or finds its slot dead) is refilled from the wave's own
+ *  statically strided share of the pool as soon as REFILL_LANES lanes are idle, so the wave
+ *  does not wait for its slowest ray ("while-while" + dynamic fetch, but without any global
+ *  atomic: the share of wave w is chunks w, w+W, w+2W, ...).
+ * ====================================================================================== */
+#ifndef REFILL_LANES
+#define REFILL_LANES 16
+#endif
+#define INVALID_RAY 0xFFFFFFFFu
+
+template <bool SHADOW, typename Source>
+__device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack &stack, Source &src,
+                                                   uint32_t &nodeVisits, uint32_t &triTests, uint32_t &raysTraced) {
+    bool active = false;
+    uint32_t handle = INVALID_RAY;
+    V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
+    float mint = 0, maxt = 0;
+    int32_t cur = 0;
+    TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle && src.more() && (__popcll(idle) >= REFILL_LANES || idle == ~0ull)) {
+            const uint32_t h = src.assign(!active, idle);
+            if (!active && h != INVALID_RAY) {
+                float rmint, rmaxt;
+                if (src.load(h, o, d, rmint, rmaxt)) {
+                    ++raysTraced;
+                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+                    if (clipToScene<SHADOW>(S, o, d, rmint, rmaxt, mint, maxt)) {
+                        rcp = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
+                        cur = S.rootRef; stack.sp = 0; handle = h; active = true;
+                    } else {
+                        src.commit(h, false, res);
+                    }
+                }
+            }
+        }
+        if (!__any(active)) { if (!src.more()) break; continue; }
+        if (active) {
+            for (;;) {
+                bool finished = false;
+                if (cur >= 0) {
+                    const float4 *n = S.nodes + 8 * (size_t) cur;
+                    const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5], chf = n[6];
+                    ++nodeVisits;
+                    float key[4]; uint32_t ref[4];
+#define SLAB(K, C)                                                                                   \
+                    {                                                                                \
+                        const float x0 = fmaf(mnx.C, rcp.x, -ordr.x), x1 = fmaf(mxx.C, rcp.x, -ordr.x); \
+                        const float y0 = fmaf(mny.C, rcp.y, -ordr.y), y1 = fmaf(mxy.C, rcp.y, -ordr.y); \
+                        const float z0 = fmaf(mnz.C, rcp.z, -ordr.z), z1 = fmaf(mxz.C, rcp.z, -ordr.z); \
+                        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint)); \
+                        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt)); \
+                        key[K] = (tn <= tf) ? tn : INFINITY;                                         \
+                        ref[K] = pm_to_bits(chf.C);                                                  \
+                    }
+                    SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)
+#undef SLAB
+                    bool descend = false;
+                    if (!SHADOW) {
+                        cswap(key[0], ref[0], key[1], ref[1]); cswap(key[2], ref[2], key[3], ref[3]);
+                        cswap(key[0], ref[0], key[2], ref[2]); cswap(key[1], ref[1], key[3], ref[3]);
+                        cswap(key[1], ref[1], key[2], ref[2]);
+                        if (key[0] < INFINITY) {
+                            if (key[3] < INFINITY) stack.push(ref[3]);
+                            if (key[2] < INFINITY) stack.push(ref[2]);
+                            if (key[1] < INFINITY) stack.push(ref[1]);
+                            cur = (int32_t) ref[0]; descend = true;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (key[k] < INFINITY) { if (descend) stack.push(ref[k]); else { cur = (int32_t) ref[k]; descend = true; } }
+                    }
+                    if (!descend) { if (stack.sp == 0) finished = true; else cur = (int32_t) stack.pop(); }
+                } else {
+                    const uint32_t r = ~(uint32_t) cur;
+                    const uint32_t first = r >> 3, count = (r & 7u) + 1u;
+                    bool shadowHit = false;
+                    for (uint32_t i = 0; i < count; ++i) {
+                        const float4 *tp = S.tris + 3 * (size_t) (first + i);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        ++triTests;
+                        float tu, tv, tt;
+                        if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
+                            if (SHADOW) { shadowHit = true; break; }
+                            maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
+                        }
+                    }
+                    if (SHADOW && shadowHit) { res.prim = 0; finished = true; }
+                    else if (stack.sp == 0) finished = true;
+                    else cur = (int32_t) stack.pop();
+                }
+                if (finished) {
+                    src.commit(handle, SHADOW ? (res.prim != PHIP_NO_HIT) : false, res);
+                    active = false;
+                    break;
+                }
+                if (src.more() && __popcll(__ballot(1)) <= 64 - REFILL_LANES) break;     /* enough idle lanes: refill */
+            }
+        }
+    }
+}
+
+/* closest-hit source: all slots of the pool, chunk-strided over the resident waves */
+struct TraceSource {
+    const PathPool &P; uint32_t chunk, pos, stride, nChunks;
+    __device__ __forceinline__ bool more() const { return chunk < nChunks; }
+    __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
+        const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
+        const uint32_t h = (want && idx < 64u && chunk * 64u + idx < P.capacity) ? chunk * 64u + idx : INVALID_RAY;
+        pos += (uint32_t) __popcll(wantMask);
+        if (pos >= 64u) { pos = 0; chunk += stride; }
+        return h;
+    }
+    __device__ __forceinline__ bool load(uint32_t slot, V3 &o, V3 &d, float &mint, float &maxt) const {
+        if (!(P.info[slot].w & F_ALIVE)) return false;
+        const float4 ro = P.rayO[slot], rd = P.rayD[slot];
+        o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
+        return true;
+    }
+    __device__ __forceinline__ void commit(uint32_t slot, bool, const TravResult &r) const {
+        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+    }
+};
+
+/* any-hit source: the block-compacted shadow queue; wave w walks blocks w, w+W, ... */
+struct ShadowSource {
+    const PathPool &P; float4 *L; uint32_t blk, pos, cnt, stride, nBlocks;
+    __device__ __forceinline__ void skipEmpty() {
+        while (blk < nBlocks) { cnt = P.shadowCount[blk]; if (cnt) break; blk += stride; }
+    }
+    __device__ __forceinline__ bool more() const { return blk < nBlocks; }
+    __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
+        const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
+        const uint32_t h = (want && idx < cnt) ? blk * BLOCK + idx : INVALID_RAY;
+        pos += (uint32_t) __popcll(wantMask);
+        if (pos >= cnt) { pos = 0; blk += stride; skipEmpty(); }
+        return h;
+    }
+    __device__ __forceinline__ bool load(uint32_t e, V3 &o, V3 &d, float &mint, float &maxt) const {
+        const float4 e0 = P.shadow[3 * (size_t) e], e1 = P.shadow[3 * (size_t) e + 1];
+        o = V3(e0.x, e0.y, e0.z); d = V3(e1.x, e1.y, e1.z); mint = PT_EPSILON; maxt = e0.w;
+        return true;
+    }
+    __device__ __forceinline__ void commit(uint32_t e, bool occluded, const TravResult &) const {
+        if (!occluded) {
+            const float4 e1 = P.shadow[3 * (size_t) e + 1], e2 = P.shadow[3 * (size_t) e + 2];
+            const uint32_t id = pm_to_bits(e1.w);
+            float4 l = L[id];
+            l.x += e2.x; l.y += e2.y; l.z += e2.z;
+            L[id] = l;
+        }
+    }
+};
+
+#ifndef TRACE_P_WAVES
+#define TRACE_P_WAVES 5
+#endif
+__global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, PathPool P) {
+    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
+    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
+    TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH; stk.sp = 0;
+    TraceSource src{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
+    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
+    persistentTraverse<false>(S, stk, src, nodeVisits, triTests, rays);
+    waveStat(P, ST_CLOSEST_RAYS, waveId, rays);
+    waveStat(P, ST_NODE, waveId, nodeVisits);
+    waveStat(P, ST_TRI, waveId, triTests);
+}
+
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, PathPool P, float4 *L) {
+    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
+    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
+    TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH; stk.sp = 0;
+    ShadowSource src{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
+    src.skipEmpty();
+    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
+    persistentTraverse<true>(S, stk, src, nodeVisits, triTests, rays);
+    waveStat(P, ST_SHADOW_RAYS, waveId, rays);
+    waveStat(P, ST_SH_NODE, waveId, nodeVisits);
+    waveStat(P, ST_SH_TRI, waveId, triTests);
+}
+
+/* ======================================================================================
  *  Lane-cooperative traversal ("group" kernels): 8 lanes work on ONE ray over the 8-wide BVH.
  *  Lane k of a group fetches and slab-tests child k (the group's loads cover one contiguous
  *  256-byte node -> fully coalesced), or Wald-tests triangle k of a leaf.  A wave64 therefore
@@ -939,7 +1127,7 @@ struct phip_scene {
     HostBVH bvh;
     DevBuf<float4> nodes, nodes8, tris, positions, normals;
     DevBuf<uint2> spill8;
-    int traversal = 0;               /* 0 = one ray per lane over the BVH4 (default), 1 = 8 lanes per ray over the BVH8
+    int traversal = 2;               /* 2 = persistent per-lane BVH4 traversal with dynamic refill (default), 0 = one launch lane per slot, 1 = 8 lanes per ray over the BVH8
                                         (PHIP_TRAVERSAL=group; measured 2-3x slower: too few rays in flight per CU) */
     DevBuf<uint4> triVerts;
     DevBuf<DevShape> shapes; DevBuf<DevMaterial> materials; DevBuf<DevEmitter> emitters;
@@ -1102,7 +1290,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     D.areaCdf = sc->areaCdf.p; D.emitterCdf = sc->emitterCdf.p;
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
     D.rootRef = sc->bvh.rootRef; D.rootRef8 = sc->bvh.rootRef8; D.nTriangles = d.n_triangles;
-    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = (strcmp(e, "group") == 0) ? 1 : 0;
+    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = (strcmp(e, "group") == 0) ? 1 : (strcmp(e, "lane") == 0 ? 0 : 2);
     for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
     setupCamera(d.camera, d.film, D.cam);
     D.film.width = d.film.crop_width; D.film.height = d.film.crop_height;
@@ -1123,7 +1311,7 @@ static void algorithmicBytes(const phip_scene *sc, phip_stats &st) {
     /* SURVEY 8(d) with this structure's sizes: 128-byte BVH4 node visits, 48-byte triangle records
        (no separate index array: records are stored in leaf order) */
     const double film = 20.0 * (double) sc->dev.film.width * sc->dev.film.height;
-    const double nodeBytes = sc->traversal ? 256.0 : 128.0;
+    const double nodeBytes = sc->traversal == 1 ? 256.0 : 128.0;
     st.algorithmic_bytes = nodeBytes * (double) (st.closest_node_visits + st.shadow_node_visits) +
            48.0 * (double) (st.closest_triangle_tests + st.shadow_triangle_tests) +
            (64.0 + 40.0 + 108.0) * (double) st.closest_rays + (64.0 + 4.0) * (double) st.shadow_rays +
@@ -1214,6 +1402,10 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
 
     HIP_TRY(hipMemsetAsync(sc->invalid.p, 0, sizeof(unsigned long long), stream));
     const dim3 grid((capacity + BLOCK - 1) / BLOCK), block(BLOCK);
+    /* persistent kernels: exactly the resident set (TRACE_WAVES waves per SIMD = TRACE_WAVES blocks of 256 per CU) */
+    int nCU = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) nCU = prop.multiProcessorCount; }
+    const dim3 pgrid((unsigned) std::max(1, std::min<int>(nCU * TRACE_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
+    const dim3 pgridTrace((unsigned) std::max(1, std::min<int>(nCU * TRACE_P_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
     Counters hc;
     bool cancelled = false;
 
@@ -1240,11 +1432,14 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             hipLaunchKernelGGL(k_shade, grid, block, 0, stream, D, P, rc, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
-            if (sc->traversal) hipLaunchKernelGGL(k_shadow8, grid, block, 0, stream, D, P, sc->L.p);
+            if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, 0, stream, D, P, sc->L.p);
+            else if (sc->traversal == 1) hipLaunchKernelGGL(k_shadow8, grid, block, 0, stream, D, P, sc->L.p);
             else hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, D, P, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-            if (sc->traversal) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
+            if (sc->traversal == 2 && sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, 0, stream, D, P);
+            else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
+            else if (sc->traversal == 1) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
             else hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
             ++iter;
@@ -1430,8 +1625,8 @@ void phip_develop(const float *rgbaw, size_t n_pixels, float *out_rgb) {
 int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
     if (!scene || !out) return setErr(PHIP_ERR_INVALID, "NULL argument");
     out->n_nodes = scene->bvh.nNodes; out->n_leaves = scene->bvh.nLeaves; out->n_triangle_refs = scene->bvh.nTriRefs;
-    out->max_depth = scene->traversal ? scene->bvh.maxDepth8 : scene->bvh.maxDepth; out->node_bytes = scene->traversal ? 256 : 128; out->triangle_bytes = 48;
-    if (scene->traversal) { out->n_nodes = scene->bvh.nNodes8; out->sah_cost = scene->bvh.sahCost8; }
+    out->max_depth = scene->traversal == 1 ? scene->bvh.maxDepth8 : scene->bvh.maxDepth; out->node_bytes = scene->traversal == 1 ? 256 : 128; out->triangle_bytes = 48;
+    if (scene->traversal == 1) { out->n_nodes = scene->bvh.nNodes8; out->sah_cost = scene->bvh.sahCost8; }
     out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
     return PHIP_OK;
 }
