@@ -721,7 +721,10 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
     return pdfA / (pdfA + pdfB);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
@@ -1380,7 +1383,10 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
 
     /* path pool */
     const unsigned long long idsFirstPass = idsPerSpp * sppPerPass;
-    uint32_t capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), 1u << 21);
+    /* pool size: large enough that per-launch fixed costs vanish, small enough that the tail (slots
+       running dry at the end of a pass) stays a small fraction of the pass (measured: 4M / 8M slots) */
+    const unsigned long long poolCap = idsFirstPass >= (256ull << 20) ? (1ull << 23) : (1ull << 22);
+    uint32_t capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
     capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
     if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
     const uint32_t nWaves = capacity / 64, nBlocks = capacity / BLOCK;
