@@ -1,0 +1,87 @@
+"""Host-side logic above the C ABI: the integrator's property handling (same defaults and error
+messages as MonteCarloIntegrator, src/librender/integrator.cpp:190-225), the scene builder's
+flattening invariants and the oracle's scene validation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mitsuba_amd import _abi as A, scene as S
+from mitsuba_amd.integrator import PathHIP, Properties, HDRFilm
+
+
+def test_integrator_defaults_and_validation():
+    i = PathHIP()
+    assert (i.m_maxDepth, i.m_rrDepth, i.m_strictNormals, i.m_hideEmitters) == (-1, 5, False, False)
+    i = PathHIP(Properties("path_hip", maxDepth=8, rrDepth=3, strictNormals=True))
+    assert (i.m_maxDepth, i.m_rrDepth, i.m_strictNormals) == (8, 3, True)
+    with pytest.raises(RuntimeError, match="'rrDepth' must be set to a value greater than zero!"):
+        PathHIP(rrDepth=0)
+    for md in (0, -2):
+        with pytest.raises(RuntimeError, match="'maxDepth' must be set to -1"):
+            PathHIP(maxDepth=md)
+
+
+def test_render_params_defaults():
+    p = A.default_render_params()
+    assert (p.spp, p.max_depth, p.rr_depth, p.block_size, p.shard_count, p.sampler) == (4, -1, 5, 32, 1, A.PHIP_SAMPLER_CTR)
+    with pytest.raises(AttributeError):
+        A.default_render_params(nonsense=1)
+
+
+def test_scene_builder_flattening(gauss):
+    sb = S.cornell_box(64, 48, gauss)
+    d = sb.desc()
+    assert d.n_triangles == 32 and d.n_shapes == 16 and d.n_emitters == 1 and d.n_materials == 4
+    t = 0
+    for i in range(d.n_shapes):
+        sh = d.shapes[i]
+        assert sh.first_triangle == t and sh.n_triangles == 2
+        t += sh.n_triangles
+        idx = np.ctypeslib.as_array(d.indices, (d.n_triangles * 3,))[3 * sh.first_triangle:3 * (sh.first_triangle + sh.n_triangles)]
+        assert idx.min() >= sh.first_vertex and idx.max() < sh.first_vertex + sh.n_vertices
+    em = d.emitters[0]
+    assert d.shapes[em.shape].emitter == 0 and tuple(em.radiance) == (17.0, 12.0, 4.0)
+    assert d.film.crop_width == 64 and d.film.crop_height == 48 and d.film.filter_radius == 2.0
+    # all Cornell faces look into the room: the face normal points towards the box centre
+    pos = np.ctypeslib.as_array(d.positions, (d.n_vertices * 3,)).reshape(-1, 3)
+    idx = np.ctypeslib.as_array(d.indices, (d.n_triangles * 3,)).reshape(-1, 3)
+    c = np.array([278, 274, 280], np.float32)
+    for s in range(5):       # floor, ceiling, back, right, left
+        tri = idx[d.shapes[s].first_triangle]
+        n = np.cross(pos[tri[1]] - pos[tri[0]], pos[tri[2]] - pos[tri[0]])
+        assert np.dot(n, c - pos[tri[0]]) > 0
+
+
+def test_big_scene_generators_are_deterministic(gauss):
+    a = S.atrium(32, 18, gauss, detail=0.2).desc(); b = S.atrium(32, 18, gauss, detail=0.2).desc()
+    assert a.n_triangles == b.n_triangles > 5000
+    pa = np.ctypeslib.as_array(a.positions, (a.n_vertices * 3,)); pb = np.ctypeslib.as_array(b.positions, (b.n_vertices * 3,))
+    assert (pa == pb).all()
+    full = S.atrium(32, 18, gauss)
+    assert 240000 < full.n_triangles < 280000            # "Sponza-class" (~260k triangles)
+    g = S.glass_room(32, 18, gauss)
+    assert 130000 < g.n_triangles < 170000
+    types = [m.type for m in full.materials]
+    assert A.PHIP_BSDF_ROUGHCONDUCTOR in types and A.PHIP_BSDF_TWOSIDED in types
+
+
+def test_oracle_rejects_malformed_scenes(oracle, gauss):
+    sb = S.cornell_box(16, 16, gauss)
+    d = sb.desc(); d.abi_version = 7
+    with pytest.raises(RuntimeError, match="ABI"):
+        oracle.OracleScene(d)
+    sb = S.cornell_box(16, 16, gauss); sb.shapes[3]["material"] = 99
+    with pytest.raises(RuntimeError, match="material"):
+        oracle.OracleScene(sb.desc())
+    sb = S.cornell_box(16, 16, gauss)
+    g = sb.dielectric(1.5, 1.0); sb.twosided(g)          # twosided(dielectric) is an error in the reference (twosided.cpp:104-106)
+    with pytest.raises(RuntimeError, match="twosided"):
+        oracle.OracleScene(sb.desc())
+
+
+def test_hdrfilm_develop_matches_reference_formula(phip):
+    f = HDRFilm(4, 2)
+    f.storage[..., :3] = 6.0; f.storage[..., 4] = 3.0; f.storage[0, 0, 4] = 0.0
+    rgb = f.develop()
+    assert np.allclose(rgb[1:], 2.0) and (rgb[0, 0] == 0).all()     # fmtconv.cpp:979-991: 0 where the weight is 0

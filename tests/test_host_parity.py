@@ -1,0 +1,111 @@
+"""CPU-only parity of the PRODUCT's shading arithmetic: the __host__ __device__ functions of
+mitsuba_amd/csrc/dv_*.h compiled for the host (phip_debug_host_*) against the oracle, bit for bit.
+(The same source compiled for gfx950 is compared on the GPU in test_gpu_parity.py / test_fmath.py.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mitsuba_amd import _abi as A, scene as S
+
+
+def fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def zoo(gauss):
+    sb = S.cornell_box(16, 16, gauss)
+    cu = dict(eta=S.CU_ETA, k=S.CU_K)
+    m = {"diffuse": 0,
+         "rc beckmann": sb.roughconductor(alpha=0.3, **cu), "rc ggx aniso": sb.roughconductor(alpha=0.1, alpha_v=0.3, distribution="ggx", **cu),
+         "rc beckmann aniso": sb.roughconductor(alpha=0.08, alpha_v=0.25, **cu), "rc non-visible": sb.roughconductor(alpha=0.05, sample_visible=False, **cu),
+         "rc ggx non-visible": sb.roughconductor(alpha=0.2, sample_visible=False, distribution="ggx", **cu),
+         "rc tiny alpha": sb.roughconductor(alpha=1e-6, **cu),
+         "dielectric glass": sb.dielectric(1.5, 1.0), "dielectric water": sb.dielectric(1.333, 1.000277), "dielectric inverted": sb.dielectric(1.0, 1.5)}
+    m["twosided diffuse"] = sb.twosided(0)
+    m["twosided rc/diffuse"] = sb.twosided(m["rc beckmann"], 1)
+    return sb, m
+
+
+def test_bsdf_sample_eval_pdf_bitwise(oracle, phip, gauss):
+    sb, mats = zoo(gauss)
+    d = sb.desc(); osc = oracle.OracleScene(d); OL = oracle.lib()
+    rng = np.random.default_rng(11); n = 100000
+    wi = rng.normal(size=(n, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    wi[:100] = [0, 0, 1]; wi[100:200] = [0, 0, -1]; wi[200:300, 2] = 0; wi[200:300] /= np.linalg.norm(wi[200:300], axis=1, keepdims=True) + 1e-30
+    smp = rng.random((n, 2)).astype(np.float32); smp[:50] = 0; smp[50:100] = np.float32(1) - np.float32(2 ** -24)
+    wo_r = rng.normal(size=(n, 3)).astype(np.float32); wo_r /= np.linalg.norm(wo_r, axis=1, keepdims=True)
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    for name, mid in mats.items():
+        a = [np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8)]
+        b = [np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8)]
+        assert phip.phip_debug_host_bsdf_sample(d.materials, d.n_materials, mid, n, fp(wi), fp(smp), fp(a[0]), fp(a[1]), fp(a[2]), u8(a[3])) == 0
+        OL.oracle_bsdf_sample(osc.h, mid, n, fp(wi), fp(smp), fp(b[0]), fp(b[1]), fp(b[2]), u8(b[3]))
+        for x, y in zip(a[:3], b[:3]):
+            assert (x.view(np.uint32) == y.view(np.uint32)).all(), name
+        nz = a[2] > 0
+        assert (a[3][nz] == b[3][nz]).all(), name
+        v1 = np.zeros((n, 3), np.float32); p1 = np.zeros(n, np.float32); v2 = np.zeros((n, 3), np.float32); p2 = np.zeros(n, np.float32)
+        phip.phip_debug_host_bsdf_eval_pdf(d.materials, d.n_materials, mid, n, fp(wi), fp(wo_r), fp(v1), fp(p1))
+        OL.oracle_bsdf_eval_pdf(osc.h, mid, n, fp(wi), fp(wo_r), fp(v2), fp(p2))
+        assert (v1.view(np.uint32) == v2.view(np.uint32)).all() and (p1.view(np.uint32) == p2.view(np.uint32)).all(), name
+
+
+def test_ctr_stream_bitwise_and_well_distributed(oracle, phip):
+    """the parity stream: pcg4d(pixel, sample, block, seed) -> 4 floats in [0,1) with a 23-bit mantissa"""
+    rng = np.random.default_rng(2)
+    keys = rng.integers(0, 2 ** 32, (2000, 4), dtype=np.uint64).astype(np.uint32)
+    keys[:64] = [[p, s, b, 0] for p in range(4) for s in range(4) for b in range(4)]
+    out_o = np.zeros((len(keys), 4), np.float32); out_p = np.zeros_like(out_o)
+    for i, (p, s, b, sd) in enumerate(keys):
+        oracle.lib().oracle_ctr_block(int(p), int(s), int(b), int(sd), fp(out_o[i]))
+        phip.phip_debug_host_ctr_block(int(p), int(s), int(b), int(sd), fp(out_p[i]))
+    assert (out_o.view(np.uint32) == out_p.view(np.uint32)).all()
+    assert (out_o >= 0).all() and (out_o < 1).all()
+    assert (np.round(out_o.astype(np.float64) * 2 ** 23) == out_o.astype(np.float64) * 2 ** 23).all()
+    # python restatement of pcg4d (Jarzynski & Olano 2020) as an independent third implementation
+    def pcg4d(v):
+        v = [(x * 1664525 + 1013904223) & 0xFFFFFFFF for x in v]
+        m = 0xFFFFFFFF
+        v[0] = (v[0] + v[1] * v[3]) & m; v[1] = (v[1] + v[2] * v[0]) & m; v[2] = (v[2] + v[0] * v[1]) & m; v[3] = (v[3] + v[1] * v[2]) & m
+        v = [x ^ (x >> 16) for x in v]
+        v[0] = (v[0] + v[1] * v[3]) & m; v[1] = (v[1] + v[2] * v[0]) & m; v[2] = (v[2] + v[0] * v[1]) & m; v[3] = (v[3] + v[1] * v[2]) & m
+        return v
+    for i in range(0, 200, 7):
+        w = pcg4d([int(x) for x in keys[i]])
+        f = ((np.array(w, np.uint32) >> 9) | np.uint32(0x3f800000)).view(np.float32) - np.float32(1)
+        assert (f == out_o[i]).all()
+    # neighbouring pixels / samples / dimensions are uncorrelated
+    grid = np.zeros((64, 64, 4), np.float32)
+    for p in range(64):
+        for s in range(64):
+            oracle.lib().oracle_ctr_block(p, s, 1, 0, fp(grid[p, s]))
+    x = grid[..., 0].astype(np.float64)
+    assert abs(x.mean() - 0.5) < 0.02 and abs(x.var() - 1 / 12) < 0.01
+    for a, b in [(x[1:], x[:-1]), (x[:, 1:], x[:, :-1]), (grid[..., 0], grid[..., 1]), (grid[..., 2], grid[..., 3])]:
+        assert abs(np.corrcoef(np.ravel(a), np.ravel(b))[0, 1]) < 0.05
+
+
+def test_bvh_build_covers_every_triangle_and_scene_box_matches_kdtree(oracle, phip, gauss):
+    """host BVH build (no GPU): every non-degenerate triangle referenced exactly once; the enlarged scene
+    box equals the kd-tree root box of the oracle (gkdtree.h:1213-1220 arithmetic)"""
+    for sb in [S.cornell_box(16, 16, gauss), S.atrium(16, 16, gauss, detail=0.25), S.glass_room(16, 16, gauss, detail=0.3)]:
+        d = sb.desc()
+        info = A.phip_accel_info(); box = np.zeros(6, np.float32)
+        assert phip.phip_debug_host_build_bvh(d.positions, d.n_vertices, d.indices, d.n_triangles, C.byref(info), fp(box)) == 0
+        assert info.n_triangle_refs == d.n_triangles            # no duplication (BVH, not kd-tree), no degenerate input
+        assert info.n_leaves >= d.n_triangles / 8 and info.max_depth < 40
+        k = oracle.OracleScene(d).kd_info()
+        assert (box[:3].view(np.uint32) == np.array(list(k.aabb_min), np.float32).view(np.uint32)).all()
+        assert (box[3:].view(np.uint32) == np.array(list(k.aabb_max), np.float32).view(np.uint32)).all()
+
+
+def test_degenerate_and_empty_geometry_build(phip):
+    p = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 1, 0]], np.float32)       # first triangle is collinear
+    idx = np.array([[0, 1, 2], [0, 1, 3]], np.uint32)
+    info = A.phip_accel_info()
+    assert phip.phip_debug_host_build_bvh(fp(p), 4, idx.ctypes.data_as(C.POINTER(C.c_uint32)), 2, C.byref(info), None) == 0
+    assert info.n_triangle_refs == 1
+    assert phip.phip_debug_host_build_bvh(fp(p), 4, idx.ctypes.data_as(C.POINTER(C.c_uint32)), 0, C.byref(info), None) == 0
+    bad = np.array([[0, 1, 9]], np.uint32)
+    assert phip.phip_debug_host_build_bvh(fp(p), 4, bad.ctypes.data_as(C.POINTER(C.c_uint32)), 1, C.byref(info), None) == A.PHIP_ERR_INVALID
