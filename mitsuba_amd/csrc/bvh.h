@@ -286,6 +286,36 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
     out.rootRef = collapse(root2, 1);
     out.sahCost = (float) (cost + 1.0);
 
+    /* The traversal kernels stage nodes [0, K) in LDS: renumber so that the top of the tree comes first
+       (breadth-first for the first TOP_BFS nodes, the rest keeps its depth-first order). */
+    if (out.rootRef >= 0 && out.nNodes > 1) {
+        const uint32_t TOP_BFS = 256;
+        std::vector<uint32_t> order; order.reserve(out.nNodes);
+        std::vector<uint8_t> taken(out.nNodes, 0);
+        order.push_back((uint32_t) out.rootRef); taken[out.rootRef] = 1;
+        for (size_t head = 0; head < order.size() && order.size() < TOP_BFS; ++head) {
+            const float *nd = &out.nodes[(size_t) order[head] * 32];
+            for (int i = 0; i < 4 && order.size() < TOP_BFS; ++i) {
+                uint32_t r; memcpy(&r, &nd[24 + i], 4);
+                if ((int32_t) r >= 0 && r < out.nNodes && !taken[r]) { taken[r] = 1; order.push_back(r); }
+            }
+        }
+        for (uint32_t i = 0; i < out.nNodes; ++i) if (!taken[i]) order.push_back(i);
+        std::vector<uint32_t> newIndex(out.nNodes);
+        for (uint32_t i = 0; i < out.nNodes; ++i) newIndex[order[i]] = i;
+        std::vector<float> nn(out.nodes.size());
+        for (uint32_t i = 0; i < out.nNodes; ++i) {
+            const float *src = &out.nodes[(size_t) order[i] * 32]; float *dst = &nn[(size_t) i * 32];
+            memcpy(dst, src, 32 * sizeof(float));
+            for (int c = 0; c < 4; ++c) {
+                uint32_t r; memcpy(&r, &src[24 + c], 4);
+                if ((int32_t) r >= 0 && r < out.nNodes && src[c] != INFINITY) { r = newIndex[r]; memcpy(&dst[24 + c], &r, 4); }
+            }
+        }
+        out.nodes.swap(nn);
+        out.rootRef = (int32_t) newIndex[out.rootRef];
+    }
+
     /* ---- 8-wide collapse for the lane-cooperative traversal (one child box per lane) ---- */
     double cost8 = 0;
     std::function<int32_t(int32_t, uint32_t)> collapse8 = [&](int32_t ref2, uint32_t depth) -> int32_t {

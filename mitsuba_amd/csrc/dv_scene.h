@@ -65,6 +65,7 @@ struct DevScene {
     const float *areaCdf; const float *emitterCdf;
     uint32_t nEmitters; float emitterNormalization;
     int32_t rootRef, rootRef8; uint32_t nTriangles;
+    uint32_t stackDepth, nodeCache, triCache;   /* LDS staging plan of the traversal kernels */
     float sceneMin[3], sceneMax[3];
     DevCamera cam; DevFilm film;
 };

@@ -61,6 +61,12 @@ static int setErr(int code, const std::string &msg) { g_err = msg; return code; 
 #ifndef STACK_DEPTH
 #define STACK_DEPTH 24          /* LDS entries per lane (96 B): 6 waves/SIMD fit in 160 KB; deeper entries spill to HBM */
 #endif
+#ifndef NODE_CACHE_MAX
+#define NODE_CACHE_MAX 16       /* BVH4 nodes staged in LDS per block (144 B each); 16 measured best (44 costs a wave of occupancy) */
+#endif
+#ifndef TRI_CACHE_MAX
+#define TRI_CACHE_MAX 96        /* triangle records staged in LDS when the whole scene has at most this many */
+#endif
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 6           /* __launch_bounds__ second argument (waves per SIMD) for the traversal kernels */
 #endif
@@ -189,21 +195,60 @@ __device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, cons
     return maxt > mint;
 }
 
-/* Per-lane traversal stack: the first STACK_DEPTH entries live in LDS (interleaved: entry e of lane l at
- * lds[e * BLOCK + l], so lane i always hits bank i), deeper entries spill to a per-lane HBM array. */
+/* Per-lane traversal stack: the first `depth` entries live in LDS (interleaved: entry e of lane l at
+ * lds[e * BLOCK + l], so lane i always hits bank i), deeper entries spill to a per-lane HBM array.
+ * The same dynamic LDS segment also stages the top of the tree: the first S.nodeCache BVH4 nodes (they
+ * are stored in breadth-first order, so these are the levels every ray visits) and, for small scenes,
+ * all triangle records.  Cached nodes use a 144-byte stride so that lanes reading different nodes hit
+ * different banks with ds_read_b128. */
+#define NODE_LDS_STRIDE 9               /* float4 per cached node (8 + 1 pad) */
 struct TravStack {
     uint32_t *lds;          /* lds base + threadIdx.x */
     uint32_t *spill;        /* global: SPILL_DEPTH entries per lane */
-    int sp;
+    const float4 *nodes;    /* LDS copy of nodes [0, nodeCache) */
+    const float4 *tris;     /* LDS copy of triangle records [0, triCache) */
+    uint32_t nodeCache, triCache;
+    int depth, sp;
     __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < STACK_DEPTH) lds[sp * BLOCK] = v; else spill[sp - STACK_DEPTH] = v;
+        if (sp < depth) lds[sp * BLOCK] = v; else spill[sp - depth] = v;
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return sp < STACK_DEPTH ? lds[sp * BLOCK] : spill[sp - STACK_DEPTH];
+        return sp < depth ? lds[sp * BLOCK] : spill[sp - depth];
     }
 };
+
+/* carve the block's dynamic LDS and stage the cached geometry (all threads of the block must call) */
+__device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char *smem, uint32_t *spill, TravStack &stk) {
+    uint32_t *stack = (uint32_t *) smem;
+    float4 *ln = (float4 *) (smem + (size_t) S.stackDepth * BLOCK * sizeof(uint32_t));
+    float4 *lt = ln + (size_t) S.nodeCache * NODE_LDS_STRIDE;
+    for (uint32_t i = threadIdx.x; i < S.nodeCache * 8u; i += BLOCK)
+        ln[(i >> 3) * NODE_LDS_STRIDE + (i & 7u)] = S.nodes[i];
+    for (uint32_t i = threadIdx.x; i < S.triCache * 3u; i += BLOCK)
+        lt[i] = S.tris[i];
+    __syncthreads();
+    stk.lds = stack + threadIdx.x; stk.spill = spill; stk.nodes = ln; stk.tris = lt;
+    stk.nodeCache = S.nodeCache; stk.triCache = S.triCache; stk.depth = (int) S.stackDepth; stk.sp = 0;
+}
+
+#define LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)                                   \
+    float4 mnx, mny, mnz, mxx, mxy, mxz, chf;                                                         \
+    if ((uint32_t) (cur) < (stack).nodeCache) {                                                      \
+        const float4 *n_ = (stack).nodes + (size_t) (cur) * NODE_LDS_STRIDE;                          \
+        mnx = n_[0]; mny = n_[1]; mnz = n_[2]; mxx = n_[3]; mxy = n_[4]; mxz = n_[5]; chf = n_[6];    \
+    } else {                                                                                          \
+        const float4 *n_ = (S).nodes + 8 * (size_t) (cur);                                            \
+        mnx = n_[0]; mny = n_[1]; mnz = n_[2]; mxx = n_[3]; mxy = n_[4]; mxz = n_[5]; chf = n_[6];    \
+    }
+#define LOAD_TRI(stack, S, idx, a, b, c)                                                              \
+    float4 a, b, c;                                                                                   \
+    if ((uint32_t) (idx) < (stack).triCache) {                                                       \
+        const float4 *t_ = (stack).tris + 3 * (size_t) (idx); a = t_[0]; b = t_[1]; c = t_[2];        \
+    } else {                                                                                          \
+        const float4 *t_ = (S).tris + 3 * (size_t) (idx); a = t_[0]; b = t_[1]; c = t_[2];            \
+    }
 #define SPILL_DEPTH 96
 
 __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
@@ -226,8 +271,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
     for (;;) {
         if (cur >= 0) {
-            const float4 *n = S.nodes + 8 * (size_t) cur;
-            const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5], chf = n[6];
+            LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)
             ++nodeVisits;
             float key[4]; uint32_t ref[4];
 #define SLAB(K, C)                                                                                   \
@@ -265,8 +309,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
             const uint32_t r = ~(uint32_t) cur;
             const uint32_t first = r >> 3, count = (r & 7u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
-                const float4 *tp = S.tris + 3 * (size_t) (first + i);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
+                LOAD_TRI(stack, S, first + i, a, b, c)
                 ++triTests;
                 float tu, tv, tt;
                 if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
@@ -328,8 +371,7 @@ __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack 
             for (;;) {
                 bool finished = false;
                 if (cur >= 0) {
-                    const float4 *n = S.nodes + 8 * (size_t) cur;
-                    const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5], chf = n[6];
+                    LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)
                     ++nodeVisits;
                     float key[4]; uint32_t ref[4];
 #define SLAB(K, C)                                                                                   \
@@ -366,8 +408,7 @@ __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack 
                     const uint32_t first = r >> 3, count = (r & 7u) + 1u;
                     bool shadowHit = false;
                     for (uint32_t i = 0; i < count; ++i) {
-                        const float4 *tp = S.tris + 3 * (size_t) (first + i);
-                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        LOAD_TRI(stack, S, first + i, a, b, c)
                         ++triTests;
                         float tu, tv, tt;
                         if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
@@ -445,10 +486,11 @@ struct ShadowSource {
 #ifndef TRACE_P_WAVES
 #define TRACE_P_WAVES 5
 #endif
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
 __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, PathPool P) {
-    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH; stk.sp = 0;
+    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
     TraceSource src{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     persistentTraverse<false>(S, stk, src, nodeVisits, triTests, rays);
@@ -458,9 +500,8 @@ __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, Pa
 }
 
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, PathPool P, float4 *L) {
-    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH; stk.sp = 0;
+    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
     ShadowSource src{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
     src.skipEmpty();
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
@@ -663,8 +704,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_shadow8(DevScene S, PathPool P, fl
  *  kernels
  * ====================================================================================== */
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPool P) {
-    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) slot * SPILL_DEPTH, stk);
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     if (slot < P.capacity) {
         const uint4 info = P.info[slot];
@@ -675,8 +716,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             rays = 1;
             if (clipToScene<false>(S, o, d, ro.w, rd.w, mint, maxt))
-                { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + (size_t) slot * SPILL_DEPTH;
-                  traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests); }
+                traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
             P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
         }
     }
@@ -687,7 +727,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
 }
 
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathPool P, float4 *L) {
-    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
+    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
     const uint32_t n = P.shadowCount[blockIdx.x];            /* entries of this block's slots */
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     if (threadIdx.x < n) {
@@ -699,8 +739,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathP
         TravResult r;
         rays = 1;
         if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt))
-            { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + idx * SPILL_DEPTH;
-              occluded = traverse<true>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests); }
+            occluded = traverse<true>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
         if (!occluded) {
             const uint32_t id = pm_to_bits(e1.w);
             float4 l = L[id];
@@ -1003,8 +1042,8 @@ __global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, co
 
 /* standalone ray casts for phip_trace */
 __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
-    __shared__ uint32_t lds[STACK_DEPTH * BLOCK];
     const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
+    TravStack stk; setupTraversal(S, g_smem, P.spill + i * SPILL_DEPTH, stk);
     uint32_t nodeVisits = 0, triTests = 0, shNodeVisits = 0, shTriTests = 0;
     if (i < n) {
         const phip_ray ry = rays[i];
@@ -1013,16 +1052,14 @@ __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *r
         if (hits) {
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + i * SPILL_DEPTH;
-                  traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests); }
+                traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
             phip_hit h; h.t = r.t; h.u = r.u; h.v = r.v; h.prim = r.prim;
             hits[i] = h;
         }
         if (occluded) {
             TravResult r; bool occ = false;
             if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                { TravStack stk; stk.lds = lds + threadIdx.x; stk.spill = P.spill + i * SPILL_DEPTH;
-                  occ = traverse<true>(S, o, d, mint, maxt, stk, r, shNodeVisits, shTriTests); }
+                occ = traverse<true>(S, o, d, mint, maxt, stk, r, shNodeVisits, shTriTests);
             occluded[i] = occ ? 1 : 0;
         }
     }
@@ -1293,6 +1330,13 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     D.areaCdf = sc->areaCdf.p; D.emitterCdf = sc->emitterCdf.p;
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
     D.rootRef = sc->bvh.rootRef; D.rootRef8 = sc->bvh.rootRef8; D.nTriangles = d.n_triangles;
+    /* LDS staging plan: stack depth from the tree depth (3 pushes per BVH4 level), top-of-tree node cache
+       (nodes are in breadth-first order), all triangle records if there are few */
+    D.stackDepth = (uint32_t) std::min<int>(STACK_DEPTH, std::max<int>(4, 3 * ((int) sc->bvh.maxDepth - 1) + 1));
+    D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, NODE_CACHE_MAX);
+    D.triCache = (sc->bvh.tris.size() / 12 <= TRI_CACHE_MAX) ? (uint32_t) (sc->bvh.tris.size() / 12) : 0u;
+    if (const char *e = getenv("PHIP_NODE_CACHE")) D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, (uint32_t) atoi(e));
+    if (D.nodeCache == 0) D.triCache = 0;
     if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = (strcmp(e, "group") == 0) ? 1 : (strcmp(e, "lane") == 0 ? 0 : 2);
     for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
     setupCamera(d.camera, d.film, D.cam);
@@ -1308,6 +1352,10 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     sc->descCopy.shapes = nullptr; sc->descCopy.materials = nullptr; sc->descCopy.emitters = nullptr;
     sc->counters.alloc(1);
     sc->invalid.alloc(1);
+}
+
+static size_t traversalLdsBytes(const DevScene &D) {
+    return (size_t) D.stackDepth * BLOCK * sizeof(uint32_t) + (size_t) D.nodeCache * NODE_LDS_STRIDE * sizeof(float4) + (size_t) D.triCache * 3 * sizeof(float4);
 }
 
 static void algorithmicBytes(const phip_scene *sc, phip_stats &st) {
@@ -1408,6 +1456,7 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
 
     HIP_TRY(hipMemsetAsync(sc->invalid.p, 0, sizeof(unsigned long long), stream));
     const dim3 grid((capacity + BLOCK - 1) / BLOCK), block(BLOCK);
+    const size_t ldsBytes = traversalLdsBytes(D);
     /* persistent kernels: exactly the resident set (TRACE_WAVES waves per SIMD = TRACE_WAVES blocks of 256 per CU) */
     int nCU = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) nCU = prop.multiProcessorCount; }
     const dim3 pgrid((unsigned) std::max(1, std::min<int>(nCU * TRACE_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
@@ -1438,15 +1487,15 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             hipLaunchKernelGGL(k_shade, grid, block, 0, stream, D, P, rc, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
-            if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, 0, stream, D, P, sc->L.p);
+            if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sc->L.p);
             else if (sc->traversal == 1) hipLaunchKernelGGL(k_shadow8, grid, block, 0, stream, D, P, sc->L.p);
-            else hipLaunchKernelGGL(k_shadow, grid, block, 0, stream, D, P, sc->L.p);
+            else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-            if (sc->traversal == 2 && sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, 0, stream, D, P);
-            else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
+            if (sc->traversal == 2 && sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, ldsBytes, stream, D, P);
+            else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
             else if (sc->traversal == 1) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
-            else hipLaunchKernelGGL(k_trace, grid, block, 0, stream, D, P);
+            else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
             ++iter;
             if (check) {
@@ -1593,7 +1642,7 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             P.stat = stat.p;
             hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
             HIP_TRY(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, scene->dev, (const phip_ray *) dr.p, n, dh.p, dz.p, P);
+            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(scene->dev), 0, scene->dev, (const phip_ray *) dr.p, n, dh.p, dz.p, P);
             HIP_TRY(hipEventRecord(e1, 0));
             hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT), dim3(256), 0, 0, P, scene->counters.p);
             HIP_TRY(hipDeviceSynchronize());
