@@ -767,7 +767,15 @@ __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPo
     __shared__ uint32_t waveCnt[BLOCK / 64];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
-    uint4 info = inRange ? P.info[slot] : make_uint4(0, 0, 0, 0);
+    /* all slot state is fetched up front, before the liveness test, so that the six 16-byte loads are
+       in flight together (the kernel is latency bound: 70 % of its wave cycles were s_waitcnt) */
+    const uint32_t lslot = inRange ? slot : 0u;
+    uint4 info = P.info[lslot];
+    const float4 hit = P.hit[lslot];
+    const float4 ro = P.rayO[lslot], rd = P.rayD[lslot];
+    float4 thr4 = P.thr[lslot];
+    const float4 rn = P.refN[lslot];
+    if (!inRange) info = make_uint4(0, 0, 0, 0);
     bool alive = inRange && (info.w & F_ALIVE);
     bool needNew = inRange && !alive && !(info.w & F_DEAD);
     unsigned long long vertices = 0, done = 0;
@@ -775,11 +783,8 @@ __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPo
     float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0;
 
     if (alive) {
-        const float4 hit = P.hit[slot];
         const uint32_t prim = pm_to_bits(hit.w);
-        const float4 ro = P.rayO[slot], rd = P.rayD[slot];
         const V3 rayD(rd.x, rd.y, rd.z);
-        float4 thr4 = P.thr[slot];
         V3 thr(thr4.x, thr4.y, thr4.z);
         float eta = thr4.w;
         uint32_t depth = info.w & DEPTH_MASK;
@@ -805,7 +810,6 @@ __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPo
                 if (shp.emitter >= 0) {
                     const DevEmitter &em = S.emitters[shp.emitter];
                     V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em.radiance);
-                    const float4 rn = P.refN[slot];
                     DirectRec dRec;
                     dRec.ref = V3(ro.x, ro.y, ro.z); dRec.refN = V3(rn.x, rn.y, rn.z);
                     dRec.p = its.p; dRec.n = its.sh.n; dRec.d = rayD; dRec.dist = its.t; dRec.emitter = shp.emitter; dRec.solidAngle = 1;
@@ -1017,6 +1021,102 @@ __global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, cons
     float *o = out + ((size_t) y * F.width + x) * 5;
     if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
     else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
+    if (invalid) atomicAdd(invalidCount, invalid);
+}
+
+/* LDS-tiled film gather (filters with reach <= FILM_MAX_REACH pixels, i.e. every reference default): a block owns
+ * 16x16 destination pixels; per sample index k the block first evaluates the sample position and loads the
+ * radiance of each of the (16+2R)^2 source pixels ONCE into LDS, then every destination lane accumulates its
+ * (2R+1)^2 neighbours from LDS.  Same arithmetic as k_film per (sample, pixel) pair; only the order of the
+ * float additions differs. */
+#define FILM_MAX_REACH 4
+#define FILM_TILE 16
+__global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
+                                                     int tilesX, float *out, int accumulate, unsigned long long *invalidCount, int R) {
+    constexpr int TMAX = FILM_TILE + 2 * FILM_MAX_REACH;
+    __shared__ float4 sVal[TMAX * TMAX];       /* radiance rgb + alpha of the source pixel's k-th sample */
+    __shared__ float2 sPos[TMAX * TMAX];       /* sample position in the source block's bitmap coordinates; x = NaN: no sample */
+    __shared__ int4 sGeo[TMAX * TMAX];         /* (offX - border, offY - border, bw, bh) of the source pixel's render block */
+    __shared__ uint32_t sBase[TMAX * TMAX];    /* low word of the sample id of k = 0 (0xFFFFFFFF: pixel not rendered here) */
+    __shared__ float sTable[PHIP_FILTER_RESOLUTION + 1];
+    const DevFilm &F = S.film;
+    const int T = FILM_TILE + 2 * R;
+    const int x0 = blockIdx.x * FILM_TILE, y0 = blockIdx.y * FILM_TILE;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = x0 + lx, y = y0 + ly;
+    if (threadIdx.x <= PHIP_FILTER_RESOLUTION) sTable[threadIdx.x] = F.table[threadIdx.x];
+    /* per source pixel constants */
+    for (int i = threadIdx.x; i < T * T; i += BLOCK) {
+        const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+        uint32_t base = 0xFFFFFFFFu; int4 g = make_int4(0, 0, 0, 0);
+        if (sx >= 0 && sy >= 0 && sx < F.width && sy < F.height) {
+            const int tx = sx >> rc.tileShift, ty = sy >> rc.tileShift;
+            const int32_t ts = tileSlot[ty * tilesX + tx];
+            if (ts >= 0) {
+                const int offX = tx << rc.tileShift, offY = ty << rc.tileShift;
+                g = make_int4(offX - F.border, offY - F.border, min(F.blockSize, F.width - offX) + 2 * F.border, min(F.blockSize, F.height - offY) + 2 * F.border);
+                base = (uint32_t) ts;                       /* id(k) = ((ts * sppPass + k) << 2*tileShift) | morton(pixel in block) */
+            }
+        }
+        sBase[i] = base; sGeo[i] = g;
+    }
+    __syncthreads();
+
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    unsigned long long invalid = 0;
+    const bool inside = x < F.width && y < F.height;
+    for (uint32_t k = 0; k < rc.sppPass; ++k) {
+        for (int i = threadIdx.x; i < T * T; i += BLOCK) {
+            const uint32_t base = sBase[i];
+            float2 pos = make_float2(__builtin_nanf(""), 0.0f);
+            float4 v = make_float4(0, 0, 0, 0);
+            if (base != 0xFFFFFFFFu) {
+                const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+                const int4 g = sGeo[i];
+                const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
+                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
+                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
+                pos = make_float2(px - 0.5f - (float) g.x, py - 0.5f - (float) g.y);
+                const uint32_t m = spreadBits((uint32_t) (sx - (g.x + F.border))) | (spreadBits((uint32_t) (sy - (g.y + F.border))) << 1);
+                const unsigned long long id = (((unsigned long long) base * rc.sppPass + k) << (2 * rc.tileShift)) | m;
+                v = L[id];
+                /* validity check of ImageBlock::put (imageblock.h:148-151) */
+                if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
+                    pos.x = __builtin_nanf("");
+                    /* count each rejected sample once: by the block that owns its pixel */
+                    if (sx >= x0 && sx < x0 + FILM_TILE && sy >= y0 && sy < y0 + FILM_TILE) ++invalid;
+                }
+            }
+            sPos[i] = pos; sVal[i] = v;
+        }
+        __syncthreads();
+        if (inside) {
+            for (int dyy = -R; dyy <= R; ++dyy) {
+                for (int dxx = -R; dxx <= R; ++dxx) {
+                    const int i = (ly + R + dyy) * T + (lx + R + dxx);
+                    const float2 pos = sPos[i];
+                    if (pos.x != pos.x) continue;
+                    const int4 g = sGeo[i];
+                    const int dx = x - g.x, dy = y - g.y;
+                    if (dx < 0 || dy < 0 || dx >= g.z || dy >= g.w) continue;
+                    const int minx = max((int) ceilf(pos.x - F.radius), 0), maxx = min((int) floorf(pos.x + F.radius), g.z - 1);
+                    const int miny = max((int) ceilf(pos.y - F.radius), 0), maxy = min((int) floorf(pos.y + F.radius), g.w - 1);
+                    if (dx < minx || dx > maxx || dy < miny || dy > maxy) continue;
+                    const float4 v = sVal[i];
+                    const float wx = sTable[min((int) fabsf(((float) dx - pos.x) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                    const float wy = sTable[min((int) fabsf(((float) dy - pos.y) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                    const float w = wx * wy;
+                    acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inside) {
+        float *o = out + ((size_t) y * F.width + x) * 5;
+        if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
+        else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
+    }
     if (invalid) atomicAdd(invalidCount, invalid);
 }
 
@@ -1512,8 +1612,13 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         if (timing) HIP_TRY(hipEventRecord(newEvent(evFilm), stream));
         {
             const dim3 fg((W + 15) / 16, (H + 15) / 16);
-            hipLaunchKernelGGL(k_film, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
-                               sppDone > 0 ? 1 : 0, sc->invalid.p);
+            const int reach = (int) std::floor(D.film.radius + 0.5f);
+            if (reach <= FILM_MAX_REACH && !getenv("PHIP_FILM_GENERIC"))
+                hipLaunchKernelGGL(k_film_tiled, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
+                                   sppDone > 0 ? 1 : 0, sc->invalid.p, reach);
+            else
+                hipLaunchKernelGGL(k_film, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
+                                   sppDone > 0 ? 1 : 0, sc->invalid.p);
         }
         if (timing) HIP_TRY(hipEventRecord(newEvent(evFilm), stream));
         if (keepSamples && rc.totalIds) {
