@@ -72,7 +72,7 @@ static int setErr(int code, const std::string &msg) { g_err = msg; return code; 
 #endif
 
 enum : uint32_t {
-    F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22,
+    F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22, F_DYNAMIC = 1u << 23,
     DEPTH_MASK = 0xFFFFu
 };
 
@@ -110,6 +110,10 @@ struct RenderConst {
     uint32_t seed;
     const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
     uint32_t countAlive;              /* this iteration records the number of live slots */
+    unsigned long long staticIds;     /* ids [0, staticIds) follow the static slot schedule, the rest is handed out dynamically */
+    unsigned long long shardIds;      /* dynamic ids per counter shard */
+    unsigned long long *dynCounter;   /* DYN_SHARDS counters, one 128-byte line each */
+    uint32_t *blockShard;             /* per block: the counter shard it currently draws from */
 };
 
 /* ======================================================================================
@@ -336,6 +340,8 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
 #define REFILL_LANES 16
 #endif
 #define INVALID_RAY 0xFFFFFFFFu
+#define DYN_SHARDS 8                    /* one dynamic-sample counter per XCD-sized group of blocks */
+#define DYN_STRIDE 16                   /* unsigned long longs between counters (128 B) */
 
 template <bool SHADOW, typename Source>
 __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack &stack, Source &src,
@@ -922,39 +928,87 @@ __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPo
     }
 
     /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183).
-       Static schedule: slot s renders sample ids s, s + capacity, s + 2*capacity, ... -- no global counter. ---- */
+       Sample ids [0, staticIds) follow a static schedule (slot s renders s, s + capacity, ... -- no global
+       counter in steady state).  The last part of the frame is handed out dynamically so that slots whose
+       paths happened to be short keep working until the frame is really finished: one atomicAdd per BLOCK
+       on one of DYN_SHARDS counters (block-aggregated through LDS; each shard owns a contiguous id range). ---- */
     bool nowAlive = alive && !needNew;
+    unsigned long long newId = ~0ull;
+    bool wantDyn = false;
     if (needNew) {
         unsigned long long id = (info.w & F_FRESH) ? (unsigned long long) slot      /* first sample of this slot */
-                                                   : (unsigned long long) info.x + P.capacity;
+                              : ((info.w & F_DYNAMIC) ? ~0ull : (unsigned long long) info.x + P.capacity);
         for (;;) {
-            if (id >= rc.totalIds) {
-                info = make_uint4(0, 0, 0, F_DEAD); P.info[slot] = info; break;       /* out of samples: slot dies */
-            }
+            if (id >= rc.staticIds) { wantDyn = true; break; }
             uint32_t px, py, k;
-            if (decodeId(rc, S.film, id, px, py, k)) {
-                const uint32_t pixel = py * (uint32_t) S.film.width + px;
-                const U4 h = pcg4d(pixel, k, 0, rc.seed);
-                const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
-                V3 o, d; float mint, maxt;
-                cameraRay(S.cam, sx, sy, o, d, mint, maxt);
-                P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
-                P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
-                P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                P.refN[slot] = make_float4(0, 0, 0, 0);
-                info = make_uint4((uint32_t) id, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST);
-                P.info[slot] = info;
-                nowAlive = true;
-                break;
-            }
+            if (decodeId(rc, S.film, id, px, py, k)) { newId = id; break; }
             id += P.capacity;       /* ids outside the crop window (edge blocks) are skipped */
         }
+    }
+    bool dynamicId = false;
+    {
+        const unsigned long long m = __ballot(wantDyn);
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        __syncthreads();                                   /* waveCnt is reused from the shadow compaction */
+        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) before += c; total += c; }
+        if (total) {                                       /* block-uniform */
+            __shared__ unsigned long long dynBase;
+            __shared__ uint32_t dynShard;
+            if (threadIdx.x == 0) {
+                uint32_t sh = (blockIdx.x + rc.blockShard[blockIdx.x]) % DYN_SHARDS;    /* blockShard = shards this block has seen run dry */
+                uint32_t dry = 0;
+                unsigned long long base = ~0ull;
+                for (int tries = 0; tries < DYN_SHARDS; ++tries) {
+                    const unsigned long long old = atomicAdd(rc.dynCounter + (size_t) sh * DYN_STRIDE, (unsigned long long) total);
+                    if (old < rc.shardIds) { base = old; break; }
+                    sh = (sh + 1) % DYN_SHARDS; ++dry;     /* this shard is used up: move on for good */
+                }
+                if (dry) rc.blockShard[blockIdx.x] += dry;
+                dynBase = base; dynShard = sh;
+            }
+            __syncthreads();
+            if (wantDyn) {
+                bool got = false;
+                if (dynBase != ~0ull) {
+                    const unsigned long long off = dynBase + before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+                    const unsigned long long id = rc.staticIds + (unsigned long long) dynShard * rc.shardIds + off;
+                    uint32_t px, py, k;
+                    if (off < rc.shardIds && id < rc.totalIds) {
+                        got = true;                        /* the id is consumed even if it lies outside the crop window */
+                        if (decodeId(rc, S.film, id, px, py, k)) { newId = id; dynamicId = true; }
+                    }
+                }
+                if (!got && dynBase == ~0ull) { info = make_uint4(0, 0, 0, F_DEAD); P.info[slot] = info; }   /* all shards empty: slot dies */
+                else if (newId == ~0ull) { info.w = F_DYNAMIC; P.info[slot] = info; }                        /* try again next iteration */
+            }
+        }
+    }
+    if (newId != ~0ull) {
+        uint32_t px, py, k;
+        decodeId(rc, S.film, newId, px, py, k);
+        const uint32_t pixel = py * (uint32_t) S.film.width + px;
+        const U4 h = pcg4d(pixel, k, 0, rc.seed);
+        const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+        V3 o, d; float mint, maxt;
+        cameraRay(S.cam, sx, sy, o, d, mint, maxt);
+        P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
+        P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
+        P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        P.refN[slot] = make_float4(0, 0, 0, 0);
+        info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
+        P.info[slot] = info;
+        nowAlive = true;
     }
     const uint32_t waveId = slot >> 6;
     if (inRange || (slot & ~63u) < P.capacity) {
         waveStat(P, ST_VERTICES, waveId, vertices);
         waveStat(P, ST_SAMPLES, waveId, done);
-        if (rc.countAlive) waveStat(P, ST_ALIVE, waveId, nowAlive ? 1ull : 0ull, true);
+        /* a slot still waiting for a dynamic sample id counts as live for the termination test */
+        if (rc.countAlive) waveStat(P, ST_ALIVE, waveId, (nowAlive || (inRange && info.w == F_DYNAMIC)) ? 1ull : 0ull, true);
     }
 }
 
@@ -1177,9 +1231,11 @@ namespace {
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
-    void alloc(size_t count) { release(); n = count; if (count) HIP_TRY(hipMalloc((void **) &p, count * sizeof(T))); }
+    size_t cap = 0;
+    /* hipMalloc / hipFree cost milliseconds: keep the allocation when it is large enough */
+    void alloc(size_t count) { if (count > cap) { release(); if (count) { HIP_TRY(hipMalloc((void **) &p, count * sizeof(T))); cap = count; } } n = count; }
     void upload(const T *src, size_t count) { alloc(count); if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice)); }
-    void release() { if (p) { (void) hipFree(p); p = nullptr; } n = 0; }
+    void release() { if (p) { (void) hipFree(p); p = nullptr; } n = 0; cap = 0; }
     ~DevBuf() { release(); }
 };
 
@@ -1277,10 +1333,12 @@ struct phip_scene {
     DevBuf<float4> rayO, rayD, hit, thr, refN, shadow, L, sampleOut;
     DevBuf<uint4> info;
     DevBuf<Counters> counters;
-    DevBuf<uint32_t> tileOrigin, shadowCount, spill; DevBuf<int32_t> tileSlot;
+    DevBuf<uint32_t> tileOrigin, shadowCount, spill, blockShard; DevBuf<int32_t> tileSlot;
+    DevBuf<unsigned long long> dynCounter;
     DevBuf<unsigned long long> stat;
     DevBuf<float> film; DevBuf<unsigned long long> invalid;
-    uint32_t lastSpp = 0;
+    uint32_t lastSpp = 0, nLocalTiles = 0;
+    int tileKey[3] = { -1, -1, -1 };
     bool haveSamples = false;
     std::atomic<int> cancel{ 0 };
     std::mutex renderLock;
@@ -1452,6 +1510,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     sc->descCopy.shapes = nullptr; sc->descCopy.materials = nullptr; sc->descCopy.emitters = nullptr;
     sc->counters.alloc(1);
     sc->invalid.alloc(1);
+    sc->dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
 }
 
 static size_t traversalLdsBytes(const DevScene &D) {
@@ -1495,21 +1554,25 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     const int W = D.film.width, H = D.film.height;
     int tileShift = 0; while ((1 << tileShift) < bs) ++tileShift;
 
-    /* tile -> shard assignment in the reference's spiral order */
-    std::vector<std::pair<int, int>> spiral;
-    spiralBlocks(W, H, bs, spiral);
+    /* tile -> shard assignment in the reference's spiral order (cached between calls with the same layout) */
     const int tilesX = (W + bs - 1) / bs, tilesY = (H + bs - 1) / bs;
-    std::vector<int32_t> tileSlot((size_t) tilesX * tilesY, -1);
-    std::vector<uint32_t> tileOrigin;
-    for (size_t i = 0; i < spiral.size(); ++i) {
-        if ((int) (i % (size_t) shardCount) != p->shard_index) continue;
-        tileSlot[(size_t) spiral[i].second * tilesX + spiral[i].first] = (int32_t) tileOrigin.size();
-        tileOrigin.push_back((uint32_t) (spiral[i].first * bs) | ((uint32_t) (spiral[i].second * bs) << 16));
+    if (sc->tileKey[0] != bs || sc->tileKey[1] != p->shard_index || sc->tileKey[2] != shardCount) {
+        std::vector<std::pair<int, int>> spiral;
+        spiralBlocks(W, H, bs, spiral);
+        std::vector<int32_t> tileSlot((size_t) tilesX * tilesY, -1);
+        std::vector<uint32_t> tileOrigin;
+        for (size_t i = 0; i < spiral.size(); ++i) {
+            if ((int) (i % (size_t) shardCount) != p->shard_index) continue;
+            tileSlot[(size_t) spiral[i].second * tilesX + spiral[i].first] = (int32_t) tileOrigin.size();
+            tileOrigin.push_back((uint32_t) (spiral[i].first * bs) | ((uint32_t) (spiral[i].second * bs) << 16));
+        }
+        sc->nLocalTiles = (uint32_t) tileOrigin.size();
+        if (tileOrigin.empty()) sc->tileOrigin.alloc(1);
+        else sc->tileOrigin.upload(tileOrigin.data(), tileOrigin.size());
+        sc->tileSlot.upload(tileSlot.data(), tileSlot.size());
+        sc->tileKey[0] = bs; sc->tileKey[1] = p->shard_index; sc->tileKey[2] = shardCount;
     }
-    const uint32_t nLocalTiles = (uint32_t) tileOrigin.size();
-    if (tileOrigin.empty()) sc->tileOrigin.alloc(1);
-    else sc->tileOrigin.upload(tileOrigin.data(), tileOrigin.size());
-    sc->tileSlot.upload(tileSlot.data(), tileSlot.size());
+    const uint32_t nLocalTiles = sc->nLocalTiles;
 
     hipStream_t stream = (hipStream_t) p->stream;
     if (!stream) { if (!sc->stream) HIP_TRY(hipStreamCreate(&sc->stream)); stream = sc->stream; }
@@ -1541,7 +1604,7 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     if (sc->rayO.n < capacity) {
         sc->rayO.alloc(capacity); sc->rayD.alloc(capacity); sc->hit.alloc(capacity); sc->thr.alloc(capacity);
         sc->refN.alloc(capacity); sc->info.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
-        sc->shadowCount.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
+        sc->shadowCount.alloc(nBlocks); sc->blockShard.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
         sc->spill8.alloc((size_t) nWaves * 8 * SPILL8);
     }
     PathPool P;
@@ -1571,6 +1634,18 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         rc.totalIds = idsPerSpp * rc.sppPass;
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
         rc.seed = p->seed; rc.tileOrigin = sc->tileOrigin.p; rc.countAlive = 0;
+        /* static share: the first 3/4 of every slot's samples; the remainder is handed out dynamically */
+        {
+            const unsigned long long perSlot = rc.totalIds / capacity;
+            unsigned long long staticPerSlot = perSlot - perSlot / 4;
+            if (const char *e = getenv("PHIP_STATIC_PERCENT")) staticPerSlot = perSlot * (unsigned long long) atoi(e) / 100;
+            rc.staticIds = staticPerSlot * capacity;
+            const unsigned long long dyn = rc.totalIds - rc.staticIds;
+            rc.shardIds = (dyn + DYN_SHARDS - 1) / DYN_SHARDS;
+            rc.dynCounter = sc->dynCounter.p; rc.blockShard = sc->blockShard.p;
+            HIP_TRY(hipMemsetAsync(sc->blockShard.p, 0, nBlocks * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(sc->dynCounter.p, 0, DYN_SHARDS * DYN_STRIDE * sizeof(unsigned long long), stream));
+        }
 
         HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
         HIP_TRY(hipMemsetAsync(sc->stat.p, 0, (size_t) ST_COUNT * nWaves * sizeof(unsigned long long), stream));
@@ -1578,6 +1653,8 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) sc->info.p, (int) F_FRESH, (size_t) capacity * 4, stream));
         if (rc.totalIds) HIP_TRY(hipMemsetAsync(sc->L.p, 0, (size_t) rc.totalIds * sizeof(float4), stream));
 
+        HIP_TRY(hipStreamSynchronize(stream));
+        const auto tLoop0 = clk::now();
         uint32_t iter = 0;
         bool done = rc.totalIds == 0;
         while (!done) {
@@ -1608,6 +1685,8 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         }
         HIP_TRY(hipGetLastError());
         st.iterations += iter;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "[phip] setup %.2f ms, loop %.2f ms (%u iterations)\n", std::chrono::duration<double, std::milli>(tLoop0 - t0).count(), std::chrono::duration<double, std::milli>(clk::now() - tLoop0).count(), iter);
         /* film */
         if (timing) HIP_TRY(hipEventRecord(newEvent(evFilm), stream));
         {
