@@ -43,6 +43,19 @@ def build_desc(workload, spp_scale=1):
     return sb.desc(), w, h, spp * spp_scale, md, sb.n_triangles
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_traffic.py), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*%s*.json" % workload)), reverse=True):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+            if k:
+                return round(k["hbm_bytes_per_launch"], 1)
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(workload, seconds_target=15.0):
     """CPU oracle on a bounded sample of the same workload: same scene/film/integrator, reduced spp."""
     from mitsuba_amd import _abi as A
@@ -98,6 +111,9 @@ def main():
     if args.spp:
         spp = args.spp * world
     scene = Scene(desc, device=local)
+    accel = scene.accel_info().as_dict()
+    # the closest-hit kernel that runs for this scene (trees under 64 nodes use the per-slot launch)
+    trace_kernel = "k_trace_p" if accel["n_nodes"] >= 64 else "k_trace"
     integ = PathHIP(maxDepth=md)
     film = torch.zeros((H, W, 5), dtype=torch.float32, device=dev)
     flags = A.PHIP_FLAG_KERNEL_TIMING
@@ -142,9 +158,11 @@ def main():
                                  D.sum_over_ranks(agg["closest_rays"] + agg["shadow_rays"], dev) / 1e6 / dt, 1),
             "mean_path_length": round(agg["path_vertices"] / max(agg["samples"], 1), 3),
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace (closest-hit BVH2 traversal)",
+                "bound": "hbm", "kernel": trace_kernel + " (closest-hit BVH4 traversal, %d nodes of 128 B, 48-B Wald records)" % accel["n_nodes"],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload, trace_kernel),
+                "note": "achieved = ALGORITHMIC bytes (node + record fetches, ray in, hit out) / HIP-event kernel time; most of them are served by L1/L2/Infinity Cache, "
+                        "traffic = PMC-measured HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated; profiles/)",
                 "algorithmic_bytes_per_launch": round(agg["trace_kernel_bytes"] / launches, 1),
                 "avg_launch_ms": round(trace_ms / launches, 5), "launches": launches,
                 "whole_job_algorithmic_GBs": round(agg["algorithmic_bytes"] / 1e9 / dt, 2),

@@ -160,3 +160,34 @@ extern "C" int phip_debug_fmath(int on_device, int op, size_t n, const float *a,
         return PHIP_OK;
     } catch (const std::exception &e) { return setErr(PHIP_ERR_DEVICE, e.what()); }
 }
+
+/* PMC calibration (MI355X_MICROARCH.md, HBM section: FETCH_SIZE is uncalibrated for non-streaming access):
+ * n lanes each gather one float4 from a pseudo-random index of a buffer far larger than the 256 MiB
+ * Infinity Cache, and n lanes stream-write one float4.  Every gather misses all caches, so the HBM read
+ * traffic is n x (line size) and the write traffic n x 16 B: comparing that with FETCH_SIZE / WRITE_SIZE of
+ * this kernel gives the correction factors for the traversal kernels' access pattern. */
+__global__ void k_debug_gather(const float4 *src, size_t nSrc, float4 *dst, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const U4 h = pcg4d((uint32_t) i, (uint32_t) (i >> 32), 12345u, 7u);
+    const size_t j = (((size_t) h.x << 32) | h.y) % nSrc;
+    dst[i] = src[j];
+}
+__global__ void k_debug_stream(const float4 *src, float4 *dst, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+extern "C" int phip_debug_pmc_calibration(size_t src_bytes, size_t n) {
+    try {
+        DevBuf<float4> src, dst;
+        src.alloc(src_bytes / 16); dst.alloc(n);
+        HIP_TRY(hipMemset(src.p, 0, src_bytes));
+        HIP_TRY(hipMemset(dst.p, 0, n * 16));
+        HIP_TRY(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_debug_gather, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, (const float4 *) src.p, src_bytes / 16, dst.p, n);
+        hipLaunchKernelGGL(k_debug_stream, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, (const float4 *) src.p, dst.p, n);
+        HIP_TRY(hipDeviceSynchronize());
+        return PHIP_OK;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_DEVICE, e.what()); }
+}
