@@ -377,47 +377,45 @@ struct BSDFSample { V3 wo; float eta; float pdf; bool delta; };
 
 DV V3 rgb(const float *p) { return V3(p[0], p[1], p[2]); }
 
-/* one-sided leaf models; wi.z sign already resolved by the twosided adapter */
-DV V3 leafEval(const DevMaterial &M, const V3 &wi, const V3 &wo) {
+/* Which leaf models a scene contains: k_shade is instantiated per mask so that a diffuse-only scene does
+   not carry (and fetch through the instruction cache) the microfacet and dielectric code. */
+enum { MM_ROUGH = 1, MM_DIELECTRIC = 2, MM_ALL = 3 };
+
+/* one-sided leaf models; wi.z sign already resolved by the twosided adapter.
+   leafEvalPdf = eval() and pdf() of the same (wi, wo) pair in one pass (diffuse.cpp:110-133,
+   roughconductor.cpp:253-337): the two share H, D and G1(wi). */
+template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &wi, const V3 &wo, float &pdf) {
+    pdf = 0.0f;
     if (M.type == PHIP_BSDF_DIFFUSE) {
         if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
+        pdf = PT_INV_PI * cosTheta(wo);
         return rgb(M.refl) * (PT_INV_PI * cosTheta(wo));
-    } else if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
+    } else if ((MM & MM_ROUGH) && M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
         V3 H = normalize(wo + wi);
         MF distr(M);
         const float D = distr.eval(H);
+        const float G1i = distr.smithG1(wi, H);
+        if (M.sampleVisible)
+            pdf = D * G1i / (4.0f * cosTheta(wi));
+        else
+            pdf = (D * cosTheta(H)) / (4 * absDot(wo, H));
         if (D == 0) return V3(0.0f);
         const V3 F = fresnelConductorExact(dot(wi, H), rgb(M.eta), rgb(M.k)) * rgb(M.refl);
-        const float G = distr.G(wi, wo, H);
+        const float G = G1i * distr.smithG1(wo, H);
         float model = D * G / (4.0f * cosTheta(wi));
         return F * model;
     }
     return V3(0.0f);
 }
-DV float leafPdf(const DevMaterial &M, const V3 &wi, const V3 &wo) {
-    if (M.type == PHIP_BSDF_DIFFUSE) {
-        if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0f;
-        return PT_INV_PI * cosTheta(wo);
-    } else if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
-        if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return 0.0f;
-        V3 H = normalize(wo + wi);
-        MF distr(M);
-        if (M.sampleVisible)
-            return distr.eval(H) * distr.smithG1(wi, H) / (4.0f * cosTheta(wi));
-        else
-            return distr.pdf(wi, H) / (4 * absDot(wo, H));
-    }
-    return 0.0f;
-}
-DV V3 leafSample(const DevMaterial &M, const V3 &wi, const V2 &smp, BSDFSample &bs) {
+template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &wi, const V2 &smp, BSDFSample &bs) {
     bs.eta = 1.0f; bs.delta = false; bs.pdf = 0.0f; bs.wo = V3(0.0f);
     if (M.type == PHIP_BSDF_DIFFUSE) {
         if (cosTheta(wi) <= 0) return V3(0.0f);
         bs.wo = squareToCosineHemisphere(smp);
         bs.pdf = PT_INV_PI * cosTheta(bs.wo);
         return rgb(M.refl);
-    } else if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
+    } else if ((MM & MM_ROUGH) && M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         if (cosTheta(wi) < 0) return V3(0.0f);
         MF distr(M);
         float pdf;
@@ -432,7 +430,7 @@ DV V3 leafSample(const DevMaterial &M, const V3 &wi, const V2 &smp, BSDFSample &
         pdf /= 4.0f * dot(bs.wo, m);
         bs.pdf = pdf;
         return F * weight;
-    } else if (M.type == PHIP_BSDF_DIELECTRIC) {
+    } else if ((MM & MM_DIELECTRIC) && M.type == PHIP_BSDF_DIELECTRIC) {
         const float eta = M.eta[0], invEta = 1 / eta;
         float cosThetaT;
         float F = fresnelDielectricExt(cosTheta(wi), cosThetaT, eta);
@@ -453,33 +451,40 @@ DV V3 leafSample(const DevMaterial &M, const V3 &wi, const V2 &smp, BSDFSample &
     return V3(0.0f);
 }
 
-/* dispatch incl. the twosided adapter (twosided.cpp:108-183) */
-DV V3 bsdfEval(const DevScene &S, const DevMaterial &M, V3 wi, V3 wo) {
+/* The twosided adapter (twosided.cpp:108-183) resolved ONCE per path vertex: eval, pdf and sample of a
+   vertex all see the same wi, so they share the nested model and the flip.  (eval/pdf pick nested0 for
+   cosTheta(wi) > 0 and sample for cosTheta(wi) >= 0; at exactly 0 every wrapped model's eval/pdf is zero
+   on either side, so one rule serves all three.) */
+struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip; };
+DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
+    BsdfCtx c; c.leaf = &M; c.wi = wi; c.flip = false;
     if (M.type == PHIP_BSDF_TWOSIDED) {
-        if (cosTheta(wi) > 0) return leafEval(S.materials[M.nested0], wi, wo);
-        wi.z *= -1; wo.z *= -1;
-        return leafEval(S.materials[M.nested1], wi, wo);
+        c.flip = cosTheta(wi) < 0;
+        c.leaf = S.materials + (c.flip ? M.nested1 : M.nested0);
+        if (c.flip) c.wi.z = -wi.z;
     }
-    return leafEval(M, wi, wo);
+    return c;
+}
+template <int MM> DV V3 bsdfEvalPdf(const BsdfCtx &c, V3 wo, float &pdf) {
+    if (c.flip) wo.z = -wo.z;
+    return leafEvalPdf<MM>(*c.leaf, c.wi, wo, pdf);
+}
+template <int MM> DV V3 bsdfSample(const BsdfCtx &c, const V2 &smp, BSDFSample &bs) {
+    V3 result = leafSample<MM>(*c.leaf, c.wi, smp, bs);
+    if (c.flip && !result.isZero() && bs.pdf != 0)
+        bs.wo.z = -bs.wo.z;
+    return result;
+}
+
+/* BSDF::eval / pdf / sample as the reference exposes them (host-side unit tests) */
+DV V3 bsdfEval(const DevScene &S, const DevMaterial &M, V3 wi, V3 wo) {
+    float pdf; return bsdfEvalPdf<MM_ALL>(bsdfResolve(S, M, wi), wo, pdf);
 }
 DV float bsdfPdf(const DevScene &S, const DevMaterial &M, V3 wi, V3 wo) {
-    if (M.type == PHIP_BSDF_TWOSIDED) {
-        if (wi.z > 0) return leafPdf(S.materials[M.nested0], wi, wo);
-        wi.z *= -1; wo.z *= -1;
-        return leafPdf(S.materials[M.nested1], wi, wo);
-    }
-    return leafPdf(M, wi, wo);
+    float pdf; bsdfEvalPdf<MM_ALL>(bsdfResolve(S, M, wi), wo, pdf); return pdf;
 }
 DV V3 bsdfSample(const DevScene &S, const DevMaterial &M, V3 wi, const V2 &smp, BSDFSample &bs) {
-    if (M.type == PHIP_BSDF_TWOSIDED) {
-        bool flipped = false;
-        if (cosTheta(wi) < 0) { wi.z *= -1; flipped = true; }
-        V3 result = leafSample(S.materials[flipped ? M.nested1 : M.nested0], wi, smp, bs);
-        if (flipped && !result.isZero() && bs.pdf != 0)
-            bs.wo.z *= -1;
-        return result;
-    }
-    return leafSample(M, wi, smp, bs);
+    return bsdfSample<MM_ALL>(bsdfResolve(S, M, wi), smp, bs);
 }
 
 /* perspective.cpp:271-297 */

@@ -786,7 +786,10 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
-__global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+#ifndef SHADE_WAVES_LEAN
+#define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
+#endif
+template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
@@ -876,13 +879,14 @@ __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPo
                 dRec.ref = its.p;
                 dRec.refN = (mat.flags & MF_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
                 dRec.pdf = 0; dRec.emitter = -1;
+                const BsdfCtx bctx = bsdfResolve(S, mat, its.wi);
                 if (mat.flags & MF_SMOOTH) {
                     V3 value = sampleEmitterDirect(S, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
                     if (dRec.pdf != 0 && !value.isZero()) {
                         const V3 wo = its.sh.toLocal(dRec.d);
-                        const V3 bsdfVal = bsdfEval(S, mat, its.wi, wo);
+                        float bPdf;
+                        const V3 bsdfVal = bsdfEvalPdf<MM>(bctx, wo, bPdf);
                         if (!bsdfVal.isZero() && (!rc.strictNormals || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
-                            const float bPdf = bsdfPdf(S, mat, its.wi, wo);
                             const float weight = miWeight(dRec.pdf, bPdf);
                             shC = thr * value * bsdfVal * weight;
                             shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
@@ -892,7 +896,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade(DevScene S, PathPo
                 }
                 /* ---- BSDF sampling, path.cpp:207-226 ---- */
                 BSDFSample bs;
-                const V3 bsdfWeight = bsdfSample(S, mat, its.wi, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
+                const V3 bsdfWeight = bsdfSample<MM>(bctx, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
                 if (bsdfWeight.isZero()) {
                     terminate = true;
                 } else {
@@ -1357,6 +1361,7 @@ struct phip_scene {
     uint32_t lastSpp = 0, nLocalTiles = 0;
     int tileKey[3] = { -1, -1, -1 };
     bool haveSamples = false;
+    int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
     std::atomic<int> cancel{ 0 };
     std::mutex renderLock;
     hipStream_t stream = nullptr;
@@ -1495,6 +1500,12 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     sc->triVerts.upload(tv.data(), tv.size());
     sc->shapes.upload(shapes.data(), shapes.size());
     sc->materials.upload(mats.data(), mats.size());
+    sc->materialMask = 0;
+    for (const DevMaterial &m : mats) {
+        if (m.type == PHIP_BSDF_ROUGHCONDUCTOR) sc->materialMask |= MM_ROUGH;
+        if (m.type == PHIP_BSDF_DIELECTRIC) sc->materialMask |= MM_DIELECTRIC;
+    }
+    if (const char *e = getenv("PHIP_SHADE_GENERIC")) if (atoi(e)) sc->materialMask = MM_ALL;
     sc->emitters.upload(ems.data(), ems.size());
     sc->areaCdf.upload(areaCdf.data(), areaCdf.size());
     sc->emitterCdf.upload(ecdf.data(), ecdf.size());
@@ -1598,7 +1609,8 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     /* passes: bound the per-sample buffer (16 B per sample id) */
     const unsigned long long tilePixels = (unsigned long long) bs * bs;
     const unsigned long long maxIdsPerPass = (1ull << 32) - 1;                 /* sample ids are 32-bit in the slot state */
-    const unsigned long long budgetIds = (24ull << 30) / 16;                  /* 24 GiB of sample buffer */
+    unsigned long long budgetIds = (24ull << 30) / 16;                        /* 24 GiB of sample buffer */
+    if (const char *e = getenv("PHIP_MAX_PASS_SAMPLES")) budgetIds = std::max(1ull, strtoull(e, nullptr, 10));   /* test hook: force several passes */
     unsigned long long idsPerSpp = (unsigned long long) nLocalTiles * tilePixels;
     uint32_t sppPerPass = (uint32_t) p->spp;
     if (idsPerSpp > 0) {
@@ -1679,7 +1691,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
             rc.countAlive = check ? 1 : 0;
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
-            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, D, P, rc, sc->L.p);
+            switch (sc->materialMask) {
+                case 0: hipLaunchKernelGGL(k_shade<0>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
+                case MM_ROUGH: hipLaunchKernelGGL(k_shade<MM_ROUGH>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
+                case MM_DIELECTRIC: hipLaunchKernelGGL(k_shade<MM_DIELECTRIC>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
+                default: hipLaunchKernelGGL(k_shade<MM_ALL>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
+            }
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
             if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sc->L.p);
