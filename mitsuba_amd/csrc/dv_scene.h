@@ -2,14 +2,12 @@
  * dv_scene.h -- device-resident scene layout and the per-vertex shading functions of path_hip.
  *
  * HBM layout (all arrays are immutable after phip_scene_create):
- *   nodes      float4[4*nNodes]    64-byte BVH2 nodes, both child boxes per node (bvh.h)
+ *   nodes      float4[8*nNodes]    128-byte BVH4 nodes, SoA over the four children (bvh.h)
  *   tris       float4[3*nTriRefs]  48-byte Wald triangle records in leaf order
- *   triVerts   uint4[nTriangles]   (v0, v1, v2, shape) per GLOBAL triangle id
- *   positions  float4[nVertices]   xyz + pad  (one 16-byte load per vertex)
- *   normals    float4[nVertices]   xyz + pad  (or null)
- *   shapes / materials / emitters  small tables
- *   areaCdf    float[...]          per-emitter-shape area CDFs (pmf.h layout, n+1 entries)
- *   emitterCdf float[nEmitters+1]
+ *   triShade   float4[6*nTriangles] 96-byte shading record per GLOBAL triangle id (vertices, leaf
+ *                                  BSDF ids, emitter id, flat-shading frame or vertex normals)
+ *   materials  DevMaterial[]       80 bytes each; staged in LDS by k_shade when there are few
+ *   emitterTab float[]             selection CDF + emitter records + area CDFs (EmitterTab), LDS-staged when small
  *
  * Functions restate (file:line under /root/reference) -- same arithmetic as oracle/, written
  * independently for the device:
@@ -59,10 +57,9 @@ struct DevFilm {
 };
 
 struct DevScene {
-    const float4 *nodes; const float4 *nodes8; const float4 *tris; const uint4 *triVerts;
-    const float4 *positions; const float4 *normals;
-    const DevShape *shapes; const DevMaterial *materials; const DevEmitter *emitters;
-    const float *areaCdf; const float *emitterCdf;
+    const float4 *nodes; const float4 *nodes8; const float4 *tris; const float4 *triShade;
+    const DevMaterial *materials; uint32_t nMaterials;
+    const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;
     int32_t rootRef, rootRef8; uint32_t nTriangles;
     uint32_t stackDepth, nodeCache, triCache;   /* LDS staging plan of the traversal kernels */
@@ -70,40 +67,64 @@ struct DevScene {
     DevCamera cam; DevFilm film;
 };
 
+/* Shading record of one triangle: 96 B = 6 x float4, indexed by the global triangle id
+ * (Intersection::primIndex).  Everything k_shade needs about a hit in ONE dependent fetch instead of
+ * the chain index -> vertices -> shape -> material -> nested material:
+ *   r0 = (p0, frontLeaf)  r1 = (p1, backLeaf)  r2 = (p2, emitter)
+ *   flat shading:   r3 = (face normal, flags)  r4 = (frame.s, -)  r5 = (frame.t, -)   -- constant per triangle,
+ *                   computed on the host by the very functions below (same IEEE operations, same bits)
+ *   vertex normals: r3 = (n0, flags)           r4 = (n1, -)       r5 = (n2, -)
+ * frontLeaf/backLeaf = the one-sided model seen from either side (the twosided adapter's nested ids, or
+ * the material itself twice). */
+enum { TS_VERTEX_NORMALS = 1, TS_TWOSIDED = 2, TS_MF_SMOOTH = 4, TS_TRANS_OR_BACK = 8 };
+#define TRISHADE_FLOAT4S 6
+
 struct Isect {
-    V3 p; Frame sh; V3 geoN; V3 wi; float t; uint32_t shape; uint32_t prim;
+    V3 p; Frame sh; V3 geoN; V3 wi; float t; uint32_t prim;
+    uint32_t front, back, flags; int32_t emitter;
 };
 
 DV V3 ld3(const float4 *a, uint32_t i) { float4 v = a[i]; return V3(v.x, v.y, v.z); }
+DV V3 xyz(const float4 &v) { return V3(v.x, v.y, v.z); }
 
-/* skdtree.h:343-428 with BarycentricPos = true, no UV tangents, no texcoords */
-DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float cu, float cv, float t, Isect &its) {
-    const uint4 tv = S.triVerts[prim];
-    const DevShape &sh = S.shapes[tv.w];
-    const V3 b(1 - cu - cv, cu, cv);
-    const V3 p0 = ld3(S.positions, tv.x), p1 = ld3(S.positions, tv.y), p2 = ld3(S.positions, tv.z);
-    its.p = p0 * b.x + p1 * b.y + p2 * b.z;
-    V3 side1(p1 - p0), side2(p2 - p0);
+/* face normal of skdtree.h:367-373 (left unnormalised when it is zero) */
+DV V3 triFaceNormal(const V3 &side1, const V3 &side2) {
     V3 faceNormal(cross(side1, side2));
     float length = faceNormal.length();
     if (!faceNormal.isZero())
         faceNormal = faceNormal / length;
-    V3 shN;
-    if (sh.hasNormals) {
-        const V3 n0 = ld3(S.normals, tv.x), n1 = ld3(S.normals, tv.y), n2 = ld3(S.normals, tv.z);
-        shN = normalize(n0 * b.x + n1 * b.y + n2 * b.z);
+    return faceNormal;
+}
+/* computeShadingFrame(n, dpdu = side1), util.cpp:603-608 */
+DV void triShadingFrame(const V3 &shN, const V3 &side1, Frame &f) {
+    f.n = shN;
+    f.s = normalize(side1 - shN * dot(shN, side1));
+    f.t = cross(shN, f.s);
+}
+
+/* skdtree.h:343-428 with BarycentricPos = true, no UV tangents, no texcoords */
+DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float cu, float cv, float t, Isect &its) {
+    const float4 *r = S.triShade + (size_t) TRISHADE_FLOAT4S * prim;
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+    const V3 b(1 - cu - cv, cu, cv);
+    const V3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
+    its.p = p0 * b.x + p1 * b.y + p2 * b.z;
+    its.front = pm_to_bits(r0.w); its.back = pm_to_bits(r1.w); its.emitter = (int32_t) pm_to_bits(r2.w);
+    its.flags = pm_to_bits(r3.w);
+    if (its.flags & TS_VERTEX_NORMALS) {
+        const V3 side1(p1 - p0), side2(p2 - p0);
+        V3 faceNormal = triFaceNormal(side1, side2);
+        const V3 shN = normalize(xyz(r3) * b.x + xyz(r4) * b.y + xyz(r5) * b.z);
         if (dot(faceNormal, shN) < 0)
             faceNormal = -faceNormal;
+        its.geoN = faceNormal;
+        triShadingFrame(shN, side1, its.sh);
     } else {
-        shN = faceNormal;
+        its.geoN = xyz(r3);
+        its.sh.n = its.geoN; its.sh.s = xyz(r4); its.sh.t = xyz(r5);
     }
-    its.geoN = faceNormal;
-    /* computeShadingFrame(n, dpdu = side1), util.cpp:603-608 */
-    its.sh.n = shN;
-    its.sh.s = normalize(side1 - shN * dot(shN, side1));
-    its.sh.t = cross(shN, its.sh.s);
     its.wi = its.sh.toLocal(-rayD);
-    its.t = t; its.shape = tv.w; its.prim = prim;
+    its.t = t; its.prim = prim;
 }
 
 /* triaccel.h:96-158 on a 48-byte record */
@@ -147,24 +168,36 @@ struct DirectRec {
     V3 p, n, d, ref, refN; float dist, pdf; int emitter; int solidAngle;
 };
 
+/* Emitter table: everything direct-illumination sampling looks up, packed into ONE float array so that
+ * k_shade can stage it in LDS when it is small (the lookups are a chain of dependent loads:
+ * selection CDF -> emitter -> area CDF of its mesh -> triangle):
+ *   t[0 .. n]                     emitter selection CDF (pmf.h layout, n + 1 entries)
+ *   t[n + 1 + 8 e .. + 7]         emitter e: radiance rgb, samplingWeight, firstTri, nTris, cdfOffset (index into t), 1 / surface area
+ *   t[cdfOffset .. + nTris]       area CDF of the emitter's mesh (trimesh.cpp:388-404) */
+struct EmitterTab { const float *t; uint32_t n; float normalization; };
+enum { EM_RADIANCE = 0, EM_WEIGHT = 3, EM_FIRST_TRI = 4, EM_N_TRIS = 5, EM_CDF = 6, EM_INV_AREA = 7, EM_STRIDE = 8 };
+DV const float *emitterRecord(const EmitterTab &T, uint32_t e) { return T.t + (T.n + 1) + EM_STRIDE * e; }
+
 /* trimesh.cpp:412-423 + triangle.cpp:24-59 + shape.cpp:102-115 */
-DV void shapeSampleDirect(const DevScene &S, const DevShape &sh, DirectRec &dRec, V2 sample) {
-    const float *cdf = S.areaCdf + sh.cdfOffset;
-    uint32_t index = cdfSample(cdf, sh.nTris, sample.y);
+DV void shapeSampleDirect(const DevScene &S, const EmitterTab &T, const float *em, DirectRec &dRec, V2 sample) {
+    const float *cdf = T.t + pm_to_bits(em[EM_CDF]);
+    uint32_t index = cdfSample(cdf, pm_to_bits(em[EM_N_TRIS]), sample.y);
     sample.y = (sample.y - cdf[index]) / (cdf[index + 1] - cdf[index]);
-    const uint32_t tri = sh.firstTri + index;
-    const uint4 tv = S.triVerts[tri];
-    const V3 p0 = ld3(S.positions, tv.x), p1 = ld3(S.positions, tv.y), p2 = ld3(S.positions, tv.z);
+    const float4 *r = S.triShade + (size_t) TRISHADE_FLOAT4S * (pm_to_bits(em[EM_FIRST_TRI]) + index);
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    const V3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
     V2 bary = squareToUniformTriangle(sample);
     V3 sideA = p1 - p0, sideB = p2 - p0;
     dRec.p = p0 + (sideA * bary.x) + (sideB * bary.y);
-    if (sh.hasNormals) {
-        const V3 n0 = ld3(S.normals, tv.x), n1 = ld3(S.normals, tv.y), n2 = ld3(S.normals, tv.z);
+    if (pm_to_bits(r3.w) & TS_VERTEX_NORMALS) {
+        const V3 n0 = xyz(r3), n1 = xyz(r[4]), n2 = xyz(r[5]);
         dRec.n = normalize(n0 * (1.0f - bary.x - bary.y) + n1 * bary.x + n2 * bary.y);
     } else {
-        dRec.n = normalize(cross(sideA, sideB));
+        /* normalize(cross(sideA, sideB)) == the stored face normal, operation for operation (a triangle
+           of zero area is never selected: its CDF step is empty) */
+        dRec.n = xyz(r3);
     }
-    dRec.pdf = sh.invSurfaceArea;
+    dRec.pdf = em[EM_INV_AREA];
     dRec.d = dRec.p - dRec.ref;
     float distSquared = dRec.d.lengthSquared();
     dRec.dist = sqrtf(distSquared);
@@ -176,16 +209,16 @@ DV void shapeSampleDirect(const DevScene &S, const DevShape &sh, DirectRec &dRec
 
 /* scene.cpp:828-852 without the visibility test (the shadow ray is traced by the wavefront),
    area.cpp:158-173.  Returns value (radiance/pdf/emPdf); dRec.pdf == 0 means "no sample". */
-DV V3 sampleEmitterDirect(const DevScene &S, DirectRec &dRec, V2 sample) {
-    if (S.nEmitters == 0) { dRec.pdf = 0; return V3(0.0f); }
-    uint32_t index = cdfSample(S.emitterCdf, S.nEmitters, sample.x);
-    float emPdf = S.emitterCdf[index + 1] - S.emitterCdf[index];
-    sample.x = (sample.x - S.emitterCdf[index]) / (S.emitterCdf[index + 1] - S.emitterCdf[index]);
-    const DevEmitter &em = S.emitters[index];
-    shapeSampleDirect(S, S.shapes[em.shape], dRec, sample);
+DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRec, V2 sample) {
+    if (T.n == 0) { dRec.pdf = 0; return V3(0.0f); }
+    uint32_t index = cdfSample(T.t, T.n, sample.x);
+    float emPdf = T.t[index + 1] - T.t[index];
+    sample.x = (sample.x - T.t[index]) / (T.t[index + 1] - T.t[index]);
+    const float *em = emitterRecord(T, index);
+    shapeSampleDirect(S, T, em, dRec, sample);
     V3 value;
     if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
-        value = V3(em.radiance[0], em.radiance[1], em.radiance[2]) / dRec.pdf;
+        value = V3(em[EM_RADIANCE], em[EM_RADIANCE + 1], em[EM_RADIANCE + 2]) / dRec.pdf;
     } else {
         dRec.pdf = 0.0f;
         return V3(0.0f);
@@ -197,16 +230,16 @@ DV V3 sampleEmitterDirect(const DevScene &S, DirectRec &dRec, V2 sample) {
 }
 
 /* scene.cpp:949-952, scene.h:848-850, area.cpp:175-182, shape.cpp:117-126 (solid-angle measure) */
-DV float pdfEmitterDirect(const DevScene &S, const DirectRec &dRec) {
-    const DevEmitter &em = S.emitters[dRec.emitter];
+DV float pdfEmitterDirect(const EmitterTab &T, const DirectRec &dRec) {
+    const float *em = emitterRecord(T, (uint32_t) dRec.emitter);
     float pdf;
     if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
-        float pdfPos = S.shapes[em.shape].invSurfaceArea;
+        float pdfPos = em[EM_INV_AREA];
         pdf = pdfPos * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
     } else {
         pdf = 0.0f;
     }
-    return pdf * (em.samplingWeight * S.emitterNormalization);
+    return pdf * (em[EM_WEIGHT] * T.normalization);
 }
 
 /* ======================================================================================
@@ -463,6 +496,14 @@ DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
         c.leaf = S.materials + (c.flip ? M.nested1 : M.nested0);
         if (c.flip) c.wi.z = -wi.z;
     }
+    return c;
+}
+/* same, from a shading record (front/back already are the nested models) */
+DV BsdfCtx bsdfResolve(const DevMaterial *materials, const Isect &its) {
+    BsdfCtx c; c.wi = its.wi;
+    c.flip = (its.flags & TS_TWOSIDED) && cosTheta(its.wi) < 0;
+    c.leaf = materials + (c.flip ? its.back : its.front);
+    if (c.flip) c.wi.z = -its.wi.z;
     return c;
 }
 template <int MM> DV V3 bsdfEvalPdf(const BsdfCtx &c, V3 wo, float &pdf) {

@@ -104,6 +104,7 @@ struct Counters {
 struct RenderConst {
     unsigned long long totalIds;      /* ids in this pass = nLocalTiles * sppPass * tilePixels */
     uint32_t sppPass, sppFirst;       /* samples in this pass, first sample index of the pass */
+    uint32_t sppMagic;                /* min(floor(2^32 / sppPass), 2^32 - 1): division by sppPass = one mulhi + one correction */
     uint32_t tilePixels, tileShift;   /* blockSize^2, log2(blockSize) */
     uint32_t nLocalTiles;
     int maxDepth, rrDepth, strictNormals, hideEmitters;
@@ -141,9 +142,10 @@ __host__ __device__ __forceinline__ uint32_t spreadBits(uint32_t x) {
 __device__ __forceinline__ bool decodeId(const RenderConst &rc, const DevFilm &film, unsigned long long id,
                                          uint32_t &px, uint32_t &py, uint32_t &k) {
     const uint32_t m = (uint32_t) (id & (rc.tilePixels - 1));
-    const unsigned long long r = id >> (2 * rc.tileShift);
-    k = (uint32_t) (r % rc.sppPass);
-    const uint32_t tile = (uint32_t) (r / rc.sppPass);
+    const uint32_t r = (uint32_t) (id >> (2 * rc.tileShift));   /* ids of a pass are < 2^32 */
+    uint32_t tile = __umulhi(r, rc.sppMagic);                  /* floor(r / sppPass) or one less */
+    k = r - tile * rc.sppPass;
+    if (k >= rc.sppPass) { k -= rc.sppPass; ++tile; }
     const uint32_t org = rc.tileOrigin[tile];
     px = (org & 0xFFFFu) + compactBits(m);
     py = (org >> 16) + compactBits(m >> 1);
@@ -786,22 +788,37 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
+#define EMITTER_LDS_FLOATS 1024      /* 4 KB */
+#define MATERIAL_LDS_MAX 48          /* 3.75 KB */
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
 #endif
 template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
+    /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
+       dependent lookups per NEE sample) and the materials */
+    __shared__ float ldsEm[EMITTER_LDS_FLOATS];
+    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
+    const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
+    if (emInLds) for (uint32_t i = threadIdx.x; i < S.emitterTabSize; i += BLOCK) ldsEm[i] = S.emitterTab[i];
+    if (matInLds) {
+        const uint32_t n4 = S.nMaterials * (uint32_t) (sizeof(DevMaterial) / 16);
+        for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) ((float4 *) ldsMat)[i] = ((const float4 *) S.materials)[i];
+    }
+    EmitterTab T; T.t = emInLds ? ldsEm : S.emitterTab; T.n = S.nEmitters; T.normalization = S.emitterNormalization;
+    const DevMaterial *materials = matInLds ? ldsMat : S.materials;
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
-    /* all slot state is fetched up front, before the liveness test, so that the six 16-byte loads are
+    /* all slot state is fetched up front, before the liveness test, so that the five 16-byte loads are
        in flight together (the kernel is latency bound: 70 % of its wave cycles were s_waitcnt) */
     const uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
     const float4 hit = P.hit[lslot];
-    const float4 ro = P.rayO[lslot], rd = P.rayD[lslot];
+    const float4 rd = P.rayD[lslot];
     float4 thr4 = P.thr[lslot];
     const float4 rn = P.refN[lslot];
     if (!inRange) info = make_uint4(0, 0, 0, 0);
+    __syncthreads();                                            /* LDS tables are complete */
     bool alive = inRange && (info.w & F_ALIVE);
     bool needNew = inRange && !alive && !(info.w & F_DEAD);
     unsigned long long vertices = 0, done = 0;
@@ -825,21 +842,19 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
         } else {
             Isect its;
             fillIntersection(S, rayD, prim, hit.y, hit.z, hit.x, its);
-            const DevShape &shp = S.shapes[its.shape];
-            const DevMaterial &mat = S.materials[shp.material];
             l = L[id];
             if (flags & F_FIRST) {
                 l.w = 1.0f;                     /* alpha, records.inl:117-144 */
                 haveAdd = true;
             } else {
                 /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
-                if (shp.emitter >= 0) {
-                    const DevEmitter &em = S.emitters[shp.emitter];
-                    V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em.radiance);
-                    DirectRec dRec;
-                    dRec.ref = V3(ro.x, ro.y, ro.z); dRec.refN = V3(rn.x, rn.y, rn.z);
-                    dRec.p = its.p; dRec.n = its.sh.n; dRec.d = rayD; dRec.dist = its.t; dRec.emitter = shp.emitter; dRec.solidAngle = 1;
-                    const float lumPdf = (!(flags & F_PREV_DELTA)) ? pdfEmitterDirect(S, dRec) : 0;
+                if (its.emitter >= 0) {
+                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
+                    V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
+                    DirectRec dRec;                                /* pdfEmitterDirect reads refN, n, d, dist only */
+                    dRec.refN = V3(rn.x, rn.y, rn.z);
+                    dRec.p = its.p; dRec.n = its.sh.n; dRec.d = rayD; dRec.dist = its.t; dRec.emitter = its.emitter; dRec.solidAngle = 1;
+                    const float lumPdf = (!(flags & F_PREV_DELTA)) ? pdfEmitterDirect(T, dRec) : 0;
                     const V3 c = thr * value * miWeight(rn.w, lumPdf);
                     l.x += c.x; l.y += c.y; l.z += c.z;
                     haveAdd = true;
@@ -860,9 +875,9 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
             if (!terminate && !(depth <= (uint32_t) rc.maxDepth || rc.maxDepth < 0))
                 terminate = true;
             if (!terminate) {
-                if (shp.emitter >= 0 && (flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
-                    const DevEmitter &em = S.emitters[shp.emitter];
-                    V3 le = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em.radiance);
+                if (its.emitter >= 0 && (flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
+                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
+                    V3 le = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
                     const V3 c = thr * le;
                     l.x += c.x; l.y += c.y; l.z += c.z;
                     haveAdd = true;
@@ -877,11 +892,11 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
                 /* ---- direct illumination sampling, path.cpp:172-200 ---- */
                 DirectRec dRec;
                 dRec.ref = its.p;
-                dRec.refN = (mat.flags & MF_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
+                dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
                 dRec.pdf = 0; dRec.emitter = -1;
-                const BsdfCtx bctx = bsdfResolve(S, mat, its.wi);
-                if (mat.flags & MF_SMOOTH) {
-                    V3 value = sampleEmitterDirect(S, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
+                const BsdfCtx bctx = bsdfResolve(materials, its);
+                if (its.flags & TS_MF_SMOOTH) {
+                    V3 value = sampleEmitterDirect(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
                     if (dRec.pdf != 0 && !value.isZero()) {
                         const V3 wo = its.sh.toLocal(dRec.d);
                         float bPdf;
@@ -1342,13 +1357,12 @@ struct phip_scene {
     int device = 0;
     phip_scene_desc descCopy;        /* scalar fields only */
     HostBVH bvh;
-    DevBuf<float4> nodes, nodes8, tris, positions, normals;
+    DevBuf<float4> nodes, nodes8, tris, triShade;
     DevBuf<uint2> spill8;
     int traversal = 2;               /* 2 = persistent per-lane BVH4 traversal with dynamic refill (default), 0 = one launch lane per slot, 1 = 8 lanes per ray over the BVH8
                                         (PHIP_TRAVERSAL=group; measured 2-3x slower: too few rays in flight per CU) */
-    DevBuf<uint4> triVerts;
-    DevBuf<DevShape> shapes; DevBuf<DevMaterial> materials; DevBuf<DevEmitter> emitters;
-    DevBuf<float> areaCdf, emitterCdf;
+    DevBuf<DevMaterial> materials;
+    DevBuf<float> emitterTab;
     DevScene dev;
     /* render-time buffers (grown on demand, reused between calls) */
     DevBuf<float4> rayO, rayD, hit, thr, refN, shadow, L, sampleOut;
@@ -1485,20 +1499,44 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     /* upload */
     HIP_TRY(hipSetDevice(sc->device));
-    std::vector<float4> pos4(d.n_vertices), nrm4;
-    for (uint32_t i = 0; i < d.n_vertices; ++i) pos4[i] = make_float4(d.positions[3 * i], d.positions[3 * i + 1], d.positions[3 * i + 2], 0);
-    if (d.normals) { nrm4.resize(d.n_vertices); for (uint32_t i = 0; i < d.n_vertices; ++i) nrm4[i] = make_float4(d.normals[3 * i], d.normals[3 * i + 1], d.normals[3 * i + 2], 0); }
-    std::vector<uint4> tv(d.n_triangles);
-    for (uint32_t i = 0; i < d.n_triangles; ++i) tv[i] = make_uint4(d.indices[3 * i], d.indices[3 * i + 1], d.indices[3 * i + 2], triShape[i]);
+    /* shading records (dv_scene.h): the per-triangle constants come from the same __host__ __device__
+       functions the kernel would run, so precomputing them does not change a single bit */
+    std::vector<float4> ts((size_t) TRISHADE_FLOAT4S * d.n_triangles);
+    for (uint32_t i = 0; i < d.n_triangles; ++i) {
+        const DevShape &sh = shapes[triShape[i]];
+        const DevMaterial &m = mats[sh.material];
+        const uint32_t *ix = d.indices + 3 * (size_t) i;
+        const V3 p0(d.positions[3 * ix[0]], d.positions[3 * ix[0] + 1], d.positions[3 * ix[0] + 2]);
+        const V3 p1(d.positions[3 * ix[1]], d.positions[3 * ix[1] + 1], d.positions[3 * ix[1] + 2]);
+        const V3 p2(d.positions[3 * ix[2]], d.positions[3 * ix[2] + 1], d.positions[3 * ix[2] + 2]);
+        const bool twosided = m.type == PHIP_BSDF_TWOSIDED;
+        const uint32_t front = twosided ? m.nested0 : sh.material, back = twosided ? m.nested1 : sh.material;
+        uint32_t flags = (sh.hasNormals ? TS_VERTEX_NORMALS : 0u) | (twosided ? TS_TWOSIDED : 0u)
+                       | ((m.flags & MF_SMOOTH) ? TS_MF_SMOOTH : 0u) | ((m.flags & MF_TRANS_OR_BACK) ? TS_TRANS_OR_BACK : 0u);
+        V3 a, b, c;
+        if (sh.hasNormals) {
+            a = V3(d.normals[3 * ix[0]], d.normals[3 * ix[0] + 1], d.normals[3 * ix[0] + 2]);
+            b = V3(d.normals[3 * ix[1]], d.normals[3 * ix[1] + 1], d.normals[3 * ix[1] + 2]);
+            c = V3(d.normals[3 * ix[2]], d.normals[3 * ix[2] + 1], d.normals[3 * ix[2] + 2]);
+        } else {
+            const V3 side1(p1 - p0), side2(p2 - p0);
+            Frame f; triShadingFrame(triFaceNormal(side1, side2), side1, f);
+            a = f.n; b = f.s; c = f.t;
+        }
+        float4 *r = ts.data() + (size_t) TRISHADE_FLOAT4S * i;
+        r[0] = make_float4(p0.x, p0.y, p0.z, pm_from_bits(front));
+        r[1] = make_float4(p1.x, p1.y, p1.z, pm_from_bits(back));
+        r[2] = make_float4(p2.x, p2.y, p2.z, pm_from_bits((uint32_t) sh.emitter));
+        r[3] = make_float4(a.x, a.y, a.z, pm_from_bits(flags));
+        r[4] = make_float4(b.x, b.y, b.z, 0.0f);
+        r[5] = make_float4(c.x, c.y, c.z, 0.0f);
+    }
+    if (ts.empty()) sc->triShade.alloc(TRISHADE_FLOAT4S); else sc->triShade.upload(ts.data(), ts.size());
     if (sc->bvh.nodes.empty()) sc->nodes.alloc(8);
     else sc->nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
     if (sc->bvh.nodes8.empty()) sc->nodes8.alloc(16);
     else sc->nodes8.upload((const float4 *) sc->bvh.nodes8.data(), sc->bvh.nodes8.size() / 4);
     sc->tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
-    sc->positions.upload(pos4.data(), pos4.size());
-    if (d.normals) sc->normals.upload(nrm4.data(), nrm4.size());
-    sc->triVerts.upload(tv.data(), tv.size());
-    sc->shapes.upload(shapes.data(), shapes.size());
     sc->materials.upload(mats.data(), mats.size());
     sc->materialMask = 0;
     for (const DevMaterial &m : mats) {
@@ -1506,15 +1544,27 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         if (m.type == PHIP_BSDF_DIELECTRIC) sc->materialMask |= MM_DIELECTRIC;
     }
     if (const char *e = getenv("PHIP_SHADE_GENERIC")) if (atoi(e)) sc->materialMask = MM_ALL;
-    sc->emitters.upload(ems.data(), ems.size());
-    sc->areaCdf.upload(areaCdf.data(), areaCdf.size());
-    sc->emitterCdf.upload(ecdf.data(), ecdf.size());
+    /* packed emitter table (dv_scene.h: EmitterTab) */
+    std::vector<float> tab(ecdf);
+    tab.resize(ecdf.size() + (size_t) EM_STRIDE * d.n_emitters, 0.0f);
+    for (uint32_t i = 0; i < d.n_emitters; ++i) {
+        const DevShape &sh = shapes[ems[i].shape];
+        float *r = tab.data() + ecdf.size() + (size_t) EM_STRIDE * i;
+        for (int k = 0; k < 3; ++k) r[EM_RADIANCE + k] = ems[i].radiance[k];
+        r[EM_WEIGHT] = ems[i].samplingWeight;
+        r[EM_FIRST_TRI] = pm_from_bits(sh.firstTri); r[EM_N_TRIS] = pm_from_bits(sh.nTris);
+        r[EM_CDF] = pm_from_bits((uint32_t) (tab.size() + sh.cdfOffset));       /* area CDFs follow the records */
+        r[EM_INV_AREA] = sh.invSurfaceArea;
+    }
+    tab.insert(tab.end(), areaCdf.begin(), areaCdf.end());
+    if (tab.size() >= (1ull << 31)) throw std::runtime_error("emitter table too large");
+    sc->emitterTab.upload(tab.data(), tab.size());
 
     DevScene &D = sc->dev;
     memset(&D, 0, sizeof(D));
-    D.nodes = sc->nodes.p; D.nodes8 = sc->nodes8.p; D.tris = sc->tris.p; D.triVerts = sc->triVerts.p; D.positions = sc->positions.p; D.normals = sc->normals.p;
-    D.shapes = sc->shapes.p; D.materials = sc->materials.p; D.emitters = sc->emitters.p;
-    D.areaCdf = sc->areaCdf.p; D.emitterCdf = sc->emitterCdf.p;
+    D.nodes = sc->nodes.p; D.nodes8 = sc->nodes8.p; D.tris = sc->tris.p; D.triShade = sc->triShade.p;
+    D.materials = sc->materials.p; D.nMaterials = (uint32_t) mats.size();
+    D.emitterTab = sc->emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
     D.rootRef = sc->bvh.rootRef; D.rootRef8 = sc->bvh.rootRef8; D.nTriangles = d.n_triangles;
     /* LDS staging plan: stack depth from the tree depth (3 pushes per BVH4 level), top-of-tree node cache
@@ -1660,6 +1710,7 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     for (uint32_t sppDone = 0; sppDone < (uint32_t) p->spp && !cancelled; sppDone += sppPerPass) {
         RenderConst rc;
         rc.sppPass = std::min(sppPerPass, (uint32_t) p->spp - sppDone); rc.sppFirst = sppDone;
+        rc.sppMagic = (uint32_t) std::min<unsigned long long>((1ull << 32) / rc.sppPass, 0xFFFFFFFFull);
         rc.tilePixels = (uint32_t) tilePixels; rc.tileShift = (uint32_t) tileShift; rc.nLocalTiles = nLocalTiles;
         rc.totalIds = idsPerSpp * rc.sppPass;
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
