@@ -264,6 +264,51 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
+#define DONE_REF ((int32_t) 0x80000000)   /* 'no more nodes' marker; as a leaf reference it would need 2^28 triangle records */
+
+/* One BVH4 node step: slab test of the four children, nearest-first order, push the farther hits,
+   continue with the nearest (or pop).  Shared by the per-slot and the persistent kernels. */
+#define NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)                                       \
+    {                                                                                                     \
+        LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)                                       \
+        ++nodeVisits;                                                                                     \
+        float key[4]; uint32_t ref[4];                                                                    \
+        SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)                                                       \
+        /* nearest child first (also a good any-hit order); misses (INFINITY) sort to the end */         \
+        cswap(key[0], ref[0], key[1], ref[1]); cswap(key[2], ref[2], key[3], ref[3]);                     \
+        cswap(key[0], ref[0], key[2], ref[2]); cswap(key[1], ref[1], key[3], ref[3]);                     \
+        cswap(key[1], ref[1], key[2], ref[2]);                                                            \
+        if (key[0] < INFINITY) {                                                                          \
+            if (stack.sp + 3 <= stack.depth) {      /* branch-free pushes: hits are a prefix of the sorted keys */ \
+                stack.lds[stack.sp * BLOCK] = ref[3]; stack.sp += key[3] < INFINITY ? 1 : 0;              \
+                stack.lds[stack.sp * BLOCK] = ref[2]; stack.sp += key[2] < INFINITY ? 1 : 0;              \
+                stack.lds[stack.sp * BLOCK] = ref[1]; stack.sp += key[1] < INFINITY ? 1 : 0;              \
+            } else {                                                                                      \
+                if (key[3] < INFINITY) stack.push(ref[3]);                                                \
+                if (key[2] < INFINITY) stack.push(ref[2]);                                                \
+                if (key[1] < INFINITY) stack.push(ref[1]);                                                \
+            }                                                                                             \
+            cur = (int32_t) ref[0];                                                                       \
+        } else {                                                                                          \
+            cur = stack.sp == 0 ? DONE_REF : (int32_t) stack.pop();                                       \
+        }                                                                                                 \
+    }
+#define SLAB(K, C)                                                                                        \
+    {                                                                                                     \
+        const float x0 = fmaf(mnx.C, rcp.x, -ordr.x), x1 = fmaf(mxx.C, rcp.x, -ordr.x);                   \
+        const float y0 = fmaf(mny.C, rcp.y, -ordr.y), y1 = fmaf(mxy.C, rcp.y, -ordr.y);                   \
+        const float z0 = fmaf(mnz.C, rcp.z, -ordr.z), z1 = fmaf(mxz.C, rcp.z, -ordr.z);                   \
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint));          \
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt));          \
+        key[K] = (tn <= tf) ? tn : INFINITY;                                                              \
+        ref[K] = pm_to_bits(chf.C);                                                                       \
+    }
+
+/* Traversal as a per-lane state machine whose loop body is ONE node step and ONE triangle test: a lane
+ * inside a leaf tests one Wald record per iteration while its neighbours go on with node
+ * steps.  (Looping over the whole leaf inside the body made every lane of the wave wait for up to eight
+ * triangle tests per iteration although only ~15 % of the lanes sit in a leaf: measured 2x the issue slots.)
+ * The order in which a ray tests its triangles is unchanged, hence so are the results. */
 template <bool SHADOW>
 __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
                                          TravStack &stack, TravResult &res,
@@ -275,58 +320,22 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
     int32_t cur = S.rootRef;
     bool found = false;
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-    for (;;) {
-        if (cur >= 0) {
-            LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)
-            ++nodeVisits;
-            float key[4]; uint32_t ref[4];
-#define SLAB(K, C)                                                                                   \
-            {                                                                                        \
-                const float x0 = fmaf(mnx.C, rcp.x, -ordr.x), x1 = fmaf(mxx.C, rcp.x, -ordr.x);        \
-                const float y0 = fmaf(mny.C, rcp.y, -ordr.y), y1 = fmaf(mxy.C, rcp.y, -ordr.y);        \
-                const float z0 = fmaf(mnz.C, rcp.z, -ordr.z), z1 = fmaf(mxz.C, rcp.z, -ordr.z);        \
-                const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint)); \
-                const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt)); \
-                key[K] = (tn <= tf) ? tn : INFINITY;                                                 \
-                ref[K] = pm_to_bits(chf.C);                                                          \
+    while (cur != DONE_REF) {
+        if (cur >= 0)
+            NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+        if (cur < 0 && cur != DONE_REF) {
+            /* a leaf reference doubles as the lane's progress inside the leaf: ~((next record << 3) | records left - 1) */
+            const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;
+            LOAD_TRI(stack, S, idx, a, b, c)
+            ++triTests;
+            float tu, tv, tt;
+            if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
+                if (SHADOW) return true;
+                maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
+                found = true;
             }
-            SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)
-#undef SLAB
-            if (!SHADOW) {
-                /* sorting network: nearest child first */
-                cswap(key[0], ref[0], key[1], ref[1]); cswap(key[2], ref[2], key[3], ref[3]);
-                cswap(key[0], ref[0], key[2], ref[2]); cswap(key[1], ref[1], key[3], ref[3]);
-                cswap(key[1], ref[1], key[2], ref[2]);
-                if (key[0] < INFINITY) {
-                    if (key[3] < INFINITY) stack.push(ref[3]);
-                    if (key[2] < INFINITY) stack.push(ref[2]);
-                    if (key[1] < INFINITY) stack.push(ref[1]);
-                    cur = (int32_t) ref[0];
-                    continue;
-                }
-            } else {
-                int32_t next = 0; bool have = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (key[k] < INFINITY) { if (have) stack.push(ref[k]); else { next = (int32_t) ref[k]; have = true; } }
-                if (have) { cur = next; continue; }
-            }
-        } else {
-            const uint32_t r = ~(uint32_t) cur;
-            const uint32_t first = r >> 3, count = (r & 7u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                LOAD_TRI(stack, S, first + i, a, b, c)
-                ++triTests;
-                float tu, tv, tt;
-                if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
-                    if (SHADOW) return true;
-                    maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
-                    found = true;
-                }
-            }
+            cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
         }
-        if (stack.sp == 0) break;
-        cur = (int32_t) stack.pop();
     }
     return found;
 }
@@ -342,18 +351,6 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
 #define REFILL_LANES 16
 #endif
 #define INVALID_RAY 0xFFFFFFFFu
-#ifndef TRAV_WHILE_WHILE
-#define TRAV_WHILE_WHILE 0              /* 1: run node steps until every lane holds a leaf ("while-while"); 0: one node OR leaf step per iteration.
-                                           Measured on MI355X: while-while is 15-35 % slower on the 250k-triangle scenes, slightly faster on Cornell */
-#endif
-#if TRAV_WHILE_WHILE
-#define TRAV_NODE_LOOP while
-#define TRAV_LEAF_COND
-#else
-#define TRAV_NODE_LOOP if
-#define TRAV_LEAF_COND && cur < 0
-#endif
-#define DONE_REF ((int32_t) 0x80000000)   /* 'no more nodes' marker; as a leaf reference it would need 2^28 triangle records */
 #define DYN_SHARDS 8                    /* one dynamic-sample counter per XCD-sized group of blocks */
 #define DYN_STRIDE 16                   /* unsigned long longs between counters (128 B) */
 
@@ -388,63 +385,23 @@ __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack 
         }
         if (!__any(active)) { if (!src.more()) break; continue; }
         if (active) {
-            /* "while-while": the wave first runs node steps until every lane holds a leaf (or is done), then
-               tests the leaves of all lanes together -- the expensive triangle loop is not re-issued on every
-               node step for the few lanes that happen to sit at a leaf. */
+            /* one node step and one triangle test per iteration (see traverse()) */
             for (;;) {
-                TRAV_NODE_LOOP (cur >= 0) {
-                    LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)
-                    ++nodeVisits;
-                    float key[4]; uint32_t ref[4];
-#define SLAB(K, C)                                                                                   \
-                    {                                                                                \
-                        const float x0 = fmaf(mnx.C, rcp.x, -ordr.x), x1 = fmaf(mxx.C, rcp.x, -ordr.x); \
-                        const float y0 = fmaf(mny.C, rcp.y, -ordr.y), y1 = fmaf(mxy.C, rcp.y, -ordr.y); \
-                        const float z0 = fmaf(mnz.C, rcp.z, -ordr.z), z1 = fmaf(mxz.C, rcp.z, -ordr.z); \
-                        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint)); \
-                        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt)); \
-                        key[K] = (tn <= tf) ? tn : INFINITY;                                         \
-                        ref[K] = pm_to_bits(chf.C);                                                  \
+                if (cur >= 0)
+                    NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+                bool finished = false;
+                if (cur < 0 && cur != DONE_REF) {
+                    const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;
+                    LOAD_TRI(stack, S, idx, a, b, c)
+                    ++triTests;
+                    float tu, tv, tt;
+                    if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
+                        if (SHADOW) { res.prim = 0; finished = true; }
+                        else { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
                     }
-                    SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)
-#undef SLAB
-                    /* nearest child first (also a good any-hit order); misses (INFINITY) sort to the end */
-                    cswap(key[0], ref[0], key[1], ref[1]); cswap(key[2], ref[2], key[3], ref[3]);
-                    cswap(key[0], ref[0], key[2], ref[2]); cswap(key[1], ref[1], key[3], ref[3]);
-                    cswap(key[1], ref[1], key[2], ref[2]);
-                    if (key[0] < INFINITY) {
-                        if (stack.sp + 3 <= stack.depth) {      /* branch-free pushes: hits are a prefix of the sorted keys */
-                            stack.lds[stack.sp * BLOCK] = ref[3]; stack.sp += key[3] < INFINITY ? 1 : 0;
-                            stack.lds[stack.sp * BLOCK] = ref[2]; stack.sp += key[2] < INFINITY ? 1 : 0;
-                            stack.lds[stack.sp * BLOCK] = ref[1]; stack.sp += key[1] < INFINITY ? 1 : 0;
-                        } else {
-                            if (key[3] < INFINITY) stack.push(ref[3]);
-                            if (key[2] < INFINITY) stack.push(ref[2]);
-                            if (key[1] < INFINITY) stack.push(ref[1]);
-                        }
-                        cur = (int32_t) ref[0];
-                    } else {
-                        cur = stack.sp == 0 ? DONE_REF : (int32_t) stack.pop();
-                    }
+                    cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
                 }
-                bool finished = cur == DONE_REF;
-                if (!finished TRAV_LEAF_COND) {
-                    const uint32_t r = ~(uint32_t) cur;
-                    const uint32_t first = r >> 3, count = (r & 7u) + 1u;
-                    bool shadowHit = false;
-                    for (uint32_t i = 0; i < count; ++i) {
-                        LOAD_TRI(stack, S, first + i, a, b, c)
-                        ++triTests;
-                        float tu, tv, tt;
-                        if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
-                            if (SHADOW) { shadowHit = true; break; }
-                            maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
-                        }
-                    }
-                    if (SHADOW && shadowHit) { res.prim = 0; finished = true; }
-                    else if (stack.sp == 0) finished = true;
-                    else cur = (int32_t) stack.pop();
-                }
+                if (cur == DONE_REF) finished = true;
                 if (finished) {
                     src.commit(handle, SHADOW ? (res.prim != PHIP_NO_HIT) : false, res);
                     active = false;
