@@ -172,10 +172,12 @@ struct DirectRec {
  * k_shade can stage it in LDS when it is small (the lookups are a chain of dependent loads:
  * selection CDF -> emitter -> area CDF of its mesh -> triangle):
  *   t[0 .. n]                     emitter selection CDF (pmf.h layout, n + 1 entries)
- *   t[n + 1 + 8 e .. + 7]         emitter e: radiance rgb, samplingWeight, firstTri, nTris, cdfOffset (index into t), 1 / surface area
- *   t[cdfOffset .. + nTris]       area CDF of the emitter's mesh (trimesh.cpp:388-404) */
+ *   t[n + 1 + 12 e .. + 11]       emitter e: radiance rgb, samplingWeight, firstTri, nTris, cdfOffset (index into t), 1 / surface area,
+ *                                 recOffset (index into t of a copy of its triangles' shading records, 16-byte aligned; 0 = none)
+ *   t[cdfOffset .. + nTris]       area CDF of the emitter's mesh (trimesh.cpp:388-404)
+ *   t[recOffset .. ]              shading records of the emitter's triangles, when all emitters together have few */
 struct EmitterTab { const float *t; uint32_t n; float normalization; };
-enum { EM_RADIANCE = 0, EM_WEIGHT = 3, EM_FIRST_TRI = 4, EM_N_TRIS = 5, EM_CDF = 6, EM_INV_AREA = 7, EM_STRIDE = 8 };
+enum { EM_RADIANCE = 0, EM_WEIGHT = 3, EM_FIRST_TRI = 4, EM_N_TRIS = 5, EM_CDF = 6, EM_INV_AREA = 7, EM_REC = 8, EM_STRIDE = 12 };
 DV const float *emitterRecord(const EmitterTab &T, uint32_t e) { return T.t + (T.n + 1) + EM_STRIDE * e; }
 
 /* trimesh.cpp:412-423 + triangle.cpp:24-59 + shape.cpp:102-115 */
@@ -183,7 +185,9 @@ DV void shapeSampleDirect(const DevScene &S, const EmitterTab &T, const float *e
     const float *cdf = T.t + pm_to_bits(em[EM_CDF]);
     uint32_t index = cdfSample(cdf, pm_to_bits(em[EM_N_TRIS]), sample.y);
     sample.y = (sample.y - cdf[index]) / (cdf[index + 1] - cdf[index]);
-    const float4 *r = S.triShade + (size_t) TRISHADE_FLOAT4S * (pm_to_bits(em[EM_FIRST_TRI]) + index);
+    const uint32_t recOffset = pm_to_bits(em[EM_REC]);
+    const float4 *r = recOffset ? (const float4 *) (T.t + recOffset) + (size_t) TRISHADE_FLOAT4S * index
+                                : S.triShade + (size_t) TRISHADE_FLOAT4S * (pm_to_bits(em[EM_FIRST_TRI]) + index);
     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
     const V3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
     V2 bary = squareToUniformTriangle(sample);

@@ -754,7 +754,7 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
     __shared__ uint32_t waveCnt[BLOCK / 64];
     /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
        dependent lookups per NEE sample) and the materials */
-    __shared__ float ldsEm[EMITTER_LDS_FLOATS];
+    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
     const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
     if (emInLds) for (uint32_t i = threadIdx.x; i < S.emitterTabSize; i += BLOCK) ldsEm[i] = S.emitterTab[i];
@@ -1005,16 +1005,19 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
     }
 }
 
-/* sums the per-wave statistics: one block per counter */
-__global__ void k_reduce_stats(PathPool P, Counters *C) {
+/* sums the per-wave statistics: REDUCE_SPLIT blocks per counter row, rows [firstRow, firstRow + gridDim.x);
+   the totals must have been zeroed (one atomicAdd per block: 32 per row) */
+#define REDUCE_SPLIT 32
+__global__ void k_reduce_stats(PathPool P, Counters *C, int firstRow) {
     __shared__ unsigned long long red[256];
-    const unsigned long long *src = P.stat + (size_t) blockIdx.x * P.nWaves;
+    const int row = firstRow + (int) blockIdx.x;
+    const unsigned long long *src = P.stat + (size_t) row * P.nWaves;
     unsigned long long v = 0;
-    for (uint32_t i = threadIdx.x; i < P.nWaves; i += 256) v += src[i];
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < P.nWaves; i += 256 * REDUCE_SPLIT) v += src[i];
     red[threadIdx.x] = v;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) { if ((int) threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0) C->total[blockIdx.x] = red[0];
+    if (threadIdx.x == 0 && red[0]) atomicAdd(&C->total[row], red[0]);
 }
 
 /* Film: one lane per crop pixel gathers every sample whose filter footprint covers it.  Restates
@@ -1504,16 +1507,32 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     /* packed emitter table (dv_scene.h: EmitterTab) */
     std::vector<float> tab(ecdf);
     tab.resize(ecdf.size() + (size_t) EM_STRIDE * d.n_emitters, 0.0f);
+    const size_t cdfBase = tab.size();
+    size_t nEmTris = 0;
+    for (uint32_t i = 0; i < d.n_emitters; ++i) nEmTris += shapes[ems[i].shape].nTris;
+    const size_t recBase = (cdfBase + areaCdf.size() + 3) / 4 * 4;                /* 16-byte aligned */
+    const bool withRecs = recBase + nEmTris * 4 * TRISHADE_FLOAT4S <= EMITTER_LDS_FLOATS;
+    size_t recPos = recBase;
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
         const DevShape &sh = shapes[ems[i].shape];
         float *r = tab.data() + ecdf.size() + (size_t) EM_STRIDE * i;
         for (int k = 0; k < 3; ++k) r[EM_RADIANCE + k] = ems[i].radiance[k];
         r[EM_WEIGHT] = ems[i].samplingWeight;
         r[EM_FIRST_TRI] = pm_from_bits(sh.firstTri); r[EM_N_TRIS] = pm_from_bits(sh.nTris);
-        r[EM_CDF] = pm_from_bits((uint32_t) (tab.size() + sh.cdfOffset));       /* area CDFs follow the records */
+        r[EM_CDF] = pm_from_bits((uint32_t) (cdfBase + sh.cdfOffset));             /* area CDFs follow the records */
         r[EM_INV_AREA] = sh.invSurfaceArea;
+        r[EM_REC] = pm_from_bits(withRecs ? (uint32_t) recPos : 0u);
+        recPos += (size_t) sh.nTris * 4 * TRISHADE_FLOAT4S;
     }
     tab.insert(tab.end(), areaCdf.begin(), areaCdf.end());
+    if (withRecs) {
+        tab.resize(recBase, 0.0f);
+        for (uint32_t i = 0; i < d.n_emitters; ++i) {
+            const DevShape &sh = shapes[ems[i].shape];
+            const float *src = (const float *) (ts.data() + (size_t) TRISHADE_FLOAT4S * sh.firstTri);
+            tab.insert(tab.end(), src, src + (size_t) sh.nTris * 4 * TRISHADE_FLOAT4S);
+        }
+    }
     if (tab.size() >= (1ull << 31)) throw std::runtime_error("emitter table too large");
     sc->emitterTab.upload(tab.data(), tab.size());
 
@@ -1663,6 +1682,7 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     const dim3 pgridTrace((unsigned) std::max(1, std::min<int>(nCU * TRACE_P_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
     Counters hc;
     bool cancelled = false;
+    const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
 
     for (uint32_t sppDone = 0; sppDone < (uint32_t) p->spp && !cancelled; sppDone += sppPerPass) {
         RenderConst rc;
@@ -1712,15 +1732,17 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sc->L.p);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-            if (sc->traversal == 2 && sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, ldsBytes, stream, D, P);
+            if (sc->traversal == 2 && (sc->bvh.nNodes >= 64 || forcePersist)) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, ldsBytes, stream, D, P);
             else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
             else if (sc->traversal == 1) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
             else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);
             if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
             ++iter;
             if (check) {
-                hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT), dim3(256), 0, stream, P, sc->counters.p);
-                HIP_TRY(hipMemcpyAsync(&hc, sc->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+                /* termination test: only the live-slot row is summed inside the loop */
+                HIP_TRY(hipMemsetAsync(&sc->counters.p->total[ST_ALIVE], 0, sizeof(unsigned long long), stream));
+                hipLaunchKernelGGL(k_reduce_stats, dim3(1, REDUCE_SPLIT), dim3(256), 0, stream, P, sc->counters.p, (int) ST_ALIVE);
+                HIP_TRY(hipMemcpyAsync(&hc.total[ST_ALIVE], &sc->counters.p->total[ST_ALIVE], sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 if (hc.total[ST_ALIVE] == 0) done = true;
                 if (sc->cancel.load()) { cancelled = true; done = true; }
@@ -1748,7 +1770,8 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             hipLaunchKernelGGL(k_export_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, D, rc, (const float4 *) sc->L.p,
                                (const int32_t *) sc->tileSlot.p, tilesX, sc->sampleOut.p, (uint32_t) p->spp);
         }
-        hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT), dim3(256), 0, stream, P, sc->counters.p);
+        HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
+        hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, stream, P, sc->counters.p, 0);
         HIP_TRY(hipMemcpyAsync(&hc, sc->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
@@ -1871,7 +1894,8 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             HIP_TRY(hipEventRecord(e0, 0));
             hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(scene->dev), 0, scene->dev, (const phip_ray *) dr.p, n, dh.p, dz.p, P);
             HIP_TRY(hipEventRecord(e1, 0));
-            hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT), dim3(256), 0, 0, P, scene->counters.p);
+            HIP_TRY(hipMemsetAsync(scene->counters.p, 0, sizeof(Counters), 0));
+            hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, 0, P, scene->counters.p, 0);
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipGetLastError());
             float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);

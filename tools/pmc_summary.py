@@ -5,7 +5,7 @@ d = sys.argv[1]; pre = sys.argv[2] if len(sys.argv) > 2 else ""
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
 for f in sorted(glob.glob(os.path.join(d, pre + "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if not k.startswith("k_"): continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 for k, v in sorted(agg.items()):
