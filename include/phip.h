@@ -83,12 +83,18 @@ typedef struct phip_shape {
     uint32_t reserved;
 } phip_shape;
 
-/* ---- emitters: only `area` (src/emitters/area.cpp) is on the path ---- */
+/* ---- emitters: `area` (src/emitters/area.cpp) and the `constant` environment (src/emitters/constant.cpp).
+ * Emitters are listed in the order of Scene::getEmitters() (the selection PDF of scene.cpp:375-381 depends on
+ * it).  At most one environment emitter (scene.cpp:510-513).  The bounding sphere of the constant emitter
+ * is derived by the library exactly like ConstantBackgroundEmitter::createShape does (constant.cpp:67-72:
+ * 1.5 x the bounding sphere of the kd-tree's box expanded by the sensor position). ---- */
+enum { PHIP_EMITTER_AREA = 0, PHIP_EMITTER_CONSTANT = 1 };
 typedef struct phip_emitter {
     float    radiance[3];
     float    sampling_weight;            /* Emitter::getSamplingWeight, default 1         */
-    uint32_t shape;                      /* the parent shape (area.cpp:185-203)           */
-    uint32_t reserved[3];
+    uint32_t shape;                      /* area: the parent shape (area.cpp:185-203); constant: ignored */
+    uint32_t type;                       /* PHIP_EMITTER_*                                 */
+    uint32_t reserved[2];
 } phip_emitter;
 
 /* ---- sensor: `perspective` pinhole (src/sensors/perspective.cpp:126-180,271-297) ---- */

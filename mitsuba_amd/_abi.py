@@ -32,9 +32,12 @@ class phip_shape(C.Structure):
                 ("has_normals", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+PHIP_EMITTER_AREA, PHIP_EMITTER_CONSTANT = 0, 1
+
+
 class phip_emitter(C.Structure):
     _fields_ = [("radiance", C.c_float * 3), ("sampling_weight", C.c_float),
-                ("shape", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("shape", C.c_uint32), ("type", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class phip_camera(C.Structure):

@@ -25,6 +25,7 @@
 #define PT_SHADOW_EPSILON 1e-3f
 #define PT_PI             3.14159265358979323846f
 #define PT_INV_PI         0.31830988618379067154f
+#define PT_INV_FOURPI     0.07957747154594766788f
 
 namespace pt {
 
@@ -108,6 +109,29 @@ DV V3 squareToCosineHemisphere(const V2 &sample) {
     float z = safe_sqrt(1.0f - p.x * p.x - p.y * p.y);
     if (z == 0) z = 1e-10f;
     return V3(p.x, p.y, z);
+}
+DV V3 squareToUniformSphere(const V2 &sample) {   /* warp.cpp:27-34 */
+    float z = 1.0f - 2.0f * sample.y;
+    float r = safe_sqrt(1.0f - z * z);
+    float sinPhi, cosPhi;
+    pm_sincosf(2.0f * PT_PI * sample.x, &sinPhi, &cosPhi);
+    return V3(r * cosPhi, r * sinPhi, z);
+}
+/* util.cpp:447-485 */
+DV bool solveQuadratic(float a, float b, float c, float &x0, float &x1) {
+    if (a == 0) {
+        if (b != 0) { x0 = x1 = -c / b; return true; }
+        return false;
+    }
+    float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0) return false;
+    float temp, sqrtDiscrim = sqrtf(discrim);
+    if (b < 0) temp = -0.5f * (b - sqrtDiscrim);
+    else temp = -0.5f * (b + sqrtDiscrim);
+    x0 = temp / a;
+    x1 = c / temp;
+    if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+    return true;
 }
 DV V2 squareToUniformTriangle(const V2 &sample) {
     float a = safe_sqrt(1.0f - sample.x);

@@ -61,6 +61,7 @@ struct DevScene {
     const DevMaterial *materials; uint32_t nMaterials;
     const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;
+    int32_t envEmitter; float envCenter[3]; float envRadius;   /* constant environment emitter (or -1) and its m_sceneBSphere */
     int32_t rootRef, rootRef8; uint32_t nTriangles;
     uint32_t stackDepth, nodeCache, triCache;   /* LDS staging plan of the traversal kernels */
     float sceneMin[3], sceneMax[3];
@@ -173,11 +174,12 @@ struct DirectRec {
  * selection CDF -> emitter -> area CDF of its mesh -> triangle):
  *   t[0 .. n]                     emitter selection CDF (pmf.h layout, n + 1 entries)
  *   t[n + 1 + 12 e .. + 11]       emitter e: radiance rgb, samplingWeight, firstTri, nTris, cdfOffset (index into t), 1 / surface area,
- *                                 recOffset (index into t of a copy of its triangles' shading records, 16-byte aligned; 0 = none)
+ *                                 recOffset (index into t of a copy of its triangles' shading records, 16-byte aligned; 0 = none),
+ *                                 type (PHIP_EMITTER_*; the constant environment emitter has no triangles)
  *   t[cdfOffset .. + nTris]       area CDF of the emitter's mesh (trimesh.cpp:388-404)
  *   t[recOffset .. ]              shading records of the emitter's triangles, when all emitters together have few */
 struct EmitterTab { const float *t; uint32_t n; float normalization; };
-enum { EM_RADIANCE = 0, EM_WEIGHT = 3, EM_FIRST_TRI = 4, EM_N_TRIS = 5, EM_CDF = 6, EM_INV_AREA = 7, EM_REC = 8, EM_STRIDE = 12 };
+enum { EM_RADIANCE = 0, EM_WEIGHT = 3, EM_FIRST_TRI = 4, EM_N_TRIS = 5, EM_CDF = 6, EM_INV_AREA = 7, EM_REC = 8, EM_TYPE = 9, EM_STRIDE = 12 };
 DV const float *emitterRecord(const EmitterTab &T, uint32_t e) { return T.t + (T.n + 1) + EM_STRIDE * e; }
 
 /* trimesh.cpp:412-423 + triangle.cpp:24-59 + shape.cpp:102-115 */
@@ -211,6 +213,53 @@ DV void shapeSampleDirect(const DevScene &S, const EmitterTab &T, const float *e
     dRec.solidAngle = 1;
 }
 
+/* bsphere.h:88-95 */
+DV bool envSphereIntersect(const DevScene &S, const V3 &ro, const V3 &rd, float &nearT, float &farT) {
+    const V3 o = ro - V3(S.envCenter[0], S.envCenter[1], S.envCenter[2]);
+    const float A = rd.lengthSquared();
+    const float B = 2 * dot(o, rd);
+    const float C = o.lengthSquared() - S.envRadius * S.envRadius;
+    return solveQuadratic(A, B, C, nearT, farT);
+}
+
+/* ConstantBackgroundEmitter::sampleDirect, constant.cpp:184-225 */
+DV V3 constantSampleDirect(const DevScene &S, const float *em, DirectRec &dRec, const V2 &sample) {
+    V3 d; float pdf;
+    if (!dRec.refN.isZero()) {
+        d = squareToCosineHemisphere(sample);
+        pdf = PT_INV_PI * cosTheta(d);
+        Frame f; f.n = dRec.refN; coordinateSystem(f.n, f.s, f.t);
+        d = f.toWorld(d);
+    } else {
+        d = squareToUniformSphere(sample);
+        pdf = PT_INV_FOURPI;
+    }
+    float nearT, farT;
+    dRec.pdf = 0.0f;
+    if (!envSphereIntersect(S, dRec.ref, d, nearT, farT)) return V3(0.0f);
+    if (!(nearT < 0 && farT > 0)) return V3(0.0f);
+    dRec.p = dRec.ref + d * farT;
+    dRec.n = normalize(V3(S.envCenter[0], S.envCenter[1], S.envCenter[2]) - dRec.p);
+    dRec.d = d; dRec.dist = farT; dRec.pdf = pdf; dRec.solidAngle = 1;
+    if (!dRec.refN.isZero() && dot(dRec.d, dRec.refN) <= 0)
+        return V3(0.0f);                 /* roundoff moved the sample to the back side: pdf stays, value is zero */
+    return V3(em[EM_RADIANCE], em[EM_RADIANCE + 1], em[EM_RADIANCE + 2]) / pdf;
+}
+
+/* ConstantBackgroundEmitter::pdfDirect, constant.cpp:227-243 (solid-angle measure) */
+DV float constantPdfDirect(const DirectRec &dRec) {
+    if (!dRec.refN.isZero())
+        return PT_INV_PI * smax(0.0f, dot(dRec.d, dRec.refN));
+    return PT_INV_FOURPI;
+}
+
+/* ConstantBackgroundEmitter::fillDirectSamplingRecord, constant.cpp:258-273: only its verdict matters here
+   (pdfDirect in the solid-angle measure reads d and refN) */
+DV bool envFillDirectRecord(const DevScene &S, const V3 &ro, const V3 &rd) {
+    float nearT, farT;
+    return !(!envSphereIntersect(S, ro, rd, nearT, farT) || nearT > 0 || farT < 0);
+}
+
 /* scene.cpp:828-852 without the visibility test (the shadow ray is traced by the wavefront),
    area.cpp:158-173.  Returns value (radiance/pdf/emPdf); dRec.pdf == 0 means "no sample". */
 DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRec, V2 sample) {
@@ -219,13 +268,18 @@ DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRe
     float emPdf = T.t[index + 1] - T.t[index];
     sample.x = (sample.x - T.t[index]) / (T.t[index + 1] - T.t[index]);
     const float *em = emitterRecord(T, index);
-    shapeSampleDirect(S, T, em, dRec, sample);
     V3 value;
-    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
-        value = V3(em[EM_RADIANCE], em[EM_RADIANCE + 1], em[EM_RADIANCE + 2]) / dRec.pdf;
+    if (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_CONSTANT) {
+        value = constantSampleDirect(S, em, dRec, sample);
+        if (dRec.pdf == 0) return V3(0.0f);
     } else {
-        dRec.pdf = 0.0f;
-        return V3(0.0f);
+        shapeSampleDirect(S, T, em, dRec, sample);
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
+            value = V3(em[EM_RADIANCE], em[EM_RADIANCE + 1], em[EM_RADIANCE + 2]) / dRec.pdf;
+        } else {
+            dRec.pdf = 0.0f;
+            return V3(0.0f);
+        }
     }
     dRec.emitter = (int) index;
     dRec.pdf *= emPdf;
@@ -237,7 +291,9 @@ DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRe
 DV float pdfEmitterDirect(const EmitterTab &T, const DirectRec &dRec) {
     const float *em = emitterRecord(T, (uint32_t) dRec.emitter);
     float pdf;
-    if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+    if (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_CONSTANT) {
+        pdf = constantPdfDirect(dRec);
+    } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
         float pdfPos = em[EM_INV_AREA];
         pdf = pdfPos * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
     } else {

@@ -795,7 +795,27 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
         float4 l = make_float4(0, 0, 0, 0);
 
         if (prim == PHIP_NO_HIT) {
-            terminate = true;                   /* no environment emitter: path.cpp:136-143 / 233-248 */
+            terminate = true;
+            if (S.envEmitter >= 0) {            /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
+                const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
+                const V3 value = rgb(em + EM_RADIANCE);
+                l = L[id];
+                if (flags & F_FIRST) {
+                    if (!rc.hideEmitters) { l.x += value.x; l.y += value.y; l.z += value.z; }   /* throughput is 1; alpha stays 0 */
+                    haveAdd = true;
+                } else {
+                    const float4 ro = P.rayO[slot];
+                    if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
+                        DirectRec dRec;
+                        dRec.refN = V3(rn.x, rn.y, rn.z); dRec.d = rayD; dRec.emitter = S.envEmitter; dRec.solidAngle = 1;
+                        const float lumPdf = (!(flags & F_PREV_DELTA)) ? pdfEmitterDirect(T, dRec) : 0;
+                        const V3 c = thr * value * miWeight(rn.w, lumPdf);
+                        l.x += c.x; l.y += c.y; l.z += c.z;
+                        haveAdd = true;
+                    }
+                }
+                if (haveAdd) L[id] = l;
+            }
         } else {
             Isect its;
             fillIntersection(S, rayD, prim, hit.y, hit.z, hit.x, its);
@@ -1404,6 +1424,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         if (s.first_triangle != expect) throw std::runtime_error("shape triangle ranges must tile the index array in order");
         if (s.material >= d.n_materials) throw std::runtime_error("shape material id out of range");
         if (s.emitter >= (int32_t) d.n_emitters) throw std::runtime_error("shape emitter id out of range");
+        if (s.emitter >= 0 && d.emitters[s.emitter].type != PHIP_EMITTER_AREA) throw std::runtime_error("a shape can only carry an area emitter");
         if (s.has_normals && !d.normals) throw std::runtime_error("shape has_normals but normals is NULL");
         expect += s.n_triangles;
         DevShape &o = shapes[i];
@@ -1437,13 +1458,18 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     /* emitters + selection pdf, scene.cpp:375-381 */
     std::vector<DevEmitter> ems(d.n_emitters);
+    int32_t envEmitter = -1;
     std::vector<float> ecdf(1, 0.0f);
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
         const phip_emitter &e = d.emitters[i];
-        if (e.shape >= d.n_shapes || d.shapes[e.shape].emitter != (int32_t) i) throw std::runtime_error("emitter/shape back reference mismatch");
+        if (e.type == PHIP_EMITTER_CONSTANT) {
+            if (envEmitter >= 0) throw std::runtime_error("The scene may only contain one environment emitter");   /* scene.cpp:510-513 */
+            envEmitter = (int32_t) i;
+        } else if (e.type != PHIP_EMITTER_AREA) throw std::runtime_error("unknown emitter type");
+        else if (e.shape >= d.n_shapes || d.shapes[e.shape].emitter != (int32_t) i) throw std::runtime_error("emitter/shape back reference mismatch");
         memset(&ems[i], 0, sizeof(DevEmitter));
         for (int k = 0; k < 3; ++k) ems[i].radiance[k] = e.radiance[k];
-        ems[i].samplingWeight = e.sampling_weight; ems[i].shape = e.shape;
+        ems[i].samplingWeight = e.sampling_weight; ems[i].shape = e.type == PHIP_EMITTER_AREA ? e.shape : 0xFFFFFFFFu;
         ecdf.push_back(ecdf.back() + e.sampling_weight);
     }
     float emNorm = 0;
@@ -1509,15 +1535,18 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     tab.resize(ecdf.size() + (size_t) EM_STRIDE * d.n_emitters, 0.0f);
     const size_t cdfBase = tab.size();
     size_t nEmTris = 0;
-    for (uint32_t i = 0; i < d.n_emitters; ++i) nEmTris += shapes[ems[i].shape].nTris;
+    auto isArea = [&](uint32_t i) { return ems[i].shape != 0xFFFFFFFFu; };
+    for (uint32_t i = 0; i < d.n_emitters; ++i) if (isArea(i)) nEmTris += shapes[ems[i].shape].nTris;
     const size_t recBase = (cdfBase + areaCdf.size() + 3) / 4 * 4;                /* 16-byte aligned */
     const bool withRecs = recBase + nEmTris * 4 * TRISHADE_FLOAT4S <= EMITTER_LDS_FLOATS;
     size_t recPos = recBase;
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
-        const DevShape &sh = shapes[ems[i].shape];
         float *r = tab.data() + ecdf.size() + (size_t) EM_STRIDE * i;
         for (int k = 0; k < 3; ++k) r[EM_RADIANCE + k] = ems[i].radiance[k];
         r[EM_WEIGHT] = ems[i].samplingWeight;
+        r[EM_TYPE] = pm_from_bits(isArea(i) ? (uint32_t) PHIP_EMITTER_AREA : (uint32_t) PHIP_EMITTER_CONSTANT);
+        if (!isArea(i)) continue;
+        const DevShape &sh = shapes[ems[i].shape];
         r[EM_FIRST_TRI] = pm_from_bits(sh.firstTri); r[EM_N_TRIS] = pm_from_bits(sh.nTris);
         r[EM_CDF] = pm_from_bits((uint32_t) (cdfBase + sh.cdfOffset));             /* area CDFs follow the records */
         r[EM_INV_AREA] = sh.invSurfaceArea;
@@ -1528,6 +1557,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (withRecs) {
         tab.resize(recBase, 0.0f);
         for (uint32_t i = 0; i < d.n_emitters; ++i) {
+            if (!isArea(i)) continue;
             const DevShape &sh = shapes[ems[i].shape];
             const float *src = (const float *) (ts.data() + (size_t) TRISHADE_FLOAT4S * sh.firstTri);
             tab.insert(tab.end(), src, src + (size_t) sh.nTris * 4 * TRISHADE_FLOAT4S);
@@ -1542,6 +1572,25 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     D.materials = sc->materials.p; D.nMaterials = (uint32_t) mats.size();
     D.emitterTab = sc->emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
+    D.envEmitter = envEmitter;
+    if (envEmitter >= 0) {
+        /* ConstantBackgroundEmitter::createShape (constant.cpp:67-72) as seen from Scene::initializeBidirectional
+           (scene.cpp:384-413): bounding sphere (aabb.cpp:44-47) of the kd-tree's enlarged box expanded by the sensor
+           position (track.cpp:79-83), radius x 1.5 */
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = d.n_triangles ? sc->bvh.sceneMin[a] : INFINITY; mx[a] = d.n_triangles ? sc->bvh.sceneMax[a] : -INFINITY;
+        }
+        const float *m = d.camera.to_world;
+        V3 sp(m[3], m[7], m[11]);
+        if (m[15] != 1.0f) sp = sp / m[15];
+        const float spv[3] = { sp.x, sp.y, sp.z };
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], spv[a]); mx[a] = std::max(mx[a], spv[a]); }
+        const V3 center = (V3(mx[0], mx[1], mx[2]) + V3(mn[0], mn[1], mn[2])) * 0.5f;
+        const float radius = (center - V3(mx[0], mx[1], mx[2])).length();
+        D.envCenter[0] = center.x; D.envCenter[1] = center.y; D.envCenter[2] = center.z;
+        D.envRadius = std::max(PT_EPSILON, radius * 1.5f);
+    }
     D.rootRef = sc->bvh.rootRef; D.rootRef8 = sc->bvh.rootRef8; D.nTriangles = d.n_triangles;
     /* LDS staging plan: stack depth from the tree depth (3 pushes per BVH4 level), top-of-tree node cache
        (nodes are in breadth-first order), all triangle records if there are few */

@@ -113,6 +113,12 @@ class SceneBuilder:
         self.shapes.append({"material": material, "emitter": emitter})
         return sid
 
+    def constant(self, radiance, sampling_weight=1.0):
+        """<emitter type="constant">: the constant environment emitter (src/emitters/constant.cpp)."""
+        self.emitters.append({"radiance": _rgb(radiance), "weight": sampling_weight, "shape": 0xFFFFFFFF,
+                              "type": A.PHIP_EMITTER_CONSTANT})
+        return len(self.emitters) - 1
+
     def quad(self, p0, p1, p2, p3, material, facing=None, radiance=None):
         """Two triangles (0,1,2),(2,3,0) like Rectangle::createTriMesh (rectangle.cpp:170-203);
         if `facing` is given the winding is flipped so the face normal points that way."""
@@ -170,6 +176,7 @@ class SceneBuilder:
             ems[i].radiance[:] = e["radiance"]
             ems[i].sampling_weight = e["weight"]
             ems[i].shape = e["shape"]
+            ems[i].type = e.get("type", A.PHIP_EMITTER_AREA)
         d.n_vertices = len(pos)
         d.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
         d.normals = nrm.ctypes.data_as(C.POINTER(C.c_float)) if nrm is not None else None

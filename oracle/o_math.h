@@ -35,6 +35,7 @@ typedef float Float;
 #define ORC_DELTA_EPSILON  1e-3f
 #define ORC_PI             3.14159265358979323846f
 #define ORC_INV_PI         0.31830988618379067154f
+#define ORC_INV_FOURPI     0.07957747154594766788f   /* constants.h:66 */
 
 namespace om {
 #if defined(ORACLE_LIBM)
@@ -199,6 +200,46 @@ inline Vec3 squareToUniformSphere(const Vec2 &sample) { /* warp.cpp:27-34 (test_
     om::sincos(2.0f * ORC_PI * sample.x, &sinPhi, &cosPhi);
     return Vec3(r * cosPhi, r * sinPhi, z);
 }
+
+inline Float squareToUniformSpherePdf() { return ORC_INV_FOURPI; } /* warp.h:43 */
+
+/* util.cpp:447-485 */
+inline bool solveQuadratic(Float a, Float b, Float c, Float &x0, Float &x1) {
+    if (a == 0) {
+        if (b != 0) {
+            x0 = x1 = -c / b;
+            return true;
+        }
+        return false;
+    }
+    Float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0)
+        return false;
+    Float temp, sqrtDiscrim = std::sqrt(discrim);
+    if (b < 0)
+        temp = -0.5f * (b - sqrtDiscrim);
+    else
+        temp = -0.5f * (b + sqrtDiscrim);
+    x0 = temp / a;
+    x1 = c / temp;
+    if (x0 > x1)
+        std::swap(x0, x1);
+    return true;
+}
+
+/* bsphere.h:30-95 */
+struct BSphere {
+    Vec3 center; Float radius;
+    BSphere() : center(0.0f), radius(0.0f) {}
+    BSphere(const Vec3 &c, Float r) : center(c), radius(r) {}
+    bool rayIntersect(const Vec3 &ro, const Vec3 &rd, Float &nearHit, Float &farHit) const {
+        Vec3 o = ro - center;
+        Float A = rd.lengthSquared();
+        Float B = 2 * dot(o, rd);
+        Float C = o.lengthSquared() - radius * radius;
+        return solveQuadratic(A, B, C, nearHit, farHit);
+    }
+};
 
 /* ---------------- math.cpp:25-72 ---------------- */
 inline Float mts_erfinv(Float x) {

@@ -3,8 +3,8 @@
  *
  * o_path.h: MIPathTracer::Li restated from src/integrators/path/path.cpp:119-300 with the
  * control flow, random-number consumption order and operation order of the reference.
- * Environment emitters, subsurface and media are outside the path's scope (no environment
- * emitter exists, so `scene->evalEnvironment` contributes 0 and a miss ends the path).
+ * The `constant` environment emitter is supported (path.cpp:136-143, 233-248); subsurface and media are
+ * outside the path's scope.
  */
 #pragma once
 #include "o_bsdf.h"
@@ -41,8 +41,12 @@ inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray
     Float eta = 1.0f;
 
     while (depth <= ip.maxDepth || ip.maxDepth < 0) {
-        if (!its.isValid())
-            break;                       /* no environment emitter: path.cpp:136-143 adds nothing */
+        if (!its.isValid()) {
+            /* path.cpp:136-143 */
+            if (emittedRadiance && (!ip.hideEmitters || scattered))
+                Li += throughput * scene.evalEnvironment(ray);
+            break;
+        }
 
         const Material &bsdf = scene.bsdfOf(its);
 
@@ -97,7 +101,17 @@ inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray
                 hitEmitter = true;
             }
         } else {
-            break;                       /* no environment emitter, path.cpp:233-248 */
+            /* path.cpp:233-248 */
+            if (scene.envEmitter >= 0) {
+                if (ip.hideEmitters && !scattered)
+                    break;
+                value = scene.evalEnvironment(ray);
+                if (!scene.fillDirectSamplingRecord(dRec, ray))
+                    break;
+                hitEmitter = true;
+            } else {
+                break;
+            }
         }
 
         throughput *= bsdfWeight;

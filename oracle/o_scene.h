@@ -176,6 +176,8 @@ public:
     std::vector<Material> materials;
     std::vector<phip_emitter> emitters;
     DiscreteDistribution emitterPDF;
+    int envEmitter = -1;                 /* Scene::m_environmentEmitter (index into emitters) */
+    BSphere envSphere;                   /* ConstantBackgroundEmitter::m_sceneBSphere */
     KDTree kdtree;
     phip_camera camera;
     phip_film film;
@@ -201,6 +203,7 @@ public:
             if (s.first_triangle != expect) throw std::runtime_error("oracle: shape triangle ranges must tile the index array");
             if (s.material >= d.n_materials) throw std::runtime_error("oracle: bad material id");
             if (s.emitter >= (int32_t) d.n_emitters) throw std::runtime_error("oracle: bad emitter id");
+            if (s.emitter >= 0 && d.emitters[s.emitter].type != PHIP_EMITTER_AREA) throw std::runtime_error("oracle: a shape can only carry an area emitter");
             expect += s.n_triangles;
             for (uint32_t j = 0; j < s.n_triangles; ++j) { triShape[s.first_triangle + j] = i; triPrim[s.first_triangle + j] = j; }
         }
@@ -222,6 +225,27 @@ public:
         for (uint32_t i = 0; i < d.n_emitters; ++i) emitterPDF.append(emitters[i].sampling_weight);
         if (d.n_emitters > 0) emitterPDF.normalize();
         kdtree.build(positions.data(), indices.data(), d.n_triangles, triShape.data(), triPrim.data());
+        for (uint32_t i = 0; i < d.n_emitters; ++i) {
+            if (emitters[i].type == PHIP_EMITTER_AREA) continue;
+            if (emitters[i].type != PHIP_EMITTER_CONSTANT) throw std::runtime_error("oracle: unknown emitter type");
+            if (envEmitter >= 0) throw std::runtime_error("The scene may only contain one environment emitter");   /* scene.cpp:510-513 */
+            envEmitter = (int) i;
+        }
+        if (envEmitter >= 0) {
+            /* Scene::initializeBidirectional (scene.cpp:384-413): the scene box seen by createShape() is the
+               kd-tree's (enlarged) box expanded by the sensor's translation bounds (track.cpp:79-83: the image of
+               the origin); constant.cpp:67-72: bounding sphere of that box (aabb.cpp:44-47), radius x 1.5 */
+            AABB aabb = kdtree.aabb;
+            const float *m = camera.to_world;
+            Vec3 sp(m[3], m[7], m[11]);
+            const Float w = m[15];
+            if (w != 1.0f) sp = sp / w;              /* transform.h: Transform::operator()(Point) */
+            aabb.expandBy(sp);
+            const Vec3 center = (aabb.max + aabb.min) * (Float) 0.5;
+            BSphere bs(center, (center - aabb.max).length());
+            bs.radius = std::max(ORC_EPSILON, bs.radius * 1.5f);
+            envSphere = bs;
+        }
     }
 
     Vec3 P(uint32_t tri, int c) const { const float *p = &positions[3 * (size_t) indices[3 * (size_t) tri + c]]; return Vec3(p[0], p[1], p[2]); }
@@ -356,21 +380,89 @@ public:
         dRec.measure = ESolidAngle;
     }
 
-    /* scene.cpp:828-852 (visibility test included), area.cpp:158-173 */
+    /* scene.h:910-913 + constant.cpp:254-256 */
+    Spectrum evalEnvironment(const Ray &) const {
+        return envEmitter >= 0 ? Spectrum(emitters[envEmitter].radiance) : Spectrum(0.0f);
+    }
+
+    /* constant.cpp:258-273; false = "internal error" (the path is terminated, path.cpp:242-243) */
+    bool fillDirectSamplingRecord(DirectSamplingRecord &dRec, const Ray &ray) const {
+        Float nearT, farT;
+        if (!envSphere.rayIntersect(ray.o, ray.d, nearT, farT) || nearT > 0 || farT < 0)
+            return false;
+        dRec.p = ray.o + ray.d * farT;
+        dRec.n = normalize(envSphere.center - dRec.p);
+        dRec.measure = ESolidAngle;
+        dRec.emitter = envEmitter;
+        dRec.d = ray.d;
+        dRec.dist = farT;
+        return true;
+    }
+
+    /* constant.cpp:184-225 */
+    Spectrum constantSampleDirect(const phip_emitter &em, DirectSamplingRecord &dRec, const Vec2 &sample) const {
+        Vec3 d;
+        Float pdf;
+        if (!dRec.refN.isZero()) {
+            d = squareToCosineHemisphere(sample);
+            pdf = squareToCosineHemispherePdf(d);
+            d = Frame(dRec.refN).toWorld(d);
+        } else {
+            d = squareToUniformSphere(sample);
+            pdf = squareToUniformSpherePdf();
+        }
+        Float nearT, farT;
+        dRec.pdf = 0.0f;
+        if (!envSphere.rayIntersect(dRec.ref, d, nearT, farT))
+            return Spectrum(0.0f);
+        if (!(nearT < 0 && farT > 0))
+            return Spectrum(0.0f);
+        dRec.p = dRec.ref + d * farT;
+        dRec.n = normalize(envSphere.center - dRec.p);
+        dRec.measure = ESolidAngle;
+        dRec.d = d;
+        dRec.dist = farT;
+        dRec.pdf = pdf;
+        if (!dRec.refN.isZero() && dot(dRec.d, dRec.refN) <= 0)
+            return Spectrum(0.0f);
+        return Spectrum(em.radiance) / pdf;
+    }
+
+    /* constant.cpp:227-243 */
+    Float constantPdfDirect(const DirectSamplingRecord &dRec) const {
+        Float pdfSA;
+        if (!dRec.refN.isZero())
+            pdfSA = ORC_INV_PI * std::max((Float) 0.0f, dot(dRec.d, dRec.refN));
+        else
+            pdfSA = squareToUniformSpherePdf();
+        if (dRec.measure == ESolidAngle)
+            return pdfSA;
+        else if (dRec.measure == EArea)
+            return pdfSA * absDot(dRec.d, dRec.n) / (dRec.dist * dRec.dist);
+        else
+            return 0.0f;
+    }
+
+    /* area.cpp:158-173 */
+    Spectrum areaSampleDirect(const phip_emitter &em, DirectSamplingRecord &dRec, const Vec2 &sample) const {
+        shapeSampleDirect(shapes[em.shape], dRec, sample);
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
+            return Spectrum(em.radiance) / dRec.pdf;
+        } else {
+            dRec.pdf = 0.0f;
+            return Spectrum(0.0f);
+        }
+    }
+
+    /* scene.cpp:828-852 (visibility test included) */
     Spectrum sampleEmitterDirect(DirectSamplingRecord &dRec, const Vec2 &_sample, PathCounters *pc) const {
         Vec2 sample(_sample);
         if (emitters.empty()) { dRec.pdf = 0; return Spectrum(0.0f); }
         Float emPdf;
         size_t index = emitterPDF.sampleReuse(sample.x, emPdf);
         const phip_emitter &em = emitters[index];
-        shapeSampleDirect(shapes[em.shape], dRec, sample);
-        Spectrum value;
-        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
-            value = Spectrum(em.radiance) / dRec.pdf;
-        } else {
-            dRec.pdf = 0.0f;
-            value = Spectrum(0.0f);
-        }
+        Spectrum value = em.type == PHIP_EMITTER_CONSTANT ? constantSampleDirect(em, dRec, sample)
+                                                          : areaSampleDirect(em, dRec, sample);
         if (dRec.pdf != 0) {
             Ray ray(dRec.ref, dRec.d, ORC_EPSILON, dRec.dist * (1 - ORC_SHADOW_EPSILON));
             if (rayIntersectShadow(ray, pc))
@@ -387,7 +479,9 @@ public:
     Float pdfEmitterDirect(const DirectSamplingRecord &dRec) const {
         const phip_emitter &em = emitters[dRec.emitter];
         Float pdf;
-        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+        if (em.type == PHIP_EMITTER_CONSTANT) {
+            pdf = constantPdfDirect(dRec);
+        } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
             Float pdfPos = shapes[em.shape].invSurfaceArea;
             if (dRec.measure == ESolidAngle)
                 pdf = pdfPos * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);

@@ -249,3 +249,39 @@ def test_material_zoo_matches_oracle(gpu, oracle, gauss):
         P, T, N = S.sphere_mesh((90 + 95 * i, 420 - 60 * (i % 2), 150 + 60 * i), 45.0, 24, 12)
         sb.mesh(P, T, m, normals=N)
     compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.999, maxDepth=8)
+
+
+def test_constant_environment_matches_oracle(gpu, oracle, gauss):
+    """the `constant` environment emitter (constant.cpp; path.cpp:136-143, 233-265)"""
+    # (a) smooth-shaded spheres (diffuse, twosided diffuse -> uniform-sphere NEE, copper, glass) on a floor, environment only
+    sb = S.SceneBuilder()
+    floor = sb.diffuse((0.4, 0.45, 0.5))
+    mats = [sb.diffuse((0.7, 0.3, 0.2)), sb.twosided(sb.diffuse((0.2, 0.6, 0.3))),
+            sb.roughconductor(alpha=0.2, eta=S.CU_ETA, k=S.CU_K), sb.dielectric(1.5, 1.0)]
+    sb.quad((-6, 0, -6), (6, 0, -6), (6, 0, 6), (-6, 0, 6), floor, facing=(0, 1, 0))
+    for i, m in enumerate(mats):
+        P, T, N = S.sphere_mesh((-3 + 2 * i, 0.8, 0.5 * (i % 2)), 0.8, 24, 12)
+        sb.mesh(P, T, m, normals=N)
+    sb.constant((0.9, 1.0, 1.2))
+    sb.perspective((0, 3, -9), (0, 0.5, 0), (0, 1, 0), 40.0)
+    sb.hdrfilm(160, 96, gauss)
+    same, r = compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.999, maxDepth=8)
+    print("env spheres: identical %.6f rel L2 %.3e" % (same, r))
+    compare_render(gpu, oracle, sb.desc(), 4, min_identical=0.999, maxDepth=8, hideEmitters=True)
+    compare_render(gpu, oracle, sb.desc(), 4, min_identical=0.999, maxDepth=3, strictNormals=True)
+    # (b) Cornell box (area light) + environment with a different sampling weight: two emitters in the selection PDF
+    sb = S.cornell_box(128, 128, gauss)
+    sb.constant((0.3, 0.3, 0.5), sampling_weight=0.5)
+    compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.9999, maxDepth=6)
+    # (c) nothing but the environment
+    sb = S.SceneBuilder(); sb.diffuse((0.5, 0.5, 0.5)); sb.constant((0.25, 0.5, 1.0))
+    sb.perspective((0, 0, -5), (0, 0, 0), (0, 1, 0), 45.0); sb.hdrfilm(40, 24, gauss)
+    compare_render(gpu, oracle, sb.desc(), 2, min_identical=1.0)
+
+
+def test_environment_error_behaviour(gpu, phip, gauss):
+    sb = S.SceneBuilder(); sb.diffuse((0.5, 0.5, 0.5)); sb.constant((1, 1, 1)); sb.constant((2, 2, 2))
+    sb.perspective((0, 0, -5), (0, 0, 0), (0, 1, 0), 45.0); sb.hdrfilm(8, 8, gauss)
+    d = sb.desc()
+    assert not phip.phip_scene_create(C.byref(d), 0)
+    assert b"one environment emitter" in phip.phip_last_error()

@@ -89,6 +89,71 @@ def test_depth_and_emitter_visibility_semantics(oracle, gauss):
         sc.render(A.default_render_params(spp=1, rr_depth=0))
 
 
+def test_constant_environment_closed_form(oracle, gauss):
+    """constant.cpp + path.cpp:136-143,233-265: a convex diffuse surface under a uniform environment L radiates
+    exactly rho * L (emitter sampling and BSDF sampling both draw cosine-distributed directions, so every
+    sample carries 0.5 rho L + 0.5 rho L); the background is L; hideEmitters removes only the background"""
+    rho, L = np.array([0.5, 0.25, 0.75], np.float32), np.array([1.0, 2.0, 3.0], np.float32)
+    sb = S.SceneBuilder()
+    m = sb.diffuse(tuple(rho))
+    sb.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), m, facing=(0, 0, -1))
+    sb.constant(tuple(L))
+    sb.perspective((0, 0, -6), (0, 0, 0), (0, 1, 0), 45.0)
+    sb.hdrfilm(48, 48, gauss)
+    sc = oracle.OracleScene(sb.desc())
+    film, smp, st = sc.render(A.default_render_params(spp=8, max_depth=-1), want_samples=True)
+    img = oracle.develop(film)
+    on_quad = film[..., 3] / film[..., 4] > 0.999          # alpha == 1: every sample of the pixel hit the quad
+    off_quad = film[..., 3] == 0
+    assert on_quad.sum() > 100 and off_quad.sum() > 500
+    assert np.abs(img[on_quad] / (rho * L) - 1).max() < 1e-5
+    assert np.abs(img[off_quad] / L - 1).max() < 1e-5
+    # per sample: alpha 0 -> L, alpha 1 -> rho L (zero variance)
+    hit = smp[..., 3] == 1
+    assert np.abs(smp[..., :3][hit] / (rho * L) - 1).max() < 1e-5 and (smp[..., :3][~hit] == L).all()
+    assert st.path_vertices == st.samples                   # one surface vertex at most (Li's depth counter starts at 1)
+    # hideEmitters: path.cpp:139-141 drops the directly visible environment only
+    fh = sc.render(A.default_render_params(spp=8, max_depth=-1, hide_emitters=1))[0]
+    ih = oracle.develop(fh)
+    assert (ih[off_quad] == 0).all() and np.abs(ih[on_quad] / (rho * L) - 1).max() < 1e-5
+    # maxDepth = 1: emitted radiance only; maxDepth = 2 already holds the whole (single-bounce) transport
+    i1 = oracle.develop(sc.render(A.default_render_params(spp=8, max_depth=1))[0])
+    assert (i1[on_quad] == 0).all() and np.abs(i1[off_quad] / L - 1).max() < 1e-5
+    i2 = oracle.develop(sc.render(A.default_render_params(spp=8, max_depth=2))[0])
+    assert np.abs(i2[on_quad] / (rho * L) - 1).max() < 1e-5
+    # the back of a one-sided diffuse surface is black; a twosided one is lit from both sides
+    # (refN = 0 for BSDFs with a back side: the emitter is then sampled over the whole sphere, constant.cpp:193-196)
+    sb2 = S.SceneBuilder()
+    one = sb2.diffuse(tuple(rho)); two = sb2.twosided(sb2.diffuse(tuple(rho)))
+    sb2.quad((-2.2, -1, 0), (-0.2, -1, 0), (-0.2, 1, 0), (-2.2, 1, 0), one, facing=(0, 0, 1))
+    sb2.quad((0.2, -1, 0), (2.2, -1, 0), (2.2, 1, 0), (0.2, 1, 0), two, facing=(0, 0, 1))
+    sb2.constant(tuple(L))
+    sb2.perspective((0, 0, -8), (0, 0, 0), (0, 1, 0), 45.0)
+    sb2.hdrfilm(64, 32, gauss)
+    sc2 = oracle.OracleScene(sb2.desc())
+    f2 = sc2.render(A.default_render_params(spp=256, max_depth=-1))[0]
+    i2 = oracle.develop(f2)
+    solid = f2[..., 3] / f2[..., 4] > 0.999
+    left = solid & (np.arange(64)[None, :] < 32); right = solid & (np.arange(64)[None, :] >= 32)
+    assert left.sum() > 30 and right.sum() > 30
+    if i2[left].max() > 0: left, right = right, left        # (the image x axis runs against world x for this camera)
+    assert i2[left].max() < 0.01 and np.median(i2[left]) == 0      # (border pixels see a trace of the background through the filter)
+    assert np.abs(i2[right].mean(axis=0) / (rho * L) - 1).max() < 0.02      # uniform-sphere NEE: no longer zero variance
+
+
+def test_environment_validation(oracle, gauss):
+    sb = S.SceneBuilder(); sb.diffuse((0.5, 0.5, 0.5))
+    sb.constant((1, 1, 1)); sb.constant((2, 2, 2))
+    sb.perspective((0, 0, -5), (0, 0, 0), (0, 1, 0), 45.0); sb.hdrfilm(8, 8, gauss)
+    with pytest.raises(RuntimeError, match="one environment emitter"):      # scene.cpp:510-513
+        oracle.OracleScene(sb.desc())
+    # an empty scene under an environment: every pixel shows it
+    sb = S.SceneBuilder(); sb.diffuse((0.5, 0.5, 0.5)); sb.constant((0.25, 0.5, 1.0))
+    sb.perspective((0, 0, -5), (0, 0, 0), (0, 1, 0), 45.0); sb.hdrfilm(8, 8, gauss)
+    img = oracle.develop(oracle.OracleScene(sb.desc()).render(A.default_render_params(spp=2))[0])
+    assert np.abs(img / np.array([0.25, 0.5, 1.0]) - 1).max() < 1e-5
+
+
 def test_sfmt_streams_agree_statistically_with_ctr_stream(oracle, gauss):
     """`independent` semantics (one SFMT19937 clone per worker, sequential consumption) and the
     counter-based parity stream estimate the same image"""
