@@ -264,6 +264,9 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
+#ifndef SHADOW_UNSORTED
+#define SHADOW_UNSORTED 1
+#endif
 #define DONE_REF ((int32_t) 0x80000000)   /* 'no more nodes' marker; as a leaf reference it would need 2^28 triangle records */
 
 /* One BVH4 node step: slab test of the four children, nearest-first order, push the farther hits,
@@ -289,6 +292,32 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
                 if (key[1] < INFINITY) stack.push(ref[1]);                                                \
             }                                                                                             \
             cur = (int32_t) ref[0];                                                                       \
+        } else {                                                                                          \
+            cur = stack.sp == 0 ? DONE_REF : (int32_t) stack.pop();                                       \
+        }                                                                                                 \
+    }
+/* Any-hit variant: the visiting order of the children does not matter for an unoccluded ray (all of them are
+   visited) -- no sorting network.  Branch-free: every hit child is written at the current stack top, the top only
+   advances once a later hit shows that the entry has to be kept; the last hit child becomes the next node. */
+#define NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)                                   \
+    {                                                                                                     \
+        LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)                                       \
+        ++nodeVisits;                                                                                     \
+        float key[4]; uint32_t ref[4];                                                                    \
+        SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)                                                       \
+        const bool h0 = key[0] < INFINITY, h1 = key[1] < INFINITY, h2 = key[2] < INFINITY, h3 = key[3] < INFINITY; \
+        if (h0 || h1 || h2 || h3) {                                                                       \
+            uint32_t nxt = ref[0]; bool have = h0;                                                        \
+            if (stack.sp + 3 <= stack.depth) {                                                            \
+                stack.lds[stack.sp * BLOCK] = nxt; stack.sp += (h1 && have) ? 1 : 0; nxt = h1 ? ref[1] : nxt; have = have || h1; \
+                stack.lds[stack.sp * BLOCK] = nxt; stack.sp += (h2 && have) ? 1 : 0; nxt = h2 ? ref[2] : nxt; have = have || h2; \
+                stack.lds[stack.sp * BLOCK] = nxt; stack.sp += (h3 && have) ? 1 : 0; nxt = h3 ? ref[3] : nxt;                     \
+            } else {                                                                                      \
+                if (h1) { if (have) stack.push(nxt); nxt = ref[1]; have = true; }                         \
+                if (h2) { if (have) stack.push(nxt); nxt = ref[2]; have = true; }                         \
+                if (h3) { if (have) stack.push(nxt); nxt = ref[3]; have = true; }                         \
+            }                                                                                             \
+            cur = (int32_t) nxt;                                                                          \
         } else {                                                                                          \
             cur = stack.sp == 0 ? DONE_REF : (int32_t) stack.pop();                                       \
         }                                                                                                 \
@@ -321,8 +350,10 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
     bool found = false;
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
     while (cur != DONE_REF) {
-        if (cur >= 0)
-            NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+        if (cur >= 0) {
+            if (SHADOW && SHADOW_UNSORTED) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+            else NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+        }
         if (cur < 0 && cur != DONE_REF) {
             /* a leaf reference doubles as the lane's progress inside the leaf: ~((next record << 3) | records left - 1) */
             const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;
@@ -387,8 +418,10 @@ __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack 
         if (active) {
             /* one node step and one triangle test per iteration (see traverse()) */
             for (;;) {
-                if (cur >= 0)
-                    NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+                if (cur >= 0) {
+                    if (SHADOW && SHADOW_UNSORTED) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+                    else NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+                }
                 bool finished = false;
                 if (cur < 0 && cur != DONE_REF) {
                     const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;

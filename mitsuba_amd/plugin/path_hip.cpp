@@ -102,6 +102,7 @@ private:
         std::vector<float> positions, normals; std::vector<uint32_t> indices;
         std::vector<phip_shape> shapes; std::vector<phip_material> materials; std::vector<phip_emitter> emitters;
         std::map<const BSDF *, uint32_t> bsdfIds;
+        std::map<const Shape *, uint32_t> shapeIds;
         bool anyNormals = false;
 
         const ref_vector<Shape> &list = scene->getShapes();
@@ -128,21 +129,32 @@ private:
                 for (int k = 0; k < 3; ++k) indices.push_back(s.first_vertex + mesh->getTriangles()[t].idx[k]);
             s.material = convertBSDF(shape->getBSDF(), materials, bsdfIds);
             s.emitter = -1;
-            if (shape->isEmitter()) {
-                const Emitter *e = shape->getEmitter();
-                if (e->getClass()->getName() != "AreaLight")
-                    Log(EError, "path_hip: only area emitters are supported");
-                phip_emitter pe; memset(&pe, 0, sizeof(pe));
-                Spectrum rad = e->getProperties().getSpectrum("radiance", Spectrum::getD65());   /* area.cpp:80 */
-                Float r, g, b; rad.toLinearRGB(r, g, b);
-                pe.radiance[0] = r; pe.radiance[1] = g; pe.radiance[2] = b;
-                pe.sampling_weight = e->getSamplingWeight(); pe.shape = (uint32_t) shapes.size();
-                s.emitter = (int32_t) emitters.size(); emitters.push_back(pe);
-            }
+            shapeIds[shape] = (uint32_t) shapes.size();
             shapes.push_back(s);
         }
-        if (scene->hasEnvironmentEmitter())
-            Log(EError, "path_hip: environment emitters are not supported yet (SURVEY 8f)");
+        /* emitters in the order of Scene::getEmitters(): the selection PDF (scene.cpp:375-381) is built in that order */
+        const ref_vector<Emitter> &ems = scene->getEmitters();
+        for (size_t i = 0; i < ems.size(); ++i) {
+            const Emitter *e = ems[i].get();
+            const std::string cls = e->getClass()->getName();
+            phip_emitter pe; memset(&pe, 0, sizeof(pe));
+            Spectrum rad = e->getProperties().getSpectrum("radiance", Spectrum::getD65());   /* area.cpp:80, constant.cpp:48 */
+            Float r, g, b; rad.toLinearRGB(r, g, b);
+            pe.radiance[0] = r; pe.radiance[1] = g; pe.radiance[2] = b;
+            pe.sampling_weight = e->getSamplingWeight();
+            if (cls == "AreaLight") {
+                std::map<const Shape *, uint32_t>::const_iterator it = shapeIds.find(e->getShape());
+                if (it == shapeIds.end())
+                    Log(EError, "path_hip: area emitter without a shape in the scene");
+                pe.type = PHIP_EMITTER_AREA; pe.shape = it->second;
+                shapes[it->second].emitter = (int32_t) emitters.size();
+            } else if (cls == "ConstantBackgroundEmitter") {
+                pe.type = PHIP_EMITTER_CONSTANT; pe.shape = 0xFFFFFFFFu;     /* the library derives m_sceneBSphere itself */
+            } else {
+                Log(EError, "path_hip: emitter \"%s\" is not supported (area, constant)", cls.c_str());
+            }
+            emitters.push_back(pe);
+        }
 
         phip_scene_desc d; memset(&d, 0, sizeof(d));
         d.abi_version = PHIP_ABI_VERSION;

@@ -14,7 +14,7 @@ for key in sys.argv[1:] or cfgs:
     t = time.time(); sc = Scene(sb.desc()); tb = time.time() - t
     integ = PathHIP(maxDepth=md); film = HDRFilm(w, h)
     integ.render(sc, film, 1)
-    t = time.time(); integ.render(sc, film, spp, flags=A.PHIP_FLAG_KERNEL_TIMING); dt = time.time() - t
+    t = time.time(); integ.render(sc, film, spp, flags=0 if os.environ.get('NOTIMING') else A.PHIP_FLAG_KERNEL_TIMING); dt = time.time() - t
     st = integ.stats.as_dict()
     n = w * h * spp
     print(json.dumps({"scene": key, "tris": sb.n_triangles, "accel": sc.accel_info().as_dict(), "scene_create_s": round(tb, 3), "spp": spp, "Msamples/s": round(n / 1e6 / dt, 1),
