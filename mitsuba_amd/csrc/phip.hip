@@ -852,13 +852,15 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
         } else {
             Isect its;
             fillIntersection(S, rayD, prim, hit.y, hit.z, hit.x, its);
-            l = L[id];
+            /* L[id] is zero until the sample's first vertex writes it (the buffer is cleared per pass), and later
+               vertices only touch it when they hit an emitter: no unconditional 64-byte-sector read per vertex */
             if (flags & F_FIRST) {
                 l.w = 1.0f;                     /* alpha, records.inl:117-144 */
                 haveAdd = true;
             } else {
                 /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
                 if (its.emitter >= 0) {
+                    l = L[id];
                     const float *em = emitterRecord(T, (uint32_t) its.emitter);
                     V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
                     DirectRec dRec;                                /* pdfEmitterDirect reads refN, n, d, dist only */
@@ -1128,17 +1130,23 @@ __global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, cons
 }
 
 /* LDS-tiled film gather (filters with reach <= FILM_MAX_REACH pixels, i.e. every reference default): a block owns
- * 16x16 destination pixels; per sample index k the block first evaluates the sample position and loads the
- * radiance of each of the (16+2R)^2 source pixels ONCE into LDS, then every destination lane accumulates its
- * (2R+1)^2 neighbours from LDS.  Same arithmetic as k_film per (sample, pixel) pair; only the order of the
- * float additions differs. */
+ * 16x16 destination pixels.  Per sample index k the block first STAGES each of the (16+2R)^2 source pixels' sample
+ * ONCE in LDS: radiance, the frame coordinates of the first pixel of its filter footprint and the separable filter
+ * weights of ImageBlock::put (imageblock.h:124-204: footprint clipped to the bitmap of the render block the sample
+ * belongs to, weights from the discretised table) -- weights outside the footprint are stored as 0, which adds
+ * nothing.  Then every destination lane accumulates its (2R+1)^2 neighbours: two integer subtractions, two weight
+ * reads, one product and five multiply-adds per neighbour.  Same arithmetic per (sample, pixel) pair as k_film;
+ * only the order of the float additions differs. */
 #define FILM_MAX_REACH 4
 #define FILM_TILE 16
+template <int RMAX>
 __global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
                                                      int tilesX, float *out, int accumulate, unsigned long long *invalidCount, int R) {
-    constexpr int TMAX = FILM_TILE + 2 * FILM_MAX_REACH;
+    constexpr int TMAX = FILM_TILE + 2 * RMAX;
+    constexpr int NW = 2 * RMAX + 2;           /* weights per axis: floor(p + r) - ceil(p - r) + 1 <= 2r + 1 with r < RMAX + 0.5 */
     __shared__ float4 sVal[TMAX * TMAX];       /* radiance rgb + alpha of the source pixel's k-th sample */
-    __shared__ float2 sPos[TMAX * TMAX];       /* sample position in the source block's bitmap coordinates; x = NaN: no sample */
+    __shared__ int2 sOrg[TMAX * TMAX];         /* frame coordinates of weight [0] of the sample's footprint */
+    __shared__ float sWx[TMAX * TMAX * NW], sWy[TMAX * TMAX * NW];
     __shared__ int4 sGeo[TMAX * TMAX];         /* (offX - border, offY - border, bw, bh) of the source pixel's render block */
     __shared__ uint32_t sBase[TMAX * TMAX];    /* low word of the sample id of k = 0 (0xFFFFFFFF: pixel not rendered here) */
     __shared__ float sTable[PHIP_FILTER_RESOLUTION + 1];
@@ -1168,47 +1176,81 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc
     float acc[5] = { 0, 0, 0, 0, 0 };
     unsigned long long invalid = 0;
     const bool inside = x < F.width && y < F.height;
+    /* the radiance of sample k + 1 is fetched while sample k is being gathered (the k loop is a chain of
+       barriers otherwise: global-load latency would be paid sppPass times in a row) */
+    constexpr int NSTAGE = (TMAX * TMAX + BLOCK - 1) / BLOCK;
+    float4 pre[NSTAGE];
+    auto fetch = [&](uint32_t k) {
+#pragma unroll
+        for (int n = 0; n < NSTAGE; ++n) {
+            const int i = (int) threadIdx.x + n * BLOCK;
+            pre[n] = make_float4(0, 0, 0, 0);
+            if (i < T * T && k < rc.sppPass) {
+                const uint32_t base = sBase[i];
+                if (base != 0xFFFFFFFFu) {
+                    const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+                    const int4 g = sGeo[i];
+                    const uint32_t m = spreadBits((uint32_t) (sx - (g.x + F.border))) | (spreadBits((uint32_t) (sy - (g.y + F.border))) << 1);
+                    pre[n] = L[(((unsigned long long) base * rc.sppPass + k) << (2 * rc.tileShift)) | m];
+                }
+            }
+        }
+    };
+    fetch(0);
     for (uint32_t k = 0; k < rc.sppPass; ++k) {
-        for (int i = threadIdx.x; i < T * T; i += BLOCK) {
+#pragma unroll
+        for (int n = 0; n < NSTAGE; ++n) {
+            const int i = (int) threadIdx.x + n * BLOCK;
+            if (i >= T * T) break;
             const uint32_t base = sBase[i];
-            float2 pos = make_float2(__builtin_nanf(""), 0.0f);
             float4 v = make_float4(0, 0, 0, 0);
+            int2 org = make_int2(0, 0);
+            float wx[NW], wy[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) { wx[j] = 0.0f; wy[j] = 0.0f; }
             if (base != 0xFFFFFFFFu) {
                 const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
                 const int4 g = sGeo[i];
                 const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
                 const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
                 const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
-                pos = make_float2(px - 0.5f - (float) g.x, py - 0.5f - (float) g.y);
-                const uint32_t m = spreadBits((uint32_t) (sx - (g.x + F.border))) | (spreadBits((uint32_t) (sy - (g.y + F.border))) << 1);
-                const unsigned long long id = (((unsigned long long) base * rc.sppPass + k) << (2 * rc.tileShift)) | m;
-                v = L[id];
+                const float posx = px - 0.5f - (float) g.x, posy = py - 0.5f - (float) g.y;   /* block-bitmap coordinates */
+                v = pre[n];
                 /* validity check of ImageBlock::put (imageblock.h:148-151) */
                 if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
-                    pos.x = __builtin_nanf("");
                     /* count each rejected sample once: by the block that owns its pixel */
                     if (sx >= x0 && sx < x0 + FILM_TILE && sy >= y0 && sy < y0 + FILM_TILE) ++invalid;
+                    v = make_float4(0, 0, 0, 0);
+                } else {
+                    /* footprint and weights, imageblock.h:159-180 */
+                    const int uminx = (int) ceilf(posx - F.radius), uminy = (int) ceilf(posy - F.radius);
+                    const int minx = max(uminx, 0), maxx = min((int) floorf(posx + F.radius), g.z - 1);
+                    const int miny = max(uminy, 0), maxy = min((int) floorf(posy + F.radius), g.w - 1);
+                    org = make_int2(g.x + uminx, g.y + uminy);
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const int bx = uminx + j, by = uminy + j;
+                        if (bx >= minx && bx <= maxx) wx[j] = sTable[min((int) fabsf(((float) bx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                        if (by >= miny && by <= maxy) wy[j] = sTable[min((int) fabsf(((float) by - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                    }
                 }
             }
-            sPos[i] = pos; sVal[i] = v;
+            sVal[i] = v; sOrg[i] = org;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) { sWx[i * NW + j] = wx[j]; sWy[i * NW + j] = wy[j]; }
         }
         __syncthreads();
+        fetch(k + 1);
         if (inside) {
             for (int dyy = -R; dyy <= R; ++dyy) {
                 for (int dxx = -R; dxx <= R; ++dxx) {
                     const int i = (ly + R + dyy) * T + (lx + R + dxx);
-                    const float2 pos = sPos[i];
-                    if (pos.x != pos.x) continue;
-                    const int4 g = sGeo[i];
-                    const int dx = x - g.x, dy = y - g.y;
-                    if (dx < 0 || dy < 0 || dx >= g.z || dy >= g.w) continue;
-                    const int minx = max((int) ceilf(pos.x - F.radius), 0), maxx = min((int) floorf(pos.x + F.radius), g.z - 1);
-                    const int miny = max((int) ceilf(pos.y - F.radius), 0), maxy = min((int) floorf(pos.y + F.radius), g.w - 1);
-                    if (dx < minx || dx > maxx || dy < miny || dy > maxy) continue;
+                    const int2 org = sOrg[i];
+                    const int jx = x - org.x, jy = y - org.y;
+                    if ((unsigned) jx >= (unsigned) NW || (unsigned) jy >= (unsigned) NW) continue;
+                    const float w = sWx[i * NW + jx] * sWy[i * NW + jy];
+                    if (w == 0.0f) continue;                   /* outside the footprint (or a zero of the filter): adds nothing */
                     const float4 v = sVal[i];
-                    const float wx = sTable[min((int) fabsf(((float) dx - pos.x) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
-                    const float wy = sTable[min((int) fabsf(((float) dy - pos.y) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
-                    const float w = wx * wy;
                     acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
                 }
             }
@@ -1840,8 +1882,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             const dim3 fg((W + 15) / 16, (H + 15) / 16);
             const int reach = (int) std::floor(D.film.radius + 0.5f);
             if (reach <= FILM_MAX_REACH && !getenv("PHIP_FILM_GENERIC"))
-                hipLaunchKernelGGL(k_film_tiled, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
-                                   sppDone > 0 ? 1 : 0, sc->invalid.p, reach);
+                if (reach <= 2)
+                    hipLaunchKernelGGL(k_film_tiled<2>, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
+                                       sppDone > 0 ? 1 : 0, sc->invalid.p, reach);
+                else
+                    hipLaunchKernelGGL(k_film_tiled<FILM_MAX_REACH>, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
+                                       sppDone > 0 ? 1 : 0, sc->invalid.p, reach);
             else
                 hipLaunchKernelGGL(k_film, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
                                    sppDone > 0 ? 1 : 0, sc->invalid.p);
