@@ -97,11 +97,14 @@ struct Builder {
     HostBVH &out;
     const float *positions; const uint32_t *indices;
     static constexpr int NBINS = 32;
-    static constexpr int MAX_LEAF = 4;
-    static constexpr float C_TRAV = 1.0f, C_ISECT = 1.0f;
+    int MAX_LEAF = 4;
+    float C_TRAV = 1.0f, C_ISECT = 1.0f;
     double sah = 0;
 
-    Builder(std::vector<BuildTri> &t, HostBVH &o, const float *p, const uint32_t *i) : T(t), out(o), positions(p), indices(i) {}
+    Builder(std::vector<BuildTri> &t, HostBVH &o, const float *p, const uint32_t *i) : T(t), out(o), positions(p), indices(i) {
+        if (const char *e = getenv("PHIP_BVH_MAXLEAF")) MAX_LEAF = std::min(8, std::max(1, atoi(e)));     /* experiment hooks */
+        if (const char *e = getenv("PHIP_BVH_CTRAV")) C_TRAV = (float) atof(e);
+    }
 
     /* pads a box so that a hit accepted by the Wald test (which tolerates a few ulp outside the
        exact triangle) can never be culled by the slab test */

@@ -783,7 +783,9 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
 #endif
-template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+/* MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
+   normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
+template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
        dependent lookups per NEE sample) and the materials */
@@ -895,7 +897,7 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
                     haveAdd = true;
                 }
                 if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
-                    || (rc.strictNormals && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
+                    || (STRICT && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
                     terminate = true;
             }
             V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
@@ -913,7 +915,7 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
                         const V3 wo = its.sh.toLocal(dRec.d);
                         float bPdf;
                         const V3 bsdfVal = bsdfEvalPdf<MM>(bctx, wo, bPdf);
-                        if (!bsdfVal.isZero() && (!rc.strictNormals || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
+                        if (!bsdfVal.isZero() && (!STRICT || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
                             const float weight = miWeight(dRec.pdf, bPdf);
                             shC = thr * value * bsdfVal * weight;
                             shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
@@ -930,7 +932,7 @@ template <int MM> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN
                     flags |= F_SCATTERED;
                     const V3 wo = its.sh.toWorld(bs.wo);
                     const float woDotGeoN = dot(its.geoN, wo);
-                    if (rc.strictNormals && woDotGeoN * cosTheta(bs.wo) <= 0) {
+                    if (STRICT && woDotGeoN * cosTheta(bs.wo) <= 0) {
                         terminate = true;
                     } else {
                         P.rayO[slot] = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
@@ -1843,11 +1845,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
             rc.countAlive = check ? 1 : 0;
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
-            switch (sc->materialMask) {
-                case 0: hipLaunchKernelGGL(k_shade<0>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
-                case MM_ROUGH: hipLaunchKernelGGL(k_shade<MM_ROUGH>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
-                case MM_DIELECTRIC: hipLaunchKernelGGL(k_shade<MM_DIELECTRIC>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
-                default: hipLaunchKernelGGL(k_shade<MM_ALL>, grid, block, 0, stream, D, P, rc, sc->L.p); break;
+            {
+                typedef void (*ShadeKernel)(DevScene, PathPool, RenderConst, float4 *);
+                static const ShadeKernel table[2][4] = {
+                    { k_shade<0, false>, k_shade<MM_ROUGH, false>, k_shade<MM_DIELECTRIC, false>, k_shade<MM_ALL, false> },
+                    { k_shade<0, true>, k_shade<MM_ROUGH, true>, k_shade<MM_DIELECTRIC, true>, k_shade<MM_ALL, true> } };
+                hipLaunchKernelGGL(table[rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
             }
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));

@@ -27,7 +27,7 @@ def run(counter, tag, cmd):
     agg = collections.defaultdict(float); n = collections.Counter()
     for f in glob.glob(os.path.join(tmp, "**", tag + "_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[k] += float(r["Counter_Value"]); n[k] += 1
     return agg, n
 
@@ -50,7 +50,7 @@ res["kernels"] = {}
 for k in sorted(rf):
     if not k.startswith("k_"):
         continue
-    gather = k.startswith("k_trace") or k.startswith("k_shadow") or k == "k_shade"
+    gather = k.startswith("k_trace") or k.startswith("k_shadow") or k.startswith("k_shade")
     fc = (fetch_gather_corr if gather else fetch_stream_corr) or 1.0
     fb = rf[k] * 1024 * fc; wb = rw.get(k, 0) * 1024 * (write_corr or 1.0)
     res["kernels"][k] = {"launches": nf[k], "fetch_KiB_raw": rf[k], "write_KiB_raw": rw.get(k, 0), "fetch_correction": fc,

@@ -22,7 +22,7 @@ def main():
     print("| kernel | calls | total_us | avg_us | min_us | max_us | % |")
     print("|---|---:|---:|---:|---:|---:|---:|")
     for n, c, t, a, mn, mx in rows:
-        short = n.split("(")[0]
+        short = n.split("(")[0].replace("void ", "")
         print("| `%s` | %d | %.1f | %.2f | %.2f | %.2f | %.1f |" % (short, c, t / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / total))
     print("\ntotal kernel time: %.2f ms" % (total / 1e6))
 
