@@ -32,7 +32,9 @@ def run(counter, tag, cmd):
     return agg, n
 
 
-res = {"workload": workload, "spp_override": spp or None, "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB"}
+res = {"workload": workload, "spp_override": spp or None, "pool_slots_override": os.environ.get("PHIP_POOL"),
+       "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB",
+       "note": "per-launch figures: the path pool must have the size of the full job (8 M slots for jobs >= 256 M samples, else 4 M) -- set PHIP_POOL when spp is reduced"}
 cf, _ = run("FETCH_SIZE", "cal_fetch", cal_cmd)
 cw, _ = run("WRITE_SIZE", "cal_write", cal_cmd)
 # gather: every 16-B read misses everything; the HBM transfer unit is a 64-B sector -> n*64 B expected (128 B if whole lines are fetched)
