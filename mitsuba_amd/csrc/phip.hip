@@ -503,6 +503,139 @@ struct ShadowSource {
 #endif
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
+/* ---- closest-hit AND any-hit rays of one iteration in ONE persistent launch ----
+ * The two ray kinds of an iteration are independent (k_shade consumes both results in the next iteration), so a wave
+ * first drains its share of the shadow queue and then, without a kernel boundary, refills idle lanes from its share
+ * of the closest-hit queue: one kernel tail (waves waiting for the slowest in-flight rays) and one launch per
+ * iteration instead of two.  The kind of a lane's ray is a per-lane flag; the loop body is shared. */
+__device__ __forceinline__ bool clipToSceneRT(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
+                                              float &mint, float &maxt, bool shadow) {
+    float nearT = -INFINITY, farT = INFINITY;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
+        if (dd[i] == 0) {
+            if (origin < minVal || origin > maxVal) return false;
+        } else {
+            const float rcp = 1.0f / dd[i];
+            float t1 = (minVal - origin) * rcp;
+            float t2 = (maxVal - origin) * rcp;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+            nearT = smax(t1, nearT);
+            farT = smin(t2, farT);
+            if (!(nearT <= farT)) return false;
+        }
+    }
+    mint = nearT; maxt = farT;
+    float rayMinT = rayMint;
+    if (rayMinT == PT_EPSILON) {
+        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+        if (!shadow) m = smax(m, PT_EPSILON);               /* skdtree.cpp:124 vs :215 */
+        rayMinT *= m;
+    }
+    if (rayMinT > mint) mint = rayMinT;
+    if (rayMaxt < maxt) maxt = rayMaxt;
+    return maxt > mint;
+}
+
+#ifndef RAYS_SHADOW_UNSORTED
+#define RAYS_SHADOW_UNSORTED 0
+#endif
+enum { WC_RAYS = 0, WC_NODE, WC_TRI, WC_SH_RAYS, WC_SH_NODE, WC_SH_TRI, WC_COUNT };
+
+__device__ __forceinline__ void persistentTraverseMixed(const DevScene &S, TravStack &stack, ShadowSource &ss, TraceSource &ts,
+                                                        uint32_t *wc /* LDS: WC_COUNT counters of this wave */) {
+    bool active = false, shadow = false;
+    uint32_t handle = INVALID_RAY;
+    V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
+    float mint = 0, maxt = 0;
+    int32_t cur = 0;
+    uint32_t nodeCur = 0, triCur = 0;
+    TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const bool moreS = ss.more(), moreAny = moreS || ts.more();              /* wave-uniform */
+        if (idle && moreAny && (__popcll(idle) >= REFILL_LANES || idle == ~0ull)) {
+            const uint32_t h = moreS ? ss.assign(!active, idle) : ts.assign(!active, idle);
+            if (!active && h != INVALID_RAY) {
+                float rmint, rmaxt;
+                const bool ok = moreS ? ss.load(h, o, d, rmint, rmaxt) : ts.load(h, o, d, rmint, rmaxt);
+                if (ok) {
+                    atomicAdd(&wc[moreS ? WC_SH_RAYS : WC_RAYS], 1u);
+                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS)) {
+                        rcp = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
+                        cur = S.rootRef; stack.sp = 0; handle = h; active = true; shadow = moreS; nodeCur = triCur = 0;
+                    } else if (moreS) {
+                        ss.commit(h, false, res);
+                    } else {
+                        ts.commit(h, false, res);
+                    }
+                }
+            }
+        }
+        if (!__any(active)) { if (!(ss.more() || ts.more())) break; continue; }
+        if (active) {
+            for (;;) {
+                if (cur >= 0) {
+#if RAYS_SHADOW_UNSORTED
+                    if (shadow) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeCur)     /* (a wave is all-shadow or all-closest except while it changes phase) */
+                    else
+#endif
+                    NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeCur)
+                }
+                bool finished = false;
+                if (cur < 0 && cur != DONE_REF) {
+                    const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;
+                    LOAD_TRI(stack, S, idx, a, b, c)
+                    ++triCur;
+                    float tu, tv, tt;
+                    if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
+                        if (shadow) { res.prim = 0; finished = true; }
+                        else { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
+                    }
+                    cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
+                }
+                if (cur == DONE_REF) finished = true;
+                if (finished) {
+                    if (shadow) ss.commit(handle, res.prim != PHIP_NO_HIT, res);
+                    else ts.commit(handle, false, res);
+                    atomicAdd(&wc[shadow ? WC_SH_NODE : WC_NODE], nodeCur);
+                    atomicAdd(&wc[shadow ? WC_SH_TRI : WC_TRI], triCur);
+                    active = false;
+                    break;
+                }
+                if ((ss.more() || ts.more()) && __popcll(__ballot(1)) <= 64 - REFILL_LANES) break;     /* enough idle lanes: refill */
+            }
+        }
+    }
+}
+
+#ifndef RAYS_WAVES
+#define RAYS_WAVES TRACE_P_WAVES
+#endif
+__global__ __launch_bounds__(BLOCK, RAYS_WAVES) void k_rays_p(DevScene S, PathPool P, float4 *L) {
+    __shared__ uint32_t wcnt[BLOCK / 64][WC_COUNT];
+    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
+    if (threadIdx.x < (BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
+    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
+    ShadowSource ss{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
+    ss.skipEmpty();
+    TraceSource ts{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
+    persistentTraverseMixed(S, stk, ss, ts, wcnt[wave]);
+    if (__lane_id() == 0) {
+        const int rows[WC_COUNT] = { ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
+#pragma unroll
+        for (int i = 0; i < WC_COUNT; ++i) {
+            const uint32_t v = wcnt[wave][i];
+            if (v) P.stat[(size_t) rows[i] * P.nWaves + waveId] += v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, PathPool P) {
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
@@ -1432,6 +1565,7 @@ struct phip_scene {
     uint32_t lastSpp = 0, nLocalTiles = 0;
     int tileKey[3] = { -1, -1, -1 };
     bool haveSamples = false;
+    bool mergedRays = false;         /* last render used k_rays_p (closest + any hit in one launch) */
     int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
     std::atomic<int> cancel{ 0 };
     std::mutex renderLock;
@@ -1711,6 +1845,9 @@ static void algorithmicBytes(const phip_scene *sc, phip_stats &st) {
        the SURVEY's read+write convention: ray 64 B, hit 40 B */
     st.trace_kernel_bytes = nodeBytes * (double) st.closest_node_visits + 48.0 * (double) st.closest_triangle_tests +
            (64.0 + 40.0) * (double) st.closest_rays;
+    if (sc->mergedRays)    /* k_rays_p also casts the shadow rays: their node + record fetches, entry read, 4-byte result */
+        st.trace_kernel_bytes += nodeBytes * (double) st.shadow_node_visits + 48.0 * (double) st.shadow_triangle_tests +
+               (64.0 + 4.0) * (double) st.shadow_rays;
 }
 
 static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /* device */, phip_stats *stats) {
@@ -1806,9 +1943,15 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     int nCU = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) nCU = prop.multiProcessorCount; }
     const dim3 pgrid((unsigned) std::max(1, std::min<int>(nCU * TRACE_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
     const dim3 pgridTrace((unsigned) std::max(1, std::min<int>(nCU * TRACE_P_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
+    const dim3 pgridRays((unsigned) std::max(1, std::min<int>(nCU * RAYS_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
     Counters hc;
     bool cancelled = false;
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
+    /* big trees: closest-hit and any-hit rays share one persistent launch (measured +2..4 % on the 250k-triangle scenes;
+       on the Cornell box the plain per-slot closest-hit launch wins, so the kernels stay separate there) */
+    bool merged = sc->traversal == 2 && sc->bvh.nNodes >= 64;
+    if (const char *e = getenv("PHIP_MERGED")) merged = sc->traversal == 2 && atoi(e) != 0;
+    sc->mergedRays = merged;
 
     for (uint32_t sppDone = 0; sppDone < (uint32_t) p->spp && !cancelled; sppDone += sppPerPass) {
         RenderConst rc;
@@ -1853,17 +1996,23 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
                 hipLaunchKernelGGL(table[rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
             }
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
-            if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
-            if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sc->L.p);
-            else if (sc->traversal == 1) hipLaunchKernelGGL(k_shadow8, grid, block, 0, stream, D, P, sc->L.p);
-            else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sc->L.p);
-            if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
-            if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-            if (sc->traversal == 2 && (sc->bvh.nNodes >= 64 || forcePersist)) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, ldsBytes, stream, D, P);
-            else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
-            else if (sc->traversal == 1) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
-            else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);
-            if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+            if (merged) {
+                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+                hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sc->L.p);
+                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+            } else {
+                if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
+                if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sc->L.p);
+                else if (sc->traversal == 1) hipLaunchKernelGGL(k_shadow8, grid, block, 0, stream, D, P, sc->L.p);
+                else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sc->L.p);
+                if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
+                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+                if (sc->traversal == 2 && (sc->bvh.nNodes >= 64 || forcePersist)) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, ldsBytes, stream, D, P);
+                else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
+                else if (sc->traversal == 1) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
+                else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);
+                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+            }
             ++iter;
             if (check) {
                 /* termination test: only the live-slot row is summed inside the loop */
