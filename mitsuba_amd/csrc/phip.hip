@@ -1941,9 +1941,13 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     const size_t ldsBytes = traversalLdsBytes(D);
     /* persistent kernels: exactly the resident set (TRACE_WAVES waves per SIMD = TRACE_WAVES blocks of 256 per CU) */
     int nCU = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) nCU = prop.multiProcessorCount; }
-    const dim3 pgrid((unsigned) std::max(1, std::min<int>(nCU * TRACE_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
-    const dim3 pgridTrace((unsigned) std::max(1, std::min<int>(nCU * TRACE_P_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
-    const dim3 pgridRays((unsigned) std::max(1, std::min<int>(nCU * RAYS_WAVES, (int) ((capacity + BLOCK - 1) / BLOCK))));
+    /* ... but never more blocks per CU than their LDS (stack + node/record cache) allows: a persistent grid larger than
+       the resident set would serialise */
+    const int ldsFit = (int) std::max<size_t>(1, (size_t) (160 * 1024) / std::max<size_t>(ldsBytes + 64, 1));
+    auto persistentGrid = [&](int blocksPerCU) {
+        return dim3((unsigned) std::max(1, std::min<int>(nCU * std::min(blocksPerCU, ldsFit), (int) ((capacity + BLOCK - 1) / BLOCK))));
+    };
+    const dim3 pgrid = persistentGrid(TRACE_WAVES), pgridTrace = persistentGrid(TRACE_P_WAVES), pgridRays = persistentGrid(RAYS_WAVES);
     Counters hc;
     bool cancelled = false;
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
