@@ -246,10 +246,10 @@ DV V3 constantSampleDirect(const DevScene &S, const float *em, DirectRec &dRec, 
     return V3(em[EM_RADIANCE], em[EM_RADIANCE + 1], em[EM_RADIANCE + 2]) / pdf;
 }
 
-/* ConstantBackgroundEmitter::pdfDirect, constant.cpp:227-243 (solid-angle measure) */
-DV float constantPdfDirect(const DirectRec &dRec) {
-    if (!dRec.refN.isZero())
-        return PT_INV_PI * smax(0.0f, dot(dRec.d, dRec.refN));
+/* ConstantBackgroundEmitter::pdfDirect, constant.cpp:227-243 (solid-angle measure); dDotRefN = dot(d, refN) */
+DV float constantPdfDirect(float dDotRefN, bool refNZero) {
+    if (!refNZero)
+        return PT_INV_PI * smax(0.0f, dDotRefN);
     return PT_INV_FOURPI;
 }
 
@@ -287,19 +287,24 @@ DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRe
     return value;
 }
 
-/* scene.cpp:949-952, scene.h:848-850, area.cpp:175-182, shape.cpp:117-126 (solid-angle measure) */
-DV float pdfEmitterDirect(const EmitterTab &T, const DirectRec &dRec) {
-    const float *em = emitterRecord(T, (uint32_t) dRec.emitter);
+/* scene.cpp:949-952, scene.h:848-850, area.cpp:175-182, shape.cpp:117-126 (solid-angle measure).
+   The reference point enters only through dot(d, refN) and refN.isZero(): the wavefront stores those two
+   (8 bytes with the BSDF pdf) instead of the normal when it spawns the ray. */
+DV float pdfEmitterDirectDot(const EmitterTab &T, uint32_t emitter, float dDotRefN, bool refNZero, float dDotN, float dist) {
+    const float *em = emitterRecord(T, emitter);
     float pdf;
     if (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_CONSTANT) {
-        pdf = constantPdfDirect(dRec);
-    } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+        pdf = constantPdfDirect(dDotRefN, refNZero);
+    } else if (dDotRefN >= 0 && dDotN < 0) {
         float pdfPos = em[EM_INV_AREA];
-        pdf = pdfPos * (dRec.dist * dRec.dist) / absDot(dRec.d, dRec.n);
+        pdf = pdfPos * (dist * dist) / fabsf(dDotN);
     } else {
         pdf = 0.0f;
     }
     return pdf * (em[EM_WEIGHT] * T.normalization);
+}
+DV float pdfEmitterDirect(const EmitterTab &T, const DirectRec &dRec) {
+    return pdfEmitterDirectDot(T, (uint32_t) dRec.emitter, dot(dRec.d, dRec.refN), dRec.refN.isZero(), dot(dRec.d, dRec.n), dRec.dist);
 }
 
 /* ======================================================================================

@@ -73,6 +73,7 @@ static int setErr(int code, const std::string &msg) { g_err = msg; return code; 
 
 enum : uint32_t {
     F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22, F_DYNAMIC = 1u << 23,
+    F_REFN_ZERO = 1u << 24,             /* DirectSamplingRecord::refN of the vertex the ray left is zero (BSDF with a back side / transmission) */
     DEPTH_MASK = 0xFFFFu
 };
 
@@ -81,8 +82,9 @@ struct PathPool {
     float4 *rayD;     /* d.xyz, maxt */
     float4 *hit;      /* t, u, v, bits(prim) */
     float4 *thr;      /* throughput rgb, eta */
-    float4 *refN;     /* refN xyz, bsdfPdf */
-    uint4 *info;      /* sampleId, pixel, sampleIndex, depth|flags */
+    float2 *mis;      /* bsdfPdf of the sampled direction, dot(direction, refN): all the emitter-hit MIS term needs (8 B instead of refN + pdf = 16 B) */
+    uint4 *info;      /* sampleId, pixel, sampleIndex, - : written when the slot starts a sample, read-only afterwards */
+    uint32_t *state;  /* depth | flags: the only per-iteration slot header (4 B instead of rewriting 16 B) */
     float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0);
                          block b's entries are compacted at [b*BLOCK, b*BLOCK + shadowCount[b]) */
     uint32_t *shadowCount;            /* per block of BLOCK slots */
@@ -458,7 +460,7 @@ struct TraceSource {
         return h;
     }
     __device__ __forceinline__ bool load(uint32_t slot, V3 &o, V3 &d, float &mint, float &maxt) const {
-        if (!(P.info[slot].w & F_ALIVE)) return false;
+        if (!(P.state[slot] & F_ALIVE)) return false;
         const float4 ro = P.rayO[slot], rd = P.rayD[slot];
         o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
         return true;
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace8(DevScene S, PathPool P) {
     traverseWave8<false>(S, lds + wave * 8 * STACK8, P.spill8 + (size_t) waveId * 8 * SPILL8, n,
         [&](uint32_t r, V3 &o, V3 &d, float &mint, float &maxt) -> bool {
             const uint32_t slot = base + r;
-            if (!(P.info[slot].w & F_ALIVE)) return false;
+            if (!(P.state[slot] & F_ALIVE)) return false;
             const float4 ro = P.rayO[slot], rd = P.rayD[slot];
             o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
             return true;
@@ -856,8 +858,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) slot * SPILL_DEPTH, stk);
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     if (slot < P.capacity) {
-        const uint4 info = P.info[slot];
-        if (info.w & F_ALIVE) {
+        if (P.state[slot] & F_ALIVE) {
             const float4 ro = P.rayO[slot], rd = P.rayD[slot];
             const V3 o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
             float mint, maxt;
@@ -938,10 +939,11 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
        in flight together (the kernel is latency bound: 70 % of its wave cycles were s_waitcnt) */
     const uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
+    info.w = P.state[lslot];
     const float4 hit = P.hit[lslot];
     const float4 rd = P.rayD[lslot];
     float4 thr4 = P.thr[lslot];
-    const float4 rn = P.refN[lslot];
+    const float2 mis = P.mis[lslot];
     if (!inRange) info = make_uint4(0, 0, 0, 0);
     __syncthreads();                                            /* LDS tables are complete */
     bool alive = inRange && (info.w & F_ALIVE);
@@ -974,10 +976,9 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                 } else {
                     const float4 ro = P.rayO[slot];
                     if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
-                        DirectRec dRec;
-                        dRec.refN = V3(rn.x, rn.y, rn.z); dRec.d = rayD; dRec.emitter = S.envEmitter; dRec.solidAngle = 1;
-                        const float lumPdf = (!(flags & F_PREV_DELTA)) ? pdfEmitterDirect(T, dRec) : 0;
-                        const V3 c = thr * value * miWeight(rn.w, lumPdf);
+                        const float lumPdf = (!(flags & F_PREV_DELTA))
+                            ? pdfEmitterDirectDot(T, (uint32_t) S.envEmitter, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
+                        const V3 c = thr * value * miWeight(mis.x, lumPdf);
                         l.x += c.x; l.y += c.y; l.z += c.z;
                         haveAdd = true;
                     }
@@ -998,11 +999,10 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                     l = L[id];
                     const float *em = emitterRecord(T, (uint32_t) its.emitter);
                     V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
-                    DirectRec dRec;                                /* pdfEmitterDirect reads refN, n, d, dist only */
-                    dRec.refN = V3(rn.x, rn.y, rn.z);
-                    dRec.p = its.p; dRec.n = its.sh.n; dRec.d = rayD; dRec.dist = its.t; dRec.emitter = its.emitter; dRec.solidAngle = 1;
-                    const float lumPdf = (!(flags & F_PREV_DELTA)) ? pdfEmitterDirect(T, dRec) : 0;
-                    const V3 c = thr * value * miWeight(rn.w, lumPdf);
+                    /* DirectSamplingRecord::setQuery (records.inl:170-178): n = shading normal, d = ray direction, dist = t */
+                    const float lumPdf = (!(flags & F_PREV_DELTA))
+                        ? pdfEmitterDirectDot(T, (uint32_t) its.emitter, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
+                    const V3 c = thr * value * miWeight(mis.x, lumPdf);
                     l.x += c.x; l.y += c.y; l.z += c.z;
                     haveAdd = true;
                 }
@@ -1073,8 +1073,9 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                         thr = thr * bsdfWeight;
                         eta *= bs.eta;
                         P.thr[slot] = make_float4(thr.x, thr.y, thr.z, eta);
-                        P.refN[slot] = make_float4(dRec.refN.x, dRec.refN.y, dRec.refN.z, bs.pdf);
+                        P.mis[slot] = make_float2(bs.pdf, dot(wo, dRec.refN));
                         flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
+                        flags = dRec.refN.isZero() ? (flags | F_REFN_ZERO) : (flags & ~F_REFN_ZERO);
                     }
                 }
             }
@@ -1090,7 +1091,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
             needNew = true;
         } else {
             info.w = flags | depth;
-            P.info[slot] = info;
+            P.state[slot] = info.w;
         }
     }
 
@@ -1165,8 +1166,8 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                         if (decodeId(rc, S.film, id, px, py, k)) { newId = id; dynamicId = true; }
                     }
                 }
-                if (!got && dynBase == ~0ull) { info = make_uint4(0, 0, 0, F_DEAD); P.info[slot] = info; }   /* all shards empty: slot dies */
-                else if (newId == ~0ull) { info.w = F_DYNAMIC; P.info[slot] = info; }                        /* try again next iteration */
+                if (!got && dynBase == ~0ull) { info.w = F_DEAD; P.state[slot] = F_DEAD; }   /* all shards empty: slot dies */
+                else if (newId == ~0ull) { info.w = F_DYNAMIC; P.state[slot] = F_DYNAMIC; }                        /* try again next iteration */
             }
         }
     }
@@ -1181,9 +1182,10 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
         P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
         P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
         P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        P.refN[slot] = make_float4(0, 0, 0, 0);
+        P.mis[slot] = make_float2(0.0f, 0.0f);
         info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
         P.info[slot] = info;
+        P.state[slot] = info.w;
         nowAlive = true;
     }
     const uint32_t waveId = slot >> 6;
@@ -1555,8 +1557,8 @@ struct phip_scene {
     DevBuf<float> emitterTab;
     DevScene dev;
     /* render-time buffers (grown on demand, reused between calls) */
-    DevBuf<float4> rayO, rayD, hit, thr, refN, shadow, L, sampleOut;
-    DevBuf<uint4> info;
+    DevBuf<float4> rayO, rayD, hit, thr, shadow, L, sampleOut;
+    DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, spill, blockShard; DevBuf<int32_t> tileSlot;
     DevBuf<unsigned long long> dynCounter;
@@ -1922,12 +1924,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     const uint32_t nWaves = capacity / 64, nBlocks = capacity / BLOCK;
     if (sc->rayO.n < capacity) {
         sc->rayO.alloc(capacity); sc->rayD.alloc(capacity); sc->hit.alloc(capacity); sc->thr.alloc(capacity);
-        sc->refN.alloc(capacity); sc->info.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
+        sc->mis.alloc(capacity); sc->info.alloc(capacity); sc->state.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
         sc->shadowCount.alloc(nBlocks); sc->blockShard.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
         sc->spill8.alloc((size_t) nWaves * 8 * SPILL8);
     }
     PathPool P;
-    P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.refN = sc->refN.p; P.info = sc->info.p;
+    P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.mis = sc->mis.p; P.info = sc->info.p; P.state = sc->state.p;
     P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.stat = sc->stat.p; P.spill = sc->spill.p; P.spill8 = sc->spill8.p; P.capacity = capacity; P.nWaves = nWaves;
     if (sc->L.n < idsFirstPass) sc->L.alloc((size_t) idsFirstPass);
 
@@ -1981,7 +1983,7 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
         HIP_TRY(hipMemsetAsync(sc->stat.p, 0, (size_t) ST_COUNT * nWaves * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(sc->shadowCount.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) sc->info.p, (int) F_FRESH, (size_t) capacity * 4, stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) sc->state.p, (int) F_FRESH, (size_t) capacity, stream));
         if (rc.totalIds) HIP_TRY(hipMemsetAsync(sc->L.p, 0, (size_t) rc.totalIds * sizeof(float4), stream));
 
         HIP_TRY(hipStreamSynchronize(stream));
