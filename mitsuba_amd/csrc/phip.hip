@@ -210,11 +210,18 @@ __device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, cons
  * all triangle records.  Cached nodes use a 144-byte stride so that lanes reading different nodes hit
  * different banks with ds_read_b128. */
 #define NODE_LDS_STRIDE 9               /* float4 per cached node (8 + 1 pad) */
+/* LDS pointers carry their address space in the type: through a generic pointer the compiler emits flat_load for the cached
+   nodes/records, which goes through the texture addresser (16 clk per 16-byte wave instruction, shared by the CU's four SIMDs)
+   instead of the LDS pipe (ds_read_b128) -- on the Cornell box, where everything is cached, that was the bottleneck. */
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f4v lds_cf4;
+__device__ __forceinline__ float4 ldsLoad4(lds_cf4 *p) { const f4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 struct TravStack {
-    uint32_t *lds;          /* lds base + threadIdx.x */
+    lds_u32 *lds;           /* lds base + threadIdx.x */
     uint32_t *spill;        /* global: SPILL_DEPTH entries per lane */
-    const float4 *nodes;    /* LDS copy of nodes [0, nodeCache) */
-    const float4 *tris;     /* LDS copy of triangle records [0, triCache) */
+    lds_cf4 *nodes;         /* LDS copy of nodes [0, nodeCache) */
+    lds_cf4 *tris;          /* LDS copy of triangle records [0, triCache) */
     uint32_t nodeCache, triCache;
     int depth, sp;
     __device__ __forceinline__ void push(uint32_t v) {
@@ -237,25 +244,40 @@ __device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char 
     for (uint32_t i = threadIdx.x; i < S.triCache * 3u; i += BLOCK)
         lt[i] = S.tris[i];
     __syncthreads();
-    stk.lds = stack + threadIdx.x; stk.spill = spill; stk.nodes = ln; stk.tris = lt;
+    stk.lds = (lds_u32 *) (stack + threadIdx.x); stk.spill = spill; stk.nodes = (lds_cf4 *) ln; stk.tris = (lds_cf4 *) lt;
     stk.nodeCache = S.nodeCache; stk.triCache = S.triCache; stk.depth = (int) S.stackDepth; stk.sp = 0;
 }
 
+/* TYPED (a constant in the scope of the caller): true = separate LDS (ds_read_b128) and global paths -- right when (almost)
+   everything is cached (small scenes); false = one flat_load path with a selected address -- fewer registers and no
+   divergence when most lanes read global memory (big scenes; measured 1-3 % faster there, 14 % slower on the Cornell box) */
 #define LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)                                   \
     float4 mnx, mny, mnz, mxx, mxy, mxz, chf;                                                         \
-    if ((uint32_t) (cur) < (stack).nodeCache) {                                                      \
-        const float4 *n_ = (stack).nodes + (size_t) (cur) * NODE_LDS_STRIDE;                          \
-        mnx = n_[0]; mny = n_[1]; mnz = n_[2]; mxx = n_[3]; mxy = n_[4]; mxz = n_[5]; chf = n_[6];    \
+    if (TYPED) {                                                                                      \
+        if ((uint32_t) (cur) < (stack).nodeCache) {                                                   \
+            lds_cf4 *n_ = (stack).nodes + (uint32_t) (cur) * NODE_LDS_STRIDE;                         \
+            mnx = ldsLoad4(n_); mny = ldsLoad4(n_ + 1); mnz = ldsLoad4(n_ + 2); mxx = ldsLoad4(n_ + 3); \
+            mxy = ldsLoad4(n_ + 4); mxz = ldsLoad4(n_ + 5); chf = ldsLoad4(n_ + 6);                   \
+        } else {                                                                                      \
+            const float4 *n_ = (S).nodes + 8 * (size_t) (cur);                                        \
+            mnx = n_[0]; mny = n_[1]; mnz = n_[2]; mxx = n_[3]; mxy = n_[4]; mxz = n_[5]; chf = n_[6]; \
+        }                                                                                             \
     } else {                                                                                          \
-        const float4 *n_ = (S).nodes + 8 * (size_t) (cur);                                            \
+        const float4 *n_ = (uint32_t) (cur) < (stack).nodeCache                                       \
+            ? (const float4 *) ((stack).nodes + (uint32_t) (cur) * NODE_LDS_STRIDE) : (S).nodes + 8 * (size_t) (cur); \
         mnx = n_[0]; mny = n_[1]; mnz = n_[2]; mxx = n_[3]; mxy = n_[4]; mxz = n_[5]; chf = n_[6];    \
     }
 #define LOAD_TRI(stack, S, idx, a, b, c)                                                              \
     float4 a, b, c;                                                                                   \
-    if ((uint32_t) (idx) < (stack).triCache) {                                                       \
-        const float4 *t_ = (stack).tris + 3 * (size_t) (idx); a = t_[0]; b = t_[1]; c = t_[2];        \
+    if (TYPED) {                                                                                      \
+        if ((uint32_t) (idx) < (stack).triCache) {                                                    \
+            lds_cf4 *t_ = (stack).tris + 3 * (uint32_t) (idx); a = ldsLoad4(t_); b = ldsLoad4(t_ + 1); c = ldsLoad4(t_ + 2); \
+        } else {                                                                                      \
+            const float4 *t_ = (S).tris + 3 * (size_t) (idx); a = t_[0]; b = t_[1]; c = t_[2];        \
+        }                                                                                             \
     } else {                                                                                          \
-        const float4 *t_ = (S).tris + 3 * (size_t) (idx); a = t_[0]; b = t_[1]; c = t_[2];            \
+        const float4 *t_ = (uint32_t) (idx) < (stack).triCache ? (const float4 *) ((stack).tris + 3 * (uint32_t) (idx)) : (S).tris + 3 * (size_t) (idx); \
+        a = t_[0]; b = t_[1]; c = t_[2];                                                              \
     }
 #define SPILL_DEPTH 96
 
@@ -344,6 +366,7 @@ template <bool SHADOW>
 __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
                                          TravStack &stack, TravResult &res,
                                          uint32_t &nodeVisits, uint32_t &triTests) {
+    constexpr bool TYPED = true;
     /* reciprocal direction for the slab tests (conservative: boxes are padded); the Wald test uses o,d */
     const V3 rcp(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const V3 ordr(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
@@ -390,6 +413,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
 template <bool SHADOW, typename Source>
 __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack &stack, Source &src,
                                                    uint32_t &nodeVisits, uint32_t &triTests, uint32_t &raysTraced) {
+    constexpr bool TYPED = SHADOW;        /* k_shadow_p serves the small scenes (big ones use k_rays_p), k_trace_p the big ones */
     bool active = false;
     uint32_t handle = INVALID_RAY;
     V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
@@ -548,6 +572,7 @@ enum { WC_RAYS = 0, WC_NODE, WC_TRI, WC_SH_RAYS, WC_SH_NODE, WC_SH_TRI, WC_COUNT
 
 __device__ __forceinline__ void persistentTraverseMixed(const DevScene &S, TravStack &stack, ShadowSource &ss, TraceSource &ts,
                                                         uint32_t *wc /* LDS: WC_COUNT counters of this wave */) {
+    constexpr bool TYPED = false;
     bool active = false, shadow = false;
     uint32_t handle = INVALID_RAY;
     V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
