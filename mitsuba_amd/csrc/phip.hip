@@ -288,6 +288,9 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
+#ifndef SHADOW_ATOMIC_COMMIT
+#define SHADOW_ATOMIC_COMMIT 0      /* measured: bit-identical, +1..3 % on the 250k-triangle scenes but the Cornell shadow kernel doubles (1.3 G 4-byte L2 atomics per frame) */
+#endif
 #ifndef SHADOW_UNSORTED
 #define SHADOW_UNSORTED 1
 #endif
@@ -494,6 +497,28 @@ struct TraceSource {
     }
 };
 
+/* L[id] += c for an unoccluded NEE entry.  A load-add-store here stalls the whole traversal wave for a random HBM round
+ * trip every time one of its lanes finishes a ray; three fire-and-forget hardware float atomics do not.  They are plain IEEE
+ * round-to-nearest additions at the L2 (no other lane touches L[id] during this kernel, so there is no ordering question), but
+ * the L2 adder flushes denormals: radiance contributions are >= 0, so the sum of a normal-or-zero addend and the accumulator
+ * (itself a sum of such addends) is never denormal -- an entry with a denormal component takes the load-add-store path. */
+__device__ __forceinline__ void addRadiance(float4 *L, uint32_t id, const float4 &c) {
+    const float tiny = 1.17549435e-38f;
+    const bool plain = (c.x == 0.0f || c.x >= tiny) && (c.y == 0.0f || c.y >= tiny) && (c.z == 0.0f || c.z >= tiny);
+#if SHADOW_ATOMIC_COMMIT
+    if (plain) {
+        float *p = (float *) (L + id);
+        if (c.x != 0.0f) unsafeAtomicAdd(p, c.x);
+        if (c.y != 0.0f) unsafeAtomicAdd(p + 1, c.y);
+        if (c.z != 0.0f) unsafeAtomicAdd(p + 2, c.z);
+        return;
+    }
+#endif
+    float4 l = L[id];
+    l.x += c.x; l.y += c.y; l.z += c.z;
+    L[id] = l;
+}
+
 /* any-hit source: the block-compacted shadow queue; wave w walks blocks w, w+W, ... */
 struct ShadowSource {
     const PathPool &P; float4 *L; uint32_t blk, pos, cnt, stride, nBlocks;
@@ -516,10 +541,7 @@ struct ShadowSource {
     __device__ __forceinline__ void commit(uint32_t e, bool occluded, const TravResult &) const {
         if (!occluded) {
             const float4 e1 = P.shadow[3 * (size_t) e + 1], e2 = P.shadow[3 * (size_t) e + 2];
-            const uint32_t id = pm_to_bits(e1.w);
-            float4 l = L[id];
-            l.x += e2.x; l.y += e2.y; l.z += e2.z;
-            L[id] = l;
+            addRadiance(L, pm_to_bits(e1.w), e2);
         }
     }
 };
@@ -864,10 +886,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_shadow8(DevScene S, PathPool P, fl
         [&](uint32_t r, bool occluded, float, float, float, uint32_t) {
             if (!occluded) {
                 const float4 e1 = P.shadow[3 * (base + r) + 1], e2 = P.shadow[3 * (base + r) + 2];
-                const uint32_t id = pm_to_bits(e1.w);
-                float4 l = L[id];
-                l.x += e2.x; l.y += e2.y; l.z += e2.z;
-                L[id] = l;
+                addRadiance(L, pm_to_bits(e1.w), e2);
             }
         }, nodeVisits, triTests, rays);
     waveStat(P, ST_SHADOW_RAYS, waveId, rays);
@@ -915,10 +934,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathP
         if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt))
             occluded = traverse<true>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
         if (!occluded) {
-            const uint32_t id = pm_to_bits(e1.w);
-            float4 l = L[id];
-            l.x += e2.x; l.y += e2.y; l.z += e2.z;
-            L[id] = l;
+            addRadiance(L, pm_to_bits(e1.w), e2);
         }
     }
     if ((threadIdx.x & ~63u) < n) {                          /* waves without entries have nothing to add */
