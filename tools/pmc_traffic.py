@@ -52,7 +52,7 @@ res["kernels"] = {}
 for k in sorted(rf):
     if not k.startswith("k_"):
         continue
-    gather = k.startswith("k_trace") or k.startswith("k_shadow") or k.startswith("k_shade")
+    gather = k.startswith(("k_trace", "k_shadow", "k_shade", "k_rays"))
     fc = (fetch_gather_corr if gather else fetch_stream_corr) or 1.0
     fb = rf[k] * 1024 * fc; wb = rw.get(k, 0) * 1024 * (write_corr or 1.0)
     res["kernels"][k] = {"launches": nf[k], "fetch_KiB_raw": rf[k], "write_KiB_raw": rw.get(k, 0), "fetch_correction": fc,
