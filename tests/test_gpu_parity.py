@@ -285,3 +285,34 @@ def test_environment_error_behaviour(gpu, phip, gauss):
     d = sb.desc()
     assert not phip.phip_scene_create(C.byref(d), 0)
     assert b"one environment emitter" in phip.phip_last_error()
+
+
+@pytest.mark.parametrize("stddev", [0.25, 0.5, 1.0, 1.5])
+def test_reconstruction_filter_widths(gpu, oracle, gauss, stddev):
+    """filters of reach 1 .. 6 pixels: k_film_tiled<2>, k_film_tiled<4> and the generic k_film gather
+    (rfilter.cpp:38-57 discretisation, imageblock.h:124-204 splat); also a box-like table"""
+    from mitsuba_amd import _ffi
+    ft = _ffi.gaussian_filter(stddev)
+    sb = S.cornell_box(96, 80, ft)
+    compare_render(gpu, oracle, sb.desc(), 4, min_identical=1.0, maxDepth=4)
+    if stddev == 0.5:
+        box = (0.5, [1.0] * 31 + [0.0])       # box filter: radius 0.5, constant table (rfilters/box.cpp)
+        sb = S.cornell_box(96, 80, box)
+        compare_render(gpu, oracle, sb.desc(), 4, min_identical=1.0, maxDepth=4)
+
+
+def test_large_emitter_mesh_and_many_materials(gpu, oracle, gauss):
+    """tables that do not fit the LDS staging of k_shade: a 1 200-triangle smooth-shaded mesh light (area CDF and
+    emitter records stay in global memory) plus a flat-shaded one, and 60 materials (> MATERIAL_LDS_MAX)"""
+    sb = S.cornell_box(128, 128, gauss)
+    black = sb.diffuse((0, 0, 0))
+    P, T, N = S.sphere_mesh((278, 300, 280), 40.0, 30, 20)
+    sb.mesh(P, T, black, normals=N, radiance=(6.0, 5.0, 3.0))
+    P, T, N = S.sphere_mesh((120, 120, 150), 25.0, 12, 8)
+    sb.mesh(P, T, black, radiance=(2.0, 4.0, 8.0), sampling_weight=0.3)
+    rng = np.random.default_rng(5)
+    for i in range(60):
+        m = sb.diffuse(tuple(rng.uniform(0.1, 0.9, 3))) if i % 3 else sb.twosided(sb.roughconductor(alpha=float(rng.uniform(0.05, 0.4)), eta=S.CU_ETA, k=S.CU_K))
+        P, T, N = S.sphere_mesh((60 + 45 * (i % 10), 40 + 60 * (i // 10), 420 + 8 * (i % 7)), 18.0, 10, 6)
+        sb.mesh(P, T, m, normals=N if i % 2 else None)
+    compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.999, maxDepth=6)
