@@ -88,6 +88,7 @@ struct PathPool {
     float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0);
                          block b's entries are compacted at [b*BLOCK, b*BLOCK + shadowCount[b]) */
     uint32_t *shadowCount;            /* per block of BLOCK slots */
+    uint32_t *blockDead;              /* per block: every slot is F_DEAD and nothing is queued any more -- the drain phase of a pass skips these blocks */
     unsigned long long *stat;         /* ST_COUNT arrays of nWaves entries */
     uint32_t *spill;                  /* traversal-stack overflow: SPILL_DEPTH entries per lane */
     uint2 *spill8;                    /* group kernels: SPILL8 entries per ray group (8 groups per wave) */
@@ -898,6 +899,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_shadow8(DevScene S, PathPool P, fl
  *  kernels
  * ====================================================================================== */
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPool P) {
+    if (P.blockDead[blockIdx.x]) return;
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) slot * SPILL_DEPTH, stk);
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
@@ -920,6 +922,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
 }
 
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathPool P, float4 *L) {
+    if (P.blockDead[blockIdx.x]) return;
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
     const uint32_t n = P.shadowCount[blockIdx.x];            /* entries of this block's slots */
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
@@ -962,6 +965,7 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
    normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
 template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
+    if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
        dependent lookups per NEE sample) and the materials */
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
@@ -1137,6 +1141,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
     }
 
     /* ---- shadow queue: compact this block's entries to the front of its own region (no global atomics) ---- */
+    uint32_t shadowTotal = 0;
     {
         const unsigned long long m = __ballot(pushShadow);
         const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
@@ -1150,6 +1155,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
             P.shadow[3 * sidx] = sh0; P.shadow[3 * sidx + 1] = sh1; P.shadow[3 * sidx + 2] = sh2;
         }
         if (threadIdx.x == 0) P.shadowCount[blockIdx.x] = total;
+        shadowTotal = total;
     }
 
     /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183).
@@ -1230,11 +1236,16 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
         nowAlive = true;
     }
     const uint32_t waveId = slot >> 6;
+    /* a slot still waiting for a dynamic sample id counts as live for the termination test */
+    const bool live = nowAlive || (inRange && info.w == F_DYNAMIC);
+    /* the block retires once none of its slots will ever work again and its last shadow entries have been consumed
+       (this launch queued nothing, so shadowCount is 0): later launches of the pass return at the first line */
+    const bool retire = !__syncthreads_or(live ? 1 : 0) && shadowTotal == 0;
+    if (retire && threadIdx.x == 0) P.blockDead[blockIdx.x] = 1u;
     if (inRange || (slot & ~63u) < P.capacity) {
         waveStat(P, ST_VERTICES, waveId, vertices);
         waveStat(P, ST_SAMPLES, waveId, done);
-        /* a slot still waiting for a dynamic sample id counts as live for the termination test */
-        if (rc.countAlive) waveStat(P, ST_ALIVE, waveId, (nowAlive || (inRange && info.w == F_DYNAMIC)) ? 1ull : 0ull, true);
+        if (rc.countAlive || retire) waveStat(P, ST_ALIVE, waveId, live ? 1ull : 0ull, true);
     }
 }
 
@@ -1601,7 +1612,7 @@ struct phip_scene {
     DevBuf<float4> rayO, rayD, hit, thr, shadow, L, sampleOut;
     DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
-    DevBuf<uint32_t> tileOrigin, shadowCount, spill, blockShard; DevBuf<int32_t> tileSlot;
+    DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
     DevBuf<unsigned long long> dynCounter;
     DevBuf<unsigned long long> stat;
     DevBuf<float> film; DevBuf<unsigned long long> invalid;
@@ -1966,12 +1977,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     if (sc->rayO.n < capacity) {
         sc->rayO.alloc(capacity); sc->rayD.alloc(capacity); sc->hit.alloc(capacity); sc->thr.alloc(capacity);
         sc->mis.alloc(capacity); sc->info.alloc(capacity); sc->state.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
-        sc->shadowCount.alloc(nBlocks); sc->blockShard.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
+        sc->shadowCount.alloc(nBlocks); sc->blockDead.alloc(nBlocks); sc->blockShard.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
         sc->spill8.alloc((size_t) nWaves * 8 * SPILL8);
     }
     PathPool P;
     P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.mis = sc->mis.p; P.info = sc->info.p; P.state = sc->state.p;
-    P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.stat = sc->stat.p; P.spill = sc->spill.p; P.spill8 = sc->spill8.p; P.capacity = capacity; P.nWaves = nWaves;
+    P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.blockDead = sc->blockDead.p; P.stat = sc->stat.p; P.spill = sc->spill.p; P.spill8 = sc->spill8.p; P.capacity = capacity; P.nWaves = nWaves;
     if (sc->L.n < idsFirstPass) sc->L.alloc((size_t) idsFirstPass);
 
     phip_stats st; memset(&st, 0, sizeof(st));
@@ -2024,6 +2035,7 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
         HIP_TRY(hipMemsetAsync(sc->stat.p, 0, (size_t) ST_COUNT * nWaves * sizeof(unsigned long long), stream));
         HIP_TRY(hipMemsetAsync(sc->shadowCount.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(sc->blockDead.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) sc->state.p, (int) F_FRESH, (size_t) capacity, stream));
         if (rc.totalIds) HIP_TRY(hipMemsetAsync(sc->L.p, 0, (size_t) rc.totalIds * sizeof(float4), stream));
 
