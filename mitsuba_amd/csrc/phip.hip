@@ -414,10 +414,9 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
 #define DYN_SHARDS 8                    /* one dynamic-sample counter per XCD-sized group of blocks */
 #define DYN_STRIDE 16                   /* unsigned long longs between counters (128 B) */
 
-template <bool SHADOW, typename Source>
+template <bool SHADOW, bool TYPED, typename Source>
 __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack &stack, Source &src,
                                                    uint32_t &nodeVisits, uint32_t &triTests, uint32_t &raysTraced) {
-    constexpr bool TYPED = SHADOW;        /* k_shadow_p serves the small scenes (big ones use k_rays_p), k_trace_p the big ones */
     bool active = false;
     uint32_t handle = INVALID_RAY;
     V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
@@ -686,12 +685,12 @@ __global__ __launch_bounds__(BLOCK, RAYS_WAVES) void k_rays_p(DevScene S, PathPo
     }
 }
 
-__global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, PathPool P) {
+template <bool TYPED> __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, PathPool P) {
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
     TraceSource src{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    persistentTraverse<false>(S, stk, src, nodeVisits, triTests, rays);
+    persistentTraverse<false, TYPED>(S, stk, src, nodeVisits, triTests, rays);
     waveStat(P, ST_CLOSEST_RAYS, waveId, rays);
     waveStat(P, ST_NODE, waveId, nodeVisits);
     waveStat(P, ST_TRI, waveId, triTests);
@@ -703,7 +702,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, Pat
     ShadowSource src{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
     src.skipEmpty();
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    persistentTraverse<true>(S, stk, src, nodeVisits, triTests, rays);
+    persistentTraverse<true, true>(S, stk, src, nodeVisits, triTests, rays);      /* k_shadow_p serves the small scenes (big ones use k_rays_p) */
     waveStat(P, ST_SHADOW_RAYS, waveId, rays);
     waveStat(P, ST_SH_NODE, waveId, nodeVisits);
     waveStat(P, ST_SH_TRI, waveId, triTests);
@@ -2066,7 +2065,7 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
                 else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sc->L.p);
                 if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
                 if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-                if (sc->traversal == 2 && (sc->bvh.nNodes >= 64 || forcePersist)) hipLaunchKernelGGL(k_trace_p, pgridTrace, block, ldsBytes, stream, D, P);
+                if (sc->traversal == 2 && (sc->bvh.nNodes >= 64 || forcePersist)) { if (sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p<false>, pgridTrace, block, ldsBytes, stream, D, P); else hipLaunchKernelGGL(k_trace_p<true>, pgridTrace, block, ldsBytes, stream, D, P); }
                 else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
                 else if (sc->traversal == 1) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
                 else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);
