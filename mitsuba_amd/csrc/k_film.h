@@ -1,0 +1,231 @@
+/*
+ * k_film.h -- statistics reduction, film gather (ImageBlock::put), per-sample export
+ * Part of the single translation unit phip.hip (included there, in this order: k_pool.h, k_traverse.h,
+ * k_group8.h, k_shade.h, k_film.h); see the header of phip.hip for the kernel overview.
+ */
+
+/* sums the per-wave statistics: REDUCE_SPLIT blocks per counter row, rows [firstRow, firstRow + gridDim.x);
+   the totals must have been zeroed (one atomicAdd per block: 32 per row) */
+#define REDUCE_SPLIT 32
+__global__ void k_reduce_stats(PathPool P, Counters *C, int firstRow) {
+    __shared__ unsigned long long red[256];
+    const int row = firstRow + (int) blockIdx.x;
+    const unsigned long long *src = P.stat + (size_t) row * P.nWaves;
+    unsigned long long v = 0;
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < P.nWaves; i += 256 * REDUCE_SPLIT) v += src[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int) threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0 && red[0]) atomicAdd(&C->total[row], red[0]);
+}
+
+/* Film: one lane per crop pixel gathers every sample whose filter footprint covers it.  Restates
+ * ImageBlock::put (imageblock.h:124-204) incl. the block-local coordinate arithmetic: a sample
+ * taken in pixel (sx,sy) belongs to the render block whose origin is (sx,sy) rounded down to the
+ * block size, and its weights are computed in that block's coordinate system. */
+__global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
+                                               int tilesX, float *out, int accumulate, unsigned long long *invalidCount) {
+    const DevFilm &F = S.film;
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= F.width || y >= F.height) return;
+    /* a sample of source pixel s lands at s + jitter - 0.5 in [s-0.5, s+0.5): it can reach x iff
+       s > x - radius - 0.5 and s <= x + radius + 0.5 */
+    const int sx0 = max((int) floorf((float) x - F.radius - 0.5f) + 1, 0), sx1 = min((int) floorf((float) x + F.radius + 0.5f), F.width - 1);
+    const int sy0 = max((int) floorf((float) y - F.radius - 0.5f) + 1, 0), sy1 = min((int) floorf((float) y + F.radius + 0.5f), F.height - 1);
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    unsigned long long invalid = 0;
+    for (int sy = sy0; sy <= sy1; ++sy) {
+        for (int sx = sx0; sx <= sx1; ++sx) {
+            const int tx = sx >> rc.tileShift, ty = sy >> rc.tileShift;
+            const int32_t ts = tileSlot[ty * tilesX + tx];
+            if (ts < 0) continue;           /* that block belongs to another shard */
+            const int offX = tx << rc.tileShift, offY = ty << rc.tileShift;
+            const int bw = min(F.blockSize, F.width - offX) + 2 * F.border, bh = min(F.blockSize, F.height - offY) + 2 * F.border;
+            /* destination pixel in the source block's bitmap coordinates */
+            const int dx = x - (offX - F.border), dy = y - (offY - F.border);
+            if (dx < 0 || dy < 0 || dx >= bw || dy >= bh) continue;
+            const uint32_t m = spreadBits((uint32_t) (sx - offX)) | (spreadBits((uint32_t) (sy - offY)) << 1);
+            const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
+            for (uint32_t k = 0; k < rc.sppPass; ++k) {
+                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
+                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
+                const float posx = px - 0.5f - (float) (offX - F.border), posy = py - 0.5f - (float) (offY - F.border);
+                const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), bw - 1);
+                const int miny = max((int) ceilf(posy - F.radius), 0), maxy = min((int) floorf(posy + F.radius), bh - 1);
+                if (dx < minx || dx > maxx || dy < miny || dy > maxy) continue;
+                const unsigned long long id = (((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m;
+                const float4 v = L[id];
+                /* validity check of ImageBlock::put: reject non-finite / negative samples (imageblock.h:148-151) */
+                if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
+                    if (sx == x && sy == y) ++invalid;
+                    continue;
+                }
+                const float wx = F.table[min((int) fabsf(((float) dx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                const float wy = F.table[min((int) fabsf(((float) dy - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                const float w = wx * wy;
+                acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
+            }
+        }
+    }
+    float *o = out + ((size_t) y * F.width + x) * 5;
+    if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
+    else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
+    if (invalid) atomicAdd(invalidCount, invalid);
+}
+
+/* LDS-tiled film gather (filters with reach <= FILM_MAX_REACH pixels, i.e. every reference default): a block owns
+ * 16x16 destination pixels.  Per sample index k the block first STAGES each of the (16+2R)^2 source pixels' sample
+ * ONCE in LDS: radiance, the frame coordinates of the first pixel of its filter footprint and the separable filter
+ * weights of ImageBlock::put (imageblock.h:124-204: footprint clipped to the bitmap of the render block the sample
+ * belongs to, weights from the discretised table) -- weights outside the footprint are stored as 0, which adds
+ * nothing.  Then every destination lane accumulates its (2R+1)^2 neighbours: two integer subtractions, two weight
+ * reads, one product and five multiply-adds per neighbour.  Same arithmetic per (sample, pixel) pair as k_film;
+ * only the order of the float additions differs. */
+#define FILM_MAX_REACH 4
+#define FILM_TILE 16
+template <int RMAX>
+__global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
+                                                     int tilesX, float *out, int accumulate, unsigned long long *invalidCount, int R) {
+    constexpr int TMAX = FILM_TILE + 2 * RMAX;
+    constexpr int NW = 2 * RMAX + 2;           /* weights per axis: floor(p + r) - ceil(p - r) + 1 <= 2r + 1 with r < RMAX + 0.5 */
+    __shared__ float4 sVal[TMAX * TMAX];       /* radiance rgb + alpha of the source pixel's k-th sample */
+    __shared__ int2 sOrg[TMAX * TMAX];         /* frame coordinates of weight [0] of the sample's footprint */
+    __shared__ float sWx[TMAX * TMAX * NW], sWy[TMAX * TMAX * NW];
+    __shared__ int4 sGeo[TMAX * TMAX];         /* (offX - border, offY - border, bw, bh) of the source pixel's render block */
+    __shared__ uint32_t sBase[TMAX * TMAX];    /* low word of the sample id of k = 0 (0xFFFFFFFF: pixel not rendered here) */
+    __shared__ float sTable[PHIP_FILTER_RESOLUTION + 1];
+    const DevFilm &F = S.film;
+    const int T = FILM_TILE + 2 * R;
+    const int x0 = blockIdx.x * FILM_TILE, y0 = blockIdx.y * FILM_TILE;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = x0 + lx, y = y0 + ly;
+    if (threadIdx.x <= PHIP_FILTER_RESOLUTION) sTable[threadIdx.x] = F.table[threadIdx.x];
+    /* per source pixel constants */
+    for (int i = threadIdx.x; i < T * T; i += BLOCK) {
+        const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+        uint32_t base = 0xFFFFFFFFu; int4 g = make_int4(0, 0, 0, 0);
+        if (sx >= 0 && sy >= 0 && sx < F.width && sy < F.height) {
+            const int tx = sx >> rc.tileShift, ty = sy >> rc.tileShift;
+            const int32_t ts = tileSlot[ty * tilesX + tx];
+            if (ts >= 0) {
+                const int offX = tx << rc.tileShift, offY = ty << rc.tileShift;
+                g = make_int4(offX - F.border, offY - F.border, min(F.blockSize, F.width - offX) + 2 * F.border, min(F.blockSize, F.height - offY) + 2 * F.border);
+                base = (uint32_t) ts;                       /* id(k) = ((ts * sppPass + k) << 2*tileShift) | morton(pixel in block) */
+            }
+        }
+        sBase[i] = base; sGeo[i] = g;
+    }
+    __syncthreads();
+
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    unsigned long long invalid = 0;
+    const bool inside = x < F.width && y < F.height;
+    /* the radiance of sample k + 1 is fetched while sample k is being gathered (the k loop is a chain of
+       barriers otherwise: global-load latency would be paid sppPass times in a row) */
+    constexpr int NSTAGE = (TMAX * TMAX + BLOCK - 1) / BLOCK;
+    float4 pre[NSTAGE];
+    auto fetch = [&](uint32_t k) {
+#pragma unroll
+        for (int n = 0; n < NSTAGE; ++n) {
+            const int i = (int) threadIdx.x + n * BLOCK;
+            pre[n] = make_float4(0, 0, 0, 0);
+            if (i < T * T && k < rc.sppPass) {
+                const uint32_t base = sBase[i];
+                if (base != 0xFFFFFFFFu) {
+                    const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+                    const int4 g = sGeo[i];
+                    const uint32_t m = spreadBits((uint32_t) (sx - (g.x + F.border))) | (spreadBits((uint32_t) (sy - (g.y + F.border))) << 1);
+                    pre[n] = L[(((unsigned long long) base * rc.sppPass + k) << (2 * rc.tileShift)) | m];
+                }
+            }
+        }
+    };
+    fetch(0);
+    for (uint32_t k = 0; k < rc.sppPass; ++k) {
+#pragma unroll
+        for (int n = 0; n < NSTAGE; ++n) {
+            const int i = (int) threadIdx.x + n * BLOCK;
+            if (i >= T * T) break;
+            const uint32_t base = sBase[i];
+            float4 v = make_float4(0, 0, 0, 0);
+            int2 org = make_int2(0, 0);
+            float wx[NW], wy[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) { wx[j] = 0.0f; wy[j] = 0.0f; }
+            if (base != 0xFFFFFFFFu) {
+                const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+                const int4 g = sGeo[i];
+                const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
+                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
+                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
+                const float posx = px - 0.5f - (float) g.x, posy = py - 0.5f - (float) g.y;   /* block-bitmap coordinates */
+                v = pre[n];
+                /* validity check of ImageBlock::put (imageblock.h:148-151) */
+                if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
+                    /* count each rejected sample once: by the block that owns its pixel */
+                    if (sx >= x0 && sx < x0 + FILM_TILE && sy >= y0 && sy < y0 + FILM_TILE) ++invalid;
+                    v = make_float4(0, 0, 0, 0);
+                } else {
+                    /* footprint and weights, imageblock.h:159-180 */
+                    const int uminx = (int) ceilf(posx - F.radius), uminy = (int) ceilf(posy - F.radius);
+                    const int minx = max(uminx, 0), maxx = min((int) floorf(posx + F.radius), g.z - 1);
+                    const int miny = max(uminy, 0), maxy = min((int) floorf(posy + F.radius), g.w - 1);
+                    org = make_int2(g.x + uminx, g.y + uminy);
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const int bx = uminx + j, by = uminy + j;
+                        if (bx >= minx && bx <= maxx) wx[j] = sTable[min((int) fabsf(((float) bx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                        if (by >= miny && by <= maxy) wy[j] = sTable[min((int) fabsf(((float) by - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                    }
+                }
+            }
+            sVal[i] = v; sOrg[i] = org;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) { sWx[i * NW + j] = wx[j]; sWy[i * NW + j] = wy[j]; }
+        }
+        __syncthreads();
+        fetch(k + 1);
+        if (inside) {
+            for (int dyy = -R; dyy <= R; ++dyy) {
+                for (int dxx = -R; dxx <= R; ++dxx) {
+                    const int i = (ly + R + dyy) * T + (lx + R + dxx);
+                    const int2 org = sOrg[i];
+                    const int jx = x - org.x, jy = y - org.y;
+                    if ((unsigned) jx >= (unsigned) NW || (unsigned) jy >= (unsigned) NW) continue;
+                    const float w = sWx[i * NW + jx] * sWy[i * NW + jy];
+                    if (w == 0.0f) continue;                   /* outside the footprint (or a zero of the filter): adds nothing */
+                    const float4 v = sVal[i];
+                    acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inside) {
+        float *o = out + ((size_t) y * F.width + x) * 5;
+        if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
+        else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
+    }
+    if (invalid) atomicAdd(invalidCount, invalid);
+}
+
+/* copy per-sample radiance out in [y][x][sample] order (tests) */
+__global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot, int tilesX,
+                                 float4 *out, uint32_t sppTotal) {
+    const DevFilm &F = S.film;
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t) F.width * F.height * rc.sppPass;
+    if (i >= n) return;
+    const uint32_t k = (uint32_t) (i % rc.sppPass);
+    const size_t p = i / rc.sppPass;
+    const int x = (int) (p % F.width), y = (int) (p / F.width);
+    const int tx = x >> rc.tileShift, ty = y >> rc.tileShift;
+    const int32_t ts = tileSlot[ty * tilesX + tx];
+    float4 v = make_float4(0, 0, 0, 0);
+    if (ts >= 0) {
+        const uint32_t m = spreadBits((uint32_t) (x - (tx << rc.tileShift))) | (spreadBits((uint32_t) (y - (ty << rc.tileShift))) << 1);
+        v = L[(((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m];
+    }
+    out[p * sppTotal + rc.sppFirst + k] = v;
+}
+

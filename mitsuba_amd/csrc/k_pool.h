@@ -1,0 +1,118 @@
+/*
+ * k_pool.h -- path-pool layout in HBM, slot flags, render constants, per-wave statistics, small device helpers
+ * Part of the single translation unit phip.hip (included there, in this order: k_pool.h, k_traverse.h,
+ * k_group8.h, k_shade.h, k_film.h); see the header of phip.hip for the kernel overview.
+ */
+
+/* ======================================================================================
+ *  device-side state
+ * ====================================================================================== */
+#define BLOCK 256
+#ifndef STACK_DEPTH
+#define STACK_DEPTH 24          /* LDS entries per lane (96 B): 6 waves/SIMD fit in 160 KB; deeper entries spill to HBM */
+#endif
+#ifndef NODE_CACHE_MAX
+#define NODE_CACHE_MAX 48            /* BVH4 nodes staged in LDS per block (144 B each): 16 -> 48 measured -2 % traversal time; 64 costs a block of occupancy */
+#endif
+#ifndef TRI_CACHE_MAX
+#define TRI_CACHE_MAX 96        /* triangle records staged in LDS when the whole scene has at most this many */
+#endif
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 6           /* __launch_bounds__ second argument (waves per SIMD) for the traversal kernels */
+#endif
+
+enum : uint32_t {
+    F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22, F_DYNAMIC = 1u << 23,
+    F_REFN_ZERO = 1u << 24,             /* DirectSamplingRecord::refN of the vertex the ray left is zero (BSDF with a back side / transmission) */
+    DEPTH_MASK = 0xFFFFu
+};
+
+struct PathPool {
+    float4 *rayO;     /* o.xyz, mint */
+    float4 *rayD;     /* d.xyz, maxt */
+    float4 *hit;      /* t, u, v, bits(prim) */
+    float4 *thr;      /* throughput rgb, eta */
+    float2 *mis;      /* bsdfPdf of the sampled direction, dot(direction, refN): all the emitter-hit MIS term needs (8 B instead of refN + pdf = 16 B) */
+    uint4 *info;      /* sampleId, pixel, sampleIndex, - : written when the slot starts a sample, read-only afterwards */
+    uint32_t *state;  /* depth | flags: the only per-iteration slot header (4 B instead of rewriting 16 B) */
+    float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0);
+                         block b's entries are compacted at [b*BLOCK, b*BLOCK + shadowCount[b]) */
+    uint32_t *shadowCount;            /* per block of BLOCK slots */
+    uint32_t *blockDead;              /* per block: every slot is F_DEAD and nothing is queued any more -- the drain phase of a pass skips these blocks */
+    unsigned long long *stat;         /* ST_COUNT arrays of nWaves entries */
+    uint32_t *spill;                  /* traversal-stack overflow: SPILL_DEPTH entries per lane */
+    uint2 *spill8;                    /* group kernels: SPILL8 entries per ray group (8 groups per wave) */
+    uint32_t capacity, nWaves;
+};
+
+/* Work counters are kept per wave (one owner, plain read-modify-write, no atomics: a single
+ * contended word saturates at ~88 atomics/us on MI355X) in SoA arrays stat[k][waveId] and summed
+ * by k_reduce_stats when the host wants them. */
+enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI, ST_VERTICES, ST_SAMPLES, ST_ALIVE, ST_COUNT };
+
+struct Counters {
+    unsigned long long total[ST_COUNT];   /* written by k_reduce_stats */
+};
+
+struct RenderConst {
+    unsigned long long totalIds;      /* ids in this pass = nLocalTiles * sppPass * tilePixels */
+    uint32_t sppPass, sppFirst;       /* samples in this pass, first sample index of the pass */
+    uint32_t sppMagic;                /* min(floor(2^32 / sppPass), 2^32 - 1): division by sppPass = one mulhi + one correction */
+    uint32_t tilePixels, tileShift;   /* blockSize^2, log2(blockSize) */
+    uint32_t nLocalTiles;
+    int maxDepth, rrDepth, strictNormals, hideEmitters;
+    uint32_t seed;
+    const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
+    uint32_t countAlive;              /* this iteration records the number of live slots */
+    unsigned long long staticIds;     /* ids [0, staticIds) follow the static slot schedule, the rest is handed out dynamically */
+    unsigned long long shardIds;      /* dynamic ids per counter shard */
+    unsigned long long *dynCounter;   /* DYN_SHARDS counters, one 128-byte line each */
+    uint32_t *blockShard;             /* per block: the counter shard it currently draws from */
+};
+
+/* ======================================================================================
+ *  small device helpers
+ * ====================================================================================== */
+__device__ __forceinline__ uint32_t compactBits(uint32_t x) {   /* even bits of x -> low 16 bits */
+    x &= 0x55555555u;
+    x = (x ^ (x >> 1)) & 0x33333333u;
+    x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu;
+    x = (x ^ (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t spreadBits(uint32_t x) {
+    x &= 0x0000ffffu;
+    x = (x ^ (x << 8)) & 0x00ff00ffu;
+    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+    x = (x ^ (x << 2)) & 0x33333333u;
+    x = (x ^ (x << 1)) & 0x55555555u;
+    return x;
+}
+
+/* sample id -> (local tile, sample-in-pass, pixel); ids are tile-major, then sample, then the
+   Morton index of the pixel inside the tile so that a wave covers an 8x8 pixel patch */
+__device__ __forceinline__ bool decodeId(const RenderConst &rc, const DevFilm &film, unsigned long long id,
+                                         uint32_t &px, uint32_t &py, uint32_t &k) {
+    const uint32_t m = (uint32_t) (id & (rc.tilePixels - 1));
+    const uint32_t r = (uint32_t) (id >> (2 * rc.tileShift));   /* ids of a pass are < 2^32 */
+    uint32_t tile = __umulhi(r, rc.sppMagic);                  /* floor(r / sppPass) or one less */
+    k = r - tile * rc.sppPass;
+    if (k >= rc.sppPass) { k -= rc.sppPass; ++tile; }
+    const uint32_t org = rc.tileOrigin[tile];
+    px = (org & 0xFFFFu) + compactBits(m);
+    py = (org >> 16) + compactBits(m >> 1);
+    k += rc.sppFirst;
+    return px < (uint32_t) film.width && py < (uint32_t) film.height;
+}
+
+/* per-wave statistics slot: wave-reduce v, lane 0 accumulates into stat[k][waveId] (unique owner) */
+__device__ __forceinline__ void waveStat(const PathPool &P, int k, uint32_t waveId, unsigned long long v, bool overwrite = false) {
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    if (__lane_id() == 0) {
+        unsigned long long *p = P.stat + (size_t) k * P.nWaves + waveId;
+        if (overwrite) *p = v; else if (v) *p += v;
+    }
+}
+

@@ -1,0 +1,307 @@
+/*
+ * k_shade.h -- k_shade: the per-vertex work of MIPathTracer::Li and same-lane path regeneration
+ * Part of the single translation unit phip.hip (included there, in this order: k_pool.h, k_traverse.h,
+ * k_group8.h, k_shade.h, k_film.h); see the header of phip.hip for the kernel overview.
+ */
+
+__device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
+    pdfA *= pdfA; pdfB *= pdfB;
+    return pdfA / (pdfA + pdfB);
+}
+
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 4
+#endif
+#define EMITTER_LDS_FLOATS 1024      /* 4 KB */
+#define MATERIAL_LDS_MAX 48          /* 3.75 KB */
+#ifndef SHADE_WAVES_LEAN
+#define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
+#endif
+/* MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
+   normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
+template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+    __shared__ uint32_t waveCnt[BLOCK / 64];
+    if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
+    /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
+       dependent lookups per NEE sample) and the materials */
+    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
+    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
+    const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
+    if (emInLds) for (uint32_t i = threadIdx.x; i < S.emitterTabSize; i += BLOCK) ldsEm[i] = S.emitterTab[i];
+    if (matInLds) {
+        const uint32_t n4 = S.nMaterials * (uint32_t) (sizeof(DevMaterial) / 16);
+        for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) ((float4 *) ldsMat)[i] = ((const float4 *) S.materials)[i];
+    }
+    EmitterTab T; T.t = emInLds ? ldsEm : S.emitterTab; T.n = S.nEmitters; T.normalization = S.emitterNormalization;
+    const DevMaterial *materials = matInLds ? ldsMat : S.materials;
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const bool inRange = slot < P.capacity;
+    /* all slot state is fetched up front, before the liveness test, so that the five 16-byte loads are
+       in flight together (the kernel is latency bound: 70 % of its wave cycles were s_waitcnt) */
+    const uint32_t lslot = inRange ? slot : 0u;
+    uint4 info = P.info[lslot];
+    info.w = P.state[lslot];
+    const float4 hit = P.hit[lslot];
+    const float4 rd = P.rayD[lslot];
+    float4 thr4 = P.thr[lslot];
+    const float2 mis = P.mis[lslot];
+    if (!inRange) info = make_uint4(0, 0, 0, 0);
+    __syncthreads();                                            /* LDS tables are complete */
+    bool alive = inRange && (info.w & F_ALIVE);
+    bool needNew = inRange && !alive && !(info.w & F_DEAD);
+    unsigned long long vertices = 0, done = 0;
+    bool pushShadow = false;
+    float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0;
+
+    if (alive) {
+        const uint32_t prim = pm_to_bits(hit.w);
+        const V3 rayD(rd.x, rd.y, rd.z);
+        V3 thr(thr4.x, thr4.y, thr4.z);
+        float eta = thr4.w;
+        uint32_t depth = info.w & DEPTH_MASK;
+        uint32_t flags = info.w & ~DEPTH_MASK;
+        const uint32_t id = info.x;
+        bool terminate = false;
+        V3 addL(0.0f); bool haveAdd = false;   /* radiance to add to L[id] (in reference order) */
+        float4 l = make_float4(0, 0, 0, 0);
+
+        if (prim == PHIP_NO_HIT) {
+            terminate = true;
+            if (S.envEmitter >= 0) {            /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
+                const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
+                const V3 value = rgb(em + EM_RADIANCE);
+                l = L[id];
+                if (flags & F_FIRST) {
+                    if (!rc.hideEmitters) { l.x += value.x; l.y += value.y; l.z += value.z; }   /* throughput is 1; alpha stays 0 */
+                    haveAdd = true;
+                } else {
+                    const float4 ro = P.rayO[slot];
+                    if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
+                        const float lumPdf = (!(flags & F_PREV_DELTA))
+                            ? pdfEmitterDirectDot(T, (uint32_t) S.envEmitter, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
+                        const V3 c = thr * value * miWeight(mis.x, lumPdf);
+                        l.x += c.x; l.y += c.y; l.z += c.z;
+                        haveAdd = true;
+                    }
+                }
+                if (haveAdd) L[id] = l;
+            }
+        } else {
+            Isect its;
+            fillIntersection(S, rayD, prim, hit.y, hit.z, hit.x, its);
+            /* L[id] is zero until the sample's first vertex writes it (the buffer is cleared per pass), and later
+               vertices only touch it when they hit an emitter: no unconditional 64-byte-sector read per vertex */
+            if (flags & F_FIRST) {
+                l.w = 1.0f;                     /* alpha, records.inl:117-144 */
+                haveAdd = true;
+            } else {
+                /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
+                if (its.emitter >= 0) {
+                    l = L[id];
+                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
+                    V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
+                    /* DirectSamplingRecord::setQuery (records.inl:170-178): n = shading normal, d = ray direction, dist = t */
+                    const float lumPdf = (!(flags & F_PREV_DELTA))
+                        ? pdfEmitterDirectDot(T, (uint32_t) its.emitter, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
+                    const V3 c = thr * value * miWeight(mis.x, lumPdf);
+                    l.x += c.x; l.y += c.y; l.z += c.z;
+                    haveAdd = true;
+                }
+                flags &= ~F_EMITTED;
+                if (depth++ >= (uint32_t) rc.rrDepth) {
+                    float q = smin(thr.maxc() * eta * eta, 0.95f);
+                    const U4 h = pcg4d(info.y, info.z, 2 + 2 * (depth - 2), rc.seed);
+                    if (u32ToFloat(h.x) >= q)
+                        terminate = true;
+                    else
+                        thr = thr / q;
+                }
+            }
+            flags &= ~F_FIRST;
+
+            /* ---- head of the loop for this vertex, path.cpp:135-165 ---- */
+            if (!terminate && !(depth <= (uint32_t) rc.maxDepth || rc.maxDepth < 0))
+                terminate = true;
+            if (!terminate) {
+                if (its.emitter >= 0 && (flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
+                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
+                    V3 le = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
+                    const V3 c = thr * le;
+                    l.x += c.x; l.y += c.y; l.z += c.z;
+                    haveAdd = true;
+                }
+                if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
+                    || (STRICT && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
+                    terminate = true;
+            }
+            V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
+            if (!terminate) {
+                const U4 h = pcg4d(info.y, info.z, 1 + 2 * (depth - 1), rc.seed);
+                /* ---- direct illumination sampling, path.cpp:172-200 ---- */
+                DirectRec dRec;
+                dRec.ref = its.p;
+                dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
+                dRec.pdf = 0; dRec.emitter = -1;
+                const BsdfCtx bctx = bsdfResolve(materials, its);
+                if (its.flags & TS_MF_SMOOTH) {
+                    V3 value = sampleEmitterDirect(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
+                    if (dRec.pdf != 0 && !value.isZero()) {
+                        const V3 wo = its.sh.toLocal(dRec.d);
+                        float bPdf;
+                        const V3 bsdfVal = bsdfEvalPdf<MM>(bctx, wo, bPdf);
+                        if (!bsdfVal.isZero() && (!STRICT || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
+                            const float weight = miWeight(dRec.pdf, bPdf);
+                            shC = thr * value * bsdfVal * weight;
+                            shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
+                            pushShadow = true;
+                        }
+                    }
+                }
+                /* ---- BSDF sampling, path.cpp:207-226 ---- */
+                BSDFSample bs;
+                const V3 bsdfWeight = bsdfSample<MM>(bctx, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
+                if (bsdfWeight.isZero()) {
+                    terminate = true;
+                } else {
+                    flags |= F_SCATTERED;
+                    const V3 wo = its.sh.toWorld(bs.wo);
+                    const float woDotGeoN = dot(its.geoN, wo);
+                    if (STRICT && woDotGeoN * cosTheta(bs.wo) <= 0) {
+                        terminate = true;
+                    } else {
+                        P.rayO[slot] = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
+                        P.rayD[slot] = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                        thr = thr * bsdfWeight;
+                        eta *= bs.eta;
+                        P.thr[slot] = make_float4(thr.x, thr.y, thr.z, eta);
+                        P.mis[slot] = make_float2(bs.pdf, dot(wo, dRec.refN));
+                        flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
+                        flags = dRec.refN.isZero() ? (flags | F_REFN_ZERO) : (flags & ~F_REFN_ZERO);
+                    }
+                }
+            }
+            if (haveAdd) L[id] = l;
+            if (pushShadow) {   /* self-contained shadow-queue entry: survives the slot being recycled */
+                sh0 = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
+                sh1 = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
+                sh2 = make_float4(shC.x, shC.y, shC.z, 0.0f);
+            }
+        }
+        if (terminate) {
+            vertices = depth; done = 1;
+            needNew = true;
+        } else {
+            info.w = flags | depth;
+            P.state[slot] = info.w;
+        }
+    }
+
+    /* ---- shadow queue: compact this block's entries to the front of its own region (no global atomics) ---- */
+    uint32_t shadowTotal = 0;
+    {
+        const unsigned long long m = __ballot(pushShadow);
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) base += c; total += c; }
+        if (pushShadow) {
+            const size_t sidx = (size_t) blockIdx.x * BLOCK + base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+            P.shadow[3 * sidx] = sh0; P.shadow[3 * sidx + 1] = sh1; P.shadow[3 * sidx + 2] = sh2;
+        }
+        if (threadIdx.x == 0) P.shadowCount[blockIdx.x] = total;
+        shadowTotal = total;
+    }
+
+    /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183).
+       Sample ids [0, staticIds) follow a static schedule (slot s renders s, s + capacity, ... -- no global
+       counter in steady state).  The last part of the frame is handed out dynamically so that slots whose
+       paths happened to be short keep working until the frame is really finished: one atomicAdd per BLOCK
+       on one of DYN_SHARDS counters (block-aggregated through LDS; each shard owns a contiguous id range). ---- */
+    bool nowAlive = alive && !needNew;
+    unsigned long long newId = ~0ull;
+    bool wantDyn = false;
+    if (needNew) {
+        unsigned long long id = (info.w & F_FRESH) ? (unsigned long long) slot      /* first sample of this slot */
+                              : ((info.w & F_DYNAMIC) ? ~0ull : (unsigned long long) info.x + P.capacity);
+        for (;;) {
+            if (id >= rc.staticIds) { wantDyn = true; break; }
+            uint32_t px, py, k;
+            if (decodeId(rc, S.film, id, px, py, k)) { newId = id; break; }
+            id += P.capacity;       /* ids outside the crop window (edge blocks) are skipped */
+        }
+    }
+    bool dynamicId = false;
+    {
+        const unsigned long long m = __ballot(wantDyn);
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        __syncthreads();                                   /* waveCnt is reused from the shadow compaction */
+        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) before += c; total += c; }
+        if (total) {                                       /* block-uniform */
+            __shared__ unsigned long long dynBase;
+            __shared__ uint32_t dynShard;
+            if (threadIdx.x == 0) {
+                uint32_t sh = (blockIdx.x + rc.blockShard[blockIdx.x]) % DYN_SHARDS;    /* blockShard = shards this block has seen run dry */
+                uint32_t dry = 0;
+                unsigned long long base = ~0ull;
+                for (int tries = 0; tries < DYN_SHARDS; ++tries) {
+                    const unsigned long long old = atomicAdd(rc.dynCounter + (size_t) sh * DYN_STRIDE, (unsigned long long) total);
+                    if (old < rc.shardIds) { base = old; break; }
+                    sh = (sh + 1) % DYN_SHARDS; ++dry;     /* this shard is used up: move on for good */
+                }
+                if (dry) rc.blockShard[blockIdx.x] += dry;
+                dynBase = base; dynShard = sh;
+            }
+            __syncthreads();
+            if (wantDyn) {
+                bool got = false;
+                if (dynBase != ~0ull) {
+                    const unsigned long long off = dynBase + before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+                    const unsigned long long id = rc.staticIds + (unsigned long long) dynShard * rc.shardIds + off;
+                    uint32_t px, py, k;
+                    if (off < rc.shardIds && id < rc.totalIds) {
+                        got = true;                        /* the id is consumed even if it lies outside the crop window */
+                        if (decodeId(rc, S.film, id, px, py, k)) { newId = id; dynamicId = true; }
+                    }
+                }
+                if (!got && dynBase == ~0ull) { info.w = F_DEAD; P.state[slot] = F_DEAD; }   /* all shards empty: slot dies */
+                else if (newId == ~0ull) { info.w = F_DYNAMIC; P.state[slot] = F_DYNAMIC; }                        /* try again next iteration */
+            }
+        }
+    }
+    if (newId != ~0ull) {
+        uint32_t px, py, k;
+        decodeId(rc, S.film, newId, px, py, k);
+        const uint32_t pixel = py * (uint32_t) S.film.width + px;
+        const U4 h = pcg4d(pixel, k, 0, rc.seed);
+        const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+        V3 o, d; float mint, maxt;
+        cameraRay(S.cam, sx, sy, o, d, mint, maxt);
+        P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
+        P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
+        P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        P.mis[slot] = make_float2(0.0f, 0.0f);
+        info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
+        P.info[slot] = info;
+        P.state[slot] = info.w;
+        nowAlive = true;
+    }
+    const uint32_t waveId = slot >> 6;
+    /* a slot still waiting for a dynamic sample id counts as live for the termination test */
+    const bool live = nowAlive || (inRange && info.w == F_DYNAMIC);
+    /* the block retires once none of its slots will ever work again and its last shadow entries have been consumed
+       (this launch queued nothing, so shadowCount is 0): later launches of the pass return at the first line */
+    const bool retire = !__syncthreads_or(live ? 1 : 0) && shadowTotal == 0;
+    if (retire && threadIdx.x == 0) P.blockDead[blockIdx.x] = 1u;
+    if (inRange || (slot & ~63u) < P.capacity) {
+        waveStat(P, ST_VERTICES, waveId, vertices);
+        waveStat(P, ST_SAMPLES, waveId, done);
+        if (rc.countAlive || retire) waveStat(P, ST_ALIVE, waveId, live ? 1ull : 0ull, true);
+    }
+}
+

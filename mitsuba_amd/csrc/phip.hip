@@ -4,26 +4,28 @@
  * Replaces the reference's per-block CPU loop (SamplingIntegrator::renderBlock ->
  * MIPathTracer::Li, src/librender/integrator.cpp:140-188, src/integrators/path/path.cpp:119-300)
  * with a slot-stable wavefront: a pool of path slots lives in HBM as SoA arrays; every iteration
- * runs   shade -> shadow -> trace   over the pool.
+ * runs   shade -> shadow rays -> closest-hit rays   over the pool, a final film kernel develops the
+ * per-sample accumulators.  One translation unit; the kernels live in the headers included below:
  *
- *   k_shade   one lane per slot.  Consumes the closest-hit record of the slot's current ray:
- *             emitter-hit MIS term, Russian roulette, then at the new vertex emission, NEE
- *             sample (emits a self-contained shadow-queue entry), BSDF sample -> next ray.
- *             When a path ends the SAME lane immediately regenerates a new camera path from a
- *             global sample counter (wave-aggregated atomic), so the pool stays full until the
- *             image runs out of samples.  Radiance is accumulated per sample in a sample buffer
- *             L[sampleId] (float4), so a finished slot has nothing to flush.
- *   k_shadow  any-hit traversal over the compacted shadow queue; unoccluded entries add their
- *             contribution to L[sampleId].
- *   k_trace   closest-hit traversal for every live slot -> hit record.
- *   k_film    per-pixel gather of the filtered samples (ImageBlock::put semantics,
- *             include/mitsuba/render/imageblock.h:124-204) -- no float atomics, deterministic.
+ *   k_pool.h      PathPool (HBM layout of the slots), slot flags, RenderConst, per-wave statistics
+ *   k_traverse.h  per-lane BVH4 traversal as a state machine (one node step + one Wald test per
+ *                 iteration), LDS-staged stacks and top-of-tree cache; k_trace / k_shadow (one lane per
+ *                 slot, small scenes), k_trace_p / k_shadow_p / k_rays_p (persistent waves with refill;
+ *                 k_rays_p casts the closest-hit and the any-hit rays of an iteration in one launch),
+ *                 k_raycast (phip_trace)
+ *   k_group8.h    8 lanes per ray over a BVH8: measured 3x slower, kept as a documented experiment
+ *   k_shade.h     k_shade<materials, strictNormals>: emitter-hit / environment MIS term, Russian roulette,
+ *                 emission, NEE sample (self-contained shadow-queue entry, block-compacted), BSDF sample ->
+ *                 next ray in place; a path that ends is replaced by the SAME lane in the same launch
+ *                 (static sample schedule + dynamic tail).  Radiance accumulates in L[sampleId] in the
+ *                 reference's order, so results are bit-reproducible.
+ *   k_film.h      k_film_tiled / k_film: gather of the filtered samples per pixel (ImageBlock::put,
+ *                 include/mitsuba/render/imageblock.h:124-204) -- no float atomics, deterministic;
+ *                 k_reduce_stats, k_export_samples
  *
- * Traversal: BVH2 with 64-byte nodes (bvh.h), per-lane stack in LDS (interleaved so that lane i
- * owns bank i), Wald triangle test with the reference's arithmetic.  Not MFMA work: irregular,
- * latency/HBM bound.
- *
- * This file is the product; it never includes, links or calls anything under oracle/.
+ * This file: error handling, host side (scene validation and upload, BVH build via bvh.h, camera set-up,
+ * the render loop) and the extern "C" entry points.  Not MFMA work: irregular traversal and gathers
+ * (SURVEY 8d).  The product never includes, links or calls anything under oracle/.
  */
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -54,1454 +56,11 @@ static int setErr(int code, const std::string &msg) { g_err = msg; return code; 
             throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__));         \
     } while (0)
 
-/* ======================================================================================
- *  device-side state
- * ====================================================================================== */
-#define BLOCK 256
-#ifndef STACK_DEPTH
-#define STACK_DEPTH 24          /* LDS entries per lane (96 B): 6 waves/SIMD fit in 160 KB; deeper entries spill to HBM */
-#endif
-#ifndef NODE_CACHE_MAX
-#define NODE_CACHE_MAX 48            /* BVH4 nodes staged in LDS per block (144 B each): 16 -> 48 measured -2 % traversal time; 64 costs a block of occupancy */
-#endif
-#ifndef TRI_CACHE_MAX
-#define TRI_CACHE_MAX 96        /* triangle records staged in LDS when the whole scene has at most this many */
-#endif
-#ifndef TRACE_WAVES
-#define TRACE_WAVES 6           /* __launch_bounds__ second argument (waves per SIMD) for the traversal kernels */
-#endif
-
-enum : uint32_t {
-    F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22, F_DYNAMIC = 1u << 23,
-    F_REFN_ZERO = 1u << 24,             /* DirectSamplingRecord::refN of the vertex the ray left is zero (BSDF with a back side / transmission) */
-    DEPTH_MASK = 0xFFFFu
-};
-
-struct PathPool {
-    float4 *rayO;     /* o.xyz, mint */
-    float4 *rayD;     /* d.xyz, maxt */
-    float4 *hit;      /* t, u, v, bits(prim) */
-    float4 *thr;      /* throughput rgb, eta */
-    float2 *mis;      /* bsdfPdf of the sampled direction, dot(direction, refN): all the emitter-hit MIS term needs (8 B instead of refN + pdf = 16 B) */
-    uint4 *info;      /* sampleId, pixel, sampleIndex, - : written when the slot starts a sample, read-only afterwards */
-    uint32_t *state;  /* depth | flags: the only per-iteration slot header (4 B instead of rewriting 16 B) */
-    float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0);
-                         block b's entries are compacted at [b*BLOCK, b*BLOCK + shadowCount[b]) */
-    uint32_t *shadowCount;            /* per block of BLOCK slots */
-    uint32_t *blockDead;              /* per block: every slot is F_DEAD and nothing is queued any more -- the drain phase of a pass skips these blocks */
-    unsigned long long *stat;         /* ST_COUNT arrays of nWaves entries */
-    uint32_t *spill;                  /* traversal-stack overflow: SPILL_DEPTH entries per lane */
-    uint2 *spill8;                    /* group kernels: SPILL8 entries per ray group (8 groups per wave) */
-    uint32_t capacity, nWaves;
-};
-
-/* Work counters are kept per wave (one owner, plain read-modify-write, no atomics: a single
- * contended word saturates at ~88 atomics/us on MI355X) in SoA arrays stat[k][waveId] and summed
- * by k_reduce_stats when the host wants them. */
-enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI, ST_VERTICES, ST_SAMPLES, ST_ALIVE, ST_COUNT };
-
-struct Counters {
-    unsigned long long total[ST_COUNT];   /* written by k_reduce_stats */
-};
-
-struct RenderConst {
-    unsigned long long totalIds;      /* ids in this pass = nLocalTiles * sppPass * tilePixels */
-    uint32_t sppPass, sppFirst;       /* samples in this pass, first sample index of the pass */
-    uint32_t sppMagic;                /* min(floor(2^32 / sppPass), 2^32 - 1): division by sppPass = one mulhi + one correction */
-    uint32_t tilePixels, tileShift;   /* blockSize^2, log2(blockSize) */
-    uint32_t nLocalTiles;
-    int maxDepth, rrDepth, strictNormals, hideEmitters;
-    uint32_t seed;
-    const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
-    uint32_t countAlive;              /* this iteration records the number of live slots */
-    unsigned long long staticIds;     /* ids [0, staticIds) follow the static slot schedule, the rest is handed out dynamically */
-    unsigned long long shardIds;      /* dynamic ids per counter shard */
-    unsigned long long *dynCounter;   /* DYN_SHARDS counters, one 128-byte line each */
-    uint32_t *blockShard;             /* per block: the counter shard it currently draws from */
-};
-
-/* ======================================================================================
- *  small device helpers
- * ====================================================================================== */
-__device__ __forceinline__ uint32_t compactBits(uint32_t x) {   /* even bits of x -> low 16 bits */
-    x &= 0x55555555u;
-    x = (x ^ (x >> 1)) & 0x33333333u;
-    x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
-    x = (x ^ (x >> 4)) & 0x00ff00ffu;
-    x = (x ^ (x >> 8)) & 0x0000ffffu;
-    return x;
-}
-__host__ __device__ __forceinline__ uint32_t spreadBits(uint32_t x) {
-    x &= 0x0000ffffu;
-    x = (x ^ (x << 8)) & 0x00ff00ffu;
-    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
-    x = (x ^ (x << 2)) & 0x33333333u;
-    x = (x ^ (x << 1)) & 0x55555555u;
-    return x;
-}
-
-/* sample id -> (local tile, sample-in-pass, pixel); ids are tile-major, then sample, then the
-   Morton index of the pixel inside the tile so that a wave covers an 8x8 pixel patch */
-__device__ __forceinline__ bool decodeId(const RenderConst &rc, const DevFilm &film, unsigned long long id,
-                                         uint32_t &px, uint32_t &py, uint32_t &k) {
-    const uint32_t m = (uint32_t) (id & (rc.tilePixels - 1));
-    const uint32_t r = (uint32_t) (id >> (2 * rc.tileShift));   /* ids of a pass are < 2^32 */
-    uint32_t tile = __umulhi(r, rc.sppMagic);                  /* floor(r / sppPass) or one less */
-    k = r - tile * rc.sppPass;
-    if (k >= rc.sppPass) { k -= rc.sppPass; ++tile; }
-    const uint32_t org = rc.tileOrigin[tile];
-    px = (org & 0xFFFFu) + compactBits(m);
-    py = (org >> 16) + compactBits(m >> 1);
-    k += rc.sppFirst;
-    return px < (uint32_t) film.width && py < (uint32_t) film.height;
-}
-
-/* per-wave statistics slot: wave-reduce v, lane 0 accumulates into stat[k][waveId] (unique owner) */
-__device__ __forceinline__ void waveStat(const PathPool &P, int k, uint32_t waveId, unsigned long long v, bool overwrite = false) {
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_down(v, off);
-    if (__lane_id() == 0) {
-        unsigned long long *p = P.stat + (size_t) k * P.nWaves + waveId;
-        if (overwrite) *p = v; else if (v) *p += v;
-    }
-}
-
-/* ======================================================================================
- *  BVH traversal (closest / any hit)
- * ====================================================================================== */
-struct TravResult { float t, u, v; uint32_t prim; };
-
-/* scene-box clip + adaptive epsilon, src/librender/skdtree.cpp:112-142 (closest) / :207-226 (shadow) */
-template <bool SHADOW>
-__device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
-                                            float &mint, float &maxt) {
-    float nearT = -INFINITY, farT = INFINITY;
-    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
-        if (dd[i] == 0) {
-            if (origin < minVal || origin > maxVal) return false;
-        } else {
-            const float rcp = 1.0f / dd[i];
-            float t1 = (minVal - origin) * rcp;
-            float t2 = (maxVal - origin) * rcp;
-            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
-            nearT = smax(t1, nearT);
-            farT = smin(t2, farT);
-            if (!(nearT <= farT)) return false;
-        }
-    }
-    mint = nearT; maxt = farT;
-    float rayMinT = rayMint;
-    if (rayMinT == PT_EPSILON) {
-        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-        if (!SHADOW) m = smax(m, PT_EPSILON);
-        rayMinT *= m;
-    }
-    if (rayMinT > mint) mint = rayMinT;
-    if (rayMaxt < maxt) maxt = rayMaxt;
-    return maxt > mint;
-}
-
-/* Per-lane traversal stack: the first `depth` entries live in LDS (interleaved: entry e of lane l at
- * lds[e * BLOCK + l], so lane i always hits bank i), deeper entries spill to a per-lane HBM array.
- * The same dynamic LDS segment also stages the top of the tree: the first S.nodeCache BVH4 nodes (they
- * are stored in breadth-first order, so these are the levels every ray visits) and, for small scenes,
- * all triangle records.  Cached nodes use a 144-byte stride so that lanes reading different nodes hit
- * different banks with ds_read_b128. */
-#define NODE_LDS_STRIDE 9               /* float4 per cached node (8 + 1 pad) */
-/* LDS pointers carry their address space in the type: through a generic pointer the compiler emits flat_load for the cached
-   nodes/records, which goes through the texture addresser (16 clk per 16-byte wave instruction, shared by the CU's four SIMDs)
-   instead of the LDS pipe (ds_read_b128) -- on the Cornell box, where everything is cached, that was the bottleneck. */
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(3))) f4v lds_cf4;
-__device__ __forceinline__ float4 ldsLoad4(lds_cf4 *p) { const f4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
-struct TravStack {
-    lds_u32 *lds;           /* lds base + threadIdx.x */
-    uint32_t *spill;        /* global: SPILL_DEPTH entries per lane */
-    lds_cf4 *nodes;         /* LDS copy of nodes [0, nodeCache) */
-    lds_cf4 *tris;          /* LDS copy of triangle records [0, triCache) */
-    uint32_t nodeCache, triCache;
-    int depth, sp;
-    __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < depth) lds[sp * BLOCK] = v; else spill[sp - depth] = v;
-        ++sp;
-    }
-    __device__ __forceinline__ uint32_t pop() {
-        --sp;
-        return sp < depth ? lds[sp * BLOCK] : spill[sp - depth];
-    }
-};
-
-/* carve the block's dynamic LDS and stage the cached geometry (all threads of the block must call) */
-__device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char *smem, uint32_t *spill, TravStack &stk) {
-    uint32_t *stack = (uint32_t *) smem;
-    float4 *ln = (float4 *) (smem + (size_t) S.stackDepth * BLOCK * sizeof(uint32_t));
-    float4 *lt = ln + (size_t) S.nodeCache * NODE_LDS_STRIDE;
-    for (uint32_t i = threadIdx.x; i < S.nodeCache * 8u; i += BLOCK)
-        ln[(i >> 3) * NODE_LDS_STRIDE + (i & 7u)] = S.nodes[i];
-    for (uint32_t i = threadIdx.x; i < S.triCache * 3u; i += BLOCK)
-        lt[i] = S.tris[i];
-    __syncthreads();
-    stk.lds = (lds_u32 *) (stack + threadIdx.x); stk.spill = spill; stk.nodes = (lds_cf4 *) ln; stk.tris = (lds_cf4 *) lt;
-    stk.nodeCache = S.nodeCache; stk.triCache = S.triCache; stk.depth = (int) S.stackDepth; stk.sp = 0;
-}
-
-/* TYPED (a constant in the scope of the caller): true = separate LDS (ds_read_b128) and global paths -- right when (almost)
-   everything is cached (small scenes); false = one flat_load path with a selected address -- fewer registers and no
-   divergence when most lanes read global memory (big scenes; measured 1-3 % faster there, 14 % slower on the Cornell box) */
-#define LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)                                   \
-    float4 mnx, mny, mnz, mxx, mxy, mxz, chf;                                                         \
-    if (TYPED) {                                                                                      \
-        if ((uint32_t) (cur) < (stack).nodeCache) {                                                   \
-            lds_cf4 *n_ = (stack).nodes + (uint32_t) (cur) * NODE_LDS_STRIDE;                         \
-            mnx = ldsLoad4(n_); mny = ldsLoad4(n_ + 1); mnz = ldsLoad4(n_ + 2); mxx = ldsLoad4(n_ + 3); \
-            mxy = ldsLoad4(n_ + 4); mxz = ldsLoad4(n_ + 5); chf = ldsLoad4(n_ + 6);                   \
-        } else {                                                                                      \
-            const float4 *n_ = (S).nodes + 8 * (size_t) (cur);                                        \
-            mnx = n_[0]; mny = n_[1]; mnz = n_[2]; mxx = n_[3]; mxy = n_[4]; mxz = n_[5]; chf = n_[6]; \
-        }                                                                                             \
-    } else {                                                                                          \
-        const float4 *n_ = (uint32_t) (cur) < (stack).nodeCache                                       \
-            ? (const float4 *) ((stack).nodes + (uint32_t) (cur) * NODE_LDS_STRIDE) : (S).nodes + 8 * (size_t) (cur); \
-        mnx = n_[0]; mny = n_[1]; mnz = n_[2]; mxx = n_[3]; mxy = n_[4]; mxz = n_[5]; chf = n_[6];    \
-    }
-#define LOAD_TRI(stack, S, idx, a, b, c)                                                              \
-    float4 a, b, c;                                                                                   \
-    if (TYPED) {                                                                                      \
-        if ((uint32_t) (idx) < (stack).triCache) {                                                    \
-            lds_cf4 *t_ = (stack).tris + 3 * (uint32_t) (idx); a = ldsLoad4(t_); b = ldsLoad4(t_ + 1); c = ldsLoad4(t_ + 2); \
-        } else {                                                                                      \
-            const float4 *t_ = (S).tris + 3 * (size_t) (idx); a = t_[0]; b = t_[1]; c = t_[2];        \
-        }                                                                                             \
-    } else {                                                                                          \
-        const float4 *t_ = (uint32_t) (idx) < (stack).triCache ? (const float4 *) ((stack).tris + 3 * (uint32_t) (idx)) : (S).tris + 3 * (size_t) (idx); \
-        a = t_[0]; b = t_[1]; c = t_[2];                                                              \
-    }
-#define SPILL_DEPTH 96
-
-__device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
-    const bool sw = kb < ka;
-    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
-    const uint32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
-    ka = k0; kb = k1; ra = r0; rb = r1;
-}
-
-#ifndef SHADOW_ATOMIC_COMMIT
-#define SHADOW_ATOMIC_COMMIT 0      /* measured: bit-identical, +1..3 % on the 250k-triangle scenes but the Cornell shadow kernel doubles (1.3 G 4-byte L2 atomics per frame) */
-#endif
-#ifndef SHADOW_UNSORTED
-#define SHADOW_UNSORTED 1
-#endif
-#define DONE_REF ((int32_t) 0x80000000)   /* 'no more nodes' marker; as a leaf reference it would need 2^28 triangle records */
-
-/* One BVH4 node step: slab test of the four children, nearest-first order, push the farther hits,
-   continue with the nearest (or pop).  Shared by the per-slot and the persistent kernels. */
-#define NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)                                       \
-    {                                                                                                     \
-        LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)                                       \
-        ++nodeVisits;                                                                                     \
-        float key[4]; uint32_t ref[4];                                                                    \
-        SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)                                                       \
-        /* nearest child first (also a good any-hit order); misses (INFINITY) sort to the end */         \
-        cswap(key[0], ref[0], key[1], ref[1]); cswap(key[2], ref[2], key[3], ref[3]);                     \
-        cswap(key[0], ref[0], key[2], ref[2]); cswap(key[1], ref[1], key[3], ref[3]);                     \
-        cswap(key[1], ref[1], key[2], ref[2]);                                                            \
-        if (key[0] < INFINITY) {                                                                          \
-            if (stack.sp + 3 <= stack.depth) {      /* branch-free pushes: hits are a prefix of the sorted keys */ \
-                stack.lds[stack.sp * BLOCK] = ref[3]; stack.sp += key[3] < INFINITY ? 1 : 0;              \
-                stack.lds[stack.sp * BLOCK] = ref[2]; stack.sp += key[2] < INFINITY ? 1 : 0;              \
-                stack.lds[stack.sp * BLOCK] = ref[1]; stack.sp += key[1] < INFINITY ? 1 : 0;              \
-            } else {                                                                                      \
-                if (key[3] < INFINITY) stack.push(ref[3]);                                                \
-                if (key[2] < INFINITY) stack.push(ref[2]);                                                \
-                if (key[1] < INFINITY) stack.push(ref[1]);                                                \
-            }                                                                                             \
-            cur = (int32_t) ref[0];                                                                       \
-        } else {                                                                                          \
-            cur = stack.sp == 0 ? DONE_REF : (int32_t) stack.pop();                                       \
-        }                                                                                                 \
-    }
-/* Any-hit variant: the visiting order of the children does not matter for an unoccluded ray (all of them are
-   visited) -- no sorting network.  Branch-free: every hit child is written at the current stack top, the top only
-   advances once a later hit shows that the entry has to be kept; the last hit child becomes the next node. */
-#define NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)                                   \
-    {                                                                                                     \
-        LOAD_NODE(stack, S, cur, mnx, mny, mnz, mxx, mxy, mxz, chf)                                       \
-        ++nodeVisits;                                                                                     \
-        float key[4]; uint32_t ref[4];                                                                    \
-        SLAB(0, x) SLAB(1, y) SLAB(2, z) SLAB(3, w)                                                       \
-        const bool h0 = key[0] < INFINITY, h1 = key[1] < INFINITY, h2 = key[2] < INFINITY, h3 = key[3] < INFINITY; \
-        if (h0 || h1 || h2 || h3) {                                                                       \
-            uint32_t nxt = ref[0]; bool have = h0;                                                        \
-            if (stack.sp + 3 <= stack.depth) {                                                            \
-                stack.lds[stack.sp * BLOCK] = nxt; stack.sp += (h1 && have) ? 1 : 0; nxt = h1 ? ref[1] : nxt; have = have || h1; \
-                stack.lds[stack.sp * BLOCK] = nxt; stack.sp += (h2 && have) ? 1 : 0; nxt = h2 ? ref[2] : nxt; have = have || h2; \
-                stack.lds[stack.sp * BLOCK] = nxt; stack.sp += (h3 && have) ? 1 : 0; nxt = h3 ? ref[3] : nxt;                     \
-            } else {                                                                                      \
-                if (h1) { if (have) stack.push(nxt); nxt = ref[1]; have = true; }                         \
-                if (h2) { if (have) stack.push(nxt); nxt = ref[2]; have = true; }                         \
-                if (h3) { if (have) stack.push(nxt); nxt = ref[3]; have = true; }                         \
-            }                                                                                             \
-            cur = (int32_t) nxt;                                                                          \
-        } else {                                                                                          \
-            cur = stack.sp == 0 ? DONE_REF : (int32_t) stack.pop();                                       \
-        }                                                                                                 \
-    }
-#define SLAB(K, C)                                                                                        \
-    {                                                                                                     \
-        const float x0 = fmaf(mnx.C, rcp.x, -ordr.x), x1 = fmaf(mxx.C, rcp.x, -ordr.x);                   \
-        const float y0 = fmaf(mny.C, rcp.y, -ordr.y), y1 = fmaf(mxy.C, rcp.y, -ordr.y);                   \
-        const float z0 = fmaf(mnz.C, rcp.z, -ordr.z), z1 = fmaf(mxz.C, rcp.z, -ordr.z);                   \
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint));          \
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt));          \
-        key[K] = (tn <= tf) ? tn : INFINITY;                                                              \
-        ref[K] = pm_to_bits(chf.C);                                                                       \
-    }
-
-/* Traversal as a per-lane state machine whose loop body is ONE node step and ONE triangle test: a lane
- * inside a leaf tests one Wald record per iteration while its neighbours go on with node
- * steps.  (Looping over the whole leaf inside the body made every lane of the wave wait for up to eight
- * triangle tests per iteration although only ~15 % of the lanes sit in a leaf: measured 2x the issue slots.)
- * The order in which a ray tests its triangles is unchanged, hence so are the results. */
-template <bool SHADOW>
-__device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
-                                         TravStack &stack, TravResult &res,
-                                         uint32_t &nodeVisits, uint32_t &triTests) {
-    constexpr bool TYPED = true;
-    /* reciprocal direction for the slab tests (conservative: boxes are padded); the Wald test uses o,d */
-    const V3 rcp(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const V3 ordr(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
-    stack.sp = 0;
-    int32_t cur = S.rootRef;
-    bool found = false;
-    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-    while (cur != DONE_REF) {
-        if (cur >= 0) {
-            if (SHADOW && SHADOW_UNSORTED) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
-            else NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
-        }
-        if (cur < 0 && cur != DONE_REF) {
-            /* a leaf reference doubles as the lane's progress inside the leaf: ~((next record << 3) | records left - 1) */
-            const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;
-            LOAD_TRI(stack, S, idx, a, b, c)
-            ++triTests;
-            float tu, tv, tt;
-            if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
-                if (SHADOW) return true;
-                maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
-                found = true;
-            }
-            cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
-        }
-    }
-    return found;
-}
-
-/* ======================================================================================
- *  Persistent per-lane traversal: a fixed grid of resident waves walks the whole ray pool.
- *  A lane that finishes its ray (or finds its slot dead) is refilled from the wave's own
- *  statically strided share of the pool as soon as REFILL_LANES lanes are idle, so the wave
- *  does not wait for its slowest ray ("while-while" + dynamic fetch, but without any global
- *  atomic: the share of wave w is chunks w, w+W, w+2W, ...).
- * ====================================================================================== */
-#ifndef REFILL_LANES
-#define REFILL_LANES 16
-#endif
-#define INVALID_RAY 0xFFFFFFFFu
-#define DYN_SHARDS 8                    /* one dynamic-sample counter per XCD-sized group of blocks */
-#define DYN_STRIDE 16                   /* unsigned long longs between counters (128 B) */
-
-template <bool SHADOW, bool TYPED, typename Source>
-__device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack &stack, Source &src,
-                                                   uint32_t &nodeVisits, uint32_t &triTests, uint32_t &raysTraced) {
-    bool active = false;
-    uint32_t handle = INVALID_RAY;
-    V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
-    float mint = 0, maxt = 0;
-    int32_t cur = 0;
-    TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        if (idle && src.more() && (__popcll(idle) >= REFILL_LANES || idle == ~0ull)) {
-            const uint32_t h = src.assign(!active, idle);
-            if (!active && h != INVALID_RAY) {
-                float rmint, rmaxt;
-                if (src.load(h, o, d, rmint, rmaxt)) {
-                    ++raysTraced;
-                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-                    if (clipToScene<SHADOW>(S, o, d, rmint, rmaxt, mint, maxt)) {
-                        rcp = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
-                        cur = S.rootRef; stack.sp = 0; handle = h; active = true;
-                    } else {
-                        src.commit(h, false, res);
-                    }
-                }
-            }
-        }
-        if (!__any(active)) { if (!src.more()) break; continue; }
-        if (active) {
-            /* one node step and one triangle test per iteration (see traverse()) */
-            for (;;) {
-                if (cur >= 0) {
-                    if (SHADOW && SHADOW_UNSORTED) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
-                    else NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
-                }
-                bool finished = false;
-                if (cur < 0 && cur != DONE_REF) {
-                    const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;
-                    LOAD_TRI(stack, S, idx, a, b, c)
-                    ++triTests;
-                    float tu, tv, tt;
-                    if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
-                        if (SHADOW) { res.prim = 0; finished = true; }
-                        else { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
-                    }
-                    cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
-                }
-                if (cur == DONE_REF) finished = true;
-                if (finished) {
-                    src.commit(handle, SHADOW ? (res.prim != PHIP_NO_HIT) : false, res);
-                    active = false;
-                    break;
-                }
-                if (src.more() && __popcll(__ballot(1)) <= 64 - REFILL_LANES) break;     /* enough idle lanes: refill */
-            }
-        }
-    }
-}
-
-/* closest-hit source: all slots of the pool, chunk-strided over the resident waves */
-struct TraceSource {
-    const PathPool &P; uint32_t chunk, pos, stride, nChunks;
-    __device__ __forceinline__ bool more() const { return chunk < nChunks; }
-    __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
-        const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
-        const uint32_t h = (want && idx < 64u && chunk * 64u + idx < P.capacity) ? chunk * 64u + idx : INVALID_RAY;
-        pos += (uint32_t) __popcll(wantMask);
-        if (pos >= 64u) { pos = 0; chunk += stride; }
-        return h;
-    }
-    __device__ __forceinline__ bool load(uint32_t slot, V3 &o, V3 &d, float &mint, float &maxt) const {
-        if (!(P.state[slot] & F_ALIVE)) return false;
-        const float4 ro = P.rayO[slot], rd = P.rayD[slot];
-        o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
-        return true;
-    }
-    __device__ __forceinline__ void commit(uint32_t slot, bool, const TravResult &r) const {
-        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
-    }
-};
-
-/* L[id] += c for an unoccluded NEE entry.  A load-add-store here stalls the whole traversal wave for a random HBM round
- * trip every time one of its lanes finishes a ray; three fire-and-forget hardware float atomics do not.  They are plain IEEE
- * round-to-nearest additions at the L2 (no other lane touches L[id] during this kernel, so there is no ordering question), but
- * the L2 adder flushes denormals: radiance contributions are >= 0, so the sum of a normal-or-zero addend and the accumulator
- * (itself a sum of such addends) is never denormal -- an entry with a denormal component takes the load-add-store path. */
-__device__ __forceinline__ void addRadiance(float4 *L, uint32_t id, const float4 &c) {
-    const float tiny = 1.17549435e-38f;
-    const bool plain = (c.x == 0.0f || c.x >= tiny) && (c.y == 0.0f || c.y >= tiny) && (c.z == 0.0f || c.z >= tiny);
-#if SHADOW_ATOMIC_COMMIT
-    if (plain) {
-        float *p = (float *) (L + id);
-        if (c.x != 0.0f) unsafeAtomicAdd(p, c.x);
-        if (c.y != 0.0f) unsafeAtomicAdd(p + 1, c.y);
-        if (c.z != 0.0f) unsafeAtomicAdd(p + 2, c.z);
-        return;
-    }
-#endif
-    float4 l = L[id];
-    l.x += c.x; l.y += c.y; l.z += c.z;
-    L[id] = l;
-}
-
-/* any-hit source: the block-compacted shadow queue; wave w walks blocks w, w+W, ... */
-struct ShadowSource {
-    const PathPool &P; float4 *L; uint32_t blk, pos, cnt, stride, nBlocks;
-    __device__ __forceinline__ void skipEmpty() {
-        while (blk < nBlocks) { cnt = P.shadowCount[blk]; if (cnt) break; blk += stride; }
-    }
-    __device__ __forceinline__ bool more() const { return blk < nBlocks; }
-    __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
-        const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
-        const uint32_t h = (want && idx < cnt) ? blk * BLOCK + idx : INVALID_RAY;
-        pos += (uint32_t) __popcll(wantMask);
-        if (pos >= cnt) { pos = 0; blk += stride; skipEmpty(); }
-        return h;
-    }
-    __device__ __forceinline__ bool load(uint32_t e, V3 &o, V3 &d, float &mint, float &maxt) const {
-        const float4 e0 = P.shadow[3 * (size_t) e], e1 = P.shadow[3 * (size_t) e + 1];
-        o = V3(e0.x, e0.y, e0.z); d = V3(e1.x, e1.y, e1.z); mint = PT_EPSILON; maxt = e0.w;
-        return true;
-    }
-    __device__ __forceinline__ void commit(uint32_t e, bool occluded, const TravResult &) const {
-        if (!occluded) {
-            const float4 e1 = P.shadow[3 * (size_t) e + 1], e2 = P.shadow[3 * (size_t) e + 2];
-            addRadiance(L, pm_to_bits(e1.w), e2);
-        }
-    }
-};
-
-#ifndef TRACE_P_WAVES
-#define TRACE_P_WAVES 5
-#endif
-extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
-
-/* ---- closest-hit AND any-hit rays of one iteration in ONE persistent launch ----
- * The two ray kinds of an iteration are independent (k_shade consumes both results in the next iteration), so a wave
- * first drains its share of the shadow queue and then, without a kernel boundary, refills idle lanes from its share
- * of the closest-hit queue: one kernel tail (waves waiting for the slowest in-flight rays) and one launch per
- * iteration instead of two.  The kind of a lane's ray is a per-lane flag; the loop body is shared. */
-__device__ __forceinline__ bool clipToSceneRT(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
-                                              float &mint, float &maxt, bool shadow) {
-    float nearT = -INFINITY, farT = INFINITY;
-    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
-        if (dd[i] == 0) {
-            if (origin < minVal || origin > maxVal) return false;
-        } else {
-            const float rcp = 1.0f / dd[i];
-            float t1 = (minVal - origin) * rcp;
-            float t2 = (maxVal - origin) * rcp;
-            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
-            nearT = smax(t1, nearT);
-            farT = smin(t2, farT);
-            if (!(nearT <= farT)) return false;
-        }
-    }
-    mint = nearT; maxt = farT;
-    float rayMinT = rayMint;
-    if (rayMinT == PT_EPSILON) {
-        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-        if (!shadow) m = smax(m, PT_EPSILON);               /* skdtree.cpp:124 vs :215 */
-        rayMinT *= m;
-    }
-    if (rayMinT > mint) mint = rayMinT;
-    if (rayMaxt < maxt) maxt = rayMaxt;
-    return maxt > mint;
-}
-
-#ifndef RAYS_SHADOW_UNSORTED
-#define RAYS_SHADOW_UNSORTED 0
-#endif
-enum { WC_RAYS = 0, WC_NODE, WC_TRI, WC_SH_RAYS, WC_SH_NODE, WC_SH_TRI, WC_COUNT };
-
-__device__ __forceinline__ void persistentTraverseMixed(const DevScene &S, TravStack &stack, ShadowSource &ss, TraceSource &ts,
-                                                        uint32_t *wc /* LDS: WC_COUNT counters of this wave */) {
-    constexpr bool TYPED = false;
-    bool active = false, shadow = false;
-    uint32_t handle = INVALID_RAY;
-    V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
-    float mint = 0, maxt = 0;
-    int32_t cur = 0;
-    uint32_t nodeCur = 0, triCur = 0;
-    TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        const bool moreS = ss.more(), moreAny = moreS || ts.more();              /* wave-uniform */
-        if (idle && moreAny && (__popcll(idle) >= REFILL_LANES || idle == ~0ull)) {
-            const uint32_t h = moreS ? ss.assign(!active, idle) : ts.assign(!active, idle);
-            if (!active && h != INVALID_RAY) {
-                float rmint, rmaxt;
-                const bool ok = moreS ? ss.load(h, o, d, rmint, rmaxt) : ts.load(h, o, d, rmint, rmaxt);
-                if (ok) {
-                    atomicAdd(&wc[moreS ? WC_SH_RAYS : WC_RAYS], 1u);
-                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS)) {
-                        rcp = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
-                        cur = S.rootRef; stack.sp = 0; handle = h; active = true; shadow = moreS; nodeCur = triCur = 0;
-                    } else if (moreS) {
-                        ss.commit(h, false, res);
-                    } else {
-                        ts.commit(h, false, res);
-                    }
-                }
-            }
-        }
-        if (!__any(active)) { if (!(ss.more() || ts.more())) break; continue; }
-        if (active) {
-            for (;;) {
-                if (cur >= 0) {
-#if RAYS_SHADOW_UNSORTED
-                    if (shadow) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeCur)     /* (a wave is all-shadow or all-closest except while it changes phase) */
-                    else
-#endif
-                    NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeCur)
-                }
-                bool finished = false;
-                if (cur < 0 && cur != DONE_REF) {
-                    const uint32_t r = ~(uint32_t) cur, idx = r >> 3, left = r & 7u;
-                    LOAD_TRI(stack, S, idx, a, b, c)
-                    ++triCur;
-                    float tu, tv, tt;
-                    if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
-                        if (shadow) { res.prim = 0; finished = true; }
-                        else { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
-                    }
-                    cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
-                }
-                if (cur == DONE_REF) finished = true;
-                if (finished) {
-                    if (shadow) ss.commit(handle, res.prim != PHIP_NO_HIT, res);
-                    else ts.commit(handle, false, res);
-                    atomicAdd(&wc[shadow ? WC_SH_NODE : WC_NODE], nodeCur);
-                    atomicAdd(&wc[shadow ? WC_SH_TRI : WC_TRI], triCur);
-                    active = false;
-                    break;
-                }
-                if ((ss.more() || ts.more()) && __popcll(__ballot(1)) <= 64 - REFILL_LANES) break;     /* enough idle lanes: refill */
-            }
-        }
-    }
-}
-
-#ifndef RAYS_WAVES
-#define RAYS_WAVES TRACE_P_WAVES
-#endif
-__global__ __launch_bounds__(BLOCK, RAYS_WAVES) void k_rays_p(DevScene S, PathPool P, float4 *L) {
-    __shared__ uint32_t wcnt[BLOCK / 64][WC_COUNT];
-    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    if (threadIdx.x < (BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
-    ShadowSource ss{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
-    ss.skipEmpty();
-    TraceSource ts{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
-    persistentTraverseMixed(S, stk, ss, ts, wcnt[wave]);
-    if (__lane_id() == 0) {
-        const int rows[WC_COUNT] = { ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
-#pragma unroll
-        for (int i = 0; i < WC_COUNT; ++i) {
-            const uint32_t v = wcnt[wave][i];
-            if (v) P.stat[(size_t) rows[i] * P.nWaves + waveId] += v;
-        }
-    }
-}
-
-template <bool TYPED> __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, PathPool P) {
-    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
-    TraceSource src{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
-    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    persistentTraverse<false, TYPED>(S, stk, src, nodeVisits, triTests, rays);
-    waveStat(P, ST_CLOSEST_RAYS, waveId, rays);
-    waveStat(P, ST_NODE, waveId, nodeVisits);
-    waveStat(P, ST_TRI, waveId, triTests);
-}
-
-__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, PathPool P, float4 *L) {
-    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
-    ShadowSource src{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
-    src.skipEmpty();
-    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    persistentTraverse<true, true>(S, stk, src, nodeVisits, triTests, rays);      /* k_shadow_p serves the small scenes (big ones use k_rays_p) */
-    waveStat(P, ST_SHADOW_RAYS, waveId, rays);
-    waveStat(P, ST_SH_NODE, waveId, nodeVisits);
-    waveStat(P, ST_SH_TRI, waveId, triTests);
-}
-
-/* ======================================================================================
- *  Lane-cooperative traversal ("group" kernels): 8 lanes work on ONE ray over the 8-wide BVH.
- *  Lane k of a group fetches and slab-tests child k (the group's loads cover one contiguous
- *  256-byte node -> fully coalesced), or Wald-tests triangle k of a leaf.  A wave64 therefore
- *  walks 8 rays at a time; trip-count divergence is 8-way instead of 64-way, the per-ray stack
- *  (ref, tnear) lives in LDS at 1/8 of the per-lane cost, and a group that finishes its ray
- *  immediately pulls the next of the wave's 64 rays (wave-local dynamic fetch, no atomics).
- * ====================================================================================== */
-#define STACK8 40                       /* (ref, tnear) entries per ray in LDS; deeper ones spill to HBM */
-#define NONE_REF 0x7fffffff
-
-struct Stack8 {
-    uint2 *lds;             /* this group's STACK8 entries */
-    uint2 *spill;           /* this group's SPILL8 entries in HBM */
-    __device__ __forceinline__ void put(int i, uint2 v) { if (i < STACK8) lds[i] = v; else spill[i - STACK8] = v; }
-    __device__ __forceinline__ uint2 get(int i) const { return i < STACK8 ? lds[i] : spill[i - STACK8]; }
-};
-#define SPILL8 64
-
-template <bool SHADOW, typename Fetch, typename Commit>
-__device__ __forceinline__ void traverseWave8(const DevScene &S, uint2 *waveStack, uint2 *waveSpill, uint32_t nRays,
-                                              Fetch fetch, Commit commit, uint32_t &nodeVisits, uint32_t &triTests, uint32_t &raysTraced) {
-    const uint32_t lane = __lane_id(), sub = lane & 7u, grp = lane >> 3, grpBase = lane & ~7u;
-    Stack8 stk; stk.lds = waveStack + grp * STACK8; stk.spill = waveSpill + grp * SPILL8;
-    uint32_t nextRay = 0;                    /* wave-uniform */
-    bool needRay = true, active = false;
-    uint32_t ray = 0;
-    V3 o(0.0f), d(0.0f), rcp(0.0f), ordr(0.0f);
-    float mint = 0, maxt = 0;
-    int32_t cur = NONE_REF; int sp = 0;
-    float bestT = INFINITY, bestU = 0, bestV = 0; uint32_t bestPrim = PHIP_NO_HIT;
-    bool occluded = false;
-
-    for (;;) {
-        /* ---- hand out rays to the groups that need one (wave-uniform bookkeeping) ---- */
-        const unsigned long long want = __ballot(needRay && sub == 0);
-        if (want) {
-            if (needRay) {
-                ray = nextRay + (uint32_t) __popcll(want & ((1ull << grpBase) - 1ull));
-                needRay = false;
-                if (ray < nRays) {
-                    float rmint, rmaxt;
-                    if (fetch(ray, o, d, rmint, rmaxt)) {
-                        if (sub == 0) ++raysTraced;
-                        bestT = INFINITY; bestU = bestV = 0; bestPrim = PHIP_NO_HIT; occluded = false;
-                        if (clipToScene<SHADOW>(S, o, d, rmint, rmaxt, mint, maxt)) {
-                            rcp = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                            ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
-                            cur = S.rootRef8; sp = 0; active = true;
-                        } else {
-                            if (sub == 0) commit(ray, false, bestT, bestU, bestV, bestPrim);
-                            needRay = true;
-                        }
-                    } else {
-                        needRay = true;                      /* dead slot: take the next one */
-                    }
-                }
-            }
-            nextRay += (uint32_t) __popcll(want);
-        }
-        if (!__any(active || needRay)) break;
-        if (!active) continue;
-
-        /* ---- one traversal step per group ---- */
-        bool done = false;
-        if (cur == NONE_REF) {                               /* pop (with distance culling for closest hit) */
-            if (sp == 0) done = true;
-            else {
-                --sp;
-                const uint2 e = stk.get(sp);
-                if (SHADOW || pm_from_bits(e.y) <= maxt) cur = (int32_t) e.x;
-            }
-        } else if (cur >= 0) {                               /* inner node: lane `sub` tests child `sub` */
-            const float4 *p = S.nodes8 + (size_t) cur * 16 + sub * 2;
-            const float4 a = p[0], b = p[1];
-            if (sub == 0) ++nodeVisits;
-            const float x0 = fmaf(a.x, rcp.x, -ordr.x), x1 = fmaf(a.w, rcp.x, -ordr.x);
-            const float y0 = fmaf(a.y, rcp.y, -ordr.y), y1 = fmaf(b.x, rcp.y, -ordr.y);
-            const float z0 = fmaf(a.z, rcp.z, -ordr.z), z1 = fmaf(b.y, rcp.z, -ordr.z);
-            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint));
-            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt));
-            const bool hit = tn <= tf;
-            const uint32_t ref = pm_to_bits(b.z);
-            const uint32_t hm = (uint32_t) (__ballot(hit) >> grpBase) & 0xffu;
-            const int nh = __popc(hm);
-            if (nh == 0) {
-                cur = NONE_REF;
-            } else {
-                int rank;
-                if (SHADOW) {
-                    rank = __popc(hm & ((1u << sub) - 1u));  /* any order will do */
-                } else {
-                    const float key = hit ? tn : INFINITY;
-                    rank = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) {
-                        const float kj = __shfl(key, (int) (grpBase + j));
-                        rank += (kj < key || (kj == key && j < sub)) ? 1 : 0;
-                    }
-                }
-                if (hit && rank > 0) stk.put(sp + nh - 1 - rank, make_uint2(ref, pm_to_bits(tn)));
-                const uint32_t fm = (uint32_t) (__ballot(hit && rank == 0) >> grpBase) & 0xffu;
-                cur = (int32_t) __shfl(ref, (int) (grpBase + (uint32_t) (__ffs((int) fm) - 1)));
-                sp += nh - 1;
-            }
-        } else {                                             /* leaf: lane `sub` tests triangle `sub` */
-            const uint32_t r = ~(uint32_t) cur;
-            const uint32_t first = r >> 3, count = (r & 7u) + 1u;
-            bool hit = false; float tu = 0, tv = 0, tt = INFINITY; uint32_t prim = PHIP_NO_HIT;
-            if (sub < count) {
-                const float4 *tp = S.tris + 3 * (size_t) (first + sub);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                hit = waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt);
-                prim = pm_to_bits(c.z);
-            }
-            if (sub == 0) triTests += count;
-            const uint32_t hm = (uint32_t) (__ballot(hit) >> grpBase) & 0xffu;
-            if (hm) {
-                if (SHADOW) { occluded = true; done = true; }
-                else {
-                    float m = hit ? tt : INFINITY;
-                    m = fminf(m, __shfl_xor(m, 1)); m = fminf(m, __shfl_xor(m, 2)); m = fminf(m, __shfl_xor(m, 4));
-                    /* ties: the later-tested triangle wins (sahkdtree3.h:286-291 semantics, `t <= maxt`) */
-                    const uint32_t wm = (uint32_t) (__ballot(hit && tt == m) >> grpBase) & 0xffu;
-                    const int jw = (int) grpBase + (31 - __clz((int) wm));
-                    maxt = m; bestT = m;
-                    bestU = __shfl(tu, jw); bestV = __shfl(tv, jw); bestPrim = __shfl(prim, jw);
-                }
-            }
-            cur = NONE_REF;
-        }
-        if (done) {
-            if (sub == 0) commit(ray, occluded, bestT, bestU, bestV, bestPrim);
-            active = false; needRay = true;
-        }
-    }
-}
-
-__global__ __launch_bounds__(BLOCK, 6) void k_trace8(DevScene S, PathPool P) {
-    __shared__ uint2 lds[(BLOCK / 64) * 8 * STACK8];
-    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const uint32_t base = waveId * 64;
-    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    const uint32_t n = base < P.capacity ? min(64u, P.capacity - base) : 0u;
-    traverseWave8<false>(S, lds + wave * 8 * STACK8, P.spill8 + (size_t) waveId * 8 * SPILL8, n,
-        [&](uint32_t r, V3 &o, V3 &d, float &mint, float &maxt) -> bool {
-            const uint32_t slot = base + r;
-            if (!(P.state[slot] & F_ALIVE)) return false;
-            const float4 ro = P.rayO[slot], rd = P.rayD[slot];
-            o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
-            return true;
-        },
-        [&](uint32_t r, bool, float t, float u, float v, uint32_t prim) {
-            P.hit[base + r] = make_float4(t, u, v, pm_from_bits(prim));
-        }, nodeVisits, triTests, rays);
-    waveStat(P, ST_CLOSEST_RAYS, waveId, rays);
-    waveStat(P, ST_NODE, waveId, nodeVisits);
-    waveStat(P, ST_TRI, waveId, triTests);
-}
-
-__global__ __launch_bounds__(BLOCK, 6) void k_shadow8(DevScene S, PathPool P, float4 *L) {
-    __shared__ uint2 lds[(BLOCK / 64) * 8 * STACK8];
-    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const uint32_t count = P.shadowCount[blockIdx.x];
-    const uint32_t first = wave * 64;
-    if (first >= count) return;
-    const uint32_t n = min(64u, count - first);
-    const size_t base = (size_t) blockIdx.x * BLOCK + first;
-    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    traverseWave8<true>(S, lds + wave * 8 * STACK8, P.spill8 + (size_t) waveId * 8 * SPILL8, n,
-        [&](uint32_t r, V3 &o, V3 &d, float &mint, float &maxt) -> bool {
-            const float4 e0 = P.shadow[3 * (base + r)], e1 = P.shadow[3 * (base + r) + 1];
-            o = V3(e0.x, e0.y, e0.z); d = V3(e1.x, e1.y, e1.z); mint = PT_EPSILON; maxt = e0.w;
-            return true;
-        },
-        [&](uint32_t r, bool occluded, float, float, float, uint32_t) {
-            if (!occluded) {
-                const float4 e1 = P.shadow[3 * (base + r) + 1], e2 = P.shadow[3 * (base + r) + 2];
-                addRadiance(L, pm_to_bits(e1.w), e2);
-            }
-        }, nodeVisits, triTests, rays);
-    waveStat(P, ST_SHADOW_RAYS, waveId, rays);
-    waveStat(P, ST_SH_NODE, waveId, nodeVisits);
-    waveStat(P, ST_SH_TRI, waveId, triTests);
-}
-
-/* ======================================================================================
- *  kernels
- * ====================================================================================== */
-__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPool P) {
-    if (P.blockDead[blockIdx.x]) return;
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) slot * SPILL_DEPTH, stk);
-    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    if (slot < P.capacity) {
-        if (P.state[slot] & F_ALIVE) {
-            const float4 ro = P.rayO[slot], rd = P.rayD[slot];
-            const V3 o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
-            float mint, maxt;
-            TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
-            rays = 1;
-            if (clipToScene<false>(S, o, d, ro.w, rd.w, mint, maxt))
-                traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
-            P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
-        }
-    }
-    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    waveStat(P, ST_CLOSEST_RAYS, waveId, rays);
-    waveStat(P, ST_NODE, waveId, nodeVisits);
-    waveStat(P, ST_TRI, waveId, triTests);
-}
-
-__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathPool P, float4 *L) {
-    if (P.blockDead[blockIdx.x]) return;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
-    const uint32_t n = P.shadowCount[blockIdx.x];            /* entries of this block's slots */
-    uint32_t nodeVisits = 0, triTests = 0, rays = 0;
-    if (threadIdx.x < n) {
-        const size_t idx = (size_t) blockIdx.x * BLOCK + threadIdx.x;
-        const float4 e0 = P.shadow[3 * idx], e1 = P.shadow[3 * idx + 1], e2 = P.shadow[3 * idx + 2];
-        const V3 o(e0.x, e0.y, e0.z), d(e1.x, e1.y, e1.z);
-        float mint, maxt;
-        bool occluded = false;
-        TravResult r;
-        rays = 1;
-        if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt))
-            occluded = traverse<true>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
-        if (!occluded) {
-            addRadiance(L, pm_to_bits(e1.w), e2);
-        }
-    }
-    if ((threadIdx.x & ~63u) < n) {                          /* waves without entries have nothing to add */
-        const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
-        waveStat(P, ST_SHADOW_RAYS, waveId, rays);
-        waveStat(P, ST_SH_NODE, waveId, nodeVisits);
-        waveStat(P, ST_SH_TRI, waveId, triTests);
-    }
-}
-
-__device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
-    pdfA *= pdfA; pdfB *= pdfB;
-    return pdfA / (pdfA + pdfB);
-}
-
-#ifndef SHADE_WAVES
-#define SHADE_WAVES 4
-#endif
-#define EMITTER_LDS_FLOATS 1024      /* 4 KB */
-#define MATERIAL_LDS_MAX 48          /* 3.75 KB */
-#ifndef SHADE_WAVES_LEAN
-#define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
-#endif
-/* MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
-   normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
-template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
-    __shared__ uint32_t waveCnt[BLOCK / 64];
-    if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
-    /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
-       dependent lookups per NEE sample) and the materials */
-    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
-    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
-    if (emInLds) for (uint32_t i = threadIdx.x; i < S.emitterTabSize; i += BLOCK) ldsEm[i] = S.emitterTab[i];
-    if (matInLds) {
-        const uint32_t n4 = S.nMaterials * (uint32_t) (sizeof(DevMaterial) / 16);
-        for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) ((float4 *) ldsMat)[i] = ((const float4 *) S.materials)[i];
-    }
-    EmitterTab T; T.t = emInLds ? ldsEm : S.emitterTab; T.n = S.nEmitters; T.normalization = S.emitterNormalization;
-    const DevMaterial *materials = matInLds ? ldsMat : S.materials;
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    const bool inRange = slot < P.capacity;
-    /* all slot state is fetched up front, before the liveness test, so that the five 16-byte loads are
-       in flight together (the kernel is latency bound: 70 % of its wave cycles were s_waitcnt) */
-    const uint32_t lslot = inRange ? slot : 0u;
-    uint4 info = P.info[lslot];
-    info.w = P.state[lslot];
-    const float4 hit = P.hit[lslot];
-    const float4 rd = P.rayD[lslot];
-    float4 thr4 = P.thr[lslot];
-    const float2 mis = P.mis[lslot];
-    if (!inRange) info = make_uint4(0, 0, 0, 0);
-    __syncthreads();                                            /* LDS tables are complete */
-    bool alive = inRange && (info.w & F_ALIVE);
-    bool needNew = inRange && !alive && !(info.w & F_DEAD);
-    unsigned long long vertices = 0, done = 0;
-    bool pushShadow = false;
-    float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0;
-
-    if (alive) {
-        const uint32_t prim = pm_to_bits(hit.w);
-        const V3 rayD(rd.x, rd.y, rd.z);
-        V3 thr(thr4.x, thr4.y, thr4.z);
-        float eta = thr4.w;
-        uint32_t depth = info.w & DEPTH_MASK;
-        uint32_t flags = info.w & ~DEPTH_MASK;
-        const uint32_t id = info.x;
-        bool terminate = false;
-        V3 addL(0.0f); bool haveAdd = false;   /* radiance to add to L[id] (in reference order) */
-        float4 l = make_float4(0, 0, 0, 0);
-
-        if (prim == PHIP_NO_HIT) {
-            terminate = true;
-            if (S.envEmitter >= 0) {            /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
-                const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
-                const V3 value = rgb(em + EM_RADIANCE);
-                l = L[id];
-                if (flags & F_FIRST) {
-                    if (!rc.hideEmitters) { l.x += value.x; l.y += value.y; l.z += value.z; }   /* throughput is 1; alpha stays 0 */
-                    haveAdd = true;
-                } else {
-                    const float4 ro = P.rayO[slot];
-                    if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
-                        const float lumPdf = (!(flags & F_PREV_DELTA))
-                            ? pdfEmitterDirectDot(T, (uint32_t) S.envEmitter, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
-                        const V3 c = thr * value * miWeight(mis.x, lumPdf);
-                        l.x += c.x; l.y += c.y; l.z += c.z;
-                        haveAdd = true;
-                    }
-                }
-                if (haveAdd) L[id] = l;
-            }
-        } else {
-            Isect its;
-            fillIntersection(S, rayD, prim, hit.y, hit.z, hit.x, its);
-            /* L[id] is zero until the sample's first vertex writes it (the buffer is cleared per pass), and later
-               vertices only touch it when they hit an emitter: no unconditional 64-byte-sector read per vertex */
-            if (flags & F_FIRST) {
-                l.w = 1.0f;                     /* alpha, records.inl:117-144 */
-                haveAdd = true;
-            } else {
-                /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
-                if (its.emitter >= 0) {
-                    l = L[id];
-                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
-                    V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
-                    /* DirectSamplingRecord::setQuery (records.inl:170-178): n = shading normal, d = ray direction, dist = t */
-                    const float lumPdf = (!(flags & F_PREV_DELTA))
-                        ? pdfEmitterDirectDot(T, (uint32_t) its.emitter, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
-                    const V3 c = thr * value * miWeight(mis.x, lumPdf);
-                    l.x += c.x; l.y += c.y; l.z += c.z;
-                    haveAdd = true;
-                }
-                flags &= ~F_EMITTED;
-                if (depth++ >= (uint32_t) rc.rrDepth) {
-                    float q = smin(thr.maxc() * eta * eta, 0.95f);
-                    const U4 h = pcg4d(info.y, info.z, 2 + 2 * (depth - 2), rc.seed);
-                    if (u32ToFloat(h.x) >= q)
-                        terminate = true;
-                    else
-                        thr = thr / q;
-                }
-            }
-            flags &= ~F_FIRST;
-
-            /* ---- head of the loop for this vertex, path.cpp:135-165 ---- */
-            if (!terminate && !(depth <= (uint32_t) rc.maxDepth || rc.maxDepth < 0))
-                terminate = true;
-            if (!terminate) {
-                if (its.emitter >= 0 && (flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
-                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
-                    V3 le = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
-                    const V3 c = thr * le;
-                    l.x += c.x; l.y += c.y; l.z += c.z;
-                    haveAdd = true;
-                }
-                if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
-                    || (STRICT && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
-                    terminate = true;
-            }
-            V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
-            if (!terminate) {
-                const U4 h = pcg4d(info.y, info.z, 1 + 2 * (depth - 1), rc.seed);
-                /* ---- direct illumination sampling, path.cpp:172-200 ---- */
-                DirectRec dRec;
-                dRec.ref = its.p;
-                dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
-                dRec.pdf = 0; dRec.emitter = -1;
-                const BsdfCtx bctx = bsdfResolve(materials, its);
-                if (its.flags & TS_MF_SMOOTH) {
-                    V3 value = sampleEmitterDirect(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
-                    if (dRec.pdf != 0 && !value.isZero()) {
-                        const V3 wo = its.sh.toLocal(dRec.d);
-                        float bPdf;
-                        const V3 bsdfVal = bsdfEvalPdf<MM>(bctx, wo, bPdf);
-                        if (!bsdfVal.isZero() && (!STRICT || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
-                            const float weight = miWeight(dRec.pdf, bPdf);
-                            shC = thr * value * bsdfVal * weight;
-                            shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
-                            pushShadow = true;
-                        }
-                    }
-                }
-                /* ---- BSDF sampling, path.cpp:207-226 ---- */
-                BSDFSample bs;
-                const V3 bsdfWeight = bsdfSample<MM>(bctx, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
-                if (bsdfWeight.isZero()) {
-                    terminate = true;
-                } else {
-                    flags |= F_SCATTERED;
-                    const V3 wo = its.sh.toWorld(bs.wo);
-                    const float woDotGeoN = dot(its.geoN, wo);
-                    if (STRICT && woDotGeoN * cosTheta(bs.wo) <= 0) {
-                        terminate = true;
-                    } else {
-                        P.rayO[slot] = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
-                        P.rayD[slot] = make_float4(wo.x, wo.y, wo.z, INFINITY);
-                        thr = thr * bsdfWeight;
-                        eta *= bs.eta;
-                        P.thr[slot] = make_float4(thr.x, thr.y, thr.z, eta);
-                        P.mis[slot] = make_float2(bs.pdf, dot(wo, dRec.refN));
-                        flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
-                        flags = dRec.refN.isZero() ? (flags | F_REFN_ZERO) : (flags & ~F_REFN_ZERO);
-                    }
-                }
-            }
-            if (haveAdd) L[id] = l;
-            if (pushShadow) {   /* self-contained shadow-queue entry: survives the slot being recycled */
-                sh0 = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
-                sh1 = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
-                sh2 = make_float4(shC.x, shC.y, shC.z, 0.0f);
-            }
-        }
-        if (terminate) {
-            vertices = depth; done = 1;
-            needNew = true;
-        } else {
-            info.w = flags | depth;
-            P.state[slot] = info.w;
-        }
-    }
-
-    /* ---- shadow queue: compact this block's entries to the front of its own region (no global atomics) ---- */
-    uint32_t shadowTotal = 0;
-    {
-        const unsigned long long m = __ballot(pushShadow);
-        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) base += c; total += c; }
-        if (pushShadow) {
-            const size_t sidx = (size_t) blockIdx.x * BLOCK + base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-            P.shadow[3 * sidx] = sh0; P.shadow[3 * sidx + 1] = sh1; P.shadow[3 * sidx + 2] = sh2;
-        }
-        if (threadIdx.x == 0) P.shadowCount[blockIdx.x] = total;
-        shadowTotal = total;
-    }
-
-    /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183).
-       Sample ids [0, staticIds) follow a static schedule (slot s renders s, s + capacity, ... -- no global
-       counter in steady state).  The last part of the frame is handed out dynamically so that slots whose
-       paths happened to be short keep working until the frame is really finished: one atomicAdd per BLOCK
-       on one of DYN_SHARDS counters (block-aggregated through LDS; each shard owns a contiguous id range). ---- */
-    bool nowAlive = alive && !needNew;
-    unsigned long long newId = ~0ull;
-    bool wantDyn = false;
-    if (needNew) {
-        unsigned long long id = (info.w & F_FRESH) ? (unsigned long long) slot      /* first sample of this slot */
-                              : ((info.w & F_DYNAMIC) ? ~0ull : (unsigned long long) info.x + P.capacity);
-        for (;;) {
-            if (id >= rc.staticIds) { wantDyn = true; break; }
-            uint32_t px, py, k;
-            if (decodeId(rc, S.film, id, px, py, k)) { newId = id; break; }
-            id += P.capacity;       /* ids outside the crop window (edge blocks) are skipped */
-        }
-    }
-    bool dynamicId = false;
-    {
-        const unsigned long long m = __ballot(wantDyn);
-        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-        __syncthreads();                                   /* waveCnt is reused from the shadow compaction */
-        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) before += c; total += c; }
-        if (total) {                                       /* block-uniform */
-            __shared__ unsigned long long dynBase;
-            __shared__ uint32_t dynShard;
-            if (threadIdx.x == 0) {
-                uint32_t sh = (blockIdx.x + rc.blockShard[blockIdx.x]) % DYN_SHARDS;    /* blockShard = shards this block has seen run dry */
-                uint32_t dry = 0;
-                unsigned long long base = ~0ull;
-                for (int tries = 0; tries < DYN_SHARDS; ++tries) {
-                    const unsigned long long old = atomicAdd(rc.dynCounter + (size_t) sh * DYN_STRIDE, (unsigned long long) total);
-                    if (old < rc.shardIds) { base = old; break; }
-                    sh = (sh + 1) % DYN_SHARDS; ++dry;     /* this shard is used up: move on for good */
-                }
-                if (dry) rc.blockShard[blockIdx.x] += dry;
-                dynBase = base; dynShard = sh;
-            }
-            __syncthreads();
-            if (wantDyn) {
-                bool got = false;
-                if (dynBase != ~0ull) {
-                    const unsigned long long off = dynBase + before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-                    const unsigned long long id = rc.staticIds + (unsigned long long) dynShard * rc.shardIds + off;
-                    uint32_t px, py, k;
-                    if (off < rc.shardIds && id < rc.totalIds) {
-                        got = true;                        /* the id is consumed even if it lies outside the crop window */
-                        if (decodeId(rc, S.film, id, px, py, k)) { newId = id; dynamicId = true; }
-                    }
-                }
-                if (!got && dynBase == ~0ull) { info.w = F_DEAD; P.state[slot] = F_DEAD; }   /* all shards empty: slot dies */
-                else if (newId == ~0ull) { info.w = F_DYNAMIC; P.state[slot] = F_DYNAMIC; }                        /* try again next iteration */
-            }
-        }
-    }
-    if (newId != ~0ull) {
-        uint32_t px, py, k;
-        decodeId(rc, S.film, newId, px, py, k);
-        const uint32_t pixel = py * (uint32_t) S.film.width + px;
-        const U4 h = pcg4d(pixel, k, 0, rc.seed);
-        const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
-        V3 o, d; float mint, maxt;
-        cameraRay(S.cam, sx, sy, o, d, mint, maxt);
-        P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
-        P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
-        P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        P.mis[slot] = make_float2(0.0f, 0.0f);
-        info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
-        P.info[slot] = info;
-        P.state[slot] = info.w;
-        nowAlive = true;
-    }
-    const uint32_t waveId = slot >> 6;
-    /* a slot still waiting for a dynamic sample id counts as live for the termination test */
-    const bool live = nowAlive || (inRange && info.w == F_DYNAMIC);
-    /* the block retires once none of its slots will ever work again and its last shadow entries have been consumed
-       (this launch queued nothing, so shadowCount is 0): later launches of the pass return at the first line */
-    const bool retire = !__syncthreads_or(live ? 1 : 0) && shadowTotal == 0;
-    if (retire && threadIdx.x == 0) P.blockDead[blockIdx.x] = 1u;
-    if (inRange || (slot & ~63u) < P.capacity) {
-        waveStat(P, ST_VERTICES, waveId, vertices);
-        waveStat(P, ST_SAMPLES, waveId, done);
-        if (rc.countAlive || retire) waveStat(P, ST_ALIVE, waveId, live ? 1ull : 0ull, true);
-    }
-}
-
-/* sums the per-wave statistics: REDUCE_SPLIT blocks per counter row, rows [firstRow, firstRow + gridDim.x);
-   the totals must have been zeroed (one atomicAdd per block: 32 per row) */
-#define REDUCE_SPLIT 32
-__global__ void k_reduce_stats(PathPool P, Counters *C, int firstRow) {
-    __shared__ unsigned long long red[256];
-    const int row = firstRow + (int) blockIdx.x;
-    const unsigned long long *src = P.stat + (size_t) row * P.nWaves;
-    unsigned long long v = 0;
-    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < P.nWaves; i += 256 * REDUCE_SPLIT) v += src[i];
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if ((int) threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0 && red[0]) atomicAdd(&C->total[row], red[0]);
-}
-
-/* Film: one lane per crop pixel gathers every sample whose filter footprint covers it.  Restates
- * ImageBlock::put (imageblock.h:124-204) incl. the block-local coordinate arithmetic: a sample
- * taken in pixel (sx,sy) belongs to the render block whose origin is (sx,sy) rounded down to the
- * block size, and its weights are computed in that block's coordinate system. */
-__global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
-                                               int tilesX, float *out, int accumulate, unsigned long long *invalidCount) {
-    const DevFilm &F = S.film;
-    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= F.width || y >= F.height) return;
-    /* a sample of source pixel s lands at s + jitter - 0.5 in [s-0.5, s+0.5): it can reach x iff
-       s > x - radius - 0.5 and s <= x + radius + 0.5 */
-    const int sx0 = max((int) floorf((float) x - F.radius - 0.5f) + 1, 0), sx1 = min((int) floorf((float) x + F.radius + 0.5f), F.width - 1);
-    const int sy0 = max((int) floorf((float) y - F.radius - 0.5f) + 1, 0), sy1 = min((int) floorf((float) y + F.radius + 0.5f), F.height - 1);
-    float acc[5] = { 0, 0, 0, 0, 0 };
-    unsigned long long invalid = 0;
-    for (int sy = sy0; sy <= sy1; ++sy) {
-        for (int sx = sx0; sx <= sx1; ++sx) {
-            const int tx = sx >> rc.tileShift, ty = sy >> rc.tileShift;
-            const int32_t ts = tileSlot[ty * tilesX + tx];
-            if (ts < 0) continue;           /* that block belongs to another shard */
-            const int offX = tx << rc.tileShift, offY = ty << rc.tileShift;
-            const int bw = min(F.blockSize, F.width - offX) + 2 * F.border, bh = min(F.blockSize, F.height - offY) + 2 * F.border;
-            /* destination pixel in the source block's bitmap coordinates */
-            const int dx = x - (offX - F.border), dy = y - (offY - F.border);
-            if (dx < 0 || dy < 0 || dx >= bw || dy >= bh) continue;
-            const uint32_t m = spreadBits((uint32_t) (sx - offX)) | (spreadBits((uint32_t) (sy - offY)) << 1);
-            const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
-            for (uint32_t k = 0; k < rc.sppPass; ++k) {
-                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
-                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
-                const float posx = px - 0.5f - (float) (offX - F.border), posy = py - 0.5f - (float) (offY - F.border);
-                const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), bw - 1);
-                const int miny = max((int) ceilf(posy - F.radius), 0), maxy = min((int) floorf(posy + F.radius), bh - 1);
-                if (dx < minx || dx > maxx || dy < miny || dy > maxy) continue;
-                const unsigned long long id = (((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m;
-                const float4 v = L[id];
-                /* validity check of ImageBlock::put: reject non-finite / negative samples (imageblock.h:148-151) */
-                if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
-                    if (sx == x && sy == y) ++invalid;
-                    continue;
-                }
-                const float wx = F.table[min((int) fabsf(((float) dx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
-                const float wy = F.table[min((int) fabsf(((float) dy - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
-                const float w = wx * wy;
-                acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
-            }
-        }
-    }
-    float *o = out + ((size_t) y * F.width + x) * 5;
-    if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
-    else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
-    if (invalid) atomicAdd(invalidCount, invalid);
-}
-
-/* LDS-tiled film gather (filters with reach <= FILM_MAX_REACH pixels, i.e. every reference default): a block owns
- * 16x16 destination pixels.  Per sample index k the block first STAGES each of the (16+2R)^2 source pixels' sample
- * ONCE in LDS: radiance, the frame coordinates of the first pixel of its filter footprint and the separable filter
- * weights of ImageBlock::put (imageblock.h:124-204: footprint clipped to the bitmap of the render block the sample
- * belongs to, weights from the discretised table) -- weights outside the footprint are stored as 0, which adds
- * nothing.  Then every destination lane accumulates its (2R+1)^2 neighbours: two integer subtractions, two weight
- * reads, one product and five multiply-adds per neighbour.  Same arithmetic per (sample, pixel) pair as k_film;
- * only the order of the float additions differs. */
-#define FILM_MAX_REACH 4
-#define FILM_TILE 16
-template <int RMAX>
-__global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
-                                                     int tilesX, float *out, int accumulate, unsigned long long *invalidCount, int R) {
-    constexpr int TMAX = FILM_TILE + 2 * RMAX;
-    constexpr int NW = 2 * RMAX + 2;           /* weights per axis: floor(p + r) - ceil(p - r) + 1 <= 2r + 1 with r < RMAX + 0.5 */
-    __shared__ float4 sVal[TMAX * TMAX];       /* radiance rgb + alpha of the source pixel's k-th sample */
-    __shared__ int2 sOrg[TMAX * TMAX];         /* frame coordinates of weight [0] of the sample's footprint */
-    __shared__ float sWx[TMAX * TMAX * NW], sWy[TMAX * TMAX * NW];
-    __shared__ int4 sGeo[TMAX * TMAX];         /* (offX - border, offY - border, bw, bh) of the source pixel's render block */
-    __shared__ uint32_t sBase[TMAX * TMAX];    /* low word of the sample id of k = 0 (0xFFFFFFFF: pixel not rendered here) */
-    __shared__ float sTable[PHIP_FILTER_RESOLUTION + 1];
-    const DevFilm &F = S.film;
-    const int T = FILM_TILE + 2 * R;
-    const int x0 = blockIdx.x * FILM_TILE, y0 = blockIdx.y * FILM_TILE;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = x0 + lx, y = y0 + ly;
-    if (threadIdx.x <= PHIP_FILTER_RESOLUTION) sTable[threadIdx.x] = F.table[threadIdx.x];
-    /* per source pixel constants */
-    for (int i = threadIdx.x; i < T * T; i += BLOCK) {
-        const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
-        uint32_t base = 0xFFFFFFFFu; int4 g = make_int4(0, 0, 0, 0);
-        if (sx >= 0 && sy >= 0 && sx < F.width && sy < F.height) {
-            const int tx = sx >> rc.tileShift, ty = sy >> rc.tileShift;
-            const int32_t ts = tileSlot[ty * tilesX + tx];
-            if (ts >= 0) {
-                const int offX = tx << rc.tileShift, offY = ty << rc.tileShift;
-                g = make_int4(offX - F.border, offY - F.border, min(F.blockSize, F.width - offX) + 2 * F.border, min(F.blockSize, F.height - offY) + 2 * F.border);
-                base = (uint32_t) ts;                       /* id(k) = ((ts * sppPass + k) << 2*tileShift) | morton(pixel in block) */
-            }
-        }
-        sBase[i] = base; sGeo[i] = g;
-    }
-    __syncthreads();
-
-    float acc[5] = { 0, 0, 0, 0, 0 };
-    unsigned long long invalid = 0;
-    const bool inside = x < F.width && y < F.height;
-    /* the radiance of sample k + 1 is fetched while sample k is being gathered (the k loop is a chain of
-       barriers otherwise: global-load latency would be paid sppPass times in a row) */
-    constexpr int NSTAGE = (TMAX * TMAX + BLOCK - 1) / BLOCK;
-    float4 pre[NSTAGE];
-    auto fetch = [&](uint32_t k) {
-#pragma unroll
-        for (int n = 0; n < NSTAGE; ++n) {
-            const int i = (int) threadIdx.x + n * BLOCK;
-            pre[n] = make_float4(0, 0, 0, 0);
-            if (i < T * T && k < rc.sppPass) {
-                const uint32_t base = sBase[i];
-                if (base != 0xFFFFFFFFu) {
-                    const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
-                    const int4 g = sGeo[i];
-                    const uint32_t m = spreadBits((uint32_t) (sx - (g.x + F.border))) | (spreadBits((uint32_t) (sy - (g.y + F.border))) << 1);
-                    pre[n] = L[(((unsigned long long) base * rc.sppPass + k) << (2 * rc.tileShift)) | m];
-                }
-            }
-        }
-    };
-    fetch(0);
-    for (uint32_t k = 0; k < rc.sppPass; ++k) {
-#pragma unroll
-        for (int n = 0; n < NSTAGE; ++n) {
-            const int i = (int) threadIdx.x + n * BLOCK;
-            if (i >= T * T) break;
-            const uint32_t base = sBase[i];
-            float4 v = make_float4(0, 0, 0, 0);
-            int2 org = make_int2(0, 0);
-            float wx[NW], wy[NW];
-#pragma unroll
-            for (int j = 0; j < NW; ++j) { wx[j] = 0.0f; wy[j] = 0.0f; }
-            if (base != 0xFFFFFFFFu) {
-                const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
-                const int4 g = sGeo[i];
-                const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
-                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
-                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
-                const float posx = px - 0.5f - (float) g.x, posy = py - 0.5f - (float) g.y;   /* block-bitmap coordinates */
-                v = pre[n];
-                /* validity check of ImageBlock::put (imageblock.h:148-151) */
-                if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
-                    /* count each rejected sample once: by the block that owns its pixel */
-                    if (sx >= x0 && sx < x0 + FILM_TILE && sy >= y0 && sy < y0 + FILM_TILE) ++invalid;
-                    v = make_float4(0, 0, 0, 0);
-                } else {
-                    /* footprint and weights, imageblock.h:159-180 */
-                    const int uminx = (int) ceilf(posx - F.radius), uminy = (int) ceilf(posy - F.radius);
-                    const int minx = max(uminx, 0), maxx = min((int) floorf(posx + F.radius), g.z - 1);
-                    const int miny = max(uminy, 0), maxy = min((int) floorf(posy + F.radius), g.w - 1);
-                    org = make_int2(g.x + uminx, g.y + uminy);
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) {
-                        const int bx = uminx + j, by = uminy + j;
-                        if (bx >= minx && bx <= maxx) wx[j] = sTable[min((int) fabsf(((float) bx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
-                        if (by >= miny && by <= maxy) wy[j] = sTable[min((int) fabsf(((float) by - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
-                    }
-                }
-            }
-            sVal[i] = v; sOrg[i] = org;
-#pragma unroll
-            for (int j = 0; j < NW; ++j) { sWx[i * NW + j] = wx[j]; sWy[i * NW + j] = wy[j]; }
-        }
-        __syncthreads();
-        fetch(k + 1);
-        if (inside) {
-            for (int dyy = -R; dyy <= R; ++dyy) {
-                for (int dxx = -R; dxx <= R; ++dxx) {
-                    const int i = (ly + R + dyy) * T + (lx + R + dxx);
-                    const int2 org = sOrg[i];
-                    const int jx = x - org.x, jy = y - org.y;
-                    if ((unsigned) jx >= (unsigned) NW || (unsigned) jy >= (unsigned) NW) continue;
-                    const float w = sWx[i * NW + jx] * sWy[i * NW + jy];
-                    if (w == 0.0f) continue;                   /* outside the footprint (or a zero of the filter): adds nothing */
-                    const float4 v = sVal[i];
-                    acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (inside) {
-        float *o = out + ((size_t) y * F.width + x) * 5;
-        if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
-        else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
-    }
-    if (invalid) atomicAdd(invalidCount, invalid);
-}
-
-/* copy per-sample radiance out in [y][x][sample] order (tests) */
-__global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot, int tilesX,
-                                 float4 *out, uint32_t sppTotal) {
-    const DevFilm &F = S.film;
-    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t n = (size_t) F.width * F.height * rc.sppPass;
-    if (i >= n) return;
-    const uint32_t k = (uint32_t) (i % rc.sppPass);
-    const size_t p = i / rc.sppPass;
-    const int x = (int) (p % F.width), y = (int) (p / F.width);
-    const int tx = x >> rc.tileShift, ty = y >> rc.tileShift;
-    const int32_t ts = tileSlot[ty * tilesX + tx];
-    float4 v = make_float4(0, 0, 0, 0);
-    if (ts >= 0) {
-        const uint32_t m = spreadBits((uint32_t) (x - (tx << rc.tileShift))) | (spreadBits((uint32_t) (y - (ty << rc.tileShift))) << 1);
-        v = L[(((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m];
-    }
-    out[p * sppTotal + rc.sppFirst + k] = v;
-}
-
-/* standalone ray casts for phip_trace */
-__global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
-    const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + i * SPILL_DEPTH, stk);
-    uint32_t nodeVisits = 0, triTests = 0, shNodeVisits = 0, shTriTests = 0;
-    if (i < n) {
-        const phip_ray ry = rays[i];
-        const V3 o(ry.o[0], ry.o[1], ry.o[2]), d(ry.d[0], ry.d[1], ry.d[2]);
-        float mint, maxt;
-        if (hits) {
-            TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
-            if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
-            phip_hit h; h.t = r.t; h.u = r.u; h.v = r.v; h.prim = r.prim;
-            hits[i] = h;
-        }
-        if (occluded) {
-            TravResult r; bool occ = false;
-            if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                occ = traverse<true>(S, o, d, mint, maxt, stk, r, shNodeVisits, shTriTests);
-            occluded[i] = occ ? 1 : 0;
-        }
-    }
-    const uint32_t waveId = (uint32_t) (i >> 6);
-    waveStat(P, ST_NODE, waveId, nodeVisits);
-    waveStat(P, ST_TRI, waveId, triTests);
-    waveStat(P, ST_SH_NODE, waveId, shNodeVisits);
-    waveStat(P, ST_SH_TRI, waveId, shTriTests);
-}
+#include "k_pool.h"
+#include "k_traverse.h"
+#include "k_group8.h"
+#include "k_shade.h"
+#include "k_film.h"
 
 /* ======================================================================================
  *  host side
