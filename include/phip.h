@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PHIP_ABI_VERSION 1
+#define PHIP_ABI_VERSION 2
 
 typedef enum phip_status {
     PHIP_OK              =  0,
@@ -87,8 +87,8 @@ typedef struct phip_shape {
  * Emitters are listed in the order of Scene::getEmitters() (the selection PDF of scene.cpp:375-381 depends on
  * it).  At most one environment emitter (scene.cpp:510-513).  The bounding sphere of the constant emitter
  * is derived by the library exactly like ConstantBackgroundEmitter::createShape does (constant.cpp:67-72:
- * 1.5 x the bounding sphere of the kd-tree's box expanded by the sensor position). ---- */
-enum { PHIP_EMITTER_AREA = 0, PHIP_EMITTER_CONSTANT = 1 };
+ * 1.5 x the bounding sphere of the kd-tree's box expanded by the sensor position); `envmap` has the same sphere. ---- */
+enum { PHIP_EMITTER_AREA = 0, PHIP_EMITTER_CONSTANT = 1, PHIP_EMITTER_ENVMAP = 2 };
 typedef struct phip_emitter {
     float    radiance[3];
     float    sampling_weight;            /* Emitter::getSamplingWeight, default 1         */
@@ -115,6 +115,19 @@ typedef struct phip_film {
     float   filter_table[PHIP_FILTER_RESOLUTION + 1]; /* m_values[], last entry 0         */
 } phip_film;
 
+/* ---- `envmap` (src/emitters/envmap.cpp): latitude-longitude radiance map.  `texels` is MIP level 0 exactly as the
+ * reference stores it (MIPMap::getArray(): RGB, already rounded to half precision by the plugin) -- the illumination
+ * code reads only that level: sampleDirect / pdfDirect (envmap.cpp:516-632) and evalEnvironment for rays without
+ * differentials (envmap.cpp:380-394, MIPMap::evalBilinear, mipmap.h:575-596).  The filtered (EWA) lookup of directly
+ * visible background pixels (camera rays carry differentials, envmap.cpp:395-407) is NOT implemented: a render with an
+ * envmap needs hideEmitters (those pixels are then never evaluated, path.cpp:139-141) or PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND. */
+typedef struct phip_envmap {
+    const float *texels;                 /* height x width x 3 floats (RGB), row 0 = +Y pole; NULL: no envmap */
+    uint32_t width, height;
+    float    scale;                      /* 'scale' property                               */
+    float    to_world[16];               /* row-major emitter-to-world transform ('toWorld') */
+} phip_envmap;
+
 typedef struct phip_scene_desc {
     uint32_t abi_version;                /* PHIP_ABI_VERSION                              */
     uint32_t n_vertices;
@@ -130,6 +143,7 @@ typedef struct phip_scene_desc {
     const phip_emitter  *emitters;
     phip_camera camera;
     phip_film   film;
+    phip_envmap envmap;                  /* used by the emitter of type PHIP_EMITTER_ENVMAP */
 } phip_scene_desc;
 
 /* ---- integrator parameters: MonteCarloIntegrator (src/librender/integrator.cpp:190-225) ---- */
@@ -157,6 +171,7 @@ typedef struct phip_render_params {
 
 #define PHIP_FLAG_KERNEL_TIMING 1   /* bracket the kernels with hipEvents, fill phip_stats.*_ms */
 #define PHIP_FLAG_SAMPLE_BUFFER 2   /* keep per-sample radiance for phip_get_samples (tests)    */
+#define PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND 4   /* directly visible envmap pixels: unfiltered level-0 lookup instead of the reference's EWA filter (deviation!) */
 
 typedef struct phip_stats {
     uint64_t samples;                /* camera samples rendered by this call                  */

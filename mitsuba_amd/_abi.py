@@ -5,7 +5,7 @@ struct against the values the C side reports through phip_abi_sizeof().
 """
 import ctypes as C
 
-PHIP_ABI_VERSION = 1
+PHIP_ABI_VERSION = 2
 PHIP_FILTER_RESOLUTION = 31
 
 PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCELLED, PHIP_ERR_NOMEM = 0, -1, -2, -3, -4, -5
@@ -14,6 +14,7 @@ PHIP_MF_BECKMANN, PHIP_MF_GGX = 0, 1
 PHIP_SAMPLER_CTR = 0
 PHIP_FLAG_KERNEL_TIMING = 1
 PHIP_FLAG_SAMPLE_BUFFER = 2
+PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND = 4
 PHIP_NO_HIT = 0xFFFFFFFF
 
 
@@ -32,7 +33,7 @@ class phip_shape(C.Structure):
                 ("has_normals", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-PHIP_EMITTER_AREA, PHIP_EMITTER_CONSTANT = 0, 1
+PHIP_EMITTER_AREA, PHIP_EMITTER_CONSTANT, PHIP_EMITTER_ENVMAP = 0, 1, 2
 
 
 class phip_emitter(C.Structure):
@@ -53,6 +54,11 @@ class phip_film(C.Structure):
                 ("filter_table", C.c_float * (PHIP_FILTER_RESOLUTION + 1))]
 
 
+class phip_envmap(C.Structure):
+    _fields_ = [("texels", C.POINTER(C.c_float)), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("scale", C.c_float), ("to_world", C.c_float * 16)]
+
+
 class phip_scene_desc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_vertices", C.c_uint32),
                 ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
@@ -60,7 +66,7 @@ class phip_scene_desc(C.Structure):
                 ("n_shapes", C.c_uint32), ("shapes", C.POINTER(phip_shape)),
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(phip_material)),
                 ("n_emitters", C.c_uint32), ("emitters", C.POINTER(phip_emitter)),
-                ("camera", phip_camera), ("film", phip_film)]
+                ("camera", phip_camera), ("film", phip_film), ("envmap", phip_envmap)]
 
 
 class phip_render_params(C.Structure):

@@ -26,6 +26,7 @@
 #define PT_PI             3.14159265358979323846f
 #define PT_INV_PI         0.31830988618379067154f
 #define PT_INV_FOURPI     0.07957747154594766788f
+#define PT_INV_TWOPI      0.15915494309189533577f
 
 namespace pt {
 

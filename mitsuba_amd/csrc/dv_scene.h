@@ -56,12 +56,23 @@ struct DevFilm {
     float table[PHIP_FILTER_RESOLUTION + 1];
 };
 
+/* `envmap` emitter (src/emitters/envmap.cpp), illumination side: MIP level 0 as float4 texels, the marginal /
+   conditional CDFs over luminance * sin(theta) built by the host like EnvironmentMap::configure (envmap.cpp:262-328) */
+struct DevEnvMap {
+    const float4 *texels;                    /* w * h, rgb + pad */
+    const float *cdfRows, *cdfCols, *rowWeights;
+    int32_t w, h;                            /* w == 0: the environment emitter (if any) is not an envmap */
+    float scale, normalization, pixelSizeX, pixelSizeY;
+    float toWorld[9], toLocal[9];            /* 3x3 parts, row-major (Transform::operator()(Vector), transform.h:175-183) */
+};
+
 struct DevScene {
     const float4 *nodes; const float4 *nodes8; const float4 *tris; const float4 *triShade;
     const DevMaterial *materials; uint32_t nMaterials;
     const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;
-    int32_t envEmitter; float envCenter[3]; float envRadius;   /* constant environment emitter (or -1) and its m_sceneBSphere */
+    int32_t envEmitter; float envCenter[3]; float envRadius;   /* environment emitter (or -1) and its m_sceneBSphere */
+    DevEnvMap env;
     int32_t rootRef, rootRef8; uint32_t nTriangles;
     uint32_t stackDepth, nodeCache, triCache;   /* LDS staging plan of the traversal kernels */
     float sceneMin[3], sceneMax[3];
@@ -260,6 +271,103 @@ DV bool envFillDirectRecord(const DevScene &S, const V3 &ro, const V3 &rd) {
     return !(!envSphereIntersect(S, ro, rd, nearT, farT) || nearT > 0 || farT < 0);
 }
 
+/* ---------------- envmap.cpp ---------------- */
+DV float rgbLuminance(const V3 &s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }   /* spectrum.h:724-727 */
+DV float intervalToTent(float sample) {   /* warp.cpp:143-155 */
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; }
+    else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - sqrtf(sample));
+}
+DV V3 xform3(const float *m, const V3 &v) {
+    return V3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+/* MIPMap::evalTexel, mipmap.h:503-571, with bcu = ERepeat and bcv = EClamp (envmap.cpp:176-178) */
+DV V3 envTexel(const DevEnvMap &E, int x, int y) {
+    if (x < 0 || x >= E.w) { int r = x % E.w; x = (r < 0) ? r + E.w : r; }
+    if (y < 0 || y >= E.h) y = y < 0 ? 0 : E.h - 1;
+    const float4 t = E.texels[(size_t) y * E.w + x];
+    return V3(t.x, t.y, t.z);
+}
+DV V2 envDirToUV(const V3 &v) {
+    return V2(pm_atan2f(v.x, -v.z) * PT_INV_TWOPI, pm_acosf(smin(1.0f, smax(-1.0f, v.y))) * PT_INV_PI);
+}
+/* EnvironmentMap::evalEnvironment for a ray without differentials (envmap.cpp:380-394,408-409) = MIPMap::evalBilinear
+   on level 0 (mipmap.h:575-596) */
+DV V3 envmapEval(const DevEnvMap &E, const V3 &rayD) {
+    const V2 uv = envDirToUV(xform3(E.toLocal, rayD));
+    if (!(isfinite(uv.x) && isfinite(uv.y))) return V3(0.0f);
+    const float u = uv.x * E.w - 0.5f, v = uv.y * E.h - 0.5f;
+    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    const V3 value = envTexel(E, xPos, yPos) * dx2 * dy2 + envTexel(E, xPos, yPos + 1) * dx2 * dy1
+                   + envTexel(E, xPos + 1, yPos) * dx1 * dy2 + envTexel(E, xPos + 1, yPos + 1) * dx1 * dy1;
+    return value * E.scale;
+}
+/* EnvironmentMap::sampleReuse, envmap.cpp:657-662 (std::lower_bound over size + 1 entries) */
+DV uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
+    uint32_t lo = 0, len = size + 1;
+    while (len > 0) {
+        const uint32_t half = len >> 1, mid = lo + half;
+        if (cdf[mid] < sample) { lo = mid + 1; len = len - half - 1; } else len = half;
+    }
+    long idx = (long) lo - 1;
+    if (idx < 0) idx = 0;
+    uint32_t index = (uint32_t) idx;
+    if (index > size - 1) index = size - 1;
+    sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+DV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* bilinear patch shared by internalSampleDirection / internalPdfDirection (envmap.cpp:577-590, 616-631) */
+DV float envPatch(const DevEnvMap &E, float px, float py, V3 &value) {
+    const int xPos = (int) floorf(px), yPos = (int) floorf(py);
+    const float dx1 = px - xPos, dx2 = 1.0f - dx1, dy1 = py - yPos, dy2 = 1.0f - dy1;
+    const V3 value1 = envTexel(E, xPos, yPos) * dx2 * dy2 + envTexel(E, xPos + 1, yPos) * dx1 * dy2;
+    const V3 value2 = envTexel(E, xPos, yPos + 1) * dx2 * dy1 + envTexel(E, xPos + 1, yPos + 1) * dx1 * dy1;
+    value = value1 + value2;
+    return (rgbLuminance(value1) * E.rowWeights[clampi(yPos, 0, E.h - 1)] +
+            rgbLuminance(value2) * E.rowWeights[clampi(yPos + 1, 0, E.h - 1)]) * E.normalization;
+}
+/* envmap.cpp:567-600 */
+DV void envmapSampleDirection(const DevEnvMap &E, V2 sample, V3 &d, V3 &value, float &pdf) {
+    const uint32_t row = envSampleReuse(E.cdfRows, (uint32_t) E.h, sample.y);
+    const uint32_t col = envSampleReuse(E.cdfCols + (size_t) row * (E.w + 1), (uint32_t) E.w, sample.x);
+    const float px = (float) col + intervalToTent(sample.x), py = (float) row + intervalToTent(sample.y);
+    pdf = envPatch(E, px, py, value);
+    value = value * E.scale;
+    float sinPhi, cosPhi, sinTheta, cosTheta;
+    pm_sincosf(E.pixelSizeX * (px + 0.5f), &sinPhi, &cosPhi);
+    pm_sincosf(E.pixelSizeY * (py + 0.5f), &sinTheta, &cosTheta);
+    d = V3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= smax(fabsf(sinTheta), PT_EPSILON);
+}
+/* envmap.cpp:603-632 */
+DV float envmapPdfDirection(const DevEnvMap &E, const V3 &d) {
+    const V2 uv = envDirToUV(d);
+    if (!(isfinite(uv.x) && isfinite(uv.y))) return 0.0f;
+    V3 value;
+    const float p = envPatch(E, uv.x * E.w - 0.5f, uv.y * E.h - 0.5f, value);
+    const float sinTheta = safe_sqrt(1 - d.y * d.y);
+    return p / smax(fabsf(sinTheta), PT_EPSILON);
+}
+/* EnvironmentMap::sampleDirect, envmap.cpp:516-542 */
+DV V3 envmapSampleDirect(const DevScene &S, DirectRec &dRec, const V2 &sample) {
+    V3 value, d; float pdf;
+    envmapSampleDirection(S.env, sample, d, value, pdf);
+    const V3 rd = xform3(S.env.toWorld, d);
+    float nearT, farT;
+    if (value.isZero() || pdf == 0 || !envSphereIntersect(S, dRec.ref, rd, nearT, farT) || nearT >= 0 || farT <= 0) {
+        dRec.pdf = 0.0f;
+        return V3(0.0f);
+    }
+    dRec.pdf = pdf;
+    dRec.p = dRec.ref + rd * farT;
+    dRec.n = normalize(V3(S.envCenter[0], S.envCenter[1], S.envCenter[2]) - dRec.p);
+    dRec.dist = farT; dRec.d = rd; dRec.solidAngle = 1;
+    return value / pdf;
+}
+
 /* scene.cpp:828-852 without the visibility test (the shadow ray is traced by the wavefront),
    area.cpp:158-173.  Returns value (radiance/pdf/emPdf); dRec.pdf == 0 means "no sample". */
 DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRec, V2 sample) {
@@ -269,8 +377,12 @@ DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRe
     sample.x = (sample.x - T.t[index]) / (T.t[index + 1] - T.t[index]);
     const float *em = emitterRecord(T, index);
     V3 value;
-    if (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_CONSTANT) {
+    const uint32_t type = pm_to_bits(em[EM_TYPE]);
+    if (type == PHIP_EMITTER_CONSTANT) {
         value = constantSampleDirect(S, em, dRec, sample);
+        if (dRec.pdf == 0) return V3(0.0f);
+    } else if (type == PHIP_EMITTER_ENVMAP) {
+        value = envmapSampleDirect(S, dRec, sample);
         if (dRec.pdf == 0) return V3(0.0f);
     } else {
         shapeSampleDirect(S, T, em, dRec, sample);
@@ -290,11 +402,14 @@ DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRe
 /* scene.cpp:949-952, scene.h:848-850, area.cpp:175-182, shape.cpp:117-126 (solid-angle measure).
    The reference point enters only through dot(d, refN) and refN.isZero(): the wavefront stores those two
    (8 bytes with the BSDF pdf) instead of the normal when it spawns the ray. */
-DV float pdfEmitterDirectDot(const EmitterTab &T, uint32_t emitter, float dDotRefN, bool refNZero, float dDotN, float dist) {
+DV float pdfEmitterDirectDot(const DevScene &S, const EmitterTab &T, uint32_t emitter, const V3 &d, float dDotRefN, bool refNZero, float dDotN, float dist) {
     const float *em = emitterRecord(T, emitter);
+    const uint32_t type = pm_to_bits(em[EM_TYPE]);
     float pdf;
-    if (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_CONSTANT) {
+    if (type == PHIP_EMITTER_CONSTANT) {
         pdf = constantPdfDirect(dDotRefN, refNZero);
+    } else if (type == PHIP_EMITTER_ENVMAP) {
+        pdf = envmapPdfDirection(S.env, xform3(S.env.toLocal, d));        /* envmap.cpp:545-549, solid-angle measure */
     } else if (dDotRefN >= 0 && dDotN < 0) {
         float pdfPos = em[EM_INV_AREA];
         pdf = pdfPos * (dist * dist) / fabsf(dDotN);
@@ -303,8 +418,8 @@ DV float pdfEmitterDirectDot(const EmitterTab &T, uint32_t emitter, float dDotRe
     }
     return pdf * (em[EM_WEIGHT] * T.normalization);
 }
-DV float pdfEmitterDirect(const EmitterTab &T, const DirectRec &dRec) {
-    return pdfEmitterDirectDot(T, (uint32_t) dRec.emitter, dot(dRec.d, dRec.refN), dRec.refN.isZero(), dot(dRec.d, dRec.n), dRec.dist);
+DV float pdfEmitterDirect(const DevScene &S, const EmitterTab &T, const DirectRec &dRec) {
+    return pdfEmitterDirectDot(S, T, (uint32_t) dRec.emitter, dRec.d, dot(dRec.d, dRec.refN), dRec.refN.isZero(), dot(dRec.d, dRec.n), dRec.dist);
 }
 
 /* ======================================================================================

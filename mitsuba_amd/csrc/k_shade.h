@@ -69,7 +69,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
             terminate = true;
             if (S.envEmitter >= 0) {            /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
                 const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
-                const V3 value = rgb(em + EM_RADIANCE);
+                const V3 value = (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_ENVMAP) ? envmapEval(S.env, rayD) : rgb(em + EM_RADIANCE);
                 l = L[id];
                 if (flags & F_FIRST) {
                     if (!rc.hideEmitters) { l.x += value.x; l.y += value.y; l.z += value.z; }   /* throughput is 1; alpha stays 0 */
@@ -78,7 +78,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                     const float4 ro = P.rayO[slot];
                     if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
                         const float lumPdf = (!(flags & F_PREV_DELTA))
-                            ? pdfEmitterDirectDot(T, (uint32_t) S.envEmitter, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
+                            ? pdfEmitterDirectDot(S, T, (uint32_t) S.envEmitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
                         const V3 c = thr * value * miWeight(mis.x, lumPdf);
                         l.x += c.x; l.y += c.y; l.z += c.z;
                         haveAdd = true;
@@ -102,7 +102,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                     V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
                     /* DirectSamplingRecord::setQuery (records.inl:170-178): n = shading normal, d = ray direction, dist = t */
                     const float lumPdf = (!(flags & F_PREV_DELTA))
-                        ? pdfEmitterDirectDot(T, (uint32_t) its.emitter, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
+                        ? pdfEmitterDirectDot(S, T, (uint32_t) its.emitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
                     const V3 c = thr * value * miWeight(mis.x, lumPdf);
                     l.x += c.x; l.y += c.y; l.z += c.z;
                     haveAdd = true;

@@ -165,6 +165,7 @@ struct phip_scene {
                                         (PHIP_TRAVERSAL=group; measured 2-3x slower: too few rays in flight per CU) */
     DevBuf<DevMaterial> materials;
     DevBuf<float> emitterTab;
+    DevBuf<float4> envTexels; DevBuf<float> envCdfRows, envCdfCols, envRowWeights;     /* `envmap` emitter */
     DevScene dev;
     /* render-time buffers (grown on demand, reused between calls) */
     DevBuf<float4> rayO, rayD, hit, thr, shadow, L, sampleOut;
@@ -281,13 +282,14 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     /* emitters + selection pdf, scene.cpp:375-381 */
     std::vector<DevEmitter> ems(d.n_emitters);
-    int32_t envEmitter = -1;
+    int32_t envEmitter = -1; bool envIsMap = false;
     std::vector<float> ecdf(1, 0.0f);
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
         const phip_emitter &e = d.emitters[i];
-        if (e.type == PHIP_EMITTER_CONSTANT) {
+        if (e.type == PHIP_EMITTER_CONSTANT || e.type == PHIP_EMITTER_ENVMAP) {
             if (envEmitter >= 0) throw std::runtime_error("The scene may only contain one environment emitter");   /* scene.cpp:510-513 */
             envEmitter = (int32_t) i;
+            envIsMap = e.type == PHIP_EMITTER_ENVMAP;
         } else if (e.type != PHIP_EMITTER_AREA) throw std::runtime_error("unknown emitter type");
         else if (e.shape >= d.n_shapes || d.shapes[e.shape].emitter != (int32_t) i) throw std::runtime_error("emitter/shape back reference mismatch");
         memset(&ems[i], 0, sizeof(DevEmitter));
@@ -367,7 +369,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         float *r = tab.data() + ecdf.size() + (size_t) EM_STRIDE * i;
         for (int k = 0; k < 3; ++k) r[EM_RADIANCE + k] = ems[i].radiance[k];
         r[EM_WEIGHT] = ems[i].samplingWeight;
-        r[EM_TYPE] = pm_from_bits(isArea(i) ? (uint32_t) PHIP_EMITTER_AREA : (uint32_t) PHIP_EMITTER_CONSTANT);
+        r[EM_TYPE] = pm_from_bits(d.emitters[i].type);
         if (!isArea(i)) continue;
         const DevShape &sh = shapes[ems[i].shape];
         r[EM_FIRST_TRI] = pm_from_bits(sh.firstTri); r[EM_N_TRIS] = pm_from_bits(sh.nTris);
@@ -413,6 +415,52 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         const float radius = (center - V3(mx[0], mx[1], mx[2])).length();
         D.envCenter[0] = center.x; D.envCenter[1] = center.y; D.envCenter[2] = center.z;
         D.envRadius = std::max(PT_EPSILON, radius * 1.5f);
+    }
+    if (envIsMap) {
+        /* EnvironmentMap::configure, envmap.cpp:262-328: marginal / conditional CDFs over luminance * sin(theta) */
+        const phip_envmap &e = d.envmap;
+        if (!e.texels || e.width == 0 || e.height == 0) throw std::runtime_error("envmap emitter without texels");
+        if (std::max(e.width, e.height) > 0xFFFF) throw std::runtime_error("Environment maps images must be smaller than 65536 pixels in width and height");
+        const int w = (int) e.width, h = (int) e.height;
+        std::vector<float4> tex((size_t) w * h);
+        for (size_t i = 0; i < tex.size(); ++i) tex[i] = make_float4(e.texels[3 * i], e.texels[3 * i + 1], e.texels[3 * i + 2], 0.0f);
+        std::vector<float> cdfCols((size_t) (w + 1) * h), cdfRows((size_t) h + 1), rowWeights((size_t) h);
+        size_t colPos = 0, rowPos = 0;
+        float rowSum = 0.0f;
+        cdfRows[rowPos++] = 0;
+        for (int y = 0; y < h; ++y) {
+            float colSum = 0;
+            cdfCols[colPos++] = 0;
+            for (int x = 0; x < w; ++x) {
+                const float4 &t = tex[(size_t) y * w + x];
+                colSum += rgbLuminance(V3(t.x, t.y, t.z));
+                cdfCols[colPos++] = colSum;
+            }
+            const float norm = 1.0f / colSum;
+            for (int x = 1; x < w; ++x) cdfCols[colPos - x - 1] *= norm;
+            cdfCols[colPos - 1] = 1.0f;
+            float sn, cs; pm_sincosf((y + 0.5f) * PT_PI / h, &sn, &cs);
+            rowWeights[y] = sn;
+            rowSum += colSum * sn;
+            cdfRows[rowPos++] = rowSum;
+        }
+        const float norm = 1.0f / rowSum;
+        for (int y = 1; y < h; ++y) cdfRows[rowPos - y - 1] *= norm;
+        cdfRows[rowPos - 1] = 1.0f;
+        if (rowSum == 0) throw std::runtime_error("The environment map is completely black -- this is not allowed.");
+        if (!std::isfinite(rowSum)) throw std::runtime_error("The environment map contains an invalid floating point value (nan/inf) -- giving up.");
+        M4 tw, tl;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) tw.m[i][j] = e.to_world[4 * i + j];
+        if (!m4invert(tw, tl)) throw std::runtime_error("envmap toWorld is singular");
+        sc->envTexels.upload(tex.data(), tex.size());
+        sc->envCdfRows.upload(cdfRows.data(), cdfRows.size()); sc->envCdfCols.upload(cdfCols.data(), cdfCols.size());
+        sc->envRowWeights.upload(rowWeights.data(), rowWeights.size());
+        DevEnvMap &E = D.env;
+        E.texels = sc->envTexels.p; E.cdfRows = sc->envCdfRows.p; E.cdfCols = sc->envCdfCols.p; E.rowWeights = sc->envRowWeights.p;
+        E.w = w; E.h = h; E.scale = e.scale;
+        E.normalization = 1.0f / (rowSum * (2 * PT_PI / w) * (PT_PI / h));
+        E.pixelSizeX = 2 * PT_PI / w; E.pixelSizeY = PT_PI / h;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { E.toWorld[3 * i + j] = tw.m[i][j]; E.toLocal[3 * i + j] = tl.m[i][j]; }
     }
     D.rootRef = sc->bvh.rootRef; D.rootRef8 = sc->bvh.rootRef8; D.nTriangles = d.n_triangles;
     /* LDS staging plan: stack depth from the tree depth (3 pushes per BVH4 level), top-of-tree node cache
@@ -469,6 +517,9 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     if (p->rr_depth <= 0) throw std::invalid_argument("'rrDepth' must be set to a value greater than zero!");                       /* integrator.cpp:219-220 */
     if (p->max_depth <= 0 && p->max_depth != -1) throw std::invalid_argument("'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); /* :222-223 */
     if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
+    if (sc->dev.env.w > 0 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
+        throw std::invalid_argument("envmap: directly visible background needs the filtered (EWA) lookup of envmap.cpp:395-407, which is not "
+                                    "implemented: render with hideEmitters or PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
     const int bs = p->block_size > 0 ? p->block_size : 32;
     if (bs < 2 || bs > 128 || (bs & (bs - 1))) throw std::invalid_argument("block_size must be a power of two in [2,128] (mitsuba.cpp:233-239 allows 2..128)");
     const int shardCount = p->shard_count > 0 ? p->shard_count : 1;

@@ -74,6 +74,7 @@ public:
         rp.strict_normals = m_strictNormals; rp.hide_emitters = m_hideEmitters;
         rp.block_size = (int32_t) scene->getBlockSize();
         rp.sampler = PHIP_SAMPLER_CTR; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
+        if (m_envmap != NULL && !m_hideEmitters) rp.flags |= PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND;   /* warned about in flatten() */
 
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, size, film->getReconstructionFilter());
         block->setOffset(Point2i(0, 0));            /* crop-relative, like renderproc.cpp:160-173 */
@@ -103,6 +104,7 @@ private:
         std::vector<phip_shape> shapes; std::vector<phip_material> materials; std::vector<phip_emitter> emitters;
         std::map<const BSDF *, uint32_t> bsdfIds;
         std::map<const Shape *, uint32_t> shapeIds;
+        phip_envmap envmap; memset(&envmap, 0, sizeof(envmap));
         bool anyNormals = false;
 
         const ref_vector<Shape> &list = scene->getShapes();
@@ -150,8 +152,21 @@ private:
                 shapes[it->second].emitter = (int32_t) emitters.size();
             } else if (cls == "ConstantBackgroundEmitter") {
                 pe.type = PHIP_EMITTER_CONSTANT; pe.shape = 0xFFFFFFFFu;     /* the library derives m_sceneBSphere itself */
+            } else if (cls == "EnvironmentMap") {
+                /* MIP level 0 exactly as the plugin stores it (half precision, read back as float RGB): envmap.cpp:634-637 */
+                pe.type = PHIP_EMITTER_ENVMAP; pe.shape = 0xFFFFFFFFu;
+                ref<Bitmap> level0 = const_cast<Emitter *>(e)->getBitmap(Vector2i(0));
+                m_envmap = level0->convert(Bitmap::ERGB, Bitmap::EFloat32);
+                envmap.texels = m_envmap->getFloat32Data();
+                envmap.width = (uint32_t) m_envmap->getWidth(); envmap.height = (uint32_t) m_envmap->getHeight();
+                envmap.scale = e->getProperties().getFloat("scale", 1.0f);
+                const Matrix4x4 &tw = e->getWorldTransform()->eval(0).getMatrix();
+                for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) envmap.to_world[4 * r + c] = tw(r, c);
+                if (!m_hideEmitters)
+                    Log(EWarn, "path_hip: directly visible environment-map pixels are looked up without the EWA filter "
+                        "(PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND); use hideEmitters for exact agreement with 'path'");
             } else {
-                Log(EError, "path_hip: emitter \"%s\" is not supported (area, constant)", cls.c_str());
+                Log(EError, "path_hip: emitter \"%s\" is not supported (area, constant, envmap)", cls.c_str());
             }
             emitters.push_back(pe);
         }
@@ -163,6 +178,7 @@ private:
         d.n_shapes = (uint32_t) shapes.size(); d.shapes = shapes.data();
         d.n_materials = (uint32_t) materials.size(); d.materials = materials.data();
         d.n_emitters = (uint32_t) emitters.size(); d.emitters = emitters.data();
+        d.envmap = envmap;
 
         const Sensor *sensor = scene->getSensor();
         if (sensor->getClass()->getName() != "PerspectiveCameraImpl")
@@ -241,6 +257,7 @@ private:
     static std::vector<const BSDF *> getNestedBSDFs(const BSDF *bsdf);
 
     phip_scene *m_scene;
+    ref<Bitmap> m_envmap;            /* float RGB copy of the environment map's MIP level 0 (kept alive for phip_scene_create) */
     int m_device;
     ref<SamplingIntegrator> m_cpuPath;
 };

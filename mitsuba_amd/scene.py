@@ -119,6 +119,16 @@ class SceneBuilder:
                               "type": A.PHIP_EMITTER_CONSTANT})
         return len(self.emitters) - 1
 
+    def envmap(self, texels, scale=1.0, to_world=None, sampling_weight=1.0):
+        """<emitter type="envmap">: lat-long radiance map (src/emitters/envmap.cpp); `texels` = (H, W, 3) float RGB
+        (MIP level 0 as the reference stores it), `to_world` = 4x4 emitter-to-world (rotation)."""
+        t = np.ascontiguousarray(texels, dtype=np.float32)
+        assert t.ndim == 3 and t.shape[2] == 3
+        self._envmap = (t, float(scale), np.eye(4, dtype=np.float32) if to_world is None else np.asarray(to_world, np.float32).reshape(4, 4))
+        self.emitters.append({"radiance": (0.0, 0.0, 0.0), "weight": sampling_weight, "shape": 0xFFFFFFFF,
+                              "type": A.PHIP_EMITTER_ENVMAP})
+        return len(self.emitters) - 1
+
     def quad(self, p0, p1, p2, p3, material, facing=None, radiance=None):
         """Two triangles (0,1,2),(2,3,0) like Rectangle::createTriMesh (rectangle.cpp:170-203);
         if `facing` is given the winding is flipped so the face normal points that way."""
@@ -186,7 +196,14 @@ class SceneBuilder:
         d.n_materials, d.materials = len(self.materials), mats
         d.n_emitters, d.emitters = len(self.emitters), ems
         d.camera, d.film = self.camera, self.film
-        d._keep = (pos, nrm, idx, shapes, mats, ems)   # keep the buffers alive with the struct
+        env = getattr(self, "_envmap", None)
+        if env is not None:
+            t, scale, m = env
+            d.envmap.texels = t.ctypes.data_as(C.POINTER(C.c_float))
+            d.envmap.height, d.envmap.width = t.shape[0], t.shape[1]
+            d.envmap.scale = scale
+            d.envmap.to_world[:] = [float(v) for v in m.reshape(-1)]
+        d._keep = (pos, nrm, idx, shapes, mats, ems, env)   # keep the buffers alive with the struct
         return d
 
     @property

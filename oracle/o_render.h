@@ -26,58 +26,6 @@
 
 namespace orc {
 
-struct Mat4 {
-    Float m[4][4];
-    static Mat4 identity() { Mat4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = i == j ? 1.0f : 0.0f; return r; }
-    Mat4 operator*(const Mat4 &o) const { /* matrix.h:744-757 */
-        Mat4 r;
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) {
-                Float sum = 0;
-                for (int k = 0; k < 4; ++k) sum += m[i][k] * o.m[k][j];
-                r.m[i][j] = sum;
-            }
-        return r;
-    }
-    bool invert(Mat4 &target) const { /* matrix.inl:138-193 */
-        const int N = 4;
-        int indxc[N], indxr[N], ipiv[N];
-        memset(ipiv, 0, sizeof(ipiv));
-        memcpy(target.m, m, sizeof(m));
-        for (int i = 0; i < N; i++) {
-            int irow = -1, icol = -1;
-            Float big = 0;
-            for (int j = 0; j < N; j++) {
-                if (ipiv[j] != 1) {
-                    for (int k = 0; k < N; k++) {
-                        if (ipiv[k] == 0) {
-                            if (std::abs(target.m[j][k]) >= big) { big = std::abs(target.m[j][k]); irow = j; icol = k; }
-                        } else if (ipiv[k] > 1) return false;
-                    }
-                }
-            }
-            ++ipiv[icol];
-            if (irow != icol) for (int k = 0; k < N; ++k) std::swap(target.m[irow][k], target.m[icol][k]);
-            indxr[i] = irow; indxc[i] = icol;
-            if (target.m[icol][icol] == 0) return false;
-            Float pivinv = 1.f / target.m[icol][icol];
-            target.m[icol][icol] = 1.f;
-            for (int j = 0; j < N; j++) target.m[icol][j] *= pivinv;
-            for (int j = 0; j < N; j++) {
-                if (j != icol) {
-                    Float save = target.m[j][icol];
-                    target.m[j][icol] = 0;
-                    for (int k = 0; k < N; k++) target.m[j][k] -= target.m[icol][k] * save;
-                }
-            }
-        }
-        for (int j = N - 1; j >= 0; j--)
-            if (indxr[j] != indxc[j])
-                for (int k = 0; k < N; k++) std::swap(target.m[k][indxr[j]], target.m[k][indxc[j]]);
-        return true;
-    }
-};
-
 struct Transform { /* forward + tracked inverse, like mitsuba::Transform */
     Mat4 fwd, inv;
     static Transform translate(const Vec3 &v) {

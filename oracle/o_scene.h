@@ -17,6 +17,7 @@
 #pragma once
 #include "o_kdtree.h"
 #include "o_sfmt.h"
+#include "o_envmap.h"
 #include "../include/phip.h"
 #include <string>
 #include <stdexcept>
@@ -177,7 +178,8 @@ public:
     std::vector<phip_emitter> emitters;
     DiscreteDistribution emitterPDF;
     int envEmitter = -1;                 /* Scene::m_environmentEmitter (index into emitters) */
-    BSphere envSphere;                   /* ConstantBackgroundEmitter::m_sceneBSphere */
+    BSphere envSphere;                   /* ConstantBackgroundEmitter / EnvironmentMap::m_sceneBSphere */
+    EnvMap envmap;                       /* valid() iff the environment emitter is an `envmap` */
     KDTree kdtree;
     phip_camera camera;
     phip_film film;
@@ -227,14 +229,15 @@ public:
         kdtree.build(positions.data(), indices.data(), d.n_triangles, triShape.data(), triPrim.data());
         for (uint32_t i = 0; i < d.n_emitters; ++i) {
             if (emitters[i].type == PHIP_EMITTER_AREA) continue;
-            if (emitters[i].type != PHIP_EMITTER_CONSTANT) throw std::runtime_error("oracle: unknown emitter type");
+            if (emitters[i].type != PHIP_EMITTER_CONSTANT && emitters[i].type != PHIP_EMITTER_ENVMAP) throw std::runtime_error("oracle: unknown emitter type");
+            if (emitters[i].type == PHIP_EMITTER_ENVMAP) envmap.load(d.envmap);
             if (envEmitter >= 0) throw std::runtime_error("The scene may only contain one environment emitter");   /* scene.cpp:510-513 */
             envEmitter = (int) i;
         }
         if (envEmitter >= 0) {
             /* Scene::initializeBidirectional (scene.cpp:384-413): the scene box seen by createShape() is the
                kd-tree's (enlarged) box expanded by the sensor's translation bounds (track.cpp:79-83: the image of
-               the origin); constant.cpp:67-72: bounding sphere of that box (aabb.cpp:44-47), radius x 1.5 */
+               the origin); constant.cpp:67-72 = envmap.cpp:330-334: bounding sphere of that box (aabb.cpp:44-47), radius x 1.5 */
             AABB aabb = kdtree.aabb;
             const float *m = camera.to_world;
             Vec3 sp(m[3], m[7], m[11]);
@@ -380,12 +383,14 @@ public:
         dRec.measure = ESolidAngle;
     }
 
-    /* scene.h:910-913 + constant.cpp:254-256 */
-    Spectrum evalEnvironment(const Ray &) const {
-        return envEmitter >= 0 ? Spectrum(emitters[envEmitter].radiance) : Spectrum(0.0f);
+    /* scene.h:910-913 + constant.cpp:254-256 / envmap.cpp:380-409 (ray without differentials) */
+    Spectrum evalEnvironment(const Ray &ray) const {
+        if (envEmitter < 0) return Spectrum(0.0f);
+        if (envmap.valid()) return envmap.evalEnvironment(ray.d);
+        return Spectrum(emitters[envEmitter].radiance);
     }
 
-    /* constant.cpp:258-273; false = "internal error" (the path is terminated, path.cpp:242-243) */
+    /* constant.cpp:258-273 = envmap.cpp:354-370; false = "internal error" (the path is terminated, path.cpp:242-243) */
     bool fillDirectSamplingRecord(DirectSamplingRecord &dRec, const Ray &ray) const {
         Float nearT, farT;
         if (!envSphere.rayIntersect(ray.o, ray.d, nearT, farT) || nearT > 0 || farT < 0)
@@ -443,6 +448,36 @@ public:
             return 0.0f;
     }
 
+    /* envmap.cpp:516-542 */
+    Spectrum envmapSampleDirect(DirectSamplingRecord &dRec, const Vec2 &sample) const {
+        Spectrum value; Vec3 d; Float pdf;
+        envmap.internalSampleDirection(sample, d, value, pdf);
+        const Vec3 rd = EnvMap::xformVec(envmap.toWorld, d);
+        Float nearT, farT;
+        if (value.isZero() || pdf == 0 || !envSphere.rayIntersect(dRec.ref, rd, nearT, farT) || nearT >= 0 || farT <= 0) {
+            dRec.pdf = 0.0f;
+            return Spectrum(0.0f);
+        }
+        dRec.pdf = pdf;
+        dRec.p = dRec.ref + rd * farT;
+        dRec.n = normalize(envSphere.center - dRec.p);
+        dRec.dist = farT;
+        dRec.d = rd;
+        dRec.measure = ESolidAngle;
+        return value / pdf;
+    }
+
+    /* envmap.cpp:545-556 */
+    Float envmapPdfDirect(const DirectSamplingRecord &dRec) const {
+        Float pdfSA = envmap.internalPdfDirection(EnvMap::xformVec(envmap.toLocal, dRec.d));
+        if (dRec.measure == ESolidAngle)
+            return pdfSA;
+        else if (dRec.measure == EArea)
+            return pdfSA * absDot(dRec.d, dRec.n) / (dRec.dist * dRec.dist);
+        else
+            return 0.0f;
+    }
+
     /* area.cpp:158-173 */
     Spectrum areaSampleDirect(const phip_emitter &em, DirectSamplingRecord &dRec, const Vec2 &sample) const {
         shapeSampleDirect(shapes[em.shape], dRec, sample);
@@ -462,7 +497,8 @@ public:
         size_t index = emitterPDF.sampleReuse(sample.x, emPdf);
         const phip_emitter &em = emitters[index];
         Spectrum value = em.type == PHIP_EMITTER_CONSTANT ? constantSampleDirect(em, dRec, sample)
-                                                          : areaSampleDirect(em, dRec, sample);
+                       : em.type == PHIP_EMITTER_ENVMAP ? envmapSampleDirect(dRec, sample)
+                                                        : areaSampleDirect(em, dRec, sample);
         if (dRec.pdf != 0) {
             Ray ray(dRec.ref, dRec.d, ORC_EPSILON, dRec.dist * (1 - ORC_SHADOW_EPSILON));
             if (rayIntersectShadow(ray, pc))
@@ -481,6 +517,8 @@ public:
         Float pdf;
         if (em.type == PHIP_EMITTER_CONSTANT) {
             pdf = constantPdfDirect(dRec);
+        } else if (em.type == PHIP_EMITTER_ENVMAP) {
+            pdf = envmapPdfDirect(dRec);
         } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
             Float pdfPos = shapes[em.shape].invSurfaceArea;
             if (dRec.measure == ESolidAngle)

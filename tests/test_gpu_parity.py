@@ -316,3 +316,39 @@ def test_large_emitter_mesh_and_many_materials(gpu, oracle, gauss):
         P, T, N = S.sphere_mesh((60 + 45 * (i % 10), 40 + 60 * (i // 10), 420 + 8 * (i % 7)), 18.0, 10, 6)
         sb.mesh(P, T, m, normals=N if i % 2 else None)
     compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.999, maxDepth=6)
+
+
+def test_envmap_matches_oracle(gpu, oracle, phip, gauss):
+    """SURVEY 8(f) row 1, second half: the `envmap` emitter's illumination (envmap.cpp:516-632, 380-394)"""
+    from test_oracle_path import _sky, _rot
+    tex = _sky(96, 48)
+
+    def scene(to_world=None, weight=1.0, extra_light=False, res=(160, 96)):
+        sb = S.SceneBuilder()
+        floor = sb.diffuse((0.4, 0.45, 0.5))
+        mats = [sb.diffuse((0.7, 0.3, 0.2)), sb.twosided(sb.diffuse((0.2, 0.6, 0.3))),
+                sb.roughconductor(alpha=0.2, eta=S.CU_ETA, k=S.CU_K), sb.dielectric(1.5, 1.0)]
+        sb.quad((-6, 0, -6), (6, 0, -6), (6, 0, 6), (-6, 0, 6), floor, facing=(0, 1, 0))
+        for i, m in enumerate(mats):
+            P, T, N = S.sphere_mesh((-3 + 2 * i, 0.8, 0.5 * (i % 2)), 0.8, 24, 12)
+            sb.mesh(P, T, m, normals=N)
+        if extra_light:
+            sb.quad((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1), sb.diffuse((0, 0, 0)), facing=(0, -1, 0), radiance=(8, 8, 6))
+        sb.envmap(tex, scale=0.8, to_world=to_world, sampling_weight=weight)
+        sb.perspective((0, 3, -9), (0, 0.5, 0), (0, 1, 0), 40.0)
+        sb.hdrfilm(res[0], res[1], gauss)
+        return sb
+    same, r = compare_render(gpu, oracle, scene().desc(), 8, min_identical=0.999, maxDepth=8, hideEmitters=True)
+    print("envmap: identical %.6f rel L2 %.3e" % (same, r))
+    compare_render(gpu, oracle, scene(_rot((1, 0.3, 0.2), 70.0), 0.5, True).desc(), 8, min_identical=0.999, maxDepth=6, hideEmitters=True)
+    compare_render(gpu, oracle, scene(_rot((0, 1, 0), 200.0)).desc(), 4, min_identical=0.999, maxDepth=3, hideEmitters=True, strictNormals=True)
+    # directly visible background: refused unless the deviation is asked for
+    from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
+    gs = Scene(scene(res=(64, 40)).desc())
+    integ = PathHIP(maxDepth=4); film = HDRFilm(64, 40)
+    with pytest.raises(RuntimeError, match="hideEmitters"):
+        integ.render(gs, film, 2)
+    assert integ.render(gs, film, 2, flags=A.PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND)
+    osc = oracle.OracleScene(scene(res=(64, 40)).desc())
+    ofilm = osc.render(A.default_render_params(spp=2, max_depth=4, flags=A.PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))[0]
+    assert rel_l2(film.storage, ofilm) < 1e-5

@@ -154,6 +154,71 @@ def test_environment_validation(oracle, gauss):
     assert np.abs(img / np.array([0.25, 0.5, 1.0]) - 1).max() < 1e-5
 
 
+def _sky(w=64, h=32):
+    """procedural HDR lat-long map: blue-ish gradient, warm ground, a bright sun patch"""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    t = (y + 0.5) / h
+    sky = np.stack([0.2 + 0.3 * t, 0.3 + 0.4 * t, 0.9 - 0.5 * t], -1)
+    ground = np.stack([0.25 + 0 * t, 0.2 + 0 * t, 0.15 + 0 * t], -1)
+    tex = np.where((t < 0.5)[..., None], sky, ground).astype(np.float32)
+    sun = ((x - 0.7 * w) ** 2 + (y - 0.25 * h) ** 2) < (0.04 * w) ** 2
+    tex[sun] = (60.0, 50.0, 35.0)
+    return np.ascontiguousarray(tex)
+
+
+def _rot(axis, deg):
+    a = np.radians(deg); c, s_ = np.cos(a), np.sin(a)
+    x, y, z = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    R = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s_, x * z * (1 - c) + y * s_],
+                  [y * x * (1 - c) + z * s_, c + y * y * (1 - c), y * z * (1 - c) - x * s_],
+                  [z * x * (1 - c) - y * s_, z * y * (1 - c) + x * s_, c + z * z * (1 - c)]])
+    m = np.eye(4); m[:3, :3] = R
+    return m.astype(np.float32)
+
+
+def test_envmap_illumination(oracle, gauss):
+    """envmap.cpp: (1) a uniform map behaves like the constant emitter (rho * L on a convex diffuse surface);
+    (2) importance sampling and BSDF sampling estimate the same irradiance (MIS consistency: maxDepth=2 image from
+    emitter sampling alone == from both strategies, statistically); (3) toWorld rotates the illumination;
+    (4) directly visible pixels need hideEmitters or the explicit bilinear-background flag"""
+    rho, L = np.array([0.5, 0.25, 0.75], np.float32), np.array([1.0, 2.0, 3.0], np.float32)
+
+    def quad_scene(env, res=32):
+        sb = S.SceneBuilder(); m = sb.diffuse(tuple(rho))
+        sb.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), m, facing=(0, 0, -1))
+        env(sb)
+        sb.perspective((0, 0, -6), (0, 0, 0), (0, 1, 0), 45.0); sb.hdrfilm(res, res, gauss)
+        return sb
+    # (1)
+    sc = oracle.OracleScene(quad_scene(lambda sb: sb.envmap(np.tile(L, (16, 32, 1)).astype(np.float32))).desc())
+    f = sc.render(A.default_render_params(spp=512, max_depth=-1, hide_emitters=1))[0]
+    on = f[..., 3] / f[..., 4] > 0.999
+    assert np.abs(oracle.develop(f)[on].mean(axis=0) / (rho * L) - 1).max() < 0.01
+    assert (oracle.develop(f)[f[..., 3] == 0] == 0).all()                 # hidden background
+    with pytest.raises(RuntimeError, match="hideEmitters"):
+        sc.render(A.default_render_params(spp=1, max_depth=-1))
+    fb = sc.render(A.default_render_params(spp=2, max_depth=-1, flags=A.PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))[0]
+    assert np.abs(oracle.develop(fb)[fb[..., 3] == 0] / L - 1).max() < 1e-5
+    # (2) + (3): sun map; the quad faces -z.  Reference irradiance by brute-force quadrature over the map.
+    tex = _sky()
+    h, w, _ = tex.shape
+
+    def irradiance(n, R):
+        th = (np.arange(h) + 0.5) * np.pi / h; ph = (np.arange(w) + 0.5) * 2 * np.pi / w
+        T, P = np.meshgrid(th, ph, indexing="ij")
+        d = np.stack([np.sin(P) * np.sin(T), np.cos(T), -np.cos(P) * np.sin(T)], -1) @ R[:3, :3].T      # envmap.cpp:596-598, then toWorld
+        cosn = np.clip(d @ np.asarray(n, np.float64), 0, None)
+        dw = np.sin(T) * (np.pi / h) * (2 * np.pi / w)
+        return (tex.astype(np.float64) * (cosn * dw)[..., None]).sum(axis=(0, 1))
+    for R in (np.eye(4, dtype=np.float32), _rot((0, 1, 0), 140.0), _rot((1, 0.3, 0.2), 70.0)):
+        sc = oracle.OracleScene(quad_scene(lambda sb: sb.envmap(tex, scale=0.5, to_world=R), res=16).desc())
+        f = sc.render(A.default_render_params(spp=4096, max_depth=-1, hide_emitters=1))[0]
+        on = f[..., 3] / f[..., 4] > 0.999
+        got = oracle.develop(f)[on].mean(axis=0)
+        expect = rho / np.pi * 0.5 * irradiance((0, 0, -1), R)
+        assert np.abs(got / expect - 1).max() < 0.03, (got, expect)        # texel-centre quadrature vs bilinear map
+
+
 def test_sfmt_streams_agree_statistically_with_ctr_stream(oracle, gauss):
     """`independent` semantics (one SFMT19937 clone per worker, sequential consumption) and the
     counter-based parity stream estimate the same image"""
