@@ -118,14 +118,19 @@ typedef struct phip_film {
 /* ---- `envmap` (src/emitters/envmap.cpp): latitude-longitude radiance map.  `texels` is MIP level 0 exactly as the
  * reference stores it (MIPMap::getArray(): RGB, already rounded to half precision by the plugin) -- the illumination
  * code reads only that level: sampleDirect / pdfDirect (envmap.cpp:516-632) and evalEnvironment for rays without
- * differentials (envmap.cpp:380-394, MIPMap::evalBilinear, mipmap.h:575-596).  The filtered (EWA) lookup of directly
- * visible background pixels (camera rays carry differentials, envmap.cpp:395-407) is NOT implemented: a render with an
- * envmap needs hideEmitters (those pixels are then never evaluated, path.cpp:139-141) or PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND. */
+ * differentials (envmap.cpp:380-394, MIPMap::evalBilinear, mipmap.h:575-596).  Directly visible background pixels
+ * (camera rays carry differentials, envmap.cpp:395-407) use the EWA-filtered lookup of MIPMap::eval (mipmap.h:629-833)
+ * over the plugin's MIP pyramid: pass every level as the reference built and stored it (`levels`, sizes halve with
+ * max(1, (n+1)/2) down to 1x1, mipmap.h:182-192).  With n_levels <= 1 a render that shows the environment needs
+ * hideEmitters (those pixels are then never evaluated, path.cpp:139-141) or PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND. */
+#define PHIP_ENVMAP_MAX_LEVELS 17        /* images are smaller than 65536 pixels (envmap.cpp:163-165) */
 typedef struct phip_envmap {
-    const float *texels;                 /* height x width x 3 floats (RGB), row 0 = +Y pole; NULL: no envmap */
+    const float *texels;                 /* level 0: height x width x 3 floats (RGB), row 0 = +Y pole; NULL: no envmap */
     uint32_t width, height;
     float    scale;                      /* 'scale' property                               */
     float    to_world[16];               /* row-major emitter-to-world transform ('toWorld') */
+    uint32_t n_levels;                   /* 0 / 1: level 0 only; else the complete pyramid  */
+    const float *levels[PHIP_ENVMAP_MAX_LEVELS];   /* levels[l], l >= 1: RGB floats of level l ([0] is ignored) */
 } phip_envmap;
 
 typedef struct phip_scene_desc {

@@ -54,9 +54,13 @@ class phip_film(C.Structure):
                 ("filter_table", C.c_float * (PHIP_FILTER_RESOLUTION + 1))]
 
 
+PHIP_ENVMAP_MAX_LEVELS = 17
+
+
 class phip_envmap(C.Structure):
     _fields_ = [("texels", C.POINTER(C.c_float)), ("width", C.c_uint32), ("height", C.c_uint32),
-                ("scale", C.c_float), ("to_world", C.c_float * 16)]
+                ("scale", C.c_float), ("to_world", C.c_float * 16),
+                ("n_levels", C.c_uint32), ("levels", C.POINTER(C.c_float) * PHIP_ENVMAP_MAX_LEVELS)]
 
 
 class phip_scene_desc(C.Structure):

@@ -47,6 +47,7 @@ struct DevCamera {
     float s2c[16];      /* sampleToCamera */
     float c2w[12];      /* camera-to-world, top 3 rows */
     float nearClip, farClip, invResX, invResY;
+    float dx[3], dy[3]; /* position differentials on the near plane, perspective.cpp:159-163 */
 };
 
 struct DevFilm {
@@ -58,8 +59,17 @@ struct DevFilm {
 
 /* `envmap` emitter (src/emitters/envmap.cpp), illumination side: MIP level 0 as float4 texels, the marginal /
    conditional CDFs over luminance * sin(theta) built by the host like EnvironmentMap::configure (envmap.cpp:262-328) */
+/* MIP pyramid of the envmap (levels as the reference built them; consecutive in `texels`) + the EWA weight table */
+struct DevEnvLevels {
+    int32_t nLevels;                         /* 1: no pyramid */
+    int32_t lw[PHIP_ENVMAP_MAX_LEVELS], lh[PHIP_ENVMAP_MAX_LEVELS];
+    uint32_t offset[PHIP_ENVMAP_MAX_LEVELS]; /* first texel of the level */
+    float weightLut[64];                     /* mipmap.h:296-301 */
+};
+
 struct DevEnvMap {
-    const float4 *texels;                    /* w * h, rgb + pad */
+    const float4 *texels;                    /* level 0: w * h, rgb + pad; further levels follow */
+    const DevEnvLevels *levels;              /* read only by camera rays that miss the scene */
     const float *cdfRows, *cdfCols, *rowWeights;
     int32_t w, h;                            /* w == 0: the environment emitter (if any) is not an envmap */
     float scale, normalization, pixelSizeX, pixelSizeY;
@@ -304,6 +314,120 @@ DV V3 envmapEval(const DevEnvMap &E, const V3 &rayD) {
                    + envTexel(E, xPos + 1, yPos) * dx1 * dy2 + envTexel(E, xPos + 1, yPos + 1) * dx1 * dy1;
     return value * E.scale;
 }
+/* ---- filtered lookup for rays with differentials (camera rays): MIPMap::eval, mipmap.h:629-712, 780-833 ---- */
+DV V3 envTexelL(const DevEnvMap &E, const DevEnvLevels &Lv, int level, int x, int y) {
+    const int sw = Lv.lw[level], sh = Lv.lh[level];
+    if (x < 0 || x >= sw) { int r = x % sw; x = (r < 0) ? r + sw : r; }
+    if (y < 0 || y >= sh) y = y < 0 ? 0 : sh - 1;
+    const float4 t = E.texels[(size_t) Lv.offset[level] + (size_t) y * sw + x];
+    return V3(t.x, t.y, t.z);
+}
+DV V3 envBoxL(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:566-569 */
+    return envTexelL(E, Lv, level, (int) floorf(uv.x * Lv.lw[level]), (int) floorf(uv.y * Lv.lh[level]));
+}
+DV V3 envBilinearL(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:575-596 */
+    if (!(isfinite(uv.x) && isfinite(uv.y))) return V3(0.0f);
+    if (level >= Lv.nLevels) return envBoxL(E, Lv, Lv.nLevels - 1, uv);
+    const float u = uv.x * Lv.lw[level] - 0.5f, v = uv.y * Lv.lh[level] - 0.5f;
+    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    return envTexelL(E, Lv, level, xPos, yPos) * dx2 * dy2 + envTexelL(E, Lv, level, xPos, yPos + 1) * dx2 * dy1
+         + envTexelL(E, Lv, level, xPos + 1, yPos) * dx1 * dy2 + envTexelL(E, Lv, level, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+DV float mtsLog2(float value) {   /* math.cpp:103-106 */
+    const float invLn2 = 1.0f / pm_logf(2.0f);
+    return pm_logf(value) * invLn2;
+}
+DV V3 envEWA(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv, float A, float B, float C) {   /* mipmap.h:780-833 */
+    if (!isfinite(A + B + C + uv.x + uv.y)) return V3(0.0f);
+    if (level >= Lv.nLevels) return envBoxL(E, Lv, Lv.nLevels - 1, uv);
+    const float u = uv.x * Lv.lw[level] - 0.5f;
+    const float v = uv.y * Lv.lh[level] - 0.5f;
+    const float ratioX = (float) Lv.lw[level] / (float) Lv.lw[0], ratioY = (float) Lv.lh[level] / (float) Lv.lh[0];
+    A /= ratioX * ratioX;
+    B /= ratioX * ratioY;
+    C /= ratioY * ratioY;
+    const float invDet = 1.0f / (-B * B + 4.0f * A * C),
+                deltaU = 2.0f * sqrtf(C * invDet),
+                deltaV = 2.0f * sqrtf(A * invDet);
+    const int u0 = (int) ceilf(u - deltaU), u1 = (int) floorf(u + deltaU);
+    const int v0 = (int) ceilf(v - deltaV), v1 = (int) floorf(v + deltaV);
+    const float As = A * 64, Bs = B * 64, Cs = C * 64;
+    V3 result(0.0f);
+    float denominator = 0.0f;
+    const float ddq = 2 * As, uu0 = (float) u0 - u;
+    for (int vt = v0; vt <= v1; ++vt) {
+        const float vv = (float) vt - v;
+        float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv;
+        float dq = As * (2 * uu0 + 1) + Bs * vv;
+        for (int ut = u0; ut <= u1; ++ut) {
+            if (q < 64.0f) {
+                const uint32_t qi = (uint32_t) q;
+                if (qi < 64) {
+                    const float weight = Lv.weightLut[(int) q];
+                    result = result + envTexelL(E, Lv, level, ut, vt) * weight;
+                    denominator += weight;
+                }
+            }
+            q += dq;
+            dq += ddq;
+        }
+    }
+    if (denominator == 0) return envBilinearL(E, Lv, level, uv);
+    return result / denominator;
+}
+DV V3 envFiltered(const DevEnvMap &E, const DevEnvLevels &Lv, const V2 &uv, const V2 &d0, const V2 &d1) {   /* mipmap.h:629-712, EEWA, maxAnisotropy 10 */
+    const float maxAnisotropy = 10.0f;
+    const float du0 = d0.x * Lv.lw[0], dv0 = d0.y * Lv.lh[0], du1 = d1.x * Lv.lw[0], dv1 = d1.y * Lv.lh[0];
+    float A = dv0 * dv0 + dv1 * dv1,
+          B = -2.0f * (du0 * dv0 + du1 * dv1),
+          C = du0 * du0 + du1 * du1,
+          F = A * C - B * B * 0.25f;
+    const float root = hypot2(A - C, B),
+                Aprime = 0.5f * (A + C - root),
+                Cprime = 0.5f * (A + C + root),
+                majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0;
+    float minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
+    if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+        const float level = mtsLog2(smax(majorRadius, PT_EPSILON));
+        const int ilevel = (int) floorf(level);
+        if (ilevel < 0) return envBilinearL(E, Lv, 0, uv);
+        const float a = level - ilevel;
+        return envBilinearL(E, Lv, ilevel, uv) * (1.0f - a) + envBilinearL(E, Lv, ilevel + 1, uv) * a;
+    }
+    if (minorRadius * maxAnisotropy < majorRadius) {
+        minorRadius = majorRadius / maxAnisotropy;
+        const float theta = 0.5f * pm_atanf(B / (A - C));
+        float sinTheta, cosTheta;
+        pm_sincosf(theta, &sinTheta, &cosTheta);
+        const float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius,
+                    sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
+        A = a2 * cosTheta2 + b2 * sinTheta2;
+        B = (a2 - b2) * sin2Theta;
+        C = a2 * sinTheta2 + b2 * cosTheta2;
+        F = a2 * b2;
+    }
+    const float scl = 1.0f / F;
+    A *= scl; B *= scl; C *= scl;
+    const float level = smax(0.0f, mtsLog2(minorRadius));
+    const int ilevel = (int) level;
+    const float a = level - ilevel;
+    if (majorRadius < 1 || !(A > 0 && C > 0))
+        return envBilinearL(E, Lv, ilevel, uv);
+    return envEWA(E, Lv, ilevel, uv, A, B, C) * (1.0f - a) + envEWA(E, Lv, ilevel + 1, uv, A, B, C) * a;
+}
+/* EnvironmentMap::evalEnvironment for a ray WITH differentials (envmap.cpp:380-409) */
+DV V3 envmapEvalDiff(const DevEnvMap &E, const V3 &rayD, const V3 &rxDirection, const V3 &ryDirection) {
+    const DevEnvLevels &Lv = *E.levels;
+    const V3 v = xform3(E.toLocal, rayD);
+    const V2 uv = envDirToUV(v);
+    const V3 dvdx = xform3(E.toLocal, rxDirection) - v, dvdy = xform3(E.toLocal, ryDirection) - v;
+    const float t1 = PT_INV_TWOPI / (v.x * v.x + v.z * v.z),
+                t2 = -PT_INV_PI / smax(safe_sqrt(1.0f - v.y * v.y), PT_EPSILON);
+    const V2 dudx(t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y), dudy(t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y);
+    return envFiltered(E, Lv, uv, dudx, dudy) * E.scale;
+}
+
 /* EnvironmentMap::sampleReuse, envmap.cpp:657-662 (std::lower_bound over size + 1 entries) */
 DV uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
     uint32_t lo = 0, len = size + 1;
@@ -370,18 +494,19 @@ DV V3 envmapSampleDirect(const DevScene &S, DirectRec &dRec, const V2 &sample) {
 
 /* scene.cpp:828-852 without the visibility test (the shadow ray is traced by the wavefront),
    area.cpp:158-173.  Returns value (radiance/pdf/emPdf); dRec.pdf == 0 means "no sample". */
-DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRec, V2 sample) {
+/* ENV = false compiles the environment-emitter branches out (scenes without one: most of them) */
+template <bool ENV> DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRec, V2 sample) {
     if (T.n == 0) { dRec.pdf = 0; return V3(0.0f); }
     uint32_t index = cdfSample(T.t, T.n, sample.x);
     float emPdf = T.t[index + 1] - T.t[index];
     sample.x = (sample.x - T.t[index]) / (T.t[index + 1] - T.t[index]);
     const float *em = emitterRecord(T, index);
     V3 value;
-    const uint32_t type = pm_to_bits(em[EM_TYPE]);
-    if (type == PHIP_EMITTER_CONSTANT) {
+    const uint32_t type = ENV ? pm_to_bits(em[EM_TYPE]) : (uint32_t) PHIP_EMITTER_AREA;
+    if (ENV && type == PHIP_EMITTER_CONSTANT) {
         value = constantSampleDirect(S, em, dRec, sample);
         if (dRec.pdf == 0) return V3(0.0f);
-    } else if (type == PHIP_EMITTER_ENVMAP) {
+    } else if (ENV && type == PHIP_EMITTER_ENVMAP) {
         value = envmapSampleDirect(S, dRec, sample);
         if (dRec.pdf == 0) return V3(0.0f);
     } else {
@@ -402,13 +527,13 @@ DV V3 sampleEmitterDirect(const DevScene &S, const EmitterTab &T, DirectRec &dRe
 /* scene.cpp:949-952, scene.h:848-850, area.cpp:175-182, shape.cpp:117-126 (solid-angle measure).
    The reference point enters only through dot(d, refN) and refN.isZero(): the wavefront stores those two
    (8 bytes with the BSDF pdf) instead of the normal when it spawns the ray. */
-DV float pdfEmitterDirectDot(const DevScene &S, const EmitterTab &T, uint32_t emitter, const V3 &d, float dDotRefN, bool refNZero, float dDotN, float dist) {
+template <bool ENV> DV float pdfEmitterDirectDot(const DevScene &S, const EmitterTab &T, uint32_t emitter, const V3 &d, float dDotRefN, bool refNZero, float dDotN, float dist) {
     const float *em = emitterRecord(T, emitter);
-    const uint32_t type = pm_to_bits(em[EM_TYPE]);
+    const uint32_t type = ENV ? pm_to_bits(em[EM_TYPE]) : (uint32_t) PHIP_EMITTER_AREA;
     float pdf;
-    if (type == PHIP_EMITTER_CONSTANT) {
+    if (ENV && type == PHIP_EMITTER_CONSTANT) {
         pdf = constantPdfDirect(dDotRefN, refNZero);
-    } else if (type == PHIP_EMITTER_ENVMAP) {
+    } else if (ENV && type == PHIP_EMITTER_ENVMAP) {
         pdf = envmapPdfDirection(S.env, xform3(S.env.toLocal, d));        /* envmap.cpp:545-549, solid-angle measure */
     } else if (dDotRefN >= 0 && dDotN < 0) {
         float pdfPos = em[EM_INV_AREA];
@@ -419,7 +544,7 @@ DV float pdfEmitterDirectDot(const DevScene &S, const EmitterTab &T, uint32_t em
     return pdf * (em[EM_WEIGHT] * T.normalization);
 }
 DV float pdfEmitterDirect(const DevScene &S, const EmitterTab &T, const DirectRec &dRec) {
-    return pdfEmitterDirectDot(S, T, (uint32_t) dRec.emitter, dRec.d, dot(dRec.d, dRec.refN), dRec.refN.isZero(), dot(dRec.d, dRec.n), dRec.dist);
+    return pdfEmitterDirectDot<true>(S, T, (uint32_t) dRec.emitter, dRec.d, dot(dRec.d, dRec.refN), dRec.refN.isZero(), dot(dRec.d, dRec.n), dRec.dist);
 }
 
 /* ======================================================================================
@@ -706,6 +831,21 @@ DV float bsdfPdf(const DevScene &S, const DevMaterial &M, V3 wi, V3 wo) {
 }
 DV V3 bsdfSample(const DevScene &S, const DevMaterial &M, V3 wi, const V2 &smp, BSDFSample &bs) {
     return bsdfSample<MM_ALL>(bsdfResolve(S, M, wi), smp, bs);
+}
+
+/* the differential directions of perspective.cpp:293-294 for the sample (sx, sy), before scaleDifferential */
+DV void cameraRayDifferentials(const DevCamera &c, float sx, float sy, V3 &rx, V3 &ry) {
+    const float px = sx * c.invResX, py = sy * c.invResY, pz = 0.0f;
+    const float *m = c.s2c;
+    float x = m[0] * px + m[1] * py + m[2] * pz + m[3];
+    float y = m[4] * px + m[5] * py + m[6] * pz + m[7];
+    float z = m[8] * px + m[9] * py + m[10] * pz + m[11];
+    float w = m[12] * px + m[13] * py + m[14] * pz + m[15];
+    const V3 nearP = (w == 1.0f) ? V3(x, y, z) : V3(x, y, z) / w;
+    const V3 a = normalize(nearP + V3(c.dx[0], c.dx[1], c.dx[2])), b = normalize(nearP + V3(c.dy[0], c.dy[1], c.dy[2]));
+    const float *t = c.c2w;
+    rx = V3(t[0] * a.x + t[1] * a.y + t[2] * a.z, t[4] * a.x + t[5] * a.y + t[6] * a.z, t[8] * a.x + t[9] * a.y + t[10] * a.z);
+    ry = V3(t[0] * b.x + t[1] * b.y + t[2] * b.z, t[4] * b.x + t[5] * b.y + t[6] * b.z, t[8] * b.x + t[9] * b.y + t[10] * b.z);
 }
 
 /* perspective.cpp:271-297 */

@@ -62,6 +62,8 @@ struct RenderConst {
     uint32_t nLocalTiles;
     int maxDepth, rrDepth, strictNormals, hideEmitters;
     uint32_t seed;
+    float diffScaleFactor;            /* 1 / sqrt(spp) of the whole render: RayDifferential::scaleDifferential, integrator.cpp:144-145,181 */
+    uint32_t envFiltered;             /* camera rays that miss use the envmap's EWA lookup (pyramid present) */
     const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
     uint32_t countAlive;              /* this iteration records the number of live slots */
     unsigned long long staticIds;     /* ids [0, staticIds) follow the static slot schedule, the rest is handed out dynamically */

@@ -17,9 +17,9 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
 #endif
-/* MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
+/* ENV: the scene has an environment emitter (constant / envmap); MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
    normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
-template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+template <int MM, bool STRICT, bool ENV> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
@@ -67,18 +67,32 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
 
         if (prim == PHIP_NO_HIT) {
             terminate = true;
-            if (S.envEmitter >= 0) {            /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
+            if (ENV && S.envEmitter >= 0) {     /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
                 const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
                 const V3 value = (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_ENVMAP) ? envmapEval(S.env, rayD) : rgb(em + EM_RADIANCE);
                 l = L[id];
                 if (flags & F_FIRST) {
-                    if (!rc.hideEmitters) { l.x += value.x; l.y += value.y; l.z += value.z; }   /* throughput is 1; alpha stays 0 */
+                    if (!rc.hideEmitters) {                                                    /* throughput is 1; alpha stays 0 */
+                        V3 bg = value;
+                        if (rc.envFiltered) {
+                            /* the camera ray is the one ray with differentials: filtered lookup, envmap.cpp:395-407.
+                               Its sample position is recomputed from the counter stream (a rare branch) */
+                            const uint32_t px = info.y % (uint32_t) S.film.width, py = info.y / (uint32_t) S.film.width;
+                            const U4 hc = pcg4d(info.y, info.z, 0, rc.seed);
+                            V3 rx, ry;
+                            cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
+                            rx = rayD + (rx - rayD) * rc.diffScaleFactor;
+                            ry = rayD + (ry - rayD) * rc.diffScaleFactor;
+                            bg = envmapEvalDiff(S.env, rayD, rx, ry);
+                        }
+                        l.x += bg.x; l.y += bg.y; l.z += bg.z;
+                    }
                     haveAdd = true;
                 } else {
                     const float4 ro = P.rayO[slot];
                     if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
                         const float lumPdf = (!(flags & F_PREV_DELTA))
-                            ? pdfEmitterDirectDot(S, T, (uint32_t) S.envEmitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
+                            ? pdfEmitterDirectDot<ENV>(S, T, (uint32_t) S.envEmitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
                         const V3 c = thr * value * miWeight(mis.x, lumPdf);
                         l.x += c.x; l.y += c.y; l.z += c.z;
                         haveAdd = true;
@@ -102,7 +116,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                     V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
                     /* DirectSamplingRecord::setQuery (records.inl:170-178): n = shading normal, d = ray direction, dist = t */
                     const float lumPdf = (!(flags & F_PREV_DELTA))
-                        ? pdfEmitterDirectDot(S, T, (uint32_t) its.emitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
+                        ? pdfEmitterDirectDot<ENV>(S, T, (uint32_t) its.emitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
                     const V3 c = thr * value * miWeight(mis.x, lumPdf);
                     l.x += c.x; l.y += c.y; l.z += c.z;
                     haveAdd = true;
@@ -144,7 +158,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHA
                 dRec.pdf = 0; dRec.emitter = -1;
                 const BsdfCtx bctx = bsdfResolve(materials, its);
                 if (its.flags & TS_MF_SMOOTH) {
-                    V3 value = sampleEmitterDirect(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
+                    V3 value = sampleEmitterDirect<ENV>(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
                     if (dRec.pdf != 0 && !value.isZero()) {
                         const V3 wo = its.sh.toLocal(dRec.d);
                         float bPdf;

@@ -135,6 +135,17 @@ void setupCamera(const phip_camera &c, const phip_film &f, DevCamera &out) {
     for (int i = 0; i < 12; ++i) out.c2w[i] = c.to_world[i];
     out.nearClip = c.near_clip; out.farClip = c.far_clip;
     out.invResX = 1.0f / (float) f.crop_width; out.invResY = 1.0f / (float) f.crop_height;
+    /* position differentials on the near plane, perspective.cpp:159-163 (Transform::operator()(Point), transform.h:108-125) */
+    auto s2cPoint = [&](float px, float py, float pz) {
+        const float x = inv.m[0][0] * px + inv.m[0][1] * py + inv.m[0][2] * pz + inv.m[0][3];
+        const float y = inv.m[1][0] * px + inv.m[1][1] * py + inv.m[1][2] * pz + inv.m[1][3];
+        const float z = inv.m[2][0] * px + inv.m[2][1] * py + inv.m[2][2] * pz + inv.m[2][3];
+        const float w = inv.m[3][0] * px + inv.m[3][1] * py + inv.m[3][2] * pz + inv.m[3][3];
+        return (w == 1.0f) ? V3(x, y, z) : V3(x, y, z) / w;
+    };
+    const V3 p0 = s2cPoint(0.0f, 0.0f, 0.0f);
+    const V3 dx = s2cPoint(out.invResX, 0.0f, 0.0f) - p0, dy = s2cPoint(0.0f, out.invResY, 0.0f) - p0;
+    out.dx[0] = dx.x; out.dx[1] = dx.y; out.dx[2] = dx.z; out.dy[0] = dy.x; out.dy[1] = dy.y; out.dy[2] = dy.z;
 }
 
 /* spiral block order, src/librender/imageproc.cpp:28-78 */
@@ -165,7 +176,7 @@ struct phip_scene {
                                         (PHIP_TRAVERSAL=group; measured 2-3x slower: too few rays in flight per CU) */
     DevBuf<DevMaterial> materials;
     DevBuf<float> emitterTab;
-    DevBuf<float4> envTexels; DevBuf<float> envCdfRows, envCdfCols, envRowWeights;     /* `envmap` emitter */
+    DevBuf<float4> envTexels; DevBuf<DevEnvLevels> envLevels; DevBuf<float> envCdfRows, envCdfCols, envRowWeights;     /* `envmap` emitter */
     DevScene dev;
     /* render-time buffers (grown on demand, reused between calls) */
     DevBuf<float4> rayO, rayD, hit, thr, shadow, L, sampleOut;
@@ -178,6 +189,7 @@ struct phip_scene {
     uint32_t lastSpp = 0, nLocalTiles = 0;
     int tileKey[3] = { -1, -1, -1 };
     bool haveSamples = false;
+    int envLevelCount = 0;           /* MIP levels of the envmap (0: no envmap) */
     bool mergedRays = false;         /* last render used k_rays_p (closest + any hit in one launch) */
     int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
     std::atomic<int> cancel{ 0 };
@@ -424,6 +436,28 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         const int w = (int) e.width, h = (int) e.height;
         std::vector<float4> tex((size_t) w * h);
         for (size_t i = 0; i < tex.size(); ++i) tex[i] = make_float4(e.texels[3 * i], e.texels[3 * i + 1], e.texels[3 * i + 2], 0.0f);
+        /* MIP pyramid (level sizes of mipmap.h:182-192) + EWA weight table (mipmap.h:296-301) */
+        DevEnvLevels lv; memset(&lv, 0, sizeof(lv));
+        lv.nLevels = 1; lv.lw[0] = w; lv.lh[0] = h; lv.offset[0] = 0;
+        if (e.n_levels > 1) {
+            int sx = w, sy = h, n = 1;
+            while (sx > 1 || sy > 1) {
+                sx = std::max(1, (sx + 1) / 2); sy = std::max(1, (sy + 1) / 2);
+                if (n >= PHIP_ENVMAP_MAX_LEVELS) throw std::runtime_error("envmap: too many MIP levels");
+                lv.lw[n] = sx; lv.lh[n] = sy; ++n;
+            }
+            if ((uint32_t) n != e.n_levels) throw std::runtime_error("envmap: n_levels must be 1 or the complete pyramid down to 1x1");
+            lv.nLevels = n;
+            for (int l = 1; l < n; ++l) {
+                if (!e.levels[l]) throw std::runtime_error("envmap: level pointer is NULL");
+                lv.offset[l] = (uint32_t) tex.size();
+                const size_t cnt = (size_t) lv.lw[l] * lv.lh[l];
+                for (size_t i = 0; i < cnt; ++i) tex.push_back(make_float4(e.levels[l][3 * i], e.levels[l][3 * i + 1], e.levels[l][3 * i + 2], 0.0f));
+            }
+        }
+        for (int i = 0; i < 64; ++i) { const float r2 = (float) i / 63.0f; lv.weightLut[i] = pm_expf(-2.0f * r2) - pm_expf(-2.0f); }
+        sc->envLevels.upload(&lv, 1);
+        sc->envLevelCount = lv.nLevels;
         std::vector<float> cdfCols((size_t) (w + 1) * h), cdfRows((size_t) h + 1), rowWeights((size_t) h);
         size_t colPos = 0, rowPos = 0;
         float rowSum = 0.0f;
@@ -456,7 +490,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         sc->envCdfRows.upload(cdfRows.data(), cdfRows.size()); sc->envCdfCols.upload(cdfCols.data(), cdfCols.size());
         sc->envRowWeights.upload(rowWeights.data(), rowWeights.size());
         DevEnvMap &E = D.env;
-        E.texels = sc->envTexels.p; E.cdfRows = sc->envCdfRows.p; E.cdfCols = sc->envCdfCols.p; E.rowWeights = sc->envRowWeights.p;
+        E.texels = sc->envTexels.p; E.levels = sc->envLevels.p; E.cdfRows = sc->envCdfRows.p; E.cdfCols = sc->envCdfCols.p; E.rowWeights = sc->envRowWeights.p;
         E.w = w; E.h = h; E.scale = e.scale;
         E.normalization = 1.0f / (rowSum * (2 * PT_PI / w) * (PT_PI / h));
         E.pixelSizeX = 2 * PT_PI / w; E.pixelSizeY = PT_PI / h;
@@ -517,9 +551,9 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     if (p->rr_depth <= 0) throw std::invalid_argument("'rrDepth' must be set to a value greater than zero!");                       /* integrator.cpp:219-220 */
     if (p->max_depth <= 0 && p->max_depth != -1) throw std::invalid_argument("'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); /* :222-223 */
     if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
-    if (sc->dev.env.w > 0 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
-        throw std::invalid_argument("envmap: directly visible background needs the filtered (EWA) lookup of envmap.cpp:395-407, which is not "
-                                    "implemented: render with hideEmitters or PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
+    if (sc->dev.env.w > 0 && sc->envLevelCount <= 1 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
+        throw std::invalid_argument("envmap without MIP levels: directly visible background needs the filtered (EWA) lookup of envmap.cpp:395-407: "
+                                    "pass the pyramid, render with hideEmitters or set PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
     const int bs = p->block_size > 0 ? p->block_size : 32;
     if (bs < 2 || bs > 128 || (bs & (bs - 1))) throw std::invalid_argument("block_size must be a power of two in [2,128] (mitsuba.cpp:233-239 allows 2..128)");
     const int shardCount = p->shard_count > 0 ? p->shard_count : 1;
@@ -628,6 +662,8 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         rc.totalIds = idsPerSpp * rc.sppPass;
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
         rc.seed = p->seed; rc.tileOrigin = sc->tileOrigin.p; rc.countAlive = 0;
+        rc.diffScaleFactor = 1.0f / sqrtf((float) p->spp);
+        rc.envFiltered = (sc->envLevelCount > 1 && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND)) ? 1u : 0u;
         /* static share: the first 3/4 of every slot's samples; the remainder is handed out dynamically */
         {
             const unsigned long long perSlot = rc.totalIds / capacity;
@@ -658,10 +694,10 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             {
                 typedef void (*ShadeKernel)(DevScene, PathPool, RenderConst, float4 *);
-                static const ShadeKernel table[2][4] = {
-                    { k_shade<0, false>, k_shade<MM_ROUGH, false>, k_shade<MM_DIELECTRIC, false>, k_shade<MM_ALL, false> },
-                    { k_shade<0, true>, k_shade<MM_ROUGH, true>, k_shade<MM_DIELECTRIC, true>, k_shade<MM_ALL, true> } };
-                hipLaunchKernelGGL(table[rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
+#define SHADE_ROW(S_, E_) { k_shade<0, S_, E_>, k_shade<MM_ROUGH, S_, E_>, k_shade<MM_DIELECTRIC, S_, E_>, k_shade<MM_ALL, S_, E_> }
+                static const ShadeKernel table[2][2][4] = { { SHADE_ROW(false, false), SHADE_ROW(true, false) }, { SHADE_ROW(false, true), SHADE_ROW(true, true) } };
+#undef SHADE_ROW
+                hipLaunchKernelGGL(table[D.envEmitter >= 0 ? 1 : 0][rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
             }
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (merged) {

@@ -27,7 +27,18 @@
 #include <boost/algorithm/string.hpp>
 #include "phip.h"
 
+#include <mitsuba/render/mipmap.h>
+
 MTS_NAMESPACE_BEGIN
+
+/* What the shim needs of src/emitters/envmap.cpp's EnvironmentMap (a plugin-local class): its MIP pyramid.  With the
+   accessor of INTEGRATION.md added there and the class declaration moved to a header, this stand-in goes away. */
+class EnvironmentMapAccess : public Emitter {
+public:
+    typedef TSpectrum<half, SPECTRUM_SAMPLES> SpectrumHalf;
+    typedef TMIPMap<Spectrum, SpectrumHalf> MIPMap;
+    virtual const MIPMap *getMIPMap() const = 0;
+};
 
 class PathHIP : public MonteCarloIntegrator {
 public:
@@ -74,7 +85,6 @@ public:
         rp.strict_normals = m_strictNormals; rp.hide_emitters = m_hideEmitters;
         rp.block_size = (int32_t) scene->getBlockSize();
         rp.sampler = PHIP_SAMPLER_CTR; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
-        if (m_envmap != NULL && !m_hideEmitters) rp.flags |= PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND;   /* warned about in flatten() */
 
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, size, film->getReconstructionFilter());
         block->setOffset(Point2i(0, 0));            /* crop-relative, like renderproc.cpp:160-173 */
@@ -153,18 +163,25 @@ private:
             } else if (cls == "ConstantBackgroundEmitter") {
                 pe.type = PHIP_EMITTER_CONSTANT; pe.shape = 0xFFFFFFFFu;     /* the library derives m_sceneBSphere itself */
             } else if (cls == "EnvironmentMap") {
-                /* MIP level 0 exactly as the plugin stores it (half precision, read back as float RGB): envmap.cpp:634-637 */
+                /* the MIP pyramid exactly as the plugin built and stores it (half precision, read back as float RGB): level 0
+                   drives the illumination (envmap.cpp:516-632), all levels the EWA lookup of directly visible pixels
+                   (envmap.cpp:395-407).  EnvironmentMap keeps m_mipmap private: INTEGRATION.md lists the one-line accessor
+                   `const MIPMap *getMIPMap() const { return m_mipmap; }` this needs. */
                 pe.type = PHIP_EMITTER_ENVMAP; pe.shape = 0xFFFFFFFFu;
-                ref<Bitmap> level0 = const_cast<Emitter *>(e)->getBitmap(Vector2i(0));
-                m_envmap = level0->convert(Bitmap::ERGB, Bitmap::EFloat32);
-                envmap.texels = m_envmap->getFloat32Data();
-                envmap.width = (uint32_t) m_envmap->getWidth(); envmap.height = (uint32_t) m_envmap->getHeight();
+                const EnvironmentMapAccess *env = static_cast<const EnvironmentMapAccess *>(e);
+                const int nLevels = env->getMIPMap()->getLevels();
+                if (nLevels > PHIP_ENVMAP_MAX_LEVELS) Log(EError, "path_hip: environment map with too many MIP levels");
+                m_envLevels.clear();
+                for (int l = 0; l < nLevels; ++l) {
+                    m_envLevels.push_back(env->getMIPMap()->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
+                    envmap.levels[l] = m_envLevels[l]->getFloat32Data();
+                }
+                envmap.n_levels = (uint32_t) nLevels;
+                envmap.texels = m_envLevels[0]->getFloat32Data();
+                envmap.width = (uint32_t) m_envLevels[0]->getWidth(); envmap.height = (uint32_t) m_envLevels[0]->getHeight();
                 envmap.scale = e->getProperties().getFloat("scale", 1.0f);
                 const Matrix4x4 &tw = e->getWorldTransform()->eval(0).getMatrix();
                 for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) envmap.to_world[4 * r + c] = tw(r, c);
-                if (!m_hideEmitters)
-                    Log(EWarn, "path_hip: directly visible environment-map pixels are looked up without the EWA filter "
-                        "(PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND); use hideEmitters for exact agreement with 'path'");
             } else {
                 Log(EError, "path_hip: emitter \"%s\" is not supported (area, constant, envmap)", cls.c_str());
             }
@@ -257,7 +274,7 @@ private:
     static std::vector<const BSDF *> getNestedBSDFs(const BSDF *bsdf);
 
     phip_scene *m_scene;
-    ref<Bitmap> m_envmap;            /* float RGB copy of the environment map's MIP level 0 (kept alive for phip_scene_create) */
+    std::vector<ref<Bitmap> > m_envLevels;   /* float RGB copies of the environment map's MIP levels (alive until phip_scene_create) */
     int m_device;
     ref<SamplingIntegrator> m_cpuPath;
 };

@@ -41,6 +41,31 @@ def look_at(origin, target, up):
     return m.astype(np.float32)
 
 
+def mip_pyramid(level0):
+    """MIP levels of an (H, W, 3) image with the level sizes of TMIPMap (max(1, (n+1)/2) down to 1x1, mipmap.h:182-192);
+    each level is an area-weighted box resampling of level 0 (a stand-in for the reference's 2-lobe Lanczos resampler)."""
+    out = [np.ascontiguousarray(level0, np.float32)]
+    h, w = out[0].shape[:2]
+    src = out[0].astype(np.float64)
+
+    def resample_axis(a, n_out, axis):
+        n_in = a.shape[axis]
+        edges = np.linspace(0, n_in, n_out + 1)
+        res = []
+        for i in range(n_out):
+            lo, hi = edges[i], edges[i + 1]
+            idx = np.arange(int(np.floor(lo)), int(np.ceil(hi)))
+            wgt = np.minimum(idx + 1, hi) - np.maximum(idx, lo)
+            sl = np.take(a, idx, axis=axis)
+            shape = [1] * a.ndim; shape[axis] = len(idx)
+            res.append((sl * wgt.reshape(shape)).sum(axis=axis) / (hi - lo))
+        return np.stack(res, axis=axis)
+    while w > 1 or h > 1:
+        w, h = max(1, (w + 1) // 2), max(1, (h + 1) // 2)
+        out.append(np.ascontiguousarray(resample_axis(resample_axis(src, h, 0), w, 1), np.float32))
+    return out
+
+
 class SceneBuilder:
     def __init__(self):
         self.positions = []      # list of (n,3) float32
@@ -119,12 +144,15 @@ class SceneBuilder:
                               "type": A.PHIP_EMITTER_CONSTANT})
         return len(self.emitters) - 1
 
-    def envmap(self, texels, scale=1.0, to_world=None, sampling_weight=1.0):
+    def envmap(self, texels, scale=1.0, to_world=None, sampling_weight=1.0, pyramid=False):
         """<emitter type="envmap">: lat-long radiance map (src/emitters/envmap.cpp); `texels` = (H, W, 3) float RGB
-        (MIP level 0 as the reference stores it), `to_world` = 4x4 emitter-to-world (rotation)."""
+        (MIP level 0 as the reference stores it), `to_world` = 4x4 emitter-to-world (rotation).  `pyramid=True` adds
+        the MIP levels the filtered background lookup needs (the Mitsuba shim passes the plugin's own Lanczos pyramid;
+        this harness builds a box-filtered one with `mip_pyramid` -- product and oracle consume the same levels)."""
         t = np.ascontiguousarray(texels, dtype=np.float32)
         assert t.ndim == 3 and t.shape[2] == 3
-        self._envmap = (t, float(scale), np.eye(4, dtype=np.float32) if to_world is None else np.asarray(to_world, np.float32).reshape(4, 4))
+        levels = mip_pyramid(t) if pyramid is True else ([t] + [np.ascontiguousarray(l, np.float32) for l in pyramid[1:]] if pyramid else [t])
+        self._envmap = (t, float(scale), np.eye(4, dtype=np.float32) if to_world is None else np.asarray(to_world, np.float32).reshape(4, 4), levels)
         self.emitters.append({"radiance": (0.0, 0.0, 0.0), "weight": sampling_weight, "shape": 0xFFFFFFFF,
                               "type": A.PHIP_EMITTER_ENVMAP})
         return len(self.emitters) - 1
@@ -198,7 +226,10 @@ class SceneBuilder:
         d.camera, d.film = self.camera, self.film
         env = getattr(self, "_envmap", None)
         if env is not None:
-            t, scale, m = env
+            t, scale, m, levels = env
+            d.envmap.n_levels = len(levels)
+            for i, l in enumerate(levels):
+                d.envmap.levels[i] = l.ctypes.data_as(C.POINTER(C.c_float))
             d.envmap.texels = t.ctypes.data_as(C.POINTER(C.c_float))
             d.envmap.height, d.envmap.width = t.shape[0], t.shape[1]
             d.envmap.scale = scale

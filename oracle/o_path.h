@@ -24,7 +24,7 @@ inline Float miWeight(Float pdfA, Float pdfB) { /* path.cpp:296-300 */
 
 /* Returns Li; alpha as set by RadianceQueryRecord::rayIntersect (records.inl:117-144). */
 inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray &r, SampleSource &smp,
-                       Float &alpha, PathCounters *pc) {
+                       Float &alpha, PathCounters *pc, const Vec3 *rxDirection = nullptr, const Vec3 *ryDirection = nullptr) {
     BSDF bsdfs(scene);
     Intersection its;
     Ray ray(r);
@@ -43,8 +43,10 @@ inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray
     while (depth <= ip.maxDepth || ip.maxDepth < 0) {
         if (!its.isValid()) {
             /* path.cpp:136-143 */
+            /* only the camera ray can get here with the emission flag set, and it is the only ray with differentials */
             if (emittedRadiance && (!ip.hideEmitters || scattered))
-                Li += throughput * scene.evalEnvironment(ray);
+                Li += throughput * ((rxDirection && ryDirection && depth == 1) ? scene.evalEnvironment(ray, *rxDirection, *ryDirection)
+                                                                                : scene.evalEnvironment(ray));
             break;
         }
 

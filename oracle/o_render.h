@@ -77,6 +77,7 @@ struct PerspectiveCamera {
     Transform sampleToCamera, toWorld;
     Float nearClip, farClip;
     Vec2 invResolution;
+    Vec3 dx, dy;                         /* position differentials on the near plane, perspective.cpp:159-163 */
 
     void configure(const phip_camera &c, const phip_film &f) { /* perspective.cpp:126-157, sensor.cpp:104-109 */
         Float aspect = f.width / (Float) f.height;
@@ -91,11 +92,13 @@ struct PerspectiveCamera {
             * Transform::translate(Vec3(-1.0f, -1.0f / aspect, 0.0f))
             * Transform::perspective(c.xfov_deg, nearClip, farClip);
         sampleToCamera = cameraToSample.inverse();
+        dx = sampleToCamera.point(Vec3(invResolution.x, 0.0f, 0.0f)) - sampleToCamera.point(Vec3(0.0f));
+        dy = sampleToCamera.point(Vec3(0.0f, invResolution.y, 0.0f)) - sampleToCamera.point(Vec3(0.0f));
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) toWorld.fwd.m[i][j] = c.to_world[4 * i + j];
     }
 
-    /* perspective.cpp:271-297 (differentials are unused: textures are constant) */
-    Ray sampleRay(const Vec2 &pixelSample) const {
+    /* perspective.cpp:271-297; rx / ry receive the differential directions (rxOrigin = ryOrigin = o) */
+    Ray sampleRay(const Vec2 &pixelSample, Vec3 *rx = nullptr, Vec3 *ry = nullptr) const {
         Vec3 nearP = sampleToCamera.point(Vec3(pixelSample.x * invResolution.x, pixelSample.y * invResolution.y, 0.0f));
         Vec3 d = normalize(nearP);
         Float invZ = 1.0f / d.z;
@@ -105,6 +108,8 @@ struct PerspectiveCamera {
         ray.o = toWorld.pointAffine(Vec3(0.0f));
         ray.d = toWorld.vector(d);
         ray.setDir();
+        if (rx) *rx = toWorld.vector(normalize(nearP + dx));
+        if (ry) *ry = toWorld.vector(normalize(nearP + dy));
         return ray;
     }
 };
@@ -254,6 +259,7 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
     std::vector<SFMT> workerRng;
     if (!rp.ctr) { workerRng.resize(nThreads); for (int i = 0; i < nThreads; ++i) workerRng[i].seedFrom(parent); }
 
+    const Float diffScaleFactor = 1.0f / std::sqrt((Float) rp.spp);      /* integrator.cpp:144-145 */
     auto t0 = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
         PathCounters &pc = counters[tid];
@@ -273,9 +279,13 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
                     smp.sample = (uint32_t) j;
                     Vec2 jit = smp.cameraSample();
                     Vec2 samplePos((Float) px + jit.x, (Float) py + jit.y);   /* integrator.cpp:171 */
-                    Ray ray = cam.sampleRay(samplePos);
+                    Vec3 rx, ry;
+                    Ray ray = cam.sampleRay(samplePos, &rx, &ry);
+                    /* RayDifferential::scaleDifferential, ray.h:163-168, integrator.cpp:144-145,181 */
+                    rx = ray.d + (rx - ray.d) * diffScaleFactor;
+                    ry = ray.d + (ry - ray.d) * diffScaleFactor;
                     Float alpha;
-                    Spectrum spec = pathLi(scene, rp.ip, ray, smp, alpha, &pc);
+                    Spectrum spec = pathLi(scene, rp.ip, ray, smp, alpha, &pc, &rx, &ry);
                     Float temp[5] = { spec[0], spec[1], spec[2], alpha, 1.0f };
                     if (!blk.put(samplePos, temp)) pc.invalidSamples++;
                     if (sampleOut) {

@@ -389,6 +389,11 @@ public:
         if (envmap.valid()) return envmap.evalEnvironment(ray.d);
         return Spectrum(emitters[envEmitter].radiance);
     }
+    /* the same for a ray with differentials (camera rays): the envmap filters the lookup, envmap.cpp:395-407 */
+    Spectrum evalEnvironment(const Ray &ray, const Vec3 &rx, const Vec3 &ry) const {
+        if (envEmitter >= 0 && envmap.valid() && envmap.nLevels > 1) return envmap.evalEnvironment(ray.d, rx, ry);
+        return evalEnvironment(ray);
+    }
 
     /* constant.cpp:258-273 = envmap.cpp:354-370; false = "internal error" (the path is terminated, path.cpp:242-243) */
     bool fillDirectSamplingRecord(DirectSamplingRecord &dRec, const Ray &ray) const {

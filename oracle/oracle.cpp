@@ -54,9 +54,9 @@ int oracle_render(void *scene_, const phip_render_params *p, int threads, int sa
         /* integrator.cpp:219-224 */
         if (rp.ip.rrDepth <= 0) throw std::runtime_error("'rrDepth' must be set to a value greater than zero!");
         if (rp.ip.maxDepth <= 0 && rp.ip.maxDepth != -1) throw std::runtime_error("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");
-        if (scene.envmap.valid() && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
-            throw std::runtime_error("envmap: directly visible background needs the filtered (EWA) lookup, which is not restated: "
-                                     "render with hideEmitters or PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
+        if (scene.envmap.valid() && scene.envmap.nLevels <= 1 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
+            throw std::runtime_error("envmap without MIP levels: directly visible background needs the filtered (EWA) lookup: "
+                                     "pass the pyramid, render with hideEmitters or set PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
         RenderResult rr = render(scene, rp, out_rgbaw, out_samples_rgba);
         if (stats) {
             memset(stats, 0, sizeof(*stats));

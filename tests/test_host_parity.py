@@ -33,7 +33,7 @@ def test_bsdf_sample_eval_pdf_bitwise(oracle, phip, gauss):
     rng = np.random.default_rng(11); n = 100000
     wi = rng.normal(size=(n, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
     wi[:100] = [0, 0, 1]; wi[100:200] = [0, 0, -1]; wi[200:300, 2] = 0; wi[200:300] /= np.linalg.norm(wi[200:300], axis=1, keepdims=True) + 1e-30
-    smp = rng.random((n, 2)).astype(np.float32); smp[:50] = 0; smp[50:100] = np.float32(1) - np.float32(2 ** -24)
+    smp = np.minimum(rng.random((n, 2)).astype(np.float32), np.float32(1) - np.float32(2 ** -24))   # [0, 1) like Random::nextFloat (a double close to 1 rounds to 1.0f); smp[:50] = 0; smp[50:100] = np.float32(1) - np.float32(2 ** -24)
     wo_r = rng.normal(size=(n, 3)).astype(np.float32); wo_r /= np.linalg.norm(wo_r, axis=1, keepdims=True)
     u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
     for name, mid in mats.items():
