@@ -219,6 +219,34 @@ def test_envmap_illumination(oracle, gauss):
         assert np.abs(got / expect - 1).max() < 0.03, (got, expect)        # texel-centre quadrature vs bilinear map
 
 
+def test_envmap_filtered_background(oracle, gauss):
+    """camera rays carry differentials: envmap.cpp:395-407 -> MIPMap::eval (EWA).  (1) a constant map stays constant under
+    any filter; (2) on a noisy high-resolution map seen through a coarse film the filtered background has the same mean
+    as the unfiltered one and less pixel-to-pixel variance; (3) more samples per pixel shrink the footprint
+    (scaleDifferential by 1/sqrt(spp), integrator.cpp:144-145); (4) level sizes follow mipmap.h:182-192"""
+    assert [l.shape[:2] for l in S.mip_pyramid(np.zeros((5, 12, 3), np.float32))] == [(5, 12), (3, 6), (2, 3), (1, 2), (1, 1)]
+    L = np.array([1.0, 2.0, 3.0], np.float32)
+
+    def scene(tex, pyramid, res=32, fov=70.0):
+        sb = S.SceneBuilder(); sb.diffuse((0.5, 0.5, 0.5))
+        sb.envmap(tex, pyramid=pyramid)
+        sb.perspective((0, 0, -6), (0, 0, 0), (0, 1, 0), fov); sb.hdrfilm(res, res, gauss)
+        return oracle.OracleScene(sb.desc())
+    img = oracle.develop(scene(np.tile(L, (256, 512, 1)).astype(np.float32), True).render(A.default_render_params(spp=1))[0])
+    assert np.abs(img / L - 1).max() < 1e-5
+    rng = np.random.default_rng(3)
+    tex = (_sky(1024, 512) * rng.uniform(0.5, 1.5, (512, 1024, 1))).astype(np.float32)
+    ewa = oracle.develop(scene(tex, True).render(A.default_render_params(spp=1))[0])
+    bil = oracle.develop(scene(tex, False).render(A.default_render_params(spp=1, flags=A.PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))[0])
+    hi = lambda a: np.abs(np.diff(a, axis=1)).mean()                 # pixel-to-pixel roughness
+    assert abs(ewa.mean() / bil.mean() - 1) < 0.01 and hi(ewa) < 0.75 * hi(bil)
+    ewa64 = oracle.develop(scene(tex, True).render(A.default_render_params(spp=64))[0])
+    bil64 = oracle.develop(scene(tex, False).render(A.default_render_params(spp=64, flags=A.PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))[0])
+    assert np.abs(ewa64 - bil64).mean() < 0.5 * np.abs(ewa - bil).mean()      # smaller footprint: closer to the unfiltered lookup
+    with pytest.raises(RuntimeError, match="pyramid"):
+        scene(tex, False).render(A.default_render_params(spp=1))
+
+
 def test_sfmt_streams_agree_statistically_with_ctr_stream(oracle, gauss):
     """`independent` semantics (one SFMT19937 clone per worker, sequential consumption) and the
     counter-based parity stream estimate the same image"""
