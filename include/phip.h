@@ -71,7 +71,31 @@ typedef struct phip_material {
     float    alpha_u, alpha_v;  /* ROUGHCONDUCTOR roughness (clamped to >= 1e-4 inside)  */
     uint32_t distribution;      /* phip_microfacet_type                                  */
     uint32_t sample_visible;    /* microfacet.h:144, default true                        */
+    uint32_t reflectance_texture; /* DIFFUSE: 0 = the constant `reflectance`, else 1 + id of a `bitmap` texture
+                                   (diffuse.cpp:110-150 evaluate m_reflectance->eval(its))  */
 } phip_material;
+
+/* ---- `bitmap` texture (src/textures/bitmap.cpp, Texture2D::eval texture.cpp:112-121): an RGB MIP pyramid exactly as
+ * the plugin built and stores it (level 0 = the image; every further level, sizes max(1, (n+1)/2) down to 1x1,
+ * mipmap.h:182-192 -- filterType nearest / bilinear: level 0 only).  Lookups without UV partials read level 0
+ * bilinearly (bitmap.cpp:431-454); the first path vertex has partials (camera-ray differentials,
+ * intersection.cpp:5-76) and uses MIPMap::eval (mipmap.h:629-833). ---- */
+typedef enum phip_wrap_mode {     /* ReconstructionFilter::EBoundaryCondition, rfilter.h */
+    PHIP_WRAP_REPEAT = 0, PHIP_WRAP_CLAMP = 1, PHIP_WRAP_MIRROR = 2, PHIP_WRAP_ZERO = 3, PHIP_WRAP_ONE = 4
+} phip_wrap_mode;
+typedef enum phip_filter_type {   /* EMIPFilterType, mipmap.h:40-52 */
+    PHIP_FILTER_NEAREST = 0, PHIP_FILTER_BILINEAR = 1, PHIP_FILTER_TRILINEAR = 2, PHIP_FILTER_EWA = 3
+} phip_filter_type;
+#define PHIP_MIP_MAX_LEVELS 17
+typedef struct phip_texture {
+    uint32_t width, height;
+    uint32_t n_levels;                    /* 1 or the complete pyramid                     */
+    const float *levels[PHIP_MIP_MAX_LEVELS];   /* levels[l]: RGB floats, row-major        */
+    uint32_t wrap_u, wrap_v;              /* phip_wrap_mode ('wrapModeU/V', default repeat) */
+    uint32_t filter_type;                 /* phip_filter_type ('filterType', default EWA)  */
+    float    max_anisotropy;              /* 'maxAnisotropy', default 20                   */
+    float    uv_scale[2], uv_offset[2];   /* Texture2D 'uscale/vscale', 'uoffset/voffset'  */
+} phip_texture;
 
 /* ---- shapes: every shape is a TriMesh (analytic shapes go through Shape::createTriMesh) ---- */
 typedef struct phip_shape {
@@ -80,7 +104,7 @@ typedef struct phip_shape {
     uint32_t material;                   /* id into materials[]                           */
     int32_t  emitter;                    /* id into emitters[] or -1                      */
     uint32_t has_normals;                /* 0: shading normal = face normal (skdtree.h:393)*/
-    uint32_t reserved;
+    uint32_t has_texcoords;              /* 1: its.uv from texcoords[], dpdu/dpdv from TriMesh::computeUVTangents (trimesh.cpp:683-735) */
 } phip_shape;
 
 /* ---- emitters: `area` (src/emitters/area.cpp) and the `constant` environment (src/emitters/constant.cpp).
@@ -149,6 +173,9 @@ typedef struct phip_scene_desc {
     phip_camera camera;
     phip_film   film;
     phip_envmap envmap;                  /* used by the emitter of type PHIP_EMITTER_ENVMAP */
+    const float *texcoords;              /* 2*n_vertices or NULL (then no shape has texcoords) */
+    uint32_t n_textures;
+    const phip_texture *textures;
 } phip_scene_desc;
 
 /* ---- integrator parameters: MonteCarloIntegrator (src/librender/integrator.cpp:190-225) ---- */

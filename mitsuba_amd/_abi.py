@@ -23,14 +23,14 @@ class phip_material(C.Structure):
                 ("reflectance", C.c_float * 3), ("transmittance", C.c_float * 3),
                 ("eta", C.c_float * 3), ("k", C.c_float * 3),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float),
-                ("distribution", C.c_uint32), ("sample_visible", C.c_uint32)]
+                ("distribution", C.c_uint32), ("sample_visible", C.c_uint32), ("reflectance_texture", C.c_uint32)]
 
 
 class phip_shape(C.Structure):
     _fields_ = [("first_vertex", C.c_uint32), ("n_vertices", C.c_uint32),
                 ("first_triangle", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("material", C.c_uint32), ("emitter", C.c_int32),
-                ("has_normals", C.c_uint32), ("reserved", C.c_uint32)]
+                ("has_normals", C.c_uint32), ("has_texcoords", C.c_uint32)]
 
 
 PHIP_EMITTER_AREA, PHIP_EMITTER_CONSTANT, PHIP_EMITTER_ENVMAP = 0, 1, 2
@@ -63,6 +63,18 @@ class phip_envmap(C.Structure):
                 ("n_levels", C.c_uint32), ("levels", C.POINTER(C.c_float) * PHIP_ENVMAP_MAX_LEVELS)]
 
 
+PHIP_WRAP_REPEAT, PHIP_WRAP_CLAMP, PHIP_WRAP_MIRROR, PHIP_WRAP_ZERO, PHIP_WRAP_ONE = range(5)
+PHIP_FILTER_NEAREST, PHIP_FILTER_BILINEAR, PHIP_FILTER_TRILINEAR, PHIP_FILTER_EWA = range(4)
+PHIP_MIP_MAX_LEVELS = 17
+
+
+class phip_texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("n_levels", C.c_uint32),
+                ("levels", C.POINTER(C.c_float) * PHIP_MIP_MAX_LEVELS),
+                ("wrap_u", C.c_uint32), ("wrap_v", C.c_uint32), ("filter_type", C.c_uint32),
+                ("max_anisotropy", C.c_float), ("uv_scale", C.c_float * 2), ("uv_offset", C.c_float * 2)]
+
+
 class phip_scene_desc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_vertices", C.c_uint32),
                 ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
@@ -70,7 +82,8 @@ class phip_scene_desc(C.Structure):
                 ("n_shapes", C.c_uint32), ("shapes", C.POINTER(phip_shape)),
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(phip_material)),
                 ("n_emitters", C.c_uint32), ("emitters", C.POINTER(phip_emitter)),
-                ("camera", phip_camera), ("film", phip_film), ("envmap", phip_envmap)]
+                ("camera", phip_camera), ("film", phip_film), ("envmap", phip_envmap),
+                ("texcoords", C.POINTER(C.c_float)), ("n_textures", C.c_uint32), ("textures", C.POINTER(phip_texture))]
 
 
 class phip_render_params(C.Structure):

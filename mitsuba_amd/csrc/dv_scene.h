@@ -39,6 +39,7 @@ struct DevMaterial {
     float trans[3]; float alphaV;
     float eta[3]; uint32_t distribution;
     float k[3]; uint32_t sampleVisible;
+    uint32_t reflTexture, pad[3];        /* DIFFUSE: 0 or 1 + id of the bitmap texture of `reflectance` */
 };
 
 struct DevEmitter { float radiance[3]; float samplingWeight; uint32_t shape; uint32_t pad[3]; };
@@ -59,17 +60,21 @@ struct DevFilm {
 
 /* `envmap` emitter (src/emitters/envmap.cpp), illumination side: MIP level 0 as float4 texels, the marginal /
    conditional CDFs over luminance * sin(theta) built by the host like EnvironmentMap::configure (envmap.cpp:262-328) */
-/* MIP pyramid of the envmap (levels as the reference built them; consecutive in `texels`) + the EWA weight table */
-struct DevEnvLevels {
+/* A MIP pyramid (levels as the reference built them, consecutive in a float4 texel array) with its lookup parameters
+   and the EWA weight table: the envmap's and every bitmap texture's descriptor (global memory) */
+struct DevMipLevels {
     int32_t nLevels;                         /* 1: no pyramid */
-    int32_t lw[PHIP_ENVMAP_MAX_LEVELS], lh[PHIP_ENVMAP_MAX_LEVELS];
-    uint32_t offset[PHIP_ENVMAP_MAX_LEVELS]; /* first texel of the level */
+    int32_t lw[PHIP_MIP_MAX_LEVELS], lh[PHIP_MIP_MAX_LEVELS];
+    uint32_t offset[PHIP_MIP_MAX_LEVELS];    /* first texel of the level (relative to the texel array passed along) */
+    uint32_t bcu, bcv, filterType;           /* phip_wrap_mode x 2, phip_filter_type */
+    float maxAnisotropy;
+    float uvScale[2], uvOffset[2];           /* Texture2D (bitmap textures only) */
     float weightLut[64];                     /* mipmap.h:296-301 */
 };
 
 struct DevEnvMap {
     const float4 *texels;                    /* level 0: w * h, rgb + pad; further levels follow */
-    const DevEnvLevels *levels;              /* read only by camera rays that miss the scene */
+    const DevMipLevels *levels;              /* read only by camera rays that miss the scene */
     const float *cdfRows, *cdfCols, *rowWeights;
     int32_t w, h;                            /* w == 0: the environment emitter (if any) is not an envmap */
     float scale, normalization, pixelSizeX, pixelSizeY;
@@ -81,6 +86,8 @@ struct DevScene {
     const DevMaterial *materials; uint32_t nMaterials;
     const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;
+    const float4 *texTexels; const DevMipLevels *textures;   /* bitmap textures: all pyramids in one texel array + one descriptor each */
+    uint32_t triShadeStride;             /* float4s per shading record: 6, or 9 when a mesh has texture coordinates */
     int32_t envEmitter; float envCenter[3]; float envRadius;   /* environment emitter (or -1) and its m_sceneBSphere */
     DevEnvMap env;
     int32_t rootRef, rootRef8; uint32_t nTriangles;
@@ -98,12 +105,17 @@ struct DevScene {
  *   vertex normals: r3 = (n0, flags)           r4 = (n1, -)       r5 = (n2, -)
  * frontLeaf/backLeaf = the one-sided model seen from either side (the twosided adapter's nested ids, or
  * the material itself twice). */
-enum { TS_VERTEX_NORMALS = 1, TS_TWOSIDED = 2, TS_MF_SMOOTH = 4, TS_TRANS_OR_BACK = 8 };
+enum { TS_VERTEX_NORMALS = 1, TS_TWOSIDED = 2, TS_MF_SMOOTH = 4, TS_TRANS_OR_BACK = 8, TS_TEXCOORDS = 16 };
 #define TRISHADE_FLOAT4S 6
+/* meshes with texture coordinates append three float4s: r6 = (uv0, uv1), r7 = (uv2, dpdu.xy), r8 = (dpdu.z, dpdv) with
+   dpdu / dpdv = TriMesh::computeUVTangents (trimesh.cpp:683-735; they replace side1 / side2 in the shading frame,
+   skdtree.h:373-380) */
+#define TRISHADE_FLOAT4S_UV 9
 
 struct Isect {
     V3 p; Frame sh; V3 geoN; V3 wi; float t; uint32_t prim;
     uint32_t front, back, flags; int32_t emitter;
+    V2 uv; V3 dpdu, dpdv;               /* filled for triangles with texture coordinates (TS_TEXCOORDS) */
 };
 
 DV V3 ld3(const float4 *a, uint32_t i) { float4 v = a[i]; return V3(v.x, v.y, v.z); }
@@ -126,13 +138,20 @@ DV void triShadingFrame(const V3 &shN, const V3 &side1, Frame &f) {
 
 /* skdtree.h:343-428 with BarycentricPos = true, no UV tangents, no texcoords */
 DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float cu, float cv, float t, Isect &its) {
-    const float4 *r = S.triShade + (size_t) TRISHADE_FLOAT4S * prim;
+    const float4 *r = S.triShade + (size_t) S.triShadeStride * prim;
     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
     const V3 b(1 - cu - cv, cu, cv);
     const V3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
     its.p = p0 * b.x + p1 * b.y + p2 * b.z;
     its.front = pm_to_bits(r0.w); its.back = pm_to_bits(r1.w); its.emitter = (int32_t) pm_to_bits(r2.w);
     its.flags = pm_to_bits(r3.w);
+    V3 dpdu = p1 - p0;                                   /* side1, skdtree.h:378-379 */
+    if (its.flags & TS_TEXCOORDS) {                      /* vertexTangents + texture coordinates, skdtree.h:373-377,397-404 */
+        const float4 r6 = r[6], r7 = r[7], r8 = r[8];
+        its.uv = V2(r6.x * b.x + r6.z * b.y + r7.x * b.z, r6.y * b.x + r6.w * b.y + r7.y * b.z);
+        its.dpdu = V3(r7.z, r7.w, r8.x); its.dpdv = V3(r8.y, r8.z, r8.w);
+        dpdu = its.dpdu;
+    }
     if (its.flags & TS_VERTEX_NORMALS) {
         const V3 side1(p1 - p0), side2(p2 - p0);
         V3 faceNormal = triFaceNormal(side1, side2);
@@ -140,13 +159,45 @@ DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float
         if (dot(faceNormal, shN) < 0)
             faceNormal = -faceNormal;
         its.geoN = faceNormal;
-        triShadingFrame(shN, side1, its.sh);
+        triShadingFrame(shN, dpdu, its.sh);
     } else {
         its.geoN = xyz(r3);
         its.sh.n = its.geoN; its.sh.s = xyz(r4); its.sh.t = xyz(r5);
     }
     its.wi = its.sh.toLocal(-rayD);
     its.t = t; its.prim = prim;
+}
+
+/* Intersection::computePartials, intersection.cpp:5-76 (rxOrigin = ryOrigin = rayO: pinhole camera) */
+DV bool solveLinearSystem2x2(const float a[2][2], const float b[2], float x[2]) {   /* util.cpp:527-539 */
+    const float det = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    if (fabsf(det) <= 2.93873587705571876e-39f) return false;      /* RCPOVERFLOW */
+    const float inverse = 1.0f / det;
+    x[0] = (a[1][1] * b[0] - a[0][1] * b[1]) * inverse;
+    x[1] = (a[0][0] * b[1] - a[1][0] * b[0]) * inverse;
+    return true;
+}
+DV void computePartials(const Isect &its, const V3 &rayO, const V3 &rxDirection, const V3 &ryDirection,
+                        float &dudx, float &dudy, float &dvdx, float &dvdy) {
+    dudx = dvdx = dudy = dvdy = 0.0f;
+    if (its.dpdu.isZero() && its.dpdv.isZero()) return;
+    const V3 &gn = its.geoN;
+    const float pp = dot(gn, its.p), pox = dot(gn, rayO), poy = dot(gn, rayO), prx = dot(gn, rxDirection), pry = dot(gn, ryDirection);
+    if (prx == 0 || pry == 0) return;
+    const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+    const float absX = fabsf(gn.x), absY = fabsf(gn.y), absZ = fabsf(gn.z);
+    int a0, a1;
+    if (absX > absY && absX > absZ) { a0 = 1; a1 = 2; }
+    else if (absY > absZ) { a0 = 0; a1 = 2; }
+    else { a0 = 0; a1 = 1; }
+    float A[2][2], Bx[2], By[2], x[2];
+    A[0][0] = its.dpdu[a0]; A[0][1] = its.dpdv[a0];
+    A[1][0] = its.dpdu[a1]; A[1][1] = its.dpdv[a1];
+    const V3 px = rayO + rxDirection * tx, py = rayO + ryDirection * ty;
+    Bx[0] = px[a0] - its.p[a0]; Bx[1] = px[a1] - its.p[a1];
+    By[0] = py[a0] - its.p[a0]; By[1] = py[a1] - its.p[a1];
+    if (solveLinearSystem2x2(A, Bx, x)) { dudx = x[0]; dvdx = x[1]; } else { dudx = 1; dvdx = 0; }
+    if (solveLinearSystem2x2(A, By, x)) { dudy = x[0]; dvdy = x[1]; } else { dudy = 1; }     /* (sic: intersection.cpp:74 assigns dudy twice) */
 }
 
 /* triaccel.h:96-158 on a 48-byte record */
@@ -210,7 +261,7 @@ DV void shapeSampleDirect(const DevScene &S, const EmitterTab &T, const float *e
     sample.y = (sample.y - cdf[index]) / (cdf[index + 1] - cdf[index]);
     const uint32_t recOffset = pm_to_bits(em[EM_REC]);
     const float4 *r = recOffset ? (const float4 *) (T.t + recOffset) + (size_t) TRISHADE_FLOAT4S * index
-                                : S.triShade + (size_t) TRISHADE_FLOAT4S * (pm_to_bits(em[EM_FIRST_TRI]) + index);
+                                : S.triShade + (size_t) S.triShadeStride * (pm_to_bits(em[EM_FIRST_TRI]) + index);
     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
     const V3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
     V2 bary = squareToUniformTriangle(sample);
@@ -314,33 +365,45 @@ DV V3 envmapEval(const DevEnvMap &E, const V3 &rayD) {
                    + envTexel(E, xPos + 1, yPos) * dx1 * dy2 + envTexel(E, xPos + 1, yPos + 1) * dx1 * dy1;
     return value * E.scale;
 }
-/* ---- filtered lookup for rays with differentials (camera rays): MIPMap::eval, mipmap.h:629-712, 780-833 ---- */
-DV V3 envTexelL(const DevEnvMap &E, const DevEnvLevels &Lv, int level, int x, int y) {
+/* ---- MIP pyramid lookups (include/mitsuba/render/mipmap.h), shared by the envmap and the bitmap textures ---- */
+DV int mipModulo(int a, int b) { const int r = a % b; return (r < 0) ? r + b : r; }   /* math.h:67-70 */
+/* one coordinate under a boundary condition (mipmap.h:506-565); false: the texel is the constant `outside` */
+DV bool mipWrap(int &x, int size, uint32_t bc, float &outside) {
+    if (x < 0 || x >= size) {
+        if (bc == PHIP_WRAP_REPEAT) x = mipModulo(x, size);
+        else if (bc == PHIP_WRAP_CLAMP) x = x < 0 ? 0 : size - 1;
+        else if (bc == PHIP_WRAP_MIRROR) { x = mipModulo(x, 2 * size); if (x >= size) x = 2 * size - x - 1; }
+        else { outside = bc == PHIP_WRAP_ONE ? 1.0f : 0.0f; return false; }
+    }
+    return true;
+}
+DV V3 mipTexel(const float4 *texels, const DevMipLevels &Lv, int level, int x, int y) {   /* mipmap.h:503-571 */
     const int sw = Lv.lw[level], sh = Lv.lh[level];
-    if (x < 0 || x >= sw) { int r = x % sw; x = (r < 0) ? r + sw : r; }
-    if (y < 0 || y >= sh) y = y < 0 ? 0 : sh - 1;
-    const float4 t = E.texels[(size_t) Lv.offset[level] + (size_t) y * sw + x];
+    float outside = 0.0f;
+    if (!mipWrap(x, sw, Lv.bcu, outside)) return V3(outside);
+    if (!mipWrap(y, sh, Lv.bcv, outside)) return V3(outside);
+    const float4 t = texels[(size_t) Lv.offset[level] + (size_t) y * sw + x];
     return V3(t.x, t.y, t.z);
 }
-DV V3 envBoxL(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:566-569 */
-    return envTexelL(E, Lv, level, (int) floorf(uv.x * Lv.lw[level]), (int) floorf(uv.y * Lv.lh[level]));
+DV V3 mipBox(const float4 *texels, const DevMipLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:566-569 */
+    return mipTexel(texels, Lv, level, (int) floorf(uv.x * Lv.lw[level]), (int) floorf(uv.y * Lv.lh[level]));
 }
-DV V3 envBilinearL(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:575-596 */
+DV V3 mipBilinear(const float4 *texels, const DevMipLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:575-596 */
     if (!(isfinite(uv.x) && isfinite(uv.y))) return V3(0.0f);
-    if (level >= Lv.nLevels) return envBoxL(E, Lv, Lv.nLevels - 1, uv);
+    if (level >= Lv.nLevels) return mipBox(texels, Lv, Lv.nLevels - 1, uv);
     const float u = uv.x * Lv.lw[level] - 0.5f, v = uv.y * Lv.lh[level] - 0.5f;
     const int xPos = (int) floorf(u), yPos = (int) floorf(v);
     const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
-    return envTexelL(E, Lv, level, xPos, yPos) * dx2 * dy2 + envTexelL(E, Lv, level, xPos, yPos + 1) * dx2 * dy1
-         + envTexelL(E, Lv, level, xPos + 1, yPos) * dx1 * dy2 + envTexelL(E, Lv, level, xPos + 1, yPos + 1) * dx1 * dy1;
+    return mipTexel(texels, Lv, level, xPos, yPos) * dx2 * dy2 + mipTexel(texels, Lv, level, xPos, yPos + 1) * dx2 * dy1
+         + mipTexel(texels, Lv, level, xPos + 1, yPos) * dx1 * dy2 + mipTexel(texels, Lv, level, xPos + 1, yPos + 1) * dx1 * dy1;
 }
 DV float mtsLog2(float value) {   /* math.cpp:103-106 */
     const float invLn2 = 1.0f / pm_logf(2.0f);
     return pm_logf(value) * invLn2;
 }
-DV V3 envEWA(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv, float A, float B, float C) {   /* mipmap.h:780-833 */
+DV V3 mipEWA(const float4 *texels, const DevMipLevels &Lv, int level, const V2 &uv, float A, float B, float C) {   /* mipmap.h:780-833 */
     if (!isfinite(A + B + C + uv.x + uv.y)) return V3(0.0f);
-    if (level >= Lv.nLevels) return envBoxL(E, Lv, Lv.nLevels - 1, uv);
+    if (level >= Lv.nLevels) return mipBox(texels, Lv, Lv.nLevels - 1, uv);
     const float u = uv.x * Lv.lw[level] - 0.5f;
     const float v = uv.y * Lv.lh[level] - 0.5f;
     const float ratioX = (float) Lv.lw[level] / (float) Lv.lw[0], ratioY = (float) Lv.lh[level] / (float) Lv.lh[0];
@@ -352,6 +415,9 @@ DV V3 envEWA(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv
                 deltaV = 2.0f * sqrtf(A * invDet);
     const int u0 = (int) ceilf(u - deltaU), u1 = (int) floorf(u + deltaU);
     const int v0 = (int) ceilf(v - deltaV), v1 = (int) floorf(v + deltaV);
+    /* (level selection bounds the footprint to ~2 x maxAnisotropy texels per axis; anything far beyond that is garbage input,
+       e.g. a NaN that slipped through: do not loop over it) */
+    if ((long) u1 - u0 > 4096 || (long) v1 - v0 > 4096) return mipBilinear(texels, Lv, level, uv);
     const float As = A * 64, Bs = B * 64, Cs = C * 64;
     V3 result(0.0f);
     float denominator = 0.0f;
@@ -365,7 +431,7 @@ DV V3 envEWA(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv
                 const uint32_t qi = (uint32_t) q;
                 if (qi < 64) {
                     const float weight = Lv.weightLut[(int) q];
-                    result = result + envTexelL(E, Lv, level, ut, vt) * weight;
+                    result = result + mipTexel(texels, Lv, level, ut, vt) * weight;
                     denominator += weight;
                 }
             }
@@ -373,11 +439,13 @@ DV V3 envEWA(const DevEnvMap &E, const DevEnvLevels &Lv, int level, const V2 &uv
             dq += ddq;
         }
     }
-    if (denominator == 0) return envBilinearL(E, Lv, level, uv);
+    if (denominator == 0) return mipBilinear(texels, Lv, level, uv);
     return result / denominator;
 }
-DV V3 envFiltered(const DevEnvMap &E, const DevEnvLevels &Lv, const V2 &uv, const V2 &d0, const V2 &d1) {   /* mipmap.h:629-712, EEWA, maxAnisotropy 10 */
-    const float maxAnisotropy = 10.0f;
+DV V3 mipEval(const float4 *texels, const DevMipLevels &Lv, const V2 &uv, const V2 &d0, const V2 &d1) {   /* MIPMap::eval, mipmap.h:629-712 */
+    if (Lv.filterType == PHIP_FILTER_NEAREST) return mipBox(texels, Lv, 0, uv);
+    if (Lv.filterType == PHIP_FILTER_BILINEAR) return mipBilinear(texels, Lv, 0, uv);
+    const float maxAnisotropy = Lv.maxAnisotropy;
     const float du0 = d0.x * Lv.lw[0], dv0 = d0.y * Lv.lh[0], du1 = d1.x * Lv.lw[0], dv1 = d1.y * Lv.lh[0];
     float A = dv0 * dv0 + dv1 * dv1,
           B = -2.0f * (du0 * dv0 + du1 * dv1),
@@ -388,12 +456,12 @@ DV V3 envFiltered(const DevEnvMap &E, const DevEnvLevels &Lv, const V2 &uv, cons
                 Cprime = 0.5f * (A + C + root),
                 majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0;
     float minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
-    if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+    if (Lv.filterType == PHIP_FILTER_TRILINEAR || !(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
         const float level = mtsLog2(smax(majorRadius, PT_EPSILON));
         const int ilevel = (int) floorf(level);
-        if (ilevel < 0) return envBilinearL(E, Lv, 0, uv);
+        if (ilevel < 0) return mipBilinear(texels, Lv, 0, uv);
         const float a = level - ilevel;
-        return envBilinearL(E, Lv, ilevel, uv) * (1.0f - a) + envBilinearL(E, Lv, ilevel + 1, uv) * a;
+        return mipBilinear(texels, Lv, ilevel, uv) * (1.0f - a) + mipBilinear(texels, Lv, ilevel + 1, uv) * a;
     }
     if (minorRadius * maxAnisotropy < majorRadius) {
         minorRadius = majorRadius / maxAnisotropy;
@@ -413,19 +481,19 @@ DV V3 envFiltered(const DevEnvMap &E, const DevEnvLevels &Lv, const V2 &uv, cons
     const int ilevel = (int) level;
     const float a = level - ilevel;
     if (majorRadius < 1 || !(A > 0 && C > 0))
-        return envBilinearL(E, Lv, ilevel, uv);
-    return envEWA(E, Lv, ilevel, uv, A, B, C) * (1.0f - a) + envEWA(E, Lv, ilevel + 1, uv, A, B, C) * a;
+        return mipBilinear(texels, Lv, ilevel, uv);
+    return mipEWA(texels, Lv, ilevel, uv, A, B, C) * (1.0f - a) + mipEWA(texels, Lv, ilevel + 1, uv, A, B, C) * a;
 }
 /* EnvironmentMap::evalEnvironment for a ray WITH differentials (envmap.cpp:380-409) */
 DV V3 envmapEvalDiff(const DevEnvMap &E, const V3 &rayD, const V3 &rxDirection, const V3 &ryDirection) {
-    const DevEnvLevels &Lv = *E.levels;
+    const DevMipLevels &Lv = *E.levels;
     const V3 v = xform3(E.toLocal, rayD);
     const V2 uv = envDirToUV(v);
     const V3 dvdx = xform3(E.toLocal, rxDirection) - v, dvdy = xform3(E.toLocal, ryDirection) - v;
     const float t1 = PT_INV_TWOPI / (v.x * v.x + v.z * v.z),
                 t2 = -PT_INV_PI / smax(safe_sqrt(1.0f - v.y * v.y), PT_EPSILON);
     const V2 dudx(t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y), dudy(t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y);
-    return envFiltered(E, Lv, uv, dudx, dudy) * E.scale;
+    return mipEval(E.texels, Lv, uv, dudx, dudy) * E.scale;
 }
 
 /* EnvironmentMap::sampleReuse, envmap.cpp:657-662 (std::lower_bound over size + 1 entries) */
@@ -545,6 +613,16 @@ template <bool ENV> DV float pdfEmitterDirectDot(const DevScene &S, const Emitte
 }
 DV float pdfEmitterDirect(const DevScene &S, const EmitterTab &T, const DirectRec &dRec) {
     return pdfEmitterDirectDot<true>(S, T, (uint32_t) dRec.emitter, dRec.d, dot(dRec.d, dRec.refN), dRec.refN.isZero(), dot(dRec.d, dRec.n), dRec.dist);
+}
+
+/* `bitmap` texture: Texture2D::eval (texture.cpp:112-121) over BitmapTexture::eval (bitmap.cpp:431-454,486-499);
+   id = texture id; partials = the vertex has UV partials (first path vertex: camera-ray differentials) */
+DV V3 textureEval(const DevScene &S, uint32_t id, const V2 &itsUV, bool partials, float dudx, float dudy, float dvdx, float dvdy) {
+    const DevMipLevels &Lv = S.textures[id];
+    const V2 uv(itsUV.x * Lv.uvScale[0] + Lv.uvOffset[0], itsUV.y * Lv.uvScale[1] + Lv.uvOffset[1]);
+    if (partials)
+        return mipEval(S.texTexels, Lv, uv, V2(dudx * Lv.uvScale[0], dvdx * Lv.uvScale[1]), V2(dudy * Lv.uvScale[0], dvdy * Lv.uvScale[1]));
+    return Lv.filterType != PHIP_FILTER_NEAREST ? mipBilinear(S.texTexels, Lv, 0, uv) : mipBox(S.texTexels, Lv, 0, uv);
 }
 
 /* ======================================================================================
@@ -722,12 +800,12 @@ enum { MM_ROUGH = 1, MM_DIELECTRIC = 2, MM_ALL = 3 };
 /* one-sided leaf models; wi.z sign already resolved by the twosided adapter.
    leafEvalPdf = eval() and pdf() of the same (wi, wo) pair in one pass (diffuse.cpp:110-133,
    roughconductor.cpp:253-337): the two share H, D and G1(wi). */
-template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &wi, const V3 &wo, float &pdf) {
+template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &albedo, const V3 &wi, const V3 &wo, float &pdf) {
     pdf = 0.0f;
     if (M.type == PHIP_BSDF_DIFFUSE) {
         if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
         pdf = PT_INV_PI * cosTheta(wo);
-        return rgb(M.refl) * (PT_INV_PI * cosTheta(wo));
+        return albedo * (PT_INV_PI * cosTheta(wo));
     } else if ((MM & MM_ROUGH) && M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
         V3 H = normalize(wo + wi);
@@ -746,13 +824,13 @@ template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &wi, const V3
     }
     return V3(0.0f);
 }
-template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &wi, const V2 &smp, BSDFSample &bs) {
+template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const V3 &wi, const V2 &smp, BSDFSample &bs) {
     bs.eta = 1.0f; bs.delta = false; bs.pdf = 0.0f; bs.wo = V3(0.0f);
     if (M.type == PHIP_BSDF_DIFFUSE) {
         if (cosTheta(wi) <= 0) return V3(0.0f);
         bs.wo = squareToCosineHemisphere(smp);
         bs.pdf = PT_INV_PI * cosTheta(bs.wo);
-        return rgb(M.refl);
+        return albedo;
     } else if ((MM & MM_ROUGH) && M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         if (cosTheta(wi) < 0) return V3(0.0f);
         MF distr(M);
@@ -793,7 +871,7 @@ template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &wi, const V2 
    vertex all see the same wi, so they share the nested model and the flip.  (eval/pdf pick nested0 for
    cosTheta(wi) > 0 and sample for cosTheta(wi) >= 0; at exactly 0 every wrapped model's eval/pdf is zero
    on either side, so one rule serves all three.) */
-struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip; };
+struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip; V3 albedo; /* diffuse reflectance at this vertex: the constant, or the texture value k_shade puts here */ };
 DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
     BsdfCtx c; c.leaf = &M; c.wi = wi; c.flip = false;
     if (M.type == PHIP_BSDF_TWOSIDED) {
@@ -801,6 +879,7 @@ DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
         c.leaf = S.materials + (c.flip ? M.nested1 : M.nested0);
         if (c.flip) c.wi.z = -wi.z;
     }
+    c.albedo = rgb(c.leaf->refl);
     return c;
 }
 /* same, from a shading record (front/back already are the nested models) */
@@ -809,14 +888,15 @@ DV BsdfCtx bsdfResolve(const DevMaterial *materials, const Isect &its) {
     c.flip = (its.flags & TS_TWOSIDED) && cosTheta(its.wi) < 0;
     c.leaf = materials + (c.flip ? its.back : its.front);
     if (c.flip) c.wi.z = -its.wi.z;
+    c.albedo = rgb(c.leaf->refl);
     return c;
 }
 template <int MM> DV V3 bsdfEvalPdf(const BsdfCtx &c, V3 wo, float &pdf) {
     if (c.flip) wo.z = -wo.z;
-    return leafEvalPdf<MM>(*c.leaf, c.wi, wo, pdf);
+    return leafEvalPdf<MM>(*c.leaf, c.albedo, c.wi, wo, pdf);
 }
 template <int MM> DV V3 bsdfSample(const BsdfCtx &c, const V2 &smp, BSDFSample &bs) {
-    V3 result = leafSample<MM>(*c.leaf, c.wi, smp, bs);
+    V3 result = leafSample<MM>(*c.leaf, c.albedo, c.wi, smp, bs);
     if (c.flip && !result.isZero() && bs.pdf != 0)
         bs.wo.z = -bs.wo.z;
     return result;

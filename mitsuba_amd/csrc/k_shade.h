@@ -17,9 +17,10 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
 #endif
-/* ENV: the scene has an environment emitter (constant / envmap); MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
+/* FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures; MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
    normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
-template <int MM, bool STRICT, bool ENV> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+    constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0;
     __shared__ uint32_t waveCnt[BLOCK / 64];
     if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
@@ -131,6 +132,7 @@ template <int MM, bool STRICT, bool ENV> __global__ __launch_bounds__(BLOCK, MM 
                         thr = thr / q;
                 }
             }
+            const bool firstVertex = (flags & F_FIRST) != 0;
             flags &= ~F_FIRST;
 
             /* ---- head of the loop for this vertex, path.cpp:135-165 ---- */
@@ -156,7 +158,23 @@ template <int MM, bool STRICT, bool ENV> __global__ __launch_bounds__(BLOCK, MM 
                 dRec.ref = its.p;
                 dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
                 dRec.pdf = 0; dRec.emitter = -1;
-                const BsdfCtx bctx = bsdfResolve(materials, its);
+                BsdfCtx bctx = bsdfResolve(materials, its);
+                if (TEX && bctx.leaf->type == PHIP_BSDF_DIFFUSE && bctx.leaf->reflTexture != 0) {
+                    /* m_reflectance->eval(its): unfiltered level-0 lookup, except at the first vertex, whose UV partials come
+                       from the camera-ray differentials (Intersection::getBSDF(ray) -> computePartials, records.inl:69-75) */
+                    float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
+                    if (firstVertex) {
+                        const uint32_t px = info.y % (uint32_t) S.film.width, py = info.y / (uint32_t) S.film.width;
+                        const U4 hc = pcg4d(info.y, info.z, 0, rc.seed);
+                        V3 rx, ry;
+                        cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
+                        rx = rayD + (rx - rayD) * rc.diffScaleFactor;
+                        ry = rayD + (ry - rayD) * rc.diffScaleFactor;
+                        const float *cw = S.cam.c2w;
+                        computePartials(its, V3(cw[3], cw[7], cw[11]), rx, ry, dudx, dudy, dvdx, dvdy);
+                    }
+                    bctx.albedo = textureEval(S, bctx.leaf->reflTexture - 1, its.uv, firstVertex, dudx, dudy, dvdx, dvdy);
+                }
                 if (its.flags & TS_MF_SMOOTH) {
                     V3 value = sampleEmitterDirect<ENV>(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
                     if (dRec.pdf != 0 && !value.isZero()) {

@@ -176,7 +176,8 @@ struct phip_scene {
                                         (PHIP_TRAVERSAL=group; measured 2-3x slower: too few rays in flight per CU) */
     DevBuf<DevMaterial> materials;
     DevBuf<float> emitterTab;
-    DevBuf<float4> envTexels; DevBuf<DevEnvLevels> envLevels; DevBuf<float> envCdfRows, envCdfCols, envRowWeights;     /* `envmap` emitter */
+    DevBuf<float4> texTexels; DevBuf<DevMipLevels> texDesc; bool hasTextures = false; uint32_t triShadeStride = TRISHADE_FLOAT4S;   /* bitmap textures */
+    DevBuf<float4> envTexels; DevBuf<DevMipLevels> envLevels; DevBuf<float> envCdfRows, envCdfCols, envRowWeights;     /* `envmap` emitter */
     DevScene dev;
     /* render-time buffers (grown on demand, reused between calls) */
     DevBuf<float4> rayO, rayD, hit, thr, shadow, L, sampleOut;
@@ -197,7 +198,7 @@ struct phip_scene {
     hipStream_t stream = nullptr;
 };
 
-static std::vector<DevMaterial> convertMaterials(const phip_material *materials, uint32_t nMaterials) {
+static std::vector<DevMaterial> convertMaterials(const phip_material *materials, uint32_t nMaterials, const std::vector<float> *textureMax = nullptr) {
     if (nMaterials && !materials) throw std::runtime_error("materials is NULL");
     std::vector<DevMaterial> mats(nMaterials);
     for (uint32_t i = 0; i < nMaterials; ++i) {
@@ -209,7 +210,12 @@ static std::vector<DevMaterial> convertMaterials(const phip_material *materials,
         o.distribution = m.distribution; o.sampleVisible = m.sample_visible ? 1 : 0;
         switch (m.type) {
             case PHIP_BSDF_DIFFUSE: {
-                const float mx = std::max(m.reflectance[0], std::max(m.reflectance[1], m.reflectance[2]));
+                float mx = std::max(m.reflectance[0], std::max(m.reflectance[1], m.reflectance[2]));
+                if (m.reflectance_texture != 0) {            /* m_reflectance->getMaximum().max() of the bitmap */
+                    if (!textureMax || m.reflectance_texture > textureMax->size()) throw std::runtime_error("material texture id out of range");
+                    mx = (*textureMax)[m.reflectance_texture - 1];
+                    o.reflTexture = m.reflectance_texture;
+                }
                 if (mx > 1.0f) throw std::runtime_error("diffuse reflectance > 1 (ensureEnergyConservation, diffuse.cpp:95)");
                 if (mx > 0) o.flags |= MF_SMOOTH;            /* component list empty otherwise, diffuse.cpp:97-100 */
             } break;
@@ -264,8 +270,9 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         if (s.has_normals && !d.normals) throw std::runtime_error("shape has_normals but normals is NULL");
         expect += s.n_triangles;
         DevShape &o = shapes[i];
+        if (s.has_texcoords && !d.texcoords) throw std::runtime_error("shape has_texcoords but texcoords is NULL");
         o.material = s.material; o.emitter = s.emitter; o.hasNormals = s.has_normals ? 1 : 0;
-        o.firstTri = s.first_triangle; o.nTris = s.n_triangles; o.cdfOffset = 0; o.invSurfaceArea = 0; o.pad = 0;
+        o.firstTri = s.first_triangle; o.nTris = s.n_triangles; o.cdfOffset = 0; o.invSurfaceArea = 0; o.pad = s.has_texcoords ? 1 : 0;    /* pad: the mesh has texture coordinates */
         for (uint32_t j = 0; j < s.n_triangles; ++j) triShape[s.first_triangle + j] = i;
         if (s.emitter >= 0) {
             /* TriMesh::prepareSamplingTable, trimesh.cpp:388-404 + DiscreteDistribution::normalize */
@@ -289,8 +296,43 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     }
     if (expect != d.n_triangles) throw std::runtime_error("shape triangle ranges do not cover the index array");
 
+    /* bitmap textures: every pyramid (as delivered) in one float4 texel array + one descriptor each */
+    std::vector<float4> texTexels; std::vector<DevMipLevels> texDesc(d.n_textures); std::vector<float> texMax(d.n_textures, 0.0f);
+    if (d.n_textures && !d.textures) throw std::runtime_error("textures is NULL");
+    for (uint32_t i = 0; i < d.n_textures; ++i) {
+        const phip_texture &t = d.textures[i];
+        if (t.width == 0 || t.height == 0 || !t.levels[0]) throw std::runtime_error("texture without level 0");
+        if (t.wrap_u > PHIP_WRAP_ONE || t.wrap_v > PHIP_WRAP_ONE || t.filter_type > PHIP_FILTER_EWA) throw std::runtime_error("bad texture wrap mode / filter type");
+        DevMipLevels &lv = texDesc[i]; memset(&lv, 0, sizeof(lv));
+        int sx = (int) t.width, sy = (int) t.height, n = 1;
+        lv.lw[0] = sx; lv.lh[0] = sy;
+        if (t.n_levels > 1) {
+            while (sx > 1 || sy > 1) {
+                sx = std::max(1, (sx + 1) / 2); sy = std::max(1, (sy + 1) / 2);
+                if (n >= PHIP_MIP_MAX_LEVELS) throw std::runtime_error("texture: too many MIP levels");
+                lv.lw[n] = sx; lv.lh[n] = sy; ++n;
+            }
+            if ((uint32_t) n != t.n_levels) throw std::runtime_error("texture: n_levels must be 1 or the complete pyramid down to 1x1");
+        }
+        lv.nLevels = n;
+        for (int l = 0; l < n; ++l) {
+            if (!t.levels[l]) throw std::runtime_error("texture: level pointer is NULL");
+            lv.offset[l] = (uint32_t) texTexels.size();
+            const size_t cnt = (size_t) lv.lw[l] * lv.lh[l];
+            for (size_t k = 0; k < cnt; ++k) {
+                const float *c = t.levels[l] + 3 * k;
+                texTexels.push_back(make_float4(c[0], c[1], c[2], 0.0f));
+                if (l == 0) texMax[i] = std::max(texMax[i], std::max(c[0], std::max(c[1], c[2])));
+            }
+        }
+        if (texTexels.size() >= (1ull << 32)) throw std::runtime_error("textures too large");
+        lv.bcu = t.wrap_u; lv.bcv = t.wrap_v; lv.filterType = t.filter_type; lv.maxAnisotropy = t.max_anisotropy;
+        lv.uvScale[0] = t.uv_scale[0]; lv.uvScale[1] = t.uv_scale[1]; lv.uvOffset[0] = t.uv_offset[0]; lv.uvOffset[1] = t.uv_offset[1];
+        for (int k = 0; k < 64; ++k) { const float r2 = (float) k / 63.0f; lv.weightLut[k] = pm_expf(-2.0f * r2) - pm_expf(-2.0f); }
+    }
+
     /* materials */
-    std::vector<DevMaterial> mats = convertMaterials(d.materials, d.n_materials);
+    std::vector<DevMaterial> mats = convertMaterials(d.materials, d.n_materials, &texMax);
 
     /* emitters + selection pdf, scene.cpp:375-381 */
     std::vector<DevEmitter> ems(d.n_emitters);
@@ -324,7 +366,10 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     HIP_TRY(hipSetDevice(sc->device));
     /* shading records (dv_scene.h): the per-triangle constants come from the same __host__ __device__
        functions the kernel would run, so precomputing them does not change a single bit */
-    std::vector<float4> ts((size_t) TRISHADE_FLOAT4S * d.n_triangles);
+    bool anyTexcoords = false;
+    for (uint32_t i = 0; i < d.n_shapes; ++i) anyTexcoords |= d.shapes[i].has_texcoords != 0;
+    const uint32_t stride = anyTexcoords ? TRISHADE_FLOAT4S_UV : TRISHADE_FLOAT4S;
+    std::vector<float4> ts((size_t) stride * d.n_triangles, make_float4(0, 0, 0, 0));
     for (uint32_t i = 0; i < d.n_triangles; ++i) {
         const DevShape &sh = shapes[triShape[i]];
         const DevMaterial &m = mats[sh.material];
@@ -332,21 +377,43 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         const V3 p0(d.positions[3 * ix[0]], d.positions[3 * ix[0] + 1], d.positions[3 * ix[0] + 2]);
         const V3 p1(d.positions[3 * ix[1]], d.positions[3 * ix[1] + 1], d.positions[3 * ix[1] + 2]);
         const V3 p2(d.positions[3 * ix[2]], d.positions[3 * ix[2] + 1], d.positions[3 * ix[2] + 2]);
-        const bool twosided = m.type == PHIP_BSDF_TWOSIDED;
+        const bool twosided = m.type == PHIP_BSDF_TWOSIDED, texcoords = sh.pad != 0;
         const uint32_t front = twosided ? m.nested0 : sh.material, back = twosided ? m.nested1 : sh.material;
-        uint32_t flags = (sh.hasNormals ? TS_VERTEX_NORMALS : 0u) | (twosided ? TS_TWOSIDED : 0u)
+        uint32_t flags = (sh.hasNormals ? TS_VERTEX_NORMALS : 0u) | (twosided ? TS_TWOSIDED : 0u) | (texcoords ? TS_TEXCOORDS : 0u)
                        | ((m.flags & MF_SMOOTH) ? TS_MF_SMOOTH : 0u) | ((m.flags & MF_TRANS_OR_BACK) ? TS_TRANS_OR_BACK : 0u);
+        const V3 side1(p1 - p0), side2(p2 - p0);
+        V3 dpdu = side1, dpdv = side2;                      /* skdtree.h:378-379 */
+        float4 *r = ts.data() + (size_t) stride * i;
+        if (texcoords) {
+            /* TriMesh::computeUVTangents, trimesh.cpp:683-735 (zero tangents for degenerate triangles) */
+            const float *t0 = d.texcoords + 2 * (size_t) ix[0], *t1 = d.texcoords + 2 * (size_t) ix[1], *t2 = d.texcoords + 2 * (size_t) ix[2];
+            dpdu = V3(0.0f); dpdv = V3(0.0f);
+            const V2 dUV1(t1[0] - t0[0], t1[1] - t0[1]), dUV2(t2[0] - t0[0], t2[1] - t0[1]);
+            const V3 n = cross(side1, side2);
+            const float length = n.length();
+            if (length != 0) {
+                const float determinant = dUV1.x * dUV2.y - dUV1.y * dUV2.x;
+                if (determinant == 0) {
+                    coordinateSystem(n / length, dpdu, dpdv);
+                } else {
+                    const float invDet = 1.0f / determinant;
+                    dpdu = (side1 * dUV2.y - side2 * dUV1.y) * invDet;
+                    dpdv = (side1 * (-dUV2.x) + side2 * dUV1.x) * invDet;
+                }
+            }
+            r[6] = make_float4(t0[0], t0[1], t1[0], t1[1]);
+            r[7] = make_float4(t2[0], t2[1], dpdu.x, dpdu.y);
+            r[8] = make_float4(dpdu.z, dpdv.x, dpdv.y, dpdv.z);
+        }
         V3 a, b, c;
         if (sh.hasNormals) {
             a = V3(d.normals[3 * ix[0]], d.normals[3 * ix[0] + 1], d.normals[3 * ix[0] + 2]);
             b = V3(d.normals[3 * ix[1]], d.normals[3 * ix[1] + 1], d.normals[3 * ix[1] + 2]);
             c = V3(d.normals[3 * ix[2]], d.normals[3 * ix[2] + 1], d.normals[3 * ix[2] + 2]);
         } else {
-            const V3 side1(p1 - p0), side2(p2 - p0);
-            Frame f; triShadingFrame(triFaceNormal(side1, side2), side1, f);
+            Frame f; triShadingFrame(triFaceNormal(side1, side2), dpdu, f);
             a = f.n; b = f.s; c = f.t;
         }
-        float4 *r = ts.data() + (size_t) TRISHADE_FLOAT4S * i;
         r[0] = make_float4(p0.x, p0.y, p0.z, pm_from_bits(front));
         r[1] = make_float4(p1.x, p1.y, p1.z, pm_from_bits(back));
         r[2] = make_float4(p2.x, p2.y, p2.z, pm_from_bits((uint32_t) sh.emitter));
@@ -354,7 +421,10 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         r[4] = make_float4(b.x, b.y, b.z, 0.0f);
         r[5] = make_float4(c.x, c.y, c.z, 0.0f);
     }
-    if (ts.empty()) sc->triShade.alloc(TRISHADE_FLOAT4S); else sc->triShade.upload(ts.data(), ts.size());
+    if (ts.empty()) sc->triShade.alloc(TRISHADE_FLOAT4S_UV); else sc->triShade.upload(ts.data(), ts.size());
+    if (texTexels.empty()) sc->texTexels.alloc(1); else sc->texTexels.upload(texTexels.data(), texTexels.size());
+    if (texDesc.empty()) sc->texDesc.alloc(1); else sc->texDesc.upload(texDesc.data(), texDesc.size());
+    sc->hasTextures = d.n_textures > 0; sc->triShadeStride = stride;
     if (sc->bvh.nodes.empty()) sc->nodes.alloc(8);
     else sc->nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
     if (sc->bvh.nodes8.empty()) sc->nodes8.alloc(16);
@@ -396,8 +466,10 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         for (uint32_t i = 0; i < d.n_emitters; ++i) {
             if (!isArea(i)) continue;
             const DevShape &sh = shapes[ems[i].shape];
-            const float *src = (const float *) (ts.data() + (size_t) TRISHADE_FLOAT4S * sh.firstTri);
-            tab.insert(tab.end(), src, src + (size_t) sh.nTris * 4 * TRISHADE_FLOAT4S);
+            for (uint32_t k = 0; k < sh.nTris; ++k) {       /* the first six float4s of each record (positions, normal / vertex normals) */
+                const float *src = (const float *) (ts.data() + (size_t) stride * (sh.firstTri + k));
+                tab.insert(tab.end(), src, src + 4 * TRISHADE_FLOAT4S);
+            }
         }
     }
     if (tab.size() >= (1ull << 31)) throw std::runtime_error("emitter table too large");
@@ -407,6 +479,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     memset(&D, 0, sizeof(D));
     D.nodes = sc->nodes.p; D.nodes8 = sc->nodes8.p; D.tris = sc->tris.p; D.triShade = sc->triShade.p;
     D.materials = sc->materials.p; D.nMaterials = (uint32_t) mats.size();
+    D.texTexels = sc->texTexels.p; D.textures = sc->texDesc.p; D.triShadeStride = sc->triShadeStride;
     D.emitterTab = sc->emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
     D.envEmitter = envEmitter;
@@ -437,8 +510,9 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         std::vector<float4> tex((size_t) w * h);
         for (size_t i = 0; i < tex.size(); ++i) tex[i] = make_float4(e.texels[3 * i], e.texels[3 * i + 1], e.texels[3 * i + 2], 0.0f);
         /* MIP pyramid (level sizes of mipmap.h:182-192) + EWA weight table (mipmap.h:296-301) */
-        DevEnvLevels lv; memset(&lv, 0, sizeof(lv));
+        DevMipLevels lv; memset(&lv, 0, sizeof(lv));
         lv.nLevels = 1; lv.lw[0] = w; lv.lh[0] = h; lv.offset[0] = 0;
+        lv.bcu = PHIP_WRAP_REPEAT; lv.bcv = PHIP_WRAP_CLAMP; lv.filterType = PHIP_FILTER_EWA; lv.maxAnisotropy = 10.0f;   /* envmap.cpp:138-139,176-178 */
         if (e.n_levels > 1) {
             int sx = w, sy = h, n = 1;
             while (sx > 1 || sy > 1) {
@@ -694,10 +768,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             {
                 typedef void (*ShadeKernel)(DevScene, PathPool, RenderConst, float4 *);
-#define SHADE_ROW(S_, E_) { k_shade<0, S_, E_>, k_shade<MM_ROUGH, S_, E_>, k_shade<MM_DIELECTRIC, S_, E_>, k_shade<MM_ALL, S_, E_> }
-                static const ShadeKernel table[2][2][4] = { { SHADE_ROW(false, false), SHADE_ROW(true, false) }, { SHADE_ROW(false, true), SHADE_ROW(true, true) } };
+#define SHADE_ROW(S_, F_) { k_shade<0, S_, F_>, k_shade<MM_ROUGH, S_, F_>, k_shade<MM_DIELECTRIC, S_, F_>, k_shade<MM_ALL, S_, F_> }
+                static const ShadeKernel table[4][2][4] = { { SHADE_ROW(false, 0), SHADE_ROW(true, 0) }, { SHADE_ROW(false, 1), SHADE_ROW(true, 1) },
+                                                            { SHADE_ROW(false, 2), SHADE_ROW(true, 2) }, { SHADE_ROW(false, 3), SHADE_ROW(true, 3) } };
 #undef SHADE_ROW
-                hipLaunchKernelGGL(table[D.envEmitter >= 0 ? 1 : 0][rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
+                const int feat = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0);     /* environment emitter, bitmap textures */
+                hipLaunchKernelGGL(table[feat][rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
             }
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (merged) {

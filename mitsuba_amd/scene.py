@@ -74,6 +74,8 @@ class SceneBuilder:
         self.shapes = []         # dicts
         self.materials = []      # phip_material
         self.emitters = []       # dicts
+        self.uvs = []            # list of (n,2) float32 or None
+        self.textures = []       # dicts
         self.camera = None
         self.film = None
         self._keep = []
@@ -83,11 +85,27 @@ class SceneBuilder:
         self.materials.append(m)
         return len(self.materials) - 1
 
-    def diffuse(self, reflectance=(0.5, 0.5, 0.5)):
+    def diffuse(self, reflectance=(0.5, 0.5, 0.5), texture=None):
+        """`texture` = id returned by bitmap(): <texture type="bitmap" name="reflectance">"""
         m = A.phip_material()
         m.type = A.PHIP_BSDF_DIFFUSE
         m.reflectance[:] = _rgb(reflectance)
+        m.reflectance_texture = 0 if texture is None else texture + 1
         return self._add_material(m)
+
+    def bitmap(self, image, wrap="repeat", wrap_v=None, filter_type="ewa", max_anisotropy=20.0,
+               uscale=1.0, vscale=1.0, uoffset=0.0, voffset=0.0, pyramid=True):
+        """<texture type="bitmap">: `image` = (H, W, 3) float RGB in [0, 1] as the plugin stores MIP level 0; the pyramid
+        comes from `mip_pyramid` (or pass the levels) unless the filter is nearest / bilinear."""
+        wraps = {"repeat": A.PHIP_WRAP_REPEAT, "clamp": A.PHIP_WRAP_CLAMP, "mirror": A.PHIP_WRAP_MIRROR, "zero": A.PHIP_WRAP_ZERO, "one": A.PHIP_WRAP_ONE}
+        filters = {"nearest": A.PHIP_FILTER_NEAREST, "bilinear": A.PHIP_FILTER_BILINEAR, "trilinear": A.PHIP_FILTER_TRILINEAR, "ewa": A.PHIP_FILTER_EWA}
+        t = np.ascontiguousarray(image, dtype=np.float32)
+        assert t.ndim == 3 and t.shape[2] == 3
+        need = filter_type in ("trilinear", "ewa")          # mipmap.h:182-192: nearest / bilinear keep a single level
+        levels = (mip_pyramid(t) if pyramid is True else [t] + [np.ascontiguousarray(l, np.float32) for l in pyramid[1:]]) if need else [t]
+        self.textures.append({"levels": levels, "wrap_u": wraps[wrap], "wrap_v": wraps[wrap_v or wrap], "filter": filters[filter_type],
+                              "aniso": float(max_anisotropy), "scale": (float(uscale), float(vscale)), "offset": (float(uoffset), float(voffset))})
+        return len(self.textures) - 1
 
     def dielectric(self, int_ior=1.5046, ext_ior=1.000277, specular_reflectance=1.0, specular_transmittance=1.0):
         """defaults: intIOR bk7, extIOR air (src/bsdfs/dielectric.cpp:149-152, ior.h)"""
@@ -121,7 +139,7 @@ class SceneBuilder:
         return self._add_material(m)
 
     # ---- shapes ------------------------------------------------------------------------
-    def mesh(self, positions, triangles, material, normals=None, radiance=None, sampling_weight=1.0):
+    def mesh(self, positions, triangles, material, normals=None, radiance=None, sampling_weight=1.0, uvs=None):
         positions = _f32(positions).reshape(-1, 3)
         triangles = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
         if normals is not None:
@@ -132,6 +150,10 @@ class SceneBuilder:
         if radiance is not None:
             emitter = len(self.emitters)
             self.emitters.append({"radiance": _rgb(radiance), "weight": sampling_weight, "shape": sid})
+        if uvs is not None:
+            uvs = _f32(uvs).reshape(-1, 2)
+            assert len(uvs) == len(positions)
+        self.uvs.append(uvs)
         self.positions.append(positions)
         self.normals.append(normals)
         self.indices.append(triangles)
@@ -157,14 +179,20 @@ class SceneBuilder:
                               "type": A.PHIP_EMITTER_ENVMAP})
         return len(self.emitters) - 1
 
-    def quad(self, p0, p1, p2, p3, material, facing=None, radiance=None):
+    def quad(self, p0, p1, p2, p3, material, facing=None, radiance=None, uvs=None):
         """Two triangles (0,1,2),(2,3,0) like Rectangle::createTriMesh (rectangle.cpp:170-203);
-        if `facing` is given the winding is flipped so the face normal points that way."""
+        if `facing` is given the winding is flipped so the face normal points that way.  uvs=True: the rectangle's
+        own parameterisation (0,0) (1,0) (1,1) (0,1); or four (u, v) pairs."""
         P = _f32([p0, p1, p2, p3])
+        if uvs is True:
+            uvs = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        U = _f32(uvs) if uvs is not None else None
         n = np.cross(P[1] - P[0], P[2] - P[0])
         if facing is not None and np.dot(n, np.asarray(facing, np.float32)) < 0:
             P = P[::-1].copy()
-        return self.mesh(P, [[0, 1, 2], [2, 3, 0]], material, radiance=radiance)
+            if U is not None:
+                U = U[::-1].copy()
+        return self.mesh(P, [[0, 1, 2], [2, 3, 0]], material, radiance=radiance, uvs=U)
 
     # ---- sensor / film ------------------------------------------------------------------
     def perspective(self, origin, target, up, fov_x_deg, near=1e-2, far=1e4):
@@ -204,6 +232,7 @@ class SceneBuilder:
             sh.first_triangle, sh.n_triangles = t0, len(t)
             sh.material, sh.emitter = s["material"], s["emitter"]
             sh.has_normals = 1 if self.normals[i] is not None else 0
+            sh.has_texcoords = 1 if self.uvs[i] is not None else 0
             v0 += len(p)
             t0 += len(t)
         idx = np.ascontiguousarray(np.concatenate(idx), dtype=np.uint32) if idx else np.zeros((0, 3), np.uint32)
@@ -224,6 +253,20 @@ class SceneBuilder:
         d.n_materials, d.materials = len(self.materials), mats
         d.n_emitters, d.emitters = len(self.emitters), ems
         d.camera, d.film = self.camera, self.film
+        tcs = None
+        if any(u is not None for u in self.uvs):
+            tcs = np.ascontiguousarray(np.concatenate([u if u is not None else np.zeros((len(p), 2), np.float32) for u, p in zip(self.uvs, self.positions)]), np.float32)
+            d.texcoords = tcs.ctypes.data_as(C.POINTER(C.c_float))
+        texs = (A.phip_texture * max(1, len(self.textures)))()
+        for i, t in enumerate(self.textures):
+            lv = t["levels"]
+            texs[i].height, texs[i].width = lv[0].shape[0], lv[0].shape[1]
+            texs[i].n_levels = len(lv)
+            for j, l in enumerate(lv):
+                texs[i].levels[j] = l.ctypes.data_as(C.POINTER(C.c_float))
+            texs[i].wrap_u, texs[i].wrap_v, texs[i].filter_type, texs[i].max_anisotropy = t["wrap_u"], t["wrap_v"], t["filter"], t["aniso"]
+            texs[i].uv_scale[:] = t["scale"]; texs[i].uv_offset[:] = t["offset"]
+        d.n_textures, d.textures = len(self.textures), texs
         env = getattr(self, "_envmap", None)
         if env is not None:
             t, scale, m, levels = env
@@ -234,7 +277,7 @@ class SceneBuilder:
             d.envmap.height, d.envmap.width = t.shape[0], t.shape[1]
             d.envmap.scale = scale
             d.envmap.to_world[:] = [float(v) for v in m.reshape(-1)]
-        d._keep = (pos, nrm, idx, shapes, mats, ems, env)   # keep the buffers alive with the struct
+        d._keep = (pos, nrm, idx, shapes, mats, ems, env, tcs, texs, [t["levels"] for t in self.textures])   # keep the buffers alive with the struct
         return d
 
     @property

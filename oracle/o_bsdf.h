@@ -211,27 +211,35 @@ struct MicrofacetDistribution {
 class BSDF {
 public:
     const Scene &scene;
+    const Intersection *its = nullptr;     /* the vertex being shaded: textures are evaluated there (bRec.its in the reference) */
     explicit BSDF(const Scene &s) : scene(s) {}
 
+    /* m_reflectance->eval(bRec.its): ConstantSpectrumTexture or a `bitmap` texture (texture.cpp:112-121) */
+    Spectrum diffuseReflectance(const Material &M) const {
+        if (M.m.reflectance_texture != 0 && its)
+            return scene.textures[M.m.reflectance_texture - 1].eval(*its);
+        return Spectrum(M.m.reflectance);
+    }
+
     /* ---- diffuse.cpp:110-150 ---- */
-    static Spectrum diffuseEval(const Material &M, const Vec3 &wi, const Vec3 &wo) {
+    Spectrum diffuseEval(const Material &M, const Vec3 &wi, const Vec3 &wo) const {
         if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0)
             return Spectrum(0.0f);
-        return Spectrum(M.m.reflectance) * (ORC_INV_PI * Frame::cosTheta(wo));
+        return diffuseReflectance(M) * (ORC_INV_PI * Frame::cosTheta(wo));
     }
     static Float diffusePdf(const Material &, const Vec3 &wi, const Vec3 &wo) {
         if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0)
             return 0.0f;
         return squareToCosineHemispherePdf(wo);
     }
-    static Spectrum diffuseSample(const Material &M, BSDFSamplingRecord &bRec, Float &pdf, const Vec2 &sample) {
+    Spectrum diffuseSample(const Material &M, BSDFSamplingRecord &bRec, Float &pdf, const Vec2 &sample) const {
         if (Frame::cosTheta(bRec.wi) <= 0)
             return Spectrum(0.0f);
         bRec.wo = squareToCosineHemisphere(sample);
         bRec.eta = 1.0f;
         bRec.sampledDelta = false;
         pdf = squareToCosineHemispherePdf(bRec.wo);
-        return Spectrum(M.m.reflectance);
+        return diffuseReflectance(M);
     }
 
     /* ---- dielectric.cpp:217-226,277-333 ---- */

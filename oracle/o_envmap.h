@@ -14,10 +14,7 @@
  * (envmap.cpp:176-178).
  */
 #pragma once
-#include "o_math.h"
-#include "../include/phip.h"
-#include <vector>
-#include <stdexcept>
+#include "o_mipmap.h"
 
 namespace orc {
 
@@ -32,11 +29,8 @@ inline Float intervalToTent(Float sample) {   /* warp.cpp:143-155 */
 
 struct EnvMap {
     int w = 0, h = 0;
-    std::vector<Spectrum> texels;                         /* level 0 */
-    std::vector<std::vector<Spectrum>> mip;               /* levels 1 .. nLevels-1 */
-    std::vector<int> lw, lh;                              /* level sizes, [0] = (w, h) */
+    MipMap mip;                                           /* ERepeat x EClamp, EWA, maxAnisotropy 10 (envmap.cpp:138-139,176-178) */
     int nLevels = 1;
-    Float weightLut[64];
     Float scale = 1.0f;
     Mat4 toWorld, toLocal;
     std::vector<float> cdfRows, cdfCols;
@@ -57,26 +51,12 @@ struct EnvMap {
         if (!e.texels || e.width == 0 || e.height == 0) throw std::runtime_error("oracle: envmap emitter without texels");
         if (std::max(e.width, e.height) > 0xFFFF) throw std::runtime_error("Environment maps images must be smaller than 65536 pixels in width and height");
         w = (int) e.width; h = (int) e.height; scale = e.scale;
-        texels.resize((size_t) w * h);
-        for (size_t i = 0; i < texels.size(); ++i) texels[i] = Spectrum(e.texels + 3 * i);
-        /* pyramid: mipmap.h:182-192 level sizes */
-        lw.assign(1, w); lh.assign(1, h); nLevels = 1;
-        if (e.n_levels > 1) {
-            int sx = w, sy = h;
-            while (sx > 1 || sy > 1) { sx = std::max(1, (sx + 1) / 2); sy = std::max(1, (sy + 1) / 2); lw.push_back(sx); lh.push_back(sy); }
-            if ((uint32_t) lw.size() != e.n_levels) throw std::runtime_error("oracle: envmap needs 1 level or the complete pyramid");
-            nLevels = (int) lw.size();
-            mip.resize(nLevels);
-            for (int l = 1; l < nLevels; ++l) {
-                if (!e.levels[l]) throw std::runtime_error("oracle: envmap level pointer is NULL");
-                mip[l].resize((size_t) lw[l] * lh[l]);
-                for (size_t i = 0; i < mip[l].size(); ++i) mip[l][i] = Spectrum(e.levels[l] + 3 * i);
-            }
-        }
-        for (int i = 0; i < 64; ++i) {                    /* mipmap.h:296-301 */
-            Float r2 = (Float) i / (Float) 63;
-            weightLut[i] = om::exp(-2.0f * r2) - om::exp(-2.0f);
-        }
+        const float *data[PHIP_ENVMAP_MAX_LEVELS];
+        data[0] = e.texels;
+        for (uint32_t l = 1; l < e.n_levels && l < PHIP_ENVMAP_MAX_LEVELS; ++l) data[l] = e.levels[l];
+        mip.bcu = PHIP_WRAP_REPEAT; mip.bcv = PHIP_WRAP_CLAMP; mip.filterType = PHIP_FILTER_EWA; mip.maxAnisotropy = 10.0f;
+        mip.load(e.width, e.height, e.n_levels > 1 ? e.n_levels : 1, data);
+        nLevels = mip.nLevels;
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) toWorld.m[i][j] = e.to_world[4 * i + j];
         if (!toWorld.invert(toLocal)) throw std::runtime_error("oracle: envmap toWorld is singular");
         configure();
@@ -93,7 +73,7 @@ struct EnvMap {
             Float colSum = 0;
             cdfCols[colPos++] = 0;
             for (int x = 0; x < w; ++x) {
-                Spectrum value(texels[(size_t) y * w + x]);
+                Spectrum value(mip.levels[0][(size_t) y * w + x]);
                 colSum += rgbLuminance(value);
                 cdfCols[colPos++] = (float) colSum;
             }
@@ -117,122 +97,8 @@ struct EnvMap {
         pixelSizeX = 2 * ORC_PI / w; pixelSizeY = ORC_PI / h;
     }
 
-    /* mipmap.h:503-571 with bcu = ERepeat, bcv = EClamp */
-    Spectrum evalTexel(int x, int y) const { return evalTexel(0, x, y); }
-    Spectrum evalTexel(int level, int x, int y) const {
-        const int sw = lw[level], sh = lh[level];
-        if (x < 0 || x >= sw) { int r = x % sw; x = (r < 0) ? r + sw : r; }       /* math::modulo */
-        if (y < 0 || y >= sh) y = std::min(std::max(y, 0), sh - 1);
-        return level == 0 ? texels[(size_t) y * sw + x] : mip[level][(size_t) y * sw + x];
-    }
-    /* mipmap.h:566-569 */
-    Spectrum evalBox(int level, const Vec2 &uv) const {
-        return evalTexel(level, (int) std::floor(uv.x * lw[level]), (int) std::floor(uv.y * lh[level]));
-    }
-    /* mipmap.h:575-596 */
-    Spectrum evalBilinear(int level, const Vec2 &uv) const {
-        if (!std::isfinite(uv.x) || !std::isfinite(uv.y)) return Spectrum(0.0f);
-        if (level >= nLevels) return evalBox(nLevels - 1, uv);
-        Float u = uv.x * lw[level] - 0.5f, v = uv.y * lh[level] - 0.5f;
-        int xPos = (int) std::floor(u), yPos = (int) std::floor(v);
-        Float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
-        return evalTexel(level, xPos, yPos) * dx2 * dy2
-             + evalTexel(level, xPos, yPos + 1) * dx2 * dy1
-             + evalTexel(level, xPos + 1, yPos) * dx1 * dy2
-             + evalTexel(level, xPos + 1, yPos + 1) * dx1 * dy1;
-    }
-    static Float log2f_(Float value) {                    /* math.cpp:103-106 */
-        const Float invLn2 = 1.0f / om::log(2.0f);
-        return om::log(value) * invLn2;
-    }
-    /* mipmap.h:780-833 */
-    Spectrum evalEWA(int level, const Vec2 &uv, Float A, Float B, Float C) const {
-        if (!std::isfinite(A + B + C + uv.x + uv.y)) return Spectrum(0.0f);
-        if (level >= nLevels) return evalBox(nLevels - 1, uv);
-        Float u = uv.x * lw[level] - 0.5f;
-        Float v = uv.y * lh[level] - 0.5f;
-        const Float ratioX = (Float) lw[level] / (Float) lw[0], ratioY = (Float) lh[level] / (Float) lh[0];   /* m_sizeRatio, mipmap.h:273-275 */
-        A /= ratioX * ratioX;
-        B /= ratioX * ratioY;
-        C /= ratioY * ratioY;
-        Float invDet = 1.0f / (-B * B + 4.0f * A * C),
-              deltaU = 2.0f * std::sqrt(C * invDet),
-              deltaV = 2.0f * std::sqrt(A * invDet);
-        int u0 = (int) std::ceil(u - deltaU), u1 = (int) std::floor(u + deltaU);
-        int v0 = (int) std::ceil(v - deltaV), v1 = (int) std::floor(v + deltaV);
-        Float As = A * 64, Bs = B * 64, Cs = C * 64;
-        Spectrum result(0.0f);
-        Float denominator = 0.0f;
-        Float ddq = 2 * As, uu0 = (Float) u0 - u;
-        for (int vt = v0; vt <= v1; ++vt) {
-            const Float vv = (Float) vt - v;
-            Float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv;
-            Float dq = As * (2 * uu0 + 1) + Bs * vv;
-            for (int ut = u0; ut <= u1; ++ut) {
-                if (q < (Float) 64) {
-                    uint32_t qi = (uint32_t) q;
-                    if (qi < 64) {
-                        const Float weight = weightLut[(int) q];
-                        result += evalTexel(level, ut, vt) * weight;
-                        denominator += weight;
-                    }
-                }
-                q += dq;
-                dq += ddq;
-            }
-        }
-        if (denominator == 0)
-            return evalBilinear(level, uv);
-        return result / denominator;
-    }
-    /* mipmap.h:629-712 with filterType = EEWA, maxAnisotropy = 10 (envmap.cpp:138-139) */
-    Spectrum eval(const Vec2 &uv, const Vec2 &d0, const Vec2 &d1) const {
-        const Float maxAnisotropy = 10.0f;
-        Float du0 = d0.x * lw[0], dv0 = d0.y * lh[0], du1 = d1.x * lw[0], dv1 = d1.y * lh[0];
-        Float A = dv0 * dv0 + dv1 * dv1,
-              B = -2.0f * (du0 * dv0 + du1 * dv1),
-              C = du0 * du0 + du1 * du1,
-              F = A * C - B * B * 0.25f;
-        Float root = hypot2(A - C, B),
-              Aprime = 0.5f * (A + C - root),
-              Cprime = 0.5f * (A + C + root),
-              majorRadius = Aprime != 0 ? std::sqrt(F / Aprime) : 0,
-              minorRadius = Cprime != 0 ? std::sqrt(F / Cprime) : 0;
-        if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
-            Float level = log2f_(std::max(majorRadius, ORC_EPSILON));
-            int ilevel = (int) std::floor(level);
-            if (ilevel < 0) {
-                return evalBilinear(0, uv);
-            } else {
-                Float a = level - ilevel;
-                return evalBilinear(ilevel, uv) * (1.0f - a) + evalBilinear(ilevel + 1, uv) * a;
-            }
-        } else {
-            if (minorRadius * maxAnisotropy < majorRadius) {
-                minorRadius = majorRadius / maxAnisotropy;
-                Float theta = 0.5f * om::atan(B / (A - C)), sinTheta, cosTheta;
-                om::sincos(theta, &sinTheta, &cosTheta);
-                Float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius,
-                      sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta,
-                      sin2Theta = 2 * sinTheta * cosTheta;
-                A = a2 * cosTheta2 + b2 * sinTheta2;
-                B = (a2 - b2) * sin2Theta;
-                C = a2 * sinTheta2 + b2 * cosTheta2;
-                F = a2 * b2;
-            }
-            Float scl = 1.0f / F;
-            A *= scl; B *= scl; C *= scl;
-            Float level = std::max((Float) 0.0f, log2f_(minorRadius));
-            int ilevel = (int) level;
-            Float a = level - ilevel;
-            if (majorRadius < 1 || !(A > 0 && C > 0))
-                return evalBilinear(ilevel, uv);
-            else
-                return evalEWA(ilevel, uv, A, B, C) * (1.0f - a) + evalEWA(ilevel + 1, uv, A, B, C) * a;
-        }
-    }
-
-    Spectrum evalBilinear(const Vec2 &uv) const { return evalBilinear(0, uv); }
+    Spectrum evalTexel(int x, int y) const { return mip.evalTexel(0, x, y); }
+    Spectrum evalBilinear(const Vec2 &uv) const { return mip.evalBilinear(0, uv); }
 
     /* envmap.cpp:380-394,408-409: a ray WITHOUT differentials (every ray Li spawns; path.cpp:229 assigns a plain Ray) */
     Spectrum evalEnvironment(const Vec3 &rayD) const {
@@ -249,7 +115,7 @@ struct EnvMap {
               t2 = -ORC_INV_PI / std::max(om::safe_sqrt(1.0f - v.y * v.y), ORC_EPSILON);
         Vec2 dudx(t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y),
              dudy(t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y);
-        return eval(uv, dudx, dudy) * scale;
+        return mip.eval(uv, dudx, dudy) * scale;
     }
 
     /* envmap.cpp:657-662 */

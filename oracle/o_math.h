@@ -37,6 +37,7 @@ typedef float Float;
 #define ORC_INV_PI         0.31830988618379067154f
 #define ORC_INV_FOURPI     0.07957747154594766788f   /* constants.h:66 */
 #define ORC_INV_TWOPI      0.15915494309189533577f   /* constants.h:65 */
+#define ORC_RCPOVERFLOW    2.93873587705571876e-39f  /* constants.h:53,58: 2^-128 */
 
 namespace om {
 #if defined(ORACLE_LIBM)
@@ -334,6 +335,17 @@ inline Spectrum fresnelConductorExact(Float cosThetaI, const Spectrum &eta, cons
              term4 = term2 * sinThetaI2;
     Spectrum Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
     return 0.5f * (Rp2 + Rs2);
+}
+
+/* util.cpp:527-539; RCPOVERFLOW = constants.h:46 (single precision) */
+inline bool solveLinearSystem2x2(const Float a[2][2], const Float b[2], Float x[2]) {
+    Float det = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    if (std::abs(det) <= ORC_RCPOVERFLOW)
+        return false;
+    Float inverse = (Float) 1.0f / det;
+    x[0] = (a[1][1] * b[0] - a[0][1] * b[1]) * inverse;
+    x[1] = (a[0][0] * b[1] - a[1][0] * b[0]) * inverse;
+    return true;
 }
 
 /* ---------------- 4x4 matrix (matrix.h / matrix.inl) ---------------- */

@@ -51,6 +51,11 @@ inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray
         }
 
         const Material &bsdf = scene.bsdfOf(its);
+        /* Intersection::getBSDF(ray), records.inl:69-75: UV partials for BSDFs that filter textures -- only the camera
+           ray carries differentials (path.cpp:229 continues with a plain Ray) */
+        if (depth == 1 && rxDirection && ryDirection && scene.usesRayDifferentials(bsdf))
+            Scene::computePartials(its, ray.o, *rxDirection, *ryDirection);
+        bsdfs.its = &its;
 
         if (scene.isEmitter(its) && emittedRadiance && (!ip.hideEmitters || scattered))
             Li += throughput * scene.Le(its, -ray.d);

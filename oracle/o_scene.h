@@ -93,6 +93,8 @@ struct Intersection {
     Frame geoFrame, shFrame;
     Vec2 uv;
     Vec3 dpdu, dpdv;
+    bool hasUVPartials = false;
+    Float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
     Vec3 wi;
     int shape;            /* -1 = invalid */
     uint32_t primIndex;   /* global triangle id */
@@ -168,9 +170,23 @@ struct PathCounters {
     }
 };
 
+/* `bitmap` texture: Texture2D::eval (texture.cpp:112-121) over BitmapTexture::eval (bitmap.cpp:431-454,486-499) */
+struct Texture {
+    MipMap mip;
+    Vec2 uvScale, uvOffset;
+    Spectrum eval(const Intersection &its) const {
+        Vec2 uv(its.uv.x * uvScale.x + uvOffset.x, its.uv.y * uvScale.y + uvOffset.y);
+        if (its.hasUVPartials)
+            return mip.eval(uv, Vec2(its.dudx * uvScale.x, its.dvdx * uvScale.y), Vec2(its.dudy * uvScale.x, its.dvdy * uvScale.y));
+        return mip.filterType != PHIP_FILTER_NEAREST ? mip.evalBilinear(0, uv) : mip.evalBox(0, uv);
+    }
+};
+
 class Scene {
 public:
-    std::vector<float> positions, normals;
+    std::vector<float> positions, normals, texcoords;
+    std::vector<Vec3> tanU, tanV;        /* TriMesh::m_tangents per triangle (shapes with texcoords) */
+    std::vector<Texture> textures;
     std::vector<uint32_t> indices;
     std::vector<uint32_t> triShape, triPrim;
     std::vector<Shape> shapes;
@@ -183,7 +199,7 @@ public:
     KDTree kdtree;
     phip_camera camera;
     phip_film film;
-    bool haveNormals = false;
+    bool haveNormals = false, haveTexcoords = false;
 
     void load(const phip_scene_desc &d) {
         if (d.abi_version != PHIP_ABI_VERSION) throw std::runtime_error("oracle: ABI version mismatch");
@@ -191,7 +207,19 @@ public:
         haveNormals = d.normals != nullptr;
         if (haveNormals) normals.assign(d.normals, d.normals + 3 * (size_t) d.n_vertices);
         indices.assign(d.indices, d.indices + 3 * (size_t) d.n_triangles);
+        haveTexcoords = d.texcoords != nullptr;
+        if (haveTexcoords) texcoords.assign(d.texcoords, d.texcoords + 2 * (size_t) d.n_vertices);
+
         camera = d.camera; film = d.film;
+textures.resize(d.n_textures);
+        for (uint32_t i = 0; i < d.n_textures; ++i) {
+            const phip_texture &t = d.textures[i];
+            Texture &o = textures[i];
+            o.mip.bcu = t.wrap_u; o.mip.bcv = t.wrap_v; o.mip.filterType = t.filter_type; o.mip.maxAnisotropy = t.max_anisotropy;
+            if (t.wrap_u > PHIP_WRAP_ONE || t.wrap_v > PHIP_WRAP_ONE || t.filter_type > PHIP_FILTER_EWA) throw std::runtime_error("oracle: bad texture wrap mode / filter type");
+            o.mip.load(t.width, t.height, t.n_levels > 1 ? t.n_levels : 1, t.levels);
+            o.uvScale = Vec2(t.uv_scale[0], t.uv_scale[1]); o.uvOffset = Vec2(t.uv_offset[0], t.uv_offset[1]);
+        }
         materials.resize(d.n_materials);
         for (uint32_t i = 0; i < d.n_materials; ++i) materials[i].m = d.materials[i];
         for (uint32_t i = 0; i < d.n_materials; ++i) configureMaterial(i);
@@ -210,6 +238,32 @@ public:
             for (uint32_t j = 0; j < s.n_triangles; ++j) { triShape[s.first_triangle + j] = i; triPrim[s.first_triangle + j] = j; }
         }
         if (expect != d.n_triangles) throw std::runtime_error("oracle: shape triangle ranges do not cover the index array");
+        /* TriMesh::computeUVTangents, trimesh.cpp:683-735 (always run for meshes with texture coordinates, :383-385) */
+        tanU.assign(d.n_triangles, Vec3(0.0f)); tanV.assign(d.n_triangles, Vec3(0.0f));
+        for (uint32_t i = 0; i < d.n_shapes; ++i) {
+            if (!shapes[i].s.has_texcoords) continue;
+            if (!haveTexcoords) throw std::runtime_error("oracle: shape has_texcoords but texcoords is NULL");
+            for (uint32_t j = 0; j < shapes[i].s.n_triangles; ++j) {
+                const uint32_t t = shapes[i].s.first_triangle + j;
+                const Vec3 v0 = P(t, 0), v1 = P(t, 1), v2 = P(t, 2);
+                const Vec2 uv0 = UV(t, 0), uv1 = UV(t, 1), uv2 = UV(t, 2);
+                Vec3 dP1 = v1 - v0, dP2 = v2 - v0;
+                Vec2 dUV1(uv1.x - uv0.x, uv1.y - uv0.y), dUV2(uv2.x - uv0.x, uv2.y - uv0.y);
+                Vec3 n = cross(dP1, dP2);
+                Float length = n.length();
+                if (length == 0) continue;
+                Float determinant = dUV1.x * dUV2.y - dUV1.y * dUV2.x;
+                if (determinant == 0) {
+                    coordinateSystem(n / length, tanU[t], tanV[t]);
+                } else {
+                    Float invDet = 1.0f / determinant;
+                    tanU[t] = (dP1 * dUV2.y - dP2 * dUV1.y) * invDet;
+                    tanV[t] = (dP1 * (-dUV2.x) + dP2 * dUV1.x) * invDet;
+                }
+            }
+        }
+        for (uint32_t i = 0; i < d.n_materials; ++i)
+            if (materials[i].m.reflectance_texture > d.n_textures) throw std::runtime_error("oracle: bad texture id");
         /* area sampling tables, trimesh.cpp:388-404 (built lazily in the reference) */
         for (uint32_t i = 0; i < d.n_shapes; ++i) {
             Shape &sh = shapes[i];
@@ -252,6 +306,7 @@ public:
     }
 
     Vec3 P(uint32_t tri, int c) const { const float *p = &positions[3 * (size_t) indices[3 * (size_t) tri + c]]; return Vec3(p[0], p[1], p[2]); }
+    Vec2 UV(uint32_t tri, int c) const { const float *p = &texcoords[2 * (size_t) indices[3 * (size_t) tri + c]]; return Vec2(p[0], p[1]); }
     Vec3 Nrm(uint32_t tri, int c) const { const float *p = &normals[3 * (size_t) indices[3 * (size_t) tri + c]]; return Vec3(p[0], p[1], p[2]); }
 
     void configureMaterial(uint32_t i) {
@@ -260,6 +315,12 @@ public:
             case PHIP_BSDF_DIFFUSE: {
                 /* diffuse.cpp:93-103: clamp to <=1 (ensureEnergyConservation), component only if max > 0 */
                 Float mx = std::max(M.m.reflectance[0], std::max(M.m.reflectance[1], M.m.reflectance[2]));
+                if (M.m.reflectance_texture != 0) {        /* m_reflectance->getMaximum().max(), level 0 of the bitmap */
+                    if (M.m.reflectance_texture > textures.size()) throw std::runtime_error("oracle: bad texture id");
+                    mx = 0;
+                    for (const Spectrum &t : textures[M.m.reflectance_texture - 1].mip.levels[0]) mx = std::max(mx, t.max());
+                    if (mx > 1.0f) throw std::runtime_error("diffuse reflectance texture > 1 (ensureEnergyConservation, diffuse.cpp:95)");
+                }
                 M.smooth = mx > 0; M.transOrBack = false;
             } break;
             case PHIP_BSDF_DIELECTRIC: M.smooth = false; M.transOrBack = true; break;
@@ -310,8 +371,13 @@ public:
         Float length = faceNormal.length();
         if (!faceNormal.isZero())
             faceNormal /= length;
-        its.dpdu = side1;
-        its.dpdv = side2;
+        if (sh.s.has_texcoords) {           /* vertexTangents, skdtree.h:373-377 */
+            its.dpdu = tanU[prim];
+            its.dpdv = tanV[prim];
+        } else {
+            its.dpdu = side1;
+            its.dpdv = side2;
+        }
         if (sh.s.has_normals && haveNormals) {
             const Vec3 n0 = Nrm(prim, 0), n1 = Nrm(prim, 1), n2 = Nrm(prim, 2);
             its.shFrame.n = normalize(n0 * b.x + n1 * b.y + n2 * b.z);
@@ -321,7 +387,13 @@ public:
             its.shFrame.n = faceNormal;
         }
         its.geoFrame = Frame(faceNormal);
-        its.uv = Vec2(b.y, b.z);
+        if (sh.s.has_texcoords) {           /* skdtree.h:397-404 */
+            const Vec2 t0 = UV(prim, 0), t1 = UV(prim, 1), t2 = UV(prim, 2);
+            its.uv = Vec2(t0.x * b.x + t1.x * b.y + t2.x * b.z, t0.y * b.x + t1.y * b.y + t2.y * b.z);
+        } else {
+            its.uv = Vec2(b.y, b.z);
+        }
+        its.hasUVPartials = false;
         its.shape = (int) shapeIdx;
         its.primIndex = prim;
         computeShadingFrame(its.shFrame.n, its.dpdu, its.shFrame);
@@ -329,6 +401,40 @@ public:
     }
 
     const Material &bsdfOf(const Intersection &its) const { return materials[shapes[its.shape].s.material]; }
+
+    /* BSDF::usesRayDifferentials: a bitmap texture somewhere below (diffuse.cpp, twosided.cpp) */
+    bool usesRayDifferentials(const Material &M) const {
+        if (M.m.type == PHIP_BSDF_TWOSIDED)
+            return usesRayDifferentials(materials[M.m.nested[0]]) || usesRayDifferentials(materials[M.m.nested[1]]);
+        return M.m.type == PHIP_BSDF_DIFFUSE && M.m.reflectance_texture != 0;
+    }
+
+    /* Intersection::computePartials, intersection.cpp:5-76 (rxOrigin = ryOrigin = the ray origin for a pinhole camera) */
+    static void computePartials(Intersection &its, const Vec3 &rayO, const Vec3 &rxDirection, const Vec3 &ryDirection) {
+        Float A[2][2], Bx[2], By[2], x[2];
+        int axes[2];
+        if (its.hasUVPartials) return;
+        its.hasUVPartials = true;
+        if (its.dpdu.isZero() && its.dpdv.isZero()) { its.dudx = its.dvdx = its.dudy = its.dvdy = 0.0f; return; }
+        const Vec3 &gn = its.geoFrame.n;
+        const Float pp = dot(gn, its.p), pox = dot(gn, rayO), poy = dot(gn, rayO),
+                    prx = dot(gn, rxDirection), pry = dot(gn, ryDirection);
+        if (prx == 0 || pry == 0) { its.dudx = its.dvdx = its.dudy = its.dvdy = 0.0f; return; }
+        const Float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+        Float absX = std::abs(gn.x), absY = std::abs(gn.y), absZ = std::abs(gn.z);
+        if (absX > absY && absX > absZ) { axes[0] = 1; axes[1] = 2; }
+        else if (absY > absZ) { axes[0] = 0; axes[1] = 2; }
+        else { axes[0] = 0; axes[1] = 1; }
+        A[0][0] = its.dpdu[axes[0]]; A[0][1] = its.dpdv[axes[0]];
+        A[1][0] = its.dpdu[axes[1]]; A[1][1] = its.dpdv[axes[1]];
+        Vec3 px = rayO + rxDirection * tx, py = rayO + ryDirection * ty;
+        Bx[0] = px[axes[0]] - its.p[axes[0]]; Bx[1] = px[axes[1]] - its.p[axes[1]];
+        By[0] = py[axes[0]] - its.p[axes[0]]; By[1] = py[axes[1]] - its.p[axes[1]];
+        if (solveLinearSystem2x2(A, Bx, x)) { its.dudx = x[0]; its.dvdx = x[1]; }
+        else { its.dudx = 1; its.dvdx = 0; }
+        if (solveLinearSystem2x2(A, By, x)) { its.dudy = x[0]; its.dvdy = x[1]; }
+        else { its.dudy = 0; its.dudy = 1; }      /* (sic, intersection.cpp:74) */
+    }
     bool isEmitter(const Intersection &its) const { return shapes[its.shape].s.emitter >= 0; }
 
     /* area.cpp:104-109 */

@@ -371,3 +371,38 @@ def test_envmap_filtered_background_matches_oracle(gpu, oracle, gauss):
         sb.hdrfilm(res[0], res[1], gauss)
         same, r = compare_render(gpu, oracle, sb.desc(), spp, min_identical=0.999, maxDepth=4)
         print("envmap background %s fov %g: identical %.6f rel L2 %.3e" % (res, fov, same, r))
+
+
+def test_bitmap_textures_match_oracle(gpu, oracle, gauss):
+    """bitmap reflectance textures (EWA / trilinear / bilinear / nearest, wrap modes, uv scale and
+    offset), UV tangents in the shading frame (also for untextured, anisotropic materials), first-vertex UV partials"""
+    from test_oracle_path import sphere_uvs, checker
+    rng = np.random.default_rng(11)
+    noise = rng.uniform(0.05, 0.95, (96, 160, 3)).astype(np.float32)
+    chk = checker(256, 32)
+
+    def scene(res=(160, 112), light=True):
+        sb = S.SceneBuilder()
+        t_floor = sb.bitmap(chk, filter_type="ewa", uscale=6.0, vscale=6.0)
+        t_tri = sb.bitmap(noise, filter_type="trilinear", wrap="mirror", wrap_v="clamp", uscale=2.0, uoffset=0.3)
+        t_bil = sb.bitmap(noise, filter_type="bilinear", wrap="zero", wrap_v="one", uscale=1.5, vscale=1.5, voffset=-0.2)
+        t_near = sb.bitmap(chk[:64, :48], filter_type="nearest", max_anisotropy=4.0)
+        t_ewa4 = sb.bitmap(noise[:50, :70], filter_type="ewa", max_anisotropy=2.0, uscale=3.0)
+        floor = sb.diffuse(texture=t_floor)
+        sb.quad((-8, 0, -8), (8, 0, -8), (8, 0, 8), (-8, 0, 8), floor, facing=(0, 1, 0), uvs=True)
+        mats = [sb.diffuse(texture=t_tri), sb.twosided(sb.diffuse(texture=t_bil)), sb.twosided(sb.diffuse(texture=t_near), sb.diffuse((0.3, 0.3, 0.3))),
+                sb.diffuse(texture=t_ewa4), sb.roughconductor(alpha=0.05, alpha_v=0.3, eta=S.CU_ETA, k=S.CU_K), sb.diffuse((0.6, 0.5, 0.4))]
+        for i, m in enumerate(mats):
+            P, T, N = S.sphere_mesh((-5 + 2 * i, 0.8, 0.4 * (i % 2)), 0.8, 24, 12)
+            smooth = i % 2 == 0
+            sb.mesh(P, T, m, normals=N if smooth else None, uvs=sphere_uvs(N))           # texcoords: the frame uses the UV tangents
+        if light:
+            sb.quad((-2, 5, -2), (2, 5, -2), (2, 5, 2), (-2, 5, 2), sb.diffuse((0, 0, 0)), facing=(0, -1, 0), radiance=(10, 10, 9))
+        sb.constant((0.4, 0.5, 0.7))
+        sb.perspective((0, 3.5, -11), (0, 0.4, 0), (0, 1, 0), 42.0)
+        sb.hdrfilm(res[0], res[1], gauss)
+        return sb
+    for spp, md in ((1, 2), (8, 6)):
+        same, r = compare_render(gpu, oracle, scene().desc(), spp, min_identical=0.999, maxDepth=md)
+        print("textures spp %d: identical %.6f rel L2 %.3e" % (spp, same, r))
+    compare_render(gpu, oracle, scene(res=(64, 48)).desc(), 4, min_identical=0.999, maxDepth=4, strictNormals=True)

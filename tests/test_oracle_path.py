@@ -247,6 +247,66 @@ def test_envmap_filtered_background(oracle, gauss):
         scene(tex, False).render(A.default_render_params(spp=1))
 
 
+def sphere_uvs(N):
+    """latitude-longitude texture coordinates of unit normals (u wraps at the seam: a few triangles span it -- fine here)"""
+    N = np.asarray(N, np.float64)
+    return np.stack([np.mod(np.arctan2(N[:, 2], N[:, 0]) / (2 * np.pi), 1.0), np.arccos(np.clip(N[:, 1], -1, 1)) / np.pi], -1).astype(np.float32)
+
+
+def checker(n=64, cells=8, lo=0.1, hi=0.9):
+    t = np.full((n, n, 3), lo, np.float32)
+    t[(np.indices((n, n)).sum(0) // (n // cells)) % 2 == 0] = hi
+    return t * np.array([1.0, 0.8, 0.6], np.float32)
+
+
+def test_bitmap_texture(oracle, gauss):
+    """`bitmap` reflectance on a diffuse BSDF (bitmap.cpp, texture.cpp:112-121, mipmap.h) with UV
+    tangents (trimesh.cpp:683-735) and first-vertex UV partials (intersection.cpp:5-76).  A convex diffuse surface under
+    a unit constant environment radiates its albedo, so the image shows the texture itself."""
+    def scene(tex_kw, res=64, fov=40.0, uvs=True, spp_scene=None):
+        sb = S.SceneBuilder()
+        tid = None if tex_kw is None else sb.bitmap(**tex_kw)
+        m = sb.diffuse((0.5, 0.25, 0.75), texture=tid)
+        sb.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), m, facing=(0, 0, -1), uvs=uvs)
+        sb.constant((1.0, 1.0, 1.0))
+        sb.perspective((0, 0, -4), (0, 0, 0), (0, 1, 0), fov); sb.hdrfilm(res, res, gauss)
+        return oracle.OracleScene(sb.desc())
+    P = A.default_render_params
+    # a constant texture is the constant reflectance
+    c = np.tile(np.array([0.5, 0.25, 0.75], np.float32), (8, 8, 1))
+    a = oracle.develop(scene(dict(image=c)).render(P(spp=4, max_depth=3))[0])
+    b = oracle.develop(scene(None).render(P(spp=4, max_depth=3))[0])
+    assert np.abs(a - b).max() < 1e-6
+    # two-texel texture, nearest filter: left half / right half of the quad (u runs with the quad's first edge)
+    two = np.array([[[0.2, 0.2, 0.2], [0.8, 0.8, 0.8]]], np.float32)
+    sc = scene(dict(image=two, filter_type="nearest"), res=64, fov=25.0)       # the quad fills the frame
+    f = sc.render(P(spp=4, max_depth=2))[0]
+    img = oracle.develop(f)[..., 0]
+    left, right = img[:, 4:28].mean(), img[:, 36:60].mean()
+    assert {round(float(left), 3), round(float(right), 3)} == {0.2, 0.8}
+    # bilinear: a linear ramp between the texel centres (u = 0.25 .. 0.75), wrap mode decides the outer quarters
+    ramp = lambda wrap: oracle.develop(scene(dict(image=two, filter_type="bilinear", wrap=wrap), res=64, fov=25.0).render(P(spp=16, max_depth=2))[0])[32, :, 0]
+    rc, rr = ramp("clamp"), ramp("repeat")
+    if rc[10] > rc[50]: rc, rr = rc[::-1], rr[::-1]
+    assert abs(rc[2] - 0.2) < 5e-3 and abs(rc[61] - 0.8) < 5e-3 and abs(rc[31] + rc[32] - 1.0) < 0.02      # clamped ends, symmetric ramp
+    assert 0.3 < rr[1] < 0.5 < rr[62] < 0.7 and abs(rr[1] + rr[62] - 1.0) < 0.02                    # repeat blends 0.8 <-> 0.2 across the edge (the frame shows u = 0.06 .. 0.94)
+    # uscale / uoffset (Texture2D): three repetitions
+    rep = oracle.develop(scene(dict(image=two, filter_type="nearest", uscale=3.0), res=96, fov=25.0).render(P(spp=4, max_depth=2))[0])[48, :, 0]
+    assert (np.abs(np.diff((rep > 0.5).astype(int))).sum()) == 5
+    # filtered first vertex: a fine checkerboard seen through a coarse film aliases without the EWA lookup
+    chk = checker(256, 64)
+    noisy = oracle.develop(scene(dict(image=chk, filter_type="bilinear"), res=24, fov=25.0).render(P(spp=1, max_depth=2))[0])[4:20, 4:20, 0]
+    ewa = oracle.develop(scene(dict(image=chk, filter_type="ewa"), res=24, fov=25.0).render(P(spp=1, max_depth=2))[0])[4:20, 4:20, 0]
+    assert abs(ewa.mean() / 0.5 - 1) < 0.05 and ewa.std() < 0.5 * noisy.std()
+    # texture coordinates change dpdu and with it the shading frame (skdtree.h:373-380) -- but not a diffuse image
+    a = oracle.develop(scene(None, uvs=True).render(P(spp=64, max_depth=3))[0])
+    b = oracle.develop(scene(None, uvs=None).render(P(spp=64, max_depth=3))[0])
+    assert abs(a.mean() / b.mean() - 1) < 0.01
+    # energy conservation is enforced like diffuse.cpp:95
+    with pytest.raises(RuntimeError, match="ensureEnergyConservation"):
+        scene(dict(image=two * 2))
+
+
 def test_sfmt_streams_agree_statistically_with_ctr_stream(oracle, gauss):
     """`independent` semantics (one SFMT19937 clone per worker, sequential consumption) and the
     counter-based parity stream estimate the same image"""
