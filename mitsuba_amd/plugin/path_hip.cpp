@@ -40,6 +40,23 @@ public:
     virtual const MIPMap *getMIPMap() const = 0;
 };
 
+/* Same for src/bsdfs/diffuse.cpp's SmoothDiffuse (its reflectance texture) and src/textures/bitmap.cpp's BitmapTexture
+   (MIP pyramid and lookup parameters): plugin-local classes without getters for what the device needs. */
+class SmoothDiffuseAccess : public BSDF {
+public:
+    virtual const Texture *getReflectanceTexture() const = 0;
+};
+class BitmapTextureAccess : public Texture2D {
+public:
+    typedef TMIPMap<Color3, Color3h> MIPMap3;
+    virtual const MIPMap3 *getMIPMap3() const = 0;
+    virtual ReconstructionFilter::EBoundaryCondition getWrapModeU() const = 0;
+    virtual ReconstructionFilter::EBoundaryCondition getWrapModeV() const = 0;
+    virtual Float getMaxAnisotropy() const = 0;
+    virtual Vector2 getUVScale() const = 0;
+    virtual Point2 getUVOffset() const = 0;
+};
+
 class PathHIP : public MonteCarloIntegrator {
 public:
     PathHIP(const Properties &props) : MonteCarloIntegrator(props), m_scene(NULL) {
@@ -110,7 +127,8 @@ public:
 private:
     /* ---- Scene -> phip_scene_desc ---- */
     void flatten(const Scene *scene) {
-        std::vector<float> positions, normals; std::vector<uint32_t> indices;
+        std::vector<float> positions, normals, texcoords; std::vector<uint32_t> indices;
+        bool anyTexcoords = false;
         std::vector<phip_shape> shapes; std::vector<phip_material> materials; std::vector<phip_emitter> emitters;
         std::map<const BSDF *, uint32_t> bsdfIds;
         std::map<const Shape *, uint32_t> shapeIds;
@@ -131,11 +149,14 @@ private:
             s.first_vertex = (uint32_t) (positions.size() / 3); s.n_vertices = (uint32_t) mesh->getVertexCount();
             s.first_triangle = (uint32_t) (indices.size() / 3); s.n_triangles = (uint32_t) mesh->getTriangleCount();
             s.has_normals = mesh->getVertexNormals() ? 1 : 0; anyNormals |= s.has_normals != 0;
+            s.has_texcoords = mesh->getVertexTexcoords() ? 1 : 0; anyTexcoords |= s.has_texcoords != 0;
             for (size_t v = 0; v < mesh->getVertexCount(); ++v) {
                 const Point &p = mesh->getVertexPositions()[v];
                 positions.push_back(p.x); positions.push_back(p.y); positions.push_back(p.z);
                 Normal n = mesh->getVertexNormals() ? mesh->getVertexNormals()[v] : Normal(0.0f);
                 normals.push_back(n.x); normals.push_back(n.y); normals.push_back(n.z);
+                Point2 uv = mesh->getVertexTexcoords() ? mesh->getVertexTexcoords()[v] : Point2(0.0f);
+                texcoords.push_back(uv.x); texcoords.push_back(uv.y);
             }
             for (size_t t = 0; t < mesh->getTriangleCount(); ++t)
                 for (int k = 0; k < 3; ++k) indices.push_back(s.first_vertex + mesh->getTriangles()[t].idx[k]);
@@ -195,6 +216,8 @@ private:
         d.n_shapes = (uint32_t) shapes.size(); d.shapes = shapes.data();
         d.n_materials = (uint32_t) materials.size(); d.materials = materials.data();
         d.n_emitters = (uint32_t) emitters.size(); d.emitters = emitters.data();
+        d.texcoords = anyTexcoords ? texcoords.data() : NULL;
+        d.n_textures = (uint32_t) m_textures.size(); d.textures = m_textures.empty() ? NULL : &m_textures[0];
         d.envmap = envmap;
 
         const Sensor *sensor = scene->getSensor();
@@ -222,6 +245,29 @@ private:
 
     static void rgb(const Spectrum &s, float out[3]) { Float r, g, b; s.toLinearRGB(r, g, b); out[0] = r; out[1] = g; out[2] = b; }
 
+    /* <texture type="bitmap">: the RGB MIP pyramid as the plugin built and stores it + the lookup parameters
+       (bitmap.cpp: wrapModeU/V, filterType, maxAnisotropy; Texture2D: uscale/vscale/uoffset/voffset) */
+    uint32_t convertBitmap(const BitmapTextureAccess *tex) {
+        std::map<const Texture *, uint32_t>::iterator it = m_textureIds.find(tex);
+        if (it != m_textureIds.end()) return it->second;
+        const BitmapTextureAccess::MIPMap3 *mip = tex->getMIPMap3();
+        if (!mip) Log(EError, "path_hip: only RGB bitmap textures are supported");
+        phip_texture t; memset(&t, 0, sizeof(t));
+        t.n_levels = (uint32_t) mip->getLevels();
+        for (int l = 0; l < mip->getLevels(); ++l) {
+            m_textureLevels.push_back(mip->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
+            t.levels[l] = m_textureLevels.back()->getFloat32Data();
+        }
+        t.width = (uint32_t) mip->getWidth(); t.height = (uint32_t) mip->getHeight();
+        t.wrap_u = (uint32_t) tex->getWrapModeU(); t.wrap_v = (uint32_t) tex->getWrapModeV();      /* EBoundaryCondition order = phip_wrap_mode */
+        t.filter_type = (uint32_t) mip->getFilterType(); t.max_anisotropy = tex->getMaxAnisotropy();
+        t.uv_scale[0] = tex->getUVScale().x; t.uv_scale[1] = tex->getUVScale().y;
+        t.uv_offset[0] = tex->getUVOffset().x; t.uv_offset[1] = tex->getUVOffset().y;
+        uint32_t id = (uint32_t) m_textures.size();
+        m_textures.push_back(t); m_textureIds[tex] = id;
+        return id;
+    }
+
     uint32_t convertBSDF(const BSDF *bsdf, std::vector<phip_material> &materials, std::map<const BSDF *, uint32_t> &ids) {
         std::map<const BSDF *, uint32_t>::iterator it = ids.find(bsdf);
         if (it != ids.end()) return it->second;
@@ -230,7 +276,14 @@ private:
         const Properties &props = bsdf->getProperties();
         Intersection its;       /* constant textures only: any intersection record evaluates to the same value */
         if (cls == "SmoothDiffuse") {
-            m.type = PHIP_BSDF_DIFFUSE; rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
+            m.type = PHIP_BSDF_DIFFUSE;
+            const Texture *tex = static_cast<const SmoothDiffuseAccess *>(bsdf)->getReflectanceTexture();   /* accessor: INTEGRATION.md */
+            if (tex->getClass()->getName() == "BitmapTexture")
+                m.reflectance_texture = 1 + convertBitmap(static_cast<const BitmapTextureAccess *>(tex));
+            else if (tex->isConstant())
+                rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
+            else
+                Log(EError, "path_hip: texture \"%s\" is not supported (constant, bitmap)", tex->getClass()->getName().c_str());
         } else if (cls == "SmoothDielectric") {
             m.type = PHIP_BSDF_DIELECTRIC; m.eta[0] = bsdf->getEta();
             rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
@@ -274,6 +327,8 @@ private:
     static std::vector<const BSDF *> getNestedBSDFs(const BSDF *bsdf);
 
     phip_scene *m_scene;
+    std::vector<phip_texture> m_textures; std::map<const Texture *, uint32_t> m_textureIds;
+    std::vector<ref<Bitmap> > m_textureLevels;   /* float RGB copies of the textures' MIP levels */
     std::vector<ref<Bitmap> > m_envLevels;   /* float RGB copies of the environment map's MIP levels (alive until phip_scene_create) */
     int m_device;
     ref<SamplingIntegrator> m_cpuPath;
