@@ -33,7 +33,26 @@ WORKLOADS = {
     "cornell_256x256_16spp_md4": ("cornell_box", 256, 256, 16, 4),
     "atrium_1920x1080_64spp_md8": ("atrium", 1920, 1080, 64, 8),
     "glassroom_1920x1080_512spp_md16": ("glass_room", 1920, 1080, 512, 16),
+    # the `direct` integrator on the same scenes
+    "cornell_1024x1024_256spp_direct": ("cornell_box", 1024, 1024, 256, "direct:1"),
+    "atrium_1920x1080_64spp_direct4": ("atrium", 1920, 1080, 64, "direct:4"),
 }
+
+
+def make_integrator(md):
+    """md: maxDepth of the path tracer, or "direct:<shadingSamples>" """
+    from mitsuba_amd.integrator import PathHIP, DirectHIP
+    if isinstance(md, str):
+        return DirectHIP(shadingSamples=int(md.split(":")[1])), "direct_hip shadingSamples=%s" % md.split(":")[1]
+    return PathHIP(maxDepth=md), "path_hip maxDepth=%d rrDepth=5" % md
+
+
+def oracle_params(md, spp):
+    from mitsuba_amd import _abi as A
+    if isinstance(md, str):
+        n = int(md.split(":")[1])
+        return A.default_render_params(spp=spp, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=n, bsdf_samples=n)
+    return A.default_render_params(spp=spp, max_depth=md)
 
 
 def build_desc(workload, spp_scale=1):
@@ -63,13 +82,13 @@ def cpu_baseline(workload, seconds_target=15.0):
     desc, w, h, spp, md, _ = build_desc(workload)
     osc = O.OracleScene(desc)
     cores = os.cpu_count() or 1
-    p = A.default_render_params(spp=1, max_depth=md)
+    p = oracle_params(md, 1)
     t = time.time()
     _, _, st = osc.render(p, threads=cores)
     dt1 = max(time.time() - t, 1e-3)
     s = int(max(1, min(spp, round(seconds_target / dt1))))
     if s > 1:
-        p = A.default_render_params(spp=s, max_depth=md)
+        p = oracle_params(md, s)
         t = time.time()
         _, _, st = osc.render(p, threads=cores)
         dt1 = time.time() - t
@@ -114,7 +133,7 @@ def main():
     accel = scene.accel_info().as_dict()
     # the closest-hit kernel that runs for this scene (trees under 64 nodes use the per-slot launch)
     trace_kernel = "k_trace_p" if accel["n_nodes"] >= 64 else "k_trace"     # refined after the run: k_rays_p when the ray kernels are merged
-    integ = PathHIP(maxDepth=md)
+    integ, integ_name = make_integrator(md)
     film = torch.zeros((H, W, 5), dtype=torch.float32, device=dev)
     flags = A.PHIP_FLAG_KERNEL_TIMING
 
@@ -154,7 +173,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": WORKLOADS[args.workload][0], "triangles": ntris, "width": W, "height": H,
-                       "spp": spp, "spp_per_gpu_equivalent": spp // world, "integrator": "path_hip maxDepth=%d rrDepth=5" % md,
+                       "spp": spp, "spp_per_gpu_equivalent": spp // world, "integrator": integ_name,
                        "rfilter": "gaussian stddev 0.5", "sampler": "ctr seed 0", "block_size": 32,
                        "parallelism": "blocks round-robin over %d GPU(s) in spiral order + RCCL reduce(sum) of the film" % world},
             "frame_ms": round(ms_per_step, 3),

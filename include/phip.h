@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PHIP_ABI_VERSION 2
+#define PHIP_ABI_VERSION 3
 
 typedef enum phip_status {
     PHIP_OK              =  0,
@@ -183,6 +183,12 @@ typedef enum phip_sampler_kind {
     PHIP_SAMPLER_CTR = 0     /* counter-based (pixel, sample, dimension) stream -- the parity stream */
 } phip_sampler_kind;
 
+/* which SamplingIntegrator::Li the call evaluates */
+typedef enum phip_integrator_kind {
+    PHIP_INTEGRATOR_PATH = 0,    /* MIPathTracer, src/integrators/path/path.cpp:119-300                                     */
+    PHIP_INTEGRATOR_DIRECT = 1   /* MIDirectIntegrator, src/integrators/direct/direct.cpp:149-312 (max_depth / rr_depth unused) */
+} phip_integrator_kind;
+
 typedef struct phip_render_params {
     int32_t  spp;                /* sampler sampleCount                                   */
     int32_t  max_depth;          /* -1 = infinite (integrator.cpp:197)                    */
@@ -199,6 +205,10 @@ typedef struct phip_render_params {
     int32_t  device;             /* HIP device ordinal                                    */
     int32_t  flags;              /* PHIP_FLAG_*                                           */
     void    *stream;             /* hipStream_t to launch on, NULL = library-owned stream */
+    uint32_t integrator;         /* phip_integrator_kind                                  */
+    int32_t  emitter_samples;    /* `direct`: emitterSamples (direct.cpp:98-99), default 1 */
+    int32_t  bsdf_samples;       /* `direct`: bsdfSamples (direct.cpp:100-101), default 1  */
+    int32_t  reserved;
 } phip_render_params;
 
 #define PHIP_FLAG_KERNEL_TIMING 1   /* bracket the kernels with hipEvents, fill phip_stats.*_ms */

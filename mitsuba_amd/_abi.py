@@ -5,13 +5,14 @@ struct against the values the C side reports through phip_abi_sizeof().
 """
 import ctypes as C
 
-PHIP_ABI_VERSION = 2
+PHIP_ABI_VERSION = 3
 PHIP_FILTER_RESOLUTION = 31
 
 PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCELLED, PHIP_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 PHIP_BSDF_DIFFUSE, PHIP_BSDF_DIELECTRIC, PHIP_BSDF_ROUGHCONDUCTOR, PHIP_BSDF_TWOSIDED = 0, 1, 2, 3
 PHIP_MF_BECKMANN, PHIP_MF_GGX = 0, 1
 PHIP_SAMPLER_CTR = 0
+PHIP_INTEGRATOR_PATH, PHIP_INTEGRATOR_DIRECT = 0, 1
 PHIP_FLAG_KERNEL_TIMING = 1
 PHIP_FLAG_SAMPLE_BUFFER = 2
 PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND = 4
@@ -91,7 +92,9 @@ class phip_render_params(C.Structure):
                 ("strict_normals", C.c_int32), ("hide_emitters", C.c_int32), ("block_size", C.c_int32),
                 ("sampler", C.c_uint32), ("seed", C.c_uint32),
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32),
-                ("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p)]
+                ("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
+                ("integrator", C.c_uint32), ("emitter_samples", C.c_int32), ("bsdf_samples", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class phip_stats(C.Structure):
@@ -140,6 +143,9 @@ def default_render_params(**kw):
     p.device = 0
     p.flags = 0
     p.stream = None
+    p.integrator = PHIP_INTEGRATOR_PATH
+    p.emitter_samples = 1
+    p.bsdf_samples = 1
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace8(DevScene S, PathPool P) {
     traverseWave8<false>(S, lds + wave * 8 * STACK8, P.spill8 + (size_t) waveId * 8 * SPILL8, n,
         [&](uint32_t r, V3 &o, V3 &d, float &mint, float &maxt) -> bool {
             const uint32_t slot = base + r;
-            if (!(P.state[slot] & F_ALIVE)) return false;
+            if ((P.state[slot] & F_TRACE_MASK) != F_ALIVE) return false;
             const float4 ro = P.rayO[slot], rd = P.rayD[slot];
             o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
             return true;

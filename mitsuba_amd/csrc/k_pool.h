@@ -24,6 +24,8 @@
 enum : uint32_t {
     F_ALIVE = 1u << 16, F_SCATTERED = 1u << 17, F_EMITTED = 1u << 18, F_PREV_DELTA = 1u << 19, F_FIRST = 1u << 20, F_DEAD = 1u << 21, F_FRESH = 1u << 22, F_DYNAMIC = 1u << 23,
     F_REFN_ZERO = 1u << 24,             /* DirectSamplingRecord::refN of the vertex the ray left is zero (BSDF with a back side / transmission) */
+    F_NOTRACE = 1u << 25,               /* `direct`: the slot is alive but has no closest-hit query in flight this iteration */
+    F_TRACE_MASK = F_ALIVE | F_NOTRACE, /* the traversal kernels trace a slot iff (state & F_TRACE_MASK) == F_ALIVE */
     DEPTH_MASK = 0xFFFFu
 };
 
@@ -33,6 +35,7 @@ struct PathPool {
     float4 *hit;      /* t, u, v, bits(prim) */
     float4 *thr;      /* throughput rgb, eta */
     float2 *mis;      /* bsdfPdf of the sampled direction, dot(direction, refN): all the emitter-hit MIS term needs (8 B instead of refN + pdf = 16 B) */
+    float4 *camHit;   /* `direct` only: the camera ray's hit record, kept while the vertex's BSDF-sampled rays are traced */
     uint4 *info;      /* sampleId, pixel, sampleIndex, - : written when the slot starts a sample, read-only afterwards */
     uint32_t *state;  /* depth | flags: the only per-iteration slot header (4 B instead of rewriting 16 B) */
     float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0);
@@ -63,6 +66,9 @@ struct RenderConst {
     int maxDepth, rrDepth, strictNormals, hideEmitters;
     uint32_t seed;
     float diffScaleFactor;            /* 1 / sqrt(spp) of the whole render: RayDifferential::scaleDifferential, integrator.cpp:144-145,181 */
+    /* `direct` (direct.cpp:130-138): sample counts, MIS fractions and per-sample weights */
+    int emitterSamples, bsdfSamples;
+    float fracLum, fracBSDF, weightLum, weightBSDF;
     uint32_t envFiltered;             /* camera rays that miss use the envmap's EWA lookup (pyramid present) */
     const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
     uint32_t countAlive;              /* this iteration records the number of live slots */

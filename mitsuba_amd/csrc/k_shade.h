@@ -17,6 +17,121 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
 #endif
+/* The common tail of the shading kernels: the block's shadow-queue entries are compacted, slots whose sample ended start
+ * the next camera sample in the same lane, blocks without work retire, per-wave statistics are recorded. */
+__device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool &P, const RenderConst &rc, uint32_t *waveCnt,
+                                              const uint32_t slot, const bool inRange, uint4 info, const bool alive, bool needNew,
+                                              const bool pushShadow, const float4 sh0, const float4 sh1, const float4 sh2,
+                                              const unsigned long long vertices, const unsigned long long done) {
+    /* ---- shadow queue: compact this block's entries to the front of its own region (no global atomics) ---- */
+    uint32_t shadowTotal = 0;
+    {
+        const unsigned long long m = __ballot(pushShadow);
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) base += c; total += c; }
+        if (pushShadow) {
+            const size_t sidx = (size_t) blockIdx.x * BLOCK + base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+            P.shadow[3 * sidx] = sh0; P.shadow[3 * sidx + 1] = sh1; P.shadow[3 * sidx + 2] = sh2;
+        }
+        if (threadIdx.x == 0) P.shadowCount[blockIdx.x] = total;
+        shadowTotal = total;
+    }
+
+    /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183).
+       Sample ids [0, staticIds) follow a static schedule (slot s renders s, s + capacity, ... -- no global
+       counter in steady state).  The last part of the frame is handed out dynamically so that slots whose
+       paths happened to be short keep working until the frame is really finished: one atomicAdd per BLOCK
+       on one of DYN_SHARDS counters (block-aggregated through LDS; each shard owns a contiguous id range). ---- */
+    bool nowAlive = alive && !needNew;
+    unsigned long long newId = ~0ull;
+    bool wantDyn = false;
+    if (needNew) {
+        unsigned long long id = (info.w & F_FRESH) ? (unsigned long long) slot      /* first sample of this slot */
+                              : ((info.w & F_DYNAMIC) ? ~0ull : (unsigned long long) info.x + P.capacity);
+        for (;;) {
+            if (id >= rc.staticIds) { wantDyn = true; break; }
+            uint32_t px, py, k;
+            if (decodeId(rc, S.film, id, px, py, k)) { newId = id; break; }
+            id += P.capacity;       /* ids outside the crop window (edge blocks) are skipped */
+        }
+    }
+    bool dynamicId = false;
+    {
+        const unsigned long long m = __ballot(wantDyn);
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        __syncthreads();                                   /* waveCnt is reused from the shadow compaction */
+        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) before += c; total += c; }
+        if (total) {                                       /* block-uniform */
+            __shared__ unsigned long long dynBase;
+            __shared__ uint32_t dynShard;
+            if (threadIdx.x == 0) {
+                uint32_t sh = (blockIdx.x + rc.blockShard[blockIdx.x]) % DYN_SHARDS;    /* blockShard = shards this block has seen run dry */
+                uint32_t dry = 0;
+                unsigned long long base = ~0ull;
+                for (int tries = 0; tries < DYN_SHARDS; ++tries) {
+                    const unsigned long long old = atomicAdd(rc.dynCounter + (size_t) sh * DYN_STRIDE, (unsigned long long) total);
+                    if (old < rc.shardIds) { base = old; break; }
+                    sh = (sh + 1) % DYN_SHARDS; ++dry;     /* this shard is used up: move on for good */
+                }
+                if (dry) rc.blockShard[blockIdx.x] += dry;
+                dynBase = base; dynShard = sh;
+            }
+            __syncthreads();
+            if (wantDyn) {
+                bool got = false;
+                if (dynBase != ~0ull) {
+                    const unsigned long long off = dynBase + before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+                    const unsigned long long id = rc.staticIds + (unsigned long long) dynShard * rc.shardIds + off;
+                    uint32_t px, py, k;
+                    if (off < rc.shardIds && id < rc.totalIds) {
+                        got = true;                        /* the id is consumed even if it lies outside the crop window */
+                        if (decodeId(rc, S.film, id, px, py, k)) { newId = id; dynamicId = true; }
+                    }
+                }
+                if (!got && dynBase == ~0ull) { info.w = F_DEAD; P.state[slot] = F_DEAD; }   /* all shards empty: slot dies */
+                else if (newId == ~0ull) { info.w = F_DYNAMIC; P.state[slot] = F_DYNAMIC; }                        /* try again next iteration */
+            }
+        }
+    }
+    if (newId != ~0ull) {
+        uint32_t px, py, k;
+        decodeId(rc, S.film, newId, px, py, k);
+        const uint32_t pixel = py * (uint32_t) S.film.width + px;
+        const U4 h = pcg4d(pixel, k, 0, rc.seed);
+        const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+        V3 o, d; float mint, maxt;
+        cameraRay(S.cam, sx, sy, o, d, mint, maxt);
+        P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
+        P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
+        P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        P.mis[slot] = make_float2(0.0f, 0.0f);
+        info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
+        P.info[slot] = info;
+        P.state[slot] = info.w;
+        nowAlive = true;
+    }
+    const uint32_t waveId = slot >> 6;
+    /* a slot still waiting for a dynamic sample id counts as live for the termination test */
+    const bool live = nowAlive || (inRange && info.w == F_DYNAMIC);
+    /* the block retires once none of its slots will ever work again and its last shadow entries have been consumed
+       (this launch queued nothing, so shadowCount is 0): later launches of the pass return at the first line */
+    const bool retire = !__syncthreads_or(live ? 1 : 0) && shadowTotal == 0;
+    if (retire && threadIdx.x == 0) P.blockDead[blockIdx.x] = 1u;
+    if (inRange || (slot & ~63u) < P.capacity) {
+        waveStat(P, ST_VERTICES, waveId, vertices);
+        waveStat(P, ST_SAMPLES, waveId, done);
+        if (rc.countAlive || retire) waveStat(P, ST_ALIVE, waveId, live ? 1ull : 0ull, true);
+    }
+}
+
 /* FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures; MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
    normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
 template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
@@ -228,112 +343,5 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
         }
     }
 
-    /* ---- shadow queue: compact this block's entries to the front of its own region (no global atomics) ---- */
-    uint32_t shadowTotal = 0;
-    {
-        const unsigned long long m = __ballot(pushShadow);
-        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) base += c; total += c; }
-        if (pushShadow) {
-            const size_t sidx = (size_t) blockIdx.x * BLOCK + base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-            P.shadow[3 * sidx] = sh0; P.shadow[3 * sidx + 1] = sh1; P.shadow[3 * sidx + 2] = sh2;
-        }
-        if (threadIdx.x == 0) P.shadowCount[blockIdx.x] = total;
-        shadowTotal = total;
-    }
-
-    /* ---- regeneration: the lane starts a new camera path right away (integrator.cpp:157-183).
-       Sample ids [0, staticIds) follow a static schedule (slot s renders s, s + capacity, ... -- no global
-       counter in steady state).  The last part of the frame is handed out dynamically so that slots whose
-       paths happened to be short keep working until the frame is really finished: one atomicAdd per BLOCK
-       on one of DYN_SHARDS counters (block-aggregated through LDS; each shard owns a contiguous id range). ---- */
-    bool nowAlive = alive && !needNew;
-    unsigned long long newId = ~0ull;
-    bool wantDyn = false;
-    if (needNew) {
-        unsigned long long id = (info.w & F_FRESH) ? (unsigned long long) slot      /* first sample of this slot */
-                              : ((info.w & F_DYNAMIC) ? ~0ull : (unsigned long long) info.x + P.capacity);
-        for (;;) {
-            if (id >= rc.staticIds) { wantDyn = true; break; }
-            uint32_t px, py, k;
-            if (decodeId(rc, S.film, id, px, py, k)) { newId = id; break; }
-            id += P.capacity;       /* ids outside the crop window (edge blocks) are skipped */
-        }
-    }
-    bool dynamicId = false;
-    {
-        const unsigned long long m = __ballot(wantDyn);
-        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-        __syncthreads();                                   /* waveCnt is reused from the shadow compaction */
-        if (lane == 0) waveCnt[wave] = (uint32_t) __popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) before += c; total += c; }
-        if (total) {                                       /* block-uniform */
-            __shared__ unsigned long long dynBase;
-            __shared__ uint32_t dynShard;
-            if (threadIdx.x == 0) {
-                uint32_t sh = (blockIdx.x + rc.blockShard[blockIdx.x]) % DYN_SHARDS;    /* blockShard = shards this block has seen run dry */
-                uint32_t dry = 0;
-                unsigned long long base = ~0ull;
-                for (int tries = 0; tries < DYN_SHARDS; ++tries) {
-                    const unsigned long long old = atomicAdd(rc.dynCounter + (size_t) sh * DYN_STRIDE, (unsigned long long) total);
-                    if (old < rc.shardIds) { base = old; break; }
-                    sh = (sh + 1) % DYN_SHARDS; ++dry;     /* this shard is used up: move on for good */
-                }
-                if (dry) rc.blockShard[blockIdx.x] += dry;
-                dynBase = base; dynShard = sh;
-            }
-            __syncthreads();
-            if (wantDyn) {
-                bool got = false;
-                if (dynBase != ~0ull) {
-                    const unsigned long long off = dynBase + before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-                    const unsigned long long id = rc.staticIds + (unsigned long long) dynShard * rc.shardIds + off;
-                    uint32_t px, py, k;
-                    if (off < rc.shardIds && id < rc.totalIds) {
-                        got = true;                        /* the id is consumed even if it lies outside the crop window */
-                        if (decodeId(rc, S.film, id, px, py, k)) { newId = id; dynamicId = true; }
-                    }
-                }
-                if (!got && dynBase == ~0ull) { info.w = F_DEAD; P.state[slot] = F_DEAD; }   /* all shards empty: slot dies */
-                else if (newId == ~0ull) { info.w = F_DYNAMIC; P.state[slot] = F_DYNAMIC; }                        /* try again next iteration */
-            }
-        }
-    }
-    if (newId != ~0ull) {
-        uint32_t px, py, k;
-        decodeId(rc, S.film, newId, px, py, k);
-        const uint32_t pixel = py * (uint32_t) S.film.width + px;
-        const U4 h = pcg4d(pixel, k, 0, rc.seed);
-        const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
-        V3 o, d; float mint, maxt;
-        cameraRay(S.cam, sx, sy, o, d, mint, maxt);
-        P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
-        P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
-        P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        P.mis[slot] = make_float2(0.0f, 0.0f);
-        info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
-        P.info[slot] = info;
-        P.state[slot] = info.w;
-        nowAlive = true;
-    }
-    const uint32_t waveId = slot >> 6;
-    /* a slot still waiting for a dynamic sample id counts as live for the termination test */
-    const bool live = nowAlive || (inRange && info.w == F_DYNAMIC);
-    /* the block retires once none of its slots will ever work again and its last shadow entries have been consumed
-       (this launch queued nothing, so shadowCount is 0): later launches of the pass return at the first line */
-    const bool retire = !__syncthreads_or(live ? 1 : 0) && shadowTotal == 0;
-    if (retire && threadIdx.x == 0) P.blockDead[blockIdx.x] = 1u;
-    if (inRange || (slot & ~63u) < P.capacity) {
-        waveStat(P, ST_VERTICES, waveId, vertices);
-        waveStat(P, ST_SAMPLES, waveId, done);
-        if (rc.countAlive || retire) waveStat(P, ST_ALIVE, waveId, live ? 1ull : 0ull, true);
-    }
+    shadeEpilogue(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh0, sh1, sh2, vertices, done);
 }
-

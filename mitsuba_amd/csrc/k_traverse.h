@@ -325,7 +325,7 @@ struct TraceSource {
         return h;
     }
     __device__ __forceinline__ bool load(uint32_t slot, V3 &o, V3 &d, float &mint, float &maxt) const {
-        if (!(P.state[slot] & F_ALIVE)) return false;
+        if ((P.state[slot] & F_TRACE_MASK) != F_ALIVE) return false;
         const float4 ro = P.rayO[slot], rd = P.rayD[slot];
         o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
         return true;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) slot * SPILL_DEPTH, stk);
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     if (slot < P.capacity) {
-        if (P.state[slot] & F_ALIVE) {
+        if ((P.state[slot] & F_TRACE_MASK) == F_ALIVE) {
             const float4 ro = P.rayO[slot], rd = P.rayD[slot];
             const V3 o(ro.x, ro.y, ro.z), d(rd.x, rd.y, rd.z);
             float mint, maxt;

@@ -60,6 +60,7 @@ static int setErr(int code, const std::string &msg) { g_err = msg; return code; 
 #include "k_traverse.h"
 #include "k_group8.h"
 #include "k_shade.h"
+#include "k_shade_direct.h"
 #include "k_film.h"
 
 /* ======================================================================================
@@ -180,7 +181,7 @@ struct phip_scene {
     DevBuf<float4> envTexels; DevBuf<DevMipLevels> envLevels; DevBuf<float> envCdfRows, envCdfCols, envRowWeights;     /* `envmap` emitter */
     DevScene dev;
     /* render-time buffers (grown on demand, reused between calls) */
-    DevBuf<float4> rayO, rayD, hit, thr, shadow, L, sampleOut;
+    DevBuf<float4> rayO, rayD, hit, thr, camHit, shadow, L, sampleOut;
     DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
@@ -622,9 +623,18 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     if (p->spp <= 0) throw std::invalid_argument("spp must be > 0");
+    if (p->integrator != PHIP_INTEGRATOR_DIRECT)
     if (p->rr_depth <= 0) throw std::invalid_argument("'rrDepth' must be set to a value greater than zero!");                       /* integrator.cpp:219-220 */
+    if (p->integrator != PHIP_INTEGRATOR_DIRECT)
     if (p->max_depth <= 0 && p->max_depth != -1) throw std::invalid_argument("'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); /* :222-223 */
     if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
+    if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::invalid_argument("unknown integrator kind");
+    const bool direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
+    if (direct) {
+        if (p->emitter_samples < 0 || p->bsdf_samples < 0) throw std::invalid_argument("direct: emitterSamples and bsdfSamples must not be negative");
+        if (p->emitter_samples + p->bsdf_samples <= 0) throw std::invalid_argument("direct: emitterSamples + bsdfSamples must be > 0");     /* Assert, direct.cpp:107 */
+        if (p->emitter_samples + p->bsdf_samples >= (int) DEPTH_MASK) throw std::invalid_argument("direct: at most 65534 shading samples per camera sample");
+    }
     if (sc->dev.env.w > 0 && sc->envLevelCount <= 1 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
         throw std::invalid_argument("envmap without MIP levels: directly visible background needs the filtered (EWA) lookup of envmap.cpp:395-407: "
                                     "pass the pyramid, render with hideEmitters or set PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
@@ -697,7 +707,9 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         sc->shadowCount.alloc(nBlocks); sc->blockDead.alloc(nBlocks); sc->blockShard.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
         sc->spill8.alloc((size_t) nWaves * 8 * SPILL8);
     }
+    if (direct && sc->camHit.n < capacity) sc->camHit.alloc(capacity);
     PathPool P;
+    P.camHit = sc->camHit.p;
     P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.mis = sc->mis.p; P.info = sc->info.p; P.state = sc->state.p;
     P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.blockDead = sc->blockDead.p; P.stat = sc->stat.p; P.spill = sc->spill.p; P.spill8 = sc->spill8.p; P.capacity = capacity; P.nWaves = nWaves;
     if (sc->L.n < idsFirstPass) sc->L.alloc((size_t) idsFirstPass);
@@ -737,6 +749,16 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
         rc.seed = p->seed; rc.tileOrigin = sc->tileOrigin.p; rc.countAlive = 0;
         rc.diffScaleFactor = 1.0f / sqrtf((float) p->spp);
+        rc.emitterSamples = direct ? p->emitter_samples : 0; rc.bsdfSamples = direct ? p->bsdf_samples : 0;
+        if (direct) {   /* direct.cpp:130-138 */
+            const size_t sum = (size_t) p->emitter_samples + (size_t) p->bsdf_samples;
+            rc.weightBSDF = 1 / (float) (size_t) p->bsdf_samples;
+            rc.weightLum = 1 / (float) (size_t) p->emitter_samples;
+            rc.fracBSDF = (size_t) p->bsdf_samples / (float) sum;
+            rc.fracLum = (size_t) p->emitter_samples / (float) sum;
+        } else {
+            rc.weightBSDF = rc.weightLum = 1.0f; rc.fracBSDF = rc.fracLum = 0.5f;
+        }
         rc.envFiltered = (sc->envLevelCount > 1 && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND)) ? 1u : 0u;
         /* static share: the first 3/4 of every slot's samples; the remainder is handed out dynamically */
         {
@@ -772,8 +794,12 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
                 static const ShadeKernel table[4][2][4] = { { SHADE_ROW(false, 0), SHADE_ROW(true, 0) }, { SHADE_ROW(false, 1), SHADE_ROW(true, 1) },
                                                             { SHADE_ROW(false, 2), SHADE_ROW(true, 2) }, { SHADE_ROW(false, 3), SHADE_ROW(true, 3) } };
 #undef SHADE_ROW
+                /* `direct`: leaf BSDF models = diffuse only / all, strictNormals at run time */
+                static const ShadeKernel directTable[4][2] = { { k_shade_direct<0, 0>, k_shade_direct<MM_ALL, 0> }, { k_shade_direct<0, 1>, k_shade_direct<MM_ALL, 1> },
+                                                               { k_shade_direct<0, 2>, k_shade_direct<MM_ALL, 2> }, { k_shade_direct<0, 3>, k_shade_direct<MM_ALL, 3> } };
                 const int feat = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0);     /* environment emitter, bitmap textures */
-                hipLaunchKernelGGL(table[feat][rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
+                if (direct) hipLaunchKernelGGL(directTable[feat][(sc->materialMask & MM_ALL) ? 1 : 0], grid, block, 0, stream, D, P, rc, sc->L.p);
+                else hipLaunchKernelGGL(table[feat][rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
             }
             if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
             if (merged) {

@@ -7,6 +7,8 @@ reference's own:
       maxDepth / rrDepth / strictNormals / hideEmitters                      src/librender/integrator.cpp:190-225
     PathHIP.render(scene)    <-> SamplingIntegrator::render(scene, queue, job, ...) -> bool   integrator.cpp:95-129
     PathHIP.cancel()         <-> SamplingIntegrator::cancel                  integrator.cpp:90-93
+    DirectHIP(props)         <-> MIDirectIntegrator(const Properties &)      src/integrators/direct/direct.cpp:91-108
+      shadingSamples / emitterSamples / bsdfSamples / strictNormals / hideEmitters
     Scene(desc)              <-> Scene::initialize (kd-tree build -> BVH build + upload)       scene.cpp:322-384
     HDRFilm.put / develop    <-> HDRFilm::put(const ImageBlock *) / develop  films/hdrfilm.cpp:391-393,427-475
 
@@ -32,6 +34,12 @@ class Properties(dict):
 
     def getBoolean(self, name, default):
         return bool(self.get(name, default))
+
+    def getSize(self, name, default):
+        v = int(self.get(name, default))
+        if v < 0:
+            raise RuntimeError("Size property '%s': expected a nonnegative value!" % name)     # properties.cpp getSize
+        return v
 
 
 class Scene:
@@ -165,3 +173,28 @@ class PathHIP:
     def cancel(self):
         if self._scene is not None:
             _ffi.lib().phip_cancel(self._scene._h)
+
+
+class DirectHIP(PathHIP):
+    """`direct_hip` integrator: MIDirectIntegrator semantics (direct.cpp:149-312) on the same kernels."""
+
+    def __init__(self, props=None, **kw):
+        props = Properties("direct_hip", **(dict(props or {}) | kw))
+        # direct.cpp:94-107
+        shadingSamples = props.getSize("shadingSamples", 1)
+        self.m_emitterSamples = props.getSize("emitterSamples", shadingSamples)
+        self.m_bsdfSamples = props.getSize("bsdfSamples", shadingSamples)
+        self.m_strictNormals = props.getBoolean("strictNormals", False)
+        self.m_hideEmitters = props.getBoolean("hideEmitters", False)
+        if self.m_emitterSamples + self.m_bsdfSamples <= 0:
+            raise RuntimeError("Assertion 'm_emitterSamples + m_bsdfSamples > 0' failed")
+        self.m_rrDepth, self.m_maxDepth = 5, -1          # not parameters of this integrator
+        self.stats = None
+        self._scene = None
+
+    def params(self, scene, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None):
+        p = super().params(scene, spp, seed, shard_index, shard_count, flags, stream)
+        p.integrator = A.PHIP_INTEGRATOR_DIRECT
+        p.emitter_samples = self.m_emitterSamples
+        p.bsdf_samples = self.m_bsdfSamples
+        return p

@@ -18,7 +18,7 @@
  * renderproc.cpp:80-82); with the ctr stream the order only permutes float additions.
  */
 #pragma once
-#include "o_path.h"
+#include "o_direct.h"
 #include <thread>
 #include <atomic>
 #include <mutex>
@@ -226,6 +226,8 @@ inline void spiralBlocks(int sizeX, int sizeY, int blockSize, std::vector<std::a
 struct RenderParams {
     int spp = 4, blockSize = 32, threads = 1;
     IntegratorParams ip;
+    bool direct = false;                 /* MIDirectIntegrator instead of MIPathTracer */
+    DirectParams dp;
     bool ctr = true; uint32_t seed = 0;
     int shardIndex = 0, shardCount = 1;
 };
@@ -275,6 +277,7 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
             for (int y = 0; y < b[3]; ++y) for (int x = 0; x < b[2]; ++x) {
                 const int px = blk.offX + x, py = blk.offY + y;     /* crop-window pixel coordinates */
                 smp.pixel = (uint32_t) (py * f.crop_width + px);
+                if (rp.direct) smp.generateDirectArrays((size_t) rp.spp, rp.dp.emitterSamples, rp.dp.bsdfSamples);   /* sampler->generate(offset), integrator.cpp:164 */
                 for (int j = 0; j < rp.spp; ++j) {
                     smp.sample = (uint32_t) j;
                     Vec2 jit = smp.cameraSample();
@@ -285,7 +288,8 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
                     rx = ray.d + (rx - ray.d) * diffScaleFactor;
                     ry = ray.d + (ry - ray.d) * diffScaleFactor;
                     Float alpha;
-                    Spectrum spec = pathLi(scene, rp.ip, ray, smp, alpha, &pc, &rx, &ry);
+                    Spectrum spec = rp.direct ? directLi(scene, rp.dp, ray, smp, alpha, &pc, rx, ry)
+                                              : pathLi(scene, rp.ip, ray, smp, alpha, &pc, &rx, &ry);
                     Float temp[5] = { spec[0], spec[1], spec[2], alpha, 1.0f };
                     if (!blk.put(samplePos, temp)) pc.invalidSamples++;
                     if (sampleOut) {

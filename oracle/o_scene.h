@@ -157,6 +157,31 @@ struct SampleSource {
         if (!ctr) return rng->nextFloat();
         float f[4]; block(2 + 2 * (uint32_t) (depth - 1), f); return f[0];
     }
+
+    /* ---- `direct`: sample arrays (which = 0: emitter samples, 1: BSDF samples) ----
+       ctr stream: block 1 + i holds (emitter sample i, BSDF sample i).
+       sfmt stream: like `independent` -- arrays with more than one entry are drawn for all samples of the pixel by
+       Sampler::generate (independent.cpp:82-93) and handed out per sample by next2DArray (sampler.cpp:82-92); a
+       single sample is drawn on the spot by nextSample2D, even when it ends up unused (direct.cpp:212-216, 251-255). */
+    std::vector<Vec2> arrays[2];
+    Vec2 single[2];
+    void generateDirectArrays(size_t sampleCount, size_t emitterSamples, size_t bsdfSamples) {
+        if (ctr) return;
+        const size_t n[2] = { emitterSamples, bsdfSamples };
+        for (int w = 0; w < 2; ++w) {
+            arrays[w].clear();
+            if (n[w] > 1)
+                for (size_t j = 0; j < sampleCount * n[w]; ++j) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); arrays[w].push_back(Vec2(a, b)); }
+        }
+    }
+    void beginDirectArray(int which, size_t count) {
+        if (!ctr && count <= 1) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); single[which] = Vec2(a, b); }
+    }
+    Vec2 directSample(int which, size_t i, size_t count) const {
+        if (!ctr) return count > 1 ? arrays[which][(size_t) sample * count + i] : single[which];
+        float f[4]; block(1 + (uint32_t) i, f);
+        return which == 0 ? Vec2(f[0], f[1]) : Vec2(f[2], f[3]);
+    }
 };
 
 struct PathCounters {

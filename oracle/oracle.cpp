@@ -51,6 +51,15 @@ int oracle_render(void *scene_, const phip_render_params *p, int threads, int sa
         rp.ip.strictNormals = p->strict_normals != 0; rp.ip.hideEmitters = p->hide_emitters != 0;
         rp.ctr = sampler_mode == 0; rp.seed = p->seed;
         rp.shardIndex = p->shard_index; rp.shardCount = p->shard_count > 0 ? p->shard_count : 1;
+        rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
+        if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::runtime_error("unknown integrator");
+        if (rp.direct) {
+            if (p->emitter_samples < 0 || p->bsdf_samples < 0) throw std::runtime_error("direct: negative sample count");
+            rp.dp.emitterSamples = (size_t) p->emitter_samples; rp.dp.bsdfSamples = (size_t) p->bsdf_samples;
+            rp.dp.strictNormals = rp.ip.strictNormals; rp.dp.hideEmitters = rp.ip.hideEmitters;
+            rp.dp.configure();
+            rp.ip.rrDepth = 5; rp.ip.maxDepth = -1;          /* unused by `direct` */
+        }
         /* integrator.cpp:219-224 */
         if (rp.ip.rrDepth <= 0) throw std::runtime_error("'rrDepth' must be set to a value greater than zero!");
         if (rp.ip.maxDepth <= 0 && rp.ip.maxDepth != -1) throw std::runtime_error("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");

@@ -38,16 +38,15 @@ def soup(rng, n, size=1.0, extent=10.0):
     return p, idx
 
 
-def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, **ikw):
+def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None, **ikw):
     from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
     gs = Scene(desc)
-    integ = PathHIP(**ikw)
+    integ = (integrator or PathHIP)(**ikw)
     film = HDRFilm(gs.width, gs.height)
     assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
     gsmp = integ.samples(gs, spp)
     osc = oracle.OracleScene(desc)
-    p = A.default_render_params(spp=spp, max_depth=integ.m_maxDepth, rr_depth=integ.m_rrDepth,
-                                strict_normals=int(integ.m_strictNormals), hide_emitters=int(integ.m_hideEmitters))
+    p = integ.params(gs, spp)           # the same phip_render_params the GPU call received (minus the sample-buffer flag)
     ofilm, osmp, ost = osc.render(p, want_samples=True)
     same = (gsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1)
     g, o = film.develop(), oracle.develop(ofilm)
