@@ -13,70 +13,35 @@
  *   - derives from MonteCarloIntegrator so that maxDepth / rrDepth / strictNormals / hideEmitters
  *     parse, validate and serialise exactly like `path` (src/librender/integrator.cpp:190-225);
  *   - preprocess(): flattens Scene::getShapes() into a phip_scene_desc (every Shape through
- *     createTriMesh() unless it already is a TriMesh) and calls phip_scene_create;
+ *     createTriMesh() unless it already is a TriMesh) and calls phip_scene_create (phip_flatten.h, shared with direct_hip.cpp);
  *   - render(): overrides SamplingIntegrator::render (integrator.cpp:95-129): one phip_render call,
  *     then film->put() of one full-frame ImageBlock; returns false when cancelled;
  *   - cancel(): phip_cancel (integrator.cpp:90-93);
  *   - Li(): still required by the interface (integrator.h:321-322, used by `adaptive`/`irrcache`):
  *     delegates to a nested CPU `path` integrator with the same parameters.
  */
-#include <mitsuba/render/scene.h>
-#include <mitsuba/render/renderproc.h>
-#include <mitsuba/core/plugin.h>
-#include <mitsuba/core/fresolver.h>
-#include <boost/algorithm/string.hpp>
-#include "phip.h"
-
-#include <mitsuba/render/mipmap.h>
+#include "phip_flatten.h"
 
 MTS_NAMESPACE_BEGIN
 
-/* What the shim needs of src/emitters/envmap.cpp's EnvironmentMap (a plugin-local class): its MIP pyramid.  With the
-   accessor of INTEGRATION.md added there and the class declaration moved to a header, this stand-in goes away. */
-class EnvironmentMapAccess : public Emitter {
-public:
-    typedef TSpectrum<half, SPECTRUM_SAMPLES> SpectrumHalf;
-    typedef TMIPMap<Spectrum, SpectrumHalf> MIPMap;
-    virtual const MIPMap *getMIPMap() const = 0;
-};
-
-/* Same for src/bsdfs/diffuse.cpp's SmoothDiffuse (its reflectance texture) and src/textures/bitmap.cpp's BitmapTexture
-   (MIP pyramid and lookup parameters): plugin-local classes without getters for what the device needs. */
-class SmoothDiffuseAccess : public BSDF {
-public:
-    virtual const Texture *getReflectanceTexture() const = 0;
-};
-class BitmapTextureAccess : public Texture2D {
-public:
-    typedef TMIPMap<Color3, Color3h> MIPMap3;
-    virtual const MIPMap3 *getMIPMap3() const = 0;
-    virtual ReconstructionFilter::EBoundaryCondition getWrapModeU() const = 0;
-    virtual ReconstructionFilter::EBoundaryCondition getWrapModeV() const = 0;
-    virtual Float getMaxAnisotropy() const = 0;
-    virtual Vector2 getUVScale() const = 0;
-    virtual Point2 getUVOffset() const = 0;
-};
-
 class PathHIP : public MonteCarloIntegrator {
 public:
-    PathHIP(const Properties &props) : MonteCarloIntegrator(props), m_scene(NULL) {
-        m_device = props.getInteger("device", 0);
+    PathHIP(const Properties &props) : MonteCarloIntegrator(props) {
+        m_holder.setDevice(props.getInteger("device", 0));
         Properties p("path");
         p.setInteger("maxDepth", m_maxDepth); p.setInteger("rrDepth", m_rrDepth);
         p.setBoolean("strictNormals", m_strictNormals); p.setBoolean("hideEmitters", m_hideEmitters);
         m_cpuPath = static_cast<SamplingIntegrator *>(PluginManager::getInstance()->createObject(MTS_CLASS(Integrator), p));
     }
 
-    PathHIP(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager), m_scene(NULL) {
-        m_device = stream->readInt();
+    PathHIP(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager) {
+        m_holder.setDevice(stream->readInt());
         m_cpuPath = static_cast<SamplingIntegrator *>(manager->getInstance(stream));
     }
 
-    virtual ~PathHIP() { if (m_scene) phip_scene_destroy(m_scene); }
-
     void serialize(Stream *stream, InstanceManager *manager) const {
         MonteCarloIntegrator::serialize(stream, manager);
-        stream->writeInt(m_device);
+        stream->writeInt(m_holder.getDevice());
         manager->serialize(stream, m_cpuPath.get());
     }
 
@@ -85,252 +50,23 @@ public:
     bool preprocess(const Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
         if (!MonteCarloIntegrator::preprocess(scene, queue, job, sceneResID, sensorResID, samplerResID))
             return false;
-        flatten(scene);
+        m_holder.flatten(scene);
         return true;
     }
 
     bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
-        ref<Sensor> sensor = scene->getSensor();
-        ref<Film> film = sensor->getFilm();
-        const Vector2i size = film->getCropSize();
-        Log(EInfo, "Starting render job (%ix%i, " SIZE_T_FMT " samples, %s) ..", size.x, size.y,
-            scene->getSampler()->getSampleCount(), phip_version());
-
         phip_render_params rp; memset(&rp, 0, sizeof(rp));
-        rp.spp = (int32_t) scene->getSampler()->getSampleCount();
+        rp.integrator = PHIP_INTEGRATOR_PATH;
         rp.max_depth = m_maxDepth; rp.rr_depth = m_rrDepth;
         rp.strict_normals = m_strictNormals; rp.hide_emitters = m_hideEmitters;
-        rp.block_size = (int32_t) scene->getBlockSize();
-        rp.sampler = PHIP_SAMPLER_CTR; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
-
-        ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, size, film->getReconstructionFilter());
-        block->setOffset(Point2i(0, 0));            /* crop-relative, like renderproc.cpp:160-173 */
-        /* ImageBlock without border: border pixels are already folded in by the device film pass */
-        ref<Bitmap> target = new Bitmap(Bitmap::EMultiSpectrumAlphaWeight, Bitmap::EFloat32, size, SPECTRUM_SAMPLES + 2);
-        phip_stats st;
-        int rc = phip_render(m_scene, &rp, target->getFloat32Data(), &st);
-        if (rc == PHIP_ERR_CANCELLED)
-            return false;
-        if (rc != PHIP_OK)
-            Log(EError, "path_hip: %s", phip_last_error());     /* throws std::runtime_error, caught by RenderJob::run */
-        film->setBitmap(target);                                  /* hdrfilm.cpp:395-425: replaces m_storage's bitmap */
-        queue->signalRefresh(job);
-        Log(EInfo, "path_hip: %.1f Msamples/s, %.1f Mrays/s, mean path length %.2f", st.samples / 1e3 / st.render_ms,
-            (st.closest_rays + st.shadow_rays) / 1e3 / st.render_ms, (double) st.path_vertices / (double) st.samples);
-        return true;
+        return m_holder.render(scene, queue, job, rp, "path_hip");
     }
 
-    void cancel() { if (m_scene) phip_cancel(m_scene); }
+    void cancel() { if (m_holder.get()) phip_cancel(m_holder.get()); }
 
     MTS_DECLARE_CLASS()
-
 private:
-    /* ---- Scene -> phip_scene_desc ---- */
-    void flatten(const Scene *scene) {
-        std::vector<float> positions, normals, texcoords; std::vector<uint32_t> indices;
-        bool anyTexcoords = false;
-        std::vector<phip_shape> shapes; std::vector<phip_material> materials; std::vector<phip_emitter> emitters;
-        std::map<const BSDF *, uint32_t> bsdfIds;
-        std::map<const Shape *, uint32_t> shapeIds;
-        phip_envmap envmap; memset(&envmap, 0, sizeof(envmap));
-        bool anyNormals = false;
-
-        const ref_vector<Shape> &list = scene->getShapes();
-        for (size_t i = 0; i < list.size(); ++i) {
-            const Shape *shape = list[i].get();
-            ref<TriMesh> mesh;
-            if (shape->getClass()->derivesFrom(MTS_CLASS(TriMesh)))
-                mesh = const_cast<TriMesh *>(static_cast<const TriMesh *>(shape));
-            else
-                mesh = const_cast<Shape *>(shape)->createTriMesh();       /* rectangle.cpp:170-203, cube, disk, sphere ... */
-            if (!mesh)
-                Log(EError, "path_hip: shape \"%s\" cannot be converted to a triangle mesh", shape->getName().c_str());
-            phip_shape s; memset(&s, 0, sizeof(s));
-            s.first_vertex = (uint32_t) (positions.size() / 3); s.n_vertices = (uint32_t) mesh->getVertexCount();
-            s.first_triangle = (uint32_t) (indices.size() / 3); s.n_triangles = (uint32_t) mesh->getTriangleCount();
-            s.has_normals = mesh->getVertexNormals() ? 1 : 0; anyNormals |= s.has_normals != 0;
-            s.has_texcoords = mesh->getVertexTexcoords() ? 1 : 0; anyTexcoords |= s.has_texcoords != 0;
-            for (size_t v = 0; v < mesh->getVertexCount(); ++v) {
-                const Point &p = mesh->getVertexPositions()[v];
-                positions.push_back(p.x); positions.push_back(p.y); positions.push_back(p.z);
-                Normal n = mesh->getVertexNormals() ? mesh->getVertexNormals()[v] : Normal(0.0f);
-                normals.push_back(n.x); normals.push_back(n.y); normals.push_back(n.z);
-                Point2 uv = mesh->getVertexTexcoords() ? mesh->getVertexTexcoords()[v] : Point2(0.0f);
-                texcoords.push_back(uv.x); texcoords.push_back(uv.y);
-            }
-            for (size_t t = 0; t < mesh->getTriangleCount(); ++t)
-                for (int k = 0; k < 3; ++k) indices.push_back(s.first_vertex + mesh->getTriangles()[t].idx[k]);
-            s.material = convertBSDF(shape->getBSDF(), materials, bsdfIds);
-            s.emitter = -1;
-            shapeIds[shape] = (uint32_t) shapes.size();
-            shapes.push_back(s);
-        }
-        /* emitters in the order of Scene::getEmitters(): the selection PDF (scene.cpp:375-381) is built in that order */
-        const ref_vector<Emitter> &ems = scene->getEmitters();
-        for (size_t i = 0; i < ems.size(); ++i) {
-            const Emitter *e = ems[i].get();
-            const std::string cls = e->getClass()->getName();
-            phip_emitter pe; memset(&pe, 0, sizeof(pe));
-            Spectrum rad = e->getProperties().getSpectrum("radiance", Spectrum::getD65());   /* area.cpp:80, constant.cpp:48 */
-            Float r, g, b; rad.toLinearRGB(r, g, b);
-            pe.radiance[0] = r; pe.radiance[1] = g; pe.radiance[2] = b;
-            pe.sampling_weight = e->getSamplingWeight();
-            if (cls == "AreaLight") {
-                std::map<const Shape *, uint32_t>::const_iterator it = shapeIds.find(e->getShape());
-                if (it == shapeIds.end())
-                    Log(EError, "path_hip: area emitter without a shape in the scene");
-                pe.type = PHIP_EMITTER_AREA; pe.shape = it->second;
-                shapes[it->second].emitter = (int32_t) emitters.size();
-            } else if (cls == "ConstantBackgroundEmitter") {
-                pe.type = PHIP_EMITTER_CONSTANT; pe.shape = 0xFFFFFFFFu;     /* the library derives m_sceneBSphere itself */
-            } else if (cls == "EnvironmentMap") {
-                /* the MIP pyramid exactly as the plugin built and stores it (half precision, read back as float RGB): level 0
-                   drives the illumination (envmap.cpp:516-632), all levels the EWA lookup of directly visible pixels
-                   (envmap.cpp:395-407).  EnvironmentMap keeps m_mipmap private: INTEGRATION.md lists the one-line accessor
-                   `const MIPMap *getMIPMap() const { return m_mipmap; }` this needs. */
-                pe.type = PHIP_EMITTER_ENVMAP; pe.shape = 0xFFFFFFFFu;
-                const EnvironmentMapAccess *env = static_cast<const EnvironmentMapAccess *>(e);
-                const int nLevels = env->getMIPMap()->getLevels();
-                if (nLevels > PHIP_ENVMAP_MAX_LEVELS) Log(EError, "path_hip: environment map with too many MIP levels");
-                m_envLevels.clear();
-                for (int l = 0; l < nLevels; ++l) {
-                    m_envLevels.push_back(env->getMIPMap()->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
-                    envmap.levels[l] = m_envLevels[l]->getFloat32Data();
-                }
-                envmap.n_levels = (uint32_t) nLevels;
-                envmap.texels = m_envLevels[0]->getFloat32Data();
-                envmap.width = (uint32_t) m_envLevels[0]->getWidth(); envmap.height = (uint32_t) m_envLevels[0]->getHeight();
-                envmap.scale = e->getProperties().getFloat("scale", 1.0f);
-                const Matrix4x4 &tw = e->getWorldTransform()->eval(0).getMatrix();
-                for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) envmap.to_world[4 * r + c] = tw(r, c);
-            } else {
-                Log(EError, "path_hip: emitter \"%s\" is not supported (area, constant, envmap)", cls.c_str());
-            }
-            emitters.push_back(pe);
-        }
-
-        phip_scene_desc d; memset(&d, 0, sizeof(d));
-        d.abi_version = PHIP_ABI_VERSION;
-        d.n_vertices = (uint32_t) (positions.size() / 3); d.positions = positions.data(); d.normals = anyNormals ? normals.data() : NULL;
-        d.n_triangles = (uint32_t) (indices.size() / 3); d.indices = indices.data();
-        d.n_shapes = (uint32_t) shapes.size(); d.shapes = shapes.data();
-        d.n_materials = (uint32_t) materials.size(); d.materials = materials.data();
-        d.n_emitters = (uint32_t) emitters.size(); d.emitters = emitters.data();
-        d.texcoords = anyTexcoords ? texcoords.data() : NULL;
-        d.n_textures = (uint32_t) m_textures.size(); d.textures = m_textures.empty() ? NULL : &m_textures[0];
-        d.envmap = envmap;
-
-        const Sensor *sensor = scene->getSensor();
-        if (sensor->getClass()->getName() != "PerspectiveCameraImpl")
-            Log(EError, "path_hip: only the 'perspective' sensor is supported");
-        const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);
-        const Matrix4x4 &m = cam->getWorldTransform(0).getMatrix();
-        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) d.camera.to_world[4 * r + c] = m(r, c);
-        d.camera.xfov_deg = cam->getXFov(); d.camera.near_clip = cam->getNearClip(); d.camera.far_clip = cam->getFarClip();
-
-        const Film *film = sensor->getFilm();
-        d.film.width = film->getSize().x; d.film.height = film->getSize().y;
-        d.film.crop_offset_x = film->getCropOffset().x; d.film.crop_offset_y = film->getCropOffset().y;
-        d.film.crop_width = film->getCropSize().x; d.film.crop_height = film->getCropSize().y;
-        const ReconstructionFilter *rf = film->getReconstructionFilter();
-        d.film.filter_radius = rf->getRadius();
-        for (int i = 0; i <= PHIP_FILTER_RESOLUTION; ++i)      /* evalDiscretized(x) = m_values[min(int(|x| * res/radius), res)] */
-            d.film.filter_table[i] = rf->evalDiscretized((i + 0.5f) * rf->getRadius() / PHIP_FILTER_RESOLUTION);
-
-        if (m_scene) phip_scene_destroy(m_scene);
-        m_scene = phip_scene_create(&d, m_device);
-        if (!m_scene)
-            Log(EError, "path_hip: %s", phip_last_error());
-    }
-
-    static void rgb(const Spectrum &s, float out[3]) { Float r, g, b; s.toLinearRGB(r, g, b); out[0] = r; out[1] = g; out[2] = b; }
-
-    /* <texture type="bitmap">: the RGB MIP pyramid as the plugin built and stores it + the lookup parameters
-       (bitmap.cpp: wrapModeU/V, filterType, maxAnisotropy; Texture2D: uscale/vscale/uoffset/voffset) */
-    uint32_t convertBitmap(const BitmapTextureAccess *tex) {
-        std::map<const Texture *, uint32_t>::iterator it = m_textureIds.find(tex);
-        if (it != m_textureIds.end()) return it->second;
-        const BitmapTextureAccess::MIPMap3 *mip = tex->getMIPMap3();
-        if (!mip) Log(EError, "path_hip: only RGB bitmap textures are supported");
-        phip_texture t; memset(&t, 0, sizeof(t));
-        t.n_levels = (uint32_t) mip->getLevels();
-        for (int l = 0; l < mip->getLevels(); ++l) {
-            m_textureLevels.push_back(mip->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
-            t.levels[l] = m_textureLevels.back()->getFloat32Data();
-        }
-        t.width = (uint32_t) mip->getWidth(); t.height = (uint32_t) mip->getHeight();
-        t.wrap_u = (uint32_t) tex->getWrapModeU(); t.wrap_v = (uint32_t) tex->getWrapModeV();      /* EBoundaryCondition order = phip_wrap_mode */
-        t.filter_type = (uint32_t) mip->getFilterType(); t.max_anisotropy = tex->getMaxAnisotropy();
-        t.uv_scale[0] = tex->getUVScale().x; t.uv_scale[1] = tex->getUVScale().y;
-        t.uv_offset[0] = tex->getUVOffset().x; t.uv_offset[1] = tex->getUVOffset().y;
-        uint32_t id = (uint32_t) m_textures.size();
-        m_textures.push_back(t); m_textureIds[tex] = id;
-        return id;
-    }
-
-    uint32_t convertBSDF(const BSDF *bsdf, std::vector<phip_material> &materials, std::map<const BSDF *, uint32_t> &ids) {
-        std::map<const BSDF *, uint32_t>::iterator it = ids.find(bsdf);
-        if (it != ids.end()) return it->second;
-        phip_material m; memset(&m, 0, sizeof(m));
-        const std::string cls = bsdf->getClass()->getName();
-        const Properties &props = bsdf->getProperties();
-        Intersection its;       /* constant textures only: any intersection record evaluates to the same value */
-        if (cls == "SmoothDiffuse") {
-            m.type = PHIP_BSDF_DIFFUSE;
-            const Texture *tex = static_cast<const SmoothDiffuseAccess *>(bsdf)->getReflectanceTexture();   /* accessor: INTEGRATION.md */
-            if (tex->getClass()->getName() == "BitmapTexture")
-                m.reflectance_texture = 1 + convertBitmap(static_cast<const BitmapTextureAccess *>(tex));
-            else if (tex->isConstant())
-                rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
-            else
-                Log(EError, "path_hip: texture \"%s\" is not supported (constant, bitmap)", tex->getClass()->getName().c_str());
-        } else if (cls == "SmoothDielectric") {
-            m.type = PHIP_BSDF_DIELECTRIC; m.eta[0] = bsdf->getEta();
-            rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
-            rgb(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.transmittance);
-        } else if (cls == "RoughConductor") {
-            m.type = PHIP_BSDF_ROUGHCONDUCTOR;
-            /* roughconductor.cpp:176-190: eta / k from data/ior/<material>.{eta,k}.spd unless given explicitly */
-            ref<FileResolver> fResolver = Thread::getThread()->getFileResolver();
-            std::string material = props.getString("material", "Cu");
-            Spectrum intEta, intK;
-            if (boost::to_lower_copy(material) == "none") { intEta = Spectrum(0.0f); intK = Spectrum(1.0f); }
-            else {
-                intEta.fromContinuousSpectrum(InterpolatedSpectrum(fResolver->resolve("data/ior/" + material + ".eta.spd")));
-                intK.fromContinuousSpectrum(InterpolatedSpectrum(fResolver->resolve("data/ior/" + material + ".k.spd")));
-            }
-            Float extEta = lookupIOR(props, "extEta", "air");
-            rgb(props.getSpectrum("eta", intEta) / extEta, m.eta); rgb(props.getSpectrum("k", intK) / extEta, m.k);
-            rgb(bsdf->getSpecularReflectance(its), m.reflectance);
-            MicrofacetDistribution distr(props);
-            if (distr.getType() == MicrofacetDistribution::EPhong)
-                Log(EError, "path_hip: the phong/as microfacet distribution is not supported");
-            m.distribution = distr.getType() == MicrofacetDistribution::EGGX ? PHIP_MF_GGX : PHIP_MF_BECKMANN;
-            m.alpha_u = distr.getAlphaU(); m.alpha_v = distr.getAlphaV(); m.sample_visible = distr.getSampleVisible() ? 1 : 0;
-        } else if (cls == "TwoSidedBRDF") {
-            /* twosided.cpp keeps its children in m_nestedBRDF[2]; they are reachable as named children */
-            std::vector<const BSDF *> nested = getNestedBSDFs(bsdf);
-            uint32_t a = convertBSDF(nested[0], materials, ids), b = nested.size() > 1 ? convertBSDF(nested[1], materials, ids) : a;
-            m.type = PHIP_BSDF_TWOSIDED; m.nested[0] = a; m.nested[1] = b;
-        } else {
-            Log(EError, "path_hip: BSDF '%s' is outside the supported set (diffuse, dielectric, roughconductor, twosided)", cls.c_str());
-        }
-        if (bsdf->getType() & BSDF::ESpatiallyVarying)
-            Log(EError, "path_hip: textured BSDF parameters are not supported yet (SURVEY 8f)");
-        materials.push_back(m);
-        ids[bsdf] = (uint32_t) materials.size() - 1;
-        return ids[bsdf];
-    }
-
-    /* the adapter exposes no getter for its children; a two-line accessor has to be added to twosided.cpp
-       (`const BSDF *getNestedBRDF(int i) const { return m_nestedBRDF[i]; }`) -- see INTEGRATION.md */
-    static std::vector<const BSDF *> getNestedBSDFs(const BSDF *bsdf);
-
-    phip_scene *m_scene;
-    std::vector<phip_texture> m_textures; std::map<const Texture *, uint32_t> m_textureIds;
-    std::vector<ref<Bitmap> > m_textureLevels;   /* float RGB copies of the textures' MIP levels */
-    std::vector<ref<Bitmap> > m_envLevels;   /* float RGB copies of the environment map's MIP levels (alive until phip_scene_create) */
-    int m_device;
+    PhipSceneHolder m_holder;
     ref<SamplingIntegrator> m_cpuPath;
 };
 
