@@ -885,7 +885,9 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
 extern "C" {
 
 const char *phip_last_error(void) { return g_err.c_str(); }
-const char *phip_version(void) { return "path_hip 0.1 (gfx950, abi 1)"; }
+#define PHIP_STR2(x) #x
+#define PHIP_STR(x) PHIP_STR2(x)
+const char *phip_version(void) { return "path_hip 0.3 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
 
 int phip_device_count(void) {
     int n = 0;

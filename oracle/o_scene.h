@@ -171,7 +171,13 @@ struct SampleSource {
         for (int w = 0; w < 2; ++w) {
             arrays[w].clear();
             if (n[w] > 1)
-                for (size_t j = 0; j < sampleCount * n[w]; ++j) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); arrays[w].push_back(Vec2(a, b)); }
+                for (size_t j = 0; j < sampleCount * n[w]; ++j) {
+                    /* independent.cpp:88-90 builds `Point2(m_random->nextFloat(), m_random->nextFloat())`: the order of the two
+                       calls is unspecified in C++; GCC (the reference's Linux compiler) evaluates the arguments right to left, so
+                       y receives the first number -- verified against the reference compiled with GCC (oracle/_ref) */
+                    Float y = rng->nextFloat(); Float x = rng->nextFloat();
+                    arrays[w].push_back(Vec2(x, y));
+                }
         }
     }
     void beginDirectArray(int which, size_t count) {

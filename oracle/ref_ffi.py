@@ -1,0 +1,134 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes loader for oracle/_ref/libmtsref.so: the REFERENCE's own libcore + librender + plugins, compiled in place from
+/root/reference by oracle/Makefile.ref, behind oracle/ref_driver.cpp.  Used by tests/test_ref_pin.py to pin the oracle's
+restatement to the real code and by tests/golden/make_golden_ref.py to produce the committed fixtures.  It only exists
+where /root/reference does (the build container); the GPU box has the prebuilt oracle/_ref at most."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from mitsuba_amd import _abi as A  # noqa: E402  (struct layouts only)
+
+REFERENCE = os.environ.get("MTS_REFERENCE", "/root/reference")
+LIB = os.path.join(HERE, "_ref", "libmtsref.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB) or os.path.isdir(os.path.join(REFERENCE, "src", "libcore"))
+
+
+def build(quiet=True):
+    if not os.path.isdir(os.path.join(REFERENCE, "src", "libcore")):
+        if os.path.exists(LIB):
+            return
+        raise RuntimeError("the reference tree is not present (%s) and oracle/_ref is not built" % REFERENCE)
+    r = subprocess.run(["make", "-C", HERE, "-f", "Makefile.ref", "-j%d" % min(64, os.cpu_count() or 4), "REF=" + REFERENCE],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("reference build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if not quiet:
+        print(r.stdout[-2000:])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        build()
+    L = C.CDLL(LIB)
+    fp, u8p, u32 = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_uint32
+    L.ref_last_error.restype = C.c_char_p
+    L.ref_scene_create.restype = C.c_void_p
+    L.ref_scene_create.argtypes = [C.POINTER(A.phip_scene_desc), C.c_float]
+    L.ref_scene_destroy.argtypes = [C.c_void_p]
+    L.ref_render.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), fp, fp]
+    L.ref_trace.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
+    L.ref_intersect.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
+    L.ref_bsdf_sample.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]
+    L.ref_bsdf_eval_pdf.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp]
+    L.ref_sample_emitter.argtypes = [C.c_void_p, fp, fp, C.c_size_t, fp, fp, fp, fp, fp, fp]
+    L.ref_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, fp]
+    if L.ref_init() != 0:
+        raise RuntimeError("ref_init: " + L.ref_last_error().decode())
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class RefScene:
+    """The reference's Scene object built from a phip_scene_desc (environment emitters must be listed first)."""
+
+    def __init__(self, desc, stddev=0.5):
+        self.L = lib()
+        self.desc = desc
+        self.h = self.L.ref_scene_create(C.byref(desc), stddev)
+        if not self.h:
+            raise RuntimeError("ref_scene_create: " + self.L.ref_last_error().decode())
+        self.width, self.height = desc.film.crop_width, desc.film.crop_height
+
+    def close(self):
+        if self.h:
+            self.L.ref_scene_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(what + ": " + self.L.ref_last_error().decode())
+
+    def render(self, params, want_samples=True):
+        film = np.zeros((self.height, self.width, 5), np.float32)
+        samples = np.zeros((self.height, self.width, params.spp, 4), np.float32) if want_samples else None
+        self._check(self.L.ref_render(self.h, C.byref(params), _fp(samples) if want_samples else None, _fp(film)), "ref_render")
+        return film, samples
+
+    def trace(self, rays):
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros((len(r), 5), np.float32)
+        self._check(self.L.ref_trace(self.h, _fp(r), len(r), _fp(out)), "ref_trace")
+        return out
+
+    def intersect(self, rays):
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros((len(r), 20), np.float32)
+        self._check(self.L.ref_intersect(self.h, _fp(r), len(r), _fp(out)), "ref_intersect")
+        return out
+
+    def bsdf_sample(self, material, wi, samples):
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3); s = np.ascontiguousarray(samples, np.float32).reshape(-1, 2)
+        n = len(s)
+        wo = np.zeros((n, 3), np.float32); w = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32); delta = np.zeros(n, np.uint8)
+        self._check(self.L.ref_bsdf_sample(self.h, material, n, _fp(wi), _fp(s), _fp(wo), _fp(w), _fp(pdf),
+                                           delta.ctypes.data_as(C.POINTER(C.c_uint8))), "ref_bsdf_sample")
+        return wo, w, pdf, delta
+
+    def bsdf_eval_pdf(self, material, wi, wo):
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3); wo = np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        n = len(wo)
+        v = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+        self._check(self.L.ref_bsdf_eval_pdf(self.h, material, n, _fp(wi), _fp(wo), _fp(v), _fp(pdf)), "ref_bsdf_eval_pdf")
+        return v, pdf
+
+    def sample_emitter(self, ref, refN, samples):
+        s = np.ascontiguousarray(samples, np.float32).reshape(-1, 2)
+        n = len(s)
+        ref = np.ascontiguousarray(ref, np.float32); refN = np.ascontiguousarray(refN, np.float32)
+        d = np.zeros((n, 3), np.float32); dist = np.zeros(n, np.float32); pdf = np.zeros(n, np.float32)
+        val = np.zeros((n, 3), np.float32); chk = np.zeros(n, np.float32)
+        self._check(self.L.ref_sample_emitter(self.h, _fp(ref), _fp(refN), n, _fp(s), _fp(d), _fp(dist), _fp(pdf), _fp(val), _fp(chk)), "ref_sample_emitter")
+        return d, dist, pdf, val, chk
+
+    def camera_ray(self, sx, sy):
+        out = np.zeros(14, np.float32)
+        self._check(self.L.ref_camera_ray(self.h, sx, sy, _fp(out)), "ref_camera_ray")
+        return out
