@@ -80,8 +80,8 @@ typedef struct phip_material {
  * mipmap.h:182-192 -- filterType nearest / bilinear: level 0 only).  Lookups without UV partials read level 0
  * bilinearly (bitmap.cpp:431-454); the first path vertex has partials (camera-ray differentials,
  * intersection.cpp:5-76) and uses MIPMap::eval (mipmap.h:629-833). ---- */
-typedef enum phip_wrap_mode {     /* ReconstructionFilter::EBoundaryCondition, rfilter.h */
-    PHIP_WRAP_REPEAT = 0, PHIP_WRAP_CLAMP = 1, PHIP_WRAP_MIRROR = 2, PHIP_WRAP_ZERO = 3, PHIP_WRAP_ONE = 4
+typedef enum phip_wrap_mode {     /* = ReconstructionFilter::EBoundaryCondition, value for value (rfilter.h:53-64) */
+    PHIP_WRAP_CLAMP = 0, PHIP_WRAP_REPEAT = 1, PHIP_WRAP_MIRROR = 2, PHIP_WRAP_ZERO = 3, PHIP_WRAP_ONE = 4
 } phip_wrap_mode;
 typedef enum phip_filter_type {   /* EMIPFilterType, mipmap.h:40-52 */
     PHIP_FILTER_NEAREST = 0, PHIP_FILTER_BILINEAR = 1, PHIP_FILTER_TRILINEAR = 2, PHIP_FILTER_EWA = 3

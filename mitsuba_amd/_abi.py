@@ -64,7 +64,7 @@ class phip_envmap(C.Structure):
                 ("n_levels", C.c_uint32), ("levels", C.POINTER(C.c_float) * PHIP_ENVMAP_MAX_LEVELS)]
 
 
-PHIP_WRAP_REPEAT, PHIP_WRAP_CLAMP, PHIP_WRAP_MIRROR, PHIP_WRAP_ZERO, PHIP_WRAP_ONE = range(5)
+PHIP_WRAP_CLAMP, PHIP_WRAP_REPEAT, PHIP_WRAP_MIRROR, PHIP_WRAP_ZERO, PHIP_WRAP_ONE = range(5)   # = EBoundaryCondition (rfilter.h:53-64)
 PHIP_FILTER_NEAREST, PHIP_FILTER_BILINEAR, PHIP_FILTER_TRILINEAR, PHIP_FILTER_EWA = range(4)
 PHIP_MIP_MAX_LEVELS = 17
 

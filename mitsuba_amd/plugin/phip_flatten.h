@@ -30,6 +30,8 @@ public:
 };
 class BitmapTextureAccess : public Texture2D {
 public:
+    typedef TSpectrum<Float, 3> Color3;            /* bitmap.cpp:172-177 */
+    typedef TSpectrum<half, 3> Color3h;
     typedef TMIPMap<Color3, Color3h> MIPMap3;
     virtual const MIPMap3 *getMIPMap3() const = 0;
     virtual ReconstructionFilter::EBoundaryCondition getWrapModeU() const = 0;

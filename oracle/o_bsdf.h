@@ -38,7 +38,7 @@ struct MicrofacetDistribution {
         Float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
         Float result;
         if (type == PHIP_MF_BECKMANN) {
-            result = om::exp(-beckmannExponent) / (ORC_PI * alphaU * alphaV * cosTheta2 * cosTheta2);
+            result = om::fastexp(-beckmannExponent) / (ORC_PI * alphaU * alphaV * cosTheta2 * cosTheta2);
         } else {
             Float root = ((Float) 1 + beckmannExponent) * cosTheta2;
             result = (Float) 1 / (ORC_PI * alphaU * alphaV * root * root);
@@ -99,7 +99,7 @@ struct MicrofacetDistribution {
             alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
         }
         if (type == PHIP_MF_BECKMANN) {
-            Float tanThetaMSqr = alphaSqr * -om::log(1.0f - sample.x);
+            Float tanThetaMSqr = alphaSqr * -om::fastlog(1.0f - sample.x);
             cosThetaM = 1.0f / std::sqrt(1.0f + tanThetaMSqr);
             pdf = (1.0f - sample.x) / (ORC_PI * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
         } else {
@@ -120,7 +120,7 @@ struct MicrofacetDistribution {
         if (type == PHIP_MF_BECKMANN) {
             if (thetaI < 1e-4f) {
                 Float sinPhi, cosPhi;
-                Float r = std::sqrt(-om::log(1.0f - sample.x));
+                Float r = std::sqrt(-om::fastlog(1.0f - sample.x));
                 om::sincos(2 * ORC_PI * sample.y, &sinPhi, &cosPhi);
                 return Vec2(r * cosPhi, r * sinPhi);
             }

@@ -44,6 +44,9 @@ namespace om {
 inline void sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
 inline float exp(float x) { return ::expf(x); }
 inline float log(float x) { return ::logf(x); }
+/* math::fastexp / math::fastlog on Linux x86_64 (core/math.h:175-199): the double-precision routine, rounded to float */
+inline float fastexp(float x) { return (float) ::exp((double) x); }
+inline float fastlog(float x) { return (float) ::log((double) x); }
 inline float acos(float x) { return ::acosf(x); }
 inline float atan2(float y, float x) { return ::atan2f(y, x); }
 inline float tan(float x) { return ::tanf(x); }
@@ -53,6 +56,8 @@ inline float pow(float x, float y) { return ::powf(x, y); }
 inline void sincos(float x, float *s, float *c) { pm_sincosf(x, s, c); }
 inline float exp(float x) { return pm_expf(x); }
 inline float log(float x) { return pm_logf(x); }
+inline float fastexp(float x) { return pm_expf(x); }
+inline float fastlog(float x) { return pm_logf(x); }
 inline float acos(float x) { return pm_acosf(x); }
 inline float atan2(float y, float x) { return pm_atan2f(y, x); }
 inline float tan(float x) { return pm_tanf(x); }
@@ -245,7 +250,7 @@ struct BSphere {
 
 /* ---------------- math.cpp:25-72 ---------------- */
 inline Float mts_erfinv(Float x) {
-    Float w = -om::log(((Float) 1 - x) * ((Float) 1 + x));
+    Float w = -om::fastlog(((Float) 1 - x) * ((Float) 1 + x));
     Float p;
     if (w < (Float) 5) {
         w = w - (Float) 2.5;
@@ -283,7 +288,7 @@ inline Float mts_erf(Float x) {
     Float sign = om::signum(x);
     x = std::abs(x);
     Float t = (Float) 1.0 / ((Float) 1.0 + p * x);
-    Float y = (Float) 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * om::exp(-x * x);
+    Float y = (Float) 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * om::fastexp(-x * x);
     return sign * y;
 }
 

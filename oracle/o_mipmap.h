@@ -42,7 +42,7 @@ struct MipMap {
         }
         for (int i = 0; i < 64; ++i) {                    /* mipmap.h:296-301 */
             Float r2 = (Float) i / (Float) 63;
-            weightLut[i] = om::exp(-2.0f * r2) - om::exp(-2.0f);
+            weightLut[i] = om::fastexp(-2.0f * r2) - om::fastexp(-2.0f);
         }
     }
 
@@ -86,7 +86,7 @@ struct MipMap {
     }
     static Float log2f_(Float value) {                    /* math.cpp:103-106 */
         const Float invLn2 = 1.0f / om::log(2.0f);
-        return om::log(value) * invLn2;
+        return om::fastlog(value) * invLn2;
     }
     /* mipmap.h:780-833 */
     Spectrum evalEWA(int level, const Vec2 &uv, Float A, Float B, Float C) const {

@@ -121,7 +121,7 @@ inline void gaussianFilterTable(Float stddev, Float &radius, Float table[PHIP_FI
     const Float alpha = -1.0f / (2.0f * stddev * stddev);
     for (size_t i = 0; i < PHIP_FILTER_RESOLUTION; ++i) {
         Float x = (radius * i) / PHIP_FILTER_RESOLUTION;
-        Float value = std::max((Float) 0.0f, om::exp(alpha * x * x) - om::exp(alpha * radius * radius));
+        Float value = std::max((Float) 0.0f, om::fastexp(alpha * x * x) - om::fastexp(alpha * radius * radius));
         table[i] = value;
         sum += value;
     }

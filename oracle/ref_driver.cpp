@@ -11,6 +11,7 @@
  *     ref_bsdf_*            BSDF::sample / eval / pdf of the scene's materials
  *     ref_sample_emitter    Scene::sampleEmitterDirect (no visibility test) + pdfEmitterDirect
  *     ref_camera_ray        Sensor::sampleRayDifferential
+ *     ref_mip_*             TMIPMap (render/mipmap.h): the MIP pyramid exactly as envmap.cpp / bitmap.cpp build it, MIPMap::eval
  * Nothing here is on the product path; nothing of it exists on the GPU box unless oracle/_ref was built beforehand.
  */
 #include <mitsuba/render/scene.h>
@@ -22,6 +23,7 @@
 #include <mitsuba/core/sched.h>
 #include <mitsuba/core/appender.h>
 #include <mitsuba/render/trimesh.h>
+#include <mitsuba/render/mipmap.h>
 #include "phip.h"
 #include <execinfo.h>
 #include <signal.h>
@@ -457,5 +459,64 @@ int ref_camera_ray(void *h, float sx, float sy, float *out14) {
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+
+
+/* ---- MIP pyramids: kind 0 = EnvironmentMap's (envmap.cpp:178-181: Spectrum / half precision, repeat x clamp, illuminant
+ * intent, no clamping), kind 1 = BitmapTexture's (bitmap.cpp:175-177,298-300: Color3 / half precision, reflectance intent, max value 1) ---- */
+struct RefMip {
+    typedef TMIPMap<Spectrum, TSpectrum<half, SPECTRUM_SAMPLES> > EnvMip;
+    typedef TSpectrum<Float, 3> TexColor3;           /* bitmap.cpp:172-177: BitmapTexture's own Color3 / Color3h */
+    typedef TSpectrum<half, 3> TexColor3h;
+    typedef TMIPMap<TexColor3, TexColor3h> TexMip;
+    ref<EnvMip> env; ref<TexMip> tex;
+    std::vector<ref<Bitmap> > levels;
+};
+
+void *ref_mip_build(int kind, const float *texels, uint32_t w, uint32_t h, uint32_t wrap_u, uint32_t wrap_v, uint32_t filter_type, float max_anisotropy) {
+    try {
+        if (ref_init() != 0) return NULL;
+        ref<Bitmap> bmp = rgbBitmap(texels, w, h);
+        Properties rp("lanczos"); rp.setInteger("lobes", 2);
+        ref<ReconstructionFilter> rf = static_cast<ReconstructionFilter *>(create(MTS_CLASS(ReconstructionFilter), rp));
+        rf->configure();
+        RefMip *m = new RefMip();
+        const EMIPFilterType ft = (EMIPFilterType) filter_type;      /* ENearest, EBilinear, ETrilinear, EEWA = phip_filter_type */
+        const Float aniso = ft == EEWA ? max_anisotropy : 1.0f;      /* bitmap.cpp:234-235 */
+        int n;
+        if (kind == 0) {
+            m->env = new RefMip::EnvMip(bmp, Bitmap::ESpectrum, Bitmap::EFloat, rf, ReconstructionFilter::ERepeat, ReconstructionFilter::EClamp,
+                                        ft, aniso, fs::path(), 0, std::numeric_limits<Float>::infinity(), Spectrum::EIlluminant);
+            n = m->env->getLevels();
+            for (int l = 0; l < n; ++l) m->levels.push_back(m->env->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
+        } else {
+            m->tex = new RefMip::TexMip(bmp, Bitmap::ERGB, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) wrap_u,
+                                        (ReconstructionFilter::EBoundaryCondition) wrap_v, ft, aniso, fs::path(), 0);
+            n = m->tex->getLevels();
+            for (int l = 0; l < n; ++l) m->levels.push_back(m->tex->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
+        }
+        return m;
+    } catch (const std::exception &e) { g_err = e.what(); return NULL; }
+}
+int ref_mip_levels(void *h) { return (int) static_cast<RefMip *>(h)->levels.size(); }
+void ref_mip_level_size(void *h, int l, int *w, int *ht) { const Bitmap *b = static_cast<RefMip *>(h)->levels.at(l); *w = b->getWidth(); *ht = b->getHeight(); }
+void ref_mip_level_data(void *h, int l, float *out) {
+    const Bitmap *b = static_cast<RefMip *>(h)->levels.at(l);
+    memcpy(out, b->getFloat32Data(), (size_t) b->getWidth() * b->getHeight() * 3 * sizeof(float));
+}
+/* MIPMap::eval(uv, d0, d1), mipmap.h:629-728 */
+int ref_mip_eval(void *h, size_t n, const float *uv2, const float *d0, const float *d1, float *out3) {
+    try {
+        RefMip *m = static_cast<RefMip *>(h);
+        for (size_t i = 0; i < n; ++i) {
+            const Point2 uv(uv2[2 * i], uv2[2 * i + 1]); const Vector2 a(d0[2 * i], d0[2 * i + 1]), b(d1[2 * i], d1[2 * i + 1]);
+            Float r, g, bl;
+            if (m->env) { Spectrum v = m->env->eval(uv, a, b); v.toLinearRGB(r, g, bl); }
+            else { RefMip::TexColor3 v = m->tex->eval(uv, a, b); r = v[0]; g = v[1]; bl = v[2]; }
+            out3[3 * i] = r; out3[3 * i + 1] = g; out3[3 * i + 2] = bl;
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+void ref_mip_destroy(void *h) { delete static_cast<RefMip *>(h); }
 
 } // extern "C"

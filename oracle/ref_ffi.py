@@ -56,6 +56,13 @@ def lib():
     L.ref_bsdf_eval_pdf.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp]
     L.ref_sample_emitter.argtypes = [C.c_void_p, fp, fp, C.c_size_t, fp, fp, fp, fp, fp, fp]
     L.ref_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, fp]
+    L.ref_mip_build.restype = C.c_void_p
+    L.ref_mip_build.argtypes = [C.c_int, fp, u32, u32, u32, u32, u32, C.c_float]
+    L.ref_mip_levels.argtypes = [C.c_void_p]
+    L.ref_mip_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ref_mip_level_data.argtypes = [C.c_void_p, C.c_int, fp]
+    L.ref_mip_eval.argtypes = [C.c_void_p, C.c_size_t, fp, fp, fp, fp]
+    L.ref_mip_destroy.argtypes = [C.c_void_p]
     if L.ref_init() != 0:
         raise RuntimeError("ref_init: " + L.ref_last_error().decode())
     _lib = L
@@ -132,3 +139,43 @@ class RefScene:
         out = np.zeros(14, np.float32)
         self._check(self.L.ref_camera_ray(self.h, sx, sy, _fp(out)), "ref_camera_ray")
         return out
+
+
+WRAP = {"clamp": A.PHIP_WRAP_CLAMP, "repeat": A.PHIP_WRAP_REPEAT, "mirror": A.PHIP_WRAP_MIRROR, "zero": A.PHIP_WRAP_ZERO, "one": A.PHIP_WRAP_ONE}
+FILTER = {"nearest": 0, "bilinear": 1, "trilinear": 2, "ewa": 3}
+
+
+class RefMip:
+    """TMIPMap built by the reference's own code (render/mipmap.h) the way envmap.cpp (kind="envmap") or bitmap.cpp
+    (kind="texture") does: Lanczos-resampled levels, stored in half precision."""
+
+    def __init__(self, image, kind="texture", wrap_u="repeat", wrap_v=None, filter_type="ewa", max_anisotropy=None):
+        self.L = lib()
+        img = np.ascontiguousarray(image, np.float32)
+        h, w = img.shape[:2]
+        if max_anisotropy is None:
+            max_anisotropy = 10.0 if kind == "envmap" else 20.0
+        self.h = self.L.ref_mip_build(0 if kind == "envmap" else 1, _fp(img), w, h, WRAP[wrap_u], WRAP[wrap_v or wrap_u],
+                                      FILTER[filter_type], max_anisotropy)
+        if not self.h:
+            raise RuntimeError("ref_mip_build: " + self.L.ref_last_error().decode())
+        self.levels = []
+        for l in range(self.L.ref_mip_levels(self.h)):
+            lw, lh = C.c_int(), C.c_int()
+            self.L.ref_mip_level_size(self.h, l, C.byref(lw), C.byref(lh))
+            a = np.zeros((lh.value, lw.value, 3), np.float32)
+            self.L.ref_mip_level_data(self.h, l, _fp(a))
+            self.levels.append(a)
+
+    def eval(self, uv, d0, d1):
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2); d0 = np.ascontiguousarray(d0, np.float32).reshape(-1, 2)
+        d1 = np.ascontiguousarray(d1, np.float32).reshape(-1, 2)
+        out = np.zeros((len(uv), 3), np.float32)
+        if self.L.ref_mip_eval(self.h, len(uv), _fp(uv), _fp(d0), _fp(d1), _fp(out)) != 0:
+            raise RuntimeError("ref_mip_eval: " + self.L.ref_last_error().decode())
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.ref_mip_destroy(self.h)
+            self.h = None
