@@ -35,6 +35,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <functional>
 #include <mutex>
 
 #include "../../include/phip.h"
@@ -334,6 +335,19 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     /* materials */
     std::vector<DevMaterial> mats = convertMaterials(d.materials, d.n_materials, &texMax);
+    /* TriMesh::computeUVTangents, trimesh.cpp:683-693: an anisotropic BSDF (roughconductor.cpp:196-200,230-231: the clamped
+       alphaU != alphaV; twosided.cpp:96-100 inherits the flag) needs texture coordinates for its tangent frame -- an error there */
+    for (uint32_t i = 0; i < d.n_shapes; ++i) {
+        std::function<bool(uint32_t, int)> aniso = [&](uint32_t m, int depth) -> bool {
+            if (m >= d.n_materials || depth > 2) return false;
+            const phip_material &M = d.materials[m];
+            if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) return std::max(M.alpha_u, 1e-4f) != std::max(M.alpha_v, 1e-4f);
+            if (M.type == PHIP_BSDF_TWOSIDED) return aniso(M.nested[0], depth + 1) || aniso(M.nested[1], depth + 1);
+            return false;
+        };
+        if (!d.shapes[i].has_texcoords && aniso(d.shapes[i].material, 0))
+            throw std::runtime_error("computeUVTangents(): texture coordinates are required to generate tangent vectors (anisotropic BSDF on a shape without them)");
+    }
 
     /* emitters + selection pdf, scene.cpp:375-381 */
     std::vector<DevEmitter> ems(d.n_emitters);

@@ -15,6 +15,7 @@
  *   src/samplers/independent.cpp:71-103, src/librender/renderjob.cpp:58-69   per-worker SFMT streams
  */
 #pragma once
+#include <functional>
 #include "o_kdtree.h"
 #include "o_sfmt.h"
 #include "o_envmap.h"
@@ -295,6 +296,19 @@ textures.resize(d.n_textures);
         }
         for (uint32_t i = 0; i < d.n_materials; ++i)
             if (materials[i].m.reflectance_texture > d.n_textures) throw std::runtime_error("oracle: bad texture id");
+        /* TriMesh::computeUVTangents, trimesh.cpp:683-693: an anisotropic BSDF (roughconductor.cpp:196-200,230-231: the clamped
+           alphaU != alphaV; twosided.cpp:96-100 inherits the flag) needs texture coordinates for its tangent frame */
+        for (uint32_t i = 0; i < d.n_shapes; ++i) {
+            std::function<bool(uint32_t, int)> aniso = [&](uint32_t m, int depth) -> bool {
+                if (m >= d.n_materials || depth > 2) return false;
+                const phip_material &M = d.materials[m];
+                if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) return std::max(M.alpha_u, 1e-4f) != std::max(M.alpha_v, 1e-4f);
+                if (M.type == PHIP_BSDF_TWOSIDED) return aniso(M.nested[0], depth + 1) || aniso(M.nested[1], depth + 1);
+                return false;
+            };
+            if (!shapes[i].s.has_texcoords && aniso(shapes[i].s.material, 0))
+                throw std::runtime_error("computeUVTangents(): texture coordinates are required to generate tangent vectors (anisotropic BSDF on a shape without them)");
+        }
         /* area sampling tables, trimesh.cpp:388-404 (built lazily in the reference) */
         for (uint32_t i = 0; i < d.n_shapes; ++i) {
             Shape &sh = shapes[i];

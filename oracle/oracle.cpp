@@ -7,14 +7,19 @@
  * parity checker and the timed CPU baseline ("port"); the product (libphip.so) never links,
  * loads or calls it.
  *
- * Parity status: the reference cannot be compiled in this image (Boost/Xerces/OpenEXR/SCons
- * are absent), so this restatement is pinned only by the reference's own
- * test vectors: SFMT19937 seed-4321 golden words (src/tests/test_random.cpp:433-473), the five
- * Triangle::getClippedAABB known answers (src/tests/test_kd.cpp:34-84) and the chi-square
- * sample/pdf/eval contracts of src/tests/test_chisquare.cpp and test_microfacet.cpp.  Li,
- * TriAccel, Havran traversal, emitter sampling, the camera and ImageBlock::put have no
- * reference vectors: for those the oracle is **parity unpinned** and is instead cross-checked
- * against brute force / closed forms (tests/test_oracle_*.py).
+ * Parity status: PINNED TO THE REFERENCE ITSELF.  oracle/Makefile.ref compiles the reference's own libcore + librender +
+ * the plugins on the path in place (oracle/_ref; Boost and Eigen are header-shimmed by oracle/ref_shims, the XML loader
+ * and the image codecs are left out), oracle/ref_driver.cpp assembles a reference Scene from the same phip_scene_desc, and
+ * the libm build of this restatement (make libm: libm transcendentals, math::fastexp/fastlog semantics), run on the
+ * reference's own sampler stream (`independent`: SFMT19937, one clone), reproduces the reference's per-sample Li and its
+ * ImageBlock accumulator BIT FOR BIT on every scene class of the path -- MIPathTracer and MIDirectIntegrator, all four
+ * BSDFs, area / constant / envmap emitters, bitmap textures, EWA-filtered lookups (tests/test_ref_pin.py live,
+ * tests/test_golden.py through the committed fixture tests/golden/ref_renders.npz, function-level hooks for
+ * Scene::rayIntersect, BSDF::sample/eval/pdf, sampleEmitterDirect, the camera).  The default (parity) build differs from
+ * that only in the transcendentals (include/phip_fmath.h, shared with the GPU): <= a few ulp per sample, ~1e-7 rel. L2.
+ * Additionally the reference's own test vectors: SFMT19937 seed-4321 golden words (src/tests/test_random.cpp:433-473), the
+ * five Triangle::getClippedAABB known answers (src/tests/test_kd.cpp:34-84) and the chi-square sample/pdf/eval contracts
+ * of src/tests/test_chisquare.cpp and test_microfacet.cpp.
  */
 #include "o_render.h"
 #include <string>

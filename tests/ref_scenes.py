@@ -1,0 +1,160 @@
+"""The scenes on which the oracle is pinned to the REFERENCE ITSELF (oracle/_ref = /root/reference compiled in place).
+
+Used three ways:
+  tests/test_ref_pin.py          live: reference vs oracle (libm build, the reference's SFMT sampler stream), where
+                                 /root/reference or a prebuilt oracle/_ref exists
+  tests/golden/make_golden_ref.py  writes the reference's per-sample radiance (and the MIP pyramids its code built)
+                                 to tests/golden/ref_renders.npz
+  tests/test_golden.py           checks the oracle against that fixture anywhere (no reference needed)
+Every scene is small enough to render in well under a second on either side."""
+import numpy as np
+
+from mitsuba_amd import _abi as A, scene as S
+
+
+def half(a):
+    """texture / environment source images are made half-representable: the reference stores MIP level 0 in half
+    precision, so the plugin's level 0 is then exactly the image handed over"""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _sky(w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    el = (0.5 - (y + 0.5) / h) * np.pi
+    az = (x + 0.5) / w * 2 * np.pi
+    base = np.stack([0.3 + 0.5 * np.clip(np.sin(el), 0, 1), 0.4 + 0.4 * np.clip(np.sin(el), 0, 1), 0.6 + 0.3 * np.cos(az)], -1)
+    sun = np.exp(-(((az - 1.0) * 2) ** 2 + ((el - 0.6) * 4) ** 2))[..., None] * np.array([30.0, 25.0, 18.0])
+    return (base + sun).astype(np.float32)
+
+
+def _rot(axis, deg):
+    a = np.asarray(axis, np.float64); a /= np.linalg.norm(a)
+    t = np.radians(deg); c, s = np.cos(t), np.sin(t)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(4); R[:3, :3] = c * np.eye(3) + s * K + (1 - c) * np.outer(a, a)
+    return R.astype(np.float32)
+
+
+def _sphere_uvs(N):
+    N = np.asarray(N, np.float64)
+    u = (np.arctan2(N[:, 2], N[:, 0]) / (2 * np.pi)) % 1.0
+    v = np.arccos(np.clip(N[:, 1], -1, 1)) / np.pi
+    return np.stack([u, v], -1).astype(np.float32)
+
+
+def _checker(n, cell):
+    y, x = np.mgrid[0:n, 0:n]
+    c = ((x // cell + y // cell) % 2).astype(np.float32)
+    return np.stack([0.1 + 0.8 * c, 0.15 + 0.7 * c, 0.2 + 0.5 * (1 - c)], -1).astype(np.float32)
+
+
+def cornell(gauss, mip, res=(24, 24)):
+    return S.cornell_box(res[0], res[1], gauss)
+
+
+def zoo(gauss, mip):
+    sb = S.cornell_box(32, 32, gauss)
+    cu = dict(eta=S.CU_ETA, k=S.CU_K)
+    mats = [sb.twosided(sb.roughconductor(alpha=0.2, distribution="ggx", **cu)),
+            sb.twosided(sb.roughconductor(alpha=0.05, alpha_v=0.3, **cu)),
+            sb.twosided(sb.roughconductor(alpha=0.15, sample_visible=False, **cu), sb.diffuse((0.2, 0.7, 0.3))),
+            sb.roughconductor(alpha=0.3, **cu),
+            sb.dielectric(1.33, 1.0)]
+    for i, m in enumerate(mats):
+        P, T, N = S.sphere_mesh((90 + 95 * i, 420 - 60 * (i % 2), 150 + 60 * i), 45.0, 24, 12)
+        sb.mesh(P, T, m, normals=N, uvs=_sphere_uvs(N))       # anisotropic BSDFs need texture coordinates (trimesh.cpp:683-690)
+    return sb
+
+
+def glass(gauss, mip):
+    return S.glass_room(32, 18, gauss, detail=0.3)
+
+
+def atrium(gauss, mip):
+    return S.atrium(32, 18, gauss, detail=0.3)
+
+
+def _env_scene(gauss, env, res=(40, 24)):
+    sb = S.SceneBuilder()
+    env(sb)                                                    # environment emitters first: the order of Scene::getEmitters()
+    floor = sb.diffuse((0.4, 0.45, 0.5))
+    mats = [sb.diffuse((0.7, 0.3, 0.2)), sb.twosided(sb.diffuse((0.2, 0.6, 0.3))),
+            sb.roughconductor(alpha=0.2, eta=S.CU_ETA, k=S.CU_K), sb.dielectric(1.5, 1.0)]
+    sb.quad((-6, 0, -6), (6, 0, -6), (6, 0, 6), (-6, 0, 6), floor, facing=(0, 1, 0))
+    for i, m in enumerate(mats):
+        P, T, N = S.sphere_mesh((-3 + 2 * i, 0.8, 0.5 * (i % 2)), 0.8, 16, 8)
+        sb.mesh(P, T, m, normals=N)
+    sb.quad((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1), sb.diffuse((0, 0, 0)), facing=(0, -1, 0), radiance=(8, 8, 6))
+    sb.perspective((0, 3, -9), (0, 0.5, 0), (0, 1, 0), 40.0)
+    sb.hdrfilm(res[0], res[1], gauss)
+    return sb
+
+
+def const_env(gauss, mip):
+    return _env_scene(gauss, lambda sb: sb.constant((0.9, 1.0, 1.2), sampling_weight=0.7))
+
+
+def envmap(gauss, mip):
+    rng = np.random.default_rng(5)
+    tex = half(_sky(64, 32) * rng.uniform(0.5, 1.5, (32, 64, 1)))
+    levels = mip("envmap", tex, kind="envmap")
+    return _env_scene(gauss, lambda sb: sb.envmap(levels[0], scale=0.8, to_world=_rot((1, 0.3, 0.2), 70.0), pyramid=levels))
+
+
+def textures(gauss, mip):
+    rng = np.random.default_rng(11)
+    noise = half(rng.uniform(0.05, 0.95, (24, 40, 3)))
+    chk = half(_checker(64, 8))
+    sb = S.SceneBuilder()
+    sb.constant((0.4, 0.5, 0.7))
+
+    def bm(key, img, **kw):
+        lv = mip(key, img, kind="texture", wrap_u=kw.get("wrap", "repeat"), wrap_v=kw.get("wrap_v"),
+                 filter_type=kw.get("filter_type", "ewa"), max_anisotropy=kw.get("max_anisotropy", 20.0))
+        return sb.bitmap(lv[0], pyramid=lv, **kw)
+    t_floor = bm("floor", chk, filter_type="ewa", uscale=6.0, vscale=6.0)
+    t_tri = bm("tri", noise, filter_type="trilinear", wrap="mirror", wrap_v="clamp", uscale=2.0, uoffset=0.3)
+    t_bil = bm("bil", noise, filter_type="bilinear", wrap="zero", wrap_v="one", uscale=1.5, vscale=1.5, voffset=-0.2)
+    t_near = bm("near", chk[:32, :24], filter_type="nearest")
+    t_ewa2 = bm("ewa2", noise[:15, :25], filter_type="ewa", max_anisotropy=2.0, uscale=3.0, wrap="clamp")
+    sb.quad((-8, 0, -8), (8, 0, -8), (8, 0, 8), (-8, 0, 8), sb.diffuse(texture=t_floor), facing=(0, 1, 0), uvs=True)
+    mats = [sb.diffuse(texture=t_tri), sb.twosided(sb.diffuse(texture=t_bil)), sb.twosided(sb.diffuse(texture=t_near), sb.diffuse((0.3, 0.3, 0.3))),
+            sb.diffuse(texture=t_ewa2), sb.roughconductor(alpha=0.05, alpha_v=0.3, eta=S.CU_ETA, k=S.CU_K), sb.diffuse((0.6, 0.5, 0.4))]
+    for i, m in enumerate(mats):
+        P, T, N = S.sphere_mesh((-5 + 2 * i, 0.8, 0.4 * (i % 2)), 0.8, 16, 8)
+        sb.mesh(P, T, m, normals=N if i % 2 == 0 else None, uvs=_sphere_uvs(N))
+    sb.quad((-2, 5, -2), (2, 5, -2), (2, 5, 2), (-2, 5, 2), sb.diffuse((0, 0, 0)), facing=(0, -1, 0), radiance=(10, 10, 9))
+    sb.perspective((0, 3.5, -11), (0, 0.4, 0), (0, 1, 0), 42.0)
+    sb.hdrfilm(48, 32, gauss)
+    return sb
+
+
+PATH, DIRECT = A.PHIP_INTEGRATOR_PATH, A.PHIP_INTEGRATOR_DIRECT
+
+# (case name, scene builder, render parameters)
+CASES = [
+    ("cornell_path", cornell, dict(spp=4, max_depth=-1)),
+    ("cornell_rr2", cornell, dict(spp=4, max_depth=-1, rr_depth=2)),
+    ("cornell_md2", cornell, dict(spp=2, max_depth=2)),
+    ("cornell_hide_strict", cornell, dict(spp=2, max_depth=6, hide_emitters=1, strict_normals=1)),
+    ("cornell_direct_1_1", cornell, dict(spp=2, integrator=DIRECT, emitter_samples=1, bsdf_samples=1)),
+    ("cornell_direct_3_2", cornell, dict(spp=2, integrator=DIRECT, emitter_samples=3, bsdf_samples=2)),
+    ("cornell_direct_0_2", cornell, dict(spp=2, integrator=DIRECT, emitter_samples=0, bsdf_samples=2)),
+    ("cornell_direct_2_0", cornell, dict(spp=2, integrator=DIRECT, emitter_samples=2, bsdf_samples=0, hide_emitters=1)),
+    ("zoo_path", zoo, dict(spp=2, max_depth=8)),
+    ("zoo_strict", zoo, dict(spp=1, max_depth=4, strict_normals=1)),
+    ("zoo_direct", zoo, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=2)),
+    ("glass_path", glass, dict(spp=2, max_depth=16)),
+    ("atrium_path", atrium, dict(spp=2, max_depth=8)),
+    ("const_env_path", const_env, dict(spp=2, max_depth=6)),
+    ("const_env_hide", const_env, dict(spp=1, max_depth=4, hide_emitters=1, strict_normals=1)),
+    ("const_env_direct", const_env, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=2)),
+    ("envmap_path", envmap, dict(spp=2, max_depth=6)),
+    ("envmap_direct", envmap, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=3)),
+    ("textures_path", textures, dict(spp=2, max_depth=6)),
+    ("textures_direct", textures, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=2)),
+]
+
+
+def params(kw):
+    return A.default_render_params(block_size=256, **kw)      # one image block: a single sampler stream, row-major pixels

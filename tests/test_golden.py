@@ -55,3 +55,35 @@ def test_clipped_aabb_known_answers(oracle):
         assert bool(valid) == case["valid"], case
         if case["valid"]:
             assert list(out)[:3] == case["min"] and list(out)[3:] == case["max"], (case, list(out))
+
+
+# ---- the reference's own renders (tests/golden/ref_renders.npz, written by tests/golden/make_golden_ref.py from
+#      oracle/_ref = /root/reference compiled in place): the oracle has to reproduce them bit for bit ----
+import pytest                                            # noqa: E402
+import ref_scenes as RS                                  # noqa: E402
+
+
+def _golden_mip(fixture, scene):
+    def mip(key, image, kind, **kw):
+        levels = []
+        while "mip/%s/%s/%d" % (scene, key, len(levels)) in fixture:
+            levels.append(np.ascontiguousarray(fixture["mip/%s/%s/%d" % (scene, key, len(levels))]))
+        assert levels and np.array_equal(levels[0], image)      # level 0 = the (half-representable) source image
+        return levels
+    return mip
+
+
+@pytest.mark.parametrize("name,build,kw", RS.CASES, ids=[c[0] for c in RS.CASES])
+def test_reference_render_fixture(oracle, name, build, kw):
+    """per-sample Li and the ImageBlock accumulator of the real MIPathTracer / MIDirectIntegrator (sampler `independent`)
+    against the oracle's libm build on the same SFMT stream -- needs no reference tree"""
+    fixture = np.load(os.path.join(G, "ref_renders.npz"))
+    oracle.build(libm=True)
+    gauss = oracle.gaussian_filter(0.5, libm=True)
+    desc = build(gauss, _golden_mip(fixture, build.__name__)).desc()
+    osc = oracle.OracleScene(desc, libm=True)
+    film, samples, _ = osc.render(RS.params(kw), threads=1, sampler="sfmt", want_samples=True)
+    ref_s, ref_f = fixture[name + "/samples"], fixture[name + "/film"]
+    same = (samples.view(np.uint32) == ref_s.view(np.uint32)).all(-1).mean()
+    assert same == 1.0, "%.4f%% of the samples are bit-identical to the reference (max abs diff %.3e)" % (100 * same, np.abs(samples - ref_s).max())
+    assert np.array_equal(film.view(np.uint32), ref_f.view(np.uint32))

@@ -237,6 +237,7 @@ def test_glass_room_matches_oracle(gpu, oracle, gauss):
 
 def test_material_zoo_matches_oracle(gpu, oracle, gauss):
     """every BSDF variant on the path in one Cornell box: ggx / anisotropic / non-visible sampling, dielectric, twosided(front, back)"""
+    from test_oracle_path import sphere_uvs
     sb = S.cornell_box(128, 128, gauss)
     cu = dict(eta=S.CU_ETA, k=S.CU_K)
     mats = [sb.twosided(sb.roughconductor(alpha=0.2, distribution="ggx", **cu)),
@@ -246,7 +247,7 @@ def test_material_zoo_matches_oracle(gpu, oracle, gauss):
             sb.dielectric(1.33, 1.0)]
     for i, m in enumerate(mats):
         P, T, N = S.sphere_mesh((90 + 95 * i, 420 - 60 * (i % 2), 150 + 60 * i), 45.0, 24, 12)
-        sb.mesh(P, T, m, normals=N)
+        sb.mesh(P, T, m, normals=N, uvs=sphere_uvs(N))           # anisotropic BSDFs need texture coordinates (trimesh.cpp:683-693)
     compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.999, maxDepth=8)
 
 
@@ -405,3 +406,19 @@ def test_bitmap_textures_match_oracle(gpu, oracle, gauss):
         same, r = compare_render(gpu, oracle, scene().desc(), spp, min_identical=0.999, maxDepth=md)
         print("textures spp %d: identical %.6f rel L2 %.3e" % (spp, same, r))
     compare_render(gpu, oracle, scene(res=(64, 48)).desc(), 4, min_identical=0.999, maxDepth=4, strictNormals=True)
+
+
+def test_reference_built_pyramids_and_pin_scenes(gpu, oracle, gauss):
+    """the scenes on which the oracle is pinned to the reference itself (tests/ref_scenes.py), with the MIP pyramids the
+    reference's own TMIPMap built (Lanczos-resampled, half precision; tests/golden/ref_renders.npz): GPU against the
+    oracle on the parity stream, path tracer and `direct`"""
+    import os
+    import ref_scenes as RS
+    from test_golden import _golden_mip, G
+    from mitsuba_amd.integrator import DirectHIP
+    fixture = np.load(os.path.join(G, "ref_renders.npz"))
+    for build in (RS.envmap, RS.textures, RS.zoo, RS.const_env):
+        desc = build(gauss, _golden_mip(fixture, build.__name__)).desc()
+        same, r = compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=6)
+        print("%s: identical %.6f rel L2 %.3e" % (build.__name__, same, r))
+        compare_render(gpu, oracle, desc, 2, min_identical=0.999, integrator=DirectHIP, emitterSamples=2, bsdfSamples=2)
