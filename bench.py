@@ -76,28 +76,42 @@ def pmc_traffic(workload, kernel):
 
 
 def cpu_baseline(workload, seconds_target=15.0):
-    """CPU oracle on a bounded sample of the same workload: same scene/film/integrator, reduced spp."""
-    from mitsuba_amd import _abi as A
-    from oracle import oracle_ffi as O
+    """The CPU baseline on a bounded sample of the same workload (same scene / film / integrator, reduced spp):
+    the REFERENCE ITSELF when oracle/_ref is there (its own libcore + librender + plugins, compiled from /root/reference by
+    oracle/Makefile.ref in the build container; the prebuilt files travel with the repository snapshot) -- its complete
+    multi-threaded render, RenderJob -> BlockedRenderProcess on one LocalWorker per core; otherwise the oracle port."""
     desc, w, h, spp, md, _ = build_desc(workload)
-    osc = O.OracleScene(desc)
     cores = os.cpu_count() or 1
-    p = oracle_params(md, 1)
-    t = time.time()
-    _, _, st = osc.render(p, threads=cores)
-    dt1 = max(time.time() - t, 1e-3)
+    try:
+        from oracle import ref_ffi as R
+        if not os.path.exists(R.LIB):
+            raise RuntimeError("oracle/_ref is not built")
+        rs = R.RefScene(desc)
+        run = lambda s: rs.render_job(oracle_params(md, s), threads=cores, want_image=False)[1]
+        kind, what = "reference", ("Mitsuba 0.6 itself (oracle/_ref: the reference's sources compiled with g++ -O3 -march=x86-64-v3, IEEE "
+                                   "float semantics; SAH kd-tree, `independent` sampler, 32x32 blocks, %d LocalWorkers)" % cores)
+        st = None
+    except Exception as e:           # no prebuilt reference on this box: the restatement is the baseline
+        print("bench.py: reference CPU baseline unavailable (%s); timing the oracle port" % e, file=sys.stderr)
+        from oracle import oracle_ffi as O
+        osc = O.OracleScene(desc)
+        last = {}
+
+        def run(s):
+            t = time.time()
+            last["st"] = osc.render(oracle_params(md, s), threads=cores)[2]
+            return time.time() - t
+        kind, what = "port", "oracle = CPU restatement of the reference path: SAH kd-tree + Havran + TriAccel, %d threads" % cores
+        st = last
+    dt1 = max(run(1), 1e-3)
     s = int(max(1, min(spp, round(seconds_target / dt1))))
     if s > 1:
-        p = oracle_params(md, s)
-        t = time.time()
-        _, _, st = osc.render(p, threads=cores)
-        dt1 = time.time() - t
-    else:
-        s = 1
-    return {"value": round(w * h * s / 1e6 / dt1, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%s at %d spp (%d samples, %.1f s, oracle = CPU restatement of the reference path: SAH kd-tree + Havran + TriAccel, %d threads)"
-                      % (workload, s, w * h * s, dt1, cores),
-            "mrays_per_s": round((st.closest_rays + st.shadow_rays) / 1e6 / dt1, 3)}
+        dt1 = run(s)
+    out = {"value": round(w * h * s / 1e6 / dt1, 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
+           "sample": "%s at %d spp (%d samples, %.1f s; %s)" % (workload, s, w * h * s, dt1, what)}
+    if st and st.get("st") is not None:
+        out["mrays_per_s"] = round((st["st"].closest_rays + st["st"].shadow_rays) / 1e6 / dt1, 3)
+    return out
 
 
 def main():

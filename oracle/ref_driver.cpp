@@ -7,6 +7,8 @@
  * src/librender/scenehandler.cpp) and exposes what the oracle restates, so that tests can pin the restatement to the real code:
  *     ref_render            SamplingIntegrator::renderBlock semantics (integrator.cpp:140-188) around the reference's
  *                           MIPathTracer::Li / MIDirectIntegrator::Li, one sampler clone, row-major pixel order
+ *     ref_render_job        the reference's complete multi-threaded render (RenderJob -> BlockedRenderProcess on the
+ *                           Scheduler's LocalWorkers): the CPU baseline of bench.py ("kind": "reference")
  *     ref_trace             Scene::rayIntersect
  *     ref_bsdf_*            BSDF::sample / eval / pdf of the scene's materials
  *     ref_sample_emitter    Scene::sampleEmitterDirect (no visibility test) + pdfEmitterDirect
@@ -24,6 +26,9 @@
 #include <mitsuba/core/appender.h>
 #include <mitsuba/render/trimesh.h>
 #include <mitsuba/render/mipmap.h>
+#include <mitsuba/render/renderjob.h>
+#include <mitsuba/render/renderqueue.h>
+#include <chrono>
 #include "phip.h"
 #include <execinfo.h>
 #include <signal.h>
@@ -154,9 +159,18 @@ int ref_init(void) {
         Bitmap::staticInitialization();
         Scheduler::staticInitialization();
         Thread::getThread()->getLogger()->setLogLevel(EWarn);
+        if (!getenv("REF_DRIVER_VERBOSE"))
+            Thread::getThread()->getLogger()->clearAppenders();      /* no progress bars; Log(EError) still throws */
         g_init = true;
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+/* stops the Scheduler's worker threads (they would keep the process alive at exit) */
+void ref_shutdown(void) {
+    if (!g_init) return;
+    Scheduler *sched = Scheduler::getInstance();
+    if (sched && sched->isRunning()) sched->stop();
 }
 
 /* filter: 0 = gaussian (stddev), 1 = box.  integrator: "path" / "direct" parameters arrive with ref_render. */
@@ -338,6 +352,61 @@ int ref_render(void *h, const phip_render_params *p, float *out_samples, float *
             for (int y = 0; y < size.y; ++y) for (int x = 0; x < size.x; ++x)
                 for (int c = 0; c < 5; ++c)
                     out_film[((size_t) y * size.x + x) * 5 + c] = src[((size_t) (y + border) * bw + (x + border)) * ch + c];
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+/*
+ * The reference's own render, start to finish, as `mitsuba scene.xml` runs it (src/mitsuba/mitsuba.cpp:330-372):
+ * RenderJob (renderjob.cpp) -> Scene::preprocess / render -> SamplingIntegrator::render (integrator.cpp:95-129) ->
+ * BlockedRenderProcess (renderproc.cpp: 32x32 blocks in spiral order, Hilbert-curve pixel order, one sampler clone per
+ * worker) on `threads` LocalWorkers -> Film::put.  out_rgb (optional): the developed crop window, H x W x 3.
+ * The worker count is fixed by the first call.
+ */
+int ref_render_job(void *h, const phip_render_params *p, int threads, float *out_rgb, double *seconds) {
+    try {
+        RefScene *rs = static_cast<RefScene *>(h);
+        Scene *scene = rs->scene;
+        Scheduler *sched = Scheduler::getInstance();
+        if (sched->getWorkerCount() == 0) {
+            for (int i = 0; i < std::max(1, threads); ++i)
+                sched->registerWorker(new LocalWorker(i, formatString("wrk%i", i)));
+            sched->start();
+        }
+        Properties ip(p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path");
+        if (p->integrator == PHIP_INTEGRATOR_DIRECT) {
+            ip.setSize("emitterSamples", (size_t) p->emitter_samples); ip.setSize("bsdfSamples", (size_t) p->bsdf_samples);
+        } else {
+            ip.setInteger("maxDepth", p->max_depth); ip.setInteger("rrDepth", p->rr_depth);
+        }
+        ip.setBoolean("strictNormals", p->strict_normals != 0); ip.setBoolean("hideEmitters", p->hide_emitters != 0);
+        ref<Integrator> integ = static_cast<Integrator *>(create(MTS_CLASS(Integrator), ip));
+        integ->configure();
+        Properties smp("independent"); smp.setSize("sampleCount", (size_t) p->spp);
+        ref<Sampler> sampler = static_cast<Sampler *>(create(MTS_CLASS(Sampler), smp));
+        sampler->configure();
+        integ->configureSampler(scene, sampler);
+        scene->setIntegrator(integ);
+        scene->setSampler(sampler);
+        scene->setBlockSize(p->block_size > 0 ? (uint32_t) p->block_size : 32u);
+        scene->getFilm()->clear();
+
+        ref<RenderQueue> queue = new RenderQueue();
+        ref<RenderJob> job = new RenderJob("rend", scene, queue, -1, -1, -1, false, false);
+        const auto t0 = std::chrono::steady_clock::now();
+        job->start();
+        queue->waitLeft(0);
+        queue->join();
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (out_rgb) {
+            const Vector2i size = scene->getFilm()->getCropSize();
+            ref<Bitmap> target = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, size);
+            scene->getFilm()->develop(Point2i(0, 0), size, Point2i(0, 0), target);
+            memcpy(out_rgb, target->getFloat32Data(), (size_t) size.x * size.y * 3 * sizeof(float));
         }
         return 0;
     } catch (const std::exception &e) {

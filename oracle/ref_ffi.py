@@ -50,6 +50,7 @@ def lib():
     L.ref_scene_create.argtypes = [C.POINTER(A.phip_scene_desc), C.c_float]
     L.ref_scene_destroy.argtypes = [C.c_void_p]
     L.ref_render.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), fp, fp]
+    L.ref_render_job.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), C.c_int, fp, C.POINTER(C.c_double)]
     L.ref_trace.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
     L.ref_intersect.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
     L.ref_bsdf_sample.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]
@@ -65,6 +66,8 @@ def lib():
     L.ref_mip_destroy.argtypes = [C.c_void_p]
     if L.ref_init() != 0:
         raise RuntimeError("ref_init: " + L.ref_last_error().decode())
+    import atexit
+    atexit.register(L.ref_shutdown)
     _lib = L
     return L
 
@@ -98,6 +101,14 @@ class RefScene:
         samples = np.zeros((self.height, self.width, params.spp, 4), np.float32) if want_samples else None
         self._check(self.L.ref_render(self.h, C.byref(params), _fp(samples) if want_samples else None, _fp(film)), "ref_render")
         return film, samples
+
+    def render_job(self, params, threads=None, want_image=True):
+        """the reference's complete multi-threaded render (RenderJob on the Scheduler); returns (rgb or None, seconds)"""
+        threads = threads or os.cpu_count() or 1
+        rgb = np.zeros((self.height, self.width, 3), np.float32) if want_image else None
+        sec = C.c_double()
+        self._check(self.L.ref_render_job(self.h, C.byref(params), threads, _fp(rgb) if want_image else None, C.byref(sec)), "ref_render_job")
+        return rgb, sec.value
 
     def trace(self, rays):
         r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

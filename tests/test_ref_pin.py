@@ -140,3 +140,23 @@ def test_reference_rejects_anisotropic_bsdf_without_texcoords(ref, olibm):
         ref.RefScene(sb.desc())
     with pytest.raises(RuntimeError, match="texture coordinates"):
         olibm.OracleScene(sb.desc(), libm=True)
+
+
+def test_reference_render_job_multi_threaded(ref, oracle):
+    """the reference's complete render (RenderJob -> BlockedRenderProcess on the Scheduler's LocalWorkers, Hilbert-curve
+    pixel order, one sampler clone per worker -- bench.py's CPU baseline) agrees with the oracle's parity-stream render
+    statistically, and repeated jobs on one scene work"""
+    gauss = oracle.gaussian_filter(0.5)
+    desc = S.cornell_box(96, 96, gauss).desc()
+    rs = ref.RefScene(desc)
+    p = A.default_render_params(spp=64, max_depth=6)
+    rgb, sec = rs.render_job(p, threads=4)
+    assert sec > 0 and np.isfinite(rgb).all()
+    film, _, _ = oracle.OracleScene(desc).render(p)
+    o = oracle.develop(film)
+    assert abs(rgb.mean() - o.mean()) / o.mean() < 0.02
+    assert np.linalg.norm(rgb - o) / np.linalg.norm(o) < 0.15          # two independent 64-spp renders
+    rgb2, _ = rs.render_job(A.default_render_params(spp=8, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2), threads=4)
+    film2, _, _ = oracle.OracleScene(desc).render(A.default_render_params(spp=8, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2))
+    o2 = oracle.develop(film2)
+    assert abs(rgb2.mean() - o2.mean()) / o2.mean() < 0.03
