@@ -9,10 +9,21 @@
 #include <mitsuba/core/fresolver.h>
 #include <mitsuba/render/mipmap.h>
 #include <boost/algorithm/string.hpp>
+#include "../../bsdfs/microfacet.h"      /* MicrofacetDistribution: plugin-local header of src/bsdfs */
+#include "../../bsdfs/ior.h"             /* lookupIOR */
 #include "phip.h"
+
+#if SPECTRUM_SAMPLES != 3 || !defined(SINGLE_PRECISION)
+#error "path_hip computes float32 linear RGB: build Mitsuba with -DSINGLE_PRECISION -DSPECTRUM_SAMPLES=3 (its default configuration)"
+#endif
 
 MTS_NAMESPACE_BEGIN
 
+/* PHIP_REFERENCE_ACCESSORS: the five one-line accessors of INTEGRATION.md section 2 have been added to the reference's
+   plugins (twosided.cpp, envmap.cpp, diffuse.cpp, bitmap.cpp, Texture2D).  Without it the shim builds against a STOCK
+   Mitsuba 0.6 and supports what the public interfaces expose: diffuse (constant reflectance) / dielectric / roughconductor
+   BSDFs, area and constant emitters -- two-sided BSDFs, bitmap textures and the envmap are an EError then. */
+#if defined(PHIP_REFERENCE_ACCESSORS)
 /* What the shim needs of src/emitters/envmap.cpp's EnvironmentMap (a plugin-local class): its MIP pyramid.  With the
    accessor of INTEGRATION.md added there and the class declaration moved to a header, this stand-in goes away. */
 class EnvironmentMapAccess : public Emitter {
@@ -47,6 +58,8 @@ public:
     virtual const BSDF *getNestedBRDF(int i) const = 0;
 };
 
+#endif
+
 /* Owns the device scene of one integrator instance. */
 class PhipSceneHolder {
 public:
@@ -67,7 +80,7 @@ public:
         rp.block_size = (int32_t) scene->getBlockSize();
         rp.sampler = PHIP_SAMPLER_CTR; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
         /* crop-relative (renderproc.cpp:160-173); no border: border pixels are already folded in by the device film pass */
-        ref<Bitmap> target = new Bitmap(Bitmap::EMultiSpectrumAlphaWeight, Bitmap::EFloat32, size, SPECTRUM_SAMPLES + 2);
+        ref<Bitmap> target = new Bitmap(Bitmap::ESpectrumAlphaWeight, Bitmap::EFloat32, size);   /* = the film storage's format: setBitmap is a memcpy */
         phip_stats st;
         int rc = phip_render(m_scene, &rp, target->getFloat32Data(), &st);
         if (rc == PHIP_ERR_CANCELLED)
@@ -145,6 +158,7 @@ public:
                    drives the illumination (envmap.cpp:516-632), all levels the EWA lookup of directly visible pixels
                    (envmap.cpp:395-407).  EnvironmentMap keeps m_mipmap private: INTEGRATION.md lists the one-line accessor
                    `const MIPMap *getMIPMap() const { return m_mipmap; }` this needs. */
+#if defined(PHIP_REFERENCE_ACCESSORS)
                 pe.type = PHIP_EMITTER_ENVMAP; pe.shape = 0xFFFFFFFFu;
                 const EnvironmentMapAccess *env = static_cast<const EnvironmentMapAccess *>(e);
                 const int nLevels = env->getMIPMap()->getLevels();
@@ -158,8 +172,11 @@ public:
                 envmap.texels = m_envLevels[0]->getFloat32Data();
                 envmap.width = (uint32_t) m_envLevels[0]->getWidth(); envmap.height = (uint32_t) m_envLevels[0]->getHeight();
                 envmap.scale = e->getProperties().getFloat("scale", 1.0f);
-                const Matrix4x4 &tw = e->getWorldTransform()->eval(0).getMatrix();
+                const Matrix4x4 tw = e->getWorldTransform()->eval(0).getMatrix();     /* a copy: eval() returns a temporary */
                 for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) envmap.to_world[4 * r + c] = tw(r, c);
+#else
+                SLog(EError, "path_hip: the envmap emitter needs the accessor patch of INTEGRATION.md (PHIP_REFERENCE_ACCESSORS)");
+#endif
             } else {
                 SLog(EError, "path_hip: emitter \"%s\" is not supported (area, constant, envmap)", cls.c_str());
             }
@@ -181,7 +198,7 @@ public:
         if (sensor->getClass()->getName() != "PerspectiveCameraImpl")
             SLog(EError, "path_hip: only the 'perspective' sensor is supported");
         const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);
-        const Matrix4x4 &m = cam->getWorldTransform(0).getMatrix();
+        const Matrix4x4 m = cam->getWorldTransform(0).getMatrix();         /* a copy: getWorldTransform(t) returns a temporary */
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) d.camera.to_world[4 * r + c] = m(r, c);
         d.camera.xfov_deg = cam->getXFov(); d.camera.near_clip = cam->getNearClip(); d.camera.far_clip = cam->getFarClip();
 
@@ -194,6 +211,22 @@ public:
         for (int i = 0; i <= PHIP_FILTER_RESOLUTION; ++i)      /* evalDiscretized(x) = m_values[min(int(|x| * res/radius), res)] */
             d.film.filter_table[i] = rf->evalDiscretized((i + 0.5f) * rf->getRadius() / PHIP_FILTER_RESOLUTION);
 
+        if (const char *dump = getenv("PHIP_SHIM_DUMP")) {      /* debugging aid: the flattened description as raw arrays */
+            FILE *f = fopen(dump, "wb");
+            if (f) {
+                uint32_t hdr[6] = { d.n_vertices, d.n_triangles, d.n_shapes, d.n_materials, d.n_emitters, d.n_textures };
+                fwrite(hdr, sizeof(hdr), 1, f);
+                fwrite(d.positions, sizeof(float), 3 * (size_t) d.n_vertices, f);
+                fwrite(normals.data(), sizeof(float), 3 * (size_t) d.n_vertices, f);
+                fwrite(d.indices, sizeof(uint32_t), 3 * (size_t) d.n_triangles, f);
+                fwrite(d.shapes, sizeof(phip_shape), d.n_shapes, f);
+                fwrite(d.materials, sizeof(phip_material), d.n_materials, f);
+                fwrite(d.emitters, sizeof(phip_emitter), d.n_emitters, f);
+                fwrite(&d.camera, sizeof(d.camera), 1, f);
+                fwrite(&d.film, sizeof(d.film), 1, f);
+                fclose(f);
+            }
+        }
         if (m_scene) phip_scene_destroy(m_scene);
         m_scene = phip_scene_create(&d, m_device);
         if (!m_scene)
@@ -202,6 +235,7 @@ public:
 
     static void rgb(const Spectrum &s, float out[3]) { Float r, g, b; s.toLinearRGB(r, g, b); out[0] = r; out[1] = g; out[2] = b; }
 
+#if defined(PHIP_REFERENCE_ACCESSORS)
     /* <texture type="bitmap">: the RGB MIP pyramid as the plugin built and stores it + the lookup parameters
        (bitmap.cpp: wrapModeU/V, filterType, maxAnisotropy; Texture2D: uscale/vscale/uoffset/voffset) */
     uint32_t convertBitmap(const BitmapTextureAccess *tex) {
@@ -225,6 +259,8 @@ public:
         return id;
     }
 
+#endif
+
     uint32_t convertBSDF(const BSDF *bsdf, std::vector<phip_material> &materials, std::map<const BSDF *, uint32_t> &ids) {
         std::map<const BSDF *, uint32_t>::iterator it = ids.find(bsdf);
         if (it != ids.end()) return it->second;
@@ -234,6 +270,7 @@ public:
         Intersection its;       /* constant textures only: any intersection record evaluates to the same value */
         if (cls == "SmoothDiffuse") {
             m.type = PHIP_BSDF_DIFFUSE;
+#if defined(PHIP_REFERENCE_ACCESSORS)
             const Texture *tex = static_cast<const SmoothDiffuseAccess *>(bsdf)->getReflectanceTexture();   /* accessor: INTEGRATION.md */
             if (tex->getClass()->getName() == "BitmapTexture")
                 m.reflectance_texture = 1 + convertBitmap(static_cast<const BitmapTextureAccess *>(tex));
@@ -241,6 +278,11 @@ public:
                 rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
             else
                 SLog(EError, "path_hip: texture \"%s\" is not supported (constant, bitmap)", tex->getClass()->getName().c_str());
+#else
+            if (bsdf->getType() & BSDF::ESpatiallyVarying)
+                SLog(EError, "path_hip: a textured reflectance needs the accessor patch of INTEGRATION.md (PHIP_REFERENCE_ACCESSORS)");
+            rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
+#endif
         } else if (cls == "SmoothDielectric") {
             m.type = PHIP_BSDF_DIELECTRIC; m.eta[0] = bsdf->getEta();
             rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
@@ -258,7 +300,8 @@ public:
             }
             Float extEta = lookupIOR(props, "extEta", "air");
             rgb(props.getSpectrum("eta", intEta) / extEta, m.eta); rgb(props.getSpectrum("k", intK) / extEta, m.k);
-            rgb(bsdf->getSpecularReflectance(its), m.reflectance);
+            /* (BSDF::getSpecularReflectance folds the Fresnel term at its.wi in, roughconductor.cpp:252-257: not the parameter) */
+            rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
             MicrofacetDistribution distr(props);
             if (distr.getType() == MicrofacetDistribution::EPhong)
                 SLog(EError, "path_hip: the phong/as microfacet distribution is not supported");
@@ -266,9 +309,13 @@ public:
             m.alpha_u = distr.getAlphaU(); m.alpha_v = distr.getAlphaV(); m.sample_visible = distr.getSampleVisible() ? 1 : 0;
         } else if (cls == "TwoSidedBRDF") {
             /* twosided.cpp keeps its children in m_nestedBRDF[2]; they are reachable as named children */
+#if defined(PHIP_REFERENCE_ACCESSORS)
             std::vector<const BSDF *> nested = getNestedBSDFs(bsdf);
             uint32_t a = convertBSDF(nested[0], materials, ids), b = nested.size() > 1 ? convertBSDF(nested[1], materials, ids) : a;
             m.type = PHIP_BSDF_TWOSIDED; m.nested[0] = a; m.nested[1] = b;
+#else
+            SLog(EError, "path_hip: the twosided adapter needs the accessor patch of INTEGRATION.md (PHIP_REFERENCE_ACCESSORS)");
+#endif
         } else {
             SLog(EError, "path_hip: BSDF '%s' is outside the supported set (diffuse, dielectric, roughconductor, twosided)", cls.c_str());
         }
@@ -279,6 +326,7 @@ public:
         return ids[bsdf];
     }
 
+#if defined(PHIP_REFERENCE_ACCESSORS)
     /* the adapter exposes no getter for its children; a one-line accessor has to be added to twosided.cpp
        (`const BSDF *getNestedBRDF(int i) const { return m_nestedBRDF[i]; }`) -- see INTEGRATION.md */
     static std::vector<const BSDF *> getNestedBSDFs(const BSDF *bsdf) {
@@ -288,6 +336,7 @@ public:
         out.push_back(t->getNestedBRDF(1));       /* twosided.cpp:64-65: the front BRDF again when only one was given */
         return out;
     }
+#endif
 
 private:
     phip_scene *m_scene;

@@ -367,7 +367,13 @@ int ref_render(void *h, const phip_render_params *p, float *out_samples, float *
  * worker) on `threads` LocalWorkers -> Film::put.  out_rgb (optional): the developed crop window, H x W x 3.
  * The worker count is fixed by the first call.
  */
+int ref_render_job_plugin(void *h, const phip_render_params *p, const char *integrator_plugin, int threads, float *out_rgb, double *seconds);
 int ref_render_job(void *h, const phip_render_params *p, int threads, float *out_rgb, double *seconds) {
+    return ref_render_job_plugin(h, p, NULL, threads, out_rgb, seconds);
+}
+/* integrator_plugin: NULL = "path" / "direct" by p->integrator, else the plugin to instantiate with the same parameters
+   -- "path_hip" / "direct_hip": the product's shims, loaded by the reference's PluginManager like any other plugin */
+int ref_render_job_plugin(void *h, const phip_render_params *p, const char *integrator_plugin, int threads, float *out_rgb, double *seconds) {
     try {
         RefScene *rs = static_cast<RefScene *>(h);
         Scene *scene = rs->scene;
@@ -377,7 +383,7 @@ int ref_render_job(void *h, const phip_render_params *p, int threads, float *out
                 sched->registerWorker(new LocalWorker(i, formatString("wrk%i", i)));
             sched->start();
         }
-        Properties ip(p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path");
+        Properties ip(integrator_plugin ? integrator_plugin : (p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path"));
         if (p->integrator == PHIP_INTEGRATOR_DIRECT) {
             ip.setSize("emitterSamples", (size_t) p->emitter_samples); ip.setSize("bsdfSamples", (size_t) p->bsdf_samples);
         } else {

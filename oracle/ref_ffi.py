@@ -37,6 +37,18 @@ def build(quiet=True):
         print(r.stdout[-2000:])
 
 
+def build_shims():
+    """oracle/_ref/plugins/{path_hip,direct_hip}.so: the product's Mitsuba plugins compiled against the reference (needs
+    libphip.so and the reference tree)"""
+    r = subprocess.run(["make", "-C", HERE, "-f", "Makefile.ref", "shims", "REF=" + REFERENCE], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("shim build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+
+
+def have_shims():
+    return all(os.path.exists(os.path.join(HERE, "_ref", "plugins", n + ".so")) for n in ("path_hip", "direct_hip"))
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -51,6 +63,7 @@ def lib():
     L.ref_scene_destroy.argtypes = [C.c_void_p]
     L.ref_render.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), fp, fp]
     L.ref_render_job.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), C.c_int, fp, C.POINTER(C.c_double)]
+    L.ref_render_job_plugin.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), C.c_char_p, C.c_int, fp, C.POINTER(C.c_double)]
     L.ref_trace.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
     L.ref_intersect.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
     L.ref_bsdf_sample.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]
@@ -102,12 +115,14 @@ class RefScene:
         self._check(self.L.ref_render(self.h, C.byref(params), _fp(samples) if want_samples else None, _fp(film)), "ref_render")
         return film, samples
 
-    def render_job(self, params, threads=None, want_image=True):
-        """the reference's complete multi-threaded render (RenderJob on the Scheduler); returns (rgb or None, seconds)"""
+    def render_job(self, params, threads=None, want_image=True, plugin=None):
+        """the reference's complete multi-threaded render (RenderJob on the Scheduler); returns (rgb or None, seconds).
+        plugin="path_hip" / "direct_hip": the same job with the product's plugin shim as the scene's integrator."""
         threads = threads or os.cpu_count() or 1
         rgb = np.zeros((self.height, self.width, 3), np.float32) if want_image else None
         sec = C.c_double()
-        self._check(self.L.ref_render_job(self.h, C.byref(params), threads, _fp(rgb) if want_image else None, C.byref(sec)), "ref_render_job")
+        self._check(self.L.ref_render_job_plugin(self.h, C.byref(params), plugin.encode() if plugin else None, threads,
+                                                 _fp(rgb) if want_image else None, C.byref(sec)), "ref_render_job")
         return rgb, sec.value
 
     def trace(self, rays):
