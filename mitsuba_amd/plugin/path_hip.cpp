@@ -5,9 +5,9 @@
  * Build (inside a Mitsuba 0.6 source tree, next to src/integrators/path/):
  *     plugins += env.SharedLibrary('path_hip', ['path_hip/path_hip.cpp'], LIBS = env['LIBS'] + ['phip'])
  * (pattern: src/integrators/SConscript:5).  Select it with <integrator type="path_hip"/>.
- * It cannot be compiled in the build container of this repository (Boost / Xerces / OpenEXR /
- * SCons are absent); the standalone harness (mitsuba_amd/*.py, tests/) drives the same
- * C ABI through ctypes instead.  See INTEGRATION.md.
+ * In this repository it is compiled against the reference's own headers and run inside the reference's libraries
+ * (oracle/Makefile.ref, target `shims`; tests/test_gpu_dropin.py); the standalone harness (mitsuba_amd/*.py, tests/)
+ * drives the same C ABI through ctypes.  See INTEGRATION.md.
  *
  * What it does, and nothing else:
  *   - derives from MonteCarloIntegrator so that maxDepth / rrDepth / strictNormals / hideEmitters
