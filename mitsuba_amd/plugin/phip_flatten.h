@@ -13,16 +13,44 @@
 #include "../../bsdfs/ior.h"             /* lookupIOR */
 #include "phip.h"
 
+/* How the shim gets at four plugin-local classes of the reference (TwoSidedBRDF's children, SmoothDiffuse's reflectance
+ * texture, BitmapTexture's and EnvironmentMap's MIP pyramids and lookup parameters), which have no public getters:
+ *   (default)                     not at all: stock Mitsuba, public getters only -- diffuse with a constant reflectance,
+ *                                 dielectric, roughconductor, area + constant emitters; anything else is an EError
+ *   -DPHIP_REFERENCE_ACCESSORS    the five one-line accessors of INTEGRATION.md section 2 have been added to the plugins
+ *   -DPHIP_REFERENCE_SOURCES      no change to Mitsuba at all: the plugins' own source files are #included here for their class
+ *                                 definitions and the members are read directly (compile with -fno-access-control); the
+ *                                 copies of the plugin code this drags into path_hip.so are never instantiated
+ */
+#if defined(PHIP_REFERENCE_SOURCES)
+#define CreateInstance CreateInstance_phip_twosided
+#define GetDescription GetDescription_phip_twosided
+#include "../../bsdfs/twosided.cpp"
+#undef CreateInstance
+#undef GetDescription
+#define CreateInstance CreateInstance_phip_diffuse
+#define GetDescription GetDescription_phip_diffuse
+#include "../../bsdfs/diffuse.cpp"
+#undef CreateInstance
+#undef GetDescription
+#define CreateInstance CreateInstance_phip_bitmap
+#define GetDescription GetDescription_phip_bitmap
+#include "../../textures/bitmap.cpp"
+#undef CreateInstance
+#undef GetDescription
+#define CreateInstance CreateInstance_phip_envmap
+#define GetDescription GetDescription_phip_envmap
+#include "../../emitters/envmap.cpp"
+#undef CreateInstance
+#undef GetDescription
+#endif
+
 #if SPECTRUM_SAMPLES != 3 || !defined(SINGLE_PRECISION)
 #error "path_hip computes float32 linear RGB: build Mitsuba with -DSINGLE_PRECISION -DSPECTRUM_SAMPLES=3 (its default configuration)"
 #endif
 
 MTS_NAMESPACE_BEGIN
 
-/* PHIP_REFERENCE_ACCESSORS: the five one-line accessors of INTEGRATION.md section 2 have been added to the reference's
-   plugins (twosided.cpp, envmap.cpp, diffuse.cpp, bitmap.cpp, Texture2D).  Without it the shim builds against a STOCK
-   Mitsuba 0.6 and supports what the public interfaces expose: diffuse (constant reflectance) / dielectric / roughconductor
-   BSDFs, area and constant emitters -- two-sided BSDFs, bitmap textures and the envmap are an EError then. */
 #if defined(PHIP_REFERENCE_ACCESSORS)
 /* What the shim needs of src/emitters/envmap.cpp's EnvironmentMap (a plugin-local class): its MIP pyramid.  With the
    accessor of INTEGRATION.md added there and the class declaration moved to a header, this stand-in goes away. */
@@ -58,6 +86,35 @@ public:
     virtual const BSDF *getNestedBRDF(int i) const = 0;
 };
 
+#endif
+
+#if defined(PHIP_REFERENCE_ACCESSORS) || defined(PHIP_REFERENCE_SOURCES)
+#define PHIP_HAVE_INTERNALS 1
+/* one spelling for both ways in */
+struct PhipBitmapInfo {
+    const TMIPMap<TSpectrum<Float, 3>, TSpectrum<half, 3> > *mip;
+    ReconstructionFilter::EBoundaryCondition wrapU, wrapV;
+    Float maxAnisotropy; Vector2 uvScale; Point2 uvOffset;
+};
+#if defined(PHIP_REFERENCE_ACCESSORS)
+inline const BSDF *phipNested(const BSDF *b, int i) { return static_cast<const TwoSidedAccess *>(b)->getNestedBRDF(i); }
+inline const Texture *phipReflectanceTexture(const BSDF *b) { return static_cast<const SmoothDiffuseAccess *>(b)->getReflectanceTexture(); }
+inline const TMIPMap<Spectrum, TSpectrum<half, SPECTRUM_SAMPLES> > *phipEnvMip(const Emitter *e) { return static_cast<const EnvironmentMapAccess *>(e)->getMIPMap(); }
+inline PhipBitmapInfo phipBitmap(const Texture *t) {
+    const BitmapTextureAccess *b = static_cast<const BitmapTextureAccess *>(t);
+    PhipBitmapInfo i = { b->getMIPMap3(), b->getWrapModeU(), b->getWrapModeV(), b->getMaxAnisotropy(), b->getUVScale(), b->getUVOffset() };
+    return i;
+}
+#else
+inline const BSDF *phipNested(const BSDF *b, int i) { return static_cast<const TwoSidedBRDF *>(b)->m_nestedBRDF[i].get(); }
+inline const Texture *phipReflectanceTexture(const BSDF *b) { return static_cast<const SmoothDiffuse *>(b)->m_reflectance.get(); }
+inline const TMIPMap<Spectrum, TSpectrum<half, SPECTRUM_SAMPLES> > *phipEnvMip(const Emitter *e) { return static_cast<const EnvironmentMap *>(e)->m_mipmap; }
+inline PhipBitmapInfo phipBitmap(const Texture *t) {
+    const BitmapTexture *b = static_cast<const BitmapTexture *>(t);
+    PhipBitmapInfo i = { b->m_mipmap3.get(), b->m_wrapModeU, b->m_wrapModeV, b->m_maxAnisotropy, b->m_uvScale, b->m_uvOffset };
+    return i;
+}
+#endif
 #endif
 
 /* Owns the device scene of one integrator instance. */
@@ -158,14 +215,13 @@ public:
                    drives the illumination (envmap.cpp:516-632), all levels the EWA lookup of directly visible pixels
                    (envmap.cpp:395-407).  EnvironmentMap keeps m_mipmap private: INTEGRATION.md lists the one-line accessor
                    `const MIPMap *getMIPMap() const { return m_mipmap; }` this needs. */
-#if defined(PHIP_REFERENCE_ACCESSORS)
+#if defined(PHIP_HAVE_INTERNALS)
                 pe.type = PHIP_EMITTER_ENVMAP; pe.shape = 0xFFFFFFFFu;
-                const EnvironmentMapAccess *env = static_cast<const EnvironmentMapAccess *>(e);
-                const int nLevels = env->getMIPMap()->getLevels();
+                const int nLevels = phipEnvMip(e)->getLevels();
                 if (nLevels > PHIP_ENVMAP_MAX_LEVELS) SLog(EError, "path_hip: environment map with too many MIP levels");
                 m_envLevels.clear();
                 for (int l = 0; l < nLevels; ++l) {
-                    m_envLevels.push_back(env->getMIPMap()->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
+                    m_envLevels.push_back(phipEnvMip(e)->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
                     envmap.levels[l] = m_envLevels[l]->getFloat32Data();
                 }
                 envmap.n_levels = (uint32_t) nLevels;
@@ -175,7 +231,7 @@ public:
                 const Matrix4x4 tw = e->getWorldTransform()->eval(0).getMatrix();     /* a copy: eval() returns a temporary */
                 for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) envmap.to_world[4 * r + c] = tw(r, c);
 #else
-                SLog(EError, "path_hip: the envmap emitter needs the accessor patch of INTEGRATION.md (PHIP_REFERENCE_ACCESSORS)");
+                SLog(EError, "path_hip: the envmap emitter needs -DPHIP_REFERENCE_SOURCES or the accessor patch of INTEGRATION.md (-DPHIP_REFERENCE_ACCESSORS)");
 #endif
             } else {
                 SLog(EError, "path_hip: emitter \"%s\" is not supported (area, constant, envmap)", cls.c_str());
@@ -235,30 +291,29 @@ public:
 
     static void rgb(const Spectrum &s, float out[3]) { Float r, g, b; s.toLinearRGB(r, g, b); out[0] = r; out[1] = g; out[2] = b; }
 
-#if defined(PHIP_REFERENCE_ACCESSORS)
+#if defined(PHIP_HAVE_INTERNALS)
     /* <texture type="bitmap">: the RGB MIP pyramid as the plugin built and stores it + the lookup parameters
        (bitmap.cpp: wrapModeU/V, filterType, maxAnisotropy; Texture2D: uscale/vscale/uoffset/voffset) */
-    uint32_t convertBitmap(const BitmapTextureAccess *tex) {
+    uint32_t convertBitmap(const Texture *tex) {
         std::map<const Texture *, uint32_t>::iterator it = m_textureIds.find(tex);
         if (it != m_textureIds.end()) return it->second;
-        const BitmapTextureAccess::MIPMap3 *mip = tex->getMIPMap3();
-        if (!mip) SLog(EError, "path_hip: only RGB bitmap textures are supported");
+        const PhipBitmapInfo info = phipBitmap(tex);
+        if (!info.mip) SLog(EError, "path_hip: only RGB bitmap textures are supported");
         phip_texture t; memset(&t, 0, sizeof(t));
-        t.n_levels = (uint32_t) mip->getLevels();
-        for (int l = 0; l < mip->getLevels(); ++l) {
-            m_textureLevels.push_back(mip->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
+        t.n_levels = (uint32_t) info.mip->getLevels();
+        for (int l = 0; l < info.mip->getLevels(); ++l) {
+            m_textureLevels.push_back(info.mip->toBitmap(l)->convert(Bitmap::ERGB, Bitmap::EFloat32));
             t.levels[l] = m_textureLevels.back()->getFloat32Data();
         }
-        t.width = (uint32_t) mip->getWidth(); t.height = (uint32_t) mip->getHeight();
-        t.wrap_u = (uint32_t) tex->getWrapModeU(); t.wrap_v = (uint32_t) tex->getWrapModeV();      /* EBoundaryCondition order = phip_wrap_mode */
-        t.filter_type = (uint32_t) mip->getFilterType(); t.max_anisotropy = tex->getMaxAnisotropy();
-        t.uv_scale[0] = tex->getUVScale().x; t.uv_scale[1] = tex->getUVScale().y;
-        t.uv_offset[0] = tex->getUVOffset().x; t.uv_offset[1] = tex->getUVOffset().y;
+        t.width = (uint32_t) info.mip->getWidth(); t.height = (uint32_t) info.mip->getHeight();
+        t.wrap_u = (uint32_t) info.wrapU; t.wrap_v = (uint32_t) info.wrapV;       /* phip_wrap_mode = EBoundaryCondition, value for value */
+        t.filter_type = (uint32_t) info.mip->getFilterType(); t.max_anisotropy = info.maxAnisotropy;
+        t.uv_scale[0] = info.uvScale.x; t.uv_scale[1] = info.uvScale.y;
+        t.uv_offset[0] = info.uvOffset.x; t.uv_offset[1] = info.uvOffset.y;
         uint32_t id = (uint32_t) m_textures.size();
         m_textures.push_back(t); m_textureIds[tex] = id;
         return id;
     }
-
 #endif
 
     uint32_t convertBSDF(const BSDF *bsdf, std::vector<phip_material> &materials, std::map<const BSDF *, uint32_t> &ids) {
@@ -270,17 +325,17 @@ public:
         Intersection its;       /* constant textures only: any intersection record evaluates to the same value */
         if (cls == "SmoothDiffuse") {
             m.type = PHIP_BSDF_DIFFUSE;
-#if defined(PHIP_REFERENCE_ACCESSORS)
-            const Texture *tex = static_cast<const SmoothDiffuseAccess *>(bsdf)->getReflectanceTexture();   /* accessor: INTEGRATION.md */
+#if defined(PHIP_HAVE_INTERNALS)
+            const Texture *tex = phipReflectanceTexture(bsdf);
             if (tex->getClass()->getName() == "BitmapTexture")
-                m.reflectance_texture = 1 + convertBitmap(static_cast<const BitmapTextureAccess *>(tex));
+                m.reflectance_texture = 1 + convertBitmap(tex);
             else if (tex->isConstant())
                 rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
             else
                 SLog(EError, "path_hip: texture \"%s\" is not supported (constant, bitmap)", tex->getClass()->getName().c_str());
 #else
             if (bsdf->getType() & BSDF::ESpatiallyVarying)
-                SLog(EError, "path_hip: a textured reflectance needs the accessor patch of INTEGRATION.md (PHIP_REFERENCE_ACCESSORS)");
+                SLog(EError, "path_hip: a textured reflectance needs -DPHIP_REFERENCE_SOURCES or the accessor patch of INTEGRATION.md (-DPHIP_REFERENCE_ACCESSORS)");
             rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
 #endif
         } else if (cls == "SmoothDielectric") {
@@ -309,12 +364,12 @@ public:
             m.alpha_u = distr.getAlphaU(); m.alpha_v = distr.getAlphaV(); m.sample_visible = distr.getSampleVisible() ? 1 : 0;
         } else if (cls == "TwoSidedBRDF") {
             /* twosided.cpp keeps its children in m_nestedBRDF[2]; they are reachable as named children */
-#if defined(PHIP_REFERENCE_ACCESSORS)
+#if defined(PHIP_HAVE_INTERNALS)
             std::vector<const BSDF *> nested = getNestedBSDFs(bsdf);
             uint32_t a = convertBSDF(nested[0], materials, ids), b = nested.size() > 1 ? convertBSDF(nested[1], materials, ids) : a;
             m.type = PHIP_BSDF_TWOSIDED; m.nested[0] = a; m.nested[1] = b;
 #else
-            SLog(EError, "path_hip: the twosided adapter needs the accessor patch of INTEGRATION.md (PHIP_REFERENCE_ACCESSORS)");
+            SLog(EError, "path_hip: the twosided adapter needs -DPHIP_REFERENCE_SOURCES or the accessor patch of INTEGRATION.md (-DPHIP_REFERENCE_ACCESSORS)");
 #endif
         } else {
             SLog(EError, "path_hip: BSDF '%s' is outside the supported set (diffuse, dielectric, roughconductor, twosided)", cls.c_str());
@@ -326,14 +381,11 @@ public:
         return ids[bsdf];
     }
 
-#if defined(PHIP_REFERENCE_ACCESSORS)
-    /* the adapter exposes no getter for its children; a one-line accessor has to be added to twosided.cpp
-       (`const BSDF *getNestedBRDF(int i) const { return m_nestedBRDF[i]; }`) -- see INTEGRATION.md */
+#if defined(PHIP_HAVE_INTERNALS)
     static std::vector<const BSDF *> getNestedBSDFs(const BSDF *bsdf) {
-        const TwoSidedAccess *t = static_cast<const TwoSidedAccess *>(bsdf);
         std::vector<const BSDF *> out;
-        out.push_back(t->getNestedBRDF(0));
-        out.push_back(t->getNestedBRDF(1));       /* twosided.cpp:64-65: the front BRDF again when only one was given */
+        out.push_back(phipNested(bsdf, 0));
+        out.push_back(phipNested(bsdf, 1));       /* twosided.cpp:87-88: the front BRDF again when only one was given */
         return out;
     }
 #endif
