@@ -82,17 +82,20 @@ def cpu_baseline(workload, seconds_target=15.0):
     multi-threaded render, RenderJob -> BlockedRenderProcess on one LocalWorker per core; otherwise the oracle port."""
     desc, w, h, spp, md, _ = build_desc(workload)
     cores = os.cpu_count() or 1
+    run = None
     try:
         from oracle import ref_ffi as R
         if not os.path.exists(R.LIB):
             raise RuntimeError("oracle/_ref is not built")
         rs = R.RefScene(desc)
-        run = lambda s: rs.render_job(oracle_params(md, s), threads=cores, want_image=False)[1]
+        ref_run = lambda s: rs.render_job(oracle_params(md, s), threads=cores, want_image=False)[1]
+        ref_run(1)                   # starts the Scheduler's workers, touches every plugin: not timed
+        run, st = ref_run, None
         kind, what = "reference", ("Mitsuba 0.6 itself (oracle/_ref: the reference's sources compiled with g++ -O3 -march=x86-64-v3, IEEE "
                                    "float semantics; SAH kd-tree, `independent` sampler, 32x32 blocks, %d LocalWorkers)" % cores)
-        st = None
     except Exception as e:           # no prebuilt reference on this box: the restatement is the baseline
         print("bench.py: reference CPU baseline unavailable (%s); timing the oracle port" % e, file=sys.stderr)
+    if run is None:
         from oracle import oracle_ffi as O
         osc = O.OracleScene(desc)
         last = {}
