@@ -129,6 +129,53 @@ def textures(gauss, mip):
     return sb
 
 
+def random_scene(gauss, seed, res=(24, 16)):
+    """fuzz input: random spheres (smooth / flat, with texture coordinates) and a triangle soup, 2-5 random materials of every
+    kind, 1-2 quad lights, sometimes a constant environment, random camera.  Returns (SceneBuilder, render parameters)."""
+    rng = np.random.default_rng(seed)
+    sb = S.SceneBuilder()
+    if rng.random() < 0.4:
+        sb.constant(tuple(rng.uniform(0.1, 1.0, 3)), sampling_weight=float(rng.uniform(0.3, 2)))
+    mats = []
+    for i in range(rng.integers(2, 6)):
+        t = rng.integers(0, 5)
+        if t == 0:
+            m = sb.diffuse(tuple(rng.uniform(0, 0.9, 3)))
+        elif t == 1:
+            m = sb.dielectric(float(rng.uniform(1.1, 2.0)), 1.0)
+        elif t == 2:
+            m = sb.roughconductor(alpha=float(rng.uniform(0.02, 0.6)), distribution=["beckmann", "ggx"][rng.integers(2)],
+                                  sample_visible=bool(rng.integers(2)), eta=S.CU_ETA, k=S.CU_K)
+        elif t == 3:
+            m = sb.twosided(sb.diffuse(tuple(rng.uniform(0, 0.9, 3))))
+        else:
+            m = sb.twosided(sb.roughconductor(alpha=float(rng.uniform(0.05, 0.4)), alpha_v=float(rng.uniform(0.05, 0.4)), eta=S.CU_ETA, k=S.CU_K),
+                            sb.diffuse(tuple(rng.uniform(0, 0.9, 3))))
+        mats.append(m)
+    for i in range(rng.integers(2, 6)):
+        P, T, N = S.sphere_mesh(tuple(rng.uniform(-2, 2, 3)), float(rng.uniform(0.3, 1.0)), 8, 5)
+        sb.mesh(P, T, mats[rng.integers(len(mats))], normals=N if rng.random() < 0.6 else None, uvs=_sphere_uvs(N))
+    n = rng.integers(5, 40)
+    c = rng.uniform(-3, 3, (n, 1, 3))
+    P = (c + rng.normal(scale=0.8, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    sb.mesh(P, np.arange(3 * n, dtype=np.uint32).reshape(n, 3), sb.diffuse(tuple(rng.uniform(0.1, 0.9, 3))))
+    for i in range(rng.integers(1, 3)):
+        o = rng.uniform(-2, 2, 3); o[1] = rng.uniform(2.5, 4)
+        sb.quad(tuple(o + [-0.5, 0, -0.5]), tuple(o + [0.5, 0, -0.5]), tuple(o + [0.5, 0, 0.5]), tuple(o + [-0.5, 0, 0.5]),
+                sb.diffuse((0, 0, 0)), facing=(0, -1, 0), radiance=tuple(rng.uniform(2, 20, 3)))
+    eye = rng.uniform(-1, 1, 3) * [4, 1, 4]; eye[2] = -6
+    sb.perspective(tuple(eye), (0, 0, 0), (0, 1, 0), float(rng.uniform(30, 80)))
+    sb.hdrfilm(res[0], res[1], gauss)
+    prng = np.random.default_rng(1000 + seed)
+    if seed % 2 == 0:
+        kw = dict(spp=2, max_depth=int(prng.integers(2, 12)), rr_depth=int(prng.integers(1, 6)), strict_normals=int(prng.integers(2)),
+                  hide_emitters=int(prng.integers(2)))
+    else:
+        kw = dict(spp=1, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=int(prng.integers(0, 3)), bsdf_samples=int(prng.integers(1, 3)),
+                  strict_normals=int(prng.integers(2)))
+    return sb, kw
+
+
 PATH, DIRECT = A.PHIP_INTEGRATOR_PATH, A.PHIP_INTEGRATOR_DIRECT
 
 # (case name, scene builder, render parameters)

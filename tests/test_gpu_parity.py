@@ -422,3 +422,32 @@ def test_reference_built_pyramids_and_pin_scenes(gpu, oracle, gauss):
         same, r = compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=6)
         print("%s: identical %.6f rel L2 %.3e" % (build.__name__, same, r))
         compare_render(gpu, oracle, desc, 2, min_identical=0.999, integrator=DirectHIP, emitterSamples=2, bsdfSamples=2)
+
+
+def test_random_scenes_fuzz_against_the_oracle(gpu, oracle, gauss):
+    """the fuzz scenes on which the oracle is pinned to the reference (ref_scenes.random_scene): GPU against the oracle on
+    the parity stream, path tracer and `direct` with random parameters"""
+    import ref_scenes as RS
+    from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+    import os
+    worst = 1.0
+    n_scenes = int(os.environ.get("PHIP_FUZZ_SCENES", "60"))         # 1500 were run once during development: all bit-identical
+    for seed in range(n_scenes):
+        sb, kw = RS.random_scene(gauss, seed, res=(48, 32))
+        desc = sb.desc()
+        if kw.get("integrator") == A.PHIP_INTEGRATOR_DIRECT:
+            integ = DirectHIP(emitterSamples=kw["emitter_samples"], bsdfSamples=kw["bsdf_samples"], strictNormals=bool(kw["strict_normals"]))
+        else:
+            integ = PathHIP(maxDepth=kw["max_depth"], rrDepth=kw["rr_depth"], strictNormals=bool(kw["strict_normals"]), hideEmitters=bool(kw["hide_emitters"]))
+        gs = Scene(desc)
+        film = HDRFilm(gs.width, gs.height)
+        assert integ.render(gs, film, 4, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
+        gsmp = integ.samples(gs, 4)
+        osc = oracle.OracleScene(desc)
+        _, osmp, _ = osc.render(integ.params(gs, 4), want_samples=True)
+        same = (gsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean()
+        worst = min(worst, same)
+        assert same >= 0.995, (seed, kw, same)            # exact-t ties between soup triangles may resolve differently
+        assert np.isfinite(gsmp).all() == np.isfinite(osmp).all()
+        gs.close(); osc.close()
+    print("fuzz: worst fraction of bit-identical samples over %d scenes: %.6f" % (n_scenes, worst))

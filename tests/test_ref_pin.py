@@ -52,6 +52,21 @@ def test_oracle_reproduces_the_reference_bit_for_bit(ref, olibm, name, build, kw
     rs.close(); osc.close()
 
 
+def test_random_scenes_fuzz(ref, olibm):
+    """random scenes (ref_scenes.random_scene: sphere and triangle soups, every material kind, random integrator
+    parameters): still bit for bit.  400 seeds were run once during development (all identical); 24 here"""
+    gauss = olibm.gaussian_filter(0.5, libm=True)
+    for seed in range(24):
+        sb, kw = RS.random_scene(gauss, seed)
+        desc = sb.desc()
+        p = RS.params(kw)
+        rs = ref.RefScene(desc); rfilm, rsmp = rs.render(p); rs.close()
+        osc = olibm.OracleScene(desc, libm=True)
+        ofilm, osmp, _ = osc.render(p, threads=1, sampler="sfmt", want_samples=True); osc.close()
+        assert np.array_equal(rsmp.view(np.uint32), osmp.view(np.uint32)), (seed, kw)
+        assert np.array_equal(rfilm.view(np.uint32), ofilm.view(np.uint32)), (seed, kw)
+
+
 def test_parity_build_stays_within_tolerance_of_the_reference(ref, oracle, olibm):
     """the parity oracle (phip_fmath.h transcendentals -- what the GPU is compared with) against the reference on the
     reference's own sample stream: identical control flow, differences of a few ulp in a minority of the samples"""
