@@ -129,15 +129,38 @@ def textures(gauss, mip):
     return sb
 
 
-def random_scene(gauss, seed, res=(24, 16)):
+def box_mip(key, image, kind, **kw):
+    """stand-in for the reference-built pyramids where the reference is not needed (GPU-vs-oracle fuzz): box-filtered levels"""
+    return S.mip_pyramid(np.ascontiguousarray(image, np.float32))
+
+
+def random_scene(gauss, seed, res=(24, 16), mip=None):
     """fuzz input: random spheres (smooth / flat, with texture coordinates) and a triangle soup, 2-5 random materials of every
     kind, 1-2 quad lights, sometimes a constant environment, random camera.  Returns (SceneBuilder, render parameters)."""
     rng = np.random.default_rng(seed)
     sb = S.SceneBuilder()
-    if rng.random() < 0.4:
+    env = rng.random()
+    if mip is not None and env < 0.25:      # envmap (rotated), with its MIP pyramid: directly visible pixels are EWA-filtered
+        w = int(rng.integers(8, 40)); h = int(rng.integers(4, 24))
+        lv = mip("env%d" % seed, half(rng.uniform(0.0, 2.0, (h, w, 3)) * rng.uniform(0.2, 3.0)), kind="envmap")
+        sb.envmap(lv[0], scale=float(rng.uniform(0.3, 2.0)), to_world=_rot(rng.normal(size=3), float(rng.uniform(0, 360))),
+                  sampling_weight=float(rng.uniform(0.3, 2)), pyramid=lv)
+    elif env < 0.5:
         sb.constant(tuple(rng.uniform(0.1, 1.0, 3)), sampling_weight=float(rng.uniform(0.3, 2)))
     mats = []
-    for i in range(rng.integers(2, 6)):
+    if mip is not None:                     # bitmap reflectance textures with random lookup parameters
+        for i in range(rng.integers(1, 4)):
+            w = int(rng.integers(3, 50)); h = int(rng.integers(3, 50))
+            wraps = ["repeat", "clamp", "mirror", "zero", "one"]
+            kw = dict(wrap=wraps[rng.integers(5)], wrap_v=wraps[rng.integers(5)], filter_type=["nearest", "bilinear", "trilinear", "ewa"][rng.integers(4)],
+                      max_anisotropy=float(rng.uniform(1.0, 20.0)))
+            lv = mip("tex%d_%d" % (seed, i), half(rng.uniform(0.0, 1.0, (h, w, 3))), kind="texture", wrap_u=kw["wrap"], wrap_v=kw["wrap_v"],
+                     filter_type=kw["filter_type"], max_anisotropy=kw["max_anisotropy"])
+            t = sb.bitmap(lv[0], pyramid=lv, uscale=float(rng.uniform(0.3, 8)), vscale=float(rng.uniform(0.3, 8)),
+                          uoffset=float(rng.uniform(-1, 1)), voffset=float(rng.uniform(-1, 1)), **kw)
+            d = sb.diffuse(texture=t)
+            mats.append(d if rng.random() < 0.5 else sb.twosided(d))
+    for i in range(rng.integers(1 if mats else 2, 6)):
         t = rng.integers(0, 5)
         if t == 0:
             m = sb.diffuse(tuple(rng.uniform(0, 0.9, 3)))

@@ -433,7 +433,7 @@ def test_random_scenes_fuzz_against_the_oracle(gpu, oracle, gauss):
     worst = 1.0
     n_scenes = int(os.environ.get("PHIP_FUZZ_SCENES", "60"))         # 1500 were run once during development: all bit-identical
     for seed in range(n_scenes):
-        sb, kw = RS.random_scene(gauss, seed, res=(48, 32))
+        sb, kw = RS.random_scene(gauss, seed, res=(48, 32), mip=RS.box_mip)
         desc = sb.desc()
         if kw.get("integrator") == A.PHIP_INTEGRATOR_DIRECT:
             integ = DirectHIP(emitterSamples=kw["emitter_samples"], bsdfSamples=kw["bsdf_samples"], strictNormals=bool(kw["strict_normals"]))
