@@ -75,6 +75,168 @@ PM_FN float pm_frexpf(float x, int *e) {
     return pm_from_bits(u);
 }
 
+#if !defined(PHIP_FMATH_CEPHES)
+/* ======================================================================================
+ *  Default implementation: every function is evaluated in DOUBLE precision from IEEE basic operations (argument
+ *  reduction with split constants, Taylor / artanh series of 1/n! and 1/n coefficients taken far enough that the
+ *  truncation error is < 1e-17) and rounded to float once.  The result is the correctly rounded float value except when
+ *  the exact value lies within ~1e-9 ulp of a rounding boundary -- i.e. what `(float) ::exp((double) x)` (the reference's
+ *  math::fastexp / fastlog on Linux x86-64, core/math.h:175-199) returns, and what glibc's sinf / cosf / expf / logf /
+ *  acosf / atan2f return in all but ~0.1-1 % of the calls (their error bounds are 0.50-0.56 ulp).  Host and device evaluate the
+ *  same IEEE double operations in the same order (-ffp-contract=off): bit-identical results, as before.
+ * ====================================================================================== */
+PM_FN double pmd_from_bits(uint64_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long) u);
+#else
+    double f; memcpy(&f, &u, 8); return f;
+#endif
+}
+PM_FN uint64_t pmd_to_bits(double f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t) __double_as_longlong(f);
+#else
+    uint64_t u; memcpy(&u, &f, 8); return u;
+#endif
+}
+
+#define PMD_PI      3.14159265358979311600e+00
+#define PMD_PI_2    1.57079632679489655800e+00
+#define PMD_PI_4    7.85398163397448278999e-01
+
+/* sin(x), cos(x) for a double argument of float magnitude (|x| < 2^31 * pi/2; beyond that the quadrant is still right
+   modulo the precision of x itself) */
+PM_FN void pmd_sincos(double x, double *s, double *c) {
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;      /* 33 significant bits: k * PIO2_HI is exact for |k| < 2^20 */
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double PIO2_LO2 = 3.52155986518361559378e-27;
+    double kd = floor(x * INV_PIO2 + 0.5);
+    double r = ((x - kd * PIO2_HI) - kd * PIO2_LO) - kd * PIO2_LO2;
+    double q4 = kd - 4.0 * floor(kd * 0.25);                  /* kd mod 4, exact */
+    int q = (int) q4;
+    double z = r * r;
+    double ps = r + r * z * (-1.66666666666666657415e-01 + z * (8.33333333333333321769e-03 + z * (-1.98412698412698412526e-04
+              + z * (2.75573192239858925110e-06 + z * (-2.50521083854417202239e-08 + z * (1.60590438368216133409e-10
+              + z * (-7.64716373181981640551e-13 + z * 2.81145725434552059811e-15)))))));
+    double pc = 1.0 + z * (-5.00000000000000000000e-01 + z * (4.16666666666666643537e-02 + z * (-1.38888888888888894189e-03
+              + z * (2.48015873015873015658e-05 + z * (-2.75573192239858882758e-07 + z * (2.08767569878681001866e-09
+              + z * (-1.14707455977297245073e-11 + z * 4.77947733238738525345e-14)))))));
+    if (q == 0) { *s = ps; *c = pc; }
+    else if (q == 1) { *s = pc; *c = -ps; }
+    else if (q == 2) { *s = -ps; *c = -pc; }
+    else { *s = -pc; *c = ps; }
+}
+
+PM_FN double pmd_exp(double x) {                               /* |x| < 700 */
+    const double INV_LN2 = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;          /* 32 significant bits */
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double kd = floor(x * INV_LN2 + 0.5);
+    double r = (x - kd * LN2_HI) - kd * LN2_LO;
+    double p = 1.0 + r + r * r * (5.00000000000000000000e-01 + r * (1.66666666666666657415e-01 + r * (4.16666666666666643537e-02
+             + r * (8.33333333333333321769e-03 + r * (1.38888888888888894189e-03 + r * (1.98412698412698412526e-04
+             + r * (2.48015873015873015658e-05 + r * (2.75573192239858925110e-06 + r * (2.75573192239858882758e-07
+             + r * (2.50521083854417202239e-08 + r * (2.08767569878681001866e-09 + r * (1.60590438368216133409e-10
+             + r * 1.14707455977297245073e-11))))))))))));
+    int k = (int) kd;
+    return p * pmd_from_bits((uint64_t) (k + 1023) << 52);     /* 2^k, k in [-1010, 1010] */
+}
+
+PM_FN double pmd_log(double x) {                               /* finite x > 0, normal double */
+    const double LN2 = 6.93147180559945286227e-01;
+    uint64_t u = pmd_to_bits(x);
+    int e = (int) ((u >> 52) & 0x7ff) - 1023;
+    double m = pmd_from_bits((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);     /* [1, 2) */
+    if (m > 1.41421356237309514547e+00) { m *= 0.5; e += 1; }
+    double t = (m - 1.0) / (m + 1.0), z = t * t;               /* log m = 2 artanh t, |t| <= 0.1716 */
+    double lm = t * (2.00000000000000000000e+00 + z * (6.66666666666666629659e-01 + z * (4.00000000000000022204e-01
+              + z * (2.85714285714285698425e-01 + z * (2.22222222222222209886e-01 + z * (1.81818181818181823228e-01
+              + z * (1.53846153846153854694e-01 + z * (1.33333333333333331483e-01 + z * (1.17647058823529410132e-01
+              + z * (1.05263157894736836262e-01 + z * (9.52380952380952328085e-02 + z * 8.69565217391304323691e-02)))))))))));
+    return (double) e * LN2 + lm;
+}
+
+PM_FN double pmd_atan(double xx) {
+    double x = fabs(xx), y;
+    if (x > 2.41421356237309492343e+00) { y = PMD_PI_2; x = -(1.0 / x); }             /* tan(3 pi / 8) */
+    else if (x > 4.14213562373095034329e-01) { y = PMD_PI_4; x = (x - 1.0) / (x + 1.0); }   /* tan(pi / 8) */
+    else y = 0.0;
+    double z = x * x;                                         /* |x| <= 0.4143: 22 terms of the alternating series */
+    double p = 1.00000000000000000000e+00 + z * (-3.33333333333333314830e-01 + z * (2.00000000000000011102e-01 + z * (-1.42857142857142849213e-01
+             + z * (1.11111111111111104943e-01 + z * (-9.09090909090909116141e-02 + z * (7.69230769230769273470e-02 + z * (-6.66666666666666657415e-02
+             + z * (5.88235294117647050660e-02 + z * (-5.26315789473684181310e-02 + z * (4.76190476190476164042e-02 + z * (-4.34782608695652161845e-02
+             + z * (4.00000000000000008327e-02 + z * (-3.70370370370370349811e-02 + z * (3.44827586206896546939e-02 + z * (-3.22580645161290313627e-02
+             + z * (3.03030303030303038714e-02 + z * (-2.85714285714285705364e-02 + z * (2.70270270270270285273e-02 + z * (-2.56410256410256401360e-02
+             + z * (2.43902439024390252365e-02 + z * -2.32558139534883717703e-02))))))))))))))))))));
+    y += x * p;
+    return xx < 0.0 ? -y : y;
+}
+
+PM_FN double pmd_atan2(double y, double x) {                   /* finite, not both zero */
+    if (x == 0.0) return y > 0.0 ? PMD_PI_2 : -PMD_PI_2;
+    double z = pmd_atan(y / x);
+    if (x < 0.0) z += (y < 0.0) ? -PMD_PI : PMD_PI;
+    return z;
+}
+
+PM_FN void pm_sincosf(float xx, float *s, float *c) {
+    double sd, cd;
+    pmd_sincos((double) xx, &sd, &cd);
+    *s = (float) sd; *c = (float) cd;
+}
+
+PM_FN float pm_expf(float x) {
+    if (x != x) return x;
+    if (x > 89.0f) return pm_from_bits(0x7f800000u);
+    if (x < -104.0f) return 0.0f;
+    return (float) pmd_exp((double) x);                        /* the cast rounds into the subnormal range / to infinity */
+}
+
+PM_FN float pm_logf(float xx) {
+    if (xx != xx) return xx;
+    if (xx < 0.0f) return pm_from_bits(0x7fc00000u);
+    if (xx == 0.0f) return pm_from_bits(0xff800000u);
+    if (pm_to_bits(xx) == 0x7f800000u) return xx;
+    return (float) pmd_log((double) xx);                       /* float subnormals are normal doubles */
+}
+
+/* x > 0 only (the path calls it with a base in (0,1]) */
+PM_FN float pm_powf(float x, float y) {
+    if (x == 0.0f) return y > 0.0f ? 0.0f : 1.0f;
+    double t = (double) y * pmd_log((double) x);
+    if (t > 89.0) return pm_from_bits(0x7f800000u);
+    if (t < -104.0) return 0.0f;
+    return (float) pmd_exp(t);
+}
+
+PM_FN float pm_acosf(float x) {
+    if (x < -1.0f || x > 1.0f || x != x) return pm_from_bits(0x7fc00000u);
+    double xd = (double) x;
+    if (xd == 1.0) return 0.0f;
+    return (float) pmd_atan2(sqrt((1.0 - xd) * (1.0 + xd)), xd);     /* (1 - x) and (1 + x) are exact in double */
+}
+
+PM_FN float pm_atanf(float xx) {
+    if (xx != xx) return xx;
+    return (float) pmd_atan((double) xx);
+}
+
+PM_FN float pm_atan2f(float y, float x) {
+    if (x != x || y != y) return pm_from_bits(0x7fc00000u);
+    if (x == 0.0f && y == 0.0f) return 0.0f;
+    if (y == 0.0f) return x > 0.0f ? 0.0f : PM_PI;
+    return (float) pmd_atan2((double) y, (double) x);
+}
+
+PM_FN float pm_tanf(float xx) {
+    double sd, cd;
+    pmd_sincos((double) xx, &sd, &cd);
+    return (float) (sd / cd);
+}
+
+#else /* PHIP_FMATH_CEPHES: the round-1 implementation, single-precision Cephes-style polynomials, <= ~4 ulp (kept for A/B) */
+
 /* sin and cos, |x| <= 8192 (larger arguments lose accuracy but stay finite) */
 PM_FN void pm_sincosf(float xx, float *s, float *c) {
     const float DP1 = 0.78515625f;
@@ -211,5 +373,7 @@ PM_FN float pm_tanf(float xx) {
     if (j & 2) y = -1.0f / y;
     return xx < 0.0f ? -y : y;
 }
+
+#endif /* PHIP_FMATH_CEPHES */
 
 #endif /* PHIP_FMATH_H */

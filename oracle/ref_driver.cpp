@@ -39,6 +39,7 @@ namespace {
 
 std::string g_err;
 bool g_init = false;
+int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream) */
 
 struct RefScene {
     ref<Scene> scene;
@@ -46,6 +47,21 @@ struct RefScene {
     std::vector<ref<Bitmap> > keep;
     int width, height;
 };
+
+/* the scene's sampler for one render: `independent`, or the parity stream (smooth-BSDF scenes only, see ctr_sampler.cpp) */
+Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
+    Properties smp(g_samplerKind == 1 ? "ctr" : "independent");
+    smp.setSize("sampleCount", (size_t) p->spp);
+    if (g_samplerKind == 1) {
+        smp.setInteger("seed", (int) p->seed);
+        smp.setInteger("cropWidth", scene->getFilm()->getCropSize().x);
+        smp.setString("mode", p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path");
+        smp.setSize("emitterSamples", (size_t) std::max(0, p->emitter_samples)); smp.setSize("bsdfSamples", (size_t) std::max(0, p->bsdf_samples));
+    }
+    Sampler *s = static_cast<Sampler *>(PluginManager::getInstance()->createObject(MTS_CLASS(Sampler), smp));
+    s->configure();
+    return s;
+}
 
 Spectrum rgb(const float *v) { Spectrum s; s.fromLinearRGB(v[0], v[1], v[2]); return s; }
 
@@ -165,6 +181,9 @@ int ref_init(void) {
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+
+/* 0 = `independent` (default), 1 = the counter-based parity stream for the following renders */
+void ref_set_sampler(int kind) { g_samplerKind = kind; }
 
 /* stops the Scheduler's worker threads (they would keep the process alive at exit) */
 void ref_shutdown(void) {
@@ -307,9 +326,7 @@ int ref_render(void *h, const phip_render_params *p, float *out_samples, float *
         ref<SamplingIntegrator> integ = static_cast<SamplingIntegrator *>(create(MTS_CLASS(Integrator), ip));
         integ->configure();
 
-        Properties smp("independent"); smp.setSize("sampleCount", (size_t) p->spp);
-        ref<Sampler> parent = static_cast<Sampler *>(create(MTS_CLASS(Sampler), smp));
-        parent->configure();
+        ref<Sampler> parent = makeSampler(scene, p);
         integ->configureSampler(scene, parent);          /* requests the sample arrays of `direct` */
         ref<Sampler> sampler = parent->clone();          /* worker 0's sampler */
 
@@ -392,9 +409,7 @@ int ref_render_job_plugin(void *h, const phip_render_params *p, const char *inte
         ip.setBoolean("strictNormals", p->strict_normals != 0); ip.setBoolean("hideEmitters", p->hide_emitters != 0);
         ref<Integrator> integ = static_cast<Integrator *>(create(MTS_CLASS(Integrator), ip));
         integ->configure();
-        Properties smp("independent"); smp.setSize("sampleCount", (size_t) p->spp);
-        ref<Sampler> sampler = static_cast<Sampler *>(create(MTS_CLASS(Sampler), smp));
-        sampler->configure();
+        ref<Sampler> sampler = makeSampler(scene, p);
         integ->configureSampler(scene, sampler);
         scene->setIntegrator(integ);
         scene->setSampler(sampler);

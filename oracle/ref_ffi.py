@@ -70,6 +70,7 @@ def lib():
     L.ref_bsdf_eval_pdf.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp]
     L.ref_sample_emitter.argtypes = [C.c_void_p, fp, fp, C.c_size_t, fp, fp, fp, fp, fp, fp]
     L.ref_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, fp]
+    L.ref_set_sampler.argtypes = [C.c_int]
     L.ref_mip_build.restype = C.c_void_p
     L.ref_mip_build.argtypes = [C.c_int, fp, u32, u32, u32, u32, u32, C.c_float]
     L.ref_mip_levels.argtypes = [C.c_void_p]
@@ -109,16 +110,20 @@ class RefScene:
         if rc != 0:
             raise RuntimeError(what + ": " + self.L.ref_last_error().decode())
 
-    def render(self, params, want_samples=True):
+    def render(self, params, want_samples=True, sampler="independent"):
+        """sampler="ctr": the reference's integrator fed with the counter-based parity stream (ref_glue/ctr_sampler.cpp;
+        only valid for scenes whose BSDFs all have a smooth component)"""
+        self.L.ref_set_sampler(1 if sampler == "ctr" else 0)
         film = np.zeros((self.height, self.width, 5), np.float32)
         samples = np.zeros((self.height, self.width, params.spp, 4), np.float32) if want_samples else None
         self._check(self.L.ref_render(self.h, C.byref(params), _fp(samples) if want_samples else None, _fp(film)), "ref_render")
         return film, samples
 
-    def render_job(self, params, threads=None, want_image=True, plugin=None):
+    def render_job(self, params, threads=None, want_image=True, plugin=None, sampler="independent"):
         """the reference's complete multi-threaded render (RenderJob on the Scheduler); returns (rgb or None, seconds).
         plugin="path_hip" / "direct_hip": the same job with the product's plugin shim as the scene's integrator."""
         threads = threads or os.cpu_count() or 1
+        self.L.ref_set_sampler(1 if sampler == "ctr" else 0)
         rgb = np.zeros((self.height, self.width, 3), np.float32) if want_image else None
         sec = C.c_double()
         self._check(self.L.ref_render_job_plugin(self.h, C.byref(params), plugin.encode() if plugin else None, threads,

@@ -51,14 +51,30 @@ def test_accuracy_vs_libm(oracle, name):
     else:
         ref = REF[name](a32.astype(np.float64))
     err = ulp_err(got, ref)
-    if name in ("sin", "cos"):
-        # relative accuracy degrades near the zeros of sin/cos; bound the absolute error there
-        absok = np.abs(got.astype(np.float64) - ref) < 2.5e-7
-        assert (absok | (err <= 4)).all(), float(err[~absok].max())
-    elif name == "pow":
-        assert err.max() <= 64, err.max()      # exp(y*log(x)) -- only used as a Newton start value
-    else:
-        assert err.max() <= 4, (name, float(err.max()))
+    # evaluated in double precision and rounded once: the correctly rounded float result
+    assert err.max() <= 0.5 + 1e-6, (name, float(err.max()))
+    assert (got == ref.astype(np.float32)).all(), name
+
+
+def test_glibc_is_what_differs_from_the_reference(oracle):
+    """the reference calls glibc's float functions, which are within 1 ulp but NOT always correctly rounded (measured
+    here: ~1 % of sinf / cosf calls, ~8 % of acosf, ~16 % of atan2f): these calls are the only place where the parity build
+    (phip_fmath.h, shared bit for bit with the GPU) and the reference differ -- tests/test_ref_pin.py pins everything else"""
+    libm = C.CDLL("libm.so.6")
+    rng = np.random.default_rng(2)
+    n = 20000
+    for name, op, a in (("sinf", 0, rng.uniform(-0.79, 2.36, n)), ("cosf", 1, rng.uniform(-0.79, 2.36, n)), ("expf", 2, rng.uniform(-20, 5, n)),
+                        ("logf", 3, rng.uniform(1e-6, 3, n)), ("acosf", 4, rng.uniform(-1, 1, n))):
+        f = getattr(libm, name); f.restype = C.c_float; f.argtypes = [C.c_float]
+        a32 = a.astype(np.float32)
+        g = np.array([f(float(x)) for x in a32], np.float32)
+        mine = run(oracle.lib().oracle_fmath, op, a32)
+        exact = {"sinf": np.sin, "cosf": np.cos, "expf": np.exp, "logf": np.log, "acosf": np.arccos}[name](a32.astype(np.float64))
+        assert (mine == exact.astype(np.float32)).all()
+        assert ulp_err(g, exact).max() <= 1.0                  # glibc: within one ulp ...
+        mis = (g != mine).mean()
+        print("%s: glibc differs from the correctly rounded result in %.2f %% of the calls" % (name, 100 * mis))
+        assert mis < 0.2                                       # ... and mostly, not always, correctly rounded
 
 
 @pytest.mark.parametrize("name", list(OPS))
