@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""BASELINE configs C2 / C3 at full size: path_hip on the GPU against Mitsuba 0.6 itself (oracle/_ref, all host cores,
+parity-stream sampler) -- developed images, relative L2.  Usage (on a GPU box): python tools/fullsize_vs_reference.py out.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mitsuba_amd import _abi as A, _ffi, scene as S          # noqa: E402
+from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm    # noqa: E402
+from oracle import ref_ffi as R                               # noqa: E402
+
+gauss = _ffi.gaussian_filter(0.5)
+out = {}
+for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1024, 1024, 256, -1),
+                                   ("C3 atrium 1920x1080x64", S.atrium, 1920, 1080, 64, 8)):
+    if len(sys.argv) > 2 and sys.argv[2] not in name:
+        continue
+    desc = build(w, h, gauss).desc()
+    gs = Scene(desc)
+    film = HDRFilm(w, h)
+    integ = PathHIP(maxDepth=md)
+    integ.render(gs, film, spp)                               # warm-up
+    film = HDRFilm(w, h)
+    t = time.time(); assert integ.render(gs, film, spp); tg = time.time() - t
+    g = film.develop()
+    rs = R.RefScene(desc)
+    cpu, sec = rs.render_job(A.default_render_params(spp=spp, max_depth=md), sampler="ctr")
+    rel = float(np.linalg.norm(g - cpu) / np.linalg.norm(cpu))
+    big = float((np.abs(g - cpu) > 1e-3 * np.maximum(1.0, np.abs(cpu))).any(-1).mean())
+    out[name] = {"gpu_seconds": round(tg, 3), "reference_seconds": round(sec, 1), "reference_threads": os.cpu_count(), "rel_l2": rel,
+                 "pixels_differing_by_more_than_1e-3": big, "speedup": round(sec / tg, 1)}
+    print(name, out[name], flush=True)
+    rs.close(); gs.close()
+json.dump(out, open(sys.argv[1], "w"), indent=1)
