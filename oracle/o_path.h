@@ -56,6 +56,7 @@ inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray
         if (depth == 1 && rxDirection && ryDirection && scene.usesRayDifferentials(bsdf))
             Scene::computePartials(its, ray.o, *rxDirection, *ryDirection);
         bsdfs.its = &its;
+        if (pc && bsdf.smooth && depth <= 32) pc->smoothMask |= 1u << (depth - 1);
 
         if (scene.isEmitter(its) && emittedRadiance && (!ip.hideEmitters || scattered))
             Li += throughput * scene.Le(its, -ray.d);

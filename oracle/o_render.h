@@ -239,9 +239,10 @@ struct RenderResult {
 
 /*
  * Renders the crop window into film (cropH*cropW*5 floats).  If sampleOut != nullptr it
- * receives cropW*cropH*spp (R,G,B,alpha) per-sample radiance values ordered [y][x][sample].
+ * receives cropW*cropH*spp (R,G,B,alpha) per-sample radiance values ordered [y][x][sample]; maskOut (optional, same order): per
+ * sample, bit d-1 = the BSDF at path vertex d is smooth (what a parity-stream sampler for the reference needs to know).
  */
-inline RenderResult render(const Scene &scene, const RenderParams &rp, float *filmOut, float *sampleOut) {
+inline RenderResult render(const Scene &scene, const RenderParams &rp, float *filmOut, float *sampleOut, uint32_t *maskOut = nullptr) {
     const phip_film &f = scene.film;
     PerspectiveCamera cam; cam.configure(scene.camera, f);
     Filter filter; filter.configure(f);
@@ -288,10 +289,12 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
                     rx = ray.d + (rx - ray.d) * diffScaleFactor;
                     ry = ray.d + (ry - ray.d) * diffScaleFactor;
                     Float alpha;
+                    pc.smoothMask = 0;
                     Spectrum spec = rp.direct ? directLi(scene, rp.dp, ray, smp, alpha, &pc, rx, ry)
                                               : pathLi(scene, rp.ip, ray, smp, alpha, &pc, &rx, &ry);
                     Float temp[5] = { spec[0], spec[1], spec[2], alpha, 1.0f };
                     if (!blk.put(samplePos, temp)) pc.invalidSamples++;
+                    if (maskOut) maskOut[((size_t) py * f.crop_width + px) * rp.spp + j] = pc.smoothMask;
                     if (sampleOut) {
                         size_t si = (((size_t) py * f.crop_width + px) * rp.spp + j) * 4;
                         sampleOut[si] = spec[0]; sampleOut[si + 1] = spec[1]; sampleOut[si + 2] = spec[2]; sampleOut[si + 3] = alpha;

@@ -193,6 +193,7 @@ struct SampleSource {
 
 struct PathCounters {
     uint64_t closestRays = 0, shadowRays = 0, pathVertices = 0, samples = 0, invalidSamples = 0;
+    uint32_t smoothMask = 0;     /* of the sample being evaluated: bit d-1 = the BSDF at path vertex d has a smooth component (d <= 32) */
     TraversalCounters closest, shadow;
     void add(const PathCounters &o) {
         closestRays += o.closestRays; shadowRays += o.shadowRays; pathVertices += o.pathVertices;

@@ -46,8 +46,14 @@ void *oracle_scene_create(const phip_scene_desc *desc) {
 void oracle_scene_destroy(void *scene) { delete static_cast<Scene *>(scene); }
 
 /* sampler_mode: 0 = ctr parity stream, 1 = per-worker SFMT19937 streams like `independent` */
+int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
+                        float *out_rgbaw, float *out_samples_rgba, uint32_t *out_smooth_masks, phip_stats *stats);
 int oracle_render(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
                   float *out_rgbaw, float *out_samples_rgba, phip_stats *stats) {
+    return oracle_render_masks(scene_, p, threads, sampler_mode, out_rgbaw, out_samples_rgba, nullptr, stats);
+}
+int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
+                        float *out_rgbaw, float *out_samples_rgba, uint32_t *out_smooth_masks, phip_stats *stats) {
     try {
         const Scene &scene = *static_cast<Scene *>(scene_);
         RenderParams rp;
@@ -71,7 +77,7 @@ int oracle_render(void *scene_, const phip_render_params *p, int threads, int sa
         if (scene.envmap.valid() && scene.envmap.nLevels <= 1 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
             throw std::runtime_error("envmap without MIP levels: directly visible background needs the filtered (EWA) lookup: "
                                      "pass the pyramid, render with hideEmitters or set PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
-        RenderResult rr = render(scene, rp, out_rgbaw, out_samples_rgba);
+        RenderResult rr = render(scene, rp, out_rgbaw, out_samples_rgba, out_smooth_masks);
         if (stats) {
             memset(stats, 0, sizeof(*stats));
             stats->samples = rr.counters.samples;

@@ -41,6 +41,7 @@ def lib(libm=False):
     L.oracle_scene_create.argtypes = [C.POINTER(A.phip_scene_desc)]
     L.oracle_scene_destroy.argtypes = [C.c_void_p]
     L.oracle_render.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), C.c_int, C.c_int, fp, fp, C.POINTER(A.phip_stats)]
+    L.oracle_render_masks.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), C.c_int, C.c_int, fp, fp, C.POINTER(C.c_uint32), C.POINTER(A.phip_stats)]
     L.oracle_trace.argtypes = [C.c_void_p, C.POINTER(A.phip_ray), C.c_size_t, C.POINTER(A.phip_hit), u8p, C.POINTER(A.phip_stats)]
     L.oracle_trace_bruteforce.argtypes = [C.c_void_p, C.POINTER(A.phip_ray), C.c_size_t, C.POINTER(A.phip_hit)]
     L.oracle_gaussian_filter.argtypes = [C.c_float, fp, fp]
@@ -110,6 +111,17 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("oracle_render: " + self.L.oracle_last_error().decode())
         return film, samples, st
+
+    def smooth_masks(self, params, threads=None):
+        """per sample ([y][x][sample], ctr stream): bit d-1 = the BSDF at path vertex d has a smooth component"""
+        threads = threads or os.cpu_count() or 1
+        film = np.zeros((self.height, self.width, 5), np.float32)
+        masks = np.zeros((self.height, self.width, params.spp), np.uint32)
+        st = A.phip_stats()
+        rc = self.L.oracle_render_masks(self.h, C.byref(params), threads, 0, _fp(film), None, masks.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st))
+        if rc != 0:
+            raise RuntimeError("oracle_render_masks: " + self.L.oracle_last_error().decode())
+        return masks
 
     def trace(self, rays, closest=True, shadow=False, bruteforce=False):
         n = len(rays)

@@ -40,6 +40,7 @@ namespace {
 std::string g_err;
 bool g_init = false;
 int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream) */
+const uint32_t *g_smoothMasks = NULL;   /* optional [pixel][sample] smooth-vertex masks for the parity sampler (scenes with dielectrics) */
 
 struct RefScene {
     ref<Scene> scene;
@@ -57,6 +58,7 @@ Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
         smp.setInteger("cropWidth", scene->getFilm()->getCropSize().x);
         smp.setString("mode", p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path");
         smp.setSize("emitterSamples", (size_t) std::max(0, p->emitter_samples)); smp.setSize("bsdfSamples", (size_t) std::max(0, p->bsdf_samples));
+        if (g_smoothMasks) { Properties::Data d; d.ptr = (uint8_t *) g_smoothMasks; d.size = 0; smp.setData("smoothMasks", d); }
     }
     Sampler *s = static_cast<Sampler *>(PluginManager::getInstance()->createObject(MTS_CLASS(Sampler), smp));
     s->configure();
@@ -184,6 +186,7 @@ int ref_init(void) {
 
 /* 0 = `independent` (default), 1 = the counter-based parity stream for the following renders */
 void ref_set_sampler(int kind) { g_samplerKind = kind; }
+void ref_set_smooth_masks(const uint32_t *masks) { g_smoothMasks = masks; }
 
 /* stops the Scheduler's worker threads (they would keep the process alive at exit) */
 void ref_shutdown(void) {

@@ -81,25 +81,31 @@ def check_scene(ref, name, desc):
 def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss):
     """BASELINE.json north_star, literally: "output radiance matches the reference CPU `path` integrator on the same
     scene / seed ... <= 1e-3 relative L2 at equal spp".  The reference's own `path` (and `direct`) run on the host with the
-    parity stream (oracle/ref_glue/ctr_sampler.cpp: the reference consumes the random numbers the GPU consumes; scenes with
-    smooth BSDFs only -- the Cornell box and the atrium of configs C1-C3, the texture scene); the GPU renders the same scene
-    through the C ABI.  Compared sample by sample: the two differ only in the transcendentals (libm there, phip_fmath.h
+    parity stream (oracle/ref_glue/ctr_sampler.cpp: the reference consumes the random numbers the GPU consumes); the GPU
+    renders the same scene through the C ABI.  Compared sample by sample: the two differ only in the transcendentals (libm there, phip_fmath.h
     here, <= 4 ulp), so most samples agree to the last bits, the rest to ~1e-6 -- except the handful of paths in which such
     an ulp flips a discrete decision (a Russian-roulette test, a CDF bin, a tie) and the path goes elsewhere: those are
     counted.  Path tracing is chaotic in exactly this sense; the reference compiled with another libm would differ from
     itself the same way."""
     import ref_scenes as RS
     from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+    oracle.build(libm=True)
     for name, desc, spp, bar in (("cornell 128x128", S.cornell_box(128, 128, gauss).desc(), 64, 1e-3),
                                  ("textures 48x32", RS.textures(gauss, live_mip(ref)).desc(), 64, 1e-3),
-                                 ("atrium 160x90", S.atrium(160, 90, gauss, detail=0.5).desc(), 32, 1e-2)):
+                                 ("atrium 160x90", S.atrium(160, 90, gauss, detail=0.5).desc(), 32, 1e-3),
+                                 ("glass room 160x90", S.glass_room(160, 90, gauss, detail=0.5).desc(), 32, 1e-3),
+                                 ("material zoo 32x32", RS.zoo(gauss, None).desc(), 64, 1e-3),
+                                 ("envmap 40x24", RS.envmap(gauss, live_mip(ref)).desc(), 64, 1e-3)):
         rs = ref.RefScene(desc)
         gs = Scene(desc)
+        osc = oracle.OracleScene(desc, libm=True)
         for what, Integ, kw, rkw in (("path", PathHIP, dict(maxDepth=8), dict(max_depth=8)),
                                      ("direct", DirectHIP, dict(emitterSamples=2, bsdfSamples=2),
                                       dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2))):
             p = A.default_render_params(spp=spp, block_size=256, **rkw)
-            rfilm, rsmp = rs.render(p, sampler="ctr")                       # the reference's Li, sample by sample
+            # which vertices have a smooth BSDF (the reference skips the emitter sample at the others, path.cpp:174): from the oracle
+            masks = osc.smooth_masks(p) if what == "path" else None
+            rfilm, rsmp = rs.render(p, sampler="ctr", smooth_masks=masks)   # the reference's Li, sample by sample
             integ = Integ(**kw)
             film = HDRFilm(gs.width, gs.height)
             assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
@@ -114,7 +120,7 @@ def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss)
                   % (name, what, spp, what, 100 * identical.mean(), int((~close).sum()), close.size, r))
             assert (~close).mean() < 2e-3
             assert r <= bar
-        rs.close(); gs.close()
+        rs.close(); gs.close(); osc.close()
 
 
 def test_baseline_config_c1_against_the_reference(phip, ref, gauss):

@@ -52,27 +52,27 @@ def test_oracle_reproduces_the_reference_bit_for_bit(ref, olibm, name, build, kw
     rs.close(); osc.close()
 
 
-SMOOTH_CASES = [c for c in RS.CASES if c[0].startswith(("cornell", "atrium", "textures"))]     # no dielectric in these
-
-
-@pytest.mark.parametrize("name,build,kw", SMOOTH_CASES, ids=[c[0] for c in SMOOTH_CASES])
+@pytest.mark.parametrize("name,build,kw", RS.CASES, ids=[c[0] for c in RS.CASES])
 def test_reference_on_the_parity_stream(ref, oracle, olibm, name, build, kw):
     """the counter-based parity stream itself, validated on the real integrators: the reference's `path` / `direct` fed by
     oracle/ref_glue/ctr_sampler.cpp (a Sampler plugin for the reference that reproduces pcg4d(pixel, sample, block, seed);
-    valid for scenes whose BSDFs are all smooth) consume exactly the numbers the oracle's -- and hence the GPU's -- ctr
-    renders consume: bit-identical with the libm build, and the parity build (= the GPU, bit for bit) is within the
-    north-star tolerance of the REFERENCE ON THE SAME SAMPLES by four orders of magnitude"""
+    which path vertices have a smooth BSDF -- the integrator skips the emitter sample otherwise, path.cpp:174 -- comes from
+    the oracle's run on the same stream) consume exactly the numbers the oracle's -- and hence the GPU's -- ctr renders
+    consume: bit-identical with the libm build, and the parity build (= the GPU, bit for bit) is within the north-star
+    tolerance of the REFERENCE ON THE SAME SAMPLES by orders of magnitude"""
     gauss = olibm.gaussian_filter(0.5, libm=True)
     desc = build(gauss, live_mip(ref)).desc()
     p = RS.params(kw)
+    osc = olibm.OracleScene(desc, libm=True)
+    masks = osc.smooth_masks(p, threads=1)
     rs = ref.RefScene(desc)
-    rfilm, rsmp = rs.render(p, sampler="ctr")
-    ofilm, osmp, _ = olibm.OracleScene(desc, libm=True).render(p, threads=1, sampler="ctr", want_samples=True)
+    rfilm, rsmp = rs.render(p, sampler="ctr", smooth_masks=masks)
+    ofilm, osmp, _ = osc.render(p, threads=1, sampler="ctr", want_samples=True)
     assert np.array_equal(rsmp.view(np.uint32), osmp.view(np.uint32))
     assert np.array_equal(rfilm.view(np.uint32), ofilm.view(np.uint32))
     pfilm, psmp, _ = oracle.OracleScene(desc).render(p, threads=1, sampler="ctr", want_samples=True)
     rel = np.linalg.norm(psmp - rsmp) / np.linalg.norm(rsmp)
-    assert rel < 1e-4, rel                                  # measured: 0 .. 3e-5 (atrium: one path takes another branch)
+    assert rel < 1e-4, rel                                  # measured: 0 .. 1e-6
     rs.close()
 
 
