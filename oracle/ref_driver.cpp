@@ -40,6 +40,7 @@ namespace {
 std::string g_err;
 bool g_init = false;
 int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream) */
+int g_analyticRectangles = 0;   /* build exact rectangles as the reference's analytic `rectangle` shape instead of a two-triangle mesh */
 const uint32_t *g_smoothMasks = NULL;   /* optional [pixel][sample] smooth-vertex masks for the parity sampler (scenes with dielectrics) */
 
 struct RefScene {
@@ -91,6 +92,26 @@ ref<Bitmap> rgbBitmap(const float *texels, uint32_t w, uint32_t h) {
 
 const char *wrapName(uint32_t m) {
     switch (m) { case PHIP_WRAP_CLAMP: return "clamp"; case PHIP_WRAP_MIRROR: return "mirror"; case PHIP_WRAP_ZERO: return "zero"; case PHIP_WRAP_ONE: return "one"; default: return "repeat"; }
+}
+
+/* a flat-shaded two-triangle shape whose four vertices form an exact rectangle -> the reference's `rectangle` plugin, else NULL */
+Shape *makeRectangle(const phip_scene_desc &d, const phip_shape &s) {
+    if (s.n_triangles != 2 || s.n_vertices != 4 || (s.has_normals && d.normals) || (s.has_texcoords && d.texcoords)) return NULL;
+    Point p[4];
+    for (int i = 0; i < 4; ++i) { const float *q = d.positions + 3 * (size_t) (s.first_vertex + i); p[i] = Point(q[0], q[1], q[2]); }
+    const uint32_t *ix = d.indices + 3 * (size_t) s.first_triangle;
+    const Vector nTri = cross(p[ix[1] - s.first_vertex] - p[ix[0] - s.first_vertex], p[ix[2] - s.first_vertex] - p[ix[0] - s.first_vertex]);
+    Vector u = (p[1] - p[0]) * 0.5f, v = (p[3] - p[0]) * 0.5f;
+    const Float scale = std::max(u.length(), v.length());
+    if ((p[2] - (p[1] + (p[3] - p[0]))).length() > 1e-5f * scale) return NULL;                   /* not a parallelogram */
+    if (std::abs(dot(normalize(u), normalize(v))) > 1e-6f) return NULL;                          /* sheared: rectangle.cpp:91-92 refuses it */
+    if (dot(cross(u, v), nTri) < 0) std::swap(u, v);                                             /* the front side of the mesh */
+    const Vector n = normalize(cross(u, v));
+    const Point c = p[0] + (p[2] - p[0]) * 0.5f;
+    Matrix4x4 m(u.x, v.x, n.x, c.x,  u.y, v.y, n.y, c.y,  u.z, v.z, n.z, c.z,  0, 0, 0, 1);
+    Properties props("rectangle");
+    props.setTransform("toWorld", Transform(m));
+    return static_cast<Shape *>(PluginManager::getInstance()->createObject(MTS_CLASS(Shape), props));
 }
 
 BSDF *makeBSDF(RefScene *rs, const phip_scene_desc &d, uint32_t id) {
@@ -187,6 +208,7 @@ int ref_init(void) {
 /* 0 = `independent` (default), 1 = the counter-based parity stream for the following renders */
 void ref_set_sampler(int kind) { g_samplerKind = kind; }
 void ref_set_smooth_masks(const uint32_t *masks) { g_smoothMasks = masks; }
+void ref_set_analytic_rectangles(int on) { g_analyticRectangles = on; }
 
 /* stops the Scheduler's worker threads (they would keep the process alive at exit) */
 void ref_shutdown(void) {
@@ -260,6 +282,24 @@ void *ref_scene_create(const phip_scene_desc *dp, float gaussian_stddev) {
         for (uint32_t si = 0; si < d.n_shapes; ++si) {
             const phip_shape &s = d.shapes[si];
             const bool hasN = s.has_normals && d.normals, hasUV = s.has_texcoords && d.texcoords;
+            ref<Shape> analytic = g_analyticRectangles ? makeRectangle(d, s) : NULL;
+            if (analytic) {
+                /* an analytic shape of the reference (shapes/rectangle.cpp): its own intersection and sampling routines on the CPU;
+                   the plugin shim turns it into a mesh through Shape::createTriMesh (rectangle.cpp:170-203) */
+                attach(analytic, "", makeBSDF(rs, d, s.material));
+                if (s.emitter >= 0) {
+                    if ((uint32_t) s.emitter != nextArea) throw std::runtime_error("ref_driver: area emitters must be listed in shape order (Scene::getEmitters())");
+                    ++nextArea;
+                    const phip_emitter &e = d.emitters[s.emitter];
+                    Properties p("area"); p.setSpectrum("radiance", rgb(e.radiance)); p.setFloat("samplingWeight", e.sampling_weight);
+                    ref<Emitter> em = static_cast<Emitter *>(create(MTS_CLASS(Emitter), p));
+                    em->configure();
+                    attach(analytic, "", em);
+                }
+                analytic->configure();
+                attach(scene, "", analytic);
+                continue;
+            }
             ref<TriMesh> mesh = new TriMesh(formatString("shape%u", si), s.n_triangles, s.n_vertices, hasN, hasUV, false, false, !hasN);
             for (uint32_t v = 0; v < s.n_vertices; ++v) {
                 const float *p = d.positions + 3 * (size_t) (s.first_vertex + v);

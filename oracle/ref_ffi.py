@@ -72,6 +72,7 @@ def lib():
     L.ref_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, fp]
     L.ref_set_sampler.argtypes = [C.c_int]
     L.ref_set_smooth_masks.argtypes = [C.c_void_p]
+    L.ref_set_analytic_rectangles.argtypes = [C.c_int]
     L.ref_mip_build.restype = C.c_void_p
     L.ref_mip_build.argtypes = [C.c_int, fp, u32, u32, u32, u32, u32, C.c_float]
     L.ref_mip_levels.argtypes = [C.c_void_p]
@@ -94,10 +95,14 @@ def _fp(a):
 class RefScene:
     """The reference's Scene object built from a phip_scene_desc (environment emitters must be listed first)."""
 
-    def __init__(self, desc, stddev=0.5):
+    def __init__(self, desc, stddev=0.5, analytic_rectangles=False):
+        """analytic_rectangles: exact rectangles of the description become the reference's analytic `rectangle` shape (its
+        own intersection / sampling code on the CPU; the plugin shims see them through Shape::createTriMesh)"""
         self.L = lib()
         self.desc = desc
+        self.L.ref_set_analytic_rectangles(1 if analytic_rectangles else 0)
         self.h = self.L.ref_scene_create(C.byref(desc), stddev)
+        self.L.ref_set_analytic_rectangles(0)
         if not self.h:
             raise RuntimeError("ref_scene_create: " + self.L.ref_last_error().decode())
         self.width, self.height = desc.film.crop_width, desc.film.crop_height

@@ -140,3 +140,25 @@ def test_baseline_config_c1_against_the_reference(phip, ref, gauss):
     print("C1: GPU %.1f ms vs the reference %.0f ms on 8 threads; image rel L2 %.2e, max abs diff %.2e" % (integ.stats.render_ms, 1e3 * sec, r, np.abs(g - cpu).max()))
     assert r <= 1e-3
     rs.close(); gs.close()
+
+
+def test_analytic_shapes_reach_the_gpu_through_createTriMesh(phip, ref, gauss):
+    """the reference's analytic `rectangle` shapes (the classic Cornell box's light and walls): the plugin shim flattens
+    them through Shape::createTriMesh (rectangle.cpp:170-203: a two-triangle mesh with normals and texture coordinates) and
+    keeps the area emitter attached to the right shape.  The reference's CPU `path` intersects and samples the analytic
+    rectangles; the shading frames (UV tangents instead of coordinateSystem) and the light's (u,v) -> point map differ from
+    the mesh, so the comparison is statistical."""
+    from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
+    desc = S.cornell_box(96, 96, gauss).desc()
+    rs = ref.RefScene(desc, analytic_rectangles=True)
+    p = A.default_render_params(spp=256, max_depth=6)
+    gpu, _ = rs.render_job(p, threads=8, plugin="path_hip")
+    cpu, _ = rs.render_job(p, threads=8)
+    gs = Scene(desc); film = HDRFilm(96, 96); assert PathHIP(maxDepth=6).render(gs, film, 256)
+    mesh = film.develop()
+    for what, other in (("the reference's CPU path on the analytic shapes", cpu), ("path_hip on the triangle-mesh description", mesh)):
+        dm = abs(gpu.mean() - other.mean()) / other.mean()
+        r = rel_l2(gpu, other)
+        print("path_hip inside Mitsuba (analytic rectangles) vs %s: mean differs by %.2f %%, rel L2 %.3f" % (what, 100 * dm, r))
+        assert dm < 0.02 and r < 0.1                 # independent 256-spp renders: noise
+    rs.close(); gs.close()
