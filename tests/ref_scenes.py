@@ -188,7 +188,16 @@ def random_scene(gauss, seed, res=(24, 16), mip=None):
                 sb.diffuse((0, 0, 0)), facing=(0, -1, 0), radiance=tuple(rng.uniform(2, 20, 3)))
     eye = rng.uniform(-1, 1, 3) * [4, 1, 4]; eye[2] = -6
     sb.perspective(tuple(eye), (0, 0, 0), (0, 1, 0), float(rng.uniform(30, 80)))
-    sb.hdrfilm(res[0], res[1], gauss)
+    if res == "random":                                 # ragged film sizes and crop windows
+        frng = np.random.default_rng(5000 + seed)
+        w, h = int(frng.integers(5, 90)), int(frng.integers(5, 70))
+        crop = None
+        if frng.random() < 0.5:
+            cw, ch = int(frng.integers(1, w + 1)), int(frng.integers(1, h + 1))
+            crop = (int(frng.integers(0, w - cw + 1)), int(frng.integers(0, h - ch + 1)), cw, ch)
+        sb.hdrfilm(w, h, gauss, crop=crop)
+    else:
+        sb.hdrfilm(res[0], res[1], gauss)
     prng = np.random.default_rng(1000 + seed)
     if seed % 2 == 0:
         kw = dict(spp=2, max_depth=int(prng.integers(2, 12)), rr_depth=int(prng.integers(1, 6)), strict_normals=int(prng.integers(2)),
