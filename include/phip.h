@@ -71,8 +71,9 @@ typedef struct phip_material {
     float    alpha_u, alpha_v;  /* ROUGHCONDUCTOR roughness (clamped to >= 1e-4 inside)  */
     uint32_t distribution;      /* phip_microfacet_type                                  */
     uint32_t sample_visible;    /* microfacet.h:144, default true                        */
-    uint32_t reflectance_texture; /* DIFFUSE: 0 = the constant `reflectance`, else 1 + id of a `bitmap` texture
-                                   (diffuse.cpp:110-150 evaluate m_reflectance->eval(its))  */
+    uint32_t reflectance_texture; /* 0 = the constant `reflectance`, else 1 + id of a `bitmap` texture on DIFFUSE `reflectance`
+                                   (diffuse.cpp:110-150) or on DIELECTRIC / ROUGHCONDUCTOR `specularReflectance`
+                                   (dielectric.cpp:300, roughconductor.cpp:297-298,373-374): texture->eval(its)  */
 } phip_material;
 
 /* ---- `bitmap` texture (src/textures/bitmap.cpp, Texture2D::eval texture.cpp:112-121): an RGB MIP pyramid exactly as

@@ -21,6 +21,13 @@
 
 #define DV __host__ __device__ __forceinline__
 
+/* float -> int the way the reference's hardware does it (x86 cvttss2si: NaN and out-of-range values give INT_MIN, the
+   "integer indefinite" -- e.g. floorToInt(NaN) < 0 sends MIPMap::eval down its bilinear branch, mipmap.h:657-662); AMD's
+   v_cvt_i32_f32 saturates and maps NaN to 0, and in C the conversion is undefined: spelled out so that the device takes the
+   reference's branch (found by the fuzz test: a camera ray through the pole of an envmap has NaN differentials) */
+DV int f2i(float x) { return (x >= -2147483648.0f && x < 2147483648.0f) ? (int) x : (int) 0x80000000; }
+
+
 #define PT_EPSILON        1e-4f
 #define PT_SHADOW_EPSILON 1e-3f
 #define PT_PI             3.14159265358979323846f

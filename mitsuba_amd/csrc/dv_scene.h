@@ -359,7 +359,7 @@ DV V3 envmapEval(const DevEnvMap &E, const V3 &rayD) {
     const V2 uv = envDirToUV(xform3(E.toLocal, rayD));
     if (!(isfinite(uv.x) && isfinite(uv.y))) return V3(0.0f);
     const float u = uv.x * E.w - 0.5f, v = uv.y * E.h - 0.5f;
-    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    const int xPos = f2i(floorf(u)), yPos = f2i(floorf(v));
     const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
     const V3 value = envTexel(E, xPos, yPos) * dx2 * dy2 + envTexel(E, xPos, yPos + 1) * dx2 * dy1
                    + envTexel(E, xPos + 1, yPos) * dx1 * dy2 + envTexel(E, xPos + 1, yPos + 1) * dx1 * dy1;
@@ -386,13 +386,13 @@ DV V3 mipTexel(const float4 *texels, const DevMipLevels &Lv, int level, int x, i
     return V3(t.x, t.y, t.z);
 }
 DV V3 mipBox(const float4 *texels, const DevMipLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:566-569 */
-    return mipTexel(texels, Lv, level, (int) floorf(uv.x * Lv.lw[level]), (int) floorf(uv.y * Lv.lh[level]));
+    return mipTexel(texels, Lv, level, f2i(floorf(uv.x * Lv.lw[level])), f2i(floorf(uv.y * Lv.lh[level])));
 }
 DV V3 mipBilinear(const float4 *texels, const DevMipLevels &Lv, int level, const V2 &uv) {   /* mipmap.h:575-596 */
     if (!(isfinite(uv.x) && isfinite(uv.y))) return V3(0.0f);
     if (level >= Lv.nLevels) return mipBox(texels, Lv, Lv.nLevels - 1, uv);
     const float u = uv.x * Lv.lw[level] - 0.5f, v = uv.y * Lv.lh[level] - 0.5f;
-    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    const int xPos = f2i(floorf(u)), yPos = f2i(floorf(v));
     const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
     return mipTexel(texels, Lv, level, xPos, yPos) * dx2 * dy2 + mipTexel(texels, Lv, level, xPos, yPos + 1) * dx2 * dy1
          + mipTexel(texels, Lv, level, xPos + 1, yPos) * dx1 * dy2 + mipTexel(texels, Lv, level, xPos + 1, yPos + 1) * dx1 * dy1;
@@ -413,8 +413,8 @@ DV V3 mipEWA(const float4 *texels, const DevMipLevels &Lv, int level, const V2 &
     const float invDet = 1.0f / (-B * B + 4.0f * A * C),
                 deltaU = 2.0f * sqrtf(C * invDet),
                 deltaV = 2.0f * sqrtf(A * invDet);
-    const int u0 = (int) ceilf(u - deltaU), u1 = (int) floorf(u + deltaU);
-    const int v0 = (int) ceilf(v - deltaV), v1 = (int) floorf(v + deltaV);
+    const int u0 = f2i(ceilf(u - deltaU)), u1 = f2i(floorf(u + deltaU));
+    const int v0 = f2i(ceilf(v - deltaV)), v1 = f2i(floorf(v + deltaV));
     /* (level selection bounds the footprint to ~2 x maxAnisotropy texels per axis; anything far beyond that is garbage input,
        e.g. a NaN that slipped through: do not loop over it) */
     if ((long) u1 - u0 > 4096 || (long) v1 - v0 > 4096) return mipBilinear(texels, Lv, level, uv);
@@ -428,9 +428,9 @@ DV V3 mipEWA(const float4 *texels, const DevMipLevels &Lv, int level, const V2 &
         float dq = As * (2 * uu0 + 1) + Bs * vv;
         for (int ut = u0; ut <= u1; ++ut) {
             if (q < 64.0f) {
-                const uint32_t qi = (uint32_t) q;
+                const uint32_t qi = (uint32_t) (long long) q;     /* x86: (uint32_t) of a negative float wraps, it does not saturate to 0 */
                 if (qi < 64) {
-                    const float weight = Lv.weightLut[(int) q];
+                    const float weight = Lv.weightLut[qi];
                     result = result + mipTexel(texels, Lv, level, ut, vt) * weight;
                     denominator += weight;
                 }
@@ -458,7 +458,7 @@ DV V3 mipEval(const float4 *texels, const DevMipLevels &Lv, const V2 &uv, const 
     float minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
     if (Lv.filterType == PHIP_FILTER_TRILINEAR || !(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
         const float level = mtsLog2(smax(majorRadius, PT_EPSILON));
-        const int ilevel = (int) floorf(level);
+        const int ilevel = f2i(floorf(level));
         if (ilevel < 0) return mipBilinear(texels, Lv, 0, uv);
         const float a = level - ilevel;
         return mipBilinear(texels, Lv, ilevel, uv) * (1.0f - a) + mipBilinear(texels, Lv, ilevel + 1, uv) * a;
@@ -478,7 +478,7 @@ DV V3 mipEval(const float4 *texels, const DevMipLevels &Lv, const V2 &uv, const 
     const float scl = 1.0f / F;
     A *= scl; B *= scl; C *= scl;
     const float level = smax(0.0f, mtsLog2(minorRadius));
-    const int ilevel = (int) level;
+    const int ilevel = f2i(level);
     const float a = level - ilevel;
     if (majorRadius < 1 || !(A > 0 && C > 0))
         return mipBilinear(texels, Lv, ilevel, uv);
@@ -513,7 +513,7 @@ DV uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
 DV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 /* bilinear patch shared by internalSampleDirection / internalPdfDirection (envmap.cpp:577-590, 616-631) */
 DV float envPatch(const DevEnvMap &E, float px, float py, V3 &value) {
-    const int xPos = (int) floorf(px), yPos = (int) floorf(py);
+    const int xPos = f2i(floorf(px)), yPos = f2i(floorf(py));
     const float dx1 = px - xPos, dx2 = 1.0f - dx1, dy1 = py - yPos, dy2 = 1.0f - dy1;
     const V3 value1 = envTexel(E, xPos, yPos) * dx2 * dy2 + envTexel(E, xPos + 1, yPos) * dx1 * dy2;
     const V3 value2 = envTexel(E, xPos, yPos + 1) * dx2 * dy1 + envTexel(E, xPos + 1, yPos + 1) * dx1 * dy1;
@@ -817,7 +817,7 @@ template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &albedo, cons
         else
             pdf = (D * cosTheta(H)) / (4 * absDot(wo, H));
         if (D == 0) return V3(0.0f);
-        const V3 F = fresnelConductorExact(dot(wi, H), rgb(M.eta), rgb(M.k)) * rgb(M.refl);
+        const V3 F = fresnelConductorExact(dot(wi, H), rgb(M.eta), rgb(M.k)) * albedo;     /* m_specularReflectance->eval(bRec.its) */
         const float G = G1i * distr.smithG1(wo, H);
         float model = D * G / (4.0f * cosTheta(wi));
         return F * model;
@@ -839,7 +839,7 @@ template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const
         if (pdf == 0) return V3(0.0f);
         bs.wo = 2 * dot(wi, m) * m - wi;
         if (cosTheta(bs.wo) <= 0) return V3(0.0f);
-        V3 F = fresnelConductorExact(dot(wi, m), rgb(M.eta), rgb(M.k)) * rgb(M.refl);
+        V3 F = fresnelConductorExact(dot(wi, m), rgb(M.eta), rgb(M.k)) * albedo;
         float weight;
         if (M.sampleVisible) weight = distr.smithG1(bs.wo, m);
         else weight = distr.eval(m) * distr.G(wi, bs.wo, m) * dot(wi, m) / (pdf * cosTheta(wi));
@@ -854,7 +854,7 @@ template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const
         if (smp.x <= F) {
             bs.wo = V3(-wi.x, -wi.y, wi.z);
             bs.eta = 1.0f; bs.pdf = F;
-            return rgb(M.refl);
+            return albedo;                                  /* m_specularReflectance->eval(bRec.its) */
         } else {
             float scale = -(cosThetaT < 0 ? invEta : eta);
             bs.wo = V3(scale * wi.x, scale * wi.y, cosThetaT);
@@ -871,7 +871,7 @@ template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const
    vertex all see the same wi, so they share the nested model and the flip.  (eval/pdf pick nested0 for
    cosTheta(wi) > 0 and sample for cosTheta(wi) >= 0; at exactly 0 every wrapped model's eval/pdf is zero
    on either side, so one rule serves all three.) */
-struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip; V3 albedo; /* diffuse reflectance at this vertex: the constant, or the texture value k_shade puts here */ };
+struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip; V3 albedo; /* reflectance (diffuse) / specularReflectance (dielectric, roughconductor) at this vertex: the constant, or the texture value k_shade puts here */ };
 DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
     BsdfCtx c; c.leaf = &M; c.wi = wi; c.flip = false;
     if (M.type == PHIP_BSDF_TWOSIDED) {

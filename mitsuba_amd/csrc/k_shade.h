@@ -274,7 +274,7 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
                 dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
                 dRec.pdf = 0; dRec.emitter = -1;
                 BsdfCtx bctx = bsdfResolve(materials, its);
-                if (TEX && bctx.leaf->type == PHIP_BSDF_DIFFUSE && bctx.leaf->reflTexture != 0) {
+                if (TEX && bctx.leaf->reflTexture != 0) {
                     /* m_reflectance->eval(its): unfiltered level-0 lookup, except at the first vertex, whose UV partials come
                        from the camera-ray differentials (Intersection::getBSDF(ray) -> computePartials, records.inl:69-75) */
                     float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;

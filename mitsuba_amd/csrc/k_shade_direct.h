@@ -103,7 +103,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             if (!terminate) {
                 const V3 refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;     /* DirectSamplingRecord(its), records.inl:146-153 */
                 BsdfCtx bctx = bsdfResolve(materials, its);
-                if (TEX && bctx.leaf->type == PHIP_BSDF_DIFFUSE && bctx.leaf->reflTexture != 0) {
+                if (TEX && bctx.leaf->reflTexture != 0) {
                     /* its.getBSDF(ray): every query at the camera vertex sees the UV partials of the camera-ray differentials */
                     float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
                     V3 rx, ry;

@@ -203,6 +203,13 @@ struct phip_scene {
 static std::vector<DevMaterial> convertMaterials(const phip_material *materials, uint32_t nMaterials, const std::vector<float> *textureMax = nullptr) {
     if (nMaterials && !materials) throw std::runtime_error("materials is NULL");
     std::vector<DevMaterial> mats(nMaterials);
+    /* a `bitmap` texture on specularReflectance (dielectric.cpp:159-160, roughconductor.cpp:173-174,236: ensureEnergyConservation) */
+    auto specularTexture = [&](const phip_material &m, DevMaterial &o) {
+        if (m.reflectance_texture == 0) return;
+        if (!textureMax || m.reflectance_texture > textureMax->size()) throw std::runtime_error("material texture id out of range");
+        if ((*textureMax)[m.reflectance_texture - 1] > 1.0f) throw std::runtime_error("specularReflectance texture > 1 (ensureEnergyConservation)");
+        o.reflTexture = m.reflectance_texture;
+    };
     for (uint32_t i = 0; i < nMaterials; ++i) {
         const phip_material &m = materials[i];
         DevMaterial &o = mats[i];
@@ -223,8 +230,10 @@ static std::vector<DevMaterial> convertMaterials(const phip_material *materials,
             } break;
             case PHIP_BSDF_DIELECTRIC:
                 if (!(m.eta[0] > 0)) throw std::runtime_error("dielectric eta must be positive");
-                o.flags |= MF_TRANS_OR_BACK; break;
+                o.flags |= MF_TRANS_OR_BACK;
+                specularTexture(m, o); break;
             case PHIP_BSDF_ROUGHCONDUCTOR: {
+                specularTexture(m, o);
                 if (m.distribution > PHIP_MF_GGX) { g_err = "unsupported microfacet distribution"; throw std::invalid_argument("unsupported microfacet distribution (only beckmann, ggx)"); }
                 o.flags |= MF_SMOOTH;
                 /* alpha = ConstantFloatTexture.eval().average() (roughconductor.cpp:275-280), clamp microfacet.h:113-114 */

@@ -130,6 +130,29 @@ __global__ void k_debug_fmath(int op, size_t n, const float *a, const float *b, 
     }
 }
 
+/* MIPMap::eval(uv, d0, d1) of dv_scene.h on the host: texture = one phip_texture (levels as delivered) */
+extern "C" int phip_debug_host_mip_eval(const phip_texture *t, size_t n, const float *uv2, const float *d0, const float *d1, float *out3) {
+    try {
+        DevMipLevels lv; memset(&lv, 0, sizeof(lv));
+        std::vector<float4> texels;
+        lv.nLevels = (int32_t) std::max<uint32_t>(1, t->n_levels);
+        int w = (int) t->width, h = (int) t->height;
+        for (int l = 0; l < lv.nLevels; ++l) {
+            lv.lw[l] = w; lv.lh[l] = h; lv.offset[l] = (uint32_t) texels.size();
+            for (size_t i = 0; i < (size_t) w * h; ++i) texels.push_back(make_float4(t->levels[l][3 * i], t->levels[l][3 * i + 1], t->levels[l][3 * i + 2], 0.0f));
+            w = std::max(1, (w + 1) / 2); h = std::max(1, (h + 1) / 2);
+        }
+        lv.bcu = t->wrap_u; lv.bcv = t->wrap_v; lv.filterType = t->filter_type; lv.maxAnisotropy = t->max_anisotropy;
+        lv.uvScale[0] = lv.uvScale[1] = 1.0f;
+        for (int k = 0; k < 64; ++k) { const float r2 = (float) k / 63.0f; lv.weightLut[k] = pm_expf(-2.0f * r2) - pm_expf(-2.0f); }
+        for (size_t i = 0; i < n; ++i) {
+            const V3 v = mipEval(texels.data(), lv, V2(uv2[2 * i], uv2[2 * i + 1]), V2(d0[2 * i], d0[2 * i + 1]), V2(d1[2 * i], d1[2 * i + 1]));
+            out3[3 * i] = v.x; out3[3 * i + 1] = v.y; out3[3 * i + 2] = v.z;
+        }
+        return 0;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_INVALID, e.what()); }
+}
+
 extern "C" int phip_debug_fmath(int on_device, int op, size_t n, const float *a, const float *b, float *out) {
     if (!on_device) {
         for (size_t i = 0; i < n; ++i) {

@@ -33,6 +33,16 @@
 #include "../../bsdfs/diffuse.cpp"
 #undef CreateInstance
 #undef GetDescription
+#define CreateInstance CreateInstance_phip_roughconductor
+#define GetDescription GetDescription_phip_roughconductor
+#include "../../bsdfs/roughconductor.cpp"
+#undef CreateInstance
+#undef GetDescription
+#define CreateInstance CreateInstance_phip_dielectric
+#define GetDescription GetDescription_phip_dielectric
+#include "../../bsdfs/dielectric.cpp"
+#undef CreateInstance
+#undef GetDescription
 #define CreateInstance CreateInstance_phip_bitmap
 #define GetDescription GetDescription_phip_bitmap
 #include "../../textures/bitmap.cpp"
@@ -80,6 +90,12 @@ public:
     virtual Point2 getUVOffset() const = 0;
 };
 
+/* src/bsdfs/{roughconductor,dielectric}.cpp: the specularReflectance texture */
+class SpecularReflectanceAccess : public BSDF {
+public:
+    virtual const Texture *getSpecularReflectanceTexture() const = 0;
+};
+
 /* src/bsdfs/twosided.cpp's TwoSidedBRDF: its two children */
 class TwoSidedAccess : public BSDF {
 public:
@@ -99,6 +115,7 @@ struct PhipBitmapInfo {
 #if defined(PHIP_REFERENCE_ACCESSORS)
 inline const BSDF *phipNested(const BSDF *b, int i) { return static_cast<const TwoSidedAccess *>(b)->getNestedBRDF(i); }
 inline const Texture *phipReflectanceTexture(const BSDF *b) { return static_cast<const SmoothDiffuseAccess *>(b)->getReflectanceTexture(); }
+inline const Texture *phipSpecularTexture(const BSDF *b, bool) { return static_cast<const SpecularReflectanceAccess *>(b)->getSpecularReflectanceTexture(); }
 inline const TMIPMap<Spectrum, TSpectrum<half, SPECTRUM_SAMPLES> > *phipEnvMip(const Emitter *e) { return static_cast<const EnvironmentMapAccess *>(e)->getMIPMap(); }
 inline PhipBitmapInfo phipBitmap(const Texture *t) {
     const BitmapTextureAccess *b = static_cast<const BitmapTextureAccess *>(t);
@@ -108,6 +125,9 @@ inline PhipBitmapInfo phipBitmap(const Texture *t) {
 #else
 inline const BSDF *phipNested(const BSDF *b, int i) { return static_cast<const TwoSidedBRDF *>(b)->m_nestedBRDF[i].get(); }
 inline const Texture *phipReflectanceTexture(const BSDF *b) { return static_cast<const SmoothDiffuse *>(b)->m_reflectance.get(); }
+inline const Texture *phipSpecularTexture(const BSDF *b, bool conductor) {
+    return conductor ? static_cast<const RoughConductor *>(b)->m_specularReflectance.get() : static_cast<const SmoothDielectric *>(b)->m_specularReflectance.get();
+}
 inline const TMIPMap<Spectrum, TSpectrum<half, SPECTRUM_SAMPLES> > *phipEnvMip(const Emitter *e) { return static_cast<const EnvironmentMap *>(e)->m_mipmap; }
 inline PhipBitmapInfo phipBitmap(const Texture *t) {
     const BitmapTexture *b = static_cast<const BitmapTexture *>(t);
@@ -316,6 +336,17 @@ public:
     }
 #endif
 
+    /* a `bitmap` texture on specularReflectance (a <texture name="specularReflectance"> child; the property is then absent) */
+    void specularTexture(const BSDF *bsdf, bool conductor, phip_material &m) {
+#if defined(PHIP_HAVE_INTERNALS)
+        const Texture *tex = phipSpecularTexture(bsdf, conductor);
+        if (tex->getClass()->getName() == "BitmapTexture")
+            m.reflectance_texture = 1 + convertBitmap(tex);
+        else if (!tex->isConstant())
+            SLog(EError, "path_hip: texture \"%s\" is not supported (constant, bitmap)", tex->getClass()->getName().c_str());
+#endif
+    }
+
     uint32_t convertBSDF(const BSDF *bsdf, std::vector<phip_material> &materials, std::map<const BSDF *, uint32_t> &ids) {
         std::map<const BSDF *, uint32_t>::iterator it = ids.find(bsdf);
         if (it != ids.end()) return it->second;
@@ -341,6 +372,7 @@ public:
         } else if (cls == "SmoothDielectric") {
             m.type = PHIP_BSDF_DIELECTRIC; m.eta[0] = bsdf->getEta();
             rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
+            specularTexture(bsdf, false, m);
             rgb(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.transmittance);
         } else if (cls == "RoughConductor") {
             m.type = PHIP_BSDF_ROUGHCONDUCTOR;
@@ -357,6 +389,7 @@ public:
             rgb(props.getSpectrum("eta", intEta) / extEta, m.eta); rgb(props.getSpectrum("k", intK) / extEta, m.k);
             /* (BSDF::getSpecularReflectance folds the Fresnel term at its.wi in, roughconductor.cpp:252-257: not the parameter) */
             rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
+            specularTexture(bsdf, true, m);
             MicrofacetDistribution distr(props);
             if (distr.getType() == MicrofacetDistribution::EPhong)
                 SLog(EError, "path_hip: the phong/as microfacet distribution is not supported");
@@ -374,8 +407,8 @@ public:
         } else {
             SLog(EError, "path_hip: BSDF '%s' is outside the supported set (diffuse, dielectric, roughconductor, twosided)", cls.c_str());
         }
-        if ((bsdf->getType() & BSDF::ESpatiallyVarying) && m.type != PHIP_BSDF_TWOSIDED && !(m.type == PHIP_BSDF_DIFFUSE && m.reflectance_texture))
-            SLog(EError, "path_hip: only the diffuse reflectance can be textured (SURVEY 8f)");
+        if ((bsdf->getType() & BSDF::ESpatiallyVarying) && m.type != PHIP_BSDF_TWOSIDED && !m.reflectance_texture)
+            SLog(EError, "path_hip: only reflectance / specularReflectance can be textured (bitmap)");
         materials.push_back(m);
         ids[bsdf] = (uint32_t) materials.size() - 1;
         return ids[bsdf];

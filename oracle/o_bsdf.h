@@ -214,7 +214,7 @@ public:
     const Intersection *its = nullptr;     /* the vertex being shaded: textures are evaluated there (bRec.its in the reference) */
     explicit BSDF(const Scene &s) : scene(s) {}
 
-    /* m_reflectance->eval(bRec.its): ConstantSpectrumTexture or a `bitmap` texture (texture.cpp:112-121) */
+    /* m_reflectance / m_specularReflectance ->eval(bRec.its): ConstantSpectrumTexture or a `bitmap` texture (texture.cpp:112-121) */
     Spectrum diffuseReflectance(const Material &M) const {
         if (M.m.reflectance_texture != 0 && its)
             return scene.textures[M.m.reflectance_texture - 1].eval(*its);
@@ -243,7 +243,7 @@ public:
     }
 
     /* ---- dielectric.cpp:217-226,277-333 ---- */
-    static Spectrum dielectricSample(const Material &M, BSDFSamplingRecord &bRec, Float &pdf, const Vec2 &sample) {
+    Spectrum dielectricSample(const Material &M, BSDFSamplingRecord &bRec, Float &pdf, const Vec2 &sample) const {
         const Float eta = M.m.eta[0], invEta = 1 / eta;
         Float cosThetaT;
         Float F = fresnelDielectricExt(Frame::cosTheta(bRec.wi), cosThetaT, eta);
@@ -252,7 +252,7 @@ public:
             bRec.wo = Vec3(-bRec.wi.x, -bRec.wi.y, bRec.wi.z);
             bRec.eta = 1.0f;
             pdf = F;
-            return Spectrum(M.m.reflectance);
+            return diffuseReflectance(M);          /* m_specularReflectance->eval(bRec.its), dielectric.cpp:300 */
         } else {
             Float scale = -(cosThetaT < 0 ? invEta : eta);
             bRec.wo = Vec3(scale * bRec.wi.x, scale * bRec.wi.y, cosThetaT);
@@ -266,7 +266,7 @@ public:
     /* ---- roughconductor.cpp:253-415 ---- */
     static Vec3 reflect(const Vec3 &wi, const Vec3 &m) { return 2 * dot(wi, m) * m - wi; }
 
-    static Spectrum roughEval(const Material &M, const Vec3 &wi, const Vec3 &wo) {
+    Spectrum roughEval(const Material &M, const Vec3 &wi, const Vec3 &wo) const {
         if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0)
             return Spectrum(0.0f);
         Vec3 H = normalize(wo + wi);
@@ -274,7 +274,7 @@ public:
         const Float D = distr.eval(H);
         if (D == 0)
             return Spectrum(0.0f);
-        const Spectrum F = fresnelConductorExact(dot(wi, H), Spectrum(M.m.eta), Spectrum(M.m.k)) * Spectrum(M.m.reflectance);
+        const Spectrum F = fresnelConductorExact(dot(wi, H), Spectrum(M.m.eta), Spectrum(M.m.k)) * diffuseReflectance(M);
         const Float G = distr.G(wi, wo, H);
         Float model = D * G / (4.0f * Frame::cosTheta(wi));
         return F * model;
@@ -289,7 +289,7 @@ public:
         else
             return distr.pdf(wi, H) / (4 * absDot(wo, H));
     }
-    static Spectrum roughSample(const Material &M, BSDFSamplingRecord &bRec, Float &pdf, const Vec2 &sample) {
+    Spectrum roughSample(const Material &M, BSDFSamplingRecord &bRec, Float &pdf, const Vec2 &sample) const {
         if (Frame::cosTheta(bRec.wi) < 0)
             return Spectrum(0.0f);
         MicrofacetDistribution distr((int) M.m.distribution, M.alphaU, M.alphaV, M.m.sample_visible != 0);
@@ -301,7 +301,7 @@ public:
         bRec.sampledDelta = false;
         if (Frame::cosTheta(bRec.wo) <= 0)
             return Spectrum(0.0f);
-        Spectrum F = fresnelConductorExact(dot(bRec.wi, m), Spectrum(M.m.eta), Spectrum(M.m.k)) * Spectrum(M.m.reflectance);
+        Spectrum F = fresnelConductorExact(dot(bRec.wi, m), Spectrum(M.m.eta), Spectrum(M.m.k)) * diffuseReflectance(M);
         Float weight;
         if (M.m.sample_visible)
             weight = distr.smithG1(bRec.wo, m);

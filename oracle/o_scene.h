@@ -355,6 +355,15 @@ textures.resize(d.n_textures);
     Vec2 UV(uint32_t tri, int c) const { const float *p = &texcoords[2 * (size_t) indices[3 * (size_t) tri + c]]; return Vec2(p[0], p[1]); }
     Vec3 Nrm(uint32_t tri, int c) const { const float *p = &normals[3 * (size_t) indices[3 * (size_t) tri + c]]; return Vec3(p[0], p[1], p[2]); }
 
+    /* a `bitmap` texture on specularReflectance: ensureEnergyConservation (dielectric.cpp:159-160, roughconductor.cpp:236) */
+    void specularTexture(const Material &M) const {
+        if (M.m.reflectance_texture == 0) return;
+        if (M.m.reflectance_texture > textures.size()) throw std::runtime_error("oracle: bad texture id");
+        Float mx = 0;
+        for (const Spectrum &t : textures[M.m.reflectance_texture - 1].mip.levels[0]) mx = std::max(mx, t.max());
+        if (mx > 1.0f) throw std::runtime_error("specularReflectance texture > 1 (ensureEnergyConservation)");
+    }
+
     void configureMaterial(uint32_t i) {
         Material &M = materials[i];
         switch (M.m.type) {
@@ -369,9 +378,9 @@ textures.resize(d.n_textures);
                 }
                 M.smooth = mx > 0; M.transOrBack = false;
             } break;
-            case PHIP_BSDF_DIELECTRIC: M.smooth = false; M.transOrBack = true; break;
+            case PHIP_BSDF_DIELECTRIC: M.smooth = false; M.transOrBack = true; specularTexture(M); break;
             case PHIP_BSDF_ROUGHCONDUCTOR: {
-                M.smooth = true; M.transOrBack = false;
+                M.smooth = true; M.transOrBack = false; specularTexture(M);
                 /* roughconductor.cpp:275-280: alpha = texture.eval().average(); microfacet.h:113-114 clamp */
                 M.alphaU = std::max(Spectrum(M.m.alpha_u).average(), (Float) 1e-4f);
                 M.alphaV = std::max(Spectrum(M.m.alpha_v).average(), (Float) 1e-4f);
@@ -452,7 +461,7 @@ textures.resize(d.n_textures);
     bool usesRayDifferentials(const Material &M) const {
         if (M.m.type == PHIP_BSDF_TWOSIDED)
             return usesRayDifferentials(materials[M.m.nested[0]]) || usesRayDifferentials(materials[M.m.nested[1]]);
-        return M.m.type == PHIP_BSDF_DIFFUSE && M.m.reflectance_texture != 0;
+        return M.m.reflectance_texture != 0;       /* diffuse.cpp, roughconductor.cpp:244-248, dielectric.cpp:196-198 */
     }
 
     /* Intersection::computePartials, intersection.cpp:5-76 (rxOrigin = ryOrigin = the ray origin for a pinhole camera) */

@@ -248,6 +248,20 @@ void oracle_sample_emitter(void *scene_, const float *ref3, const float *refN3, 
     }
 }
 
+/* MipMap::eval on explicit inputs (mipmap.h:629-728) */
+int oracle_mip_eval(const phip_texture *t, size_t n, const float *uv2, const float *d0, const float *d1, float *out3) {
+    try {
+        MipMap m;
+        m.load(t->width, t->height, t->n_levels, t->levels);
+        m.bcu = t->wrap_u; m.bcv = t->wrap_v; m.filterType = t->filter_type; m.maxAnisotropy = t->max_anisotropy;
+        for (size_t i = 0; i < n; ++i) {
+            Spectrum v = m.eval(Vec2(uv2[2 * i], uv2[2 * i + 1]), Vec2(d0[2 * i], d0[2 * i + 1]), Vec2(d1[2 * i], d1[2 * i + 1]));
+            for (int k = 0; k < 3; ++k) out3[3 * i + k] = v[k];
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
 /* ---- phip_fmath.h spot checks: op 0 sin,1 cos,2 exp,3 log,4 acos,5 atan2,6 tan,7 pow,8 erf,9 erfinv,10 atan ---- */
 void oracle_fmath(int op, size_t n, const float *a, const float *b, float *out) {
     for (size_t i = 0; i < n; ++i) {

@@ -47,6 +47,7 @@ struct RefScene {
     ref<Scene> scene;
     std::vector<ref<BSDF> > materials;     /* by phip material id */
     std::vector<ref<Bitmap> > keep;
+    std::vector<ref<Texture> > textures;
     int width, height;
 };
 
@@ -114,6 +115,29 @@ Shape *makeRectangle(const phip_scene_desc &d, const phip_shape &s) {
     return static_cast<Shape *>(PluginManager::getInstance()->createObject(MTS_CLASS(Shape), props));
 }
 
+/* <texture type="bitmap"> from the in-memory image (bitmap.cpp:187-190); the plugin builds its own MIP pyramid */
+Texture *makeTexture(RefScene *rs, const phip_scene_desc &d, uint32_t id) {
+    const phip_texture &t = d.textures[id];
+    ref<Bitmap> bmp = rgbBitmap(t.levels[0], t.width, t.height);
+    rs->keep.push_back(bmp);
+    Properties tp("bitmap");
+    Properties::Data data; data.ptr = (uint8_t *) bmp.get(); data.size = sizeof(Bitmap);
+    tp.setData("bitmap", data);
+    static const char *filters[] = { "nearest", "bilinear", "trilinear", "ewa" };
+    tp.setString("filterType", filters[t.filter_type & 3]);
+    tp.setString("wrapModeU", wrapName(t.wrap_u)); tp.setString("wrapModeV", wrapName(t.wrap_v));
+    tp.setFloat("maxAnisotropy", t.max_anisotropy);
+    tp.setFloat("gamma", 1.0f);
+    tp.setFloat("uscale", t.uv_scale[0]); tp.setFloat("vscale", t.uv_scale[1]);
+    tp.setFloat("uoffset", t.uv_offset[0]); tp.setFloat("voffset", t.uv_offset[1]);
+    Texture *tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp));
+    tex->incRef();
+    tex->configure();
+    rs->textures.push_back(tex);
+    tex->decRef(false);
+    return tex;
+}
+
 BSDF *makeBSDF(RefScene *rs, const phip_scene_desc &d, uint32_t id) {
     if (rs->materials[id]) return rs->materials[id];
     const phip_material &m = d.materials[id];
@@ -122,39 +146,24 @@ BSDF *makeBSDF(RefScene *rs, const phip_scene_desc &d, uint32_t id) {
         Properties p("diffuse");
         if (!m.reflectance_texture) p.setSpectrum("reflectance", rgb(m.reflectance));
         bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
-        if (m.reflectance_texture) {
-            const phip_texture &t = d.textures[m.reflectance_texture - 1];
-            ref<Bitmap> bmp = rgbBitmap(t.levels[0], t.width, t.height);
-            rs->keep.push_back(bmp);
-            Properties tp("bitmap");
-            Properties::Data data; data.ptr = (uint8_t *) bmp.get(); data.size = sizeof(Bitmap);
-            tp.setData("bitmap", data);
-            static const char *filters[] = { "nearest", "bilinear", "trilinear", "ewa" };
-            tp.setString("filterType", filters[t.filter_type & 3]);
-            tp.setString("wrapModeU", wrapName(t.wrap_u)); tp.setString("wrapModeV", wrapName(t.wrap_v));
-            tp.setFloat("maxAnisotropy", t.max_anisotropy);
-            tp.setFloat("gamma", 1.0f);
-            tp.setFloat("uscale", t.uv_scale[0]); tp.setFloat("vscale", t.uv_scale[1]);
-            tp.setFloat("uoffset", t.uv_offset[0]); tp.setFloat("voffset", t.uv_offset[1]);
-            ref<Texture> tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp));
-            tex->configure();
-            attach(bsdf, "reflectance", tex);
-        }
+        if (m.reflectance_texture) attach(bsdf, "reflectance", makeTexture(rs, d, m.reflectance_texture - 1));
     } else if (m.type == PHIP_BSDF_DIELECTRIC) {
         Properties p("dielectric");
         p.setFloat("intIOR", m.eta[0]); p.setFloat("extIOR", 1.0f);
-        p.setSpectrum("specularReflectance", rgb(m.reflectance));
+        if (!m.reflectance_texture) p.setSpectrum("specularReflectance", rgb(m.reflectance));
         p.setSpectrum("specularTransmittance", rgb(m.transmittance));
         bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        if (m.reflectance_texture) attach(bsdf, "specularReflectance", makeTexture(rs, d, m.reflectance_texture - 1));
     } else if (m.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         Properties p("roughconductor");
         p.setString("material", "none");              /* no data/ior lookup (roughconductor.cpp:176-190): eta and k are given */
         p.setSpectrum("eta", rgb(m.eta)); p.setSpectrum("k", rgb(m.k)); p.setFloat("extEta", 1.0f);
-        p.setSpectrum("specularReflectance", rgb(m.reflectance));
+        if (!m.reflectance_texture) p.setSpectrum("specularReflectance", rgb(m.reflectance));
         p.setString("distribution", m.distribution == PHIP_MF_GGX ? "ggx" : "beckmann");
         p.setFloat("alphaU", m.alpha_u); p.setFloat("alphaV", m.alpha_v);
         p.setBoolean("sampleVisible", m.sample_visible != 0);
         bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        if (m.reflectance_texture) attach(bsdf, "specularReflectance", makeTexture(rs, d, m.reflectance_texture - 1));
     } else if (m.type == PHIP_BSDF_TWOSIDED) {
         Properties p("twosided");
         bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));

@@ -119,7 +119,8 @@ def textures(gauss, mip):
     t_ewa2 = bm("ewa2", noise[:15, :25], filter_type="ewa", max_anisotropy=2.0, uscale=3.0, wrap="clamp")
     sb.quad((-8, 0, -8), (8, 0, -8), (8, 0, 8), (-8, 0, 8), sb.diffuse(texture=t_floor), facing=(0, 1, 0), uvs=True)
     mats = [sb.diffuse(texture=t_tri), sb.twosided(sb.diffuse(texture=t_bil)), sb.twosided(sb.diffuse(texture=t_near), sb.diffuse((0.3, 0.3, 0.3))),
-            sb.diffuse(texture=t_ewa2), sb.roughconductor(alpha=0.05, alpha_v=0.3, eta=S.CU_ETA, k=S.CU_K), sb.diffuse((0.6, 0.5, 0.4))]
+            sb.diffuse(texture=t_ewa2), sb.roughconductor(alpha=0.05, alpha_v=0.3, eta=S.CU_ETA, k=S.CU_K, texture=t_tri),   # textured specularReflectance
+            sb.dielectric(1.5, 1.0, texture=t_floor)]
     for i, m in enumerate(mats):
         P, T, N = S.sphere_mesh((-5 + 2 * i, 0.8, 0.4 * (i % 2)), 0.8, 16, 8)
         sb.mesh(P, T, m, normals=N if i % 2 == 0 else None, uvs=_sphere_uvs(N))
@@ -158,7 +159,13 @@ def random_scene(gauss, seed, res=(24, 16), mip=None):
                      filter_type=kw["filter_type"], max_anisotropy=kw["max_anisotropy"])
             t = sb.bitmap(lv[0], pyramid=lv, uscale=float(rng.uniform(0.3, 8)), vscale=float(rng.uniform(0.3, 8)),
                           uoffset=float(rng.uniform(-1, 1)), voffset=float(rng.uniform(-1, 1)), **kw)
-            d = sb.diffuse(texture=t)
+            kind = rng.integers(0, 4)
+            if kind == 2:
+                d = sb.roughconductor(alpha=float(rng.uniform(0.05, 0.5)), eta=S.CU_ETA, k=S.CU_K, texture=t)      # specularReflectance
+            elif kind == 3:
+                mats.append(sb.dielectric(float(rng.uniform(1.2, 1.8)), 1.0, texture=t)); continue
+            else:
+                d = sb.diffuse(texture=t)
             mats.append(d if rng.random() < 0.5 else sb.twosided(d))
     for i in range(rng.integers(1 if mats else 2, 6)):
         t = rng.integers(0, 5)

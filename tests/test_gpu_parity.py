@@ -431,7 +431,7 @@ def test_random_scenes_fuzz_against_the_oracle(gpu, oracle, gauss):
     from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
     import os
     worst = 1.0
-    n_scenes = int(os.environ.get("PHIP_FUZZ_SCENES", "60"))         # 2000 were run once during development: all bit-identical
+    n_scenes = int(os.environ.get("PHIP_FUZZ_SCENES", "600"))         # 2000 were run once during development: all bit-identical
     for seed in range(n_scenes):
         sb, kw = RS.random_scene(gauss, seed, res=(48, 32) if seed % 2 else "random", mip=RS.box_mip)
         desc = sb.desc()
