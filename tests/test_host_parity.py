@@ -109,3 +109,34 @@ def test_degenerate_and_empty_geometry_build(phip):
     assert phip.phip_debug_host_build_bvh(fp(p), 4, idx.ctypes.data_as(C.POINTER(C.c_uint32)), 0, C.byref(info), None) == 0
     bad = np.array([[0, 1, 9]], np.uint32)
     assert phip.phip_debug_host_build_bvh(fp(p), 4, bad.ctypes.data_as(C.POINTER(C.c_uint32)), 1, C.byref(info), None) == A.PHIP_ERR_INVALID
+
+
+def test_host_mip_eval_matches_the_oracle(oracle, phip):
+    """MIPMap::eval as the kernels compile it (dv_scene.h, executed on the host) against the oracle's restatement -- itself
+    pinned to the reference's TMIPMap -- on random pyramids, lookup parameters and footprints, including degenerate and
+    non-finite differentials (NaN results must agree as well)"""
+    import ctypes as C
+    from mitsuba_amd import scene as S
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rng = np.random.default_rng(1)
+    L, Lo = phip, oracle.lib()
+    for trial in range(60):
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        keep = [np.ascontiguousarray(l, np.float32) for l in S.mip_pyramid(rng.uniform(0, 2, (h, w, 3)).astype(np.float32))]
+        t = A.phip_texture(); t.width, t.height, t.n_levels = w, h, len(keep)
+        for i, l in enumerate(keep):
+            t.levels[i] = fp(l)
+        t.wrap_u, t.wrap_v = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        t.filter_type = int(rng.integers(0, 4)); t.max_anisotropy = float(rng.uniform(1, 20))
+        n = 3000
+        uv = rng.uniform(-2, 3, (n, 2)).astype(np.float32)
+        sc = 10.0 ** rng.uniform(-6, 1, (n, 1))
+        d0 = (rng.normal(size=(n, 2)) * sc).astype(np.float32)
+        d1 = (rng.normal(size=(n, 2)) * sc * 10.0 ** rng.uniform(-3, 3, (n, 1))).astype(np.float32)
+        d0[:50] = 0; d1[50:100] = 0; d1[100:150] = d0[100:150]; d1[150:200] = -d0[150:200] * 3
+        d0[200:220] = np.nan; d1[220:240] = np.inf; d0[240:250] = 1e30; uv[250:260] = np.nan
+        a = np.zeros((n, 3), np.float32); b = np.zeros((n, 3), np.float32)
+        assert L.phip_debug_host_mip_eval(C.byref(t), n, fp(uv), fp(d0), fp(d1), fp(a)) == 0
+        assert Lo.oracle_mip_eval(C.byref(t), n, fp(uv), fp(d0), fp(d1), fp(b)) == 0
+        ok = (a.view(np.uint32) == b.view(np.uint32)).all(-1) | (np.isnan(a).all(-1) & np.isnan(b).all(-1))
+        assert ok.all(), (trial, int((~ok).sum()))
