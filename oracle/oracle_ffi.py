@@ -56,6 +56,7 @@ def lib(libm=False):
     L.oracle_mf_pdf.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_size_t, fp, fp, fp, fp]
     L.oracle_sample_emitter.argtypes = [C.c_void_p, fp, fp, C.c_size_t, fp, fp, fp, fp, fp, fp]
     L.oracle_fmath.argtypes = [C.c_int, C.c_size_t, fp, fp, fp]
+    L.oracle_mip_eval.argtypes = [C.POINTER(A.phip_texture), C.c_size_t, fp, fp, fp, fp]
     L.oracle_kd_info_get.argtypes = [C.c_void_p, C.c_void_p]
     _libs[key] = L
     return L
