@@ -112,16 +112,12 @@ PM_FN void pmd_sincos(double x, double *s, double *c) {
     const double PIO2_LO = 6.07710050650619224932e-11;
     const double PIO2_LO2 = 3.52155986518361559378e-27;
     double kd = floor(x * INV_PIO2 + 0.5);
-    double r = ((x - kd * PIO2_HI) - kd * PIO2_LO) - kd * PIO2_LO2;
+    double r = fma(-kd, PIO2_LO2, fma(-kd, PIO2_LO, fma(-kd, PIO2_HI, x)));
     double q4 = kd - 4.0 * floor(kd * 0.25);                  /* kd mod 4, exact */
     int q = (int) q4;
     double z = r * r;
-    double ps = r + r * z * (-1.66666666666666657415e-01 + z * (8.33333333333333321769e-03 + z * (-1.98412698412698412526e-04
-              + z * (2.75573192239858925110e-06 + z * (-2.50521083854417202239e-08 + z * (1.60590438368216133409e-10
-              + z * (-7.64716373181981640551e-13 + z * 2.81145725434552059811e-15)))))));
-    double pc = 1.0 + z * (-5.00000000000000000000e-01 + z * (4.16666666666666643537e-02 + z * (-1.38888888888888894189e-03
-              + z * (2.48015873015873015658e-05 + z * (-2.75573192239858882758e-07 + z * (2.08767569878681001866e-09
-              + z * (-1.14707455977297245073e-11 + z * 4.77947733238738525345e-14)))))));
+    double ps = fma(r * z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, 2.81145725434552059811e-15, -7.64716373181981640551e-13), 1.60590438368216133409e-10), -2.50521083854417202239e-08), 2.75573192239858925110e-06), -1.98412698412698412526e-04), 8.33333333333333321769e-03), -1.66666666666666657415e-01), r);
+    double pc = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, 4.77947733238738525345e-14, -1.14707455977297245073e-11), 2.08767569878681001866e-09), -2.75573192239858882758e-07), 2.48015873015873015658e-05), -1.38888888888888894189e-03), 4.16666666666666643537e-02), -5.00000000000000000000e-01), 1.0);
     if (q == 0) { *s = ps; *c = pc; }
     else if (q == 1) { *s = pc; *c = -ps; }
     else if (q == 2) { *s = -ps; *c = -pc; }
@@ -133,12 +129,8 @@ PM_FN double pmd_exp(double x) {                               /* |x| < 700 */
     const double LN2_HI = 6.93147180369123816490e-01;          /* 32 significant bits */
     const double LN2_LO = 1.90821492927058770002e-10;
     double kd = floor(x * INV_LN2 + 0.5);
-    double r = (x - kd * LN2_HI) - kd * LN2_LO;
-    double p = 1.0 + r + r * r * (5.00000000000000000000e-01 + r * (1.66666666666666657415e-01 + r * (4.16666666666666643537e-02
-             + r * (8.33333333333333321769e-03 + r * (1.38888888888888894189e-03 + r * (1.98412698412698412526e-04
-             + r * (2.48015873015873015658e-05 + r * (2.75573192239858925110e-06 + r * (2.75573192239858882758e-07
-             + r * (2.50521083854417202239e-08 + r * (2.08767569878681001866e-09 + r * (1.60590438368216133409e-10
-             + r * 1.14707455977297245073e-11))))))))))));
+    double r = fma(-kd, LN2_LO, fma(-kd, LN2_HI, x));
+    double p = fma(r * r, fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, 1.14707455977297245073e-11, 1.60590438368216133409e-10), 2.08767569878681001866e-09), 2.50521083854417202239e-08), 2.75573192239858882758e-07), 2.75573192239858925110e-06), 2.48015873015873015658e-05), 1.98412698412698412526e-04), 1.38888888888888894189e-03), 8.33333333333333321769e-03), 4.16666666666666643537e-02), 1.66666666666666657415e-01), 5.00000000000000000000e-01), 1.0 + r);
     int k = (int) kd;
     return p * pmd_from_bits((uint64_t) (k + 1023) << 52);     /* 2^k, k in [-1010, 1010] */
 }
@@ -150,11 +142,8 @@ PM_FN double pmd_log(double x) {                               /* finite x > 0, 
     double m = pmd_from_bits((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);     /* [1, 2) */
     if (m > 1.41421356237309514547e+00) { m *= 0.5; e += 1; }
     double t = (m - 1.0) / (m + 1.0), z = t * t;               /* log m = 2 artanh t, |t| <= 0.1716 */
-    double lm = t * (2.00000000000000000000e+00 + z * (6.66666666666666629659e-01 + z * (4.00000000000000022204e-01
-              + z * (2.85714285714285698425e-01 + z * (2.22222222222222209886e-01 + z * (1.81818181818181823228e-01
-              + z * (1.53846153846153854694e-01 + z * (1.33333333333333331483e-01 + z * (1.17647058823529410132e-01
-              + z * (1.05263157894736836262e-01 + z * (9.52380952380952328085e-02 + z * 8.69565217391304323691e-02)))))))))));
-    return (double) e * LN2 + lm;
+    double lm = t * fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, 8.69565217391304323691e-02, 9.52380952380952328085e-02), 1.05263157894736836262e-01), 1.17647058823529410132e-01), 1.33333333333333331483e-01), 1.53846153846153854694e-01), 1.81818181818181823228e-01), 2.22222222222222209886e-01), 2.85714285714285698425e-01), 4.00000000000000022204e-01), 6.66666666666666629659e-01), 2.00000000000000000000e+00);
+    return fma((double) e, LN2, lm);
 }
 
 PM_FN double pmd_atan(double xx) {
@@ -163,13 +152,8 @@ PM_FN double pmd_atan(double xx) {
     else if (x > 4.14213562373095034329e-01) { y = PMD_PI_4; x = (x - 1.0) / (x + 1.0); }   /* tan(pi / 8) */
     else y = 0.0;
     double z = x * x;                                         /* |x| <= 0.4143: 22 terms of the alternating series */
-    double p = 1.00000000000000000000e+00 + z * (-3.33333333333333314830e-01 + z * (2.00000000000000011102e-01 + z * (-1.42857142857142849213e-01
-             + z * (1.11111111111111104943e-01 + z * (-9.09090909090909116141e-02 + z * (7.69230769230769273470e-02 + z * (-6.66666666666666657415e-02
-             + z * (5.88235294117647050660e-02 + z * (-5.26315789473684181310e-02 + z * (4.76190476190476164042e-02 + z * (-4.34782608695652161845e-02
-             + z * (4.00000000000000008327e-02 + z * (-3.70370370370370349811e-02 + z * (3.44827586206896546939e-02 + z * (-3.22580645161290313627e-02
-             + z * (3.03030303030303038714e-02 + z * (-2.85714285714285705364e-02 + z * (2.70270270270270285273e-02 + z * (-2.56410256410256401360e-02
-             + z * (2.43902439024390252365e-02 + z * -2.32558139534883717703e-02))))))))))))))))))));
-    y += x * p;
+    double p = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, -2.32558139534883717703e-02, 2.43902439024390252365e-02), -2.56410256410256401360e-02), 2.70270270270270285273e-02), -2.85714285714285705364e-02), 3.03030303030303038714e-02), -3.22580645161290313627e-02), 3.44827586206896546939e-02), -3.70370370370370349811e-02), 4.00000000000000008327e-02), -4.34782608695652161845e-02), 4.76190476190476164042e-02), -5.26315789473684181310e-02), 5.88235294117647050660e-02), -6.66666666666666657415e-02), 7.69230769230769273470e-02), -9.09090909090909116141e-02), 1.11111111111111104943e-01), -1.42857142857142849213e-01), 2.00000000000000011102e-01), -3.33333333333333314830e-01), 1.00000000000000000000e+00);
+    y = fma(x, p, y);
     return xx < 0.0 ? -y : y;
 }
 
