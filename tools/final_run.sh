@@ -1,5 +1,5 @@
 set -x
-O=gpurun_out/final6
+O=gpurun_out/final7
 mkdir -p $O
 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
 python -m pytest tests/test_ref_pin.py tests/test_golden.py -q 2>&1 | tail -3 > $O/pytest_ref_pin.txt
