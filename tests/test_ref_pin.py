@@ -79,7 +79,7 @@ def test_reference_on_the_parity_stream(ref, oracle, olibm, name, build, kw):
 def test_random_scenes_fuzz(ref, olibm):
     """random scenes (ref_scenes.random_scene: sphere and triangle soups, every material kind, bitmap textures with random
     size / filter / wrap modes / uv transform, rotated envmaps, random integrator parameters): still bit for bit.
-    600 seeds were run once during development (all identical); 24 here"""
+    3000 seeds were run once during development (all identical); 24 here"""
     gauss = olibm.gaussian_filter(0.5, libm=True)
     for seed in range(24):
         sb, kw = RS.random_scene(gauss, seed, mip=live_mip(ref))
