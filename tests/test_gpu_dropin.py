@@ -4,6 +4,8 @@ compiled from /root/reference) load the product's plugin shims `path_hip.so` / `
 the shim flattens the reference's object graph through public getters, renders through the C ABI on the GPU and hands the
 film back through Film::setBitmap.  Compared with (a) the same scene description rendered through the ctypes harness --
 the flattening must round-trip -- and (b) the reference's own `path` / `direct` on the CPU, statistically."""
+import os
+
 import numpy as np
 import pytest
 
@@ -162,3 +164,44 @@ def test_analytic_shapes_reach_the_gpu_through_createTriMesh(phip, ref, gauss):
         print("path_hip inside Mitsuba (analytic rectangles) vs %s: mean differs by %.2f %%, rel L2 %.3f" % (what, 100 * dm, r))
         assert dm < 0.02 and r < 0.1                 # independent 256-spp renders: noise
     rs.close(); gs.close()
+
+
+@pytest.mark.skipif(not os.environ.get("PHIP_FUZZ_REFERENCE"), reason="opt-in (PHIP_FUZZ_REFERENCE=1): on a many-core host the reference's "
+                    "kd-tree builder spawns one thread per core for every scene, ~1.5 s per scene on the 256-thread GPU box")
+def test_random_scenes_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss):
+    """(opt-in; written at the very end of round 1 and not yet run to completion on a GPU box -- the same comparison on fixed
+    scenes is test_gpu_against_the_reference_on_the_same_samples above)
+    the fuzz scenes (ref_scenes.random_scene, with the reference's own MIP pyramids): GPU against Mitsuba's `path` /
+    `direct` fed with the parity stream, sample by sample.  Only glibc's rounding separates the two:
+    nearly all samples agree to the last bit, the rest to ~1e-6, a handful of paths per scene at most take another branch"""
+    import ref_scenes as RS
+    from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+    oracle.build(libm=True)
+    n_scenes = int(os.environ.get("PHIP_FUZZ_SCENES", "40"))
+    tot = ident = diverged = 0
+    for seed in range(n_scenes):
+        sb, kw = RS.random_scene(gauss, seed, res=(40, 28), mip=live_mip(ref))
+        desc = sb.desc()
+        if kw.get("integrator") == A.PHIP_INTEGRATOR_DIRECT:
+            integ = DirectHIP(emitterSamples=kw["emitter_samples"], bsdfSamples=kw["bsdf_samples"], strictNormals=bool(kw["strict_normals"]))
+        else:
+            integ = PathHIP(maxDepth=kw["max_depth"], rrDepth=kw["rr_depth"], strictNormals=bool(kw["strict_normals"]), hideEmitters=bool(kw["hide_emitters"]))
+        gs = Scene(desc); gs.setBlockSize(64)
+        film = HDRFilm(gs.width, gs.height)
+        spp = 4
+        assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
+        gsmp = integ.samples(gs, spp)
+        p = integ.params(gs, spp)
+        osc = oracle.OracleScene(desc, libm=True)
+        masks = osc.smooth_masks(p) if p.integrator == A.PHIP_INTEGRATOR_PATH else None
+        rs = ref.RefScene(desc)
+        _, rsmp = rs.render(p, sampler="ctr", smooth_masks=masks)
+        both_nan = np.isnan(gsmp) & np.isnan(rsmp)
+        same = ((gsmp.view(np.uint32) == rsmp.view(np.uint32)) | both_nan).all(-1)
+        close = ((np.abs(gsmp - rsmp) <= 1e-4 * np.maximum(1.0, np.abs(rsmp))) | both_nan).all(-1)
+        tot += same.size; ident += int(same.sum()); diverged += int((~close).sum())
+        assert (~close).mean() < 5e-3, (seed, kw, float((~close).mean()))
+        rs.close(); gs.close(); osc.close()
+    print("GPU vs Mitsuba on the same samples over %d random scenes: %.2f %% of %d samples bit-identical, %d took another path"
+          % (n_scenes, 100.0 * ident / tot, tot, diverged))
+    assert ident / tot > 0.9
