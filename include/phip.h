@@ -14,6 +14,12 @@
  *                                                                      include/mitsuba/render/imageblock.h:103-204
  *   phip_render_device  <- same, result left in device memory so the caller can RCCL-reduce it
  *                          (replaces StreamBackend::sendWorkResult,    src/libcore/sched_remote.cpp:519-532)
+ *   phip_render_params.n_devices / devices[]  <- the Scheduler's worker set: one host thread + stream per GPU, the
+ *                          reference's spiral block list dealt over them, the per-device films merged by one
+ *                          ncclReduce(sum) (replaces BlockedRenderProcess::processResult's film->put under a mutex,
+ *                          src/librender/renderproc.cpp:142-149, and sched_remote.cpp:519-532)
+ *   phip_render_params.progress  <- ProgressReporter::update / RenderQueue::signalWorkEnd
+ *                                                                      src/librender/renderproc.cpp:146-154
  *   phip_trace          <- ShapeKDTree::rayIntersect(ray, its) / (ray) src/librender/skdtree.cpp:112-142,207-226
  *   phip_cancel         <- SamplingIntegrator::cancel                  src/librender/integrator.cpp:90-93
  *   phip_develop        <- HDRFilm::develop weight normalisation       src/libcore/fmtconv.cpp:979-991
@@ -34,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PHIP_ABI_VERSION 3
+#define PHIP_ABI_VERSION 4
 
 typedef enum phip_status {
     PHIP_OK              =  0,
@@ -181,7 +187,10 @@ typedef struct phip_scene_desc {
 
 /* ---- integrator parameters: MonteCarloIntegrator (src/librender/integrator.cpp:190-225) ---- */
 typedef enum phip_sampler_kind {
-    PHIP_SAMPLER_CTR = 0     /* counter-based (pixel, sample, dimension) stream -- the parity stream */
+    PHIP_SAMPLER_CTR = 0     /* counter-based (pixel, sample, dimension) stream -- the parity stream.  `seed` selects the
+                                stream: the Mitsuba shim maps the scene's `independent` sampler here (its SFMT stream is
+                                a per-worker sequential generator, src/samplers/independent.cpp:71-103, that no parallel
+                                schedule can reproduce) and rejects the QMC samplers. */
 } phip_sampler_kind;
 
 /* which SamplingIntegrator::Li the call evaluates */
@@ -190,6 +199,7 @@ typedef enum phip_integrator_kind {
     PHIP_INTEGRATOR_DIRECT = 1   /* MIDirectIntegrator, src/integrators/direct/direct.cpp:149-312 (max_depth / rr_depth unused) */
 } phip_integrator_kind;
 
+#define PHIP_MAX_DEVICES 16
 typedef struct phip_render_params {
     int32_t  spp;                /* sampler sampleCount                                   */
     int32_t  max_depth;          /* -1 = infinite (integrator.cpp:197)                    */
@@ -209,12 +219,33 @@ typedef struct phip_render_params {
     uint32_t integrator;         /* phip_integrator_kind                                  */
     int32_t  emitter_samples;    /* `direct`: emitterSamples (direct.cpp:98-99), default 1 */
     int32_t  bsdf_samples;       /* `direct`: bsdfSamples (direct.cpp:100-101), default 1  */
-    int32_t  reserved;
+    /* Multi-GPU inside the call (ABI 4).  n_devices <= 1: the scene's device (`device`).  n_devices > 1: the blocks of this
+       call's shard are dealt round-robin, in the reference's spiral order, over devices[0..n_devices): one host thread and
+       one stream per device, the scene is replicated to a device on first use (phip_scene_replicate does it ahead of time),
+       and the per-device (R,G,B,alpha,weight) films are merged on devices[0] with one ncclReduce(sum) (RCCL over xGMI).
+       devices[0] must be the scene's device; phip_render_device's buffer lives there.  A device may not be listed twice
+       unless PHIP_FLAG_ALIAS_DEVICES is set (test hook for single-GPU boxes: the films are then summed by a kernel). */
+    int32_t  n_devices;
+    int32_t  devices[PHIP_MAX_DEVICES];
+    /* Progressive rendering (ABI 4): this call renders sample indices [sample_offset, sample_offset + spp) of a render of
+       sample_total samples per pixel (0 = spp; only the camera-ray differential scale 1/sqrt(sampleCount),
+       integrator.cpp:144-145, depends on it); with PHIP_FLAG_ACCUMULATE the result is ADDED to the film left by the
+       previous call (phip_render: the library-owned film; phip_render_device: the caller's buffer). */
+    int32_t  sample_offset;
+    int32_t  sample_total;
+    /* Progress (ABI 4): called from the rendering host thread(s) whenever the job's live-path count is polled
+       (about every 8 wavefront iterations) and at the end, with the camera samples finished so far by that device.
+       May be NULL.  The callback may call phip_cancel. */
+    void   (*progress)(void *user, int32_t device, uint64_t samples_done, uint64_t samples_total);
+    void    *progress_user;
 } phip_render_params;
 
 #define PHIP_FLAG_KERNEL_TIMING 1   /* bracket the kernels with hipEvents, fill phip_stats.*_ms */
 #define PHIP_FLAG_SAMPLE_BUFFER 2   /* keep per-sample radiance for phip_get_samples (tests)    */
 #define PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND 4   /* directly visible envmap pixels: unfiltered level-0 lookup instead of the reference's EWA filter (deviation!) */
+#define PHIP_FLAG_ACCUMULATE 8      /* add to the film of the previous call instead of overwriting it (progressive rendering) */
+#define PHIP_FLAG_ALIAS_DEVICES 16  /* devices[] may name one GPU several times (exercises the multi-device path on a 1-GPU box) */
+#define PHIP_FLAG_NO_FUSED 32       /* never use the fused single-kernel path (k_mega) -- A/B and parity tests of the wavefront kernels on small scenes */
 
 typedef struct phip_stats {
     uint64_t samples;                /* camera samples rendered by this call                  */
@@ -235,6 +266,10 @@ typedef struct phip_stats {
     double   film_kernel_ms;
     double   algorithmic_bytes;      /* SURVEY 8(d) bytes of the whole call, from the counters */
     double   trace_kernel_bytes;     /* the closest-hit kernel's share: node + triangle + ray + hit bytes */
+    double   fused_kernel_ms;        /* ... of k_mega (scenes that fit LDS: the whole path in one kernel) */
+    double   reduce_ms;              /* multi-device: ncclReduce of the films + its synchronisation, host wall clock */
+    uint32_t fused;                  /* 1: the call ran the fused kernel (then trace/shadow/shade ms are 0) */
+    uint32_t n_devices;              /* devices that rendered (counters are summed over them, *_ms are the maximum) */
 } phip_stats;
 
 typedef struct phip_ray  { float o[3]; float mint; float d[3]; float maxt; } phip_ray;
@@ -271,7 +306,13 @@ int  phip_get_samples(phip_scene *scene, float *out_rgba, size_t n_samples);
 int  phip_trace(phip_scene *scene, const phip_ray *rays, size_t n,
                 phip_hit *hits, uint8_t *occluded, phip_stats *out_stats);
 
-/* Thread-safe; makes a concurrent phip_render return PHIP_ERR_CANCELLED. */
+/* Replicates the device-resident scene (geometry, acceleration structure, materials, textures) from the scene's device
+   to each listed device (device-to-device copies over xGMI), so that a later multi-device render starts immediately. */
+int  phip_scene_replicate(phip_scene *scene, const int32_t *devices, int32_t n_devices);
+
+/* Thread-safe and sticky, like Scheduler::cancel on a process (src/libcore/sched.cpp): a running phip_render returns
+   PHIP_ERR_CANCELLED; a request that arrives before the render starts cancels that render.  The flag is consumed by the
+   call that observes it. */
 void phip_cancel(phip_scene *scene);
 
 /* RGB = sum/weight (0 where weight == 0): rgbaw[n*5] -> rgb[n*3]. Host-side helper. */
@@ -283,6 +324,8 @@ typedef struct phip_accel_info {
     uint32_t node_bytes, triangle_bytes;
     float    sah_cost;
     float    build_ms;
+    uint32_t fits_lds;       /* 1: tree, records, emitter table and materials fit the fused kernel's LDS plan (k_mega) */
+    uint32_t reserved;
 } phip_accel_info;
 int  phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out);
 

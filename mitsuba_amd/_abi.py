@@ -5,7 +5,7 @@ struct against the values the C side reports through phip_abi_sizeof().
 """
 import ctypes as C
 
-PHIP_ABI_VERSION = 3
+PHIP_ABI_VERSION = 4
 PHIP_FILTER_RESOLUTION = 31
 
 PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCELLED, PHIP_ERR_NOMEM = 0, -1, -2, -3, -4, -5
@@ -16,6 +16,9 @@ PHIP_INTEGRATOR_PATH, PHIP_INTEGRATOR_DIRECT = 0, 1
 PHIP_FLAG_KERNEL_TIMING = 1
 PHIP_FLAG_SAMPLE_BUFFER = 2
 PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND = 4
+PHIP_FLAG_ACCUMULATE = 8
+PHIP_FLAG_ALIAS_DEVICES = 16
+PHIP_FLAG_NO_FUSED = 32
 PHIP_NO_HIT = 0xFFFFFFFF
 
 
@@ -87,6 +90,11 @@ class phip_scene_desc(C.Structure):
                 ("texcoords", C.POINTER(C.c_float)), ("n_textures", C.c_uint32), ("textures", C.POINTER(phip_texture))]
 
 
+PHIP_MAX_DEVICES = 16
+# void (*progress)(void *user, int32_t device, uint64_t samples_done, uint64_t samples_total)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64)
+
+
 class phip_render_params(C.Structure):
     _fields_ = [("spp", C.c_int32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
                 ("strict_normals", C.c_int32), ("hide_emitters", C.c_int32), ("block_size", C.c_int32),
@@ -94,7 +102,9 @@ class phip_render_params(C.Structure):
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32),
                 ("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
                 ("integrator", C.c_uint32), ("emitter_samples", C.c_int32), ("bsdf_samples", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("n_devices", C.c_int32), ("devices", C.c_int32 * PHIP_MAX_DEVICES),
+                ("sample_offset", C.c_int32), ("sample_total", C.c_int32),
+                ("progress", PROGRESS_FN), ("progress_user", C.c_void_p)]
 
 
 class phip_stats(C.Structure):
@@ -104,7 +114,8 @@ class phip_stats(C.Structure):
                 ("invalid_samples", C.c_uint64), ("iterations", C.c_uint32), ("reserved", C.c_uint32),
                 ("render_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
                 ("shade_kernel_ms", C.c_double), ("film_kernel_ms", C.c_double),
-                ("algorithmic_bytes", C.c_double), ("trace_kernel_bytes", C.c_double)]
+                ("algorithmic_bytes", C.c_double), ("trace_kernel_bytes", C.c_double),
+                ("fused_kernel_ms", C.c_double), ("reduce_ms", C.c_double), ("fused", C.c_uint32), ("n_devices", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
@@ -121,7 +132,7 @@ class phip_hit(C.Structure):
 class phip_accel_info(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_triangle_refs", C.c_uint32),
                 ("max_depth", C.c_uint32), ("node_bytes", C.c_uint32), ("triangle_bytes", C.c_uint32),
-                ("sah_cost", C.c_float), ("build_ms", C.c_float)]
+                ("sah_cost", C.c_float), ("build_ms", C.c_float), ("fits_lds", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -146,6 +157,18 @@ def default_render_params(**kw):
     p.integrator = PHIP_INTEGRATOR_PATH
     p.emitter_samples = 1
     p.bsdf_samples = 1
+    p.n_devices = 0
+    p.sample_offset = 0
+    p.sample_total = 0
+    devices = kw.pop("devices", None)
+    if devices is not None:
+        p.n_devices = len(devices)
+        for i, d in enumerate(devices):
+            p.devices[i] = d
+    progress = kw.pop("progress", None)
+    if progress is not None:
+        p.progress = progress if isinstance(progress, PROGRESS_FN) else PROGRESS_FN(progress)
+        p._keep_progress = p.progress          # keep the thunk alive as long as the struct
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

@@ -30,22 +30,36 @@ def _sources():
     return out
 
 
+# objects of libphip.so: (source, extra flags, object name) -- see csrc/phip_common.h
+UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", [], "phip_mega.o")] + \
+        [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f], "phip_shade%d.o" % f) for f in range(4)]
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 (cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 (cross-compiles without a GPU): the objects in parallel, then one link."""
     os.makedirs(BUILD, exist_ok=True)
     if not force and os.path.exists(LIB):
         mt = os.path.getmtime(LIB)
         if all(os.path.getmtime(s) <= mt for s in _sources()):
             return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "phip.hip")]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", "").split()
+    procs = []
+    for src, extra, obj in UNITS:
+        cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj)]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+        if verbose:
+            print(" ".join(cmd)); print(out)
+    out_lib = os.environ.get("PHIP_BUILD_OUTPUT", LIB)      # experiment hook: alternative builds next to the product (load with PHIP_LIB)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + [os.path.join(BUILD, u[2]) for u in UNITS] + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-    if verbose:
-        print(" ".join(cmd))
-        print(r.stderr)
-    return LIB
+        raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return out_lib
 
 
 def lib():
@@ -69,6 +83,7 @@ def lib():
     L.phip_get_samples.argtypes = [C.c_void_p, fp, C.c_size_t]
     L.phip_trace.argtypes = [C.c_void_p, C.POINTER(A.phip_ray), C.c_size_t, C.POINTER(A.phip_hit), u8p, C.POINTER(A.phip_stats)]
     L.phip_cancel.argtypes = [C.c_void_p]
+    L.phip_scene_replicate.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
     L.phip_develop.argtypes = [fp, C.c_size_t, fp]
     L.phip_scene_accel_info.argtypes = [C.c_void_p, C.POINTER(A.phip_accel_info)]
     L.phip_gaussian_filter.argtypes = [C.c_float, fp, fp]

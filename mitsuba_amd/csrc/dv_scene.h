@@ -82,7 +82,7 @@ struct DevEnvMap {
 };
 
 struct DevScene {
-    const float4 *nodes; const float4 *nodes8; const float4 *tris; const float4 *triShade;
+    const float4 *nodes; const float4 *tris; const float4 *triShade;
     const DevMaterial *materials; uint32_t nMaterials;
     const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;
@@ -90,7 +90,7 @@ struct DevScene {
     uint32_t triShadeStride;             /* float4s per shading record: 6, or 9 when a mesh has texture coordinates */
     int32_t envEmitter; float envCenter[3]; float envRadius;   /* environment emitter (or -1) and its m_sceneBSphere */
     DevEnvMap env;
-    int32_t rootRef, rootRef8; uint32_t nTriangles;
+    int32_t rootRef; uint32_t nTriangles;
     uint32_t stackDepth, nodeCache, triCache;   /* LDS staging plan of the traversal kernels */
     float sceneMin[3], sceneMax[3];
     DevCamera cam; DevFilm film;

@@ -1,7 +1,6 @@
 /*
  * k_film.h -- statistics reduction, film gather (ImageBlock::put), per-sample export
- * Part of the single translation unit phip.hip (included there, in this order: k_pool.h, k_traverse.h,
- * k_group8.h, k_shade.h, k_film.h); see the header of phip.hip for the kernel overview.
+ * Included by phip.hip; see its header for the kernel overview.
  */
 
 /* sums the per-wave statistics: REDUCE_SPLIT blocks per counter row, rows [firstRow, firstRow + gridDim.x);

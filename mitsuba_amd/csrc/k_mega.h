@@ -1,0 +1,153 @@
+/*
+ * k_mega.h -- k_mega: the whole path of MIPathTracer::Li in ONE persistent kernel, for scenes whose acceleration structure,
+ * Wald records, shading records, emitter table and materials all fit in LDS (the Cornell box of BASELINE.json configs[1]).
+ *
+ * The wavefront design (k_shade -> k_shadow_p -> k_trace, state streamed through HBM between three kernels per iteration)
+ * exists to keep traversal kernels small when every node fetch is an HBM/L2 round trip.  When the geometry is a few KB in
+ * LDS there is no latency to hide and the round trips ARE the cost: on the Cornell box k_shade moved 0.8 GB of pool state per
+ * launch (2.5 TB/s) and the shadow kernel paid a random read-modify-write of L[id] per unoccluded ray, for a scene of 2.4 KB.
+ * Here a lane owns one path from the camera sample to its end:
+ *
+ *   loop:  lanes without a path draw the next sample id of the wave's chunk (same-lane regeneration, integrator.cpp:157-183)
+ *          closest hit   (traverse<false>, k_traverse.h: the same per-lane BVH4 state machine, nodes + records from LDS)
+ *          shadeVertex   (k_shade.h: the same statement of path.cpp:119-300 the wavefront kernel runs)
+ *          shadow ray    (traverse<true>); an unoccluded entry adds its contribution to the lane's accumulator REGISTER
+ *          a finished path stores its (R,G,B,alpha) once: L[id] = acc
+ *
+ * Ray, hit, throughput, MIS record and radiance never leave registers; HBM sees 16 B per sample (the L store the film
+ * kernel reads) instead of ~600 B.  Radiance is added in the reference's order (emitter hit of vertex n, NEE of vertex n,
+ * emitter hit of vertex n + 1, ...), exactly as the wavefront path does through L[id], so both are bit-identical.
+ *
+ * Sample ids are handed out in chunks from one global counter: a wave takes `chunk` consecutive ids with one atomicAdd by
+ * lane 0 (guided: the chunk shrinks towards the end of the pass so that the waves finish together) and deals them to its
+ * lanes in order -- 64 consecutive ids are one 8x8 pixel patch of one sample index (ids are block-major, then sample, then
+ * Morton index), so the camera rays of a wave are coherent.
+ */
+
+#define MEGA_CHUNK_MAX 4096u
+#define MEGA_CHUNK_MIN 64u
+
+enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
+
+template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
+    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
+    __shared__ float4 ldsTriShade[MEGA_TRISHADE_MAX * TRISHADE_FLOAT4S];
+    __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs */
+    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    for (uint32_t i = threadIdx.x; i < S.nTriangles * TRISHADE_FLOAT4S; i += BLOCK) ldsTriShade[i] = S.triShade[i];
+    S.triShade = ldsTriShade;                                   /* (generic pointer into LDS: six loads per vertex, not the inner loop) */
+    TravStack stk; setupTraversal(S, g_smem, nullptr, stk);     /* stack + all nodes + all Wald records in LDS (barrier inside); the host checked that nothing can spill */
+
+    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = __lane_id();
+    const unsigned long long laneBit = 1ull << lane;
+    unsigned long long next = 0, end = 0;                       /* the wave's chunk of sample ids (wave-uniform) */
+    bool exhausted = rc.totalIds == 0;
+
+    bool alive = false;
+    PathVertex v; v.id = v.pixel = v.k = v.state = 0;
+    v.hit = v.rayO = v.rayD = v.thr = make_float4(0, 0, 0, 0); v.mis = make_float2(0, 0);
+    float4 accum = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MC_COUNT; ++i) ldsCount[i][threadIdx.x] = 0;
+
+    for (;;) {
+        /* ---- regeneration: lanes without a path start the next camera sample (integrator.cpp:157-183) ---- */
+        for (;;) {
+            const unsigned long long want = __ballot(!alive);
+            if (!want || exhausted) break;
+            if (next >= end) {                                  /* draw a chunk (wave-uniform branch) */
+                unsigned long long base = 0; uint32_t chunk = 0;
+                if (lane == 0) {
+                    const unsigned long long seen = __hip_atomic_load(M.nextId, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool stop = __hip_atomic_load(M.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                    if (seen < rc.totalIds && !stop) {
+                        /* guided self-scheduling: half of what would remain per wave, within [64, 4096] ids */
+                        const unsigned long long share = (rc.totalIds - seen) / (2ull * M.nWaves);
+                        chunk = (uint32_t) (share > MEGA_CHUNK_MAX ? MEGA_CHUNK_MAX : (share < MEGA_CHUNK_MIN ? MEGA_CHUNK_MIN : share));
+                        chunk &= ~63u;
+                        base = atomicAdd(M.nextId, (unsigned long long) chunk);
+                    } else {
+                        base = rc.totalIds;
+                    }
+                }
+                const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t) base), bhi = __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32));
+                chunk = __builtin_amdgcn_readfirstlane(chunk);
+                next = ((unsigned long long) bhi << 32) | blo;
+                end = next + chunk; if (end > rc.totalIds) end = rc.totalIds;
+                if (next >= end) { exhausted = true; break; }
+            }
+            const uint32_t rank = (uint32_t) __popcll(want & (laneBit - 1ull));
+            const unsigned long long id = next + rank;
+            if (!alive && id < end) {
+                uint32_t px, py, k;
+                if (decodeId(rc, S.film, id, px, py, k)) {      /* ids outside the crop window (edge blocks) are consumed and skipped */
+                    const uint32_t pixel = py * (uint32_t) S.film.width + px;
+                    const U4 h = pcg4d(pixel, k, 0, rc.seed);
+                    const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+                    V3 o, d; float mint, maxt;
+                    cameraRay(S.cam, sx, sy, o, d, mint, maxt);
+                    v.rayO = make_float4(o.x, o.y, o.z, mint);
+                    v.rayD = make_float4(d.x, d.y, d.z, maxt);
+                    v.thr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    v.mis = make_float2(0.0f, 0.0f);
+                    v.id = (uint32_t) id; v.pixel = pixel; v.k = k;
+                    v.state = 1u | F_ALIVE | F_EMITTED | F_FIRST;
+                    accum = make_float4(0, 0, 0, 0);
+                    alive = true;
+                }
+            }
+            const unsigned long long used = (unsigned long long) __popcll(want);
+            next = (end - next < used) ? end : next + used;
+        }
+        if (!__any(alive)) break;
+
+        /* ---- closest hit ---- */
+        if (alive) {
+            const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
+            float mint, maxt;
+            TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
+            uint32_t nNode = 0, nTri = 0;
+            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt))
+                traverse<false, true>(S, o, d, mint, maxt, stk, r, nNode, nTri);
+            v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+            ldsCount[MC_RAYS][threadIdx.x] += 1; ldsCount[MC_NODE][threadIdx.x] += nNode; ldsCount[MC_TRI][threadIdx.x] += nTri;
+        }
+
+        /* ---- the vertex: emitter hit / Russian roulette / emission / NEE sample / BSDF sample ---- */
+        bool pushShadow = false, ended = false;
+        ShadowEntry sh;
+        if (alive) {
+            uint32_t nv = 0;
+            bool newRay;
+            const LRegister acc{ accum };
+            ended = shadeVertex<MM, STRICT, 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
+            if (ended) ldsCount[MC_VERTICES][threadIdx.x] += nv;
+        }
+
+        /* ---- shadow ray of the NEE sample; unoccluded: the contribution joins the accumulator (path.cpp:187-199) ---- */
+        if (pushShadow) {
+            const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
+            float mint, maxt;
+            bool occluded = false;
+            TravResult r;
+            uint32_t nNode = 0, nTri = 0;
+            if (clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt))
+                occluded = traverse<true, true>(S, o, d, mint, maxt, stk, r, nNode, nTri);
+            ldsCount[MC_SH_RAYS][threadIdx.x] += 1; ldsCount[MC_SH_NODE][threadIdx.x] += nNode; ldsCount[MC_SH_TRI][threadIdx.x] += nTri;
+            if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
+        }
+
+        if (ended) {
+            L[v.id] = accum;
+            ldsCount[MC_SAMPLES][threadIdx.x] += 1;
+            alive = false;
+        }
+    }
+
+    /* per-wave statistics (one owner per entry, no atomics) */
+    PathPool P; P.stat = M.stat; P.nWaves = M.nWaves;
+    const int rows[MC_COUNT] = { ST_SAMPLES, ST_VERTICES, ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
+#pragma unroll
+    for (int i = 0; i < MC_COUNT; ++i) waveStat(P, rows[i], waveId, ldsCount[i][threadIdx.x]);
+}

@@ -1,7 +1,6 @@
 /*
  * k_pool.h -- path-pool layout in HBM, slot flags, render constants, per-wave statistics, small device helpers
- * Part of the single translation unit phip.hip (included there, in this order: k_pool.h, k_traverse.h,
- * k_group8.h, k_shade.h, k_film.h); see the header of phip.hip for the kernel overview.
+ * Included by every translation unit through phip_common.h; see the header of phip.hip for the kernel overview.
  */
 
 /* ======================================================================================
@@ -44,7 +43,6 @@ struct PathPool {
     uint32_t *blockDead;              /* per block: every slot is F_DEAD and nothing is queued any more -- the drain phase of a pass skips these blocks */
     unsigned long long *stat;         /* ST_COUNT arrays of nWaves entries */
     uint32_t *spill;                  /* traversal-stack overflow: SPILL_DEPTH entries per lane */
-    uint2 *spill8;                    /* group kernels: SPILL8 entries per ray group (8 groups per wave) */
     uint32_t capacity, nWaves;
 };
 
@@ -52,6 +50,23 @@ struct PathPool {
  * contended word saturates at ~88 atomics/us on MI355X) in SoA arrays stat[k][waveId] and summed
  * by k_reduce_stats when the host wants them. */
 enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI, ST_VERTICES, ST_SAMPLES, ST_ALIVE, ST_COUNT };
+
+#define EMITTER_LDS_FLOATS 1024      /* emitter table staged in LDS by the shading kernels when it has at most this many floats (4 KB) */
+#define MATERIAL_LDS_MAX 48          /* ... and the materials when there are at most this many (4.5 KB) */
+#ifndef MEGA_WAVES
+#define MEGA_WAVES 3                 /* k_mega: waves per SIMD (= blocks of 256 per CU): 168 VGPRs, no scratch (at 4: 128 VGPRs + 148 B of scratch per lane) */
+#endif
+#define MEGA_TRISHADE_MAX 96         /* k_mega: shading records staged in LDS (9 KB) */
+#define DYN_SHARDS 8                    /* one dynamic-sample counter per XCD-sized group of blocks */
+#define DYN_STRIDE 16                   /* unsigned long longs between counters (128 B) */
+
+/* k_mega (k_mega.h): the fused single-kernel path for scenes that fit LDS */
+struct MegaParams {
+    unsigned long long *nextId;      /* the pass's sample-id counter (zeroed by the host) */
+    const int *cancel;               /* host-pinned flag polled when a wave draws a chunk of ids (phip_cancel) */
+    unsigned long long *stat;        /* ST_COUNT rows of nWaves entries */
+    uint32_t nWaves;
+};
 
 struct Counters {
     unsigned long long total[ST_COUNT];   /* written by k_reduce_stats */

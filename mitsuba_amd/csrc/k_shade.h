@@ -1,7 +1,6 @@
 /*
  * k_shade.h -- k_shade: the per-vertex work of MIPathTracer::Li and same-lane path regeneration
- * Part of the single translation unit phip.hip (included there, in this order: k_pool.h, k_traverse.h,
- * k_group8.h, k_shade.h, k_film.h); see the header of phip.hip for the kernel overview.
+ * Included by phip_shade.hip (k_shade) and phip_mega.hip (shadeVertex inside the fused kernel); see the header of phip.hip.
  */
 
 __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
@@ -12,8 +11,6 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
-#define EMITTER_LDS_FLOATS 1024      /* 4 KB */
-#define MATERIAL_LDS_MAX 48          /* 3.75 KB */
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
 #endif
@@ -132,24 +129,239 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
     }
 }
 
-/* FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures; MM: leaf BSDF models present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric
-   normal is dead after fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
-template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+/* ======================================================================================
+ *  One path vertex of MIPathTracer::Li (path.cpp:119-300) on the register image of a path.
+ *  Shared by the wavefront kernel k_shade (slot state streamed through HBM, radiance accumulated in L[id]) and the fused
+ *  kernel k_mega (k_mega.h: state and accumulator live in registers for the whole path) -- ONE statement of the
+ *  integrator's control flow and arithmetic, so both produce the same bits.
+ * ====================================================================================== */
+struct PathVertex {
+    uint32_t id, pixel, k;      /* sample id of the pass, crop pixel index, sample index */
+    uint32_t state;             /* depth | F_* flags */
+    float4 hit;                 /* in: (t, u, v, bits(prim)) of the ray that arrived here */
+    float4 rayO, rayD;          /* in: rayD = that ray's direction; out (newRay): the next ray (o, mint | d, maxt) */
+    float4 thr;                 /* throughput rgb, eta */
+    float2 mis;                 /* (BSDF pdf of the sampled direction, dot(direction, refN)) of the previous vertex */
+};
+struct ShadowEntry { float4 e0, e1, e2; };     /* (o, maxt) (d, bits(id)) (contribution, 0) */
+
+/* Radiance access policies: LGlobal = the per-sample buffer (read only when an emitter is hit: one random sector),
+   LRegister = an accumulator register (k_mega).  rayO() is needed by one rare branch (environment hit by a BSDF ray). */
+struct LGlobal {
+    float4 *L; const PathPool &P; uint32_t slot;
+    __device__ __forceinline__ float4 load(uint32_t id) const { return L[id]; }
+    __device__ __forceinline__ void store(uint32_t id, const float4 &l) const { L[id] = l; }
+    __device__ __forceinline__ float4 rayO(const PathVertex &) const { return P.rayO[slot]; }
+};
+struct LRegister {
+    float4 &acc;
+    __device__ __forceinline__ float4 load(uint32_t) const { return acc; }
+    __device__ __forceinline__ void store(uint32_t, const float4 &l) const { acc = l; }
+    __device__ __forceinline__ float4 rayO(const PathVertex &v) const { return v.rayO; }
+};
+
+/* Returns true when the path ends at this vertex (then `vertices` = its depth).  newRay: v.rayO / rayD / thr / mis hold the
+   next ray; v.state is updated whenever the path goes on.  A shadow-queue entry is returned in sh when pushShadow.
+   FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures; MM: leaf BSDF models
+   present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric normal is dead after
+   fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
+template <int MM, bool STRICT, int FEAT, typename LAcc>
+__device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab &T, const DevMaterial *materials, const RenderConst &rc,
+                                            PathVertex &v, const LAcc &acc, bool &newRay, bool &pushShadow, ShadowEntry &sh, uint32_t &vertices) {
     constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0;
-    __shared__ uint32_t waveCnt[BLOCK / 64];
-    if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
-    /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
-       dependent lookups per NEE sample) and the materials */
-    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
-    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
+    const uint32_t prim = pm_to_bits(v.hit.w);
+    const V3 rayD(v.rayD.x, v.rayD.y, v.rayD.z);
+    V3 thr(v.thr.x, v.thr.y, v.thr.z);
+    float eta = v.thr.w;
+    uint32_t depth = v.state & DEPTH_MASK;
+    uint32_t flags = v.state & ~DEPTH_MASK;
+    const uint32_t id = v.id;
+    bool terminate = false;
+    bool haveAdd = false;                  /* radiance to add to the sample's accumulator (in reference order) */
+    float4 l = make_float4(0, 0, 0, 0);
+    newRay = false; pushShadow = false;
+
+    if (prim == PHIP_NO_HIT) {
+        terminate = true;
+        if (flags & F_FIRST) haveAdd = true;   /* a camera ray that leaves the scene: the sample is (0,0,0, alpha 0) -- written, so the buffer needs no clear */
+        if (ENV && S.envEmitter >= 0) {     /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
+            const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
+            const V3 value = (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_ENVMAP) ? envmapEval(S.env, rayD) : rgb(em + EM_RADIANCE);
+            if (flags & F_FIRST) {
+                if (!rc.hideEmitters) {                                                    /* throughput is 1; alpha stays 0 */
+                    V3 bg = value;
+                    if (rc.envFiltered) {
+                        /* the camera ray is the one ray with differentials: filtered lookup, envmap.cpp:395-407.
+                           Its sample position is recomputed from the counter stream (a rare branch) */
+                        const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
+                        const U4 hc = pcg4d(v.pixel, v.k, 0, rc.seed);
+                        V3 rx, ry;
+                        cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
+                        rx = rayD + (rx - rayD) * rc.diffScaleFactor;
+                        ry = rayD + (ry - rayD) * rc.diffScaleFactor;
+                        bg = envmapEvalDiff(S.env, rayD, rx, ry);
+                    }
+                    l.x += bg.x; l.y += bg.y; l.z += bg.z;
+                }
+            } else {
+                const float4 ro = acc.rayO(v);
+                if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
+                    const float lumPdf = (!(flags & F_PREV_DELTA))
+                        ? pdfEmitterDirectDot<ENV>(S, T, (uint32_t) S.envEmitter, rayD, v.mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
+                    const V3 c = thr * value * miWeight(v.mis.x, lumPdf);
+                    l = acc.load(id);
+                    l.x += c.x; l.y += c.y; l.z += c.z;
+                    haveAdd = true;
+                }
+            }
+        }
+        if (haveAdd) acc.store(id, l);
+    } else {
+        Isect its;
+        fillIntersection(S, rayD, prim, v.hit.y, v.hit.z, v.hit.x, its);
+        /* the accumulator is zero until the sample's first vertex writes it, and later vertices only touch it when they
+           hit an emitter: no unconditional 64-byte-sector read per vertex (LGlobal) */
+        if (flags & F_FIRST) {
+            l.w = 1.0f;                     /* alpha, records.inl:117-144 */
+            haveAdd = true;
+        } else {
+            /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
+            if (its.emitter >= 0) {
+                l = acc.load(id);
+                const float *em = emitterRecord(T, (uint32_t) its.emitter);
+                V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
+                /* DirectSamplingRecord::setQuery (records.inl:170-178): n = shading normal, d = ray direction, dist = t */
+                const float lumPdf = (!(flags & F_PREV_DELTA))
+                    ? pdfEmitterDirectDot<ENV>(S, T, (uint32_t) its.emitter, rayD, v.mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
+                const V3 c = thr * value * miWeight(v.mis.x, lumPdf);
+                l.x += c.x; l.y += c.y; l.z += c.z;
+                haveAdd = true;
+            }
+            flags &= ~F_EMITTED;
+            if (depth++ >= (uint32_t) rc.rrDepth) {
+                float q = smin(thr.maxc() * eta * eta, 0.95f);
+                const U4 h = pcg4d(v.pixel, v.k, 2 + 2 * (depth - 2), rc.seed);
+                if (u32ToFloat(h.x) >= q)
+                    terminate = true;
+                else
+                    thr = thr / q;
+            }
+        }
+        const bool firstVertex = (flags & F_FIRST) != 0;
+        flags &= ~F_FIRST;
+
+        /* ---- head of the loop for this vertex, path.cpp:135-165 ---- */
+        if (!terminate && !(depth <= (uint32_t) rc.maxDepth || rc.maxDepth < 0))
+            terminate = true;
+        if (!terminate) {
+            if (its.emitter >= 0 && (flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
+                const float *em = emitterRecord(T, (uint32_t) its.emitter);
+                V3 le = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
+                const V3 c = thr * le;
+                l.x += c.x; l.y += c.y; l.z += c.z;
+                haveAdd = true;
+            }
+            if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
+                || (STRICT && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
+                terminate = true;
+        }
+        V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
+        if (!terminate) {
+            const U4 h = pcg4d(v.pixel, v.k, 1 + 2 * (depth - 1), rc.seed);
+            /* ---- direct illumination sampling, path.cpp:172-200 ---- */
+            DirectRec dRec;
+            dRec.ref = its.p;
+            dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
+            dRec.pdf = 0; dRec.emitter = -1;
+            BsdfCtx bctx = bsdfResolve(materials, its);
+            if (TEX && bctx.leaf->reflTexture != 0) {
+                /* m_reflectance->eval(its): unfiltered level-0 lookup, except at the first vertex, whose UV partials come
+                   from the camera-ray differentials (Intersection::getBSDF(ray) -> computePartials, records.inl:69-75) */
+                float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
+                if (firstVertex) {
+                    const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
+                    const U4 hc = pcg4d(v.pixel, v.k, 0, rc.seed);
+                    V3 rx, ry;
+                    cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
+                    rx = rayD + (rx - rayD) * rc.diffScaleFactor;
+                    ry = rayD + (ry - rayD) * rc.diffScaleFactor;
+                    const float *cw = S.cam.c2w;
+                    computePartials(its, V3(cw[3], cw[7], cw[11]), rx, ry, dudx, dudy, dvdx, dvdy);
+                }
+                bctx.albedo = textureEval(S, bctx.leaf->reflTexture - 1, its.uv, firstVertex, dudx, dudy, dvdx, dvdy);
+            }
+            if (its.flags & TS_MF_SMOOTH) {
+                V3 value = sampleEmitterDirect<ENV>(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
+                if (dRec.pdf != 0 && !value.isZero()) {
+                    const V3 wo = its.sh.toLocal(dRec.d);
+                    float bPdf;
+                    const V3 bsdfVal = bsdfEvalPdf<MM>(bctx, wo, bPdf);
+                    if (!bsdfVal.isZero() && (!STRICT || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
+                        const float weight = miWeight(dRec.pdf, bPdf);
+                        shC = thr * value * bsdfVal * weight;
+                        shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
+                        pushShadow = true;
+                    }
+                }
+            }
+            /* ---- BSDF sampling, path.cpp:207-226 ---- */
+            BSDFSample bs;
+            const V3 bsdfWeight = bsdfSample<MM>(bctx, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
+            if (bsdfWeight.isZero()) {
+                terminate = true;
+            } else {
+                flags |= F_SCATTERED;
+                const V3 wo = its.sh.toWorld(bs.wo);
+                const float woDotGeoN = dot(its.geoN, wo);
+                if (STRICT && woDotGeoN * cosTheta(bs.wo) <= 0) {
+                    terminate = true;
+                } else {
+                    v.rayO = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
+                    v.rayD = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                    thr = thr * bsdfWeight;
+                    eta *= bs.eta;
+                    v.thr = make_float4(thr.x, thr.y, thr.z, eta);
+                    v.mis = make_float2(bs.pdf, dot(wo, dRec.refN));
+                    newRay = true;
+                    flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
+                    flags = dRec.refN.isZero() ? (flags | F_REFN_ZERO) : (flags & ~F_REFN_ZERO);
+                }
+            }
+        }
+        if (haveAdd) acc.store(id, l);
+        if (pushShadow) {   /* self-contained shadow-queue entry: survives the slot being recycled */
+            sh.e0 = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
+            sh.e1 = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
+            sh.e2 = make_float4(shC.x, shC.y, shC.z, 0.0f);
+        }
+    }
+    if (terminate) vertices = depth;
+    else v.state = flags | depth;
+    return terminate;
+}
+
+/* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
+   dependent lookups per NEE sample) and the materials (all threads of the block must call; no barrier inside) */
+struct ShadeTables { EmitterTab T; const DevMaterial *materials; };
+__device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float *ldsEm, DevMaterial *ldsMat) {
     const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
     if (emInLds) for (uint32_t i = threadIdx.x; i < S.emitterTabSize; i += BLOCK) ldsEm[i] = S.emitterTab[i];
     if (matInLds) {
         const uint32_t n4 = S.nMaterials * (uint32_t) (sizeof(DevMaterial) / 16);
         for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) ((float4 *) ldsMat)[i] = ((const float4 *) S.materials)[i];
     }
-    EmitterTab T; T.t = emInLds ? ldsEm : S.emitterTab; T.n = S.nEmitters; T.normalization = S.emitterNormalization;
-    const DevMaterial *materials = matInLds ? ldsMat : S.materials;
+    ShadeTables t;
+    t.T.t = emInLds ? ldsEm : S.emitterTab; t.T.n = S.nEmitters; t.T.normalization = S.emitterNormalization;
+    t.materials = matInLds ? ldsMat : S.materials;
+    return t;
+}
+
+template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+    __shared__ uint32_t waveCnt[BLOCK / 64];
+    if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
+    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
+    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
+    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
     /* all slot state is fetched up front, before the liveness test, so that the five 16-byte loads are
@@ -157,191 +369,34 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
     const uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
     info.w = P.state[lslot];
-    const float4 hit = P.hit[lslot];
-    const float4 rd = P.rayD[lslot];
-    float4 thr4 = P.thr[lslot];
-    const float2 mis = P.mis[lslot];
+    PathVertex v;
+    v.hit = P.hit[lslot];
+    v.rayD = P.rayD[lslot];
+    v.thr = P.thr[lslot];
+    v.mis = P.mis[lslot];
     if (!inRange) info = make_uint4(0, 0, 0, 0);
     __syncthreads();                                            /* LDS tables are complete */
     bool alive = inRange && (info.w & F_ALIVE);
     bool needNew = inRange && !alive && !(info.w & F_DEAD);
     unsigned long long vertices = 0, done = 0;
     bool pushShadow = false;
-    float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0;
+    ShadowEntry sh; sh.e0 = make_float4(0, 0, 0, 0); sh.e1 = sh.e0; sh.e2 = sh.e0;
 
     if (alive) {
-        const uint32_t prim = pm_to_bits(hit.w);
-        const V3 rayD(rd.x, rd.y, rd.z);
-        V3 thr(thr4.x, thr4.y, thr4.z);
-        float eta = thr4.w;
-        uint32_t depth = info.w & DEPTH_MASK;
-        uint32_t flags = info.w & ~DEPTH_MASK;
-        const uint32_t id = info.x;
-        bool terminate = false;
-        V3 addL(0.0f); bool haveAdd = false;   /* radiance to add to L[id] (in reference order) */
-        float4 l = make_float4(0, 0, 0, 0);
-
-        if (prim == PHIP_NO_HIT) {
-            terminate = true;
-            if (ENV && S.envEmitter >= 0) {     /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
-                const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
-                const V3 value = (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_ENVMAP) ? envmapEval(S.env, rayD) : rgb(em + EM_RADIANCE);
-                l = L[id];
-                if (flags & F_FIRST) {
-                    if (!rc.hideEmitters) {                                                    /* throughput is 1; alpha stays 0 */
-                        V3 bg = value;
-                        if (rc.envFiltered) {
-                            /* the camera ray is the one ray with differentials: filtered lookup, envmap.cpp:395-407.
-                               Its sample position is recomputed from the counter stream (a rare branch) */
-                            const uint32_t px = info.y % (uint32_t) S.film.width, py = info.y / (uint32_t) S.film.width;
-                            const U4 hc = pcg4d(info.y, info.z, 0, rc.seed);
-                            V3 rx, ry;
-                            cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
-                            rx = rayD + (rx - rayD) * rc.diffScaleFactor;
-                            ry = rayD + (ry - rayD) * rc.diffScaleFactor;
-                            bg = envmapEvalDiff(S.env, rayD, rx, ry);
-                        }
-                        l.x += bg.x; l.y += bg.y; l.z += bg.z;
-                    }
-                    haveAdd = true;
-                } else {
-                    const float4 ro = P.rayO[slot];
-                    if (envFillDirectRecord(S, V3(ro.x, ro.y, ro.z), rayD)) {
-                        const float lumPdf = (!(flags & F_PREV_DELTA))
-                            ? pdfEmitterDirectDot<ENV>(S, T, (uint32_t) S.envEmitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, 0.0f, 0.0f) : 0;
-                        const V3 c = thr * value * miWeight(mis.x, lumPdf);
-                        l.x += c.x; l.y += c.y; l.z += c.z;
-                        haveAdd = true;
-                    }
-                }
-                if (haveAdd) L[id] = l;
-            }
-        } else {
-            Isect its;
-            fillIntersection(S, rayD, prim, hit.y, hit.z, hit.x, its);
-            /* L[id] is zero until the sample's first vertex writes it (the buffer is cleared per pass), and later
-               vertices only touch it when they hit an emitter: no unconditional 64-byte-sector read per vertex */
-            if (flags & F_FIRST) {
-                l.w = 1.0f;                     /* alpha, records.inl:117-144 */
-                haveAdd = true;
-            } else {
-                /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
-                if (its.emitter >= 0) {
-                    l = L[id];
-                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
-                    V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
-                    /* DirectSamplingRecord::setQuery (records.inl:170-178): n = shading normal, d = ray direction, dist = t */
-                    const float lumPdf = (!(flags & F_PREV_DELTA))
-                        ? pdfEmitterDirectDot<ENV>(S, T, (uint32_t) its.emitter, rayD, mis.y, (flags & F_REFN_ZERO) != 0, dot(rayD, its.sh.n), its.t) : 0;
-                    const V3 c = thr * value * miWeight(mis.x, lumPdf);
-                    l.x += c.x; l.y += c.y; l.z += c.z;
-                    haveAdd = true;
-                }
-                flags &= ~F_EMITTED;
-                if (depth++ >= (uint32_t) rc.rrDepth) {
-                    float q = smin(thr.maxc() * eta * eta, 0.95f);
-                    const U4 h = pcg4d(info.y, info.z, 2 + 2 * (depth - 2), rc.seed);
-                    if (u32ToFloat(h.x) >= q)
-                        terminate = true;
-                    else
-                        thr = thr / q;
-                }
-            }
-            const bool firstVertex = (flags & F_FIRST) != 0;
-            flags &= ~F_FIRST;
-
-            /* ---- head of the loop for this vertex, path.cpp:135-165 ---- */
-            if (!terminate && !(depth <= (uint32_t) rc.maxDepth || rc.maxDepth < 0))
-                terminate = true;
-            if (!terminate) {
-                if (its.emitter >= 0 && (flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
-                    const float *em = emitterRecord(T, (uint32_t) its.emitter);
-                    V3 le = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
-                    const V3 c = thr * le;
-                    l.x += c.x; l.y += c.y; l.z += c.z;
-                    haveAdd = true;
-                }
-                if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
-                    || (STRICT && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
-                    terminate = true;
-            }
-            V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
-            if (!terminate) {
-                const U4 h = pcg4d(info.y, info.z, 1 + 2 * (depth - 1), rc.seed);
-                /* ---- direct illumination sampling, path.cpp:172-200 ---- */
-                DirectRec dRec;
-                dRec.ref = its.p;
-                dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
-                dRec.pdf = 0; dRec.emitter = -1;
-                BsdfCtx bctx = bsdfResolve(materials, its);
-                if (TEX && bctx.leaf->reflTexture != 0) {
-                    /* m_reflectance->eval(its): unfiltered level-0 lookup, except at the first vertex, whose UV partials come
-                       from the camera-ray differentials (Intersection::getBSDF(ray) -> computePartials, records.inl:69-75) */
-                    float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
-                    if (firstVertex) {
-                        const uint32_t px = info.y % (uint32_t) S.film.width, py = info.y / (uint32_t) S.film.width;
-                        const U4 hc = pcg4d(info.y, info.z, 0, rc.seed);
-                        V3 rx, ry;
-                        cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
-                        rx = rayD + (rx - rayD) * rc.diffScaleFactor;
-                        ry = rayD + (ry - rayD) * rc.diffScaleFactor;
-                        const float *cw = S.cam.c2w;
-                        computePartials(its, V3(cw[3], cw[7], cw[11]), rx, ry, dudx, dudy, dvdx, dvdy);
-                    }
-                    bctx.albedo = textureEval(S, bctx.leaf->reflTexture - 1, its.uv, firstVertex, dudx, dudy, dvdx, dvdy);
-                }
-                if (its.flags & TS_MF_SMOOTH) {
-                    V3 value = sampleEmitterDirect<ENV>(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
-                    if (dRec.pdf != 0 && !value.isZero()) {
-                        const V3 wo = its.sh.toLocal(dRec.d);
-                        float bPdf;
-                        const V3 bsdfVal = bsdfEvalPdf<MM>(bctx, wo, bPdf);
-                        if (!bsdfVal.isZero() && (!STRICT || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
-                            const float weight = miWeight(dRec.pdf, bPdf);
-                            shC = thr * value * bsdfVal * weight;
-                            shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
-                            pushShadow = true;
-                        }
-                    }
-                }
-                /* ---- BSDF sampling, path.cpp:207-226 ---- */
-                BSDFSample bs;
-                const V3 bsdfWeight = bsdfSample<MM>(bctx, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
-                if (bsdfWeight.isZero()) {
-                    terminate = true;
-                } else {
-                    flags |= F_SCATTERED;
-                    const V3 wo = its.sh.toWorld(bs.wo);
-                    const float woDotGeoN = dot(its.geoN, wo);
-                    if (STRICT && woDotGeoN * cosTheta(bs.wo) <= 0) {
-                        terminate = true;
-                    } else {
-                        P.rayO[slot] = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
-                        P.rayD[slot] = make_float4(wo.x, wo.y, wo.z, INFINITY);
-                        thr = thr * bsdfWeight;
-                        eta *= bs.eta;
-                        P.thr[slot] = make_float4(thr.x, thr.y, thr.z, eta);
-                        P.mis[slot] = make_float2(bs.pdf, dot(wo, dRec.refN));
-                        flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
-                        flags = dRec.refN.isZero() ? (flags | F_REFN_ZERO) : (flags & ~F_REFN_ZERO);
-                    }
-                }
-            }
-            if (haveAdd) L[id] = l;
-            if (pushShadow) {   /* self-contained shadow-queue entry: survives the slot being recycled */
-                sh0 = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
-                sh1 = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
-                sh2 = make_float4(shC.x, shC.y, shC.z, 0.0f);
-            }
-        }
-        if (terminate) {
-            vertices = depth; done = 1;
+        v.id = info.x; v.pixel = info.y; v.k = info.z; v.state = info.w;
+        bool newRay; uint32_t nv = 0;
+        const LGlobal acc{ L, P, slot };
+        if (shadeVertex<MM, STRICT, FEAT>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv)) {
+            vertices = nv; done = 1;
             needNew = true;
         } else {
-            info.w = flags | depth;
+            info.w = v.state;
             P.state[slot] = info.w;
+        }
+        if (newRay) {
+            P.rayO[slot] = v.rayO; P.rayD[slot] = v.rayD; P.thr[slot] = v.thr; P.mis[slot] = v.mis;
         }
     }
 
-    shadeEpilogue(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh0, sh1, sh2, vertices, done);
+    shadeEpilogue(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh.e0, sh.e1, sh.e2, vertices, done);
 }

@@ -1,6 +1,6 @@
 /*
  * k_shade_direct.h -- k_shade_direct: MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:149-312) on the wavefront
- * Part of the single translation unit phip.hip (included after k_shade.h, whose LDS staging and epilogue it shares).
+ * Included by phip_shade.hip after k_shade.h, whose LDS staging and epilogue it shares.
  *
  * The camera vertex stays in its slot for emitterSamples + bsdfSamples "rounds" (launches); state.depth - 1 = round.
  *   round r < E:                    emitter sample r           -> one shadow-queue entry (as in k_shade)
@@ -18,14 +18,9 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
     if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
-    if (emInLds) for (uint32_t i = threadIdx.x; i < S.emitterTabSize; i += BLOCK) ldsEm[i] = S.emitterTab[i];
-    if (matInLds) {
-        const uint32_t n4 = S.nMaterials * (uint32_t) (sizeof(DevMaterial) / 16);
-        for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) ((float4 *) ldsMat)[i] = ((const float4 *) S.materials)[i];
-    }
-    EmitterTab T; T.t = emInLds ? ldsEm : S.emitterTab; T.n = S.nEmitters; T.normalization = S.emitterNormalization;
-    const DevMaterial *materials = matInLds ? ldsMat : S.materials;
+    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    const EmitterTab &T = tab.T;
+    const DevMaterial *materials = tab.materials;
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
     const uint32_t lslot = inRange ? slot : 0u;
@@ -70,6 +65,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
 
         if (prim == PHIP_NO_HIT) {                               /* direct.cpp:157-165 (only in round 0) */
             terminate = true;
+            haveAdd = true;                                      /* (0,0,0, alpha 0) is written: the sample buffer needs no clear */
             if (ENV && S.envEmitter >= 0 && !rc.hideEmitters) {
                 const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
                 V3 bg = (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_ENVMAP) ? envmapEval(S.env, camD) : rgb(em + EM_RADIANCE);
@@ -81,7 +77,6 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                     bg = envmapEvalDiff(S.env, camD, rx, ry);
                 }
                 l.x = bg.x; l.y = bg.y; l.z = bg.z;                /* alpha stays 0 */
-                haveAdd = true;
             }
         } else {
             Isect its;

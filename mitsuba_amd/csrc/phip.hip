@@ -1,68 +1,51 @@
 /*
- * phip.hip -- MI355X (gfx950) wavefront path tracer behind the C ABI of include/phip.h.
+ * phip.hip -- MI355X (gfx950) path tracer behind the C ABI of include/phip.h: host side + ray and film kernels.
  *
  * Replaces the reference's per-block CPU loop (SamplingIntegrator::renderBlock ->
- * MIPathTracer::Li, src/librender/integrator.cpp:140-188, src/integrators/path/path.cpp:119-300)
- * with a slot-stable wavefront: a pool of path slots lives in HBM as SoA arrays; every iteration
- * runs   shade -> shadow rays -> closest-hit rays   over the pool, a final film kernel develops the
- * per-sample accumulators.  One translation unit; the kernels live in the headers included below:
+ * MIPathTracer::Li, src/librender/integrator.cpp:140-188, src/integrators/path/path.cpp:119-300).
+ * Two device paths share one statement of the integrator (shadeVertex, k_shade.h) and one traversal (k_traverse.h):
  *
+ *   wavefront (any scene): a pool of path slots lives in HBM as SoA arrays; every iteration runs
+ *       shade -> shadow rays -> closest-hit rays   over the pool, a final film kernel develops the per-sample accumulators
+ *   fused (scenes that fit LDS, diffuse materials -- the Cornell box of BASELINE.json configs[1]): k_mega keeps a path in
+ *       registers from the camera sample to its end; HBM sees one 16-byte store per sample (k_mega.h)
+ *
+ * libphip.so is three translation units (phip_common.h).  Kernels and where they live:
  *   k_pool.h      PathPool (HBM layout of the slots), slot flags, RenderConst, per-wave statistics
  *   k_traverse.h  per-lane BVH4 traversal as a state machine (one node step + one Wald test per
- *                 iteration), LDS-staged stacks and top-of-tree cache; k_trace / k_shadow (one lane per
- *                 slot, small scenes), k_trace_p / k_shadow_p / k_rays_p (persistent waves with refill;
- *                 k_rays_p casts the closest-hit and the any-hit rays of an iteration in one launch),
- *                 k_raycast (phip_trace)
- *   k_group8.h    8 lanes per ray over a BVH8: measured 3x slower, kept as a documented experiment
- *   k_shade.h     k_shade<materials, strictNormals>: emitter-hit / environment MIS term, Russian roulette,
- *                 emission, NEE sample (self-contained shadow-queue entry, block-compacted), BSDF sample ->
- *                 next ray in place; a path that ends is replaced by the SAME lane in the same launch
- *                 (static sample schedule + dynamic tail).  Radiance accumulates in L[sampleId] in the
- *                 reference's order, so results are bit-reproducible.
+ *                 iteration), LDS-staged stacks and top-of-tree cache                  [this unit, phip_mega.hip]
+ *   k_rays.h      k_trace / k_shadow (one lane per slot, small scenes), k_trace_p / k_shadow_p / k_rays_p (persistent
+ *                 waves with refill; k_rays_p casts the closest-hit and the any-hit rays of an iteration in one launch),
+ *                 k_raycast (phip_trace)                                                     [this unit]
+ *   k_shade.h     shadeVertex + k_shade<materials, strictNormals, features>: emitter-hit / environment MIS term, Russian
+ *                 roulette, emission, NEE sample (self-contained shadow-queue entry, block-compacted), BSDF sample -> next
+ *                 ray in place; a path that ends is replaced by the SAME lane in the same launch (static sample schedule
+ *                 + dynamic tail).  Radiance accumulates in L[sampleId] in the reference's order.   [phip_shade.hip]
+ *   k_shade_direct.h  MIDirectIntegrator::Li on the same pool                                     [phip_shade.hip]
+ *   k_mega.h      the fused kernel                                                                [phip_mega.hip]
  *   k_film.h      k_film_tiled / k_film: gather of the filtered samples per pixel (ImageBlock::put,
  *                 include/mitsuba/render/imageblock.h:124-204) -- no float atomics, deterministic;
- *                 k_reduce_stats, k_export_samples
+ *                 k_reduce_stats, k_export_samples                                             [this unit]
  *
- * This file: error handling, host side (scene validation and upload, BVH build via bvh.h, camera set-up,
- * the render loop) and the extern "C" entry points.  Not MFMA work: irregular traversal and gathers
- * (SURVEY 8d).  The product never includes, links or calls anything under oracle/.
+ * This file: error handling, scene validation and upload (BVH build via bvh.h, camera set-up), replication of the scene to
+ * further GPUs, the render loop, the multi-device orchestration (one host thread + stream per GPU, ncclReduce of the
+ * films over RCCL/xGMI) and the extern "C" entry points.  Not MFMA work: irregular traversal and gathers.
+ * The product never includes, links or calls anything under oracle/.
  */
-#include <hip/hip_runtime.h>
-#include <atomic>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-#include <functional>
-#include <mutex>
-
-#include "../../include/phip.h"
-#include "dv_scene.h"
+#include "phip_common.h"
 #include "bvh.h"
-
-using namespace pt;
+#include "k_traverse.h"
+#include "k_rays.h"
+#include "k_film.h"
+#include <dlfcn.h>
+#include <map>
+#include <rccl/rccl.h>          /* types and prototypes only: librccl is bound with dlopen at the first multi-GPU render */
 
 /* ======================================================================================
  *  error handling
  * ====================================================================================== */
 static thread_local std::string g_err;
 static int setErr(int code, const std::string &msg) { g_err = msg; return code; }
-
-#define HIP_TRY(expr)                                                                             \
-    do {                                                                                          \
-        hipError_t e__ = (expr);                                                                  \
-        if (e__ != hipSuccess)                                                                    \
-            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__));         \
-    } while (0)
-
-#include "k_pool.h"
-#include "k_traverse.h"
-#include "k_group8.h"
-#include "k_shade.h"
-#include "k_shade_direct.h"
-#include "k_film.h"
 
 /* ======================================================================================
  *  host side
@@ -75,6 +58,7 @@ template <typename T> struct DevBuf {
     /* hipMalloc / hipFree cost milliseconds: keep the allocation when it is large enough */
     void alloc(size_t count) { if (count > cap) { release(); if (count) { HIP_TRY(hipMalloc((void **) &p, count * sizeof(T))); cap = count; } } n = count; }
     void upload(const T *src, size_t count) { alloc(count); if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice)); }
+    void cloneFrom(const DevBuf<T> &src) { alloc(src.n); if (src.n) HIP_TRY(hipMemcpy(p, src.p, src.n * sizeof(T), hipMemcpyDeviceToDevice)); }   /* UVA: also across GPUs (xGMI) */
     void release() { if (p) { (void) hipFree(p); p = nullptr; } n = 0; cap = 0; }
     ~DevBuf() { release(); }
 };
@@ -167,37 +151,61 @@ void spiralBlocks(int sizeX, int sizeY, int bs, std::vector<std::pair<int, int>>
 }
 
 } // namespace
-
-struct phip_scene {
+/* Everything that lives on ONE GPU: the immutable scene arrays and the render-time buffers of the jobs that run there.
+   devs[0] of a phip_scene is the device of phip_scene_create; further entries are replicas made by device-to-device copies. */
+struct SceneDev {
     int device = 0;
-    phip_scene_desc descCopy;        /* scalar fields only */
-    HostBVH bvh;
-    DevBuf<float4> nodes, nodes8, tris, triShade;
-    DevBuf<uint2> spill8;
-    int traversal = 2;               /* 2 = persistent per-lane BVH4 traversal with dynamic refill (default), 0 = one launch lane per slot, 1 = 8 lanes per ray over the BVH8
-                                        (PHIP_TRAVERSAL=group; measured 2-3x slower: too few rays in flight per CU) */
+    /* ---- scene (immutable after build / replication) ---- */
+    DevBuf<float4> nodes, tris, triShade;
     DevBuf<DevMaterial> materials;
     DevBuf<float> emitterTab;
-    DevBuf<float4> texTexels; DevBuf<DevMipLevels> texDesc; bool hasTextures = false; uint32_t triShadeStride = TRISHADE_FLOAT4S;   /* bitmap textures */
+    DevBuf<float4> texTexels; DevBuf<DevMipLevels> texDesc;                                   /* bitmap textures */
     DevBuf<float4> envTexels; DevBuf<DevMipLevels> envLevels; DevBuf<float> envCdfRows, envCdfCols, envRowWeights;     /* `envmap` emitter */
     DevScene dev;
-    /* render-time buffers (grown on demand, reused between calls) */
+    /* ---- render-time buffers (grown on demand, reused between calls) ---- */
     DevBuf<float4> rayO, rayD, hit, thr, camHit, shadow, L, sampleOut;
     DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
-    DevBuf<unsigned long long> dynCounter;
-    DevBuf<unsigned long long> stat;
-    DevBuf<float> film; DevBuf<unsigned long long> invalid;
-    uint32_t lastSpp = 0, nLocalTiles = 0;
+    DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
+    DevBuf<float> film;
+    uint32_t lastSpp = 0, nLocalTiles = 0; unsigned long long localPixels = 0;
     int tileKey[3] = { -1, -1, -1 };
     bool haveSamples = false;
-    int envLevelCount = 0;           /* MIP levels of the envmap (0: no envmap) */
     bool mergedRays = false;         /* last render used k_rays_p (closest + any hit in one launch) */
-    int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
-    std::atomic<int> cancel{ 0 };
-    std::mutex renderLock;
+    bool fused = false;              /* last render used k_mega */
     hipStream_t stream = nullptr;
+
+    template <typename F> void forEachSceneBuffer(F f) {
+        f(nodes); f(tris); f(triShade); f(materials); f(emitterTab); f(texTexels); f(texDesc);
+        f(envTexels); f(envLevels); f(envCdfRows); f(envCdfCols); f(envRowWeights);
+    }
+    /* the pointer members of the DevScene (everything else in it is plain data, equal on every device) */
+    void bind() {
+        dev.nodes = nodes.p; dev.tris = tris.p; dev.triShade = triShade.p; dev.materials = materials.p;
+        dev.texTexels = texTexels.p; dev.textures = texDesc.p; dev.emitterTab = emitterTab.p;
+        dev.env.texels = envTexels.p; dev.env.levels = envLevels.p; dev.env.cdfRows = envCdfRows.p; dev.env.cdfCols = envCdfCols.p;
+        dev.env.rowWeights = envRowWeights.p;
+    }
+    ~SceneDev() {
+        (void) hipSetDevice(device);
+        if (stream) (void) hipStreamDestroy(stream);
+    }
+};
+
+struct phip_scene {
+    phip_scene_desc descCopy;        /* scalar fields only */
+    HostBVH bvh;                     /* tree statistics (the node / record arrays are released after the upload) */
+    int traversal = 2;               /* 2 = persistent per-lane BVH4 traversal with dynamic refill (default), 0 = one launch lane per slot (PHIP_TRAVERSAL=lane) */
+    bool hasTextures = false; uint32_t triShadeStride = TRISHADE_FLOAT4S;
+    int envLevelCount = 0;           /* MIP levels of the envmap (0: no envmap) */
+    int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
+    bool fitsLds = false;            /* tree, Wald records, shading records, emitter table and materials fit the fused kernel's LDS plan */
+    std::vector<std::unique_ptr<SceneDev>> devs;
+    int *cancelFlag = nullptr;       /* host-pinned (portable, mapped): phip_cancel writes it, host loops and k_mega poll it */
+    std::mutex renderLock;
+    phip_scene() { devs.emplace_back(new SceneDev()); }
+    ~phip_scene() { devs.clear(); if (cancelFlag) (void) hipHostFree(cancelFlag); }
 };
 
 static std::vector<DevMaterial> convertMaterials(const phip_material *materials, uint32_t nMaterials, const std::vector<float> *textureMax = nullptr) {
@@ -255,6 +263,7 @@ static std::vector<DevMaterial> convertMaterials(const phip_material *materials,
 }
 
 static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
+    SceneDev &sd = *sc->devs[0];
     if (d.abi_version != PHIP_ABI_VERSION) throw std::runtime_error("phip_scene_desc.abi_version mismatch");
     if (d.n_vertices && !d.positions) throw std::runtime_error("positions is NULL");
     if (d.n_triangles && !d.indices) throw std::runtime_error("indices is NULL");
@@ -263,6 +272,8 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (d.film.crop_offset_x < 0 || d.film.crop_offset_y < 0 || d.film.crop_offset_x + d.film.crop_width > d.film.width ||
         d.film.crop_offset_y + d.film.crop_height > d.film.height)
         throw std::runtime_error("invalid crop window");          /* film.cpp:44-48 */
+    if (d.film.crop_width >= 65536 || d.film.crop_height >= 65536)
+        throw std::runtime_error("crop window of 65536 pixels or more per side (block origins are packed into 16 bits)");
     if (!(d.film.filter_radius > 0)) throw std::runtime_error("filter radius must be > 0");
     for (uint32_t i = 0; i < 3 * d.n_triangles; ++i)
         if (d.indices[i] >= d.n_vertices) throw std::runtime_error("triangle index out of range");
@@ -387,7 +398,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (sc->bvh.tris.size() / 12 >= (1u << 28)) throw std::runtime_error("too many triangle records for the leaf reference encoding");
 
     /* upload */
-    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipSetDevice(sd.device));
     /* shading records (dv_scene.h): the per-triangle constants come from the same __host__ __device__
        functions the kernel would run, so precomputing them does not change a single bit */
     bool anyTexcoords = false;
@@ -445,16 +456,14 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         r[4] = make_float4(b.x, b.y, b.z, 0.0f);
         r[5] = make_float4(c.x, c.y, c.z, 0.0f);
     }
-    if (ts.empty()) sc->triShade.alloc(TRISHADE_FLOAT4S_UV); else sc->triShade.upload(ts.data(), ts.size());
-    if (texTexels.empty()) sc->texTexels.alloc(1); else sc->texTexels.upload(texTexels.data(), texTexels.size());
-    if (texDesc.empty()) sc->texDesc.alloc(1); else sc->texDesc.upload(texDesc.data(), texDesc.size());
+    if (ts.empty()) sd.triShade.alloc(TRISHADE_FLOAT4S_UV); else sd.triShade.upload(ts.data(), ts.size());
+    if (texTexels.empty()) sd.texTexels.alloc(1); else sd.texTexels.upload(texTexels.data(), texTexels.size());
+    if (texDesc.empty()) sd.texDesc.alloc(1); else sd.texDesc.upload(texDesc.data(), texDesc.size());
     sc->hasTextures = d.n_textures > 0; sc->triShadeStride = stride;
-    if (sc->bvh.nodes.empty()) sc->nodes.alloc(8);
-    else sc->nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
-    if (sc->bvh.nodes8.empty()) sc->nodes8.alloc(16);
-    else sc->nodes8.upload((const float4 *) sc->bvh.nodes8.data(), sc->bvh.nodes8.size() / 4);
-    sc->tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
-    sc->materials.upload(mats.data(), mats.size());
+    if (sc->bvh.nodes.empty()) sd.nodes.alloc(8);
+    else sd.nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
+    sd.tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
+    sd.materials.upload(mats.data(), mats.size());
     sc->materialMask = 0;
     for (const DevMaterial &m : mats) {
         if (m.type == PHIP_BSDF_ROUGHCONDUCTOR) sc->materialMask |= MM_ROUGH;
@@ -497,14 +506,14 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         }
     }
     if (tab.size() >= (1ull << 31)) throw std::runtime_error("emitter table too large");
-    sc->emitterTab.upload(tab.data(), tab.size());
+    sd.emitterTab.upload(tab.data(), tab.size());
 
-    DevScene &D = sc->dev;
+    DevScene &D = sd.dev;
     memset(&D, 0, sizeof(D));
-    D.nodes = sc->nodes.p; D.nodes8 = sc->nodes8.p; D.tris = sc->tris.p; D.triShade = sc->triShade.p;
-    D.materials = sc->materials.p; D.nMaterials = (uint32_t) mats.size();
-    D.texTexels = sc->texTexels.p; D.textures = sc->texDesc.p; D.triShadeStride = sc->triShadeStride;
-    D.emitterTab = sc->emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
+    D.nodes = sd.nodes.p; D.tris = sd.tris.p; D.triShade = sd.triShade.p;
+    D.materials = sd.materials.p; D.nMaterials = (uint32_t) mats.size();
+    D.texTexels = sd.texTexels.p; D.textures = sd.texDesc.p; D.triShadeStride = sc->triShadeStride;
+    D.emitterTab = sd.emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
     D.envEmitter = envEmitter;
     if (envEmitter >= 0) {
@@ -554,7 +563,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
             }
         }
         for (int i = 0; i < 64; ++i) { const float r2 = (float) i / 63.0f; lv.weightLut[i] = pm_expf(-2.0f * r2) - pm_expf(-2.0f); }
-        sc->envLevels.upload(&lv, 1);
+        sd.envLevels.upload(&lv, 1);
         sc->envLevelCount = lv.nLevels;
         std::vector<float> cdfCols((size_t) (w + 1) * h), cdfRows((size_t) h + 1), rowWeights((size_t) h);
         size_t colPos = 0, rowPos = 0;
@@ -584,17 +593,17 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         M4 tw, tl;
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) tw.m[i][j] = e.to_world[4 * i + j];
         if (!m4invert(tw, tl)) throw std::runtime_error("envmap toWorld is singular");
-        sc->envTexels.upload(tex.data(), tex.size());
-        sc->envCdfRows.upload(cdfRows.data(), cdfRows.size()); sc->envCdfCols.upload(cdfCols.data(), cdfCols.size());
-        sc->envRowWeights.upload(rowWeights.data(), rowWeights.size());
+        sd.envTexels.upload(tex.data(), tex.size());
+        sd.envCdfRows.upload(cdfRows.data(), cdfRows.size()); sd.envCdfCols.upload(cdfCols.data(), cdfCols.size());
+        sd.envRowWeights.upload(rowWeights.data(), rowWeights.size());
         DevEnvMap &E = D.env;
-        E.texels = sc->envTexels.p; E.levels = sc->envLevels.p; E.cdfRows = sc->envCdfRows.p; E.cdfCols = sc->envCdfCols.p; E.rowWeights = sc->envRowWeights.p;
+        E.texels = sd.envTexels.p; E.levels = sd.envLevels.p; E.cdfRows = sd.envCdfRows.p; E.cdfCols = sd.envCdfCols.p; E.rowWeights = sd.envRowWeights.p;
         E.w = w; E.h = h; E.scale = e.scale;
         E.normalization = 1.0f / (rowSum * (2 * PT_PI / w) * (PT_PI / h));
         E.pixelSizeX = 2 * PT_PI / w; E.pixelSizeY = PT_PI / h;
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { E.toWorld[3 * i + j] = tw.m[i][j]; E.toLocal[3 * i + j] = tl.m[i][j]; }
     }
-    D.rootRef = sc->bvh.rootRef; D.rootRef8 = sc->bvh.rootRef8; D.nTriangles = d.n_triangles;
+    D.rootRef = sc->bvh.rootRef; D.nTriangles = d.n_triangles;
     /* LDS staging plan: stack depth from the tree depth (3 pushes per BVH4 level), top-of-tree node cache
        (nodes are in breadth-first order), all triangle records if there are few */
     D.stackDepth = (uint32_t) std::min<int>(STACK_DEPTH, std::max<int>(4, 3 * ((int) sc->bvh.maxDepth - 1) + 1));
@@ -602,7 +611,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     D.triCache = (sc->bvh.tris.size() / 12 <= TRI_CACHE_MAX) ? (uint32_t) (sc->bvh.tris.size() / 12) : 0u;
     if (const char *e = getenv("PHIP_NODE_CACHE")) D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, (uint32_t) atoi(e));
     if (D.nodeCache == 0) D.triCache = 0;
-    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = (strcmp(e, "group") == 0) ? 1 : (strcmp(e, "lane") == 0 ? 0 : 2);
+    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = strcmp(e, "lane") == 0 ? 0 : 2;
     for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
     setupCamera(d.camera, d.film, D.cam);
     D.film.width = d.film.crop_width; D.film.height = d.film.crop_height;
@@ -615,20 +624,68 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     sc->descCopy = d;
     sc->descCopy.positions = nullptr; sc->descCopy.normals = nullptr; sc->descCopy.indices = nullptr;
     sc->descCopy.shapes = nullptr; sc->descCopy.materials = nullptr; sc->descCopy.emitters = nullptr;
-    sc->counters.alloc(1);
-    sc->invalid.alloc(1);
-    sc->dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
+    /* the fused kernel's LDS plan (k_mega.h): the whole tree, every Wald and shading record, the emitter table and the
+       materials in LDS, a stack that cannot spill; diffuse materials only (phip_mega.hip) */
+    sc->fitsLds = sc->materialMask == 0 && !sc->hasTextures && envEmitter < 0 && stride == TRISHADE_FLOAT4S
+        && D.nodeCache == sc->bvh.nNodes && D.triCache == sc->bvh.tris.size() / 12 && d.n_triangles <= MEGA_TRISHADE_MAX
+        && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX
+        && 3 * ((int) sc->bvh.maxDepth - 1) + 1 <= (int) D.stackDepth;
+    sd.counters.alloc(1);
+    sd.invalid.alloc(1);
+    sd.dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
+    sd.megaNext.alloc(1);
+    std::vector<float>().swap(sc->bvh.nodes); std::vector<float>().swap(sc->bvh.tris);      /* keep the statistics, drop the arrays */
+    HIP_TRY(hipHostMalloc((void **) &sc->cancelFlag, sizeof(int), hipHostMallocPortable | hipHostMallocMapped));
+    *sc->cancelFlag = 0;
+}
+
+/* Replica of the scene on another GPU: device-to-device copies of the immutable arrays (xGMI), same DevScene. */
+static SceneDev *replicateScene(phip_scene *sc, int device) {
+    SceneDev &src = *sc->devs[0];
+    std::unique_ptr<SceneDev> dst(new SceneDev());
+    dst->device = device;
+    HIP_TRY(hipSetDevice(device));
+    dst->nodes.cloneFrom(src.nodes); dst->tris.cloneFrom(src.tris); dst->triShade.cloneFrom(src.triShade);
+    dst->materials.cloneFrom(src.materials); dst->emitterTab.cloneFrom(src.emitterTab);
+    dst->texTexels.cloneFrom(src.texTexels); dst->texDesc.cloneFrom(src.texDesc);
+    dst->envTexels.cloneFrom(src.envTexels); dst->envLevels.cloneFrom(src.envLevels);
+    dst->envCdfRows.cloneFrom(src.envCdfRows); dst->envCdfCols.cloneFrom(src.envCdfCols); dst->envRowWeights.cloneFrom(src.envRowWeights);
+    dst->dev = src.dev;
+    dst->bind();
+    dst->counters.alloc(1); dst->invalid.alloc(1); dst->dynCounter.alloc(DYN_SHARDS * DYN_STRIDE); dst->megaNext.alloc(1);
+    HIP_TRY(hipDeviceSynchronize());
+    sc->devs.emplace_back(std::move(dst));
+    return sc->devs.back().get();
+}
+
+static void phipLaunchShade(int feat, bool strictNormals, int materialMask, dim3 grid, hipStream_t stream,
+                            const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
+    switch (feat & 3) {
+        case 0: phipLaunchShadeF0(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
+        case 1: phipLaunchShadeF1(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
+        case 2: phipLaunchShadeF2(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
+        default: phipLaunchShadeF3(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
+    }
+}
+static void phipLaunchShadeDirect(int feat, int materialMask, dim3 grid, hipStream_t stream,
+                                  const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
+    switch (feat & 3) {
+        case 0: phipLaunchShadeDirectF0(materialMask, grid, stream, S, P, rc, L); break;
+        case 1: phipLaunchShadeDirectF1(materialMask, grid, stream, S, P, rc, L); break;
+        case 2: phipLaunchShadeDirectF2(materialMask, grid, stream, S, P, rc, L); break;
+        default: phipLaunchShadeDirectF3(materialMask, grid, stream, S, P, rc, L); break;
+    }
 }
 
 static size_t traversalLdsBytes(const DevScene &D) {
     return (size_t) D.stackDepth * BLOCK * sizeof(uint32_t) + (size_t) D.nodeCache * NODE_LDS_STRIDE * sizeof(float4) + (size_t) D.triCache * 3 * sizeof(float4);
 }
 
-static void algorithmicBytes(const phip_scene *sc, phip_stats &st) {
+static void algorithmicBytes(bool mergedRays, phip_stats &st, double filmPixels) {
     /* SURVEY 8(d) with this structure's sizes: 128-byte BVH4 node visits, 48-byte triangle records
        (no separate index array: records are stored in leaf order) */
-    const double film = 20.0 * (double) sc->dev.film.width * sc->dev.film.height;
-    const double nodeBytes = sc->traversal == 1 ? 256.0 : 128.0;
+    const double film = 20.0 * filmPixels;
+    const double nodeBytes = 128.0;
     st.algorithmic_bytes = nodeBytes * (double) (st.closest_node_visits + st.shadow_node_visits) +
            48.0 * (double) (st.closest_triangle_tests + st.shadow_triangle_tests) +
            (64.0 + 40.0 + 108.0) * (double) st.closest_rays + (64.0 + 4.0) * (double) st.shadow_rays +
@@ -637,67 +694,87 @@ static void algorithmicBytes(const phip_scene *sc, phip_stats &st) {
        the SURVEY's read+write convention: ray 64 B, hit 40 B */
     st.trace_kernel_bytes = nodeBytes * (double) st.closest_node_visits + 48.0 * (double) st.closest_triangle_tests +
            (64.0 + 40.0) * (double) st.closest_rays;
-    if (sc->mergedRays)    /* k_rays_p also casts the shadow rays: their node + record fetches, entry read, 4-byte result */
+    if (mergedRays)    /* k_rays_p also casts the shadow rays: their node + record fetches, entry read, 4-byte result */
         st.trace_kernel_bytes += nodeBytes * (double) st.shadow_node_visits + 48.0 * (double) st.shadow_triangle_tests +
                (64.0 + 4.0) * (double) st.shadow_rays;
 }
 
-static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /* device */, phip_stats *stats) {
-    using clk = std::chrono::steady_clock;
-    const auto t0 = clk::now();
+/* hipEvents of one render call; destroyed whatever happens (an exception leaves through HIP_TRY) */
+struct EventList {
+    std::vector<hipEvent_t> ev;
+    hipEvent_t record(hipStream_t s) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ev.push_back(e); HIP_TRY(hipEventRecord(e, s)); return e; }
+    double sumPairs() const { double ms = 0; for (size_t i = 0; i + 1 < ev.size(); i += 2) { float t = 0; (void) hipEventElapsedTime(&t, ev[i], ev[i + 1]); ms += t; } return ms; }
+    ~EventList() { for (auto e : ev) (void) hipEventDestroy(e); }
+};
+
+static bool cancelRequested(const phip_scene *sc) { return __atomic_load_n(sc->cancelFlag, __ATOMIC_RELAXED) != 0; }
+
+static void validateParams(const phip_scene *sc, const phip_render_params *p) {
     if (p->spp <= 0) throw std::invalid_argument("spp must be > 0");
-    if (p->integrator != PHIP_INTEGRATOR_DIRECT)
-    if (p->rr_depth <= 0) throw std::invalid_argument("'rrDepth' must be set to a value greater than zero!");                       /* integrator.cpp:219-220 */
-    if (p->integrator != PHIP_INTEGRATOR_DIRECT)
-    if (p->max_depth <= 0 && p->max_depth != -1) throw std::invalid_argument("'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); /* :222-223 */
-    if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
     if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::invalid_argument("unknown integrator kind");
     const bool direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
-    if (direct) {
+    if (!direct) {
+        if (p->rr_depth <= 0) throw std::invalid_argument("'rrDepth' must be set to a value greater than zero!");                       /* integrator.cpp:219-220 */
+        if (p->max_depth <= 0 && p->max_depth != -1) throw std::invalid_argument("'maxDepth' must be set to -1 (infinite) or a value greater than zero!"); /* :222-223 */
+    } else {
         if (p->emitter_samples < 0 || p->bsdf_samples < 0) throw std::invalid_argument("direct: emitterSamples and bsdfSamples must not be negative");
         if (p->emitter_samples + p->bsdf_samples <= 0) throw std::invalid_argument("direct: emitterSamples + bsdfSamples must be > 0");     /* Assert, direct.cpp:107 */
         if (p->emitter_samples + p->bsdf_samples >= (int) DEPTH_MASK) throw std::invalid_argument("direct: at most 65534 shading samples per camera sample");
     }
-    if (sc->dev.env.w > 0 && sc->envLevelCount <= 1 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
+    if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
+    if (p->sample_offset < 0 || p->sample_total < 0) throw std::invalid_argument("sample_offset / sample_total must not be negative");
+    if (p->sample_total != 0 && (long long) p->sample_offset + p->spp > p->sample_total) throw std::invalid_argument("sample_offset + spp exceeds sample_total");
+    if ((p->flags & PHIP_FLAG_SAMPLE_BUFFER) && (p->sample_offset != 0 || (p->flags & PHIP_FLAG_ACCUMULATE)))
+        throw std::invalid_argument("PHIP_FLAG_SAMPLE_BUFFER needs a complete render (sample_offset 0, no PHIP_FLAG_ACCUMULATE)");
+    if (sc->devs[0]->dev.env.w > 0 && sc->envLevelCount <= 1 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
         throw std::invalid_argument("envmap without MIP levels: directly visible background needs the filtered (EWA) lookup of envmap.cpp:395-407: "
                                     "pass the pyramid, render with hideEmitters or set PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
     const int bs = p->block_size > 0 ? p->block_size : 32;
     if (bs < 2 || bs > 128 || (bs & (bs - 1))) throw std::invalid_argument("block_size must be a power of two in [2,128] (mitsuba.cpp:233-239 allows 2..128)");
+    if (bs < sc->devs[0]->dev.film.border) throw std::invalid_argument("The block size must be larger than the image reconstruction filter radius!"); /* renderproc.cpp:175-176 */
     const int shardCount = p->shard_count > 0 ? p->shard_count : 1;
     if (p->shard_index < 0 || p->shard_index >= shardCount) throw std::invalid_argument("shard_index out of range");
-    if (p->device != sc->device) throw std::invalid_argument("scene was created on a different device");
-    HIP_TRY(hipSetDevice(sc->device));
-    std::lock_guard<std::mutex> lock(sc->renderLock);
-    sc->cancel.store(0);
+    if (p->n_devices < 0 || p->n_devices > PHIP_MAX_DEVICES) throw std::invalid_argument("n_devices out of range");
+}
 
-    DevScene D = sc->dev;
+/* One device's share of a render call: the blocks whose index in the reference's spiral order is congruent to shardIndex
+   modulo shardCount, into dOut (device memory of sd.device).  The caller holds the scene's render lock and has validated p. */
+static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params *p, int shardIndex, int shardCount, float *dOut, phip_stats *stats) {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    const bool direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
+    const int bs = p->block_size > 0 ? p->block_size : 32;
+    HIP_TRY(hipSetDevice(sd.device));
+
+    DevScene D = sd.dev;
     D.film.blockSize = bs;
-    if (bs < D.film.border) throw std::invalid_argument("The block size must be larger than the image reconstruction filter radius!"); /* renderproc.cpp:175-176 */
     const int W = D.film.width, H = D.film.height;
     int tileShift = 0; while ((1 << tileShift) < bs) ++tileShift;
 
     /* tile -> shard assignment in the reference's spiral order (cached between calls with the same layout) */
     const int tilesX = (W + bs - 1) / bs, tilesY = (H + bs - 1) / bs;
-    if (sc->tileKey[0] != bs || sc->tileKey[1] != p->shard_index || sc->tileKey[2] != shardCount) {
+    if (sd.tileKey[0] != bs || sd.tileKey[1] != shardIndex || sd.tileKey[2] != shardCount) {
         std::vector<std::pair<int, int>> spiral;
         spiralBlocks(W, H, bs, spiral);
         std::vector<int32_t> tileSlot((size_t) tilesX * tilesY, -1);
         std::vector<uint32_t> tileOrigin;
         for (size_t i = 0; i < spiral.size(); ++i) {
-            if ((int) (i % (size_t) shardCount) != p->shard_index) continue;
+            if ((int) (i % (size_t) shardCount) != shardIndex) continue;
             tileSlot[(size_t) spiral[i].second * tilesX + spiral[i].first] = (int32_t) tileOrigin.size();
             tileOrigin.push_back((uint32_t) (spiral[i].first * bs) | ((uint32_t) (spiral[i].second * bs) << 16));
         }
-        sc->nLocalTiles = (uint32_t) tileOrigin.size();
-        if (tileOrigin.empty()) sc->tileOrigin.alloc(1);
-        else sc->tileOrigin.upload(tileOrigin.data(), tileOrigin.size());
-        sc->tileSlot.upload(tileSlot.data(), tileSlot.size());
-        sc->tileKey[0] = bs; sc->tileKey[1] = p->shard_index; sc->tileKey[2] = shardCount;
+        sd.nLocalTiles = (uint32_t) tileOrigin.size();
+        sd.localPixels = 0;
+        for (uint32_t o : tileOrigin) sd.localPixels += (unsigned long long) std::min(bs, W - (int) (o & 0xFFFFu)) * std::min(bs, H - (int) (o >> 16));
+        if (tileOrigin.empty()) sd.tileOrigin.alloc(1);
+        else sd.tileOrigin.upload(tileOrigin.data(), tileOrigin.size());
+        sd.tileSlot.upload(tileSlot.data(), tileSlot.size());
+        sd.tileKey[0] = bs; sd.tileKey[1] = shardIndex; sd.tileKey[2] = shardCount;
     }
-    const uint32_t nLocalTiles = sc->nLocalTiles;
+    const uint32_t nLocalTiles = sd.nLocalTiles;
 
-    hipStream_t stream = (hipStream_t) p->stream;
-    if (!stream) { if (!sc->stream) HIP_TRY(hipStreamCreate(&sc->stream)); stream = sc->stream; }
+    hipStream_t stream = (p->n_devices <= 1) ? (hipStream_t) p->stream : nullptr;    /* a caller's stream belongs to one device */
+    if (!stream) { if (!sd.stream) HIP_TRY(hipStreamCreate(&sd.stream)); stream = sd.stream; }
 
     /* passes: bound the per-sample buffer (16 B per sample id) */
     const unsigned long long tilePixels = (unsigned long long) bs * bs;
@@ -712,66 +789,94 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         sppPerPass = (uint32_t) std::min<unsigned long long>(cap, (unsigned long long) p->spp);
     }
     const bool keepSamples = (p->flags & PHIP_FLAG_SAMPLE_BUFFER) != 0;
-    if (keepSamples) { sc->sampleOut.alloc((size_t) W * H * (size_t) p->spp); HIP_TRY(hipMemsetAsync(sc->sampleOut.p, 0, sc->sampleOut.n * sizeof(float4), stream)); }
-    sc->haveSamples = keepSamples; sc->lastSpp = (uint32_t) p->spp;
+    if (keepSamples) { sd.sampleOut.alloc((size_t) W * H * (size_t) p->spp); HIP_TRY(hipMemsetAsync(sd.sampleOut.p, 0, sd.sampleOut.n * sizeof(float4), stream)); }
+    sd.haveSamples = keepSamples; sd.lastSpp = (uint32_t) p->spp;
 
-    /* path pool */
     const unsigned long long idsFirstPass = idsPerSpp * sppPerPass;
-    /* pool size: large enough that per-launch fixed costs vanish, small enough that the tail (slots
-       running dry at the end of a pass) stays a small fraction of the pass (measured: 4M / 8M slots) */
-    const unsigned long long poolCap = idsFirstPass >= (256ull << 20) ? (1ull << 23) : (1ull << 22);
-    uint32_t capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
-    capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
-    if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
-    const uint32_t nWaves = capacity / 64, nBlocks = capacity / BLOCK;
-    if (sc->rayO.n < capacity) {
-        sc->rayO.alloc(capacity); sc->rayD.alloc(capacity); sc->hit.alloc(capacity); sc->thr.alloc(capacity);
-        sc->mis.alloc(capacity); sc->info.alloc(capacity); sc->state.alloc(capacity); sc->shadow.alloc(3 * (size_t) capacity);
-        sc->shadowCount.alloc(nBlocks); sc->blockDead.alloc(nBlocks); sc->blockShard.alloc(nBlocks); sc->stat.alloc((size_t) ST_COUNT * nWaves); sc->spill.alloc((size_t) capacity * SPILL_DEPTH);
-        sc->spill8.alloc((size_t) nWaves * 8 * SPILL8);
-    }
-    if (direct && sc->camHit.n < capacity) sc->camHit.alloc(capacity);
-    PathPool P;
-    P.camHit = sc->camHit.p;
-    P.rayO = sc->rayO.p; P.rayD = sc->rayD.p; P.hit = sc->hit.p; P.thr = sc->thr.p; P.mis = sc->mis.p; P.info = sc->info.p; P.state = sc->state.p;
-    P.shadow = sc->shadow.p; P.shadowCount = sc->shadowCount.p; P.blockDead = sc->blockDead.p; P.stat = sc->stat.p; P.spill = sc->spill.p; P.spill8 = sc->spill8.p; P.capacity = capacity; P.nWaves = nWaves;
-    if (sc->L.n < idsFirstPass) sc->L.alloc((size_t) idsFirstPass);
+    if (sd.L.n < idsFirstPass) sd.L.alloc((size_t) idsFirstPass);
+
+    /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
+    bool fused = !direct && sc->fitsLds && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
+    if (const char *e = getenv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
+    sd.fused = fused;
 
     phip_stats st; memset(&st, 0, sizeof(st));
     const bool timing = (p->flags & PHIP_FLAG_KERNEL_TIMING) != 0;
-    std::vector<hipEvent_t> evTrace, evShadow, evShade, evFilm;
-    auto newEvent = [&](std::vector<hipEvent_t> &v) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); v.push_back(e); return e; };
+    EventList evTrace, evShadow, evShade, evFilm, evFused;
+    const unsigned long long samplesTotal = sd.localPixels;                  /* crop pixels of this device's blocks */
 
-    HIP_TRY(hipMemsetAsync(sc->invalid.p, 0, sizeof(unsigned long long), stream));
-    const dim3 grid((capacity + BLOCK - 1) / BLOCK), block(BLOCK);
+    HIP_TRY(hipMemsetAsync(sd.invalid.p, 0, sizeof(unsigned long long), stream));
+    int nCU = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, sd.device) == hipSuccess) nCU = prop.multiProcessorCount; }
     const size_t ldsBytes = traversalLdsBytes(D);
-    /* persistent kernels: exactly the resident set (TRACE_WAVES waves per SIMD = TRACE_WAVES blocks of 256 per CU) */
-    int nCU = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) nCU = prop.multiProcessorCount; }
-    /* ... but never more blocks per CU than their LDS (stack + node/record cache) allows: a persistent grid larger than
+    const dim3 block(BLOCK);
+    Counters hc;
+    bool cancelled = false;
+    bool accumulate = (p->flags & PHIP_FLAG_ACCUMULATE) != 0;
+    unsigned long long samplesDone = 0;
+
+    /* wavefront state (allocated only when that path runs) */
+    uint32_t capacity = 0, nWaves = 0, nBlocks = 0;
+    PathPool P; memset(&P, 0, sizeof(P));
+    bool merged = false;
+    if (!fused) {
+        /* pool size: large enough that per-launch fixed costs vanish, small enough that the tail (slots
+           running dry at the end of a pass) stays a small fraction of the pass (measured: 4M / 8M slots) */
+        const unsigned long long poolCap = idsFirstPass >= (256ull << 20) ? (1ull << 23) : (1ull << 22);
+        capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
+        capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
+        if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
+        nWaves = capacity / 64; nBlocks = capacity / BLOCK;
+        if (sd.rayO.n < capacity) {
+            sd.rayO.alloc(capacity); sd.rayD.alloc(capacity); sd.hit.alloc(capacity); sd.thr.alloc(capacity);
+            sd.mis.alloc(capacity); sd.info.alloc(capacity); sd.state.alloc(capacity); sd.shadow.alloc(3 * (size_t) capacity);
+            sd.shadowCount.alloc(nBlocks); sd.blockDead.alloc(nBlocks); sd.blockShard.alloc(nBlocks); sd.spill.alloc((size_t) capacity * SPILL_DEPTH);
+        }
+        if (sd.stat.n < (size_t) ST_COUNT * nWaves) sd.stat.alloc((size_t) ST_COUNT * nWaves);
+        if (direct && sd.camHit.n < capacity) sd.camHit.alloc(capacity);
+        P.camHit = sd.camHit.p;
+        P.rayO = sd.rayO.p; P.rayD = sd.rayD.p; P.hit = sd.hit.p; P.thr = sd.thr.p; P.mis = sd.mis.p; P.info = sd.info.p; P.state = sd.state.p;
+        P.shadow = sd.shadow.p; P.shadowCount = sd.shadowCount.p; P.blockDead = sd.blockDead.p; P.stat = sd.stat.p; P.spill = sd.spill.p; P.capacity = capacity; P.nWaves = nWaves;
+        /* big trees: closest-hit and any-hit rays share one persistent launch (measured +2..4 % on the 250k-triangle scenes;
+           on small trees the plain per-slot closest-hit launch wins, so the kernels stay separate there) */
+        merged = sc->traversal == 2 && sc->bvh.nNodes >= 64;
+        if (const char *e = getenv("PHIP_MERGED")) merged = sc->traversal == 2 && atoi(e) != 0;
+    }
+    sd.mergedRays = merged;
+    /* persistent kernels: exactly the resident set (TRACE_WAVES waves per SIMD = TRACE_WAVES blocks of 256 per CU)
+       ... but never more blocks per CU than their LDS (stack + node/record cache) allows: a persistent grid larger than
        the resident set would serialise */
     const int ldsFit = (int) std::max<size_t>(1, (size_t) (160 * 1024) / std::max<size_t>(ldsBytes + 64, 1));
     auto persistentGrid = [&](int blocksPerCU) {
         return dim3((unsigned) std::max(1, std::min<int>(nCU * std::min(blocksPerCU, ldsFit), (int) ((capacity + BLOCK - 1) / BLOCK))));
     };
+    const dim3 grid((capacity + BLOCK - 1) / BLOCK);
     const dim3 pgrid = persistentGrid(TRACE_WAVES), pgridTrace = persistentGrid(TRACE_P_WAVES), pgridRays = persistentGrid(RAYS_WAVES);
-    Counters hc;
-    bool cancelled = false;
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
-    /* big trees: closest-hit and any-hit rays share one persistent launch (measured +2..4 % on the 250k-triangle scenes;
-       on the Cornell box the plain per-slot closest-hit launch wins, so the kernels stay separate there) */
-    bool merged = sc->traversal == 2 && sc->bvh.nNodes >= 64;
-    if (const char *e = getenv("PHIP_MERGED")) merged = sc->traversal == 2 && atoi(e) != 0;
-    sc->mergedRays = merged;
+
+    /* fused path: resident grid and per-wave statistics rows */
+    dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
+    if (fused) {
+        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, ldsBytes));
+        if (const char *e = getenv("PHIP_MEGA_BLOCKS")) perCU = std::max(1, std::min(perCU, atoi(e)));
+        if (perCU <= 0) throw std::runtime_error("k_mega does not fit a compute unit");
+        megaGrid = dim3((unsigned) (nCU * perCU));
+        M.nWaves = megaGrid.x * (BLOCK / 64);
+        if (sd.stat.n < (size_t) ST_COUNT * M.nWaves) sd.stat.alloc((size_t) ST_COUNT * M.nWaves);
+        M.stat = sd.stat.p; M.nextId = sd.megaNext.p;
+        int *dflag = nullptr; HIP_TRY(hipHostGetDevicePointer((void **) &dflag, sc->cancelFlag, 0));
+        M.cancel = dflag;
+        P.stat = sd.stat.p; P.nWaves = M.nWaves;               /* k_reduce_stats reads these two */
+    }
 
     for (uint32_t sppDone = 0; sppDone < (uint32_t) p->spp && !cancelled; sppDone += sppPerPass) {
         RenderConst rc;
-        rc.sppPass = std::min(sppPerPass, (uint32_t) p->spp - sppDone); rc.sppFirst = sppDone;
+        rc.sppPass = std::min(sppPerPass, (uint32_t) p->spp - sppDone); rc.sppFirst = (uint32_t) p->sample_offset + sppDone;
         rc.sppMagic = (uint32_t) std::min<unsigned long long>((1ull << 32) / rc.sppPass, 0xFFFFFFFFull);
         rc.tilePixels = (uint32_t) tilePixels; rc.tileShift = (uint32_t) tileShift; rc.nLocalTiles = nLocalTiles;
         rc.totalIds = idsPerSpp * rc.sppPass;
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
-        rc.seed = p->seed; rc.tileOrigin = sc->tileOrigin.p; rc.countAlive = 0;
-        rc.diffScaleFactor = 1.0f / sqrtf((float) p->spp);
+        rc.seed = p->seed; rc.tileOrigin = sd.tileOrigin.p; rc.countAlive = 0;
+        rc.diffScaleFactor = 1.0f / sqrtf((float) (p->sample_total > 0 ? p->sample_total : p->spp));
         rc.emitterSamples = direct ? p->emitter_samples : 0; rc.bsdfSamples = direct ? p->bsdf_samples : 0;
         if (direct) {   /* direct.cpp:130-138 */
             const size_t sum = (size_t) p->emitter_samples + (size_t) p->bsdf_samples;
@@ -783,123 +888,297 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
             rc.weightBSDF = rc.weightLum = 1.0f; rc.fracBSDF = rc.fracLum = 0.5f;
         }
         rc.envFiltered = (sc->envLevelCount > 1 && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND)) ? 1u : 0u;
-        /* static share: the first 3/4 of every slot's samples; the remainder is handed out dynamically */
-        {
-            const unsigned long long perSlot = rc.totalIds / capacity;
-            unsigned long long staticPerSlot = perSlot - perSlot / 4;
-            if (const char *e = getenv("PHIP_STATIC_PERCENT")) staticPerSlot = perSlot * (unsigned long long) atoi(e) / 100;
-            rc.staticIds = staticPerSlot * capacity;
-            const unsigned long long dyn = rc.totalIds - rc.staticIds;
-            rc.shardIds = (dyn + DYN_SHARDS - 1) / DYN_SHARDS;
-            rc.dynCounter = sc->dynCounter.p; rc.blockShard = sc->blockShard.p;
-            HIP_TRY(hipMemsetAsync(sc->blockShard.p, 0, nBlocks * sizeof(uint32_t), stream));
-            HIP_TRY(hipMemsetAsync(sc->dynCounter.p, 0, DYN_SHARDS * DYN_STRIDE * sizeof(unsigned long long), stream));
-        }
-
-        HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
-        HIP_TRY(hipMemsetAsync(sc->stat.p, 0, (size_t) ST_COUNT * nWaves * sizeof(unsigned long long), stream));
-        HIP_TRY(hipMemsetAsync(sc->shadowCount.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
-        HIP_TRY(hipMemsetAsync(sc->blockDead.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) sc->state.p, (int) F_FRESH, (size_t) capacity, stream));
-        if (rc.totalIds) HIP_TRY(hipMemsetAsync(sc->L.p, 0, (size_t) rc.totalIds * sizeof(float4), stream));
-
-        HIP_TRY(hipStreamSynchronize(stream));
-        const auto tLoop0 = clk::now();
+        rc.staticIds = 0; rc.shardIds = 0; rc.dynCounter = sd.dynCounter.p; rc.blockShard = sd.blockShard.p;
+        HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), stream));
         uint32_t iter = 0;
-        bool done = rc.totalIds == 0;
-        while (!done) {
-            const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
-            rc.countAlive = check ? 1 : 0;
-            if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
+
+        if (fused) {
+            /* ---- one launch: every path of the pass from camera sample to its last vertex (k_mega.h) ---- */
+            HIP_TRY(hipMemsetAsync(sd.megaNext.p, 0, sizeof(unsigned long long), stream));
+            HIP_TRY(hipMemsetAsync(sd.stat.p, 0, (size_t) ST_COUNT * M.nWaves * sizeof(unsigned long long), stream));
+            if (rc.totalIds) {
+                if (timing) evFused.record(stream);
+                phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaGrid, ldsBytes, stream, D, M, rc, sd.L.p);
+                if (timing) evFused.record(stream);
+                iter = 1;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (cancelRequested(sc)) cancelled = true;
+        } else {
+            /* static share: the first 3/4 of every slot's samples; the remainder is handed out dynamically */
             {
-                typedef void (*ShadeKernel)(DevScene, PathPool, RenderConst, float4 *);
-#define SHADE_ROW(S_, F_) { k_shade<0, S_, F_>, k_shade<MM_ROUGH, S_, F_>, k_shade<MM_DIELECTRIC, S_, F_>, k_shade<MM_ALL, S_, F_> }
-                static const ShadeKernel table[4][2][4] = { { SHADE_ROW(false, 0), SHADE_ROW(true, 0) }, { SHADE_ROW(false, 1), SHADE_ROW(true, 1) },
-                                                            { SHADE_ROW(false, 2), SHADE_ROW(true, 2) }, { SHADE_ROW(false, 3), SHADE_ROW(true, 3) } };
-#undef SHADE_ROW
-                /* `direct`: leaf BSDF models = diffuse only / all, strictNormals at run time */
-                static const ShadeKernel directTable[4][2] = { { k_shade_direct<0, 0>, k_shade_direct<MM_ALL, 0> }, { k_shade_direct<0, 1>, k_shade_direct<MM_ALL, 1> },
-                                                               { k_shade_direct<0, 2>, k_shade_direct<MM_ALL, 2> }, { k_shade_direct<0, 3>, k_shade_direct<MM_ALL, 3> } };
-                const int feat = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0);     /* environment emitter, bitmap textures */
-                if (direct) hipLaunchKernelGGL(directTable[feat][(sc->materialMask & MM_ALL) ? 1 : 0], grid, block, 0, stream, D, P, rc, sc->L.p);
-                else hipLaunchKernelGGL(table[feat][rc.strictNormals ? 1 : 0][sc->materialMask & MM_ALL], grid, block, 0, stream, D, P, rc, sc->L.p);
+                const unsigned long long perSlot = rc.totalIds / capacity;
+                unsigned long long staticPerSlot = perSlot - perSlot / 4;
+                if (const char *e = getenv("PHIP_STATIC_PERCENT")) staticPerSlot = perSlot * (unsigned long long) atoi(e) / 100;
+                rc.staticIds = staticPerSlot * capacity;
+                const unsigned long long dyn = rc.totalIds - rc.staticIds;
+                rc.shardIds = (dyn + DYN_SHARDS - 1) / DYN_SHARDS;
+                HIP_TRY(hipMemsetAsync(sd.blockShard.p, 0, nBlocks * sizeof(uint32_t), stream));
+                HIP_TRY(hipMemsetAsync(sd.dynCounter.p, 0, DYN_SHARDS * DYN_STRIDE * sizeof(unsigned long long), stream));
             }
-            if (timing) HIP_TRY(hipEventRecord(newEvent(evShade), stream));
-            if (merged) {
-                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-                hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sc->L.p);
-                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-            } else {
-                if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
-                if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sc->L.p);
-                else if (sc->traversal == 1) hipLaunchKernelGGL(k_shadow8, grid, block, 0, stream, D, P, sc->L.p);
-                else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sc->L.p);
-                if (timing) HIP_TRY(hipEventRecord(newEvent(evShadow), stream));
-                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
-                if (sc->traversal == 2 && (sc->bvh.nNodes >= 64 || forcePersist)) { if (sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p<false>, pgridTrace, block, ldsBytes, stream, D, P); else hipLaunchKernelGGL(k_trace_p<true>, pgridTrace, block, ldsBytes, stream, D, P); }
-                else if (sc->traversal == 2) hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);   /* tiny trees: the plain per-slot launch wins (measured) */
-                else if (sc->traversal == 1) hipLaunchKernelGGL(k_trace8, grid, block, 0, stream, D, P);
-                else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);
-                if (timing) HIP_TRY(hipEventRecord(newEvent(evTrace), stream));
+            HIP_TRY(hipMemsetAsync(sd.stat.p, 0, (size_t) ST_COUNT * nWaves * sizeof(unsigned long long), stream));
+            HIP_TRY(hipMemsetAsync(sd.shadowCount.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(sd.blockDead.p, 0, (size_t) nBlocks * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) sd.state.p, (int) F_FRESH, (size_t) capacity, stream));
+            /* (no clear of L: the first vertex of every sample -- or its camera ray leaving the scene -- writes L[id]) */
+
+            HIP_TRY(hipStreamSynchronize(stream));
+            const auto tLoop0 = clk::now();
+            bool done = rc.totalIds == 0;
+            const int feat = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0);     /* environment emitter, bitmap textures */
+            while (!done) {
+                const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
+                rc.countAlive = check ? 1 : 0;
+                if (timing) evShade.record(stream);
+                if (direct) phipLaunchShadeDirect(feat, sc->materialMask, grid, stream, D, P, rc, sd.L.p);
+                else phipLaunchShade(feat, rc.strictNormals != 0, sc->materialMask, grid, stream, D, P, rc, sd.L.p);
+                if (timing) evShade.record(stream);
+                if (merged) {
+                    if (timing) evTrace.record(stream);
+                    hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
+                    if (timing) evTrace.record(stream);
+                } else {
+                    if (timing) evShadow.record(stream);
+                    if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sd.L.p);
+                    else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sd.L.p);
+                    if (timing) evShadow.record(stream);
+                    if (timing) evTrace.record(stream);
+                    if (sc->traversal == 2 && sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p<false>, pgridTrace, block, ldsBytes, stream, D, P);
+                    else if (sc->traversal == 2 && forcePersist) hipLaunchKernelGGL(k_trace_p<true>, pgridTrace, block, ldsBytes, stream, D, P);
+                    else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);     /* tiny trees: the plain per-slot launch wins (measured) */
+                    if (timing) evTrace.record(stream);
+                }
+                ++iter;
+                if (check) {
+                    /* termination test: only the live-slot row (and, for a progress callback, the finished-sample row) is summed inside the loop */
+                    HIP_TRY(hipMemsetAsync(&sd.counters.p->total[ST_ALIVE], 0, sizeof(unsigned long long), stream));
+                    hipLaunchKernelGGL(k_reduce_stats, dim3(1, REDUCE_SPLIT), dim3(256), 0, stream, P, sd.counters.p, (int) ST_ALIVE);
+                    HIP_TRY(hipMemcpyAsync(&hc.total[ST_ALIVE], &sd.counters.p->total[ST_ALIVE], sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                    if (p->progress) {
+                        HIP_TRY(hipMemsetAsync(&sd.counters.p->total[ST_SAMPLES], 0, sizeof(unsigned long long), stream));
+                        hipLaunchKernelGGL(k_reduce_stats, dim3(1, REDUCE_SPLIT), dim3(256), 0, stream, P, sd.counters.p, (int) ST_SAMPLES);
+                        HIP_TRY(hipMemcpyAsync(&hc.total[ST_SAMPLES], &sd.counters.p->total[ST_SAMPLES], sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                    }
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    if (hc.total[ST_ALIVE] == 0) done = true;
+                    if (p->progress) p->progress(p->progress_user, sd.device, samplesDone + hc.total[ST_SAMPLES], samplesTotal * (unsigned long long) p->spp);
+                    if (cancelRequested(sc)) { cancelled = true; done = true; }
+                }
             }
-            ++iter;
-            if (check) {
-                /* termination test: only the live-slot row is summed inside the loop */
-                HIP_TRY(hipMemsetAsync(&sc->counters.p->total[ST_ALIVE], 0, sizeof(unsigned long long), stream));
-                hipLaunchKernelGGL(k_reduce_stats, dim3(1, REDUCE_SPLIT), dim3(256), 0, stream, P, sc->counters.p, (int) ST_ALIVE);
-                HIP_TRY(hipMemcpyAsync(&hc.total[ST_ALIVE], &sc->counters.p->total[ST_ALIVE], sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                if (hc.total[ST_ALIVE] == 0) done = true;
-                if (sc->cancel.load()) { cancelled = true; done = true; }
-            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "[phip] setup %.2f ms, loop %.2f ms (%u iterations)\n", std::chrono::duration<double, std::milli>(tLoop0 - t0).count(), std::chrono::duration<double, std::milli>(clk::now() - tLoop0).count(), iter);
         }
-        HIP_TRY(hipGetLastError());
         st.iterations += iter;
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "[phip] setup %.2f ms, loop %.2f ms (%u iterations)\n", std::chrono::duration<double, std::milli>(tLoop0 - t0).count(), std::chrono::duration<double, std::milli>(clk::now() - tLoop0).count(), iter);
+        if (cancelled) break;                                   /* L is incomplete: no film pass */
+
         /* film */
-        if (timing) HIP_TRY(hipEventRecord(newEvent(evFilm), stream));
+        if (timing) evFilm.record(stream);
         {
             const dim3 fg((W + 15) / 16, (H + 15) / 16);
             const int reach = (int) std::floor(D.film.radius + 0.5f);
+            const int acc = (sppDone > 0 || accumulate) ? 1 : 0;
             if (reach <= FILM_MAX_REACH && !getenv("PHIP_FILM_GENERIC"))
                 if (reach <= 2)
-                    hipLaunchKernelGGL(k_film_tiled<2>, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
-                                       sppDone > 0 ? 1 : 0, sc->invalid.p, reach);
+                    hipLaunchKernelGGL(k_film_tiled<2>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
+                                       acc, sd.invalid.p, reach);
                 else
-                    hipLaunchKernelGGL(k_film_tiled<FILM_MAX_REACH>, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
-                                       sppDone > 0 ? 1 : 0, sc->invalid.p, reach);
+                    hipLaunchKernelGGL(k_film_tiled<FILM_MAX_REACH>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
+                                       acc, sd.invalid.p, reach);
             else
-                hipLaunchKernelGGL(k_film, fg, block, 0, stream, D, rc, (const float4 *) sc->L.p, (const int32_t *) sc->tileSlot.p, tilesX, dOut,
-                                   sppDone > 0 ? 1 : 0, sc->invalid.p);
+                hipLaunchKernelGGL(k_film, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
+                                   acc, sd.invalid.p);
         }
-        if (timing) HIP_TRY(hipEventRecord(newEvent(evFilm), stream));
+        if (timing) evFilm.record(stream);
         if (keepSamples && rc.totalIds) {
             const size_t n = (size_t) W * H * rc.sppPass;
-            hipLaunchKernelGGL(k_export_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, D, rc, (const float4 *) sc->L.p,
-                               (const int32_t *) sc->tileSlot.p, tilesX, sc->sampleOut.p, (uint32_t) p->spp);
+            hipLaunchKernelGGL(k_export_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, D, rc, (const float4 *) sd.L.p,
+                               (const int32_t *) sd.tileSlot.p, tilesX, sd.sampleOut.p, (uint32_t) p->spp);
         }
-        HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(Counters), stream));
-        hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, stream, P, sc->counters.p, 0);
-        HIP_TRY(hipMemcpyAsync(&hc, sc->counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), stream));
+        hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, stream, P, sd.counters.p, 0);
+        HIP_TRY(hipMemcpyAsync(&hc, sd.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         st.samples += hc.total[ST_SAMPLES]; st.closest_rays += hc.total[ST_CLOSEST_RAYS]; st.shadow_rays += hc.total[ST_SHADOW_RAYS];
         st.path_vertices += hc.total[ST_VERTICES]; st.closest_node_visits += hc.total[ST_NODE]; st.closest_triangle_tests += hc.total[ST_TRI];
         st.shadow_node_visits += hc.total[ST_SH_NODE]; st.shadow_triangle_tests += hc.total[ST_SH_TRI];
+        samplesDone += hc.total[ST_SAMPLES];
+        if (p->progress) p->progress(p->progress_user, sd.device, samplesDone, samplesTotal * (unsigned long long) p->spp);
     }
-    if (nLocalTiles == 0) { HIP_TRY(hipMemsetAsync(dOut, 0, (size_t) W * H * 5 * sizeof(float), stream)); HIP_TRY(hipStreamSynchronize(stream)); }
+    if ((nLocalTiles == 0 || cancelled) && !accumulate) { HIP_TRY(hipMemsetAsync(dOut, 0, (size_t) W * H * 5 * sizeof(float), stream)); HIP_TRY(hipStreamSynchronize(stream)); }
     unsigned long long inv = 0;
-    HIP_TRY(hipMemcpy(&inv, sc->invalid.p, sizeof(inv), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&inv, sd.invalid.p, sizeof(inv), hipMemcpyDeviceToHost));
     st.invalid_samples = inv;
-    auto sumPairs = [&](std::vector<hipEvent_t> &v) { double ms = 0; for (size_t i = 0; i + 1 < v.size(); i += 2) { float t = 0; (void) hipEventElapsedTime(&t, v[i], v[i + 1]); ms += t; } for (auto e : v) (void) hipEventDestroy(e); return ms; };
-    st.trace_kernel_ms = sumPairs(evTrace); st.shadow_kernel_ms = sumPairs(evShadow);
-    st.shade_kernel_ms = sumPairs(evShade); st.film_kernel_ms = sumPairs(evFilm);
+    st.trace_kernel_ms = evTrace.sumPairs(); st.shadow_kernel_ms = evShadow.sumPairs();
+    st.shade_kernel_ms = evShade.sumPairs(); st.film_kernel_ms = evFilm.sumPairs(); st.fused_kernel_ms = evFused.sumPairs();
+    st.fused = fused ? 1u : 0u; st.n_devices = 1;
     st.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
-    algorithmicBytes(sc, st);
+    algorithmicBytes(merged, st, (double) W * H);
     if (stats) *stats = st;
-    if (cancelled) return setErr(PHIP_ERR_CANCELLED, "rendering was cancelled");
-    return PHIP_OK;
+    return cancelled ? PHIP_ERR_CANCELLED : PHIP_OK;
+}
+
+/* ---- RCCL, bound at the first multi-GPU render (librccl is not a load-time dependency of single-GPU users; a process that
+   already carries an RCCL -- PyTorch does -- keeps exactly one copy) ---- */
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::mutex lock;
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;       /* one communicator clique per device list, kept for the process */
+    void bind() {
+        if (handle) return;
+        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { handle = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (handle) break; }
+        if (!handle) throw std::runtime_error(std::string("multi-GPU render needs librccl: ") + dlerror());
+        auto sym = [&](const char *n) { void *s = dlsym(handle, n); if (!s) throw std::runtime_error(std::string("librccl lacks ") + n); return s; };
+        CommInitAll = (decltype(CommInitAll)) sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy)) sym("ncclCommDestroy");
+        Reduce = (decltype(Reduce)) sym("ncclReduce"); GroupStart = (decltype(GroupStart)) sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd)) sym("ncclGroupEnd"); GetErrorString = (decltype(GetErrorString)) sym("ncclGetErrorString");
+    }
+    void check(ncclResult_t r, const char *what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + (GetErrorString ? GetErrorString(r) : "RCCL error")); }
+    const std::vector<ncclComm_t> &clique(const std::vector<int> &devices) {
+        auto it = comms.find(devices);
+        if (it != comms.end()) return it->second;
+        std::vector<ncclComm_t> c(devices.size());
+        check(CommInitAll(c.data(), (int) devices.size(), devices.data()), "ncclCommInitAll");
+        return comms.emplace(devices, std::move(c)).first->second;
+    }
+};
+Rccl g_rccl;
+
+__global__ void k_add_films(float *dst, const float *src, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+} // namespace
+
+/* The call's shard on p->n_devices GPUs: one host thread + stream per device, blocks dealt round-robin in the reference's
+   spiral order, films merged on devices[0] by one ncclReduce(sum) -- the in-process analogue of the reference's workers
+   handing ImageBlocks to BlockedRenderProcess::processResult (renderproc.cpp:142-149). */
+static int renderMultiDevice(phip_scene *sc, const phip_render_params *p, float *dOut, phip_stats *stats) {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    const int n = p->n_devices;
+    const bool alias = (p->flags & PHIP_FLAG_ALIAS_DEVICES) != 0;
+    int visible = 0; HIP_TRY(hipGetDeviceCount(&visible));
+    if (p->devices[0] != sc->devs[0]->device) throw std::invalid_argument("devices[0] must be the scene's device");
+    std::vector<int> devices(p->devices, p->devices + n);
+    bool distinct = true;
+    for (int i = 0; i < n; ++i) {
+        if (devices[i] < 0 || devices[i] >= visible) throw std::invalid_argument("device ordinal out of range");
+        for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) distinct = false;
+    }
+    if (!distinct && !alias) throw std::invalid_argument("a device is listed twice (PHIP_FLAG_ALIAS_DEVICES allows it for tests)");
+    /* replicas: position i of the list renders on devs[i] */
+    for (int i = 1; i < n; ++i) {
+        if ((int) sc->devs.size() > i && sc->devs[i]->device == devices[i]) continue;
+        if ((int) sc->devs.size() > i) sc->devs.resize(i);          /* a different device list: rebuild from here */
+        replicateScene(sc, devices[i]);
+    }
+    const int W = sc->devs[0]->dev.film.width, H = sc->devs[0]->dev.film.height;
+    const size_t filmFloats = (size_t) W * H * 5;
+    const int S = p->shard_count > 0 ? p->shard_count : 1, s = p->shard_index;
+    std::vector<float *> out(n, nullptr);
+    out[0] = dOut;
+    for (int i = 1; i < n; ++i) {
+        SceneDev &sd = *sc->devs[i];
+        HIP_TRY(hipSetDevice(sd.device));
+        if (sd.film.n < filmFloats) sd.film.alloc(filmFloats);
+        out[i] = sd.film.p;
+    }
+    std::vector<phip_stats> st(n);
+    std::vector<int> rc(n, PHIP_OK);
+    std::vector<std::string> err(n);
+    std::vector<std::thread> workers;
+    phip_render_params q = *p;
+    q.flags &= ~PHIP_FLAG_SAMPLE_BUFFER;                         /* per-sample export is a single-device test hook */
+    for (int i = 0; i < n; ++i) {
+        workers.emplace_back([&, i]() {
+            try {
+                phip_render_params mine = q;
+                if (i > 0) mine.flags &= ~PHIP_FLAG_ACCUMULATE;   /* only the root's buffer carries the previous calls */
+                rc[i] = renderOnDevice(sc, *sc->devs[i], &mine, s + S * i, S * n, out[i], &st[i]);
+            } catch (const std::invalid_argument &e) { rc[i] = PHIP_ERR_INVALID; err[i] = e.what(); }
+              catch (const std::exception &e) { rc[i] = PHIP_ERR_DEVICE; err[i] = e.what(); }
+        });
+    }
+    for (auto &w : workers) w.join();
+    bool cancelled = false;
+    for (int i = 0; i < n; ++i) {
+        if (rc[i] == PHIP_ERR_CANCELLED) cancelled = true;
+        else if (rc[i] != PHIP_OK) return setErr(rc[i], "device " + std::to_string(devices[i]) + ": " + err[i]);
+    }
+    /* ---- merge: film(devices[0]) += sum of the others ---- */
+    const auto tr0 = clk::now();
+    if (!cancelled) {
+        if (distinct) {
+            std::lock_guard<std::mutex> g(g_rccl.lock);
+            g_rccl.bind();
+            const std::vector<ncclComm_t> &comm = g_rccl.clique(devices);
+            g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+            for (int i = 0; i < n; ++i) {
+                SceneDev &sd = *sc->devs[i];
+                HIP_TRY(hipSetDevice(sd.device));
+                g_rccl.check(g_rccl.Reduce(out[i], out[i], filmFloats, ncclFloat, ncclSum, 0, comm[i], sd.stream), "ncclReduce");
+            }
+            g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+            for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(sc->devs[i]->device)); HIP_TRY(hipStreamSynchronize(sc->devs[i]->stream)); }
+        } else {
+            /* aliased devices (test hook): the films are in the same memory, a kernel sums them */
+            HIP_TRY(hipSetDevice(devices[0]));
+            for (int i = 1; i < n; ++i)
+                hipLaunchKernelGGL(k_add_films, dim3((unsigned) ((filmFloats + 255) / 256)), dim3(256), 0, sc->devs[0]->stream, out[0], (const float *) out[i], filmFloats);
+            HIP_TRY(hipStreamSynchronize(sc->devs[0]->stream));
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipSetDevice(devices[0]));
+    if (stats) {
+        phip_stats t; memset(&t, 0, sizeof(t));
+        for (int i = 0; i < n; ++i) {
+            const phip_stats &a = st[i];
+            t.samples += a.samples; t.closest_rays += a.closest_rays; t.shadow_rays += a.shadow_rays; t.path_vertices += a.path_vertices;
+            t.closest_node_visits += a.closest_node_visits; t.closest_triangle_tests += a.closest_triangle_tests;
+            t.shadow_node_visits += a.shadow_node_visits; t.shadow_triangle_tests += a.shadow_triangle_tests;
+            t.invalid_samples += a.invalid_samples; t.iterations = std::max(t.iterations, a.iterations);
+            t.trace_kernel_ms = std::max(t.trace_kernel_ms, a.trace_kernel_ms); t.shadow_kernel_ms = std::max(t.shadow_kernel_ms, a.shadow_kernel_ms);
+            t.shade_kernel_ms = std::max(t.shade_kernel_ms, a.shade_kernel_ms); t.film_kernel_ms = std::max(t.film_kernel_ms, a.film_kernel_ms);
+            t.fused_kernel_ms = std::max(t.fused_kernel_ms, a.fused_kernel_ms);
+            t.algorithmic_bytes += a.algorithmic_bytes; t.trace_kernel_bytes += a.trace_kernel_bytes; t.fused |= a.fused;
+        }
+        t.n_devices = (uint32_t) n;
+        t.reduce_ms = std::chrono::duration<double, std::milli>(clk::now() - tr0).count();
+        t.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        *stats = t;
+    }
+    return cancelled ? PHIP_ERR_CANCELLED : PHIP_OK;
+}
+
+/* Entry of both render functions: validation, the scene's render lock, single- or multi-device dispatch, the sticky
+   cancellation flag (consumed by the call that observed it). */
+static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /* device memory on the scene's device */, phip_stats *stats) {
+    validateParams(sc, p);
+    std::lock_guard<std::mutex> lock(sc->renderLock);
+    int rc;
+    if (p->n_devices > 1) {
+        rc = renderMultiDevice(sc, p, dOut, stats);
+    } else {
+        const int device = p->n_devices == 1 ? p->devices[0] : p->device;
+        if (device != sc->devs[0]->device) throw std::invalid_argument("scene was created on a different device");
+        rc = renderOnDevice(sc, *sc->devs[0], p, p->shard_index, p->shard_count > 0 ? p->shard_count : 1, dOut, stats);
+    }
+    if (rc == PHIP_ERR_CANCELLED) {
+        __atomic_store_n(sc->cancelFlag, 0, __ATOMIC_RELAXED);
+        return setErr(PHIP_ERR_CANCELLED, "rendering was cancelled");
+    }
+    return rc;
 }
 
 /* ======================================================================================
@@ -910,7 +1189,7 @@ extern "C" {
 const char *phip_last_error(void) { return g_err.c_str(); }
 #define PHIP_STR2(x) #x
 #define PHIP_STR(x) PHIP_STR2(x)
-const char *phip_version(void) { return "path_hip 0.3 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
+const char *phip_version(void) { return "path_hip 0.4 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
 
 int phip_device_count(void) {
     int n = 0;
@@ -926,7 +1205,7 @@ phip_scene *phip_scene_create(const phip_scene_desc *desc, int device) {
     if (device < 0 || device >= n) { setErr(PHIP_ERR_INVALID, "device ordinal out of range"); return nullptr; }
     phip_scene *sc = new (std::nothrow) phip_scene();
     if (!sc) { setErr(PHIP_ERR_NOMEM, "out of memory"); return nullptr; }
-    sc->device = device;
+    sc->devs[0]->device = device;
     try {
         buildScene(sc, *desc);
         return sc;
@@ -941,9 +1220,27 @@ phip_scene *phip_scene_create(const phip_scene_desc *desc, int device) {
 
 void phip_scene_destroy(phip_scene *scene) {
     if (!scene) return;
-    (void) hipSetDevice(scene->device);
-    if (scene->stream) (void) hipStreamDestroy(scene->stream);
     delete scene;
+}
+
+int phip_scene_replicate(phip_scene *scene, const int32_t *devices, int32_t n_devices) {
+    if (!scene || (!devices && n_devices)) return setErr(PHIP_ERR_INVALID, "NULL argument");
+    if (n_devices < 1 || n_devices > PHIP_MAX_DEVICES) return setErr(PHIP_ERR_INVALID, "n_devices out of range");
+    try {
+        std::lock_guard<std::mutex> lock(scene->renderLock);
+        int visible = 0; HIP_TRY(hipGetDeviceCount(&visible));
+        if (devices[0] != scene->devs[0]->device) return setErr(PHIP_ERR_INVALID, "devices[0] must be the scene's device");
+        for (int i = 1; i < n_devices; ++i) {
+            if (devices[i] < 0 || devices[i] >= visible) return setErr(PHIP_ERR_INVALID, "device ordinal out of range");
+            if ((int) scene->devs.size() > i && scene->devs[i]->device == devices[i]) continue;
+            if ((int) scene->devs.size() > i) scene->devs.resize(i);
+            replicateScene(scene, devices[i]);
+        }
+        HIP_TRY(hipSetDevice(scene->devs[0]->device));
+        return PHIP_OK;
+    } catch (const std::exception &e) {
+        return setErr(PHIP_ERR_DEVICE, e.what());
+    }
 }
 
 int phip_render_device(phip_scene *scene, const phip_render_params *params, void *d_out, phip_stats *out_stats) {
@@ -960,12 +1257,16 @@ int phip_render_device(phip_scene *scene, const phip_render_params *params, void
 int phip_render(phip_scene *scene, const phip_render_params *params, float *out_rgbaw, phip_stats *out_stats) {
     if (!scene || !params || !out_rgbaw) return setErr(PHIP_ERR_INVALID, "NULL argument");
     try {
-        HIP_TRY(hipSetDevice(scene->device));
-        const size_t n = (size_t) scene->dev.film.width * scene->dev.film.height * 5;
-        if (scene->film.n < n) scene->film.alloc(n);
-        int rc = renderImpl(scene, params, scene->film.p, out_stats);
+        SceneDev &sd = *scene->devs[0];
+        HIP_TRY(hipSetDevice(sd.device));
+        const size_t n = (size_t) sd.dev.film.width * sd.dev.film.height * 5;
+        if (sd.film.n < n) {
+            if (params->flags & PHIP_FLAG_ACCUMULATE) return setErr(PHIP_ERR_INVALID, "PHIP_FLAG_ACCUMULATE without a previous phip_render on this scene");
+            sd.film.alloc(n);
+        }
+        int rc = renderImpl(scene, params, sd.film.p, out_stats);
         if (rc != PHIP_OK) return rc;
-        HIP_TRY(hipMemcpy(out_rgbaw, scene->film.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_rgbaw, sd.film.p, n * sizeof(float), hipMemcpyDeviceToHost));
         return PHIP_OK;
     } catch (const std::invalid_argument &e) {
         return setErr(PHIP_ERR_INVALID, e.what());
@@ -976,10 +1277,12 @@ int phip_render(phip_scene *scene, const phip_render_params *params, float *out_
 
 int phip_get_samples(phip_scene *scene, float *out_rgba, size_t n_samples) {
     if (!scene || !out_rgba) return setErr(PHIP_ERR_INVALID, "NULL argument");
-    if (!scene->haveSamples) return setErr(PHIP_ERR_INVALID, "last render did not set PHIP_FLAG_SAMPLE_BUFFER");
-    const size_t n = (size_t) scene->dev.film.width * scene->dev.film.height * scene->lastSpp;
+    SceneDev &sd = *scene->devs[0];
+    if (!sd.haveSamples) return setErr(PHIP_ERR_INVALID, "last render did not set PHIP_FLAG_SAMPLE_BUFFER");
+    const size_t n = (size_t) sd.dev.film.width * sd.dev.film.height * sd.lastSpp;
     if (n_samples != n) return setErr(PHIP_ERR_INVALID, "n_samples does not match crop_w*crop_h*spp");
-    hipError_t e = hipMemcpy(out_rgba, scene->sampleOut.p, n * sizeof(float4), hipMemcpyDeviceToHost);
+    (void) hipSetDevice(sd.device);
+    hipError_t e = hipMemcpy(out_rgba, sd.sampleOut.p, n * sizeof(float4), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return setErr(PHIP_ERR_DEVICE, hipGetErrorString(e));
     return PHIP_OK;
 }
@@ -987,40 +1290,47 @@ int phip_get_samples(phip_scene *scene, float *out_rgba, size_t n_samples) {
 int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, phip_stats *out_stats) {
     if (!scene || (!rays && n)) return setErr(PHIP_ERR_INVALID, "NULL argument");
     try {
-        HIP_TRY(hipSetDevice(scene->device));
+        SceneDev &sd = *scene->devs[0];
+        HIP_TRY(hipSetDevice(sd.device));
         std::lock_guard<std::mutex> lock(scene->renderLock);
-        DevBuf<phip_ray> dr; DevBuf<phip_hit> dh; DevBuf<uint8_t> dz;
+        if (out_stats) memset(out_stats, 0, sizeof(*out_stats));
+        /* bounded chunks: the per-lane spill region alone is SPILL_DEPTH * 4 = 384 B per ray */
+        const size_t CHUNK = 4u << 20;
+        DevBuf<phip_ray> dr; DevBuf<phip_hit> dh; DevBuf<uint8_t> dz; DevBuf<unsigned long long> stat; DevBuf<uint32_t> spill;
+        const size_t cap = std::min(n, CHUNK);
         if (n) {
-            dr.upload(rays, n);
-            if (hits) dh.alloc(n);
-            if (occluded) dz.alloc(n);
-            DevBuf<unsigned long long> stat;
+            dr.alloc(cap); if (hits) dh.alloc(cap); if (occluded) dz.alloc(cap);
+            spill.alloc(((cap + BLOCK - 1) / BLOCK * BLOCK) * (size_t) SPILL_DEPTH);
+        }
+        EventList ev;
+        for (size_t first = 0; first < n; first += CHUNK) {
+            const size_t m = std::min(CHUNK, n - first);
+            HIP_TRY(hipMemcpy(dr.p, rays + first, m * sizeof(phip_ray), hipMemcpyHostToDevice));
             PathPool P; memset(&P, 0, sizeof(P));
-            P.nWaves = (uint32_t) ((n + 63) / 64 + BLOCK / 64);
+            P.nWaves = (uint32_t) ((m + 63) / 64 + BLOCK / 64);
             stat.alloc((size_t) ST_COUNT * P.nWaves);
-            DevBuf<uint32_t> spill; spill.alloc(((n + BLOCK - 1) / BLOCK * BLOCK) * (size_t) SPILL_DEPTH); P.spill = spill.p;
             HIP_TRY(hipMemset(stat.p, 0, stat.n * sizeof(unsigned long long)));
-            P.stat = stat.p;
-            hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(scene->dev), 0, scene->dev, (const phip_ray *) dr.p, n, dh.p, dz.p, P);
-            HIP_TRY(hipEventRecord(e1, 0));
-            HIP_TRY(hipMemsetAsync(scene->counters.p, 0, sizeof(Counters), 0));
-            hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, 0, P, scene->counters.p, 0);
+            P.stat = stat.p; P.spill = spill.p;
+            ev.record(0);
+            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);
+            ev.record(0);
+            HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), 0));
+            hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, 0, P, sd.counters.p, 0);
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipGetLastError());
-            float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1); (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-            if (hits) HIP_TRY(hipMemcpy(hits, dh.p, n * sizeof(phip_hit), hipMemcpyDeviceToHost));
-            if (occluded) HIP_TRY(hipMemcpy(occluded, dz.p, n, hipMemcpyDeviceToHost));
+            if (hits) HIP_TRY(hipMemcpy(hits + first, dh.p, m * sizeof(phip_hit), hipMemcpyDeviceToHost));
+            if (occluded) HIP_TRY(hipMemcpy(occluded + first, dz.p, m, hipMemcpyDeviceToHost));
             if (out_stats) {
-                Counters hc; HIP_TRY(hipMemcpy(&hc, scene->counters.p, sizeof(hc), hipMemcpyDeviceToHost));
-                memset(out_stats, 0, sizeof(*out_stats));
-                out_stats->closest_rays = hits ? n : 0; out_stats->shadow_rays = occluded ? n : 0;
-                out_stats->closest_node_visits = hc.total[ST_NODE]; out_stats->closest_triangle_tests = hc.total[ST_TRI];
-                out_stats->shadow_node_visits = hc.total[ST_SH_NODE]; out_stats->shadow_triangle_tests = hc.total[ST_SH_TRI];
-                out_stats->trace_kernel_ms = ms; out_stats->iterations = 1;
-                algorithmicBytes(scene, *out_stats);
+                Counters hc; HIP_TRY(hipMemcpy(&hc, sd.counters.p, sizeof(hc), hipMemcpyDeviceToHost));
+                out_stats->closest_node_visits += hc.total[ST_NODE]; out_stats->closest_triangle_tests += hc.total[ST_TRI];
+                out_stats->shadow_node_visits += hc.total[ST_SH_NODE]; out_stats->shadow_triangle_tests += hc.total[ST_SH_TRI];
             }
+        }
+        if (out_stats) {
+            out_stats->closest_rays = hits ? n : 0; out_stats->shadow_rays = occluded ? n : 0;
+            out_stats->trace_kernel_ms = ev.sumPairs(); out_stats->iterations = (uint32_t) ((n + CHUNK - 1) / CHUNK);
+            out_stats->n_devices = 1;
+            algorithmicBytes(false, *out_stats, 0.0);
         }
         return PHIP_OK;
     } catch (const std::exception &e) {
@@ -1028,7 +1338,7 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
     }
 }
 
-void phip_cancel(phip_scene *scene) { if (scene) scene->cancel.store(1); }
+void phip_cancel(phip_scene *scene) { if (scene && scene->cancelFlag) __atomic_store_n(scene->cancelFlag, 1, __ATOMIC_RELAXED); }
 
 void phip_develop(const float *rgbaw, size_t n_pixels, float *out_rgb) {
     /* fmtconv.cpp:979-991: divide by the weight channel, 0 if the weight is 0 */
@@ -1042,9 +1352,9 @@ void phip_develop(const float *rgbaw, size_t n_pixels, float *out_rgb) {
 int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
     if (!scene || !out) return setErr(PHIP_ERR_INVALID, "NULL argument");
     out->n_nodes = scene->bvh.nNodes; out->n_leaves = scene->bvh.nLeaves; out->n_triangle_refs = scene->bvh.nTriRefs;
-    out->max_depth = scene->traversal == 1 ? scene->bvh.maxDepth8 : scene->bvh.maxDepth; out->node_bytes = scene->traversal == 1 ? 256 : 128; out->triangle_bytes = 48;
-    if (scene->traversal == 1) { out->n_nodes = scene->bvh.nNodes8; out->sah_cost = scene->bvh.sahCost8; }
+    out->max_depth = scene->bvh.maxDepth; out->node_bytes = 128; out->triangle_bytes = 48;
     out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
+    out->fits_lds = scene->fitsLds ? 1u : 0u; out->reserved = 0;
     return PHIP_OK;
 }
 

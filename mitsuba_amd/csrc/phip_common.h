@@ -1,0 +1,53 @@
+/*
+ * phip_common.h -- what every translation unit of libphip.so starts with: HIP, the C ABI, the device scene layout and
+ * shading functions (dv_scene.h), the path-pool layout (k_pool.h), the error macro.
+ *
+ * libphip.so is built from three sources (six objects) so that they compile in parallel (the shading kernels are 40
+ * template instantiations):
+ *   phip.hip        host side (scene build, render loop, multi-device orchestration, C ABI) + traversal and film kernels
+ *   phip_shade.hip  k_shade / k_shade_direct instantiations behind phipLaunchShadeF<n> (compiled four times, -DSHADE_FEAT=0..3)
+ *   phip_mega.hip   k_mega instantiations behind phipLaunchMega
+ * No device function is called across units (everything on the device side is inline in headers), so no -fgpu-rdc.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+#include "../../include/phip.h"
+#include "dv_scene.h"
+
+using namespace pt;
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__));         \
+    } while (0)
+
+#include "k_pool.h"
+
+/* ---- launchers defined in the other translation units ---- */
+/* k_shade<materials, strictNormals, FEAT> / k_shade_direct<materials, FEAT> over the pool: phip_shade.hip compiled with -DSHADE_FEAT=n */
+#define PHIP_DECLARE_SHADE(n)                                                                                              \
+    void phipLaunchShadeF##n(bool strictNormals, int materialMask, dim3 grid, hipStream_t stream,                          \
+                             const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);                      \
+    void phipLaunchShadeDirectF##n(int materialMask, dim3 grid, hipStream_t stream,                                        \
+                                   const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);
+PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3)
+#undef PHIP_DECLARE_SHADE
+/* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */
+int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, size_t ldsBytes);
+void phipLaunchMega(int materialMask, bool strictNormals, dim3 grid, size_t ldsBytes, hipStream_t stream,
+                    const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);

@@ -79,6 +79,13 @@ class Scene:
             raise _ffi.PhipError(rc, "phip_trace")
         return hits, occ, st
 
+    def replicate(self, devices):
+        """Copies the device scene to further GPUs ahead of a multi-device render (phip_scene_replicate)."""
+        arr = (C.c_int32 * len(devices))(*devices)
+        rc = self._L.phip_scene_replicate(self._h, arr, len(devices))
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_scene_replicate")
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.phip_scene_destroy(self._h)
@@ -127,17 +134,18 @@ class PathHIP:
         self.stats = None
         self._scene = None
 
-    def params(self, scene, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None):
+    def params(self, scene, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None, **extra):
+        """extra: devices=[...] (multi-GPU inside the call), sample_offset / sample_total (progressive passes), progress=callable"""
         return A.default_render_params(spp=spp, max_depth=self.m_maxDepth, rr_depth=self.m_rrDepth,
                                        strict_normals=int(self.m_strictNormals), hide_emitters=int(self.m_hideEmitters),
                                        block_size=scene.block_size, seed=seed, shard_index=shard_index,
-                                       shard_count=shard_count, device=scene.device, flags=flags, stream=stream)
+                                       shard_count=shard_count, device=scene.device, flags=flags, stream=stream, **extra)
 
-    def render(self, scene, film, spp, seed=0, shard_index=0, shard_count=1, flags=0):
+    def render(self, scene, film, spp, seed=0, shard_index=0, shard_count=1, flags=0, **extra):
         """Renders into `film` (film.put of one full-frame block).  Returns True on success,
         False if cancelled (SamplingIntegrator::render returns proc->getReturnStatus() == ESuccess)."""
         self._scene = scene
-        p = self.params(scene, spp, seed, shard_index, shard_count, flags)
+        p = self.params(scene, spp, seed, shard_index, shard_count, flags, **extra)
         block = np.zeros((scene.height, scene.width, 5), np.float32)
         st = A.phip_stats()
         rc = _ffi.lib().phip_render(scene._h, C.byref(p), _ffi.fptr(block), C.byref(st))
@@ -149,10 +157,10 @@ class PathHIP:
         film.put(block)
         return True
 
-    def render_device(self, scene, d_out_ptr, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None):
+    def render_device(self, scene, d_out_ptr, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None, **extra):
         """Renders this shard's blocks into device memory (e.g. a torch tensor) for an RCCL reduce."""
         self._scene = scene
-        p = self.params(scene, spp, seed, shard_index, shard_count, flags, stream)
+        p = self.params(scene, spp, seed, shard_index, shard_count, flags, stream, **extra)
         st = A.phip_stats()
         rc = _ffi.lib().phip_render_device(scene._h, C.byref(p), C.c_void_p(d_out_ptr), C.byref(st))
         self.stats = st
@@ -192,8 +200,8 @@ class DirectHIP(PathHIP):
         self.stats = None
         self._scene = None
 
-    def params(self, scene, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None):
-        p = super().params(scene, spp, seed, shard_index, shard_count, flags, stream)
+    def params(self, scene, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None, **extra):
+        p = super().params(scene, spp, seed, shard_index, shard_count, flags, stream, **extra)
         p.integrator = A.PHIP_INTEGRATOR_DIRECT
         p.emitter_samples = self.m_emitterSamples
         p.bsdf_samples = self.m_bsdfSamples

@@ -61,6 +61,16 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
     assert abs(int(st.closest_rays) - int(ost.closest_rays)) <= max(4, 1e-4 * ost.closest_rays)
     assert abs(int(st.path_vertices) - int(ost.path_vertices)) <= max(4, 1e-4 * ost.path_vertices)
     assert st.invalid_samples == ost.invalid_samples
+    if st.fused:
+        # the scene fits LDS, so the fused kernel (k_mega) rendered it: the wavefront kernels must give the same bits
+        film2 = HDRFilm(gs.width, gs.height)
+        assert integ.render(gs, film2, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_NO_FUSED)
+        assert not integ.stats.fused
+        wsmp = integ.samples(gs, spp)
+        assert (wsmp.view(np.uint32) == gsmp.view(np.uint32)).all(), "fused and wavefront paths differ"
+        assert (film2.storage.view(np.uint32) == film.storage.view(np.uint32)).all()
+        assert integ.stats.samples == st.samples and integ.stats.path_vertices == st.path_vertices
+        assert integ.stats.closest_rays == st.closest_rays and integ.stats.shadow_rays == st.shadow_rays
     gs.close(); osc.close()
     return same.mean(), r
 

@@ -1,0 +1,193 @@
+"""GPU tests of the round-2 additions, through the C ABI: the fused kernel's dispatch, axis-aligned rays (zero direction
+components in the slab test), multi-device rendering inside phip_render (one host thread per device + film merge),
+progressive passes (sample_offset / PHIP_FLAG_ACCUMULATE), the sticky cancellation flag and the progress callback."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from mitsuba_amd import _abi as A, scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(phip):
+    if phip.phip_device_count() <= 0:
+        pytest.fail("no HIP device visible: " + phip.phip_last_error().decode())
+    from mitsuba_amd import integrator
+    return integrator
+
+
+def test_fused_kernel_is_chosen_for_lds_resident_diffuse_scenes_only(gpu, gauss):
+    cb = gpu.Scene(S.cornell_box(64, 64, gauss).desc())
+    assert cb.accel_info().fits_lds == 1
+    integ = gpu.PathHIP(maxDepth=5)
+    film = gpu.HDRFilm(64, 64)
+    assert integ.render(cb, film, 4)
+    assert integ.stats.fused == 1 and integ.stats.iterations == 1 and integ.stats.n_devices == 1
+    assert integ.render(cb, gpu.HDRFilm(64, 64), 4, flags=A.PHIP_FLAG_NO_FUSED)
+    assert integ.stats.fused == 0 and integ.stats.iterations > 1
+    d = gpu.DirectHIP()
+    assert d.render(cb, gpu.HDRFilm(64, 64), 4) and d.stats.fused == 0      # `direct` stays on the wavefront kernels
+    sb = S.cornell_box(64, 64, gauss)
+    P, T, N = S.sphere_mesh((200, 300, 200), 45.0, 4, 3)
+    sb.mesh(P, T, sb.dielectric(1.33, 1.0), normals=N)
+    glass = gpu.Scene(sb.desc())
+    assert glass.accel_info().fits_lds == 0                                  # dielectric / microfacet models keep the wavefront kernels
+    big = gpu.Scene(S.atrium(64, 36, gauss).desc())
+    assert big.accel_info().fits_lds == 0
+
+
+def axis_rays(rng, n, lo, hi):
+    """rays along +-X / +-Y / +-Z (incl. -0.0 components) and rays with one or two zero components"""
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    kind = rng.integers(0, 3, n)
+    for i in range(n):
+        if kind[i] == 0:                         # one axis
+            d[i, rng.integers(0, 3)] = rng.choice([-1.0, 1.0])
+        elif kind[i] == 1:                       # one zero component
+            v = rng.normal(size=3); v[rng.integers(0, 3)] = 0.0
+            d[i] = v / np.linalg.norm(v)
+        else:                                    # axis direction with negative zeros elsewhere
+            a = rng.integers(0, 3); d[i] = -0.0; d[i, a] = rng.choice([-1.0, 1.0])
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3] = o; rays[:, 3] = 1e-4; rays[:, 4:7] = d; rays[:, 7] = np.inf
+    return rays
+
+
+def test_axis_aligned_rays_on_an_origin_centred_scene(gpu, oracle, gauss):
+    """a zero direction component must not turn the slab test into NaNs: boxes straddling 0, origin != 0"""
+    rng = np.random.default_rng(11)
+    n = 4000
+    c = rng.uniform(-4, 4, (n, 1, 3))
+    p = (c + rng.normal(scale=0.5, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    sb = S.SceneBuilder()
+    sb.mesh(p, idx, sb.diffuse((0.5, 0.5, 0.5)))
+    sb.perspective((0, 0, -20), (0, 0, 0), (0, 1, 0), 45.0)
+    sb.hdrfilm(32, 32, gauss)
+    desc = sb.desc()
+    gs = gpu.Scene(desc); osc = oracle.OracleScene(desc)
+    rays = axis_rays(rng, 30000, -5, 5)
+    gh, go, _ = gs.rayIntersect(rays, True, True)
+    oh, oo, _ = osc.trace(rays, True, True)
+    assert (oh[:, 3].view(np.uint32) != A.PHIP_NO_HIT).mean() > 0.3          # the workload does hit things
+    same = (gh.view(np.uint32) == oh.view(np.uint32)).all(axis=1)
+    assert same.mean() > 0.9995, same.mean()                                 # (exact-t ties on shared edges aside)
+    assert (go == oo).mean() > 0.9995
+    # the Cornell box as well (walls are axis-aligned: rays run inside wall planes' boxes)
+    desc = S.cornell_box(32, 32, gauss).desc()
+    gs = gpu.Scene(desc); osc = oracle.OracleScene(desc)
+    rays = axis_rays(rng, 30000, 0, 550)
+    gh, go, _ = gs.rayIntersect(rays, True, True)
+    oh, oo, _ = osc.trace(rays, True, True)
+    assert ((gh.view(np.uint32) == oh.view(np.uint32)).all(axis=1)).mean() > 0.9995
+    assert (go == oo).mean() > 0.9995
+
+
+@pytest.mark.parametrize("scene,md", [("cornell_box", 5), ("atrium", 4)])
+def test_multi_device_render_equals_the_single_device_frame(gpu, phip, gauss, scene, md):
+    """n_devices > 1 through the C ABI: one host thread + stream per device, blocks dealt in spiral order, films merged on
+    devices[0].  On a box with >= 2 GPUs the merge is ncclReduce; a 1-GPU box lists the GPU twice (alias test hook)."""
+    w, h, spp = (160, 96, 4)
+    desc = getattr(S, scene)(w, h, gauss).desc()
+    gs = gpu.Scene(desc)
+    integ = gpu.PathHIP(maxDepth=md)
+    one = gpu.HDRFilm(w, h)
+    assert integ.render(gs, one, spp)
+    samples = integ.stats.samples
+    ngpu = phip.phip_device_count()
+    cases = [([0, 0], A.PHIP_FLAG_ALIAS_DEVICES), ([0, 0, 0], A.PHIP_FLAG_ALIAS_DEVICES)]
+    if ngpu >= 2:
+        cases.append((list(range(min(ngpu, 2))), 0))
+    for devs, fl in cases:
+        multi = gpu.HDRFilm(w, h)
+        assert integ.render(gs, multi, spp, flags=fl, devices=devs)
+        assert integ.stats.n_devices == len(devs) and integ.stats.samples == samples
+        # same samples, same per-pixel weights; only the order of the float additions across devices differs
+        assert rel_l2(multi.storage, one.storage) < 2e-6
+        assert np.abs(multi.storage[..., 4] - one.storage[..., 4]).max() < 1e-4
+    # a second call on the same replicas, sharded from outside as well (2 ranks x 2 devices)
+    parts = gpu.HDRFilm(w, h)
+    for r in range(2):
+        assert integ.render(gs, parts, spp, shard_index=r, shard_count=2, flags=A.PHIP_FLAG_ALIAS_DEVICES, devices=[0, 0])
+    assert rel_l2(parts.storage, one.storage) < 2e-6
+    # error behaviour
+    with pytest.raises(Exception):
+        integ.render(gs, gpu.HDRFilm(w, h), spp, devices=[0, 0])            # listed twice without the alias flag
+    with pytest.raises(Exception):
+        integ.render(gs, gpu.HDRFilm(w, h), spp, devices=[0, 99], flags=A.PHIP_FLAG_ALIAS_DEVICES)
+
+
+def test_scene_replicate(gpu, phip, gauss):
+    gs = gpu.Scene(S.cornell_box(32, 32, gauss).desc())
+    gs.replicate([0])
+    if phip.phip_device_count() >= 2:
+        gs.replicate([0, 1])
+    with pytest.raises(Exception):
+        gs.replicate([5, 0])                                                # devices[0] must be the scene's device
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_progressive_passes_add_up_to_the_single_render(gpu, phip, gauss, fused):
+    """sample_offset / sample_total / PHIP_FLAG_ACCUMULATE: 3 + 5 samples in two calls = one 8-sample render (same sample
+    indices, hence the same radiance values; the film differs by the order of the float additions only)"""
+    w, h = 96, 64
+    gs = gpu.Scene(S.cornell_box(w, h, gauss).desc())
+    integ = gpu.PathHIP(maxDepth=6)
+    base = 0 if fused else A.PHIP_FLAG_NO_FUSED
+    whole = gpu.HDRFilm(w, h)
+    assert integ.render(gs, whole, 8, flags=base)
+    block = np.zeros((h, w, 5), np.float32)
+    st = A.phip_stats()
+    p = integ.params(gs, 3, flags=base, sample_offset=0, sample_total=8)
+    assert phip.phip_render(gs._h, C.byref(p), block.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
+    first = block.copy()
+    p = integ.params(gs, 5, flags=base | A.PHIP_FLAG_ACCUMULATE, sample_offset=3, sample_total=8)
+    assert phip.phip_render(gs._h, C.byref(p), block.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
+    assert st.samples == w * h * 5
+    assert rel_l2(block, whole.storage) < 2e-6
+    assert np.abs(block[..., 4] - whole.storage[..., 4]).max() < 1e-4
+    assert (block[..., 4] > first[..., 4]).all()
+    # sample_offset + spp beyond sample_total is an error
+    p = integ.params(gs, 5, flags=base, sample_offset=4, sample_total=8)
+    assert phip.phip_render(gs._h, C.byref(p), block.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == A.PHIP_ERR_INVALID
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_cancel_is_sticky_and_consumed(gpu, gauss, fused):
+    """a phip_cancel that arrives before the render starts cancels that render (Scheduler::cancel semantics); the render
+    that observed it consumes the flag"""
+    gs = gpu.Scene(S.cornell_box(64, 64, gauss).desc())
+    integ = gpu.PathHIP(maxDepth=5)
+    fl = 0 if fused else A.PHIP_FLAG_NO_FUSED
+    film = gpu.HDRFilm(64, 64)
+    assert integ.render(gs, film, 2, flags=fl)
+    integ.cancel()
+    film2 = gpu.HDRFilm(64, 64)
+    assert integ.render(gs, film2, 64, flags=fl) is False
+    assert (film2.storage == 0).all()
+    film3 = gpu.HDRFilm(64, 64)
+    assert integ.render(gs, film3, 2, flags=fl)
+    assert (film3.storage.view(np.uint32) == film.storage.view(np.uint32)).all()
+
+
+def test_progress_callback_and_cancel_from_it(gpu, gauss):
+    w, h, spp = 128, 128, 32
+    gs = gpu.Scene(S.atrium(w, h, gauss).desc())
+    integ = gpu.PathHIP(maxDepth=6)
+    seen = []
+    assert integ.render(gs, gpu.HDRFilm(w, h), spp, progress=lambda user, dev, done, total: seen.append((dev, done, total)))
+    assert seen and seen[-1][1] == seen[-1][2] == w * h * spp
+    assert all(a[1] <= b[1] for a, b in zip(seen, seen[1:]))
+    # cancelling from inside the callback stops the render
+    calls = []
+
+    def stop(user, dev, done, total):
+        calls.append(done)
+        integ.cancel()
+    assert integ.render(gs, gpu.HDRFilm(w, h), 256, progress=stop) is False
+    assert len(calls) >= 1 and calls[0] < w * h * 256

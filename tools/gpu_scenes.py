@@ -14,6 +14,8 @@ for key in sys.argv[1:] or cfgs:
     t = time.time(); sc = Scene(sb.desc()); tb = time.time() - t
     integ = PathHIP(maxDepth=md); film = HDRFilm(w, h)
     integ.render(sc, film, 1)
+    for _ in range(int(os.environ.get("REPEAT", 1)) - 1):
+        integ.render(sc, film, spp)
     t = time.time(); integ.render(sc, film, spp, flags=0 if os.environ.get('NOTIMING') else A.PHIP_FLAG_KERNEL_TIMING); dt = time.time() - t
     st = integ.stats.as_dict()
     n = w * h * spp
@@ -21,5 +23,6 @@ for key in sys.argv[1:] or cfgs:
                       "Mrays/s": round((st["closest_rays"] + st["shadow_rays"]) / 1e6 / dt, 1), "mean_len": round(st["path_vertices"] / n, 2),
                       "nodes/closest": round(st["closest_node_visits"] / max(st["closest_rays"], 1), 1), "tris/closest": round(st["closest_triangle_tests"] / max(st["closest_rays"], 1), 1),
                       "nodes/shadow": round(st["shadow_node_visits"] / max(st["shadow_rays"], 1), 1),
-                      "kernel_ms": {k: round(st[k], 1) for k in ("trace_kernel_ms", "shadow_kernel_ms", "shade_kernel_ms", "film_kernel_ms")}, "wall_ms": round(dt * 1e3, 1),
-                      "iters": st["iterations"], "trace_GBs_alg": round(st["trace_kernel_bytes"] / 1e9 / (st["trace_kernel_ms"] / 1e3), 1)}))
+                      "fused": st["fused"], "lib": os.environ.get("PHIP_LIB", ""),
+                      "kernel_ms": {k: round(st[k], 1) for k in ("trace_kernel_ms", "shadow_kernel_ms", "shade_kernel_ms", "film_kernel_ms", "fused_kernel_ms")}, "wall_ms": round(dt * 1e3, 1),
+                      "iters": st["iterations"], "trace_GBs_alg": round(st["trace_kernel_bytes"] / 1e9 / (max(st["trace_kernel_ms"], 1e-9) / 1e3), 1)}))
