@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- Msamples/s of the path_hip hot path on MI355X (BASELINE.json metric).
+"""bench.py -- Msamples/s of the path_hip hot path on MI355X (BASELINE.json metric: Cornell box + Sponza class).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one full pass of the hot path over the workload: render every camera sample of the
-frame (generate -> trace -> shade -> shadow ... -> film) with the scene already resident in HBM.
-Workload (BASELINE.json configs[1], the config the metric is quoted on): Cornell box, 1024x1024,
-256 spp, diffuse + area light, path maxDepth=-1 rrDepth=5, gaussian rfilter, synthetic scene.
-With N GPUs the job is the same frame at 256*N spp whose 32x32 blocks are dealt round-robin (in
-the reference's spiral order) to the N ranks -- per-GPU work is constant (weak scaling) -- and a
-single RCCL reduce(SUM) of the (R,G,B,alpha,weight) film onto rank 0 closes every step.
+One "step" = one full pass of the hot path over the workload: render every camera sample of the frame
+(generate -> trace -> shade -> shadow ... -> film) with the scene already resident in HBM.
 
-Prints ONE JSON line on rank 0 (see the driver contract); `roofline` is for the dominant kernel
-(k_trace, closest-hit BVH traversal) from HIP events recorded inside libphip on its own stream;
-`cpu_baseline` is the CPU oracle ("port") timed on this node's host cores on a bounded sample.
+N = 1 (the driver's BENCH run): `value` is BASELINE.json configs[1], the config the metric is quoted on -- Cornell box,
+1024x1024, 256 spp, diffuse + area light, path maxDepth=-1 rrDepth=5, gaussian rfilter (K timed steps after W warm-up
+steps) -- and the same line carries the other single-GPU configs under "workloads": C3 (Sponza-class atrium, 1920x1080,
+64 spp, maxDepth 8), C4 (glass room, 1920x1080, 512 spp, maxDepth 16) and a 1/16-spp slice of C5, each timed the same way
+(min(K, 3) steps after one warm-up step).
+
+N > 1 (the driver's SCALE runs): the job is BASELINE.json configs[4] -- the atrium at 3840x2160, 1024 spp -- as ONE FIXED
+JOB split N ways (strong scaling): the 32x32 blocks are dealt round-robin in the reference's spiral order over the ranks
+(one process per GPU), every rank renders its blocks into a private full-frame film, and a single RCCL reduce(SUM) of the
+(R,G,B,alpha,weight) film onto rank 0 closes every step.  `value` = samples of the whole job / max-over-ranks time.
+(Launched WITHOUT torchrun, `--gpus N` uses the library's own multi-device path instead: one host thread per GPU inside
+phip_render_device and ncclReduce from C++ -- what the Mitsuba plugin uses.)
+
+Prints ONE JSON line on rank 0 (see the driver contract).  `roofline` describes the dominant kernel of the `value`
+workload with two honest fractions (neither can exceed 1): hbm = PMC-measured HBM bytes per launch / live launch time /
+8 TB/s, valu = active lane-operations / lane-slots (SQ counters); `cpu_baseline` is the reference itself (oracle/_ref,
+Mitsuba 0.6 compiled from /root/reference) -- or the CPU oracle port where that is not built -- timed on this node's host
+cores on a bounded sample, BEFORE the GPU phase.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -29,14 +40,19 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 
 WORKLOADS = {
     # name: (scene builder name, width, height, spp, maxDepth)
-    "cornell_1024x1024_256spp": ("cornell_box", 1024, 1024, 256, -1),
-    "cornell_256x256_16spp_md4": ("cornell_box", 256, 256, 16, 4),
-    "atrium_1920x1080_64spp_md8": ("atrium", 1920, 1080, 64, 8),
-    "glassroom_1920x1080_512spp_md16": ("glass_room", 1920, 1080, 512, 16),
+    "cornell_1024x1024_256spp": ("cornell_box", 1024, 1024, 256, -1),                 # C2 (the metric's config)
+    "cornell_256x256_16spp_md4": ("cornell_box", 256, 256, 16, 4),                    # C1
+    "atrium_1920x1080_64spp_md8": ("atrium", 1920, 1080, 64, 8),                      # C3
+    "glassroom_1920x1080_512spp_md16": ("glass_room", 1920, 1080, 512, 16),           # C4
+    "atrium_3840x2160_1024spp_md8": ("atrium", 3840, 2160, 1024, 8),                  # C5: the multi-GPU job (strong scaling)
+    "atrium_3840x2160_64spp_md8": ("atrium", 3840, 2160, 64, 8),                      # 1/16 of C5's samples per pixel: its single-GPU rate
     # the `direct` integrator on the same scenes
     "cornell_1024x1024_256spp_direct": ("cornell_box", 1024, 1024, 256, "direct:1"),
     "atrium_1920x1080_64spp_direct4": ("atrium", 1920, 1080, 64, "direct:4"),
 }
+HEADLINE = "cornell_1024x1024_256spp"
+EXTRA_SINGLE_GPU = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8"]
+MULTI_GPU_JOB = "atrium_3840x2160_1024spp_md8"
 
 
 def make_integrator(md):
@@ -55,27 +71,24 @@ def oracle_params(md, spp):
     return A.default_render_params(spp=spp, max_depth=md)
 
 
-def build_desc(workload, spp_scale=1):
+def build_desc(workload):
     from mitsuba_amd import _ffi, scene as S
     name, w, h, spp, md = WORKLOADS[workload]
     sb = getattr(S, name)(w, h, _ffi.gaussian_filter(0.5))
-    return sb.desc(), w, h, spp * spp_scale, md, sb.n_triangles
+    return sb.desc(), w, h, spp, md, sb.n_triangles
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_traffic.py), or None."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*%s*.json" % workload)), reverse=True):
+def profile_json(kind, workload):
+    """newest committed profiles/*<kind>*<workload>*.json (written on the GPU box by tools/pmc_traffic.py / tools/pmc_valu.py), or None"""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*%s*.json" % (kind, workload))), reverse=True):
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
-            if k:
-                return round(k["hbm_bytes_per_launch"], 1)
+            return json.load(open(f)), os.path.relpath(f, ROOT)
         except Exception:
             pass
-    return None
+    return None, None
 
 
-def cpu_baseline(workload, seconds_target=15.0):
+def cpu_baseline(workload, seconds_target=10.0):
     """The CPU baseline on a bounded sample of the same workload (same scene / film / integrator, reduced spp):
     the REFERENCE ITSELF when oracle/_ref is there (its own libcore + librender + plugins, compiled from /root/reference by
     oracle/Makefile.ref in the build container; the prebuilt files travel with the repository snapshot) -- its complete
@@ -117,108 +130,162 @@ def cpu_baseline(workload, seconds_target=15.0):
     return out
 
 
+def time_workload(workload, steps, warmup, rank, world, local, devices, D, torch):
+    """Renders `workload` warmup + steps times on this rank's share (blocks rank, rank + world, ... in spiral order) and
+    returns the per-rank aggregate.  Timed region: barrier + synchronize on both sides, max over ranks."""
+    from mitsuba_amd import _abi as A
+    from mitsuba_amd.integrator import Scene
+    desc, W, H, spp, md, ntris = build_desc(workload)
+    scene = Scene(desc, device=local)
+    if devices:
+        scene.replicate(devices)
+    accel = scene.accel_info().as_dict()
+    integ, integ_name = make_integrator(md)
+    dev = torch.device("cuda", local)
+    film = torch.zeros((H, W, 5), dtype=torch.float32, device=dev)
+    extra = {"devices": devices} if devices else {}
+
+    def step():
+        ok = integ.render_device(scene, film.data_ptr(), spp, seed=0, shard_index=rank, shard_count=world,
+                                 flags=A.PHIP_FLAG_KERNEL_TIMING, **extra)
+        assert ok
+        D.reduce_film(film, dst=0)
+        return integ.stats
+
+    for _ in range(warmup):
+        step()
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    agg = {}
+    for _ in range(steps):
+        st = step()
+        for k, v in st.as_dict().items():
+            agg[k] = agg.get(k, 0) + v
+    D.barrier(); torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    total_samples = D.sum_over_ranks(agg["samples"], dev)
+    total_rays = D.sum_over_ranks(agg["closest_rays"] + agg["shadow_rays"], dev)
+    scene.close()
+    del film
+    return {"workload": workload, "scene": WORKLOADS[workload][0], "triangles": ntris, "W": W, "H": H, "spp": spp, "integrator": integ_name,
+            "accel": accel, "agg": agg, "dt": dt, "steps": steps, "warmup": warmup, "samples": total_samples, "rays": total_rays}
+
+
+def dominant_kernel(r):
+    """(name, description, kernel ms over the timed steps, launches) of the kernel that takes most of the frame"""
+    a = r["agg"]
+    nodes = r["accel"]["n_nodes"]
+    if a["fused"]:
+        return "k_mega", "whole path in one persistent kernel: BVH4 (%d nodes), Wald + shading records, emitters, materials in LDS" % nodes, a["fused_kernel_ms"], max(int(a["iterations"]), 1)
+    merged = a["shadow_kernel_ms"] == 0 and a["shadow_rays"] > 0        # closest-hit + any-hit rays in one persistent launch (big trees)
+    cands = {("k_rays_p" if merged else ("k_trace_p" if nodes >= 64 else "k_trace")): a["trace_kernel_ms"], "k_shade": a["shade_kernel_ms"]}
+    if not merged:
+        cands["k_shadow_p"] = a["shadow_kernel_ms"]
+    name = max(cands, key=cands.get)
+    desc = {"k_rays_p": "closest-hit + any-hit BVH4 traversal, %d nodes of 128 B, 48-B Wald records" % nodes,
+            "k_trace_p": "closest-hit BVH4 traversal", "k_trace": "closest-hit BVH4 traversal", "k_shade": "path vertex shading over the pool",
+            "k_shadow_p": "any-hit BVH4 traversal"}[name]
+    return name, desc, cands[name], max(int(a["iterations"]), 1)
+
+
+def roofline(r):
+    """Two measured fractions for the dominant kernel -- neither can exceed 1:
+       hbm:  HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE + WRITE_SIZE, calibrated as the MI355X
+             guide prescribes) / this run's average launch duration (HIP events on the library's stream) / 8 TB/s
+       valu: active lane-operations / available lane-slots from the SQ counters committed under profiles/ (tools/pmc_valu.py)"""
+    name, desc, kms, launches = dominant_kernel(r)
+    a = r["agg"]
+    avg_ms = kms / launches if launches else 0.0
+    traffic, tsrc = profile_json("traffic", r["workload"])
+    valu, vsrc = profile_json("valu", r["workload"])
+    tk = (traffic or {}).get("kernels", {}).get(name)
+    hbm_bytes = tk["hbm_bytes_per_launch"] if tk else None
+    hbm_gbs = (hbm_bytes / 1e9) / (avg_ms / 1e3) if (hbm_bytes and avg_ms > 0) else None
+    alg_per_launch = a["trace_kernel_bytes"] / launches if name in ("k_rays_p", "k_trace_p", "k_trace") else a["algorithmic_bytes"] / launches
+    out = {"bound": "hbm", "kernel": name + " (" + desc + ")",
+           "achieved": round(hbm_gbs, 2) if hbm_gbs is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(min(hbm_gbs / HBM_PEAK_GBS, 1.0), 5) if hbm_gbs is not None else None,
+           "traffic": round(hbm_bytes, 1) if hbm_bytes else None, "traffic_source": tsrc,
+           "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+           "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
+           "note": "achieved = MEASURED HBM bytes per launch (PMC) / live launch time; the SURVEY 8(d) algorithmic bytes (node + record "
+                   "fetches, ray/hit state) are listed beside it but are served by LDS / L2 / Infinity Cache, not by the HBM pins: "
+                   "this path is bounded by VALU issue under divergence, see `valu`",
+           "kernel_ms_per_step": {k: round(a[k + "_kernel_ms"] / r["steps"], 3) for k in ("fused", "trace", "shadow", "shade", "film")}}
+    vk = (valu or {}).get(name)
+    if vk:
+        out["valu"] = {"frac": vk.get("valu_frac"), "issue_frac": vk.get("valu_issue_frac"), "lane_util": vk.get("lane_util"),
+                       "wave_cycles_waiting": vk.get("wave_cycles_wait_frac"), "source": vsrc,
+                       "definition": "frac = SQ_THREAD_CYCLES_VALU / (256 CU x 4 SIMD x 32 lanes x cycles); issue_frac = SQ_INSTS_VALU x 2 / (1024 x cycles)"}
+    return out
+
+
+def summary(r, world):
+    a = r["agg"]
+    msps = r["samples"] / 1e6 / r["dt"]
+    return {"value": round(msps, 3), "unit": "Msamples/s", "ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "steps": r["steps"], "warmup": r["warmup"],
+            "mrays_per_s": round(r["rays"] / 1e6 / r["dt"], 1), "mean_path_length": round(a["path_vertices"] / max(a["samples"], 1), 3),
+            "scene": r["scene"], "triangles": r["triangles"], "width": r["W"], "height": r["H"], "spp": r["spp"], "integrator": r["integrator"],
+            "fused_kernel": bool(a["fused"]), "roofline": roofline(r)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell_1024x1024_256spp", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS), help="time only this workload (default: the driver contract, see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spp", type=int, default=0, help="override spp (debug only; makes the line non-comparable)")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the C3 / C4 / C5-slice workloads")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
-    from mitsuba_amd import _ffi, _abi as A, distributed as D
-    from mitsuba_amd.integrator import Scene, PathHIP
+    from mitsuba_amd import distributed as D
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus:
+    in_library = world == 1 and args.gpus > 1          # no torchrun: the library's own multi-device path
+    if world != args.gpus and not in_library:
         if rank == 0:
             print("bench.py: WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (world, args.gpus, args.gpus), file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: path_hip has no CPU fallback")
+    if in_library and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    n_gpus = args.gpus if in_library else world
+    devices = list(range(args.gpus)) if in_library else None
 
-    desc, W, H, spp, md, ntris = build_desc(args.workload, spp_scale=world)
-    if args.spp:
-        spp = args.spp * world
-    scene = Scene(desc, device=local)
-    accel = scene.accel_info().as_dict()
-    # the closest-hit kernel that runs for this scene (trees under 64 nodes use the per-slot launch)
-    trace_kernel = "k_trace_p" if accel["n_nodes"] >= 64 else "k_trace"     # refined after the run: k_rays_p when the ray kernels are merged
-    integ, integ_name = make_integrator(md)
-    film = torch.zeros((H, W, 5), dtype=torch.float32, device=dev)
-    flags = A.PHIP_FLAG_KERNEL_TIMING
+    headline = args.workload or (HEADLINE if n_gpus == 1 else MULTI_GPU_JOB)
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(headline)                   # before the GPU phase: the GPU is busy for the rest of the run
 
-    def step():
-        ok = integ.render_device(scene, film.data_ptr(), spp, seed=0, shard_index=rank, shard_count=world, flags=flags)
-        assert ok
-        D.reduce_film(film, dst=0)
-        return integ.stats
-
-    for _ in range(args.warmup):
-        step()
-    D.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    agg = {}
-    for _ in range(args.steps):
-        st = step()
-        for k, v in st.as_dict().items():
-            agg[k] = agg.get(k, 0) + v
-    D.barrier(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, dev)
-    local_samples = agg["samples"]
-    total_samples = D.sum_over_ranks(local_samples, dev)
+    main_r = time_workload(headline, args.steps, args.warmup, rank, world, local, devices, D, torch)
+    extras = {}
+    if n_gpus == 1 and not args.workload and not args.no_extra:
+        for w in EXTRA_SINGLE_GPU:
+            extras[w] = time_workload(w, min(args.steps, 3), 1, rank, world, local, devices, D, torch)
 
     if rank == 0:
-        msps = total_samples / 1e6 / dt
-        ms_per_step = dt / args.steps * 1e3
-        launches = max(int(agg["iterations"]), 1)
-        trace_ms = agg["trace_kernel_ms"]
-        merged = agg["shadow_kernel_ms"] == 0 and agg["shadow_rays"] > 0     # closest-hit + any-hit rays in one persistent launch (big trees)
-        if merged:
-            trace_kernel = "k_rays_p"
-        kernel_desc = ("closest-hit + any-hit" if merged else "closest-hit") + " BVH4 traversal, %d nodes of 128 B, 48-B Wald records" % accel["n_nodes"]
-        achieved = (agg["trace_kernel_bytes"] / 1e9) / (trace_ms / 1e3) if trace_ms > 0 else 0.0
+        s = summary(main_r, world)
         out = {
-            "metric": "Msamples/s", "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene": WORKLOADS[args.workload][0], "triangles": ntris, "width": W, "height": H,
-                       "spp": spp, "spp_per_gpu_equivalent": spp // world, "integrator": integ_name,
-                       "rfilter": "gaussian stddev 0.5", "sampler": "ctr seed 0", "block_size": 32,
-                       "parallelism": "blocks round-robin over %d GPU(s) in spiral order + RCCL reduce(sum) of the film" % world},
-            "frame_ms": round(ms_per_step, 3),
-            "mrays_per_s": round((agg["closest_rays"] + agg["shadow_rays"]) / 1e6 / dt * world if world == 1 else
-                                 D.sum_over_ranks(agg["closest_rays"] + agg["shadow_rays"], dev) / 1e6 / dt, 1),
-            "mean_path_length": round(agg["path_vertices"] / max(agg["samples"], 1), 3),
-            "roofline": {
-                "bound": "hbm", "kernel": trace_kernel + " (" + kernel_desc + ")",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload, trace_kernel),
-                "note": "achieved = ALGORITHMIC bytes (node + record fetches, ray in, hit out) / HIP-event kernel time; most of them are served by L1/L2/Infinity Cache, "
-                        "traffic = PMC-measured HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated; profiles/)",
-                "algorithmic_bytes_per_launch": round(agg["trace_kernel_bytes"] / launches, 1),
-                "avg_launch_ms": round(trace_ms / launches, 5), "launches": launches,
-                "whole_job_algorithmic_GBs": round(agg["algorithmic_bytes"] / 1e9 / dt, 2),
-                "kernel_ms": {"trace": round(agg["trace_kernel_ms"], 2), "shadow": round(agg["shadow_kernel_ms"], 2),
-                              "shade": round(agg["shade_kernel_ms"], 2), "film": round(agg["film_kernel_ms"], 2)},
-            },
+            "metric": "Msamples/s", "value": s["value"], "unit": "Msamples/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": s["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong" if n_gpus > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": headline, "scene": s["scene"], "triangles": s["triangles"], "width": s["width"], "height": s["height"],
+                       "spp": s["spp"], "integrator": s["integrator"], "rfilter": "gaussian stddev 0.5", "sampler": "ctr seed 0", "block_size": 32,
+                       "parallelism": ("one fixed job: 32x32 blocks dealt round-robin in spiral order over %d GPU(s), " % n_gpus) +
+                                      ("one host thread per GPU inside libphip + ncclReduce(sum) of the film" if in_library else
+                                       "one process per GPU + RCCL reduce(sum) of the film") if n_gpus > 1 else "1 GPU"},
+            "frame_ms": s["ms_per_step"], "mrays_per_s": s["mrays_per_s"], "mean_path_length": s["mean_path_length"],
+            "fused_kernel": s["fused_kernel"], "roofline": s["roofline"],
         }
-    else:
-        # keep collectives matched on the other ranks
-        if world > 1:
-            D.sum_over_ranks(agg["closest_rays"] + agg["shadow_rays"], dev)
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
-        else:
-            out["cpu_baseline"] = None
+        if extras:
+            out["workloads"] = {headline: {k: v for k, v in s.items() if k != "roofline"}}
+            out["workloads"][headline]["roofline_frac_hbm"] = (s["roofline"] or {}).get("frac")
+            for w, r in extras.items():
+                out["workloads"][w] = summary(r, world)
+        out["cpu_baseline"] = cpu
         print(json.dumps(out))
 
 

@@ -19,6 +19,7 @@ public:
         m_hideEmitters = props.getBoolean("hideEmitters", false);
         Assert(m_emitterSamples + m_bsdfSamples > 0);
         m_holder.setDevice(props.getInteger("device", 0));
+        m_holder.setDeviceCount(props.getInteger("devices", 1));       /* GPUs of the node to spread the job over (0 = all) */
         Properties p("direct");
         p.setSize("emitterSamples", m_emitterSamples); p.setSize("bsdfSamples", m_bsdfSamples);
         p.setBoolean("strictNormals", m_strictNormals); p.setBoolean("hideEmitters", m_hideEmitters);
@@ -29,6 +30,7 @@ public:
         m_emitterSamples = stream->readSize(); m_bsdfSamples = stream->readSize();
         m_strictNormals = stream->readBool(); m_hideEmitters = stream->readBool();
         m_holder.setDevice(stream->readInt());
+        m_holder.setDeviceCount(stream->readInt());
         m_cpuDirect = static_cast<SamplingIntegrator *>(manager->getInstance(stream));
     }
 
@@ -37,6 +39,7 @@ public:
         stream->writeSize(m_emitterSamples); stream->writeSize(m_bsdfSamples);
         stream->writeBool(m_strictNormals); stream->writeBool(m_hideEmitters);
         stream->writeInt(m_holder.getDevice());
+        stream->writeInt(m_holder.getDeviceCount());
         manager->serialize(stream, m_cpuDirect.get());
     }
 

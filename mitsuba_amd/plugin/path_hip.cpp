@@ -28,6 +28,7 @@ class PathHIP : public MonteCarloIntegrator {
 public:
     PathHIP(const Properties &props) : MonteCarloIntegrator(props) {
         m_holder.setDevice(props.getInteger("device", 0));
+        m_holder.setDeviceCount(props.getInteger("devices", 1));       /* GPUs of the node to spread the job over (0 = all) */
         Properties p("path");
         p.setInteger("maxDepth", m_maxDepth); p.setInteger("rrDepth", m_rrDepth);
         p.setBoolean("strictNormals", m_strictNormals); p.setBoolean("hideEmitters", m_hideEmitters);
@@ -36,12 +37,14 @@ public:
 
     PathHIP(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager) {
         m_holder.setDevice(stream->readInt());
+        m_holder.setDeviceCount(stream->readInt());
         m_cpuPath = static_cast<SamplingIntegrator *>(manager->getInstance(stream));
     }
 
     void serialize(Stream *stream, InstanceManager *manager) const {
         MonteCarloIntegrator::serialize(stream, manager);
         stream->writeInt(m_holder.getDevice());
+        stream->writeInt(m_holder.getDeviceCount());
         manager->serialize(stream, m_cpuPath.get());
     }
 

@@ -140,34 +140,86 @@ inline PhipBitmapInfo phipBitmap(const Texture *t) {
 /* Owns the device scene of one integrator instance. */
 class PhipSceneHolder {
 public:
-    PhipSceneHolder() : m_scene(NULL), m_device(0) { }
+    PhipSceneHolder() : m_scene(NULL), m_device(0), m_deviceCount(1) { }
     ~PhipSceneHolder() { if (m_scene) phip_scene_destroy(m_scene); }
     phip_scene *get() const { return m_scene; }
     void setDevice(int device) { m_device = device; }
     int getDevice() const { return m_device; }
 
-    /* one phip_render call, then the film takes the full-frame accumulator (shared by both integrators' render()) */
+    /* Devices of the job: `devices` = how many GPUs the render spreads over (default 1; 0 = every visible GPU), starting at
+       `device`.  With more than one, libphip runs one host thread + stream per GPU and merges the films with ncclReduce. */
+    void setDeviceCount(int n) { m_deviceCount = n; }
+    int getDeviceCount() const { return m_deviceCount; }
+
+    /* The scene's <sampler> (src/librender/integrator.cpp:104,169 clone it per worker): `independent` is honoured as "independent
+       uniform samples" -- its SFMT stream is one sequential generator per worker thread (independent.cpp:71-103), which no
+       parallel schedule reproduces, not even the reference's own from run to run (independent.cpp:42-45) -- so the device's
+       counter-based stream stands in, which is said once; a QMC sampler would silently lose its stratification: an error. */
+    static void checkSampler(const Sampler *sampler, const char *name) {
+        const std::string cls = sampler->getClass()->getName();
+        if (cls == "IndependentSampler") {
+            static bool told = false;
+            if (!told) {
+                told = true;
+                SLog(EWarn, "%s: the 'independent' sampler is served by the device's counter-based stream (pcg4d(pixel, sample, dimension), seed 0): "
+                            "statistically equivalent, not the same random numbers as the CPU integrator", name);
+            }
+            return;
+        }
+        SLog(EError, "%s: sampler \"%s\" is not supported (only 'independent'; QMC samplers would lose their stratification)", name, cls.c_str());
+    }
+
+    /* SamplingIntegrator::render (integrator.cpp:95-129) + BlockedRenderProcess (renderproc.cpp:142-176): the job runs as a few
+       progressive passes over the whole frame (sample indices [k0, k1) of every pixel per pass), so that listeners see what the
+       reference's block stream gives them: signalWorkBegin when a pass starts, film->put + signalWorkEnd + a ProgressReporter
+       update when it ends, and a cancellation point in between. */
     bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, phip_render_params &rp, const char *name) {
         ref<Sensor> sensor = scene->getSensor();
         ref<Film> film = sensor->getFilm();
         const Vector2i size = film->getCropSize();
-        SLog(EInfo, "Starting render job (%ix%i, " SIZE_T_FMT " samples, %s) ..", size.x, size.y,
-            scene->getSampler()->getSampleCount(), phip_version());
-        rp.spp = (int32_t) scene->getSampler()->getSampleCount();
+        const Sampler *sampler = scene->getSampler();
+        checkSampler(sampler, name);
+        const size_t spp = sampler->getSampleCount();
+        SLog(EInfo, "Starting render job (%ix%i, " SIZE_T_FMT " samples, %s) ..", size.x, size.y, spp, phip_version());
         rp.block_size = (int32_t) scene->getBlockSize();
         rp.sampler = PHIP_SAMPLER_CTR; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
+        int nDev = m_deviceCount == 0 ? phip_device_count() - m_device : m_deviceCount;
+        if (nDev > PHIP_MAX_DEVICES) nDev = PHIP_MAX_DEVICES;
+        if (nDev > 1) { rp.n_devices = nDev; for (int i = 0; i < nDev; ++i) rp.devices[i] = m_device + i; }
+        /* passes of at most ~128 M camera samples: a fraction of a second each on one MI355X */
+        const double pixels = (double) size.x * (double) size.y;
+        size_t sppPerPass = (size_t) std::max(1.0, std::floor(128e6 * std::max(1, nDev) / pixels));
+        if (const char *e = getenv("PHIP_SHIM_PASS_SPP")) sppPerPass = (size_t) std::max(1, atoi(e));
+        const size_t nPasses = (spp + sppPerPass - 1) / sppPerPass;
         /* crop-relative (renderproc.cpp:160-173); no border: border pixels are already folded in by the device film pass */
         ref<Bitmap> target = new Bitmap(Bitmap::ESpectrumAlphaWeight, Bitmap::EFloat32, size);   /* = the film storage's format: setBitmap is a memcpy */
-        phip_stats st;
-        int rc = phip_render(m_scene, &rp, target->getFloat32Data(), &st);
-        if (rc == PHIP_ERR_CANCELLED)
-            return false;
-        if (rc != PHIP_OK)
-            SLog(EError, "%s: %s", name, phip_last_error());       /* throws std::runtime_error, caught by RenderJob::run */
-        film->setBitmap(target);                                  /* hdrfilm.cpp:395-425: replaces m_storage's bitmap */
+        ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, size, NULL);          /* what listeners are handed (no border) */
+        block->setOffset(Point2i(0, 0));
+        RectangularWorkUnit wu; wu.setOffset(Point2i(0, 0)); wu.setSize(size);
+        ProgressReporter progress("Rendering", nPasses, job);
+        phip_stats total; memset(&total, 0, sizeof(total));
+        for (size_t pass = 0, k0 = 0; pass < nPasses; ++pass, k0 += sppPerPass) {
+            rp.spp = (int32_t) std::min(sppPerPass, spp - k0);
+            rp.sample_offset = (int32_t) k0; rp.sample_total = (int32_t) spp;
+            rp.flags = (rp.flags & ~PHIP_FLAG_ACCUMULATE) | (pass > 0 ? PHIP_FLAG_ACCUMULATE : 0);
+            queue->signalWorkBegin(job, &wu, 0);
+            phip_stats st;
+            int rc = phip_render(m_scene, &rp, target->getFloat32Data(), &st);
+            if (rc == PHIP_ERR_CANCELLED) {
+                queue->signalWorkCanceled(job, Point2i(0, 0), size);
+                return false;
+            }
+            if (rc != PHIP_OK)
+                SLog(EError, "%s: %s", name, phip_last_error());   /* throws std::runtime_error, caught by RenderJob::run */
+            film->setBitmap(target);                              /* hdrfilm.cpp:395-425: replaces m_storage's bitmap with the accumulated frame */
+            memcpy(block->getBitmap()->getFloat32Data(), target->getFloat32Data(), target->getBufferSize());
+            queue->signalWorkEnd(job, block, false);
+            progress.update(pass + 1);
+            total.samples += st.samples; total.closest_rays += st.closest_rays; total.shadow_rays += st.shadow_rays; total.render_ms += st.render_ms;
+        }
         queue->signalRefresh(job);
-        SLog(EInfo, "%s: %.1f Msamples/s, %.1f Mrays/s", name, st.samples / 1e3 / st.render_ms,
-            (st.closest_rays + st.shadow_rays) / 1e3 / st.render_ms);
+        SLog(EInfo, "%s: %.1f Msamples/s, %.1f Mrays/s (%i GPU%s, %i pass%s)", name, total.samples / 1e3 / total.render_ms,
+            (total.closest_rays + total.shadow_rays) / 1e3 / total.render_ms, std::max(1, nDev), nDev > 1 ? "s" : "", (int) nPasses, nPasses > 1 ? "es" : "");
         return true;
     }
 
@@ -186,10 +238,20 @@ public:
         for (size_t i = 0; i < list.size(); ++i) {
             const Shape *shape = list[i].get();
             ref<TriMesh> mesh;
+            /* outside the path: an error, never a silent approximation */
+            if (shape->hasSubsurface())
+                SLog(EError, "path_hip: shape \"%s\" has a subsurface integrator -- not supported", shape->getName().c_str());
+            if (shape->isMediumTransition())
+                SLog(EError, "path_hip: shape \"%s\" marks a participating-medium transition -- media are not supported", shape->getName().c_str());
             if (shape->getClass()->derivesFrom(MTS_CLASS(TriMesh)))
                 mesh = const_cast<TriMesh *>(static_cast<const TriMesh *>(shape));
-            else
+            else {
                 mesh = const_cast<Shape *>(shape)->createTriMesh();       /* rectangle.cpp:170-203, cube, disk, sphere ... */
+                const std::string scls = shape->getClass()->getName();
+                if (scls != "Rectangle" && scls != "Cube")                  /* planar shapes tessellate exactly */
+                    SLog(EWarn, "path_hip: analytic shape \"%s\" (%s) is rendered as its createTriMesh() tessellation: silhouette and "
+                                "area-emitter sampling differ from the CPU integrator", shape->getName().c_str(), scls.c_str());
+            }
             if (!mesh)
                 SLog(EError, "path_hip: shape \"%s\" cannot be converted to a triangle mesh", shape->getName().c_str());
             phip_shape s; memset(&s, 0, sizeof(s));
@@ -426,6 +488,7 @@ public:
 private:
     phip_scene *m_scene;
     int m_device;
+    int m_deviceCount;           /* GPUs the render spreads over (0 = all visible) */
     std::vector<phip_texture> m_textures; std::map<const Texture *, uint32_t> m_textureIds;
     std::vector<ref<Bitmap> > m_textureLevels;   /* float RGB copies of the textures' MIP levels */
     std::vector<ref<Bitmap> > m_envLevels;       /* float RGB copies of the environment map's MIP levels (alive until phip_scene_create) */

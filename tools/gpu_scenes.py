@@ -6,7 +6,8 @@ from mitsuba_amd import _ffi, _abi as A, scene as S
 from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
 
 ft = _ffi.gaussian_filter()
-cfgs = {"cornell": ("cornell_box", 1024, 1024, 64, -1), "atrium": ("atrium", 1920, 1080, 16, 8), "glass": ("glass_room", 1920, 1080, 32, 16)}
+cfgs = {"cornell": ("cornell_box", 1024, 1024, 64, -1), "atrium": ("atrium", 1920, 1080, 16, 8), "glass": ("glass_room", 1920, 1080, 32, 16),
+        "atrium4k": ("atrium", 3840, 2160, 16, 8)}
 for key in sys.argv[1:] or cfgs:
     name, w, h, spp, md = cfgs[key]
     spp = int(os.environ.get("SPP", spp))

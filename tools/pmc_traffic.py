@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic of the path_hip kernels from rocprofv3 PMC counters (run ON the GPU box).
 
-    python tools/pmc_traffic.py <workload> <out.json> [spp]
+    python tools/pmc_traffic.py <scene key of tools/gpu_scenes.py> <out.json> [spp] [bench workload name]
 
 Runs (1) a calibration kernel pair with known HBM traffic and (2) one render of the workload, each under
 `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, as the MI355X guide
@@ -11,6 +11,7 @@ import csv, glob, json, os, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 workload, out = sys.argv[1], sys.argv[2]
 spp = sys.argv[3] if len(sys.argv) > 3 else ""
+bench_name = sys.argv[4] if len(sys.argv) > 4 else workload
 tmp = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
 os.makedirs(tmp, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
@@ -18,7 +19,9 @@ env = dict(os.environ, TMPDIR="/tmp")
 CAL_N, CAL_SRC = 1 << 26, 2 << 30        # 64M gathers from a 2 GiB buffer
 cal_cmd = [sys.executable, "-c", "import ctypes,sys; sys.path.insert(0,%r); from mitsuba_amd import _ffi; L=_ffi.lib(); "
            "L.phip_debug_pmc_calibration.argtypes=[ctypes.c_size_t,ctypes.c_size_t]; assert L.phip_debug_pmc_calibration(%d,%d)==0" % (ROOT, CAL_SRC, CAL_N)]
-ren_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", workload] + (["--spp", spp] if spp else [])
+ren_cmd = [sys.executable, os.path.join(ROOT, "tools", "gpu_scenes.py"), workload]       # (1-spp warm-up render + the timed render: both are counted, the per-launch figure divides by the launches)
+if spp:
+    env["SPP"] = spp
 
 
 def run(counter, tag, cmd):
@@ -32,7 +35,7 @@ def run(counter, tag, cmd):
     return agg, n
 
 
-res = {"workload": workload, "spp_override": spp or None, "pool_slots_override": os.environ.get("PHIP_POOL"),
+res = {"workload": bench_name, "scene_key": workload, "spp_override": spp or None, "pool_slots_override": os.environ.get("PHIP_POOL"),
        "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB",
        "note": "per-launch figures: the path pool must have the size of the full job (8 M slots for jobs >= 256 M samples, else 4 M) -- set PHIP_POOL when spp is reduced"}
 cf, _ = run("FETCH_SIZE", "cal_fetch", cal_cmd)
@@ -52,7 +55,7 @@ res["kernels"] = {}
 for k in sorted(rf):
     if not k.startswith("k_"):
         continue
-    gather = k.startswith(("k_trace", "k_shadow", "k_shade", "k_rays"))
+    gather = k.startswith(("k_trace", "k_shadow", "k_shade", "k_rays", "k_mega"))
     fc = (fetch_gather_corr if gather else fetch_stream_corr) or 1.0
     fb = rf[k] * 1024 * fc; wb = rw.get(k, 0) * 1024 * (write_corr or 1.0)
     res["kernels"][k] = {"launches": nf[k], "fetch_KiB_raw": rf[k], "write_KiB_raw": rw.get(k, 0), "fetch_correction": fc,

@@ -8,8 +8,9 @@ Per kernel (summed over its launches in the profiled run; durations are the disp
   lane_util       = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU)                -- active lanes per issued VALU instruction
   valu_frac       = SQ_THREAD_CYCLES_VALU / (256 * 4 * 32 lanes * GPU cycles)   -- useful lane-operations / lane-slots available
   wait / stall    = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY as fractions of SQ_WAVE_CYCLES (disjoint, sum ~ 1)
-GPU cycles of a launch = its duration x the shader clock measured in the same pass (GRBM_GUI_ACTIVE / duration when the
-counter is there, else 2.4 GHz)."""
+GPU cycles of a launch = its duration x the shader clock measured in the same pass (GRBM_GUI_ACTIVE / 8 XCDs / duration when
+the counter is there, else 2.4 GHz).  Cross-check built in: avg_waves_per_simd must come out at the kernel's resident
+waves per SIMD (k_mega: 3.0 = its launch bounds)."""
 import collections
 import csv
 import glob
@@ -45,6 +46,8 @@ for k, c in sorted(agg.items()):
     sec, launches = base("SQ_INSTS_VALU") if "SQ_INSTS_VALU" in c else base(next(iter(c)))
     gsec, _ = base("GRBM_GUI_ACTIVE")
     clock = c["GRBM_GUI_ACTIVE"] / gsec if gsec else 2.4e9
+    if clock > 4e9:
+        clock /= 8.0              # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs (measured: 19.0 "GHz" = 8 x 2.38); the SQ counters are chip-wide sums
     cycles = sec * clock
     insts, thr = c.get("SQ_INSTS_VALU", 0.0), c.get("SQ_THREAD_CYCLES_VALU", 0.0)
     wave = c.get("SQ_WAVE_CYCLES", 0.0)
