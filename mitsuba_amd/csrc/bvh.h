@@ -36,8 +36,11 @@ namespace pt {
 struct BuildTri { float bmin[3], bmax[3], c[3]; uint32_t prim; };
 
 struct HostBVH {
-    std::vector<float> nodes8;    /* 64 floats per BVH8 node: child k at [8k..8k+7] = min.xyz, max.xyz, bits(ref), 0 */
-    uint32_t nNodes8 = 0, maxDepth8 = 0; int32_t rootRef8 = 0; float sahCost8 = 0;
+    /* 8-wide tree with quantised child boxes for the big-scene ray kernels (k_wide.h), after Ylitie, Karras & Laine,
+       "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs" (HPG 2017): 80-byte nodes, see buildWide() */
+    std::vector<uint32_t> wnodes; /* 20 dwords per node */
+    std::vector<float> wtris;     /* 12 floats per triangle record, grouped per wide node (each node's leaf triangles are consecutive) */
+    uint32_t nWNodes = 0, wMaxDepth = 0, nWTris = 0; float wSahCost = 0;
     std::vector<float> nodes;     /* 32 floats per BVH4 node */
     std::vector<float> nodes2;    /* 16 floats per intermediate BVH2 node */
     uint32_t nNodes2 = 0;
@@ -91,6 +94,8 @@ struct Box {
         return 2.0f * (d[0] * d[1] + d[1] * d[2] + d[0] * d[2]);
     }
 };
+
+struct ChildRef { int32_t ref; Box box; };      /* a child of a BVH2 node: reference (>= 0 inner, < 0 leaf) + padded box */
 
 struct Builder {
     std::vector<BuildTri> &T;
@@ -204,6 +209,137 @@ struct Builder {
 
 } // namespace detail
 
+/*
+ * Compressed wide BVH (CWBVH, Ylitie et al. 2017), built by collapsing the binary SAH tree.  The ray kernels of the big scenes
+ * are bound by the CU's vector-memory path (every lane of a wave fetches its own node: 64 cache lines per load instruction),
+ * so what counts is bytes and dependent round trips per ray: one 80-byte node replaces ~2.3 of the 128-byte BVH4 nodes.
+ *
+ * Node = 5 x 16 bytes:
+ *   [0] p.x p.y p.z (float: the node box's lower corner)   e.x | e.y << 8 | e.z << 16 | imask << 24
+ *       (e = biased exponent byte of the per-axis power-of-two grid step; imask bit s: slot s holds an inner node)
+ *   [1] childBase  triBase  meta[0..3]  meta[4..7]
+ *       inner children are nodes childBase + rank (rank = number of inner slots below s); the node's leaf triangles are
+ *       records triBase + offset.  meta byte of slot s: 0 = empty; inner: 0x20 | (24 + s); leaf: unary(count) << 5 | offset
+ *       with count 1..3 -> 0b001, 0b011, 0b111 and offset < 24
+ *   [2] qlo.x[0..3] qlo.x[4..7] qlo.y[0..3] qlo.y[4..7]    [3] qlo.z[0..3] qlo.z[4..7] qhi.x[0..3] qhi.x[4..7]
+ *   [4] qhi.y[0..3] qhi.y[4..7] qhi.z[0..3] qhi.z[4..7]    child box = p + q * 2^(e - 127), rounded outwards (conservative)
+ * Children sit in the slot whose octant direction ((s & 1 ? + : -), (s & 2 ? + : -), (s & 4 ? + : -)) best matches their
+ * offset from the node centre (greedy assignment), so that slot ^ rayOctant orders them approximately front to back
+ * without a sort.  Empty slots have qlo = 255 > qhi = 0.
+ */
+template <typename Children2>
+inline void buildWide(HostBVH &out, int32_t root2, const detail::Box &rootBox, Children2 children2) {
+    out.wnodes.clear(); out.wtris.clear(); out.nWNodes = 0; out.wMaxDepth = 0; out.nWTris = 0; out.wSahCost = 0;
+    if (root2 < 0) return;                                   /* a single leaf: small scenes use the BVH4 */
+    typedef detail::ChildRef Child;
+    struct WChild { Child c; uint32_t firstTri, nTris; };    /* leaf pieces carry their record range (in out.tris) */
+    struct Item { int32_t ref2; uint32_t index, depth; detail::Box box; };
+    std::vector<Item> queue;
+    queue.push_back({ root2, 0u, 1u, rootBox });
+    out.nWNodes = 1;
+    double cost = 0; const double rootA = rootBox.area() > 0 ? rootBox.area() : 1.0;
+    auto slotsOf = [](int32_t ref) -> int { if (ref >= 0) return 1; const uint32_t cnt = ((~(uint32_t) ref) & 7u) + 1u; return (int) ((cnt + 2) / 3); };
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const Item it = queue[head];
+        out.wMaxDepth = std::max(out.wMaxDepth, it.depth);
+        /* collapse: open the inner child with the largest area while the slots last */
+        std::vector<Child> ch(2);
+        { Child two[2]; children2(it.ref2, two); ch[0] = two[0]; ch[1] = two[1]; }
+        for (;;) {
+            int used = 0; for (const Child &c : ch) used += slotsOf(c.ref);
+            int best = -1; float bestA = -1;
+            for (size_t i = 0; i < ch.size(); ++i) {
+                if (ch[i].ref < 0) continue;
+                Child two[2]; children2(ch[i].ref, two);
+                const int extra = slotsOf(two[0].ref) + slotsOf(two[1].ref) - 1;
+                if (used + extra > 8) continue;
+                if (ch[i].box.area() > bestA) { bestA = ch[i].box.area(); best = (int) i; }
+            }
+            if (best < 0) break;
+            Child two[2]; children2(ch[best].ref, two);
+            ch[best] = two[0]; ch.push_back(two[1]);
+        }
+        /* leaf children of more than 3 records are split into pieces of <= 3 (same box) */
+        std::vector<WChild> wc;
+        for (const Child &c : ch) {
+            if (c.ref >= 0) { wc.push_back({ c, 0u, 0u }); continue; }
+            const uint32_t r = ~(uint32_t) c.ref, first = r >> 3, cnt = (r & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k += 3) wc.push_back({ c, first + k, std::min(3u, cnt - k) });
+        }
+        /* node box = union of the (padded) child boxes */
+        detail::Box nb; nb.reset();
+        for (const WChild &w : wc) nb.grow(w.c.box.mn, w.c.box.mx);
+        float p[3]; uint32_t e8[3]; double step[3];
+        for (int a = 0; a < 3; ++a) {
+            p[a] = nb.mn[a];
+            const double ext = (double) nb.mx[a] - (double) p[a];
+            int e = -120;
+            if (ext > 0) { int ex; std::frexp(ext / 255.0, &ex); e = ex; }            /* 2^e >= ext / 255 */
+            while (std::ldexp(1.0, e) * 255.0 < ext) ++e;
+            e = std::min(127, std::max(-120, e));
+            e8[a] = (uint32_t) (e + 127); step[a] = std::ldexp(1.0, e);
+        }
+        /* slot assignment by octant direction (greedy on the dot product) */
+        const float cen[3] = { 0.5f * (nb.mn[0] + nb.mx[0]), 0.5f * (nb.mn[1] + nb.mx[1]), 0.5f * (nb.mn[2] + nb.mx[2]) };
+        int slotOf[8]; bool slotUsed[8] = { false }, childDone[8] = { false };
+        for (size_t k = 0; k < wc.size(); ++k) {
+            float bestV = -INFINITY; int bc = -1, bs = -1;
+            for (size_t c = 0; c < wc.size(); ++c) {
+                if (childDone[c]) continue;
+                const float d[3] = { 0.5f * (wc[c].c.box.mn[0] + wc[c].c.box.mx[0]) - cen[0], 0.5f * (wc[c].c.box.mn[1] + wc[c].c.box.mx[1]) - cen[1],
+                                     0.5f * (wc[c].c.box.mn[2] + wc[c].c.box.mx[2]) - cen[2] };
+                for (int sl = 0; sl < 8; ++sl) {
+                    if (slotUsed[sl]) continue;
+                    const float v = ((sl & 1) ? d[0] : -d[0]) + ((sl & 2) ? d[1] : -d[1]) + ((sl & 4) ? d[2] : -d[2]);
+                    if (v > bestV) { bestV = v; bc = (int) c; bs = sl; }
+                }
+            }
+            childDone[bc] = true; slotUsed[bs] = true; slotOf[bc] = bs;
+        }
+        int childAt[8]; for (int sl = 0; sl < 8; ++sl) childAt[sl] = -1;
+        for (size_t c = 0; c < wc.size(); ++c) childAt[slotOf[c]] = (int) c;
+        /* emit */
+        uint32_t nInner = 0; for (const WChild &w : wc) if (w.c.ref >= 0) ++nInner;
+        const uint32_t childBase = out.nWNodes; out.nWNodes += nInner;
+        const uint32_t triBase = out.nWTris;
+        if (out.wnodes.size() < (size_t) out.nWNodes * 20) out.wnodes.resize((size_t) out.nWNodes * 20, 0u);
+        uint32_t *nd = &out.wnodes[(size_t) it.index * 20];
+        uint8_t meta[8], q[6][8]; uint32_t imask = 0, rank = 0, triOff = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            meta[sl] = 0;
+            for (int a = 0; a < 3; ++a) { q[a][sl] = 255; q[3 + a][sl] = 0; }
+            const int c = childAt[sl];
+            if (c < 0) continue;
+            const WChild &w = wc[c];
+            for (int a = 0; a < 3; ++a) {
+                const double lo = std::floor(((double) w.c.box.mn[a] - (double) p[a]) / step[a]);
+                const double hi = std::ceil(((double) w.c.box.mx[a] - (double) p[a]) / step[a]);
+                q[a][sl] = (uint8_t) std::min(255.0, std::max(0.0, lo));
+                q[3 + a][sl] = (uint8_t) std::min(255.0, std::max(0.0, hi));
+            }
+            cost += w.c.box.area() / rootA * (w.c.ref < 0 ? (double) w.nTris : 1.0);
+            if (w.c.ref >= 0) {
+                imask |= 1u << sl;
+                meta[sl] = (uint8_t) (0x20u | (24u + (uint32_t) sl));
+                queue.push_back({ w.c.ref, childBase + rank, it.depth + 1, w.c.box });
+                ++rank;
+            } else {
+                meta[sl] = (uint8_t) ((((1u << w.nTris) - 1u) << 5) | triOff);
+                out.wtris.insert(out.wtris.end(), out.tris.begin() + (size_t) w.firstTri * 12, out.tris.begin() + (size_t) (w.firstTri + w.nTris) * 12);
+                triOff += w.nTris; out.nWTris += w.nTris;
+            }
+        }
+        auto pack4 = [](const uint8_t *b) { return (uint32_t) b[0] | ((uint32_t) b[1] << 8) | ((uint32_t) b[2] << 16) | ((uint32_t) b[3] << 24); };
+        memcpy(&nd[0], &p[0], 4); memcpy(&nd[1], &p[1], 4); memcpy(&nd[2], &p[2], 4);
+        nd[3] = e8[0] | (e8[1] << 8) | (e8[2] << 16) | (imask << 24);
+        nd[4] = childBase; nd[5] = triBase; nd[6] = pack4(meta); nd[7] = pack4(meta + 4);
+        nd[8] = pack4(q[0]); nd[9] = pack4(q[0] + 4); nd[10] = pack4(q[1]); nd[11] = pack4(q[1] + 4);
+        nd[12] = pack4(q[2]); nd[13] = pack4(q[2] + 4); nd[14] = pack4(q[3]); nd[15] = pack4(q[3] + 4);
+        nd[16] = pack4(q[4]); nd[17] = pack4(q[4] + 4); nd[18] = pack4(q[5]); nd[19] = pack4(q[5] + 4);
+    }
+    out.wSahCost = (float) (cost + 1.0);
+}
+
 inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t nTris, HostBVH &out) {
     auto t0 = std::chrono::steady_clock::now();
     std::vector<BuildTri> T; T.reserve(nTris);
@@ -245,7 +381,7 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
     const int32_t root2 = B.build(0, T.size(), rootBox, 1);
 
     /* ---- collapse to BVH4 ---- */
-    struct Child { int32_t ref; detail::Box box; };
+    typedef detail::ChildRef Child;
     auto children2 = [&](int32_t ref, Child out2[2]) {
         const float *nd = &out.nodes2[(size_t) ref * 16];
         out2[0].box.mn[0] = nd[0]; out2[0].box.mn[1] = nd[1]; out2[0].box.mn[2] = nd[2]; out2[0].box.mx[0] = nd[3]; out2[0].box.mx[1] = nd[4]; out2[0].box.mx[2] = nd[5];
@@ -319,39 +455,8 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
         out.rootRef = (int32_t) newIndex[out.rootRef];
     }
 
-    /* ---- 8-wide collapse for the lane-cooperative traversal (one child box per lane) ---- */
-    double cost8 = 0;
-    std::function<int32_t(int32_t, uint32_t)> collapse8 = [&](int32_t ref2, uint32_t depth) -> int32_t {
-        out.maxDepth8 = std::max(out.maxDepth8, depth);
-        if (ref2 < 0) return ref2;
-        Child ch[8]; int n = 2;
-        children2(ref2, ch);
-        while (n < 8) {
-            int best = -1; float bestA = -1;
-            for (int i = 0; i < n; ++i) if (ch[i].ref >= 0 && ch[i].box.area() > bestA) { bestA = ch[i].box.area(); best = i; }
-            if (best < 0) break;
-            Child two[2]; children2(ch[best].ref, two);
-            ch[best] = two[0]; ch[n++] = two[1];
-        }
-        const uint32_t idx = out.nNodes8++;
-        out.nodes8.resize((size_t) out.nNodes8 * 64);
-        int32_t refs[8];
-        for (int i = 0; i < n; ++i) {
-            refs[i] = collapse8(ch[i].ref, depth + 1);
-            cost8 += ch[i].box.area() / rootA;
-        }
-        float *nd = &out.nodes8[(size_t) idx * 64];
-        for (int i = 0; i < 8; ++i) {
-            const bool used = i < n;
-            float *c = nd + 8 * i;
-            for (int a = 0; a < 3; ++a) { c[a] = used ? ch[i].box.mn[a] : INFINITY; c[3 + a] = used ? ch[i].box.mx[a] : -INFINITY; }
-            c[6] = detail::bits2f(used ? (uint32_t) refs[i] : 0xffffffffu);
-            c[7] = 0.0f;
-        }
-        return (int32_t) idx;
-    };
-    out.rootRef8 = collapse8(root2, 1);
-    out.sahCost8 = (float) (cost8 + 1.0);
+    /* ---- compressed 8-wide tree for the big-scene ray kernels ---- */
+    buildWide(out, root2, rootBox, children2);
     std::vector<float>().swap(out.nodes2);
     out.buildMs = (float) std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

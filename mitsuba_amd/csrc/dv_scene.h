@@ -83,6 +83,7 @@ struct DevEnvMap {
 
 struct DevScene {
     const float4 *nodes; const float4 *tris; const float4 *triShade;
+    const uint4 *wnodes; uint32_t wideNodeCache;             /* big scenes: the compressed 8-wide tree (k_wide.h); tris is then in ITS leaf order and nodes is unused */
     const DevMaterial *materials; uint32_t nMaterials;
     const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;

@@ -128,7 +128,7 @@ __device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char 
  * the ray is inside the slab iff min <= o <= max).  A finite +-2^90 keeps the arithmetic meaningful: inside the slab the
  * two plane distances are -huge / +huge (no constraint), outside both have the same sign and |t| >= 2^90 * distance
  * exceeds every finite maxt; boxes are padded (bvh.h), so the rounding of o * rcp cannot flip a decision. */
-__device__ __forceinline__ float slabRcp(float d) {
+DV float slabRcp(float d) {
     return fabsf(d) < 8.0779357e-28f /* 2^-90 */ ? copysignf(1.2379400e27f /* 2^90 */, d) : 1.0f / d;
 }
 

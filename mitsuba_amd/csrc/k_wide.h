@@ -1,0 +1,295 @@
+/*
+ * k_wide.h -- traversal of the compressed 8-wide BVH (bvh.h: buildWide) for the big scenes: k_rays_w (persistent waves with
+ * refill; closest-hit and any-hit rays of an iteration in one launch) and k_raycast_w (phip_trace).  Included by phip.hip
+ * after k_rays.h, whose ray sources (ShadowSource / TraceSource) it shares.
+ *
+ * Why a second structure: the BVH4 ray kernel of the 250k-triangle scenes was measured (round 2, SQ counters) at 34 % VALU
+ * issue with 64 % of its wave cycles waiting -- every lane of a wave fetches its own node, i.e. 64 different cache lines per
+ * load instruction and seven instructions per 128-byte node, so the CU's vector-memory path is the bound, not the ALUs.  An
+ * 80-byte node with eight quantised child boxes (Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through
+ * Compressed Wide BVHs", HPG 2017) costs five load instructions and replaces ~2.3 BVH4 nodes: fewer bytes AND fewer
+ * dependent round trips per ray, paid for with ALU work there is room for.
+ *
+ * Per-lane state machine, as in k_traverse.h: one node step and one triangle test per loop iteration.  The traversal stack
+ * holds GROUPS, 8 bytes each: a node group (childBase, hit bits 24..31 | imask) or a triangle group (triBase, hit bits 0..23),
+ * so a node pushes at most one entry however many of its children are hit and the stack is as deep as the tree (LDS:
+ * WIDE_STACK_LDS entries per lane, the rest spills to HBM).  Children are visited in the order slot ^ rayOctant, which the
+ * builder's slot assignment makes approximately front to back -- no sort.  Hits are decided by the same Wald test on the same
+ * records (waldIntersect, dv_scene.h); boxes are conservative, so results do not depend on the structure.
+ */
+
+#define WIDE_STACK_LDS 12                /* 8-byte entries per lane in LDS (24 KB per block of 256) */
+#define WIDE_NODE_CACHE_MAX 64           /* top-of-tree nodes (BFS order) staged in LDS: 5 KB */
+#ifndef WIDE_WAVES
+#define WIDE_WAVES 5                     /* waves per SIMD of k_rays_w */
+#endif
+
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u2v lds_u2;
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u4v lds_cu4;
+
+struct WideStack {
+    lds_u2 *lds;            /* LDS base + threadIdx.x: entry e at lds[e * BLOCK] */
+    uint2 *spill;           /* global: SPILL_DEPTH / 2 entries per lane (the BVH4 kernels' region, reinterpreted) */
+    lds_cu4 *nodes;         /* LDS copy of wide nodes [0, nodeCache) */
+    uint32_t nodeCache;
+    int sp;
+    __device__ __forceinline__ void push(uint2 v) {
+        if (sp < WIDE_STACK_LDS) { u2v t; t.x = v.x; t.y = v.y; lds[sp * BLOCK] = t; } else spill[sp - WIDE_STACK_LDS] = v;
+        ++sp;
+    }
+    __device__ __forceinline__ uint2 pop() {
+        --sp;
+        if (sp < WIDE_STACK_LDS) { const u2v t = lds[sp * BLOCK]; return make_uint2(t.x, t.y); }
+        return spill[sp - WIDE_STACK_LDS];
+    }
+};
+
+__host__ __device__ __forceinline__ size_t wideLdsBytes(uint32_t nodeCache) { return (size_t) WIDE_STACK_LDS * BLOCK * sizeof(uint2) + (size_t) nodeCache * 5 * sizeof(uint4); }
+
+/* carve the block's dynamic LDS and stage the top of the tree (all threads of the block must call) */
+__device__ __forceinline__ void setupWide(const DevScene &S, unsigned char *smem, uint32_t *spill, WideStack &stk) {
+    uint2 *stack = (uint2 *) smem;
+    uint4 *ln = (uint4 *) (smem + (size_t) WIDE_STACK_LDS * BLOCK * sizeof(uint2));
+    for (uint32_t i = threadIdx.x; i < S.wideNodeCache * 5u; i += BLOCK) ln[i] = S.wnodes[i];
+    __syncthreads();
+    stk.lds = (lds_u2 *) (stack + threadIdx.x); stk.spill = (uint2 *) spill; stk.nodes = (lds_cu4 *) ln; stk.nodeCache = S.wideNodeCache; stk.sp = 0;
+}
+
+struct WideRay {
+    V3 o, d, rcp;
+    float mint, maxt;
+    uint32_t octinv4;       /* (7 - octant) replicated into the four bytes; octant bit a = direction component a is negative */
+};
+
+DV void wideRaySetup(WideRay &r, const V3 &o, const V3 &d, float mint, float maxt) {
+    r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
+    r.rcp = V3(slabRcp(d.x), slabRcp(d.y), slabRcp(d.z));
+    const uint32_t oct = (r.rcp.x < 0 ? 1u : 0u) | (r.rcp.y < 0 ? 2u : 0u) | (r.rcp.z < 0 ? 4u : 0u);
+    r.octinv4 = (7u - oct) * 0x01010101u;
+}
+
+DV float ubyte(uint32_t v, int k) { return (float) ((v >> (8 * k)) & 0xffu); }     /* v_cvt_f32_ubyte<k> */
+
+/* One node: slab test of the eight quantised child boxes.  Returns the hit bits: 24..31 inner children in traversal order
+   (highest bit = first), 0..23 the leaf triangles of the hit leaves. */
+DV uint32_t wideNodeHits(const uint4 &n0, const uint4 &n1, const uint4 &n2, const uint4 &n3, const uint4 &n4, const WideRay &r) {
+    /* child box plane = p + q * 2^(e-127): t = q * (2^e * rcp) + (p - o) * rcp */
+    const float sx = pm_from_bits((n0.w & 0xffu) << 23) * r.rcp.x, sy = pm_from_bits(((n0.w >> 8) & 0xffu) << 23) * r.rcp.y,
+                sz = pm_from_bits(((n0.w >> 16) & 0xffu) << 23) * r.rcp.z;
+    const float bx = (pm_from_bits(n0.x) - r.o.x) * r.rcp.x, by = (pm_from_bits(n0.y) - r.o.y) * r.rcp.y, bz = (pm_from_bits(n0.z) - r.o.z) * r.rcp.z;
+    /* near / far planes by the sign of the direction: swap whole dwords (four children each) */
+    const bool nx = r.rcp.x < 0, ny = r.rcp.y < 0, nz = r.rcp.z < 0;
+    const uint32_t lox[2] = { n2.x, n2.y }, loy[2] = { n2.z, n2.w }, loz[2] = { n3.x, n3.y }, hix[2] = { n3.z, n3.w }, hiy[2] = { n4.x, n4.y }, hiz[2] = { n4.z, n4.w };
+    const uint32_t meta[2] = { n1.z, n1.w };
+    uint32_t hits = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (h) __builtin_amdgcn_sched_barrier(0);        /* four children at a time: the two halves interleaved cost more live registers */
+#endif
+        const uint32_t qnx = nx ? hix[h] : lox[h], qfx = nx ? lox[h] : hix[h];
+        const uint32_t qny = ny ? hiy[h] : loy[h], qfy = ny ? loy[h] : hiy[h];
+        const uint32_t qnz = nz ? hiz[h] : loz[h], qfz = nz ? loz[h] : hiz[h];
+        /* byte-parallel decode of the four meta bytes (CWBVH): inner children (low 5 bits >= 24) get their slot xor-ed with the
+           inverted ray octant, which turns "slot" into "traversal priority"; leaves keep their triangle offset */
+        const uint32_t m4 = meta[h];
+        const uint32_t isInner4 = (m4 & (m4 << 1)) & 0x10101010u;                    /* bit 4 of a byte: bits 3 and 4 both set <=> low5 >= 24 */
+        const uint32_t innerMask4 = (isInner4 >> 4) * 0xffu;                         /* 0xff in the bytes of inner children */
+        const uint32_t bitIndex4 = (m4 ^ (r.octinv4 & innerMask4)) & 0x1f1f1f1fu;
+        const uint32_t childBits4 = (m4 >> 5) & 0x07070707u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float tnx = fmaf(ubyte(qnx, k), sx, bx), tfx = fmaf(ubyte(qfx, k), sx, bx);
+            const float tny = fmaf(ubyte(qny, k), sy, by), tfy = fmaf(ubyte(qfy, k), sy, by);
+            const float tnz = fmaf(ubyte(qnz, k), sz, bz), tfz = fmaf(ubyte(qfz, k), sz, bz);
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, r.mint));
+            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, r.maxt));
+            const uint32_t bits = (childBits4 >> (8 * k)) & 0xffu, idx = (bitIndex4 >> (8 * k)) & 0xffu;
+            hits |= (tn <= tf) ? (bits << idx) : 0u;
+        }
+    }
+    return hits;
+}
+
+#define WIDE_LOAD_NODE(stack, S, idx, n0, n1, n2, n3, n4)                                             \
+    uint4 n0, n1, n2, n3, n4;                                                                         \
+    {                                                                                                 \
+        const uint4 *g_ = (idx) < (stack).nodeCache ? (const uint4 *) ((stack).nodes + 5u * (idx)) : (S).wnodes + 5 * (size_t) (idx); \
+        n0 = g_[0]; n1 = g_[1]; n2 = g_[2]; n3 = g_[3]; n4 = g_[4];                                   \
+    }
+
+/* One node step of a lane whose node group `ng` has inner hits: take the first child in traversal order, push the rest of the
+   group, intersect the child node -> new node group and triangle group.  A pending triangle group must be empty. */
+#define WIDE_NODE_STEP(stack, S, ray, ng, tg, nodeVisits)                                             \
+    {                                                                                                 \
+        const uint32_t bit_ = 31u - (uint32_t) __clz((int) (ng).y);                                   \
+        (ng).y &= ~(1u << bit_);                                                                      \
+        if ((ng).y & 0xff000000u) (stack).push(ng);                                                   \
+        const uint32_t slot_ = (bit_ - 24u) ^ ((ray).octinv4 & 7u);                                   \
+        const uint32_t idx_ = (ng).x + (uint32_t) __popc((ng).y & ((1u << slot_) - 1u) & 0xffu);      \
+        WIDE_LOAD_NODE(stack, S, idx_, n0, n1, n2, n3, n4)                                            \
+        ++nodeVisits;                                                                                 \
+        const uint32_t hits_ = wideNodeHits(n0, n1, n2, n3, n4, ray);                                 \
+        (ng) = make_uint2(n1.x, (hits_ & 0xff000000u) | (n0.w >> 24));                                \
+        (tg) = make_uint2(n1.y, hits_ & 0x00ffffffu);                                                 \
+    }
+
+/* the root: node 0 is entered as the only child of a virtual group (child base 0, no inner slots below it: rank 0) */
+__device__ __forceinline__ uint2 wideRootGroup() { return make_uint2(0u, 0x80000000u); }
+
+/* per-lane traversal to completion (k_raycast_w) */
+template <bool SHADOW>
+__device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
+                                             WideStack &stack, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
+    WideRay ray; wideRaySetup(ray, o, d, mint, maxt);
+    stack.sp = 0;
+    uint2 ng = wideRootGroup(), tg = make_uint2(0u, 0u);
+    bool found = false;
+    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+    for (;;) {
+        if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, nodeVisits)
+        if (tg.y) {
+            const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;
+            tg.y &= tg.y - 1u;
+            const float4 *t_ = S.tris + 3 * (size_t) (tg.x + bit);
+            const float4 a = t_[0], b = t_[1], c = t_[2];
+            ++triTests;
+            float tu, tv, tt;
+            if (waldIntersect(a, b, c, o, d, ray.mint, ray.maxt, tu, tv, tt)) {
+                if (SHADOW) return true;
+                ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
+                found = true;
+            }
+        }
+        if (tg.y == 0u && !(ng.y & 0xff000000u)) {
+            if (stack.sp == 0) break;
+            const uint2 e = stack.pop();
+            if (e.y & 0xff000000u) ng = e; else { tg = e; ng = make_uint2(0u, 0u); }
+        }
+    }
+    return found;
+}
+
+/* ---- persistent waves with refill: closest-hit AND any-hit rays of one iteration in ONE launch (as k_rays_p) ---- */
+__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStack &stack, ShadowSource &ss, TraceSource &ts,
+                                                       uint32_t *wc /* LDS: WC_COUNT counters of this wave */) {
+    bool active = false, shadow = false;
+    uint32_t handle = INVALID_RAY;
+    WideRay ray; ray.o = ray.d = ray.rcp = V3(0.0f); ray.mint = ray.maxt = 0; ray.octinv4 = 0;
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    uint32_t nodeCur = 0, triCur = 0;
+    TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const bool moreS = ss.more(), moreAny = moreS || ts.more();              /* wave-uniform */
+        if (idle && moreAny && (__popcll(idle) >= REFILL_LANES || idle == ~0ull)) {
+            const uint32_t h = moreS ? ss.assign(!active, idle) : ts.assign(!active, idle);
+            if (!active && h != INVALID_RAY) {
+                V3 o, d; float rmint, rmaxt;
+                const bool ok = moreS ? ss.load(h, o, d, rmint, rmaxt) : ts.load(h, o, d, rmint, rmaxt);
+                if (ok) {
+                    atomicAdd(&wc[moreS ? WC_SH_RAYS : WC_RAYS], 1u);
+                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+                    float mint, maxt;
+                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS)) {
+                        wideRaySetup(ray, o, d, mint, maxt);
+                        ng = wideRootGroup(); tg = make_uint2(0u, 0u);
+                        stack.sp = 0; handle = h; active = true; shadow = moreS; nodeCur = triCur = 0;
+                    } else if (moreS) {
+                        ss.commit(h, false, res);
+                    } else {
+                        ts.commit(h, false, res);
+                    }
+                }
+            }
+        }
+        if (!__any(active)) { if (!(ss.more() || ts.more())) break; continue; }
+        if (active) {
+            for (;;) {
+                /* one node step and one triangle test per iteration */
+                if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, nodeCur)
+                bool finished = false;
+                if (tg.y) {
+                    const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;
+                    tg.y &= tg.y - 1u;
+                    const float4 *t_ = S.tris + 3 * (size_t) (tg.x + bit);
+                    const float4 a = t_[0], b = t_[1], c = t_[2];
+                    ++triCur;
+                    float tu, tv, tt;
+                    if (waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {
+                        if (shadow) { res.prim = 0; finished = true; }
+                        else { ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
+                    }
+                }
+                if (!finished && tg.y == 0u && !(ng.y & 0xff000000u)) {
+                    if (stack.sp == 0) finished = true;
+                    else {
+                        const uint2 e = stack.pop();
+                        if (e.y & 0xff000000u) ng = e; else { tg = e; ng = make_uint2(0u, 0u); }
+                    }
+                }
+                if (finished) {
+                    if (shadow) ss.commit(handle, res.prim != PHIP_NO_HIT, res);
+                    else ts.commit(handle, false, res);
+                    atomicAdd(&wc[shadow ? WC_SH_NODE : WC_NODE], nodeCur);
+                    atomicAdd(&wc[shadow ? WC_SH_TRI : WC_TRI], triCur);
+                    active = false;
+                    break;
+                }
+                if ((ss.more() || ts.more()) && __popcll(__ballot(1)) <= 64 - REFILL_LANES) break;     /* enough idle lanes: refill */
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L) {
+    __shared__ uint32_t wcnt[BLOCK / 64][WC_COUNT];
+    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
+    if (threadIdx.x < (BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
+    WideStack stk; setupWide(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
+    ShadowSource ss{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
+    ss.skipEmpty();
+    TraceSource ts{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
+    persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
+    if (__lane_id() == 0) {
+        const int rows[WC_COUNT] = { ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
+#pragma unroll
+        for (int i = 0; i < WC_COUNT; ++i) {
+            const uint32_t v = wcnt[wave][i];
+            if (v) P.stat[(size_t) rows[i] * P.nWaves + waveId] += v;
+        }
+    }
+}
+
+/* standalone ray casts for phip_trace on the wide tree */
+__global__ __launch_bounds__(BLOCK) void k_raycast_w(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
+    const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
+    WideStack stk; setupWide(S, g_smem, P.spill + i * SPILL_DEPTH, stk);
+    uint32_t nodeVisits = 0, triTests = 0, shNodeVisits = 0, shTriTests = 0;
+    if (i < n) {
+        const phip_ray ry = rays[i];
+        const V3 o(ry.o[0], ry.o[1], ry.o[2]), d(ry.d[0], ry.d[1], ry.d[2]);
+        float mint, maxt;
+        if (hits) {
+            TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
+            if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt))
+                traverseWide<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
+            phip_hit h; h.t = r.t; h.u = r.u; h.v = r.v; h.prim = r.prim;
+            hits[i] = h;
+        }
+        if (occluded) {
+            TravResult r; bool occ = false;
+            if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
+                occ = traverseWide<true>(S, o, d, mint, maxt, stk, r, shNodeVisits, shTriTests);
+            occluded[i] = occ ? 1 : 0;
+        }
+    }
+    const uint32_t waveId = (uint32_t) (i >> 6);
+    waveStat(P, ST_NODE, waveId, nodeVisits);
+    waveStat(P, ST_TRI, waveId, triTests);
+    waveStat(P, ST_SH_NODE, waveId, shNodeVisits);
+    waveStat(P, ST_SH_TRI, waveId, shTriTests);
+}

@@ -17,6 +17,8 @@
  *   k_rays.h      k_trace / k_shadow (one lane per slot, small scenes), k_trace_p / k_shadow_p / k_rays_p (persistent
  *                 waves with refill; k_rays_p casts the closest-hit and the any-hit rays of an iteration in one launch),
  *                 k_raycast (phip_trace)                                                     [this unit]
+ *   k_wide.h      the same ray kernels over the compressed 8-wide BVH (80-byte nodes, quantised child boxes) that the big
+ *                 scenes use: k_rays_w, k_raycast_w                                            [this unit]
  *   k_shade.h     shadeVertex + k_shade<materials, strictNormals, features>: emitter-hit / environment MIS term, Russian
  *                 roulette, emission, NEE sample (self-contained shadow-queue entry, block-compacted), BSDF sample -> next
  *                 ray in place; a path that ends is replaced by the SAME lane in the same launch (static sample schedule
@@ -36,6 +38,7 @@
 #include "bvh.h"
 #include "k_traverse.h"
 #include "k_rays.h"
+#include "k_wide.h"
 #include "k_film.h"
 #include <dlfcn.h>
 #include <map>
@@ -157,6 +160,7 @@ struct SceneDev {
     int device = 0;
     /* ---- scene (immutable after build / replication) ---- */
     DevBuf<float4> nodes, tris, triShade;
+    DevBuf<uint4> wnodes;                                                                     /* compressed wide BVH (big scenes) */
     DevBuf<DevMaterial> materials;
     DevBuf<float> emitterTab;
     DevBuf<float4> texTexels; DevBuf<DevMipLevels> texDesc;                                   /* bitmap textures */
@@ -177,12 +181,12 @@ struct SceneDev {
     hipStream_t stream = nullptr;
 
     template <typename F> void forEachSceneBuffer(F f) {
-        f(nodes); f(tris); f(triShade); f(materials); f(emitterTab); f(texTexels); f(texDesc);
+        f(nodes); f(wnodes); f(tris); f(triShade); f(materials); f(emitterTab); f(texTexels); f(texDesc);
         f(envTexels); f(envLevels); f(envCdfRows); f(envCdfCols); f(envRowWeights);
     }
     /* the pointer members of the DevScene (everything else in it is plain data, equal on every device) */
     void bind() {
-        dev.nodes = nodes.p; dev.tris = tris.p; dev.triShade = triShade.p; dev.materials = materials.p;
+        dev.nodes = nodes.p; dev.wnodes = wnodes.p; dev.tris = tris.p; dev.triShade = triShade.p; dev.materials = materials.p;
         dev.texTexels = texTexels.p; dev.textures = texDesc.p; dev.emitterTab = emitterTab.p;
         dev.env.texels = envTexels.p; dev.env.levels = envLevels.p; dev.env.cdfRows = envCdfRows.p; dev.env.cdfCols = envCdfCols.p;
         dev.env.rowWeights = envRowWeights.p;
@@ -200,6 +204,7 @@ struct phip_scene {
     bool hasTextures = false; uint32_t triShadeStride = TRISHADE_FLOAT4S;
     int envLevelCount = 0;           /* MIP levels of the envmap (0: no envmap) */
     int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
+    bool wide = false;               /* the ray kernels walk the compressed 8-wide BVH (trees of >= 64 BVH4 nodes; PHIP_WIDE=0 keeps the BVH4) */
     bool fitsLds = false;            /* tree, Wald records, shading records, emitter table and materials fit the fused kernel's LDS plan */
     std::vector<std::unique_ptr<SceneDev>> devs;
     int *cancelFlag = nullptr;       /* host-pinned (portable, mapped): phip_cancel writes it, host loops and k_mega poll it */
@@ -460,9 +465,20 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (texTexels.empty()) sd.texTexels.alloc(1); else sd.texTexels.upload(texTexels.data(), texTexels.size());
     if (texDesc.empty()) sd.texDesc.alloc(1); else sd.texDesc.upload(texDesc.data(), texDesc.size());
     sc->hasTextures = d.n_textures > 0; sc->triShadeStride = stride;
-    if (sc->bvh.nodes.empty()) sd.nodes.alloc(8);
-    else sd.nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
-    sd.tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
+    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = strcmp(e, "lane") == 0 ? 0 : 2;
+    sc->wide = sc->traversal == 2 && sc->bvh.nWNodes > 0 && sc->bvh.nNodes >= 64;
+    if (const char *e = getenv("PHIP_WIDE")) sc->wide = sc->wide && atoi(e) != 0;
+    if (sc->wide) {
+        /* big scenes: the compressed wide tree and the records in ITS leaf order; the BVH4 stays on the host */
+        sd.nodes.alloc(8);
+        sd.wnodes.upload((const uint4 *) sc->bvh.wnodes.data(), sc->bvh.wnodes.size() / 4);
+        sd.tris.upload((const float4 *) sc->bvh.wtris.data(), sc->bvh.wtris.size() / 4);
+    } else {
+        if (sc->bvh.nodes.empty()) sd.nodes.alloc(8);
+        else sd.nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
+        sd.wnodes.alloc(5);
+        sd.tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
+    }
     sd.materials.upload(mats.data(), mats.size());
     sc->materialMask = 0;
     for (const DevMaterial &m : mats) {
@@ -611,7 +627,13 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     D.triCache = (sc->bvh.tris.size() / 12 <= TRI_CACHE_MAX) ? (uint32_t) (sc->bvh.tris.size() / 12) : 0u;
     if (const char *e = getenv("PHIP_NODE_CACHE")) D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, (uint32_t) atoi(e));
     if (D.nodeCache == 0) D.triCache = 0;
-    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = strcmp(e, "lane") == 0 ? 0 : 2;
+    D.wnodes = sd.wnodes.p; D.wideNodeCache = 0;
+    if (sc->wide) {
+        D.nodeCache = 0; D.triCache = 0;
+        D.wideNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, WIDE_NODE_CACHE_MAX);
+        if (const char *e = getenv("PHIP_NODE_CACHE")) D.wideNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, (uint32_t) atoi(e));
+        if ((int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS + SPILL_DEPTH / 2) throw std::runtime_error("wide BVH too deep for the traversal stack");
+    }
     for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
     setupCamera(d.camera, d.film, D.cam);
     D.film.width = d.film.crop_width; D.film.height = d.film.crop_height;
@@ -635,6 +657,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     sd.dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
     sd.megaNext.alloc(1);
     std::vector<float>().swap(sc->bvh.nodes); std::vector<float>().swap(sc->bvh.tris);      /* keep the statistics, drop the arrays */
+    std::vector<uint32_t>().swap(sc->bvh.wnodes); std::vector<float>().swap(sc->bvh.wtris);
     HIP_TRY(hipHostMalloc((void **) &sc->cancelFlag, sizeof(int), hipHostMallocPortable | hipHostMallocMapped));
     *sc->cancelFlag = 0;
 }
@@ -645,7 +668,7 @@ static SceneDev *replicateScene(phip_scene *sc, int device) {
     std::unique_ptr<SceneDev> dst(new SceneDev());
     dst->device = device;
     HIP_TRY(hipSetDevice(device));
-    dst->nodes.cloneFrom(src.nodes); dst->tris.cloneFrom(src.tris); dst->triShade.cloneFrom(src.triShade);
+    dst->nodes.cloneFrom(src.nodes); dst->wnodes.cloneFrom(src.wnodes); dst->tris.cloneFrom(src.tris); dst->triShade.cloneFrom(src.triShade);
     dst->materials.cloneFrom(src.materials); dst->emitterTab.cloneFrom(src.emitterTab);
     dst->texTexels.cloneFrom(src.texTexels); dst->texDesc.cloneFrom(src.texDesc);
     dst->envTexels.cloneFrom(src.envTexels); dst->envLevels.cloneFrom(src.envLevels);
@@ -678,14 +701,15 @@ static void phipLaunchShadeDirect(int feat, int materialMask, dim3 grid, hipStre
 }
 
 static size_t traversalLdsBytes(const DevScene &D) {
+    if (D.wideNodeCache) return wideLdsBytes(D.wideNodeCache);
     return (size_t) D.stackDepth * BLOCK * sizeof(uint32_t) + (size_t) D.nodeCache * NODE_LDS_STRIDE * sizeof(float4) + (size_t) D.triCache * 3 * sizeof(float4);
 }
 
-static void algorithmicBytes(bool mergedRays, phip_stats &st, double filmPixels) {
+static void algorithmicBytes(bool mergedRays, phip_stats &st, double filmPixels, bool wide = false) {
     /* SURVEY 8(d) with this structure's sizes: 128-byte BVH4 node visits, 48-byte triangle records
        (no separate index array: records are stored in leaf order) */
     const double film = 20.0 * filmPixels;
-    const double nodeBytes = 128.0;
+    const double nodeBytes = wide ? 80.0 : 128.0;
     st.algorithmic_bytes = nodeBytes * (double) (st.closest_node_visits + st.shadow_node_visits) +
            48.0 * (double) (st.closest_triangle_tests + st.shadow_triangle_tests) +
            (64.0 + 40.0 + 108.0) * (double) st.closest_rays + (64.0 + 4.0) * (double) st.shadow_rays +
@@ -840,6 +864,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
            on small trees the plain per-slot closest-hit launch wins, so the kernels stay separate there) */
         merged = sc->traversal == 2 && sc->bvh.nNodes >= 64;
         if (const char *e = getenv("PHIP_MERGED")) merged = sc->traversal == 2 && atoi(e) != 0;
+        if (sc->wide) merged = true;                             /* the wide tree has the merged kernel only */
     }
     sd.mergedRays = merged;
     /* persistent kernels: exactly the resident set (TRACE_WAVES waves per SIMD = TRACE_WAVES blocks of 256 per CU)
@@ -850,7 +875,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         return dim3((unsigned) std::max(1, std::min<int>(nCU * std::min(blocksPerCU, ldsFit), (int) ((capacity + BLOCK - 1) / BLOCK))));
     };
     const dim3 grid((capacity + BLOCK - 1) / BLOCK);
-    const dim3 pgrid = persistentGrid(TRACE_WAVES), pgridTrace = persistentGrid(TRACE_P_WAVES), pgridRays = persistentGrid(RAYS_WAVES);
+    const dim3 pgrid = persistentGrid(TRACE_WAVES), pgridTrace = persistentGrid(TRACE_P_WAVES), pgridRays = persistentGrid(sc->wide ? WIDE_WAVES : RAYS_WAVES);
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
 
     /* fused path: resident grid and per-wave statistics rows */
@@ -936,7 +961,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                 if (timing) evShade.record(stream);
                 if (merged) {
                     if (timing) evTrace.record(stream);
-                    hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
+                    if (sc->wide) hipLaunchKernelGGL(k_rays_w, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
+                    else hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
                     if (timing) evTrace.record(stream);
                 } else {
                     if (timing) evShadow.record(stream);
@@ -1015,7 +1041,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     st.shade_kernel_ms = evShade.sumPairs(); st.film_kernel_ms = evFilm.sumPairs(); st.fused_kernel_ms = evFused.sumPairs();
     st.fused = fused ? 1u : 0u; st.n_devices = 1;
     st.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
-    algorithmicBytes(merged, st, (double) W * H);
+    algorithmicBytes(merged, st, (double) W * H, sc->wide);
     if (stats) *stats = st;
     return cancelled ? PHIP_ERR_CANCELLED : PHIP_OK;
 }
@@ -1312,7 +1338,8 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             HIP_TRY(hipMemset(stat.p, 0, stat.n * sizeof(unsigned long long)));
             P.stat = stat.p; P.spill = spill.p;
             ev.record(0);
-            hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);
+            if (scene->wide) hipLaunchKernelGGL(k_raycast_w, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);
+            else hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);
             ev.record(0);
             HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), 0));
             hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, 0, P, sd.counters.p, 0);
@@ -1330,7 +1357,7 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             out_stats->closest_rays = hits ? n : 0; out_stats->shadow_rays = occluded ? n : 0;
             out_stats->trace_kernel_ms = ev.sumPairs(); out_stats->iterations = (uint32_t) ((n + CHUNK - 1) / CHUNK);
             out_stats->n_devices = 1;
-            algorithmicBytes(false, *out_stats, 0.0);
+            algorithmicBytes(false, *out_stats, 0.0, scene->wide);
         }
         return PHIP_OK;
     } catch (const std::exception &e) {
@@ -1354,6 +1381,7 @@ int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
     out->n_nodes = scene->bvh.nNodes; out->n_leaves = scene->bvh.nLeaves; out->n_triangle_refs = scene->bvh.nTriRefs;
     out->max_depth = scene->bvh.maxDepth; out->node_bytes = 128; out->triangle_bytes = 48;
     out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
+    if (scene->wide) { out->n_nodes = scene->bvh.nWNodes; out->max_depth = scene->bvh.wMaxDepth; out->node_bytes = 80; out->sah_cost = scene->bvh.wSahCost; }
     out->fits_lds = scene->fitsLds ? 1u : 0u; out->reserved = 0;
     return PHIP_OK;
 }

@@ -107,6 +107,92 @@ int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const
     } catch (const std::exception &e) { return setErr(PHIP_ERR_INVALID, e.what()); }
 }
 
+/* Closest-hit ray casts through the compressed wide BVH ON THE HOST: the tree of buildWide() walked with the node-step
+   arithmetic of k_wide.h (wideNodeHits is __host__ __device__) and the Wald test of dv_scene.h.  Lets the CPU test-suite pin
+   the builder's encoding (quantisation, slots, child / triangle indexing) and the group stack logic against the oracle
+   without a GPU; the device kernels run the same functions.  use_wide = 0 walks nothing and tests every record (brute force). */
+int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles,
+                               const phip_ray *rays, size_t n_rays, phip_hit *hits, int use_wide, phip_accel_info *info) {
+    try {
+        for (uint32_t i = 0; i < 3 * n_triangles; ++i) if (indices[i] >= n_vertices) return setErr(PHIP_ERR_INVALID, "index out of range");
+        HostBVH bvh; buildBVH(positions, indices, n_triangles, bvh);
+        if (info) {
+            memset(info, 0, sizeof(*info));
+            info->n_nodes = bvh.nWNodes; info->max_depth = bvh.wMaxDepth; info->n_triangle_refs = bvh.nWTris; info->node_bytes = 80; info->triangle_bytes = 48;
+            info->sah_cost = bvh.wSahCost; info->build_ms = bvh.buildMs;
+        }
+        if (use_wide && bvh.nWNodes == 0) return setErr(PHIP_ERR_INVALID, "the scene has no wide tree (a single leaf)");
+        DevScene S; memset(&S, 0, sizeof(S));
+        for (int a = 0; a < 3; ++a) { S.sceneMin[a] = bvh.sceneMin[a]; S.sceneMax[a] = bvh.sceneMax[a]; }
+        const float4 *recs = (const float4 *) (use_wide ? bvh.wtris.data() : bvh.tris.data());
+        const size_t nRecs = (use_wide ? bvh.wtris.size() : bvh.tris.size()) / 12;
+        const uint4 *wn = (const uint4 *) bvh.wnodes.data();
+        for (size_t i = 0; i < n_rays; ++i) {
+            const V3 o(rays[i].o[0], rays[i].o[1], rays[i].o[2]), d(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
+            phip_hit h; h.t = INFINITY; h.u = h.v = 0; h.prim = PHIP_NO_HIT;
+            /* scene-box clip + adaptive epsilon, skdtree.cpp:112-142 (the host twin of clipToScene<false>) */
+            float nearT = -INFINITY, farT = INFINITY; bool ok = true;
+            const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+            for (int a = 0; a < 3 && ok; ++a) {
+                if (dd[a] == 0) { if (oo[a] < S.sceneMin[a] || oo[a] > S.sceneMax[a]) ok = false; }
+                else {
+                    const float rcp = 1.0f / dd[a];
+                    float t1 = (S.sceneMin[a] - oo[a]) * rcp, t2 = (S.sceneMax[a] - oo[a]) * rcp;
+                    if (t1 > t2) std::swap(t1, t2);
+                    nearT = smax(t1, nearT); farT = smin(t2, farT);
+                    if (!(nearT <= farT)) ok = false;
+                }
+            }
+            float mint = nearT, maxt = farT;
+            if (ok) {
+                float rayMinT = rays[i].mint;
+                if (rayMinT == PT_EPSILON) rayMinT *= smax(smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), PT_EPSILON);
+                if (rayMinT > mint) mint = rayMinT;
+                if (rays[i].maxt < maxt) maxt = rays[i].maxt;
+                ok = maxt > mint;
+            }
+            if (ok && !use_wide) {
+                for (size_t k = 0; k < nRecs; ++k) {
+                    float tu, tv, tt;
+                    if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, mint, maxt, tu, tv, tt)) { maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
+                }
+            } else if (ok) {
+                WideRay ray; wideRaySetup(ray, o, d, mint, maxt);
+                std::vector<uint2> stack;
+                uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
+                for (;;) {
+                    if (tg.y == 0u && (ng.y & 0xff000000u)) {
+                        const uint32_t bit = 31u - (uint32_t) __builtin_clz(ng.y);
+                        ng.y &= ~(1u << bit);
+                        if (ng.y & 0xff000000u) stack.push_back(ng);
+                        const uint32_t slot = (bit - 24u) ^ (ray.octinv4 & 7u);
+                        const uint32_t idx = ng.x + (uint32_t) __builtin_popcount(ng.y & ((1u << slot) - 1u) & 0xffu);
+                        if (idx >= bvh.nWNodes) throw std::runtime_error("wide BVH: child index out of range");
+                        const uint4 *g = wn + 5 * (size_t) idx;
+                        const uint32_t hitsMask = wideNodeHits(g[0], g[1], g[2], g[3], g[4], ray);
+                        ng = make_uint2(g[1].x, (hitsMask & 0xff000000u) | (g[0].w >> 24));
+                        tg = make_uint2(g[1].y, hitsMask & 0x00ffffffu);
+                    }
+                    if (tg.y) {
+                        const uint32_t bit = (uint32_t) __builtin_ctz(tg.y);
+                        tg.y &= tg.y - 1u;
+                        const size_t k = (size_t) tg.x + bit;
+                        if (k >= nRecs) throw std::runtime_error("wide BVH: triangle index out of range");
+                        float tu, tv, tt;
+                        if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, ray.mint, ray.maxt, tu, tv, tt)) { ray.maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
+                    }
+                    if (tg.y == 0u && !(ng.y & 0xff000000u)) {
+                        if (stack.empty()) break;
+                        ng = stack.back(); stack.pop_back();
+                    }
+                }
+            }
+            hits[i] = h;
+        }
+        return PHIP_OK;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_INVALID, e.what()); }
+}
+
 } // extern "C"
 
 /* device execution of the phip_fmath.h functions (bitwise host/device agreement test) */

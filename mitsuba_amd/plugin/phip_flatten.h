@@ -195,14 +195,14 @@ public:
         ref<Bitmap> target = new Bitmap(Bitmap::ESpectrumAlphaWeight, Bitmap::EFloat32, size);   /* = the film storage's format: setBitmap is a memcpy */
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, size, NULL);          /* what listeners are handed (no border) */
         block->setOffset(Point2i(0, 0));
-        RectangularWorkUnit wu; wu.setOffset(Point2i(0, 0)); wu.setSize(size);
+        ref<RectangularWorkUnit> wu = new RectangularWorkUnit(); wu->setOffset(Point2i(0, 0)); wu->setSize(size);
         ProgressReporter progress("Rendering", nPasses, job);
         phip_stats total; memset(&total, 0, sizeof(total));
         for (size_t pass = 0, k0 = 0; pass < nPasses; ++pass, k0 += sppPerPass) {
             rp.spp = (int32_t) std::min(sppPerPass, spp - k0);
             rp.sample_offset = (int32_t) k0; rp.sample_total = (int32_t) spp;
             rp.flags = (rp.flags & ~PHIP_FLAG_ACCUMULATE) | (pass > 0 ? PHIP_FLAG_ACCUMULATE : 0);
-            queue->signalWorkBegin(job, &wu, 0);
+            queue->signalWorkBegin(job, wu.get(), 0);
             phip_stats st;
             int rc = phip_render(m_scene, &rp, target->getFloat32Data(), &st);
             if (rc == PHIP_ERR_CANCELLED) {

@@ -1,0 +1,97 @@
+"""The compressed 8-wide BVH of the big-scene ray kernels (mitsuba_amd/csrc/bvh.h: buildWide, k_wide.h), pinned on the CPU:
+phip_debug_host_trace_wide walks the tree the builder emits with the SAME node-step arithmetic the device kernels compile
+(wideNodeHits is __host__ __device__) and the same Wald test; compared with a brute-force sweep over every record and with
+the oracle's kd-tree (the reference's structure).  No GPU needed."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mitsuba_amd import _abi as A, scene as S
+
+
+def host_trace(phip, P, T, rays, wide=1):
+    P = np.ascontiguousarray(P, np.float32).reshape(-1, 3); T = np.ascontiguousarray(T, np.uint32).reshape(-1, 3)
+    r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    hits = np.zeros((len(r), 4), np.float32)
+    info = A.phip_accel_info()
+    rc = phip.phip_debug_host_trace_wide(P.ctypes.data_as(C.POINTER(C.c_float)), len(P), T.ctypes.data_as(C.POINTER(C.c_uint32)), len(T),
+                                         r.ctypes.data_as(C.POINTER(A.phip_ray)), len(r), hits.ctypes.data_as(C.POINTER(A.phip_hit)), wide, C.byref(info))
+    assert rc == 0, phip.phip_last_error()
+    return hits, info
+
+
+def rays_through(rng, n, lo, hi, axis_aligned=0.0):
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    k = int(n * axis_aligned)
+    if k:                                              # zero components (incl. -0.0): the slab test must not produce NaNs
+        d[:k] = 0.0
+        d[np.arange(k), rng.integers(0, 3, k)] = rng.choice([-1.0, 1.0], k)
+        d[: k // 2][d[: k // 2] == 0] = -0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3] = o; rays[:, 3] = 1e-4; rays[:, 4:7] = d; rays[:, 7] = np.inf
+    return rays
+
+
+def soup(rng, n, size, extent):
+    c = rng.uniform(-extent, extent, (n, 1, 3))
+    P = (c + rng.normal(scale=size, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    return P, np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+
+
+@pytest.mark.parametrize("n,size,extent", [(300, 1.0, 5.0), (5000, 0.3, 8.0), (40000, 0.05, 10.0), (2000, 4.0, 3.0)])
+def test_wide_tree_equals_brute_force_on_triangle_soups(phip, n, size, extent):
+    rng = np.random.default_rng(n)
+    P, T = soup(rng, n, size, extent)
+    rays = rays_through(rng, 3000, -extent, extent, axis_aligned=0.2)
+    w, info = host_trace(phip, P, T, rays, 1)
+    b, _ = host_trace(phip, P, T, rays, 0)
+    assert info.n_nodes > 1 and info.node_bytes == 80 and info.n_triangle_refs == n
+    hit = b[:, 3].view(np.uint32) != A.PHIP_NO_HIT
+    assert 0.05 < hit.mean() <= 1.0
+    # structure-independent answer: (t, u, v, prim) bit for bit, exact-t ties (a ray through a shared vertex) aside
+    same = (w.view(np.uint32) == b.view(np.uint32)).all(axis=1)
+    assert same.mean() >= 0.9995, same.mean()
+    assert (w[:, 0].view(np.uint32) == b[:, 0].view(np.uint32)).mean() >= 0.9999          # the distance always agrees
+
+
+def test_wide_tree_on_the_atrium_against_the_oracle_kd_tree(phip, oracle, gauss):
+    """the Sponza-class scene of BASELINE.json configs[2]: long thin triangles, instanced columns, ~250k triangles"""
+    sb = S.atrium(64, 36, gauss)
+    desc = sb.desc()
+    P = np.ctypeslib.as_array(desc.positions, shape=(desc.n_vertices, 3)).copy()
+    T = np.ctypeslib.as_array(desc.indices, shape=(desc.n_triangles, 3)).copy()
+    rng = np.random.default_rng(5)
+    lo, hi = P.min(axis=0), P.max(axis=0)
+    rays = rays_through(rng, 6000, lo + 0.02 * (hi - lo), hi - 0.02 * (hi - lo), axis_aligned=0.1)
+    w, info = host_trace(phip, P, T, rays, 1)
+    assert info.n_nodes < desc.n_triangles / 4 and info.max_depth <= 12
+    osc = oracle.OracleScene(desc)
+    oh, _, _ = osc.trace(rays, True, False)
+    assert (oh[:, 3].view(np.uint32) != A.PHIP_NO_HIT).mean() > 0.9
+    # the atrium has coincident coplanar surfaces (wall panels on the room shell): rays that hit both at the same t report
+    # whichever the structure tests last -- the distance is the same bit for bit, the primitive may differ
+    same = (w.view(np.uint32) == oh.view(np.uint32)).all(axis=1)
+    assert same.mean() >= 0.995, same.mean()
+    assert (w[:, 0].view(np.uint32) == oh[:, 0].view(np.uint32)).all()
+
+
+def test_degenerate_inputs(phip):
+    rng = np.random.default_rng(3)
+    # coplanar triangles (one flat axis: the grid step of that axis is degenerate), duplicates, zero-area triangles
+    n = 600
+    P = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32); P[..., 1] = 0.25
+    P[10] = P[11]; P[20, 1] = P[20, 0]                       # a duplicate and a zero-area triangle
+    T = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    rays = rays_through(rng, 2000, -1.5, 1.5, axis_aligned=0.3)
+    w, _ = host_trace(phip, P.reshape(-1, 3), T, rays, 1)
+    b, _ = host_trace(phip, P.reshape(-1, 3), T, rays, 0)
+    assert (w[:, 0].view(np.uint32) == b[:, 0].view(np.uint32)).mean() >= 0.999
+    # identical centroids: the builder falls back to median splits and leaves of up to 8 records (split into pieces of 3)
+    P = np.tile(rng.uniform(-1, 1, (1, 3, 3)).astype(np.float32), (40, 1, 1))
+    T = np.arange(120, dtype=np.uint32).reshape(40, 3)
+    w, info = host_trace(phip, P.reshape(-1, 3), T, rays, 1)
+    b, _ = host_trace(phip, P.reshape(-1, 3), T, rays, 0)
+    assert (w[:, 0].view(np.uint32) == b[:, 0].view(np.uint32)).all()
