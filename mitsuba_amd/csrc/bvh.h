@@ -234,6 +234,54 @@ inline void buildWide(HostBVH &out, int32_t root2, const detail::Box &rootBox, C
     typedef detail::ChildRef Child;
     struct WChild { Child c; uint32_t firstTri, nTris; };    /* leaf pieces carry their record range (in out.tris) */
     struct Item { int32_t ref2; uint32_t index, depth; detail::Box box; };
+    /* ---- optimal collapse (Ylitie et al. 2017, section 3.1): C[n][i] = the least SAH cost of representing BVH2 subtree n with
+       at most i slots of its wide parent: either n becomes ONE wide node (cost area * cNode + the best distribution of its own
+       8 slots over its two children) or its slots are split between its children.  A leaf of P records needs ceil(P / 3)
+       slots.  Filled bottom-up; the tree is then emitted top-down along the recorded decisions.  The greedy "open the
+       largest child" collapse it replaces left the bottom of the tree underfilled (4 children per node on average). ---- */
+    const float cNode = 2.5f, cTri = 1.0f;                   /* a node step costs about 2.5 Wald tests in k_rays_w */
+    const uint32_t n2 = out.nNodes2;
+    std::vector<float> C((size_t) n2 * 8, INFINITY);          /* C[n * 8 + i], i = 1..7; [n * 8 + 0] = cost as a wide node's root */
+    std::vector<uint8_t> split((size_t) n2 * 9, 0);           /* split[n * 9 + j]: slots given to the LEFT child when n distributes j slots (j = 2..8) */
+    auto leafCost = [&](const Child &c, int i) -> float {     /* c.ref < 0 */
+        const uint32_t cnt = ((~(uint32_t) c.ref) & 7u) + 1u;
+        return i >= (int) ((cnt + 2) / 3) ? c.box.area() * cTri * (float) cnt : INFINITY;
+    };
+    auto costOf = [&](const Child &c, int i) -> float { return c.ref < 0 ? leafCost(c, i) : C[(size_t) c.ref * 8 + std::min(i, 7)]; };
+    {
+        /* post-order over the BVH2 (children have larger indices than their parent in build order: iterate backwards) */
+        for (int32_t n = (int32_t) n2 - 1; n >= 0; --n) {
+            Child two[2]; children2(n, two);
+            float dist[9];
+            for (int j = 2; j <= 8; ++j) {
+                float best = INFINITY; int bk = 1;
+                for (int k = 1; k < j; ++k) {
+                    const float v = costOf(two[0], k) + costOf(two[1], j - k);
+                    if (v < best) { best = v; bk = k; }
+                }
+                dist[j] = best; split[(size_t) n * 9 + j] = (uint8_t) bk;
+            }
+            detail::Box nb; nb.reset(); nb.grow(two[0].box.mn, two[0].box.mx); nb.grow(two[1].box.mn, two[1].box.mx);
+            float *c = &C[(size_t) n * 8];
+            c[1] = nb.area() * cNode + dist[8];
+            for (int i = 2; i <= 7; ++i) c[i] = std::min(dist[i], c[i - 1]);
+        }
+    }
+    /* children of BVH2 node n when it distributes j slots */
+    std::function<void(int32_t, int, std::vector<Child> &)> expand = [&](int32_t n, int j, std::vector<Child> &outc) {
+        Child two[2]; children2(n, two);
+        const int k = split[(size_t) n * 9 + j];
+        const int budget[2] = { k, j - k };
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const Child &c = two[s2];
+            if (c.ref < 0) { outc.push_back(c); continue; }
+            int i = std::min(budget[s2], 7);
+            const float *cc = &C[(size_t) c.ref * 8];
+            while (i > 1 && cc[i] == cc[i - 1]) --i;
+            if (i == 1) outc.push_back(c);                    /* c becomes a wide node of its own */
+            else expand(c.ref, i, outc);
+        }
+    };
     std::vector<Item> queue;
     queue.push_back({ root2, 0u, 1u, rootBox });
     out.nWNodes = 1;
@@ -242,23 +290,9 @@ inline void buildWide(HostBVH &out, int32_t root2, const detail::Box &rootBox, C
     for (size_t head = 0; head < queue.size(); ++head) {
         const Item it = queue[head];
         out.wMaxDepth = std::max(out.wMaxDepth, it.depth);
-        /* collapse: open the inner child with the largest area while the slots last */
-        std::vector<Child> ch(2);
-        { Child two[2]; children2(it.ref2, two); ch[0] = two[0]; ch[1] = two[1]; }
-        for (;;) {
-            int used = 0; for (const Child &c : ch) used += slotsOf(c.ref);
-            int best = -1; float bestA = -1;
-            for (size_t i = 0; i < ch.size(); ++i) {
-                if (ch[i].ref < 0) continue;
-                Child two[2]; children2(ch[i].ref, two);
-                const int extra = slotsOf(two[0].ref) + slotsOf(two[1].ref) - 1;
-                if (used + extra > 8) continue;
-                if (ch[i].box.area() > bestA) { bestA = ch[i].box.area(); best = (int) i; }
-            }
-            if (best < 0) break;
-            Child two[2]; children2(ch[best].ref, two);
-            ch[best] = two[0]; ch.push_back(two[1]);
-        }
+        /* the children of this wide node, as the SAH-optimal collapse (cost table below) distributes its 8 slots */
+        std::vector<Child> ch;
+        expand(it.ref2, 8, ch);
         /* leaf children of more than 3 records are split into pieces of <= 3 (same box) */
         std::vector<WChild> wc;
         for (const Child &c : ch) {

@@ -19,7 +19,13 @@
  */
 
 #define WIDE_STACK_LDS 12                /* 8-byte entries per lane in LDS (24 KB per block of 256) */
-#define WIDE_NODE_CACHE_MAX 64           /* top-of-tree nodes (BFS order) staged in LDS: 5 KB */
+#ifndef WIDE_NODE_CACHE_MAX
+#define WIDE_NODE_CACHE_MAX 96           /* top-of-tree nodes (BFS order) staged in LDS: 7.5 KB */
+#endif
+#ifndef WIDE_TYPED
+#define WIDE_TYPED 1                     /* cached nodes are read with ds_read_b128 (LDS pipe) instead of flat_load (which sends LDS addresses through the
+                                            texture addresser / data path the kernel is bound by: TD busy 95 %, round-2 counters) */
+#endif
 #ifndef WIDE_WAVES
 #define WIDE_WAVES 5                     /* waves per SIMD of k_rays_w */
 #endif
@@ -113,11 +119,28 @@ DV uint32_t wideNodeHits(const uint4 &n0, const uint4 &n1, const uint4 &n2, cons
     return hits;
 }
 
+__device__ __forceinline__ uint4 ldsLoadU4(lds_cu4 *p) { const u4v v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
 #define WIDE_LOAD_NODE(stack, S, idx, n0, n1, n2, n3, n4)                                             \
     uint4 n0, n1, n2, n3, n4;                                                                         \
-    {                                                                                                 \
-        const uint4 *g_ = (idx) < (stack).nodeCache ? (const uint4 *) ((stack).nodes + 5u * (idx)) : (S).wnodes + 5 * (size_t) (idx); \
+    if (WIDE_TYPED && (idx) < (stack).nodeCache) {                                                    \
+        lds_cu4 *l_ = (stack).nodes + 5u * (idx);                                                     \
+        n0 = ldsLoadU4(l_); n1 = ldsLoadU4(l_ + 1); n2 = ldsLoadU4(l_ + 2); n3 = ldsLoadU4(l_ + 3); n4 = ldsLoadU4(l_ + 4); \
+    } else {                                                                                          \
+        const uint4 *g_ = (!WIDE_TYPED && (idx) < (stack).nodeCache) ? (const uint4 *) ((stack).nodes + 5u * (idx)) : (S).wnodes + 5 * (size_t) (idx); \
         n0 = g_[0]; n1 = g_[1]; n2 = g_[2]; n3 = g_[3]; n4 = g_[4];                                   \
+    }
+
+/* a Wald record = three 16-byte loads.  Written as inline assembly: the compiler narrows the loads to the eleven dwords in use
+   and re-splits them into FOUR instructions (12 + 16 + 16 + 4 bytes), and this kernel is bound by the number of vector-memory
+   instructions it issues (texture-data path 95 % busy), not by bytes. */
+#define WIDE_LOAD_TRI(S, idx, a, b, c)                                                                \
+    float4 a, b, c;                                                                                   \
+    {                                                                                                 \
+        const float4 *t_ = (S).tris + 3 * (size_t) (idx);                                             \
+        f4v va_, vb_, vc_;                                                                            \
+        asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx4 %2, %3, off offset:32\n\ts_waitcnt vmcnt(0)" \
+                     : "=&v"(va_), "=&v"(vb_), "=&v"(vc_) : "v"(t_) : "memory");                       \
+        a = make_float4(va_.x, va_.y, va_.z, va_.w); b = make_float4(vb_.x, vb_.y, vb_.z, vb_.w); c = make_float4(vc_.x, vc_.y, vc_.z, vc_.w); \
     }
 
 /* One node step of a lane whose node group `ng` has inner hits: take the first child in traversal order, push the rest of the
@@ -153,8 +176,7 @@ __device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, con
         if (tg.y) {
             const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;
             tg.y &= tg.y - 1u;
-            const float4 *t_ = S.tris + 3 * (size_t) (tg.x + bit);
-            const float4 a = t_[0], b = t_[1], c = t_[2];
+            WIDE_LOAD_TRI(S, tg.x + bit, a, b, c)
             ++triTests;
             float tu, tv, tt;
             if (waldIntersect(a, b, c, o, d, ray.mint, ray.maxt, tu, tv, tt)) {
@@ -215,8 +237,7 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                 if (tg.y) {
                     const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;
                     tg.y &= tg.y - 1u;
-                    const float4 *t_ = S.tris + 3 * (size_t) (tg.x + bit);
-                    const float4 a = t_[0], b = t_[1], c = t_[2];
+                    WIDE_LOAD_TRI(S, tg.x + bit, a, b, c)
                     ++triCur;
                     float tu, tv, tt;
                     if (waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {

@@ -112,7 +112,8 @@ int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const
    the builder's encoding (quantisation, slots, child / triangle indexing) and the group stack logic against the oracle
    without a GPU; the device kernels run the same functions.  use_wide = 0 walks nothing and tests every record (brute force). */
 int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles,
-                               const phip_ray *rays, size_t n_rays, phip_hit *hits, int use_wide, phip_accel_info *info) {
+                               const phip_ray *rays, size_t n_rays, phip_hit *hits, int use_wide, phip_accel_info *info,
+                               uint8_t *seq, uint32_t seq_stride /* optional: the ray's steps in order, 1 = node step, 2 = triangle test, 0 = end */) {
     try {
         for (uint32_t i = 0; i < 3 * n_triangles; ++i) if (indices[i] >= n_vertices) return setErr(PHIP_ERR_INVALID, "index out of range");
         HostBVH bvh; buildBVH(positions, indices, n_triangles, bvh);
@@ -159,6 +160,8 @@ int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, cons
             } else if (ok) {
                 WideRay ray; wideRaySetup(ray, o, d, mint, maxt);
                 std::vector<uint2> stack;
+                uint32_t nSeq = 0;
+                auto note = [&](uint8_t what) { if (seq && nSeq + 1 < seq_stride) seq[i * seq_stride + nSeq++] = what; };
                 uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
                 for (;;) {
                     if (tg.y == 0u && (ng.y & 0xff000000u)) {
@@ -169,6 +172,7 @@ int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, cons
                         const uint32_t idx = ng.x + (uint32_t) __builtin_popcount(ng.y & ((1u << slot) - 1u) & 0xffu);
                         if (idx >= bvh.nWNodes) throw std::runtime_error("wide BVH: child index out of range");
                         const uint4 *g = wn + 5 * (size_t) idx;
+                        note(1);
                         const uint32_t hitsMask = wideNodeHits(g[0], g[1], g[2], g[3], g[4], ray);
                         ng = make_uint2(g[1].x, (hitsMask & 0xff000000u) | (g[0].w >> 24));
                         tg = make_uint2(g[1].y, hitsMask & 0x00ffffffu);
@@ -178,6 +182,7 @@ int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, cons
                         tg.y &= tg.y - 1u;
                         const size_t k = (size_t) tg.x + bit;
                         if (k >= nRecs) throw std::runtime_error("wide BVH: triangle index out of range");
+                        note(2);
                         float tu, tv, tt;
                         if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, ray.mint, ray.maxt, tu, tv, tt)) { ray.maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
                     }

@@ -40,6 +40,10 @@ namespace {
 std::string g_err;
 bool g_init = false;
 int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream) */
+/* shapes the NEXT ref_scene_create loads through one of the reference's own mesh-loader plugins (shapes/obj.cpp): (plugin, file,
+   material id of the description, toWorld) -- a real asset enters the scene exactly as the XML loader would add it */
+struct FileShape { std::string plugin, filename; uint32_t material; float toWorld[16]; };
+std::vector<FileShape> g_fileShapes;
 int g_analyticRectangles = 0;   /* build exact rectangles as the reference's analytic `rectangle` shape instead of a two-triangle mesh */
 const uint32_t *g_smoothMasks = NULL;   /* optional [pixel][sample] smooth-vertex masks for the parity sampler (scenes with dielectrics) */
 
@@ -218,6 +222,11 @@ int ref_init(void) {
 void ref_set_sampler(int kind) { g_samplerKind = kind; }
 void ref_set_smooth_masks(const uint32_t *masks) { g_smoothMasks = masks; }
 void ref_set_analytic_rectangles(int on) { g_analyticRectangles = on; }
+void ref_add_shape_file(const char *plugin, const char *filename, uint32_t material, const float *to_world16) {
+    FileShape f; f.plugin = plugin; f.filename = filename; f.material = material;
+    for (int i = 0; i < 16; ++i) f.toWorld[i] = to_world16 ? to_world16[i] : (i % 5 == 0 ? 1.0f : 0.0f);
+    g_fileShapes.push_back(f);
+}
 
 /* stops the Scheduler's worker threads (they would keep the process alive at exit) */
 void ref_shutdown(void) {
@@ -331,6 +340,20 @@ void *ref_scene_create(const phip_scene_desc *dp, float gaussian_stddev) {
             }
             mesh->configure();
             attach(scene, "", mesh);
+        }
+        /* ---- shapes from files, through the reference's loader plugins (after the description's shapes: Scene::getShapes() order) ---- */
+        {
+            std::vector<FileShape> files; files.swap(g_fileShapes);
+            for (const FileShape &f : files) {
+                Properties p(f.plugin);
+                p.setString("filename", f.filename);
+                p.setTransform("toWorld", toTransform(f.toWorld));
+                p.setBoolean("faceNormals", true);            /* flat shading: what the harness mesh without vertex normals gets (trimesh.cpp) */
+                ref<Shape> shape = static_cast<Shape *>(create(MTS_CLASS(Shape), p));
+                attach(shape, "", makeBSDF(rs, d, f.material));
+                shape->configure();
+                attach(scene, "", shape);
+            }
         }
         for (uint32_t i = 0; i < d.n_materials; ++i) makeBSDF(rs, d, i);
 

@@ -73,6 +73,7 @@ def lib():
     L.ref_set_sampler.argtypes = [C.c_int]
     L.ref_set_smooth_masks.argtypes = [C.c_void_p]
     L.ref_set_analytic_rectangles.argtypes = [C.c_int]
+    L.ref_add_shape_file.argtypes = [C.c_char_p, C.c_char_p, u32, fp]
     L.ref_mip_build.restype = C.c_void_p
     L.ref_mip_build.argtypes = [C.c_int, fp, u32, u32, u32, u32, u32, C.c_float]
     L.ref_mip_levels.argtypes = [C.c_void_p]
@@ -95,12 +96,16 @@ def _fp(a):
 class RefScene:
     """The reference's Scene object built from a phip_scene_desc (environment emitters must be listed first)."""
 
-    def __init__(self, desc, stddev=0.5, analytic_rectangles=False):
+    def __init__(self, desc, stddev=0.5, analytic_rectangles=False, shape_files=()):
         """analytic_rectangles: exact rectangles of the description become the reference's analytic `rectangle` shape (its
         own intersection / sampling code on the CPU; the plugin shims see them through Shape::createTriMesh)"""
         self.L = lib()
         self.desc = desc
         self.L.ref_set_analytic_rectangles(1 if analytic_rectangles else 0)
+        # shape_files: (plugin, filename, material id[, row-major 4x4 toWorld]) loaded by the reference's own mesh-loader plugins
+        for sf in shape_files:
+            tw = np.ascontiguousarray(sf[3] if len(sf) > 3 else np.eye(4), np.float32)
+            self.L.ref_add_shape_file(sf[0].encode(), sf[1].encode(), int(sf[2]), tw.ctypes.data_as(C.POINTER(C.c_float)))
         self.h = self.L.ref_scene_create(C.byref(desc), stddev)
         self.L.ref_set_analytic_rectangles(0)
         if not self.h:

@@ -16,7 +16,7 @@ def host_trace(phip, P, T, rays, wide=1):
     hits = np.zeros((len(r), 4), np.float32)
     info = A.phip_accel_info()
     rc = phip.phip_debug_host_trace_wide(P.ctypes.data_as(C.POINTER(C.c_float)), len(P), T.ctypes.data_as(C.POINTER(C.c_uint32)), len(T),
-                                         r.ctypes.data_as(C.POINTER(A.phip_ray)), len(r), hits.ctypes.data_as(C.POINTER(A.phip_hit)), wide, C.byref(info))
+                                         r.ctypes.data_as(C.POINTER(A.phip_ray)), len(r), hits.ctypes.data_as(C.POINTER(A.phip_hit)), wide, C.byref(info), None, 0)
     assert rc == 0, phip.phip_last_error()
     return hits, info
 
