@@ -31,7 +31,9 @@ def _sources():
 
 
 # objects of libphip.so: (source, extra flags, object name) -- see csrc/phip_common.h
-UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", [], "phip_mega.o")] + \
+# phip_mega.hip is compiled without MachineLICM: hoisting the double-precision polynomial constants of phip_fmath.h (two VGPRs each,
+# 64-bit literals cannot be encoded) out of k_mega's persistent loop cost ~40 VGPRs -- 168 instead of 128, i.e. 3 instead of 4 waves per SIMD
+UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", ["-mllvm", "-disable-machine-licm"], "phip_mega.o")] + \
         [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f], "phip_shade%d.o" % f) for f in range(4)]
 
 

@@ -30,10 +30,12 @@
 enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
 
 template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
-    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
-    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    __shared__ float4 ldsTriShade[MEGA_TRISHADE_MAX * TRISHADE_FLOAT4S];
     __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs */
+    /* dynamic LDS: [traversal stack | all nodes | all Wald records] (setupTraversal) [shading records | emitter table | materials],
+       sized for THIS scene (megaLdsBytes) so that as many blocks as the registers allow fit a CU */
+    float4 *ldsTriShade = (float4 *) (g_smem + traversalLdsBytesOf(S));
+    float *ldsEm = (float *) (ldsTriShade + (size_t) S.nTriangles * TRISHADE_FLOAT4S);
+    DevMaterial *ldsMat = (DevMaterial *) (ldsEm + ((S.emitterTabSize + 3u) & ~3u));
     const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
     for (uint32_t i = threadIdx.x; i < S.nTriangles * TRISHADE_FLOAT4S; i += BLOCK) ldsTriShade[i] = S.triShade[i];
     S.triShade = ldsTriShade;                                   /* (generic pointer into LDS: six loads per vertex, not the inner loop) */

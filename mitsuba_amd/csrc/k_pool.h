@@ -54,7 +54,8 @@ enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_T
 #define EMITTER_LDS_FLOATS 1024      /* emitter table staged in LDS by the shading kernels when it has at most this many floats (4 KB) */
 #define MATERIAL_LDS_MAX 48          /* ... and the materials when there are at most this many (4.5 KB) */
 #ifndef MEGA_WAVES
-#define MEGA_WAVES 3                 /* k_mega: waves per SIMD (= blocks of 256 per CU): 168 VGPRs, no scratch (at 4: 128 VGPRs + 148 B of scratch per lane) */
+#define MEGA_WAVES 4                 /* k_mega: waves per SIMD (= blocks of 256 per CU): 128 VGPRs, no scratch -- with MachineLICM off for that unit (_ffi.py);
+                                        with it on the kernel needs 168 VGPRs (3 waves: measured 2020 vs 2171 Msamples/s at 4 waves even with 148 B of scratch) */
 #endif
 #define MEGA_TRISHADE_MAX 96         /* k_mega: shading records staged in LDS (9 KB) */
 #define DYN_SHARDS 8                    /* one dynamic-sample counter per XCD-sized group of blocks */

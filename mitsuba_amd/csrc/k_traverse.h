@@ -73,6 +73,15 @@ struct TravStack {
     __device__ __forceinline__ uint32_t popLds() { --sp; return lds[sp * BLOCK]; }    /* the caller knows that nothing spilled */
 };
 
+/* bytes of dynamic LDS setupTraversal() uses; k_mega appends its shading tables (megaLdsBytesOf) */
+__host__ __device__ __forceinline__ size_t traversalLdsBytesOf(const DevScene &S) {
+    return (size_t) S.stackDepth * BLOCK * sizeof(uint32_t) + (size_t) S.nodeCache * NODE_LDS_STRIDE * sizeof(float4) + (size_t) S.triCache * 3 * sizeof(float4);
+}
+__host__ __device__ __forceinline__ size_t megaLdsBytesOf(const DevScene &S) {
+    return traversalLdsBytesOf(S) + (size_t) S.nTriangles * TRISHADE_FLOAT4S * sizeof(float4) + (size_t) ((S.emitterTabSize + 3u) & ~3u) * sizeof(float)
+         + (size_t) S.nMaterials * sizeof(DevMaterial);
+}
+
 /* carve the block's dynamic LDS and stage the cached geometry (all threads of the block must call) */
 __device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char *smem, uint32_t *spill, TravStack &stk) {
     uint32_t *stack = (uint32_t *) smem;

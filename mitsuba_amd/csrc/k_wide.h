@@ -27,7 +27,9 @@
                                             texture addresser / data path the kernel is bound by: TD busy 95 %, round-2 counters) */
 #endif
 #ifndef WIDE_WAVES
-#define WIDE_WAVES 5                     /* waves per SIMD of k_rays_w */
+#define WIDE_WAVES 4                     /* waves per SIMD of k_rays_w: 112 VGPRs, no scratch.  Measured (C3 / C4 ray-kernel ms per frame): 4 waves 256.7 / 520 --
+                                            5 waves (96 VGPRs + 84 B of scratch in the refill path) 254.6 / 532 with a 64-node cache, and a disaster
+                                            (391 / 813) once the cache no longer let five blocks fit a CU -- see residentBlocks() in phip.hip */
 #endif
 
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));

@@ -702,7 +702,7 @@ static void phipLaunchShadeDirect(int feat, int materialMask, dim3 grid, hipStre
 
 static size_t traversalLdsBytes(const DevScene &D) {
     if (D.wideNodeCache) return wideLdsBytes(D.wideNodeCache);
-    return (size_t) D.stackDepth * BLOCK * sizeof(uint32_t) + (size_t) D.nodeCache * NODE_LDS_STRIDE * sizeof(float4) + (size_t) D.triCache * 3 * sizeof(float4);
+    return traversalLdsBytesOf(D);
 }
 
 static void algorithmicBytes(bool mergedRays, phip_stats &st, double filmPixels, bool wide = false) {
@@ -870,18 +870,29 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     /* persistent kernels: exactly the resident set (TRACE_WAVES waves per SIMD = TRACE_WAVES blocks of 256 per CU)
        ... but never more blocks per CU than their LDS (stack + node/record cache) allows: a persistent grid larger than
        the resident set would serialise */
-    const int ldsFit = (int) std::max<size_t>(1, (size_t) (160 * 1024) / std::max<size_t>(ldsBytes + 64, 1));
-    auto persistentGrid = [&](int blocksPerCU) {
-        return dim3((unsigned) std::max(1, std::min<int>(nCU * std::min(blocksPerCU, ldsFit), (int) ((capacity + BLOCK - 1) / BLOCK))));
+    /* The grid of a persistent kernel is exactly its resident set.  Residency is asked of the runtime (registers, the block's static
+       + dynamic LDS and the LDS allocation granule all enter) -- an arithmetic estimate that is one block per CU too high makes
+       the surplus blocks wait for a resident one to finish: a second round that doubled the ray kernel's time when the LDS
+       node cache grew to 7.5 KB (round 2). */
+    auto residentBlocks = [&](const void *kernel, int wanted) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, ldsBytes) != hipSuccess || n <= 0) n = 1;
+        return std::min(n, wanted);
+    };
+    auto persistentGrid = [&](const void *kernel, int blocksPerCU) {
+        return dim3((unsigned) std::max(1, std::min<int>(nCU * residentBlocks(kernel, blocksPerCU), (int) ((capacity + BLOCK - 1) / BLOCK))));
     };
     const dim3 grid((capacity + BLOCK - 1) / BLOCK);
-    const dim3 pgrid = persistentGrid(TRACE_WAVES), pgridTrace = persistentGrid(TRACE_P_WAVES), pgridRays = persistentGrid(sc->wide ? WIDE_WAVES : RAYS_WAVES);
+    const dim3 pgrid = persistentGrid((const void *) k_shadow_p, TRACE_WAVES);
+    const dim3 pgridTrace = persistentGrid(sc->bvh.nNodes >= 64 ? (const void *) k_trace_p<false> : (const void *) k_trace_p<true>, TRACE_P_WAVES);
+    const dim3 pgridRays = sc->wide ? persistentGrid((const void *) k_rays_w, WIDE_WAVES) : persistentGrid((const void *) k_rays_p, RAYS_WAVES);
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
 
     /* fused path: resident grid and per-wave statistics rows */
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
     if (fused) {
-        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, ldsBytes));
+        const size_t megaLds = megaLdsBytesOf(D);
+        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, megaLds));
         if (const char *e = getenv("PHIP_MEGA_BLOCKS")) perCU = std::max(1, std::min(perCU, atoi(e)));
         if (perCU <= 0) throw std::runtime_error("k_mega does not fit a compute unit");
         megaGrid = dim3((unsigned) (nCU * perCU));
@@ -923,7 +934,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipMemsetAsync(sd.stat.p, 0, (size_t) ST_COUNT * M.nWaves * sizeof(unsigned long long), stream));
             if (rc.totalIds) {
                 if (timing) evFused.record(stream);
-                phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaGrid, ldsBytes, stream, D, M, rc, sd.L.p);
+                phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaGrid, megaLdsBytesOf(D), stream, D, M, rc, sd.L.p);
                 if (timing) evFused.record(stream);
                 iter = 1;
             }

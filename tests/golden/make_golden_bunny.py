@@ -59,7 +59,7 @@ def bunny_scene(V, F, gauss, w=64, h=64):
     sb.mesh(V, F, sb.diffuse((0.6, 0.55, 0.5)))
     sb.quad((-0.3, 0.032, -0.3), (0.3, 0.032, -0.3), (0.3, 0.032, 0.3), (-0.3, 0.032, 0.3), sb.diffuse((0.4, 0.4, 0.45)), facing=(0, 1, 0))
     light = sb.diffuse((0, 0, 0))
-    sb.quad((-0.2, 0.5, -0.2), (0.2, 0.5, -0.2), (0.2, 0.5, 0.2), (-0.2, 0.5, 0.2), light, facing=(0, -1, 0), emitter=(18.0, 17.0, 15.0))
+    sb.quad((-0.2, 0.5, -0.2), (0.2, 0.5, -0.2), (0.2, 0.5, 0.2), (-0.2, 0.5, 0.2), light, facing=(0, -1, 0), radiance=(18.0, 17.0, 15.0))
     sb.perspective((-0.05, 0.18, 0.32), (-0.017, 0.10, 0.0), (0, 1, 0), 40.0)
     sb.hdrfilm(w, h, gauss)
     return sb
