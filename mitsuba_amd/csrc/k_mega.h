@@ -110,8 +110,9 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
             float mint, maxt;
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             uint32_t nNode = 0, nTri = 0;
-            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt))
-                traverse<false, true>(S, o, d, mint, maxt, stk, r, nNode, nTri);
+            V3 rcp;
+            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp))
+                traverse<false, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
             v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
             ldsCount[MC_RAYS][threadIdx.x] += 1; ldsCount[MC_NODE][threadIdx.x] += nNode; ldsCount[MC_TRI][threadIdx.x] += nTri;
         }
@@ -134,8 +135,9 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
             bool occluded = false;
             TravResult r;
             uint32_t nNode = 0, nTri = 0;
-            if (clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt))
-                occluded = traverse<true, true>(S, o, d, mint, maxt, stk, r, nNode, nTri);
+            V3 rcp;
+            if (clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp))
+                occluded = traverse<true, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
             ldsCount[MC_SH_RAYS][threadIdx.x] += 1; ldsCount[MC_SH_NODE][threadIdx.x] += nNode; ldsCount[MC_SH_TRI][threadIdx.x] += nTri;
             if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
         }

@@ -36,8 +36,7 @@ __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack 
                 if (src.load(h, o, d, rmint, rmaxt)) {
                     ++raysTraced;
                     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-                    if (clipToScene<SHADOW>(S, o, d, rmint, rmaxt, mint, maxt)) {
-                        rcp = V3(slabRcp(d.x), slabRcp(d.y), slabRcp(d.z));
+                    if (clipToScene<SHADOW>(S, o, d, rmint, rmaxt, mint, maxt, rcp)) {
                         ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
                         cur = S.rootRef; stack.sp = 0; handle = h; active = true;
                     } else {
@@ -147,16 +146,18 @@ struct ShadowSource {
  * of the closest-hit queue: one kernel tail (waves waiting for the slowest in-flight rays) and one launch per
  * iteration instead of two.  The kind of a lane's ray is a per-lane flag; the loop body is shared. */
 __device__ __forceinline__ bool clipToSceneRT(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
-                                              float &mint, float &maxt, bool shadow) {
+                                              float &mint, float &maxt, bool shadow, V3 &slab) {
     float nearT = -INFINITY, farT = INFINITY;
     const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
         if (dd[i] == 0) {
             if (origin < minVal || origin > maxVal) return false;
         } else {
-            const float rcp = 1.0f / dd[i];
+            const float rcp = rr[i];
             float t1 = (minVal - origin) * rcp;
             float t2 = (maxVal - origin) * rcp;
             if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
@@ -201,8 +202,7 @@ __device__ __forceinline__ void persistentTraverseMixed(const DevScene &S, TravS
                 if (ok) {
                     atomicAdd(&wc[moreS ? WC_SH_RAYS : WC_RAYS], 1u);
                     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS)) {
-                        rcp = V3(slabRcp(d.x), slabRcp(d.y), slabRcp(d.z));
+                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS, rcp)) {
                         ordr = V3(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
                         cur = S.rootRef; stack.sp = 0; handle = h; active = true; shadow = moreS; nodeCur = triCur = 0;
                     } else if (moreS) {
@@ -306,8 +306,9 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
             float mint, maxt;
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             rays = 1;
-            if (clipToScene<false>(S, o, d, ro.w, rd.w, mint, maxt))
-                traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
+            V3 rcp;
+            if (clipToScene<false>(S, o, d, ro.w, rd.w, mint, maxt, rcp))
+                traverse<false>(S, o, d, rcp, mint, maxt, stk, r, nodeVisits, triTests);
             P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
         }
     }
@@ -330,8 +331,9 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathP
         bool occluded = false;
         TravResult r;
         rays = 1;
-        if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt))
-            occluded = traverse<true>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
+        V3 rcp;
+        if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt, rcp))
+            occluded = traverse<true>(S, o, d, rcp, mint, maxt, stk, r, nodeVisits, triTests);
         if (!occluded) {
             addRadiance(L, pm_to_bits(e1.w), e2);
         }
@@ -355,15 +357,17 @@ __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *r
         float mint, maxt;
         if (hits) {
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
-            if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                traverse<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
+            V3 rcp;
+            if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt, rcp))
+                traverse<false>(S, o, d, rcp, mint, maxt, stk, r, nodeVisits, triTests);
             phip_hit h; h.t = r.t; h.u = r.u; h.v = r.v; h.prim = r.prim;
             hits[i] = h;
         }
         if (occluded) {
             TravResult r; bool occ = false;
-            if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                occ = traverse<true>(S, o, d, mint, maxt, stk, r, shNodeVisits, shTriTests);
+            V3 rcp;
+            if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt, rcp))
+                occ = traverse<true>(S, o, d, rcp, mint, maxt, stk, r, shNodeVisits, shTriTests);
             occluded[i] = occ ? 1 : 0;
         }
     }

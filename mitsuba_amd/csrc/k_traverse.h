@@ -8,19 +8,37 @@
  * ====================================================================================== */
 struct TravResult { float t, u, v; uint32_t prim; };
 
-/* scene-box clip + adaptive epsilon, src/librender/skdtree.cpp:112-142 (closest) / :207-226 (shadow) */
+/* Reciprocal direction for the slab tests.  A zero (or denormal) component must not become +-inf: the slab form
+ * fma(plane, rcp, -o * rcp) would then evaluate inf - inf = NaN for EVERY box, fminf/fmaxf drop the NaN and the node
+ * is rejected -- an axis-aligned ray missed the whole tree (the reference handles d == 0 explicitly, aabb.h / skdtree.cpp:
+ * the ray is inside the slab iff min <= o <= max).  A finite +-2^90 keeps the arithmetic meaningful: inside the slab the
+ * two plane distances are -huge / +huge (no constraint), outside both have the same sign and |t| >= 2^90 * distance
+ * exceeds every finite maxt; boxes are padded (bvh.h), so the rounding of o * rcp cannot flip a decision. */
+DV float slabRcp(float d) {
+    return fabsf(d) < 8.0779357e-28f /* 2^-90 */ ? copysignf(1.2379400e27f /* 2^90 */, d) : 1.0f / d;
+}
+/* ... from a reciprocal that is already there (the scene-box clip divides by the same components) */
+DV float slabRcpFrom(float d, float rcp) {
+    return fabsf(d) < 8.0779357e-28f ? copysignf(1.2379400e27f, d) : rcp;
+}
+
+/* scene-box clip + adaptive epsilon, src/librender/skdtree.cpp:112-142 (closest) / :207-226 (shadow).  Also hands out the
+   reciprocal direction for the slab tests: the clip divides by the same three components (an IEEE division is ~12 instructions;
+   a ray used to pay six of them). */
 template <bool SHADOW>
 __device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
-                                            float &mint, float &maxt) {
+                                            float &mint, float &maxt, V3 &slab) {
     float nearT = -INFINITY, farT = INFINITY;
     const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };       /* (inf for a zero component: not used by the clip then) */
+    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
         if (dd[i] == 0) {
             if (origin < minVal || origin > maxVal) return false;
         } else {
-            const float rcp = 1.0f / dd[i];
+            const float rcp = rr[i];
             float t1 = (minVal - origin) * rcp;
             float t2 = (maxVal - origin) * rcp;
             if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
@@ -131,15 +149,6 @@ __device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char 
     }
 #define SPILL_DEPTH 96
 
-/* Reciprocal direction for the slab tests.  A zero (or denormal) component must not become +-inf: the slab form
- * fma(plane, rcp, -o * rcp) would then evaluate inf - inf = NaN for EVERY box, fminf/fmaxf drop the NaN and the node
- * is rejected -- an axis-aligned ray missed the whole tree (the reference handles d == 0 explicitly, aabb.h / skdtree.cpp:
- * the ray is inside the slab iff min <= o <= max).  A finite +-2^90 keeps the arithmetic meaningful: inside the slab the
- * two plane distances are -huge / +huge (no constraint), outside both have the same sign and |t| >= 2^90 * distance
- * exceeds every finite maxt; boxes are padded (bvh.h), so the rounding of o * rcp cannot flip a decision. */
-DV float slabRcp(float d) {
-    return fabsf(d) < 8.0779357e-28f /* 2^-90 */ ? copysignf(1.2379400e27f /* 2^90 */, d) : 1.0f / d;
-}
 
 __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
     const bool sw = kb < ka;
@@ -221,12 +230,11 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
  * triangle tests per iteration although only ~15 % of the lanes sit in a leaf: measured 2x the issue slots.)
  * The order in which a ray tests its triangles is unchanged, hence so are the results. */
 template <bool SHADOW, bool ALL_LDS = false>
-__device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
+__device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V3 &d, const V3 &rcp /* clipToScene's slab reciprocal */, float mint, float maxt,
                                          TravStack &stack, TravResult &res,
                                          uint32_t &nodeVisits, uint32_t &triTests) {
     constexpr bool TYPED = true;
-    /* reciprocal direction for the slab tests (conservative: boxes are padded); the Wald test uses o,d */
-    const V3 rcp(slabRcp(d.x), slabRcp(d.y), slabRcp(d.z));
+    /* the slab tests use the reciprocal direction (conservative: boxes are padded); the Wald test uses o,d */
     const V3 ordr(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
     stack.sp = 0;
     int32_t cur = S.rootRef;

@@ -71,9 +71,9 @@ struct WideRay {
     uint32_t octinv4;       /* (7 - octant) replicated into the four bytes; octant bit a = direction component a is negative */
 };
 
-DV void wideRaySetup(WideRay &r, const V3 &o, const V3 &d, float mint, float maxt) {
+DV void wideRaySetup(WideRay &r, const V3 &o, const V3 &d, const V3 &rcp /* the slab reciprocal (clipToScene) */, float mint, float maxt) {
     r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
-    r.rcp = V3(slabRcp(d.x), slabRcp(d.y), slabRcp(d.z));
+    r.rcp = rcp;
     const uint32_t oct = (r.rcp.x < 0 ? 1u : 0u) | (r.rcp.y < 0 ? 2u : 0u) | (r.rcp.z < 0 ? 4u : 0u);
     r.octinv4 = (7u - oct) * 0x01010101u;
 }
@@ -166,9 +166,9 @@ __device__ __forceinline__ uint2 wideRootGroup() { return make_uint2(0u, 0x80000
 
 /* per-lane traversal to completion (k_raycast_w) */
 template <bool SHADOW>
-__device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, const V3 &d, float mint, float maxt,
+__device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, const V3 &d, const V3 &rcp, float mint, float maxt,
                                              WideStack &stack, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
-    WideRay ray; wideRaySetup(ray, o, d, mint, maxt);
+    WideRay ray; wideRaySetup(ray, o, d, rcp, mint, maxt);
     stack.sp = 0;
     uint2 ng = wideRootGroup(), tg = make_uint2(0u, 0u);
     bool found = false;
@@ -218,8 +218,9 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                     atomicAdd(&wc[moreS ? WC_SH_RAYS : WC_RAYS], 1u);
                     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
                     float mint, maxt;
-                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS)) {
-                        wideRaySetup(ray, o, d, mint, maxt);
+                    V3 rcp;
+                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS, rcp)) {
+                        wideRaySetup(ray, o, d, rcp, mint, maxt);
                         ng = wideRootGroup(); tg = make_uint2(0u, 0u);
                         stack.sp = 0; handle = h; active = true; shadow = moreS; nodeCur = triCur = 0;
                     } else if (moreS) {
@@ -298,15 +299,17 @@ __global__ __launch_bounds__(BLOCK) void k_raycast_w(DevScene S, const phip_ray 
         float mint, maxt;
         if (hits) {
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
-            if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                traverseWide<false>(S, o, d, mint, maxt, stk, r, nodeVisits, triTests);
+            V3 rcp;
+            if (clipToScene<false>(S, o, d, ry.mint, ry.maxt, mint, maxt, rcp))
+                traverseWide<false>(S, o, d, rcp, mint, maxt, stk, r, nodeVisits, triTests);
             phip_hit h; h.t = r.t; h.u = r.u; h.v = r.v; h.prim = r.prim;
             hits[i] = h;
         }
         if (occluded) {
             TravResult r; bool occ = false;
-            if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt))
-                occ = traverseWide<true>(S, o, d, mint, maxt, stk, r, shNodeVisits, shTriTests);
+            V3 rcp;
+            if (clipToScene<true>(S, o, d, ry.mint, ry.maxt, mint, maxt, rcp))
+                occ = traverseWide<true>(S, o, d, rcp, mint, maxt, stk, r, shNodeVisits, shTriTests);
             occluded[i] = occ ? 1 : 0;
         }
     }

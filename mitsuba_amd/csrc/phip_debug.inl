@@ -158,7 +158,7 @@ int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, cons
                     if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, mint, maxt, tu, tv, tt)) { maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
                 }
             } else if (ok) {
-                WideRay ray; wideRaySetup(ray, o, d, mint, maxt);
+                WideRay ray; wideRaySetup(ray, o, d, V3(slabRcp(d.x), slabRcp(d.y), slabRcp(d.z)), mint, maxt);
                 std::vector<uint2> stack;
                 uint32_t nSeq = 0;
                 auto note = [&](uint8_t what) { if (seq && nSeq + 1 < seq_stride) seq[i * seq_stride + nSeq++] = what; };
