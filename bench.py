@@ -119,10 +119,11 @@ def cpu_baseline(workload, seconds_target=10.0):
             return time.time() - t
         kind, what = "port", "oracle = CPU restatement of the reference path: SAH kd-tree + Havran + TriAccel, %d threads" % cores
         st = last
-    dt1 = max(run(1), 1e-3)
-    s = int(max(1, min(spp, round(seconds_target / dt1))))
-    if s > 1:
-        dt1 = run(s)
+    # calibrate on a short render (a 1-spp job is dominated by per-job set-up), then time ~seconds_target of work
+    s0 = min(spp, 4)
+    dt0 = max(run(s0), 1e-3)
+    s = int(max(1, min(spp, round(seconds_target / (dt0 / s0)))))
+    dt1 = run(s) if s != s0 else dt0
     out = {"value": round(w * h * s / 1e6 / dt1, 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
            "sample": "%s at %d spp (%d samples, %.1f s; %s)" % (workload, s, w * h * s, dt1, what)}
     if st and st.get("st") is not None:
@@ -178,11 +179,14 @@ def dominant_kernel(r):
     if a["fused"]:
         return "k_mega", "whole path in one persistent kernel: BVH4 (%d nodes), Wald + shading records, emitters, materials in LDS" % nodes, a["fused_kernel_ms"], max(int(a["iterations"]), 1)
     merged = a["shadow_kernel_ms"] == 0 and a["shadow_rays"] > 0        # closest-hit + any-hit rays in one persistent launch (big trees)
-    cands = {("k_rays_p" if merged else ("k_trace_p" if nodes >= 64 else "k_trace")): a["trace_kernel_ms"], "k_shade": a["shade_kernel_ms"]}
+    wide = r["accel"]["node_bytes"] == 80                                # ... over the compressed 8-wide BVH
+    rays = "k_rays_w" if wide else "k_rays_p"
+    cands = {(rays if merged else ("k_trace_p" if nodes >= 64 else "k_trace")): a["trace_kernel_ms"], "k_shade": a["shade_kernel_ms"]}
     if not merged:
         cands["k_shadow_p"] = a["shadow_kernel_ms"]
     name = max(cands, key=cands.get)
-    desc = {"k_rays_p": "closest-hit + any-hit BVH4 traversal, %d nodes of 128 B, 48-B Wald records" % nodes,
+    desc = {"k_rays_w": "closest-hit + any-hit traversal of the compressed 8-wide BVH, %d nodes of 80 B, 48-B Wald records" % nodes,
+            "k_rays_p": "closest-hit + any-hit BVH4 traversal, %d nodes of 128 B, 48-B Wald records" % nodes,
             "k_trace_p": "closest-hit BVH4 traversal", "k_trace": "closest-hit BVH4 traversal", "k_shade": "path vertex shading over the pool",
             "k_shadow_p": "any-hit BVH4 traversal"}[name]
     return name, desc, cands[name], max(int(a["iterations"]), 1)
@@ -198,10 +202,15 @@ def roofline(r):
     avg_ms = kms / launches if launches else 0.0
     traffic, tsrc = profile_json("traffic", r["workload"])
     valu, vsrc = profile_json("valu", r["workload"])
-    tk = (traffic or {}).get("kernels", {}).get(name)
+    def by_kernel(table):        # profile keys carry template arguments ("k_mega<0, false>"): match the kernel's base name
+        for k, v in (table or {}).items():
+            if k.split("<")[0] == name:
+                return v
+        return None
+    tk = by_kernel((traffic or {}).get("kernels"))
     hbm_bytes = tk["hbm_bytes_per_launch"] if tk else None
     hbm_gbs = (hbm_bytes / 1e9) / (avg_ms / 1e3) if (hbm_bytes and avg_ms > 0) else None
-    alg_per_launch = a["trace_kernel_bytes"] / launches if name in ("k_rays_p", "k_trace_p", "k_trace") else a["algorithmic_bytes"] / launches
+    alg_per_launch = a["trace_kernel_bytes"] / launches if name in ("k_rays_w", "k_rays_p", "k_trace_p", "k_trace") else a["algorithmic_bytes"] / launches
     out = {"bound": "hbm", "kernel": name + " (" + desc + ")",
            "achieved": round(hbm_gbs, 2) if hbm_gbs is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(min(hbm_gbs / HBM_PEAK_GBS, 1.0), 5) if hbm_gbs is not None else None,
@@ -212,7 +221,7 @@ def roofline(r):
                    "fetches, ray/hit state) are listed beside it but are served by LDS / L2 / Infinity Cache, not by the HBM pins: "
                    "this path is bounded by VALU issue under divergence, see `valu`",
            "kernel_ms_per_step": {k: round(a[k + "_kernel_ms"] / r["steps"], 3) for k in ("fused", "trace", "shadow", "shade", "film")}}
-    vk = (valu or {}).get(name)
+    vk = by_kernel(valu)
     if vk:
         out["valu"] = {"frac": vk.get("valu_frac"), "issue_frac": vk.get("valu_issue_frac"), "lane_util": vk.get("lane_util"),
                        "wave_cycles_waiting": vk.get("wave_cycles_wait_frac"), "source": vsrc,

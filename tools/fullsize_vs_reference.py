@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""BASELINE configs C2 / C3 at full size: path_hip on the GPU against Mitsuba 0.6 itself (oracle/_ref, all host cores,
-parity-stream sampler) -- developed images, relative L2.  Usage (on a GPU box): python tools/fullsize_vs_reference.py out.json"""
+"""BASELINE configs C2 / C3 / C4 at full size: path_hip on the GPU against Mitsuba 0.6 itself (oracle/_ref, all host cores,
+parity-stream sampler) -- developed images, relative L2.
+    python tools/fullsize_vs_reference.py out.json [C2|C3|C4-class|C4full]          (on a GPU box)
+    LD_PRELOAD=$PWD/oracle/_build/libcrm.so python tools/fullsize_vs_reference.py ...  the same against the reference with the
+        correctly rounded transcendentals of include/phip_fmath.h in place of glibc's (oracle/ref_glue/crlibm_shim.cpp)"""
 import json
 import os
 import sys
@@ -18,9 +21,12 @@ out = {}
 from oracle import oracle_ffi as O                             # noqa: E402
 for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1024, 1024, 256, -1),
                                    ("C3 atrium 1920x1080x64", S.atrium, 1920, 1080, 64, 8),
-                                   ("C4-class glass room 960x540x64 md16", S.glass_room, 960, 540, 64, 16)):
-    if len(sys.argv) > 2 and sys.argv[2] not in name:
+                                   ("C4-class glass room 960x540x64 md16", S.glass_room, 960, 540, 64, 16),
+                                   ("C4full glass room 1920x1080x512 md16", S.glass_room, 1920, 1080, 512, 16)):
+    if len(sys.argv) > 2 and not any(k in name for k in sys.argv[2:]):
         continue
+    if "C4full" in name and "C4full" not in sys.argv[2:]:
+        continue                                              # ~10 minutes of the reference on 256 threads: only on request
     desc = build(w, h, gauss).desc()
     gs = Scene(desc)
     film = HDRFilm(w, h)
@@ -38,7 +44,8 @@ for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1
     rel = float(np.linalg.norm(g - cpu) / np.linalg.norm(cpu))
     big = float((np.abs(g - cpu) > 1e-3 * np.maximum(1.0, np.abs(cpu))).any(-1).mean())
     out[name] = {"gpu_seconds": round(tg, 3), "reference_seconds": round(sec, 1), "reference_threads": os.cpu_count(), "rel_l2": rel,
-                 "pixels_differing_by_more_than_1e-3": big, "speedup": round(sec / tg, 1)}
+                 "pixels_differing_by_more_than_1e-3": big, "speedup": round(sec / tg, 1),
+                 "reference_libm": "phip_fmath.h (LD_PRELOAD libcrm.so)" if "libcrm" in os.environ.get("LD_PRELOAD", "") else "glibc"}
     print(name, out[name], flush=True)
     rs.close(); gs.close()
 os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)

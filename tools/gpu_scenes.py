@@ -14,7 +14,8 @@ for key in sys.argv[1:] or cfgs:
     sb = getattr(S, name)(w, h, ft)
     t = time.time(); sc = Scene(sb.desc()); tb = time.time() - t
     integ = PathHIP(maxDepth=md); film = HDRFilm(w, h)
-    integ.render(sc, film, 1)
+    if not os.environ.get("NOWARM"):
+        integ.render(sc, film, 1)
     for _ in range(int(os.environ.get("REPEAT", 1)) - 1):
         integ.render(sc, film, spp)
     t = time.time(); integ.render(sc, film, spp, flags=0 if os.environ.get('NOTIMING') else A.PHIP_FLAG_KERNEL_TIMING); dt = time.time() - t

@@ -9,5 +9,5 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "SQ_INST_LEVEL_VMEM SQ_WAVES SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_IFETCH SQ_INSTS_SMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU"; do
   i=$((i+1))
   [ -n "$PMC_GROUPS" ] && [ $i -gt $PMC_GROUPS ] && break
-  (cd $root && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $out -o ${tag}_g$i --output-format csv -- python tools/gpu_scenes.py $sc > $out/${tag}_g$i.log 2>&1)
+  (cd $root && NOWARM=1 timeout 600 rocprofv3 --kernel-trace --pmc $c -d $out -o ${tag}_g$i --output-format csv -- python tools/gpu_scenes.py $sc > $out/${tag}_g$i.log 2>&1)
 done

@@ -19,9 +19,10 @@ env = dict(os.environ, TMPDIR="/tmp")
 CAL_N, CAL_SRC = 1 << 26, 2 << 30        # 64M gathers from a 2 GiB buffer
 cal_cmd = [sys.executable, "-c", "import ctypes,sys; sys.path.insert(0,%r); from mitsuba_amd import _ffi; L=_ffi.lib(); "
            "L.phip_debug_pmc_calibration.argtypes=[ctypes.c_size_t,ctypes.c_size_t]; assert L.phip_debug_pmc_calibration(%d,%d)==0" % (ROOT, CAL_SRC, CAL_N)]
-ren_cmd = [sys.executable, os.path.join(ROOT, "tools", "gpu_scenes.py"), workload]       # (1-spp warm-up render + the timed render: both are counted, the per-launch figure divides by the launches)
+ren_cmd = [sys.executable, os.path.join(ROOT, "tools", "gpu_scenes.py"), workload]       # (one render of the workload)
 if spp:
     env["SPP"] = spp
+env["NOWARM"] = "1"                     # no 1-spp warm-up render: a kernel with ONE launch per render (k_mega) would average it in
 
 
 def run(counter, tag, cmd):
