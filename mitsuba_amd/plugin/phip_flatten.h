@@ -457,6 +457,22 @@ public:
                 SLog(EError, "path_hip: the phong/as microfacet distribution is not supported");
             m.distribution = distr.getType() == MicrofacetDistribution::EGGX ? PHIP_MF_GGX : PHIP_MF_BECKMANN;
             m.alpha_u = distr.getAlphaU(); m.alpha_v = distr.getAlphaV(); m.sample_visible = distr.getSampleVisible() ? 1 : 0;
+            /* a TEXTURE on alpha / alphaU / alphaV (roughconductor.cpp:196-200: a child object, invisible in the Properties) is outside
+               the supported set; it would otherwise hide behind a textured specularReflectance in the ESpatiallyVarying test below.
+               Probed through the public interface: the roughness must not depend on the texture coordinates. */
+            {
+                Intersection probe; probe.p = Point(0.0f); probe.geoFrame = probe.shFrame = Frame(Normal(0, 0, 1)); probe.wi = Vector(0, 0, 1);
+                probe.hasUVPartials = false; probe.dudx = probe.dudy = probe.dvdx = probe.dvdy = 0;
+                const Float uvs[4][2] = { { 0.13f, 0.71f }, { 0.62f, 0.29f }, { 0.91f, 0.87f }, { 0.37f, 0.05f } };
+                Float first = 0;
+                for (int k = 0; k < 4; ++k) {
+                    probe.uv = Point2(uvs[k][0], uvs[k][1]);
+                    const Float r = bsdf->getRoughness(probe, 0);
+                    if (k == 0) first = r;
+                    else if (r != first)
+                        SLog(EError, "path_hip: a textured roughness (alpha) on roughconductor is not supported");
+                }
+            }
         } else if (cls == "TwoSidedBRDF") {
             /* twosided.cpp keeps its children in m_nestedBRDF[2]; they are reachable as named children */
 #if defined(PHIP_HAVE_INTERNALS)

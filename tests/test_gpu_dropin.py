@@ -205,3 +205,45 @@ def test_random_scenes_gpu_against_the_reference_on_the_same_samples(phip, ref, 
     print("GPU vs Mitsuba on the same samples over %d random scenes: %.2f %% of %d samples bit-identical, %d took another path"
           % (n_scenes, 100.0 * ident / tot, tot, diverged))
     assert ident / tot > 0.9
+
+
+def _fullsize(tmp_path, keys, preload):
+    """tools/fullsize_vs_reference.py in a subprocess (LD_PRELOAD has to be in place before the process starts)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if preload:
+        r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "crm"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        env["LD_PRELOAD"] = os.path.join(root, "oracle", "_build", "libcrm.so")
+    out = tmp_path / ("fullsize_%s.json" % ("cr" if preload else "glibc"))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fullsize_vs_reference.py"), str(out)] + list(keys),
+                       capture_output=True, text=True, env=env, timeout=3000)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.load(open(out))
+
+
+def test_baseline_configs_at_full_size_against_the_reference(phip, ref, gauss, tmp_path):
+    """BASELINE.json configs[1] and [2] AT FULL SIZE -- Cornell box 1024x1024x256 spp and the Sponza-class atrium 1920x1080x64 spp --
+    rendered by path_hip on the GPU and by Mitsuba 0.6 itself (its RenderJob on every host core, parity-stream sampler): the
+    developed images agree within the north star's 1e-3 relative L2.  Then the same against the reference with the correctly
+    rounded transcendentals of include/phip_fmath.h LD_PRELOADed over glibc's (oracle/ref_glue/crlibm_shim.cpp): what is left
+    is the order of float additions in the film, i.e. glibc's <= 1 ulp rounding was the whole difference.
+    (PHIP_FULLSIZE_C4=1 adds configs[3], 1920x1080x512 spp maxDepth 16: about ten minutes of the reference.)"""
+    keys = ["C2", "C3"] + (["C4full"] if os.environ.get("PHIP_FULLSIZE_C4") else [])
+    stock = _fullsize(tmp_path, keys, preload=False)
+    for name, r in stock.items():
+        print("%s vs Mitsuba 0.6 (glibc): rel L2 %.3e, %.4f %% of the pixels differ by more than 1e-3; GPU %.3f s, reference %.1f s on %d threads"
+              % (name, r["rel_l2"], 100 * r["pixels_differing_by_more_than_1e-3"], r["gpu_seconds"], r["reference_seconds"], r["reference_threads"]))
+        assert r["rel_l2"] <= 1e-3, (name, r)
+    cr = _fullsize(tmp_path, keys, preload=True)
+    for name, r in cr.items():
+        print("%s vs Mitsuba 0.6 with phip_fmath.h transcendentals: rel L2 %.3e" % (name, r["rel_l2"]))
+        assert "phip_fmath" in r["reference_libm"]
+        assert r["rel_l2"] <= 2e-6, (name, r)
+    record = os.environ.get("PHIP_FULLSIZE_RECORD")
+    if record:
+        import json
+        json.dump({"glibc": stock, "phip_fmath_preloaded": cr}, open(record, "w"), indent=1)
