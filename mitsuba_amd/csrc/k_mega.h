@@ -27,61 +27,9 @@
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
-/* Two-pass intersection for scenes of <= 32 records (the Cornell box: 32): no tree at all.
- *   pass 1  every lane tests EVERY record, but approximately and without divergence: the record is wave-uniform (kernel argument ->
- *           SGPRs: no LDS traffic, no per-lane axis select, the projection axis is a uniform branch), the division is one v_rcp_f32,
- *           the barycentrics use FMAs.  A record survives unless it is CLEARLY missed: t outside [mint, maxt] by more than 2^-20 |t|,
- *           or a barycentric beyond its bounds by more than the record's margin eps (c.w, set by the host: 2^-15 * R * the record's
- *           largest edge-function gradient, R = the largest coordinate magnitude of the scene box and the sensor -- at least 8x the
- *           worst-case difference between these approximate values and the exact ones).
- *   pass 2  the exact Wald test (waldIntersect: the reference's arithmetic, IEEE division) on the lane's survivors -- 1.3 on average
- *           -- in record order, from LDS.
- * A record the exact test accepts always survives pass 1, so the result is what testing all records exactly in record order gives;
- * closest hits do not depend on the order (exact-t ties aside), any-hit answers not at all.  Versus the BVH4 walk on the Cornell box:
- * ~30 instructions x 32 records at FULL lane utilisation + ~2 exact tests, instead of 3.3 node steps + 4.0 exact tests at one third. */
-template <bool SHADOW>
-__device__ __forceinline__ bool bruteIntersect(const MegaTris &T, lds_cf4 *ldsTris, const V3 &o, const V3 &d, float mint, float maxt,
-                                               TravResult &res, uint32_t &triTests) {
-    uint32_t cand = 0;
-    for (uint32_t k = 0; k < T.n; ++k) {                       /* wave-uniform trip count and addresses: scalar loads */
-        const float4 a = T.r[3 * k], b = T.r[3 * k + 1], c = T.r[3 * k + 2];
-        const uint32_t axis = pm_to_bits(a.x);
-        float o_u, o_v, o_k, d_u, d_v, d_k;
-        if (axis == 0) { o_u = o.y; o_v = o.z; o_k = o.x; d_u = d.y; d_v = d.z; d_k = d.x; }
-        else if (axis == 1) { o_u = o.z; o_v = o.x; o_k = o.y; d_u = d.z; d_v = d.x; d_k = d.y; }
-        else if (axis == 2) { o_u = o.x; o_v = o.y; o_k = o.z; d_u = d.x; d_v = d.y; d_k = d.z; }
-        else continue;                                          /* degenerate record (never hit) */
-        const float num = a.w - o_u * a.y - o_v * a.z - o_k;   /* the exact test's numerator and denominator, same operations */
-        const float den = d_u * a.y + d_v * a.z + d_k;
-        const float t = num * __builtin_amdgcn_rcpf(den);
-        const float slack = fabsf(t) * 9.5367431640625e-07f;   /* 2^-20 |t| */
-        const float hu = fmaf(t, d_u, o_u) - b.x, hv = fmaf(t, d_v, o_v) - b.y;
-        const float u = fmaf(hv, b.z, hu * b.w), v = fmaf(hu, c.x, hv * c.y);
-        const float eps = c.w;
-        /* (a NaN or infinite t -- den == 0 -- fails these comparisons: the exact test rejects those too) */
-        const bool keep = (t + slack >= mint) && (t - slack <= maxt) && (u >= -eps) && (v >= -eps) && (u + v <= 1.0f + 2.0f * eps);
-        cand |= keep ? (1u << k) : 0u;
-    }
-    bool found = false;
-    while (cand) {
-        const uint32_t k = (uint32_t) __ffs((int) cand) - 1u;
-        cand &= cand - 1u;
-        lds_cf4 *t_ = ldsTris + 3u * k;
-        const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
-        ++triTests;
-        float tu, tv, tt;
-        if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
-            if (SHADOW) return true;
-            maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
-            found = true;
-        }
-    }
-    return found;
-}
-
 enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
 
-template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L, MegaTris T) {
+template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
     __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs */
     /* dynamic LDS: [traversal stack | all nodes | all Wald records] (setupTraversal) [shading records | emitter table | materials],
        sized for THIS scene (megaLdsBytes) so that as many blocks as the registers allow fit a CU */
@@ -163,10 +111,8 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
-            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp)) {
-                if (T.n) bruteIntersect<false>(T, stk.tris, o, d, mint, maxt, r, nTri);          /* (wave-uniform) */
-                else traverse<false, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
-            }
+            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp))
+                traverse<false, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
             v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
             ldsCount[MC_RAYS][threadIdx.x] += 1; ldsCount[MC_NODE][threadIdx.x] += nNode; ldsCount[MC_TRI][threadIdx.x] += nTri;
         }
@@ -191,8 +137,7 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
             if (clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp))
-                occluded = T.n ? bruteIntersect<true>(T, stk.tris, o, d, mint, maxt, r, nTri)
-                               : traverse<true, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
+                occluded = traverse<true, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
             ldsCount[MC_SH_RAYS][threadIdx.x] += 1; ldsCount[MC_SH_NODE][threadIdx.x] += nNode; ldsCount[MC_SH_TRI][threadIdx.x] += nTri;
             if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
         }

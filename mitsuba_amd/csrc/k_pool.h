@@ -69,11 +69,6 @@ struct MegaParams {
     uint32_t nWaves;
 };
 
-/* Scenes of at most MEGA_BRUTE_MAX Wald records: the records travel as KERNEL ARGUMENTS, i.e. wave-uniform data that the scalar
-   unit loads into SGPRs, for the first pass of k_mega's two-pass intersection (k_mega.h: bruteIntersect) */
-#define MEGA_BRUTE_MAX 32
-struct MegaTris { float4 r[3 * MEGA_BRUTE_MAX]; uint32_t n; uint32_t pad[3]; };     /* n = 0: walk the BVH4 instead */
-
 struct Counters {
     unsigned long long total[ST_COUNT];   /* written by k_reduce_stats */
 };

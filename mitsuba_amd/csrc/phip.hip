@@ -205,7 +205,6 @@ struct phip_scene {
     int envLevelCount = 0;           /* MIP levels of the envmap (0: no envmap) */
     int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
     bool wide = false;               /* the ray kernels walk the compressed 8-wide BVH (trees of >= 64 BVH4 nodes; PHIP_WIDE=0 keeps the BVH4) */
-    MegaTris megaTris;               /* scenes of <= 32 records: the records as kernel arguments of k_mega (n = 0 otherwise) */
     bool fitsLds = false;            /* tree, Wald records, shading records, emitter table and materials fit the fused kernel's LDS plan */
     std::vector<std::unique_ptr<SceneDev>> devs;
     int *cancelFlag = nullptr;       /* host-pinned (portable, mapped): phip_cancel writes it, host loops and k_mega poll it */
@@ -400,24 +399,6 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     /* acceleration structure */
     buildBVH(d.positions, d.indices, d.n_triangles, sc->bvh);
-    {
-        /* margin of the approximate first pass of k_mega's two-pass intersection (k_mega.h: bruteIntersect), kept in the unused
-           12th float of every Wald record: 2^-15 * R * the larger edge-function gradient sum, R = the largest coordinate magnitude a
-           ray origin or hit point can have (scene box, sensor position) */
-        float R = 0;
-        for (int a = 0; a < 3; ++a) R = std::max(R, std::max(std::fabs(sc->bvh.sceneMin[a]), std::fabs(sc->bvh.sceneMax[a])));
-        { const float *m = d.camera.to_world; R = std::max(R, std::max(std::fabs(m[3]), std::max(std::fabs(m[7]), std::fabs(m[11])))); }
-        for (size_t k = 0; k + 12 <= sc->bvh.tris.size(); k += 12) {
-            float *r = &sc->bvh.tris[k];
-            r[11] = 3.0517578125e-05f * R * std::max(std::fabs(r[6]) + std::fabs(r[7]), std::fabs(r[8]) + std::fabs(r[9]));
-        }
-        memset(&sc->megaTris, 0, sizeof(sc->megaTris));
-        const size_t nRec = sc->bvh.tris.size() / 12;
-        if (nRec <= MEGA_BRUTE_MAX && !getenv("PHIP_MEGA_BVH")) {      /* PHIP_MEGA_BVH=1: experiment hook, keep the BVH4 walk in k_mega */
-            memcpy(sc->megaTris.r, sc->bvh.tris.data(), nRec * 12 * sizeof(float));
-            sc->megaTris.n = (uint32_t) nRec;
-        }
-    }
     if (3 * sc->bvh.maxDepth + 2 > STACK_DEPTH + SPILL_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
     if (sc->bvh.tris.size() / 12 >= (1u << 28)) throw std::runtime_error("too many triangle records for the leaf reference encoding");
 
@@ -953,7 +934,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipMemsetAsync(sd.stat.p, 0, (size_t) ST_COUNT * M.nWaves * sizeof(unsigned long long), stream));
             if (rc.totalIds) {
                 if (timing) evFused.record(stream);
-                phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaGrid, megaLdsBytesOf(D), stream, D, M, rc, sd.L.p, sc->megaTris);
+                phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaGrid, megaLdsBytesOf(D), stream, D, M, rc, sd.L.p);
                 if (timing) evFused.record(stream);
                 iter = 1;
             }

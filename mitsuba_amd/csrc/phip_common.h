@@ -50,4 +50,4 @@ PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_S
 /* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */
 int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, size_t ldsBytes);
 void phipLaunchMega(int materialMask, bool strictNormals, dim3 grid, size_t ldsBytes, hipStream_t stream,
-                    const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L, const MegaTris &T);
+                    const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);

@@ -7,7 +7,7 @@
 #include "k_shade.h"
 #include "k_mega.h"
 
-typedef void (*MegaKernel)(DevScene, MegaParams, RenderConst, float4 *, MegaTris);
+typedef void (*MegaKernel)(DevScene, MegaParams, RenderConst, float4 *);
 
 /* Only the diffuse instantiation exists: with the microfacet / dielectric code inlined next to the traversal the kernel needs
    more than 256 VGPRs (measured: 256 + scratch at 2 waves per SIMD), and the scenes of that kind that fit LDS are test
@@ -25,6 +25,6 @@ int phipMegaBlocksPerCU(int materialMask, bool strictNormals, size_t ldsBytes) {
 }
 
 void phipLaunchMega(int materialMask, bool strictNormals, dim3 grid, size_t ldsBytes, hipStream_t stream,
-                    const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L, const MegaTris &T) {
-    hipLaunchKernelGGL(megaKernel(materialMask, strictNormals), grid, dim3(BLOCK), ldsBytes, stream, S, M, rc, L, T);
+                    const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L) {
+    hipLaunchKernelGGL(megaKernel(materialMask, strictNormals), grid, dim3(BLOCK), ldsBytes, stream, S, M, rc, L);
 }

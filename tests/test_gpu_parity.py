@@ -67,14 +67,10 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
         assert integ.render(gs, film2, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_NO_FUSED)
         assert not integ.stats.fused
         wsmp = integ.samples(gs, spp)
-        # (bit for bit, except for a ray through an edge that two triangles share: both are hit at the same t and the structure's
-        #  test order decides which one is reported -- the fused kernel tests the records of a <= 32-record scene in record order)
-        wsame = (wsmp.view(np.uint32) == gsmp.view(np.uint32)).all(axis=-1)
-        assert wsame.mean() >= 0.9999, "fused and wavefront paths differ: %.6f" % wsame.mean()
-        assert rel_l2(film2.storage, film.storage) <= 1e-5
-        assert integ.stats.samples == st.samples
-        assert abs(int(integ.stats.path_vertices) - int(st.path_vertices)) <= max(4, 1e-4 * st.path_vertices)
-        assert abs(int(integ.stats.closest_rays) - int(st.closest_rays)) <= max(4, 1e-4 * st.closest_rays)
+        assert (wsmp.view(np.uint32) == gsmp.view(np.uint32)).all(), "fused and wavefront paths differ"
+        assert (film2.storage.view(np.uint32) == film.storage.view(np.uint32)).all()
+        assert integ.stats.samples == st.samples and integ.stats.path_vertices == st.path_vertices
+        assert integ.stats.closest_rays == st.closest_rays and integ.stats.shadow_rays == st.shadow_rays
     gs.close(); osc.close()
     return same.mean(), r
 
