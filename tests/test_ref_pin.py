@@ -4,6 +4,8 @@ The oracle's libm build with the reference's sampler stream (`independent`: SFMT
 reference's per-sample radiance and its ImageBlock accumulator BIT FOR BIT; function-level hooks pin the pieces.
 Runs where the reference tree (or a prebuilt oracle/_ref) exists; tests/test_golden.py carries the same check everywhere
 through the committed fixture tests/golden/ref_renders.npz."""
+import os
+
 import numpy as np
 import pytest
 
