@@ -196,8 +196,88 @@ __device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, con
     return found;
 }
 
+/* ---- work distribution of k_rays_w: chunks of 64 slots (closest-hit rays) and blocks of the shadow queue are DRAWN from sharded
+ *      counters instead of being dealt statically (wave w: chunks w, w + W, ...).  Rays differ in cost by an order of magnitude, so
+ *      the static deal left the waves finishing far apart: 3.2 of 4 waves per SIMD resident on average over a launch (round-2 SQ
+ *      counters).  RAY_SHARDS counters, one 128-byte line each, every shard owns a contiguous range; a wave draws from the shard
+ *      of its block and moves on to the next shard when that one is empty.  One atomic per 64 rays (per 256-entry shadow block):
+ *      ~20 per wave and launch -- not the per-wave-per-iteration atomics on five shared words that round 1 banned. ---- */
+#define RAY_SHARDS 32
+#define RAY_SHARD_STRIDE 32              /* uint32 between counters (128 B) */
+struct DrawCounter {
+    unsigned int *ctr;                   /* RAY_SHARDS counters (zeroed by the host before the launch) */
+    uint32_t shard0, tried, perShard, total;
+    /* next unit of this wave (wave-uniform), or 0xFFFFFFFF when every shard is empty */
+    __device__ __forceinline__ uint32_t draw() {
+        while (tried < RAY_SHARDS) {
+            const uint32_t s = (shard0 + tried) % RAY_SHARDS;
+            uint32_t c = 0;
+            if (__lane_id() == 0) c = atomicAdd(ctr + (size_t) s * RAY_SHARD_STRIDE, 1u);
+            c = __builtin_amdgcn_readfirstlane(c);
+            const uint32_t first = s * perShard, n = first >= total ? 0u : (total - first < perShard ? total - first : perShard);
+            if (c < n) return first + c;
+            ++tried;                     /* this shard is used up: for good */
+        }
+        return 0xFFFFFFFFu;
+    }
+};
+
+struct TraceSourceDyn {
+    const PathPool &P; DrawCounter q; uint32_t chunk, pos;
+    __device__ __forceinline__ void start() { chunk = q.draw(); pos = 0; }
+    __device__ __forceinline__ bool more() const { return chunk != 0xFFFFFFFFu; }
+    __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
+        const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
+        const uint32_t h = (want && idx < 64u && chunk * 64u + idx < P.capacity) ? chunk * 64u + idx : INVALID_RAY;
+        pos += (uint32_t) __popcll(wantMask);
+        if (pos >= 64u) start();
+        return h;
+    }
+    __device__ __forceinline__ bool load(uint32_t slot, V3 &o, V3 &d, float &mint, float &maxt) const {
+        if ((P.state[slot] & F_TRACE_MASK) != F_ALIVE) return false;
+        const float4 ro = P.rayO[slot], rd = P.rayD[slot];
+        o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
+        return true;
+    }
+    __device__ __forceinline__ void commit(uint32_t slot, bool, const TravResult &r) const {
+        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+    }
+};
+
+struct ShadowSourceDyn {
+    const PathPool &P; float4 *L; DrawCounter q; uint32_t blk, pos, cnt;
+    __device__ __forceinline__ void start() {
+        for (;;) {
+            blk = q.draw(); pos = 0; cnt = 0;
+            if (blk == 0xFFFFFFFFu) return;
+            cnt = P.shadowCount[blk];
+            if (cnt) return;
+        }
+    }
+    __device__ __forceinline__ bool more() const { return blk != 0xFFFFFFFFu; }
+    __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
+        const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
+        const uint32_t h = (want && idx < cnt) ? blk * BLOCK + idx : INVALID_RAY;
+        pos += (uint32_t) __popcll(wantMask);
+        if (pos >= cnt) start();
+        return h;
+    }
+    __device__ __forceinline__ bool load(uint32_t e, V3 &o, V3 &d, float &mint, float &maxt) const {
+        const float4 e0 = P.shadow[3 * (size_t) e], e1 = P.shadow[3 * (size_t) e + 1];
+        o = V3(e0.x, e0.y, e0.z); d = V3(e1.x, e1.y, e1.z); mint = PT_EPSILON; maxt = e0.w;
+        return true;
+    }
+    __device__ __forceinline__ void commit(uint32_t e, bool occluded, const TravResult &) const {
+        if (!occluded) {
+            const float4 e1 = P.shadow[3 * (size_t) e + 1], e2 = P.shadow[3 * (size_t) e + 2];
+            addRadiance(L, pm_to_bits(e1.w), e2);
+        }
+    }
+};
+
 /* ---- persistent waves with refill: closest-hit AND any-hit rays of one iteration in ONE launch (as k_rays_p) ---- */
-__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStack &stack, ShadowSource &ss, TraceSource &ts,
+template <typename ShadowSrc, typename TraceSrc>
+__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStack &stack, ShadowSrc &ss, TraceSrc &ts,
                                                        uint32_t *wc /* LDS: WC_COUNT counters of this wave */) {
     bool active = false, shadow = false;
     uint32_t handle = INVALID_RAY;
@@ -269,15 +349,23 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
     }
 }
 
-__global__ __launch_bounds__(BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L) {
+__global__ __launch_bounds__(BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L, unsigned int *drawCounters /* 2 * RAY_SHARDS lines, zeroed; NULL: static deal */) {
     __shared__ uint32_t wcnt[BLOCK / 64][WC_COUNT];
     const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
     if (threadIdx.x < (BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
     WideStack stk; setupWide(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
-    ShadowSource ss{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
-    ss.skipEmpty();
-    TraceSource ts{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
-    persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
+    if (drawCounters) {
+        const uint32_t nBlk = P.capacity / BLOCK, nChunk = (P.capacity + 63u) / 64u;
+        ShadowSourceDyn ss{ P, L, { drawCounters, blockIdx.x % RAY_SHARDS, 0u, (nBlk + RAY_SHARDS - 1) / RAY_SHARDS, nBlk }, 0u, 0u, 0u };
+        TraceSourceDyn ts{ P, { drawCounters + RAY_SHARDS * RAY_SHARD_STRIDE, blockIdx.x % RAY_SHARDS, 0u, (nChunk + RAY_SHARDS - 1) / RAY_SHARDS, nChunk }, 0u, 0u };
+        ss.start(); ts.start();
+        persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
+    } else {
+        ShadowSource ss{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
+        ss.skipEmpty();
+        TraceSource ts{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
+        persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
+    }
     if (__lane_id() == 0) {
         const int rows[WC_COUNT] = { ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
 #pragma unroll

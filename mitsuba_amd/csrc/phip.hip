@@ -172,6 +172,7 @@ struct SceneDev {
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
     DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
+    DevBuf<unsigned int> drawCounters;                                                       /* k_rays_w: 2 x RAY_SHARDS sharded work counters */
     DevBuf<float> film;
     uint32_t lastSpp = 0, nLocalTiles = 0; unsigned long long localPixels = 0;
     int tileKey[3] = { -1, -1, -1 };
@@ -887,6 +888,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     const dim3 pgridTrace = persistentGrid(sc->bvh.nNodes >= 64 ? (const void *) k_trace_p<false> : (const void *) k_trace_p<true>, TRACE_P_WAVES);
     const dim3 pgridRays = sc->wide ? persistentGrid((const void *) k_rays_w, WIDE_WAVES) : persistentGrid((const void *) k_rays_p, RAYS_WAVES);
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
+    bool dynamicDeal = true;                                             /* k_rays_w draws its chunks from sharded counters */
+    if (const char *e = getenv("PHIP_RAYS_STATIC")) dynamicDeal = atoi(e) == 0;
 
     /* fused path: resident grid and per-wave statistics rows */
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
@@ -972,7 +975,15 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                 if (timing) evShade.record(stream);
                 if (merged) {
                     if (timing) evTrace.record(stream);
-                    if (sc->wide) hipLaunchKernelGGL(k_rays_w, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
+                    if (sc->wide) {
+                        unsigned int *dc = nullptr;
+                        if (dynamicDeal) {
+                            if (sd.drawCounters.n < 2 * RAY_SHARDS * RAY_SHARD_STRIDE) sd.drawCounters.alloc(2 * RAY_SHARDS * RAY_SHARD_STRIDE);
+                            HIP_TRY(hipMemsetAsync(sd.drawCounters.p, 0, 2 * RAY_SHARDS * RAY_SHARD_STRIDE * sizeof(unsigned int), stream));
+                            dc = sd.drawCounters.p;
+                        }
+                        hipLaunchKernelGGL(k_rays_w, pgridRays, block, ldsBytes, stream, D, P, sd.L.p, dc);
+                    }
                     else hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
                     if (timing) evTrace.record(stream);
                 } else {
