@@ -25,7 +25,8 @@ enum : uint32_t {
     F_REFN_ZERO = 1u << 24,             /* DirectSamplingRecord::refN of the vertex the ray left is zero (BSDF with a back side / transmission) */
     F_NOTRACE = 1u << 25,               /* `direct`: the slot is alive but has no closest-hit query in flight this iteration */
     F_TRACE_MASK = F_ALIVE | F_NOTRACE, /* the traversal kernels trace a slot iff (state & F_TRACE_MASK) == F_ALIVE */
-    DEPTH_MASK = 0xFFFFu
+    DEPTH_MASK = 0xFFFFu,
+    NS_SHIFT = 26                       /* bits 26..31: non-smooth vertices of the path so far, modulo 64 (call-order parity stream, k_shade.h) */
 };
 
 struct PathPool {

@@ -267,7 +267,18 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
         }
         V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
         if (!terminate) {
-            const U4 h = pcg4d(v.pixel, v.k, 1 + 2 * (depth - 1), rc.seed);
+            /* the parity stream is consumed in CALL ORDER, like a Sampler: the k-th 2D request after the pixel jitter is
+               pair k & 1 (.xy / .zw) of block 1 + 2 (k >> 1).  A vertex with a smooth BSDF makes two requests (emitter sample, BSDF
+               sample), a vertex without one; k0 = 2 (depth - 1) - ns is this vertex's first, ns = the non-smooth vertices so far
+               (bits 26..31 of the state word, modulo 64).  All-smooth paths: k0 is even and both pairs come from one block. */
+            const bool smoothVertex = (its.flags & TS_MF_SMOOTH) != 0;
+            const uint32_t k0 = 2u * (depth - 1u) - (flags >> NS_SHIFT);
+            U4 h = pcg4d(v.pixel, v.k, 1 + 2 * (k0 >> 1), rc.seed);
+            if (k0 & 1u) {
+                if (smoothVertex) { const U4 h2 = pcg4d(v.pixel, v.k, 3 + 2 * (k0 >> 1), rc.seed); h = U4{ h.z, h.w, h2.x, h2.y }; }
+                else h = U4{ h.z, h.w, h.z, h.w };
+            }
+            if (!smoothVertex) { h.z = h.x; h.w = h.y; flags += 1u << NS_SHIFT; }      /* its one request is the BSDF sample */
             /* ---- direct illumination sampling, path.cpp:172-200 ---- */
             DirectRec dRec;
             dRec.ref = its.p;

@@ -87,7 +87,7 @@ inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray
         Float bsdfPdf = 0;
         BSDFSamplingRecord bRec;
         bRec.wi = its.wi; bRec.eta = 1.0f; bRec.sampledDelta = false;
-        Spectrum bsdfWeight = bsdfs.sample(bsdf, bRec, bsdfPdf, smp.bsdfSample(depth));
+        Spectrum bsdfWeight = bsdfs.sample(bsdf, bRec, bsdfPdf, smp.bsdfSample(depth, bsdf.smooth));
         if (bsdfWeight.isZero())
             break;
 

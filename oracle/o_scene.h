@@ -113,9 +113,9 @@ struct DirectSamplingRecord {
 
 /* Sample source: the reference consumes one sequential stream per worker (`sfmt` mode); the
  * parity stream (`ctr`) is addressed by (pixel, sample, dimension block) so CPU and GPU see the
- * same numbers regardless of scheduling.  Block layout (shared with the HIP kernels):
+ * same numbers regardless of scheduling.  Block layout (shared with the HIP kernels; DESIGN.md 3.5):
  *   block 0              : (jitter.x, jitter.y, -, -)
- *   block 1 + 2*(d-1)    : (emitter.x, emitter.y, bsdf.x, bsdf.y) at path depth d (d >= 1)
+ *   block 1 + 2*(k>>1)   : pair k & 1 = the k-th 2D request after the jitter (= (emitter.xy, bsdf.xy) of depth k/2+1 without dielectrics)
  *   block 2 + 2*(d-1)    : (rr, -, -, -)
  * word -> float exactly like Random::nextFloat (random.cpp:632-641): (u >> 9 | 0x3f800000) - 1.
  */
@@ -142,17 +142,26 @@ struct SampleSource {
         pcg4d(v);
         for (int i = 0; i < 4; ++i) out[i] = u32ToFloat(v[i]);
     }
+    /* ctr mode, `path`: the stream is defined by CALL ORDER, like a Sampler is consumed: the k-th 2D request after
+       the pixel jitter (k = 0, 1, ...) is pair k & 1 (.xy / .zw) of block 1 + 2 (k >> 1).  A vertex with a smooth BSDF makes two
+       requests (emitter sample, BSDF sample), a vertex without (dielectric) one: k = 2 (depth - 1) - ns at the start of vertex
+       `depth`, ns = non-smooth vertices so far (modulo 64: six bits of device state). */
+    uint32_t ns = 0;
+    Vec2 pair(uint32_t k) const { float f[4]; block(1 + 2 * (k >> 1), f); return (k & 1u) ? Vec2(f[2], f[3]) : Vec2(f[0], f[1]); }
     Vec2 cameraSample() {
         if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
+        ns = 0;
         float f[4]; block(0, f); return Vec2(f[0], f[1]);
     }
-    Vec2 emitterSample(int depth) {
+    Vec2 emitterSample(int depth) {                      /* (only requested at vertices with a smooth BSDF, path.cpp:174-176) */
         if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
-        float f[4]; block(1 + 2 * (uint32_t) (depth - 1), f); return Vec2(f[0], f[1]);
+        return pair(2 * (uint32_t) (depth - 1) - ns);
     }
-    Vec2 bsdfSample(int depth) {
+    Vec2 bsdfSample(int depth, bool smooth) {
         if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
-        float f[4]; block(1 + 2 * (uint32_t) (depth - 1), f); return Vec2(f[2], f[3]);
+        const uint32_t k = 2 * (uint32_t) (depth - 1) - ns + (smooth ? 1u : 0u);
+        if (!smooth) ns = (ns + 1u) & 63u;
+        return pair(k);
     }
     Float rrSample(int depth) {
         if (!ctr) return rng->nextFloat();

@@ -45,7 +45,6 @@ int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref
 struct FileShape { std::string plugin, filename; uint32_t material; float toWorld[16]; };
 std::vector<FileShape> g_fileShapes;
 int g_analyticRectangles = 0;   /* build exact rectangles as the reference's analytic `rectangle` shape instead of a two-triangle mesh */
-const uint32_t *g_smoothMasks = NULL;   /* optional [pixel][sample] smooth-vertex masks for the parity sampler (scenes with dielectrics) */
 
 struct RefScene {
     ref<Scene> scene;
@@ -55,7 +54,8 @@ struct RefScene {
     int width, height;
 };
 
-/* the scene's sampler for one render: `independent`, or the parity stream (smooth-BSDF scenes only, see ctr_sampler.cpp) */
+/* the scene's sampler for one render: `independent`, or the parity stream (ctr_sampler.cpp: defined by call order, so it needs to know
+   nothing about the scene) */
 Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
     Properties smp(g_samplerKind == 1 ? "ctr" : "independent");
     smp.setSize("sampleCount", (size_t) p->spp);
@@ -64,7 +64,7 @@ Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
         smp.setInteger("cropWidth", scene->getFilm()->getCropSize().x);
         smp.setString("mode", p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path");
         smp.setSize("emitterSamples", (size_t) std::max(0, p->emitter_samples)); smp.setSize("bsdfSamples", (size_t) std::max(0, p->bsdf_samples));
-        if (g_smoothMasks) { Properties::Data d; d.ptr = (uint8_t *) g_smoothMasks; d.size = 0; smp.setData("smoothMasks", d); }
+        smp.setInteger("rrDepth", p->rr_depth);          /* the depth of the first Russian-roulette request (path.cpp:276-283) */
     }
     Sampler *s = static_cast<Sampler *>(PluginManager::getInstance()->createObject(MTS_CLASS(Sampler), smp));
     s->configure();
@@ -220,7 +220,6 @@ int ref_init(void) {
 
 /* 0 = `independent` (default), 1 = the counter-based parity stream for the following renders */
 void ref_set_sampler(int kind) { g_samplerKind = kind; }
-void ref_set_smooth_masks(const uint32_t *masks) { g_smoothMasks = masks; }
 void ref_set_analytic_rectangles(int on) { g_analyticRectangles = on; }
 void ref_add_shape_file(const char *plugin, const char *filename, uint32_t material, const float *to_world16) {
     FileShape f; f.plugin = plugin; f.filename = filename; f.material = material;

@@ -71,7 +71,6 @@ def lib():
     L.ref_sample_emitter.argtypes = [C.c_void_p, fp, fp, C.c_size_t, fp, fp, fp, fp, fp, fp]
     L.ref_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, fp]
     L.ref_set_sampler.argtypes = [C.c_int]
-    L.ref_set_smooth_masks.argtypes = [C.c_void_p]
     L.ref_set_analytic_rectangles.argtypes = [C.c_int]
     L.ref_add_shape_file.argtypes = [C.c_char_p, C.c_char_p, u32, fp]
     L.ref_mip_build.restype = C.c_void_p
@@ -121,25 +120,23 @@ class RefScene:
         if rc != 0:
             raise RuntimeError(what + ": " + self.L.ref_last_error().decode())
 
-    def _sampler(self, sampler, smooth_masks):
+    def _sampler(self, sampler):
         self.L.ref_set_sampler(1 if sampler == "ctr" else 0)
-        self._masks = None if smooth_masks is None else np.ascontiguousarray(smooth_masks, np.uint32)
-        self.L.ref_set_smooth_masks(None if self._masks is None else self._masks.ctypes.data)
 
-    def render(self, params, want_samples=True, sampler="independent", smooth_masks=None):
-        """sampler="ctr": the reference's integrator fed with the counter-based parity stream (ref_glue/ctr_sampler.cpp).
-        Scenes with non-smooth BSDFs (dielectrics) also need smooth_masks = OracleScene.smooth_masks(params)."""
-        self._sampler(sampler, smooth_masks)
+    def render(self, params, want_samples=True, sampler="independent"):
+        """sampler="ctr": the reference's integrator fed with the counter-based parity stream (ref_glue/ctr_sampler.cpp: defined by
+        call order, so the plugin needs to know nothing about the scene)."""
+        self._sampler(sampler)
         film = np.zeros((self.height, self.width, 5), np.float32)
         samples = np.zeros((self.height, self.width, params.spp, 4), np.float32) if want_samples else None
         self._check(self.L.ref_render(self.h, C.byref(params), _fp(samples) if want_samples else None, _fp(film)), "ref_render")
         return film, samples
 
-    def render_job(self, params, threads=None, want_image=True, plugin=None, sampler="independent", smooth_masks=None):
+    def render_job(self, params, threads=None, want_image=True, plugin=None, sampler="independent"):
         """the reference's complete multi-threaded render (RenderJob on the Scheduler); returns (rgb or None, seconds).
         plugin="path_hip" / "direct_hip": the same job with the product's plugin shim as the scene's integrator."""
         threads = threads or os.cpu_count() or 1
-        self._sampler(sampler, smooth_masks)
+        self._sampler(sampler)
         rgb = np.zeros((self.height, self.width, 3), np.float32) if want_image else None
         sec = C.c_double()
         self._check(self.L.ref_render_job_plugin(self.h, C.byref(params), plugin.encode() if plugin else None, threads,

@@ -4,15 +4,14 @@
  * ctr_sampler.cpp: a Sampler plugin FOR THE REFERENCE ("ctr", oracle/_ref/plugins/ctr.so) that hands the reference's own
  * integrators the counter-based parity stream of DESIGN.md 3.5 -- pcg4d(pixel, sampleIndex, block, seed) -- so that the
  * reference's `path` / `direct` and the GPU consume THE SAME random numbers and their images can be compared directly
- * (tests/test_gpu_dropin.py).  A sampler only sees next1D / next2D calls, so the block a call belongs to is inferred from
- * the call order of MIPathTracer::Li (path.cpp:119-300): pixel jitter, then per path vertex [emitter 2D] [BSDF 2D]
- * [Russian-roulette 1D].  The emitter sample is skipped by the integrator for non-smooth BSDFs (path.cpp:174), which a sampler
- * cannot see.  Without further information the plugin assumes that every BSDF has a smooth component (diffuse,
- * roughconductor, two-sided wrappers of those -- BASELINE configs C2 and C3).  For scenes with dielectrics the caller passes
- * `smoothMasks` (property of type data): per (pixel, sample) a 32-bit word whose bit d-1 says whether the BSDF at path
- * vertex d is smooth, recorded by the oracle on the same stream (OracleScene.smooth_masks).  A wrong mask cannot make a
- * wrong render look right: the reference would then consume other numbers than the oracle and the comparison fails.
- * `mode` = "path" or "direct"; for `direct` the sample counts tell which 2D calls are single samples (direct.cpp:212-216,251-255).
+ * (tests/test_gpu_dropin.py).  The stream is defined by CALL ORDER, which is all a sampler sees:
+ *   `path`:   2D request 0 of a sample = the pixel jitter (block 0 .xy, integrator.cpp:171); 2D request 1 + k = pair k & 1 (.xy / .zw)
+ *             of block 1 + 2 (k >> 1) -- a vertex with a smooth BSDF makes two requests (emitter sample, path.cpp:176; BSDF sample,
+ *             :209), one without (dielectric) makes one, and the device / the oracle count exactly like that (k_shade.h,
+ *             o_scene.h); 1D request j (Russian roulette, path.cpp:283: one per vertex from depth rrDepth on) = .x of block
+ *             2 + 2 (rrDepth - 1 + j).
+ *   `direct`: the sample counts tell which 2D calls are single samples (direct.cpp:212-216,251-255); arrays as in generate().
+ * Nothing about the scene is needed (round 1 needed the oracle's per-sample smooth-vertex masks for scenes with dielectrics).
  */
 #include <mitsuba/render/sampler.h>
 #include <mitsuba/render/scene.h>
@@ -28,15 +27,15 @@ public:
         m_direct = props.getString("mode", "path") == "direct";
         m_emitterSamples = props.getSize("emitterSamples", 1);
         m_bsdfSamples = props.getSize("bsdfSamples", 1);
-        m_masks = props.hasProperty("smoothMasks") ? (const uint32_t *) props.getData("smoothMasks").ptr : NULL;
-        m_pixel = 0; m_call2D = 0; m_depth = 1; m_rrDepth = 1; m_phase = 0;
+        m_rrFirst = (uint32_t) props.getInteger("rrDepth", 5);
+        m_pixel = 0; m_call2D = 0; m_call1D = 0;
     }
     CtrSampler(Stream *stream, InstanceManager *manager) : Sampler(stream, manager) { Log(EError, "ctr sampler: not serializable"); }
 
     ref<Sampler> clone() {
         ref<CtrSampler> s = new CtrSampler(getProperties());
         s->m_sampleCount = m_sampleCount; s->m_seed = m_seed; s->m_width = m_width; s->m_direct = m_direct;
-        s->m_emitterSamples = m_emitterSamples; s->m_bsdfSamples = m_bsdfSamples; s->m_masks = m_masks;
+        s->m_emitterSamples = m_emitterSamples; s->m_bsdfSamples = m_bsdfSamples; s->m_rrFirst = m_rrFirst;
         for (size_t i = 0; i < m_req1D.size(); ++i) s->request1DArray(m_req1D[i]);
         for (size_t i = 0; i < m_req2D.size(); ++i) s->request2DArray(m_req2D[i]);
         return s.get();
@@ -72,28 +71,20 @@ public:
             block((uint32_t) m_sampleIndex, 1, f);
             return emitterCall ? Point2(f[0], f[1]) : Point2(f[2], f[3]);
         }
-        /* path.cpp:176 (emitter sample of vertex m_depth, only for smooth BSDFs), :209 (BSDF sample of the same vertex) */
-        bool emitterCall;
-        if (m_phase == 1) { emitterCall = false; }                                  /* the BSDF sample after an emitter sample */
-        else {
-            const bool smooth = !m_masks || m_depth > 32 ||
-                ((m_masks[(size_t) m_pixel * m_sampleCount + m_sampleIndex] >> (m_depth - 1)) & 1u);
-            emitterCall = smooth;
-        }
-        block((uint32_t) m_sampleIndex, 1 + 2 * (m_depth - 1), f);
-        if (emitterCall) { m_phase = 1; return Point2(f[0], f[1]); }
-        m_rrDepth = m_depth; ++m_depth; m_phase = 0;
-        return Point2(f[2], f[3]);
+        /* `path`: 2D request 1 + k of the sample */
+        const uint32_t k = call - 1;
+        block((uint32_t) m_sampleIndex, 1 + 2 * (k >> 1), f);
+        return (k & 1u) ? Point2(f[2], f[3]) : Point2(f[0], f[1]);
     }
     Float next1D() {                                                                                /* path.cpp:283, Russian roulette */
-        float f[4]; block((uint32_t) m_sampleIndex, 2 + 2 * (m_rrDepth - 1), f);
+        float f[4]; block((uint32_t) m_sampleIndex, 2 + 2 * (m_rrFirst - 1 + m_call1D++), f);
         return f[0];
     }
 
     std::string toString() const { return "CtrSampler[]"; }
     MTS_DECLARE_CLASS()
 private:
-    void beginSample() { m_call2D = 0; m_depth = 1; m_rrDepth = 1; m_phase = 0; }
+    void beginSample() { m_call2D = 0; m_call1D = 0; }
     static float toFloat(uint32_t u) { uint32_t b = (u >> 9) | 0x3f800000u; float f; memcpy(&f, &b, 4); return f - 1.0f; }   /* random.cpp:632-641 */
     void block(uint32_t sample, uint32_t blk, float out[4]) const {
         /* pcg4d (Jarzynski & Olano, JCGT 9(3) 2020) over (pixel, sample, block, seed) */
@@ -104,8 +95,7 @@ private:
         v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
         for (int i = 0; i < 4; ++i) out[i] = toFloat(v[i]);
     }
-    uint32_t m_seed, m_pixel, m_call2D, m_depth, m_rrDepth, m_phase;
-    const uint32_t *m_masks;
+    uint32_t m_seed, m_pixel, m_call2D, m_call1D, m_rrFirst;
     int m_width;
     bool m_direct;
     size_t m_emitterSamples, m_bsdfSamples;

@@ -83,7 +83,8 @@ def check_scene(ref, name, desc):
 def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss):
     """BASELINE.json north_star, literally: "output radiance matches the reference CPU `path` integrator on the same
     scene / seed ... <= 1e-3 relative L2 at equal spp".  The reference's own `path` (and `direct`) run on the host with the
-    parity stream (oracle/ref_glue/ctr_sampler.cpp: the reference consumes the random numbers the GPU consumes); the GPU
+    parity stream (oracle/ref_glue/ctr_sampler.cpp: the reference consumes the random numbers the GPU consumes -- the stream is defined
+    by call order, so nothing of the oracle is involved, dielectrics or not); the GPU
     renders the same scene through the C ABI.  Compared sample by sample: the two differ only in the transcendentals (libm there, phip_fmath.h
     here, <= 4 ulp), so most samples agree to the last bits, the rest to ~1e-6 -- except the handful of paths in which such
     an ulp flips a discrete decision (a Russian-roulette test, a CDF bin, a tie) and the path goes elsewhere: those are
@@ -91,7 +92,6 @@ def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss)
     itself the same way."""
     import ref_scenes as RS
     from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
-    oracle.build(libm=True)
     for name, desc, spp, bar in (("cornell 128x128", S.cornell_box(128, 128, gauss).desc(), 64, 1e-3),
                                  ("textures 48x32", RS.textures(gauss, live_mip(ref)).desc(), 64, 1e-3),
                                  ("atrium 160x90", S.atrium(160, 90, gauss, detail=0.5).desc(), 32, 1e-3),
@@ -100,14 +100,11 @@ def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss)
                                  ("envmap 40x24", RS.envmap(gauss, live_mip(ref)).desc(), 64, 1e-3)):
         rs = ref.RefScene(desc)
         gs = Scene(desc)
-        osc = oracle.OracleScene(desc, libm=True)
         for what, Integ, kw, rkw in (("path", PathHIP, dict(maxDepth=8), dict(max_depth=8)),
                                      ("direct", DirectHIP, dict(emitterSamples=2, bsdfSamples=2),
                                       dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2))):
             p = A.default_render_params(spp=spp, block_size=256, **rkw)
-            # which vertices have a smooth BSDF (the reference skips the emitter sample at the others, path.cpp:174): from the oracle
-            masks = osc.smooth_masks(p) if what == "path" else None
-            rfilm, rsmp = rs.render(p, sampler="ctr", smooth_masks=masks)   # the reference's Li, sample by sample
+            rfilm, rsmp = rs.render(p, sampler="ctr")   # the reference's Li, sample by sample
             integ = Integ(**kw)
             film = HDRFilm(gs.width, gs.height)
             assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
@@ -122,7 +119,7 @@ def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss)
                   % (name, what, spp, what, 100 * identical.mean(), int((~close).sum()), close.size, r))
             assert (~close).mean() < 2e-3
             assert r <= bar
-        rs.close(); gs.close(); osc.close()
+        rs.close(); gs.close()
 
 
 def test_baseline_config_c1_against_the_reference(phip, ref, gauss):
@@ -176,7 +173,6 @@ def test_random_scenes_gpu_against_the_reference_on_the_same_samples(phip, ref, 
     nearly all samples agree to the last bit, the rest to ~1e-6, a handful of paths per scene at most take another branch"""
     import ref_scenes as RS
     from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
-    oracle.build(libm=True)
     n_scenes = int(os.environ.get("PHIP_FUZZ_SCENES", "40"))
     tot = ident = diverged = 0
     for seed in range(n_scenes):
@@ -192,16 +188,14 @@ def test_random_scenes_gpu_against_the_reference_on_the_same_samples(phip, ref, 
         assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
         gsmp = integ.samples(gs, spp)
         p = integ.params(gs, spp)
-        osc = oracle.OracleScene(desc, libm=True)
-        masks = osc.smooth_masks(p) if p.integrator == A.PHIP_INTEGRATOR_PATH else None
         rs = ref.RefScene(desc)
-        _, rsmp = rs.render(p, sampler="ctr", smooth_masks=masks)
+        _, rsmp = rs.render(p, sampler="ctr")                   # (no oracle in the loop: the parity stream is defined by call order)
         both_nan = np.isnan(gsmp) & np.isnan(rsmp)
         same = ((gsmp.view(np.uint32) == rsmp.view(np.uint32)) | both_nan).all(-1)
         close = ((np.abs(gsmp - rsmp) <= 1e-4 * np.maximum(1.0, np.abs(rsmp))) | both_nan).all(-1)
         tot += same.size; ident += int(same.sum()); diverged += int((~close).sum())
         assert (~close).mean() < 5e-3, (seed, kw, float((~close).mean()))
-        rs.close(); gs.close(); osc.close()
+        rs.close(); gs.close()
     print("GPU vs Mitsuba on the same samples over %d random scenes: %.2f %% of %d samples bit-identical, %d took another path"
           % (n_scenes, 100.0 * ident / tot, tot, diverged))
     assert ident / tot > 0.9

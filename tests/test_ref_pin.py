@@ -57,18 +57,16 @@ def test_oracle_reproduces_the_reference_bit_for_bit(ref, olibm, name, build, kw
 @pytest.mark.parametrize("name,build,kw", RS.CASES, ids=[c[0] for c in RS.CASES])
 def test_reference_on_the_parity_stream(ref, oracle, olibm, name, build, kw):
     """the counter-based parity stream itself, validated on the real integrators: the reference's `path` / `direct` fed by
-    oracle/ref_glue/ctr_sampler.cpp (a Sampler plugin for the reference that reproduces pcg4d(pixel, sample, block, seed);
-    which path vertices have a smooth BSDF -- the integrator skips the emitter sample otherwise, path.cpp:174 -- comes from
-    the oracle's run on the same stream) consume exactly the numbers the oracle's -- and hence the GPU's -- ctr renders
+    oracle/ref_glue/ctr_sampler.cpp (a Sampler plugin for the reference that serves pcg4d(pixel, sample, block, seed) purely
+    by call order -- it knows nothing about the scene, dielectrics included) consume exactly the numbers the oracle's -- and hence the GPU's -- ctr renders
     consume: bit-identical with the libm build, and the parity build (= the GPU, bit for bit) is within the north-star
     tolerance of the REFERENCE ON THE SAME SAMPLES by orders of magnitude"""
     gauss = olibm.gaussian_filter(0.5, libm=True)
     desc = build(gauss, live_mip(ref)).desc()
     p = RS.params(kw)
     osc = olibm.OracleScene(desc, libm=True)
-    masks = osc.smooth_masks(p, threads=1)
     rs = ref.RefScene(desc)
-    rfilm, rsmp = rs.render(p, sampler="ctr", smooth_masks=masks)
+    rfilm, rsmp = rs.render(p, sampler="ctr")
     ofilm, osmp, _ = osc.render(p, threads=1, sampler="ctr", want_samples=True)
     assert np.array_equal(rsmp.view(np.uint32), osmp.view(np.uint32))
     assert np.array_equal(rfilm.view(np.uint32), ofilm.view(np.uint32))

@@ -36,11 +36,7 @@ for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1
     t = time.time(); assert integ.render(gs, film, spp); tg = time.time() - t
     g = film.develop()
     rs = R.RefScene(desc)
-    masks = None
-    if "glass" in name:       # dielectrics: the parity sampler has to know which vertices are smooth -- from the oracle on the same stream
-        O.build(libm=True)
-        masks = O.OracleScene(desc, libm=True).smooth_masks(A.default_render_params(spp=spp, max_depth=md))
-    cpu, sec = rs.render_job(A.default_render_params(spp=spp, max_depth=md), sampler="ctr", smooth_masks=masks)
+    cpu, sec = rs.render_job(A.default_render_params(spp=spp, max_depth=md), sampler="ctr")
     rel = float(np.linalg.norm(g - cpu) / np.linalg.norm(cpu))
     big = float((np.abs(g - cpu) > 1e-3 * np.maximum(1.0, np.abs(cpu))).any(-1).mean())
     out[name] = {"gpu_seconds": round(tg, 3), "reference_seconds": round(sec, 1), "reference_threads": os.cpu_count(), "rel_l2": rel,

@@ -30,9 +30,8 @@ for name in (sys.argv[1:] or list(SCENES)):
     p = A.default_render_params(spp=spp, max_depth=md, block_size=256)
     osc = O.OracleScene(desc)                               # parity build: phip_fmath.h
     ofilm, osmp, _ = osc.render(p, want_samples=True)
-    masks = osc.smooth_masks(p)
     rs = R.RefScene(desc)
-    rfilm, rsmp = rs.render(p, sampler="ctr", smooth_masks=masks)
+    rfilm, rsmp = rs.render(p, sampler="ctr")
     same = (osmp.view(np.uint32) == rsmp.view(np.uint32)).all(-1)
     rel = float(np.linalg.norm(ofilm.astype(np.float64) - rfilm) / np.linalg.norm(rfilm))
     print(json.dumps({"scene": name, "spp": spp, "samples": int(same.size), "bit_identical": float(same.mean()),
