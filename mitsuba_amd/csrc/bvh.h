@@ -34,6 +34,7 @@
 namespace pt {
 
 struct BuildTri { float bmin[3], bmax[3], c[3]; uint32_t prim; };
+constexpr uint32_t SPATIAL_MIN_TRIS = 4096;     /* scenes from this size on are built with spatial splits */
 
 struct HostBVH {
     /* 8-wide tree with quantised child boxes for the big-scene ray kernels (k_wide.h), after Ylitie, Karras & Laine,
@@ -105,10 +106,55 @@ struct Builder {
     int MAX_LEAF = 4;
     float C_TRAV = 1.0f, C_ISECT = 1.0f;
     double sah = 0;
+    /* spatial splits (Stich, Friedrich & Dietrich, "Spatial Splits in Bounding Volume Hierarchies", HPG 2009): scenes with long
+       thin triangles (architecture: floors, walls, beams next to finely tessellated detail) */
+    static constexpr int SBINS = 32;
+    bool spatial = false;
+    float alpha = 1e-5f;               /* a spatial split is only tried when the object split's children overlap by more than alpha * root area */
+    double rootArea = 1;
+    size_t refBudget = 0, nRefs = 0;   /* total triangle references (duplicates included) may not exceed refBudget */
 
     Builder(std::vector<BuildTri> &t, HostBVH &o, const float *p, const uint32_t *i) : T(t), out(o), positions(p), indices(i) {
         if (const char *e = getenv("PHIP_BVH_MAXLEAF")) MAX_LEAF = std::min(8, std::max(1, atoi(e)));     /* experiment hooks */
         if (const char *e = getenv("PHIP_BVH_CTRAV")) C_TRAV = (float) atof(e);
+        if (const char *e = getenv("PHIP_BVH_ALPHA")) alpha = (float) atof(e);
+    }
+
+    /* bounds of (triangle `prim` restricted to lo <= x[axis] <= hi), intersected with `within`; false if nothing is left.
+       Computed in double and widened by one float ulp: conservative (and the node boxes are padded on top, pad()). */
+    bool clippedBounds(uint32_t prim, int axis, double lo, double hi, const Box &within, Box &outb) const {
+        double v[3][3];
+        for (int k = 0; k < 3; ++k) { const float *p = positions + 3 * (size_t) indices[3 * (size_t) prim + k]; v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2]; }
+        double mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+        auto add = [&](const double *q) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], q[a]); mx[a] = std::max(mx[a], q[a]); } };
+        for (int k = 0; k < 3; ++k) {
+            const double *p0 = v[k], *p1 = v[(k + 1) % 3];
+            if (p0[axis] >= lo && p0[axis] <= hi) add(p0);
+            const double planes[2] = { lo, hi };
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const double pl = planes[s2];
+                if (!std::isfinite(pl)) continue;
+                if ((p0[axis] < pl && p1[axis] > pl) || (p0[axis] > pl && p1[axis] < pl)) {
+                    const double t = (pl - p0[axis]) / (p1[axis] - p0[axis]);
+                    double q[3]; for (int a = 0; a < 3; ++a) q[a] = p0[a] + t * (p1[a] - p0[a]);
+                    q[axis] = pl; add(q);
+                }
+            }
+        }
+        outb.reset();
+        for (int a = 0; a < 3; ++a) {
+            if (!(mn[a] <= mx[a])) return false;
+            float l = std::nextafterf((float) mn[a], -INFINITY), h = std::nextafterf((float) mx[a], INFINITY);
+            l = std::max(l, within.mn[a]); h = std::min(h, within.mx[a]);
+            if (!(l <= h)) return false;
+            outb.mn[a] = l; outb.mx[a] = h;
+        }
+        return true;
+    }
+    static BuildTri makeRef(const Box &b, uint32_t prim) {
+        BuildTri r; r.prim = prim;
+        for (int a = 0; a < 3; ++a) { r.bmin[a] = b.mn[a]; r.bmax[a] = b.mx[a]; r.c[a] = 0.5f * (b.mn[a] + b.mx[a]); }
+        return r;
     }
 
     /* pads a box so that a hit accepted by the Wald test (which tolerates a few ulp outside the
@@ -120,12 +166,13 @@ struct Builder {
         }
     }
 
-    int32_t makeLeaf(size_t b, size_t e) {
+    int32_t makeLeaf(size_t b, size_t e) { return makeLeaf(T.data() + b, T.data() + e); }
+    int32_t makeLeaf(const BuildTri *rb, const BuildTri *re) {
         uint32_t first = (uint32_t) (out.tris.size() / 12);
         uint32_t count = 0;
-        for (size_t i = b; i < e; ++i) {
+        for (const BuildTri *it = rb; it != re; ++it) {
             float rec[12];
-            const uint32_t p = T[i].prim;
+            const uint32_t p = it->prim;
             const float *A = positions + 3 * (size_t) indices[3 * (size_t) p], *B = positions + 3 * (size_t) indices[3 * (size_t) p + 1],
                         *C = positions + 3 * (size_t) indices[3 * (size_t) p + 2];
             if (!waldLoad(A, B, C, p, rec)) continue;
@@ -198,6 +245,152 @@ struct Builder {
         int32_t l = build(b, mid, lb, depth + 1);
         int32_t r = build(mid, e, rb, depth + 1);
         Box lp = lb, rp = rb; pad(lp); pad(rp);
+        float *nd = &out.nodes2[(size_t) idx * 16];
+        nd[0] = lp.mn[0]; nd[1] = lp.mn[1]; nd[2] = lp.mn[2]; nd[3] = lp.mx[0];
+        nd[4] = lp.mx[1]; nd[5] = lp.mx[2]; nd[6] = rp.mn[0]; nd[7] = rp.mn[1];
+        nd[8] = rp.mn[2]; nd[9] = rp.mx[0]; nd[10] = rp.mx[1]; nd[11] = rp.mx[2];
+        nd[12] = bits2f((uint32_t) l); nd[13] = bits2f((uint32_t) r); nd[14] = 0; nd[15] = 0;
+        return (int32_t) idx;
+    }
+
+    /* the same recursion over a reference LIST, with spatial splits: at every node the best object split (binned over the
+       centroids, as above) competes with the best spatial split (SBINS slabs of the node box per axis, triangles clipped to the
+       slabs they cross); a reference that straddles the chosen plane is split into two references with clipped boxes unless
+       keeping it whole on one side is cheaper ("reference unsplitting", section 4.4 of the paper). */
+    int32_t buildSpatial(std::vector<BuildTri> &refs, Box &box, uint32_t depth) {
+        out.maxDepth = std::max(out.maxDepth, depth);
+        box.reset();
+        Box cb; cb.reset();
+        for (const BuildTri &t : refs) { box.grow(t.bmin, t.bmax); cb.growPt(t.c); }
+        const size_t n = refs.size();
+        if (n == 1) return makeLeaf(refs.data(), refs.data() + n);
+
+        /* object split */
+        float bestCost = INFINITY; int bestAxis = -1, bestBin = -1; Box bestL, bestR; bestL.reset(); bestR.reset();
+        for (int axis = 0; axis < 3; ++axis) {
+            float lo = cb.mn[axis], hi = cb.mx[axis];
+            if (!(hi > lo)) continue;
+            Box bins[NBINS]; uint32_t cnt[NBINS];
+            for (int i = 0; i < NBINS; ++i) { bins[i].reset(); cnt[i] = 0; }
+            const float scale = NBINS / (hi - lo);
+            for (const BuildTri &t : refs) {
+                int k = (int) ((t.c[axis] - lo) * scale); k = std::min(std::max(k, 0), NBINS - 1);
+                bins[k].grow(t.bmin, t.bmax); cnt[k]++;
+            }
+            Box rightBox[NBINS]; uint32_t rightCnt[NBINS];
+            Box acc; acc.reset(); uint32_t c = 0;
+            for (int i = NBINS - 1; i > 0; --i) { acc.grow(bins[i].mn, bins[i].mx); c += cnt[i]; rightBox[i] = acc; rightCnt[i] = c; }
+            acc.reset(); c = 0;
+            for (int i = 0; i < NBINS - 1; ++i) {
+                acc.grow(bins[i].mn, bins[i].mx); c += cnt[i];
+                if (c == 0 || rightCnt[i + 1] == 0) continue;
+                float cost = acc.area() * c + rightBox[i + 1].area() * rightCnt[i + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = i; bestL = acc; bestR = rightBox[i + 1]; }
+            }
+        }
+        /* spatial split, when the object split's children overlap enough */
+        float sCost = INFINITY; int sAxis = -1; float sPos = 0;
+        bool trySpatial = depth < 48 && nRefs + n / 2 < refBudget;
+        if (trySpatial && bestAxis >= 0) {
+            Box ov; for (int a = 0; a < 3; ++a) { ov.mn[a] = std::max(bestL.mn[a], bestR.mn[a]); ov.mx[a] = std::min(bestL.mx[a], bestR.mx[a]); }
+            trySpatial = ov.area() / rootArea > alpha;
+        }
+        if (trySpatial) {
+            for (int axis = 0; axis < 3; ++axis) {
+                const float lo = box.mn[axis], hi = box.mx[axis];
+                if (!(hi > lo)) continue;
+                Box bins[SBINS]; uint32_t enter[SBINS], leave[SBINS];
+                for (int i = 0; i < SBINS; ++i) { bins[i].reset(); enter[i] = leave[i] = 0; }
+                const double w = ((double) hi - lo) / SBINS;
+                for (const BuildTri &t : refs) {
+                    int b0 = (int) (((double) t.bmin[axis] - lo) / w), b1 = (int) (((double) t.bmax[axis] - lo) / w);
+                    b0 = std::min(std::max(b0, 0), SBINS - 1); b1 = std::min(std::max(b1, b0), SBINS - 1);
+                    Box rb; for (int a = 0; a < 3; ++a) { rb.mn[a] = t.bmin[a]; rb.mx[a] = t.bmax[a]; }
+                    if (b0 == b1) bins[b0].grow(rb.mn, rb.mx);
+                    else for (int b = b0; b <= b1; ++b) {
+                        Box cbx;
+                        if (clippedBounds(t.prim, axis, lo + b * w, lo + (b + 1) * w, rb, cbx)) bins[b].grow(cbx.mn, cbx.mx);
+                    }
+                    enter[b0]++; leave[b1]++;
+                }
+                float rightArea[SBINS]; uint32_t rightCnt[SBINS];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int i = SBINS - 1; i > 0; --i) { acc.grow(bins[i].mn, bins[i].mx); c += leave[i]; rightArea[i] = acc.area(); rightCnt[i] = c; }
+                acc.reset(); c = 0;
+                for (int i = 0; i < SBINS - 1; ++i) {
+                    acc.grow(bins[i].mn, bins[i].mx); c += enter[i];
+                    if (c == 0 || rightCnt[i + 1] == 0) continue;
+                    const float cost = acc.area() * c + rightArea[i + 1] * rightCnt[i + 1];
+                    if (cost < sCost) { sCost = cost; sAxis = axis; sPos = (float) (lo + (i + 1) * w); }
+                }
+            }
+        }
+        const float parentArea = box.area();
+        const float leafCost = C_ISECT * (float) n;
+        std::vector<BuildTri> L, R;
+        bool done = false;
+        if (sAxis >= 0 && sCost < bestCost) {
+            /* partition by the plane; straddlers are split or kept whole on one side */
+            Box lb, rb; lb.reset(); rb.reset();
+            std::vector<const BuildTri *> straddle;
+            for (const BuildTri &t : refs) {
+                if (t.bmax[sAxis] <= sPos) { L.push_back(t); lb.grow(t.bmin, t.bmax); }
+                else if (t.bmin[sAxis] >= sPos) { R.push_back(t); rb.grow(t.bmin, t.bmax); }
+                else straddle.push_back(&t);
+            }
+            size_t nl = L.size() + straddle.size(), nr = R.size() + straddle.size();
+            struct Piece { Box l, r; bool hasL, hasR; };
+            std::vector<Piece> pieces(straddle.size());
+            for (size_t i = 0; i < straddle.size(); ++i) {
+                const BuildTri &t = *straddle[i];
+                Box tb; for (int a = 0; a < 3; ++a) { tb.mn[a] = t.bmin[a]; tb.mx[a] = t.bmax[a]; }
+                pieces[i].hasL = clippedBounds(t.prim, sAxis, -INFINITY, sPos, tb, pieces[i].l);
+                pieces[i].hasR = clippedBounds(t.prim, sAxis, sPos, INFINITY, tb, pieces[i].r);
+                if (pieces[i].hasL) lb.grow(pieces[i].l.mn, pieces[i].l.mx);
+                if (pieces[i].hasR) rb.grow(pieces[i].r.mn, pieces[i].r.mx);
+            }
+            for (size_t i = 0; i < straddle.size(); ++i) {
+                const BuildTri &t = *straddle[i];
+                const Piece &pc = pieces[i];
+                if (!pc.hasL && !pc.hasR) { L.push_back(t); continue; }                 /* (numerically empty: keep it somewhere) */
+                if (!pc.hasR) { L.push_back(makeRef(pc.l, t.prim)); --nr; continue; }
+                if (!pc.hasL) { R.push_back(makeRef(pc.r, t.prim)); --nl; continue; }
+                Box lw = lb, rw = rb; lw.grow(t.bmin, t.bmax); rw.grow(t.bmin, t.bmax);
+                const float cSplit = lb.area() * nl + rb.area() * nr;
+                const float cLeft = lw.area() * nl + rb.area() * (nr - 1), cRight = lb.area() * (nl - 1) + rw.area() * nr;
+                if (cLeft < cSplit && cLeft <= cRight) { L.push_back(t); lb = lw; --nr; }
+                else if (cRight < cSplit) { R.push_back(t); rb = rw; --nl; }
+                else { L.push_back(makeRef(pc.l, t.prim)); R.push_back(makeRef(pc.r, t.prim)); }
+            }
+            if (!L.empty() && !R.empty() && L.size() < n && R.size() < n) { done = true; nRefs += L.size() + R.size() - n; }
+            else { L.clear(); R.clear(); }
+        }
+        if (!done) {
+            if (bestAxis < 0) {
+                if (n <= 8) return makeLeaf(refs.data(), refs.data() + n);
+                L.assign(refs.begin(), refs.begin() + n / 2); R.assign(refs.begin() + n / 2, refs.end());
+            } else {
+                const float splitCost = C_TRAV + C_ISECT * bestCost / (parentArea > 0 ? parentArea : 1.0f);
+                if (n <= (size_t) MAX_LEAF && splitCost >= leafCost) return makeLeaf(refs.data(), refs.data() + n);
+                const float lo = cb.mn[bestAxis], hi = cb.mx[bestAxis];
+                const float scale = NBINS / (hi - lo);
+                for (const BuildTri &t : refs) {
+                    int k = (int) ((t.c[bestAxis] - lo) * scale); k = std::min(std::max(k, 0), NBINS - 1);
+                    (k <= bestBin ? L : R).push_back(t);
+                }
+                if (L.empty() || R.empty()) { L.assign(refs.begin(), refs.begin() + n / 2); R.assign(refs.begin() + n / 2, refs.end()); }
+            }
+        } else if (n <= (size_t) MAX_LEAF) {
+            const float splitCost = C_TRAV + C_ISECT * sCost / (parentArea > 0 ? parentArea : 1.0f);
+            if (splitCost >= leafCost) { nRefs -= L.size() + R.size() - n; return makeLeaf(refs.data(), refs.data() + n); }
+        }
+        std::vector<BuildTri>().swap(refs);
+        const uint32_t idx = out.nNodes2++;
+        out.nodes2.resize((size_t) out.nNodes2 * 16);
+        Box lbx, rbx;
+        int32_t l = buildSpatial(L, lbx, depth + 1);
+        int32_t r = buildSpatial(R, rbx, depth + 1);
+        Box lp = lbx, rp = rbx; pad(lp); pad(rp);
         float *nd = &out.nodes2[(size_t) idx * 16];
         nd[0] = lp.mn[0]; nd[1] = lp.mn[1]; nd[2] = lp.mn[2]; nd[3] = lp.mx[0];
         nd[4] = lp.mx[1]; nd[5] = lp.mx[2]; nd[6] = rp.mn[0]; nd[7] = rp.mn[1];
@@ -412,7 +605,17 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
     }
     detail::Builder B(T, out, positions, indices);
     detail::Box rootBox;
-    const int32_t root2 = B.build(0, T.size(), rootBox, 1);
+    /* spatial splits for the scenes that use the wide tree (small scenes are laid out for LDS record by record) */
+    const char *sp = getenv("PHIP_BVH_SPATIAL");
+    B.spatial = sp ? atoi(sp) != 0 : nTris >= SPATIAL_MIN_TRIS;
+    int32_t root2;
+    if (B.spatial) {
+        B.rootArea = tight.area() > 0 ? tight.area() : 1.0;
+        B.nRefs = nTris; B.refBudget = (size_t) nTris + nTris / 2 + 64;      /* at most 1.5 references per triangle */
+        out.nodes2.reserve((size_t) nTris * 24); out.tris.reserve((size_t) nTris * 18);
+        root2 = B.buildSpatial(T, rootBox, 1);
+    } else
+        root2 = B.build(0, T.size(), rootBox, 1);
 
     /* ---- collapse to BVH4 ---- */
     typedef detail::ChildRef Child;

@@ -221,6 +221,13 @@ DV bool waldIntersect(const float4 &a, const float4 &b, const float4 &c, const V
     return u >= 0 && v >= 0 && u + v <= 1.0f;
 }
 
+/* Closest-hit bookkeeping.  Several triangles can report EXACTLY the same distance (a ray through a shared edge, coincident
+   surfaces), and the Wald test accepts t == maxt (triaccel.h:140: `t > maxt` rejects), so which of them a structure reports is
+   whichever it tests last -- in the reference that is a property of its kd-tree's leaf order.  To make the answer independent
+   of the structure (BVH4 / 8-wide tree, traversal order, spatial splits) the HIGHEST triangle index wins a tie: what a sweep
+   over all triangles in index order returns (oracle: set_bruteforce; tests/test_gpu_parity.py, C2 at full size). */
+DV bool winsTie(float tt, uint32_t prim, float bestT, uint32_t bestPrim) { return !(tt == bestT && prim < bestPrim); }
+
 /* std::lower_bound over cdf[0..n] + DiscreteDistribution::sample, pmf.h:124-136 */
 DV uint32_t cdfSample(const float *cdf, uint32_t nEntries, float sampleValue) {
     /* cdf has nEntries+1 values */

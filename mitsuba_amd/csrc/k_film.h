@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc
 
 /* copy per-sample radiance out in [y][x][sample] order (tests) */
 __global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot, int tilesX,
-                                 float4 *out, uint32_t sppTotal) {
+                                 float4 *out, uint32_t sppTotal, uint32_t sampleOffset /* phip_render_params::sample_offset: index of the call's first sample */) {
     const DevFilm &F = S.film;
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n = (size_t) F.width * F.height * rc.sppPass;
@@ -225,6 +225,6 @@ __global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, co
         const uint32_t m = spreadBits((uint32_t) (x - (tx << rc.tileShift))) | (spreadBits((uint32_t) (y - (ty << rc.tileShift))) << 1);
         v = L[(((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m];
     }
-    out[p * sppTotal + rc.sppFirst + k] = v;
+    out[p * sppTotal + (rc.sppFirst - sampleOffset) + k] = v;
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ void persistentTraverse(const DevScene &S, TravStack 
                     float tu, tv, tt;
                     if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
                         if (SHADOW) { res.prim = 0; finished = true; }
-                        else { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
+                        else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
                     }
                     cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
                 }
@@ -227,7 +227,7 @@ __device__ __forceinline__ void persistentTraverseMixed(const DevScene &S, TravS
                     float tu, tv, tt;
                     if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
                         if (shadow) { res.prim = 0; finished = true; }
-                        else { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
+                        else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
                     }
                     cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) stack.pop());
                 }

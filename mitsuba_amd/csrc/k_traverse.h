@@ -253,7 +253,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
             float tu, tv, tt;
             if (waldIntersect(a, b, c, o, d, mint, maxt, tu, tv, tt)) {
                 if (SHADOW) return true;
-                maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
+                if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
                 found = true;
             }
             cur = left ? (int32_t) ~(((idx + 1u) << 3) | (left - 1u)) : (stack.sp == 0 ? DONE_REF : (int32_t) (ALL_LDS ? stack.popLds() : stack.pop()));

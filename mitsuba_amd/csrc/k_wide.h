@@ -18,10 +18,19 @@
  * records (waldIntersect, dv_scene.h); boxes are conservative, so results do not depend on the structure.
  */
 
+#ifndef WIDE_STACK_LDS
 #define WIDE_STACK_LDS 12                /* 8-byte entries per lane in LDS (24 KB per block of 256) */
-#ifndef WIDE_NODE_CACHE_MAX
-#define WIDE_NODE_CACHE_MAX 96           /* top-of-tree nodes (BFS order) staged in LDS: 7.5 KB */
 #endif
+#ifndef WIDE_BLOCK
+#define WIDE_BLOCK 256                   /* threads per block of k_rays_w.  Measured (round 2): ONE block of 1024 per CU, whose LDS then holds a single copy of the
+                                            top 800 nodes (the first four levels) instead of four copies of 96, changes nothing -- C3 405.7 vs 406.3 Msamples/s,
+                                            C4 436 vs 438, and the same again with the cache cut back to 96, 300 or 585 nodes: the node fetches of the upper
+                                            levels are not what the kernel waits for (they hit L2; the Wald records come from the Infinity Cache) */
+#endif
+#ifndef WIDE_NODE_CACHE_MAX
+#define WIDE_NODE_CACHE_MAX 96           /* top-of-tree nodes (BFS order) staged in LDS by k_rays_w: 7.5 KB per block */
+#endif
+#define WIDE_NODE_CACHE_RAYCAST 96       /* ... by k_raycast_w (blocks of 256, several per CU) */
 #ifndef WIDE_TYPED
 #define WIDE_TYPED 1                     /* cached nodes are read with ds_read_b128 (LDS pipe) instead of flat_load (which sends LDS addresses through the
                                             texture addresser / data path the kernel is bound by: TD busy 95 %, round-2 counters) */
@@ -37,32 +46,37 @@ typedef __attribute__((address_space(3))) u2v lds_u2;
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u4v lds_cu4;
 
-struct WideStack {
-    lds_u2 *lds;            /* LDS base + threadIdx.x: entry e at lds[e * BLOCK] */
+template <int NB> struct WideStackT {
+    lds_u2 *lds;            /* LDS base + threadIdx.x: entry e at lds[e * NB] (NB = threads per block) */
     uint2 *spill;           /* global: SPILL_DEPTH / 2 entries per lane (the BVH4 kernels' region, reinterpreted) */
     lds_cu4 *nodes;         /* LDS copy of wide nodes [0, nodeCache) */
     uint32_t nodeCache;
     int sp;
     __device__ __forceinline__ void push(uint2 v) {
-        if (sp < WIDE_STACK_LDS) { u2v t; t.x = v.x; t.y = v.y; lds[sp * BLOCK] = t; } else spill[sp - WIDE_STACK_LDS] = v;
+        if (sp < WIDE_STACK_LDS) { u2v t; t.x = v.x; t.y = v.y; lds[sp * NB] = t; } else spill[sp - WIDE_STACK_LDS] = v;
         ++sp;
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
-        if (sp < WIDE_STACK_LDS) { const u2v t = lds[sp * BLOCK]; return make_uint2(t.x, t.y); }
+        if (sp < WIDE_STACK_LDS) { const u2v t = lds[sp * NB]; return make_uint2(t.x, t.y); }
         return spill[sp - WIDE_STACK_LDS];
     }
 };
 
-__host__ __device__ __forceinline__ size_t wideLdsBytes(uint32_t nodeCache) { return (size_t) WIDE_STACK_LDS * BLOCK * sizeof(uint2) + (size_t) nodeCache * 5 * sizeof(uint4); }
+typedef WideStackT<BLOCK> WideStack;
+
+__host__ __device__ __forceinline__ size_t wideLdsBytes(uint32_t nodeCache, uint32_t blockThreads) {
+    return (size_t) WIDE_STACK_LDS * blockThreads * sizeof(uint2) + (size_t) nodeCache * 5 * sizeof(uint4);
+}
+__host__ __device__ __forceinline__ uint32_t wideRaycastCache(uint32_t nodeCache) { return nodeCache < WIDE_NODE_CACHE_RAYCAST ? nodeCache : WIDE_NODE_CACHE_RAYCAST; }
 
 /* carve the block's dynamic LDS and stage the top of the tree (all threads of the block must call) */
-__device__ __forceinline__ void setupWide(const DevScene &S, unsigned char *smem, uint32_t *spill, WideStack &stk) {
+template <int NB> __device__ __forceinline__ void setupWide(const DevScene &S, uint32_t nodeCache, unsigned char *smem, uint32_t *spill, WideStackT<NB> &stk) {
     uint2 *stack = (uint2 *) smem;
-    uint4 *ln = (uint4 *) (smem + (size_t) WIDE_STACK_LDS * BLOCK * sizeof(uint2));
-    for (uint32_t i = threadIdx.x; i < S.wideNodeCache * 5u; i += BLOCK) ln[i] = S.wnodes[i];
+    uint4 *ln = (uint4 *) (smem + (size_t) WIDE_STACK_LDS * NB * sizeof(uint2));
+    for (uint32_t i = threadIdx.x; i < nodeCache * 5u; i += NB) ln[i] = S.wnodes[i];
     __syncthreads();
-    stk.lds = (lds_u2 *) (stack + threadIdx.x); stk.spill = (uint2 *) spill; stk.nodes = (lds_cu4 *) ln; stk.nodeCache = S.wideNodeCache; stk.sp = 0;
+    stk.lds = (lds_u2 *) (stack + threadIdx.x); stk.spill = (uint2 *) spill; stk.nodes = (lds_cu4 *) ln; stk.nodeCache = nodeCache; stk.sp = 0;
 }
 
 struct WideRay {
@@ -183,7 +197,7 @@ __device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, con
             float tu, tv, tt;
             if (waldIntersect(a, b, c, o, d, ray.mint, ray.maxt, tu, tv, tt)) {
                 if (SHADOW) return true;
-                ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z);
+                if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
                 found = true;
             }
         }
@@ -277,7 +291,7 @@ struct ShadowSourceDyn {
 
 /* ---- persistent waves with refill: closest-hit AND any-hit rays of one iteration in ONE launch (as k_rays_p) ---- */
 template <typename ShadowSrc, typename TraceSrc>
-__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStack &stack, ShadowSrc &ss, TraceSrc &ts,
+__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStackT<WIDE_BLOCK> &stack, ShadowSrc &ss, TraceSrc &ts,
                                                        uint32_t *wc /* LDS: WC_COUNT counters of this wave */) {
     bool active = false, shadow = false;
     uint32_t handle = INVALID_RAY;
@@ -325,7 +339,7 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                     float tu, tv, tt;
                     if (waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {
                         if (shadow) { res.prim = 0; finished = true; }
-                        else { ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
+                        else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
                     }
                 }
                 if (!finished && tg.y == 0u && !(ng.y & 0xff000000u)) {
@@ -349,11 +363,11 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
     }
 }
 
-__global__ __launch_bounds__(BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L, unsigned int *drawCounters /* 2 * RAY_SHARDS lines, zeroed; NULL: static deal */) {
-    __shared__ uint32_t wcnt[BLOCK / 64][WC_COUNT];
-    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    if (threadIdx.x < (BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
-    WideStack stk; setupWide(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
+__global__ __launch_bounds__(WIDE_BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L, unsigned int *drawCounters /* 2 * RAY_SHARDS lines, zeroed; NULL: static deal */) {
+    __shared__ uint32_t wcnt[WIDE_BLOCK / 64][WC_COUNT];
+    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * WIDE_BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (WIDE_BLOCK / 64);
+    if (threadIdx.x < (WIDE_BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
+    WideStackT<WIDE_BLOCK> stk; setupWide<WIDE_BLOCK>(S, S.wideNodeCache, g_smem, P.spill + (size_t) (blockIdx.x * WIDE_BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
     if (drawCounters) {
         const uint32_t nBlk = P.capacity / BLOCK, nChunk = (P.capacity + 63u) / 64u;
         ShadowSourceDyn ss{ P, L, { drawCounters, blockIdx.x % RAY_SHARDS, 0u, (nBlk + RAY_SHARDS - 1) / RAY_SHARDS, nBlk }, 0u, 0u, 0u };
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPo
 /* standalone ray casts for phip_trace on the wide tree */
 __global__ __launch_bounds__(BLOCK) void k_raycast_w(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
     const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
-    WideStack stk; setupWide(S, g_smem, P.spill + i * SPILL_DEPTH, stk);
+    WideStack stk; setupWide<BLOCK>(S, wideRaycastCache(S.wideNodeCache), g_smem, P.spill + i * SPILL_DEPTH, stk);
     uint32_t nodeVisits = 0, triTests = 0, shNodeVisits = 0, shTriTests = 0;
     if (i < n) {
         const phip_ray ry = rays[i];

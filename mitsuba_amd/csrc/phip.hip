@@ -632,7 +632,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (sc->wide) {
         D.nodeCache = 0; D.triCache = 0;
         D.wideNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, WIDE_NODE_CACHE_MAX);
-        if (const char *e = getenv("PHIP_NODE_CACHE")) D.wideNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, (uint32_t) atoi(e));
+        if (const char *e = getenv("PHIP_NODE_CACHE")) D.wideNodeCache = std::min<uint32_t>(D.wideNodeCache, (uint32_t) atoi(e));
         if ((int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS + SPILL_DEPTH / 2) throw std::runtime_error("wide BVH too deep for the traversal stack");
     }
     for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
@@ -701,8 +701,8 @@ static void phipLaunchShadeDirect(int feat, int materialMask, dim3 grid, hipStre
     }
 }
 
-static size_t traversalLdsBytes(const DevScene &D) {
-    if (D.wideNodeCache) return wideLdsBytes(D.wideNodeCache);
+static size_t traversalLdsBytes(const DevScene &D) {               /* kernels launched with blocks of BLOCK threads */
+    if (D.wideNodeCache) return wideLdsBytes(wideRaycastCache(D.wideNodeCache), BLOCK);
     return traversalLdsBytesOf(D);
 }
 
@@ -749,8 +749,8 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
     if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
     if (p->sample_offset < 0 || p->sample_total < 0) throw std::invalid_argument("sample_offset / sample_total must not be negative");
     if (p->sample_total != 0 && (long long) p->sample_offset + p->spp > p->sample_total) throw std::invalid_argument("sample_offset + spp exceeds sample_total");
-    if ((p->flags & PHIP_FLAG_SAMPLE_BUFFER) && (p->sample_offset != 0 || (p->flags & PHIP_FLAG_ACCUMULATE)))
-        throw std::invalid_argument("PHIP_FLAG_SAMPLE_BUFFER needs a complete render (sample_offset 0, no PHIP_FLAG_ACCUMULATE)");
+    if ((p->flags & PHIP_FLAG_SAMPLE_BUFFER) && (p->flags & PHIP_FLAG_ACCUMULATE))
+        throw std::invalid_argument("PHIP_FLAG_SAMPLE_BUFFER holds the samples of one call: not with PHIP_FLAG_ACCUMULATE");
     if (sc->devs[0]->dev.env.w > 0 && sc->envLevelCount <= 1 && !p->hide_emitters && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND))
         throw std::invalid_argument("envmap without MIP levels: directly visible background needs the filtered (EWA) lookup of envmap.cpp:395-407: "
                                     "pass the pyramid, render with hideEmitters or set PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND");
@@ -850,11 +850,12 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
         capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
         if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
-        nWaves = capacity / 64; nBlocks = capacity / BLOCK;
+        const size_t laneCap = ((size_t) capacity + WIDE_BLOCK - 1) / WIDE_BLOCK * WIDE_BLOCK;      /* k_rays_w runs whole blocks of WIDE_BLOCK lanes */
+        nWaves = (uint32_t) (laneCap / 64); nBlocks = capacity / BLOCK;
         if (sd.rayO.n < capacity) {
             sd.rayO.alloc(capacity); sd.rayD.alloc(capacity); sd.hit.alloc(capacity); sd.thr.alloc(capacity);
             sd.mis.alloc(capacity); sd.info.alloc(capacity); sd.state.alloc(capacity); sd.shadow.alloc(3 * (size_t) capacity);
-            sd.shadowCount.alloc(nBlocks); sd.blockDead.alloc(nBlocks); sd.blockShard.alloc(nBlocks); sd.spill.alloc((size_t) capacity * SPILL_DEPTH);
+            sd.shadowCount.alloc(nBlocks); sd.blockDead.alloc(nBlocks); sd.blockShard.alloc(nBlocks); sd.spill.alloc(laneCap * SPILL_DEPTH);
         }
         if (sd.stat.n < (size_t) ST_COUNT * nWaves) sd.stat.alloc((size_t) ST_COUNT * nWaves);
         if (direct && sd.camHit.n < capacity) sd.camHit.alloc(capacity);
@@ -886,7 +887,17 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     const dim3 grid((capacity + BLOCK - 1) / BLOCK);
     const dim3 pgrid = persistentGrid((const void *) k_shadow_p, TRACE_WAVES);
     const dim3 pgridTrace = persistentGrid(sc->bvh.nNodes >= 64 ? (const void *) k_trace_p<false> : (const void *) k_trace_p<true>, TRACE_P_WAVES);
-    const dim3 pgridRays = sc->wide ? persistentGrid((const void *) k_rays_w, WIDE_WAVES) : persistentGrid((const void *) k_rays_p, RAYS_WAVES);
+    /* k_rays_w: blocks of WIDE_BLOCK threads with their own LDS plan (one block per CU holds 800 nodes of the tree) */
+    const size_t wideLds = sc->wide ? wideLdsBytes(D.wideNodeCache, WIDE_BLOCK) : 0;
+    dim3 pgridRays = persistentGrid((const void *) k_rays_p, RAYS_WAVES);
+    if (sc->wide) {
+        if (wideLds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) k_rays_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int) wideLds));
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *) k_rays_w, WIDE_BLOCK, wideLds) != hipSuccess || n <= 0) n = 1;
+        n = std::min(n, WIDE_WAVES * 256 / WIDE_BLOCK);
+        if (n <= 0) n = 1;
+        pgridRays = dim3((unsigned) std::max(1, std::min<int>(nCU * n, (int) ((capacity + WIDE_BLOCK - 1) / WIDE_BLOCK))));
+    }
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
     bool dynamicDeal = true;                                             /* k_rays_w draws its chunks from sharded counters */
     if (const char *e = getenv("PHIP_RAYS_STATIC")) dynamicDeal = atoi(e) == 0;
@@ -982,7 +993,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                             HIP_TRY(hipMemsetAsync(sd.drawCounters.p, 0, 2 * RAY_SHARDS * RAY_SHARD_STRIDE * sizeof(unsigned int), stream));
                             dc = sd.drawCounters.p;
                         }
-                        hipLaunchKernelGGL(k_rays_w, pgridRays, block, ldsBytes, stream, D, P, sd.L.p, dc);
+                        hipLaunchKernelGGL(k_rays_w, pgridRays, dim3(WIDE_BLOCK), wideLds, stream, D, P, sd.L.p, dc);
                     }
                     else hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
                     if (timing) evTrace.record(stream);
@@ -1042,7 +1053,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         if (keepSamples && rc.totalIds) {
             const size_t n = (size_t) W * H * rc.sppPass;
             hipLaunchKernelGGL(k_export_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, D, rc, (const float4 *) sd.L.p,
-                               (const int32_t *) sd.tileSlot.p, tilesX, sd.sampleOut.p, (uint32_t) p->spp);
+                               (const int32_t *) sd.tileSlot.p, tilesX, sd.sampleOut.p, (uint32_t) p->spp, (uint32_t) p->sample_offset);
         }
         HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), stream));
         hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, stream, P, sd.counters.p, 0);

@@ -155,7 +155,7 @@ int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, cons
             if (ok && !use_wide) {
                 for (size_t k = 0; k < nRecs; ++k) {
                     float tu, tv, tt;
-                    if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, mint, maxt, tu, tv, tt)) { maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
+                    if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, mint, maxt, tu, tv, tt) && winsTie(tt, pm_to_bits(recs[3 * k + 2].z), h.t, h.prim)) { maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
                 }
             } else if (ok) {
                 WideRay ray; wideRaySetup(ray, o, d, V3(slabRcp(d.x), slabRcp(d.y), slabRcp(d.z)), mint, maxt);
@@ -184,7 +184,7 @@ int phip_debug_host_trace_wide(const float *positions, uint32_t n_vertices, cons
                         if (k >= nRecs) throw std::runtime_error("wide BVH: triangle index out of range");
                         note(2);
                         float tu, tv, tt;
-                        if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, ray.mint, ray.maxt, tu, tv, tt)) { ray.maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
+                        if (waldIntersect(recs[3 * k], recs[3 * k + 1], recs[3 * k + 2], o, d, ray.mint, ray.maxt, tu, tv, tt) && winsTie(tt, pm_to_bits(recs[3 * k + 2].z), h.t, h.prim)) { ray.maxt = tt; h.t = tt; h.u = tu; h.v = tv; h.prim = pm_to_bits(recs[3 * k + 2].z); }
                     }
                     if (tg.y == 0u && !(ng.y & 0xff000000u)) {
                         if (stack.empty()) break;

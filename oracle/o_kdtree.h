@@ -223,6 +223,22 @@ public:
     uint32_t stopPrims = 6, maxBadRefines = 3, exactPrimThreshold = 65536, minMaxBinCount = 128;
     uint32_t maxDepth = 0;
     bool clip = true, retract = true;
+    /* test hook (oracle_scene_set_bruteforce): answer ray queries by testing EVERY TriAccel inside the clipped ray interval -- the
+       structure-independent answer.  The reference's kd-tree loses a hit that lies exactly on a triangle's silhouette edge when
+       that edge is a split plane and the Wald distance comes out an ulp beyond the leaf's exit distance (sahkdtree3.h:263-272
+       tests against [searchStart, searchEnd] of the leaf); a BVH finds it.  Rate: ~2e-8 per sample on the Cornell box. */
+    bool bruteForce = false;
+    template <bool shadowRay> bool sweep(const Ray &ray, Float mint, Float maxt, Float &t, Float &uOut, Float &vOut, uint32_t &primOut) const {
+        bool found = false;
+        for (uint32_t p = 0; p < primCount; ++p) {
+            Float u, v, tt;
+            if (triAccel[p].rayIntersect(ray, mint, maxt, u, v, tt)) {
+                if (shadowRay) return true;
+                maxt = tt; t = tt; uOut = u; vOut = v; primOut = p; found = true;
+            }
+        }
+        return found;
+    }
 
     std::vector<KDNode> nodes;
     std::vector<uint32_t> indices;
@@ -254,7 +270,7 @@ public:
             if (rayMinT > mint) mint = rayMinT;
             if (ray.maxt < maxt) maxt = ray.maxt;
             if (maxt > mint)
-                return havran<false>(ray, mint, maxt, t, u, v, prim, ctr);
+                return bruteForce ? sweep<false>(ray, mint, maxt, t, u, v, prim) : havran<false>(ray, mint, maxt, t, u, v, prim, ctr);
         }
         return false;
     }
@@ -269,7 +285,7 @@ public:
             if (rayMinT > mint) mint = rayMinT;
             if (ray.maxt < maxt) maxt = ray.maxt;
             if (maxt > mint)
-                if (havran<true>(ray, mint, maxt, t, u, v, prim, ctr))
+                if (bruteForce ? sweep<true>(ray, mint, maxt, t, u, v, prim) : havran<true>(ray, mint, maxt, t, u, v, prim, ctr))
                     return true;
         }
         return false;

@@ -7,6 +7,7 @@
  * outside the path's scope.
  */
 #pragma once
+#include <cstdio>
 #include "o_bsdf.h"
 
 namespace orc {
@@ -57,6 +58,9 @@ inline Spectrum pathLi(const Scene &scene, const IntegratorParams &ip, const Ray
             Scene::computePartials(its, ray.o, *rxDirection, *ryDirection);
         bsdfs.its = &its;
         if (pc && bsdf.smooth && depth <= 32) pc->smoothMask |= 1u << (depth - 1);
+        if (pc && pc->verbose)
+            fprintf(stderr, "  vertex %d: prim %u t %.9g (%08x) p (%.9g %.9g %.9g) Li (%.9g %.9g %.9g) thr (%.9g %.9g %.9g) shadow rays so far %llu\n", depth, its.primIndex, its.t,
+                    (unsigned) *(const uint32_t *) &its.t, its.p.x, its.p.y, its.p.z, Li[0], Li[1], Li[2], throughput[0], throughput[1], throughput[2], (unsigned long long) pc->shadowRays);
 
         if (scene.isEmitter(its) && emittedRadiance && (!ip.hideEmitters || scattered))
             Li += throughput * scene.Le(its, -ray.d);

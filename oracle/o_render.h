@@ -230,6 +230,7 @@ struct RenderParams {
     DirectParams dp;
     bool ctr = true; uint32_t seed = 0;
     int shardIndex = 0, shardCount = 1;
+    int sampleOffset = 0, sampleTotal = 0;   /* phip_render_params::sample_offset / sample_total: this call renders samples [offset, offset + spp) of sampleTotal */
 };
 
 struct RenderResult {
@@ -262,7 +263,7 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
     std::vector<SFMT> workerRng;
     if (!rp.ctr) { workerRng.resize(nThreads); for (int i = 0; i < nThreads; ++i) workerRng[i].seedFrom(parent); }
 
-    const Float diffScaleFactor = 1.0f / std::sqrt((Float) rp.spp);      /* integrator.cpp:144-145 */
+    const Float diffScaleFactor = 1.0f / std::sqrt((Float) (rp.sampleTotal > 0 ? rp.sampleTotal : rp.spp));      /* integrator.cpp:144-145 */
     auto t0 = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
         PathCounters &pc = counters[tid];
@@ -280,7 +281,7 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
                 smp.pixel = (uint32_t) (py * f.crop_width + px);
                 if (rp.direct) smp.generateDirectArrays((size_t) rp.spp, rp.dp.emitterSamples, rp.dp.bsdfSamples);   /* sampler->generate(offset), integrator.cpp:164 */
                 for (int j = 0; j < rp.spp; ++j) {
-                    smp.sample = (uint32_t) j;
+                    smp.sample = (uint32_t) (j + rp.sampleOffset);
                     Vec2 jit = smp.cameraSample();
                     Vec2 samplePos((Float) px + jit.x, (Float) py + jit.y);   /* integrator.cpp:171 */
                     Vec3 rx, ry;

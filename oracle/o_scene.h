@@ -16,6 +16,7 @@
  */
 #pragma once
 #include <functional>
+#include <cstdio>
 #include "o_kdtree.h"
 #include "o_sfmt.h"
 #include "o_envmap.h"
@@ -203,6 +204,7 @@ struct SampleSource {
 struct PathCounters {
     uint64_t closestRays = 0, shadowRays = 0, pathVertices = 0, samples = 0, invalidSamples = 0;
     uint32_t smoothMask = 0;     /* of the sample being evaluated: bit d-1 = the BSDF at path vertex d has a smooth component (d <= 32) */
+    bool verbose = false;        /* oracle_path_sample: print every vertex of the path to stderr */
     TraversalCounters closest, shadow;
     void add(const PathCounters &o) {
         closestRays += o.closestRays; shadowRays += o.shadowRays; pathVertices += o.pathVertices;
@@ -674,9 +676,14 @@ textures.resize(d.n_textures);
         Spectrum value = em.type == PHIP_EMITTER_CONSTANT ? constantSampleDirect(em, dRec, sample)
                        : em.type == PHIP_EMITTER_ENVMAP ? envmapSampleDirect(dRec, sample)
                                                         : areaSampleDirect(em, dRec, sample);
+        if (pc && pc->verbose)
+            fprintf(stderr, "    NEE: emitter %zu pdf %.9g value (%.9g %.9g %.9g) point (%.9g %.9g %.9g) d (%.9g %.9g %.9g) dist %.9g\n", index, dRec.pdf, value[0], value[1], value[2],
+                    dRec.p.x, dRec.p.y, dRec.p.z, dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist);
         if (dRec.pdf != 0) {
             Ray ray(dRec.ref, dRec.d, ORC_EPSILON, dRec.dist * (1 - ORC_SHADOW_EPSILON));
-            if (rayIntersectShadow(ray, pc))
+            const bool occ = rayIntersectShadow(ray, pc);
+            if (pc && pc->verbose) fprintf(stderr, "    NEE: shadow ray %s\n", occ ? "OCCLUDED" : "free");
+            if (occ)
                 return Spectrum(0.0f);
             dRec.emitter = (int) index;
             dRec.pdf *= emPdf;

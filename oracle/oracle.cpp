@@ -44,6 +44,8 @@ void *oracle_scene_create(const phip_scene_desc *desc) {
 }
 
 void oracle_scene_destroy(void *scene) { delete static_cast<Scene *>(scene); }
+/* test hook: ray queries by a sweep over every triangle instead of the kd-tree (o_kdtree.h: bruteForce) */
+void oracle_scene_set_bruteforce(void *scene, int on) { static_cast<Scene *>(scene)->kdtree.bruteForce = on != 0; }
 
 /* sampler_mode: 0 = ctr parity stream, 1 = per-worker SFMT19937 streams like `independent` */
 int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
@@ -62,6 +64,7 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
         rp.ip.strictNormals = p->strict_normals != 0; rp.ip.hideEmitters = p->hide_emitters != 0;
         rp.ctr = sampler_mode == 0; rp.seed = p->seed;
         rp.shardIndex = p->shard_index; rp.shardCount = p->shard_count > 0 ? p->shard_count : 1;
+        rp.sampleOffset = p->sample_offset; rp.sampleTotal = p->sample_total;
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
         if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::runtime_error("unknown integrator");
         if (rp.direct) {
@@ -123,6 +126,29 @@ int oracle_trace(void *scene_, const phip_ray *rays, size_t n, phip_hit *hits, u
         stats->closest_triangle_tests = c.triTests; stats->shadow_triangle_tests = cs.triTests;
     }
     return 0;
+}
+
+/* one sample of the path tracer with the keys of the full frame (debugging aid of tools/fullsize_sample_diff.py) */
+int oracle_path_sample(void *scene_, const phip_render_params *p, int px, int py, int k, float *out4, int verbose) {
+    try {
+        const Scene &scene = *static_cast<Scene *>(scene_);
+        const phip_film &f = scene.film;
+        PerspectiveCamera cam; cam.configure(scene.camera, f);
+        IntegratorParams ip; ip.maxDepth = p->max_depth; ip.rrDepth = p->rr_depth; ip.strictNormals = p->strict_normals != 0; ip.hideEmitters = p->hide_emitters != 0;
+        SampleSource smp; smp.ctr = true; smp.seed = p->seed; smp.rng = nullptr;
+        smp.pixel = (uint32_t) (py * f.crop_width + px); smp.sample = (uint32_t) k;
+        const Float diffScaleFactor = 1.0f / std::sqrt((Float) (p->sample_total > 0 ? p->sample_total : p->spp));
+        Vec2 jit = smp.cameraSample();
+        Vec2 samplePos((Float) px + jit.x, (Float) py + jit.y);
+        Vec3 rx, ry;
+        Ray ray = cam.sampleRay(samplePos, &rx, &ry);
+        rx = ray.d + (rx - ray.d) * diffScaleFactor; ry = ray.d + (ry - ray.d) * diffScaleFactor;
+        PathCounters pc; pc.verbose = verbose != 0;
+        Float alpha;
+        Spectrum spec = pathLi(scene, ip, ray, smp, alpha, &pc, &rx, &ry);
+        out4[0] = spec[0]; out4[1] = spec[1]; out4[2] = spec[2]; out4[3] = alpha;
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
 /* brute-force closest hit over every TriAccel: the structure-independent answer */

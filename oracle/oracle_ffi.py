@@ -45,6 +45,8 @@ def lib(libm=False):
     L.oracle_trace.argtypes = [C.c_void_p, C.POINTER(A.phip_ray), C.c_size_t, C.POINTER(A.phip_hit), u8p, C.POINTER(A.phip_stats)]
     L.oracle_trace_bruteforce.argtypes = [C.c_void_p, C.POINTER(A.phip_ray), C.c_size_t, C.POINTER(A.phip_hit)]
     L.oracle_gaussian_filter.argtypes = [C.c_float, fp, fp]
+    L.oracle_scene_set_bruteforce.argtypes = [C.c_void_p, C.c_int]; L.oracle_scene_set_bruteforce.restype = None
+    L.oracle_path_sample.argtypes = [C.c_void_p, C.POINTER(A.phip_render_params), C.c_int, C.c_int, C.c_int, fp, C.c_int]
     L.oracle_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.POINTER(A.phip_ray)]
     L.oracle_sfmt_words.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64)]
     L.oracle_sfmt_floats.argtypes = [C.c_uint64, C.c_int, C.c_size_t, fp]
@@ -142,6 +144,17 @@ class OracleScene:
         k = KdInfo()
         self.L.oracle_kd_info_get(self.h, C.byref(k))
         return k
+
+    def set_bruteforce(self, on=True):
+        """ray queries by a sweep over every triangle (the structure-independent answer) instead of the reference's kd-tree"""
+        self.L.oracle_scene_set_bruteforce(self.h, 1 if on else 0)
+
+    def path_sample(self, params, px, py, k, verbose=False):
+        """(R, G, B, alpha) of ONE sample of the path tracer with the stream keys of the full frame"""
+        out = np.zeros(4, np.float32)
+        if self.L.oracle_path_sample(self.h, C.byref(params), px, py, k, _fp(out), 1 if verbose else 0) != 0:
+            raise RuntimeError("oracle_path_sample: " + self.L.oracle_last_error().decode())
+        return out
 
     def camera_ray(self, sx, sy):
         r = A.phip_ray()

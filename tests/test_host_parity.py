@@ -87,13 +87,17 @@ def test_ctr_stream_bitwise_and_well_distributed(oracle, phip):
 
 
 def test_bvh_build_covers_every_triangle_and_scene_box_matches_kdtree(oracle, phip, gauss):
-    """host BVH build (no GPU): every non-degenerate triangle referenced exactly once; the enlarged scene
-    box equals the kd-tree root box of the oracle (gkdtree.h:1213-1220 arithmetic)"""
+    """host BVH build (no GPU): every non-degenerate triangle referenced exactly once (scenes of 4096 triangles or more are built with
+    spatial splits, bvh.h: at most 1.5 references per triangle); the enlarged scene box equals the kd-tree root box of the oracle
+    (gkdtree.h:1213-1220 arithmetic)"""
     for sb in [S.cornell_box(16, 16, gauss), S.atrium(16, 16, gauss, detail=0.25), S.glass_room(16, 16, gauss, detail=0.3)]:
         d = sb.desc()
         info = A.phip_accel_info(); box = np.zeros(6, np.float32)
         assert phip.phip_debug_host_build_bvh(d.positions, d.n_vertices, d.indices, d.n_triangles, C.byref(info), fp(box)) == 0
-        assert info.n_triangle_refs == d.n_triangles            # no duplication (BVH, not kd-tree), no degenerate input
+        if d.n_triangles < 4096:
+            assert info.n_triangle_refs == d.n_triangles        # no duplication, no degenerate input
+        else:
+            assert d.n_triangles <= info.n_triangle_refs <= 1.5 * d.n_triangles + 64
         assert info.n_leaves >= d.n_triangles / 8 and info.max_depth < 40
         k = oracle.OracleScene(d).kd_info()
         assert (box[:3].view(np.uint32) == np.array(list(k.aabb_min), np.float32).view(np.uint32)).all()

@@ -368,3 +368,18 @@ def test_film_weights_and_filter_table(oracle, phip, gauss):
     film = sc.render(A.default_render_params(spp=64, max_depth=2))[0]
     w = film[4:-4, 4:-4, 4]
     assert abs(w.mean() / 64 - 1.0) < 0.05
+
+
+def test_sweep_mode_equals_the_kd_tree_on_ordinary_rays(oracle, gauss):
+    """the oracle's test hook that answers ray queries by testing every triangle (o_kdtree.h: bruteForce) renders the same bits as
+    the kd-tree restatement wherever no ray grazes a split plane (tests/test_ref_pin.py pins the one place it does not)"""
+    for desc, spp, md in ((S.cornell_box(64, 64, gauss).desc(), 16, -1), (S.glass_room(32, 18, gauss, detail=0.1).desc(), 4, 8)):
+        sc = oracle.OracleScene(desc)
+        p = A.default_render_params(spp=spp, max_depth=md)
+        f0, s0, st0 = sc.render(p, want_samples=True)
+        sc.set_bruteforce(True)
+        f1, s1, st1 = sc.render(p, want_samples=True)
+        same = (s0.view(np.uint32) == s1.view(np.uint32)).all(-1)
+        assert same.mean() > 0.9999, same.mean()
+        assert st0.samples == st1.samples
+        sc.close()

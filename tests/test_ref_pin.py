@@ -222,3 +222,40 @@ def test_reference_with_correctly_rounded_libm_is_bit_identical_to_the_parity_bu
     for x in rows:
         assert "libcrm" in x["preload"]
         assert x["differing_samples"] == 0 and x["film_rel_l2"] == 0.0, x
+
+
+def test_kd_tree_loses_a_silhouette_edge_hit_that_a_bvh_finds(ref, oracle, phip):
+    """The one structural difference between the reference and path_hip, found by rendering BASELINE's C2 at full size
+    (tests/test_gpu_parity.py::test_c2_at_full_size_against_the_oracle): camera sample 110 of pixel (602, 127) of the 1024x1024
+    Cornell box passes through the edge x = 213 of the area light.  Every triangle test (TriAccel, bit-identical in all four
+    implementations) accepts the hit on the light (v == 0 exactly), but x = 213 is also a split plane of the SAH kd-tree and the
+    Wald distance comes out beyond the leaf's exit distance (sahkdtree3.h:263-272 intersects within [searchStart, searchEnd]),
+    so Mitsuba's kd-tree -- and the oracle's restatement of it, bit for bit -- reports the ceiling behind it.  A BVH has no cell
+    boundaries to lose a hit at: path_hip returns the structure-independent answer (the sweep over every triangle).  About five
+    of C2's 268 M camera samples are affected (image rel. L2 3e-5)."""
+    import ctypes as C
+    gauss = oracle.gaussian_filter(0.5)
+    desc = S.cornell_box(1024, 1024, gauss).desc()
+    osc = oracle.OracleScene(desc)
+    rs = ref.RefScene(desc)
+    jit = np.zeros(4, np.float32)
+    oracle.lib().oracle_ctr_block(127 * 1024 + 602, 110, 0, 0, jit.ctypes.data_as(C.POINTER(C.c_float)))
+    ray = osc.camera_ray(np.float32(602) + jit[0], np.float32(127) + jit[1])
+    assert np.array_equal(ray[[0, 1, 2, 4, 5, 6]], rs.camera_ray(np.float32(602) + jit[0], np.float32(127) + jit[1])[[0, 1, 2, 3, 4, 5]])
+    rays = ray[None]
+    kd, _, _ = osc.trace(rays, True, False)
+    rt = rs.trace(rays)[0]
+    assert rt[0] == kd[0, 0] and int(kd[0].view(np.uint32)[3]) == 3 and int(rt[3]) == 1      # Mitsuba and the oracle: the ceiling (shape 1, triangle 3)
+    bf, _, _ = osc.trace(rays, True, False, bruteforce=True)
+    assert int(bf[0].view(np.uint32)[3]) == 11 and bf[0, 2] == 0.0 and bf[0, 0] < kd[0, 0]   # every TriAccel: the light, on its edge (v == 0), in front
+    P = np.ctypeslib.as_array(desc.positions, shape=(desc.n_vertices, 3)).copy()
+    T = np.ctypeslib.as_array(desc.indices, shape=(desc.n_triangles, 3)).copy()
+    hit = np.zeros((1, 4), np.float32)
+    fpp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rc = phip.phip_debug_host_trace_wide(fpp(P), len(P), T.ctypes.data_as(C.POINTER(C.c_uint32)), len(T), rays.ctypes.data_as(C.POINTER(A.phip_ray)), 1,
+                                         hit.ctypes.data_as(C.POINTER(A.phip_hit)), 0, None, None, 0)
+    assert rc == 0
+    assert np.array_equal(hit.view(np.uint32), bf.view(np.uint32))                            # the BVH the GPU kernels walk: the sweep's answer, bit for bit
+    hitp = ray[:3] + ray[4:7] * bf[0, 0]
+    assert abs(hitp[0] - 213.0) < 1e-3 and abs(hitp[1] - 548.7) < 1e-3
+    rs.close(); osc.close()

@@ -48,13 +48,12 @@ def test_wide_tree_equals_brute_force_on_triangle_soups(phip, n, size, extent):
     rays = rays_through(rng, 3000, -extent, extent, axis_aligned=0.2)
     w, info = host_trace(phip, P, T, rays, 1)
     b, _ = host_trace(phip, P, T, rays, 0)
-    assert info.n_nodes > 1 and info.node_bytes == 80 and info.n_triangle_refs == n
+    assert info.n_nodes > 1 and info.node_bytes == 80
+    assert info.n_triangle_refs == n if n < 4096 else n <= info.n_triangle_refs <= 1.5 * n + 64      # spatial splits (bvh.h) duplicate references from 4096 triangles on
     hit = b[:, 3].view(np.uint32) != A.PHIP_NO_HIT
     assert 0.05 < hit.mean() <= 1.0
-    # structure-independent answer: (t, u, v, prim) bit for bit, exact-t ties (a ray through a shared vertex) aside
-    same = (w.view(np.uint32) == b.view(np.uint32)).all(axis=1)
-    assert same.mean() >= 0.9995, same.mean()
-    assert (w[:, 0].view(np.uint32) == b[:, 0].view(np.uint32)).mean() >= 0.9999          # the distance always agrees
+    # structure-independent answer: (t, u, v, prim) bit for bit -- exact-t ties included (the highest triangle index wins, dv_scene.h: winsTie)
+    assert (w.view(np.uint32) == b.view(np.uint32)).all()
 
 
 def test_wide_tree_on_the_atrium_against_the_oracle_kd_tree(phip, oracle, gauss):
@@ -72,10 +71,15 @@ def test_wide_tree_on_the_atrium_against_the_oracle_kd_tree(phip, oracle, gauss)
     oh, _, _ = osc.trace(rays, True, False)
     assert (oh[:, 3].view(np.uint32) != A.PHIP_NO_HIT).mean() > 0.9
     # the atrium has coincident coplanar surfaces (wall panels on the room shell): rays that hit both at the same t report
-    # whichever the structure tests last -- the distance is the same bit for bit, the primitive may differ
+    # whichever the kd-tree tests last -- the distance is the same bit for bit, the primitive may differ ...
     same = (w.view(np.uint32) == oh.view(np.uint32)).all(axis=1)
     assert same.mean() >= 0.995, same.mean()
     assert (w[:, 0].view(np.uint32) == oh[:, 0].view(np.uint32)).all()
+    # ... while the 8-wide tree (built with spatial splits here) returns the structure-independent answer: what a sweep over every
+    # triangle in index order finds, ties included
+    osc.set_bruteforce(True)                                   # (the kd-tree's ray-interval clipping and adaptive epsilon, then the sweep)
+    ob, _, _ = osc.trace(rays, True, False)
+    assert (w.view(np.uint32) == ob.view(np.uint32)).all()
 
 
 def test_degenerate_inputs(phip):
