@@ -49,6 +49,14 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
     p = integ.params(gs, spp)           # the same phip_render_params the GPU call received (minus the sample-buffer flag)
     ofilm, osmp, ost = osc.render(p, want_samples=True)
     same = (gsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1)
+    if desc.n_triangles <= 512 and not same.all():
+        # the oracle's kd-tree (= the reference's) and a BVH may disagree on a ray through an edge: an exact-distance tie decided by
+        # the kd-tree's leaf order, or a silhouette hit lost at a split plane (~1e-7 of the samples).  path_hip returns
+        # the structure-independent answer, so the bar applies against the oracle answering ray queries by a sweep over all triangles
+        assert same.mean() >= min(min_identical, 0.9999), "only %.5f%% of the samples are bit-identical to the kd-tree oracle" % (100 * same.mean())
+        osc.set_bruteforce(True)
+        ofilm, osmp, ost = osc.render(p, want_samples=True)
+        same = (gsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1)
     g, o = film.develop(), oracle.develop(ofilm)
     r = rel_l2(g, o) if np.abs(o).max() > 0 else float(np.abs(g).max())
     st = integ.stats
