@@ -157,11 +157,15 @@ struct Builder {
         return r;
     }
 
-    /* pads a box so that a hit accepted by the Wald test (which tolerates a few ulp outside the
-       exact triangle) can never be culled by the slab test */
-    static void pad(Box &b) {
+    /* pads a box so that a hit accepted by the Wald test (which tolerates a few ulp outside the exact triangle) can never be
+       culled by the slab test -- including a hit at EXACTLY the current maxt (a tie with a hit found earlier, winsTie in
+       dv_scene.h): the slab's entry distance and the Wald distance are rounded differently, a few ulp of t apart, i.e. up to
+       ~3e-7 x the distance travelled along the axis.  A pad relative to the coordinate alone vanishes for a flat box in the
+       plane x = 0 (round 2: ties on such planes were decided by the traversal order), hence the term in the scene's extent. */
+    float extent[3] = { 0, 0, 0 };
+    void pad(Box &b) const {
         for (int i = 0; i < 3; ++i) {
-            float e = 1e-5f * std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])) + 1e-7f * (b.mx[i] - b.mn[i]) + 1e-30f;
+            float e = 1e-5f * std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])) + 1e-7f * (b.mx[i] - b.mn[i]) + 2e-6f * extent[i] + 1e-30f;
             b.mn[i] -= e; b.mx[i] += e;
         }
     }
@@ -604,6 +608,7 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
         return;
     }
     detail::Builder B(T, out, positions, indices);
+    for (int a = 0; a < 3; ++a) B.extent[a] = tight.mx[a] - tight.mn[a];
     detail::Box rootBox;
     /* spatial splits for the scenes that use the wide tree (small scenes are laid out for LDS record by record) */
     const char *sp = getenv("PHIP_BVH_SPATIAL");
