@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PHIP_ABI_VERSION 4
+#define PHIP_ABI_VERSION 5
 
 typedef enum phip_status {
     PHIP_OK              =  0,
@@ -80,6 +80,11 @@ typedef struct phip_material {
     uint32_t reflectance_texture; /* 0 = the constant `reflectance`, else 1 + id of a `bitmap` texture on DIFFUSE `reflectance`
                                    (diffuse.cpp:110-150) or on DIELECTRIC / ROUGHCONDUCTOR `specularReflectance`
                                    (dielectric.cpp:300, roughconductor.cpp:297-298,373-374): texture->eval(its)  */
+    uint32_t alpha_u_texture, alpha_v_texture;   /* ROUGHCONDUCTOR (ABI 5): 0 = the constants alpha_u / alpha_v, else 1 + id of a `bitmap` texture
+                                   given as the child "alpha" (then both ids are equal), "alphaU" or "alphaV" (roughconductor.cpp:424-431);
+                                   the roughness at a vertex is texture->eval(its).average() (roughconductor.cpp:275-280), clamped to >= 1e-4
+                                   (microfacet.h:113-114).  Two different textures make the BSDF anisotropic (roughconductor.cpp:228-229) */
+    uint32_t transmittance_texture; /* DIELECTRIC (ABI 5): 0 or 1 + id of a `bitmap` texture on specularTransmittance (dielectric.cpp:301,348) */
 } phip_material;
 
 /* ---- `bitmap` texture (src/textures/bitmap.cpp, Texture2D::eval texture.cpp:112-121): an RGB MIP pyramid exactly as

@@ -5,7 +5,7 @@ struct against the values the C side reports through phip_abi_sizeof().
 """
 import ctypes as C
 
-PHIP_ABI_VERSION = 4
+PHIP_ABI_VERSION = 5
 PHIP_FILTER_RESOLUTION = 31
 
 PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCELLED, PHIP_ERR_NOMEM = 0, -1, -2, -3, -4, -5
@@ -27,7 +27,8 @@ class phip_material(C.Structure):
                 ("reflectance", C.c_float * 3), ("transmittance", C.c_float * 3),
                 ("eta", C.c_float * 3), ("k", C.c_float * 3),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float),
-                ("distribution", C.c_uint32), ("sample_visible", C.c_uint32), ("reflectance_texture", C.c_uint32)]
+                ("distribution", C.c_uint32), ("sample_visible", C.c_uint32), ("reflectance_texture", C.c_uint32),
+                ("alpha_u_texture", C.c_uint32), ("alpha_v_texture", C.c_uint32), ("transmittance_texture", C.c_uint32)]
 
 
 class phip_shape(C.Structure):

@@ -39,7 +39,9 @@ struct DevMaterial {
     float trans[3]; float alphaV;
     float eta[3]; uint32_t distribution;
     float k[3]; uint32_t sampleVisible;
-    uint32_t reflTexture, pad[3];        /* DIFFUSE: 0 or 1 + id of the bitmap texture of `reflectance` */
+    uint32_t reflTexture;                /* 0 or 1 + id of the bitmap texture of `reflectance` (DIFFUSE) / `specularReflectance` */
+    uint32_t alphaUTexture, alphaVTexture;   /* ROUGHCONDUCTOR: 0 or 1 + id of the bitmap texture of alpha / alphaU / alphaV */
+    uint32_t transTexture;               /* DIELECTRIC: 0 or 1 + id of the bitmap texture of specularTransmittance */
 };
 
 struct DevEmitter { float radiance[3]; float samplingWeight; uint32_t shape; uint32_t pad[3]; };
@@ -638,7 +640,8 @@ DV V3 textureEval(const DevScene &S, uint32_t id, const V2 &itsUV, bool partials
  * ====================================================================================== */
 struct MF {   /* MicrofacetDistribution, microfacet.h */
     int type; float alphaU, alphaV; bool visible;
-    DV MF(const DevMaterial &M) : type((int) M.distribution), alphaU(M.alphaU), alphaV(M.alphaV), visible(M.sampleVisible != 0) {
+    /* (aU, aV): the material's constants or, with a texture on alpha / alphaU / alphaV, texture->eval(its).average() at this vertex */
+    DV MF(const DevMaterial &M, float aU, float aV) : type((int) M.distribution), alphaU(aU), alphaV(aV), visible(M.sampleVisible != 0) {
         alphaU = smax(alphaU, 1e-4f); alphaV = smax(alphaV, 1e-4f);
     }
     DV bool isIsotropic() const { return alphaU == alphaV; }
@@ -808,7 +811,9 @@ enum { MM_ROUGH = 1, MM_DIELECTRIC = 2, MM_ALL = 3 };
 /* one-sided leaf models; wi.z sign already resolved by the twosided adapter.
    leafEvalPdf = eval() and pdf() of the same (wi, wo) pair in one pass (diffuse.cpp:110-133,
    roughconductor.cpp:253-337): the two share H, D and G1(wi). */
-template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &albedo, const V3 &wi, const V3 &wo, float &pdf) {
+struct LeafVarying { V3 albedo; float alphaU, alphaV; V3 trans; };   /* the spatially varying parameters at this vertex: constants or texture values */
+template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const LeafVarying &lv, const V3 &wi, const V3 &wo, float &pdf) {
+    const V3 &albedo = lv.albedo;
     pdf = 0.0f;
     if (M.type == PHIP_BSDF_DIFFUSE) {
         if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
@@ -817,7 +822,7 @@ template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &albedo, cons
     } else if ((MM & MM_ROUGH) && M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
         V3 H = normalize(wo + wi);
-        MF distr(M);
+        MF distr(M, lv.alphaU, lv.alphaV);
         const float D = distr.eval(H);
         const float G1i = distr.smithG1(wi, H);
         if (M.sampleVisible)
@@ -832,7 +837,8 @@ template <int MM> DV V3 leafEvalPdf(const DevMaterial &M, const V3 &albedo, cons
     }
     return V3(0.0f);
 }
-template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const V3 &wi, const V2 &smp, BSDFSample &bs) {
+template <int MM> DV V3 leafSample(const DevMaterial &M, const LeafVarying &lv, const V3 &wi, const V2 &smp, BSDFSample &bs) {
+    const V3 &albedo = lv.albedo;
     bs.eta = 1.0f; bs.delta = false; bs.pdf = 0.0f; bs.wo = V3(0.0f);
     if (M.type == PHIP_BSDF_DIFFUSE) {
         if (cosTheta(wi) <= 0) return V3(0.0f);
@@ -841,7 +847,7 @@ template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const
         return albedo;
     } else if ((MM & MM_ROUGH) && M.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         if (cosTheta(wi) < 0) return V3(0.0f);
-        MF distr(M);
+        MF distr(M, lv.alphaU, lv.alphaV);
         float pdf;
         V3 m = distr.sample(wi, smp, pdf);
         if (pdf == 0) return V3(0.0f);
@@ -869,7 +875,7 @@ template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const
             bs.eta = cosThetaT < 0 ? eta : invEta;
             bs.pdf = 1 - F;
             float factor = cosThetaT < 0 ? invEta : eta;
-            return rgb(M.trans) * (factor * factor);
+            return lv.trans * (factor * factor);            /* m_specularTransmittance->eval(bRec.its) */
         }
     }
     return V3(0.0f);
@@ -879,7 +885,10 @@ template <int MM> DV V3 leafSample(const DevMaterial &M, const V3 &albedo, const
    vertex all see the same wi, so they share the nested model and the flip.  (eval/pdf pick nested0 for
    cosTheta(wi) > 0 and sample for cosTheta(wi) >= 0; at exactly 0 every wrapped model's eval/pdf is zero
    on either side, so one rule serves all three.) */
-struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip; V3 albedo; /* reflectance (diffuse) / specularReflectance (dielectric, roughconductor) at this vertex: the constant, or the texture value k_shade puts here */ };
+struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip;
+                 LeafVarying v; /* reflectance (diffuse) / specularReflectance (dielectric, roughconductor), roughness, specularTransmittance at this vertex:
+                                   the constants, or the texture values k_shade puts here */
+                 DV void constants() { v.albedo = rgb(leaf->refl); v.alphaU = leaf->alphaU; v.alphaV = leaf->alphaV; v.trans = rgb(leaf->trans); } };
 DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
     BsdfCtx c; c.leaf = &M; c.wi = wi; c.flip = false;
     if (M.type == PHIP_BSDF_TWOSIDED) {
@@ -887,7 +896,7 @@ DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
         c.leaf = S.materials + (c.flip ? M.nested1 : M.nested0);
         if (c.flip) c.wi.z = -wi.z;
     }
-    c.albedo = rgb(c.leaf->refl);
+    c.constants();
     return c;
 }
 /* same, from a shading record (front/back already are the nested models) */
@@ -896,15 +905,26 @@ DV BsdfCtx bsdfResolve(const DevMaterial *materials, const Isect &its) {
     c.flip = (its.flags & TS_TWOSIDED) && cosTheta(its.wi) < 0;
     c.leaf = materials + (c.flip ? its.back : its.front);
     if (c.flip) c.wi.z = -its.wi.z;
-    c.albedo = rgb(c.leaf->refl);
+    c.constants();
     return c;
+}
+/* The textured parameters of the vertex's leaf model: texture->eval(its) of every `bitmap` child (reflectance / specularReflectance,
+   alpha / alphaU / alphaV as the RGB average, specularTransmittance).  `partials`: the vertex carries UV partials (the first vertex:
+   camera-ray differentials, records.inl:69-75) -> MIPMap::eval; otherwise the unfiltered level-0 lookup (bitmap.cpp:431-454). */
+DV bool leafIsTextured(const DevMaterial &M) { return (M.reflTexture | M.alphaUTexture | M.alphaVTexture | M.transTexture) != 0; }
+DV void bsdfTextures(const DevScene &S, BsdfCtx &c, const V2 &uv, bool partials, float dudx, float dudy, float dvdx, float dvdy) {
+    const DevMaterial &M = *c.leaf;
+    if (M.reflTexture) c.v.albedo = textureEval(S, M.reflTexture - 1, uv, partials, dudx, dudy, dvdx, dvdy);
+    if (M.alphaUTexture) c.v.alphaU = textureEval(S, M.alphaUTexture - 1, uv, partials, dudx, dudy, dvdx, dvdy).average();
+    if (M.alphaVTexture) c.v.alphaV = (M.alphaVTexture == M.alphaUTexture) ? c.v.alphaU : textureEval(S, M.alphaVTexture - 1, uv, partials, dudx, dudy, dvdx, dvdy).average();
+    if (M.transTexture) c.v.trans = textureEval(S, M.transTexture - 1, uv, partials, dudx, dudy, dvdx, dvdy);
 }
 template <int MM> DV V3 bsdfEvalPdf(const BsdfCtx &c, V3 wo, float &pdf) {
     if (c.flip) wo.z = -wo.z;
-    return leafEvalPdf<MM>(*c.leaf, c.albedo, c.wi, wo, pdf);
+    return leafEvalPdf<MM>(*c.leaf, c.v, c.wi, wo, pdf);
 }
 template <int MM> DV V3 bsdfSample(const BsdfCtx &c, const V2 &smp, BSDFSample &bs) {
-    V3 result = leafSample<MM>(*c.leaf, c.albedo, c.wi, smp, bs);
+    V3 result = leafSample<MM>(*c.leaf, c.v, c.wi, smp, bs);
     if (c.flip && !result.isZero() && bs.pdf != 0)
         bs.wo.z = -bs.wo.z;
     return result;

@@ -285,8 +285,8 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
             dRec.pdf = 0; dRec.emitter = -1;
             BsdfCtx bctx = bsdfResolve(materials, its);
-            if (TEX && bctx.leaf->reflTexture != 0) {
-                /* m_reflectance->eval(its): unfiltered level-0 lookup, except at the first vertex, whose UV partials come
+            if (TEX && leafIsTextured(*bctx.leaf)) {
+                /* texture->eval(its) of the BSDF's bitmap children: unfiltered level-0 lookup, except at the first vertex, whose UV partials come
                    from the camera-ray differentials (Intersection::getBSDF(ray) -> computePartials, records.inl:69-75) */
                 float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
                 if (firstVertex) {
@@ -299,7 +299,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                     const float *cw = S.cam.c2w;
                     computePartials(its, V3(cw[3], cw[7], cw[11]), rx, ry, dudx, dudy, dvdx, dvdy);
                 }
-                bctx.albedo = textureEval(S, bctx.leaf->reflTexture - 1, its.uv, firstVertex, dudx, dudy, dvdx, dvdy);
+                bsdfTextures(S, bctx, its.uv, firstVertex, dudx, dudy, dvdx, dvdy);
             }
             if (its.flags & TS_MF_SMOOTH) {
                 V3 value = sampleEmitterDirect<ENV>(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));

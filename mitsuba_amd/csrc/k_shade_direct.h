@@ -98,7 +98,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             if (!terminate) {
                 const V3 refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;     /* DirectSamplingRecord(its), records.inl:146-153 */
                 BsdfCtx bctx = bsdfResolve(materials, its);
-                if (TEX && bctx.leaf->reflTexture != 0) {
+                if (TEX && leafIsTextured(*bctx.leaf)) {
                     /* its.getBSDF(ray): every query at the camera vertex sees the UV partials of the camera-ray differentials */
                     float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
                     V3 rx, ry;
@@ -107,7 +107,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                     ry = camD + (ry - camD) * rc.diffScaleFactor;
                     const float *cw = S.cam.c2w;
                     computePartials(its, V3(cw[3], cw[7], cw[11]), rx, ry, dudx, dudy, dvdx, dvdy);
-                    bctx.albedo = textureEval(S, bctx.leaf->reflTexture - 1, its.uv, true, dudx, dudy, dvdx, dvdy);
+                    bsdfTextures(S, bctx, its.uv, true, dudx, dudy, dvdx, dvdy);
                 }
 
                 /* ---- the BSDF sample traced since the last round, direct.cpp:273-306 ---- */

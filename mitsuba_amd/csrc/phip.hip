@@ -245,7 +245,13 @@ static std::vector<DevMaterial> convertMaterials(const phip_material *materials,
             case PHIP_BSDF_DIELECTRIC:
                 if (!(m.eta[0] > 0)) throw std::runtime_error("dielectric eta must be positive");
                 o.flags |= MF_TRANS_OR_BACK;
-                specularTexture(m, o); break;
+                specularTexture(m, o);
+                if (m.transmittance_texture != 0) {          /* dielectric.cpp:161-162,207-208: ensureEnergyConservation(specularTransmittance) */
+                    if (!textureMax || m.transmittance_texture > textureMax->size()) throw std::runtime_error("material texture id out of range");
+                    if ((*textureMax)[m.transmittance_texture - 1] > 1.0f) throw std::runtime_error("specularTransmittance texture > 1 (ensureEnergyConservation)");
+                    o.transTexture = m.transmittance_texture;
+                }
+                break;
             case PHIP_BSDF_ROUGHCONDUCTOR: {
                 specularTexture(m, o);
                 if (m.distribution > PHIP_MF_GGX) { g_err = "unsupported microfacet distribution"; throw std::invalid_argument("unsupported microfacet distribution (only beckmann, ggx)"); }
@@ -253,6 +259,10 @@ static std::vector<DevMaterial> convertMaterials(const phip_material *materials,
                 /* alpha = ConstantFloatTexture.eval().average() (roughconductor.cpp:275-280), clamp microfacet.h:113-114 */
                 o.alphaU = std::max(V3(m.alpha_u).average(), 1e-4f);
                 o.alphaV = std::max(V3(m.alpha_v).average(), 1e-4f);
+                /* a `bitmap` texture as the child "alpha" / "alphaU" / "alphaV" (roughconductor.cpp:424-431): evaluated per vertex */
+                for (uint32_t t : { m.alpha_u_texture, m.alpha_v_texture })
+                    if (t != 0 && (!textureMax || t > textureMax->size())) throw std::runtime_error("material texture id out of range");
+                o.alphaUTexture = m.alpha_u_texture; o.alphaVTexture = m.alpha_v_texture;
             } break;
             case PHIP_BSDF_TWOSIDED: {
                 if (m.nested[0] >= i || m.nested[1] >= i) throw std::runtime_error("twosided: nested materials must precede the adapter");
@@ -367,7 +377,8 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         std::function<bool(uint32_t, int)> aniso = [&](uint32_t m, int depth) -> bool {
             if (m >= d.n_materials || depth > 2) return false;
             const phip_material &M = d.materials[m];
-            if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) return std::max(M.alpha_u, 1e-4f) != std::max(M.alpha_v, 1e-4f);
+            if (M.type == PHIP_BSDF_ROUGHCONDUCTOR)            /* m_alphaU != m_alphaV as OBJECTS: one texture for both is isotropic, roughconductor.cpp:228-229 */
+                return (M.alpha_u_texture | M.alpha_v_texture) ? M.alpha_u_texture != M.alpha_v_texture : std::max(M.alpha_u, 1e-4f) != std::max(M.alpha_v, 1e-4f);
             if (M.type == PHIP_BSDF_TWOSIDED) return aniso(M.nested[0], depth + 1) || aniso(M.nested[1], depth + 1);
             return false;
         };
@@ -1248,7 +1259,7 @@ extern "C" {
 const char *phip_last_error(void) { return g_err.c_str(); }
 #define PHIP_STR2(x) #x
 #define PHIP_STR(x) PHIP_STR2(x)
-const char *phip_version(void) { return "path_hip 0.4 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
+const char *phip_version(void) { return "path_hip 0.5 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
 
 int phip_device_count(void) {
     int n = 0;

@@ -96,6 +96,18 @@ public:
     virtual const Texture *getSpecularReflectanceTexture() const = 0;
 };
 
+/* ... and the second accessor of each of the two, declared AFTER getSpecularReflectanceTexture in the plugin source:
+   src/bsdfs/roughconductor.cpp: the roughness textures (children "alpha" / "alphaU" / "alphaV"), axis 0 = m_alphaU, 1 = m_alphaV;
+   src/bsdfs/dielectric.cpp: the specularTransmittance texture */
+class RoughConductorAccess : public SpecularReflectanceAccess {
+public:
+    virtual const Texture *getAlphaTexture(int axis) const = 0;
+};
+class DielectricAccess : public SpecularReflectanceAccess {
+public:
+    virtual const Texture *getSpecularTransmittanceTexture() const = 0;
+};
+
 /* src/bsdfs/twosided.cpp's TwoSidedBRDF: its two children */
 class TwoSidedAccess : public BSDF {
 public:
@@ -116,6 +128,8 @@ struct PhipBitmapInfo {
 inline const BSDF *phipNested(const BSDF *b, int i) { return static_cast<const TwoSidedAccess *>(b)->getNestedBRDF(i); }
 inline const Texture *phipReflectanceTexture(const BSDF *b) { return static_cast<const SmoothDiffuseAccess *>(b)->getReflectanceTexture(); }
 inline const Texture *phipSpecularTexture(const BSDF *b, bool) { return static_cast<const SpecularReflectanceAccess *>(b)->getSpecularReflectanceTexture(); }
+inline const Texture *phipAlphaTexture(const BSDF *b, int axis) { return static_cast<const RoughConductorAccess *>(b)->getAlphaTexture(axis); }
+inline const Texture *phipTransmittanceTexture(const BSDF *b) { return static_cast<const DielectricAccess *>(b)->getSpecularTransmittanceTexture(); }
 inline const TMIPMap<Spectrum, TSpectrum<half, SPECTRUM_SAMPLES> > *phipEnvMip(const Emitter *e) { return static_cast<const EnvironmentMapAccess *>(e)->getMIPMap(); }
 inline PhipBitmapInfo phipBitmap(const Texture *t) {
     const BitmapTextureAccess *b = static_cast<const BitmapTextureAccess *>(t);
@@ -128,6 +142,8 @@ inline const Texture *phipReflectanceTexture(const BSDF *b) { return static_cast
 inline const Texture *phipSpecularTexture(const BSDF *b, bool conductor) {
     return conductor ? static_cast<const RoughConductor *>(b)->m_specularReflectance.get() : static_cast<const SmoothDielectric *>(b)->m_specularReflectance.get();
 }
+inline const Texture *phipAlphaTexture(const BSDF *b, int axis) { const RoughConductor *r = static_cast<const RoughConductor *>(b); return axis ? r->m_alphaV.get() : r->m_alphaU.get(); }
+inline const Texture *phipTransmittanceTexture(const BSDF *b) { return static_cast<const SmoothDielectric *>(b)->m_specularTransmittance.get(); }
 inline const TMIPMap<Spectrum, TSpectrum<half, SPECTRUM_SAMPLES> > *phipEnvMip(const Emitter *e) { return static_cast<const EnvironmentMap *>(e)->m_mipmap; }
 inline PhipBitmapInfo phipBitmap(const Texture *t) {
     const BitmapTexture *b = static_cast<const BitmapTexture *>(t);
@@ -436,6 +452,14 @@ public:
             rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
             specularTexture(bsdf, false, m);
             rgb(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.transmittance);
+#if defined(PHIP_HAVE_INTERNALS)
+            if (const Texture *tex = phipTransmittanceTexture(bsdf)) {       /* a <texture name="specularTransmittance"> child */
+                if (tex->getClass()->getName() == "BitmapTexture")
+                    m.transmittance_texture = 1 + convertBitmap(tex);
+                else if (!tex->isConstant())
+                    SLog(EError, "path_hip: texture \"%s\" is not supported (constant, bitmap)", tex->getClass()->getName().c_str());
+            }
+#endif
         } else if (cls == "RoughConductor") {
             m.type = PHIP_BSDF_ROUGHCONDUCTOR;
             /* roughconductor.cpp:176-190: eta / k from data/ior/<material>.{eta,k}.spd unless given explicitly */
@@ -457,10 +481,26 @@ public:
                 SLog(EError, "path_hip: the phong/as microfacet distribution is not supported");
             m.distribution = distr.getType() == MicrofacetDistribution::EGGX ? PHIP_MF_GGX : PHIP_MF_BECKMANN;
             m.alpha_u = distr.getAlphaU(); m.alpha_v = distr.getAlphaV(); m.sample_visible = distr.getSampleVisible() ? 1 : 0;
-            /* a TEXTURE on alpha / alphaU / alphaV (roughconductor.cpp:196-200: a child object, invisible in the Properties) is outside
-               the supported set; it would otherwise hide behind a textured specularReflectance in the ESpatiallyVarying test below.
-               Probed through the public interface: the roughness must not depend on the texture coordinates. */
-            {
+            /* a TEXTURE on alpha / alphaU / alphaV is a child object (roughconductor.cpp:424-431), invisible in the Properties */
+            bool roughnessDone = false;
+#if defined(PHIP_HAVE_INTERNALS)
+            if (const Texture *tu = phipAlphaTexture(bsdf, 0)) {
+                const Texture *tv = phipAlphaTexture(bsdf, 1);
+                const Texture *axes[2] = { tu, tv };
+                uint32_t *ids2[2] = { &m.alpha_u_texture, &m.alpha_v_texture };
+                for (int a = 0; a < 2; ++a) {
+                    if (axes[a]->getClass()->getName() == "BitmapTexture")
+                        *ids2[a] = 1 + convertBitmap(axes[a]);         /* (one object for both axes -> one id: isotropic) */
+                    else if (!axes[a]->isConstant())
+                        SLog(EError, "path_hip: texture \"%s\" on the roughness is not supported (constant, bitmap)", axes[a]->getClass()->getName().c_str());
+                }
+                roughnessDone = true;
+            }
+#endif
+            if (!roughnessDone) {
+                /* no way in (stock build / an accessor set without getAlphaTexture): a textured roughness must not slip through behind a
+                   textured specularReflectance in the ESpatiallyVarying test below.  Probed through the public interface: the roughness
+                   must not depend on the texture coordinates. */
                 Intersection probe; probe.p = Point(0.0f); probe.geoFrame = probe.shFrame = Frame(Normal(0, 0, 1)); probe.wi = Vector(0, 0, 1);
                 probe.hasUVPartials = false; probe.dudx = probe.dudy = probe.dvdx = probe.dvdy = 0;
                 const Float uvs[4][2] = { { 0.13f, 0.71f }, { 0.62f, 0.29f }, { 0.91f, 0.87f }, { 0.37f, 0.05f } };
@@ -470,7 +510,7 @@ public:
                     const Float r = bsdf->getRoughness(probe, 0);
                     if (k == 0) first = r;
                     else if (r != first)
-                        SLog(EError, "path_hip: a textured roughness (alpha) on roughconductor is not supported");
+                        SLog(EError, "path_hip: a textured roughness (alpha) on roughconductor needs -DPHIP_REFERENCE_SOURCES or the getAlphaTexture accessor of INTEGRATION.md");
                 }
             }
         } else if (cls == "TwoSidedBRDF") {
@@ -485,8 +525,9 @@ public:
         } else {
             SLog(EError, "path_hip: BSDF '%s' is outside the supported set (diffuse, dielectric, roughconductor, twosided)", cls.c_str());
         }
-        if ((bsdf->getType() & BSDF::ESpatiallyVarying) && m.type != PHIP_BSDF_TWOSIDED && !m.reflectance_texture)
-            SLog(EError, "path_hip: only reflectance / specularReflectance can be textured (bitmap)");
+        if ((bsdf->getType() & BSDF::ESpatiallyVarying) && m.type != PHIP_BSDF_TWOSIDED
+            && !(m.reflectance_texture | m.alpha_u_texture | m.alpha_v_texture | m.transmittance_texture))
+            SLog(EError, "path_hip: only reflectance / specularReflectance / specularTransmittance / alpha can be textured (bitmap)");
         materials.push_back(m);
         ids[bsdf] = (uint32_t) materials.size() - 1;
         return ids[bsdf];

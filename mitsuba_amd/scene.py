@@ -107,19 +107,21 @@ class SceneBuilder:
                               "aniso": float(max_anisotropy), "scale": (float(uscale), float(vscale)), "offset": (float(uoffset), float(voffset))})
         return len(self.textures) - 1
 
-    def dielectric(self, int_ior=1.5046, ext_ior=1.000277, specular_reflectance=1.0, specular_transmittance=1.0, texture=None):
-        """defaults: intIOR bk7, extIOR air (src/bsdfs/dielectric.cpp:149-152, ior.h)"""
+    def dielectric(self, int_ior=1.5046, ext_ior=1.000277, specular_reflectance=1.0, specular_transmittance=1.0, texture=None, transmittance_texture=None):
+        """defaults: intIOR bk7, extIOR air (src/bsdfs/dielectric.cpp:149-152, ior.h); `transmittance_texture`: <texture name="specularTransmittance">"""
         m = A.phip_material()
         m.type = A.PHIP_BSDF_DIELECTRIC
         m.eta[0] = np.float32(np.float32(int_ior) / np.float32(ext_ior))
         m.reflectance[:] = _rgb(specular_reflectance)
         m.transmittance[:] = _rgb(specular_transmittance)
         m.reflectance_texture = 0 if texture is None else texture + 1      # <texture name="specularReflectance">
+        m.transmittance_texture = 0 if transmittance_texture is None else transmittance_texture + 1
         return self._add_material(m)
 
     def roughconductor(self, eta, k, alpha=0.1, alpha_v=None, distribution="beckmann", sample_visible=True,
-                       specular_reflectance=1.0, ext_eta=1.000277, texture=None):
-        """eta/k are linear-RGB (the host converts data/ior/*.spd, roughconductor.cpp:176-190)."""
+                       specular_reflectance=1.0, ext_eta=1.000277, texture=None, alpha_texture=None, alpha_v_texture=None):
+        """eta/k are linear-RGB (the host converts data/ior/*.spd, roughconductor.cpp:176-190).  `alpha_texture`: <texture name="alpha">
+        (or name="alphaU" when `alpha_v_texture`, <texture name="alphaV">, is given too); the roughness is the texture's RGB average."""
         m = A.phip_material()
         m.type = A.PHIP_BSDF_ROUGHCONDUCTOR
         e = np.float32(ext_eta)
@@ -131,6 +133,8 @@ class SceneBuilder:
         m.sample_visible = 1 if sample_visible else 0
         m.reflectance[:] = _rgb(specular_reflectance)
         m.reflectance_texture = 0 if texture is None else texture + 1      # <texture name="specularReflectance">
+        m.alpha_u_texture = 0 if alpha_texture is None else alpha_texture + 1
+        m.alpha_v_texture = m.alpha_u_texture if alpha_v_texture is None else alpha_v_texture + 1
         return self._add_material(m)
 
     def twosided(self, front, back=None):

@@ -221,6 +221,22 @@ public:
         return Spectrum(M.m.reflectance);
     }
 
+    /* m_specularTransmittance->eval(bRec.its), dielectric.cpp:307,363 */
+    Spectrum specularTransmittance(const Material &M) const {
+        if (M.m.transmittance_texture != 0 && its)
+            return scene.textures[M.m.transmittance_texture - 1].eval(*its);
+        return Spectrum(M.m.transmittance);
+    }
+    /* m_alphaU / m_alphaV ->eval(bRec.its).average(), roughconductor.cpp:275-280 (the MicrofacetDistribution constructor clamps) */
+    Float alphaU(const Material &M) const {
+        if (M.m.alpha_u_texture != 0 && its) return scene.textures[M.m.alpha_u_texture - 1].eval(*its).average();
+        return M.alphaU;
+    }
+    Float alphaV(const Material &M) const {
+        if (M.m.alpha_v_texture != 0 && its) return scene.textures[M.m.alpha_v_texture - 1].eval(*its).average();
+        return M.alphaV;
+    }
+
     /* ---- diffuse.cpp:110-150 ---- */
     Spectrum diffuseEval(const Material &M, const Vec3 &wi, const Vec3 &wo) const {
         if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0)
@@ -259,7 +275,7 @@ public:
             bRec.eta = cosThetaT < 0 ? eta : invEta;
             pdf = 1 - F;
             Float factor = cosThetaT < 0 ? invEta : eta;   /* ERadiance */
-            return Spectrum(M.m.transmittance) * (factor * factor);
+            return specularTransmittance(M) * (factor * factor);
         }
     }
 
@@ -270,7 +286,7 @@ public:
         if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0)
             return Spectrum(0.0f);
         Vec3 H = normalize(wo + wi);
-        MicrofacetDistribution distr((int) M.m.distribution, M.alphaU, M.alphaV, M.m.sample_visible != 0);
+        MicrofacetDistribution distr((int) M.m.distribution, alphaU(M), alphaV(M), M.m.sample_visible != 0);
         const Float D = distr.eval(H);
         if (D == 0)
             return Spectrum(0.0f);
@@ -279,11 +295,11 @@ public:
         Float model = D * G / (4.0f * Frame::cosTheta(wi));
         return F * model;
     }
-    static Float roughPdf(const Material &M, const Vec3 &wi, const Vec3 &wo) {
+    Float roughPdf(const Material &M, const Vec3 &wi, const Vec3 &wo) const {
         if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0)
             return 0.0f;
         Vec3 H = normalize(wo + wi);
-        MicrofacetDistribution distr((int) M.m.distribution, M.alphaU, M.alphaV, M.m.sample_visible != 0);
+        MicrofacetDistribution distr((int) M.m.distribution, alphaU(M), alphaV(M), M.m.sample_visible != 0);
         if (M.m.sample_visible)
             return distr.eval(H) * distr.smithG1(wi, H) / (4.0f * Frame::cosTheta(wi));
         else
@@ -292,7 +308,7 @@ public:
     Spectrum roughSample(const Material &M, BSDFSamplingRecord &bRec, Float &pdf, const Vec2 &sample) const {
         if (Frame::cosTheta(bRec.wi) < 0)
             return Spectrum(0.0f);
-        MicrofacetDistribution distr((int) M.m.distribution, M.alphaU, M.alphaV, M.m.sample_visible != 0);
+        MicrofacetDistribution distr((int) M.m.distribution, alphaU(M), alphaV(M), M.m.sample_visible != 0);
         Vec3 m = distr.sample(bRec.wi, sample, pdf);
         if (pdf == 0)
             return Spectrum(0.0f);

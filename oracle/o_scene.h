@@ -307,14 +307,16 @@ textures.resize(d.n_textures);
             }
         }
         for (uint32_t i = 0; i < d.n_materials; ++i)
-            if (materials[i].m.reflectance_texture > d.n_textures) throw std::runtime_error("oracle: bad texture id");
+            for (uint32_t t : { materials[i].m.reflectance_texture, materials[i].m.alpha_u_texture, materials[i].m.alpha_v_texture, materials[i].m.transmittance_texture })
+                if (t > d.n_textures) throw std::runtime_error("oracle: bad texture id");
         /* TriMesh::computeUVTangents, trimesh.cpp:683-693: an anisotropic BSDF (roughconductor.cpp:196-200,230-231: the clamped
            alphaU != alphaV; twosided.cpp:96-100 inherits the flag) needs texture coordinates for its tangent frame */
         for (uint32_t i = 0; i < d.n_shapes; ++i) {
             std::function<bool(uint32_t, int)> aniso = [&](uint32_t m, int depth) -> bool {
                 if (m >= d.n_materials || depth > 2) return false;
                 const phip_material &M = d.materials[m];
-                if (M.type == PHIP_BSDF_ROUGHCONDUCTOR) return std::max(M.alpha_u, 1e-4f) != std::max(M.alpha_v, 1e-4f);
+                if (M.type == PHIP_BSDF_ROUGHCONDUCTOR)          /* m_alphaU != m_alphaV as objects, roughconductor.cpp:228-229 */
+                    return (M.alpha_u_texture | M.alpha_v_texture) ? M.alpha_u_texture != M.alpha_v_texture : std::max(M.alpha_u, 1e-4f) != std::max(M.alpha_v, 1e-4f);
                 if (M.type == PHIP_BSDF_TWOSIDED) return aniso(M.nested[0], depth + 1) || aniso(M.nested[1], depth + 1);
                 return false;
             };
@@ -389,7 +391,14 @@ textures.resize(d.n_textures);
                 }
                 M.smooth = mx > 0; M.transOrBack = false;
             } break;
-            case PHIP_BSDF_DIELECTRIC: M.smooth = false; M.transOrBack = true; specularTexture(M); break;
+            case PHIP_BSDF_DIELECTRIC: {
+                M.smooth = false; M.transOrBack = true; specularTexture(M);
+                if (M.m.transmittance_texture != 0) {      /* ensureEnergyConservation(specularTransmittance), dielectric.cpp:207-208 */
+                    Float mx = 0;
+                    for (const Spectrum &t : textures[M.m.transmittance_texture - 1].mip.levels[0]) mx = std::max(mx, t.max());
+                    if (mx > 1.0f) throw std::runtime_error("specularTransmittance texture > 1 (ensureEnergyConservation)");
+                }
+            } break;
             case PHIP_BSDF_ROUGHCONDUCTOR: {
                 M.smooth = true; M.transOrBack = false; specularTexture(M);
                 /* roughconductor.cpp:275-280: alpha = texture.eval().average(); microfacet.h:113-114 clamp */
@@ -472,7 +481,7 @@ textures.resize(d.n_textures);
     bool usesRayDifferentials(const Material &M) const {
         if (M.m.type == PHIP_BSDF_TWOSIDED)
             return usesRayDifferentials(materials[M.m.nested[0]]) || usesRayDifferentials(materials[M.m.nested[1]]);
-        return M.m.reflectance_texture != 0;       /* diffuse.cpp, roughconductor.cpp:244-248, dielectric.cpp:196-198 */
+        return (M.m.reflectance_texture | M.m.alpha_u_texture | M.m.alpha_v_texture | M.m.transmittance_texture) != 0;   /* diffuse.cpp, roughconductor.cpp:244-248, dielectric.cpp:196-198 */
     }
 
     /* Intersection::computePartials, intersection.cpp:5-76 (rxOrigin = ryOrigin = the ray origin for a pinhole camera) */

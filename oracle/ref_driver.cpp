@@ -158,6 +158,7 @@ BSDF *makeBSDF(RefScene *rs, const phip_scene_desc &d, uint32_t id) {
         p.setSpectrum("specularTransmittance", rgb(m.transmittance));
         bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         if (m.reflectance_texture) attach(bsdf, "specularReflectance", makeTexture(rs, d, m.reflectance_texture - 1));
+        if (m.transmittance_texture) attach(bsdf, "specularTransmittance", makeTexture(rs, d, m.transmittance_texture - 1));
     } else if (m.type == PHIP_BSDF_ROUGHCONDUCTOR) {
         Properties p("roughconductor");
         p.setString("material", "none");              /* no data/ior lookup (roughconductor.cpp:176-190): eta and k are given */
@@ -168,6 +169,12 @@ BSDF *makeBSDF(RefScene *rs, const phip_scene_desc &d, uint32_t id) {
         p.setBoolean("sampleVisible", m.sample_visible != 0);
         bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         if (m.reflectance_texture) attach(bsdf, "specularReflectance", makeTexture(rs, d, m.reflectance_texture - 1));
+        /* roughconductor.cpp:424-431: one texture as "alpha" serves both axes (isotropic); "alphaU" / "alphaV" are separate objects */
+        if (m.alpha_u_texture && m.alpha_u_texture == m.alpha_v_texture) attach(bsdf, "alpha", makeTexture(rs, d, m.alpha_u_texture - 1));
+        else {
+            if (m.alpha_u_texture) attach(bsdf, "alphaU", makeTexture(rs, d, m.alpha_u_texture - 1));
+            if (m.alpha_v_texture) attach(bsdf, "alphaV", makeTexture(rs, d, m.alpha_v_texture - 1));
+        }
     } else if (m.type == PHIP_BSDF_TWOSIDED) {
         Properties p("twosided");
         bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));

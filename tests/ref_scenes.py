@@ -130,6 +130,44 @@ def textures(gauss, mip):
     return sb
 
 
+def roughness_maps(gauss, mip):
+    """`bitmap` textures on the roughness of roughconductor (child "alpha": one texture for both axes; "alphaU" + "alphaV": two
+    textures, anisotropic) and on the dielectric's specularTransmittance (roughconductor.cpp:275-280,424-431; dielectric.cpp:307,363)"""
+    rng = np.random.default_rng(23)
+    a_chk = half(0.04 + 0.5 * _checker(64, 8))                                  # roughness 0.04 / 0.54 in a checkerboard
+    a_noise = half(rng.uniform(0.03, 0.6, (20, 32, 3)))
+    a_noise2 = half(rng.uniform(0.05, 0.4, (16, 16, 3)))
+    tint = half(rng.uniform(0.3, 1.0, (12, 20, 3)))
+    refl = half(rng.uniform(0.4, 1.0, (16, 24, 3)))
+    sb = S.SceneBuilder()
+    sb.constant((0.5, 0.55, 0.7))
+
+    def bm(key, img, **kw):
+        lv = mip(key, img, kind="texture", wrap_u=kw.get("wrap", "repeat"), wrap_v=kw.get("wrap_v"),
+                 filter_type=kw.get("filter_type", "ewa"), max_anisotropy=kw.get("max_anisotropy", 20.0))
+        return sb.bitmap(lv[0], pyramid=lv, **kw)
+    t_floor = bm("rm_floor", a_chk, filter_type="ewa", uscale=5.0, vscale=5.0)
+    t_u = bm("rm_u", a_noise, filter_type="trilinear", wrap="mirror", uscale=2.0)
+    t_v = bm("rm_v", a_noise2, filter_type="bilinear", vscale=3.0, voffset=0.1)
+    t_n = bm("rm_n", a_noise2[:9, :13], filter_type="nearest", uscale=4.0, vscale=2.0)
+    t_tint = bm("rm_tint", tint, filter_type="ewa", uscale=2.0, vscale=2.0)
+    t_refl = bm("rm_refl", refl, filter_type="ewa", max_anisotropy=4.0)
+    sb.quad((-8, 0, -8), (8, 0, -8), (8, 0, 8), (-8, 0, 8), sb.twosided(sb.roughconductor(eta=S.CU_ETA, k=S.CU_K, alpha_texture=t_floor)), facing=(0, 1, 0), uvs=True)
+    mats = [sb.roughconductor(eta=S.CU_ETA, k=S.CU_K, alpha_texture=t_u, alpha_v_texture=t_v),                       # anisotropic: two textures
+            sb.twosided(sb.roughconductor(eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.2), distribution="ggx", alpha_texture=t_n, texture=t_refl)),
+            sb.dielectric(1.5, 1.0, transmittance_texture=t_tint),
+            sb.roughconductor(eta=S.CU_ETA, k=S.CU_K, alpha_texture=t_v, sample_visible=False),
+            sb.dielectric(1.33, 1.0, specular_transmittance=(0.9, 0.95, 1.0), texture=t_refl, transmittance_texture=t_tint),
+            sb.diffuse((0.6, 0.5, 0.4))]
+    for i, m in enumerate(mats):
+        P, T, N = S.sphere_mesh((-5 + 2 * i, 0.8, 0.4 * (i % 2)), 0.8, 16, 8)
+        sb.mesh(P, T, m, normals=N if i % 2 == 0 else None, uvs=_sphere_uvs(N))
+    sb.quad((-2, 5, -2), (2, 5, -2), (2, 5, 2), (-2, 5, 2), sb.diffuse((0, 0, 0)), facing=(0, -1, 0), radiance=(10, 10, 9))
+    sb.perspective((0, 3.5, -11), (0, 0.4, 0), (0, 1, 0), 42.0)
+    sb.hdrfilm(48, 32, gauss)
+    return sb
+
+
 def box_mip(key, image, kind, **kw):
     """stand-in for the reference-built pyramids where the reference is not needed (GPU-vs-oracle fuzz): box-filtered levels"""
     return S.mip_pyramid(np.ascontiguousarray(image, np.float32))
@@ -159,11 +197,18 @@ def random_scene(gauss, seed, res=(24, 16), mip=None):
                      filter_type=kw["filter_type"], max_anisotropy=kw["max_anisotropy"])
             t = sb.bitmap(lv[0], pyramid=lv, uscale=float(rng.uniform(0.3, 8)), vscale=float(rng.uniform(0.3, 8)),
                           uoffset=float(rng.uniform(-1, 1)), voffset=float(rng.uniform(-1, 1)), **kw)
-            kind = rng.integers(0, 4)
+            kind = rng.integers(0, 7)
             if kind == 2:
                 d = sb.roughconductor(alpha=float(rng.uniform(0.05, 0.5)), eta=S.CU_ETA, k=S.CU_K, texture=t)      # specularReflectance
             elif kind == 3:
                 mats.append(sb.dielectric(float(rng.uniform(1.2, 1.8)), 1.0, texture=t)); continue
+            elif kind == 4:                                  # the same image as the roughness of both axes (child "alpha")
+                d = sb.roughconductor(eta=S.CU_ETA, k=S.CU_K, alpha_texture=t, distribution=["beckmann", "ggx"][rng.integers(2)], sample_visible=bool(rng.integers(2)))
+            elif kind == 5:                                  # "alphaU" textured, alphaV constant: anisotropic
+                d = sb.roughconductor(eta=S.CU_ETA, k=S.CU_K, alpha_texture=t, alpha_v=float(rng.uniform(0.05, 0.4)))
+                sb.materials[d].alpha_v_texture = 0
+            elif kind == 6:
+                mats.append(sb.dielectric(float(rng.uniform(1.2, 1.8)), 1.0, transmittance_texture=t)); continue
             else:
                 d = sb.diffuse(texture=t)
             mats.append(d if rng.random() < 0.5 else sb.twosided(d))
@@ -239,6 +284,8 @@ CASES = [
     ("envmap_direct", envmap, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=3)),
     ("textures_path", textures, dict(spp=2, max_depth=6)),
     ("textures_direct", textures, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=2)),
+    ("roughness_maps_path", roughness_maps, dict(spp=2, max_depth=8)),
+    ("roughness_maps_direct", roughness_maps, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=2)),
 ]
 
 

@@ -45,7 +45,7 @@ def scenes(ref, gauss):
     yield "stock", stock_scene(gauss).desc()
     # two-sided BSDFs, bitmap textures (the plugin's own Lanczos / half-precision pyramid), the envmap: the shim reads them
     # out of the reference's plugin objects (PHIP_REFERENCE_SOURCES)
-    for build in (RS.zoo, RS.textures, RS.envmap, RS.const_env, RS.atrium):
+    for build in (RS.zoo, RS.textures, RS.roughness_maps, RS.envmap, RS.const_env, RS.atrium):
         yield build.__name__, build(gauss, live_mip(ref)).desc()
 
 
@@ -94,6 +94,7 @@ def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss)
     from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
     for name, desc, spp, bar in (("cornell 128x128", S.cornell_box(128, 128, gauss).desc(), 64, 1e-3),
                                  ("textures 48x32", RS.textures(gauss, live_mip(ref)).desc(), 64, 1e-3),
+                                 ("roughness maps 48x32", RS.roughness_maps(gauss, live_mip(ref)).desc(), 64, 1e-3),
                                  ("atrium 160x90", S.atrium(160, 90, gauss, detail=0.5).desc(), 32, 1e-3),
                                  ("glass room 160x90", S.glass_room(160, 90, gauss, detail=0.5).desc(), 32, 1e-3),
                                  ("material zoo 32x32", RS.zoo(gauss, None).desc(), 64, 1e-3),

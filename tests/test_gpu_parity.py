@@ -435,7 +435,7 @@ def test_reference_built_pyramids_and_pin_scenes(gpu, oracle, gauss):
     from test_golden import _golden_mip, G
     from mitsuba_amd.integrator import DirectHIP
     fixture = np.load(os.path.join(G, "ref_renders.npz"))
-    for build in (RS.envmap, RS.textures, RS.zoo, RS.const_env):
+    for build in (RS.envmap, RS.textures, RS.roughness_maps, RS.zoo, RS.const_env):
         desc = build(gauss, _golden_mip(fixture, build.__name__)).desc()
         same, r = compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=6)
         print("%s: identical %.6f rel L2 %.3e" % (build.__name__, same, r))

@@ -99,3 +99,31 @@ def test_degenerate_inputs(phip):
     w, info = host_trace(phip, P.reshape(-1, 3), T, rays, 1)
     b, _ = host_trace(phip, P.reshape(-1, 3), T, rays, 0)
     assert (w[:, 0].view(np.uint32) == b[:, 0].view(np.uint32)).all()
+
+
+def test_answer_does_not_depend_on_the_structure(phip, gauss, monkeypatch):
+    """binned-SAH tree, spatial splits, cheaper / dearer traversal constants (different leaf contents and traversal orders), 8-wide
+    tree and the plain sweep over the records: the same (t, u, v, prim) for every ray, bit for bit -- including the rays that hit the
+    atrium's coincident wall panels, where two triangles report exactly the same distance (the highest index wins: winsTie; the node
+    boxes are padded so that a tie at the current maxt is never culled: bvh.h pad())"""
+    sb = S.atrium(64, 36, gauss, detail=0.5)
+    desc = sb.desc()
+    P = np.ctypeslib.as_array(desc.positions, shape=(desc.n_vertices, 3)).copy()
+    T = np.ctypeslib.as_array(desc.indices, shape=(desc.n_triangles, 3)).copy()
+    rng = np.random.default_rng(11)
+    rays = rays_through(rng, 60000, P.min(axis=0), P.max(axis=0), axis_aligned=0.05)
+    answers = []
+    for env in ({"PHIP_BVH_SPATIAL": "0"}, {"PHIP_BVH_SPATIAL": "1"}, {"PHIP_BVH_SPATIAL": "1", "PHIP_BVH_CTRAV": "0.4", "PHIP_BVH_ALPHA": "1e-7"},
+                {"PHIP_BVH_SPATIAL": "0", "PHIP_BVH_CTRAV": "2.5", "PHIP_BVH_MAXLEAF": "8"}):
+        for k in ("PHIP_BVH_SPATIAL", "PHIP_BVH_CTRAV", "PHIP_BVH_ALPHA", "PHIP_BVH_MAXLEAF"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        w, info = host_trace(phip, P, T, rays, 1)
+        answers.append((env, w.view(np.uint32).copy(), info.n_triangle_refs))
+    b, _ = host_trace(phip, P, T, rays, 0)
+    ties = 0
+    for env, w, refs in answers:
+        assert (w == answers[0][1]).all(), env
+        assert (w == b.view(np.uint32)).all(), env
+    assert answers[1][2] > answers[0][2] == desc.n_triangles          # the spatial builds did duplicate references
