@@ -195,7 +195,14 @@ typedef enum phip_sampler_kind {
     PHIP_SAMPLER_CTR = 0     /* counter-based (pixel, sample, dimension) stream -- the parity stream.  `seed` selects the
                                 stream: the Mitsuba shim maps the scene's `independent` sampler here (its SFMT stream is
                                 a per-worker sequential generator, src/samplers/independent.cpp:71-103, that no parallel
-                                schedule can reproduce) and rejects the QMC samplers. */
+                                schedule can reproduce). */
+    , PHIP_SAMPLER_LD = 1    /* (ABI 5) the construction of `ldsampler` (src/samplers/ldsampler.cpp): the first 4 2D requests of a sample
+                                (pixel jitter, emitter / BSDF samples of the first vertices) and its first 4 1D requests (Russian
+                                roulette) are points of randomly scrambled (0,2)-sequences (core/qmc.h) visited in a random order per
+                                pixel and dimension, later requests fall back to the counter stream -- with the scrambles and the
+                                order taken from the counter-based generator instead of the worker's sequential Random, so the
+                                stream is addressable and reproducible.  The sample count of the whole render (`sample_total`,
+                                else `spp`) must be a power of two (ldsampler.cpp:83-87 rounds it up); `path` only. */
 } phip_sampler_kind;
 
 /* which SamplingIntegrator::Li the call evaluates */

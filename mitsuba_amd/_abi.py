@@ -12,6 +12,7 @@ PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCE
 PHIP_BSDF_DIFFUSE, PHIP_BSDF_DIELECTRIC, PHIP_BSDF_ROUGHCONDUCTOR, PHIP_BSDF_TWOSIDED = 0, 1, 2, 3
 PHIP_MF_BECKMANN, PHIP_MF_GGX = 0, 1
 PHIP_SAMPLER_CTR = 0
+PHIP_SAMPLER_LD = 1
 PHIP_INTEGRATOR_PATH, PHIP_INTEGRATOR_DIRECT = 0, 1
 PHIP_FLAG_KERNEL_TIMING = 1
 PHIP_FLAG_SAMPLE_BUFFER = 2

@@ -237,4 +237,48 @@ DV U4 pcg4d(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
 }
 DV float u32ToFloat(uint32_t u) { return pm_from_bits((u >> 9) | 0x3f800000u) - 1.0f; }
 
+/* ---- PHIP_SAMPLER_LD: the construction of src/samplers/ldsampler.cpp (per pixel and dimension a randomly scrambled (0,2)-sequence
+ * in a random order, ldsampler.cpp:151-186) with the scrambles and the order drawn from the counter-based generator instead of the
+ * worker's sequential Random, so that every (pixel, sample, dimension) is addressable.  Point construction: include/mitsuba/core/qmc.h. */
+#define LD_DIMENSIONS 4u               /* ldsampler's `dimension` default: that many 1D and 2D requests per sample are stratified (ldsampler.cpp:79) */
+DV float radicalInverse2Single(uint32_t n, uint32_t scramble) {      /* qmc.h:43-59: van der Corput, 24 bits */
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x00ff00ffu) << 8) | ((n & 0xff00ff00u) >> 8);
+    n = ((n & 0x0f0f0f0fu) << 4) | ((n & 0xf0f0f0f0u) >> 4);
+    n = ((n & 0x33333333u) << 2) | ((n & 0xccccccccu) >> 2);
+    n = ((n & 0x55555555u) << 1) | ((n & 0xaaaaaaaau) >> 1);
+    n = (n >> 8) ^ (scramble & 0x00ffffffu);
+    return (float) n / 16777216.0f;
+}
+DV float sobol2Single(uint32_t n, uint32_t scramble) {               /* qmc.h:82-87 (may round to 1.0f, as in the reference) */
+    for (uint32_t v = 1u << 31; n != 0; n >>= 1, v ^= v >> 1)
+        if (n & 1u) scramble ^= v;
+    return (float) scramble / 4294967296.0f;
+}
+/* a keyed pseudo-random permutation of [0, mask] (mask = 2^m - 1): the "random order" (Random::shuffle, ldsampler.cpp:163,186) */
+DV uint32_t ldPermute(uint32_t i, uint32_t mask, uint32_t key) {
+    /* A. Kensler, "Correlated Multi-Jittered Sampling", Pixar TR 13-01, listing `permute` for a power-of-two domain (no cycle walking):
+       multiplications by odd constants and xor-shifts, all confined to the low bits */
+    i ^= key;                i *= 0xe170893du;
+    i ^= key >> 16;
+    i ^= (i & mask) >> 4;
+    i ^= key >> 8;           i *= 0x0929eb3fu;
+    i ^= key >> 23;
+    i ^= (i & mask) >> 1;    i *= 1u | key >> 27;
+                             i *= 0x6935fa69u;
+    i ^= (i & mask) >> 11;   i *= 0x74dcb303u;
+    i ^= (i & mask) >> 2;    i *= 0x9e501cc3u;
+    i ^= (i & mask) >> 2;    i *= 0xc860a3dfu;
+    i &= mask;
+    i ^= i >> 5;
+    return (i + key) & mask;
+}
+/* the request `dim` (2D: 2 * q, 1D: 2 * j + 1) of sample `k` of `pixel`; mask = sampleCount - 1 (a power of two, ldsampler.cpp:83-87) */
+DV void ldPoint(uint32_t pixel, uint32_t k, uint32_t dim, uint32_t seed, uint32_t mask, float &x, float &y) {
+    const U4 h = pcg4d(pixel, dim, 0x4c44u /* 'LD' */, seed);
+    const uint32_t i = ldPermute(k & mask, mask, h.x);
+    x = radicalInverse2Single(i, h.y);
+    y = sobol2Single(i, h.z);
+}
+
 } // namespace pt

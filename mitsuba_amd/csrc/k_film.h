@@ -46,8 +46,8 @@ __global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, cons
             const uint32_t m = spreadBits((uint32_t) (sx - offX)) | (spreadBits((uint32_t) (sy - offY)) << 1);
             const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
             for (uint32_t k = 0; k < rc.sppPass; ++k) {
-                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
-                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
+                const V2 jit = streamJitter(rc, pixel, k + rc.sppFirst);
+                const float px = (float) sx + jit.x, py = (float) sy + jit.y;
                 const float posx = px - 0.5f - (float) (offX - F.border), posy = py - 0.5f - (float) (offY - F.border);
                 const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), bw - 1);
                 const int miny = max((int) ceilf(posy - F.radius), 0), maxy = min((int) floorf(posy + F.radius), bh - 1);
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc
                 const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
                 const int4 g = sGeo[i];
                 const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
-                const U4 h = pcg4d(pixel, k + rc.sppFirst, 0, rc.seed);
-                const float px = (float) sx + u32ToFloat(h.x), py = (float) sy + u32ToFloat(h.y);
+                const V2 jit = streamJitter(rc, pixel, k + rc.sppFirst);
+                const float px = (float) sx + jit.x, py = (float) sy + jit.y;
                 const float posx = px - 0.5f - (float) g.x, posy = py - 0.5f - (float) g.y;   /* block-bitmap coordinates */
                 v = pre[n];
                 /* validity check of ImageBlock::put (imageblock.h:148-151) */

@@ -85,8 +85,8 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
                 uint32_t px, py, k;
                 if (decodeId(rc, S.film, id, px, py, k)) {      /* ids outside the crop window (edge blocks) are consumed and skipped */
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
-                    const U4 h = pcg4d(pixel, k, 0, rc.seed);
-                    const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+                    const V2 jit = streamJitter(rc, pixel, k);
+                    const float sx = (float) px + jit.x, sy = (float) py + jit.y;
                     V3 o, d; float mint, maxt;
                     cameraRay(S.cam, sx, sy, o, d, mint, maxt);
                     v.rayO = make_float4(o.x, o.y, o.z, mint);

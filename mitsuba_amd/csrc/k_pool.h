@@ -82,6 +82,7 @@ struct RenderConst {
     uint32_t nLocalTiles;
     int maxDepth, rrDepth, strictNormals, hideEmitters;
     uint32_t seed;
+    uint32_t sampler, ldMask;         /* phip_sampler_kind; PHIP_SAMPLER_LD: sampleCount - 1 of the whole render (a power of two) */
     float diffScaleFactor;            /* 1 / sqrt(spp) of the whole render: RayDifferential::scaleDifferential, integrator.cpp:144-145,181 */
     /* `direct` (direct.cpp:130-138): sample counts, MIS fractions and per-sample weights */
     int emitterSamples, bsdfSamples;
@@ -113,6 +114,15 @@ __host__ __device__ __forceinline__ uint32_t spreadBits(uint32_t x) {
     x = (x ^ (x << 2)) & 0x33333333u;
     x = (x ^ (x << 1)) & 0x55555555u;
     return x;
+}
+
+/* ---- the sample stream: what the `c`-th request of a sample returns.  PHIP_SAMPLER_CTR: words of pcg4d blocks;
+ *      PHIP_SAMPLER_LD: the first LD_DIMENSIONS 2D requests (the pixel jitter is request 0) and 1D requests of a sample come from
+ *      scrambled (0,2)-sequences, later ones from the counter stream -- next1D / next2D of ldsampler.cpp:212-226 ---- */
+__device__ __forceinline__ V2 streamJitter(const RenderConst &rc, uint32_t pixel, uint32_t k) {
+    if (rc.sampler == PHIP_SAMPLER_LD) { float x, y; ldPoint(pixel, k, 0u, rc.seed, rc.ldMask, x, y); return V2(x, y); }
+    const U4 h = pcg4d(pixel, k, 0, rc.seed);
+    return V2(u32ToFloat(h.x), u32ToFloat(h.y));
 }
 
 /* sample id -> (local tile, sample-in-pass, pixel); ids are tile-major, then sample, then the

@@ -102,8 +102,8 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         uint32_t px, py, k;
         decodeId(rc, S.film, newId, px, py, k);
         const uint32_t pixel = py * (uint32_t) S.film.width + px;
-        const U4 h = pcg4d(pixel, k, 0, rc.seed);
-        const float sx = (float) px + u32ToFloat(h.x), sy = (float) py + u32ToFloat(h.y);
+        const V2 jit = streamJitter(rc, pixel, k);
+        const float sx = (float) px + jit.x, sy = (float) py + jit.y;
         V3 o, d; float mint, maxt;
         cameraRay(S.cam, sx, sy, o, d, mint, maxt);
         P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
@@ -194,9 +194,9 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                         /* the camera ray is the one ray with differentials: filtered lookup, envmap.cpp:395-407.
                            Its sample position is recomputed from the counter stream (a rare branch) */
                         const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
-                        const U4 hc = pcg4d(v.pixel, v.k, 0, rc.seed);
+                        const V2 hc = streamJitter(rc, v.pixel, v.k);
                         V3 rx, ry;
-                        cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
+                        cameraRayDifferentials(S.cam, (float) px + hc.x, (float) py + hc.y, rx, ry);
                         rx = rayD + (rx - rayD) * rc.diffScaleFactor;
                         ry = rayD + (ry - rayD) * rc.diffScaleFactor;
                         bg = envmapEvalDiff(S.env, rayD, rx, ry);
@@ -240,8 +240,13 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             flags &= ~F_EMITTED;
             if (depth++ >= (uint32_t) rc.rrDepth) {
                 float q = smin(thr.maxc() * eta * eta, 0.95f);
-                const U4 h = pcg4d(v.pixel, v.k, 2 + 2 * (depth - 2), rc.seed);
-                if (u32ToFloat(h.x) >= q)
+                /* the (depth - 1 - rrDepth)-th 1D request of the sample (path.cpp:283) */
+                float rr;
+                if (rc.sampler == PHIP_SAMPLER_LD && depth - 1u - (uint32_t) rc.rrDepth < LD_DIMENSIONS) {
+                    float unused; ldPoint(v.pixel, v.k, 2u * (depth - 1u - (uint32_t) rc.rrDepth) + 1u, rc.seed, rc.ldMask, rr, unused);
+                } else
+                    rr = u32ToFloat(pcg4d(v.pixel, v.k, 2 + 2 * (depth - 2), rc.seed).x);
+                if (rr >= q)
                     terminate = true;
                 else
                     thr = thr / q;
@@ -279,6 +284,17 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 else h = U4{ h.z, h.w, h.z, h.w };
             }
             if (!smoothVertex) { h.z = h.x; h.w = h.y; flags += 1u << NS_SHIFT; }      /* its one request is the BSDF sample */
+            V2 smpEmitter(u32ToFloat(h.x), u32ToFloat(h.y)), smpBSDF(u32ToFloat(h.z), u32ToFloat(h.w));
+            if (rc.sampler == PHIP_SAMPLER_LD) {
+                /* 2D requests k0 + 1 (and k0 + 2 at a smooth vertex) of the sample, the pixel jitter being request 0: the first
+                   LD_DIMENSIONS come from the scrambled (0,2)-sequences (ldsampler.cpp:218-224) */
+                const uint32_t q = k0 + 1u;
+                if (smoothVertex) {
+                    if (q < LD_DIMENSIONS) ldPoint(v.pixel, v.k, 2u * q, rc.seed, rc.ldMask, smpEmitter.x, smpEmitter.y);
+                    if (q + 1u < LD_DIMENSIONS) ldPoint(v.pixel, v.k, 2u * (q + 1u), rc.seed, rc.ldMask, smpBSDF.x, smpBSDF.y);
+                } else if (q < LD_DIMENSIONS)
+                    ldPoint(v.pixel, v.k, 2u * q, rc.seed, rc.ldMask, smpBSDF.x, smpBSDF.y);
+            }
             /* ---- direct illumination sampling, path.cpp:172-200 ---- */
             DirectRec dRec;
             dRec.ref = its.p;
@@ -291,9 +307,9 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
                 if (firstVertex) {
                     const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
-                    const U4 hc = pcg4d(v.pixel, v.k, 0, rc.seed);
+                    const V2 hc = streamJitter(rc, v.pixel, v.k);
                     V3 rx, ry;
-                    cameraRayDifferentials(S.cam, (float) px + u32ToFloat(hc.x), (float) py + u32ToFloat(hc.y), rx, ry);
+                    cameraRayDifferentials(S.cam, (float) px + hc.x, (float) py + hc.y, rx, ry);
                     rx = rayD + (rx - rayD) * rc.diffScaleFactor;
                     ry = rayD + (ry - rayD) * rc.diffScaleFactor;
                     const float *cw = S.cam.c2w;
@@ -302,7 +318,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 bsdfTextures(S, bctx, its.uv, firstVertex, dudx, dudy, dvdx, dvdy);
             }
             if (its.flags & TS_MF_SMOOTH) {
-                V3 value = sampleEmitterDirect<ENV>(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
+                V3 value = sampleEmitterDirect<ENV>(S, T, dRec, smpEmitter);
                 if (dRec.pdf != 0 && !value.isZero()) {
                     const V3 wo = its.sh.toLocal(dRec.d);
                     float bPdf;
@@ -317,7 +333,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             }
             /* ---- BSDF sampling, path.cpp:207-226 ---- */
             BSDFSample bs;
-            const V3 bsdfWeight = bsdfSample<MM>(bctx, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
+            const V3 bsdfWeight = bsdfSample<MM>(bctx, smpBSDF, bs);
             if (bsdfWeight.isZero()) {
                 terminate = true;
             } else {

@@ -51,8 +51,8 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
 
         /* the camera ray of this sample: direction, differentials (integrator.cpp:171-181) */
         const uint32_t px = info.y % (uint32_t) S.film.width, py = info.y / (uint32_t) S.film.width;
-        const U4 hc = pcg4d(info.y, info.z, 0, rc.seed);
-        const float sx = (float) px + u32ToFloat(hc.x), sy = (float) py + u32ToFloat(hc.y);
+        const V2 hc = streamJitter(rc, info.y, info.z);
+        const float sx = (float) px + hc.x, sy = (float) py + hc.y;
         V3 camD;
         if (first) {
             camD = V3(rd.x, rd.y, rd.z);

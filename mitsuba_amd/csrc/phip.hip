@@ -757,7 +757,12 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
         if (p->emitter_samples + p->bsdf_samples <= 0) throw std::invalid_argument("direct: emitterSamples + bsdfSamples must be > 0");     /* Assert, direct.cpp:107 */
         if (p->emitter_samples + p->bsdf_samples >= (int) DEPTH_MASK) throw std::invalid_argument("direct: at most 65534 shading samples per camera sample");
     }
-    if (p->sampler != PHIP_SAMPLER_CTR) throw std::invalid_argument("unknown sampler kind");
+    if (p->sampler != PHIP_SAMPLER_CTR && p->sampler != PHIP_SAMPLER_LD) throw std::invalid_argument("unknown sampler kind");
+    if (p->sampler == PHIP_SAMPLER_LD) {
+        if (p->integrator != PHIP_INTEGRATOR_PATH) throw std::invalid_argument("PHIP_SAMPLER_LD is implemented for the path tracer only");
+        const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
+        if (n == 0 || (n & (n - 1))) throw std::invalid_argument("PHIP_SAMPLER_LD: the sample count of the render must be a power of two (ldsampler.cpp:83-87)");
+    }
     if (p->sample_offset < 0 || p->sample_total < 0) throw std::invalid_argument("sample_offset / sample_total must not be negative");
     if (p->sample_total != 0 && (long long) p->sample_offset + p->spp > p->sample_total) throw std::invalid_argument("sample_offset + spp exceeds sample_total");
     if ((p->flags & PHIP_FLAG_SAMPLE_BUFFER) && (p->flags & PHIP_FLAG_ACCUMULATE))
@@ -937,6 +942,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         rc.totalIds = idsPerSpp * rc.sppPass;
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
         rc.seed = p->seed; rc.tileOrigin = sd.tileOrigin.p; rc.countAlive = 0;
+        rc.sampler = (uint32_t) p->sampler; rc.ldMask = (uint32_t) (p->sample_total > 0 ? p->sample_total : p->spp) - 1u;
         rc.diffScaleFactor = 1.0f / sqrtf((float) (p->sample_total > 0 ? p->sample_total : p->spp));
         rc.emitterSamples = direct ? p->emitter_samples : 0; rc.bsdfSamples = direct ? p->bsdf_samples : 0;
         if (direct) {   /* direct.cpp:130-138 */

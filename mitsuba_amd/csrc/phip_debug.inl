@@ -92,6 +92,11 @@ void phip_debug_host_ctr_block(uint32_t pixel, uint32_t sample, uint32_t block, 
     out4[0] = u32ToFloat(h.x); out4[1] = u32ToFloat(h.y); out4[2] = u32ToFloat(h.z); out4[3] = u32ToFloat(h.w);
 }
 
+/* PHIP_SAMPLER_LD: the point of request `dim` (2D request q: 2 q; 1D request j: 2 j + 1) of sample `sample` of `pixel` -- the code the kernels compile */
+void phip_debug_host_ld_point(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed, uint32_t mask, float *out2) {
+    ldPoint(pixel, sample, dim, seed, mask, out2[0], out2[1]);
+}
+
 /* Wald records + BVH statistics of a triangle soup, built exactly like phip_scene_create does (no GPU needed) */
 int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles,
                               phip_accel_info *info, float *scene_box6) {

@@ -170,9 +170,23 @@ public:
     /* The scene's <sampler> (src/librender/integrator.cpp:104,169 clone it per worker): `independent` is honoured as "independent
        uniform samples" -- its SFMT stream is one sequential generator per worker thread (independent.cpp:71-103), which no
        parallel schedule reproduces, not even the reference's own from run to run (independent.cpp:42-45) -- so the device's
-       counter-based stream stands in, which is said once; a QMC sampler would silently lose its stratification: an error. */
-    static void checkSampler(const Sampler *sampler, const char *name) {
+       counter-based stream stands in, which is said once.  `ldsampler` maps to PHIP_SAMPLER_LD: the same construction (scrambled
+       (0,2)-sequences in a random order per pixel and dimension for the first four 1D / 2D requests of a sample, ldsampler.cpp:151-226)
+       with the scrambles and the order drawn from the counter-based generator instead of the worker's Random -- `path_hip` only,
+       default `dimension` only.  Any other QMC sampler would silently lose its stratification: an error. */
+    static int checkSampler(const Sampler *sampler, const char *name, bool pathTracer) {
         const std::string cls = sampler->getClass()->getName();
+        if (cls == "LowDiscrepancySampler" && pathTracer) {
+            if (sampler->getProperties().getSize("dimension", 4) != 4)
+                SLog(EError, "%s: ldsampler with dimension != 4 is not supported", name);
+            static bool toldLD = false;
+            if (!toldLD) {
+                toldLD = true;
+                SLog(EWarn, "%s: 'ldsampler' is served by the device's low-discrepancy stream (the same scrambled (0,2)-sequences per pixel and "
+                            "dimension, scrambles from the counter-based generator): the same stratification, not the same numbers as the CPU integrator", name);
+            }
+            return PHIP_SAMPLER_LD;
+        }
         if (cls == "IndependentSampler") {
             static bool told = false;
             if (!told) {
@@ -180,9 +194,10 @@ public:
                 SLog(EWarn, "%s: the 'independent' sampler is served by the device's counter-based stream (pcg4d(pixel, sample, dimension), seed 0): "
                             "statistically equivalent, not the same random numbers as the CPU integrator", name);
             }
-            return;
+            return PHIP_SAMPLER_CTR;
         }
-        SLog(EError, "%s: sampler \"%s\" is not supported (only 'independent'; QMC samplers would lose their stratification)", name, cls.c_str());
+        SLog(EError, "%s: sampler \"%s\" is not supported ('independent'; 'ldsampler' with path_hip; other QMC samplers would lose their stratification)", name, cls.c_str());
+        return PHIP_SAMPLER_CTR;
     }
 
     /* SamplingIntegrator::render (integrator.cpp:95-129) + BlockedRenderProcess (renderproc.cpp:142-176): the job runs as a few
@@ -194,11 +209,11 @@ public:
         ref<Film> film = sensor->getFilm();
         const Vector2i size = film->getCropSize();
         const Sampler *sampler = scene->getSampler();
-        checkSampler(sampler, name);
+        const int samplerKind = checkSampler(sampler, name, rp.integrator == PHIP_INTEGRATOR_PATH);
         const size_t spp = sampler->getSampleCount();
         SLog(EInfo, "Starting render job (%ix%i, " SIZE_T_FMT " samples, %s) ..", size.x, size.y, spp, phip_version());
         rp.block_size = (int32_t) scene->getBlockSize();
-        rp.sampler = PHIP_SAMPLER_CTR; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
+        rp.sampler = samplerKind; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
         int nDev = m_deviceCount == 0 ? phip_device_count() - m_device : m_deviceCount;
         if (nDev > PHIP_MAX_DEVICES) nDev = PHIP_MAX_DEVICES;
         if (nDev > 1) { rp.n_devices = nDev; for (int i = 0; i < nDev; ++i) rp.devices[i] = m_device + i; }

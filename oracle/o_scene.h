@@ -131,10 +131,52 @@ inline float u32ToFloat(uint32_t u) {
     uint32_t b = (u >> 9) | 0x3f800000u; float f; memcpy(&f, &b, 4); return f - 1.0f;
 }
 
+/* ---- PHIP_SAMPLER_LD: ldsampler.cpp's construction on the counter-based generator.  Points: core/qmc.h:43-59,82-87 ---- */
+inline float radicalInverse2Single(uint32_t n, uint32_t scramble) {
+    n = __builtin_bswap32(n);
+    n = ((n & 0x0f0f0f0f) << 4) | ((n & 0xf0f0f0f0) >> 4);
+    n = ((n & 0x33333333) << 2) | ((n & 0xcccccccc) >> 2);
+    n = ((n & 0x55555555) << 1) | ((n & 0xaaaaaaaa) >> 1);
+    n = (n >> (32 - 24)) ^ (scramble & ~-(1 << 24));
+    return (float) n / (float) (1U << 24);
+}
+inline float sobol2Single(uint32_t n, uint32_t scramble) {
+    for (uint32_t v = 1U << 31; n != 0; n >>= 1, v ^= v >> 1)
+        if (n & 1) scramble ^= v;
+    return (float) scramble / (float) (1ULL << 32);
+}
+/* the keyed bijection of [0, mask] that stands in for Random::shuffle (every step is invertible modulo mask + 1) */
+inline uint32_t ldPermute(uint32_t i, uint32_t mask, uint32_t key) {
+    /* A. Kensler, "Correlated Multi-Jittered Sampling", Pixar TR 13-01, listing `permute` for a power-of-two domain (no cycle walking):
+       multiplications by odd constants and xor-shifts, all confined to the low bits */
+    i ^= key;                i *= 0xe170893du;
+    i ^= key >> 16;
+    i ^= (i & mask) >> 4;
+    i ^= key >> 8;           i *= 0x0929eb3fu;
+    i ^= key >> 23;
+    i ^= (i & mask) >> 1;    i *= 1u | key >> 27;
+                             i *= 0x6935fa69u;
+    i ^= (i & mask) >> 11;   i *= 0x74dcb303u;
+    i ^= (i & mask) >> 2;    i *= 0x9e501cc3u;
+    i ^= (i & mask) >> 2;    i *= 0xc860a3dfu;
+    i &= mask;
+    i ^= i >> 5;
+    return (i + key) & mask;
+}
+static const uint32_t LD_DIMENSIONS = 4;     /* ldsampler.cpp:79 */
+
 struct SampleSource {
     /* ctr mode */
     bool ctr = true;
     uint32_t pixel = 0, sample = 0, seed = 0;
+    /* ld mode (on top of ctr): the first LD_DIMENSIONS 2D requests (the pixel jitter is request 0) and 1D requests of a sample */
+    bool ld = false; uint32_t ldMask = 0; int rrDepth = 5;
+    Vec2 ldPoint(uint32_t dim) const {
+        uint32_t h[4] = { pixel, dim, 0x4c44u, seed };
+        pcg4d(h);
+        const uint32_t i = ldPermute(sample & ldMask, ldMask, h[0]);
+        return Vec2(radicalInverse2Single(i, h[1]), sobol2Single(i, h[2]));
+    }
     /* sfmt mode */
     SFMT *rng = nullptr;
 
@@ -148,10 +190,14 @@ struct SampleSource {
        requests (emitter sample, BSDF sample), a vertex without (dielectric) one: k = 2 (depth - 1) - ns at the start of vertex
        `depth`, ns = non-smooth vertices so far (modulo 64: six bits of device state). */
     uint32_t ns = 0;
-    Vec2 pair(uint32_t k) const { float f[4]; block(1 + 2 * (k >> 1), f); return (k & 1u) ? Vec2(f[2], f[3]) : Vec2(f[0], f[1]); }
+    Vec2 pair(uint32_t k) const {
+        if (ld && k + 1 < LD_DIMENSIONS) return ldPoint(2 * (k + 1));
+        float f[4]; block(1 + 2 * (k >> 1), f); return (k & 1u) ? Vec2(f[2], f[3]) : Vec2(f[0], f[1]);
+    }
     Vec2 cameraSample() {
         if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
         ns = 0;
+        if (ld) return ldPoint(0);
         float f[4]; block(0, f); return Vec2(f[0], f[1]);
     }
     Vec2 emitterSample(int depth) {                      /* (only requested at vertices with a smooth BSDF, path.cpp:174-176) */
@@ -166,6 +212,7 @@ struct SampleSource {
     }
     Float rrSample(int depth) {
         if (!ctr) return rng->nextFloat();
+        if (ld && (uint32_t) (depth - rrDepth) < LD_DIMENSIONS) return ldPoint(2 * (uint32_t) (depth - rrDepth) + 1).x;   /* the (depth - rrDepth)-th 1D request */
         float f[4]; block(2 + 2 * (uint32_t) (depth - 1), f); return f[0];
     }
 

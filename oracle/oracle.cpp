@@ -65,6 +65,12 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
         rp.ctr = sampler_mode == 0; rp.seed = p->seed;
         rp.shardIndex = p->shard_index; rp.shardCount = p->shard_count > 0 ? p->shard_count : 1;
         rp.sampleOffset = p->sample_offset; rp.sampleTotal = p->sample_total;
+        rp.ld = p->sampler == PHIP_SAMPLER_LD;
+        if (rp.ld) {
+            const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
+            if (sampler_mode != 0 || p->integrator != PHIP_INTEGRATOR_PATH || n == 0 || (n & (n - 1)))
+                throw std::runtime_error("PHIP_SAMPLER_LD: path tracer on the counter stream, power-of-two sample count");
+        }
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
         if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::runtime_error("unknown integrator");
         if (rp.direct) {
@@ -137,6 +143,7 @@ int oracle_path_sample(void *scene_, const phip_render_params *p, int px, int py
         IntegratorParams ip; ip.maxDepth = p->max_depth; ip.rrDepth = p->rr_depth; ip.strictNormals = p->strict_normals != 0; ip.hideEmitters = p->hide_emitters != 0;
         SampleSource smp; smp.ctr = true; smp.seed = p->seed; smp.rng = nullptr;
         smp.pixel = (uint32_t) (py * f.crop_width + px); smp.sample = (uint32_t) k;
+        smp.ld = p->sampler == PHIP_SAMPLER_LD; smp.ldMask = (uint32_t) (p->sample_total > 0 ? p->sample_total : p->spp) - 1u; smp.rrDepth = p->rr_depth;
         const Float diffScaleFactor = 1.0f / std::sqrt((Float) (p->sample_total > 0 ? p->sample_total : p->spp));
         Vec2 jit = smp.cameraSample();
         Vec2 samplePos((Float) px + jit.x, (Float) py + jit.y);
@@ -201,6 +208,10 @@ void oracle_sfmt_floats(uint64_t seed, int clone, size_t n, float *out) {
     SFMT parent(seed);
     if (clone) { SFMT child; child.seedFrom(parent); for (size_t i = 0; i < n; ++i) out[i] = child.nextFloat(); }
     else for (size_t i = 0; i < n; ++i) out[i] = parent.nextFloat();
+}
+void oracle_ld_point(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed, uint32_t mask, float *out2) {
+    SampleSource s; s.pixel = pixel; s.sample = sample; s.seed = seed; s.ld = true; s.ldMask = mask;
+    const Vec2 p = s.ldPoint(dim); out2[0] = p.x; out2[1] = p.y;
 }
 void oracle_ctr_block(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, float *out4) {
     SampleSource s; s.pixel = pixel; s.sample = sample; s.seed = seed; s.block(block, out4);

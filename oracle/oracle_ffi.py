@@ -51,6 +51,7 @@ def lib(libm=False):
     L.oracle_sfmt_words.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64)]
     L.oracle_sfmt_floats.argtypes = [C.c_uint64, C.c_int, C.c_size_t, fp]
     L.oracle_ctr_block.argtypes = [u32, u32, u32, u32, fp]
+    L.oracle_ld_point.argtypes = [u32, u32, u32, u32, u32, fp]
     L.oracle_clipped_aabb.argtypes = [fp, fp, fp]
     L.oracle_bsdf_sample.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]
     L.oracle_bsdf_eval_pdf.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp]

@@ -121,7 +121,7 @@ class RefScene:
             raise RuntimeError(what + ": " + self.L.ref_last_error().decode())
 
     def _sampler(self, sampler):
-        self.L.ref_set_sampler(1 if sampler == "ctr" else 0)
+        self.L.ref_set_sampler({"independent": 0, "ctr": 1, "ldsampler": 2}[sampler])
 
     def render(self, params, want_samples=True, sampler="independent"):
         """sampler="ctr": the reference's integrator fed with the counter-based parity stream (ref_glue/ctr_sampler.cpp: defined by

@@ -12,9 +12,12 @@
  *             2 + 2 (rrDepth - 1 + j).
  *   `direct`: the sample counts tell which 2D calls are single samples (direct.cpp:212-216,251-255); arrays as in generate().
  * Nothing about the scene is needed (round 1 needed the oracle's per-sample smooth-vertex masks for scenes with dielectrics).
+ * ld = true (`path` only): PHIP_SAMPLER_LD -- the first four 2D and the first four 1D requests of a sample are points of scrambled
+ * (0,2)-sequences in a keyed order (include/phip.h), made with the reference's own qmc.h functions.
  */
 #include <mitsuba/render/sampler.h>
 #include <mitsuba/render/scene.h>
+#include <mitsuba/core/qmc.h>     /* PHIP_SAMPLER_LD: the reference's own radicalInverse2Single / sobol2Single make the points */
 
 MTS_NAMESPACE_BEGIN
 
@@ -28,6 +31,8 @@ public:
         m_emitterSamples = props.getSize("emitterSamples", 1);
         m_bsdfSamples = props.getSize("bsdfSamples", 1);
         m_rrFirst = (uint32_t) props.getInteger("rrDepth", 5);
+        m_ld = props.getBoolean("ld", false);
+        m_ldMask = (uint32_t) props.getSize("sampleTotal", m_sampleCount) - 1u;
         m_pixel = 0; m_call2D = 0; m_call1D = 0;
     }
     CtrSampler(Stream *stream, InstanceManager *manager) : Sampler(stream, manager) { Log(EError, "ctr sampler: not serializable"); }
@@ -36,6 +41,7 @@ public:
         ref<CtrSampler> s = new CtrSampler(getProperties());
         s->m_sampleCount = m_sampleCount; s->m_seed = m_seed; s->m_width = m_width; s->m_direct = m_direct;
         s->m_emitterSamples = m_emitterSamples; s->m_bsdfSamples = m_bsdfSamples; s->m_rrFirst = m_rrFirst;
+        s->m_ld = m_ld; s->m_ldMask = m_ldMask;
         for (size_t i = 0; i < m_req1D.size(); ++i) s->request1DArray(m_req1D[i]);
         for (size_t i = 0; i < m_req2D.size(); ++i) s->request2DArray(m_req2D[i]);
         return s.get();
@@ -64,6 +70,7 @@ public:
     Point2 next2D() {
         float f[4];
         const uint32_t call = m_call2D++;
+        if (m_ld && !m_direct && call < 4) return ldPoint(2 * call);                                /* ldsampler.cpp:218-224 */
         if (call == 0) { block((uint32_t) m_sampleIndex, 0, f); return Point2(f[0], f[1]); }        /* integrator.cpp:171 */
         if (m_direct) {
             /* direct.cpp:212-216: a single emitter sample (also drawn when emitterSamples == 0); :251-255 the same for the BSDF */
@@ -77,7 +84,9 @@ public:
         return (k & 1u) ? Point2(f[2], f[3]) : Point2(f[0], f[1]);
     }
     Float next1D() {                                                                                /* path.cpp:283, Russian roulette */
-        float f[4]; block((uint32_t) m_sampleIndex, 2 + 2 * (m_rrFirst - 1 + m_call1D++), f);
+        const uint32_t call = m_call1D++;
+        if (m_ld && !m_direct && call < 4) return ldPoint(2 * call + 1).x;                          /* ldsampler.cpp:212-216 */
+        float f[4]; block((uint32_t) m_sampleIndex, 2 + 2 * (m_rrFirst - 1 + call), f);
         return f[0];
     }
 
@@ -95,6 +104,34 @@ private:
         v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
         for (int i = 0; i < 4; ++i) out[i] = toFloat(v[i]);
     }
+    /* the keyed order (stands in for Random::shuffle, ldsampler.cpp:163,186) and the scrambles: words of pcg4d(pixel, dim, 'LD', seed) */
+    static uint32_t permute(uint32_t i, uint32_t mask, uint32_t key) {
+        /* A. Kensler, "Correlated Multi-Jittered Sampling", Pixar TR 13-01, listing `permute` for a power-of-two domain (no cycle walking):
+           multiplications by odd constants and xor-shifts, all confined to the low bits */
+        i ^= key;                i *= 0xe170893du;
+        i ^= key >> 16;
+        i ^= (i & mask) >> 4;
+        i ^= key >> 8;           i *= 0x0929eb3fu;
+        i ^= key >> 23;
+        i ^= (i & mask) >> 1;    i *= 1u | key >> 27;
+                                 i *= 0x6935fa69u;
+        i ^= (i & mask) >> 11;   i *= 0x74dcb303u;
+        i ^= (i & mask) >> 2;    i *= 0x9e501cc3u;
+        i ^= (i & mask) >> 2;    i *= 0xc860a3dfu;
+        i &= mask;
+        i ^= i >> 5;
+        return (i + key) & mask;
+    }
+    Point2 ldPoint(uint32_t dim) const {
+        uint32_t v[4] = { m_pixel, dim, 0x4c44u, m_seed };
+        for (int i = 0; i < 4; ++i) v[i] = v[i] * 1664525u + 1013904223u;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        const uint32_t i = permute((uint32_t) m_sampleIndex & m_ldMask, m_ldMask, v[0]);
+        return Point2(radicalInverse2Single(i, v[1]), sobol2Single(i, v[2]));
+    }
+    bool m_ld; uint32_t m_ldMask;
     uint32_t m_seed, m_pixel, m_call2D, m_call1D, m_rrFirst;
     int m_width;
     bool m_direct;

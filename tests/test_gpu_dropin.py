@@ -60,19 +60,22 @@ def check_scene(ref, name, desc):
     from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
     rs = ref.RefScene(desc)
     gs = Scene(desc)
-    for plugin, Integ, kw, rkw in (("path_hip", PathHIP, dict(maxDepth=6), dict(max_depth=6)),
-                                   ("direct_hip", DirectHIP, dict(emitterSamples=2, bsdfSamples=2),
-                                    dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2))):
+    for plugin, Integ, kw, rkw, sampler in (("path_hip", PathHIP, dict(maxDepth=6), dict(max_depth=6), "independent"),
+                                           ("path_hip", PathHIP, dict(maxDepth=6), dict(max_depth=6), "ldsampler"),
+                                           ("direct_hip", DirectHIP, dict(emitterSamples=2, bsdfSamples=2),
+                                            dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2), "independent")):
+        # <sampler type="ldsampler"/> in the scene makes the shim select PHIP_SAMPLER_LD (phip_flatten.h: checkSampler)
+        ld = dict(sampler=A.PHIP_SAMPLER_LD) if sampler == "ldsampler" else {}
         p = A.default_render_params(spp=32, **rkw)
-        img, sec = rs.render_job(p, threads=2, plugin=plugin)               # Mitsuba -> plugin shim -> libphip.so -> GPU
+        img, sec = rs.render_job(p, threads=2, plugin=plugin, sampler=sampler)   # Mitsuba -> plugin shim -> libphip.so -> GPU
         film = HDRFilm(gs.width, gs.height)
-        assert Integ(**kw).render(gs, film, 32)                             # ctypes harness -> libphip.so -> GPU
+        assert Integ(**kw).render(gs, film, 32, **ld)                       # ctypes harness -> libphip.so -> GPU
         direct = film.develop()
         assert np.isfinite(img).all() and img.max() > 0
         r = rel_l2(img, direct)
-        print("%s: %s inside Mitsuba vs ctypes harness: rel L2 %.3e (%.3f s)" % (name, plugin, r, sec))
+        print("%s: %s inside Mitsuba (%s) vs ctypes harness: rel L2 %.3e (%.3f s)" % (name, plugin, sampler, r, sec))
         assert r < 1e-5                                                      # same scene after the round trip through Mitsuba's objects
-        cpu, _ = rs.render_job(p, threads=8)                                 # the reference's own integrator on the CPU
+        cpu, _ = rs.render_job(p, threads=8, sampler=sampler)                # the reference's own integrator (and sampler) on the CPU
         dm = abs(img.mean() - cpu.mean()) / cpu.mean()
         print("    vs the reference's CPU %s: mean differs by %.2f %%, rel L2 %.2f" % (plugin.replace("_hip", ""), 100 * dm, rel_l2(img, cpu)))
         assert dm < 0.08                                                     # small, noisy images (32 spp)

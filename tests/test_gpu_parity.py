@@ -38,15 +38,16 @@ def soup(rng, n, size=1.0, extent=10.0):
     return p, idx
 
 
-def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None, **ikw):
+def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None, render_kw=None, **ikw):
+    render_kw = render_kw or {}
     from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
     gs = Scene(desc)
     integ = (integrator or PathHIP)(**ikw)
     film = HDRFilm(gs.width, gs.height)
-    assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
+    assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER, **render_kw)
     gsmp = integ.samples(gs, spp)
     osc = oracle.OracleScene(desc)
-    p = integ.params(gs, spp)           # the same phip_render_params the GPU call received (minus the sample-buffer flag)
+    p = integ.params(gs, spp, **render_kw)           # the same phip_render_params the GPU call received (minus the sample-buffer flag)
     ofilm, osmp, ost = osc.render(p, want_samples=True)
     same = (gsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1)
     if desc.n_triangles <= 512 and not same.all():
@@ -72,7 +73,7 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
     if st.fused:
         # the scene fits LDS, so the fused kernel (k_mega) rendered it: the wavefront kernels must give the same bits
         film2 = HDRFilm(gs.width, gs.height)
-        assert integ.render(gs, film2, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_NO_FUSED)
+        assert integ.render(gs, film2, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_NO_FUSED, **render_kw)
         assert not integ.stats.fused
         wsmp = integ.samples(gs, spp)
         assert (wsmp.view(np.uint32) == gsmp.view(np.uint32)).all(), "fused and wavefront paths differ"
@@ -517,3 +518,36 @@ def test_c2_at_full_size_against_the_oracle(gpu, oracle, gauss):
     r, nbig, dv, dc, ds = out["kd-tree"]
     assert r <= 1e-4 and nbig <= 256 and dv <= 64, out
     gs.close(); osc.close()
+
+
+def test_ld_sampler_matches_oracle(gpu, phip, oracle, gauss):
+    """PHIP_SAMPLER_LD (the construction of ldsampler on the counter-based generator): per-sample radiance bit-identical to the oracle --
+    which is pinned to Mitsuba's own `path` fed with the same points (tests/test_ref_pin.py::test_ld_sampler_on_the_reference) -- on
+    the fused kernel and the wavefront kernels, with dielectrics (request order shifts), an early Russian roulette, several passes
+    (sample_offset) and a seed; the error cases"""
+    import ref_scenes as RS
+    from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+    ld = dict(sampler=A.PHIP_SAMPLER_LD)
+    same, r = compare_render(gpu, oracle, S.cornell_box(64, 64, gauss).desc(), 16, min_identical=1.0, render_kw=ld)
+    same, r = compare_render(gpu, oracle, S.cornell_box(48, 40, gauss).desc(), 8, min_identical=1.0, render_kw=dict(ld, seed=3), rrDepth=2)
+    same, r = compare_render(gpu, oracle, S.glass_room(64, 36, gauss, detail=0.2).desc(), 8, min_identical=0.9999, render_kw=ld, maxDepth=12, rrDepth=3)
+    same, r = compare_render(gpu, oracle, RS.zoo(gauss, None).desc(), 4, min_identical=0.9999, render_kw=ld, maxDepth=8)
+    same, r = compare_render(gpu, oracle, S.atrium(64, 36, gauss, detail=0.3).desc(), 4, min_identical=0.999, render_kw=ld, maxDepth=6)
+    # two passes of 8 of 16 samples = one render of 16
+    desc = S.cornell_box(32, 32, gauss).desc()
+    gs = Scene(desc); integ = PathHIP()
+    whole = HDRFilm(32, 32); assert integ.render(gs, whole, 16, **ld)
+    parts = HDRFilm(32, 32)
+    assert integ.render(gs, parts, 8, sample_offset=0, sample_total=16, **ld)
+    p = integ.params(gs, 8, flags=A.PHIP_FLAG_ACCUMULATE, sample_offset=8, sample_total=16, **ld)
+    acc = parts.storage.copy()
+    st = A.phip_stats()
+    assert phip.phip_render(gs._h, C.byref(p), acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
+    assert rel_l2(acc, whole.storage) < 1e-6
+    # a sample count that is not a power of two; the `direct` integrator
+    from mitsuba_amd._ffi import PhipError
+    with pytest.raises(PhipError):
+        integ.render(gs, HDRFilm(32, 32), 12, **ld)
+    with pytest.raises(PhipError):
+        DirectHIP().render(gs, HDRFilm(32, 32), 16, **ld)
+    gs.close()

@@ -144,3 +144,30 @@ def test_host_mip_eval_matches_the_oracle(oracle, phip):
         assert Lo.oracle_mip_eval(C.byref(t), n, fp(uv), fp(d0), fp(d1), fp(b)) == 0
         ok = (a.view(np.uint32) == b.view(np.uint32)).all(-1) | (np.isnan(a).all(-1) & np.isnan(b).all(-1))
         assert ok.all(), (trial, int((~ok).sum()))
+
+
+def test_ld_sampler_points(oracle, phip):
+    """PHIP_SAMPLER_LD: (1) the device code (compiled for the host) and the oracle produce the same points, bit for bit; (2) the n points
+    of a (pixel, dimension) are a scrambled (0,2)-net -- every elementary interval of area 1/n holds exactly one of them -- and every
+    sample index is used exactly once (the keyed order is a permutation); (3) different pixels and dimensions are scrambled
+    differently; (4) the 1D requests are stratified too.  (ldsampler.cpp:151-186, core/qmc.h)"""
+    O = oracle.lib()
+    for n in (1, 2, 16, 64, 256):
+        mask = n - 1
+        for pixel, dim, seed in ((0, 0, 0), (12345, 2, 0), (7, 4, 3), (99999, 6, 1), (5, 1, 0), (5, 7, 9)):
+            a = np.zeros((n, 2), np.float32); b = np.zeros((n, 2), np.float32)
+            for k in range(n):
+                O.oracle_ld_point(pixel, k, dim, seed, mask, fp(a[k]))
+                phip.phip_debug_host_ld_point(pixel, k, dim, seed, mask, fp(b[k]))
+            assert (a.view(np.uint32) == b.view(np.uint32)).all()
+            assert (a[:, 0] >= 0).all() and (a[:, 0] < 1).all() and (a[:, 1] >= 0).all() and (a[:, 1] <= 1).all()
+            x = np.minimum(a[:, 0].astype(np.float64), 1 - 1e-9); y = np.minimum(a[:, 1].astype(np.float64), 1 - 1e-9)
+            m = n.bit_length() - 1
+            for i in range(m + 1):                                  # elementary intervals 2^-i x 2^-(m-i)
+                cells = np.floor(x * (1 << i)).astype(int) * (1 << (m - i)) + np.floor(y * (1 << (m - i))).astype(int)
+                assert len(set(cells.tolist())) == n, (n, pixel, dim, i)
+    pts = np.zeros((3, 16, 2), np.float32)
+    for j, (pixel, dim) in enumerate(((1, 0), (2, 0), (1, 2))):
+        for k in range(16):
+            O.oracle_ld_point(pixel, k, dim, 0, 15, fp(pts[j, k]))
+    assert not np.array_equal(pts[0], pts[1]) and not np.array_equal(pts[0], pts[2])

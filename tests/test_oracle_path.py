@@ -383,3 +383,29 @@ def test_sweep_mode_equals_the_kd_tree_on_ordinary_rays(oracle, gauss):
         assert same.mean() > 0.9999, same.mean()
         assert st0.samples == st1.samples
         sc.close()
+
+
+def test_ld_sampler_reduces_the_error_of_smooth_integrands(oracle, gauss):
+    """PHIP_SAMPLER_LD against the counter stream at equal sample counts: on a scene whose pixel integrals are smooth in the first
+    dimensions (pixel filter, one bounce of an area light on diffuse walls) the stratified (0,2)-sequences give a clearly lower
+    error against a converged image -- the reason ldsampler exists -- and the same expectation"""
+    desc = S.cornell_box(24, 24, gauss).desc()
+    sc = oracle.OracleScene(desc)
+    ref_film, _, _ = sc.render(A.default_render_params(spp=4096, max_depth=2, seed=77))
+    ref = oracle.develop(ref_film)
+    err = {}
+    for name, smp in (("ctr", A.PHIP_SAMPLER_CTR), ("ld", A.PHIP_SAMPLER_LD)):
+        e = []
+        for seed in range(4):
+            f, _, _ = sc.render(A.default_render_params(spp=16, max_depth=2, seed=seed, sampler=smp))
+            e.append(np.mean((oracle.develop(f) - ref) ** 2))
+        err[name] = float(np.mean(e))
+    assert err["ld"] < 0.6 * err["ctr"], err
+    big, _, _ = sc.render(A.default_render_params(spp=1024, max_depth=2, seed=5, sampler=A.PHIP_SAMPLER_LD))
+    assert abs(oracle.develop(big).mean() - ref.mean()) / ref.mean() < 0.01
+    # error behaviour: a sample count that is not a power of two, the `direct` integrator
+    with pytest.raises(RuntimeError):
+        sc.render(A.default_render_params(spp=12, sampler=A.PHIP_SAMPLER_LD))
+    with pytest.raises(RuntimeError):
+        sc.render(A.default_render_params(spp=16, sampler=A.PHIP_SAMPLER_LD, integrator=A.PHIP_INTEGRATOR_DIRECT))
+    sc.close()

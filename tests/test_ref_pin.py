@@ -259,3 +259,50 @@ def test_kd_tree_loses_a_silhouette_edge_hit_that_a_bvh_finds(ref, oracle, phip)
     hitp = ray[:3] + ray[4:7] * bf[0, 0]
     assert abs(hitp[0] - 213.0) < 1e-3 and abs(hitp[1] - 548.7) < 1e-3
     rs.close(); osc.close()
+
+
+def test_ld_sampler_on_the_reference(ref, olibm):
+    """PHIP_SAMPLER_LD, validated on the real integrator: Mitsuba's own `path` fed by oracle/ref_glue/ctr_sampler.cpp in its `ld` mode
+    (the points are made by the reference's own qmc.h functions, served purely by call order: 2D requests 0..3 and 1D requests 0..3 of
+    a sample are stratified, later ones fall back to the counter stream, exactly how ldsampler.cpp:212-226 hands them out) consumes the
+    numbers the oracle -- and hence the GPU -- consumes: per-sample radiance bit-identical with the libm build"""
+    import ref_scenes as RS
+    gauss = olibm.gaussian_filter(0.5, libm=True)
+    for name, desc, md in (("cornell", S.cornell_box(24, 24, gauss).desc(), -1), ("glass", S.glass_room(32, 18, gauss, detail=0.1).desc(), 12),
+                           ("zoo", RS.zoo(gauss, None).desc(), 8)):
+        for rr, spp in ((5, 8), (2, 4), (1, 16)):
+            p = A.default_render_params(spp=spp, max_depth=md, rr_depth=rr, sampler=A.PHIP_SAMPLER_LD, block_size=256, seed=rr)
+            osc = olibm.OracleScene(desc, libm=True)
+            _, osmp, _ = osc.render(p, threads=1, want_samples=True)
+            rs = ref.RefScene(desc)
+            _, rsmp = rs.render(p, sampler="ctr")
+            assert np.array_equal(osmp.view(np.uint32), rsmp.view(np.uint32)), (name, rr)
+            p.sampler = A.PHIP_SAMPLER_CTR
+            _, csmp, _ = osc.render(p, threads=1, want_samples=True)
+            assert not np.array_equal(osmp, csmp)
+            rs.close(); osc.close()
+
+
+def test_ld_stream_converges_like_the_reference_ldsampler(ref, oracle):
+    """PHIP_SAMPLER_LD is the construction of Mitsuba's ldsampler with other scrambles, so its numbers cannot be compared -- its
+    quality can: on the Cornell box at 16 spp (path, maxDepth 3) the mean squared error against a converged image is that of the
+    reference's own `path` + `ldsampler` (within +-40 %), and both are well below the `independent` sampler's"""
+    gauss = oracle.gaussian_filter(0.5)
+    desc = S.cornell_box(32, 32, gauss).desc()
+    rs = ref.RefScene(desc)
+    conv, _ = rs.render_job(A.default_render_params(spp=8192, max_depth=3), sampler="independent")
+    mse = {}
+    p = A.default_render_params(spp=16, max_depth=3)
+    for smp in ("independent", "ldsampler"):
+        img, _ = rs.render_job(p, sampler=smp)
+        mse[smp] = float(np.mean((img - conv) ** 2))
+    osc = oracle.OracleScene(desc)
+    e = []
+    for seed in range(3):
+        f, _, _ = osc.render(A.default_render_params(spp=16, max_depth=3, sampler=A.PHIP_SAMPLER_LD, seed=seed))
+        e.append(float(np.mean((oracle.develop(f) - conv) ** 2)))
+    mse["phip_ld"] = float(np.mean(e))
+    print(mse)
+    assert mse["ldsampler"] < 0.7 * mse["independent"] and mse["phip_ld"] < 0.7 * mse["independent"], mse
+    assert 0.6 < mse["phip_ld"] / mse["ldsampler"] < 1.4, mse
+    rs.close(); osc.close()
