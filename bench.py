@@ -288,6 +288,8 @@ def main():
                                        "one process per GPU + RCCL reduce(sum) of the film") if n_gpus > 1 else "1 GPU"},
             "frame_ms": s["ms_per_step"], "mrays_per_s": s["mrays_per_s"], "mean_path_length": s["mean_path_length"],
             "fused_kernel": s["fused_kernel"], "roofline": s["roofline"],
+            "build": {"library": _ffi.lib().phip_version().decode(), "id": _ffi.lib().phip_build_id().decode(),
+                      "note": "id = hash of mitsuba_amd/csrc + include + compile flags, compiled into libphip.so and checked against the sources when it is loaded"},
         }
         if extras:
             out["workloads"] = {headline: {k: v for k, v in s.items() if k != "roofline"}}

@@ -294,6 +294,7 @@ typedef struct phip_scene phip_scene;   /* opaque */
 int          phip_device_count(void);
 const char  *phip_last_error(void);
 const char  *phip_version(void);
+const char  *phip_build_id(void);         /* hash of the sources + flags the library was built from (mitsuba_amd/_ffi.py: source_id); "unknown-build-id" outside the in-tree build */
 
 /* Flattens the scene, builds the acceleration structure on the host and uploads it to `device`. */
 phip_scene  *phip_scene_create(const phip_scene_desc *desc, int device);

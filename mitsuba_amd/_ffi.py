@@ -37,17 +37,39 @@ UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", ["-mllvm", "-disable-mach
         [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f], "phip_shade%d.o" % f) for f in range(4)]
 
 
+def source_id():
+    """Provenance of a build: a hash of every source file and the compile flags.  It is compiled into the library (phip_build_id) so
+    that a stale libphip.so -- file times mean nothing after a copy to another machine -- is recognised when it is loaded."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in _sources():
+        h.update(os.path.basename(s).encode()); h.update(open(s, "rb").read())
+    h.update(repr((HIPCC_FLAGS, UNITS, os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", ""))).encode())
+    return h.hexdigest()[:16]
+
+
+def built_id(path=None):
+    """the source id compiled into an existing library (None: no library / built before ids existed)"""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    data = open(path, "rb").read()
+    i = data.find(b"phip-build-id:")
+    return data[i + 14:i + 30].decode() if i >= 0 else None
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 (cross-compiles without a GPU): the objects in parallel, then one link."""
     os.makedirs(BUILD, exist_ok=True)
-    if not force and os.path.exists(LIB):
-        mt = os.path.getmtime(LIB)
-        if all(os.path.getmtime(s) <= mt for s in _sources()):
-            return LIB
+    sid = source_id()
+    if not force and built_id() == sid:
+        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", "").split()
     procs = []
     for src, extra, obj in UNITS:
+        if src == "phip.hip":
+            extra = extra + ['-DPHIP_BUILD_ID="%s"' % sid]
         cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj)]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
@@ -72,8 +94,12 @@ def lib():
     if not os.path.exists(path):
         raise RuntimeError("libphip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "-- path_hip has no CPU fallback" % LIB)
+    if "PHIP_LIB" not in os.environ and built_id(path) != source_id():
+        raise RuntimeError("libphip.so (%s, build id %s) was not built from the sources next to it (id %s): rebuild with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'`" % (path, built_id(path), source_id()))
     L = C.CDLL(path)
     fp, u8p, u32 = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_uint32
+    L.phip_build_id.restype = C.c_char_p
     L.phip_last_error.restype = C.c_char_p
     L.phip_version.restype = C.c_char_p
     L.phip_device_count.restype = C.c_int

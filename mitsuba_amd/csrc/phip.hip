@@ -1265,6 +1265,11 @@ extern "C" {
 const char *phip_last_error(void) { return g_err.c_str(); }
 #define PHIP_STR2(x) #x
 #define PHIP_STR(x) PHIP_STR2(x)
+#ifndef PHIP_BUILD_ID
+#define PHIP_BUILD_ID "unknown-build-id"
+#endif
+/* the hash of the sources and flags this library was compiled from (mitsuba_amd/_ffi.py: source_id) */
+const char *phip_build_id(void) { static const char tag[] = "phip-build-id:" PHIP_BUILD_ID; return tag + 14; }
 const char *phip_version(void) { return "path_hip 0.5 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
 
 int phip_device_count(void) {

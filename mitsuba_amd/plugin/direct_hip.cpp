@@ -49,7 +49,11 @@ public:
         m_cpuDirect->configureSampler(scene, sampler);
     }
 
-    Spectrum Li(const RayDifferential &ray, RadianceQueryRecord &rRec) const { return m_cpuDirect->Li(ray, rRec); }
+    Spectrum Li(const RayDifferential &ray, RadianceQueryRecord &rRec) const {
+        static bool told = false;      /* (only a wrapping integrator -- `adaptive`, `irrcache` -- gets here) */
+        if (!told) { told = true; SLog(EWarn, "direct_hip: Li() was called by a wrapping integrator -- these samples run on the CPU (nested `direct`), not on the GPU"); }
+        return m_cpuDirect->Li(ray, rRec);
+    }
 
     bool preprocess(const Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
         if (!SamplingIntegrator::preprocess(scene, queue, job, sceneResID, sensorResID, samplerResID))

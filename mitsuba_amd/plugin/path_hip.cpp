@@ -48,7 +48,12 @@ public:
         manager->serialize(stream, m_cpuPath.get());
     }
 
-    Spectrum Li(const RayDifferential &ray, RadianceQueryRecord &rRec) const { return m_cpuPath->Li(ray, rRec); }
+    Spectrum Li(const RayDifferential &ray, RadianceQueryRecord &rRec) const {
+        /* reached only through an integrator that wraps this one (`adaptive`, `irrcache`): those call Li() per sample on the host */
+        static bool told = false;
+        if (!told) { told = true; SLog(EWarn, "path_hip: Li() was called by a wrapping integrator -- these samples run on the CPU (nested `path`), not on the GPU"); }
+        return m_cpuPath->Li(ray, rRec);
+    }
 
     bool preprocess(const Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
         if (!MonteCarloIntegrator::preprocess(scene, queue, job, sceneResID, sensorResID, samplerResID))
