@@ -249,7 +249,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from mitsuba_amd import distributed as D
+    from mitsuba_amd import _ffi, distributed as D
 
     rank, world, local = D.init_from_env()
     in_library = world == 1 and args.gpus > 1          # no torchrun: the library's own multi-device path
