@@ -202,7 +202,9 @@ typedef enum phip_sampler_kind {
                                 pixel and dimension, later requests fall back to the counter stream -- with the scrambles and the
                                 order taken from the counter-based generator instead of the worker's sequential Random, so the
                                 stream is addressable and reproducible.  The sample count of the whole render (`sample_total`,
-                                else `spp`) must be a power of two (ldsampler.cpp:83-87 rounds it up); `path` only. */
+                                else `spp`) must be a power of two (ldsampler.cpp:83-87 rounds it up).  `direct`: its sample arrays
+                                (direct.cpp:139-146) are one scrambled sequence of sampleCount x N points each, in a random order
+                                (ldsampler.cpp:193-197); single shading samples are the sample's next 2D requests. */
 } phip_sampler_kind;
 
 /* which SamplingIntegrator::Li the call evaluates */

@@ -273,6 +273,34 @@ DV uint32_t ldPermute(uint32_t i, uint32_t mask, uint32_t key) {
     i ^= i >> 5;
     return (i + key) & mask;
 }
+/* the same over a domain of any size (`direct`: a sample array of sampleCount * N entries is ONE scrambled sequence in a random order,
+   ldsampler.cpp:193-197): the permutation of the next power of two, walked until it lands inside (Kensler, ibid.) */
+DV uint32_t ldPermuteAny(uint32_t i, uint32_t l, uint32_t key) {
+    uint32_t w = l - 1u;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= key;             i *= 0xe170893du;
+        i ^= key >> 16;
+        i ^= (i & w) >> 4;
+        i ^= key >> 8;        i *= 0x0929eb3fu;
+        i ^= key >> 23;
+        i ^= (i & w) >> 1;    i *= 1u | key >> 27;
+                              i *= 0x6935fa69u;
+        i ^= (i & w) >> 11;   i *= 0x74dcb303u;
+        i ^= (i & w) >> 2;    i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2;    i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + key) % l;
+}
+/* entry `idx` of the 2D sample array `a` (in request order) of `pixel`, `total` = sampleCount * entries per sample */
+DV void ldArrayPoint(uint32_t pixel, uint32_t a, uint32_t idx, uint32_t total, uint32_t seed, float &x, float &y) {
+    const U4 h = pcg4d(pixel, 0x100u + a, 0x4c44u, seed);
+    const uint32_t i = ldPermuteAny(idx, total, h.x);
+    x = radicalInverse2Single(i, h.y);
+    y = sobol2Single(i, h.z);
+}
 /* the request `dim` (2D: 2 * q, 1D: 2 * j + 1) of sample `k` of `pixel`; mask = sampleCount - 1 (a power of two, ldsampler.cpp:83-87) */
 DV void ldPoint(uint32_t pixel, uint32_t k, uint32_t dim, uint32_t seed, uint32_t mask, float &x, float &y) {
     const U4 h = pcg4d(pixel, dim, 0x4c44u /* 'LD' */, seed);

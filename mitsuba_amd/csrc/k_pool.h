@@ -125,6 +125,21 @@ __device__ __forceinline__ V2 streamJitter(const RenderConst &rc, uint32_t pixel
     return V2(u32ToFloat(h.x), u32ToFloat(h.y));
 }
 
+/* `direct`: shading sample i of kind `which` (0: emitter sample, direct.cpp:212-216; 1: BSDF sample, :251-255) of camera sample k.
+   PHIP_SAMPLER_CTR: block 1 + i holds (emitter sample i, BSDF sample i).  PHIP_SAMPLER_LD: more than one sample of a kind is a
+   requested 2D array (direct.cpp:139-146; the emitter array first), a single one the next 2D request of the sample (the jitter is 0) */
+__device__ __forceinline__ V2 streamDirectSample(const RenderConst &rc, uint32_t pixel, uint32_t k, int which, uint32_t i) {
+    if (rc.sampler == PHIP_SAMPLER_LD) {
+        const uint32_t E = (uint32_t) rc.emitterSamples, B = (uint32_t) rc.bsdfSamples, count = which ? B : E;
+        float x, y;
+        if (count > 1) ldArrayPoint(pixel, which ? (E > 1 ? 1u : 0u) : 0u, (k & rc.ldMask) * count + i, (rc.ldMask + 1u) * count, rc.seed, x, y);
+        else ldPoint(pixel, k, 2u * (which ? (E > 1 ? 1u : 2u) : 1u), rc.seed, rc.ldMask, x, y);
+        return V2(x, y);
+    }
+    const U4 h = pcg4d(pixel, k, 1 + i, rc.seed);
+    return which ? V2(u32ToFloat(h.z), u32ToFloat(h.w)) : V2(u32ToFloat(h.x), u32ToFloat(h.y));
+}
+
 /* sample id -> (local tile, sample-in-pass, pixel); ids are tile-major, then sample, then the
    Morton index of the pixel inside the tile so that a wave covers an 8x8 pixel patch */
 __device__ __forceinline__ bool decodeId(const RenderConst &rc, const DevFilm &film, unsigned long long id,

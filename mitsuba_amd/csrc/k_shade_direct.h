@@ -148,10 +148,9 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
 
                 /* ---- emitter sample `round`, direct.cpp:218-247 ---- */
                 if (round < E && (its.flags & TS_MF_SMOOTH)) {
-                    const U4 h = pcg4d(info.y, info.z, 1 + (uint32_t) round, rc.seed);
                     DirectRec dRec;
                     dRec.ref = its.p; dRec.refN = refN; dRec.pdf = 0; dRec.emitter = -1;
-                    const V3 value = sampleEmitterDirect<ENV>(S, T, dRec, V2(u32ToFloat(h.x), u32ToFloat(h.y)));
+                    const V3 value = sampleEmitterDirect<ENV>(S, T, dRec, streamDirectSample(rc, info.y, info.z, 0, (uint32_t) round));
                     if (dRec.pdf != 0 && !value.isZero()) {
                         const V3 wo = its.sh.toLocal(dRec.d);
                         float bPdf;
@@ -170,9 +169,8 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                 bool issued = false;
                 const int i = round - bs0;
                 if (i >= 0 && i < B) {
-                    const U4 h = pcg4d(info.y, info.z, 1 + (uint32_t) i, rc.seed);
                     BSDFSample bs;
-                    const V3 bsdfVal = bsdfSample<MM>(bctx, V2(u32ToFloat(h.z), u32ToFloat(h.w)), bs);
+                    const V3 bsdfVal = bsdfSample<MM>(bctx, streamDirectSample(rc, info.y, info.z, 1, (uint32_t) i), bs);
                     if (!bsdfVal.isZero()) {
                         const V3 wo = its.sh.toWorld(bs.wo);
                         const float woDotGeoN = dot(its.geoN, wo);

@@ -759,9 +759,10 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
     }
     if (p->sampler != PHIP_SAMPLER_CTR && p->sampler != PHIP_SAMPLER_LD) throw std::invalid_argument("unknown sampler kind");
     if (p->sampler == PHIP_SAMPLER_LD) {
-        if (p->integrator != PHIP_INTEGRATOR_PATH) throw std::invalid_argument("PHIP_SAMPLER_LD is implemented for the path tracer only");
         const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
         if (n == 0 || (n & (n - 1))) throw std::invalid_argument("PHIP_SAMPLER_LD: the sample count of the render must be a power of two (ldsampler.cpp:83-87)");
+        if (p->integrator == PHIP_INTEGRATOR_DIRECT && (unsigned long long) n * (unsigned) std::max(p->emitter_samples, p->bsdf_samples) > 0x7fffffffull)
+            throw std::invalid_argument("PHIP_SAMPLER_LD: sample array too long");
     }
     if (p->sample_offset < 0 || p->sample_total < 0) throw std::invalid_argument("sample_offset / sample_total must not be negative");
     if (p->sample_total != 0 && (long long) p->sample_offset + p->spp > p->sample_total) throw std::invalid_argument("sample_offset + spp exceeds sample_total");

@@ -172,11 +172,10 @@ public:
        parallel schedule reproduces, not even the reference's own from run to run (independent.cpp:42-45) -- so the device's
        counter-based stream stands in, which is said once.  `ldsampler` maps to PHIP_SAMPLER_LD: the same construction (scrambled
        (0,2)-sequences in a random order per pixel and dimension for the first four 1D / 2D requests of a sample, ldsampler.cpp:151-226)
-       with the scrambles and the order drawn from the counter-based generator instead of the worker's Random -- `path_hip` only,
-       default `dimension` only.  Any other QMC sampler would silently lose its stratification: an error. */
-    static int checkSampler(const Sampler *sampler, const char *name, bool pathTracer) {
+       with the scrambles and the order drawn from the counter-based generator instead of the worker's Random -- default `dimension` only.  Any other QMC sampler would silently lose its stratification: an error. */
+    static int checkSampler(const Sampler *sampler, const char *name) {
         const std::string cls = sampler->getClass()->getName();
-        if (cls == "LowDiscrepancySampler" && pathTracer) {
+        if (cls == "LowDiscrepancySampler") {
             if (sampler->getProperties().getSize("dimension", 4) != 4)
                 SLog(EError, "%s: ldsampler with dimension != 4 is not supported", name);
             static bool toldLD = false;
@@ -196,7 +195,7 @@ public:
             }
             return PHIP_SAMPLER_CTR;
         }
-        SLog(EError, "%s: sampler \"%s\" is not supported ('independent'; 'ldsampler' with path_hip; other QMC samplers would lose their stratification)", name, cls.c_str());
+        SLog(EError, "%s: sampler \"%s\" is not supported ('independent', 'ldsampler'; other QMC samplers would lose their stratification)", name, cls.c_str());
         return PHIP_SAMPLER_CTR;
     }
 
@@ -209,7 +208,7 @@ public:
         ref<Film> film = sensor->getFilm();
         const Vector2i size = film->getCropSize();
         const Sampler *sampler = scene->getSampler();
-        const int samplerKind = checkSampler(sampler, name, rp.integrator == PHIP_INTEGRATOR_PATH);
+        const int samplerKind = checkSampler(sampler, name);
         const size_t spp = sampler->getSampleCount();
         SLog(EInfo, "Starting render job (%ix%i, " SIZE_T_FMT " samples, %s) ..", size.x, size.y, spp, phip_version());
         rp.block_size = (int32_t) scene->getBlockSize();

@@ -163,6 +163,25 @@ inline uint32_t ldPermute(uint32_t i, uint32_t mask, uint32_t key) {
     i ^= i >> 5;
     return (i + key) & mask;
 }
+inline uint32_t ldPermuteAny(uint32_t i, uint32_t l, uint32_t key) {     /* ... for a domain of any size: cycle walking (Kensler, ibid.) */
+    uint32_t w = l - 1u;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= key;             i *= 0xe170893du;
+        i ^= key >> 16;
+        i ^= (i & w) >> 4;
+        i ^= key >> 8;        i *= 0x0929eb3fu;
+        i ^= key >> 23;
+        i ^= (i & w) >> 1;    i *= 1u | key >> 27;
+                              i *= 0x6935fa69u;
+        i ^= (i & w) >> 11;   i *= 0x74dcb303u;
+        i ^= (i & w) >> 2;    i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2;    i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + key) % l;
+}
 static const uint32_t LD_DIMENSIONS = 4;     /* ldsampler.cpp:79 */
 
 struct SampleSource {
@@ -224,6 +243,7 @@ struct SampleSource {
     std::vector<Vec2> arrays[2];
     Vec2 single[2];
     void generateDirectArrays(size_t sampleCount, size_t emitterSamples, size_t bsdfSamples) {
+        dirEmitterSamples = emitterSamples;
         if (ctr) return;
         const size_t n[2] = { emitterSamples, bsdfSamples };
         for (int w = 0; w < 2; ++w) {
@@ -241,8 +261,22 @@ struct SampleSource {
     void beginDirectArray(int which, size_t count) {
         if (!ctr && count <= 1) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); single[which] = Vec2(a, b); }
     }
+    size_t dirEmitterSamples = 1;      /* (set by generateDirectArrays: which request / array the BSDF samples are depends on it) */
     Vec2 directSample(int which, size_t i, size_t count) const {
         if (!ctr) return count > 1 ? arrays[which][(size_t) sample * count + i] : single[which];
+        if (ld) {
+            /* more than one sample of a kind: a requested 2D array (direct.cpp:139-146, the emitter array first) = ONE scrambled
+               sequence of sampleCount * count points in a random order (ldsampler.cpp:193-197); a single one: the sample's next 2D request */
+            const uint32_t E = (uint32_t) dirEmitterSamples;
+            if (count > 1) {
+                const uint32_t a = which ? (E > 1 ? 1u : 0u) : 0u;
+                uint32_t h[4] = { pixel, 0x100u + a, 0x4c44u, seed };
+                pcg4d(h);
+                const uint32_t p = ldPermuteAny((sample & ldMask) * (uint32_t) count + (uint32_t) i, (ldMask + 1u) * (uint32_t) count, h[0]);
+                return Vec2(radicalInverse2Single(p, h[1]), sobol2Single(p, h[2]));
+            }
+            return ldPoint(2u * (which ? (E > 1 ? 1u : 2u) : 1u));
+        }
         float f[4]; block(1 + (uint32_t) i, f);
         return which == 0 ? Vec2(f[0], f[1]) : Vec2(f[2], f[3]);
     }

@@ -68,8 +68,8 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
         rp.ld = p->sampler == PHIP_SAMPLER_LD;
         if (rp.ld) {
             const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
-            if (sampler_mode != 0 || p->integrator != PHIP_INTEGRATOR_PATH || n == 0 || (n & (n - 1)))
-                throw std::runtime_error("PHIP_SAMPLER_LD: path tracer on the counter stream, power-of-two sample count");
+            if (sampler_mode != 0 || n == 0 || (n & (n - 1)))
+                throw std::runtime_error("PHIP_SAMPLER_LD: on the counter stream, power-of-two sample count");
         }
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
         if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::runtime_error("unknown integrator");

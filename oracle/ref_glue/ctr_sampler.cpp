@@ -53,7 +53,10 @@ public:
         m_pixel = (uint32_t) (offset.y * m_width + offset.x);           /* crop-relative pixel, row-major: the parity stream's key */
         /* sample arrays of `direct`: array a of sample j, entry i = block 1 + i of that sample; the emitter array (if
            requested, direct.cpp:140-146) comes first and takes .xy, the BSDF array .zw */
-        for (size_t a = 0; a < m_req2D.size(); ++a) {
+        for (size_t a = 0; a < m_req2D.size() && m_ld; ++a)           /* ldsampler.cpp:193-197: one scrambled sequence per array, in a random order */
+            for (size_t e = 0; e < m_sampleCount * m_req2D[a]; ++e)
+                m_sampleArrays2D[a][e] = ldArrayPoint((uint32_t) a, (uint32_t) e, (uint32_t) ((m_ldMask + 1u) * m_req2D[a]));
+        for (size_t a = 0; a < m_req2D.size() && !m_ld; ++a) {
             const bool emitter = (a == 0 && m_emitterSamples > 1);
             for (size_t j = 0; j < m_sampleCount; ++j)
                 for (size_t i = 0; i < m_req2D[a]; ++i) {
@@ -70,7 +73,7 @@ public:
     Point2 next2D() {
         float f[4];
         const uint32_t call = m_call2D++;
-        if (m_ld && !m_direct && call < 4) return ldPoint(2 * call);                                /* ldsampler.cpp:218-224 */
+        if (m_ld && call < 4) return ldPoint(2 * call);                                             /* ldsampler.cpp:218-224 */
         if (call == 0) { block((uint32_t) m_sampleIndex, 0, f); return Point2(f[0], f[1]); }        /* integrator.cpp:171 */
         if (m_direct) {
             /* direct.cpp:212-216: a single emitter sample (also drawn when emitterSamples == 0); :251-255 the same for the BSDF */
@@ -121,6 +124,34 @@ private:
         i &= mask;
         i ^= i >> 5;
         return (i + key) & mask;
+    }
+    static uint32_t permuteAny(uint32_t i, uint32_t l, uint32_t key) {      /* the same for a domain of any size: cycle walking */
+        uint32_t w = l - 1u;
+        w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+        do {
+            i ^= key;             i *= 0xe170893du;
+            i ^= key >> 16;
+            i ^= (i & w) >> 4;
+            i ^= key >> 8;        i *= 0x0929eb3fu;
+            i ^= key >> 23;
+            i ^= (i & w) >> 1;    i *= 1u | key >> 27;
+                                  i *= 0x6935fa69u;
+            i ^= (i & w) >> 11;   i *= 0x74dcb303u;
+            i ^= (i & w) >> 2;    i *= 0x9e501cc3u;
+            i ^= (i & w) >> 2;    i *= 0xc860a3dfu;
+            i &= w;
+            i ^= i >> 5;
+        } while (i >= l);
+        return (i + key) % l;
+    }
+    Point2 ldArrayPoint(uint32_t a, uint32_t idx, uint32_t total) const {
+        uint32_t v[4] = { m_pixel, 0x100u + a, 0x4c44u, m_seed };
+        for (int i = 0; i < 4; ++i) v[i] = v[i] * 1664525u + 1013904223u;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        const uint32_t i = permuteAny(idx, total, v[0]);
+        return Point2(radicalInverse2Single(i, v[1]), sobol2Single(i, v[2]));
     }
     Point2 ldPoint(uint32_t dim) const {
         uint32_t v[4] = { m_pixel, dim, 0x4c44u, m_seed };

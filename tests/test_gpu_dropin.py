@@ -63,7 +63,9 @@ def check_scene(ref, name, desc):
     for plugin, Integ, kw, rkw, sampler in (("path_hip", PathHIP, dict(maxDepth=6), dict(max_depth=6), "independent"),
                                            ("path_hip", PathHIP, dict(maxDepth=6), dict(max_depth=6), "ldsampler"),
                                            ("direct_hip", DirectHIP, dict(emitterSamples=2, bsdfSamples=2),
-                                            dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2), "independent")):
+                                            dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2), "independent"),
+                                           ("direct_hip", DirectHIP, dict(emitterSamples=2, bsdfSamples=1),
+                                            dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=1), "ldsampler")):
         # <sampler type="ldsampler"/> in the scene makes the shim select PHIP_SAMPLER_LD (phip_flatten.h: checkSampler)
         ld = dict(sampler=A.PHIP_SAMPLER_LD) if sampler == "ldsampler" else {}
         p = A.default_render_params(spp=32, **rkw)

@@ -544,10 +544,12 @@ def test_ld_sampler_matches_oracle(gpu, phip, oracle, gauss):
     st = A.phip_stats()
     assert phip.phip_render(gs._h, C.byref(p), acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
     assert rel_l2(acc, whole.storage) < 1e-6
-    # a sample count that is not a power of two; the `direct` integrator
+    # a sample count that is not a power of two
     from mitsuba_amd._ffi import PhipError
     with pytest.raises(PhipError):
         integ.render(gs, HDRFilm(32, 32), 12, **ld)
-    with pytest.raises(PhipError):
-        DirectHIP().render(gs, HDRFilm(32, 32), 16, **ld)
     gs.close()
+    # `direct`: sample arrays and single samples
+    for e, b in ((1, 1), (3, 2), (0, 2), (4, 1)):
+        compare_render(gpu, oracle, RS.zoo(gauss, None).desc(), 8, min_identical=0.9999, integrator=DirectHIP, render_kw=ld, emitterSamples=e, bsdfSamples=b)
+    compare_render(gpu, oracle, S.cornell_box(40, 40, gauss).desc(), 16, min_identical=1.0, integrator=DirectHIP, render_kw=ld, emitterSamples=2, bsdfSamples=3)

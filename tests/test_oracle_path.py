@@ -406,6 +406,12 @@ def test_ld_sampler_reduces_the_error_of_smooth_integrands(oracle, gauss):
     # error behaviour: a sample count that is not a power of two, the `direct` integrator
     with pytest.raises(RuntimeError):
         sc.render(A.default_render_params(spp=12, sampler=A.PHIP_SAMPLER_LD))
-    with pytest.raises(RuntimeError):
-        sc.render(A.default_render_params(spp=16, sampler=A.PHIP_SAMPLER_LD, integrator=A.PHIP_INTEGRATOR_DIRECT))
+    # `direct` with sample arrays: same expectation, lower error than the counter stream
+    dref = oracle.develop(sc.render(A.default_render_params(spp=2048, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=1, bsdf_samples=1, seed=9))[0])
+    derr = {}
+    for name, smp in (("ctr", A.PHIP_SAMPLER_CTR), ("ld", A.PHIP_SAMPLER_LD)):
+        e = [np.mean((oracle.develop(sc.render(A.default_render_params(spp=4, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=4, bsdf_samples=2,
+                                                                              seed=s, sampler=smp))[0]) - dref) ** 2) for s in range(4)]
+        derr[name] = float(np.mean(e))
+    assert derr["ld"] < 0.7 * derr["ctr"], derr
     sc.close()

@@ -281,28 +281,34 @@ def test_ld_sampler_on_the_reference(ref, olibm):
             _, csmp, _ = osc.render(p, threads=1, want_samples=True)
             assert not np.array_equal(osmp, csmp)
             rs.close(); osc.close()
+        # `direct`: sample arrays (more than one shading sample of a kind) and single samples in every combination
+        for e, b, spp in ((1, 1, 8), (3, 2, 4), (0, 2, 4), (2, 0, 8), (1, 5, 2), (4, 1, 16)):
+            p = A.default_render_params(spp=spp, sampler=A.PHIP_SAMPLER_LD, block_size=256, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=e, bsdf_samples=b)
+            osc = olibm.OracleScene(desc, libm=True)
+            _, osmp, _ = osc.render(p, threads=1, want_samples=True)
+            rs = ref.RefScene(desc)
+            _, rsmp = rs.render(p, sampler="ctr")
+            assert np.array_equal(osmp.view(np.uint32), rsmp.view(np.uint32)), (name, "direct", e, b)
+            rs.close(); osc.close()
 
 
 def test_ld_stream_converges_like_the_reference_ldsampler(ref, oracle):
     """PHIP_SAMPLER_LD is the construction of Mitsuba's ldsampler with other scrambles, so its numbers cannot be compared -- its
-    quality can: on the Cornell box at 16 spp (path, maxDepth 3) the mean squared error against a converged image is that of the
-    reference's own `path` + `ldsampler` (within +-40 %), and both are well below the `independent` sampler's"""
+    quality can: on the Cornell box at 16 spp (path, maxDepth 3) the mean absolute error against a converged image is that of the
+    reference's own `path` + `ldsampler` (within +-25 %; measured 0.0044 vs 0.0049), and both are well below the `independent`
+    sampler's (0.0076).  (The mean SQUARED error is dominated by a few pixels and varies by a factor of two between runs of the reference.)"""
     gauss = oracle.gaussian_filter(0.5)
-    desc = S.cornell_box(32, 32, gauss).desc()
+    desc = S.cornell_box(48, 48, gauss).desc()
     rs = ref.RefScene(desc)
-    conv, _ = rs.render_job(A.default_render_params(spp=8192, max_depth=3), sampler="independent")
-    mse = {}
+    conv, _ = rs.render_job(A.default_render_params(spp=16384, max_depth=3), sampler="independent")
+    mae = {}
     p = A.default_render_params(spp=16, max_depth=3)
     for smp in ("independent", "ldsampler"):
-        img, _ = rs.render_job(p, sampler=smp)
-        mse[smp] = float(np.mean((img - conv) ** 2))
+        mae[smp] = float(np.mean([np.mean(np.abs(rs.render_job(p, sampler=smp, threads=t)[0] - conv)) for t in (1, 2, 3)]))
     osc = oracle.OracleScene(desc)
-    e = []
-    for seed in range(3):
-        f, _, _ = osc.render(A.default_render_params(spp=16, max_depth=3, sampler=A.PHIP_SAMPLER_LD, seed=seed))
-        e.append(float(np.mean((oracle.develop(f) - conv) ** 2)))
-    mse["phip_ld"] = float(np.mean(e))
-    print(mse)
-    assert mse["ldsampler"] < 0.7 * mse["independent"] and mse["phip_ld"] < 0.7 * mse["independent"], mse
-    assert 0.6 < mse["phip_ld"] / mse["ldsampler"] < 1.4, mse
+    mae["phip_ld"] = float(np.mean([np.mean(np.abs(oracle.develop(osc.render(A.default_render_params(spp=16, max_depth=3, sampler=A.PHIP_SAMPLER_LD, seed=seed))[0]) - conv))
+                                    for seed in range(3)]))
+    print(mae)
+    assert mae["ldsampler"] < 0.8 * mae["independent"] and mae["phip_ld"] < 0.8 * mae["independent"], mae
+    assert 0.75 < mae["phip_ld"] / mae["ldsampler"] < 1.25, mae
     rs.close(); osc.close()
