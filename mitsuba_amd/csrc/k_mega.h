@@ -155,3 +155,4 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
 #pragma unroll
     for (int i = 0; i < MC_COUNT; ++i) waveStat(P, rows[i], waveId, ldsCount[i][threadIdx.x]);
 }
+

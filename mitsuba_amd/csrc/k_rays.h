@@ -145,38 +145,6 @@ struct ShadowSource {
  * first drains its share of the shadow queue and then, without a kernel boundary, refills idle lanes from its share
  * of the closest-hit queue: one kernel tail (waves waiting for the slowest in-flight rays) and one launch per
  * iteration instead of two.  The kind of a lane's ray is a per-lane flag; the loop body is shared. */
-__device__ __forceinline__ bool clipToSceneRT(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
-                                              float &mint, float &maxt, bool shadow, V3 &slab) {
-    float nearT = -INFINITY, farT = INFINITY;
-    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
-    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
-        if (dd[i] == 0) {
-            if (origin < minVal || origin > maxVal) return false;
-        } else {
-            const float rcp = rr[i];
-            float t1 = (minVal - origin) * rcp;
-            float t2 = (maxVal - origin) * rcp;
-            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
-            nearT = smax(t1, nearT);
-            farT = smin(t2, farT);
-            if (!(nearT <= farT)) return false;
-        }
-    }
-    mint = nearT; maxt = farT;
-    float rayMinT = rayMint;
-    if (rayMinT == PT_EPSILON) {
-        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-        if (!shadow) m = smax(m, PT_EPSILON);               /* skdtree.cpp:124 vs :215 */
-        rayMinT *= m;
-    }
-    if (rayMinT > mint) mint = rayMinT;
-    if (rayMaxt < maxt) maxt = rayMaxt;
-    return maxt > mint;
-}
 
 enum { WC_RAYS = 0, WC_NODE, WC_TRI, WC_SH_RAYS, WC_SH_NODE, WC_SH_TRI, WC_COUNT };
 

@@ -59,6 +59,40 @@ __device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, cons
     return maxt > mint;
 }
 
+/* the same with the kind of the ray as a per-lane flag (the kernels that trace closest-hit and any-hit rays in one loop) */
+__device__ __forceinline__ bool clipToSceneRT(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
+                                              float &mint, float &maxt, bool shadow, V3 &slab) {
+    float nearT = -INFINITY, farT = INFINITY;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
+        if (dd[i] == 0) {
+            if (origin < minVal || origin > maxVal) return false;
+        } else {
+            const float rcp = rr[i];
+            float t1 = (minVal - origin) * rcp;
+            float t2 = (maxVal - origin) * rcp;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+            nearT = smax(t1, nearT);
+            farT = smin(t2, farT);
+            if (!(nearT <= farT)) return false;
+        }
+    }
+    mint = nearT; maxt = farT;
+    float rayMinT = rayMint;
+    if (rayMinT == PT_EPSILON) {
+        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+        if (!shadow) m = smax(m, PT_EPSILON);               /* skdtree.cpp:124 vs :215 */
+        rayMinT *= m;
+    }
+    if (rayMinT > mint) mint = rayMinT;
+    if (rayMaxt < maxt) maxt = rayMaxt;
+    return maxt > mint;
+}
+
 /* Per-lane traversal stack: the first `depth` entries live in LDS (interleaved: entry e of lane l at
  * lds[e * BLOCK + l], so lane i always hits bank i), deeper entries spill to a per-lane HBM array.
  * The same dynamic LDS segment also stages the top of the tree: the first S.nodeCache BVH4 nodes (they
