@@ -192,6 +192,9 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 }
 
 #define SHADOW_UNSORTED 1
+#ifndef MEGA_UNSORTED
+#define MEGA_UNSORTED 1          /* k_mega (whole tree in LDS, 7 nodes on the Cornell box): closest-hit rays visit the children unsorted too -- the sorting network costs more than the culling it buys: 106.9 -> 103.7 ms per C2 frame (the answer does not depend on the order: winsTie) */
+#endif
 #define DONE_REF ((int32_t) 0x80000000)   /* 'no more nodes' marker; as a leaf reference it would need 2^28 triangle records */
 
 /* One BVH4 node step: slab test of the four children, nearest-first order, push the farther hits,
@@ -276,7 +279,7 @@ __device__ __forceinline__ bool traverse(const DevScene &S, const V3 &o, const V
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
     while (cur != DONE_REF) {
         if (cur >= 0) {
-            if (SHADOW && SHADOW_UNSORTED) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
+            if ((SHADOW && SHADOW_UNSORTED) || (ALL_LDS && MEGA_UNSORTED)) NODE_STEP_ANY(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
             else NODE_STEP(stack, S, cur, rcp, ordr, mint, maxt, nodeVisits)
         }
         if (cur < 0 && cur != DONE_REF) {
