@@ -94,6 +94,8 @@ def lib():
     if not os.path.exists(path):
         raise RuntimeError("libphip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "-- path_hip has no CPU fallback" % LIB)
+    if "PHIP_LIB" not in os.environ and built_id(path) != source_id() and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        build()                                 # stale (or missing id): rebuild from the sources next to it
     if "PHIP_LIB" not in os.environ and built_id(path) != source_id():
         raise RuntimeError("libphip.so (%s, build id %s) was not built from the sources next to it (id %s): rebuild with "
                            "`python -c 'import __graft_entry__ as g; g.build()'`" % (path, built_id(path), source_id()))
