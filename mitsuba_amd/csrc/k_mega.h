@@ -29,7 +29,7 @@
 
 enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
 
-template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
     __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs */
     /* dynamic LDS: [traversal stack | all nodes | all Wald records] (setupTraversal) [shading records | emitter table | materials],
        sized for THIS scene (megaLdsBytes) so that as many blocks as the registers allow fit a CU */
@@ -37,6 +37,9 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
     float *ldsEm = (float *) (ldsTriShade + (size_t) S.nTriangles * TRISHADE_FLOAT4S);
     DevMaterial *ldsMat = (DevMaterial *) (ldsEm + ((S.emitterTabSize + 3u) & ~3u));
     const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    float4 *ldsFlat = (float4 *) (((uintptr_t) (ldsMat + S.nMaterials) + 15u) & ~(uintptr_t) 15u);      /* FLAT: the table of leaf boxes (traverseFlat) */
+    if (FLAT) for (uint32_t i = threadIdx.x; i < 2u * S.nFlatLeaves; i += BLOCK) ldsFlat[i] = S.flatLeaves[i];
+    lds_cf4 *flat = (lds_cf4 *) ldsFlat;
     for (uint32_t i = threadIdx.x; i < S.nTriangles * TRISHADE_FLOAT4S; i += BLOCK) ldsTriShade[i] = S.triShade[i];
     S.triShade = ldsTriShade;                                   /* (generic pointer into LDS: six loads per vertex, not the inner loop) */
     TravStack stk; setupTraversal(S, g_smem, nullptr, stk);     /* stack + all nodes + all Wald records in LDS (barrier inside); the host checked that nothing can spill */
@@ -111,8 +114,10 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
-            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp))
-                traverse<false, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
+            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp)) {
+                if (FLAT) traverseFlat<false>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
+                else traverse<false, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
+            }
             v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
             ldsCount[MC_RAYS][threadIdx.x] += 1; ldsCount[MC_NODE][threadIdx.x] += nNode; ldsCount[MC_TRI][threadIdx.x] += nTri;
         }
@@ -137,7 +142,8 @@ template <int MM, bool STRICT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) v
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
             if (clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp))
-                occluded = traverse<true, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
+                occluded = FLAT ? traverseFlat<true>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri)
+                                : traverse<true, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
             ldsCount[MC_SH_RAYS][threadIdx.x] += 1; ldsCount[MC_SH_NODE][threadIdx.x] += nNode; ldsCount[MC_SH_TRI][threadIdx.x] += nTri;
             if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
         }

@@ -159,7 +159,7 @@ void spiralBlocks(int sizeX, int sizeY, int bs, std::vector<std::pair<int, int>>
 struct SceneDev {
     int device = 0;
     /* ---- scene (immutable after build / replication) ---- */
-    DevBuf<float4> nodes, tris, triShade;
+    DevBuf<float4> nodes, tris, triShade, flatLeaves;
     DevBuf<uint4> wnodes;                                                                     /* compressed wide BVH (big scenes) */
     DevBuf<DevMaterial> materials;
     DevBuf<float> emitterTab;
@@ -182,12 +182,12 @@ struct SceneDev {
     hipStream_t stream = nullptr;
 
     template <typename F> void forEachSceneBuffer(F f) {
-        f(nodes); f(wnodes); f(tris); f(triShade); f(materials); f(emitterTab); f(texTexels); f(texDesc);
+        f(nodes); f(wnodes); f(tris); f(triShade); f(flatLeaves); f(materials); f(emitterTab); f(texTexels); f(texDesc);
         f(envTexels); f(envLevels); f(envCdfRows); f(envCdfCols); f(envRowWeights);
     }
     /* the pointer members of the DevScene (everything else in it is plain data, equal on every device) */
     void bind() {
-        dev.nodes = nodes.p; dev.wnodes = wnodes.p; dev.tris = tris.p; dev.triShade = triShade.p; dev.materials = materials.p;
+        dev.nodes = nodes.p; dev.wnodes = wnodes.p; dev.tris = tris.p; dev.triShade = triShade.p; dev.flatLeaves = flatLeaves.p; dev.materials = materials.p;
         dev.texTexels = texTexels.p; dev.textures = texDesc.p; dev.emitterTab = emitterTab.p;
         dev.env.texels = envTexels.p; dev.env.levels = envLevels.p; dev.env.cdfRows = envCdfRows.p; dev.env.cdfCols = envCdfCols.p;
         dev.env.rowWeights = envRowWeights.p;
@@ -664,6 +664,29 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         && D.nodeCache == sc->bvh.nNodes && D.triCache == sc->bvh.tris.size() / 12 && d.n_triangles <= MEGA_TRISHADE_MAX
         && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX
         && 3 * ((int) sc->bvh.maxDepth - 1) + 1 <= (int) D.stackDepth;
+    /* ... and, for trees of at most FLAT_LEAVES_MAX leaves (the Cornell box: 17), the leaves as a flat table: the fused kernel tests
+       every leaf box in one uniform pass instead of walking the 7-node tree (k_traverse.h: traverseFlat).  Entry = (min.xyz, bits(leaf
+       reference)) (max.xyz, 0), boxes as the BVH4 nodes hold them (padded). */
+    D.nFlatLeaves = 0; sd.flatLeaves.alloc(2); D.flatLeaves = sd.flatLeaves.p;
+    if (sc->fitsLds && sc->bvh.nLeaves <= FLAT_LEAVES_MAX && !getenv("PHIP_NO_FLAT")) {
+        std::vector<float4> flat;
+        if (sc->bvh.rootRef < 0) {                         /* a single leaf: its box is the scene's */
+            flat.push_back(make_float4(sc->bvh.tightMin[0] - 1.0f, sc->bvh.tightMin[1] - 1.0f, sc->bvh.tightMin[2] - 1.0f, pm_from_bits((uint32_t) sc->bvh.rootRef)));
+            flat.push_back(make_float4(sc->bvh.tightMax[0] + 1.0f, sc->bvh.tightMax[1] + 1.0f, sc->bvh.tightMax[2] + 1.0f, 0.0f));
+        } else for (uint32_t n = 0; n < sc->bvh.nNodes; ++n) {
+            const float *nd = &sc->bvh.nodes[(size_t) n * 32];
+            for (int c = 0; c < 4; ++c) {
+                uint32_t ref; memcpy(&ref, &nd[24 + c], 4);
+                if (nd[c] == INFINITY || (int32_t) ref >= 0) continue;           /* empty slot / inner child */
+                flat.push_back(make_float4(nd[c], nd[4 + c], nd[8 + c], pm_from_bits(ref)));
+                flat.push_back(make_float4(nd[12 + c], nd[16 + c], nd[20 + c], 0.0f));
+            }
+        }
+        if (flat.size() / 2 <= FLAT_LEAVES_MAX) {
+            sd.flatLeaves.upload(flat.data(), flat.size());
+            D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
+        }
+    }
     sd.counters.alloc(1);
     sd.invalid.alloc(1);
     sd.dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
@@ -923,7 +946,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
     if (fused) {
         const size_t megaLds = megaLdsBytesOf(D);
-        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, megaLds));
+        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves != 0, megaLds));
         if (const char *e = getenv("PHIP_MEGA_BLOCKS")) perCU = std::max(1, std::min(perCU, atoi(e)));
         if (perCU <= 0) throw std::runtime_error("k_mega does not fit a compute unit");
         megaGrid = dim3((unsigned) (nCU * perCU));

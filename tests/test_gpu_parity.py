@@ -228,15 +228,16 @@ def test_error_behaviour(gpu, phip, gauss):
 def test_cancel_returns_false(gpu, gauss):
     import threading, time
     from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
-    gs = Scene(S.cornell_box(512, 512, gauss).desc())
+    gs = Scene(S.cornell_box(1024, 1024, gauss).desc())
     integ = PathHIP(maxDepth=-1)
-    film = HDRFilm(512, 512)
+    film = HDRFilm(1024, 1024)
+    assert integ.render(gs, film, 1)         # (warm-up: allocations, so that the timed render below is all kernel time)
     integ._scene = gs
     t = threading.Timer(0.05, integ.cancel); t.start()
-    ok = integ.render(gs, film, 512)
+    ok = integ.render(gs, film, 2048)        # 2.1 G samples: ~0.7 s at 3 G samples/s -- the request arrives in the middle
     t.join()
     assert ok is False                       # SamplingIntegrator::render returns false when cancelled
-    film2 = HDRFilm(512, 512)
+    film2 = HDRFilm(1024, 1024)
     assert integ.render(gs, film2, 1) is True   # the scene is reusable afterwards
 
 
