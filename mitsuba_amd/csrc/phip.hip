@@ -703,7 +703,7 @@ static SceneDev *replicateScene(phip_scene *sc, int device) {
     std::unique_ptr<SceneDev> dst(new SceneDev());
     dst->device = device;
     HIP_TRY(hipSetDevice(device));
-    dst->nodes.cloneFrom(src.nodes); dst->wnodes.cloneFrom(src.wnodes); dst->tris.cloneFrom(src.tris); dst->triShade.cloneFrom(src.triShade);
+    dst->nodes.cloneFrom(src.nodes); dst->wnodes.cloneFrom(src.wnodes); dst->tris.cloneFrom(src.tris); dst->triShade.cloneFrom(src.triShade); dst->flatLeaves.cloneFrom(src.flatLeaves);
     dst->materials.cloneFrom(src.materials); dst->emitterTab.cloneFrom(src.emitterTab);
     dst->texTexels.cloneFrom(src.texTexels); dst->texDesc.cloneFrom(src.texDesc);
     dst->envTexels.cloneFrom(src.envTexels); dst->envLevels.cloneFrom(src.envLevels);
