@@ -313,7 +313,7 @@ __device__ __forceinline__ bool traverseFlat(const DevScene &S, lds_cf4 *flat, u
     const V3 ordr(o.x * rcp.x, o.y * rcp.y, o.z * rcp.z);
     uint32_t mask = 0;
     for (uint32_t c = 0; c < nFlat; ++c) {
-        const float4 mn = ldsLoad4(flat + 2 * c), mx = ldsLoad4(flat + 2 * c + 1);
+        const float4 mn = ldsLoad4(flat + 2 * c), mx = ldsLoad4(flat + 2 * c + 1);      /* (scalar loads from the kernel argument instead: 87.6 vs 80.4 ms per C2 frame) */
         const float x0 = fmaf(mn.x, rcp.x, -ordr.x), x1 = fmaf(mx.x, rcp.x, -ordr.x);
         const float y0 = fmaf(mn.y, rcp.y, -ordr.y), y1 = fmaf(mx.y, rcp.y, -ordr.y);
         const float z0 = fmaf(mn.z, rcp.z, -ordr.z), z1 = fmaf(mx.z, rcp.z, -ordr.z);
