@@ -177,7 +177,9 @@ def dominant_kernel(r):
     a = r["agg"]
     nodes = r["accel"]["n_nodes"]
     if a["fused"]:
-        return "k_mega", "whole path in one persistent kernel: BVH4 (%d nodes), Wald + shading records, emitters, materials in LDS" % nodes, a["fused_kernel_ms"], max(int(a["iterations"]), 1)
+        leaves = r["accel"]["n_leaves"]
+        tree = ("the tree's %d leaves as a flat table of boxes (one uniform pass), " % leaves) if leaves <= 32 else ("BVH4 (%d nodes), " % nodes)
+        return "k_mega", "whole path in one persistent kernel: " + tree + "Wald + shading records, emitters, materials in LDS", a["fused_kernel_ms"], max(int(a["iterations"]), 1)
     merged = a["shadow_kernel_ms"] == 0 and a["shadow_rays"] > 0        # closest-hit + any-hit rays in one persistent launch (big trees)
     wide = r["accel"]["node_bytes"] == 80                                # ... over the compressed 8-wide BVH
     rays = "k_rays_w" if wide else "k_rays_p"
