@@ -26,6 +26,7 @@
 #include <vector>
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
 #include <cmath>
 #include <algorithm>
 #include <chrono>
@@ -407,6 +408,101 @@ struct Builder {
 } // namespace detail
 
 /*
+ * Insertion-based optimisation of the binary tree (Bittner, Hapala, Havran: "Fast Insertion-Based Optimization of Bounding Volume
+ * Hierarchies", CGF 2013), EXPERIMENT: off unless PHIP_BVH_OPT=<passes> is set (round 2: written and measured on the CPU twin of the
+ * traversal only, tools/bvh_quality.py).  One step: take an inner node n out of the tree (its parent goes with it, the sibling moves
+ * up), then put each of n's two subtrees back where it costs least -- branch-and-bound over the whole tree for the node Y that
+ * minimises area(Y u X) + the growth of Y's ancestors -- under a new parent made from one of the two freed nodes.  Leaves (record
+ * ranges) are never touched, so the records and the answers stay what they were; only the inner topology changes.
+ */
+namespace detail {
+struct Reinserter {
+    struct Inner { int32_t parent; int32_t child[2]; Box box[2]; };
+    std::vector<Inner> n;                      /* inner nodes; child >= 0: inner, < 0: leaf reference */
+    std::vector<int32_t> leafParent;           /* by first record of the leaf */
+    int32_t root;
+    static uint32_t leafKey(int32_t ref) { return (~(uint32_t) ref) >> 3; }
+    Box boxOf(int32_t i) const { Box b = n[i].box[0]; b.grow(n[i].box[1].mn, n[i].box[1].mx); return b; }
+    int32_t parentOf(int32_t ref) const { return ref >= 0 ? n[ref].parent : leafParent[leafKey(ref)]; }
+    void setParent(int32_t ref, int32_t p) { if (ref >= 0) n[ref].parent = p; else leafParent[leafKey(ref)] = p; }
+    int slotOf(int32_t p, int32_t ref) const { return n[p].child[0] == ref ? 0 : 1; }
+    static float unionArea(const Box &a, const Box &b) { Box u = a; u.grow(b.mn, b.mx); return u.area(); }
+    /* boxes of the ancestors of p's slots, from p up to the root */
+    void refit(int32_t p) {
+        while (p >= 0) {
+            const int32_t g = n[p].parent;
+            if (g < 0) break;
+            n[g].box[slotOf(g, p)] = boxOf(p);
+            p = g;
+        }
+    }
+    /* best node to pair subtree X (box bx) with */
+    int32_t findBest(const Box &bx, Box &bestBox) const {
+        struct Cand { float induced; int32_t ref; Box box; };
+        auto cmp = [](const Cand &a, const Cand &b) { return a.induced > b.induced; };
+        std::vector<Cand> heap;
+        const float ax = bx.area();
+        float best = INFINITY; int32_t bestRef = root; bestBox = boxOf(root);
+        heap.push_back({ 0.0f, root, boxOf(root) });
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            const Cand c = heap.back(); heap.pop_back();
+            if (c.induced + ax >= best) break;                           /* every remaining candidate is at least this bad */
+            const float direct = unionArea(c.box, bx);
+            const float total = c.induced + direct;
+            if (total < best) { best = total; bestRef = c.ref; bestBox = c.box; }
+            if (c.ref >= 0) {
+                const float ind = total - c.box.area();                  /* growth this node would suffer as an ancestor */
+                if (ind + ax < best)
+                    for (int k = 0; k < 2; ++k) { heap.push_back({ ind, n[c.ref].child[k], n[c.ref].box[k] }); std::push_heap(heap.begin(), heap.end(), cmp); }
+            }
+        }
+        return bestRef;
+    }
+    /* pair subtree x with node y under the free inner node q */
+    void insert(int32_t x, const Box &bx, int32_t y, const Box &by, int32_t q) {
+        const int32_t p = parentOf(y);
+        n[q].child[0] = y; n[q].box[0] = by; n[q].child[1] = x; n[q].box[1] = bx; n[q].parent = p;
+        if (p >= 0) { const int sl = slotOf(p, y); n[p].child[sl] = q; }
+        else root = q;
+        setParent(y, q); setParent(x, q);
+        if (p >= 0) { n[p].box[slotOf(p, q)] = boxOf(q); refit(p); }
+    }
+    double sah() const {
+        double c = 0;
+        for (size_t i = 0; i < n.size(); ++i) c += n[i].box[0].area() + n[i].box[1].area();
+        return c;
+    }
+    /* one pass over the inner nodes, largest boxes first */
+    void pass() {
+        std::vector<std::pair<float, int32_t>> order;
+        for (int32_t i = 0; i < (int32_t) n.size(); ++i) order.push_back({ -boxOf(i).area(), i });
+        std::sort(order.begin(), order.end());
+        for (const auto &o : order) {
+            const int32_t v = o.second;
+            const int32_t p = n[v].parent;
+            if (v == root || p < 0 || p == root) continue;               /* keep the top two levels in place */
+            const int32_t g = n[p].parent;
+            const int sv = slotOf(p, v);
+            const int32_t sib = n[p].child[1 - sv]; const Box sibBox = n[p].box[1 - sv];
+            /* take v and p out: the sibling moves up into p's slot */
+            const int sp = slotOf(g, p);
+            n[g].child[sp] = sib; n[g].box[sp] = sibBox; setParent(sib, g);
+            refit(g);
+            const int32_t kids[2] = { n[v].child[0], n[v].child[1] }; const Box kb[2] = { n[v].box[0], n[v].box[1] };
+            const int first = kb[0].area() >= kb[1].area() ? 0 : 1;     /* the larger subtree first */
+            const int32_t freeIds[2] = { v, p };
+            for (int t = 0; t < 2; ++t) {
+                const int k = t == 0 ? first : 1 - first;
+                Box by; const int32_t y = findBest(kb[k], by);
+                insert(kids[k], kb[k], y, by, freeIds[t]);
+            }
+        }
+    }
+};
+} // namespace detail
+
+/*
  * Compressed wide BVH (CWBVH, Ylitie et al. 2017), built by collapsing the binary SAH tree.  The ray kernels of the big scenes
  * are bound by the CU's vector-memory path (every lane of a wave fetches its own node: 64 cache lines per load instruction),
  * so what counts is bytes and dependent round trips per ray: one 80-byte node replaces ~2.3 of the 128-byte BVH4 nodes.
@@ -621,6 +717,49 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
         root2 = B.buildSpatial(T, rootBox, 1);
     } else
         root2 = B.build(0, T.size(), rootBox, 1);
+    if (const char *e = getenv("PHIP_BVH_OPT")) {
+        const int passes = atoi(e);
+        if (passes > 0 && root2 >= 0 && out.nNodes2 > 8) {
+            detail::Reinserter R;
+            R.n.resize(out.nNodes2); R.leafParent.assign(out.tris.size() / 12 + 1, -1); R.root = root2;
+            for (uint32_t i = 0; i < out.nNodes2; ++i) {
+                const float *nd = &out.nodes2[(size_t) i * 16];
+                detail::Box a, b;
+                a.mn[0] = nd[0]; a.mn[1] = nd[1]; a.mn[2] = nd[2]; a.mx[0] = nd[3]; a.mx[1] = nd[4]; a.mx[2] = nd[5];
+                b.mn[0] = nd[6]; b.mn[1] = nd[7]; b.mn[2] = nd[8]; b.mx[0] = nd[9]; b.mx[1] = nd[10]; b.mx[2] = nd[11];
+                uint32_t l, r; memcpy(&l, &nd[12], 4); memcpy(&r, &nd[13], 4);
+                R.n[i].box[0] = a; R.n[i].box[1] = b; R.n[i].child[0] = (int32_t) l; R.n[i].child[1] = (int32_t) r; R.n[i].parent = -1;
+            }
+            for (uint32_t i = 0; i < out.nNodes2; ++i)
+                for (int k = 0; k < 2; ++k) R.setParent(R.n[i].child[k], (int32_t) i);
+            R.n[root2].parent = -1;
+            const double before = R.sah();
+            for (int it = 0; it < passes; ++it) R.pass();
+            if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "phip: BVH reinsertion, %d passes: sum of child areas %.6g -> %.6g\n", passes, before, R.sah());
+            /* write back, inner nodes renumbered in depth-first pre-order (a parent before its children: buildWide's post-order loop) */
+            std::vector<float> nn((size_t) out.nNodes2 * 16);
+            std::vector<int32_t> newId(out.nNodes2, -1), stack;
+            uint32_t next = 0;
+            stack.push_back(R.root);
+            std::vector<int32_t> orderIds;
+            while (!stack.empty()) {
+                const int32_t v = stack.back(); stack.pop_back();
+                newId[v] = (int32_t) next++; orderIds.push_back(v);
+                for (int k = 1; k >= 0; --k) if (R.n[v].child[k] >= 0) stack.push_back(R.n[v].child[k]);
+            }
+            for (int32_t v : orderIds) {
+                float *nd = &nn[(size_t) newId[v] * 16];
+                const detail::Box &a = R.n[v].box[0], &b = R.n[v].box[1];
+                nd[0] = a.mn[0]; nd[1] = a.mn[1]; nd[2] = a.mn[2]; nd[3] = a.mx[0]; nd[4] = a.mx[1]; nd[5] = a.mx[2];
+                nd[6] = b.mn[0]; nd[7] = b.mn[1]; nd[8] = b.mn[2]; nd[9] = b.mx[0]; nd[10] = b.mx[1]; nd[11] = b.mx[2];
+                const uint32_t l = (uint32_t) (R.n[v].child[0] >= 0 ? newId[R.n[v].child[0]] : R.n[v].child[0]);
+                const uint32_t r = (uint32_t) (R.n[v].child[1] >= 0 ? newId[R.n[v].child[1]] : R.n[v].child[1]);
+                memcpy(&nd[12], &l, 4); memcpy(&nd[13], &r, 4); nd[14] = 0; nd[15] = 0;
+            }
+            out.nodes2.swap(nn);
+            root2 = 0;
+        }
+    }
 
     /* ---- collapse to BVH4 ---- */
     typedef detail::ChildRef Child;

@@ -114,8 +114,9 @@ def test_answer_does_not_depend_on_the_structure(phip, gauss, monkeypatch):
     rays = rays_through(rng, 60000, P.min(axis=0), P.max(axis=0), axis_aligned=0.05)
     answers = []
     for env in ({"PHIP_BVH_SPATIAL": "0"}, {"PHIP_BVH_SPATIAL": "1"}, {"PHIP_BVH_SPATIAL": "1", "PHIP_BVH_CTRAV": "0.4", "PHIP_BVH_ALPHA": "1e-7"},
-                {"PHIP_BVH_SPATIAL": "0", "PHIP_BVH_CTRAV": "2.5", "PHIP_BVH_MAXLEAF": "8"}):
-        for k in ("PHIP_BVH_SPATIAL", "PHIP_BVH_CTRAV", "PHIP_BVH_ALPHA", "PHIP_BVH_MAXLEAF"):
+                {"PHIP_BVH_SPATIAL": "0", "PHIP_BVH_CTRAV": "2.5", "PHIP_BVH_MAXLEAF": "8"},
+                {"PHIP_BVH_SPATIAL": "1", "PHIP_BVH_OPT": "2"}, {"PHIP_BVH_SPATIAL": "0", "PHIP_BVH_OPT": "1"}):     # + insertion-based re-optimisation of the topology
+        for k in ("PHIP_BVH_SPATIAL", "PHIP_BVH_CTRAV", "PHIP_BVH_ALPHA", "PHIP_BVH_MAXLEAF", "PHIP_BVH_OPT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
