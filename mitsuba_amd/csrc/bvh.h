@@ -409,8 +409,8 @@ struct Builder {
 
 /*
  * Insertion-based optimisation of the binary tree (Bittner, Hapala, Havran: "Fast Insertion-Based Optimization of Bounding Volume
- * Hierarchies", CGF 2013), EXPERIMENT: off unless PHIP_BVH_OPT=<passes> is set (round 2: written and measured on the CPU twin of the
- * traversal only, tools/bvh_quality.py).  One step: take an inner node n out of the tree (its parent goes with it, the sibling moves
+ * Hierarchies", CGF 2013).  One pass for scenes of SPATIAL_MIN_TRIS triangles or more (PHIP_BVH_OPT=<passes> overrides; round 2: measured on
+ * the CPU twin of the traversal, tools/bvh_quality.py: node steps per ray -7 % / -13 % on the atrium, -5 % / -9 % on the glass room).  One step: take an inner node n out of the tree (its parent goes with it, the sibling moves
  * up), then put each of n's two subtrees back where it costs least -- branch-and-bound over the whole tree for the node Y that
  * minimises area(Y u X) + the growth of Y's ancestors -- under a new parent made from one of the two freed nodes.  Leaves (record
  * ranges) are never touched, so the records and the answers stay what they were; only the inner topology changes.
@@ -717,9 +717,12 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
         root2 = B.buildSpatial(T, rootBox, 1);
     } else
         root2 = B.build(0, T.size(), rootBox, 1);
-    if (const char *e = getenv("PHIP_BVH_OPT")) {
-        const int passes = atoi(e);
+    {
+        /* one pass for the scenes that use the wide tree (the gate of the spatial splits); PHIP_BVH_OPT=<passes> overrides, 0 disables */
+        const char *e = getenv("PHIP_BVH_OPT");
+        const int passes = e ? atoi(e) : (nTris >= SPATIAL_MIN_TRIS ? 1 : 0);
         if (passes > 0 && root2 >= 0 && out.nNodes2 > 8) {
+            const std::vector<float> nodes2Before = out.nodes2; const int32_t root2Before = root2;
             detail::Reinserter R;
             R.n.resize(out.nNodes2); R.leafParent.assign(out.tris.size() / 12 + 1, -1); R.root = root2;
             for (uint32_t i = 0; i < out.nNodes2; ++i) {
@@ -758,6 +761,13 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
             }
             out.nodes2.swap(nn);
             root2 = 0;
+            /* guard: reinsertion may chain nodes of identical boxes; a tree that got much deeper is not worth having (stack depth) */
+            std::function<uint32_t(int32_t)> depthOf = [&](int32_t v) -> uint32_t {
+                uint32_t l, r; memcpy(&l, &out.nodes2[(size_t) v * 16 + 12], 4); memcpy(&r, &out.nodes2[(size_t) v * 16 + 13], 4);
+                return 1u + std::max((int32_t) l >= 0 ? depthOf((int32_t) l) : 1u, (int32_t) r >= 0 ? depthOf((int32_t) r) : 1u);
+            };
+            const uint32_t depthAfter = depthOf(root2);
+            if (depthAfter > std::max<uint32_t>(out.maxDepth + 12u, 40u)) { out.nodes2 = nodes2Before; root2 = root2Before; }
         }
     }
 
