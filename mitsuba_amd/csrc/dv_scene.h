@@ -96,6 +96,8 @@ struct DevScene {
     DevEnvMap env;
     int32_t rootRef; uint32_t nTriangles;
     uint32_t stackDepth, nodeCache, triCache;   /* LDS staging plan of the traversal kernels */
+    uint32_t preclip;                    /* the shading kernels clip the rays they make against the scene box (k_clip.h); k_rays_w expects it */
+    uint32_t shadeSort;                  /* the Wald records carry shade classes and the scene has more than one: k_shade deals slots to lanes by class */
     float sceneMin[3], sceneMax[3];
     DevCamera cam; DevFilm film;
 };

@@ -38,7 +38,7 @@ struct PathPool {
     float4 *camHit;   /* `direct` only: the camera ray's hit record, kept while the vertex's BSDF-sampled rays are traced */
     uint4 *info;      /* sampleId, pixel, sampleIndex, - : written when the slot starts a sample, read-only afterwards */
     uint32_t *state;  /* depth | flags: the only per-iteration slot header (4 B instead of rewriting 16 B) */
-    float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,bits(sampleId)) (contrib.rgb,0);
+    float4 *shadow;   /* 3 float4 per entry: (o.xyz,maxt) (d.xyz,0) (contrib.rgb,bits(sampleId)) -- clipped, (o,maxt') (d,mint'), with DevScene::preclip (k_clip.h);
                          block b's entries are compacted at [b*BLOCK, b*BLOCK + shadowCount[b]) */
     uint32_t *shadowCount;            /* per block of BLOCK slots */
     uint32_t *blockDead;              /* per block: every slot is F_DEAD and nothing is queued any more -- the drain phase of a pass skips these blocks */
@@ -46,6 +46,15 @@ struct PathPool {
     uint32_t *spill;                  /* traversal-stack overflow: SPILL_DEPTH entries per lane */
     uint32_t capacity, nWaves;
 };
+
+/* The closest-hit record of a slot is (t, u, v, w) with w = bits(prim) | shade class << 30 (PHIP_NO_HIT stays all ones): the ray kernel
+ * of the big scenes (k_rays_w) passes on the class it finds in the spare word of the Wald record it hit -- 0 diffuse, 1 rough
+ * conductor, 2 dielectric (the heavier of the two sides of a two-sided surface) -- so that k_shade can deal a block's slots to its
+ * lanes by BSDF model before it has fetched anything else (k_shade.h).  The other ray kernels leave the class 0. */
+#define HIT_CLASS_SHIFT 30
+#define HIT_PRIM_MASK 0x3FFFFFFFu
+__host__ __device__ __forceinline__ uint32_t hitPrim(uint32_t w) { return w == PHIP_NO_HIT ? w : (w & HIT_PRIM_MASK); }
+__host__ __device__ __forceinline__ uint32_t hitClass(uint32_t w) { return w == PHIP_NO_HIT ? 0u : (w >> HIT_CLASS_SHIFT); }
 
 /* Work counters are kept per wave (one owner, plain read-modify-write, no atomics: a single
  * contended word saturates at ~88 atomics/us on MI355X) in SoA arrays stat[k][waveId] and summed

@@ -95,7 +95,7 @@ struct TraceSource {
         return true;
     }
     __device__ __forceinline__ void commit(uint32_t slot, bool, const TravResult &r) const {
-        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim == PHIP_NO_HIT ? r.prim : (r.prim | (r.cls << HIT_CLASS_SHIFT))));
     }
 };
 
@@ -130,8 +130,8 @@ struct ShadowSource {
     }
     __device__ __forceinline__ void commit(uint32_t e, bool occluded, const TravResult &) const {
         if (!occluded) {
-            const float4 e1 = P.shadow[3 * (size_t) e + 1], e2 = P.shadow[3 * (size_t) e + 2];
-            addRadiance(L, pm_to_bits(e1.w), e2);
+            const float4 e2 = P.shadow[3 * (size_t) e + 2];
+            addRadiance(L, pm_to_bits(e2.w), e2);
         }
     }
 };
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathP
         if (clipToScene<true>(S, o, d, PT_EPSILON, e0.w, mint, maxt, rcp))
             occluded = traverse<true>(S, o, d, rcp, mint, maxt, stk, r, nodeVisits, triTests);
         if (!occluded) {
-            addRadiance(L, pm_to_bits(e1.w), e2);
+            addRadiance(L, pm_to_bits(e2.w), e2);
         }
     }
     if ((threadIdx.x & ~63u) < n) {                          /* waves without entries have nothing to add */

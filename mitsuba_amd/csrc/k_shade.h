@@ -8,8 +8,14 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
     return pdfA / (pdfA + pdfB);
 }
 
+#ifndef SHADE_SORT
+#define SHADE_SORT 1                /* scenes with more than one BSDF model: deal the block's slots to its lanes by the model of the surface hit (k_shade) */
+#endif
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
+#endif
+#ifndef SHADE_WAVES_ROUGH
+#define SHADE_WAVES_ROUGH 5         /* diffuse + rough conductor, no strictNormals / environment / textures (the other instantiations spill at this bound): 95-97 VGPRs without the bound; with the lane deal the kernel waits on memory two thirds of its time, so the fifth wave counts */
 #endif
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
@@ -32,7 +38,9 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         for (uint32_t w = 0; w < BLOCK / 64; ++w) { const uint32_t c = waveCnt[w]; if (w < wave) base += c; total += c; }
         if (pushShadow) {
             const size_t sidx = (size_t) blockIdx.x * BLOCK + base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-            P.shadow[3 * sidx] = sh0; P.shadow[3 * sidx + 1] = sh1; P.shadow[3 * sidx + 2] = sh2;
+            float4 e0 = sh0, e1 = sh1;
+            if (S.preclip) preclipShadow(S, e0, e1);
+            P.shadow[3 * sidx] = e0; P.shadow[3 * sidx + 1] = e1; P.shadow[3 * sidx + 2] = sh2;
         }
         if (threadIdx.x == 0) P.shadowCount[blockIdx.x] = total;
         shadowTotal = total;
@@ -106,8 +114,10 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         const float sx = (float) px + jit.x, sy = (float) py + jit.y;
         V3 o, d; float mint, maxt;
         cameraRay(S.cam, sx, sy, o, d, mint, maxt);
-        P.rayO[slot] = make_float4(o.x, o.y, o.z, mint);
-        P.rayD[slot] = make_float4(d.x, d.y, d.z, maxt);
+        float4 ro = make_float4(o.x, o.y, o.z, mint), rd = make_float4(d.x, d.y, d.z, maxt);
+        if (S.preclip) preclipRay(S, ro, rd);
+        P.rayO[slot] = ro;
+        P.rayD[slot] = rd;
         P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         P.mis[slot] = make_float2(0.0f, 0.0f);
         info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
@@ -115,7 +125,7 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         P.state[slot] = info.w;
         nowAlive = true;
     }
-    const uint32_t waveId = slot >> 6;
+    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;      /* the wave's position in the grid (NOT slot >> 6: k_shade may have permuted the block's slots) */
     /* a slot still waiting for a dynamic sample id counts as live for the termination test */
     const bool live = nowAlive || (inRange && info.w == F_DYNAMIC);
     /* the block retires once none of its slots will ever work again and its last shadow entries have been consumed
@@ -143,7 +153,7 @@ struct PathVertex {
     float4 thr;                 /* throughput rgb, eta */
     float2 mis;                 /* (BSDF pdf of the sampled direction, dot(direction, refN)) of the previous vertex */
 };
-struct ShadowEntry { float4 e0, e1, e2; };     /* (o, maxt) (d, bits(id)) (contribution, 0) */
+struct ShadowEntry { float4 e0, e1, e2; };     /* (o, maxt) (d, 0) (contribution, bits(id)); with DevScene::preclip the queue holds (o, maxt') (d, mint'): k_clip.h */
 
 /* Radiance access policies: LGlobal = the per-sample buffer (read only when an emitter is hit: one random sector),
    LRegister = an accumulator register (k_mega).  rayO() is needed by one rare branch (environment hit by a BSDF ray). */
@@ -358,8 +368,8 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
         if (haveAdd) acc.store(id, l);
         if (pushShadow) {   /* self-contained shadow-queue entry: survives the slot being recycled */
             sh.e0 = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
-            sh.e1 = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
-            sh.e2 = make_float4(shC.x, shC.y, shC.z, 0.0f);
+            sh.e1 = make_float4(shD.x, shD.y, shD.z, 0.0f);
+            sh.e2 = make_float4(shC.x, shC.y, shC.z, pm_from_bits(id));
         }
     }
     if (terminate) vertices = depth;
@@ -383,17 +393,17 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
     return t;
 }
 
-template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : SHADE_WAVES) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : ((MM == MM_ROUGH && !STRICT && FEAT == 0) ? SHADE_WAVES_ROUGH : SHADE_WAVES)) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
     const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    const bool inRange = slot < P.capacity;
+    uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    bool inRange = slot < P.capacity;
     /* all slot state is fetched up front, before the liveness test, so that the five 16-byte loads are
        in flight together (the kernel is latency bound: 70 % of its wave cycles were s_waitcnt) */
-    const uint32_t lslot = inRange ? slot : 0u;
+    uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
     info.w = P.state[lslot];
     PathVertex v;
@@ -401,6 +411,50 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
     v.rayD = P.rayD[lslot];
     v.thr = P.thr[lslot];
     v.mis = P.mis[lslot];
+    if (MM != 0 && SHADE_SORT && S.shadeSort) {                 /* (block-uniform) */
+        /* Scenes with more than one BSDF model: on the atrium 8 % of the vertices lie on copper, so nearly every wave ran the
+           microfacet code -- the longest branch of the vertex by far -- for its two or three conductor lanes (round 2: lane
+           utilisation 0.27).  Which LANE shades which of the block's 256 slots is free (all state is addressed by slot), so the
+           slots are dealt to the lanes by the class the ray kernel left in the hit record (k_pool.h): diffuse, rough conductor,
+           dielectric, then the slots without a live path (they regenerate).  A wave runs the microfacet code only if it got
+           conductor vertices (VALU instructions per launch -40 %, lane utilisation 0.29 -> 0.53).  Every lane fetches the state of
+           ITS slot (coalesced, one round trip, as without the deal) and hands it to the lane that shades it through LDS.  Results
+           cannot change: every slot is shaded by exactly one lane with the same code. */
+        __shared__ uint4 xInfo[BLOCK];
+        __shared__ float4 xHit[BLOCK], xRayD[BLOCK], xThr[BLOCK];
+        __shared__ float2 xMis[BLOCK];
+        __shared__ uint32_t xSlot[BLOCK];
+        __shared__ uint32_t clsCnt[4][BLOCK / 64];
+        uint32_t cls = 3u;
+        if (inRange && (info.w & F_ALIVE)) {
+            const uint32_t w = pm_to_bits(v.hit.w);
+            if (w != PHIP_NO_HIT) cls = w >> HIT_CLASS_SHIFT;       /* (a path that left the scene ends here: with the idle slots) */
+        }
+        const uint32_t wave = threadIdx.x >> 6, lane = __lane_id();
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (cls == c) rank = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) clsCnt[c][wave] = (uint32_t) __popcll(m);
+        }
+        __syncthreads();
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c)
+#pragma unroll
+            for (uint32_t w = 0; w < BLOCK / 64; ++w) {
+                const uint32_t n = clsCnt[c][w];
+                if (c < cls || (c == cls && w < wave)) base += n;
+            }
+        const uint32_t dst = base + rank;
+        xInfo[dst] = info; xHit[dst] = v.hit; xRayD[dst] = v.rayD; xThr[dst] = v.thr; xMis[dst] = v.mis; xSlot[dst] = slot;
+        __syncthreads();
+        info = xInfo[threadIdx.x]; v.hit = xHit[threadIdx.x]; v.rayD = xRayD[threadIdx.x]; v.thr = xThr[threadIdx.x]; v.mis = xMis[threadIdx.x];
+        slot = xSlot[threadIdx.x];
+        inRange = slot < P.capacity;
+    }
+    v.hit.w = pm_from_bits(hitPrim(pm_to_bits(v.hit.w)));       /* (the class bits have served: k_pool.h) */
     if (!inRange) info = make_uint4(0, 0, 0, 0);
     __syncthreads();                                            /* LDS tables are complete */
     bool alive = inRange && (info.w & F_ALIVE);
@@ -421,6 +475,7 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
             P.state[slot] = info.w;
         }
         if (newRay) {
+            if (S.preclip) preclipRay(S, v.rayO, v.rayD);
             P.rayO[slot] = v.rayO; P.rayD[slot] = v.rayD; P.thr[slot] = v.thr; P.mis[slot] = v.mis;
         }
     }

@@ -26,7 +26,8 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
     const uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
     info.w = P.state[lslot];
-    const float4 hit = P.hit[lslot];
+    float4 hit = P.hit[lslot];
+    hit.w = pm_from_bits(hitPrim(pm_to_bits(hit.w)));           /* (class bits of k_rays_w: k_pool.h) */
     const float4 rd = P.rayD[lslot];
     const float4 thr4 = P.thr[lslot];
     float4 camHit = P.camHit[lslot];
@@ -175,8 +176,10 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                         const V3 wo = its.sh.toWorld(bs.wo);
                         const float woDotGeoN = dot(its.geoN, wo);
                         if (!(rc.strictNormals && woDotGeoN * cosTheta(bs.wo) <= 0)) {
-                            P.rayO[slot] = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
-                            P.rayD[slot] = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                            float4 ro = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON), rdn = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                            if (S.preclip) preclipRay(S, ro, rdn);
+                            P.rayO[slot] = ro;
+                            P.rayD[slot] = rdn;
                             P.thr[slot] = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bs.pdf);
                             flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
                             issued = true;
@@ -189,8 +192,8 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             }
             if (pushShadow) {
                 sh0 = make_float4(its.p.x, its.p.y, its.p.z, shMaxt);
-                sh1 = make_float4(shD.x, shD.y, shD.z, pm_from_bits(id));
-                sh2 = make_float4(shC.x, shC.y, shC.z, 0.0f);
+                sh1 = make_float4(shD.x, shD.y, shD.z, 0.0f);
+                sh2 = make_float4(shC.x, shC.y, shC.z, pm_from_bits(id));
             }
         }
         if (haveAdd) L[id] = l;

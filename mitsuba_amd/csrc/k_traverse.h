@@ -6,92 +6,7 @@
 /* ======================================================================================
  *  BVH traversal (closest / any hit)
  * ====================================================================================== */
-struct TravResult { float t, u, v; uint32_t prim; };
-
-/* Reciprocal direction for the slab tests.  A zero (or denormal) component must not become +-inf: the slab form
- * fma(plane, rcp, -o * rcp) would then evaluate inf - inf = NaN for EVERY box, fminf/fmaxf drop the NaN and the node
- * is rejected -- an axis-aligned ray missed the whole tree (the reference handles d == 0 explicitly, aabb.h / skdtree.cpp:
- * the ray is inside the slab iff min <= o <= max).  A finite +-2^90 keeps the arithmetic meaningful: inside the slab the
- * two plane distances are -huge / +huge (no constraint), outside both have the same sign and |t| >= 2^90 * distance
- * exceeds every finite maxt; boxes are padded (bvh.h), so the rounding of o * rcp cannot flip a decision. */
-DV float slabRcp(float d) {
-    return fabsf(d) < 8.0779357e-28f /* 2^-90 */ ? copysignf(1.2379400e27f /* 2^90 */, d) : 1.0f / d;
-}
-/* ... from a reciprocal that is already there (the scene-box clip divides by the same components) */
-DV float slabRcpFrom(float d, float rcp) {
-    return fabsf(d) < 8.0779357e-28f ? copysignf(1.2379400e27f, d) : rcp;
-}
-
-/* scene-box clip + adaptive epsilon, src/librender/skdtree.cpp:112-142 (closest) / :207-226 (shadow).  Also hands out the
-   reciprocal direction for the slab tests: the clip divides by the same three components (an IEEE division is ~12 instructions;
-   a ray used to pay six of them). */
-template <bool SHADOW>
-__device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
-                                            float &mint, float &maxt, V3 &slab) {
-    float nearT = -INFINITY, farT = INFINITY;
-    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };       /* (inf for a zero component: not used by the clip then) */
-    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
-        if (dd[i] == 0) {
-            if (origin < minVal || origin > maxVal) return false;
-        } else {
-            const float rcp = rr[i];
-            float t1 = (minVal - origin) * rcp;
-            float t2 = (maxVal - origin) * rcp;
-            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
-            nearT = smax(t1, nearT);
-            farT = smin(t2, farT);
-            if (!(nearT <= farT)) return false;
-        }
-    }
-    mint = nearT; maxt = farT;
-    float rayMinT = rayMint;
-    if (rayMinT == PT_EPSILON) {
-        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-        if (!SHADOW) m = smax(m, PT_EPSILON);
-        rayMinT *= m;
-    }
-    if (rayMinT > mint) mint = rayMinT;
-    if (rayMaxt < maxt) maxt = rayMaxt;
-    return maxt > mint;
-}
-
-/* the same with the kind of the ray as a per-lane flag (the kernels that trace closest-hit and any-hit rays in one loop) */
-__device__ __forceinline__ bool clipToSceneRT(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
-                                              float &mint, float &maxt, bool shadow, V3 &slab) {
-    float nearT = -INFINITY, farT = INFINITY;
-    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
-    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
-        if (dd[i] == 0) {
-            if (origin < minVal || origin > maxVal) return false;
-        } else {
-            const float rcp = rr[i];
-            float t1 = (minVal - origin) * rcp;
-            float t2 = (maxVal - origin) * rcp;
-            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
-            nearT = smax(t1, nearT);
-            farT = smin(t2, farT);
-            if (!(nearT <= farT)) return false;
-        }
-    }
-    mint = nearT; maxt = farT;
-    float rayMinT = rayMint;
-    if (rayMinT == PT_EPSILON) {
-        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-        if (!shadow) m = smax(m, PT_EPSILON);               /* skdtree.cpp:124 vs :215 */
-        rayMinT *= m;
-    }
-    if (rayMinT > mint) mint = rayMinT;
-    if (rayMaxt < maxt) maxt = rayMaxt;
-    return maxt > mint;
-}
+struct TravResult { float t, u, v; uint32_t prim; uint32_t cls = 0; /* shade class of the record hit (k_rays_w only: k_pool.h) */ };
 
 /* Per-lane traversal stack: the first `depth` entries live in LDS (interleaved: entry e of lane l at
  * lds[e * BLOCK + l], so lane i always hits bank i), deeper entries spill to a per-lane HBM array.

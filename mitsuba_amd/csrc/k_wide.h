@@ -35,6 +35,15 @@
 #define WIDE_TYPED 1                     /* cached nodes are read with ds_read_b128 (LDS pipe) instead of flat_load (which sends LDS addresses through the
                                             texture addresser / data path the kernel is bound by: TD busy 95 %, round-2 counters) */
 #endif
+#ifndef WIDE_NODE_STRIDE
+#define WIDE_NODE_STRIDE 5               /* uint4 per node in HBM: 5 = packed 80-byte nodes (half of them straddle two 128-byte lines), 8 = one node per 128-byte line */
+#endif
+#ifndef WIDE_DUMMY_LOADS
+#define WIDE_DUMMY_LOADS 0               /* measurement: extra 16-byte loads of the node's own line per node step (L1 hits): what does one more vector-memory instruction cost? */
+#endif
+#ifndef WIDE_PROFILE
+#define WIDE_PROFILE 0
+#endif
 #ifndef WIDE_WAVES
 #define WIDE_WAVES 4                     /* waves per SIMD of k_rays_w: 112 VGPRs, no scratch.  Measured (C3 / C4 ray-kernel ms per frame): 4 waves 256.7 / 520 --
                                             5 waves (96 VGPRs + 84 B of scratch in the refill path) 254.6 / 532 with a 64-node cache, and a disaster
@@ -74,7 +83,7 @@ __host__ __device__ __forceinline__ uint32_t wideRaycastCache(uint32_t nodeCache
 template <int NB> __device__ __forceinline__ void setupWide(const DevScene &S, uint32_t nodeCache, unsigned char *smem, uint32_t *spill, WideStackT<NB> &stk) {
     uint2 *stack = (uint2 *) smem;
     uint4 *ln = (uint4 *) (smem + (size_t) WIDE_STACK_LDS * NB * sizeof(uint2));
-    for (uint32_t i = threadIdx.x; i < nodeCache * 5u; i += NB) ln[i] = S.wnodes[i];
+    for (uint32_t i = threadIdx.x; i < nodeCache * 5u; i += NB) ln[i] = S.wnodes[(i / 5u) * WIDE_NODE_STRIDE + i % 5u];
     __syncthreads();
     stk.lds = (lds_u2 *) (stack + threadIdx.x); stk.spill = (uint2 *) spill; stk.nodes = (lds_cu4 *) ln; stk.nodeCache = nodeCache; stk.sp = 0;
 }
@@ -142,8 +151,11 @@ __device__ __forceinline__ uint4 ldsLoadU4(lds_cu4 *p) { const u4v v = *p; retur
         lds_cu4 *l_ = (stack).nodes + 5u * (idx);                                                     \
         n0 = ldsLoadU4(l_); n1 = ldsLoadU4(l_ + 1); n2 = ldsLoadU4(l_ + 2); n3 = ldsLoadU4(l_ + 3); n4 = ldsLoadU4(l_ + 4); \
     } else {                                                                                          \
-        const uint4 *g_ = (!WIDE_TYPED && (idx) < (stack).nodeCache) ? (const uint4 *) ((stack).nodes + 5u * (idx)) : (S).wnodes + 5 * (size_t) (idx); \
+        const uint4 *g_ = (!WIDE_TYPED && (idx) < (stack).nodeCache) ? (const uint4 *) ((stack).nodes + 5u * (idx)) : (S).wnodes + WIDE_NODE_STRIDE * (size_t) (idx); \
         n0 = g_[0]; n1 = g_[1]; n2 = g_[2]; n3 = g_[3]; n4 = g_[4];                                   \
+        for (int dl_ = 0; dl_ < WIDE_DUMMY_LOADS; ++dl_) {                                            \
+            f4v dv_; asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(dv_) : "v"(g_) : "memory"); asm volatile("" :: "v"(dv_)); \
+        }                                                                                             \
     }
 
 /* a Wald record = three 16-byte loads.  Written as inline assembly: the compiler narrows the loads to the eleven dwords in use
@@ -218,17 +230,32 @@ __device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, con
  *      ~20 per wave and launch -- not the per-wave-per-iteration atomics on five shared words that round 1 banned. ---- */
 #define RAY_SHARDS 32
 #define RAY_SHARD_STRIDE 32              /* uint32 between counters (128 B) */
+#ifndef RAY_STATIC_PERCENT
+#define RAY_STATIC_PERCENT 60            /* share of a launch's work units dealt statically (wave w: units w, w + W, ...) before the waves draw from the counters */
+#endif
 struct DrawCounter {
-    unsigned int *ctr;                   /* RAY_SHARDS counters (zeroed by the host before the launch) */
+    unsigned int *ctr;                   /* RAY_SHARDS counters (zeroed before the launch) */
     uint32_t shard0, tried, perShard, total;
-    /* next unit of this wave (wave-uniform), or 0xFFFFFFFF when every shard is empty */
+    /* A returning atomic on a loaded chip is a round trip of more than a microsecond in which the whole wave stands still (round 3:
+       7 % of the ray kernel's wave time went into these draws).  So the first RAY_STATIC_PERCENT of the units are dealt statically
+       -- no memory access at all -- and only the rest is drawn: enough to level the waves out (the static deal alone left a fifth
+       of the wave slots empty towards the end of a launch), a third of the atomics. */
+    uint32_t sNext, sStride, nStatic;    /* static part: units sNext, sNext + sStride, ... < nStatic; dynamic part: units [nStatic, total) */
+    __device__ __forceinline__ void init(unsigned int *c, uint32_t shard, uint32_t totalUnits, uint32_t waveId, uint32_t nWavesGrid) {
+        ctr = c; shard0 = shard; tried = 0; total = totalUnits;
+        nStatic = (uint32_t) ((unsigned long long) totalUnits * RAY_STATIC_PERCENT / 100u) / nWavesGrid * nWavesGrid;
+        sNext = waveId; sStride = nWavesGrid;
+        perShard = (total - nStatic + RAY_SHARDS - 1) / RAY_SHARDS;
+    }
+    /* next unit of this wave (wave-uniform), or 0xFFFFFFFF when there is none left */
     __device__ __forceinline__ uint32_t draw() {
+        if (sNext < nStatic) { const uint32_t u = sNext; sNext += sStride; return u; }
         while (tried < RAY_SHARDS) {
             const uint32_t s = (shard0 + tried) % RAY_SHARDS;
             uint32_t c = 0;
             if (__lane_id() == 0) c = atomicAdd(ctr + (size_t) s * RAY_SHARD_STRIDE, 1u);
             c = __builtin_amdgcn_readfirstlane(c);
-            const uint32_t first = s * perShard, n = first >= total ? 0u : (total - first < perShard ? total - first : perShard);
+            const uint32_t first = nStatic + s * perShard, n = first >= total ? 0u : (total - first < perShard ? total - first : perShard);
             if (c < n) return first + c;
             ++tried;                     /* this shard is used up: for good */
         }
@@ -236,6 +263,8 @@ struct DrawCounter {
     }
 };
 
+/* closest-hit rays of the pool: chunks of 64 slots drawn from the sharded counters.  The rays are PRE-CLIPPED by the shading kernels
+   (DevScene::preclip, k_clip.h): (o, mint' | d, maxt'), maxt' < mint' = the ray misses the scene box */
 struct TraceSourceDyn {
     const PathPool &P; DrawCounter q; uint32_t chunk, pos;
     __device__ __forceinline__ void start() { chunk = q.draw(); pos = 0; }
@@ -248,16 +277,18 @@ struct TraceSourceDyn {
         return h;
     }
     __device__ __forceinline__ bool load(uint32_t slot, V3 &o, V3 &d, float &mint, float &maxt) const {
-        if ((P.state[slot] & F_TRACE_MASK) != F_ALIVE) return false;
+        /* state and ray in flight together: one memory round trip per refill instead of two (nearly every slot is alive outside the drain phase) */
+        const uint32_t st = P.state[slot];
         const float4 ro = P.rayO[slot], rd = P.rayD[slot];
         o = V3(ro.x, ro.y, ro.z); d = V3(rd.x, rd.y, rd.z); mint = ro.w; maxt = rd.w;
-        return true;
+        return (st & F_TRACE_MASK) == F_ALIVE;
     }
     __device__ __forceinline__ void commit(uint32_t slot, bool, const TravResult &r) const {
-        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim == PHIP_NO_HIT ? r.prim : (r.prim | (r.cls << HIT_CLASS_SHIFT))));
     }
 };
 
+/* the block-compacted shadow queue: blocks of up to 256 entries drawn from the sharded counters; entries pre-clipped: (o, maxt' | d, mint' | c, id) */
 struct ShadowSourceDyn {
     const PathPool &P; float4 *L; DrawCounter q; uint32_t blk, pos, cnt;
     __device__ __forceinline__ void start() {
@@ -278,45 +309,66 @@ struct ShadowSourceDyn {
     }
     __device__ __forceinline__ bool load(uint32_t e, V3 &o, V3 &d, float &mint, float &maxt) const {
         const float4 e0 = P.shadow[3 * (size_t) e], e1 = P.shadow[3 * (size_t) e + 1];
-        o = V3(e0.x, e0.y, e0.z); d = V3(e1.x, e1.y, e1.z); mint = PT_EPSILON; maxt = e0.w;
+        o = V3(e0.x, e0.y, e0.z); d = V3(e1.x, e1.y, e1.z); mint = e1.w; maxt = e0.w;
         return true;
     }
     __device__ __forceinline__ void commit(uint32_t e, bool occluded, const TravResult &) const {
         if (!occluded) {
-            const float4 e1 = P.shadow[3 * (size_t) e + 1], e2 = P.shadow[3 * (size_t) e + 2];
-            addRadiance(L, pm_to_bits(e1.w), e2);
+            const float4 e2 = P.shadow[3 * (size_t) e + 2];
+            addRadiance(L, pm_to_bits(e2.w), e2);
         }
     }
 };
 
-/* ---- persistent waves with refill: closest-hit AND any-hit rays of one iteration in ONE launch (as k_rays_p) ---- */
-template <typename ShadowSrc, typename TraceSrc>
-__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStackT<WIDE_BLOCK> &stack, ShadowSrc &ss, TraceSrc &ts,
-                                                       uint32_t *wc /* LDS: WC_COUNT counters of this wave */) {
-    bool active = false, shadow = false;
-    uint32_t handle = INVALID_RAY;
+/* the slab reciprocal of a pre-clipped ray: v_rcp_f32 (1 ulp) instead of the IEEE division the clip made in the shading kernel --
+   the slab tests only have to be conservative (boxes are quantised outwards and padded by 2e-6 of the scene extent, twenty times the
+   error this adds to a plane distance), the hit itself is decided by the Wald test on (o, d, mint', maxt') */
+__device__ __forceinline__ float slabRcpFast(float d) { return slabRcpFrom(d, __builtin_amdgcn_rcpf(d)); }
+
+/* ---- persistent waves with refill: closest-hit AND any-hit rays of one iteration in ONE launch (as k_rays_p) ----
+ * Per-lane state is kept small (the kernel wants five waves per SIMD): `meta` = handle | shade class << 28 | any-hit flag << 31,
+ * `steps` = node steps | triangle tests << 16 of the ray in flight. */
+enum { WW_RAYS = 0, WW_STEPS, WW_SH_RAYS, WW_SH_STEPS, WW_COUNT };     /* 64-bit LDS counters of a wave: rays, node steps | triangle tests << 32 */
+#define WM_HANDLE 0x0FFFFFFFu
+#define WM_SHADOW 0x80000000u
+__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStackT<WIDE_BLOCK> &stack, ShadowSourceDyn &ss, TraceSourceDyn &ts,
+                                                       unsigned long long *wc /* LDS: WC_COUNT counters of this wave */) {
+    bool active = false;
+    uint32_t meta = 0, steps = 0;
     WideRay ray; ray.o = ray.d = ray.rcp = V3(0.0f); ray.mint = ray.maxt = 0; ray.octinv4 = 0;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
-    uint32_t nodeCur = 0, triCur = 0;
     TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
 
+#if WIDE_PROFILE
+    /* measurement build: wave clock spent in the refill branch, refills, loop iterations (reported in the rows of the any-hit
+       counters, which this build therefore falsifies) */
+    unsigned long long pfRefill = 0, pfAssign = 0, pfLoad = 0, pfStart = clock64(); uint32_t pfRefills = 0, pfIters = 0;
+#endif
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const bool moreS = ss.more(), moreAny = moreS || ts.more();              /* wave-uniform */
         if (idle && moreAny && (__popcll(idle) >= REFILL_LANES || idle == ~0ull)) {
+#if WIDE_PROFILE
+            const unsigned long long pf0 = clock64(); ++pfRefills;
+#endif
             const uint32_t h = moreS ? ss.assign(!active, idle) : ts.assign(!active, idle);
+#if WIDE_PROFILE
+            __builtin_amdgcn_s_waitcnt(0); const unsigned long long pf1 = clock64(); pfAssign += pf1 - pf0;
+#endif
             if (!active && h != INVALID_RAY) {
-                V3 o, d; float rmint, rmaxt;
-                const bool ok = moreS ? ss.load(h, o, d, rmint, rmaxt) : ts.load(h, o, d, rmint, rmaxt);
+                V3 o, d; float mint, maxt;                   /* (already clipped to the scene box) */
+                const bool ok = moreS ? ss.load(h, o, d, mint, maxt) : ts.load(h, o, d, mint, maxt);
+#if WIDE_PROFILE
+                __builtin_amdgcn_s_waitcnt(0); pfLoad += clock64() - pf1;
+#endif
                 if (ok) {
-                    atomicAdd(&wc[moreS ? WC_SH_RAYS : WC_RAYS], 1u);
-                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
-                    float mint, maxt;
-                    V3 rcp;
-                    if (clipToSceneRT(S, o, d, rmint, rmaxt, mint, maxt, moreS, rcp)) {
-                        wideRaySetup(ray, o, d, rcp, mint, maxt);
+                    const unsigned long long got = __ballot(1);
+                    if (__lane_id() == (uint32_t) __ffsll((long long) got) - 1u) wc[moreS ? WW_SH_RAYS : WW_RAYS] += (uint32_t) __popcll(got);
+                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0; res.cls = 0;
+                    if (maxt > mint) {
+                        wideRaySetup(ray, o, d, V3(slabRcpFast(d.x), slabRcpFast(d.y), slabRcpFast(d.z)), mint, maxt);
                         ng = wideRootGroup(); tg = make_uint2(0u, 0u);
-                        stack.sp = 0; handle = h; active = true; shadow = moreS; nodeCur = triCur = 0;
+                        stack.sp = 0; meta = h | (moreS ? WM_SHADOW : 0u); active = true; steps = 0;
                     } else if (moreS) {
                         ss.commit(h, false, res);
                     } else {
@@ -324,22 +376,28 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                     }
                 }
             }
+#if WIDE_PROFILE
+            __builtin_amdgcn_s_waitcnt(0); pfRefill += clock64() - pf0;
+#endif
         }
         if (!__any(active)) { if (!(ss.more() || ts.more())) break; continue; }
         if (active) {
             for (;;) {
+#if WIDE_PROFILE
+                if (__builtin_amdgcn_readfirstlane(__lane_id()) == __lane_id()) ++pfIters;
+#endif
                 /* one node step and one triangle test per iteration */
-                if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, nodeCur)
+                if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps)
                 bool finished = false;
                 if (tg.y) {
                     const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;
                     tg.y &= tg.y - 1u;
                     WIDE_LOAD_TRI(S, tg.x + bit, a, b, c)
-                    ++triCur;
+                    steps += 0x10000u;
                     float tu, tv, tt;
                     if (waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {
-                        if (shadow) { res.prim = 0; finished = true; }
-                        else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); }
+                        if (meta & WM_SHADOW) { res.prim = 0; finished = true; }
+                        else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); res.cls = pm_to_bits(c.w); }
                     }
                 }
                 if (!finished && tg.y == 0u && !(ng.y & 0xff000000u)) {
@@ -350,10 +408,11 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                     }
                 }
                 if (finished) {
-                    if (shadow) ss.commit(handle, res.prim != PHIP_NO_HIT, res);
-                    else ts.commit(handle, false, res);
-                    atomicAdd(&wc[shadow ? WC_SH_NODE : WC_NODE], nodeCur);
-                    atomicAdd(&wc[shadow ? WC_SH_TRI : WC_TRI], triCur);
+                    const bool shadow = (meta & WM_SHADOW) != 0;
+                    if (shadow) ss.commit(meta & WM_HANDLE, res.prim != PHIP_NO_HIT, res);
+                    else ts.commit(meta & WM_HANDLE, false, res);
+                    /* node steps (low word) and triangle tests (high word) of the ray in ONE 64-bit LDS add */
+                    atomicAdd(&wc[shadow ? WW_SH_STEPS : WW_STEPS], (unsigned long long) (steps & 0xFFFFu) | ((unsigned long long) (steps >> 16) << 32));
                     active = false;
                     break;
                 }
@@ -361,32 +420,37 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
             }
         }
     }
+#if WIDE_PROFILE
+    {
+        const unsigned long long tot = clock64() - pfStart;
+        uint32_t it = pfIters;
+        for (int off = 32; off > 0; off >>= 1) it += __shfl_down(it, off);          /* one lane per iteration counted: the sum is the wave's iterations */
+        uint32_t ld = (uint32_t) pfLoad;
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o_ = __shfl_down(ld, off); ld = o_ > ld ? o_ : ld; }      /* the lane that waited longest */
+        if (__lane_id() == 0) { wc[WW_SH_STEPS] = (pfRefill & 0xFFFFFFFFull) | (tot << 32); wc[WW_SH_RAYS] = pfRefills; wc[WW_STEPS] = (unsigned long long) (uint32_t) pfAssign | ((unsigned long long) it << 32); wc[WW_RAYS] = ld; }
+    }
+#endif
 }
 
-__global__ __launch_bounds__(WIDE_BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L, unsigned int *drawCounters /* 2 * RAY_SHARDS lines, zeroed; NULL: static deal */) {
-    __shared__ uint32_t wcnt[WIDE_BLOCK / 64][WC_COUNT];
-    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * WIDE_BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (WIDE_BLOCK / 64);
-    if (threadIdx.x < (WIDE_BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
+__global__ __launch_bounds__(WIDE_BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L, unsigned int *drawCounters /* 2 * RAY_SHARDS lines, zeroed */) {
+    __shared__ unsigned long long wcnt[WIDE_BLOCK / 64][WW_COUNT];
+    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * WIDE_BLOCK + threadIdx.x) >> 6;
+    if (threadIdx.x < (WIDE_BLOCK / 64) * WW_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
     WideStackT<WIDE_BLOCK> stk; setupWide<WIDE_BLOCK>(S, S.wideNodeCache, g_smem, P.spill + (size_t) (blockIdx.x * WIDE_BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
-    if (drawCounters) {
-        const uint32_t nBlk = P.capacity / BLOCK, nChunk = (P.capacity + 63u) / 64u;
-        ShadowSourceDyn ss{ P, L, { drawCounters, blockIdx.x % RAY_SHARDS, 0u, (nBlk + RAY_SHARDS - 1) / RAY_SHARDS, nBlk }, 0u, 0u, 0u };
-        TraceSourceDyn ts{ P, { drawCounters + RAY_SHARDS * RAY_SHARD_STRIDE, blockIdx.x % RAY_SHARDS, 0u, (nChunk + RAY_SHARDS - 1) / RAY_SHARDS, nChunk }, 0u, 0u };
-        ss.start(); ts.start();
-        persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
-    } else {
-        ShadowSource ss{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
-        ss.skipEmpty();
-        TraceSource ts{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
-        persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
-    }
+    const uint32_t nBlk = P.capacity / BLOCK, nChunk = (P.capacity + 63u) / 64u, nWavesGrid = gridDim.x * (WIDE_BLOCK / 64);
+    ShadowSourceDyn ss{ P, L, {}, 0u, 0u, 0u };
+    TraceSourceDyn ts{ P, {}, 0u, 0u };
+    ss.q.init(drawCounters, blockIdx.x % RAY_SHARDS, nBlk, waveId, nWavesGrid);
+    ts.q.init(drawCounters + RAY_SHARDS * RAY_SHARD_STRIDE, blockIdx.x % RAY_SHARDS, nChunk, waveId, nWavesGrid);
+    ss.start(); ts.start();
+    persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
     if (__lane_id() == 0) {
-        const int rows[WC_COUNT] = { ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
+        const unsigned long long v[6] = { wcnt[wave][WW_RAYS], wcnt[wave][WW_STEPS] & 0xFFFFFFFFull, wcnt[wave][WW_STEPS] >> 32,
+                                          wcnt[wave][WW_SH_RAYS], wcnt[wave][WW_SH_STEPS] & 0xFFFFFFFFull, wcnt[wave][WW_SH_STEPS] >> 32 };
+        const int rows[6] = { ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
 #pragma unroll
-        for (int i = 0; i < WC_COUNT; ++i) {
-            const uint32_t v = wcnt[wave][i];
-            if (v) P.stat[(size_t) rows[i] * P.nWaves + waveId] += v;
-        }
+        for (int i = 0; i < 6; ++i)
+            if (v[i]) P.stat[(size_t) rows[i] * P.nWaves + waveId] += v[i];
     }
 }
 

@@ -413,6 +413,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     buildBVH(d.positions, d.indices, d.n_triangles, sc->bvh);
     if (3 * sc->bvh.maxDepth + 2 > STACK_DEPTH + SPILL_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
     if (sc->bvh.tris.size() / 12 >= (1u << 28)) throw std::runtime_error("too many triangle records for the leaf reference encoding");
+    if (d.n_triangles > HIT_PRIM_MASK) throw std::runtime_error("too many triangles for the hit record (30-bit primitive index)");
 
     /* upload */
     HIP_TRY(hipSetDevice(sd.device));
@@ -473,6 +474,24 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         r[4] = make_float4(b.x, b.y, b.z, 0.0f);
         r[5] = make_float4(c.x, c.y, c.z, 0.0f);
     }
+    /* shade class of every triangle in the spare word of its Wald record(s): 0 diffuse, 1 rough conductor, 2 dielectric -- the heavier
+       of the two sides of a two-sided surface; k_rays_w passes it on in the hit record and k_shade deals its lanes by it (k_pool.h) */
+    {
+        auto classOf = [&](uint32_t leaf) { const int t = mats[leaf].type; return t == PHIP_BSDF_ROUGHCONDUCTOR ? 1u : (t == PHIP_BSDF_DIELECTRIC ? 2u : 0u); };
+        std::vector<uint8_t> cls(d.n_triangles);
+        for (uint32_t i = 0; i < d.n_triangles; ++i) {
+            const DevMaterial &m = mats[shapes[triShape[i]].material];
+            const bool twosided = m.type == PHIP_BSDF_TWOSIDED;
+            const uint32_t a = classOf(twosided ? m.nested0 : shapes[triShape[i]].material), b = classOf(twosided ? m.nested1 : shapes[triShape[i]].material);
+            cls[i] = (uint8_t) ((a == 1u || b == 1u) ? 1u : std::max(a, b));
+        }
+        for (std::vector<float> *recs : { &sc->bvh.tris, &sc->bvh.wtris })
+            for (size_t r = 0; r + 12 <= recs->size(); r += 12) {
+                uint32_t prim; memcpy(&prim, &(*recs)[r + 10], 4);
+                const uint32_t c = prim < d.n_triangles ? cls[prim] : 0u;
+                memcpy(&(*recs)[r + 11], &c, 4);
+            }
+    }
     if (ts.empty()) sd.triShade.alloc(TRISHADE_FLOAT4S_UV); else sd.triShade.upload(ts.data(), ts.size());
     if (texTexels.empty()) sd.texTexels.alloc(1); else sd.texTexels.upload(texTexels.data(), texTexels.size());
     if (texDesc.empty()) sd.texDesc.alloc(1); else sd.texDesc.upload(texDesc.data(), texDesc.size());
@@ -483,7 +502,13 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (sc->wide) {
         /* big scenes: the compressed wide tree and the records in ITS leaf order; the BVH4 stays on the host */
         sd.nodes.alloc(8);
-        sd.wnodes.upload((const uint4 *) sc->bvh.wnodes.data(), sc->bvh.wnodes.size() / 4);
+        if (WIDE_NODE_STRIDE == 5) sd.wnodes.upload((const uint4 *) sc->bvh.wnodes.data(), sc->bvh.wnodes.size() / 4);
+        else {                                               /* one node per WIDE_NODE_STRIDE * 16 bytes (a 128-byte line) */
+            const size_t n = sc->bvh.wnodes.size() / 20;
+            std::vector<uint4> padded(n * WIDE_NODE_STRIDE, make_uint4(0, 0, 0, 0));
+            for (size_t i = 0; i < n; ++i) memcpy(&padded[i * WIDE_NODE_STRIDE], &sc->bvh.wnodes[i * 20], 80);
+            sd.wnodes.upload(padded.data(), padded.size());
+        }
         sd.tris.upload((const float4 *) sc->bvh.wtris.data(), sc->bvh.wtris.size() / 4);
     } else {
         if (sc->bvh.nodes.empty()) sd.nodes.alloc(8);
@@ -640,6 +665,11 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (const char *e = getenv("PHIP_NODE_CACHE")) D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, (uint32_t) atoi(e));
     if (D.nodeCache == 0) D.triCache = 0;
     D.wnodes = sd.wnodes.p; D.wideNodeCache = 0;
+    D.preclip = sc->wide ? 1u : 0u;                          /* k_rays_w traverses rays the shading kernels have clipped (k_clip.h) */
+    /* the lane deal of k_shade pays where the expensive model is rare: rough conductors (microfacet sampling: atrium, 8 % of the vertices,
+       k_shade -7 %); on a diffuse + dielectric mix the extra round trip costs more than the cheap Fresnel branch (glass room: +8 %) */
+    D.shadeSort = (sc->wide && (sc->materialMask & MM_ROUGH)) ? 1u : 0u;
+    if (const char *e = getenv("PHIP_SHADE_SORT")) D.shadeSort = D.shadeSort && atoi(e) != 0;       /* experiment hook */
     if (sc->wide) {
         D.nodeCache = 0; D.triCache = 0;
         D.wideNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, WIDE_NODE_CACHE_MAX);
@@ -886,7 +916,12 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     if (!fused) {
         /* pool size: large enough that per-launch fixed costs vanish, small enough that the tail (slots
            running dry at the end of a pass) stays a small fraction of the pass (measured: 4M / 8M slots) */
-        const unsigned long long poolCap = idsFirstPass >= (256ull << 20) ? (1ull << 23) : (1ull << 22);
+        /* (round 3) Every launch of the persistent ray kernel ends with a drain in which each wave waits for its longest ray while the
+           work queue is empty: ~0.15 ms per launch on the 250 k-triangle scenes, 14 % of a launch over 4 M slots, 7 % over 8 M.  A bigger
+           pool means fewer, longer launches: atrium 1920x1080x64 spp 427 / 454 / 470 / 470 Msamples/s with 4 / 8 / 16 / 32 M slots, the
+           glass room at 512 spp 480 / 496 / 505 with 8 / 16 / 32 M -- so the pool grows with the job (about 0.14 KB of HBM per slot). */
+        const unsigned long long poolCap = idsFirstPass >= (512ull << 20) ? (1ull << 25) : idsFirstPass >= (64ull << 20) ? (1ull << 24)
+                                         : idsFirstPass >= (16ull << 20) ? (1ull << 23) : (1ull << 22);
         capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
         capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
         if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
@@ -895,7 +930,12 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         if (sd.rayO.n < capacity) {
             sd.rayO.alloc(capacity); sd.rayD.alloc(capacity); sd.hit.alloc(capacity); sd.thr.alloc(capacity);
             sd.mis.alloc(capacity); sd.info.alloc(capacity); sd.state.alloc(capacity); sd.shadow.alloc(3 * (size_t) capacity);
-            sd.shadowCount.alloc(nBlocks); sd.blockDead.alloc(nBlocks); sd.blockShard.alloc(nBlocks); sd.spill.alloc(laneCap * SPILL_DEPTH);
+            sd.shadowCount.alloc(nBlocks); sd.blockDead.alloc(nBlocks); sd.blockShard.alloc(nBlocks);
+        }
+        {   /* traversal-stack overflow: SPILL_DEPTH words per LANE of a ray kernel -- the wide tree is only walked by persistent grids
+               (at most 8 resident blocks of 256 per CU), the BVH4 also by one-lane-per-slot launches */
+            const size_t spillLanes = sc->wide ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : laneCap;
+            if (sd.spill.n < spillLanes * SPILL_DEPTH) sd.spill.alloc(spillLanes * SPILL_DEPTH);
         }
         if (sd.stat.n < (size_t) ST_COUNT * nWaves) sd.stat.alloc((size_t) ST_COUNT * nWaves);
         if (direct && sd.camHit.n < capacity) sd.camHit.alloc(capacity);
@@ -939,8 +979,6 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         pgridRays = dim3((unsigned) std::max(1, std::min<int>(nCU * n, (int) ((capacity + WIDE_BLOCK - 1) / WIDE_BLOCK))));
     }
     const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
-    bool dynamicDeal = true;                                             /* k_rays_w draws its chunks from sharded counters */
-    if (const char *e = getenv("PHIP_RAYS_STATIC")) dynamicDeal = atoi(e) == 0;
 
     /* fused path: resident grid and per-wave statistics rows */
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
@@ -1028,13 +1066,10 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                 if (merged) {
                     if (timing) evTrace.record(stream);
                     if (sc->wide) {
-                        unsigned int *dc = nullptr;
-                        if (dynamicDeal) {
-                            if (sd.drawCounters.n < 2 * RAY_SHARDS * RAY_SHARD_STRIDE) sd.drawCounters.alloc(2 * RAY_SHARDS * RAY_SHARD_STRIDE);
-                            HIP_TRY(hipMemsetAsync(sd.drawCounters.p, 0, 2 * RAY_SHARDS * RAY_SHARD_STRIDE * sizeof(unsigned int), stream));
-                            dc = sd.drawCounters.p;
-                        }
-                        hipLaunchKernelGGL(k_rays_w, pgridRays, dim3(WIDE_BLOCK), wideLds, stream, D, P, sd.L.p, dc);
+                        /* k_rays_w draws its chunks from sharded counters */
+                        if (sd.drawCounters.n < 2 * RAY_SHARDS * RAY_SHARD_STRIDE) sd.drawCounters.alloc(2 * RAY_SHARDS * RAY_SHARD_STRIDE);
+                        HIP_TRY(hipMemsetAsync(sd.drawCounters.p, 0, 2 * RAY_SHARDS * RAY_SHARD_STRIDE * sizeof(unsigned int), stream));
+                        hipLaunchKernelGGL(k_rays_w, pgridRays, dim3(WIDE_BLOCK), wideLds, stream, D, P, sd.L.p, sd.drawCounters.p);
                     }
                     else hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
                     if (timing) evTrace.record(stream);

@@ -37,6 +37,7 @@ using namespace pt;
     } while (0)
 
 #include "k_pool.h"
+#include "k_clip.h"
 
 /* ---- launchers defined in the other translation units ---- */
 /* k_shade<materials, strictNormals, FEAT> / k_shade_direct<materials, FEAT> over the pool: phip_shade.hip compiled with -DSHADE_FEAT=n */

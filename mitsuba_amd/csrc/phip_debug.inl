@@ -310,3 +310,80 @@ extern "C" int phip_debug_pmc_calibration(size_t src_bytes, size_t n) {
         return PHIP_OK;
     } catch (const std::exception &e) { return setErr(PHIP_ERR_DEVICE, e.what()); }
 }
+
+/* ---- the vector-memory roof of a CU under divergence (round 3) ----
+ * The ray kernels of the big scenes are bound neither by HBM (7-10 % of the peak) nor by the ALUs (VALU issue 40 %): every lane
+ * fetches its own node, so what they load the chip with is LANE-LEVEL 16-byte requests to the CU's texture addresser / L1
+ * (TA / TCP).  This micro-benchmark measures what that path sustains, as the ray kernels use it: every lane of a resident grid
+ * issues `iters` x 4 independent loads of 16 bytes from pseudo-random places of a buffer that lives in L1 / L2 / Infinity Cache.
+ *   mode 0  one random 16-byte element per lane                        (a node / record fetch of k_rays_w)
+ *   mode 1  the 4 lanes of a quad read the 4 pieces of one random 64-byte block  (what a transposed, quad-cooperative node fetch would issue)
+ *   mode 2  8 lanes share a random 128-byte line        mode 3  16 lanes share 256 bytes
+ *   mode 4  as 0 with every second lane switched off    mode 5  as 0 with 16 of the 64 lanes active   (is the cost per instruction or per lane?)
+ *   mode 6  five consecutive 16-byte pieces of one random 80-byte record per lane, as five instructions (an 80-byte wide node)
+ *   mode 7  one random dword per lane                   mode 8  one random 8 bytes per lane
+ *   mode 9  fully coalesced: lane i reads element base + i of a random 1-KB block
+ *   mode 10 / 11  as 0 with 8 / 4 of the 64 lanes active
+ * Returns the time of the launch; lane_loads = active lanes x loads.  Blocks per CU are pinned with dynamic LDS. */
+template <int MODE> __global__ __launch_bounds__(256) void k_debug_vmem(const uint4 *src, uint32_t mask /* elements - 1 */, int iters, uint4 *out) {
+    extern __shared__ unsigned char dummy[];
+    const uint32_t lane = __lane_id(), gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t grp = MODE == 1 ? 4u : (MODE == 2 ? 8u : (MODE == 3 ? 16u : (MODE == 9 ? 64u : 1u)));
+    uint32_t x = (gid / grp) * 2654435761u + 12345u;            /* the lanes of a group draw the same numbers */
+    const bool on = MODE == 4 ? (lane & 1u) == 0u : (MODE == 5 ? (lane & 3u) == 0u : (MODE == 10 ? (lane & 7u) == 0u : (MODE == 11 ? (lane & 15u) == 0u : true)));
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    if (on) {
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x = x * 1664525u + 1013904223u;
+                const uint32_t r = x >> 4;
+                if (MODE == 6) {
+                    const uint32_t e = (r % ((mask + 1u) / 5u)) * 5u;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { const uint4 v = src[e + k]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+                } else if (MODE == 7) {
+                    acc.x ^= ((const uint32_t *) src)[r & (4u * mask + 3u)];
+                } else if (MODE == 8) {
+                    const uint2 v = ((const uint2 *) src)[r & (2u * mask + 1u)]; acc.x ^= v.x; acc.y ^= v.y;
+                } else {
+                    const uint32_t e = grp == 1u ? (r & mask) : (((r * grp) & mask) + (lane & (grp - 1u)));
+                    const uint4 v = src[e]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+                }
+            }
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[gid] = acc;       /* (practically never: keeps the loads alive) */
+    if (dummy[0] == 77 && acc.z == 1u) out[0] = acc;
+}
+
+extern "C" int phip_debug_vmem_roof(int mode, size_t bytes, int blocks_per_cu, int iters, double *out_ms, double *out_lane_loads) {
+    try {
+        size_t n = 1; while (n * 2 * 16 <= bytes) n *= 2;       /* 16-byte elements, a power of two */
+        DevBuf<uint4> src, out;
+        src.alloc(n);
+        HIP_TRY(hipMemset(src.p, 0x5a, n * 16));
+        int dev = 0, nCU = 256; HIP_TRY(hipGetDevice(&dev));
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess) nCU = prop.multiProcessorCount; }
+        const int grid = nCU * blocks_per_cu;
+        out.alloc((size_t) grid * 256);
+        const size_t lds = (size_t) (160 * 1024 / blocks_per_cu) / 1024 * 1024 - 1024;     /* exactly blocks_per_cu blocks fit a CU */
+        typedef void (*K)(const uint4 *, uint32_t, int, uint4 *);
+        static const K table[12] = { k_debug_vmem<0>, k_debug_vmem<1>, k_debug_vmem<2>, k_debug_vmem<3>, k_debug_vmem<4>, k_debug_vmem<5>, k_debug_vmem<6>, k_debug_vmem<7>, k_debug_vmem<8>, k_debug_vmem<9>, k_debug_vmem<10>, k_debug_vmem<11> };
+        if (mode < 0 || mode > 11) return setErr(PHIP_ERR_INVALID, "mode");
+        const K k = table[mode];
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, (const uint4 *) src.p, (uint32_t) (n - 1), std::max(1, iters / 8), out.p);     /* warm-up: caches, clocks */
+        HIP_TRY(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, (const uint4 *) src.p, (uint32_t) (n - 1), iters, out.p);
+        HIP_TRY(hipEventRecord(e1, 0));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        const double lanesOn = mode == 4 ? 0.5 : (mode == 5 ? 0.25 : (mode == 10 ? 0.125 : (mode == 11 ? 0.0625 : 1.0)));
+        if (out_ms) *out_ms = ms;
+        if (out_lane_loads) *out_lane_loads = (double) grid * 256.0 * lanesOn * (double) iters * 4.0 * (mode == 6 ? 5.0 : 1.0);
+        return PHIP_OK;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_DEVICE, e.what()); }
+}
