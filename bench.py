@@ -53,6 +53,9 @@ WORKLOADS = {
 HEADLINE = "cornell_1024x1024_256spp"
 EXTRA_SINGLE_GPU = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8"]
 MULTI_GPU_JOB = "atrium_3840x2160_1024spp_md8"
+MULTI_GPU_SLICE = "atrium_3840x2160_64spp_md8"        # the same job at 1/16 of the samples per pixel: its single-GPU rate
+MULTI_GPU_MAX_STEPS = 3
+CPU_BASELINE_EXTRA = "atrium_1920x1080_64spp_md8"      # the second scene of the metric gets a CPU figure of its own
 
 
 def make_integrator(md):
@@ -137,7 +140,9 @@ def time_workload(workload, steps, warmup, rank, world, local, devices, D, torch
     from mitsuba_amd import _abi as A
     from mitsuba_amd.integrator import Scene
     desc, W, H, spp, md, ntris = build_desc(workload)
+    t_create = time.perf_counter()
     scene = Scene(desc, device=local)
+    t_create = time.perf_counter() - t_create
     if devices:
         scene.replicate(devices)
     accel = scene.accel_info().as_dict()
@@ -166,10 +171,13 @@ def time_workload(workload, steps, warmup, rank, world, local, devices, D, torch
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     total_samples = D.sum_over_ranks(agg["samples"], dev)
     total_rays = D.sum_over_ranks(agg["closest_rays"] + agg["shadow_rays"], dev)
+    # `value` is measured with the film resident in HBM (phip_render_device); what phip_render adds is this copy of the (H, W, 5) film
+    torch.cuda.synchronize(); t_d2h = time.perf_counter(); film.cpu(); t_d2h = time.perf_counter() - t_d2h
     scene.close()
     del film
     return {"workload": workload, "scene": WORKLOADS[workload][0], "triangles": ntris, "W": W, "H": H, "spp": spp, "integrator": integ_name,
-            "accel": accel, "agg": agg, "dt": dt, "steps": steps, "warmup": warmup, "samples": total_samples, "rays": total_rays}
+            "accel": accel, "agg": agg, "dt": dt, "steps": steps, "warmup": warmup, "samples": total_samples, "rays": total_rays,
+            "scene_create_ms": t_create * 1e3, "d2h_ms": t_d2h * 1e3}
 
 
 def dominant_kernel(r):
@@ -194,16 +202,27 @@ def dominant_kernel(r):
     return name, desc, cands[name], max(int(a["iterations"]), 1)
 
 
+VMEM_LOADS_PER_NODE = {80: 5, 128: 7}     # 16-byte lane loads per node step: 80-byte wide node / 128-byte BVH4 node
+VMEM_LOADS_PER_TRI = 3                      # ... per Wald record
+VMEM_LOADS_PER_RAY = 2                      # ... per ray fetched (o | d)
+
+
 def roofline(r):
-    """Two measured fractions for the dominant kernel -- neither can exceed 1:
+    """Three measured fractions for the dominant kernel -- none can exceed 1 -- and `bound` = the largest:
        hbm:  HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE + WRITE_SIZE, calibrated as the MI355X
              guide prescribes) / this run's average launch duration (HIP events on the library's stream) / 8 TB/s
-       valu: active lane-operations / available lane-slots from the SQ counters committed under profiles/ (tools/pmc_valu.py)"""
+       valu: active lane-operations / available lane-slots from the SQ counters committed under profiles/ (tools/pmc_valu.py)
+       vmem: lane-level 16-byte load requests per second (counted by the kernel itself: node steps, triangle tests, rays fetched)
+             / what the chip sustains when every lane gathers 16 bytes from an L1-resident set (tools/vmem_roof.py ->
+             profiles/r03_vmem_roof.json); beside it the texture-data unit's busy share and the L1 / L2 hit rates of the kernel's
+             own TA / TCP / TCC counters (tools/pmc_tcp.py -> profiles/r03_tcp_*.json)"""
     name, desc, kms, launches = dominant_kernel(r)
     a = r["agg"]
     avg_ms = kms / launches if launches else 0.0
     traffic, tsrc = profile_json("traffic", r["workload"])
     valu, vsrc = profile_json("valu", r["workload"])
+    tcp, csrc = profile_json("tcp", r["workload"])
+    vroof, rsrc = profile_json("vmem_roof", "")
     def by_kernel(table):        # profile keys carry template arguments ("k_mega<0, false>"): match the kernel's base name
         for k, v in (table or {}).items():
             if k.split("<")[0] == name:
@@ -213,21 +232,46 @@ def roofline(r):
     hbm_bytes = tk["hbm_bytes_per_launch"] if tk else None
     hbm_gbs = (hbm_bytes / 1e9) / (avg_ms / 1e3) if (hbm_bytes and avg_ms > 0) else None
     alg_per_launch = a["trace_kernel_bytes"] / launches if name in ("k_rays_w", "k_rays_p", "k_trace_p", "k_trace") else a["algorithmic_bytes"] / launches
-    out = {"bound": "hbm", "kernel": name + " (" + desc + ")",
+    out = {"bound": None, "kernel": name + " (" + desc + ")",
            "achieved": round(hbm_gbs, 2) if hbm_gbs is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(min(hbm_gbs / HBM_PEAK_GBS, 1.0), 5) if hbm_gbs is not None else None,
            "traffic": round(hbm_bytes, 1) if hbm_bytes else None, "traffic_source": tsrc,
            "avg_launch_ms": round(avg_ms, 5), "launches": launches,
            "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
-           "note": "achieved = MEASURED HBM bytes per launch (PMC) / live launch time; the SURVEY 8(d) algorithmic bytes (node + record "
-                   "fetches, ray/hit state) are listed beside it but are served by LDS / L2 / Infinity Cache, not by the HBM pins: "
-                   "this path is bounded by VALU issue under divergence, see `valu`",
+           "note": "achieved / frac = MEASURED HBM bytes per launch (PMC) / live launch time (/ 8 TB/s); the SURVEY 8(d) algorithmic bytes "
+                   "(node + record fetches, ray / hit state) are listed beside it but are served by LDS / L1 / L2 / Infinity Cache, not by "
+                   "the HBM pins.  `bound` names the largest of the three measured fractions hbm / valu / vmem",
            "kernel_ms_per_step": {k: round(a[k + "_kernel_ms"] / r["steps"], 3) for k in ("fused", "trace", "shadow", "shade", "film")}}
     vk = by_kernel(valu)
     if vk:
         out["valu"] = {"frac": vk.get("valu_frac"), "issue_frac": vk.get("valu_issue_frac"), "lane_util": vk.get("lane_util"),
                        "wave_cycles_waiting": vk.get("wave_cycles_wait_frac"), "source": vsrc,
                        "definition": "frac = SQ_THREAD_CYCLES_VALU / (256 CU x 4 SIMD x 32 lanes x cycles); issue_frac = SQ_INSTS_VALU x 2 / (1024 x cycles)"}
+    # vector-memory path: lane-level load requests against the measured roof
+    peak = ((vroof or {}).get("peak_lane_random_16B") or {}).get("16KB_L1")
+    if name in ("k_rays_w", "k_rays_p", "k_trace_p", "k_trace") and kms > 0:
+        per_node = VMEM_LOADS_PER_NODE.get(r["accel"]["node_bytes"], 7)
+        loads = per_node * (a["closest_node_visits"] + a["shadow_node_visits"]) + VMEM_LOADS_PER_TRI * (a["closest_triangle_tests"] + a["shadow_triangle_tests"]) \
+            + VMEM_LOADS_PER_RAY * (a["closest_rays"] + a["shadow_rays"])
+    elif name == "k_mega":
+        loads = 0.0                  # nodes, records, tables and stack live in LDS; one 16-byte store per sample
+    else:
+        loads = None
+    if loads is not None and peak and kms > 0:
+        rate = loads / (kms / 1e3)
+        ck = by_kernel((tcp or {}).get("kernels"))
+        out["vmem"] = {"achieved": round(rate / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G lane-loads/s", "frac": round(min(rate / peak, 1.0), 4),
+                       "lane_loads_per_ray": round(loads / max(a["closest_rays"] + a["shadow_rays"], 1), 2),
+                       "peak_source": rsrc, "peak_definition": "every lane of the chip gathering 16 B from an L1-resident set, 8 waves per SIMD (L2-resident set: %.0f, Infinity-Cache-resident: %.0f G lane-loads/s)"
+                       % (((vroof or {}).get("peak_lane_random_16B") or {}).get("2MB_L2", 0) / 1e9, ((vroof or {}).get("peak_lane_random_16B") or {}).get("16MB_MALL", 0) / 1e9)}
+        if ck:
+            out["vmem"].update({"td_busy_frac": ck.get("td_busy_frac"), "l1_hit_rate": ck.get("l1_hit_rate"), "l2_hit_rate": ck.get("l2_hit_rate"),
+                                "lines_per_wave_instruction": ck.get("lines_per_instruction"), "clk_per_wave_instruction_per_cu": ck.get("clk_per_wave_instruction_per_cu"),
+                                "counters_source": csrc})
+    fr = {"hbm": out["frac"], "valu": (out.get("valu") or {}).get("frac"), "vmem": (out.get("vmem") or {}).get("frac")}
+    fr = {k: v for k, v in fr.items() if v is not None}
+    out["bound"] = max(fr, key=fr.get) if fr else "hbm"
+    out["fractions"] = fr
     return out
 
 
@@ -237,7 +281,8 @@ def summary(r, world):
     return {"value": round(msps, 3), "unit": "Msamples/s", "ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "steps": r["steps"], "warmup": r["warmup"],
             "mrays_per_s": round(r["rays"] / 1e6 / r["dt"], 1), "mean_path_length": round(a["path_vertices"] / max(a["samples"], 1), 3),
             "scene": r["scene"], "triangles": r["triangles"], "width": r["W"], "height": r["H"], "spp": r["spp"], "integrator": r["integrator"],
-            "fused_kernel": bool(a["fused"]), "roofline": roofline(r)}
+            "fused_kernel": bool(a["fused"]), "bvh_build_ms": round(r["accel"].get("build_ms", 0.0), 1), "scene_create_ms": round(r.get("scene_create_ms", 0.0), 1),
+            "film_d2h_ms_not_in_value": round(r.get("d2h_ms", 0.0), 3), "roofline": roofline(r)}
 
 
 def main():
@@ -267,11 +312,28 @@ def main():
     devices = list(range(args.gpus)) if in_library else None
 
     headline = args.workload or (HEADLINE if n_gpus == 1 else MULTI_GPU_JOB)
-    cpu = None
+    cpu, cpu_extra = None, {}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(headline)                   # before the GPU phase: the GPU is busy for the rest of the run
+        if not args.workload and not args.no_extra:
+            cpu_extra[CPU_BASELINE_EXTRA] = cpu_baseline(CPU_BASELINE_EXTRA, seconds_target=8.0)
 
-    main_r = time_workload(headline, args.steps, args.warmup, rank, world, local, devices, D, torch)
+    steps, warmup = args.steps, args.warmup
+    single = None
+    if n_gpus > 1:
+        # the multi-GPU job is 8.5 G samples per step (about 17 s on one GPU): a bounded number of steps keeps every N inside the
+        # driver's time limit; the line reports the steps that were timed
+        steps, warmup = min(steps, MULTI_GPU_MAX_STEPS), min(warmup, 1)
+        if not args.workload:
+            # the SAME job on ONE GPU, unsharded, at 1/16 of the samples per pixel (the rate does not depend on the sample count at
+            # this size): the denominator of the scaling efficiency, measured in this very run by rank 0 alone
+            if rank == 0:
+                one = time_workload(MULTI_GPU_SLICE, 1, 1, 0, 1, local, None, D.Solo, torch)
+                single = {"workload": MULTI_GPU_SLICE, "value": round(one["samples"] / 1e6 / one["dt"], 3), "unit": "Msamples/s", "ms_per_step": round(one["dt"] * 1e3, 3),
+                          "note": "rank 0 alone, all blocks, before the timed region; same scene / film / integrator as the job, 64 of its 1024 samples per pixel"}
+            D.barrier()
+
+    main_r = time_workload(headline, steps, warmup, rank, world, local, devices, D, torch)
     extras = {}
     if n_gpus == 1 and not args.workload and not args.no_extra:
         for w in EXTRA_SINGLE_GPU:
@@ -281,8 +343,9 @@ def main():
         s = summary(main_r, world)
         out = {
             "metric": "Msamples/s", "value": s["value"], "unit": "Msamples/s", "n_gpus": n_gpus,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": s["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong" if n_gpus > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "steps": steps, "warmup": warmup, "ms_per_step": s["ms_per_step"],
+            # every job of this bench is a FIXED frame: more GPUs split the same blocks (strong scaling), also at N = 1
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": headline, "scene": s["scene"], "triangles": s["triangles"], "width": s["width"], "height": s["height"],
                        "spp": s["spp"], "integrator": s["integrator"], "rfilter": "gaussian stddev 0.5", "sampler": "ctr seed 0", "block_size": 32,
                        "parallelism": ("one fixed job: 32x32 blocks dealt round-robin in spiral order over %d GPU(s), " % n_gpus) +
@@ -293,11 +356,20 @@ def main():
             "build": {"library": _ffi.lib().phip_version().decode(), "id": _ffi.lib().phip_build_id().decode(),
                       "note": "id = hash of mitsuba_amd/csrc + include + compile flags, compiled into libphip.so and checked against the sources when it is loaded"},
         }
+        if n_gpus > 1:
+            out["requested"] = {"steps": args.steps, "warmup": args.warmup}
+            if single:
+                out["single_gpu_same_job"] = single
+                out["scaling_efficiency"] = round(s["value"] / (n_gpus * single["value"]), 4)
+                out["scaling_note"] = ("the N = 1 line of this bench times ANOTHER job (%s, the config the metric is quoted on); the efficiency of this "
+                                       "N-GPU job is value / (N x single_gpu_same_job.value), both measured in this run" % HEADLINE)
         if extras:
             out["workloads"] = {headline: {k: v for k, v in s.items() if k != "roofline"}}
             out["workloads"][headline]["roofline_frac_hbm"] = (s["roofline"] or {}).get("frac")
             for w, r in extras.items():
                 out["workloads"][w] = summary(r, world)
+                if w in cpu_extra:
+                    out["workloads"][w]["cpu_baseline"] = cpu_extra[w]
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
 

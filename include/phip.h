@@ -229,7 +229,7 @@ typedef struct phip_render_params {
     int32_t  shard_count;
     int32_t  device;             /* HIP device ordinal                                    */
     int32_t  flags;              /* PHIP_FLAG_*                                           */
-    void    *stream;             /* hipStream_t to launch on, NULL = library-owned stream */
+    void    *stream;             /* hipStream_t to launch on, NULL = library-owned stream; must be NULL when n_devices > 1 (PHIP_ERR_INVALID otherwise) */
     uint32_t integrator;         /* phip_integrator_kind                                  */
     int32_t  emitter_samples;    /* `direct`: emitterSamples (direct.cpp:98-99), default 1 */
     int32_t  bsdf_samples;       /* `direct`: bsdfSamples (direct.cpp:100-101), default 1  */
@@ -247,8 +247,9 @@ typedef struct phip_render_params {
        previous call (phip_render: the library-owned film; phip_render_device: the caller's buffer). */
     int32_t  sample_offset;
     int32_t  sample_total;
-    /* Progress (ABI 4): called from the rendering host thread(s) whenever the job's live-path count is polled
-       (about every 8 wavefront iterations) and at the end, with the camera samples finished so far by that device.
+    /* Progress (ABI 4): called whenever the job's live-path count is polled (about every 8 wavefront iterations) and at the
+       end, with the camera samples finished so far by that device.  With n_devices > 1 the calls come from the library's
+       per-device host threads -- never two at a time (they are serialised), but not on the caller's thread.
        May be NULL.  The callback may call phip_cancel. */
     void   (*progress)(void *user, int32_t device, uint64_t samples_done, uint64_t samples_total);
     void    *progress_user;

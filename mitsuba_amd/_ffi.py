@@ -24,9 +24,11 @@ _lib = None
 
 
 def _sources():
-    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    """the files a build depends on: *.hip / *.h / *.inl of csrc/ and include/ (an editor backup must not mark the library stale)"""
+    keep = (".hip", ".h", ".inl")
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(keep)]
     inc = os.path.join(os.path.dirname(HERE), "include")
-    out += [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
+    out += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(keep)]
     return out
 
 
@@ -62,15 +64,27 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 (cross-compiles without a GPU): the objects in parallel, then one link."""
     os.makedirs(BUILD, exist_ok=True)
     sid = source_id()
-    if not force and built_id() == sid:
-        return LIB
+    out_lib = os.environ.get("PHIP_BUILD_OUTPUT", LIB)      # experiment hook: alternative builds next to the product (load with PHIP_LIB)
+    if not force and built_id(out_lib) == sid:
+        return out_lib
+    # several processes may find the library stale at once (ranks of a torchrun job, pytest-xdist workers): one builds, the others
+    # wait for the lock and find the fresh file; objects and library are written under temporary names and renamed into place
+    import fcntl
+    with open(os.path.join(BUILD, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and built_id(out_lib) == sid:
+            return out_lib
+        return _build_locked(sid, out_lib, verbose)
+
+
+def _build_locked(sid, out_lib, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", "").split()
     procs = []
     for src, extra, obj in UNITS:
         if src == "phip.hip":
             extra = extra + ['-DPHIP_BUILD_ID="%s"' % sid]
-        cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj)]
+        cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj + ".tmp.o")]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
         out, _ = p.communicate()
@@ -78,11 +92,14 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
         if verbose:
             print(" ".join(cmd)); print(out)
-    out_lib = os.environ.get("PHIP_BUILD_OUTPUT", LIB)      # experiment hook: alternative builds next to the product (load with PHIP_LIB)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + [os.path.join(BUILD, u[2]) for u in UNITS] + ["-ldl"]
+    for _, _, obj in UNITS:
+        os.replace(os.path.join(BUILD, obj + ".tmp.o"), os.path.join(BUILD, obj))
+    tmp = out_lib + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [os.path.join(BUILD, u[2]) for u in UNITS] + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    os.replace(tmp, out_lib)                                # a concurrent loader sees the old library or the new one, never half of one
     return out_lib
 
 

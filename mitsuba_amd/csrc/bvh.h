@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <chrono>
 #include <functional>
+#include <thread>
 
 namespace pt {
 
@@ -113,7 +114,10 @@ struct Builder {
     bool spatial = false;
     float alpha = 1e-5f;               /* a spatial split is only tried when the object split's children overlap by more than alpha * root area */
     double rootArea = 1;
-    size_t refBudget = 0, nRefs = 0;   /* total triangle references (duplicates included) may not exceed refBudget */
+    size_t slack = 0;                  /* references spatial splits may still ADD below this node (the whole tree: at most 0.5 per triangle) */
+    int parallelLevels = 0;            /* buildSpatial: levels of the tree whose two subtrees are built on two threads (round 3: the builder was
+                                          single-threaded and 8 x slower than the plain SAH build on a 250 k-triangle scene) */
+    static constexpr size_t PAR_MIN_REFS = 8192;
 
     Builder(std::vector<BuildTri> &t, HostBVH &o, const float *p, const uint32_t *i) : T(t), out(o), positions(p), indices(i) {
         if (const char *e = getenv("PHIP_BVH_MAXLEAF")) MAX_LEAF = std::min(8, std::max(1, atoi(e)));     /* experiment hooks */
@@ -165,8 +169,10 @@ struct Builder {
        plane x = 0 (round 2: ties on such planes were decided by the traversal order), hence the term in the scene's extent. */
     float extent[3] = { 0, 0, 0 };
     void pad(Box &b) const {
+        /* (the LARGEST extent on every axis: a scene that is flat on one axis -- everything in the plane y = 0 -- must not lose its pad there) */
+        const float maxExtent = std::max(extent[0], std::max(extent[1], extent[2]));
         for (int i = 0; i < 3; ++i) {
-            float e = 1e-5f * std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])) + 1e-7f * (b.mx[i] - b.mn[i]) + 2e-6f * extent[i] + 1e-30f;
+            float e = 1e-5f * std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])) + 1e-7f * (b.mx[i] - b.mn[i]) + 2e-6f * maxExtent + 1e-30f;
             b.mn[i] -= e; b.mx[i] += e;
         }
     }
@@ -295,7 +301,7 @@ struct Builder {
         }
         /* spatial split, when the object split's children overlap enough */
         float sCost = INFINITY; int sAxis = -1; float sPos = 0;
-        bool trySpatial = depth < 48 && nRefs + n / 2 < refBudget;
+        bool trySpatial = depth < 48 && slack > 0;               /* (the budget itself is enforced when a split is accepted) */
         if (trySpatial && bestAxis >= 0) {
             Box ov; for (int a = 0; a < 3; ++a) { ov.mn[a] = std::max(bestL.mn[a], bestR.mn[a]); ov.mx[a] = std::min(bestL.mx[a], bestR.mx[a]); }
             trySpatial = ov.area() / rootArea > alpha;
@@ -367,7 +373,7 @@ struct Builder {
                 else if (cRight < cSplit) { R.push_back(t); rb = rw; --nl; }
                 else { L.push_back(makeRef(pc.l, t.prim)); R.push_back(makeRef(pc.r, t.prim)); }
             }
-            if (!L.empty() && !R.empty() && L.size() < n && R.size() < n) { done = true; nRefs += L.size() + R.size() - n; }
+            if (!L.empty() && !R.empty() && L.size() < n && R.size() < n && L.size() + R.size() - n <= slack) { done = true; slack -= L.size() + R.size() - n; }
             else { L.clear(); R.clear(); }
         }
         if (!done) {
@@ -387,14 +393,52 @@ struct Builder {
             }
         } else if (n <= (size_t) MAX_LEAF) {
             const float splitCost = C_TRAV + C_ISECT * sCost / (parentArea > 0 ? parentArea : 1.0f);
-            if (splitCost >= leafCost) { nRefs -= L.size() + R.size() - n; return makeLeaf(refs.data(), refs.data() + n); }
+            if (splitCost >= leafCost) { slack += L.size() + R.size() - n; return makeLeaf(refs.data(), refs.data() + n); }
         }
         std::vector<BuildTri>().swap(refs);
         const uint32_t idx = out.nNodes2++;
         out.nodes2.resize((size_t) out.nNodes2 * 16);
         Box lbx, rbx;
-        int32_t l = buildSpatial(L, lbx, depth + 1);
-        int32_t r = buildSpatial(R, rbx, depth + 1);
+        int32_t l, r;
+        if (parallelLevels > 0 && L.size() >= PAR_MIN_REFS && R.size() >= PAR_MIN_REFS) {
+            /* the right subtree on another thread, into arrays of its own; spliced in behind the left subtree afterwards (node and
+               record indices shifted), so the layout is the depth-first one of the serial build.  The reference budget is dealt in
+               proportion to the two sides: deterministic, whatever the threads' timing. */
+            HostBVH sub; std::vector<BuildTri> none;
+            Builder SB(none, sub, positions, indices);
+            SB.MAX_LEAF = MAX_LEAF; SB.C_TRAV = C_TRAV; SB.C_ISECT = C_ISECT; SB.spatial = spatial; SB.alpha = alpha; SB.rootArea = rootArea;
+            for (int a = 0; a < 3; ++a) SB.extent[a] = extent[a];
+            SB.parallelLevels = parallelLevels - 1;
+            const size_t total = slack, slackR = (size_t) ((double) total * (double) R.size() / (double) (L.size() + R.size()));
+            SB.slack = slackR; slack = total - slackR;
+            int32_t rr = 0;
+            std::thread worker([&]() { rr = SB.buildSpatial(R, rbx, depth + 1); });
+            const int saved = parallelLevels; parallelLevels = saved - 1;
+            l = buildSpatial(L, lbx, depth + 1);
+            parallelLevels = saved;
+            worker.join();
+            slack += SB.slack;
+            const uint32_t nodeOff = out.nNodes2, recOff = (uint32_t) (out.tris.size() / 12);
+            auto shift = [&](int32_t ref) -> int32_t {
+                if (ref >= 0) return ref + (int32_t) nodeOff;
+                const uint32_t q = ~(uint32_t) ref;
+                return ~(int32_t) ((((q >> 3) + recOff) << 3) | (q & 7u));
+            };
+            for (uint32_t i = 0; i < sub.nNodes2; ++i) {
+                float *nd2 = &sub.nodes2[(size_t) i * 16];
+                uint32_t a, b; memcpy(&a, &nd2[12], 4); memcpy(&b, &nd2[13], 4);
+                a = (uint32_t) shift((int32_t) a); b = (uint32_t) shift((int32_t) b);
+                memcpy(&nd2[12], &a, 4); memcpy(&nd2[13], &b, 4);
+            }
+            out.nodes2.insert(out.nodes2.end(), sub.nodes2.begin(), sub.nodes2.begin() + (size_t) sub.nNodes2 * 16);
+            out.nNodes2 += sub.nNodes2;
+            out.tris.insert(out.tris.end(), sub.tris.begin(), sub.tris.end());
+            out.nLeaves += sub.nLeaves; out.nTriRefs += sub.nTriRefs; out.maxDepth = std::max(out.maxDepth, sub.maxDepth);
+            r = shift(rr);
+        } else {
+            l = buildSpatial(L, lbx, depth + 1);
+            r = buildSpatial(R, rbx, depth + 1);
+        }
         Box lp = lbx, rp = rbx; pad(lp); pad(rp);
         float *nd = &out.nodes2[(size_t) idx * 16];
         nd[0] = lp.mn[0]; nd[1] = lp.mn[1]; nd[2] = lp.mn[2]; nd[3] = lp.mx[0];
@@ -437,14 +481,19 @@ struct Reinserter {
         }
     }
     /* best node to pair subtree X (box bx) with */
+    struct Cand { float induced; int32_t ref; Box box; };
+    mutable std::vector<Cand> heap;            /* (kept between searches: no allocation per insertion) */
+    uint32_t maxPops = 512;                    /* search bound per insertion: with many identical boxes the branch-and-bound prunes nothing and one
+                                                  search visits the whole tree -- O(n^2) per pass (round-2 advice: 1 M coincident triangles took 121 s);
+                                                  the best candidate found within the bound is a valid place all the same */
     int32_t findBest(const Box &bx, Box &bestBox) const {
-        struct Cand { float induced; int32_t ref; Box box; };
         auto cmp = [](const Cand &a, const Cand &b) { return a.induced > b.induced; };
-        std::vector<Cand> heap;
+        heap.clear();
         const float ax = bx.area();
         float best = INFINITY; int32_t bestRef = root; bestBox = boxOf(root);
         heap.push_back({ 0.0f, root, boxOf(root) });
-        while (!heap.empty()) {
+        uint32_t pops = 0;
+        while (!heap.empty() && pops++ < maxPops) {
             std::pop_heap(heap.begin(), heap.end(), cmp);
             const Cand c = heap.back(); heap.pop_back();
             if (c.induced + ax >= best) break;                           /* every remaining candidate is at least this bad */
@@ -712,7 +761,12 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
     int32_t root2;
     if (B.spatial) {
         B.rootArea = tight.area() > 0 ? tight.area() : 1.0;
-        B.nRefs = nTris; B.refBudget = (size_t) nTris + nTris / 2 + 64;      /* at most 1.5 references per triangle */
+        B.slack = (size_t) nTris / 2 + 64;                                   /* at most 1.5 references per triangle */
+        {   /* the top levels' subtrees are built on 2^levels threads (PHIP_BVH_THREADS=1: serial) */
+            unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
+            if (const char *e = getenv("PHIP_BVH_THREADS")) hw = (unsigned) std::max(1, atoi(e));
+            B.parallelLevels = 0; while ((2u << B.parallelLevels) <= hw && B.parallelLevels < 5) ++B.parallelLevels;
+        }
         out.nodes2.reserve((size_t) nTris * 24); out.tris.reserve((size_t) nTris * 18);
         root2 = B.buildSpatial(T, rootBox, 1);
     } else
@@ -736,6 +790,7 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
             for (uint32_t i = 0; i < out.nNodes2; ++i)
                 for (int k = 0; k < 2; ++k) R.setParent(R.n[i].child[k], (int32_t) i);
             R.n[root2].parent = -1;
+            if (const char *pe = getenv("PHIP_BVH_OPT_POPS")) R.maxPops = (uint32_t) std::max(1, atoi(pe));
             const double before = R.sah();
             for (int it = 0; it < passes; ++it) R.pass();
             if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "phip: BVH reinsertion, %d passes: sum of child areas %.6g -> %.6g\n", passes, before, R.sah());

@@ -210,6 +210,7 @@ struct phip_scene {
     std::vector<std::unique_ptr<SceneDev>> devs;
     int *cancelFlag = nullptr;       /* host-pinned (portable, mapped): phip_cancel writes it, host loops and k_mega poll it */
     std::mutex renderLock;
+    std::mutex progressLock;         /* the progress callback is entered by one device thread at a time (renderMultiDevice runs one host thread per GPU) */
     phip_scene() { devs.emplace_back(new SceneDev()); }
     ~phip_scene() { devs.clear(); if (cancelFlag) (void) hipHostFree(cancelFlag); }
 };
@@ -411,7 +412,6 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     /* acceleration structure */
     buildBVH(d.positions, d.indices, d.n_triangles, sc->bvh);
-    if (3 * sc->bvh.maxDepth + 2 > STACK_DEPTH + SPILL_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
     if (sc->bvh.tris.size() / 12 >= (1u << 28)) throw std::runtime_error("too many triangle records for the leaf reference encoding");
     if (d.n_triangles > HIT_PRIM_MASK) throw std::runtime_error("too many triangles for the hit record (30-bit primitive index)");
 
@@ -499,6 +499,8 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = strcmp(e, "lane") == 0 ? 0 : 2;
     sc->wide = sc->traversal == 2 && sc->bvh.nWNodes > 0 && sc->bvh.nNodes >= 64;
     if (const char *e = getenv("PHIP_WIDE")) sc->wide = sc->wide && atoi(e) != 0;
+    /* the stack of the structure that is going to be walked: three pushes per BVH4 level (the wide tree's group stack is checked below) */
+    if (!sc->wide && 3 * sc->bvh.maxDepth + 2 > STACK_DEPTH + SPILL_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
     if (sc->wide) {
         /* big scenes: the compressed wide tree and the records in ITS leaf order; the BVH4 stays on the host */
         sd.nodes.alloc(8);
@@ -830,6 +832,7 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
     const int shardCount = p->shard_count > 0 ? p->shard_count : 1;
     if (p->shard_index < 0 || p->shard_index >= shardCount) throw std::invalid_argument("shard_index out of range");
     if (p->n_devices < 0 || p->n_devices > PHIP_MAX_DEVICES) throw std::invalid_argument("n_devices out of range");
+    if (p->n_devices > 1 && p->stream) throw std::invalid_argument("a caller's stream belongs to one device: leave `stream` NULL when n_devices > 1 (every device renders on a stream of the library)");
 }
 
 /* One device's share of a render call: the blocks whose index in the reference's spiral order is congruent to shardIndex
@@ -1097,7 +1100,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                     }
                     HIP_TRY(hipStreamSynchronize(stream));
                     if (hc.total[ST_ALIVE] == 0) done = true;
-                    if (p->progress) p->progress(p->progress_user, sd.device, samplesDone + hc.total[ST_SAMPLES], samplesTotal * (unsigned long long) p->spp);
+                    if (p->progress) { std::lock_guard<std::mutex> g(sc->progressLock); p->progress(p->progress_user, sd.device, samplesDone + hc.total[ST_SAMPLES], samplesTotal * (unsigned long long) p->spp); }
                     if (cancelRequested(sc)) { cancelled = true; done = true; }
                 }
             }
@@ -1140,7 +1143,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         st.path_vertices += hc.total[ST_VERTICES]; st.closest_node_visits += hc.total[ST_NODE]; st.closest_triangle_tests += hc.total[ST_TRI];
         st.shadow_node_visits += hc.total[ST_SH_NODE]; st.shadow_triangle_tests += hc.total[ST_SH_TRI];
         samplesDone += hc.total[ST_SAMPLES];
-        if (p->progress) p->progress(p->progress_user, sd.device, samplesDone, samplesTotal * (unsigned long long) p->spp);
+        if (p->progress) { std::lock_guard<std::mutex> g(sc->progressLock); p->progress(p->progress_user, sd.device, samplesDone, samplesTotal * (unsigned long long) p->spp); }
     }
     if ((nLocalTiles == 0 || cancelled) && !accumulate) { HIP_TRY(hipMemsetAsync(dOut, 0, (size_t) W * H * 5 * sizeof(float), stream)); HIP_TRY(hipStreamSynchronize(stream)); }
     unsigned long long inv = 0;

@@ -56,3 +56,23 @@ def sum_over_ranks(value, device="cpu"):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
     return float(value)
+
+
+class Solo:
+    """The same interface without any collective: what ONE rank uses when it renders a job on its own while the others wait
+    (bench.py: the single-GPU rate of the multi-GPU job, measured by rank 0 before the timed region)."""
+    @staticmethod
+    def barrier():
+        pass
+
+    @staticmethod
+    def reduce_film(film, dst=0):
+        return film
+
+    @staticmethod
+    def max_over_ranks(value, device="cpu"):
+        return float(value)
+
+    @staticmethod
+    def sum_over_ranks(value, device="cpu"):
+        return float(value)

@@ -2,6 +2,7 @@
 components in the slab test), multi-device rendering inside phip_render (one host thread per device + film merge),
 progressive passes (sample_offset / PHIP_FLAG_ACCUMULATE), the sticky cancellation flag and the progress callback."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -191,3 +192,26 @@ def test_progress_callback_and_cancel_from_it(gpu, gauss):
         integ.cancel()
     assert integ.render(gs, gpu.HDRFilm(w, h), 256, progress=stop) is False
     assert len(calls) >= 1 and calls[0] < w * h * 256
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("launcher", ["torchrun", "in_library"])
+def test_bench_two_gpus(gpu, phip, launcher):
+    """bench.py --gpus 2 on a box with at least two GPUs (skipped otherwise): one process per GPU over RCCL (the driver's launch line), and the
+    library's own multi-device path (host threads + ncclReduce from C++).  One JSON line, n_gpus 2, every sample of the job rendered."""
+    import json, socket, subprocess, sys
+    if phip.phip_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["bench.py", "--gpus", "2", "--workload", "cornell_256x256_16spp_md4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    if launcher == "torchrun":
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=840, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["workload"] == "cornell_256x256_16spp_md4"

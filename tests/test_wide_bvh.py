@@ -133,13 +133,14 @@ def test_answer_does_not_depend_on_the_structure(phip, gauss, monkeypatch):
 def test_big_degenerate_inputs_through_spatial_splits_and_reinsertion(phip):
     """inputs of >= 4096 triangles take the full builder (spatial splits + one pass of insertion-based re-optimisation): thousands of
     identical triangles, long slivers, and a completely flat scene of overlapping coplanar duplicates -- the build terminates with a
-    shallow tree and the traversal returns what the sweep over all records returns (on the flat scene the distance: with every box
-    flat in y the pad that keeps exact ties alive vanishes, so WHICH of twenty coincident copies is reported may differ)"""
+    shallow tree and the traversal returns what the sweep over all records returns, bit for bit -- also on the flat scene: the pad that
+    keeps exact ties alive is taken from the scene's LARGEST extent on every axis (round 2 used the per-axis extent, which vanished
+    for a scene flat in y, and which of twenty coincident copies was reported depended on the structure)"""
     rng = np.random.default_rng(1)
     tri = rng.uniform(-1, 1, (1, 3, 3)).astype(np.float32)
     flat = np.tile(rng.uniform(-1, 1, (300, 3, 3)).astype(np.float32) * np.array([1, 0, 1], np.float32), (20, 1, 1))
     slivers = (rng.uniform(-5, 5, (8000, 1, 3)) + rng.normal(size=(8000, 3, 3)) * np.array([3, 0.001, 0.001])).astype(np.float32)
-    for name, P, exact in (("identical", np.tile(tri, (6000, 1, 1)), True), ("slivers", slivers, True), ("flat", flat, False)):
+    for name, P, exact in (("identical", np.tile(tri, (6000, 1, 1)), True), ("slivers", slivers, True), ("flat", flat, True)):
         n = len(P); T = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
         rays = rays_through(rng, 2000, -2, 2, axis_aligned=0.2)
         w, info = host_trace(phip, P.reshape(-1, 3), T, rays, 1)
@@ -148,3 +149,39 @@ def test_big_degenerate_inputs_through_spatial_splits_and_reinsertion(phip):
         assert (w[:, 0].view(np.uint32) == b[:, 0].view(np.uint32)).all(), name
         if exact:
             assert (w.view(np.uint32) == b.view(np.uint32)).all(), name
+
+
+def test_build_time_is_bounded(phip):
+    """scene creation pays for the builder (spatial splits + reinsertion from 4096 triangles on): the top levels' subtrees are built on
+    several threads and the reinsertion search is bounded per insertion, so neither a 120 k-triangle soup nor 60 k coincident triangles
+    (where the branch-and-bound of the reinsertion prunes nothing: O(n^2) without the bound) take long.  Generous limits: a regression
+    of the kind round 2 shipped (10 s for 100 k coincident triangles, 121 s for a million) fails, machine noise does not."""
+    rng = np.random.default_rng(5)
+    n = 120000
+    c = rng.uniform(-10, 10, (n, 1, 3)).astype(np.float32)
+    soup = (c + rng.normal(0, 0.05, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    co = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (60000, 1))
+    for name, P, limit_ms in (("soup", soup, 20000.0), ("coincident", co, 20000.0)):
+        T = np.arange(len(P), dtype=np.uint32).reshape(-1, 3)
+        info = A.phip_accel_info(); box = (C.c_float * 6)()
+        rc = phip.phip_debug_host_build_bvh(np.ascontiguousarray(P).ctypes.data_as(C.POINTER(C.c_float)), len(P), T.ctypes.data_as(C.POINTER(C.c_uint32)), len(T), C.byref(info), box)
+        assert rc == 0
+        assert info.build_ms < limit_ms, (name, info.build_ms)
+        assert info.max_depth <= 40, (name, info.max_depth)
+
+
+def test_parallel_build_equals_the_serial_build(phip, monkeypatch):
+    """the subtrees of the builder's top levels are built on several threads and spliced in depth-first order: same tree as one thread builds"""
+    rng = np.random.default_rng(9)
+    n = 40000
+    c = rng.uniform(-4, 4, (n, 1, 3)).astype(np.float32)
+    P = (c + rng.normal(0, 0.2, (n, 3, 3)).astype(np.float32) * np.array([1.0, 0.05, 0.3], np.float32)).reshape(-1, 3)
+    T = np.arange(len(P), dtype=np.uint32).reshape(-1, 3)
+    rays = rays_through(rng, 3000, -5, 5)
+    res = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("PHIP_BVH_THREADS", threads)
+        w, info = host_trace(phip, P, T, rays, 1)
+        res.append((w.copy(), info.n_nodes, info.n_triangle_refs, info.max_depth, info.sah_cost))
+    assert res[0][1:] == res[1][1:], (res[0][1:], res[1][1:])
+    assert (res[0][0].view(np.uint32) == res[1][0].view(np.uint32)).all()
