@@ -208,6 +208,140 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc
     if (invalid) atomicAdd(invalidCount, invalid);
 }
 
+/* ---- round 3: the tiled gather for the reference's default filters (reach R = 1 or 2 pixels: box, tent, gaussian stddev 0.5) ----
+ * Same arithmetic per (sample, pixel) pair and the same order of additions as k_film_tiled, restructured around what round 2's
+ * counters showed (53 % of the wave cycles waiting at 3.7 waves per SIMD, 37 KB of LDS per block, two barriers per sample index):
+ *   - a sample's footprint starts one or two pixels left of its own pixel (ceil(jitter - 0.5 - radius)), so its separable weights are
+ *     staged at ABSOLUTE offsets, wx[j] = weight of pixel sx - R + j (0 outside the footprint or the render block's bitmap): the
+ *     gather needs no footprint origin, no bounds test and no branch -- w = wx[R - dx] * wy[R - dy] for all (2R+1)^2 neighbours,
+ *     fully unrolled (a zero weight adds +0: same bits as skipping it, invalid samples are staged as zero radiance);
+ *   - staging is double-buffered: sample k + 1 is staged while sample k is gathered, ONE barrier per sample index;
+ *   - per source pixel constants shrink to the sample-id base and an index into the (at most four) render blocks the tile touches.
+ * LDS: 2 x (20x20) x (16 + 44) B + 3.3 KB = 51 KB per block for R = 2. */
+template <int R>
+__global__ __launch_bounds__(BLOCK) void k_film_tiled2(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
+                                                      int tilesX, float *out, int accumulate, unsigned long long *invalidCount) {
+    constexpr int T = FILM_TILE + 2 * R, NW = 2 * R + 1, NP = T * T;
+    constexpr int NSTAGE = (NP + BLOCK - 1) / BLOCK;
+    __shared__ float4 sVal[2][NP];
+    __shared__ float sW[2][NP][2 * NW + 1];        /* wx[0..NW), wy[0..NW) at absolute offsets (+1: an odd stride keeps consecutive source pixels on different banks) */
+    __shared__ uint32_t sBase[NP];                 /* local tile slot of the source pixel's render block (0xFFFFFFFF: not rendered here) */
+    __shared__ uint32_t sMorton[NP];               /* Morton index of the source pixel in its block | geometry index << 30 */
+    __shared__ int4 sGeo[4];                       /* (offX - border, offY - border, bw, bh) of the up to 2 x 2 render blocks under the tile */
+    __shared__ float sTable[PHIP_FILTER_RESOLUTION + 1];
+    const DevFilm &F = S.film;
+    const int x0 = blockIdx.x * FILM_TILE, y0 = blockIdx.y * FILM_TILE;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = x0 + lx, y = y0 + ly;
+    if (threadIdx.x <= PHIP_FILTER_RESOLUTION) sTable[threadIdx.x] = F.table[threadIdx.x];
+    /* the render blocks under the tile + halo: block size >= 2 R + ... >= FILM_TILE is NOT assumed -- at most 2 x 2 blocks when
+       blockSize >= T, which the host guarantees before choosing this kernel */
+    const int tx0 = max(x0 - R, 0) >> rc.tileShift, ty0 = max(y0 - R, 0) >> rc.tileShift;
+    if (threadIdx.x < 4) {
+        const int tx = tx0 + (threadIdx.x & 1), ty = ty0 + (threadIdx.x >> 1);
+        const int offX = tx << rc.tileShift, offY = ty << rc.tileShift;
+        sGeo[threadIdx.x] = make_int4(offX - F.border, offY - F.border, min(F.blockSize, F.width - offX) + 2 * F.border, min(F.blockSize, F.height - offY) + 2 * F.border);
+    }
+    for (int i = threadIdx.x; i < NP; i += BLOCK) {
+        const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+        uint32_t base = 0xFFFFFFFFu, mm = 0;
+        if (sx >= 0 && sy >= 0 && sx < F.width && sy < F.height) {
+            const int tx = sx >> rc.tileShift, ty = sy >> rc.tileShift;
+            const int32_t ts = tileSlot[ty * tilesX + tx];
+            if (ts >= 0) {
+                base = (uint32_t) ts;
+                mm = (spreadBits((uint32_t) (sx - (tx << rc.tileShift))) | (spreadBits((uint32_t) (sy - (ty << rc.tileShift))) << 1))
+                   | ((uint32_t) ((tx - tx0) | ((ty - ty0) << 1)) << 30);
+            }
+        }
+        sBase[i] = base; sMorton[i] = mm;
+    }
+    __syncthreads();
+
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    unsigned long long invalid = 0;
+    const bool inside = x < F.width && y < F.height;
+    float4 pre[NSTAGE];
+    auto fetch = [&](uint32_t k) {
+#pragma unroll
+        for (int n = 0; n < NSTAGE; ++n) {
+            const int i = (int) threadIdx.x + n * BLOCK;
+            pre[n] = make_float4(0, 0, 0, 0);
+            if (i < NP && k < rc.sppPass) {
+                const uint32_t base = sBase[i];
+                if (base != 0xFFFFFFFFu)
+                    pre[n] = L[(((unsigned long long) base * rc.sppPass + k) << (2 * rc.tileShift)) | (sMorton[i] & 0x3FFFFFFFu)];
+            }
+        }
+    };
+    auto stage = [&](uint32_t k, int buf) {
+#pragma unroll
+        for (int n = 0; n < NSTAGE; ++n) {
+            const int i = (int) threadIdx.x + n * BLOCK;
+            if (i >= NP) break;
+            float4 v = make_float4(0, 0, 0, 0);
+            float w[2 * NW];
+#pragma unroll
+            for (int j = 0; j < 2 * NW; ++j) w[j] = 0.0f;
+            if (sBase[i] != 0xFFFFFFFFu) {
+                const int sx = x0 - R + (i % T), sy = y0 - R + (i / T);
+                const int4 g = sGeo[sMorton[i] >> 30];
+                const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
+                const V2 jit = streamJitter(rc, pixel, k + rc.sppFirst);
+                const float px = (float) sx + jit.x, py = (float) sy + jit.y;
+                const float posx = px - 0.5f - (float) g.x, posy = py - 0.5f - (float) g.y;   /* block-bitmap coordinates */
+                v = pre[n];
+                /* validity check of ImageBlock::put (imageblock.h:148-151) */
+                if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
+                    if (sx >= x0 && sx < x0 + FILM_TILE && sy >= y0 && sy < y0 + FILM_TILE) ++invalid;      /* counted once: by the tile that owns the pixel */
+                    v = make_float4(0, 0, 0, 0);
+                } else {
+                    /* footprint and weights, imageblock.h:159-180 */
+                    const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), g.z - 1);
+                    const int miny = max((int) ceilf(posy - F.radius), 0), maxy = min((int) floorf(posy + F.radius), g.w - 1);
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const int bx = sx - R + j - g.x, by = sy - R + j - g.y;             /* bitmap coordinates of the pixels sx - R + j, sy - R + j */
+                        if (bx >= minx && bx <= maxx) w[j] = sTable[min((int) fabsf(((float) bx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                        if (by >= miny && by <= maxy) w[NW + j] = sTable[min((int) fabsf(((float) by - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                    }
+                }
+            }
+            sVal[buf][i] = v;
+#pragma unroll
+            for (int j = 0; j < 2 * NW; ++j) sW[buf][i][j] = w[j];
+        }
+    };
+    fetch(0);
+    if (rc.sppPass) stage(0, 0);
+    fetch(1);
+    __syncthreads();
+    for (uint32_t k = 0; k < rc.sppPass; ++k) {
+        const int buf = (int) (k & 1u);
+        if (k + 1 < rc.sppPass) stage(k + 1, buf ^ 1);      /* (uses pre[] = sample k + 1; the other buffer) */
+        fetch(k + 2);
+        if (inside) {
+#pragma unroll
+            for (int dyy = -R; dyy <= R; ++dyy) {
+#pragma unroll
+                for (int dxx = -R; dxx <= R; ++dxx) {
+                    const int i = (ly + R + dyy) * T + (lx + R + dxx);
+                    const float w = sW[buf][i][R - dxx] * sW[buf][i][NW + R - dyy];
+                    const float4 v = sVal[buf][i];
+                    acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w; acc[4] += w * 1.0f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inside) {
+        float *o = out + ((size_t) y * F.width + x) * 5;
+        if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
+        else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
+    }
+    if (invalid) atomicAdd(invalidCount, invalid);
+}
+
 /* copy per-sample radiance out in [y][x][sample] order (tests) */
 __global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot, int tilesX,
                                  float4 *out, uint32_t sppTotal, uint32_t sampleOffset /* phip_render_params::sample_offset: index of the call's first sample */) {

@@ -24,6 +24,9 @@
  * Morton index), so the camera rays of a wave are coherent.
  */
 
+#ifndef MEGA_PROFILE
+#define MEGA_PROFILE 0               /* measurement build: wave clock and active lanes per phase of the loop (reported in the work-counter rows, which it falsifies) */
+#endif
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
@@ -36,7 +39,10 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
     float4 *ldsTriShade = (float4 *) (g_smem + traversalLdsBytesOf(S));
     float *ldsEm = (float *) (ldsTriShade + (size_t) S.nTriangles * TRISHADE_FLOAT4S);
     DevMaterial *ldsMat = (DevMaterial *) (ldsEm + ((S.emitterTabSize + 3u) & ~3u));
-    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    /* the host chose this kernel because every table fits (phip.hip: fitsLds): no run-time choice between the LDS copy and HBM, so that
+       the compiler can address the tables as LDS (ds_read) instead of through flat loads, which occupy the texture addresser */
+    tab.T.t = ldsEm; tab.materials = ldsMat;
     float4 *ldsFlat = (float4 *) (((uintptr_t) (ldsMat + S.nMaterials) + 15u) & ~(uintptr_t) 15u);      /* FLAT: the table of leaf boxes (traverseFlat) */
     if (FLAT) for (uint32_t i = threadIdx.x; i < 2u * S.nFlatLeaves; i += BLOCK) ldsFlat[i] = S.flatLeaves[i];
     lds_cf4 *flat = (lds_cf4 *) ldsFlat;
@@ -56,7 +62,20 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
 #pragma unroll
     for (int i = 0; i < MC_COUNT; ++i) ldsCount[i][threadIdx.x] = 0;
 
+#if MEGA_PROFILE
+    unsigned long long pfT[4] = { 0, 0, 0, 0 }, pfL[4] = { 0, 0, 0, 0 }, pfIter = 0;      /* regeneration, closest hit, vertex, shadow ray */
+#define PF_BEGIN unsigned long long pf0_ = clock64();
+#define PF_END(i, lanes) { __builtin_amdgcn_s_waitcnt(0); pfT[i] += clock64() - pf0_; pfL[i] += (unsigned long long) __popcll(lanes); }
+#else
+#define PF_BEGIN
+#define PF_END(i, lanes)
+#endif
     for (;;) {
+#if MEGA_PROFILE
+        ++pfIter;
+#endif
+        { PF_BEGIN
+        const unsigned long long pfWant_ = __ballot(!alive);
         /* ---- regeneration: lanes without a path start the next camera sample (integrator.cpp:157-183) ---- */
         for (;;) {
             const unsigned long long want = __ballot(!alive);
@@ -105,9 +124,11 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             const unsigned long long used = (unsigned long long) __popcll(want);
             next = (end - next < used) ? end : next + used;
         }
+        PF_END(0, pfWant_) }
         if (!__any(alive)) break;
 
         /* ---- closest hit ---- */
+        { PF_BEGIN
         if (alive) {
             const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
             float mint, maxt;
@@ -122,9 +143,11 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             ldsCount[MC_RAYS][threadIdx.x] += 1; ldsCount[MC_NODE][threadIdx.x] += nNode; ldsCount[MC_TRI][threadIdx.x] += nTri;
         }
 
+        PF_END(1, __ballot(alive)) }
         /* ---- the vertex: emitter hit / Russian roulette / emission / NEE sample / BSDF sample ---- */
         bool pushShadow = false, ended = false;
         ShadowEntry sh;
+        { PF_BEGIN
         if (alive) {
             uint32_t nv = 0;
             bool newRay;
@@ -133,7 +156,9 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             if (ended) ldsCount[MC_VERTICES][threadIdx.x] += nv;
         }
 
+        PF_END(2, __ballot(alive)) }
         /* ---- shadow ray of the NEE sample; unoccluded: the contribution joins the accumulator (path.cpp:187-199) ---- */
+        { PF_BEGIN
         if (pushShadow) {
             const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
             float mint, maxt;
@@ -148,12 +173,24 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
         }
 
+        PF_END(3, __ballot(pushShadow)) }
         if (ended) {
             L[v.id] = accum;
             ldsCount[MC_SAMPLES][threadIdx.x] += 1;
             alive = false;
         }
     }
+#if MEGA_PROFILE
+    if (lane == 0) {      /* rows: closest rays / nodes / tris / shadow rays = ticks of the four phases; shadow nodes / tris / vertices = lanes x 1 of phases 1..3; samples stay */
+        ldsCount[MC_RAYS][threadIdx.x] = (uint32_t) (pfT[0] >> 8); ldsCount[MC_NODE][threadIdx.x] = (uint32_t) (pfT[1] >> 8); ldsCount[MC_TRI][threadIdx.x] = (uint32_t) (pfT[2] >> 8);
+        ldsCount[MC_SH_RAYS][threadIdx.x] = (uint32_t) (pfT[3] >> 8);
+        ldsCount[MC_SH_NODE][threadIdx.x] = (uint32_t) pfL[1]; ldsCount[MC_SH_TRI][threadIdx.x] = (uint32_t) pfL[2]; ldsCount[MC_VERTICES][threadIdx.x] = (uint32_t) pfL[3];
+        ldsCount[MC_SAMPLES][threadIdx.x] = (uint32_t) pfIter;
+    } else {
+#pragma unroll
+        for (int i = 0; i < MC_COUNT; ++i) ldsCount[i][threadIdx.x] = 0;
+    }
+#endif
 
     /* per-wave statistics (one owner per entry, no atomics) */
     PathPool P; P.stat = M.stat; P.nWaves = M.nWaves;

@@ -172,7 +172,8 @@ struct LRegister {
 
 /* Returns true when the path ends at this vertex (then `vertices` = its depth).  newRay: v.rayO / rayD / thr / mis hold the
    next ray; v.state is updated whenever the path goes on.  A shadow-queue entry is returned in sh when pushShadow.
-   FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures; MM: leaf BSDF models
+   FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures, bit 2 (k_shade only) = the
+   emitter table and the materials are known to fit LDS (the kernel then reads them with ds_read instead of flat loads); MM: leaf BSDF models
    present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric normal is dead after
    fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
 template <int MM, bool STRICT, int FEAT, typename LAcc>
@@ -393,12 +394,13 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
     return t;
 }
 
-template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : ((MM == MM_ROUGH && !STRICT && FEAT == 0) ? SHADE_WAVES_ROUGH : SHADE_WAVES)) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : ((MM == MM_ROUGH && !STRICT && (FEAT & 3) == 0) ? SHADE_WAVES_ROUGH : SHADE_WAVES)) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    if (FEAT & 4) { tab.T.t = ldsEm; tab.materials = ldsMat; }     /* the host checked that both tables fit: LDS addressing (ds_read), no flat loads */
     uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     bool inRange = slot < P.capacity;
     /* all slot state is fetched up front, before the liveness test, so that the five 16-byte loads are

@@ -937,7 +937,9 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         }
         {   /* traversal-stack overflow: SPILL_DEPTH words per LANE of a ray kernel -- the wide tree is only walked by persistent grids
                (at most 8 resident blocks of 256 per CU), the BVH4 also by one-lane-per-slot launches */
-            const size_t spillLanes = sc->wide ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : laneCap;
+            const bool canSpill = sc->wide ? (int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS : 3 * ((int) sc->bvh.maxDepth - 1) + 1 > (int) D.stackDepth;
+            const bool persistentOnly = sc->wide || (sc->traversal == 2 && sc->bvh.nNodes >= 64 && !getenv("PHIP_MERGED"));
+            const size_t spillLanes = !canSpill ? (size_t) WIDE_BLOCK : (persistentOnly ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : laneCap);
             if (sd.spill.n < spillLanes * SPILL_DEPTH) sd.spill.alloc(spillLanes * SPILL_DEPTH);
         }
         if (sd.stat.n < (size_t) ST_COUNT * nWaves) sd.stat.alloc((size_t) ST_COUNT * nWaves);
@@ -1117,7 +1119,13 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             const dim3 fg((W + 15) / 16, (H + 15) / 16);
             const int reach = (int) std::floor(D.film.radius + 0.5f);
             const int acc = (sppDone > 0 || accumulate) ? 1 : 0;
-            if (reach <= FILM_MAX_REACH && !getenv("PHIP_FILM_GENERIC"))
+            const char *fv = getenv("PHIP_FILM_V1");                  /* experiment hook: the round-2 tiled kernel */
+            if (reach <= 2 && bs >= FILM_TILE + 2 * std::max(reach, 1) && !getenv("PHIP_FILM_GENERIC") && !(fv && atoi(fv))) {
+                if (reach <= 1)
+                    hipLaunchKernelGGL(k_film_tiled2<1>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut, acc, sd.invalid.p);
+                else
+                    hipLaunchKernelGGL(k_film_tiled2<2>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut, acc, sd.invalid.p);
+            } else if (reach <= FILM_MAX_REACH && !getenv("PHIP_FILM_GENERIC"))
                 if (reach <= 2)
                     hipLaunchKernelGGL(k_film_tiled<2>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
                                        acc, sd.invalid.p, reach);

@@ -18,10 +18,17 @@ typedef void (*ShadeKernel)(DevScene, PathPool, RenderConst, float4 *);
 
 void SHADE_CAT(phipLaunchShadeF, SHADE_FEAT)(bool strictNormals, int materialMask, dim3 grid, hipStream_t stream,
                                              const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
-#define SHADE_ROW(S_) { k_shade<0, S_, SHADE_FEAT>, k_shade<MM_ROUGH, S_, SHADE_FEAT>, k_shade<MM_DIELECTRIC, S_, SHADE_FEAT>, k_shade<MM_ALL, S_, SHADE_FEAT> }
-    static const ShadeKernel table[2][4] = { SHADE_ROW(false), SHADE_ROW(true) };
+#define SHADE_ROW(S_, F_) { k_shade<0, S_, F_>, k_shade<MM_ROUGH, S_, F_>, k_shade<MM_DIELECTRIC, S_, F_>, k_shade<MM_ALL, S_, F_> }
+    static const ShadeKernel table[2][4] = { SHADE_ROW(false, SHADE_FEAT), SHADE_ROW(true, SHADE_FEAT) };
+    const ShadeKernel *row = table[strictNormals ? 1 : 0];
+#if SHADE_FEAT == 0
+    /* no environment emitter, no textures (the configurations the metric is quoted on): a second set of kernels for scenes whose emitter
+       table and materials fit LDS -- nearly all -- which addresses them as LDS */
+    static const ShadeKernel tableLds[2][4] = { SHADE_ROW(false, 4), SHADE_ROW(true, 4) };
+    if (S.emitterTabSize <= EMITTER_LDS_FLOATS && S.nMaterials <= MATERIAL_LDS_MAX && !getenv("PHIP_SHADE_FLAT_TABLES")) row = tableLds[strictNormals ? 1 : 0];
+#endif
 #undef SHADE_ROW
-    hipLaunchKernelGGL(table[strictNormals ? 1 : 0][materialMask & MM_ALL], grid, dim3(BLOCK), 0, stream, S, P, rc, L);
+    hipLaunchKernelGGL(row[materialMask & MM_ALL], grid, dim3(BLOCK), 0, stream, S, P, rc, L);
 }
 
 void SHADE_CAT(phipLaunchShadeDirectF, SHADE_FEAT)(int materialMask, dim3 grid, hipStream_t stream,

@@ -233,8 +233,10 @@ def test_baseline_configs_at_full_size_against_the_reference(phip, ref, gauss, t
     the libm term: what is left is the handful of samples on which the reference's kd-tree returns another closest hit than a
     sweep over all triangles (tests/test_gpu_parity.py::test_c2_at_full_size_against_the_oracle, profiles/r02_c2_fullsize_sample_parity.json:
     20 of C2's 268 M samples) and the order of the float additions in the film.
-    (PHIP_FULLSIZE_C4=1 adds configs[3], 1920x1080x512 spp maxDepth 16: about ten minutes of the reference.)"""
-    keys = ["C2", "C3"] + (["C4full"] if os.environ.get("PHIP_FULLSIZE_C4") else [])
+    configs[3] -- the glass room, 1920x1080, maxDepth 16 -- runs at its full frame and depth with 64 of its 512 samples per pixel (the
+    reference needs about a minute for that on 256 threads, eight for the full count: PHIP_FULLSIZE_C4=1 renders all 512; round 2's
+    one-off run of it: 8.2e-5)."""
+    keys = ["C2", "C3", "C4res"] + (["C4full"] if os.environ.get("PHIP_FULLSIZE_C4") else [])
     stock = _fullsize(tmp_path, keys, preload=False)
     for name, r in stock.items():
         print("%s vs Mitsuba 0.6 (glibc): rel L2 %.3e, %.4f %% of the pixels differ by more than 1e-3; GPU %.3f s, reference %.1f s on %d threads"

@@ -122,6 +122,14 @@ def test_c4_full_size_counts(gpu, gauss):
     assert np.isfinite(whole.storage).all() and (whole.storage[..., 4] > 0).all()
 
 
+# ---- C5: the multi-GPU job, 3840 x 2160 x 1024 spp: a crop window at the full sample count against the oracle --------
+def test_c5_crop_of_the_full_size_job_matches_oracle(gpu, oracle, gauss):
+    sb = S.atrium(3840, 2160, gauss)
+    sb.hdrfilm(3840, 2160, gauss, crop=(1900, 1070, 40, 24))
+    same, r = compare_render(gpu, oracle, sb.desc(), 1024, min_identical=0.999, maxDepth=8)
+    print("C5 crop: identical %.6f rel L2 %.3e" % (same, r))
+
+
 # ---- C5: one GPU's share (1 of 8 shards) of the 3840 x 2160 x 1024 spp job ---------------------------
 def test_c5_one_of_eight_shards_at_full_size(gpu, gauss):
     W, H, spp, bs = 3840, 2160, 1024, 32

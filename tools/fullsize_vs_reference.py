@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs C2 / C3 / C4 at full size: path_hip on the GPU against Mitsuba 0.6 itself (oracle/_ref, all host cores,
 parity-stream sampler) -- developed images, relative L2.
-    python tools/fullsize_vs_reference.py out.json [C2|C3|C4-class|C4full]          (on a GPU box)
+    python tools/fullsize_vs_reference.py out.json [C2|C3|C4-class|C4res|C4full]          (on a GPU box)
     LD_PRELOAD=$PWD/oracle/_build/libcrm.so python tools/fullsize_vs_reference.py ...  the same against the reference with the
         correctly rounded transcendentals of include/phip_fmath.h in place of glibc's (oracle/ref_glue/crlibm_shim.cpp)"""
 import json
@@ -22,9 +22,12 @@ from oracle import oracle_ffi as O                             # noqa: E402
 for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1024, 1024, 256, -1),
                                    ("C3 atrium 1920x1080x64", S.atrium, 1920, 1080, 64, 8),
                                    ("C4-class glass room 960x540x64 md16", S.glass_room, 960, 540, 64, 16),
+                                   ("C4res glass room 1920x1080x64 md16", S.glass_room, 1920, 1080, 64, 16),
                                    ("C4full glass room 1920x1080x512 md16", S.glass_room, 1920, 1080, 512, 16)):
     if len(sys.argv) > 2 and not any(k in name for k in sys.argv[2:]):
         continue
+    if "C4res" in name and "C4res" not in sys.argv[2:]:
+        continue                                              # (C4's frame and depth at 1/8 of its samples per pixel: the driver-run suite asks for it)
     if "C4full" in name and "C4full" not in sys.argv[2:]:
         continue                                              # ~10 minutes of the reference on 256 threads: only on request
     desc = build(w, h, gauss).desc()
