@@ -14,8 +14,10 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
-#ifndef SHADE_WAVES_ROUGH
-#define SHADE_WAVES_ROUGH 5         /* diffuse + rough conductor, no strictNormals / environment / textures (the other instantiations spill at this bound): 95-97 VGPRs without the bound; with the lane deal the kernel waits on memory two thirds of its time, so the fifth wave counts */
+#ifndef SHADE_WAVES_PLAIN
+#define SHADE_WAVES_PLAIN 5         /* scenes with more than one BSDF model but no environment emitter and no textures (the other instantiations spill
+                                       100-200 B per lane at this bound): 95-102 VGPRs without the bound, 96 + 12..28 B of scratch with it.  The kernel waits
+                                       on memory two thirds of its time, so the fifth wave counts: glass room k_shade -4 %, atrium -1 % (6 waves: no further gain) */
 #endif
 #ifndef SHADE_WAVES_LEAN
 #define SHADE_WAVES_LEAN 4          /* diffuse-only instantiation */
@@ -394,7 +396,7 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
     return t;
 }
 
-template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : ((MM == MM_ROUGH && !STRICT && (FEAT & 3) == 0) ? SHADE_WAVES_ROUGH : SHADE_WAVES)) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : ((FEAT & 3) == 0 ? SHADE_WAVES_PLAIN : SHADE_WAVES)) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];

@@ -58,6 +58,18 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
         osc.set_bruteforce(True)
         ofilm, osmp, ost = osc.render(p, want_samples=True)
         same = (gsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1)
+    elif not same.all() and integrator is None and len(np.argwhere(~same)) <= 400:
+        # big scenes (a sweep over 250 k triangles per ray for every sample is out of reach): the FEW samples on which path_hip and the
+        # kd-tree oracle differ are re-evaluated one by one with the oracle answering its ray queries by that sweep -- each must then
+        # be path_hip's value bit for bit: what separates the two is the reference's kd-tree (a silhouette hit lost at a split plane, an
+        # exact-distance tie decided by leaf order: DESIGN.md 2.1), not the renderer
+        idx = np.argwhere(~same)
+        osc.set_bruteforce(True)
+        n_equal = sum(int((osc.path_sample(p, int(x), int(y), int(k)).view(np.uint32) == gsmp[y, x, k].view(np.uint32)).all()) for y, x, k in idx)
+        osc.set_bruteforce(False)
+        print("%d of %d samples differ from the kd-tree oracle; with the oracle answering by a sweep over all triangles %d of them are bit-identical to the GPU"
+              % (len(idx), same.size, n_equal))
+        assert n_equal == len(idx), (len(idx), n_equal)
     g, o = film.develop(), oracle.develop(ofilm)
     r = rel_l2(g, o) if np.abs(o).max() > 0 else float(np.abs(g).max())
     st = integ.stats
