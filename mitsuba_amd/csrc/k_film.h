@@ -218,13 +218,17 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc
  *   - staging is double-buffered: sample k + 1 is staged while sample k is gathered, ONE barrier per sample index;
  *   - per source pixel constants shrink to the sample-id base and an index into the (at most four) render blocks the tile touches.
  * LDS: 2 x (20x20) x (16 + 44) B + 3.3 KB = 51 KB per block for R = 2. */
+#ifndef FILM_NBUF
+#define FILM_NBUF 2                  /* staging buffers of k_film_tiled2: 2 = sample k + 1 is staged while k is gathered (one barrier per sample index, 51 KB: 3 blocks per CU);
+                                        1 = stage, barrier, gather, barrier (26 KB: 6 blocks per CU) */
+#endif
 template <int R>
 __global__ __launch_bounds__(BLOCK) void k_film_tiled2(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
                                                       int tilesX, float *out, int accumulate, unsigned long long *invalidCount) {
     constexpr int T = FILM_TILE + 2 * R, NW = 2 * R + 1, NP = T * T;
     constexpr int NSTAGE = (NP + BLOCK - 1) / BLOCK;
-    __shared__ float4 sVal[2][NP];
-    __shared__ float sW[2][NP][2 * NW + 1];        /* wx[0..NW), wy[0..NW) at absolute offsets (+1: an odd stride keeps consecutive source pixels on different banks) */
+    __shared__ float4 sVal[FILM_NBUF][NP];
+    __shared__ float sW[FILM_NBUF][NP][2 * NW + 1];        /* wx[0..NW), wy[0..NW) at absolute offsets (+1: an odd stride keeps consecutive source pixels on different banks) */
     __shared__ uint32_t sBase[NP];                 /* local tile slot of the source pixel's render block (0xFFFFFFFF: not rendered here) */
     __shared__ uint32_t sMorton[NP];               /* Morton index of the source pixel in its block | geometry index << 30 */
     __shared__ int4 sGeo[4];                       /* (offX - border, offY - border, bw, bh) of the up to 2 x 2 render blocks under the tile */
@@ -313,13 +317,21 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled2(DevScene S, RenderConst r
         }
     };
     fetch(0);
-    if (rc.sppPass) stage(0, 0);
-    fetch(1);
-    __syncthreads();
+    if (FILM_NBUF == 2) {
+        if (rc.sppPass) stage(0, 0);
+        fetch(1);
+        __syncthreads();
+    }
     for (uint32_t k = 0; k < rc.sppPass; ++k) {
-        const int buf = (int) (k & 1u);
-        if (k + 1 < rc.sppPass) stage(k + 1, buf ^ 1);      /* (uses pre[] = sample k + 1; the other buffer) */
-        fetch(k + 2);
+        const int buf = FILM_NBUF == 2 ? (int) (k & 1u) : 0;
+        if (FILM_NBUF == 2) {
+            if (k + 1 < rc.sppPass) stage(k + 1, buf ^ 1);  /* (uses pre[] = sample k + 1; the other buffer) */
+            fetch(k + 2);
+        } else {
+            stage(k, 0);
+            __syncthreads();
+            fetch(k + 1);
+        }
         if (inside) {
 #pragma unroll
             for (int dyy = -R; dyy <= R; ++dyy) {

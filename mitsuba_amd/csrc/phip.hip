@@ -1205,6 +1205,41 @@ __global__ void k_add_films(float *dst, const float *src, size_t n) {
 }
 } // namespace
 
+/* The RCCL calls of the merge on whatever is there: librccl is bound as renderMultiDevice binds it, a clique is made of the first
+   min(n, visible) devices -- ONE device is a valid clique --, and ncclReduce(sum) is run inside a group as the merge runs it, on a buffer
+   of ones.  On the single-GPU boxes of this pool that is the only way the six entry points ever execute (the merge itself needs two distinct
+   devices); returns the number of devices that took part, or a negative error code (phip_last_error). */
+extern "C" int phip_debug_rccl_selftest(int n_devices, size_t n_floats) {
+    try {
+        int visible = 0; HIP_TRY(hipGetDeviceCount(&visible));
+        const int n = std::max(1, std::min(n_devices, visible));
+        std::vector<int> devices(n); for (int i = 0; i < n; ++i) devices[i] = i;
+        std::lock_guard<std::mutex> g(g_rccl.lock);
+        g_rccl.bind();
+        const std::vector<ncclComm_t> &comm = g_rccl.clique(devices);
+        std::vector<float *> buf(n, nullptr); std::vector<hipStream_t> st(n, nullptr);
+        std::vector<float> ones(n_floats, 1.0f);
+        for (int i = 0; i < n; ++i) {
+            HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamCreate(&st[i]));
+            HIP_TRY(hipMalloc((void **) &buf[i], n_floats * sizeof(float)));
+            HIP_TRY(hipMemcpy(buf[i], ones.data(), n_floats * sizeof(float), hipMemcpyHostToDevice));
+        }
+        g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+        for (int i = 0; i < n; ++i) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            g_rccl.check(g_rccl.Reduce(buf[i], buf[i], n_floats, ncclFloat, ncclSum, 0, comm[i], st[i]), "ncclReduce");
+        }
+        g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(st[i])); }
+        HIP_TRY(hipSetDevice(devices[0]));
+        HIP_TRY(hipMemcpy(ones.data(), buf[0], n_floats * sizeof(float), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(devices[i])); (void) hipFree(buf[i]); (void) hipStreamDestroy(st[i]); }
+        HIP_TRY(hipSetDevice(devices[0]));
+        for (size_t k = 0; k < n_floats; ++k) if (ones[k] != (float) n) return setErr(PHIP_ERR_DEVICE, "ncclReduce(sum) of ones over " + std::to_string(n) + " device(s) gave " + std::to_string(ones[k]));
+        return n;
+    } catch (const std::exception &e) { return setErr(PHIP_ERR_DEVICE, e.what()); }
+}
+
 /* The call's shard on p->n_devices GPUs: one host thread + stream per device, blocks dealt round-robin in the reference's
    spiral order, films merged on devices[0] by one ncclReduce(sum) -- the in-process analogue of the reference's workers
    handing ImageBlocks to BlockedRenderProcess::processResult (renderproc.cpp:142-149). */

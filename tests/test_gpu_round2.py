@@ -215,3 +215,12 @@ def test_bench_two_gpus(gpu, phip, launcher):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["workload"] == "cornell_256x256_16spp_md4"
+
+
+def test_rccl_calls_of_the_merge_on_the_devices_that_are_there(gpu, phip):
+    """ncclCommInitAll / ncclGroupStart / ncclReduce / ncclGroupEnd as renderMultiDevice issues them, bound through the same dlopen,
+    on a clique of the visible devices (one device is a valid clique: the only way these calls run on a single-GPU box)"""
+    phip.phip_debug_rccl_selftest.argtypes = [C.c_int, C.c_size_t]
+    n = phip.phip_debug_rccl_selftest(8, 1 << 20)
+    assert n >= 1, phip.phip_last_error()
+    assert n == min(8, phip.phip_device_count())
