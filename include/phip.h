@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PHIP_ABI_VERSION 5
+#define PHIP_ABI_VERSION 6
 
 typedef enum phip_status {
     PHIP_OK              =  0,
@@ -205,7 +205,26 @@ typedef enum phip_sampler_kind {
                                 else `spp`) must be a power of two (ldsampler.cpp:83-87 rounds it up).  `direct`: its sample arrays
                                 (direct.cpp:139-146) are one scrambled sequence of sampleCount x N points each, in a random order
                                 (ldsampler.cpp:193-197); single shading samples are the sample's next 2D requests. */
+    , PHIP_SAMPLER_SOBOL = 2 /* (ABI 6, `path` only) the reference's `sobol` sampler (src/samplers/sobol.cpp): its stream is addressable as it
+                                stands -- sample k of pixel (x, y) is point sobol::look_up(m, k, x, y) of the global Sobol' sequence
+                                (Gruenschloss' enumeration of elementary intervals, sobolseq.h:94-130), dimension d of that point is
+                                sobol::sampleSingle(index, d) (sobolseq.h:42-58), dimensions are consumed in call order (camera sample 0-1,
+                                then every 2D request two and every 1D request one; as the plugin stands no 2D request is served from
+                                dimension 4, sobol.cpp:241-242 with m_arrayStartDim = m_arrayEndDim = 5: the third 2D request of a sample
+                                starts at 5 -- restated for rr_depth >= 2, where the first two requests after the camera sample are 2D;
+                                rr_depth 1 is PHIP_ERR_INVALID) -- so the device reproduces it bit for bit, given the
+                                plugin's direction numbers as DATA: phip_render_params.sobol_* (the Mitsuba shim reads them out of the
+                                loaded plugin, the test harness out of oracle/_ref/plugins/sobol.so or the fixture tests/golden/sobol_tables.npz made from it).
+                                Requests beyond sobol_dimensions fall back to the counter stream (the reference stops with an error there).
+                                The film's crop window must start at the origin. */
+    , PHIP_SAMPLER_STRATIFIED = 3 /* (ABI 6, `path` only) the construction of `stratified` (src/samplers/stratified.cpp:147-200): the first 4 2D
+                                requests of a sample (the pixel jitter is the first) and its first 4 1D requests are jittered points of a
+                                res x res (res^2 x 1) grid whose cells the samples of a pixel visit in a random order per dimension, later
+                                requests are independent -- with the order a keyed permutation (as PHIP_SAMPLER_LD) and the jitter the
+                                counter stream's number for that request, instead of the worker's sequential Random.  The sample count of
+                                the render must be a perfect square (stratified.cpp:64-72 rounds it up). */
 } phip_sampler_kind;
+#define PHIP_SOBOL_MATRIX_SIZE 52    /* words per dimension of sobol::Matrices (sobolseq.h:30) */
 
 /* which SamplingIntegrator::Li the call evaluates */
 typedef enum phip_integrator_kind {
@@ -253,6 +272,16 @@ typedef struct phip_render_params {
        May be NULL.  The callback may call phip_cancel. */
     void   (*progress)(void *user, int32_t device, uint64_t samples_done, uint64_t samples_total);
     void    *progress_user;
+    /* PHIP_SAMPLER_SOBOL (ABI 6): host pointers, read during the call.  sobol_matrices = sobol::Matrices::matrices32, sobol_dimensions x 52
+       words; sobol_vdc / sobol_vdc_inv = rows [m - 1] of sobol::Matrices::vdc_sobol_matrices / _inv (52 words each), m = sobol_log_resolution =
+       log2 of the larger side of the crop window rounded up to a power of two (SobolSampler::setFilmResolution, sobol.cpp:147-157; m <= 1:
+       no per-pixel enumeration, the tables may be NULL); sobol_scramble = the sampler's m_scramble (0 unless the scene sets `scramble`: then sampleTEA of it, sobol.cpp:92-102). */
+    const uint32_t *sobol_matrices;
+    const uint64_t *sobol_vdc;
+    const uint64_t *sobol_vdc_inv;
+    uint32_t sobol_dimensions;
+    uint32_t sobol_log_resolution;
+    uint64_t sobol_scramble;
 } phip_render_params;
 
 #define PHIP_FLAG_KERNEL_TIMING 1   /* bracket the kernels with hipEvents, fill phip_stats.*_ms */

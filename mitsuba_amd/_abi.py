@@ -5,7 +5,7 @@ struct against the values the C side reports through phip_abi_sizeof().
 """
 import ctypes as C
 
-PHIP_ABI_VERSION = 5
+PHIP_ABI_VERSION = 6
 PHIP_FILTER_RESOLUTION = 31
 
 PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCELLED, PHIP_ERR_NOMEM = 0, -1, -2, -3, -4, -5
@@ -13,6 +13,9 @@ PHIP_BSDF_DIFFUSE, PHIP_BSDF_DIELECTRIC, PHIP_BSDF_ROUGHCONDUCTOR, PHIP_BSDF_TWO
 PHIP_MF_BECKMANN, PHIP_MF_GGX = 0, 1
 PHIP_SAMPLER_CTR = 0
 PHIP_SAMPLER_LD = 1
+PHIP_SAMPLER_SOBOL = 2
+PHIP_SAMPLER_STRATIFIED = 3
+PHIP_SOBOL_MATRIX_SIZE = 52
 PHIP_INTEGRATOR_PATH, PHIP_INTEGRATOR_DIRECT = 0, 1
 PHIP_FLAG_KERNEL_TIMING = 1
 PHIP_FLAG_SAMPLE_BUFFER = 2
@@ -106,7 +109,9 @@ class phip_render_params(C.Structure):
                 ("integrator", C.c_uint32), ("emitter_samples", C.c_int32), ("bsdf_samples", C.c_int32),
                 ("n_devices", C.c_int32), ("devices", C.c_int32 * PHIP_MAX_DEVICES),
                 ("sample_offset", C.c_int32), ("sample_total", C.c_int32),
-                ("progress", PROGRESS_FN), ("progress_user", C.c_void_p)]
+                ("progress", PROGRESS_FN), ("progress_user", C.c_void_p),
+                ("sobol_matrices", C.POINTER(C.c_uint32)), ("sobol_vdc", C.POINTER(C.c_uint64)), ("sobol_vdc_inv", C.POINTER(C.c_uint64)),
+                ("sobol_dimensions", C.c_uint32), ("sobol_log_resolution", C.c_uint32), ("sobol_scramble", C.c_uint64)]
 
 
 class phip_stats(C.Structure):
@@ -167,6 +172,14 @@ def default_render_params(**kw):
         p.n_devices = len(devices)
         for i, d in enumerate(devices):
             p.devices[i] = d
+    sobol = kw.pop("sobol", None)      # (matrices32, vdc, vdc_inv, log_resolution): numpy arrays out of the reference's sobol plugin (oracle/ref_ffi.sobol_tables)
+    if sobol is not None:
+        matrices, vdc, inv, m = sobol
+        p.sampler = PHIP_SAMPLER_SOBOL
+        p.sobol_matrices = matrices.ctypes.data_as(C.POINTER(C.c_uint32))
+        p.sobol_vdc = vdc.ctypes.data_as(C.POINTER(C.c_uint64)); p.sobol_vdc_inv = inv.ctypes.data_as(C.POINTER(C.c_uint64))
+        p.sobol_dimensions = len(matrices) // PHIP_SOBOL_MATRIX_SIZE; p.sobol_log_resolution = m; p.sobol_scramble = 0
+        p._keep_sobol = sobol                  # keep the arrays alive as long as the struct
     progress = kw.pop("progress", None)
     if progress is not None:
         p.progress = progress if isinstance(progress, PROGRESS_FN) else PROGRESS_FN(progress)

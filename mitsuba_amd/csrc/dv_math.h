@@ -309,4 +309,64 @@ DV void ldPoint(uint32_t pixel, uint32_t k, uint32_t dim, uint32_t seed, uint32_
     y = sobol2Single(i, h.z);
 }
 
+/* ---- PHIP_SAMPLER_SOBOL: the reference's `sobol` sampler as it stands (src/samplers/sobol.cpp, sobolseq.h), SINGLE_PRECISION.  The
+ *      direction numbers are DATA handed through the ABI (phip_render_params.sobol_*): nothing of sobolseq.cpp is in this repository. ---- */
+struct SobolTab {
+    const uint32_t *matrices;           /* sobol::Matrices::matrices32: dims x 52 */
+    const uint64_t *vdc, *vdcInv;       /* rows [m - 1] of vdc_sobol_matrices / vdc_sobol_matrices_inv */
+    uint32_t dims, logRes, scramble;    /* m_scramble truncated to 32 bits (sobolseq.h:86: sampleSingle(index, dimension, (uint32_t) scramble)) */
+    float resolution;                   /* 2^logRes */
+};
+/* index of the frame-th point of the sequence that falls into pixel (px, py): sobol::look_up, sobolseq.h:94-130 */
+DV uint64_t sobolLookUp(const SobolTab &T, uint32_t frame, uint32_t px, uint32_t py) {
+    const uint32_t m = T.logRes, m2 = m << 1;
+    uint64_t index = (uint64_t) frame << m2;
+    uint64_t delta = 0;
+    for (uint32_t c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1u) delta ^= T.vdc[c];
+    const uint64_t scramble = (uint64_t) (T.scramble >> (32u - m));
+    uint64_t b = ((((uint64_t) px ^ scramble) << m) | ((uint64_t) py ^ scramble)) ^ delta;
+    for (uint32_t c = 0; b; b >>= 1, ++c)
+        if (b & 1ull) index ^= T.vdcInv[c];
+    return index;
+}
+/* SobolSampler::setSampleIndex, sobol.cpp:207-219 */
+DV uint64_t sobolSampleIndex(const SobolTab &T, uint32_t sampleIndex, uint32_t px, uint32_t py) {
+    return T.logRes > 1u ? sobolLookUp(T, sampleIndex, px, py) : (uint64_t) sampleIndex;
+}
+/* sobol::sampleSingle, sobolseq.h:42-58 */
+DV float sobolSample(const SobolTab &T, uint64_t index, uint32_t dimension) {
+    uint32_t result = T.scramble;
+    for (uint32_t i = dimension * 52u; index; index >>= 1, ++i)
+        if (index & 1ull) result ^= T.matrices[i];
+    const float v = (float) result * (1.0f / 4294967296.0f);
+    return 0.99999994f < v ? 0.99999994f : v;            /* std::min(result * 2^-32, ONE_MINUS_EPS_FLT) */
+}
+/* the camera sample: SobolSampler::next2D at dimension 0 (sobol.cpp:244-247) -> the jitter renderBlock adds to the pixel (integrator.cpp:171) */
+DV void sobolCameraSample(const SobolTab &T, uint32_t sampleIndex, uint32_t px, uint32_t py, float &jx, float &jy) {
+    const uint64_t idx = sobolSampleIndex(T, sampleIndex, px, py);
+    if (idx != (uint64_t) sampleIndex) {
+        jx = sobolSample(T, idx, 0u) * T.resolution - (float) (int) px;
+        jy = sobolSample(T, idx, 1u) * T.resolution - (float) (int) py;
+    } else { jx = sobolSample(T, idx, 0u); jy = sobolSample(T, idx, 1u); }
+}
+
+/* ---- PHIP_SAMPLER_STRATIFIED: the construction of `stratified` (src/samplers/stratified.cpp:147-200) made addressable: the cell a sample
+ *      visits in dimension `dim` (2D request q: 2 q, 1D request j: 2 j + 1) is a keyed permutation of its index (stratified.cpp:147-158 shuffles with
+ *      the worker's Random), the jitter inside the cell is the counter stream's number for that request. ---- */
+#define ST_DIMENSIONS 4u                /* `dimension` default: that many 2D and 1D requests per sample are stratified (stratified.cpp:79) */
+DV uint32_t stCell(uint32_t pixel, uint32_t k, uint32_t dim, uint32_t seed, uint32_t count) {
+    const U4 h = pcg4d(pixel, dim, 0x5354u /* 'ST' */, seed);
+    return ldPermuteAny(k % count, count, h.x);
+}
+DV void stPoint2D(uint32_t pixel, uint32_t k, uint32_t q, uint32_t seed, uint32_t res, float u1, float u2, float &x, float &y) {
+    const uint32_t c = stCell(pixel, k, 2u * q, seed, res * res);
+    const float inv = 1.0f / (float) (int) res;
+    x = ((float) (int) (c % res) + u1) * inv; y = ((float) (int) (c / res) + u2) * inv;       /* stratified.cpp:181-189 */
+}
+DV float stPoint1D(uint32_t pixel, uint32_t k, uint32_t j, uint32_t seed, uint32_t res, float u) {
+    const uint32_t c = stCell(pixel, k, 2u * j + 1u, seed, res * res);
+    return ((float) (int) c + u) * (1.0f / (float) (size_t) (res * res));                      /* stratified.cpp:170-173 */
+}
+
 } // namespace pt

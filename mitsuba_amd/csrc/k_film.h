@@ -22,6 +22,7 @@ __global__ void k_reduce_stats(PathPool P, Counters *C, int firstRow) {
  * ImageBlock::put (imageblock.h:124-204) incl. the block-local coordinate arithmetic: a sample
  * taken in pixel (sx,sy) belongs to the render block whose origin is (sx,sy) rounded down to the
  * block size, and its weights are computed in that block's coordinate system. */
+template <bool QMC>        /* QMC: the sample positions of PHIP_SAMPLER_SOBOL / _STRATIFIED (the tiled kernels serve the counter and LD streams) */
 __global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot,
                                                int tilesX, float *out, int accumulate, unsigned long long *invalidCount) {
     const DevFilm &F = S.film;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, cons
             const uint32_t m = spreadBits((uint32_t) (sx - offX)) | (spreadBits((uint32_t) (sy - offY)) << 1);
             const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
             for (uint32_t k = 0; k < rc.sppPass; ++k) {
-                const V2 jit = streamJitter(rc, pixel, k + rc.sppFirst);
+                const V2 jit = streamJitter<QMC>(rc, pixel, k + rc.sppFirst, (uint32_t) F.width);
                 const float px = (float) sx + jit.x, py = (float) sy + jit.y;
                 const float posx = px - 0.5f - (float) (offX - F.border), posy = py - 0.5f - (float) (offY - F.border);
                 const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), bw - 1);

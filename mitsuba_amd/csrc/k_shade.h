@@ -24,6 +24,7 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #endif
 /* The common tail of the shading kernels: the block's shadow-queue entries are compacted, slots whose sample ended start
  * the next camera sample in the same lane, blocks without work retire, per-wave statistics are recorded. */
+template <bool QMC = false>
 __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool &P, const RenderConst &rc, uint32_t *waveCnt,
                                               const uint32_t slot, const bool inRange, uint4 info, const bool alive, bool needNew,
                                               const bool pushShadow, const float4 sh0, const float4 sh1, const float4 sh2,
@@ -112,7 +113,7 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         uint32_t px, py, k;
         decodeId(rc, S.film, newId, px, py, k);
         const uint32_t pixel = py * (uint32_t) S.film.width + px;
-        const V2 jit = streamJitter(rc, pixel, k);
+        const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
         const float sx = (float) px + jit.x, sy = (float) py + jit.y;
         V3 o, d; float mint, maxt;
         cameraRay(S.cam, sx, sy, o, d, mint, maxt);
@@ -181,7 +182,7 @@ struct LRegister {
 template <int MM, bool STRICT, int FEAT, typename LAcc>
 __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab &T, const DevMaterial *materials, const RenderConst &rc,
                                             PathVertex &v, const LAcc &acc, bool &newRay, bool &pushShadow, ShadowEntry &sh, uint32_t &vertices) {
-    constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0;
+    constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0, QMC = (FEAT & 8) != 0;
     const uint32_t prim = pm_to_bits(v.hit.w);
     const V3 rayD(v.rayD.x, v.rayD.y, v.rayD.z);
     V3 thr(v.thr.x, v.thr.y, v.thr.z);
@@ -207,7 +208,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                         /* the camera ray is the one ray with differentials: filtered lookup, envmap.cpp:395-407.
                            Its sample position is recomputed from the counter stream (a rare branch) */
                         const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
-                        const V2 hc = streamJitter(rc, v.pixel, v.k);
+                        const V2 hc = streamJitter<QMC>(rc, v.pixel, v.k, (uint32_t) S.film.width);
                         V3 rx, ry;
                         cameraRayDifferentials(S.cam, (float) px + hc.x, (float) py + hc.y, rx, ry);
                         rx = rayD + (rx - rayD) * rc.diffScaleFactor;
@@ -259,6 +260,16 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                     float unused; ldPoint(v.pixel, v.k, 2u * (depth - 1u - (uint32_t) rc.rrDepth) + 1u, rc.seed, rc.ldMask, rr, unused);
                 } else
                     rr = u32ToFloat(pcg4d(v.pixel, v.k, 2 + 2 * (depth - 2), rc.seed).x);
+                if (QMC) {
+                    /* the (depth - 1 - rrDepth)-th 1D request of the sample.  sobol: its dimension is two per 2D request made so far (the camera
+                       sample and the kq requests of the vertices behind) plus one per earlier 1D request (SobolSampler::next1D, sobol.cpp:226-236) */
+                    const uint32_t j = depth - 1u - (uint32_t) rc.rrDepth, kq = 2u * (depth - 1u) - (flags >> NS_SHIFT);
+                    if (rc.sampler == PHIP_SAMPLER_SOBOL) {
+                        const uint32_t dim = 2u * (1u + kq) + j + 1u;      /* (+ 1: SobolSampler::next2D skips dimension 4, see the vertex's requests below) */
+                        if (dim < rc.sobol.dims) rr = sobolSample(rc.sobol, sobolSampleIndex(rc.sobol, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width), dim);
+                    } else if (rc.sampler == PHIP_SAMPLER_STRATIFIED && j < ST_DIMENSIONS)
+                        rr = stPoint1D(v.pixel, v.k, j, rc.seed, rc.stRes, rr);
+                }
                 if (rr >= q)
                     terminate = true;
                 else
@@ -308,6 +319,28 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 } else if (q < LD_DIMENSIONS)
                     ldPoint(v.pixel, v.k, 2u * q, rc.seed, rc.ldMask, smpBSDF.x, smpBSDF.y);
             }
+            if (QMC && rc.sampler == PHIP_SAMPLER_SOBOL) {
+                /* SobolSampler::next2D (sobol.cpp:238-257): the requests of this vertex start at dimension 2 (1 + k0) + the 1D requests made so far
+                   (one Russian-roulette request behind every vertex from rrDepth on: max(0, depth - rrDepth)) */
+                const uint64_t idx = sobolSampleIndex(rc.sobol, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width);
+                /* ... and the sampler never hands out dimension 4 to a 2D request (sobol.cpp:241-242: the test for the dimensions reserved to sample
+                   arrays, [5, 5) when none is requested, fires for m_dimension == 4): the sample's third 2D request starts there -- no 1D request
+                   can come earlier with rrDepth >= 2 -- so it and every later request is shifted by one */
+                uint32_t dim = 2u * (1u + k0) + (depth > (uint32_t) rc.rrDepth ? depth - (uint32_t) rc.rrDepth : 0u) + (k0 >= 1u ? 1u : 0u);
+                if (smoothVertex) {
+                    if (dim + 1u < rc.sobol.dims) smpEmitter = V2(sobolSample(rc.sobol, idx, dim), sobolSample(rc.sobol, idx, dim + 1u));
+                    dim += 2u + (k0 == 0u ? 1u : 0u);
+                }
+                if (dim + 1u < rc.sobol.dims) smpBSDF = V2(sobolSample(rc.sobol, idx, dim), sobolSample(rc.sobol, idx, dim + 1u));
+            } else if (QMC && rc.sampler == PHIP_SAMPLER_STRATIFIED) {
+                /* 2D requests k0 + 1 (and k0 + 2 at a smooth vertex) of the sample: the first ST_DIMENSIONS are stratified, jittered by the counter stream's own numbers */
+                const uint32_t q = k0 + 1u;
+                if (smoothVertex) {
+                    if (q < ST_DIMENSIONS) stPoint2D(v.pixel, v.k, q, rc.seed, rc.stRes, smpEmitter.x, smpEmitter.y, smpEmitter.x, smpEmitter.y);
+                    if (q + 1u < ST_DIMENSIONS) stPoint2D(v.pixel, v.k, q + 1u, rc.seed, rc.stRes, smpBSDF.x, smpBSDF.y, smpBSDF.x, smpBSDF.y);
+                } else if (q < ST_DIMENSIONS)
+                    stPoint2D(v.pixel, v.k, q, rc.seed, rc.stRes, smpBSDF.x, smpBSDF.y, smpBSDF.x, smpBSDF.y);
+            }
             /* ---- direct illumination sampling, path.cpp:172-200 ---- */
             DirectRec dRec;
             dRec.ref = its.p;
@@ -320,7 +353,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
                 if (firstVertex) {
                     const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
-                    const V2 hc = streamJitter(rc, v.pixel, v.k);
+                    const V2 hc = streamJitter<QMC>(rc, v.pixel, v.k, (uint32_t) S.film.width);
                     V3 rx, ry;
                     cameraRayDifferentials(S.cam, (float) px + hc.x, (float) py + hc.y, rx, ry);
                     rx = rayD + (rx - rayD) * rc.diffScaleFactor;
@@ -484,5 +517,5 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
         }
     }
 
-    shadeEpilogue(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh.e0, sh.e1, sh.e2, vertices, done);
+    shadeEpilogue<(FEAT & 8) != 0>(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh.e0, sh.e1, sh.e2, vertices, done);
 }

@@ -171,6 +171,7 @@ struct SceneDev {
     DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
+    DevBuf<uint32_t> sobolMat; DevBuf<unsigned long long> sobolVdc; const void *sobolKey = nullptr; uint32_t sobolLogRes = 0;    /* PHIP_SAMPLER_SOBOL: the plugin's tables */
     DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
     DevBuf<unsigned int> drawCounters;                                                       /* k_rays_w: 2 x RAY_SHARDS sharded work counters */
     DevBuf<float> film;
@@ -754,6 +755,7 @@ static void phipLaunchShade(int feat, bool strictNormals, int materialMask, dim3
         case 0: phipLaunchShadeF0(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         case 1: phipLaunchShadeF1(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         case 2: phipLaunchShadeF2(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
+        case 8: phipLaunchShadeF8(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         default: phipLaunchShadeF3(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
     }
 }
@@ -812,7 +814,26 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
         if (p->emitter_samples + p->bsdf_samples <= 0) throw std::invalid_argument("direct: emitterSamples + bsdfSamples must be > 0");     /* Assert, direct.cpp:107 */
         if (p->emitter_samples + p->bsdf_samples >= (int) DEPTH_MASK) throw std::invalid_argument("direct: at most 65534 shading samples per camera sample");
     }
-    if (p->sampler != PHIP_SAMPLER_CTR && p->sampler != PHIP_SAMPLER_LD) throw std::invalid_argument("unknown sampler kind");
+    if (p->sampler > PHIP_SAMPLER_STRATIFIED) throw std::invalid_argument("unknown sampler kind");
+    if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) {
+        const char *name = p->sampler == PHIP_SAMPLER_SOBOL ? "PHIP_SAMPLER_SOBOL" : "PHIP_SAMPLER_STRATIFIED";
+        if (direct) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
+        const DevScene &D0 = sc->devs[0]->dev;
+        if (D0.envEmitter >= 0 || sc->hasTextures) throw std::invalid_argument(std::string(name) + ": not built for scenes with an environment emitter or bitmap textures");
+        if (p->sampler == PHIP_SAMPLER_SOBOL) {
+            if (!p->sobol_matrices || p->sobol_dimensions < 8) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_matrices / sobol_dimensions (the reference plugin's direction numbers) are required");
+            if (p->sobol_log_resolution > 26) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_log_resolution out of range");
+            if (p->rr_depth < 2) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: rrDepth must be at least 2 (the dimension bookkeeping of sobol.cpp:241-242 is restated for that case)");
+            if (p->sobol_log_resolution > 1 && (!p->sobol_vdc || !p->sobol_vdc_inv)) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_vdc / sobol_vdc_inv are required when the film is enumerated per pixel");
+            if (sc->descCopy.film.crop_offset_x != 0 || sc->descCopy.film.crop_offset_y != 0) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: the crop window must start at the film's origin");
+            uint32_t need = 0; { uint32_t side = (uint32_t) std::max(D0.film.width, D0.film.height), r = 1; while (r < side) { r <<= 1; ++need; } }
+            if (p->sobol_log_resolution != need) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_log_resolution must be log2 of the crop window's larger side rounded up to a power of two (sobol.cpp:147-157)");
+        } else {
+            const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
+            unsigned r = 1; while (r * r < n) ++r;
+            if (r * r != n) throw std::invalid_argument("PHIP_SAMPLER_STRATIFIED: the sample count of the render must be a perfect square (stratified.cpp:64-72 rounds it up)");
+        }
+    }
     if (p->sampler == PHIP_SAMPLER_LD) {
         const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
         if (n == 0 || (n & (n - 1))) throw std::invalid_argument("PHIP_SAMPLER_LD: the sample count of the render must be a power of two (ldsampler.cpp:83-87)");
@@ -894,7 +915,20 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     if (sd.L.n < idsFirstPass) sd.L.alloc((size_t) idsFirstPass);
 
     /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
-    bool fused = !direct && sc->fitsLds && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
+    const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED;     /* served by the wavefront kernels compiled with FEAT bit 3 */
+    bool fused = !direct && !qmc && sc->fitsLds && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
+    if (qmc && p->sampler == PHIP_SAMPLER_SOBOL) {
+        /* the plugin's tables, uploaded once per (pointer, size): ~210 KB of direction numbers + the two 52-word enumeration rows */
+        const size_t nm = (size_t) p->sobol_dimensions * PHIP_SOBOL_MATRIX_SIZE;
+        if (sd.sobolKey != (const void *) p->sobol_matrices || sd.sobolMat.n != nm || sd.sobolLogRes != p->sobol_log_resolution) {
+            sd.sobolMat.upload(p->sobol_matrices, nm);
+            std::vector<unsigned long long> v(2 * PHIP_SOBOL_MATRIX_SIZE, 0ull);
+            if (p->sobol_log_resolution > 1)
+                for (int i = 0; i < PHIP_SOBOL_MATRIX_SIZE; ++i) { v[i] = p->sobol_vdc[i]; v[PHIP_SOBOL_MATRIX_SIZE + i] = p->sobol_vdc_inv[i]; }
+            sd.sobolVdc.upload(v.data(), v.size());
+            sd.sobolKey = (const void *) p->sobol_matrices; sd.sobolLogRes = p->sobol_log_resolution;
+        }
+    }
     if (const char *e = getenv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
     sd.fused = fused;
 
@@ -1010,6 +1044,16 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         rc.maxDepth = p->max_depth; rc.rrDepth = p->rr_depth; rc.strictNormals = p->strict_normals; rc.hideEmitters = p->hide_emitters;
         rc.seed = p->seed; rc.tileOrigin = sd.tileOrigin.p; rc.countAlive = 0;
         rc.sampler = (uint32_t) p->sampler; rc.ldMask = (uint32_t) (p->sample_total > 0 ? p->sample_total : p->spp) - 1u;
+        memset(&rc.sobol, 0, sizeof(rc.sobol)); rc.stRes = 1;
+        if (p->sampler == PHIP_SAMPLER_SOBOL) {
+            rc.sobol.matrices = sd.sobolMat.p; rc.sobol.vdc = (const uint64_t *) sd.sobolVdc.p; rc.sobol.vdcInv = (const uint64_t *) sd.sobolVdc.p + PHIP_SOBOL_MATRIX_SIZE;
+            rc.sobol.dims = p->sobol_dimensions; rc.sobol.logRes = p->sobol_log_resolution; rc.sobol.scramble = (uint32_t) p->sobol_scramble;
+            rc.sobol.resolution = (float) (1u << p->sobol_log_resolution);
+        } else if (p->sampler == PHIP_SAMPLER_STRATIFIED) {
+            const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
+            unsigned r = 1; while (r * r < n) ++r;
+            rc.stRes = r;
+        }
         rc.diffScaleFactor = 1.0f / sqrtf((float) (p->sample_total > 0 ? p->sample_total : p->spp));
         rc.emitterSamples = direct ? p->emitter_samples : 0; rc.bsdfSamples = direct ? p->bsdf_samples : 0;
         if (direct) {   /* direct.cpp:130-138 */
@@ -1060,7 +1104,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipStreamSynchronize(stream));
             const auto tLoop0 = clk::now();
             bool done = rc.totalIds == 0;
-            const int feat = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0);     /* environment emitter, bitmap textures */
+            const int feat = qmc ? 8 : ((D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0));     /* environment emitter, bitmap textures; 8: the QMC samplers */
             while (!done) {
                 const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
                 rc.countAlive = check ? 1 : 0;
@@ -1120,7 +1164,10 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             const int reach = (int) std::floor(D.film.radius + 0.5f);
             const int acc = (sppDone > 0 || accumulate) ? 1 : 0;
             const char *fv = getenv("PHIP_FILM_V1");                  /* experiment hook: the round-2 tiled kernel */
-            if (reach <= 2 && bs >= FILM_TILE + 2 * std::max(reach, 1) && !getenv("PHIP_FILM_GENERIC") && !(fv && atoi(fv))) {
+            if (qmc)
+                hipLaunchKernelGGL(k_film<true>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
+                                   acc, sd.invalid.p);
+            else if (reach <= 2 && bs >= FILM_TILE + 2 * std::max(reach, 1) && !getenv("PHIP_FILM_GENERIC") && !(fv && atoi(fv))) {
                 if (reach <= 1)
                     hipLaunchKernelGGL(k_film_tiled2<1>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut, acc, sd.invalid.p);
                 else
@@ -1133,7 +1180,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                     hipLaunchKernelGGL(k_film_tiled<FILM_MAX_REACH>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
                                        acc, sd.invalid.p, reach);
             else
-                hipLaunchKernelGGL(k_film, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
+                hipLaunchKernelGGL(k_film<false>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
                                    acc, sd.invalid.p);
         }
         if (timing) evFilm.record(stream);
@@ -1375,7 +1422,7 @@ const char *phip_last_error(void) { return g_err.c_str(); }
 #endif
 /* the hash of the sources and flags this library was compiled from (mitsuba_amd/_ffi.py: source_id) */
 const char *phip_build_id(void) { static const char tag[] = "phip-build-id:" PHIP_BUILD_ID; return tag + 14; }
-const char *phip_version(void) { return "path_hip 0.5 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
+const char *phip_version(void) { return "path_hip 0.6 (gfx950, abi " PHIP_STR(PHIP_ABI_VERSION) ")"; }
 
 int phip_device_count(void) {
     int n = 0;

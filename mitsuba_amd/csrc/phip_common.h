@@ -5,7 +5,7 @@
  * libphip.so is built from three sources (six objects) so that they compile in parallel (the shading kernels are 40
  * template instantiations):
  *   phip.hip        host side (scene build, render loop, multi-device orchestration, C ABI) + traversal and film kernels
- *   phip_shade.hip  k_shade / k_shade_direct instantiations behind phipLaunchShadeF<n> (compiled four times, -DSHADE_FEAT=0..3)
+ *   phip_shade.hip  k_shade / k_shade_direct instantiations behind phipLaunchShadeF<n> (compiled five times, -DSHADE_FEAT=0..3 and 8: the QMC samplers)
  *   phip_mega.hip   k_mega instantiations behind phipLaunchMega
  * No device function is called across units (everything on the device side is inline in headers), so no -fgpu-rdc.
  */
@@ -46,7 +46,7 @@ using namespace pt;
                              const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);                      \
     void phipLaunchShadeDirectF##n(int materialMask, dim3 grid, hipStream_t stream,                                        \
                                    const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);
-PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3)
+PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3) PHIP_DECLARE_SHADE(8)
 #undef PHIP_DECLARE_SHADE
 /* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */
 int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, bool flat, size_t ldsBytes);

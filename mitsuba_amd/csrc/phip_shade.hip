@@ -9,7 +9,7 @@
 #include "k_shade_direct.h"
 
 #ifndef SHADE_FEAT
-#error "compile with -DSHADE_FEAT=0..3"
+#error "compile with -DSHADE_FEAT=0..3 or 8"
 #endif
 #define SHADE_CAT2(a, b) a##b
 #define SHADE_CAT(a, b) SHADE_CAT2(a, b)
@@ -33,7 +33,11 @@ void SHADE_CAT(phipLaunchShadeF, SHADE_FEAT)(bool strictNormals, int materialMas
 
 void SHADE_CAT(phipLaunchShadeDirectF, SHADE_FEAT)(int materialMask, dim3 grid, hipStream_t stream,
                                                    const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
+#if SHADE_FEAT == 8
+    throw std::runtime_error("the QMC samplers are built for the `path` integrator only");      /* (validateParams refuses it before) */
+#else
     /* `direct`: leaf BSDF models = diffuse only / all, strictNormals at run time */
     static const ShadeKernel table[2] = { k_shade_direct<0, SHADE_FEAT>, k_shade_direct<MM_ALL, SHADE_FEAT> };
     hipLaunchKernelGGL(table[(materialMask & MM_ALL) ? 1 : 0], grid, dim3(BLOCK), 0, stream, S, P, rc, L);
+#endif
 }

@@ -8,7 +8,10 @@
 #include <mitsuba/core/plugin.h>
 #include <mitsuba/core/fresolver.h>
 #include <mitsuba/render/mipmap.h>
+#include <mitsuba/core/qmc.h>
 #include <boost/algorithm/string.hpp>
+#include <dlfcn.h>
+#include <link.h>
 #include "../../bsdfs/microfacet.h"      /* MicrofacetDistribution: plugin-local header of src/bsdfs */
 #include "../../bsdfs/ior.h"             /* lookupIOR */
 #include "phip.h"
@@ -172,7 +175,7 @@ public:
        parallel schedule reproduces, not even the reference's own from run to run (independent.cpp:42-45) -- so the device's
        counter-based stream stands in, which is said once.  `ldsampler` maps to PHIP_SAMPLER_LD: the same construction (scrambled
        (0,2)-sequences in a random order per pixel and dimension for the first four 1D / 2D requests of a sample, ldsampler.cpp:151-226)
-       with the scrambles and the order drawn from the counter-based generator instead of the worker's Random -- default `dimension` only.  Any other QMC sampler would silently lose its stratification: an error. */
+       with the scrambles and the order drawn from the counter-based generator instead of the worker's Random -- default `dimension` only.  `stratified` maps to PHIP_SAMPLER_STRATIFIED the same way; `sobol` is deterministic and maps to PHIP_SAMPLER_SOBOL, the plugin's own numbers.  Any other QMC sampler (halton, hammersley) would silently lose its stratification: an error. */
     static int checkSampler(const Sampler *sampler, const char *name) {
         const std::string cls = sampler->getClass()->getName();
         if (cls == "LowDiscrepancySampler") {
@@ -195,8 +198,54 @@ public:
             }
             return PHIP_SAMPLER_CTR;
         }
-        SLog(EError, "%s: sampler \"%s\" is not supported ('independent', 'ldsampler'; other QMC samplers would lose their stratification)", name, cls.c_str());
+        if (cls == "StratifiedSampler") {
+            if (sampler->getProperties().getInteger("dimension", 4) != 4)
+                SLog(EError, "%s: stratified sampler with dimension != 4 is not supported", name);
+            static bool toldST = false;
+            if (!toldST) {
+                toldST = true;
+                SLog(EWarn, "%s: 'stratified' is served by the device's stratified stream (one cell of the sampleCount grid per sample and dimension in a "
+                            "permuted order, jittered: stratified.cpp:147-200 with the permutations and jitter from the counter-based generator): the same stratification, "
+                            "not the same numbers as the CPU integrator", name);
+            }
+            return PHIP_SAMPLER_STRATIFIED;
+        }
+        if (cls == "SobolSampler")
+            return PHIP_SAMPLER_SOBOL;          /* the plugin's own sequence, number for number: setSobol() below */
+        SLog(EError, "%s: sampler \"%s\" is not supported ('independent', 'ldsampler', 'stratified', 'sobol'; other QMC samplers would lose their stratification)", name, cls.c_str());
         return PHIP_SAMPLER_CTR;
+    }
+
+    /* PHIP_SAMPLER_SOBOL: the direction numbers are the `sobol` plugin's (sobol::Matrices, src/samplers/sobolseq.cpp). The scene's sampler
+       is an instance of it, so the plugin is loaded (PluginManager dlopens plugins RTLD_LOCAL, plugin.cpp:71): find it among the loaded
+       objects, take a second handle on it and read the three tables as data.  Dimensions are consumed in call order exactly as
+       SobolSampler does (sobol.cpp:218-247), so path_hip + sobol renders the image `path` + sobol renders, sample for sample. */
+    struct FindPlugin { const char *suffix; std::string path; };
+    static int findPluginCb(struct dl_phdr_info *info, size_t, void *data) {
+        FindPlugin *f = (FindPlugin *) data;
+        const std::string n = info->dlpi_name ? info->dlpi_name : "";
+        const size_t l = strlen(f->suffix);
+        if (n.size() >= l && n.compare(n.size() - l, l, f->suffix) == 0) { f->path = n; return 1; }
+        return 0;
+    }
+    static void setSobol(const Sampler *sampler, const Vector2i &cropSize, phip_render_params &rp, const char *name) {
+        FindPlugin f; f.suffix = "/sobol.so";
+        dl_iterate_phdr(findPluginCb, &f);
+        void *h = f.path.empty() ? NULL : dlopen(f.path.c_str(), RTLD_LAZY | RTLD_NOLOAD);
+        const uint32_t *m32 = h ? (const uint32_t *) dlsym(h, "_ZN5sobol8Matrices10matrices32E") : NULL;
+        const uint64_t *vdc = h ? (const uint64_t *) dlsym(h, "_ZN5sobol8Matrices18vdc_sobol_matricesE") : NULL;
+        const uint64_t *inv = h ? (const uint64_t *) dlsym(h, "_ZN5sobol8Matrices22vdc_sobol_matrices_invE") : NULL;
+        if (!m32 || !vdc || !inv)
+            SLog(EError, "%s: the direction numbers of the loaded 'sobol' plugin were not found (%s)", name, f.path.empty() ? "plugin not among the loaded objects" : f.path.c_str());
+        uint32_t res = 1, m = 0;
+        while (res < (uint32_t) std::max(cropSize.x, cropSize.y)) { res <<= 1; ++m; }        /* SobolSampler::setFilmResolution, sobol.cpp:147-157 */
+        rp.sobol_matrices = m32; rp.sobol_dimensions = 1024;                                 /* sobol::Matrices::num_dimensions */
+        rp.sobol_log_resolution = m;
+        rp.sobol_vdc = m > 1 ? vdc + (size_t) (m - 1) * PHIP_SOBOL_MATRIX_SIZE : NULL;       /* vdc_sobol_matrices[m - 1] (sobolseq.h:104-107) */
+        rp.sobol_vdc_inv = m > 1 ? inv + (size_t) (m - 1) * PHIP_SOBOL_MATRIX_SIZE : NULL;
+        uint64_t scramble = (uint64_t) sampler->getProperties().getSize("scramble", 0);
+        if (scramble) { union { uint64_t ui64; uint32_t v[2]; } u = { scramble }; scramble = sampleTEA(u.v[0], u.v[1]); }   /* sobol.cpp:92-102 */
+        rp.sobol_scramble = scramble;
     }
 
     /* SamplingIntegrator::render (integrator.cpp:95-129) + BlockedRenderProcess (renderproc.cpp:142-176): the job runs as a few
@@ -212,6 +261,7 @@ public:
         const size_t spp = sampler->getSampleCount();
         SLog(EInfo, "Starting render job (%ix%i, " SIZE_T_FMT " samples, %s) ..", size.x, size.y, spp, phip_version());
         rp.block_size = (int32_t) scene->getBlockSize();
+        if (samplerKind == PHIP_SAMPLER_SOBOL) setSobol(sampler, size, rp, name);
         rp.sampler = samplerKind; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
         int nDev = m_deviceCount == 0 ? phip_device_count() - m_device : m_deviceCount;
         if (nDev > PHIP_MAX_DEVICES) nDev = PHIP_MAX_DEVICES;

@@ -184,6 +184,37 @@ inline uint32_t ldPermuteAny(uint32_t i, uint32_t l, uint32_t key) {     /* ... 
 }
 static const uint32_t LD_DIMENSIONS = 4;     /* ldsampler.cpp:79 */
 
+/* ---- PHIP_SAMPLER_SOBOL: the reference's `sobol` sampler (src/samplers/sobol.cpp), SINGLE_PRECISION.  The direction numbers are the
+ *      plugin's own tables, handed in as data (phip_render_params.sobol_*). ---- */
+struct SobolTables {
+    const uint32_t *matrices = nullptr;              /* sobol::Matrices::matrices32 (sobolseq.h:31) */
+    const uint64_t *vdc = nullptr, *vdcInv = nullptr; /* rows [m - 1] of vdc_sobol_matrices / _inv (sobolseq.h:33-34) */
+    uint32_t dims = 0, logRes = 0; uint64_t scramble = 0;
+    float resolution = 1.0f;
+    uint64_t lookUp(uint32_t frame, uint32_t px, uint32_t py) const {          /* sobol::look_up, sobolseq.h:94-130 */
+        const uint32_t m = logRes, m2 = m << 1;
+        uint64_t index = uint64_t(frame) << m2;
+        uint64_t delta = 0;
+        for (uint32_t c = 0; frame; frame >>= 1, ++c)
+            if (frame & 1) delta ^= vdc[c];
+        const uint64_t scr = (scramble & 0xFFFFFFFFull) >> (32 - m);
+        uint64_t b = (((uint64_t) (px ^ scr) << m) | (py ^ scr)) ^ delta;
+        for (uint32_t c = 0; b; b >>= 1, ++c)
+            if (b & 1) index ^= vdcInv[c];
+        return index;
+    }
+    uint64_t sampleIndex(uint32_t sample, uint32_t px, uint32_t py) const {    /* SobolSampler::setSampleIndex, sobol.cpp:207-219 */
+        return logRes > 1 ? lookUp(sample, px, py) : (uint64_t) sample;
+    }
+    float sample(uint64_t index, uint32_t dimension) const {                   /* sobol::sampleSingle, sobolseq.h:42-58 */
+        uint32_t result = (uint32_t) scramble;
+        for (uint32_t i = dimension * 52; index; index >>= 1, ++i)
+            if (index & 1) result ^= matrices[i];
+        return std::min(result * (1.0f / (1ULL << 32)), 0.999999940395355225f /* ONE_MINUS_EPS_FLT */);
+    }
+};
+static const uint32_t ST_DIMENSIONS = 4;     /* stratified.cpp:79 */
+
 struct SampleSource {
     /* ctr mode */
     bool ctr = true;
@@ -195,6 +226,30 @@ struct SampleSource {
         pcg4d(h);
         const uint32_t i = ldPermute(sample & ldMask, ldMask, h[0]);
         return Vec2(radicalInverse2Single(i, h[1]), sobol2Single(i, h[2]));
+    }
+    /* sobol mode (the reference's stream as it stands) / stratified mode (its construction on the counter stream, as ld): PHIP_SAMPLER_SOBOL / _STRATIFIED */
+    int qmc = 0;                             /* 0: off, 1: sobol, 2: stratified */
+    const SobolTables *sobol = nullptr; uint32_t px = 0, py = 0;             /* pixel position SobolSampler::generate received */
+    uint32_t stRes = 1;
+    uint32_t stCell(uint32_t dim) const {    /* the cell sample `sample` visits in dimension dim: a keyed permutation (stratified.cpp:147-158 shuffles) */
+        uint32_t h[4] = { pixel, dim, 0x5354u, seed };
+        pcg4d(h);
+        return ldPermuteAny(sample % (stRes * stRes), stRes * stRes, h[0]);
+    }
+    Vec2 stPoint2D(uint32_t q, Vec2 u) const {           /* StratifiedSampler::next2D, stratified.cpp:177-189 */
+        const uint32_t c = stCell(2 * q);
+        const int x = (int) (c % stRes), y = (int) (c / stRes);
+        const float inv = 1 / (Float) (int) stRes;
+        return Vec2((x + u.x) * inv, (y + u.y) * inv);
+    }
+    Float stPoint1D(uint32_t j, Float u) const {         /* StratifiedSampler::next1D, stratified.cpp:167-175 */
+        const int c = (int) stCell(2 * j + 1);
+        return (c + u) * (1 / (Float) (size_t) (stRes * stRes));
+    }
+    Vec2 sobol2D(uint32_t dim, Vec2 fallback) const {
+        if (dim + 1 >= sobol->dims) return fallback;     /* (the reference stops with an error here, sobol.cpp:243-245) */
+        const uint64_t idx = sobol->sampleIndex(sample, px, py);
+        return Vec2(sobol->sample(idx, dim), sobol->sample(idx, dim + 1));
     }
     /* sfmt mode */
     SFMT *rng = nullptr;
@@ -209,30 +264,53 @@ struct SampleSource {
        requests (emitter sample, BSDF sample), a vertex without (dielectric) one: k = 2 (depth - 1) - ns at the start of vertex
        `depth`, ns = non-smooth vertices so far (modulo 64: six bits of device state). */
     uint32_t ns = 0;
-    Vec2 pair(uint32_t k) const {
+    Vec2 ctrPair(uint32_t k) const { float f[4]; block(1 + 2 * (k >> 1), f); return (k & 1u) ? Vec2(f[2], f[3]) : Vec2(f[0], f[1]); }
+    /* the k-th 2D request after the camera sample, made at vertex `depth`.  sobol: dimensions are consumed in call order -- two per 2D request
+       (the camera sample took 0 and 1), one per 1D request; before the requests of vertex `depth` there were max(0, depth - rrDepth)
+       Russian-roulette requests (one behind every vertex from rrDepth on, path.cpp:276-283) */
+    Vec2 pair(uint32_t k, int depth) const {
         if (ld && k + 1 < LD_DIMENSIONS) return ldPoint(2 * (k + 1));
-        float f[4]; block(1 + 2 * (k >> 1), f); return (k & 1u) ? Vec2(f[2], f[3]) : Vec2(f[0], f[1]);
+        /* ... and SobolSampler::next2D skips dimension 4 (sobol.cpp:241-242: `m_dimension + 1 >= m_arrayStartDim && m_dimension < m_arrayEndDim` with both = 5
+           when no sample array is requested): the third 2D request of a sample starts there (rrDepth >= 2: no 1D request comes earlier), so it
+           and everything behind it is shifted by one */
+        if (qmc == 1) return sobol2D(2 * (1 + k) + (uint32_t) std::max(0, depth - rrDepth) + (k >= 1 ? 1u : 0u), ctrPair(k));
+        if (qmc == 2 && k + 1 < ST_DIMENSIONS) return stPoint2D(k + 1, ctrPair(k));
+        return ctrPair(k);
     }
     Vec2 cameraSample() {
         if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
         ns = 0;
         if (ld) return ldPoint(0);
-        float f[4]; block(0, f); return Vec2(f[0], f[1]);
+        if (qmc == 1) {                                      /* SobolSampler::next2D at dimension 0, sobol.cpp:246-252 */
+            const uint64_t idx = sobol->sampleIndex(sample, px, py);
+            if (idx != (uint64_t) sample)
+                return Vec2(sobol->sample(idx, 0) * sobol->resolution - (int) px, sobol->sample(idx, 1) * sobol->resolution - (int) py);
+            return Vec2(sobol->sample(idx, 0), sobol->sample(idx, 1));
+        }
+        float f[4]; block(0, f);
+        if (qmc == 2) return stPoint2D(0, Vec2(f[0], f[1]));
+        return Vec2(f[0], f[1]);
     }
     Vec2 emitterSample(int depth) {                      /* (only requested at vertices with a smooth BSDF, path.cpp:174-176) */
         if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
-        return pair(2 * (uint32_t) (depth - 1) - ns);
+        return pair(2 * (uint32_t) (depth - 1) - ns, depth);
     }
     Vec2 bsdfSample(int depth, bool smooth) {
         if (!ctr) { Float a = rng->nextFloat(); Float b = rng->nextFloat(); return Vec2(a, b); }
         const uint32_t k = 2 * (uint32_t) (depth - 1) - ns + (smooth ? 1u : 0u);
         if (!smooth) ns = (ns + 1u) & 63u;
-        return pair(k);
+        return pair(k, depth);
     }
     Float rrSample(int depth) {
         if (!ctr) return rng->nextFloat();
         if (ld && (uint32_t) (depth - rrDepth) < LD_DIMENSIONS) return ldPoint(2 * (uint32_t) (depth - rrDepth) + 1).x;   /* the (depth - rrDepth)-th 1D request */
-        float f[4]; block(2 + 2 * (uint32_t) (depth - 1), f); return f[0];
+        float f[4]; block(2 + 2 * (uint32_t) (depth - 1), f);
+        if (qmc == 1) {                                      /* SobolSampler::next1D: after 1 + (2 depth - ns) 2D requests and depth - rrDepth 1D requests */
+            const uint32_t dim = 2 * (1 + 2 * (uint32_t) depth - ns) + (uint32_t) (depth - rrDepth) + 1u;      /* (+ 1: the skipped dimension 4, see pair()) */
+            return dim < sobol->dims ? sobol->sample(sobol->sampleIndex(sample, px, py), dim) : f[0];
+        }
+        if (qmc == 2 && (uint32_t) (depth - rrDepth) < ST_DIMENSIONS) return stPoint1D((uint32_t) (depth - rrDepth), f[0]);
+        return f[0];
     }
 
     /* ---- `direct`: sample arrays (which = 0: emitter samples, 1: BSDF samples) ----

@@ -50,6 +50,22 @@ void oracle_scene_set_bruteforce(void *scene, int on) { static_cast<Scene *>(sce
 /* sampler_mode: 0 = ctr parity stream, 1 = per-worker SFMT19937 streams like `independent` */
 int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
                         float *out_rgbaw, float *out_samples_rgba, uint32_t *out_smooth_masks, phip_stats *stats);
+/* PHIP_SAMPLER_SOBOL / _STRATIFIED: the sampler's parameters out of phip_render_params (the tables stay where the caller has them) */
+static void setQmc(const Scene &scene, const phip_render_params *p, int &qmc, SobolTables &sob, uint32_t &stRes) {
+    if (p->sampler == PHIP_SAMPLER_SOBOL) {
+        if (!p->sobol_matrices || (p->sobol_log_resolution > 1 && (!p->sobol_vdc || !p->sobol_vdc_inv))) throw std::runtime_error("PHIP_SAMPLER_SOBOL: tables missing");
+        if (scene.film.crop_offset_x != 0 || scene.film.crop_offset_y != 0) throw std::runtime_error("PHIP_SAMPLER_SOBOL: crop window at the origin");
+        if (p->rr_depth < 2) throw std::runtime_error("PHIP_SAMPLER_SOBOL: rrDepth >= 2");
+        qmc = 1; sob.matrices = p->sobol_matrices; sob.vdc = p->sobol_vdc; sob.vdcInv = p->sobol_vdc_inv; sob.dims = p->sobol_dimensions;
+        sob.logRes = p->sobol_log_resolution; sob.scramble = p->sobol_scramble; sob.resolution = (float) (1u << p->sobol_log_resolution);
+    } else {
+        const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
+        unsigned r = 1; while (r * r < n) ++r;
+        if (r * r != n) throw std::runtime_error("PHIP_SAMPLER_STRATIFIED: perfect-square sample count");
+        qmc = 2; stRes = r;
+    }
+}
+
 int oracle_render(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
                   float *out_rgbaw, float *out_samples_rgba, phip_stats *stats) {
     return oracle_render_masks(scene_, p, threads, sampler_mode, out_rgbaw, out_samples_rgba, nullptr, stats);
@@ -70,6 +86,10 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
             const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
             if (sampler_mode != 0 || n == 0 || (n & (n - 1)))
                 throw std::runtime_error("PHIP_SAMPLER_LD: on the counter stream, power-of-two sample count");
+        }
+        if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) {
+            if (sampler_mode != 0 || p->integrator != PHIP_INTEGRATOR_PATH) throw std::runtime_error("PHIP_SAMPLER_SOBOL / _STRATIFIED: `path`, counter-stream mode");
+            setQmc(scene, p, rp.qmc, rp.sobol, rp.stRes);
         }
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
         if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::runtime_error("unknown integrator");
@@ -144,6 +164,8 @@ int oracle_path_sample(void *scene_, const phip_render_params *p, int px, int py
         SampleSource smp; smp.ctr = true; smp.seed = p->seed; smp.rng = nullptr;
         smp.pixel = (uint32_t) (py * f.crop_width + px); smp.sample = (uint32_t) k;
         smp.ld = p->sampler == PHIP_SAMPLER_LD; smp.ldMask = (uint32_t) (p->sample_total > 0 ? p->sample_total : p->spp) - 1u; smp.rrDepth = p->rr_depth;
+        SobolTables sob;
+        if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) { setQmc(scene, p, smp.qmc, sob, smp.stRes); smp.sobol = &sob; smp.px = (uint32_t) px; smp.py = (uint32_t) py; }
         const Float diffScaleFactor = 1.0f / std::sqrt((Float) (p->sample_total > 0 ? p->sample_total : p->spp));
         Vec2 jit = smp.cameraSample();
         Vec2 samplePos((Float) px + jit.x, (Float) py + jit.y);

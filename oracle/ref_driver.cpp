@@ -39,7 +39,7 @@ namespace {
 
 std::string g_err;
 bool g_init = false;
-int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream); 2 = the reference's `ldsampler` */
+int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream); 2 / 3 / 4 = the reference's `ldsampler` / `sobol` / `stratified` */
 /* shapes the NEXT ref_scene_create loads through one of the reference's own mesh-loader plugins (shapes/obj.cpp): (plugin, file,
    material id of the description, toWorld) -- a real asset enters the scene exactly as the XML loader would add it */
 struct FileShape { std::string plugin, filename; uint32_t material; float toWorld[16]; };
@@ -57,7 +57,7 @@ struct RefScene {
 /* the scene's sampler for one render: `independent`, or the parity stream (ctr_sampler.cpp: defined by call order, so it needs to know
    nothing about the scene) */
 Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
-    Properties smp(g_samplerKind == 1 ? "ctr" : g_samplerKind == 2 ? "ldsampler" : "independent");
+    Properties smp(g_samplerKind == 1 ? "ctr" : g_samplerKind == 2 ? "ldsampler" : g_samplerKind == 3 ? "sobol" : g_samplerKind == 4 ? "stratified" : "independent");
     smp.setSize("sampleCount", (size_t) p->spp);
     if (g_samplerKind == 1) {
         smp.setInteger("seed", (int) p->seed);
@@ -67,7 +67,9 @@ Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
         smp.setInteger("rrDepth", p->rr_depth);          /* the depth of the first Russian-roulette request (path.cpp:276-283) */
         smp.setBoolean("ld", p->sampler == PHIP_SAMPLER_LD);   /* the ldsampler construction on the counter-based generator (include/phip.h) */
         smp.setSize("sampleTotal", (size_t) (p->sample_total > 0 ? p->sample_total : p->spp));
+        smp.setBoolean("stratified", p->sampler == PHIP_SAMPLER_STRATIFIED);   /* the construction of `stratified` on the counter stream (include/phip.h) */
     }
+    if (g_samplerKind == 3 && p->seed) smp.setSize("scramble", (size_t) p->seed);   /* the plugin's frame number; phip_render_params.sobol_scramble holds what the plugin makes of it (sobol.cpp:92-102) */
     Sampler *s = static_cast<Sampler *>(PluginManager::getInstance()->createObject(MTS_CLASS(Sampler), smp));
     s->configure();
     return s;
@@ -410,6 +412,7 @@ int ref_render(void *h, const phip_render_params *p, float *out_samples, float *
         integ->configure();
 
         ref<Sampler> parent = makeSampler(scene, p);
+        parent->setFilmResolution(film->getCropSize(), true);   /* SamplingIntegrator::preprocess, integrator.cpp:40-41 (`sobol` enumerates the sequence per pixel) */
         integ->configureSampler(scene, parent);          /* requests the sample arrays of `direct` */
         ref<Sampler> sampler = parent->clone();          /* worker 0's sampler */
 

@@ -121,7 +121,7 @@ class RefScene:
             raise RuntimeError(what + ": " + self.L.ref_last_error().decode())
 
     def _sampler(self, sampler):
-        self.L.ref_set_sampler({"independent": 0, "ctr": 1, "ldsampler": 2}[sampler])
+        self.L.ref_set_sampler({"independent": 0, "ctr": 1, "ldsampler": 2, "sobol": 3, "stratified": 4}[sampler])
 
     def render(self, params, want_samples=True, sampler="independent"):
         """sampler="ctr": the reference's integrator fed with the counter-based parity stream (ref_glue/ctr_sampler.cpp: defined by
@@ -223,3 +223,35 @@ class RefMip:
         if self.h:
             self.L.ref_mip_destroy(self.h)
             self.h = None
+
+
+def sobol_tables(width, height, dimensions=1024):
+    """The direction numbers of the reference's OWN sobol plugin (oracle/_ref/plugins/sobol.so = src/samplers/sobol.cpp + sobolseq.cpp,
+    compiled in place), read out of the loaded library as data: (matrices32[dimensions * 52], vdc[52], vdc_inv[52], log_resolution) for a
+    film whose crop window is width x height (SobolSampler::setFilmResolution, sobol.cpp:147-157).  Nothing is copied into the repository."""
+    so = C.CDLL(os.path.join(HERE, "_ref", "plugins", "sobol.so"))
+    res, m = 1, 0
+    while res < max(width, height):
+        res <<= 1; m += 1
+    mat = (C.c_uint32 * (1024 * 52)).in_dll(so, "_ZN5sobol8Matrices10matrices32E")
+    matrices = np.frombuffer(mat, dtype=np.uint32)[:dimensions * 52].copy()
+    vdc = np.zeros(52, np.uint64); inv = np.zeros(52, np.uint64)
+    if m > 1:
+        rows = 26                                           # vdc_sobol_matrices[m - 1], m = 1 .. 26 (sobolseq.cpp:106537, 107241)
+        a = np.frombuffer((C.c_uint64 * (rows * 52)).in_dll(so, "_ZN5sobol8Matrices18vdc_sobol_matricesE"), dtype=np.uint64).reshape(rows, 52)
+        b = np.frombuffer((C.c_uint64 * (rows * 52)).in_dll(so, "_ZN5sobol8Matrices22vdc_sobol_matrices_invE"), dtype=np.uint64).reshape(rows, 52)
+        vdc, inv = a[m - 1].copy(), b[m - 1].copy()
+    return matrices, vdc, inv, m
+
+
+def sobol_scramble(frame):
+    """phip_render_params.sobol_scramble for the plugin's `scramble` property (a frame number): 0 stays 0, anything else goes through four
+    rounds of TEA (sobol.cpp:92-102 -> qmc.h:146-156, Wheeler & Needham's block cipher)"""
+    if frame == 0:
+        return 0
+    v0, v1, s, M = frame & 0xFFFFFFFF, (frame >> 32) & 0xFFFFFFFF, 0, 0xFFFFFFFF
+    for _ in range(4):
+        s = (s + 0x9e3779b9) & M
+        v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C) ^ (v1 + s) ^ ((v1 >> 5) + 0xC8013EA4))) & M
+        v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D) ^ (v0 + s) ^ ((v0 >> 5) + 0x7E95761E))) & M
+    return (v1 << 32) + v0

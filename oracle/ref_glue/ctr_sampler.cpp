@@ -33,6 +33,9 @@ public:
         m_rrFirst = (uint32_t) props.getInteger("rrDepth", 5);
         m_ld = props.getBoolean("ld", false);
         m_ldMask = (uint32_t) props.getSize("sampleTotal", m_sampleCount) - 1u;
+        /* PHIP_SAMPLER_STRATIFIED: the construction of stratified.cpp:147-200 on the counter stream (include/phip.h); `path` only */
+        m_stratified = props.getBoolean("stratified", false);
+        m_stRes = 1; while ((size_t) m_stRes * m_stRes < props.getSize("sampleTotal", m_sampleCount)) ++m_stRes;
         m_pixel = 0; m_call2D = 0; m_call1D = 0;
     }
     CtrSampler(Stream *stream, InstanceManager *manager) : Sampler(stream, manager) { Log(EError, "ctr sampler: not serializable"); }
@@ -41,7 +44,7 @@ public:
         ref<CtrSampler> s = new CtrSampler(getProperties());
         s->m_sampleCount = m_sampleCount; s->m_seed = m_seed; s->m_width = m_width; s->m_direct = m_direct;
         s->m_emitterSamples = m_emitterSamples; s->m_bsdfSamples = m_bsdfSamples; s->m_rrFirst = m_rrFirst;
-        s->m_ld = m_ld; s->m_ldMask = m_ldMask;
+        s->m_ld = m_ld; s->m_ldMask = m_ldMask; s->m_stratified = m_stratified; s->m_stRes = m_stRes;
         for (size_t i = 0; i < m_req1D.size(); ++i) s->request1DArray(m_req1D[i]);
         for (size_t i = 0; i < m_req2D.size(); ++i) s->request2DArray(m_req2D[i]);
         return s.get();
@@ -74,7 +77,10 @@ public:
         float f[4];
         const uint32_t call = m_call2D++;
         if (m_ld && call < 4) return ldPoint(2 * call);                                             /* ldsampler.cpp:218-224 */
-        if (call == 0) { block((uint32_t) m_sampleIndex, 0, f); return Point2(f[0], f[1]); }        /* integrator.cpp:171 */
+        if (call == 0) {                                                                            /* integrator.cpp:171 */
+            block((uint32_t) m_sampleIndex, 0, f);
+            return (m_stratified && !m_direct) ? stPoint2D(0, f[0], f[1]) : Point2(f[0], f[1]);
+        }
         if (m_direct) {
             /* direct.cpp:212-216: a single emitter sample (also drawn when emitterSamples == 0); :251-255 the same for the BSDF */
             const bool emitterCall = (m_emitterSamples <= 1) && call == 1;
@@ -84,12 +90,15 @@ public:
         /* `path`: 2D request 1 + k of the sample */
         const uint32_t k = call - 1;
         block((uint32_t) m_sampleIndex, 1 + 2 * (k >> 1), f);
-        return (k & 1u) ? Point2(f[2], f[3]) : Point2(f[0], f[1]);
+        const Point2 u = (k & 1u) ? Point2(f[2], f[3]) : Point2(f[0], f[1]);
+        return (m_stratified && call < 4) ? stPoint2D(call, u.x, u.y) : u;                          /* stratified.cpp:177-195: the first `dimension` = 4 requests */
     }
     Float next1D() {                                                                                /* path.cpp:283, Russian roulette */
         const uint32_t call = m_call1D++;
         if (m_ld && !m_direct && call < 4) return ldPoint(2 * call + 1).x;                          /* ldsampler.cpp:212-216 */
         float f[4]; block((uint32_t) m_sampleIndex, 2 + 2 * (m_rrFirst - 1 + call), f);
+        if (m_stratified && !m_direct && call < 4)                                                  /* stratified.cpp:167-175 */
+            return ((int) stCell(2 * call + 1) + f[0]) * (1 / (Float) (size_t) (m_stRes * m_stRes));
         return f[0];
     }
 
@@ -97,6 +106,22 @@ public:
     MTS_DECLARE_CLASS()
 private:
     void beginSample() { m_call2D = 0; m_call1D = 0; }
+    /* the cell sample m_sampleIndex visits in dimension dim (2D request q: 2 q, 1D request j: 2 j + 1): a keyed permutation of the sample index */
+    uint32_t stCell(uint32_t dim) const {
+        uint32_t v[4] = { m_pixel, dim, 0x5354u, m_seed };
+        for (int i = 0; i < 4; ++i) v[i] = v[i] * 1664525u + 1013904223u;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        const uint32_t n = m_stRes * m_stRes;
+        return permuteAny((uint32_t) m_sampleIndex % n, n, v[0]);
+    }
+    Point2 stPoint2D(uint32_t q, Float u1, Float u2) const {
+        const uint32_t c = stCell(2 * q);
+        const int x = (int) (c % m_stRes), y = (int) (c / m_stRes);
+        const Float inv = 1 / (Float) (int) m_stRes;
+        return Point2((x + u1) * inv, (y + u2) * inv);
+    }
     static float toFloat(uint32_t u) { uint32_t b = (u >> 9) | 0x3f800000u; float f; memcpy(&f, &b, 4); return f - 1.0f; }   /* random.cpp:632-641 */
     void block(uint32_t sample, uint32_t blk, float out[4]) const {
         /* pcg4d (Jarzynski & Olano, JCGT 9(3) 2020) over (pixel, sample, block, seed) */
@@ -163,6 +188,7 @@ private:
         return Point2(radicalInverse2Single(i, v[1]), sobol2Single(i, v[2]));
     }
     bool m_ld; uint32_t m_ldMask;
+    bool m_stratified; uint32_t m_stRes;
     uint32_t m_seed, m_pixel, m_call2D, m_call1D, m_rrFirst;
     int m_width;
     bool m_direct;

@@ -46,3 +46,14 @@ def bits(a):
 
 def rel_l2(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+
+
+def sobol_tables(width, height, dimensions=128):
+    """(matrices32, vdc, vdc_inv, log_resolution) for `default_render_params(sobol=...)` out of tests/golden/sobol_tables.npz (the reference
+    plugin's direction numbers, tests/golden/make_sobol_tables.py) for a film whose crop window is width x height (sobol.cpp:147-157)"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sobol_tables.npz"))
+    m = int(np.ceil(np.log2(max(width, height, 1))))
+    mat = np.ascontiguousarray(z["matrices32"][:dimensions * 52])
+    if m > 1:
+        return mat, np.ascontiguousarray(z["vdc"][m - 1]), np.ascontiguousarray(z["vdc_inv"][m - 1]), m
+    return mat, np.zeros(52, np.uint64), np.zeros(52, np.uint64), m

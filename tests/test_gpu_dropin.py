@@ -85,6 +85,33 @@ def check_scene(ref, name, desc):
     rs.close(); gs.close()
 
 
+def test_qmc_samplers_of_the_scene_reach_the_device(phip, ref, oracle, gauss):
+    """<sampler type="sobol"/> and <sampler type="stratified"/>.  `sobol` is deterministic, so the comparison is the strongest
+    of this file: Mitsuba's own `path` + `sobol` on the CPU and path_hip + the same <sampler> on the GPU render THE SAME IMAGE (<= 1e-3 rel L2;
+    the shim reads the direction numbers out of the loaded sobol plugin, phip_flatten.h: setSobol) -- no glue sampler anywhere.  `stratified`
+    keeps its stratification (the device's stratified stream) and agrees with the harness."""
+    import ref_scenes as RS
+    from conftest import sobol_tables
+    from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
+    if phip.phip_device_count() <= 0:
+        pytest.fail("no HIP device visible")
+    for name, desc in (("stock", stock_scene(gauss).desc()), ("zoo", RS.zoo(gauss, None).desc()), ("cornell", S.cornell_box(96, 64, gauss).desc())):
+        rs = ref.RefScene(desc); gs = Scene(desc)
+        w, h = desc.film.crop_width, desc.film.crop_height
+        p = A.default_render_params(spp=16, max_depth=6)
+        for sampler, kw in (("sobol", dict(sobol=sobol_tables(w, h))), ("stratified", dict(sampler=A.PHIP_SAMPLER_STRATIFIED))):
+            img, sec = rs.render_job(p, threads=2, plugin="path_hip", sampler=sampler)     # Mitsuba -> plugin shim -> libphip.so -> GPU
+            film = HDRFilm(gs.width, gs.height)
+            assert PathHIP(maxDepth=6).render(gs, film, 16, **kw)                           # ctypes harness -> libphip.so -> GPU
+            r = rel_l2(img, film.develop())
+            cpu, _ = rs.render_job(p, threads=4, sampler=sampler)                           # the reference's own path + its own sampler plugin
+            rc = rel_l2(img, cpu)
+            print("%s, %s: path_hip inside Mitsuba vs harness rel L2 %.3e; vs the reference's own path + %s on the CPU rel L2 %.3e" % (name, sampler, r, sampler, rc))
+            assert r < 1e-5
+            assert rc <= (1e-3 if sampler == "sobol" else 0.6), rc
+        rs.close(); gs.close()
+
+
 def test_gpu_against_the_reference_on_the_same_samples(phip, ref, oracle, gauss):
     """BASELINE.json north_star, literally: "output radiance matches the reference CPU `path` integrator on the same
     scene / seed ... <= 1e-3 relative L2 at equal spp".  The reference's own `path` (and `direct`) run on the host with the

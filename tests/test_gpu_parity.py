@@ -566,3 +566,41 @@ def test_ld_sampler_matches_oracle(gpu, phip, oracle, gauss):
     for e, b in ((1, 1), (3, 2), (0, 2), (4, 1)):
         compare_render(gpu, oracle, RS.zoo(gauss, None).desc(), 8, min_identical=0.9999, integrator=DirectHIP, render_kw=ld, emitterSamples=e, bsdfSamples=b)
     compare_render(gpu, oracle, S.cornell_box(40, 40, gauss).desc(), 16, min_identical=1.0, integrator=DirectHIP, render_kw=ld, emitterSamples=2, bsdfSamples=3)
+
+
+def test_sobol_and_stratified_samplers_match_oracle(gpu, phip, oracle, gauss):
+    """PHIP_SAMPLER_SOBOL (the reference's `sobol` plugin restated: per-pixel enumeration of the global sequence, dimensions by call order) and
+    PHIP_SAMPLER_STRATIFIED (the construction of `stratified`, addressable): per-sample radiance bit-identical to the oracle, which
+    tests/test_ref_pin.py pins to the reference's own `path` + `sobol` and to `path` on the glue sampler -- diffuse, microfacet and dielectric
+    scenes, a film that is not square (resolution = the next power of two of the larger side), progressive passes; and the error cases"""
+    import ref_scenes as RS
+    from conftest import sobol_tables
+    from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+    from mitsuba_amd._ffi import PhipError
+    for desc, spp, kw, mi in ((S.cornell_box(64, 64, gauss).desc(), 16, {}, 1.0), (S.cornell_box(48, 40, gauss).desc(), 8, dict(rrDepth=2), 1.0),
+                              (S.glass_room(64, 36, gauss, detail=0.2).desc(), 8, dict(maxDepth=12, rrDepth=3), 0.9999),
+                              (RS.zoo(gauss, None).desc(), 4, dict(maxDepth=8), 0.9999), (S.atrium(64, 36, gauss, detail=0.3).desc(), 4, dict(maxDepth=6), 0.999)):
+        w, h = desc.film.crop_width, desc.film.crop_height
+        compare_render(gpu, oracle, desc, spp, min_identical=mi, render_kw=dict(sobol=sobol_tables(w, h)), **kw)
+        compare_render(gpu, oracle, desc, spp if int(np.sqrt(spp)) ** 2 == spp else 4, min_identical=mi, render_kw=dict(sampler=A.PHIP_SAMPLER_STRATIFIED, seed=5), **kw)
+    # the Sobol' stream differs from the counter stream and from a film of another resolution (the pixel enumeration depends on it)
+    desc = S.cornell_box(32, 32, gauss).desc()
+    gs = Scene(desc); integ = PathHIP()
+    a, b, c = HDRFilm(32, 32), HDRFilm(32, 32), HDRFilm(32, 32)
+    assert integ.render(gs, a, 16, sobol=sobol_tables(32, 32)) and integ.render(gs, b, 16) and integ.render(gs, c, 16, sampler=A.PHIP_SAMPLER_STRATIFIED)
+    assert 1e-3 < rel_l2(a.storage, b.storage) < 0.2 and 1e-3 < rel_l2(c.storage, b.storage) < 0.2
+    # two passes of 8 of 16 samples = one render of 16 (the sequence index of a sample is its global number)
+    for kw in (dict(sobol=sobol_tables(32, 32)), dict(sampler=A.PHIP_SAMPLER_STRATIFIED)):
+        whole = HDRFilm(32, 32); assert integ.render(gs, whole, 16, **kw)
+        parts = HDRFilm(32, 32); assert integ.render(gs, parts, 8, sample_offset=0, sample_total=16, **kw)
+        p = integ.params(gs, 8, flags=A.PHIP_FLAG_ACCUMULATE, sample_offset=8, sample_total=16, **kw)
+        acc = parts.storage.copy(); st = A.phip_stats()
+        assert phip.phip_render(gs._h, C.byref(p), acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
+        assert rel_l2(acc, whole.storage) < 1e-6
+    # errors: a wrong resolution, no tables, rrDepth 1 (sobol.cpp:241-242 is restated for rrDepth >= 2), a stratified count that is no square, `direct`
+    with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(64, 64))
+    with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sampler=A.PHIP_SAMPLER_SOBOL)
+    with pytest.raises(PhipError): PathHIP(rrDepth=1).render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(32, 32))
+    with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 8, sampler=A.PHIP_SAMPLER_STRATIFIED)
+    with pytest.raises(PhipError): DirectHIP().render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(32, 32))
+    gs.close()

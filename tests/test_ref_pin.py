@@ -361,3 +361,61 @@ def test_scene_xml_errors_reach_the_reference_loader(ref, gauss, tmp_path):
         p.write_text(text)
         r = subprocess.run([exe, "-q", "-p", "1", "-o", str(tmp_path / ("bad%d.pfm" % i)), str(p)], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
         assert r.returncode != 0 and not os.path.exists(tmp_path / ("bad%d.pfm" % i))
+
+
+# ---- QMC samplers of SURVEY 8(f) row 4: `sobol` (the reference's stream as it stands) and `stratified` (its construction, addressable) ----
+def test_sobol_sampler_of_the_reference_is_reproduced_bit_for_bit(ref, olibm):
+    """PHIP_SAMPLER_SOBOL: the reference's OWN `path` integrator with its OWN `sobol` sampler plugin (src/samplers/sobol.cpp: Gruenschloss'
+    per-pixel enumeration of the global Sobol' sequence, dimensions consumed in call order, the quirk that no 2D request is served from
+    dimension 4) against the restatement fed with the plugin's direction numbers as data (ref_ffi.sobol_tables reads them out of the loaded
+    sobol.so): every sample bit-identical -- diffuse, two-sided microfacet and dielectric scenes (non-smooth vertices make one request)."""
+    gauss_libm = olibm.gaussian_filter(0.5, libm=True)
+    for name, build, md, spp in (("cornell", lambda: S.cornell_box(24, 20, gauss_libm), 8, 4), ("zoo", lambda: RS.zoo(gauss_libm, None), 8, 4),
+                                 ("glass", lambda: RS.glass(gauss_libm, None), 12, 2)):
+        desc = build().desc()
+        p = A.default_render_params(spp=spp, max_depth=md, block_size=256, sobol=ref.sobol_tables(desc.film.crop_width, desc.film.crop_height))
+        rs = ref.RefScene(desc)
+        _, smp = rs.render(p, sampler="sobol")
+        osc = olibm.OracleScene(desc, libm=True)
+        _, osmp, _ = osc.render(p, want_samples=True)
+        # the plugin's `scramble` (a frame number, run through TEA: sobol.cpp:92-102): the driver passes `seed` as that property
+        p.seed = 7; p.sobol_scramble = ref.sobol_scramble(7)
+        _, smp7 = rs.render(p, sampler="sobol")
+        _, osmp7, _ = osc.render(p, want_samples=True)
+        assert (smp7.view(np.uint32) == osmp7.view(np.uint32)).all() and not np.array_equal(smp7, smp), name
+        rs.close(); osc.close()
+        assert smp[..., :3].mean() > 0.01
+        # the committed fixture (the GPU box has no reference plugin) holds the same numbers
+        from conftest import sobol_tables
+        for a, b in zip(sobol_tables(desc.film.crop_width, desc.film.crop_height), ref.sobol_tables(desc.film.crop_width, desc.film.crop_height, 128)):
+            assert np.array_equal(a, b)
+        assert (smp.view(np.uint32) == osmp.view(np.uint32)).all(), (name, float((smp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean()))
+
+
+def test_stratified_construction_on_the_reference(ref, olibm):
+    """PHIP_SAMPLER_STRATIFIED: the reference's `path` consuming the addressable stratified construction through the glue sampler
+    (ref_glue/ctr_sampler.cpp, `stratified` mode: it calls nothing of the oracle) equals the restatement sample for sample; and the
+    construction stratifies like the reference's `stratified` plugin: the Cornell box converges like the reference's own stratified render (mean absolute error at 16 spp within 25 %)."""
+    gauss_libm = olibm.gaussian_filter(0.5, libm=True)
+    desc = S.cornell_box(24, 20, gauss_libm).desc()
+    for spp in (4, 16):
+        p = A.default_render_params(spp=spp, max_depth=8, block_size=256); p.sampler = A.PHIP_SAMPLER_STRATIFIED
+        rs = ref.RefScene(desc)
+        _, smp = rs.render(p, sampler="ctr")
+        osc = olibm.OracleScene(desc, libm=True)
+        _, osmp, _ = osc.render(p, want_samples=True)
+        assert (smp.view(np.uint32) == osmp.view(np.uint32)).all()
+        rs.close(); osc.close()
+    # convergence: error against a high-spp reference image, ours vs the reference's own `stratified` and `independent`
+    desc = S.cornell_box(32, 32, gauss_libm).desc()
+    rs = ref.RefScene(desc)
+    truth, _ = rs.render_job(A.default_render_params(spp=4096, max_depth=4), threads=os.cpu_count(), sampler="independent")
+    def mse(img): return float(np.abs(img - truth).mean())       # mean ABSOLUTE error: the squared error is dominated by a few pixels
+    p16 = A.default_render_params(spp=16, max_depth=4)
+    own, _ = rs.render_job(p16, threads=2, sampler="stratified")
+    ind, _ = rs.render_job(p16, threads=2, sampler="independent")
+    ps = A.default_render_params(spp=16, max_depth=4); ps.sampler = A.PHIP_SAMPLER_STRATIFIED
+    ours, _ = rs.render_job(ps, threads=2, sampler="ctr")
+    rs.close()
+    print("mean abs error at 16 spp: stratified construction %.3e, the reference's stratified %.3e, independent %.3e" % (mse(ours), mse(own), mse(ind)))
+    assert mse(ours) < 1.25 * mse(own) and mse(ours) < mse(ind)
