@@ -36,7 +36,7 @@ def _sources():
 # phip_mega.hip is compiled without MachineLICM: hoisting the double-precision polynomial constants of phip_fmath.h (two VGPRs each,
 # 64-bit literals cannot be encoded) out of k_mega's persistent loop cost ~40 VGPRs -- 168 instead of 128, i.e. 3 instead of 4 waves per SIMD
 UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", ["-mllvm", "-disable-machine-licm"], "phip_mega.o")] + \
-        [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f], "phip_shade%d.o" % f) for f in (0, 1, 2, 3, 8)]
+        [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f], "phip_shade%d.o" % f) for f in (0, 1, 2, 3, 8, 11)]
 
 
 def source_id():

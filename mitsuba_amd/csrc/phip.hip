@@ -751,11 +751,12 @@ static SceneDev *replicateScene(phip_scene *sc, int device) {
 
 static void phipLaunchShade(int feat, bool strictNormals, int materialMask, dim3 grid, hipStream_t stream,
                             const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
-    switch (feat & 3) {
+    switch (feat & 11) {
         case 0: phipLaunchShadeF0(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         case 1: phipLaunchShadeF1(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         case 2: phipLaunchShadeF2(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         case 8: phipLaunchShadeF8(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
+        case 11: phipLaunchShadeF11(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         default: phipLaunchShadeF3(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
     }
 }
@@ -819,7 +820,6 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
         const char *name = p->sampler == PHIP_SAMPLER_SOBOL ? "PHIP_SAMPLER_SOBOL" : "PHIP_SAMPLER_STRATIFIED";
         if (direct) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
         const DevScene &D0 = sc->devs[0]->dev;
-        if (D0.envEmitter >= 0 || sc->hasTextures) throw std::invalid_argument(std::string(name) + ": not built for scenes with an environment emitter or bitmap textures");
         if (p->sampler == PHIP_SAMPLER_SOBOL) {
             if (!p->sobol_matrices || p->sobol_dimensions < 8) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_matrices / sobol_dimensions (the reference plugin's direction numbers) are required");
             if (p->sobol_log_resolution > 26) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_log_resolution out of range");
@@ -1104,7 +1104,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipStreamSynchronize(stream));
             const auto tLoop0 = clk::now();
             bool done = rc.totalIds == 0;
-            const int feat = qmc ? 8 : ((D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0));     /* environment emitter, bitmap textures; 8: the QMC samplers */
+            /* environment emitter, bitmap textures; 8: the QMC samplers (two builds: the plain one, and one with both other features) */
+            const int feat0 = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0), feat = qmc ? (feat0 ? 11 : 8) : feat0;
             while (!done) {
                 const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
                 rc.countAlive = check ? 1 : 0;

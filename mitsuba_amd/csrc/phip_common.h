@@ -46,7 +46,7 @@ using namespace pt;
                              const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);                      \
     void phipLaunchShadeDirectF##n(int materialMask, dim3 grid, hipStream_t stream,                                        \
                                    const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);
-PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3) PHIP_DECLARE_SHADE(8)
+PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3) PHIP_DECLARE_SHADE(8) PHIP_DECLARE_SHADE(11)
 #undef PHIP_DECLARE_SHADE
 /* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */
 int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, bool flat, size_t ldsBytes);

@@ -1,7 +1,8 @@
 /*
  * phip_shade.hip -- the shading kernels of the wavefront path: k_shade<materials, strictNormals, features> (k_shade.h) and
  * k_shade_direct<materials, features> (k_shade_direct.h), 40 instantiations.  Compiled once per feature set
- * (-DSHADE_FEAT=0..3: bit 0 = environment emitter, bit 1 = bitmap textures) so that the four objects build in parallel;
+ * (-DSHADE_FEAT=0..3: bit 0 = environment emitter, bit 1 = bitmap textures; 8 and 11: bit 3 = the QMC samplers, without / with both other features)
+ * so that the objects build in parallel;
  * phip.hip dispatches on the scene's feature set (phipLaunchShade / phipLaunchShadeDirect).  See phip_common.h.
  */
 #include "phip_common.h"
@@ -9,7 +10,7 @@
 #include "k_shade_direct.h"
 
 #ifndef SHADE_FEAT
-#error "compile with -DSHADE_FEAT=0..3 or 8"
+#error "compile with -DSHADE_FEAT=0..3, 8 or 11"
 #endif
 #define SHADE_CAT2(a, b) a##b
 #define SHADE_CAT(a, b) SHADE_CAT2(a, b)
@@ -33,7 +34,7 @@ void SHADE_CAT(phipLaunchShadeF, SHADE_FEAT)(bool strictNormals, int materialMas
 
 void SHADE_CAT(phipLaunchShadeDirectF, SHADE_FEAT)(int materialMask, dim3 grid, hipStream_t stream,
                                                    const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
-#if SHADE_FEAT == 8
+#if SHADE_FEAT >= 8
     throw std::runtime_error("the QMC samplers are built for the `path` integrator only");      /* (validateParams refuses it before) */
 #else
     /* `direct`: leaf BSDF models = diffuse only / all, strictNormals at run time */

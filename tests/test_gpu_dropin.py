@@ -264,7 +264,9 @@ def test_baseline_configs_at_full_size_against_the_reference(phip, ref, gauss, t
     reference needs about a minute for that on 256 threads, eight for the full count: PHIP_FULLSIZE_C4=1 renders all 512; round 2's
     one-off run of it: 8.2e-5)."""
     keys = ["C2", "C3", "C4res"] + (["C4full"] if os.environ.get("PHIP_FULLSIZE_C4") else [])
-    stock = _fullsize(tmp_path, keys, preload=False)
+    stock = _fullsize(tmp_path, keys + ["C2sobol"], preload=False)
+    # C2 with <sampler type="sobol"/>: the reference's own sampler plugin on the CPU side, its direction numbers on the GPU side -- no parity
+    # sampler anywhere, the image the reference renders for that scene file
     for name, r in stock.items():
         print("%s vs Mitsuba 0.6 (glibc): rel L2 %.3e, %.4f %% of the pixels differ by more than 1e-3; GPU %.3f s, reference %.1f s on %d threads"
               % (name, r["rel_l2"], 100 * r["pixels_differing_by_more_than_1e-3"], r["gpu_seconds"], r["reference_seconds"], r["reference_threads"]))

@@ -3,6 +3,7 @@ seeded inputs.  Bar: per-sample radiance bit-identical for (almost) every sample
 L2 of the developed image <= 1e-3 (BASELINE.json north_star tolerance)."""
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 
@@ -583,6 +584,13 @@ def test_sobol_and_stratified_samplers_match_oracle(gpu, phip, oracle, gauss):
         w, h = desc.film.crop_width, desc.film.crop_height
         compare_render(gpu, oracle, desc, spp, min_identical=mi, render_kw=dict(sobol=sobol_tables(w, h)), **kw)
         compare_render(gpu, oracle, desc, spp if int(np.sqrt(spp)) ** 2 == spp else 4, min_identical=mi, render_kw=dict(sampler=A.PHIP_SAMPLER_STRATIFIED, seed=5), **kw)
+    # scenes with an environment emitter / bitmap textures (the QMC build of the shading kernel with both features)
+    from test_golden import _golden_mip, G
+    fixture = np.load(os.path.join(G, "ref_renders.npz"))
+    for build in (RS.envmap, RS.textures, RS.const_env):
+        desc = build(gauss, _golden_mip(fixture, build.__name__)).desc()
+        compare_render(gpu, oracle, desc, 4, min_identical=0.999, render_kw=dict(sobol=sobol_tables(desc.film.crop_width, desc.film.crop_height)), maxDepth=6)
+        compare_render(gpu, oracle, desc, 4, min_identical=0.999, render_kw=dict(sampler=A.PHIP_SAMPLER_STRATIFIED), maxDepth=6)
     # the Sobol' stream differs from the counter stream and from a film of another resolution (the pixel enumeration depends on it)
     desc = S.cornell_box(32, 32, gauss).desc()
     gs = Scene(desc); integ = PathHIP()

@@ -371,7 +371,8 @@ def test_sobol_sampler_of_the_reference_is_reproduced_bit_for_bit(ref, olibm):
     sobol.so): every sample bit-identical -- diffuse, two-sided microfacet and dielectric scenes (non-smooth vertices make one request)."""
     gauss_libm = olibm.gaussian_filter(0.5, libm=True)
     for name, build, md, spp in (("cornell", lambda: S.cornell_box(24, 20, gauss_libm), 8, 4), ("zoo", lambda: RS.zoo(gauss_libm, None), 8, 4),
-                                 ("glass", lambda: RS.glass(gauss_libm, None), 12, 2)):
+                                 ("glass", lambda: RS.glass(gauss_libm, None), 12, 2), ("envmap", lambda: RS.envmap(gauss_libm, live_mip(ref)), 6, 4),
+                                 ("textures", lambda: RS.textures(gauss_libm, live_mip(ref)), 6, 4), ("const_env", lambda: RS.const_env(gauss_libm, live_mip(ref)), 6, 4)):
         desc = build().desc()
         p = A.default_render_params(spp=spp, max_depth=md, block_size=256, sobol=ref.sobol_tables(desc.film.crop_width, desc.film.crop_height))
         rs = ref.RefScene(desc)

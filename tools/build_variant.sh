@@ -11,7 +11,7 @@ PROD_MEGA="-mllvm -disable-machine-licm"
 objs=""
 if [ -n "$MAIN_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F $MAIN_FLAGS "$@" -c $c/phip.hip -o $b/phip_$tag.o & objs="$objs $b/phip_$tag.o"; else objs="$objs $b/phip.o"; fi
 if [ -n "$MEGA_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F ${MEGA_FLAGS:-$PROD_MEGA} "$@" -c $c/phip_mega.hip -o $b/phip_mega_$tag.o & objs="$objs $b/phip_mega_$tag.o"; else objs="$objs $b/phip_mega.o"; fi
-for f in 0 1 2 3 8; do
+for f in 0 1 2 3 8 11; do
   if [ -n "$SHADE_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F $SHADE_FLAGS "$@" -DSHADE_FEAT=$f -c $c/phip_shade.hip -o $b/phip_shade${f}_$tag.o & objs="$objs $b/phip_shade${f}_$tag.o"; else objs="$objs $b/phip_shade$f.o"; fi
 done
 wait

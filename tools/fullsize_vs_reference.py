@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs C2 / C3 / C4 at full size: path_hip on the GPU against Mitsuba 0.6 itself (oracle/_ref, all host cores,
 parity-stream sampler) -- developed images, relative L2.
-    python tools/fullsize_vs_reference.py out.json [C2|C3|C4-class|C4res|C4full]          (on a GPU box)
+    python tools/fullsize_vs_reference.py out.json [C2|C2sobol|C3|C4-class|C4res|C4full]          (on a GPU box)
     LD_PRELOAD=$PWD/oracle/_build/libcrm.so python tools/fullsize_vs_reference.py ...  the same against the reference with the
         correctly rounded transcendentals of include/phip_fmath.h in place of glibc's (oracle/ref_glue/crlibm_shim.cpp)"""
 import json
@@ -20,12 +20,15 @@ gauss = _ffi.gaussian_filter(0.5)
 out = {}
 from oracle import oracle_ffi as O                             # noqa: E402
 for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1024, 1024, 256, -1),
+                                   ("C2sobol cornell 1024x1024x256, the reference's own sobol sampler on both sides", S.cornell_box, 1024, 1024, 256, -1),
                                    ("C3 atrium 1920x1080x64", S.atrium, 1920, 1080, 64, 8),
                                    ("C4-class glass room 960x540x64 md16", S.glass_room, 960, 540, 64, 16),
                                    ("C4res glass room 1920x1080x64 md16", S.glass_room, 1920, 1080, 64, 16),
                                    ("C4full glass room 1920x1080x512 md16", S.glass_room, 1920, 1080, 512, 16)):
     if len(sys.argv) > 2 and not any(k in name for k in sys.argv[2:]):
         continue
+    if "C2sobol" in name and "C2sobol" not in sys.argv[2:]:
+        continue                                              # (no glue sampler at all: <sampler type="sobol"/> is deterministic; only on request)
     if "C4res" in name and "C4res" not in sys.argv[2:]:
         continue                                              # (C4's frame and depth at 1/8 of its samples per pixel: the driver-run suite asks for it)
     if "C4full" in name and "C4full" not in sys.argv[2:]:
@@ -34,12 +37,13 @@ for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1
     gs = Scene(desc)
     film = HDRFilm(w, h)
     integ = PathHIP(maxDepth=md)
-    integ.render(gs, film, spp)                               # warm-up
+    kw = dict(sobol=R.sobol_tables(w, h)) if "C2sobol" in name else {}      # the plugin's direction numbers, read out of the loaded sobol.so
+    integ.render(gs, film, spp, **kw)                         # warm-up
     film = HDRFilm(w, h)
-    t = time.time(); assert integ.render(gs, film, spp); tg = time.time() - t
+    t = time.time(); assert integ.render(gs, film, spp, **kw); tg = time.time() - t
     g = film.develop()
     rs = R.RefScene(desc)
-    cpu, sec = rs.render_job(A.default_render_params(spp=spp, max_depth=md), sampler="ctr")
+    cpu, sec = rs.render_job(A.default_render_params(spp=spp, max_depth=md), sampler="sobol" if "C2sobol" in name else "ctr")
     rel = float(np.linalg.norm(g - cpu) / np.linalg.norm(cpu))
     big = float((np.abs(g - cpu) > 1e-3 * np.maximum(1.0, np.abs(cpu))).any(-1).mean())
     out[name] = {"gpu_seconds": round(tg, 3), "reference_seconds": round(sec, 1), "reference_threads": os.cpu_count(), "rel_l2": rel,
