@@ -238,6 +238,32 @@ void ref_add_shape_file(const char *plugin, const char *filename, uint32_t mater
     g_fileShapes.push_back(f);
 }
 
+/* writes shape `si` of a scene description as a .serialized mesh file -- by the reference's own TriMesh::serialize (trimesh.cpp:1131-1180: header, zlib
+   stream, version 4), so that the reference's `serialized` loader plugin (src/shapes/serialized.cpp) has a file of its own format to read */
+int ref_write_serialized(const phip_scene_desc *dp, uint32_t si, const char *path) {
+    try {
+        const phip_scene_desc &d = *dp;
+        if (si >= d.n_shapes) throw std::runtime_error("ref_write_serialized: no such shape");
+        const phip_shape &s = d.shapes[si];
+        const bool hasN = s.has_normals && d.normals, hasUV = s.has_texcoords && d.texcoords;
+        ref<TriMesh> mesh = new TriMesh(formatString("shape%u", si), s.n_triangles, s.n_vertices, hasN, hasUV, false, false, !hasN);
+        for (uint32_t v = 0; v < s.n_vertices; ++v) {
+            const float *p = d.positions + 3 * (size_t) (s.first_vertex + v);
+            mesh->getVertexPositions()[v] = Point(p[0], p[1], p[2]);
+            if (hasN) { const float *n = d.normals + 3 * (size_t) (s.first_vertex + v); mesh->getVertexNormals()[v] = Normal(n[0], n[1], n[2]); }
+            if (hasUV) { const float *t = d.texcoords + 2 * (size_t) (s.first_vertex + v); mesh->getVertexTexcoords()[v] = Point2(t[0], t[1]); }
+        }
+        for (uint32_t t = 0; t < s.n_triangles; ++t)
+            for (int k = 0; k < 3; ++k)
+                mesh->getTriangles()[t].idx[k] = d.indices[3 * (size_t) (s.first_triangle + t) + k] - s.first_vertex;
+        ref<FileStream> fsOut = new FileStream(fs::path(path), FileStream::ETruncReadWrite);
+        fsOut->setByteOrder(Stream::ELittleEndian);
+        mesh->serialize(fsOut);
+        fsOut->close();
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
 /* stops the Scheduler's worker threads (they would keep the process alive at exit) */
 void ref_shutdown(void) {
     if (!g_init) return;

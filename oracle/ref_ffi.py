@@ -73,6 +73,7 @@ def lib():
     L.ref_set_sampler.argtypes = [C.c_int]
     L.ref_set_analytic_rectangles.argtypes = [C.c_int]
     L.ref_add_shape_file.argtypes = [C.c_char_p, C.c_char_p, u32, fp]
+    L.ref_write_serialized.argtypes = [C.POINTER(A.phip_scene_desc), u32, C.c_char_p]
     L.ref_mip_build.restype = C.c_void_p
     L.ref_mip_build.argtypes = [C.c_int, fp, u32, u32, u32, u32, u32, C.c_float]
     L.ref_mip_levels.argtypes = [C.c_void_p]
@@ -255,3 +256,9 @@ def sobol_scramble(frame):
         v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C) ^ (v1 + s) ^ ((v1 >> 5) + 0xC8013EA4))) & M
         v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D) ^ (v0 + s) ^ ((v0 >> 5) + 0x7E95761E))) & M
     return (v1 << 32) + v0
+
+
+def write_serialized(desc, shape, path):
+    """shape `shape` of a scene description as a .serialized mesh file, written by the reference's own TriMesh::serialize"""
+    if lib().ref_write_serialized(C.byref(desc), int(shape), path.encode()) != 0:
+        raise RuntimeError("ref_write_serialized: " + lib().ref_last_error().decode())

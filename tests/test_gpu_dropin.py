@@ -322,3 +322,17 @@ def test_path_hip_in_a_scene_file_through_the_reference_cli(phip, ref, gauss, tm
             dm = abs(cli.mean() - cpu.mean()) / cpu.mean()
             print("    vs <integrator type=\"%s\"/> on the CPU: mean differs by %.2f %%, rel L2 %.2f" % (plugin.replace("_hip", ""), 100 * dm, rel_l2(cli, cpu)))
             assert dm < 0.08 and rel_l2(cli, cpu) < 0.6
+    # the scene file as a user of the reference would write it for a QMC render: meshes in Mitsuba's own .serialized format (written by the
+    # reference's TriMesh::serialize, read by its `serialized` plugin), <sampler type="sobol"/> -- path_hip and the reference's path render
+    # the same image from the same file, nothing of the test harness in between
+    desc = stock_scene(gauss).desc()
+    imgs = {}
+    for plugin in ("path_hip", "path"):
+        out = tmp_path / ("sobol_" + plugin)
+        xml = X.write_scene_xml(desc, str(out), integrator=plugin, integrator_props=dict(maxDepth=6, rrDepth=5), sampler="sobol", spp=16, mesh_format="serialized")
+        r = subprocess.run([exe, "-q", "-p", "4", "-o", str(out / "img.pfm"), xml], capture_output=True, text=True, cwd=str(out), timeout=900)
+        assert r.returncode == 0 and os.path.exists(out / "img.pfm"), r.stdout[-3000:] + r.stderr[-3000:]
+        imgs[plugin] = X.read_pfm(str(out / "img.pfm"))
+    rr = rel_l2(imgs["path_hip"], imgs["path"])
+    print("scene.xml with .serialized meshes and <sampler type=\"sobol\"/>: mitsuba with path_hip vs mitsuba with path: rel L2 %.3e" % rr)
+    assert rr <= 1e-3

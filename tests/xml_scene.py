@@ -40,7 +40,7 @@ def _bsdf(desc, i, indent):
     raise ValueError("material type %d" % m.type)
 
 
-def write_scene_xml(desc, outdir, integrator="path", integrator_props=None, sampler="independent", spp=16, sampler_props=None, stddev=0.5):
+def write_scene_xml(desc, outdir, integrator="path", integrator_props=None, sampler="independent", spp=16, sampler_props=None, stddev=0.5, mesh_format="obj"):
     """-> path of scene.xml.  Bitmap textures / environment maps are not written (the pin scenes that use them go through ref_driver)."""
     os.makedirs(outdir, exist_ok=True)
     if desc.n_textures or any(desc.emitters[i].type == A.PHIP_EMITTER_ENVMAP for i in range(desc.n_emitters)):
@@ -76,6 +76,20 @@ def write_scene_xml(desc, outdir, integrator="path", integrator_props=None, samp
             x.append('  <emitter type="constant"><spectrum name="radiance" value="%s"/><float name="samplingWeight" value="%s"/></emitter>\n' % (_spec(e.radiance), _f(e.sampling_weight)))
     for si in range(desc.n_shapes):
         s = desc.shapes[si]
+        if mesh_format == "serialized":
+            # Mitsuba's own mesh format, written by the reference's TriMesh::serialize and read back by its `serialized` loader plugin
+            from oracle import ref_ffi
+            name = "shape%d.serialized" % si
+            ref_ffi.write_serialized(desc, si, os.path.join(outdir, name))
+            x.append('  <shape type="serialized"><string name="filename" value="%s"/>' % name)
+            if not (s.has_normals and N is not None):
+                x.append('<boolean name="faceNormals" value="true"/>')
+            x.append('\n' + _bsdf(desc, s.material, 4))
+            if s.emitter >= 0:
+                e = desc.emitters[s.emitter]
+                x.append('    <emitter type="area"><spectrum name="radiance" value="%s"/><float name="samplingWeight" value="%s"/></emitter>\n' % (_spec(e.radiance), _f(e.sampling_weight)))
+            x.append('  </shape>\n')
+            continue
         name = "shape%d.obj" % si
         with open(os.path.join(outdir, name), "w") as o:
             v0 = s.first_vertex
