@@ -223,6 +223,15 @@ typedef enum phip_sampler_kind {
                                 requests are independent -- with the order a keyed permutation (as PHIP_SAMPLER_LD) and the jitter the
                                 counter stream's number for that request, instead of the worker's sequential Random.  The sample count of
                                 the render must be a perfect square (stratified.cpp:64-72 rounds it up). */
+    , PHIP_SAMPLER_HALTON = 4     /* (ABI 6, `path` only) the reference's `halton` sampler as it stands (src/samplers/halton.cpp): sample k of pixel (x, y) is
+                                point offset(x mod 128, y mod 128) + stride * k of the Halton sequence (Gruenschloss' enumeration over bases 2 and 3,
+                                halton.cpp:244-296: stride = 2^a 3^b, the offset by the Chinese remainder theorem), dimension d is the (scrambled) radical
+                                inverse in the d-th prime (qmc.cpp:141-166); dimensions are consumed exactly as by PHIP_SAMPLER_SOBOL (the same bookkeeping,
+                                incl. the 2D request that skips dimension 4).  The primes and the digit permutations (Faure's by default, `scramble` = -1;
+                                none for 0; pseudorandom ones otherwise) are DATA: phip_render_params.qmc_*. */
+    , PHIP_SAMPLER_HAMMERSLEY = 5 /* (ABI 6, `path` only) the reference's `hammersley` sampler (src/samplers/hammersley.cpp): dimension 0 is index * 1 / (sampleCount
+                                resX resY), dimension d > 0 the radical inverse in the (d-1)-th prime, index = offset(x mod 128, y mod 128) + resY * k
+                                (hammersley.cpp:181-222); the rest as PHIP_SAMPLER_HALTON.  The sample count is that of the whole render (`sample_total`). */
 } phip_sampler_kind;
 #define PHIP_SOBOL_MATRIX_SIZE 52    /* words per dimension of sobol::Matrices (sobolseq.h:30) */
 
@@ -282,6 +291,13 @@ typedef struct phip_render_params {
     uint32_t sobol_dimensions;
     uint32_t sobol_log_resolution;
     uint64_t sobol_scramble;
+    /* PHIP_SAMPLER_HALTON / _HAMMERSLEY (ABI 6): host pointers, read during the call.  qmc_primes = the first qmc_dimensions entries of the
+       reference's primeTable (qmc.cpp:27-81); qmc_permutations = the digit permutations of its PermutationStorage (src/samplers/faure.cpp)
+       for those bases, concatenated -- the one of dimension d starts at primes[0] + ... + primes[d - 1] -- or NULL for `scramble` = 0. */
+    const uint32_t *qmc_primes;
+    const uint16_t *qmc_permutations;
+    uint32_t qmc_dimensions;
+    uint32_t qmc_reserved;
 } phip_render_params;
 
 #define PHIP_FLAG_KERNEL_TIMING 1   /* bracket the kernels with hipEvents, fill phip_stats.*_ms */

@@ -15,6 +15,8 @@ PHIP_SAMPLER_CTR = 0
 PHIP_SAMPLER_LD = 1
 PHIP_SAMPLER_SOBOL = 2
 PHIP_SAMPLER_STRATIFIED = 3
+PHIP_SAMPLER_HALTON = 4
+PHIP_SAMPLER_HAMMERSLEY = 5
 PHIP_SOBOL_MATRIX_SIZE = 52
 PHIP_INTEGRATOR_PATH, PHIP_INTEGRATOR_DIRECT = 0, 1
 PHIP_FLAG_KERNEL_TIMING = 1
@@ -111,7 +113,8 @@ class phip_render_params(C.Structure):
                 ("sample_offset", C.c_int32), ("sample_total", C.c_int32),
                 ("progress", PROGRESS_FN), ("progress_user", C.c_void_p),
                 ("sobol_matrices", C.POINTER(C.c_uint32)), ("sobol_vdc", C.POINTER(C.c_uint64)), ("sobol_vdc_inv", C.POINTER(C.c_uint64)),
-                ("sobol_dimensions", C.c_uint32), ("sobol_log_resolution", C.c_uint32), ("sobol_scramble", C.c_uint64)]
+                ("sobol_dimensions", C.c_uint32), ("sobol_log_resolution", C.c_uint32), ("sobol_scramble", C.c_uint64),
+                ("qmc_primes", C.POINTER(C.c_uint32)), ("qmc_permutations", C.POINTER(C.c_uint16)), ("qmc_dimensions", C.c_uint32), ("qmc_reserved", C.c_uint32)]
 
 
 class phip_stats(C.Structure):
@@ -180,6 +183,12 @@ def default_render_params(**kw):
         p.sobol_vdc = vdc.ctypes.data_as(C.POINTER(C.c_uint64)); p.sobol_vdc_inv = inv.ctypes.data_as(C.POINTER(C.c_uint64))
         p.sobol_dimensions = len(matrices) // PHIP_SOBOL_MATRIX_SIZE; p.sobol_log_resolution = m; p.sobol_scramble = 0
         p._keep_sobol = sobol                  # keep the arrays alive as long as the struct
+    rinv = kw.pop("qmc", None)         # (primes, permutations or None): numpy arrays out of the reference (oracle/ref_ffi.qmc_tables); the caller sets sampler=
+    if rinv is not None:
+        primes, perm = rinv
+        p.qmc_primes = primes.ctypes.data_as(C.POINTER(C.c_uint32)); p.qmc_dimensions = len(primes)
+        p.qmc_permutations = perm.ctypes.data_as(C.POINTER(C.c_uint16)) if perm is not None else None
+        p._keep_qmc = rinv
     progress = kw.pop("progress", None)
     if progress is not None:
         p.progress = progress if isinstance(progress, PROGRESS_FN) else PROGRESS_FN(progress)

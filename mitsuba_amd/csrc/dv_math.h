@@ -351,6 +351,92 @@ DV void sobolCameraSample(const SobolTab &T, uint32_t sampleIndex, uint32_t px, 
     } else { jx = sobolSample(T, idx, 0u); jy = sobolSample(T, idx, 1u); }
 }
 
+/* ---- PHIP_SAMPLER_HALTON / _HAMMERSLEY: the reference's radical-inverse samplers as they stand (src/samplers/halton.cpp, hammersley.cpp).  The
+ *      primes and the digit permutations (PermutationStorage, src/samplers/faure.cpp) are DATA handed through the ABI (phip_render_params.qmc_*);
+ *      the partition of the sequence over the pixels (setFilmResolution) is computed by the host (phip.hip: setupRadicalInverse). ---- */
+#define RINV_MAX_RESOLUTION 128u        /* halton.cpp:29, hammersley.cpp:29: pixel positions enter modulo this */
+struct RinvTab {
+    const uint32_t *primes;             /* primeTable[0 .. dims) */
+    const uint16_t *perm;               /* the permutations of those bases, concatenated; NULL: no scrambling */
+    const uint32_t *permOffset;         /* start of the permutation of dimension d */
+    uint32_t dims;
+    uint32_t hammersley;                /* 0: halton, 1: hammersley */
+    uint32_t stride;                    /* halton: 2^expX 3^expY (<= 128 * 243); hammersley: resY */
+    uint32_t powX, powY, expX, expY;    /* halton: m_primePowers, m_primeExponents; hammersley: resX, resY, -, log2 resY */
+    uint32_t multInvX, multInvY;        /* halton: m_multInverse */
+    uint32_t invPerm2, invPerm3;        /* inverse permutations of bases 2 and 3, two bits per digit (identity without scrambling) */
+    uint32_t sampleCount;               /* hammersley: m_sampleCount (of the whole render) */
+    float factor;                       /* hammersley: m_factor */
+};
+/* inverseScrambledRadicalInverse, halton.cpp:198-211 / hammersley.cpp:165-178 */
+DV uint32_t rinvInverse(uint32_t base, uint32_t inverse, uint32_t digits, uint32_t invPerm) {
+    uint32_t index = 0;
+    for (; digits; --digits) {
+        const uint32_t digit = (invPerm >> (2u * (inverse % base))) & 3u;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+/* the index of sample k of pixel (px, py): generate() + next*D, halton.cpp:272-296,352-372 / hammersley.cpp:206-222,252-268 */
+DV uint64_t rinvSampleIndex(const RinvTab &T, uint32_t k, uint32_t px, uint32_t py) {
+    const uint32_t x = px % RINV_MAX_RESOLUTION, y = py % RINV_MAX_RESOLUTION;
+    uint32_t offset = 0;
+    if (T.stride > 1u) {
+        if (T.hammersley)
+            offset = x * T.powY * T.sampleCount + rinvInverse(2u, y, T.expY, T.invPerm2);
+        else {
+            /* (each term is below 128 * 243 * 243 < 2^23: the 64-bit arithmetic of the reference fits 32 bits) */
+            offset = rinvInverse(2u, x, T.expX, T.invPerm2) * (T.stride / T.powX) * T.multInvX
+                   + rinvInverse(3u, y, T.expY, T.invPerm3) * (T.stride / T.powY) * T.multInvY;
+            offset %= T.stride;
+        }
+    }
+    return (uint64_t) offset + (uint64_t) T.stride * (uint64_t) k;
+}
+/* radicalInverseFast / scrambledRadicalInverseFast, qmc.cpp:141-166,169-1198,1201-2230 (the macros RINV / SCRAMBLED_RINV: integer digits, one
+   float factor): bit for bit */
+DV float rinvRadicalInverse(const RinvTab &T, uint32_t baseIndex, uint64_t index) {
+    const uint32_t base = T.primes[baseIndex];
+    const float radical = 1.0f / (float) (int) base;
+    const uint16_t *perm = T.perm ? T.perm + T.permOffset[baseIndex] : nullptr;
+    uint64_t value = 0;
+    float factor = 1.0f;
+    if (index >> 32) {                                       /* (only with more than 2^32 / stride samples per pixel) */
+        while (index >> 32) {
+            const uint64_t next = index / base, digit = index - next * base;
+            value = value * base + (perm ? (uint64_t) perm[digit] : digit);
+            factor *= radical;
+            index = next;
+        }
+    }
+    uint32_t i32 = (uint32_t) index;
+    while (i32) {
+        const uint32_t next = i32 / base, digit = i32 - next * base;
+        value = value * base + (perm ? (uint64_t) perm[digit] : (uint64_t) digit);
+        factor *= radical;
+        i32 = next;
+    }
+    float inverse;
+    if (perm) inverse = factor * ((float) value + radical * (float) (int) perm[0] / (1.0f - radical));
+    else inverse = (float) value * factor;
+    return 0.99999994f < inverse ? 0.99999994f : inverse;    /* std::min(inverse, ONE_MINUS_EPS) */
+}
+/* dimension `dimension` of point `index`: nextFloat, halton.cpp:343-350 / hammersley.cpp:235-243 */
+DV float rinvSample(const RinvTab &T, uint64_t index, uint32_t dimension) {
+    if (T.hammersley) {
+        if (dimension == 0u) return (float) index * T.factor;
+        return rinvRadicalInverse(T, dimension - 1u, index);
+    }
+    return rinvRadicalInverse(T, dimension, index);
+}
+/* the camera sample: next2D at dimension 0, halton.cpp:375-378 / hammersley.cpp:271-274 */
+DV void rinvCameraSample(const RinvTab &T, uint32_t sampleIndex, uint32_t px, uint32_t py, float &jx, float &jy) {
+    const uint64_t idx = rinvSampleIndex(T, sampleIndex, px, py);
+    jx = rinvSample(T, idx, 0u) * (float) (int) T.powX - (float) (int) (px % RINV_MAX_RESOLUTION);
+    jy = rinvSample(T, idx, 1u) * (float) (int) T.powY - (float) (int) (py % RINV_MAX_RESOLUTION);
+}
+
 /* ---- PHIP_SAMPLER_STRATIFIED: the construction of `stratified` (src/samplers/stratified.cpp:147-200) made addressable: the cell a sample
  *      visits in dimension `dim` (2D request q: 2 q, 1D request j: 2 j + 1) is a keyed permutation of its index (stratified.cpp:147-158 shuffles with
  *      the worker's Random), the jitter inside the cell is the counter stream's number for that request. ---- */

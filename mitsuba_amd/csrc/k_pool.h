@@ -94,6 +94,7 @@ struct RenderConst {
     uint32_t seed;
     uint32_t sampler, ldMask;         /* phip_sampler_kind; PHIP_SAMPLER_LD: sampleCount - 1 of the whole render (a power of two) */
     SobolTab sobol;                   /* PHIP_SAMPLER_SOBOL: the reference plugin's tables in device memory (dv_math.h) */
+    RinvTab rinv;                     /* PHIP_SAMPLER_HALTON / _HAMMERSLEY: primes, permutations, the partition of the sequence over the pixels */
     uint32_t stRes;                   /* PHIP_SAMPLER_STRATIFIED: sqrt of the render's sample count */
     float diffScaleFactor;            /* 1 / sqrt(spp) of the whole render: RayDifferential::scaleDifferential, integrator.cpp:144-145,181 */
     /* `direct` (direct.cpp:130-138): sample counts, MIS fractions and per-sample weights */
@@ -131,12 +132,29 @@ __host__ __device__ __forceinline__ uint32_t spreadBits(uint32_t x) {
 /* ---- the sample stream: what the `c`-th request of a sample returns.  PHIP_SAMPLER_CTR: words of pcg4d blocks;
  *      PHIP_SAMPLER_LD: the first LD_DIMENSIONS 2D requests (the pixel jitter is request 0) and 1D requests of a sample come from
  *      scrambled (0,2)-sequences, later ones from the counter stream -- next1D / next2D of ldsampler.cpp:212-226 ---- */
-/* QMC (a compile-time switch: the kernels of the metric's configurations are compiled without this code): PHIP_SAMPLER_SOBOL / _STRATIFIED */
+/* The reference's deterministic sequence samplers (sobol, halton, hammersley) share their consumption: a point index per (pixel, sample), one
+   dimension after the other in call order (k_shade.h restates the bookkeeping of sobol.cpp:218-247 = halton.cpp:352-384 = hammersley.cpp:245-280) */
+__device__ __forceinline__ bool isSequenceSampler(uint32_t s) { return s == PHIP_SAMPLER_SOBOL || s == PHIP_SAMPLER_HALTON || s == PHIP_SAMPLER_HAMMERSLEY; }
+__device__ __forceinline__ uint64_t seqIndex(const RenderConst &rc, uint32_t k, uint32_t px, uint32_t py) {
+    return rc.sampler == PHIP_SAMPLER_SOBOL ? sobolSampleIndex(rc.sobol, k, px, py) : rinvSampleIndex(rc.rinv, k, px, py);
+}
+__device__ __forceinline__ float seqSample(const RenderConst &rc, uint64_t idx, uint32_t dim) {
+    return rc.sampler == PHIP_SAMPLER_SOBOL ? sobolSample(rc.sobol, idx, dim) : rinvSample(rc.rinv, idx, dim);
+}
+/* dimensions the tables hold (hammersley: its dimension d > 0 uses prime d - 1) */
+__device__ __forceinline__ uint32_t seqDims(const RenderConst &rc) {
+    return rc.sampler == PHIP_SAMPLER_SOBOL ? rc.sobol.dims : rc.rinv.dims + rc.rinv.hammersley;
+}
+
+/* QMC (a compile-time switch: the kernels of the metric's configurations are compiled without this code): PHIP_SAMPLER_SOBOL / _HALTON / _HAMMERSLEY / _STRATIFIED */
 template <bool QMC = false>
 __device__ __forceinline__ V2 streamJitter(const RenderConst &rc, uint32_t pixel, uint32_t k, uint32_t filmWidth = 1u) {
     if (rc.sampler == PHIP_SAMPLER_LD) { float x, y; ldPoint(pixel, k, 0u, rc.seed, rc.ldMask, x, y); return V2(x, y); }
     if (QMC && rc.sampler == PHIP_SAMPLER_SOBOL) {
         float x, y; sobolCameraSample(rc.sobol, k, pixel % filmWidth, pixel / filmWidth, x, y); return V2(x, y);
+    }
+    if (QMC && (rc.sampler == PHIP_SAMPLER_HALTON || rc.sampler == PHIP_SAMPLER_HAMMERSLEY)) {
+        float x, y; rinvCameraSample(rc.rinv, k, pixel % filmWidth, pixel / filmWidth, x, y); return V2(x, y);
     }
     const U4 h = pcg4d(pixel, k, 0, rc.seed);
     if (QMC && rc.sampler == PHIP_SAMPLER_STRATIFIED) {       /* 2D request 0 of the sample (stratified.cpp:177-189) */

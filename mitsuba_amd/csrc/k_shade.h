@@ -264,9 +264,9 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                     /* the (depth - 1 - rrDepth)-th 1D request of the sample.  sobol: its dimension is two per 2D request made so far (the camera
                        sample and the kq requests of the vertices behind) plus one per earlier 1D request (SobolSampler::next1D, sobol.cpp:226-236) */
                     const uint32_t j = depth - 1u - (uint32_t) rc.rrDepth, kq = 2u * (depth - 1u) - (flags >> NS_SHIFT);
-                    if (rc.sampler == PHIP_SAMPLER_SOBOL) {
+                    if (isSequenceSampler(rc.sampler)) {
                         const uint32_t dim = 2u * (1u + kq) + j + 1u;      /* (+ 1: SobolSampler::next2D skips dimension 4, see the vertex's requests below) */
-                        if (dim < rc.sobol.dims) rr = sobolSample(rc.sobol, sobolSampleIndex(rc.sobol, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width), dim);
+                        if (dim < seqDims(rc)) rr = seqSample(rc, seqIndex(rc, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width), dim);
                     } else if (rc.sampler == PHIP_SAMPLER_STRATIFIED && j < ST_DIMENSIONS)
                         rr = stPoint1D(v.pixel, v.k, j, rc.seed, rc.stRes, rr);
                 }
@@ -319,19 +319,20 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 } else if (q < LD_DIMENSIONS)
                     ldPoint(v.pixel, v.k, 2u * q, rc.seed, rc.ldMask, smpBSDF.x, smpBSDF.y);
             }
-            if (QMC && rc.sampler == PHIP_SAMPLER_SOBOL) {
+            if (QMC && isSequenceSampler(rc.sampler)) {
                 /* SobolSampler::next2D (sobol.cpp:238-257): the requests of this vertex start at dimension 2 (1 + k0) + the 1D requests made so far
                    (one Russian-roulette request behind every vertex from rrDepth on: max(0, depth - rrDepth)) */
-                const uint64_t idx = sobolSampleIndex(rc.sobol, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width);
+                const uint64_t idx = seqIndex(rc, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width);
+                const uint32_t nDims = seqDims(rc);
                 /* ... and the sampler never hands out dimension 4 to a 2D request (sobol.cpp:241-242: the test for the dimensions reserved to sample
                    arrays, [5, 5) when none is requested, fires for m_dimension == 4): the sample's third 2D request starts there -- no 1D request
                    can come earlier with rrDepth >= 2 -- so it and every later request is shifted by one */
                 uint32_t dim = 2u * (1u + k0) + (depth > (uint32_t) rc.rrDepth ? depth - (uint32_t) rc.rrDepth : 0u) + (k0 >= 1u ? 1u : 0u);
                 if (smoothVertex) {
-                    if (dim + 1u < rc.sobol.dims) smpEmitter = V2(sobolSample(rc.sobol, idx, dim), sobolSample(rc.sobol, idx, dim + 1u));
+                    if (dim + 1u < nDims) smpEmitter = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
                     dim += 2u + (k0 == 0u ? 1u : 0u);
                 }
-                if (dim + 1u < rc.sobol.dims) smpBSDF = V2(sobolSample(rc.sobol, idx, dim), sobolSample(rc.sobol, idx, dim + 1u));
+                if (dim + 1u < nDims) smpBSDF = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
             } else if (QMC && rc.sampler == PHIP_SAMPLER_STRATIFIED) {
                 /* 2D requests k0 + 1 (and k0 + 2 at a smooth vertex) of the sample: the first ST_DIMENSIONS are stratified, jittered by the counter stream's own numbers */
                 const uint32_t q = k0 + 1u;

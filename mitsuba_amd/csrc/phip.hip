@@ -172,6 +172,8 @@ struct SceneDev {
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
     DevBuf<uint32_t> sobolMat; DevBuf<unsigned long long> sobolVdc; const void *sobolKey = nullptr; uint32_t sobolLogRes = 0;    /* PHIP_SAMPLER_SOBOL: the plugin's tables */
+    DevBuf<uint32_t> rinvPrimes, rinvOffsets; DevBuf<uint16_t> rinvPerm; const void *rinvKey = nullptr, *rinvPermKey = nullptr;   /* PHIP_SAMPLER_HALTON / _HAMMERSLEY: primes + permutations */
+    uint32_t rinvInvPerm2 = 0x4u, rinvInvPerm3 = 0x24u;                                                                         /* inverse permutations of bases 2 and 3, two bits per digit */
     DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
     DevBuf<unsigned int> drawCounters;                                                       /* k_rays_w: 2 x RAY_SHARDS sharded work counters */
     DevBuf<float> film;
@@ -815,7 +817,22 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
         if (p->emitter_samples + p->bsdf_samples <= 0) throw std::invalid_argument("direct: emitterSamples + bsdfSamples must be > 0");     /* Assert, direct.cpp:107 */
         if (p->emitter_samples + p->bsdf_samples >= (int) DEPTH_MASK) throw std::invalid_argument("direct: at most 65534 shading samples per camera sample");
     }
-    if (p->sampler > PHIP_SAMPLER_STRATIFIED) throw std::invalid_argument("unknown sampler kind");
+    if (p->sampler > PHIP_SAMPLER_HAMMERSLEY) throw std::invalid_argument("unknown sampler kind");
+    if (p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY) {
+        const char *name = p->sampler == PHIP_SAMPLER_HALTON ? "PHIP_SAMPLER_HALTON" : "PHIP_SAMPLER_HAMMERSLEY";
+        if (direct) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
+        if (!p->qmc_primes || p->qmc_dimensions < 8 || p->qmc_dimensions > 1024) throw std::invalid_argument(std::string(name) + ": qmc_primes / qmc_dimensions (the reference's prime table, 8 .. 1024 entries) are required");
+        if (p->qmc_primes[0] != 2 || p->qmc_primes[1] != 3) throw std::invalid_argument(std::string(name) + ": qmc_primes must start 2, 3 (the pixel enumeration is over those bases)");
+        for (uint32_t d = 0; d < p->qmc_dimensions; ++d) if (p->qmc_primes[d] < 2 || p->qmc_primes[d] > 65535u) throw std::invalid_argument(std::string(name) + ": qmc_primes out of range");
+        if (p->qmc_permutations) {
+            if (p->qmc_permutations[0] > 1 || p->qmc_permutations[1] > 1 || p->qmc_permutations[0] == p->qmc_permutations[1]) throw std::invalid_argument(std::string(name) + ": qmc_permutations does not start with a permutation of {0, 1}");
+            if (p->qmc_permutations[2] > 2 || p->qmc_permutations[3] > 2 || p->qmc_permutations[4] > 2) throw std::invalid_argument(std::string(name) + ": the permutation of base 3 is not one of {0, 1, 2}");
+        }
+        if (p->rr_depth < 2) throw std::invalid_argument(std::string(name) + ": rrDepth must be at least 2 (the dimension bookkeeping of halton.cpp:364-366 is restated for that case)");
+        if (sc->descCopy.film.crop_offset_x != 0 || sc->descCopy.film.crop_offset_y != 0) throw std::invalid_argument(std::string(name) + ": the crop window must start at the film's origin");
+        const unsigned long long n = (unsigned long long) (p->sample_total > 0 ? p->sample_total : p->spp);
+        if (n >= (1ull << 17)) throw std::invalid_argument(std::string(name) + ": at most 131071 samples per pixel (32-bit pixel offsets)");
+    }
     if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) {
         const char *name = p->sampler == PHIP_SAMPLER_SOBOL ? "PHIP_SAMPLER_SOBOL" : "PHIP_SAMPLER_STRATIFIED";
         if (direct) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
@@ -915,7 +932,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     if (sd.L.n < idsFirstPass) sd.L.alloc((size_t) idsFirstPass);
 
     /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
-    const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED;     /* served by the wavefront kernels compiled with FEAT bit 3 */
+    const bool rinv = p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY;
+    const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED || rinv;     /* served by the wavefront kernels compiled with FEAT bit 3 */
     bool fused = !direct && !qmc && sc->fitsLds && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
     if (qmc && p->sampler == PHIP_SAMPLER_SOBOL) {
         /* the plugin's tables, uploaded once per (pointer, size): ~210 KB of direction numbers + the two 52-word enumeration rows */
@@ -928,6 +946,22 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             sd.sobolVdc.upload(v.data(), v.size());
             sd.sobolKey = (const void *) p->sobol_matrices; sd.sobolLogRes = p->sobol_log_resolution;
         }
+    }
+    if (rinv && (sd.rinvKey != (const void *) p->qmc_primes || sd.rinvPermKey != (const void *) p->qmc_permutations || sd.rinvPrimes.n != p->qmc_dimensions)) {
+        /* primes, the start of every base's permutation, the permutations themselves; the inverse permutations of bases 2 and 3 (the pixel enumeration) */
+        std::vector<uint32_t> off(p->qmc_dimensions);
+        size_t total = 0;
+        for (uint32_t d = 0; d < p->qmc_dimensions; ++d) { off[d] = (uint32_t) total; total += p->qmc_primes[d]; }
+        sd.rinvPrimes.upload(p->qmc_primes, p->qmc_dimensions); sd.rinvOffsets.upload(off.data(), off.size());
+        sd.rinvInvPerm2 = 0x4u; sd.rinvInvPerm3 = 0x24u;
+        if (p->qmc_permutations) {
+            sd.rinvPerm.upload(p->qmc_permutations, total);
+            const uint16_t *p2 = p->qmc_permutations, *p3 = p->qmc_permutations + 2;
+            sd.rinvInvPerm2 = sd.rinvInvPerm3 = 0;
+            for (uint32_t i = 0; i < 2; ++i) sd.rinvInvPerm2 |= i << (2u * p2[i]);          /* invPerm[perm[i]] = i (faure.cpp: invertPermutation) */
+            for (uint32_t i = 0; i < 3; ++i) sd.rinvInvPerm3 |= i << (2u * p3[i]);
+        }
+        sd.rinvKey = (const void *) p->qmc_primes; sd.rinvPermKey = (const void *) p->qmc_permutations;
     }
     if (const char *e = getenv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
     sd.fused = fused;
@@ -1053,6 +1087,36 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
             unsigned r = 1; while (r * r < n) ++r;
             rc.stRes = r;
+        }
+        memset(&rc.rinv, 0, sizeof(rc.rinv));
+        if (rinv) {
+            RinvTab &T = rc.rinv;
+            T.primes = sd.rinvPrimes.p; T.perm = p->qmc_permutations ? sd.rinvPerm.p : nullptr; T.permOffset = sd.rinvOffsets.p; T.dims = p->qmc_dimensions;
+            T.invPerm2 = sd.rinvInvPerm2; T.invPerm3 = sd.rinvInvPerm3;
+            const uint32_t res[2] = { (uint32_t) D.film.width, (uint32_t) D.film.height };
+            T.sampleCount = (uint32_t) (p->sample_total > 0 ? p->sample_total : p->spp);
+            if (p->sampler == PHIP_SAMPLER_HALTON) {
+                /* HaltonSampler::setFilmResolution(res, blocked = true), halton.cpp:244-266 */
+                T.hammersley = 0; T.stride = 1;
+                uint32_t pw[2], ex[2];
+                for (int i = 0; i < 2; ++i) {
+                    const uint32_t prime = i ? 3u : 2u; uint32_t value = 1, e = 0;
+                    while (value < std::min(res[i], RINV_MAX_RESOLUTION)) { value *= prime; ++e; }
+                    pw[i] = value; ex[i] = e; T.stride *= value;
+                }
+                T.powX = pw[0]; T.powY = pw[1]; T.expX = ex[0]; T.expY = ex[1];
+                /* multiplicativeInverse(a, n): x with a x = 1 (mod n), in 0 .. n - 1 (halton.cpp:214-241; n = 1 gives 0) */
+                auto inverse = [](uint32_t a, uint32_t n) { for (uint32_t x = 0; x < n; ++x) if ((unsigned long long) a * x % n == 1u % n) return x; return 0u; };
+                T.multInvX = inverse(T.powY, T.powX); T.multInvY = inverse(T.powX, T.powY);
+            } else {
+                /* HammersleySampler::setFilmResolution(res, blocked = true), hammersley.cpp:181-196 */
+                T.hammersley = 1;
+                uint32_t r[2];
+                for (int i = 0; i < 2; ++i) { uint32_t v = 1; while (v < res[i]) v <<= 1; r[i] = std::min(RINV_MAX_RESOLUTION, v); }
+                T.powX = r[0]; T.powY = r[1]; T.expX = 0; T.expY = 0; while ((1u << T.expY) < r[1]) ++T.expY;
+                T.stride = r[1];
+                T.factor = 1.0f / (float) ((size_t) T.sampleCount * (size_t) r[0] * (size_t) r[1]);
+            }
         }
         rc.diffScaleFactor = 1.0f / sqrtf((float) (p->sample_total > 0 ? p->sample_total : p->spp));
         rc.emitterSamples = direct ? p->emitter_samples : 0; rc.bsdfSamples = direct ? p->bsdf_samples : 0;

@@ -14,6 +14,9 @@
 #include <link.h>
 #include "../../bsdfs/microfacet.h"      /* MicrofacetDistribution: plugin-local header of src/bsdfs */
 #include "../../bsdfs/ior.h"             /* lookupIOR */
+#include "../../samplers/faure.cpp"      /* PermutationStorage (faure.h, which has no include guard, comes with it): plugin-local to src/samplers and compiled into every plugin
+                                            that uses it (src/samplers/SConscript:5-6), so into this one too -- the digit permutations of <sampler type="halton"/> /
+                                            "hammersley" are handed to the device as data */
 #include "phip.h"
 
 /* How the shim gets at four plugin-local classes of the reference (TwoSidedBRDF's children, SmoothDiffuse's reflectance
@@ -159,7 +162,7 @@ inline PhipBitmapInfo phipBitmap(const Texture *t) {
 /* Owns the device scene of one integrator instance. */
 class PhipSceneHolder {
 public:
-    PhipSceneHolder() : m_scene(NULL), m_device(0), m_deviceCount(1) { }
+    PhipSceneHolder() : m_qmcScramble(0), m_scene(NULL), m_device(0), m_deviceCount(1) { }
     ~PhipSceneHolder() { if (m_scene) phip_scene_destroy(m_scene); }
     phip_scene *get() const { return m_scene; }
     void setDevice(int device) { m_device = device; }
@@ -175,7 +178,7 @@ public:
        parallel schedule reproduces, not even the reference's own from run to run (independent.cpp:42-45) -- so the device's
        counter-based stream stands in, which is said once.  `ldsampler` maps to PHIP_SAMPLER_LD: the same construction (scrambled
        (0,2)-sequences in a random order per pixel and dimension for the first four 1D / 2D requests of a sample, ldsampler.cpp:151-226)
-       with the scrambles and the order drawn from the counter-based generator instead of the worker's Random -- default `dimension` only.  `stratified` maps to PHIP_SAMPLER_STRATIFIED the same way; `sobol` is deterministic and maps to PHIP_SAMPLER_SOBOL, the plugin's own numbers.  Any other QMC sampler (halton, hammersley) would silently lose its stratification: an error. */
+       with the scrambles and the order drawn from the counter-based generator instead of the worker's Random -- default `dimension` only.  `stratified` maps to PHIP_SAMPLER_STRATIFIED the same way; `sobol`, `halton` and `hammersley` are deterministic and map to PHIP_SAMPLER_SOBOL / _HALTON / _HAMMERSLEY: the plugins' own numbers. */
     static int checkSampler(const Sampler *sampler, const char *name) {
         const std::string cls = sampler->getClass()->getName();
         if (cls == "LowDiscrepancySampler") {
@@ -212,7 +215,9 @@ public:
         }
         if (cls == "SobolSampler")
             return PHIP_SAMPLER_SOBOL;          /* the plugin's own sequence, number for number: setSobol() below */
-        SLog(EError, "%s: sampler \"%s\" is not supported ('independent', 'ldsampler', 'stratified', 'sobol'; other QMC samplers would lose their stratification)", name, cls.c_str());
+        if (cls == "HaltonSampler") return PHIP_SAMPLER_HALTON;              /* likewise: setRadicalInverse() below */
+        if (cls == "HammersleySampler") return PHIP_SAMPLER_HAMMERSLEY;
+        SLog(EError, "%s: sampler \"%s\" is not supported ('independent', 'ldsampler', 'stratified', 'sobol', 'halton', 'hammersley')", name, cls.c_str());
         return PHIP_SAMPLER_CTR;
     }
 
@@ -228,6 +233,27 @@ public:
         if (n.size() >= l && n.compare(n.size() - l, l, f->suffix) == 0) { f->path = n; return 1; }
         return 0;
     }
+    /* PHIP_SAMPLER_HALTON / _HAMMERSLEY: the reference's prime table (libcore, exported) and the digit permutations its PermutationStorage builds for the
+       sampler's `scramble` property (-1, the default: Faure's; 0: none; otherwise pseudorandom ones -- halton.cpp:124,184-194), concatenated; built once
+       per scramble value like the plugins' own m_globalPermutations */
+    void setRadicalInverse(const Sampler *sampler, phip_render_params &rp) {
+        const int scramble = sampler->getProperties().getInteger("scramble", -1);
+        if (m_qmcPrimes.empty() || m_qmcScramble != scramble) {
+            m_qmcPrimes.assign(primeTable, primeTable + primeTableSize);
+            m_qmcPerm.clear();
+            if (scramble != 0) {
+                ref<PermutationStorage> ps = new PermutationStorage(scramble);
+                for (size_t d = 0; d < primeTableSize; ++d)
+                    m_qmcPerm.insert(m_qmcPerm.end(), ps->getPermutation((uint32_t) d), ps->getPermutation((uint32_t) d) + primeTable[d]);
+            }
+            m_qmcScramble = scramble;
+        }
+        rp.qmc_primes = (const uint32_t *) &m_qmcPrimes[0];             /* (primeTable is `const int[]`: the values are positive) */
+        rp.qmc_permutations = m_qmcPerm.empty() ? NULL : &m_qmcPerm[0];
+        rp.qmc_dimensions = (uint32_t) primeTableSize;
+    }
+    std::vector<int> m_qmcPrimes; std::vector<uint16_t> m_qmcPerm; int m_qmcScramble;
+
     static void setSobol(const Sampler *sampler, const Vector2i &cropSize, phip_render_params &rp, const char *name) {
         FindPlugin f; f.suffix = "/sobol.so";
         dl_iterate_phdr(findPluginCb, &f);
@@ -262,6 +288,7 @@ public:
         SLog(EInfo, "Starting render job (%ix%i, " SIZE_T_FMT " samples, %s) ..", size.x, size.y, spp, phip_version());
         rp.block_size = (int32_t) scene->getBlockSize();
         if (samplerKind == PHIP_SAMPLER_SOBOL) setSobol(sampler, size, rp, name);
+        if (samplerKind == PHIP_SAMPLER_HALTON || samplerKind == PHIP_SAMPLER_HAMMERSLEY) setRadicalInverse(sampler, rp);
         rp.sampler = samplerKind; rp.seed = 0; rp.shard_index = 0; rp.shard_count = 1; rp.device = m_device;
         int nDev = m_deviceCount == 0 ? phip_device_count() - m_device : m_deviceCount;
         if (nDev > PHIP_MAX_DEVICES) nDev = PHIP_MAX_DEVICES;

@@ -231,7 +231,8 @@ struct RenderParams {
     bool ctr = true; uint32_t seed = 0;
     int shardIndex = 0, shardCount = 1;
     bool ld = false;                         /* PHIP_SAMPLER_LD on top of the counter stream */
-    int qmc = 0; SobolTables sobol; uint32_t stRes = 1;      /* PHIP_SAMPLER_SOBOL (1) / PHIP_SAMPLER_STRATIFIED (2), `path` only */
+    int qmc = 0; SobolTables sobol; uint32_t stRes = 1;      /* PHIP_SAMPLER_SOBOL (1) / PHIP_SAMPLER_STRATIFIED (2) / _HALTON, _HAMMERSLEY (3), `path` only */
+    RinvTables rinv;
     int sampleOffset = 0, sampleTotal = 0;   /* phip_render_params::sample_offset / sample_total: this call renders samples [offset, offset + spp) of sampleTotal */
 };
 
@@ -279,7 +280,7 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
             blk.offX = b[0]; blk.offY = b[1];
             SampleSource smp; smp.ctr = rp.ctr; smp.seed = rp.seed; smp.rng = rp.ctr ? nullptr : &workerRng[tid];
             smp.ld = rp.ld; smp.ldMask = (uint32_t) (rp.sampleTotal > 0 ? rp.sampleTotal : rp.spp) - 1u; smp.rrDepth = rp.ip.rrDepth;
-            smp.qmc = rp.qmc; smp.sobol = &rp.sobol; smp.stRes = rp.stRes;
+            smp.qmc = rp.qmc; smp.sobol = &rp.sobol; smp.stRes = rp.stRes; smp.rinv = &rp.rinv;
             for (int y = 0; y < b[3]; ++y) for (int x = 0; x < b[2]; ++x) {
                 const int px = blk.offX + x, py = blk.offY + y;     /* crop-window pixel coordinates */
                 smp.pixel = (uint32_t) (py * f.crop_width + px);

@@ -213,6 +213,100 @@ struct SobolTables {
         return std::min(result * (1.0f / (1ULL << 32)), 0.999999940395355225f /* ONE_MINUS_EPS_FLT */);
     }
 };
+/* ---- PHIP_SAMPLER_HALTON / _HAMMERSLEY: the reference's radical-inverse samplers (src/samplers/halton.cpp, hammersley.cpp), SINGLE_PRECISION.
+ *      Primes and digit permutations are the reference's own tables, handed in as data (phip_render_params.qmc_*). ---- */
+struct RinvTables {
+    const uint32_t *primes = nullptr; const uint16_t *perm = nullptr; uint32_t dims = 0;
+    std::vector<size_t> permOffset;                  /* start of the permutation of dimension d: primes[0] + ... + primes[d - 1] */
+    bool hammersley = false;
+    uint64_t stride = 1, multInverse[2] = { 0, 0 };  /* m_stride, m_multInverse */
+    int primePowers[2] = { 1, 1 }, primeExponents[2] = { 0, 0 };   /* halton; hammersley: m_resolution, (-, m_logHeight) */
+    size_t sampleCount = 1; float factor = 1.0f;     /* hammersley: m_sampleCount, m_factor */
+    static const int MAX_RESOLUTION = 128;           /* halton.cpp:29, hammersley.cpp:29 */
+    /* getPermutation(d) / getInversePermutation(d) of PermutationStorage (faure.h:44-52; the inverse by inversion, faure.cpp) */
+    const uint16_t *permutation(uint32_t d) const { return perm ? perm + permOffset[d] : nullptr; }
+    uint64_t inverseDigit(uint32_t d, uint64_t digit) const {
+        if (!perm) return digit;
+        const uint16_t *pm = permutation(d);
+        for (uint32_t i = 0; i < primes[d]; ++i) if (pm[i] == digit) return i;
+        return digit;
+    }
+    static void extendedGCD(uint64_t a, uint64_t b, int64_t &x, int64_t &y) {           /* halton.cpp:219-229 */
+        if (b == 0) { x = 1; y = 0; return; }
+        int64_t d = (int64_t) (a / b), x_, y_;
+        extendedGCD(b, a % b, x_, y_);
+        x = y_; y = x_ - d * y_;
+    }
+    static uint64_t multiplicativeInverse(int64_t a, int64_t n) {                       /* halton.cpp:236-241; math::modulo: the non-negative remainder */
+        int64_t x, y; extendedGCD((uint64_t) a, (uint64_t) n, x, y);
+        int64_t r = x % n; return (uint64_t) (r < 0 ? r + n : r);
+    }
+    void setFilmResolution(int resX, int resY, size_t sampleCount_) {                   /* blocked = true: halton.cpp:244-266, hammersley.cpp:181-196 */
+        const int res[2] = { resX, resY };
+        sampleCount = sampleCount_;
+        if (!hammersley) {
+            stride = 1;
+            for (int i = 0; i < 2; ++i) {
+                int prime = (int) primes[i], value = 1, exp = 0;
+                while (value < std::min(res[i], MAX_RESOLUTION)) { value *= prime; ++exp; }
+                primePowers[i] = value; primeExponents[i] = exp; stride *= (uint64_t) value;
+            }
+            multInverse[0] = multiplicativeInverse(primePowers[1], primePowers[0]);
+            multInverse[1] = multiplicativeInverse(primePowers[0], primePowers[1]);
+        } else {
+            for (int i = 0; i < 2; ++i) { uint32_t v = 1; while (v < (uint32_t) res[i]) v <<= 1; primePowers[i] = (int) std::min((uint32_t) MAX_RESOLUTION, v); }
+            primeExponents[0] = 0; primeExponents[1] = 0; while ((1 << primeExponents[1]) < primePowers[1]) ++primeExponents[1];
+            factor = (float) 1.0f / (sampleCount * (size_t) primePowers[0] * (size_t) primePowers[1]);
+            stride = (uint64_t) primePowers[1];
+        }
+    }
+    uint64_t inverseScrambledRadicalInverse(uint32_t d, uint64_t inverse, uint64_t digits) const {     /* halton.cpp:198-211 */
+        const uint64_t base = primes[d];
+        uint64_t index = 0;
+        while (digits) {
+            uint64_t digit = inverseDigit(d, inverse % base);
+            inverse /= base;
+            index = index * base + digit;
+            --digits;
+        }
+        return index;
+    }
+    uint64_t sampleIndex(uint32_t sample, uint32_t px, uint32_t py) const {             /* generate() + next*D: halton.cpp:272-296,372 / hammersley.cpp:206-222,268 */
+        const uint64_t pos[2] = { px % (uint32_t) MAX_RESOLUTION, py % (uint32_t) MAX_RESOLUTION };
+        uint64_t offset = 0;
+        if (stride > 1) {
+            if (hammersley)
+                offset = pos[0] * (uint64_t) primePowers[1] * sampleCount + inverseScrambledRadicalInverse(0, pos[1], (uint64_t) primeExponents[1]);
+            else {
+                for (int i = 0; i < 2; ++i)
+                    offset += inverseScrambledRadicalInverse((uint32_t) i, pos[i], (uint64_t) primeExponents[i]) * (stride / (uint64_t) primePowers[i]) * multInverse[i];
+                offset %= stride;
+            }
+        }
+        return offset + stride * (uint64_t) sample;
+    }
+    float radicalInverse(uint32_t baseIndex, uint64_t index) const {                    /* RINV / SCRAMBLED_RINV, qmc.cpp:141-166 */
+        const int base = (int) primes[baseIndex];
+        const uint16_t *pm = permutation(baseIndex);
+        const float radical = (float) 1 / (float) base;
+        uint64_t value = 0;
+        float factor_ = 1.0f;
+        while (index) {
+            uint64_t next = index / (uint64_t) base;
+            uint64_t digit = index - next * (uint64_t) base;
+            value = value * (uint64_t) base + (pm ? (uint64_t) pm[digit] : digit);
+            factor_ *= radical;
+            index = next;
+        }
+        float inverse = pm ? factor_ * ((float) value + radical * pm[0] / (1 - radical)) : (float) value * factor_;
+        return std::min(inverse, 0.999999940395355225f /* ONE_MINUS_EPS_FLT */);
+    }
+    float sample(uint64_t index, uint32_t dimension) const {                            /* nextFloat, halton.cpp:343-350 / hammersley.cpp:235-243 */
+        if (hammersley) return dimension == 0 ? index * factor : radicalInverse(dimension - 1, index);
+        return radicalInverse(dimension, index);
+    }
+    uint32_t dimensions() const { return dims + (hammersley ? 1u : 0u); }
+};
 static const uint32_t ST_DIMENSIONS = 4;     /* stratified.cpp:79 */
 
 struct SampleSource {
@@ -228,7 +322,12 @@ struct SampleSource {
         return Vec2(radicalInverse2Single(i, h[1]), sobol2Single(i, h[2]));
     }
     /* sobol mode (the reference's stream as it stands) / stratified mode (its construction on the counter stream, as ld): PHIP_SAMPLER_SOBOL / _STRATIFIED */
-    int qmc = 0;                             /* 0: off, 1: sobol, 2: stratified */
+    int qmc = 0;                             /* 0: off, 1: sobol, 2: stratified, 3: halton / hammersley (sequence samplers: 1 and 3) */
+    const RinvTables *rinv = nullptr;
+    bool sequence() const { return qmc == 1 || qmc == 3; }
+    uint64_t seqIndex() const { return qmc == 1 ? sobol->sampleIndex(sample, px, py) : rinv->sampleIndex(sample, px, py); }
+    float seqSample(uint64_t idx, uint32_t dim) const { return qmc == 1 ? sobol->sample(idx, dim) : rinv->sample(idx, dim); }
+    uint32_t seqDims() const { return qmc == 1 ? sobol->dims : rinv->dimensions(); }
     const SobolTables *sobol = nullptr; uint32_t px = 0, py = 0;             /* pixel position SobolSampler::generate received */
     uint32_t stRes = 1;
     uint32_t stCell(uint32_t dim) const {    /* the cell sample `sample` visits in dimension dim: a keyed permutation (stratified.cpp:147-158 shuffles) */
@@ -247,9 +346,9 @@ struct SampleSource {
         return (c + u) * (1 / (Float) (size_t) (stRes * stRes));
     }
     Vec2 sobol2D(uint32_t dim, Vec2 fallback) const {
-        if (dim + 1 >= sobol->dims) return fallback;     /* (the reference stops with an error here, sobol.cpp:243-245) */
-        const uint64_t idx = sobol->sampleIndex(sample, px, py);
-        return Vec2(sobol->sample(idx, dim), sobol->sample(idx, dim + 1));
+        if (dim + 1 >= seqDims()) return fallback;       /* (the reference stops with an error here, sobol.cpp:243-245) */
+        const uint64_t idx = seqIndex();
+        return Vec2(seqSample(idx, dim), seqSample(idx, dim + 1));
     }
     /* sfmt mode */
     SFMT *rng = nullptr;
@@ -273,7 +372,7 @@ struct SampleSource {
         /* ... and SobolSampler::next2D skips dimension 4 (sobol.cpp:241-242: `m_dimension + 1 >= m_arrayStartDim && m_dimension < m_arrayEndDim` with both = 5
            when no sample array is requested): the third 2D request of a sample starts there (rrDepth >= 2: no 1D request comes earlier), so it
            and everything behind it is shifted by one */
-        if (qmc == 1) return sobol2D(2 * (1 + k) + (uint32_t) std::max(0, depth - rrDepth) + (k >= 1 ? 1u : 0u), ctrPair(k));
+        if (sequence()) return sobol2D(2 * (1 + k) + (uint32_t) std::max(0, depth - rrDepth) + (k >= 1 ? 1u : 0u), ctrPair(k));      /* (halton.cpp:364-366 and hammersley.cpp:257-259 are the same test) */
         if (qmc == 2 && k + 1 < ST_DIMENSIONS) return stPoint2D(k + 1, ctrPair(k));
         return ctrPair(k);
     }
@@ -286,6 +385,12 @@ struct SampleSource {
             if (idx != (uint64_t) sample)
                 return Vec2(sobol->sample(idx, 0) * sobol->resolution - (int) px, sobol->sample(idx, 1) * sobol->resolution - (int) py);
             return Vec2(sobol->sample(idx, 0), sobol->sample(idx, 1));
+        }
+        if (qmc == 3) {                                      /* next2D at dimension 0, halton.cpp:375-378 / hammersley.cpp:271-274 */
+            const uint64_t idx = rinv->sampleIndex(sample, px, py);
+            const float v1 = rinv->sample(idx, 0) * rinv->primePowers[0] - (int) (px % (uint32_t) RinvTables::MAX_RESOLUTION);
+            const float v2 = rinv->sample(idx, 1) * rinv->primePowers[1] - (int) (py % (uint32_t) RinvTables::MAX_RESOLUTION);
+            return Vec2(v1, v2);
         }
         float f[4]; block(0, f);
         if (qmc == 2) return stPoint2D(0, Vec2(f[0], f[1]));
@@ -305,9 +410,9 @@ struct SampleSource {
         if (!ctr) return rng->nextFloat();
         if (ld && (uint32_t) (depth - rrDepth) < LD_DIMENSIONS) return ldPoint(2 * (uint32_t) (depth - rrDepth) + 1).x;   /* the (depth - rrDepth)-th 1D request */
         float f[4]; block(2 + 2 * (uint32_t) (depth - 1), f);
-        if (qmc == 1) {                                      /* SobolSampler::next1D: after 1 + (2 depth - ns) 2D requests and depth - rrDepth 1D requests */
+        if (sequence()) {                                    /* SobolSampler::next1D: after 1 + (2 depth - ns) 2D requests and depth - rrDepth 1D requests */
             const uint32_t dim = 2 * (1 + 2 * (uint32_t) depth - ns) + (uint32_t) (depth - rrDepth) + 1u;      /* (+ 1: the skipped dimension 4, see pair()) */
-            return dim < sobol->dims ? sobol->sample(sobol->sampleIndex(sample, px, py), dim) : f[0];
+            return dim < seqDims() ? seqSample(seqIndex(), dim) : f[0];
         }
         if (qmc == 2 && (uint32_t) (depth - rrDepth) < ST_DIMENSIONS) return stPoint1D((uint32_t) (depth - rrDepth), f[0]);
         return f[0];

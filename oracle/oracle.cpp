@@ -51,8 +51,18 @@ void oracle_scene_set_bruteforce(void *scene, int on) { static_cast<Scene *>(sce
 int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, int sampler_mode,
                         float *out_rgbaw, float *out_samples_rgba, uint32_t *out_smooth_masks, phip_stats *stats);
 /* PHIP_SAMPLER_SOBOL / _STRATIFIED: the sampler's parameters out of phip_render_params (the tables stay where the caller has them) */
-static void setQmc(const Scene &scene, const phip_render_params *p, int &qmc, SobolTables &sob, uint32_t &stRes) {
-    if (p->sampler == PHIP_SAMPLER_SOBOL) {
+static bool isQmc(uint32_t s) { return s == PHIP_SAMPLER_SOBOL || s == PHIP_SAMPLER_STRATIFIED || s == PHIP_SAMPLER_HALTON || s == PHIP_SAMPLER_HAMMERSLEY; }
+static void setQmc(const Scene &scene, const phip_render_params *p, int &qmc, SobolTables &sob, uint32_t &stRes, RinvTables &rinv) {
+    if (p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY) {
+        if (!p->qmc_primes || p->qmc_dimensions < 8) throw std::runtime_error("PHIP_SAMPLER_HALTON / _HAMMERSLEY: tables missing");
+        if (scene.film.crop_offset_x != 0 || scene.film.crop_offset_y != 0) throw std::runtime_error("PHIP_SAMPLER_HALTON / _HAMMERSLEY: crop window at the origin");
+        if (p->rr_depth < 2) throw std::runtime_error("PHIP_SAMPLER_HALTON / _HAMMERSLEY: rrDepth >= 2");
+        qmc = 3; rinv.primes = p->qmc_primes; rinv.perm = p->qmc_permutations; rinv.dims = p->qmc_dimensions;
+        rinv.permOffset.assign(p->qmc_dimensions, 0);
+        for (uint32_t d = 1; d < p->qmc_dimensions; ++d) rinv.permOffset[d] = rinv.permOffset[d - 1] + p->qmc_primes[d - 1];
+        rinv.hammersley = p->sampler == PHIP_SAMPLER_HAMMERSLEY;
+        rinv.setFilmResolution(scene.film.crop_width, scene.film.crop_height, (size_t) (p->sample_total > 0 ? p->sample_total : p->spp));
+    } else if (p->sampler == PHIP_SAMPLER_SOBOL) {
         if (!p->sobol_matrices || (p->sobol_log_resolution > 1 && (!p->sobol_vdc || !p->sobol_vdc_inv))) throw std::runtime_error("PHIP_SAMPLER_SOBOL: tables missing");
         if (scene.film.crop_offset_x != 0 || scene.film.crop_offset_y != 0) throw std::runtime_error("PHIP_SAMPLER_SOBOL: crop window at the origin");
         if (p->rr_depth < 2) throw std::runtime_error("PHIP_SAMPLER_SOBOL: rrDepth >= 2");
@@ -87,9 +97,9 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
             if (sampler_mode != 0 || n == 0 || (n & (n - 1)))
                 throw std::runtime_error("PHIP_SAMPLER_LD: on the counter stream, power-of-two sample count");
         }
-        if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) {
-            if (sampler_mode != 0 || p->integrator != PHIP_INTEGRATOR_PATH) throw std::runtime_error("PHIP_SAMPLER_SOBOL / _STRATIFIED: `path`, counter-stream mode");
-            setQmc(scene, p, rp.qmc, rp.sobol, rp.stRes);
+        if (isQmc(p->sampler)) {
+            if (sampler_mode != 0 || p->integrator != PHIP_INTEGRATOR_PATH) throw std::runtime_error("the QMC samplers: `path`, counter-stream mode");
+            setQmc(scene, p, rp.qmc, rp.sobol, rp.stRes, rp.rinv);
         }
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
         if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::runtime_error("unknown integrator");
@@ -164,8 +174,8 @@ int oracle_path_sample(void *scene_, const phip_render_params *p, int px, int py
         SampleSource smp; smp.ctr = true; smp.seed = p->seed; smp.rng = nullptr;
         smp.pixel = (uint32_t) (py * f.crop_width + px); smp.sample = (uint32_t) k;
         smp.ld = p->sampler == PHIP_SAMPLER_LD; smp.ldMask = (uint32_t) (p->sample_total > 0 ? p->sample_total : p->spp) - 1u; smp.rrDepth = p->rr_depth;
-        SobolTables sob;
-        if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) { setQmc(scene, p, smp.qmc, sob, smp.stRes); smp.sobol = &sob; smp.px = (uint32_t) px; smp.py = (uint32_t) py; }
+        SobolTables sob; RinvTables rinv;
+        if (isQmc(p->sampler)) { setQmc(scene, p, smp.qmc, sob, smp.stRes, rinv); smp.sobol = &sob; smp.rinv = &rinv; smp.px = (uint32_t) px; smp.py = (uint32_t) py; }
         const Float diffScaleFactor = 1.0f / std::sqrt((Float) (p->sample_total > 0 ? p->sample_total : p->spp));
         Vec2 jit = smp.cameraSample();
         Vec2 samplePos((Float) px + jit.x, (Float) py + jit.y);

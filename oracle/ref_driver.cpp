@@ -21,6 +21,8 @@
 #include <mitsuba/core/plugin.h>
 #include <mitsuba/core/statistics.h>
 #include <mitsuba/core/fstream.h>
+#include <mitsuba/core/qmc.h>
+#include "faure.h"                      /* src/samplers/faure.h (plugin-local): PermutationStorage */
 #include <mitsuba/core/bitmap.h>
 #include <mitsuba/core/sched.h>
 #include <mitsuba/core/appender.h>
@@ -39,7 +41,7 @@ namespace {
 
 std::string g_err;
 bool g_init = false;
-int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream); 2 / 3 / 4 = the reference's `ldsampler` / `sobol` / `stratified` */
+int g_samplerKind = 0;      /* 0 = the reference's `independent`; 1 = oracle/ref_glue/ctr_sampler.cpp (the parity stream); 2 / 3 / 4 / 5 / 6 = the reference's `ldsampler` / `sobol` / `stratified` / `halton` / `hammersley` */
 /* shapes the NEXT ref_scene_create loads through one of the reference's own mesh-loader plugins (shapes/obj.cpp): (plugin, file,
    material id of the description, toWorld) -- a real asset enters the scene exactly as the XML loader would add it */
 struct FileShape { std::string plugin, filename; uint32_t material; float toWorld[16]; };
@@ -57,7 +59,7 @@ struct RefScene {
 /* the scene's sampler for one render: `independent`, or the parity stream (ctr_sampler.cpp: defined by call order, so it needs to know
    nothing about the scene) */
 Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
-    Properties smp(g_samplerKind == 1 ? "ctr" : g_samplerKind == 2 ? "ldsampler" : g_samplerKind == 3 ? "sobol" : g_samplerKind == 4 ? "stratified" : "independent");
+    Properties smp(g_samplerKind == 1 ? "ctr" : g_samplerKind == 2 ? "ldsampler" : g_samplerKind == 3 ? "sobol" : g_samplerKind == 4 ? "stratified" : g_samplerKind == 5 ? "halton" : g_samplerKind == 6 ? "hammersley" : "independent");
     smp.setSize("sampleCount", (size_t) p->spp);
     if (g_samplerKind == 1) {
         smp.setInteger("seed", (int) p->seed);
@@ -69,6 +71,7 @@ Sampler *makeSampler(const Scene *scene, const phip_render_params *p) {
         smp.setSize("sampleTotal", (size_t) (p->sample_total > 0 ? p->sample_total : p->spp));
         smp.setBoolean("stratified", p->sampler == PHIP_SAMPLER_STRATIFIED);   /* the construction of `stratified` on the counter stream (include/phip.h) */
     }
+    if ((g_samplerKind == 5 || g_samplerKind == 6) && p->seed) smp.setInteger("scramble", (int) p->seed - 2);   /* seed 1 -> -1 (Faure, the default), 2 -> 0 (none), n -> n - 2 */
     if (g_samplerKind == 3 && p->seed) smp.setSize("scramble", (size_t) p->seed);   /* the plugin's frame number; phip_render_params.sobol_scramble holds what the plugin makes of it (sobol.cpp:92-102) */
     Sampler *s = static_cast<Sampler *>(PluginManager::getInstance()->createObject(MTS_CLASS(Sampler), smp));
     s->configure();
@@ -236,6 +239,23 @@ void ref_add_shape_file(const char *plugin, const char *filename, uint32_t mater
     FileShape f; f.plugin = plugin; f.filename = filename; f.material = material;
     for (int i = 0; i < 16; ++i) f.toWorld[i] = to_world16 ? to_world16[i] : (i % 5 == 0 ? 1.0f : 0.0f);
     g_fileShapes.push_back(f);
+}
+
+/* the data of the radical-inverse samplers (`halton`, `hammersley`): the first `dims` primes of the reference's table (qmc.cpp:27-81) and, for
+   scramble != 0, the digit permutations its own PermutationStorage builds (src/samplers/faure.cpp: -1 = Faure's, any other value = pseudorandom
+   ones), concatenated -- the permutation of dimension d starts at the sum of the primes before it.  perm_out: sum(primes[0..dims)) entries. */
+int ref_qmc_tables(int scramble, uint32_t dims, uint32_t *primes_out, uint16_t *perm_out) {
+    try {
+        if (dims > primeTableSize) throw std::runtime_error("ref_qmc_tables: at most 1024 dimensions");
+        ref<PermutationStorage> ps = scramble != 0 ? new PermutationStorage(scramble) : NULL;
+        size_t off = 0;
+        for (uint32_t d = 0; d < dims; ++d) {
+            primes_out[d] = (uint32_t) primeTable[d];
+            if (ps != NULL && perm_out) memcpy(perm_out + off, ps->getPermutation(d), sizeof(uint16_t) * (size_t) primeTable[d]);
+            off += (size_t) primeTable[d];
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
 /* writes shape `si` of a scene description as a .serialized mesh file -- by the reference's own TriMesh::serialize (trimesh.cpp:1131-1180: header, zlib

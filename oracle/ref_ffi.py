@@ -74,6 +74,7 @@ def lib():
     L.ref_set_analytic_rectangles.argtypes = [C.c_int]
     L.ref_add_shape_file.argtypes = [C.c_char_p, C.c_char_p, u32, fp]
     L.ref_write_serialized.argtypes = [C.POINTER(A.phip_scene_desc), u32, C.c_char_p]
+    L.ref_qmc_tables.argtypes = [C.c_int, u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]
     L.ref_mip_build.restype = C.c_void_p
     L.ref_mip_build.argtypes = [C.c_int, fp, u32, u32, u32, u32, u32, C.c_float]
     L.ref_mip_levels.argtypes = [C.c_void_p]
@@ -122,7 +123,7 @@ class RefScene:
             raise RuntimeError(what + ": " + self.L.ref_last_error().decode())
 
     def _sampler(self, sampler):
-        self.L.ref_set_sampler({"independent": 0, "ctr": 1, "ldsampler": 2, "sobol": 3, "stratified": 4}[sampler])
+        self.L.ref_set_sampler({"independent": 0, "ctr": 1, "ldsampler": 2, "sobol": 3, "stratified": 4, "halton": 5, "hammersley": 6}[sampler])
 
     def render(self, params, want_samples=True, sampler="independent"):
         """sampler="ctr": the reference's integrator fed with the counter-based parity stream (ref_glue/ctr_sampler.cpp: defined by
@@ -262,3 +263,17 @@ def write_serialized(desc, shape, path):
     """shape `shape` of a scene description as a .serialized mesh file, written by the reference's own TriMesh::serialize"""
     if lib().ref_write_serialized(C.byref(desc), int(shape), path.encode()) != 0:
         raise RuntimeError("ref_write_serialized: " + lib().ref_last_error().decode())
+
+
+def qmc_tables(scramble=-1, dimensions=128):
+    """(primes[dimensions], permutations or None) for `default_render_params(qmc=...)`: the reference's prime table and the digit permutations its
+    PermutationStorage builds for `scramble` (-1: Faure's, the samplers' default; 0: none; otherwise pseudorandom ones), read out of the reference"""
+    primes = np.zeros(dimensions, np.uint32)
+    if lib().ref_qmc_tables(0, dimensions, primes.ctypes.data_as(C.POINTER(C.c_uint32)), None) != 0:
+        raise RuntimeError(lib().ref_last_error().decode())
+    if scramble == 0:
+        return primes, None
+    perm = np.zeros(int(primes.sum()), np.uint16)
+    if lib().ref_qmc_tables(int(scramble), dimensions, primes.ctypes.data_as(C.POINTER(C.c_uint32)), perm.ctypes.data_as(C.POINTER(C.c_uint16))) != 0:
+        raise RuntimeError(lib().ref_last_error().decode())
+    return primes, perm

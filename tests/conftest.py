@@ -57,3 +57,13 @@ def sobol_tables(width, height, dimensions=128):
     if m > 1:
         return mat, np.ascontiguousarray(z["vdc"][m - 1]), np.ascontiguousarray(z["vdc_inv"][m - 1]), m
     return mat, np.zeros(52, np.uint64), np.zeros(52, np.uint64), m
+
+
+def qmc_tables(scramble=-1, dimensions=64):
+    """(primes, permutations or None) for `default_render_params(qmc=...)` out of tests/golden/qmc_tables.npz (the reference's prime table and the
+    permutations of its PermutationStorage: Faure's for scramble -1, the pseudorandom ones for scramble 7, none for 0)"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "qmc_tables.npz"))
+    primes = np.ascontiguousarray(z["primes"][:dimensions])
+    if scramble == 0:
+        return primes, None
+    return primes, np.ascontiguousarray(z[{-1: "faure", 7: "random7"}[scramble]][:int(primes.sum())])

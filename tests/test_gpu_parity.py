@@ -612,3 +612,41 @@ def test_sobol_and_stratified_samplers_match_oracle(gpu, phip, oracle, gauss):
     with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 8, sampler=A.PHIP_SAMPLER_STRATIFIED)
     with pytest.raises(PhipError): DirectHIP().render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(32, 32))
     gs.close()
+
+
+def test_halton_and_hammersley_samplers_match_oracle(gpu, phip, oracle, gauss):
+    """PHIP_SAMPLER_HALTON / _HAMMERSLEY (the reference's `halton` / `hammersley` plugins restated: tests/test_ref_pin.py pins the oracle to Mitsuba's own
+    `path` + those plugins): per-sample radiance bit-identical to the oracle -- Faure permutations, none, pseudorandom ones; microfacet, dielectric,
+    environment-map and textured scenes; a film wider than 128 pixels (positions enter modulo 128); progressive passes; the error cases"""
+    import ref_scenes as RS
+    from conftest import qmc_tables
+    from test_golden import _golden_mip, G
+    from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+    from mitsuba_amd._ffi import PhipError
+    fixture = np.load(os.path.join(G, "ref_renders.npz"))
+    for desc, spp, kw, mi in ((S.cornell_box(64, 64, gauss).desc(), 16, dict(maxDepth=10), 1.0), (S.cornell_box(150, 40, gauss).desc(), 5, dict(maxDepth=8, rrDepth=2), 1.0),
+                              (S.glass_room(64, 36, gauss, detail=0.2).desc(), 8, dict(maxDepth=10, rrDepth=3), 0.9999),
+                              (RS.zoo(gauss, None).desc(), 4, dict(maxDepth=8), 0.9999), (S.atrium(64, 36, gauss, detail=0.3).desc(), 4, dict(maxDepth=6), 0.999),
+                              (RS.envmap(gauss, _golden_mip(fixture, "envmap")).desc(), 4, dict(maxDepth=6), 0.999),
+                              (RS.textures(gauss, _golden_mip(fixture, "textures")).desc(), 4, dict(maxDepth=6), 0.999)):
+        for kind in (A.PHIP_SAMPLER_HALTON, A.PHIP_SAMPLER_HAMMERSLEY):
+            for scramble in (-1, 0, 7):
+                compare_render(gpu, oracle, desc, spp, min_identical=mi, render_kw=dict(sampler=kind, qmc=qmc_tables(scramble)), **kw)
+    desc = S.cornell_box(32, 32, gauss).desc()
+    gs = Scene(desc); integ = PathHIP(maxDepth=8)
+    for kind in (A.PHIP_SAMPLER_HALTON, A.PHIP_SAMPLER_HAMMERSLEY):
+        kw = dict(sampler=kind, qmc=qmc_tables(-1))
+        # two passes of 8 of 16 samples = one render of 16 (hammersley: the set is that of the whole render's sample count)
+        whole = HDRFilm(32, 32); assert integ.render(gs, whole, 16, **kw)
+        parts = HDRFilm(32, 32); assert integ.render(gs, parts, 8, sample_offset=0, sample_total=16, **kw)
+        p = integ.params(gs, 8, flags=A.PHIP_FLAG_ACCUMULATE, sample_offset=8, sample_total=16, **kw)
+        acc = parts.storage.copy(); st = A.phip_stats()
+        assert phip.phip_render(gs._h, C.byref(p), acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
+        assert rel_l2(acc, whole.storage) < 1e-6
+        ctr = HDRFilm(32, 32); assert integ.render(gs, ctr, 16)
+        assert 1e-3 < rel_l2(whole.storage, ctr.storage) < 0.3
+        # errors: no tables, rrDepth 1, `direct`
+        with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sampler=kind)
+        with pytest.raises(PhipError): PathHIP(rrDepth=1).render(gs, HDRFilm(32, 32), 16, **kw)
+        with pytest.raises(PhipError): DirectHIP().render(gs, HDRFilm(32, 32), 16, **kw)
+    gs.close()

@@ -423,3 +423,29 @@ def test_stratified_construction_on_the_reference(ref, olibm):
     rs.close()
     print("mean abs error at 16 spp: stratified construction %.3e, the reference's stratified %.3e, independent %.3e" % (mse(ours), mse(own), mse(ind)))
     assert mse(ours) < 1.25 * mse(own) and mse(ours) < mse(ind)
+
+
+def test_halton_and_hammersley_samplers_of_the_reference_are_reproduced_bit_for_bit(ref, olibm):
+    """PHIP_SAMPLER_HALTON / _HAMMERSLEY: the reference's OWN `path` with its OWN `halton` / `hammersley` sampler plugins (Gruenschloss' enumeration of the
+    points per pixel over bases 2 and 3 / of the Hammersley set, the scrambled radical inverses of qmc.cpp:141-166, pixel positions modulo 128, the
+    dimension bookkeeping they share with `sobol`) against the restatement fed with the reference's prime table and the digit permutations of its
+    PermutationStorage as data: every sample bit-identical -- Faure permutations (the default), none, pseudorandom ones; a film wider than 128 pixels"""
+    from conftest import qmc_tables
+    gauss_libm = olibm.gaussian_filter(0.5, libm=True)
+    for name, build, md, spp in (("cornell", lambda: S.cornell_box(24, 20, gauss_libm), 8, 4), ("zoo", lambda: RS.zoo(gauss_libm, None), 8, 4),
+                                 ("glass", lambda: RS.glass(gauss_libm, None), 12, 2), ("envmap", lambda: RS.envmap(gauss_libm, live_mip(ref)), 6, 4),
+                                 ("cornell wide", lambda: S.cornell_box(150, 9, gauss_libm), 5, 3)):
+        desc = build().desc()
+        rs = ref.RefScene(desc); osc = olibm.OracleScene(desc, libm=True)
+        for smp_name, kind in (("halton", A.PHIP_SAMPLER_HALTON), ("hammersley", A.PHIP_SAMPLER_HAMMERSLEY)):
+            for seed, scramble in ((0, -1), (2, 0), (9, 7)):          # (ref_driver passes `seed` on as the plugin's `scramble` property: 0 -> default, n -> n - 2)
+                p = A.default_render_params(spp=spp, max_depth=md, block_size=256, sampler=kind, qmc=ref.qmc_tables(scramble, 256), seed=seed)
+                _, smp = rs.render(p, sampler=smp_name)
+                _, osmp, _ = osc.render(p, want_samples=True)
+                assert smp[..., :3].mean() > 0.01
+                assert (smp.view(np.uint32) == osmp.view(np.uint32)).all(), (name, smp_name, scramble, float((smp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean()))
+        rs.close(); osc.close()
+    # the committed fixture (the GPU box has no reference) holds the same numbers
+    for scramble in (-1, 7, 0):
+        a, b = qmc_tables(scramble), ref.qmc_tables(scramble, 64)
+        assert np.array_equal(a[0], b[0]) and (a[1] is None and b[1] is None or np.array_equal(a[1], b[1]))
