@@ -41,6 +41,9 @@
 #ifndef WIDE_DUMMY_LOADS
 #define WIDE_DUMMY_LOADS 0               /* measurement: extra 16-byte loads of the node's own line per node step (L1 hits): what does one more vector-memory instruction cost? */
 #endif
+#ifndef WIDE_DUMMY_VALU
+#define WIDE_DUMMY_VALU 0                /* measurement: extra VALU instructions per node step (independent v_fma_f32 on a scratch register): what does the ALU work cost? */
+#endif
 #ifndef WIDE_PROFILE
 #define WIDE_PROFILE 0
 #endif
@@ -115,6 +118,12 @@ DV uint32_t wideNodeHits(const uint4 &n0, const uint4 &n1, const uint4 &n2, cons
     const uint32_t lox[2] = { n2.x, n2.y }, loy[2] = { n2.z, n2.w }, loz[2] = { n3.x, n3.y }, hix[2] = { n3.z, n3.w }, hiy[2] = { n4.x, n4.y }, hiz[2] = { n4.z, n4.w };
     const uint32_t meta[2] = { n1.z, n1.w };
     uint32_t hits = 0;
+#if WIDE_DUMMY_VALU && defined(__HIP_DEVICE_COMPILE__)
+    { float dv_ = sx;
+#pragma unroll
+      for (int i_ = 0; i_ < WIDE_DUMMY_VALU; ++i_) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(dv_) : "v"(sy), "v"(sz));
+      asm volatile("" :: "v"(dv_)); }
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #if defined(__HIP_DEVICE_COMPILE__)
