@@ -19,7 +19,7 @@
  */
 
 #ifndef WIDE_STACK_LDS
-#define WIDE_STACK_LDS 12                /* 8-byte entries per lane in LDS (24 KB per block of 256) */
+#define WIDE_STACK_LDS 10                /* 8-byte entries per lane in LDS (20 KB per block of 256) */
 #endif
 #ifndef WIDE_BLOCK
 #define WIDE_BLOCK 256                   /* threads per block of k_rays_w.  Measured (round 2): ONE block of 1024 per CU, whose LDS then holds a single copy of the
@@ -28,9 +28,9 @@
                                             levels are not what the kernel waits for (they hit L2; the Wald records come from the Infinity Cache) */
 #endif
 #ifndef WIDE_NODE_CACHE_MAX
-#define WIDE_NODE_CACHE_MAX 96           /* top-of-tree nodes (BFS order) staged in LDS by k_rays_w: 7.5 KB per block */
+#define WIDE_NODE_CACHE_MAX 64           /* top-of-tree nodes (BFS order) staged in LDS by k_rays_w: 5 KB per block */
 #endif
-#define WIDE_NODE_CACHE_RAYCAST 96       /* ... by k_raycast_w (blocks of 256, several per CU) */
+#define WIDE_NODE_CACHE_RAYCAST 64       /* ... by k_raycast_w (blocks of 256, several per CU) */
 #ifndef WIDE_TYPED
 #define WIDE_TYPED 1                     /* cached nodes are read with ds_read_b128 (LDS pipe) instead of flat_load (which sends LDS addresses through the
                                             texture addresser / data path the kernel is bound by: TD busy 95 %, round-2 counters) */
@@ -48,7 +48,7 @@
 #define WIDE_PROFILE 0
 #endif
 #ifndef WIDE_WAVES
-#define WIDE_WAVES 4                     /* waves per SIMD of k_rays_w: 112 VGPRs, no scratch.  Measured (C3 / C4 ray-kernel ms per frame): 4 waves 256.7 / 520 --
+#define WIDE_WAVES 6                     /* waves per SIMD of k_rays_w: 112 VGPRs, no scratch.  Measured (C3 / C4 ray-kernel ms per frame): 4 waves 256.7 / 520 --
                                             5 waves (96 VGPRs + 84 B of scratch in the refill path) 254.6 / 532 with a 64-node cache, and a disaster
                                             (391 / 813) once the cache no longer let five blocks fit a CU -- see residentBlocks() in phip.hip */
 #endif
@@ -58,20 +58,32 @@ typedef __attribute__((address_space(3))) u2v lds_u2;
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u4v lds_cu4;
 
+/* The stack keeps ONE per-lane register, sp.  Its addresses -- LDS entry e of thread t at (e * NB + t) * 8, spill entry at
+   spillBlock[t * SPILL_DEPTH / 2 + e] -- are rebuilt from the lane index at every push / pop (v_mbcnt, two instructions): the LDS
+   base and the 64-bit spill pointer used to be three VGPRs that lived across the whole persistent loop, in a kernel whose
+   occupancy is decided by its VGPR count (k_rays_w: WIDE_WAVES).  The asm is volatile so that the compiler does not hoist the
+   lane index back out of the loop. */
 template <int NB> struct WideStackT {
-    lds_u2 *lds;            /* LDS base + threadIdx.x: entry e at lds[e * NB] (NB = threads per block) */
-    uint2 *spill;           /* global: SPILL_DEPTH / 2 entries per lane (the BVH4 kernels' region, reinterpreted) */
+    lds_u2 *ldsBlock;       /* LDS: the block's stack region (wave-uniform) */
+    uint2 *spillBlock;      /* global: the block's spill region, SPILL_DEPTH / 2 entries per lane (the BVH4 kernels' region, reinterpreted) */
     lds_cu4 *nodes;         /* LDS copy of wide nodes [0, nodeCache) */
     uint32_t nodeCache;
+    uint32_t waveBase;      /* first thread of this wave in the block (wave-uniform) */
     int sp;
+    __device__ __forceinline__ uint32_t tid() const {
+        uint32_t l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return waveBase + l;
+    }
     __device__ __forceinline__ void push(uint2 v) {
-        if (sp < WIDE_STACK_LDS) { u2v t; t.x = v.x; t.y = v.y; lds[sp * NB] = t; } else spill[sp - WIDE_STACK_LDS] = v;
+        if (sp < WIDE_STACK_LDS) { u2v t; t.x = v.x; t.y = v.y; ldsBlock[(uint32_t) sp * NB + tid()] = t; }
+        else spillBlock[(size_t) tid() * (SPILL_DEPTH / 2) + (uint32_t) (sp - WIDE_STACK_LDS)] = v;
         ++sp;
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
-        if (sp < WIDE_STACK_LDS) { const u2v t = lds[sp * NB]; return make_uint2(t.x, t.y); }
-        return spill[sp - WIDE_STACK_LDS];
+        if (sp < WIDE_STACK_LDS) { const u2v t = ldsBlock[(uint32_t) sp * NB + tid()]; return make_uint2(t.x, t.y); }
+        return spillBlock[(size_t) tid() * (SPILL_DEPTH / 2) + (uint32_t) (sp - WIDE_STACK_LDS)];
     }
 };
 
@@ -83,12 +95,13 @@ __host__ __device__ __forceinline__ size_t wideLdsBytes(uint32_t nodeCache, uint
 __host__ __device__ __forceinline__ uint32_t wideRaycastCache(uint32_t nodeCache) { return nodeCache < WIDE_NODE_CACHE_RAYCAST ? nodeCache : WIDE_NODE_CACHE_RAYCAST; }
 
 /* carve the block's dynamic LDS and stage the top of the tree (all threads of the block must call) */
-template <int NB> __device__ __forceinline__ void setupWide(const DevScene &S, uint32_t nodeCache, unsigned char *smem, uint32_t *spill, WideStackT<NB> &stk) {
+template <int NB> __device__ __forceinline__ void setupWide(const DevScene &S, uint32_t nodeCache, unsigned char *smem, uint32_t *spillBlock /* of this BLOCK's first thread */, WideStackT<NB> &stk) {
     uint2 *stack = (uint2 *) smem;
     uint4 *ln = (uint4 *) (smem + (size_t) WIDE_STACK_LDS * NB * sizeof(uint2));
     for (uint32_t i = threadIdx.x; i < nodeCache * 5u; i += NB) ln[i] = S.wnodes[(i / 5u) * WIDE_NODE_STRIDE + i % 5u];
     __syncthreads();
-    stk.lds = (lds_u2 *) (stack + threadIdx.x); stk.spill = (uint2 *) spill; stk.nodes = (lds_cu4 *) ln; stk.nodeCache = nodeCache; stk.sp = 0;
+    stk.ldsBlock = (lds_u2 *) stack; stk.spillBlock = (uint2 *) spillBlock; stk.nodes = (lds_cu4 *) ln; stk.nodeCache = nodeCache; stk.sp = 0;
+    stk.waveBase = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x & ~63u));
 }
 
 struct WideRay {
@@ -242,6 +255,10 @@ __device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, con
 #ifndef RAY_STATIC_PERCENT
 #define RAY_STATIC_PERCENT 60            /* share of a launch's work units dealt statically (wave w: units w, w + W, ...) before the waves draw from the counters */
 #endif
+/* The source state of a wave (which chunk, how far into it, the draw counters' bookkeeping) is wave-uniform, but derives from
+   threadIdx, returning atomics and vector loads of uniform addresses -- values the compiler must assume divergent, so it kept a dozen
+   of them in VGPRs across the traversal loop.  readfirstlane pins them to SGPRs. */
+#define WIDE_UNIFORM(x) ((uint32_t) __builtin_amdgcn_readfirstlane((int) (x)))
 struct DrawCounter {
     unsigned int *ctr;                   /* RAY_SHARDS counters (zeroed before the launch) */
     uint32_t shard0, tried, perShard, total;
@@ -253,7 +270,7 @@ struct DrawCounter {
     __device__ __forceinline__ void init(unsigned int *c, uint32_t shard, uint32_t totalUnits, uint32_t waveId, uint32_t nWavesGrid) {
         ctr = c; shard0 = shard; tried = 0; total = totalUnits;
         nStatic = (uint32_t) ((unsigned long long) totalUnits * RAY_STATIC_PERCENT / 100u) / nWavesGrid * nWavesGrid;
-        sNext = waveId; sStride = nWavesGrid;
+        sNext = WIDE_UNIFORM(waveId); sStride = nWavesGrid;      /* (waveId comes from threadIdx: the compiler cannot know it is wave-uniform) */
         perShard = (total - nStatic + RAY_SHARDS - 1) / RAY_SHARDS;
     }
     /* next unit of this wave (wave-uniform), or 0xFFFFFFFF when there is none left */
@@ -263,7 +280,7 @@ struct DrawCounter {
             const uint32_t s = (shard0 + tried) % RAY_SHARDS;
             uint32_t c = 0;
             if (__lane_id() == 0) c = atomicAdd(ctr + (size_t) s * RAY_SHARD_STRIDE, 1u);
-            c = __builtin_amdgcn_readfirstlane(c);
+            c = WIDE_UNIFORM(c);
             const uint32_t first = nStatic + s * perShard, n = first >= total ? 0u : (total - first < perShard ? total - first : perShard);
             if (c < n) return first + c;
             ++tried;                     /* this shard is used up: for good */
@@ -276,12 +293,12 @@ struct DrawCounter {
    (DevScene::preclip, k_clip.h): (o, mint' | d, maxt'), maxt' < mint' = the ray misses the scene box */
 struct TraceSourceDyn {
     const PathPool &P; DrawCounter q; uint32_t chunk, pos;
-    __device__ __forceinline__ void start() { chunk = q.draw(); pos = 0; }
+    __device__ __forceinline__ void start() { chunk = WIDE_UNIFORM(q.draw()); pos = 0; }
     __device__ __forceinline__ bool more() const { return chunk != 0xFFFFFFFFu; }
     __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
         const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
         const uint32_t h = (want && idx < 64u && chunk * 64u + idx < P.capacity) ? chunk * 64u + idx : INVALID_RAY;
-        pos += (uint32_t) __popcll(wantMask);
+        pos = WIDE_UNIFORM(pos + (uint32_t) __popcll(wantMask));
         if (pos >= 64u) start();
         return h;
     }
@@ -293,7 +310,7 @@ struct TraceSourceDyn {
         return (st & F_TRACE_MASK) == F_ALIVE;
     }
     __device__ __forceinline__ void commit(uint32_t slot, bool, const TravResult &r) const {
-        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim == PHIP_NO_HIT ? r.prim : (r.prim | (r.cls << HIT_CLASS_SHIFT))));
+        P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));      /* r.prim = the packed hit word: bits(prim) | shade class << 30 (k_pool.h) */
     }
 };
 
@@ -302,9 +319,9 @@ struct ShadowSourceDyn {
     const PathPool &P; float4 *L; DrawCounter q; uint32_t blk, pos, cnt;
     __device__ __forceinline__ void start() {
         for (;;) {
-            blk = q.draw(); pos = 0; cnt = 0;
+            blk = WIDE_UNIFORM(q.draw()); pos = 0; cnt = 0;
             if (blk == 0xFFFFFFFFu) return;
-            cnt = P.shadowCount[blk];
+            cnt = WIDE_UNIFORM(P.shadowCount[blk]);      /* (a vector load of a uniform address: the value is uniform, the register is not) */
             if (cnt) return;
         }
     }
@@ -312,7 +329,7 @@ struct ShadowSourceDyn {
     __device__ __forceinline__ uint32_t assign(bool want, unsigned long long wantMask) {
         const uint32_t idx = pos + (uint32_t) __popcll(wantMask & ((1ull << __lane_id()) - 1ull));
         const uint32_t h = (want && idx < cnt) ? blk * BLOCK + idx : INVALID_RAY;
-        pos += (uint32_t) __popcll(wantMask);
+        pos = WIDE_UNIFORM(pos + (uint32_t) __popcll(wantMask));
         if (pos >= cnt) start();
         return h;
     }
@@ -340,6 +357,83 @@ __device__ __forceinline__ float slabRcpFast(float d) { return slabRcpFrom(d, __
 enum { WW_RAYS = 0, WW_STEPS, WW_SH_RAYS, WW_SH_STEPS, WW_COUNT };     /* 64-bit LDS counters of a wave: rays, node steps | triangle tests << 32 */
 #define WM_HANDLE 0x0FFFFFFFu
 #define WM_SHADOW 0x80000000u
+#ifndef WIDE_FLAT
+#define WIDE_FLAT 1                      /* ONE loop (refill test, then one traversal iteration of the live lanes) instead of a traversal loop nested in a refill loop */
+#endif
+#if WIDE_FLAT
+/* The loop is flat: every pass tests the refill condition (two scalar instructions on the ballot of the idle lanes) and then runs one
+   traversal iteration -- one node step, one triangle test, one pop -- for the lanes that have a ray.  The nested form (an inner loop the
+   live lanes stay in until enough of them have finished) made the compiler keep two register images of the lane state, one per loop,
+   and copy between them at every entry and exit; flat, the state has one home and the kernel fits 96 VGPRs (5 waves per SIMD)
+   without spilling. */
+__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStackT<WIDE_BLOCK> &stack, ShadowSourceDyn &ss, TraceSourceDyn &ts,
+                                                       unsigned long long *wc /* LDS: WC_COUNT counters of this wave */) {
+    bool active = false, shadow = false;
+    uint32_t handle = 0, steps = 0;
+    WideRay ray; ray.o = ray.d = ray.rcp = V3(0.0f); ray.mint = ray.maxt = 0; ray.octinv4 = 0;
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const bool moreS = ss.more(), moreAny = moreS || ts.more();              /* wave-uniform */
+        if (moreAny) {
+            if (__popcll(idle) >= REFILL_LANES) {
+                const uint32_t h = moreS ? ss.assign(!active, idle) : ts.assign(!active, idle);
+                if (!active && h != INVALID_RAY) {
+                    V3 o, d; float mint, maxt;                   /* (already clipped to the scene box) */
+                    const bool ok = moreS ? ss.load(h, o, d, mint, maxt) : ts.load(h, o, d, mint, maxt);
+                    if (ok) {
+                        const unsigned long long got = __ballot(1);
+                        if (__lane_id() == (uint32_t) __ffsll((long long) got) - 1u) wc[moreS ? WW_SH_RAYS : WW_RAYS] += (uint32_t) __popcll(got);
+                        res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+                        if (maxt > mint) {
+                            wideRaySetup(ray, o, d, V3(slabRcpFast(d.x), slabRcpFast(d.y), slabRcpFast(d.z)), mint, maxt);
+                            ng = wideRootGroup(); tg = make_uint2(0u, 0u);
+                            stack.sp = 0; handle = h; shadow = moreS; active = true; steps = 0;
+                        } else if (moreS) {
+                            ss.commit(h, false, res);
+                        } else {
+                            ts.commit(h, false, res);
+                        }
+                    }
+                }
+            }
+        } else if (idle == ~0ull) break;
+        if (active) {
+            /* one node step and one triangle test per iteration */
+            if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps)
+            bool finished = false;
+            if (tg.y) {
+                const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;
+                tg.y &= tg.y - 1u;
+                WIDE_LOAD_TRI(S, tg.x + bit, a, b, c)
+                steps += 0x10000u;
+                float tu, tv, tt;
+                if (waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {
+                    if (shadow) { res.prim = 0; finished = true; }
+                    else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim & HIT_PRIM_MASK)) {      /* (res.prim is the packed hit word: one register for primitive and class) */
+                        ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z) | (pm_to_bits(c.w) << HIT_CLASS_SHIFT);
+                    }
+                }
+            }
+            if (!finished && tg.y == 0u && !(ng.y & 0xff000000u)) {
+                if (stack.sp == 0) finished = true;
+                else {
+                    const uint2 e = stack.pop();
+                    if (e.y & 0xff000000u) ng = e; else { tg = e; ng = make_uint2(0u, 0u); }
+                }
+            }
+            if (finished) {
+                if (shadow) ss.commit(handle, res.prim != PHIP_NO_HIT, res);
+                else ts.commit(handle, false, res);
+                /* node steps (low word) and triangle tests (high word) of the ray in ONE 64-bit LDS add */
+                atomicAdd(&wc[shadow ? WW_SH_STEPS : WW_STEPS], (unsigned long long) (steps & 0xFFFFu) | ((unsigned long long) (steps >> 16) << 32));
+                active = false;
+            }
+        }
+    }
+}
+#else
 __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStackT<WIDE_BLOCK> &stack, ShadowSourceDyn &ss, TraceSourceDyn &ts,
                                                        unsigned long long *wc /* LDS: WC_COUNT counters of this wave */) {
     bool active = false;
@@ -373,7 +467,7 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                 if (ok) {
                     const unsigned long long got = __ballot(1);
                     if (__lane_id() == (uint32_t) __ffsll((long long) got) - 1u) wc[moreS ? WW_SH_RAYS : WW_RAYS] += (uint32_t) __popcll(got);
-                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0; res.cls = 0;
+                    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
                     if (maxt > mint) {
                         wideRaySetup(ray, o, d, V3(slabRcpFast(d.x), slabRcpFast(d.y), slabRcpFast(d.z)), mint, maxt);
                         ng = wideRootGroup(); tg = make_uint2(0u, 0u);
@@ -406,7 +500,9 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                     float tu, tv, tt;
                     if (waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {
                         if (meta & WM_SHADOW) { res.prim = 0; finished = true; }
-                        else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim)) { ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z); res.cls = pm_to_bits(c.w); }
+                        else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim & HIT_PRIM_MASK)) {      /* (res.prim is the packed hit word: one register for primitive and class) */
+                            ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z) | (pm_to_bits(c.w) << HIT_CLASS_SHIFT);
+                        }
                     }
                 }
                 if (!finished && tg.y == 0u && !(ng.y & 0xff000000u)) {
@@ -441,11 +537,13 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
 #endif
 }
 
+#endif  /* WIDE_FLAT */
+
 __global__ __launch_bounds__(WIDE_BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, PathPool P, float4 *L, unsigned int *drawCounters /* 2 * RAY_SHARDS lines, zeroed */) {
     __shared__ unsigned long long wcnt[WIDE_BLOCK / 64][WW_COUNT];
-    const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * WIDE_BLOCK + threadIdx.x) >> 6;
+    const uint32_t wave = WIDE_UNIFORM(threadIdx.x >> 6), waveId = blockIdx.x * (WIDE_BLOCK / 64) + wave;
     if (threadIdx.x < (WIDE_BLOCK / 64) * WW_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
-    WideStackT<WIDE_BLOCK> stk; setupWide<WIDE_BLOCK>(S, S.wideNodeCache, g_smem, P.spill + (size_t) (blockIdx.x * WIDE_BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
+    WideStackT<WIDE_BLOCK> stk; setupWide<WIDE_BLOCK>(S, S.wideNodeCache, g_smem, P.spill + (size_t) blockIdx.x * WIDE_BLOCK * SPILL_DEPTH, stk);   /* (barrier inside) */
     const uint32_t nBlk = P.capacity / BLOCK, nChunk = (P.capacity + 63u) / 64u, nWavesGrid = gridDim.x * (WIDE_BLOCK / 64);
     ShadowSourceDyn ss{ P, L, {}, 0u, 0u, 0u };
     TraceSourceDyn ts{ P, {}, 0u, 0u };
@@ -466,7 +564,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, P
 /* standalone ray casts for phip_trace on the wide tree */
 __global__ __launch_bounds__(BLOCK) void k_raycast_w(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
     const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
-    WideStack stk; setupWide<BLOCK>(S, wideRaycastCache(S.wideNodeCache), g_smem, P.spill + i * SPILL_DEPTH, stk);
+    WideStack stk; setupWide<BLOCK>(S, wideRaycastCache(S.wideNodeCache), g_smem, P.spill + (size_t) blockIdx.x * BLOCK * SPILL_DEPTH, stk);
     uint32_t nodeVisits = 0, triTests = 0, shNodeVisits = 0, shTriTests = 0;
     if (i < n) {
         const phip_ray ry = rays[i];
