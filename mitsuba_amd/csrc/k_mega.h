@@ -39,7 +39,8 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
     float4 *ldsTriShade = (float4 *) (g_smem + traversalLdsBytesOf(S));
     float *ldsEm = (float *) (ldsTriShade + (size_t) S.nTriangles * TRISHADE_FLOAT4S);
     DevMaterial *ldsMat = (DevMaterial *) (ldsEm + ((S.emitterTabSize + 3u) & ~3u));
-    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    uint32_t noPin = 0;
+    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat, noPin);
     /* the host chose this kernel because every table fits (phip.hip: fitsLds): no run-time choice between the LDS copy and HBM, so that
        the compiler can address the tables as LDS (ds_read) instead of through flat loads, which occupy the texture addresser */
     tab.T.t = ldsEm; tab.materials = ldsMat;

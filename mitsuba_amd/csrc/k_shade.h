@@ -417,13 +417,31 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
 /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
    dependent lookups per NEE sample) and the materials (all threads of the block must call; no barrier inside) */
 struct ShadeTables { EmitterTab T; const DevMaterial *materials; };
-__device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float *ldsEm, DevMaterial *ldsMat) {
+__device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float *ldsEm, DevMaterial *ldsMat, uint32_t &pinned /* a scalar the caller has just loaded: pinned with the tables */) {
     const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
-    if (emInLds) for (uint32_t i = threadIdx.x; i < S.emitterTabSize; i += BLOCK) ldsEm[i] = S.emitterTab[i];
-    if (matInLds) {
-        const uint32_t n4 = S.nMaterials * (uint32_t) (sizeof(DevMaterial) / 16);
-        for (uint32_t i = threadIdx.x; i < n4; i += BLOCK) ((float4 *) ldsMat)[i] = ((const float4 *) S.materials)[i];
-    }
+    /* Both tables are requested before either is stored: ONE memory round trip at the head of a block (the kernels that call this are
+       latency bound), not one per table and per loop iteration.  A thread covers the whole staged range with one float4 of the emitter
+       table (the host pads it to whole float4s; EMITTER_LDS_FLOATS / 4 = BLOCK) and MAT_F4 of the materials. */
+    constexpr uint32_t MAT_F4 = (MATERIAL_LDS_MAX * (uint32_t) (sizeof(DevMaterial) / 16) + BLOCK - 1) / BLOCK;
+    static_assert(EMITTER_LDS_FLOATS / 4 <= BLOCK, "one float4 of the emitter table per thread");
+    const uint32_t nE4 = emInLds ? S.emitterTabSize / 4u : 0u, nM4 = matInLds ? S.nMaterials * (uint32_t) (sizeof(DevMaterial) / 16) : 0u;
+    /* branch-free: every thread loads (a clamped index, a valid address even for an empty table) and only the stores are predicated --
+       predicated loads compile to one skipped block and one wait each */
+    const float4 *srcE = nE4 ? (const float4 *) S.emitterTab : (const float4 *) S.triShade;
+    const float4 *srcM = nM4 ? (const float4 *) S.materials : (const float4 *) S.triShade;
+    const uint32_t lastE = nE4 ? nE4 - 1u : 0u, lastM = nM4 ? nM4 - 1u : 0u;
+    float4 m[MAT_F4];
+    float4 e = srcE[threadIdx.x < lastE ? threadIdx.x : lastE];
+#pragma unroll
+    for (uint32_t j = 0; j < MAT_F4; ++j) { const uint32_t i = threadIdx.x + j * BLOCK; m[j] = srcM[i < lastM ? i : lastM]; }
+    /* the values are "used" HERE, all at once: without this the compiler sinks every load into the predicated block of its store (load,
+       wait, store -- one round trip per table) and issues the caller's scalar load behind them */
+    static_assert(MAT_F4 == 2, "the pin below names m[0] and m[1]");
+    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w), "+v"(m[0].x), "+v"(m[0].y), "+v"(m[0].z), "+v"(m[0].w),
+                      "+v"(m[1].x), "+v"(m[1].y), "+v"(m[1].z), "+v"(m[1].w), "+s"(pinned));
+    if (threadIdx.x < nE4) ((float4 *) ldsEm)[threadIdx.x] = e;
+#pragma unroll
+    for (uint32_t j = 0; j < MAT_F4; ++j) if (threadIdx.x + j * BLOCK < nM4) ((float4 *) ldsMat)[threadIdx.x + j * BLOCK] = m[j];
     ShadeTables t;
     t.T.t = emInLds ? ldsEm : S.emitterTab; t.T.n = S.nEmitters; t.T.normalization = S.emitterNormalization;
     t.materials = matInLds ? ldsMat : S.materials;
@@ -432,15 +450,14 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
 
 template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : ((FEAT & 3) == 0 ? SHADE_WAVES_PLAIN : SHADE_WAVES)) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
-    if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
-    if (FEAT & 4) { tab.T.t = ldsEm; tab.materials = ldsMat; }     /* the host checked that both tables fit: LDS addressing (ds_read), no flat loads */
+    /* The kernel is latency bound (two thirds of its wave cycles are s_waitcnt), so the head of a block is ONE round trip: the slot
+       state (five 16-byte loads and a word), the block's retired flag and the tables staged in LDS are all requested before anything
+       waits.  (Round 3 found the order flag -> branch -> table loop -> wait -> remainder loop -> wait -> materials -> wait -> state: five
+       dependent round trips before the first useful instruction.) */
     uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     bool inRange = slot < P.capacity;
-    /* all slot state is fetched up front, before the liveness test, so that the five 16-byte loads are
-       in flight together (the kernel is latency bound: 70 % of its wave cycles were s_waitcnt) */
     uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
     info.w = P.state[lslot];
@@ -449,6 +466,10 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
     v.rayD = P.rayD[lslot];
     v.thr = P.thr[lslot];
     v.mis = P.mis[lslot];
+    uint32_t retired = P.blockDead[blockIdx.x];                 /* (block-uniform) */
+    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat, retired);
+    if (FEAT & 4) { tab.T.t = ldsEm; tab.materials = ldsMat; }     /* the host checked that both tables fit: LDS addressing (ds_read), no flat loads */
+    if (retired) return;
     if (MM != 0 && SHADE_SORT && S.shadeSort) {                 /* (block-uniform) */
         /* Scenes with more than one BSDF model: on the atrium 8 % of the vertices lie on copper, so nearly every wave ran the
            microfacet code -- the longest branch of the vertex by far -- for its two or three conductor lanes (round 2: lane

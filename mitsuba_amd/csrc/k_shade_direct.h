@@ -15,22 +15,24 @@
 template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade_direct(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0;
     __shared__ uint32_t waveCnt[BLOCK / 64];
-    if (P.blockDead[blockIdx.x]) return;                        /* (block-uniform) */
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
-    const EmitterTab &T = tab.T;
-    const DevMaterial *materials = tab.materials;
+    /* slot state, the block's retired flag and the LDS tables in ONE round trip (see k_shade) */
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
     const uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
     info.w = P.state[lslot];
     float4 hit = P.hit[lslot];
-    hit.w = pm_from_bits(hitPrim(pm_to_bits(hit.w)));           /* (class bits of k_rays_w: k_pool.h) */
     const float4 rd = P.rayD[lslot];
     const float4 thr4 = P.thr[lslot];
     float4 camHit = P.camHit[lslot];
+    uint32_t retired = P.blockDead[blockIdx.x];                 /* (block-uniform) */
+    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat, retired);
+    const EmitterTab &T = tab.T;
+    const DevMaterial *materials = tab.materials;
+    if (retired) return;
+    hit.w = pm_from_bits(hitPrim(pm_to_bits(hit.w)));           /* (class bits of k_rays_w: k_pool.h) */
     if (!inRange) info = make_uint4(0, 0, 0, 0);
     __syncthreads();                                            /* LDS tables are complete */
     const bool alive = inRange && (info.w & F_ALIVE);

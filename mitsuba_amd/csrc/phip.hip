@@ -564,6 +564,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         }
     }
     if (tab.size() >= (1ull << 31)) throw std::runtime_error("emitter table too large");
+    tab.resize((tab.size() + 3) / 4 * 4, 0.0f);              /* whole float4s: the shading kernels stage the table in LDS with 16-byte loads */
     sd.emitterTab.upload(tab.data(), tab.size());
 
     DevScene &D = sd.dev;
