@@ -628,7 +628,6 @@ inline void buildWide(HostBVH &out, int32_t root2, const detail::Box &rootBox, C
     queue.push_back({ root2, 0u, 1u, rootBox });
     out.nWNodes = 1;
     double cost = 0; const double rootA = rootBox.area() > 0 ? rootBox.area() : 1.0;
-    auto slotsOf = [](int32_t ref) -> int { if (ref >= 0) return 1; const uint32_t cnt = ((~(uint32_t) ref) & 7u) + 1u; return (int) ((cnt + 2) / 3); };
     for (size_t head = 0; head < queue.size(); ++head) {
         const Item it = queue[head];
         out.wMaxDepth = std::max(out.wMaxDepth, it.depth);

@@ -39,8 +39,7 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
     float4 *ldsTriShade = (float4 *) (g_smem + traversalLdsBytesOf(S));
     float *ldsEm = (float *) (ldsTriShade + (size_t) S.nTriangles * TRISHADE_FLOAT4S);
     DevMaterial *ldsMat = (DevMaterial *) (ldsEm + ((S.emitterTabSize + 3u) & ~3u));
-    uint32_t noPin = 0;
-    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat, noPin);
+    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
     /* the host chose this kernel because every table fits (phip.hip: fitsLds): no run-time choice between the LDS copy and HBM, so that
        the compiler can address the tables as LDS (ds_read) instead of through flat loads, which occupy the texture addresser */
     tab.T.t = ldsEm; tab.materials = ldsMat;
@@ -51,8 +50,7 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
     S.triShade = ldsTriShade;                                   /* (generic pointer into LDS: six loads per vertex, not the inner loop) */
     TravStack stk; setupTraversal(S, g_smem, nullptr, stk);     /* stack + all nodes + all Wald records in LDS (barrier inside); the host checked that nothing can spill */
 
-    const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = __lane_id();
-    const unsigned long long laneBit = 1ull << lane;
+    const uint32_t waveId = blockIdx.x * (BLOCK / 64) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = __lane_id();
     unsigned long long next = 0, end = 0;                       /* the wave's chunk of sample ids (wave-uniform) */
     bool exhausted = rc.totalIds == 0;
 
@@ -76,7 +74,9 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
         ++pfIter;
 #endif
         { PF_BEGIN
+#if MEGA_PROFILE
         const unsigned long long pfWant_ = __ballot(!alive);
+#endif
         /* ---- regeneration: lanes without a path start the next camera sample (integrator.cpp:157-183) ---- */
         for (;;) {
             const unsigned long long want = __ballot(!alive);
@@ -102,7 +102,7 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
                 end = next + chunk; if (end > rc.totalIds) end = rc.totalIds;
                 if (next >= end) { exhausted = true; break; }
             }
-            const uint32_t rank = (uint32_t) __popcll(want & (laneBit - 1ull));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) want, 0u));
             const unsigned long long id = next + rank;
             if (!alive && id < end) {
                 uint32_t px, py, k;

@@ -103,6 +103,7 @@ struct RenderConst {
     uint32_t envFiltered;             /* camera rays that miss use the envmap's EWA lookup (pyramid present) */
     const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
     uint32_t countAlive;              /* this iteration records the number of live slots */
+    uint32_t draining;                /* some slots of the pool have died (the host has seen a live count below the capacity): the shading kernels test their block's retired flag before anything else */
     unsigned long long staticIds;     /* ids [0, staticIds) follow the static slot schedule, the rest is handed out dynamically */
     unsigned long long shardIds;      /* dynamic ids per counter shard */
     unsigned long long *dynCounter;   /* DYN_SHARDS counters, one 128-byte line each */

@@ -417,7 +417,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
 /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
    dependent lookups per NEE sample) and the materials (all threads of the block must call; no barrier inside) */
 struct ShadeTables { EmitterTab T; const DevMaterial *materials; };
-__device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float *ldsEm, DevMaterial *ldsMat, uint32_t &pinned /* a scalar the caller has just loaded: pinned with the tables */) {
+__device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float *ldsEm, DevMaterial *ldsMat) {
     const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
     /* Both tables are requested before either is stored: ONE memory round trip at the head of a block (the kernels that call this are
        latency bound), not one per table and per loop iteration.  A thread covers the whole staged range with one float4 of the emitter
@@ -435,10 +435,10 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
 #pragma unroll
     for (uint32_t j = 0; j < MAT_F4; ++j) { const uint32_t i = threadIdx.x + j * BLOCK; m[j] = srcM[i < lastM ? i : lastM]; }
     /* the values are "used" HERE, all at once: without this the compiler sinks every load into the predicated block of its store (load,
-       wait, store -- one round trip per table) and issues the caller's scalar load behind them */
+       wait, store -- one round trip per table) */
     static_assert(MAT_F4 == 2, "the pin below names m[0] and m[1]");
     asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w), "+v"(m[0].x), "+v"(m[0].y), "+v"(m[0].z), "+v"(m[0].w),
-                      "+v"(m[1].x), "+v"(m[1].y), "+v"(m[1].z), "+v"(m[1].w), "+s"(pinned));
+                      "+v"(m[1].x), "+v"(m[1].y), "+v"(m[1].z), "+v"(m[1].w));
     if (threadIdx.x < nE4) ((float4 *) ldsEm)[threadIdx.x] = e;
 #pragma unroll
     for (uint32_t j = 0; j < MAT_F4; ++j) if (threadIdx.x + j * BLOCK < nM4) ((float4 *) ldsMat)[threadIdx.x + j * BLOCK] = m[j];
@@ -453,9 +453,10 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
     /* The kernel is latency bound (two thirds of its wave cycles are s_waitcnt), so the head of a block is ONE round trip: the slot
-       state (five 16-byte loads and a word), the block's retired flag and the tables staged in LDS are all requested before anything
-       waits.  (Round 3 found the order flag -> branch -> table loop -> wait -> remainder loop -> wait -> materials -> wait -> state: five
+       state (five 16-byte loads and a word) and the tables staged in LDS are all requested before anything waits; the block's retired
+       flag is looked at only while the pass drains (before that no block can have retired).  (Round 3 found the order flag -> branch -> table loop -> wait -> remainder loop -> wait -> materials -> wait -> state: five
        dependent round trips before the first useful instruction.) */
+    if (rc.draining && P.blockDead[blockIdx.x]) return;         /* (block-uniform; the flag costs a scalar round trip, paid only while the pass drains: rc.draining is a kernel argument) */
     uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     bool inRange = slot < P.capacity;
     uint32_t lslot = inRange ? slot : 0u;
@@ -466,10 +467,8 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
     v.rayD = P.rayD[lslot];
     v.thr = P.thr[lslot];
     v.mis = P.mis[lslot];
-    uint32_t retired = P.blockDead[blockIdx.x];                 /* (block-uniform) */
-    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat, retired);
+    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
     if (FEAT & 4) { tab.T.t = ldsEm; tab.materials = ldsMat; }     /* the host checked that both tables fit: LDS addressing (ds_read), no flat loads */
-    if (retired) return;
     if (MM != 0 && SHADE_SORT && S.shadeSort) {                 /* (block-uniform) */
         /* Scenes with more than one BSDF model: on the atrium 8 % of the vertices lie on copper, so nearly every wave ran the
            microfacet code -- the longest branch of the vertex by far -- for its two or three conductor lanes (round 2: lane

@@ -17,7 +17,8 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
     __shared__ uint32_t waveCnt[BLOCK / 64];
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    /* slot state, the block's retired flag and the LDS tables in ONE round trip (see k_shade) */
+    if (rc.draining && P.blockDead[blockIdx.x]) return;         /* (block-uniform; see k_shade) */
+    /* slot state and the LDS tables in ONE round trip (see k_shade) */
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool inRange = slot < P.capacity;
     const uint32_t lslot = inRange ? slot : 0u;
@@ -27,11 +28,9 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
     const float4 rd = P.rayD[lslot];
     const float4 thr4 = P.thr[lslot];
     float4 camHit = P.camHit[lslot];
-    uint32_t retired = P.blockDead[blockIdx.x];                 /* (block-uniform) */
-    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat, retired);
+    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
     const EmitterTab &T = tab.T;
     const DevMaterial *materials = tab.materials;
-    if (retired) return;
     hit.w = pm_from_bits(hitPrim(pm_to_bits(hit.w)));           /* (class bits of k_rays_w: k_pool.h) */
     if (!inRange) info = make_uint4(0, 0, 0, 0);
     __syncthreads();                                            /* LDS tables are complete */

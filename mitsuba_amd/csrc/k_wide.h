@@ -25,7 +25,8 @@
 #define WIDE_BLOCK 256                   /* threads per block of k_rays_w.  Measured (round 2): ONE block of 1024 per CU, whose LDS then holds a single copy of the
                                             top 800 nodes (the first four levels) instead of four copies of 96, changes nothing -- C3 405.7 vs 406.3 Msamples/s,
                                             C4 436 vs 438, and the same again with the cache cut back to 96, 300 or 585 nodes: the node fetches of the upper
-                                            levels are not what the kernel waits for (they hit L2; the Wald records come from the Infinity Cache) */
+                                            levels are not what the kernel waits for (they hit L2; the Wald records come from the Infinity Cache).  Round 3, at 6 waves
+                                            per SIMD: blocks of 512 with a 150-node cache / of 768 with 240 nodes: 159.5 / 158.6 ms vs 158.8 (C3) -- still nothing */
 #endif
 #ifndef WIDE_NODE_CACHE_MAX
 #define WIDE_NODE_CACHE_MAX 64           /* top-of-tree nodes (BFS order) staged in LDS by k_rays_w: 5 KB per block */
@@ -48,9 +49,14 @@
 #define WIDE_PROFILE 0
 #endif
 #ifndef WIDE_WAVES
-#define WIDE_WAVES 6                     /* waves per SIMD of k_rays_w: 112 VGPRs, no scratch.  Measured (C3 / C4 ray-kernel ms per frame): 4 waves 256.7 / 520 --
-                                            5 waves (96 VGPRs + 84 B of scratch in the refill path) 254.6 / 532 with a 64-node cache, and a disaster
-                                            (391 / 813) once the cache no longer let five blocks fit a CU -- see residentBlocks() in phip.hip */
+#define WIDE_WAVES 6                     /* waves per SIMD of k_rays_w = blocks of 256 per CU.  The kernel needs 74 VGPRs (flat loop, wave-uniform state in
+                                            SGPRs, stack addresses rebuilt from the lane index: see persistentTraverseWide), i.e. 6 waves fit 80 VGPRs without
+                                            scratch; its 91 SGPRs admit 7 blocks per CU (MI355X guide: 82..96 SGPRs -> 7, whatever the occupancy API says), and
+                                            6 x (20 KB stack + 5 KB node cache) fit the CU's 160 KB of LDS.  Measured (C3 / C4 at 128 spp, ray-kernel ms per
+                                            frame, profiles/r03_gpu_call_i.log): nested loop at 4 waves (110 VGPRs) 191.8 / 385.4 -- flat loop at 4 waves
+                                            188.7 / 376.6 -- 5 waves 169.1 / 343.0 -- 6 waves 158.9 / 327.5 -- 7 waves (72 VGPRs, 9-entry stack, 48-node
+                                            cache) 167.0 / 336.9 -- 8 waves (64 VGPRs + 52 B of scratch) 241.0 / 488.3.  tests/test_kernel_resources.py
+                                            pins the register counts. */
 #endif
 
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
@@ -352,8 +358,9 @@ struct ShadowSourceDyn {
 __device__ __forceinline__ float slabRcpFast(float d) { return slabRcpFrom(d, __builtin_amdgcn_rcpf(d)); }
 
 /* ---- persistent waves with refill: closest-hit AND any-hit rays of one iteration in ONE launch (as k_rays_p) ----
- * Per-lane state is kept small (the kernel wants five waves per SIMD): `meta` = handle | shade class << 28 | any-hit flag << 31,
- * `steps` = node steps | triangle tests << 16 of the ray in flight. */
+ * Per-lane state is kept small (the kernel's speed follows its resident waves: it is bound by memory latency and by the CU's
+ * vector-memory path, WIDE_WAVES): `steps` = node steps | triangle tests << 16 of the ray in flight, the hit word carries the shade
+ * class, the any-hit flag is a lane mask.  (nested variant below: `meta` = handle | any-hit flag << 31) */
 enum { WW_RAYS = 0, WW_STEPS, WW_SH_RAYS, WW_SH_STEPS, WW_COUNT };     /* 64-bit LDS counters of a wave: rays, node steps | triangle tests << 32 */
 #define WM_HANDLE 0x0FFFFFFFu
 #define WM_SHADOW 0x80000000u

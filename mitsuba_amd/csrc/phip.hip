@@ -1169,11 +1169,13 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipStreamSynchronize(stream));
             const auto tLoop0 = clk::now();
             bool done = rc.totalIds == 0;
+            bool drainingSeen = false;                          /* a termination test has counted fewer live slots than the pool holds: blocks may have retired */
             /* environment emitter, bitmap textures; 8: the QMC samplers (two builds: the plain one, and one with both other features) */
             const int feat0 = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0), feat = qmc ? (feat0 ? 11 : 8) : feat0;
             while (!done) {
                 const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
                 rc.countAlive = check ? 1 : 0;
+                rc.draining = drainingSeen ? 1u : 0u;
                 if (timing) evShade.record(stream);
                 if (direct) phipLaunchShadeDirect(feat, sc->materialMask, grid, stream, D, P, rc, sd.L.p);
                 else phipLaunchShade(feat, rc.strictNormals != 0, sc->materialMask, grid, stream, D, P, rc, sd.L.p);
@@ -1212,6 +1214,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                     }
                     HIP_TRY(hipStreamSynchronize(stream));
                     if (hc.total[ST_ALIVE] == 0) done = true;
+                    if (hc.total[ST_ALIVE] < capacity) drainingSeen = true;
                     if (p->progress) { std::lock_guard<std::mutex> g(sc->progressLock); p->progress(p->progress_user, sd.device, samplesDone + hc.total[ST_SAMPLES], samplesTotal * (unsigned long long) p->spp); }
                     if (cancelRequested(sc)) { cancelled = true; done = true; }
                 }

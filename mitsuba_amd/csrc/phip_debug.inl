@@ -380,7 +380,7 @@ extern "C" int phip_debug_vmem_roof(int mode, size_t bytes, int blocks_per_cu, i
         HIP_TRY(hipEventRecord(e1, 0));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        hipEventDestroy(e0); hipEventDestroy(e1);
+        (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
         const double lanesOn = mode == 4 ? 0.5 : (mode == 5 ? 0.25 : (mode == 10 ? 0.125 : (mode == 11 ? 0.0625 : 1.0)));
         if (out_ms) *out_ms = ms;
         if (out_lane_loads) *out_lane_loads = (double) grid * 256.0 * lanesOn * (double) iters * 4.0 * (mode == 6 ? 5.0 : 1.0);

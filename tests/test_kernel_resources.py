@@ -1,0 +1,66 @@
+"""Register budgets of the hot kernels, read from the compiler (hipcc -Rpass-analysis=kernel-resource-usage; cross-compiles, no GPU).
+
+The persistent ray kernel's speed follows its resident waves (4 / 5 / 6 waves per SIMD = 188.7 / 169.1 / 158.9 ms per C3
+frame), so its VGPR count is a design property, not an accident of the compiler: 6 waves per SIMD need <= 80 VGPRs and no scratch.  Its SGPR
+count decides how many 256-thread blocks a CU admits (MI355X guide: 82..96 SGPRs -> 7 blocks, whatever the occupancy API answers); the
+persistent grid is sized for WIDE_WAVES blocks per CU, so the count must admit that many or the surplus blocks run in a second round."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from mitsuba_amd import _ffi
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+
+
+def resources(unit, extra=()):
+    """{kernel name: {"vgprs": .., "sgprs": .., "scratch": .., "lds": ..}} of one translation unit (device code only, nothing is written)"""
+    flags = [f for f in _ffi.HIPCC_FLAGS if f != "-shared"]
+    cmd = [HIPCC] + flags + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", os.path.join(_ffi.CSRC, unit), "-o", os.devnull]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("sgprs", r"TotalSGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return out
+
+
+def blocks_per_cu_by_sgprs(sgprs):
+    """256-thread blocks a CU admits by its scalar registers: floor(800 / (ceil(sgpr / 16) * 16 + 16)), at most 8"""
+    return min(8, 800 // (-(-sgprs // 16) * 16 + 16))
+
+
+def test_ray_kernel_of_the_big_scenes_fits_six_waves_per_simd():
+    res = resources("phip.hip")
+    k = next(v for name, v in res.items() if name.startswith("_Z8k_rays_w"))
+    src = open(os.path.join(_ffi.CSRC, "k_wide.h")).read()
+    waves = int(re.search(r"#define WIDE_WAVES (\d+)", src).group(1))
+    assert waves == 6
+    assert k["scratch"] == 0, k
+    assert k["vgprs"] <= 512 // waves // 8 * 8, k                  # 80: the allocation granule is 8 registers
+    assert blocks_per_cu_by_sgprs(k["sgprs"]) >= waves, k           # the persistent grid is sized for `waves` blocks per CU
+    stack = int(re.search(r"#define WIDE_STACK_LDS (\d+)", src).group(1)); cache = int(re.search(r"#define WIDE_NODE_CACHE_MAX (\d+)", src).group(1))
+    assert waves * (stack * 8 * 256 + cache * 80 + k["lds"]) <= 160 * 1024      # ... and their LDS (stack + node cache + counters) fits the CU
+    # the standalone ray cast of phip_trace on the same tree
+    rc = next(v for name, v in res.items() if name.startswith("_Z11k_raycast_w"))
+    assert rc["scratch"] == 0 and rc["vgprs"] <= 80, rc
+
+
+def test_fused_kernel_keeps_four_waves_without_scratch():
+    flags = next(u[1] for u in _ffi.UNITS if u[0] == "phip_mega.hip")
+    res = resources("phip_mega.hip", flags)
+    flat = [v for name, v in res.items() if name.startswith("_Z6k_megaILi0ELb0ELb1E")]          # diffuse, no strictNormals, flat leaf table: C2's kernel
+    assert flat and flat[0]["vgprs"] <= 128 and flat[0]["scratch"] == 0, flat
+    for name, v in res.items():
+        if name.startswith("_Z6k_mega"):
+            assert v["vgprs"] <= 128, (name, v)
