@@ -236,6 +236,21 @@ DV bool winsTie(float tt, uint32_t prim, float bestT, uint32_t bestPrim) { retur
 /* std::lower_bound over cdf[0..n] + DiscreteDistribution::sample, pmf.h:124-136 */
 DV uint32_t cdfSample(const float *cdf, uint32_t nEntries, float sampleValue) {
     /* cdf has nEntries+1 values */
+    if (nEntries - 1u < 3u) {                /* 1 .. 3 entries */
+        /* Few entries (one or two emitters, an emitter of two triangles -- every area light that is a rectangle): the binary search is a
+           chain of DEPENDENT reads (LDS or memory round trips), two chains per NEE sample.  The array is non-decreasing, so
+           lower_bound = the number of elements < value: all (at most four) elements are read at once and counted -- the same index.
+           (The kernel's tables continue behind the CDF, so element nEntries + 1 .. 3 is readable; it is not counted.) */
+        const float c0 = cdf[0], c1 = cdf[1], c2 = nEntries >= 2u ? cdf[2] : 0.0f, c3 = nEntries >= 3u ? cdf[3] : 0.0f;
+        const uint32_t lo = (c0 < sampleValue ? 1u : 0u) + (c1 < sampleValue ? 1u : 0u)
+                          + ((nEntries >= 2u && c2 < sampleValue) ? 1u : 0u) + ((nEntries >= 3u && c3 < sampleValue) ? 1u : 0u);
+        uint32_t index = lo ? lo - 1u : 0u;
+        if (index > nEntries - 1u) index = nEntries - 1u;
+        /* skip entries of zero probability, as below (cdf[index + 1] - cdf[index] == 0), on the values already read */
+        if (index == 0u && 1u < nEntries && c1 - c0 == 0) index = 1u;
+        if (index == 1u && 2u < nEntries && c2 - c1 == 0) index = 2u;
+        return index;
+    }
     uint32_t lo = 0, len = nEntries + 1;
     while (len > 0) {                       /* lower_bound: first element not < value */
         uint32_t half = len >> 1, mid = lo + half;

@@ -430,18 +430,15 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
     const float4 *srcE = nE4 ? (const float4 *) S.emitterTab : (const float4 *) S.triShade;
     const float4 *srcM = nM4 ? (const float4 *) S.materials : (const float4 *) S.triShade;
     const uint32_t lastE = nE4 ? nE4 - 1u : 0u, lastM = nM4 ? nM4 - 1u : 0u;
-    float4 m[MAT_F4];
     float4 e = srcE[threadIdx.x < lastE ? threadIdx.x : lastE];
-#pragma unroll
-    for (uint32_t j = 0; j < MAT_F4; ++j) { const uint32_t i = threadIdx.x + j * BLOCK; m[j] = srcM[i < lastM ? i : lastM]; }
+    static_assert(MAT_F4 == 2, "two float4s of the materials per thread (m0, m1)");
+    float4 m0 = srcM[threadIdx.x < lastM ? threadIdx.x : lastM], m1 = srcM[threadIdx.x + BLOCK < lastM ? threadIdx.x + BLOCK : lastM];
     /* the values are "used" HERE, all at once: without this the compiler sinks every load into the predicated block of its store (load,
        wait, store -- one round trip per table) */
-    static_assert(MAT_F4 == 2, "the pin below names m[0] and m[1]");
-    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w), "+v"(m[0].x), "+v"(m[0].y), "+v"(m[0].z), "+v"(m[0].w),
-                      "+v"(m[1].x), "+v"(m[1].y), "+v"(m[1].z), "+v"(m[1].w));
+    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w), "+v"(m0.x), "+v"(m0.y), "+v"(m0.z), "+v"(m0.w), "+v"(m1.x), "+v"(m1.y), "+v"(m1.z), "+v"(m1.w));
     if (threadIdx.x < nE4) ((float4 *) ldsEm)[threadIdx.x] = e;
-#pragma unroll
-    for (uint32_t j = 0; j < MAT_F4; ++j) if (threadIdx.x + j * BLOCK < nM4) ((float4 *) ldsMat)[threadIdx.x + j * BLOCK] = m[j];
+    if (threadIdx.x < nM4) ((float4 *) ldsMat)[threadIdx.x] = m0;
+    if (threadIdx.x + BLOCK < nM4) ((float4 *) ldsMat)[threadIdx.x + BLOCK] = m1;
     ShadeTables t;
     t.T.t = emInLds ? ldsEm : S.emitterTab; t.T.n = S.nEmitters; t.T.normalization = S.emitterNormalization;
     t.materials = matInLds ? ldsMat : S.materials;

@@ -92,6 +92,12 @@ void phip_debug_host_ctr_block(uint32_t pixel, uint32_t sample, uint32_t block, 
     out4[0] = u32ToFloat(h.x); out4[1] = u32ToFloat(h.y); out4[2] = u32ToFloat(h.z); out4[3] = u32ToFloat(h.w);
 }
 
+/* DiscreteDistribution::sample (pmf.h:124-136) as the kernels compile it (cdfSample, dv_scene.h: tables of one to three entries are counted, larger
+   ones searched): index of each value; `cdf` holds n_entries + 1 values followed by at least three readable floats */
+void phip_debug_host_cdf_sample(const float *cdf, uint32_t n_entries, const float *values, size_t n_values, uint32_t *out_index) {
+    for (size_t i = 0; i < n_values; ++i) out_index[i] = cdfSample(cdf, n_entries, values[i]);
+}
+
 /* PHIP_SAMPLER_LD: the point of request `dim` (2D request q: 2 q; 1D request j: 2 j + 1) of sample `sample` of `pixel` -- the code the kernels compile */
 void phip_debug_host_ld_point(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed, uint32_t mask, float *out2) {
     ldPoint(pixel, sample, dim, seed, mask, out2[0], out2[1]);

@@ -171,3 +171,38 @@ def test_ld_sampler_points(oracle, phip):
         for k in range(16):
             O.oracle_ld_point(pixel, k, dim, 0, 15, fp(pts[j, k]))
     assert not np.array_equal(pts[0], pts[1]) and not np.array_equal(pts[0], pts[2])
+
+
+def test_cdf_sample_small_tables_equal_the_search(phip):
+    """cdfSample (dv_scene.h) counts the elements below the value for tables of one to three entries instead of searching (the kernels'
+    NEE samples do two such look-ups, each a chain of dependent reads): the index must be DiscreteDistribution::sample's
+    (pmf.h:124-136: lower_bound - 1, clamped, zero-probability entries skipped) for every table size, ties and empty entries included."""
+    L = phip
+    rng = np.random.default_rng(11)
+
+    def reference(cdf, n, v):
+        lo = int(np.searchsorted(cdf[:n + 1], v, side="left"))       # std::lower_bound
+        idx = min(max(lo - 1, 0), n - 1)
+        while idx < n - 1 and np.float32(cdf[idx + 1]) - np.float32(cdf[idx]) == 0:
+            idx += 1
+        return idx
+
+    for n in range(1, 8):
+        for trial in range(40):
+            pmf = rng.uniform(0, 1, n).astype(np.float32)
+            pmf[rng.uniform(0, 1, n) < 0.3] = 0                         # entries of zero probability
+            if pmf.sum() == 0:
+                pmf[rng.integers(n)] = 1
+            cdf = np.zeros(n + 1 + 3, np.float32)
+            acc = np.float32(0)
+            for i in range(n):
+                acc = np.float32(acc + pmf[i]); cdf[i + 1] = acc
+            cdf[:n + 1] /= cdf[n]; cdf[n] = 1.0
+            cdf[n + 1:] = rng.uniform(-5, 5, 3)                          # whatever follows the table in memory must not matter
+            vals = np.concatenate([rng.uniform(0, 1, 64).astype(np.float32), cdf[:n + 1], np.nextafter(cdf[:n + 1], 2).astype(np.float32),
+                                   np.nextafter(cdf[:n + 1], -2).astype(np.float32), np.float32([0, 1])]).astype(np.float32)
+            out = np.zeros(len(vals), np.uint32)
+            L.phip_debug_host_cdf_sample(cdf.ctypes.data_as(C.POINTER(C.c_float)), n, vals.ctypes.data_as(C.POINTER(C.c_float)), len(vals),
+                                         out.ctypes.data_as(C.POINTER(C.c_uint32)))
+            want = np.array([reference(cdf, n, v) for v in vals], np.uint32)
+            assert (out == want).all(), (n, cdf[:n + 1], vals[out != want], out[out != want], want[out != want])
