@@ -288,6 +288,8 @@ DV void shapeSampleDirect(const DevScene &S, const EmitterTab &T, const float *e
     uint32_t index = cdfSample(cdf, pm_to_bits(em[EM_N_TRIS]), sample.y);
     sample.y = (sample.y - cdf[index]) / (cdf[index + 1] - cdf[index]);
     const uint32_t recOffset = pm_to_bits(em[EM_REC]);
+    /* (one load sequence through a selected pointer: two typed sequences -- ds_read for the copy inside the table, global loads for the scene's
+       record -- measured slower in k_mega, 77.2 -> 78.0 ms per C2 frame, and no faster in k_shade: round 3, profiles/r03_gpu_call_n.log) */
     const float4 *r = recOffset ? (const float4 *) (T.t + recOffset) + (size_t) TRISHADE_FLOAT4S * index
                                 : S.triShade + (size_t) S.triShadeStride * (pm_to_bits(em[EM_FIRST_TRI]) + index);
     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];

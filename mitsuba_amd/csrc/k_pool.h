@@ -195,13 +195,15 @@ __device__ __forceinline__ bool decodeId(const RenderConst &rc, const DevFilm &f
     return px < (uint32_t) film.width && py < (uint32_t) film.height;
 }
 
-/* per-wave statistics slot: wave-reduce v, lane 0 accumulates into stat[k][waveId] (unique owner) */
+/* per-wave statistics slot: wave-reduce v, lane 0 accumulates into stat[k][waveId] (unique owner).  The accumulation is an atomic add WITHOUT
+   return value -- not for exclusion (the slot has one owner) but because it is fire-and-forget: `*p += v` is load - add - store, and a wave
+   of a shading kernel that ends on three of them waits three memory round trips before it frees its registers and LDS */
 __device__ __forceinline__ void waveStat(const PathPool &P, int k, uint32_t waveId, unsigned long long v, bool overwrite = false) {
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_down(v, off);
     if (__lane_id() == 0) {
         unsigned long long *p = P.stat + (size_t) k * P.nWaves + waveId;
-        if (overwrite) *p = v; else if (v) *p += v;
+        if (overwrite) *p = v; else if (v) (void) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -176,7 +176,8 @@ struct LRegister {
 /* Returns true when the path ends at this vertex (then `vertices` = its depth).  newRay: v.rayO / rayD / thr / mis hold the
    next ray; v.state is updated whenever the path goes on.  A shadow-queue entry is returned in sh when pushShadow.
    FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures, bit 2 (k_shade only) = the
-   emitter table and the materials are known to fit LDS (the kernel then reads them with ds_read instead of flat loads); MM: leaf BSDF models
+   emitter table and the materials are known to fit LDS (the kernel then reads them with ds_read instead of flat loads), bit 4 (k_shade only) =
+   the emitter table fits LDS, the materials stay in memory; MM: leaf BSDF models
    present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric normal is dead after
    fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
 template <int MM, bool STRICT, int FEAT, typename LAcc>
@@ -466,6 +467,13 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
     v.mis = P.mis[lslot];
     ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
     if (FEAT & 4) { tab.T.t = ldsEm; tab.materials = ldsMat; }     /* the host checked that both tables fit: LDS addressing (ds_read), no flat loads */
+    else if (FEAT & 16) {
+        /* the emitter table fits, the materials do not (the atrium: 252 materials = 24 KB): the emitter look-ups -- two dozen per NEE sample --
+           are addressed as LDS, the one material record of the vertex comes from memory.  Without this the whole vertex went through
+           generic pointers: k_shade of the atrium issued 52 vector-memory instructions per wave at 53 clk each on a texture-data path
+           that was 87 % busy (profiles/r03b_tcp_atrium_*.json), half of them flat loads of LDS addresses */
+        tab.T.t = ldsEm; tab.materials = S.materials;
+    }
     if (MM != 0 && SHADE_SORT && S.shadeSort) {                 /* (block-uniform) */
         /* Scenes with more than one BSDF model: on the atrium 8 % of the vertices lie on copper, so nearly every wave ran the
            microfacet code -- the longest branch of the vertex by far -- for its two or three conductor lanes (round 2: lane

@@ -26,7 +26,9 @@ void SHADE_CAT(phipLaunchShadeF, SHADE_FEAT)(bool strictNormals, int materialMas
     /* no environment emitter, no textures (the configurations the metric is quoted on): a second set of kernels for scenes whose emitter
        table and materials fit LDS -- nearly all -- which addresses them as LDS */
     static const ShadeKernel tableLds[2][4] = { SHADE_ROW(false, 4), SHADE_ROW(true, 4) };
-    if (S.emitterTabSize <= EMITTER_LDS_FLOATS && S.nMaterials <= MATERIAL_LDS_MAX && !getenv("PHIP_SHADE_FLAT_TABLES")) row = tableLds[strictNormals ? 1 : 0];
+    static const ShadeKernel tableEmLds[2][4] = { SHADE_ROW(false, 16), SHADE_ROW(true, 16) };      /* ... only the emitter table fits (scenes of many materials) */
+    if (S.emitterTabSize <= EMITTER_LDS_FLOATS && !getenv("PHIP_SHADE_FLAT_TABLES"))
+        row = (S.nMaterials <= MATERIAL_LDS_MAX ? tableLds : tableEmLds)[strictNormals ? 1 : 0];
 #endif
 #undef SHADE_ROW
     hipLaunchKernelGGL(row[materialMask & MM_ALL], grid, dim3(BLOCK), 0, stream, S, P, rc, L);
