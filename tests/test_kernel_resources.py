@@ -64,3 +64,22 @@ def test_fused_kernel_keeps_four_waves_without_scratch():
     for name, v in res.items():
         if name.startswith("_Z6k_mega"):
             assert v["vgprs"] <= 128, (name, v)
+
+
+def test_shading_kernels_of_the_metric_configurations_keep_their_waves():
+    """k_shade of scenes without environment emitter / textures (FEAT bits 2 and 4: LDS-addressed tables) runs five waves per SIMD where more than one BSDF
+    model is present (SHADE_WAVES_PLAIN; <= 96 VGPRs, its LDS of 28.5 KB admits five blocks per CU) and the lean diffuse instantiation fits 88.  Scratch is
+    bounded: the allocator may park a few dwords outside the vertex's hot path, not more (k_shade forced to more waves with spills lost)."""
+    flags = next(u[1] for u in _ffi.UNITS if u[2] == "phip_shade0.o")
+    res = resources("phip_shade.hip", flags)
+    seen = 0
+    for name, v in res.items():
+        m = re.match(r"_Z7k_shadeILi(\d)ELb([01])ELi(\d+)E", name)
+        if not m or int(m.group(3)) not in (4, 16):
+            continue
+        seen += 1
+        mm = int(m.group(1))
+        assert v["vgprs"] <= (88 if mm == 0 else 96), (name, v)
+        assert v["scratch"] <= (64 if (mm in (1, 2) and m.group(2) == "0") else 96), (name, v)      # (1, 2, no strictNormals: the atrium's and the glass room's kernels)
+        assert 5 * v["lds"] <= 160 * 1024, (name, v)
+    assert seen == 16                                               # 4 material sets x strictNormals x {both tables in LDS, the emitter table only}
