@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PHIP_ABI_VERSION 6
+#define PHIP_ABI_VERSION 7
 
 typedef enum phip_status {
     PHIP_OK              =  0,
@@ -330,6 +330,7 @@ typedef struct phip_stats {
     double   reduce_ms;              /* multi-device: ncclReduce of the films + its synchronisation, host wall clock */
     uint32_t fused;                  /* 1: the call ran the fused kernel (then trace/shadow/shade ms are 0) */
     uint32_t n_devices;              /* devices that rendered (counters are summed over them, *_ms are the maximum) */
+    double   d2h_ms;                 /* (ABI 7) phip_render: the film's device-to-host copy, host wall clock; included in render_ms */
 } phip_stats;
 
 typedef struct phip_ray  { float o[3]; float mint; float d[3]; float maxt; } phip_ray;
@@ -349,7 +350,9 @@ phip_scene  *phip_scene_create(const phip_scene_desc *desc, int device);
 void         phip_scene_destroy(phip_scene *scene);
 
 /* Renders the crop window; out_rgbaw = crop_h*crop_w*5 float32 (R,G,B,alpha,weight) on the HOST,
-   accumulated filter-weighted sums exactly like the film's ESpectrumAlphaWeight bitmap. */
+   accumulated filter-weighted sums exactly like the film's ESpectrumAlphaWeight bitmap.
+   out_rgbaw may be any host memory.  Pinned memory (phip_host_alloc, hipHostMalloc, a registered range) receives the film in one
+   asynchronous copy at the link's rate; pageable memory receives it in chunks through the library's pinned staging buffers. */
 int  phip_render(phip_scene *scene, const phip_render_params *params,
                  float *out_rgbaw, phip_stats *out_stats);
 
@@ -375,6 +378,11 @@ int  phip_scene_replicate(phip_scene *scene, const int32_t *devices, int32_t n_d
    PHIP_ERR_CANCELLED; a request that arrives before the render starts cancels that render.  The flag is consumed by the
    call that observes it. */
 void phip_cancel(phip_scene *scene);
+
+/* (ABI 7) Page-locked host memory for phip_render's out_rgbaw (hipHostMalloc, portable); NULL + phip_last_error() on failure.
+   Replaces nothing in the reference: its film lives in the process that renders (src/librender/film.cpp). */
+void *phip_host_alloc(size_t bytes);
+void  phip_host_free(void *p);
 
 /* RGB = sum/weight (0 where weight == 0): rgbaw[n*5] -> rgb[n*3]. Host-side helper. */
 void phip_develop(const float *rgbaw, size_t n_pixels, float *out_rgb);

@@ -5,7 +5,7 @@ struct against the values the C side reports through phip_abi_sizeof().
 """
 import ctypes as C
 
-PHIP_ABI_VERSION = 6
+PHIP_ABI_VERSION = 7
 PHIP_FILTER_RESOLUTION = 31
 
 PHIP_OK, PHIP_ERR_INVALID, PHIP_ERR_UNSUPPORTED, PHIP_ERR_DEVICE, PHIP_ERR_CANCELLED, PHIP_ERR_NOMEM = 0, -1, -2, -3, -4, -5
@@ -125,7 +125,8 @@ class phip_stats(C.Structure):
                 ("render_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
                 ("shade_kernel_ms", C.c_double), ("film_kernel_ms", C.c_double),
                 ("algorithmic_bytes", C.c_double), ("trace_kernel_bytes", C.c_double),
-                ("fused_kernel_ms", C.c_double), ("reduce_ms", C.c_double), ("fused", C.c_uint32), ("n_devices", C.c_uint32)]
+                ("fused_kernel_ms", C.c_double), ("reduce_ms", C.c_double), ("fused", C.c_uint32), ("n_devices", C.c_uint32),
+                ("d2h_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}

@@ -134,6 +134,9 @@ def lib():
     L.phip_develop.argtypes = [fp, C.c_size_t, fp]
     L.phip_scene_accel_info.argtypes = [C.c_void_p, C.POINTER(A.phip_accel_info)]
     L.phip_gaussian_filter.argtypes = [C.c_float, fp, fp]
+    L.phip_host_alloc.restype = C.c_void_p
+    L.phip_host_alloc.argtypes = [C.c_size_t]
+    L.phip_host_free.argtypes = [C.c_void_p]; L.phip_host_free.restype = None
     L.phip_abi_sizeof.restype = C.c_size_t
     L.phip_abi_sizeof.argtypes = [C.c_int]
     L.phip_debug_host_bsdf_sample.argtypes = [C.POINTER(A.phip_material), u32, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]

@@ -32,6 +32,7 @@
 #include <chrono>
 #include <functional>
 #include <thread>
+#include <exception>
 
 namespace pt {
 
@@ -115,6 +116,8 @@ struct Builder {
     float alpha = 1e-5f;               /* a spatial split is only tried when the object split's children overlap by more than alpha * root area */
     double rootArea = 1;
     size_t slack = 0;                  /* references spatial splits may still ADD below this node (the whole tree: at most 0.5 per triangle) */
+    int dealLevels = 5;                /* buildSpatial: top levels of the tree on which the reference budget is dealt to the two sides in proportion to their
+                                          reference counts -- on every host, threaded or not, so that the tree is the same on every machine */
     int parallelLevels = 0;            /* buildSpatial: levels of the tree whose two subtrees are built on two threads (round 3: the builder was
                                           single-threaded and 8 x slower than the plain SAH build on a 250 k-triangle scene) */
     static constexpr size_t PAR_MIN_REFS = 8192;
@@ -400,7 +403,8 @@ struct Builder {
         out.nodes2.resize((size_t) out.nNodes2 * 16);
         Box lbx, rbx;
         int32_t l, r;
-        if (parallelLevels > 0 && L.size() >= PAR_MIN_REFS && R.size() >= PAR_MIN_REFS) {
+        const bool deal = dealLevels > 0 && L.size() >= PAR_MIN_REFS && R.size() >= PAR_MIN_REFS;
+        if (deal && parallelLevels > 0) {
             /* the right subtree on another thread, into arrays of its own; spliced in behind the left subtree afterwards (node and
                record indices shifted), so the layout is the depth-first one of the serial build.  The reference budget is dealt in
                proportion to the two sides: deterministic, whatever the threads' timing. */
@@ -408,15 +412,17 @@ struct Builder {
             Builder SB(none, sub, positions, indices);
             SB.MAX_LEAF = MAX_LEAF; SB.C_TRAV = C_TRAV; SB.C_ISECT = C_ISECT; SB.spatial = spatial; SB.alpha = alpha; SB.rootArea = rootArea;
             for (int a = 0; a < 3; ++a) SB.extent[a] = extent[a];
-            SB.parallelLevels = parallelLevels - 1;
+            SB.parallelLevels = parallelLevels - 1; SB.dealLevels = dealLevels - 1;
             const size_t total = slack, slackR = (size_t) ((double) total * (double) R.size() / (double) (L.size() + R.size()));
             SB.slack = slackR; slack = total - slackR;
             int32_t rr = 0;
-            std::thread worker([&]() { rr = SB.buildSpatial(R, rbx, depth + 1); });
-            const int saved = parallelLevels; parallelLevels = saved - 1;
-            l = buildSpatial(L, lbx, depth + 1);
-            parallelLevels = saved;
+            std::exception_ptr failed;                            /* (an exception that leaves a std::thread is std::terminate) */
+            std::thread worker([&]() { try { rr = SB.buildSpatial(R, rbx, depth + 1); } catch (...) { failed = std::current_exception(); } });
+            const int saved = parallelLevels, savedDeal = dealLevels; parallelLevels = saved - 1; dealLevels = savedDeal - 1;
+            try { l = buildSpatial(L, lbx, depth + 1); } catch (...) { worker.join(); throw; }
+            parallelLevels = saved; dealLevels = savedDeal;
             worker.join();
+            if (failed) std::rethrow_exception(failed);
             slack += SB.slack;
             const uint32_t nodeOff = out.nNodes2, recOff = (uint32_t) (out.tris.size() / 12);
             auto shift = [&](int32_t ref) -> int32_t {
@@ -435,6 +441,17 @@ struct Builder {
             out.tris.insert(out.tris.end(), sub.tris.begin(), sub.tris.end());
             out.nLeaves += sub.nLeaves; out.nTriRefs += sub.nTriRefs; out.maxDepth = std::max(out.maxDepth, sub.maxDepth);
             r = shift(rr);
+        } else if (deal) {
+            /* the same deal of the reference budget without a second thread: the tree does not depend on the host's core count */
+            const size_t total = slack, slackR = (size_t) ((double) total * (double) R.size() / (double) (L.size() + R.size()));
+            const int savedDeal = dealLevels; dealLevels = savedDeal - 1;
+            slack = total - slackR;
+            l = buildSpatial(L, lbx, depth + 1);
+            const size_t leftL = slack;
+            slack = slackR;
+            r = buildSpatial(R, rbx, depth + 1);
+            slack += leftL;
+            dealLevels = savedDeal;
         } else {
             l = buildSpatial(L, lbx, depth + 1);
             r = buildSpatial(R, rbx, depth + 1);

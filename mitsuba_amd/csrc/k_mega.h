@@ -27,13 +27,22 @@
 #ifndef MEGA_PROFILE
 #define MEGA_PROFILE 0               /* measurement build: wave clock and active lanes per phase of the loop (reported in the work-counter rows, which it falsifies) */
 #endif
+#ifndef MEGA_REGEN_QUEUE
+#define MEGA_REGEN_QUEUE 1           /* camera samples are prepared 64 at a time by the whole wave into an LDS queue (0: by the lanes whose paths ended, in every pass) */
+#endif
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
 enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
 
-template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
-    __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs */
+template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+    __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
+                                                                   no wait -- and the three that count lanes as ballots in SGPRs: 66.9 vs 66.5 ms per C2 frame and
+                                                                   125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
+#define MEGA_COUNT(row, amount) ldsCount[row][threadIdx.x] += (uint32_t) (amount)
+#if MEGA_REGEN_QUEUE
+    __shared__ uint32_t ldsRegen[BLOCK / 64][11][64];           /* per wave: 64 prepared camera samples (o, mint | d, maxt | id, pixel, k), one word per entry and row */
+#endif
     /* dynamic LDS: [traversal stack | all nodes | all Wald records] (setupTraversal) [shading records | emitter table | materials],
        sized for THIS scene (megaLdsBytes) so that as many blocks as the registers allow fit a CU */
     float4 *ldsTriShade = (float4 *) (g_smem + traversalLdsBytesOf(S));
@@ -52,6 +61,10 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
 
     const uint32_t waveId = blockIdx.x * (BLOCK / 64) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = __lane_id();
     unsigned long long next = 0, end = 0;                       /* the wave's chunk of sample ids (wave-uniform) */
+#if MEGA_REGEN_QUEUE
+    const uint32_t waveInBlock = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    uint32_t qHead = 0, qCount = 0;                             /* the wave's queue of prepared camera samples (wave-uniform) */
+#endif
     bool exhausted = rc.totalIds == 0;
 
     bool alive = false;
@@ -78,6 +91,73 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
         const unsigned long long pfWant_ = __ballot(!alive);
 #endif
         /* ---- regeneration: lanes without a path start the next camera sample (integrator.cpp:157-183) ---- */
+#if MEGA_REGEN_QUEUE
+        /* Camera samples are prepared 64 at a time by ALL lanes of the wave (id decode, pixel jitter, camera ray: ~670 instructions) into a
+           per-wave LDS queue; a lane whose path ended pops the next entry (eleven LDS words).  Before, that code ran in every pass of the
+           loop for the ~18 lanes (28 %) whose paths had just ended: 14 % of the kernel's time at a quarter of the lanes. */
+        for (;;) {
+            const unsigned long long want = __ballot(!alive);
+            if (!want) break;
+            if (qCount == 0u) {
+                if (exhausted) break;
+                if (next >= end) {                              /* draw a chunk (wave-uniform branch) */
+                    unsigned long long base = 0; uint32_t chunk = 0;
+                    if (lane == 0) {
+                        const unsigned long long seen = __hip_atomic_load(M.nextId, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const bool stop = __hip_atomic_load(M.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                        if (seen < rc.totalIds && !stop) {
+                            /* guided self-scheduling: half of what would remain per wave, within [64, 4096] ids */
+                            const unsigned long long share = (rc.totalIds - seen) / (2ull * M.nWaves);
+                            chunk = (uint32_t) (share > MEGA_CHUNK_MAX ? MEGA_CHUNK_MAX : (share < MEGA_CHUNK_MIN ? MEGA_CHUNK_MIN : share));
+                            chunk &= ~63u;
+                            base = atomicAdd(M.nextId, (unsigned long long) chunk);
+                        } else {
+                            base = rc.totalIds;
+                        }
+                    }
+                    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t) base), bhi = __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32));
+                    chunk = __builtin_amdgcn_readfirstlane(chunk);
+                    next = ((unsigned long long) bhi << 32) | blo;
+                    end = next + chunk; if (end > rc.totalIds) end = rc.totalIds;
+                    if (next >= end) { exhausted = true; break; }
+                }
+                /* the next 64 ids of the chunk, one per lane (ids outside the crop window -- edge blocks -- are consumed and skipped) */
+                const unsigned long long id = next + lane;
+                uint32_t px = 0, py = 0, k = 0;
+                const bool valid = id < end && decodeId(rc, S.film, id, px, py, k);
+                const unsigned long long vmask = __ballot(valid);
+                if (valid) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) vmask, 0u));
+                    const uint32_t pixel = py * (uint32_t) S.film.width + px;
+                    const V2 jit = streamJitter(rc, pixel, k);
+                    const float sx = (float) px + jit.x, sy = (float) py + jit.y;
+                    V3 o, d; float mint, maxt;
+                    cameraRay(S.cam, sx, sy, o, d, mint, maxt);
+                    uint32_t *q = &ldsRegen[waveInBlock][0][pos];
+                    q[0 * 64] = pm_to_bits(o.x); q[1 * 64] = pm_to_bits(o.y); q[2 * 64] = pm_to_bits(o.z); q[3 * 64] = pm_to_bits(mint);
+                    q[4 * 64] = pm_to_bits(d.x); q[5 * 64] = pm_to_bits(d.y); q[6 * 64] = pm_to_bits(d.z); q[7 * 64] = pm_to_bits(maxt);
+                    q[8 * 64] = (uint32_t) id; q[9 * 64] = pixel; q[10 * 64] = k;
+                }
+                qHead = 0u; qCount = (uint32_t) __popcll(vmask);
+                next = (end - next < 64ull) ? end : next + 64ull;
+                if (qCount == 0u) continue;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) want, 0u));
+            if (!alive && rank < qCount) {
+                const uint32_t *q = &ldsRegen[waveInBlock][0][qHead + rank];
+                v.rayO = make_float4(pm_from_bits(q[0 * 64]), pm_from_bits(q[1 * 64]), pm_from_bits(q[2 * 64]), pm_from_bits(q[3 * 64]));
+                v.rayD = make_float4(pm_from_bits(q[4 * 64]), pm_from_bits(q[5 * 64]), pm_from_bits(q[6 * 64]), pm_from_bits(q[7 * 64]));
+                v.id = q[8 * 64]; v.pixel = q[9 * 64]; v.k = q[10 * 64];
+                v.thr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                v.mis = make_float2(0.0f, 0.0f);
+                v.state = 1u | F_ALIVE | F_EMITTED | F_FIRST;
+                accum = make_float4(0, 0, 0, 0);
+                alive = true;
+            }
+            const uint32_t wanted = (uint32_t) __popcll(want), took = wanted < qCount ? wanted : qCount;
+            qHead += took; qCount -= took;
+        }
+#else
         for (;;) {
             const unsigned long long want = __ballot(!alive);
             if (!want || exhausted) break;
@@ -125,6 +205,7 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             const unsigned long long used = (unsigned long long) __popcll(want);
             next = (end - next < used) ? end : next + used;
         }
+#endif
         PF_END(0, pfWant_) }
         if (!__any(alive)) break;
 
@@ -137,11 +218,12 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
             if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp)) {
-                if (FLAT) traverseFlat<false>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
+                if (FLAT == 2) traverseFlat2<false>(flat, S.nFlatLeaves, stk.tris, o, d, rcp, mint, maxt, r, nNode, nTri);
+                else if (FLAT) traverseFlat<false>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
                 else traverse<false, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
             }
             v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
-            ldsCount[MC_RAYS][threadIdx.x] += 1; ldsCount[MC_NODE][threadIdx.x] += nNode; ldsCount[MC_TRI][threadIdx.x] += nTri;
+            MEGA_COUNT(MC_RAYS, 1); MEGA_COUNT(MC_NODE, nNode); MEGA_COUNT(MC_TRI, nTri);
         }
 
         PF_END(1, __ballot(alive)) }
@@ -154,7 +236,7 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             bool newRay;
             const LRegister acc{ accum };
             ended = shadeVertex<MM, STRICT, 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
-            if (ended) ldsCount[MC_VERTICES][threadIdx.x] += nv;
+            if (ended) MEGA_COUNT(MC_VERTICES, nv);
         }
 
         PF_END(2, __ballot(alive)) }
@@ -168,16 +250,17 @@ template <int MM, bool STRICT, bool FLAT> __global__ __launch_bounds__(BLOCK, ME
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
             if (clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp))
-                occluded = FLAT ? traverseFlat<true>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri)
+                occluded = FLAT == 2 ? traverseFlat2<true>(flat, S.nFlatLeaves, stk.tris, o, d, rcp, mint, maxt, r, nNode, nTri)
+                         : FLAT ? traverseFlat<true>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri)
                                 : traverse<true, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
-            ldsCount[MC_SH_RAYS][threadIdx.x] += 1; ldsCount[MC_SH_NODE][threadIdx.x] += nNode; ldsCount[MC_SH_TRI][threadIdx.x] += nTri;
+            MEGA_COUNT(MC_SH_RAYS, 1); MEGA_COUNT(MC_SH_NODE, nNode); MEGA_COUNT(MC_SH_TRI, nTri);
             if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
         }
 
         PF_END(3, __ballot(pushShadow)) }
         if (ended) {
             L[v.id] = accum;
-            ldsCount[MC_SAMPLES][threadIdx.x] += 1;
+            MEGA_COUNT(MC_SAMPLES, 1);
             alive = false;
         }
     }

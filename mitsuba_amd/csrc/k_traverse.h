@@ -262,5 +262,109 @@ __device__ __forceinline__ bool traverseFlat(const DevScene &S, lds_cf4 *flat, u
     return found;
 }
 
+/* Second form of the flat table, for trees of at most 32 Wald records (the Cornell box: 32 triangles in 17 leaves): entry c =
+ *   A = (min.x, max.x, min.y, max.y)   B = (min.z, max.z, bits(mask of the leaf's records), 0)
+ * so that (a) the two planes of an axis are one packed multiply-add (v_pk_fma_f32), and (b) pass 1 yields a bit mask of RECORDS: pass 2
+ * is `while (mask) test record ffs(mask)` -- no leaf reference to fetch and decode between records, a record referenced by two leaves is
+ * tested once.  The table is padded to a multiple of four entries with empty record masks (pass 1 is unrolled by four: eight LDS
+ * broadcasts in flight instead of a wait per leaf).  The Wald test is branch-free here (waldIntersectSel: the axis permutation as twelve
+ * selects instead of three divergent branches -- inside traverseFlat the exec-mask bookkeeping was 40 scalar instructions per record).
+ * Same arithmetic on the same operands, so (t, u, v, prim) are the same bits; records in index order instead of leaf order: winsTie. */
+#ifndef MEGA_WALD_PAIR
+#define MEGA_WALD_PAIR 0
+#endif
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool waldIntersectSel(const float4 &a, const float4 &b, const float4 &c, const V3 &o, const V3 &d,
+                                                 float mint, float maxt, float &u, float &v, float &t) {
+    const uint32_t k = pm_to_bits(a.x);
+    const bool k0 = k == 0, k2 = k == 2;                       /* k == 1: the default of the selects; k == 3 (degenerate record) fails below */
+    const float o_u = k0 ? o.y : (k2 ? o.x : o.z), o_v = k0 ? o.z : (k2 ? o.y : o.x), o_k = k0 ? o.x : (k2 ? o.z : o.y);
+    const float d_u = k0 ? d.y : (k2 ? d.x : d.z), d_v = k0 ? d.z : (k2 ? d.y : d.x), d_k = k0 ? d.x : (k2 ? d.z : d.y);
+    const float n_u = a.y, n_v = a.z, n_d = a.w;
+    t = (n_d - o_u * n_u - o_v * n_v - o_k) / (d_u * n_u + d_v * n_v + d_k);
+    const float hu = o_u + t * d_u - b.x;
+    const float hv = o_v + t * d_v - b.y;
+    u = hv * b.z + hu * b.w;
+    v = hu * c.x + hv * c.y;
+    /* waldIntersect: `if (t < mint || t > maxt) return false; ... return u >= 0 && v >= 0 && u + v <= 1` (a NaN t fails through u) */
+    return (k < 3u) & !(t < mint) & !(t > maxt) & (u >= 0) & (v >= 0) & (u + v <= 1.0f);
+}
+
+template <bool SHADOW>
+__device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat /* a multiple of four */, lds_cf4 *tris, const V3 &o, const V3 &d, const V3 &rcp,
+                                              float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
+    const f2v rx = { rcp.x, rcp.x }, ry = { rcp.y, rcp.y }, rz = { rcp.z, rcp.z };
+    const f2v ox = { -(o.x * rcp.x), -(o.x * rcp.x) }, oy = { -(o.y * rcp.y), -(o.y * rcp.y) }, oz = { -(o.z * rcp.z), -(o.z * rcp.z) };
+    uint32_t mask = 0;
+    for (uint32_t c4 = 0; c4 < nFlat; c4 += 4) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const f4v A = flat[2 * (c4 + j)], B = flat[2 * (c4 + j) + 1];
+            const f2v x = __builtin_elementwise_fma(A.xy, rx, ox), y = __builtin_elementwise_fma(A.zw, ry, oy), z = __builtin_elementwise_fma(B.xy, rz, oz);
+            const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), mint));
+            const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), maxt));
+            mask |= (tn <= tf) ? pm_to_bits(B.z) : 0u;
+        }
+    }
+    ++nodeVisits;
+    bool found = false;
+    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+#define FLAT2_TEST(a, b, c)                                                                                        \
+    {                                                                                                              \
+        ++triTests;                                                                                                \
+        float tu, tv, tt;                                                                                          \
+        const bool hit = waldIntersectSel(a, b, c, o, d, mint, maxt, tu, tv, tt);                                  \
+        if (SHADOW) {                                                                                              \
+            found = found | hit;                                                                                   \
+            mask = hit ? 0u : mask;                                                                                \
+        } else {                                                                                                   \
+            const bool win = hit & winsTie(tt, pm_to_bits(c.z), res.t, res.prim);                                  \
+            maxt = win ? tt : maxt; res.t = win ? tt : res.t; res.u = win ? tu : res.u; res.v = win ? tv : res.v;  \
+            res.prim = win ? pm_to_bits(c.z) : res.prim;                                                           \
+            found = found | hit;                                                                                   \
+        }                                                                                                          \
+    }
+#if MEGA_WALD_PAIR
+    /* two records per pass of the loop: two independent dependency chains (each Wald test is ~35 dependent instructions behind an LDS round
+       trip, and four waves per SIMD do not cover that).  The second record is judged after the first, against the interval the first may have
+       shortened -- the sequential loop's decisions in the sequential loop's order.  A lane with one record left tests it twice. */
+    while (mask) {
+        const uint32_t i0 = (uint32_t) __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const bool two = mask != 0;
+        const uint32_t i1 = two ? (uint32_t) __builtin_ctz(mask) : i0;
+        mask &= mask - 1u;
+        const float4 a0 = ldsLoad4(tris + 3 * i0), b0 = ldsLoad4(tris + 3 * i0 + 1), c0 = ldsLoad4(tris + 3 * i0 + 2);
+        const float4 a1 = ldsLoad4(tris + 3 * i1), b1 = ldsLoad4(tris + 3 * i1 + 1), c1 = ldsLoad4(tris + 3 * i1 + 2);
+        float u0, v0, t0, u1, v1, t1;
+        const bool h0 = waldIntersectSel(a0, b0, c0, o, d, mint, maxt, u0, v0, t0);
+        bool h1 = two & waldIntersectSel(a1, b1, c1, o, d, mint, maxt, u1, v1, t1);
+        if (SHADOW) {
+            triTests += (two & !h0) ? 2u : 1u;                   /* the sequential loop stops at the first hit */
+            found = found | h0 | h1;
+            mask = (h0 | h1) ? 0u : mask;
+        } else {
+            triTests += two ? 2u : 1u;
+            const bool w0 = h0 & winsTie(t0, pm_to_bits(c0.z), res.t, res.prim);
+            maxt = w0 ? t0 : maxt; res.t = w0 ? t0 : res.t; res.u = w0 ? u0 : res.u; res.v = w0 ? v0 : res.v; res.prim = w0 ? pm_to_bits(c0.z) : res.prim;
+            h1 = h1 & !(t1 > maxt);
+            const bool w1 = h1 & winsTie(t1, pm_to_bits(c1.z), res.t, res.prim);
+            maxt = w1 ? t1 : maxt; res.t = w1 ? t1 : res.t; res.u = w1 ? u1 : res.u; res.v = w1 ? v1 : res.v; res.prim = w1 ? pm_to_bits(c1.z) : res.prim;
+            found = found | h0 | h1;
+        }
+    }
+#else
+    while (mask) {
+        const uint32_t idx = (uint32_t) __builtin_ctz(mask);
+        mask &= mask - 1u;
+        lds_cf4 *t_ = tris + 3 * idx;
+        const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
+        FLAT2_TEST(a, b, c)
+    }
+#endif
+#undef FLAT2_TEST
+    return found;
+}
+
 /* the block's dynamic LDS: traversal stack + node / record cache (setupTraversal) */
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];

@@ -171,8 +171,8 @@ struct SceneDev {
     DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
-    DevBuf<uint32_t> sobolMat; DevBuf<unsigned long long> sobolVdc; const void *sobolKey = nullptr; uint32_t sobolLogRes = 0;    /* PHIP_SAMPLER_SOBOL: the plugin's tables */
-    DevBuf<uint32_t> rinvPrimes, rinvOffsets; DevBuf<uint16_t> rinvPerm; const void *rinvKey = nullptr, *rinvPermKey = nullptr;   /* PHIP_SAMPLER_HALTON / _HAMMERSLEY: primes + permutations */
+    DevBuf<uint32_t> sobolMat; DevBuf<unsigned long long> sobolVdc; uint64_t sobolKey = 0; uint32_t sobolLogRes = 0;    /* PHIP_SAMPLER_SOBOL: the plugin's tables */
+    DevBuf<uint32_t> rinvPrimes, rinvOffsets; DevBuf<uint16_t> rinvPerm; uint64_t rinvKey = 0;   /* PHIP_SAMPLER_HALTON / _HAMMERSLEY: primes + permutations */
     uint32_t rinvInvPerm2 = 0x4u, rinvInvPerm3 = 0x24u;                                                                         /* inverse permutations of bases 2 and 3, two bits per digit */
     DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
     DevBuf<unsigned int> drawCounters;                                                       /* k_rays_w: 2 x RAY_SHARDS sharded work counters */
@@ -183,6 +183,8 @@ struct SceneDev {
     bool mergedRays = false;         /* last render used k_rays_p (closest + any hit in one launch) */
     bool fused = false;              /* last render used k_mega */
     hipStream_t stream = nullptr;
+    /* phip_render's device-to-host copy of the film into PAGEABLE memory: two pinned staging chunks (filmToHost) */
+    float *stage[2] = { nullptr, nullptr }; hipEvent_t stageDone[2] = { nullptr, nullptr };
 
     template <typename F> void forEachSceneBuffer(F f) {
         f(nodes); f(wnodes); f(tris); f(triShade); f(flatLeaves); f(materials); f(emitterTab); f(texTexels); f(texDesc);
@@ -198,6 +200,7 @@ struct SceneDev {
     ~SceneDev() {
         (void) hipSetDevice(device);
         if (stream) (void) hipStreamDestroy(stream);
+        for (int i = 0; i < 2; ++i) { if (stage[i]) (void) hipHostFree(stage[i]); if (stageDone[i]) (void) hipEventDestroy(stageDone[i]); }
     }
 };
 
@@ -703,7 +706,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     /* ... and, for trees of at most FLAT_LEAVES_MAX leaves (the Cornell box: 17), the leaves as a flat table: the fused kernel tests
        every leaf box in one uniform pass instead of walking the 7-node tree (k_traverse.h: traverseFlat).  Entry = (min.xyz, bits(leaf
        reference)) (max.xyz, 0), boxes as the BVH4 nodes hold them (padded). */
-    D.nFlatLeaves = 0; sd.flatLeaves.alloc(2); D.flatLeaves = sd.flatLeaves.p;
+    D.nFlatLeaves = 0; D.flatMode = 0; sd.flatLeaves.alloc(2); D.flatLeaves = sd.flatLeaves.p;
     if (sc->fitsLds && sc->bvh.nLeaves <= FLAT_LEAVES_MAX && !getenv("PHIP_NO_FLAT")) {
         std::vector<float4> flat;
         if (sc->bvh.rootRef < 0) {                         /* a single leaf: its box is the scene's */
@@ -719,6 +722,29 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
             }
         }
         if (flat.size() / 2 <= FLAT_LEAVES_MAX) {
+            D.flatMode = 1;
+            /* at most 32 Wald records: the packed form with record masks (k_traverse.h: traverseFlat2).  A leaf reference is
+               ~((first record << 3) | records - 1); a triangle referenced by several leaves (spatial splits) has one record per
+               reference -- the copies carry the same 12 words, so only the first copy's bit is set */
+            const size_t nRec = sc->bvh.tris.size() / 12;
+            if (nRec <= 32 && !getenv("PHIP_NO_FLAT2")) {
+                std::vector<uint32_t> firstCopy(nRec);
+                for (size_t i = 0; i < nRec; ++i) {
+                    firstCopy[i] = (uint32_t) i;
+                    for (size_t j = 0; j < i; ++j) if (!memcmp(&sc->bvh.tris[12 * i], &sc->bvh.tris[12 * j], 48)) { firstCopy[i] = (uint32_t) j; break; }
+                }
+                std::vector<float4> packed;
+                for (size_t l = 0; l < flat.size() / 2; ++l) {
+                    const float4 mn = flat[2 * l], mx = flat[2 * l + 1];
+                    const uint32_t r = ~pm_to_bits(mn.w), first = r >> 3, count = (r & 7u) + 1u;
+                    uint32_t bits = 0;
+                    for (uint32_t i = 0; i < count; ++i) bits |= 1u << firstCopy[first + i];
+                    packed.push_back(make_float4(mn.x, mx.x, mn.y, mx.y));
+                    packed.push_back(make_float4(mn.z, mx.z, pm_from_bits(bits), 0.0f));
+                }
+                while ((packed.size() / 2) % 4) { packed.push_back(make_float4(0, 0, 0, 0)); packed.push_back(make_float4(0, 0, 0, 0)); }
+                flat.swap(packed); D.flatMode = 2;
+            }
             sd.flatLeaves.upload(flat.data(), flat.size());
             D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
         }
@@ -731,6 +757,16 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     std::vector<uint32_t>().swap(sc->bvh.wnodes); std::vector<float>().swap(sc->bvh.wtris);
     HIP_TRY(hipHostMalloc((void **) &sc->cancelFlag, sizeof(int), hipHostMallocPortable | hipHostMallocMapped));
     *sc->cancelFlag = 0;
+}
+
+/* 64-bit content key of a caller's table (word-wise multiply-xorshift; ~2 GB/s: 0.1 ms for the Sobol direction numbers) */
+static uint64_t contentHash(const void *data, size_t bytes, uint64_t h) {
+    const unsigned char *b = (const unsigned char *) data;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    uint64_t w = 0; if (i < bytes) memcpy(&w, b + i, bytes - i);
+    h = (h ^ w ^ (uint64_t) bytes) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+    return h ? h : 1;
 }
 
 /* Replica of the scene on another GPU: device-to-device copies of the immutable arrays (xGMI), same DevScene. */
@@ -939,16 +975,26 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     if (qmc && p->sampler == PHIP_SAMPLER_SOBOL) {
         /* the plugin's tables, uploaded once per (pointer, size): ~210 KB of direction numbers + the two 52-word enumeration rows */
         const size_t nm = (size_t) p->sobol_dimensions * PHIP_SOBOL_MATRIX_SIZE;
-        if (sd.sobolKey != (const void *) p->sobol_matrices || sd.sobolMat.n != nm || sd.sobolLogRes != p->sobol_log_resolution) {
+        /* (keyed by CONTENT: the tables are host pointers "read during the call" -- a caller may refill or reallocate them at the same address) */
+        uint64_t key = contentHash(p->sobol_matrices, nm * sizeof(uint32_t), 0x9E3779B97F4A7C15ull);
+        if (p->sobol_log_resolution > 1) { key = contentHash(p->sobol_vdc, PHIP_SOBOL_MATRIX_SIZE * sizeof(uint64_t), key); key = contentHash(p->sobol_vdc_inv, PHIP_SOBOL_MATRIX_SIZE * sizeof(uint64_t), key); }
+        if (sd.sobolKey != key || sd.sobolMat.n != nm || sd.sobolLogRes != p->sobol_log_resolution) {
             sd.sobolMat.upload(p->sobol_matrices, nm);
             std::vector<unsigned long long> v(2 * PHIP_SOBOL_MATRIX_SIZE, 0ull);
             if (p->sobol_log_resolution > 1)
                 for (int i = 0; i < PHIP_SOBOL_MATRIX_SIZE; ++i) { v[i] = p->sobol_vdc[i]; v[PHIP_SOBOL_MATRIX_SIZE + i] = p->sobol_vdc_inv[i]; }
             sd.sobolVdc.upload(v.data(), v.size());
-            sd.sobolKey = (const void *) p->sobol_matrices; sd.sobolLogRes = p->sobol_log_resolution;
+            sd.sobolKey = key; sd.sobolLogRes = p->sobol_log_resolution;
         }
     }
-    if (rinv && (sd.rinvKey != (const void *) p->qmc_primes || sd.rinvPermKey != (const void *) p->qmc_permutations || sd.rinvPrimes.n != p->qmc_dimensions)) {
+    uint64_t rinvKey = 0;
+    if (rinv) {                                        /* content key of primes + permutations (at most ~200 KB; see the Sobol tables above) */
+        size_t total = 0;
+        for (uint32_t d = 0; d < p->qmc_dimensions; ++d) total += p->qmc_primes[d];
+        rinvKey = contentHash(p->qmc_primes, p->qmc_dimensions * sizeof(uint32_t), p->qmc_permutations ? 0x51ED270B7A5F1D3Bull : 0x2545F4914F6CDD1Dull);
+        if (p->qmc_permutations) rinvKey = contentHash(p->qmc_permutations, total * sizeof(uint16_t), rinvKey);
+    }
+    if (rinv && (sd.rinvKey != rinvKey || sd.rinvPrimes.n != p->qmc_dimensions)) {
         /* primes, the start of every base's permutation, the permutations themselves; the inverse permutations of bases 2 and 3 (the pixel enumeration) */
         std::vector<uint32_t> off(p->qmc_dimensions);
         size_t total = 0;
@@ -962,7 +1008,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             for (uint32_t i = 0; i < 2; ++i) sd.rinvInvPerm2 |= i << (2u * p2[i]);          /* invPerm[perm[i]] = i (faure.cpp: invertPermutation) */
             for (uint32_t i = 0; i < 3; ++i) sd.rinvInvPerm3 |= i << (2u * p3[i]);
         }
-        sd.rinvKey = (const void *) p->qmc_primes; sd.rinvPermKey = (const void *) p->qmc_permutations;
+        sd.rinvKey = rinvKey;
     }
     if (const char *e = getenv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
     sd.fused = fused;
@@ -995,6 +1041,14 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         const unsigned long long poolCap = idsFirstPass >= (512ull << 20) ? (1ull << 25) : idsFirstPass >= (64ull << 20) ? (1ull << 24)
                                          : idsFirstPass >= (16ull << 20) ? (1ull << 23) : (1ull << 22);
         capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
+        {   /* ... and with the memory that is there: the pool's state is ~144 B per slot; it may take a quarter of what is free now (a
+               shared or partitioned GPU, n_devices replicas), never less than the 4 M slots every job ran with before the pool grew */
+            size_t freeB = 0, totalB = 0;
+            if (sd.rayO.n < capacity && hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+                unsigned long long fit = (unsigned long long) (freeB / 4) / 144ull;
+                while (capacity > (1u << 22) && capacity > fit) capacity >>= 1;
+            }
+        }
         capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
         if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
         const size_t laneCap = ((size_t) capacity + WIDE_BLOCK - 1) / WIDE_BLOCK * WIDE_BLOCK;      /* k_rays_w runs whole blocks of WIDE_BLOCK lanes */
@@ -1058,7 +1112,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
     if (fused) {
         const size_t megaLds = megaLdsBytesOf(D);
-        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves != 0, megaLds));
+        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, megaLds));
         if (const char *e = getenv("PHIP_MEGA_BLOCKS")) perCU = std::max(1, std::min(perCU, atoi(e)));
         if (perCU <= 0) throw std::runtime_error("k_mega does not fit a compute unit");
         megaGrid = dim3((unsigned) (nCU * perCU));
@@ -1556,6 +1610,62 @@ int phip_render_device(phip_scene *scene, const phip_render_params *params, void
     }
 }
 
+/* The film's way to the host (inside the metric: SURVEY 8(d), renderjob.cpp:105 -- the reference's `Render time` includes film->put).
+   A pageable hipMemcpy of the 20 MB C2 film measured 8.4 ms (2.5 GB/s: the runtime stages it through one small pinned buffer, copy and
+   memcpy in turn).  Here:
+     * `dst` is pinned memory (phip_host_alloc, hipHostMalloc, torch pin_memory, hipHostRegister): ONE asynchronous copy at the link's rate;
+     * `dst` is pageable (the Bitmap of the Mitsuba shim): the film crosses in FILM_STAGE_BYTES chunks through two pinned staging buffers,
+       the copy of chunk i + 1 in flight while chunk i is moved to `dst` by up to four host threads. */
+#define FILM_STAGE_BYTES ((size_t) 4 << 20)
+static void parallelCopy(char *dst, const char *src, size_t bytes) {
+    const size_t nThreads = std::min<size_t>(4, bytes / ((size_t) 512 << 10));
+    if (nThreads < 2) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nThreads) + 4095) & ~(size_t) 4095;
+    for (size_t i = 1; i < nThreads; ++i) {
+        const size_t b = i * per, e = std::min(bytes, b + per);
+        if (b < e) th.emplace_back([=] { memcpy(dst + b, src + b, e - b); });
+    }
+    memcpy(dst, src, std::min(bytes, per));
+    for (auto &t : th) t.join();
+}
+static void filmToHost(SceneDev &sd, float *dst, const float *dFilm, size_t bytes) {
+    if (!sd.stream) HIP_TRY(hipStreamCreate(&sd.stream));
+    hipPointerAttribute_t attr; memset(&attr, 0, sizeof(attr));
+    const hipError_t e = hipPointerGetAttributes(&attr, dst);
+    if (e != hipSuccess) (void) hipGetLastError();             /* an unregistered host pointer is "invalid value" on some runtimes: pageable */
+    if (e == hipSuccess && attr.type == hipMemoryTypeHost) {
+        HIP_TRY(hipMemcpyAsync(dst, dFilm, bytes, hipMemcpyDeviceToHost, sd.stream));
+        HIP_TRY(hipStreamSynchronize(sd.stream));
+        return;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!sd.stage[i]) HIP_TRY(hipHostMalloc((void **) &sd.stage[i], FILM_STAGE_BYTES, hipHostMallocDefault));
+        if (!sd.stageDone[i]) HIP_TRY(hipEventCreateWithFlags(&sd.stageDone[i], hipEventDisableTiming));
+    }
+    const size_t nChunks = (bytes + FILM_STAGE_BYTES - 1) / FILM_STAGE_BYTES;
+    auto issue = [&](size_t c) {
+        const size_t off = c * FILM_STAGE_BYTES, len = std::min(FILM_STAGE_BYTES, bytes - off);
+        HIP_TRY(hipMemcpyAsync(sd.stage[c & 1], (const char *) dFilm + off, len, hipMemcpyDeviceToHost, sd.stream));
+        HIP_TRY(hipEventRecord(sd.stageDone[c & 1], sd.stream));
+    };
+    if (nChunks) issue(0);
+    for (size_t c = 0; c < nChunks; ++c) {
+        if (c + 1 < nChunks) issue(c + 1);                     /* chunk c + 1 lands in the other buffer while chunk c is moved out of this one */
+        HIP_TRY(hipEventSynchronize(sd.stageDone[c & 1]));
+        const size_t off = c * FILM_STAGE_BYTES, len = std::min(FILM_STAGE_BYTES, bytes - off);
+        parallelCopy((char *) dst + off, (const char *) sd.stage[c & 1], len);
+    }
+}
+
+void *phip_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) { setErr(PHIP_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+void phip_host_free(void *p) { if (p) (void) hipHostFree(p); }
+
 int phip_render(phip_scene *scene, const phip_render_params *params, float *out_rgbaw, phip_stats *out_stats) {
     if (!scene || !params || !out_rgbaw) return setErr(PHIP_ERR_INVALID, "NULL argument");
     try {
@@ -1568,7 +1678,12 @@ int phip_render(phip_scene *scene, const phip_render_params *params, float *out_
         }
         int rc = renderImpl(scene, params, sd.film.p, out_stats);
         if (rc != PHIP_OK) return rc;
-        HIP_TRY(hipMemcpy(out_rgbaw, sd.film.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        const auto t0 = std::chrono::steady_clock::now();
+        filmToHost(sd, out_rgbaw, sd.film.p, n * sizeof(float));
+        if (out_stats) {
+            out_stats->d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            out_stats->render_ms += out_stats->d2h_ms;
+        }
         return PHIP_OK;
     } catch (const std::invalid_argument &e) {
         return setErr(PHIP_ERR_INVALID, e.what());

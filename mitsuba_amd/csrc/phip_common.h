@@ -2,10 +2,10 @@
  * phip_common.h -- what every translation unit of libphip.so starts with: HIP, the C ABI, the device scene layout and
  * shading functions (dv_scene.h), the path-pool layout (k_pool.h), the error macro.
  *
- * libphip.so is built from three sources (six objects) so that they compile in parallel (the shading kernels are 40
+ * libphip.so is built from three sources (eight objects) so that they compile in parallel (the shading kernels are 40
  * template instantiations):
  *   phip.hip        host side (scene build, render loop, multi-device orchestration, C ABI) + traversal and film kernels
- *   phip_shade.hip  k_shade / k_shade_direct instantiations behind phipLaunchShadeF<n> (compiled five times, -DSHADE_FEAT=0..3 and 8: the QMC samplers)
+ *   phip_shade.hip  k_shade / k_shade_direct instantiations behind phipLaunchShadeF<n> (compiled six times, -DSHADE_FEAT=0..3, 8 and 11: the QMC samplers)
  *   phip_mega.hip   k_mega instantiations behind phipLaunchMega
  * No device function is called across units (everything on the device side is inline in headers), so no -fgpu-rdc.
  */
@@ -49,6 +49,6 @@ using namespace pt;
 PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3) PHIP_DECLARE_SHADE(8) PHIP_DECLARE_SHADE(11)
 #undef PHIP_DECLARE_SHADE
 /* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */
-int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, bool flat, size_t ldsBytes);
+int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, int flat /* 0 / DevScene::flatMode */, size_t ldsBytes);
 void phipLaunchMega(int materialMask, bool strictNormals, dim3 grid, size_t ldsBytes, hipStream_t stream,
                     const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);

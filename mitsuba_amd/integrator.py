@@ -117,6 +117,32 @@ class HDRFilm:
         return out
 
 
+class PinnedFilm(HDRFilm):
+    """HDRFilm whose storage is page-locked (phip_host_alloc): PathHIP.render_into(scene, film.ptr, spp) receives the frame in one
+    asynchronous device-to-host copy instead of the staged copy pageable memory needs."""
+
+    def __init__(self, width, height):
+        n = width * height * 5
+        self._p = _ffi.lib().phip_host_alloc(n * 4)
+        if not self._p:
+            raise RuntimeError("phip_host_alloc: " + _ffi.last_error())
+        self.ptr = self._p
+        self.storage = np.ctypeslib.as_array(C.cast(C.c_void_p(self._p), C.POINTER(C.c_float)), shape=(height, width, 5))
+        self.storage[...] = 0
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.storage = None
+            _ffi.lib().phip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PathHIP:
     """`path_hip` integrator: MIPathTracer semantics, MI355X execution."""
 
@@ -155,6 +181,20 @@ class PathHIP:
         if rc != 0:
             raise _ffi.PhipError(rc, "phip_render")     # Log(EError, ...) throws in the reference
         film.put(block)
+        return True
+
+    def render_into(self, scene, host_ptr, spp, seed=0, shard_index=0, shard_count=1, flags=0, **extra):
+        """phip_render into the caller's host memory (height x width x 5 float32 at address `host_ptr`): what the Mitsuba shim does with
+        the film's bitmap.  Pinned memory (PinnedFilm below, torch pin_memory) gets the film in one asynchronous copy."""
+        self._scene = scene
+        p = self.params(scene, spp, seed, shard_index, shard_count, flags, **extra)
+        st = A.phip_stats()
+        rc = _ffi.lib().phip_render(scene._h, C.byref(p), C.cast(C.c_void_p(host_ptr), C.POINTER(C.c_float)), C.byref(st))
+        self.stats = st
+        if rc == A.PHIP_ERR_CANCELLED:
+            return False
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_render")
         return True
 
     def render_device(self, scene, d_out_ptr, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None, **extra):

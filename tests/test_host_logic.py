@@ -68,7 +68,7 @@ def test_big_scene_generators_are_deterministic(gauss):
 
 def test_oracle_rejects_malformed_scenes(oracle, gauss):
     sb = S.cornell_box(16, 16, gauss)
-    d = sb.desc(); d.abi_version = 7
+    d = sb.desc(); d.abi_version = 99
     with pytest.raises(RuntimeError, match="ABI"):
         oracle.OracleScene(d)
     sb = S.cornell_box(16, 16, gauss); sb.shapes[3]["material"] = 99

@@ -59,11 +59,15 @@ def test_ray_kernel_of_the_big_scenes_fits_six_waves_per_simd():
 def test_fused_kernel_keeps_four_waves_without_scratch():
     flags = next(u[1] for u in _ffi.UNITS if u[0] == "phip_mega.hip")
     res = resources("phip_mega.hip", flags)
-    flat = [v for name, v in res.items() if name.startswith("_Z6k_megaILi0ELb0ELb1E")]          # diffuse, no strictNormals, flat leaf table: C2's kernel
+    flat = [v for name, v in res.items() if name.startswith("_Z6k_megaILi0ELb0ELi2E")]          # diffuse, no strictNormals, packed flat table + record masks: C2's kernel
     assert flat and flat[0]["vgprs"] <= 128 and flat[0]["scratch"] == 0, flat
+    n = 0
     for name, v in res.items():
         if name.startswith("_Z6k_mega"):
-            assert v["vgprs"] <= 128, (name, v)
+            n += 1
+            assert v["vgprs"] <= 128 and v["scratch"] == 0, (name, v)
+            assert 4 * (v["lds"] + 12 * 1024) <= 160 * 1024, (name, v)      # four blocks per CU with the Cornell box's 11 KB of dynamic LDS (tables, records, flat table)
+    assert n == 6                                                   # strictNormals x {BVH4 walk, flat table, packed flat table}
 
 
 def test_shading_kernels_of_the_metric_configurations_keep_their_waves():
