@@ -57,6 +57,41 @@ __device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, cons
     return maxt > mint;
 }
 
+/* The same statement without control flow (k_mega): the early returns of the loop above are divergent branches -- twenty exec-mask
+   manipulations around three short blocks -- for a test that fails for no ray of a closed scene.  Every axis is evaluated, the verdicts
+   are and-ed: nearT only grows and farT only shrinks along the axes, so "nearT <= farT after every axis" and the early return say the same;
+   the arithmetic on a ray that passes is the loop's, operation for operation. */
+template <bool SHADOW>
+__device__ __forceinline__ bool clipToSceneSel(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
+                                               float &mint, float &maxt, V3 &slab) {
+    float nearT = -INFINITY, farT = INFINITY;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
+        const bool zero = dd[i] == 0;
+        const float a = (minVal - origin) * rr[i], b = (maxVal - origin) * rr[i];
+        const bool sw = a > b;
+        const float t1 = sw ? b : a, t2 = sw ? a : b;
+        const float n2 = smax(t1, nearT), f2 = smin(t2, farT);
+        nearT = zero ? nearT : n2; farT = zero ? farT : f2;
+        ok = ok & (zero ? !((origin < minVal) | (origin > maxVal)) : (nearT <= farT));
+    }
+    mint = nearT; maxt = farT;
+    float rayMinT = rayMint;
+    {
+        float m = smax(smax(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+        if (!SHADOW) m = smax(m, PT_EPSILON);
+        rayMinT = (rayMinT == PT_EPSILON) ? rayMinT * m : rayMinT;
+    }
+    mint = (rayMinT > mint) ? rayMinT : mint;
+    maxt = (rayMaxt < maxt) ? rayMaxt : maxt;
+    return ok & (maxt > mint);
+}
+
 /* the same with the kind of the ray as a per-lane flag (the kernels that trace closest-hit and any-hit rays in one loop) */
 __device__ __forceinline__ bool clipToSceneRT(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
                                               float &mint, float &maxt, bool shadow, V3 &slab) {

@@ -30,12 +30,16 @@
 #ifndef MEGA_REGEN_QUEUE
 #define MEGA_REGEN_QUEUE 1           /* camera samples are prepared 64 at a time by the whole wave into an LDS queue (0: by the lanes whose paths ended, in every pass) */
 #endif
+#ifndef MEGA_CLIP_SEL
+#define MEGA_CLIP_SEL 1              /* the scene-box clip without control flow (k_clip.h: clipToSceneSel) */
+#endif
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
 enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
 
-template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2) */,
+          bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
     __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
                                                                    no wait -- and the three that count lanes as ballots in SGPRs: 66.9 vs 66.5 ms per C2 frame and
                                                                    125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
@@ -129,7 +133,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 if (valid) {
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) vmask, 0u));
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
-                    const V2 jit = streamJitter(rc, pixel, k);
+                    const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
                     const float sx = (float) px + jit.x, sy = (float) py + jit.y;
                     V3 o, d; float mint, maxt;
                     cameraRay(S.cam, sx, sy, o, d, mint, maxt);
@@ -188,7 +192,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 uint32_t px, py, k;
                 if (decodeId(rc, S.film, id, px, py, k)) {      /* ids outside the crop window (edge blocks) are consumed and skipped */
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
-                    const V2 jit = streamJitter(rc, pixel, k);
+                    const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
                     const float sx = (float) px + jit.x, sy = (float) py + jit.y;
                     V3 o, d; float mint, maxt;
                     cameraRay(S.cam, sx, sy, o, d, mint, maxt);
@@ -217,7 +221,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             TravResult r; r.prim = PHIP_NO_HIT; r.t = INFINITY; r.u = r.v = 0;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
-            if (clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp)) {
+            if (MEGA_CLIP_SEL ? clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp) : clipToScene<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp)) {
                 if (FLAT == 2) traverseFlat2<false>(flat, S.nFlatLeaves, stk.tris, o, d, rcp, mint, maxt, r, nNode, nTri);
                 else if (FLAT) traverseFlat<false>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
                 else traverse<false, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);
@@ -235,7 +239,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             uint32_t nv = 0;
             bool newRay;
             const LRegister acc{ accum };
-            ended = shadeVertex<MM, STRICT, 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
+            ended = shadeVertex<MM, STRICT, QMC ? 8 : 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
             if (ended) MEGA_COUNT(MC_VERTICES, nv);
         }
 
@@ -249,7 +253,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             TravResult r;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
-            if (clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp))
+            if (MEGA_CLIP_SEL ? clipToSceneSel<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp) : clipToScene<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp))
                 occluded = FLAT == 2 ? traverseFlat2<true>(flat, S.nFlatLeaves, stk.tris, o, d, rcp, mint, maxt, r, nNode, nTri)
                          : FLAT ? traverseFlat<true>(S, flat, S.nFlatLeaves, o, d, rcp, mint, maxt, stk, r, nNode, nTri)
                                 : traverse<true, true>(S, o, d, rcp, mint, maxt, stk, r, nNode, nTri);

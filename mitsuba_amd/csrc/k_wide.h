@@ -19,7 +19,7 @@
  */
 
 #ifndef WIDE_STACK_LDS
-#define WIDE_STACK_LDS 10                /* 8-byte entries per lane in LDS (20 KB per block of 256) */
+#define WIDE_STACK_LDS 9                 /* 8-byte entries per lane in LDS (18 KB per block of 256) */
 #endif
 #ifndef WIDE_BLOCK
 #define WIDE_BLOCK 256                   /* threads per block of k_rays_w.  Measured (round 2): ONE block of 1024 per CU, whose LDS then holds a single copy of the
@@ -29,7 +29,7 @@
                                             per SIMD: blocks of 512 with a 150-node cache / of 768 with 240 nodes: 159.5 / 158.6 ms vs 158.8 (C3) -- still nothing */
 #endif
 #ifndef WIDE_NODE_CACHE_MAX
-#define WIDE_NODE_CACHE_MAX 64           /* top-of-tree nodes (BFS order) staged in LDS by k_rays_w: 5 KB per block */
+#define WIDE_NODE_CACHE_MAX 48           /* top-of-tree nodes (BFS order) staged in LDS by k_rays_w: 3.75 KB per block */
 #endif
 #define WIDE_NODE_CACHE_RAYCAST 64       /* ... by k_raycast_w (blocks of 256, several per CU) */
 #ifndef WIDE_TYPED
@@ -49,14 +49,16 @@
 #define WIDE_PROFILE 0
 #endif
 #ifndef WIDE_WAVES
-#define WIDE_WAVES 6                     /* waves per SIMD of k_rays_w = blocks of 256 per CU.  The kernel needs 74 VGPRs (flat loop, wave-uniform state in
-                                            SGPRs, stack addresses rebuilt from the lane index: see persistentTraverseWide), i.e. 6 waves fit 80 VGPRs without
-                                            scratch; its 91 SGPRs admit 7 blocks per CU (MI355X guide: 82..96 SGPRs -> 7, whatever the occupancy API says), and
-                                            6 x (20 KB stack + 5 KB node cache) fit the CU's 160 KB of LDS.  Measured (C3 / C4 at 128 spp, ray-kernel ms per
-                                            frame, profiles/r03_gpu_call_i.log): nested loop at 4 waves (110 VGPRs) 191.8 / 385.4 -- flat loop at 4 waves
-                                            188.7 / 376.6 -- 5 waves 169.1 / 343.0 -- 6 waves 158.9 / 327.5 -- 7 waves (72 VGPRs, 9-entry stack, 48-node
-                                            cache) 167.0 / 336.9 -- 8 waves (64 VGPRs + 52 B of scratch) 241.0 / 488.3.  tests/test_kernel_resources.py
-                                            pins the register counts. */
+#define WIDE_WAVES 7                     /* waves per SIMD of k_rays_w = blocks of 256 per CU.  Round 3: 74 VGPRs (flat loop, wave-uniform state in SGPRs, stack
+                                            addresses rebuilt from the lane index: see persistentTraverseWide), six waves -- measured C3 / C4 at 128 spp, ray-kernel
+                                            ms per frame: nested loop at 4 waves (110 VGPRs) 191.8 / 385.4 -- flat loop at 4 waves 188.7 / 376.6 -- 5 waves
+                                            169.1 / 343.0 -- 6 waves 158.9 / 327.5 -- 7 waves (72 VGPRs, 9-entry stack, 48-node cache) 167.0 / 336.9 -- 8 waves
+                                            (64 VGPRs + 52 B of scratch) 241.0 / 488.3.  Round 4: with the Wald test's axis permutation as selects
+                                            (WIDE_WALD_SEL) the kernel needs 64 VGPRs without scratch, and the seventh wave pays (profiles/r04_gpu_call_e_*):
+                                            branches, 6 waves 159.3 / 327.5 -- selects, 6 waves 156.1 / 321.6 -- 7 waves (9-entry stack, 48-node cache)
+                                            152.6 / 317.1 -- 8 waves (8-entry stack, 32-node cache) 155.6 / 323.5.  Its 91 SGPRs admit 7 blocks per CU (MI355X
+                                            guide: 82..96 SGPRs -> 7), 7 x (18 KB stack + 3.75 KB node cache) fit the CU's 160 KB of LDS.
+                                            tests/test_kernel_resources.py pins the register counts. */
 #endif
 
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
@@ -365,6 +367,9 @@ enum { WW_RAYS = 0, WW_STEPS, WW_SH_RAYS, WW_SH_STEPS, WW_COUNT };     /* 64-bit
 #define WM_HANDLE 0x0FFFFFFFu
 #define WM_SHADOW 0x80000000u
 #ifndef WIDE_FLAT
+#ifndef WIDE_WALD_SEL
+#define WIDE_WALD_SEL 1                  /* the Wald test's axis permutation as selects (k_traverse.h: waldIntersectSel) instead of three divergent branches */
+#endif
 #define WIDE_FLAT 1                      /* ONE loop (refill test, then one traversal iteration of the live lanes) instead of a traversal loop nested in a refill loop */
 #endif
 #if WIDE_FLAT
@@ -416,7 +421,7 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                 WIDE_LOAD_TRI(S, tg.x + bit, a, b, c)
                 steps += 0x10000u;
                 float tu, tv, tt;
-                if (waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {
+                if (WIDE_WALD_SEL ? waldIntersectSel(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt) : waldIntersect(a, b, c, ray.o, ray.d, ray.mint, ray.maxt, tu, tv, tt)) {
                     if (shadow) { res.prim = 0; finished = true; }
                     else if (winsTie(tt, pm_to_bits(c.z), res.t, res.prim & HIT_PRIM_MASK)) {      /* (res.prim is the packed hit word: one register for primitive and class) */
                         ray.maxt = tt; res.t = tt; res.u = tu; res.v = tv; res.prim = pm_to_bits(c.z) | (pm_to_bits(c.w) << HIT_CLASS_SHIFT);

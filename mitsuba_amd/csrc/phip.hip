@@ -971,7 +971,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
     const bool rinv = p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY;
     const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED || rinv;     /* served by the wavefront kernels compiled with FEAT bit 3 */
-    bool fused = !direct && !qmc && sc->fitsLds && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
+    bool fused = !direct && sc->fitsLds && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
     if (qmc && p->sampler == PHIP_SAMPLER_SOBOL) {
         /* the plugin's tables, uploaded once per (pointer, size): ~210 KB of direction numbers + the two 52-word enumeration rows */
         const size_t nm = (size_t) p->sobol_dimensions * PHIP_SOBOL_MATRIX_SIZE;
@@ -1062,7 +1062,10 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                (at most 8 resident blocks of 256 per CU), the BVH4 also by one-lane-per-slot launches */
             const bool canSpill = sc->wide ? (int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS : 3 * ((int) sc->bvh.maxDepth - 1) + 1 > (int) D.stackDepth;
             const bool persistentOnly = sc->wide || (sc->traversal == 2 && sc->bvh.nNodes >= 64 && !getenv("PHIP_MERGED"));
-            const size_t spillLanes = !canSpill ? (size_t) WIDE_BLOCK : (persistentOnly ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : laneCap);
+            /* (every block is handed spill + blockIdx * WIDE_BLOCK * SPILL_DEPTH, so the buffer covers the whole grid also when the host's depth bound
+               says that no lane can reach it: 200 MB of 288 GB against a silent out-of-bounds write should that hand-derived bound ever be off) */
+            (void) canSpill;
+            const size_t spillLanes = persistentOnly ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : laneCap;
             if (sd.spill.n < spillLanes * SPILL_DEPTH) sd.spill.alloc(spillLanes * SPILL_DEPTH);
         }
         if (sd.stat.n < (size_t) ST_COUNT * nWaves) sd.stat.alloc((size_t) ST_COUNT * nWaves);
@@ -1112,7 +1115,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
     if (fused) {
         const size_t megaLds = megaLdsBytesOf(D);
-        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, megaLds));
+        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, qmc, megaLds));
         if (const char *e = getenv("PHIP_MEGA_BLOCKS")) perCU = std::max(1, std::min(perCU, atoi(e)));
         if (perCU <= 0) throw std::runtime_error("k_mega does not fit a compute unit");
         megaGrid = dim3((unsigned) (nCU * perCU));
@@ -1195,7 +1198,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipMemsetAsync(sd.stat.p, 0, (size_t) ST_COUNT * M.nWaves * sizeof(unsigned long long), stream));
             if (rc.totalIds) {
                 if (timing) evFused.record(stream);
-                phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaGrid, megaLdsBytesOf(D), stream, D, M, rc, sd.L.p);
+                phipLaunchMega(sc->materialMask, p->strict_normals != 0, qmc, megaGrid, megaLdsBytesOf(D), stream, D, M, rc, sd.L.p);
                 if (timing) evFused.record(stream);
                 iter = 1;
             }

@@ -49,6 +49,6 @@ using namespace pt;
 PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3) PHIP_DECLARE_SHADE(8) PHIP_DECLARE_SHADE(11)
 #undef PHIP_DECLARE_SHADE
 /* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */
-int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, int flat /* 0 / DevScene::flatMode */, size_t ldsBytes);
-void phipLaunchMega(int materialMask, bool strictNormals, dim3 grid, size_t ldsBytes, hipStream_t stream,
+int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, int flat /* 0 / DevScene::flatMode */, bool qmc, size_t ldsBytes);
+void phipLaunchMega(int materialMask, bool strictNormals, bool qmc, dim3 grid, size_t ldsBytes, hipStream_t stream,
                     const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);

@@ -645,6 +645,15 @@ def test_halton_and_hammersley_samplers_match_oracle(gpu, phip, oracle, gauss):
         assert rel_l2(acc, whole.storage) < 1e-6
         ctr = HDRFilm(32, 32); assert integ.render(gs, ctr, 16)
         assert 1e-3 < rel_l2(whole.storage, ctr.storage) < 0.3
+        # the device copies of the tables are keyed by CONTENT: the plugin refills its permutation vector in place when `scramble` changes
+        # (same address, same size), and phip.h only promises "read during the call"
+        primes, faure = qmc_tables(-1); _, rnd = qmc_tables(7)
+        buf = faure.copy()
+        a = HDRFilm(32, 32); assert integ.render(gs, a, 16, sampler=kind, qmc=(primes, buf))
+        buf[:] = rnd
+        b = HDRFilm(32, 32); assert integ.render(gs, b, 16, sampler=kind, qmc=(primes, buf))
+        fresh = HDRFilm(32, 32); assert integ.render(gs, fresh, 16, sampler=kind, qmc=(primes, rnd))
+        assert (b.storage == fresh.storage).all() and (a.storage == whole.storage).all() and not (a.storage == b.storage).all()
         # errors: no tables, rrDepth 1, `direct`
         with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sampler=kind)
         with pytest.raises(PhipError): PathHIP(rrDepth=1).render(gs, HDRFilm(32, 32), 16, **kw)
