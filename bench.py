@@ -55,7 +55,7 @@ EXTRA_SINGLE_GPU = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md
 MULTI_GPU_JOB = "atrium_3840x2160_1024spp_md8"
 MULTI_GPU_SLICE = "atrium_3840x2160_64spp_md8"        # the same job at 1/16 of the samples per pixel: its single-GPU rate
 MULTI_GPU_MAX_STEPS = 3
-CPU_BASELINE_EXTRA = "atrium_1920x1080_64spp_md8"      # the second scene of the metric gets a CPU figure of its own
+CPU_BASELINE_EXTRA = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8"]      # every workload of the line gets a bounded CPU figure of its own
 
 
 def make_integrator(md):
@@ -253,6 +253,11 @@ def roofline(r):
             if k.split("<")[0] == name:
                 return v
         return None
+    # the PMC summaries are canned (counter passes cannot run inside the timed region): each carries the id of the library it was taken on
+    from mitsuba_amd import _ffi as _F
+    cur = _F.lib().phip_build_id().decode()
+    ids = {"traffic": (traffic or {}).get("build_id"), "valu": (valu or {}).get("build_id"), "tcp": (tcp or {}).get("build_id")}
+    stale = sorted(k for k, v in ids.items() if (traffic, valu, tcp)[("traffic", "valu", "tcp").index(k)] is not None and v != cur)
     tk = by_kernel((traffic or {}).get("kernels"))
     hbm_bytes = tk["hbm_bytes_per_launch"] if tk else None
     hbm_gbs = (hbm_bytes / 1e9) / (avg_ms / 1e3) if (hbm_bytes and avg_ms > 0) else None
@@ -266,7 +271,11 @@ def roofline(r):
            "note": "achieved / frac = MEASURED HBM bytes per launch (PMC) / live launch time (/ 8 TB/s); the SURVEY 8(d) algorithmic bytes "
                    "(node + record fetches, ray / hit state) are listed beside it but are served by LDS / L1 / L2 / Infinity Cache, not by "
                    "the HBM pins.  `bound` names the largest of the three measured fractions hbm / valu / vmem",
-           "kernel_ms_per_step": {k: round(a[k + "_kernel_ms"] / r["steps"], 3) for k in ("fused", "trace", "shadow", "shade", "film")}}
+           "kernel_ms_per_step": {k: round(a[k + "_kernel_ms"] / r["steps"], 3) for k in ("fused", "trace", "shadow", "shade", "film")},
+           "stale_counters": bool(stale),
+           "counters_build_ids": {"library": cur, **ids, "note": ("the PMC summaries under profiles/ named in *_source were taken on ANOTHER build than the one timed here (%s): "
+                                                                  "launch times are live, bytes / lane counts are that build's" % ", ".join(stale)) if stale else
+                                                                 "counter summaries and timed library are the same build"}}
     vk = by_kernel(valu)
     if vk:
         out["valu"] = {"frac": vk.get("valu_frac"), "issue_frac": vk.get("valu_issue_frac"), "lane_util": vk.get("lane_util"),
@@ -289,6 +298,15 @@ def roofline(r):
                        "lane_loads_per_ray": round(loads / max(a["closest_rays"] + a["shadow_rays"], 1), 2),
                        "peak_source": rsrc, "peak_definition": "every lane of the chip gathering 16 B from an L1-resident set, 8 waves per SIMD (L2-resident set: %.0f, Infinity-Cache-resident: %.0f G lane-loads/s)"
                        % (((vroof or {}).get("peak_lane_random_16B") or {}).get("2MB_L2", 0) / 1e9, ((vroof or {}).get("peak_lane_random_16B") or {}).get("16MB_MALL", 0) / 1e9)}
+        if ck and ck.get("lines_per_instruction") and ck.get("clk_per_wave_instruction_per_cu") and ck.get("l1_hit_rate") is not None and ck.get("l2_hit_rate") is not None:
+            # what the texture-data path allows for this kernel's line mix (the measured table of profiles/r03_vmem_roof.json): a 16-byte wave
+            # instruction occupies the CU's return path for 17 clk, an L1 miss served by L2 costs 2.3 clk of the CU, one served by the Infinity Cache 7.6
+            misses = ck["lines_per_instruction"] * (1.0 - ck["l1_hit_rate"])
+            allowed = 17.0 + misses * (ck["l2_hit_rate"] * 2.3 + (1.0 - ck["l2_hit_rate"]) * 7.6)
+            out["vmem"]["model_frac"] = round(min(allowed / ck["clk_per_wave_instruction_per_cu"], 1.0), 4)
+            out["vmem"]["model_note"] = ("allowed / measured clk per wave instruction and CU = %.1f / %.1f for %.1f distinct lines per instruction at L1 / L2 hit rates %.2f / %.2f: "
+                                         "the share of the texture-data path's throughput for THIS line mix (frac above is against fully divergent L1-resident gathers)"
+                                         % (allowed, ck["clk_per_wave_instruction_per_cu"], ck["lines_per_instruction"], ck["l1_hit_rate"], ck["l2_hit_rate"]))
         if ck:
             out["vmem"].update({"td_busy_frac": ck.get("td_busy_frac"), "l1_hit_rate": ck.get("l1_hit_rate"), "l2_hit_rate": ck.get("l2_hit_rate"),
                                 "lines_per_wave_instruction": ck.get("lines_per_instruction"), "clk_per_wave_instruction_per_cu": ck.get("clk_per_wave_instruction_per_cu"),
@@ -345,7 +363,8 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(headline)                   # before the GPU phase: the GPU is busy for the rest of the run
         if not args.workload and not args.no_extra:
-            cpu_extra[CPU_BASELINE_EXTRA] = cpu_baseline(CPU_BASELINE_EXTRA, seconds_target=8.0)
+            for wl in CPU_BASELINE_EXTRA:
+                cpu_extra[wl] = cpu_baseline(wl, seconds_target=8.0)
 
     steps, warmup = args.steps, args.warmup
     single = None
@@ -375,7 +394,7 @@ def main():
             "steps": steps, "warmup": warmup, "ms_per_step": s["ms_per_step"],
             # every job of this bench is a FIXED frame: more GPUs split the same blocks (strong scaling), also at N = 1
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": headline, "scene": s["scene"], "triangles": s["triangles"], "width": s["width"], "height": s["height"],
+            "config": {"workload": headline, "scene": s["scene"], "scene_generator": "mitsuba_amd/scene.py rev 3 (round 3 shrank the atrium's balcony slabs by 3 cm: C3 / C4 / C5 numbers of rounds 1-2 are another scene)", "triangles": s["triangles"], "width": s["width"], "height": s["height"],
                        "spp": s["spp"], "integrator": s["integrator"], "rfilter": "gaussian stddev 0.5", "sampler": "ctr seed 0", "block_size": 32,
                        "parallelism": ("one fixed job: 32x32 blocks dealt round-robin in spiral order over %d GPU(s), " % n_gpus) +
                                       ("one host thread per GPU inside libphip + ncclReduce(sum) of the film" if in_library else
@@ -387,6 +406,15 @@ def main():
         }
         if n_gpus > 1:
             out["requested"] = {"steps": args.steps, "warmup": args.warmup}
+            out["roofline"]["scope"] = "the dominant kernel of ONE rank's share of the job (rank 0): the N-GPU line prices no collective -- the film reduce is reduce_ms of the library path / inside ms_per_step here"
+            out["cpu_baseline_note"] = "no CPU baseline on the N > 1 line (the N = 1 line carries one per workload)"
+            sbal, ssrc = profile_json("shard_balance", "")
+            pred = ((sbal or {}).get("N") or {}).get(str(n_gpus))
+            if pred:
+                out["predicted_scaling_efficiency"] = pred.get("predicted_scaling_efficiency")
+                out["prediction"] = {"source": ssrc, "max_over_mean_shard_time": pred.get("max_over_mean"), "loss_to_imbalance": pred.get("loss_to_imbalance"),
+                                     "loss_to_fixed_costs": pred.get("loss_to_fixed_costs"), "reduce_s_estimate": pred.get("reduce_s_estimate"),
+                                     "note": "tools/shard_balance.py: the N shards of the job's 64-spp slice rendered one after another on ONE GPU; efficiency = T(1) / (N (max shard time + ring reduce at 153 GB/s per link))"}
             if single:
                 out["single_gpu_same_job"] = single
                 out["scaling_efficiency"] = round(s["value"] / (n_gpus * single["value"]), 4)

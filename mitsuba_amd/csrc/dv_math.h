@@ -317,17 +317,25 @@ struct SobolTab {
     uint32_t dims, logRes, scramble;    /* m_scramble truncated to 32 bits (sobolseq.h:86: sampleSingle(index, dimension, (uint32_t) scramble)) */
     float resolution;                   /* 2^logRes */
 };
+/* The loops of sobolseq.h are `for (; bits; bits >>= 1, ++c) if (bits & 1) acc ^= table[c]`: a table read behind a branch behind a shift, one
+   memory round trip per bit -- ~28 dependent round trips per number drawn (C2 with <sampler type="sobol"/>: 158.8 ms per frame in k_mega, 173 ms in
+   the film pass that re-derives the pixel jitter).  XOR does not care about order and a zero changes nothing, so every row up to the highest set
+   bit is read unconditionally, eight reads in flight, and masked by its bit: the same number. */
+DV uint32_t bitLength32(uint32_t v) { return v ? 32u - (uint32_t) __builtin_clz(v) : 0u; }
+DV uint32_t bitLength64(uint64_t v) { return v ? 64u - (uint32_t) __builtin_clzll((unsigned long long) v) : 0u; }
 /* index of the frame-th point of the sequence that falls into pixel (px, py): sobol::look_up, sobolseq.h:94-130 */
 DV uint64_t sobolLookUp(const SobolTab &T, uint32_t frame, uint32_t px, uint32_t py) {
     const uint32_t m = T.logRes, m2 = m << 1;
     uint64_t index = (uint64_t) frame << m2;
     uint64_t delta = 0;
-    for (uint32_t c = 0; frame; frame >>= 1, ++c)
-        if (frame & 1u) delta ^= T.vdc[c];
+    const uint32_t nf = bitLength32(frame);
+#pragma unroll 8
+    for (uint32_t c = 0; c < nf; ++c) { const uint64_t v = T.vdc[c]; delta ^= ((frame >> c) & 1u) ? v : 0ull; }
     const uint64_t scramble = (uint64_t) (T.scramble >> (32u - m));
-    uint64_t b = ((((uint64_t) px ^ scramble) << m) | ((uint64_t) py ^ scramble)) ^ delta;
-    for (uint32_t c = 0; b; b >>= 1, ++c)
-        if (b & 1ull) index ^= T.vdcInv[c];
+    const uint64_t b = ((((uint64_t) px ^ scramble) << m) | ((uint64_t) py ^ scramble)) ^ delta;
+    const uint32_t nb = bitLength64(b);
+#pragma unroll 8
+    for (uint32_t c = 0; c < nb; ++c) { const uint64_t v = T.vdcInv[c]; index ^= ((b >> c) & 1ull) ? v : 0ull; }
     return index;
 }
 /* SobolSampler::setSampleIndex, sobol.cpp:207-219 */
@@ -337,8 +345,10 @@ DV uint64_t sobolSampleIndex(const SobolTab &T, uint32_t sampleIndex, uint32_t p
 /* sobol::sampleSingle, sobolseq.h:42-58 */
 DV float sobolSample(const SobolTab &T, uint64_t index, uint32_t dimension) {
     uint32_t result = T.scramble;
-    for (uint32_t i = dimension * 52u; index; index >>= 1, ++i)
-        if (index & 1ull) result ^= T.matrices[i];
+    const uint32_t *row = T.matrices + dimension * 52u;
+    const uint32_t n = bitLength64(index);
+#pragma unroll 8
+    for (uint32_t i = 0; i < n; ++i) { const uint32_t v = row[i]; result ^= ((index >> i) & 1ull) ? v : 0u; }
     const float v = (float) result * (1.0f / 4294967296.0f);
     return 0.99999994f < v ? 0.99999994f : v;            /* std::min(result * 2^-32, ONE_MINUS_EPS_FLT) */
 }

@@ -23,28 +23,27 @@ DV float slabRcpFrom(float d, float rcp) {
 /* scene-box clip + adaptive epsilon, src/librender/skdtree.cpp:112-142 (closest) / :207-226 (shadow).  Also hands out the
    reciprocal direction for the slab tests: the clip divides by the same three components (an IEEE division is ~12 instructions;
    a ray used to pay six of them). */
+/* one axis of the clip (skdtree.cpp:118-133): false = the ray misses the slab */
+__device__ __forceinline__ bool clipAxis(float origin, float dir, float rcp, float minVal, float maxVal, float &nearT, float &farT) {
+    if (dir == 0) return !(origin < minVal || origin > maxVal);
+    float t1 = (minVal - origin) * rcp;
+    float t2 = (maxVal - origin) * rcp;
+    if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+    nearT = smax(t1, nearT);
+    farT = smin(t2, farT);
+    return nearT <= farT;
+}
 template <bool SHADOW>
 __device__ __forceinline__ bool clipToScene(const DevScene &S, const V3 &o, const V3 &d, float rayMint, float rayMaxt,
                                             float &mint, float &maxt, V3 &slab) {
     float nearT = -INFINITY, farT = INFINITY;
-    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
-    const float rr[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };       /* (inf for a zero component: not used by the clip then) */
-    slab = V3(slabRcpFrom(d.x, rr[0]), slabRcpFrom(d.y, rr[1]), slabRcpFrom(d.z, rr[2]));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float origin = oo[i], minVal = S.sceneMin[i], maxVal = S.sceneMax[i];
-        if (dd[i] == 0) {
-            if (origin < minVal || origin > maxVal) return false;
-        } else {
-            const float rcp = rr[i];
-            float t1 = (minVal - origin) * rcp;
-            float t2 = (maxVal - origin) * rcp;
-            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
-            nearT = smax(t1, nearT);
-            farT = smin(t2, farT);
-            if (!(nearT <= farT)) return false;
-        }
-    }
+    /* (scalars, not float[3] arrays walked by an unrolled loop: the arrays left a 36-byte private segment behind in every kernel that clips --
+       allocated per wave at launch although no instruction touched it) */
+    const float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;       /* (inf for a zero component: not used by the clip then) */
+    slab = V3(slabRcpFrom(d.x, rx), slabRcpFrom(d.y, ry), slabRcpFrom(d.z, rz));
+    if (!clipAxis(o.x, d.x, rx, S.sceneMin[0], S.sceneMax[0], nearT, farT)) return false;
+    if (!clipAxis(o.y, d.y, ry, S.sceneMin[1], S.sceneMax[1], nearT, farT)) return false;
+    if (!clipAxis(o.z, d.z, rz, S.sceneMin[2], S.sceneMax[2], nearT, farT)) return false;
     mint = nearT; maxt = farT;
     float rayMinT = rayMint;
     if (rayMinT == PT_EPSILON) {

@@ -355,6 +355,149 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled2(DevScene S, RenderConst r
     if (invalid) atomicAdd(invalidCount, invalid);
 }
 
+/* ---- round 4: the film as a SPLAT in registers + an ordered merge (filters of reach R <= 2: every default of the reference) ----
+ * The gathers above read each staged sample 25 times out of LDS (one per destination pixel under its footprint), stage 1.56 source
+ * pixels per destination pixel (the halo), and synchronise the block once per sample index: 5.0 ms per C2 frame at 0.17 of the HBM
+ * rate for what is one pass over 4.3 GB.  Here a thread OWNS a source pixel for the whole pass:
+ *   k_film_splat   block = one 16 x 16 patch of a render block (256 consecutive Morton indices: L is read in 1 KB runs, every sample once),
+ *                  thread = one source pixel; it walks the pixel's samples and keeps the (2R+1)^2 x 5 partial sums of its footprint in
+ *                  REGISTERS (125 accumulators for R = 2: jitter and ten table weights once per sample, then 25 products and 125 fused
+ *                  multiply-adds -- no LDS, no barrier inside the pass).  At the end the block folds its threads' partial sums into a
+ *                  (16+2R)^2 x 5 patch image in LDS -- (2R+1)^2 rounds, in round j every thread adds its j-th partial to the cell at
+ *                  offset j of its own pixel: distinct cells within a round, a fixed order over the rounds, so the sums are deterministic --
+ *                  and stores the patch image (8 KB);
+ *   k_film_merge   thread = one film pixel: adds the cells the (at most four of nine neighbouring) patch images hold for it, in a fixed order.
+ * ImageBlock::put's arithmetic per (sample, pixel) pair is unchanged (imageblock.h:148-186: validity test, block-local position, footprint,
+ * table weights, weight = wx * wy); the ORDER of the additions per film pixel is this kernel's own (per source pixel over its samples, then
+ * over the source pixels) -- the reference's depends on its thread schedule.  Both device paths (k_mega, wavefront) share it. */
+#ifndef FILM_SPLAT_PF
+#define FILM_SPLAT_PF 4
+#endif
+#ifndef FILM_SPLAT_WAVES
+#define FILM_SPLAT_WAVES 2                /* 125 accumulators + the working set of one sample: 256 VGPRs, two waves per SIMD (three: 168 VGPRs and 640 B of scratch) */
+#endif
+template <int R, bool QMC>
+__global__ __launch_bounds__(256, FILM_SPLAT_WAVES) void k_film_splat(DevScene S, RenderConst rc, const float4 *L, float *patchImages, unsigned long long *invalidCount) {
+    constexpr int NW = 2 * R + 1, T = 16 + 2 * R, NP = T * T;
+    __shared__ float sImg[NP * 5];
+    __shared__ float sTable[PHIP_FILTER_RESOLUTION + 1];
+    const DevFilm &F = S.film;
+    const uint32_t patchesPerTile = rc.tilePixels >> 8;
+    const uint32_t ts = blockIdx.x / patchesPerTile, q = blockIdx.x - ts * patchesPerTile;          /* local render block, patch inside it */
+    const uint32_t m = (q << 8) | threadIdx.x;                                                        /* Morton index of this thread's pixel in the render block */
+    const uint32_t org = rc.tileOrigin[ts];
+    const int offX = (int) (org & 0xFFFFu), offY = (int) (org >> 16);
+    const int sxP = offX + (int) compactBits(m), syP = offY + (int) compactBits(m >> 1);
+    const int lx = (int) compactBits(threadIdx.x), ly = (int) compactBits(threadIdx.x >> 1);        /* position inside the patch */
+    if (threadIdx.x <= PHIP_FILTER_RESOLUTION) sTable[threadIdx.x] = F.table[threadIdx.x];
+    for (int i = threadIdx.x; i < NP * 5; i += 256) sImg[i] = 0.0f;
+    __syncthreads();
+    const bool inside = sxP < F.width && syP < F.height;
+    /* the render block's bitmap: (offX - border, offY - border), bw x bh (imageblock.cpp:26-30, renderproc.cpp:160-173) */
+    const int gx = offX - F.border, gy = offY - F.border;
+    const int bw = min(F.blockSize, F.width - offX) + 2 * F.border, bh = min(F.blockSize, F.height - offY) + 2 * F.border;
+    f4v part[NW * NW]; float partW[NW * NW];                  /* (R, G, B, alpha) as register quads -- pairs for v_pk_fma_f32 without padding -- and the weight */
+#pragma unroll
+    for (int j = 0; j < NW * NW; ++j) { part[j] = f4v{ 0.0f, 0.0f, 0.0f, 0.0f }; partW[j] = 0.0f; }
+    unsigned long long invalid = 0;
+    if (inside) {
+        const uint32_t pixelP = (uint32_t) syP * (uint32_t) F.width + (uint32_t) sxP;
+        const float4 *src = L + ((((unsigned long long) ts * rc.sppPass) << (2 * rc.tileShift)) | m);
+        const size_t stride = (size_t) 1 << (2 * rc.tileShift);
+        constexpr uint32_t PF = FILM_SPLAT_PF;                                                                 /* samples in flight */
+        float4 pre[PF];
+#pragma unroll
+        for (uint32_t i = 0; i < PF; ++i) pre[i] = i < rc.sppPass ? src[i * stride] : make_float4(0, 0, 0, 0);
+        for (uint32_t k0 = 0; k0 < rc.sppPass; k0 += PF) {
+#pragma unroll
+            for (uint32_t i = 0; i < PF; ++i) {
+                const uint32_t k = k0 + i;
+                const float4 v = pre[i];
+                if (k + PF < rc.sppPass) pre[i] = src[(size_t) (k + PF) * stride];
+                const bool live = k < rc.sppPass;
+                /* (the pixel's coordinates are made opaque per sample: everything derived from them -- ten bitmap columns / rows, their float forms, the
+                   first rounds of the jitter hash -- is loop-invariant, and hoisted out of the loop it cost 35 registers the 125 accumulators need) */
+                int sx = sxP, sy = syP; uint32_t pixel = pixelP;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(sx), "+v"(sy), "+v"(pixel));
+#endif
+                const V2 jit = streamJitter<QMC>(rc, pixel, k + rc.sppFirst, (uint32_t) F.width);
+                const float px = (float) sx + jit.x, py = (float) sy + jit.y;
+                const float posx = px - 0.5f - (float) gx, posy = py - 0.5f - (float) gy;             /* block-bitmap coordinates */
+                /* validity check of ImageBlock::put (imageblock.h:148-151).  No branch around the 125 accumulators (the two paths' copies of them do not fit
+                   the register file): a rejected sample -- and the padding behind the pass's last sample -- is zero radiance under zero weights */
+                const bool bad = !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0;
+                invalid += (live && bad) ? 1ull : 0ull;
+                const bool ok = live && !bad;
+                /* footprint and weights, imageblock.h:159-180; wx[j] / wy[j] = weight of pixel sx - R + j / sy - R + j (0 outside the footprint or the bitmap) */
+                const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), bw - 1);
+                const int miny = max((int) ceilf(posy - F.radius), 0), maxy = min((int) floorf(posy + F.radius), bh - 1);
+                const f4v vv = { ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f };
+                float wx[NW], wy[NW];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const int bx = sx - R + j - gx, by = sy - R + j - gy;
+                    const float tx_ = sTable[min((int) fabsf(((float) bx - posx) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                    const float ty_ = sTable[min((int) fabsf(((float) by - posy) * F.scaleFactor), PHIP_FILTER_RESOLUTION)];
+                    wx[j] = (ok && bx >= minx && bx <= maxx) ? tx_ : 0.0f;
+                    wy[j] = (by >= miny && by <= maxy) ? ty_ : 0.0f;
+                }
+#pragma unroll
+                for (int jy = 0; jy < NW; ++jy) {
+#pragma unroll
+                    for (int jx = 0; jx < NW; ++jx) {
+                        const float w = wx[jx] * wy[jy];
+                        part[jy * NW + jx] = __builtin_elementwise_fma(f4v{ w, w, w, w }, vv, part[jy * NW + jx]);
+                        partW[jy * NW + jx] += w;
+                    }
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);               /* one sample after the other: interleaved, the unrolled copies' temporaries pushed the accumulators out of the registers */
+#endif
+            }
+        }
+    }
+    /* fold the threads' partial sums into the patch image: round j = offset (jx, jy) of every thread's own pixel */
+#pragma unroll
+    for (int j = 0; j < NW * NW; ++j) {
+        float *c = &sImg[((ly + j / NW) * T + (lx + j % NW)) * 5];
+        c[0] += part[j].x; c[1] += part[j].y; c[2] += part[j].z; c[3] += part[j].w; c[4] += partW[j];
+        __syncthreads();
+    }
+    float *dst = patchImages + (size_t) blockIdx.x * (NP * 5);
+    for (int i = threadIdx.x; i < NP * 5; i += 256) dst[i] = sImg[i];
+    if (invalid) atomicAdd(invalidCount, invalid);
+}
+
+/* thread = one film pixel: the sum of what the patch images around it hold for it (its own patch and those of the eight neighbouring patches
+   whose halo reaches it), own patch first, then row by row */
+template <int R>
+__global__ __launch_bounds__(256) void k_film_merge(DevScene S, RenderConst rc, const float *patchImages, const int32_t *tileSlot, int tilesX, float *out, int accumulate) {
+    constexpr int T = 16 + 2 * R, NP = T * T;
+    const DevFilm &F = S.film;
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= F.width || y >= F.height) return;
+    const int PX = x >> 4, PY = y >> 4, patchShift = (int) rc.tileShift - 4;                          /* patches per render-block side = 1 << patchShift */
+    float acc[5] = { 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const int dx = o == 0 ? 0 : ((o - (o <= 4 ? 1 : 0)) % 3) - 1, dy = o == 0 ? 0 : ((o - (o <= 4 ? 1 : 0)) / 3) - 1;      /* (0,0) first, then the other eight row by row */
+        const int qx = PX + dx, qy = PY + dy;
+        if (qx < 0 || qy < 0 || (qx << 4) >= F.width || (qy << 4) >= F.height) continue;
+        const int cx = x - (qx << 4) + R, cy = y - (qy << 4) + R;                                    /* cell of (x, y) in that patch's image */
+        if (cx < 0 || cy < 0 || cx >= T || cy >= T) continue;
+        const int tx = qx >> patchShift, ty = qy >> patchShift;
+        const int32_t ts = tileSlot[ty * tilesX + tx];
+        if (ts < 0) continue;                                                                         /* that render block belongs to another shard */
+        const uint32_t pq = (spreadBits((uint32_t) (qx - (tx << patchShift))) | (spreadBits((uint32_t) (qy - (ty << patchShift))) << 1));
+        const float *c = patchImages + ((size_t) ((uint32_t) ts << (2 * patchShift)) + pq) * (NP * 5) + (size_t) (cy * T + cx) * 5;
+        acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; acc[3] += c[3]; acc[4] += c[4];
+    }
+    float *o = out + ((size_t) y * F.width + x) * 5;
+    if (accumulate) { for (int i = 0; i < 5; ++i) o[i] += acc[i]; }
+    else { for (int i = 0; i < 5; ++i) o[i] = acc[i]; }
+}
+
 /* copy per-sample radiance out in [y][x][sample] order (tests) */
 __global__ void k_export_samples(DevScene S, RenderConst rc, const float4 *L, const int32_t *tileSlot, int tilesX,
                                  float4 *out, uint32_t sppTotal, uint32_t sampleOffset /* phip_render_params::sample_offset: index of the call's first sample */) {

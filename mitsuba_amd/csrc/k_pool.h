@@ -167,7 +167,32 @@ __device__ __forceinline__ V2 streamJitter(const RenderConst &rc, uint32_t pixel
 /* `direct`: shading sample i of kind `which` (0: emitter sample, direct.cpp:212-216; 1: BSDF sample, :251-255) of camera sample k.
    PHIP_SAMPLER_CTR: block 1 + i holds (emitter sample i, BSDF sample i).  PHIP_SAMPLER_LD: more than one sample of a kind is a
    requested 2D array (direct.cpp:139-146; the emitter array first), a single one the next 2D request of the sample (the jitter is 0) */
-__device__ __forceinline__ V2 streamDirectSample(const RenderConst &rc, uint32_t pixel, uint32_t k, int which, uint32_t i) {
+/* QMC, the sequence samplers (sobol.cpp:170-196,226-257 = halton.cpp:274-328,352-384 = hammersley.cpp:206-280): the integrator's requests are, in
+   this order, the emitter samples and the BSDF samples (direct.cpp:139-146, 212-216, 251-255).
+     more than one sample of a kind = a requested 2D ARRAY: array a (the emitter array first) owns dimensions 5 + 2 a, 6 + 2 a, and its element
+       k * count + i is THE POINT OF SAMPLE k * count + i OF THE PIXEL in those dimensions (generate(): look_up(j, pixel) / offset + j * stride) --
+       hammersley refuses arrays (hammersley.cpp:293-300), so does validateParams;
+     a single sample = the sample's next 2D request: the emitter sample at dimensions (2, 3) behind the camera sample; the BSDF sample at (2, 3)
+       when the emitter samples are an array, else at (5, 6) -- next2D() never hands out dimension 4 (`m_dimension + 1 >= m_arrayStartDim &&
+       m_dimension < m_arrayEndDim` with the arrays' range [5, 5) when none is requested: the skip k_shade.h restates for `path`).
+   A single request is made even when it is not used (zero samples of that kind, a BSDF without smooth component). */
+template <bool QMC = false>
+__device__ __forceinline__ V2 streamDirectSample(const RenderConst &rc, uint32_t pixel, uint32_t k, int which, uint32_t i, uint32_t filmWidth = 1u) {
+    if (QMC && isSequenceSampler(rc.sampler)) {
+        const uint32_t E = (uint32_t) rc.emitterSamples, B = (uint32_t) rc.bsdfSamples, count = which ? B : E;
+        const uint32_t px = pixel % filmWidth, py = pixel / filmWidth;
+        uint32_t dim; uint64_t idx;
+        if (count > 1u) {
+            dim = 5u + 2u * (which ? (E > 1u ? 1u : 0u) : 0u);
+            const uint32_t j = k * count + i;
+            idx = rc.sampler == PHIP_SAMPLER_SOBOL ? sobolLookUp(rc.sobol, j, px, py) : rinvSampleIndex(rc.rinv, j, px, py);
+        } else {
+            dim = which == 0 ? 2u : (E > 1u ? 2u : 5u);
+            idx = seqIndex(rc, k, px, py);
+        }
+        if (dim + 1u < seqDims(rc)) return V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
+        /* (beyond the tables -- the reference stops with an error there -- the counter stream below) */
+    }
     if (rc.sampler == PHIP_SAMPLER_LD) {
         const uint32_t E = (uint32_t) rc.emitterSamples, B = (uint32_t) rc.bsdfSamples, count = which ? B : E;
         float x, y;

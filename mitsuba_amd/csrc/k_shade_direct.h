@@ -13,7 +13,7 @@
  * thr = (bsdfVal, bsdfPdf) of the BSDF sample in flight, F_PREV_DELTA, F_SCATTERED (= a BSDF ray is in flight).
  */
 template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade_direct(DevScene S, PathPool P, RenderConst rc, float4 *L) {
-    constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0;
+    constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0, QMC = (FEAT & 8) != 0;
     __shared__ uint32_t waveCnt[BLOCK / 64];
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
     __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
@@ -53,7 +53,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
 
         /* the camera ray of this sample: direction, differentials (integrator.cpp:171-181) */
         const uint32_t px = info.y % (uint32_t) S.film.width, py = info.y / (uint32_t) S.film.width;
-        const V2 hc = streamJitter(rc, info.y, info.z);
+        const V2 hc = streamJitter<QMC>(rc, info.y, info.z, (uint32_t) S.film.width);
         const float sx = (float) px + hc.x, sy = (float) py + hc.y;
         V3 camD;
         if (first) {
@@ -152,7 +152,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                 if (round < E && (its.flags & TS_MF_SMOOTH)) {
                     DirectRec dRec;
                     dRec.ref = its.p; dRec.refN = refN; dRec.pdf = 0; dRec.emitter = -1;
-                    const V3 value = sampleEmitterDirect<ENV>(S, T, dRec, streamDirectSample(rc, info.y, info.z, 0, (uint32_t) round));
+                    const V3 value = sampleEmitterDirect<ENV>(S, T, dRec, streamDirectSample<QMC>(rc, info.y, info.z, 0, (uint32_t) round, (uint32_t) S.film.width));
                     if (dRec.pdf != 0 && !value.isZero()) {
                         const V3 wo = its.sh.toLocal(dRec.d);
                         float bPdf;
@@ -172,7 +172,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                 const int i = round - bs0;
                 if (i >= 0 && i < B) {
                     BSDFSample bs;
-                    const V3 bsdfVal = bsdfSample<MM>(bctx, streamDirectSample(rc, info.y, info.z, 1, (uint32_t) i), bs);
+                    const V3 bsdfVal = bsdfSample<MM>(bctx, streamDirectSample<QMC>(rc, info.y, info.z, 1, (uint32_t) i, (uint32_t) S.film.width), bs);
                     if (!bsdfVal.isZero()) {
                         const V3 wo = its.sh.toWorld(bs.wo);
                         const float woDotGeoN = dot(its.geoN, wo);
@@ -206,5 +206,5 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             P.state[slot] = info.w;
         }
     }
-    shadeEpilogue(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh0, sh1, sh2, vertices, done);
+    shadeEpilogue<QMC>(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh0, sh1, sh2, vertices, done);
 }

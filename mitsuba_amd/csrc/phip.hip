@@ -176,7 +176,7 @@ struct SceneDev {
     uint32_t rinvInvPerm2 = 0x4u, rinvInvPerm3 = 0x24u;                                                                         /* inverse permutations of bases 2 and 3, two bits per digit */
     DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
     DevBuf<unsigned int> drawCounters;                                                       /* k_rays_w: 2 x RAY_SHARDS sharded work counters */
-    DevBuf<float> film;
+    DevBuf<float> film, patchImg;                                                            /* patchImg: k_film_splat's 16 x 16 patch images (k_film.h) */
     uint32_t lastSpp = 0, nLocalTiles = 0; unsigned long long localPixels = 0;
     int tileKey[3] = { -1, -1, -1 };
     bool haveSamples = false;
@@ -801,7 +801,9 @@ static void phipLaunchShade(int feat, bool strictNormals, int materialMask, dim3
 }
 static void phipLaunchShadeDirect(int feat, int materialMask, dim3 grid, hipStream_t stream,
                                   const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
-    switch (feat & 3) {
+    switch (feat & 11) {
+        case 8: phipLaunchShadeDirectF8(materialMask, grid, stream, S, P, rc, L); break;
+        case 11: phipLaunchShadeDirectF11(materialMask, grid, stream, S, P, rc, L); break;
         case 0: phipLaunchShadeDirectF0(materialMask, grid, stream, S, P, rc, L); break;
         case 1: phipLaunchShadeDirectF1(materialMask, grid, stream, S, P, rc, L); break;
         case 2: phipLaunchShadeDirectF2(materialMask, grid, stream, S, P, rc, L); break;
@@ -857,7 +859,9 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
     if (p->sampler > PHIP_SAMPLER_HAMMERSLEY) throw std::invalid_argument("unknown sampler kind");
     if (p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY) {
         const char *name = p->sampler == PHIP_SAMPLER_HALTON ? "PHIP_SAMPLER_HALTON" : "PHIP_SAMPLER_HAMMERSLEY";
-        if (direct) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
+        /* `direct`: more than one sample of a kind is a requested sample array -- hammersley has none (hammersley.cpp:293-300: Log(EError)) */
+        if (direct && p->sampler == PHIP_SAMPLER_HAMMERSLEY && (p->emitter_samples > 1 || p->bsdf_samples > 1))
+            throw std::invalid_argument("PHIP_SAMPLER_HAMMERSLEY: request2DArray(): Not supported for the Hammersley QMC sequence! With `direct`, emitterSamples and bsdfSamples must be at most 1");
         if (!p->qmc_primes || p->qmc_dimensions < 8 || p->qmc_dimensions > 1024) throw std::invalid_argument(std::string(name) + ": qmc_primes / qmc_dimensions (the reference's prime table, 8 .. 1024 entries) are required");
         if (p->qmc_primes[0] != 2 || p->qmc_primes[1] != 3) throw std::invalid_argument(std::string(name) + ": qmc_primes must start 2, 3 (the pixel enumeration is over those bases)");
         for (uint32_t d = 0; d < p->qmc_dimensions; ++d) if (p->qmc_primes[d] < 2 || p->qmc_primes[d] > 65535u) throw std::invalid_argument(std::string(name) + ": qmc_primes out of range");
@@ -865,19 +869,21 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
             if (p->qmc_permutations[0] > 1 || p->qmc_permutations[1] > 1 || p->qmc_permutations[0] == p->qmc_permutations[1]) throw std::invalid_argument(std::string(name) + ": qmc_permutations does not start with a permutation of {0, 1}");
             if (p->qmc_permutations[2] > 2 || p->qmc_permutations[3] > 2 || p->qmc_permutations[4] > 2) throw std::invalid_argument(std::string(name) + ": the permutation of base 3 is not one of {0, 1, 2}");
         }
-        if (p->rr_depth < 2) throw std::invalid_argument(std::string(name) + ": rrDepth must be at least 2 (the dimension bookkeeping of halton.cpp:364-366 is restated for that case)");
+        if (!direct && p->rr_depth < 2) throw std::invalid_argument(std::string(name) + ": rrDepth must be at least 2 (the dimension bookkeeping of halton.cpp:364-366 is restated for that case)");
         if (sc->descCopy.film.crop_offset_x != 0 || sc->descCopy.film.crop_offset_y != 0) throw std::invalid_argument(std::string(name) + ": the crop window must start at the film's origin");
         const unsigned long long n = (unsigned long long) (p->sample_total > 0 ? p->sample_total : p->spp);
         if (n >= (1ull << 17)) throw std::invalid_argument(std::string(name) + ": at most 131071 samples per pixel (32-bit pixel offsets)");
     }
     if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) {
         const char *name = p->sampler == PHIP_SAMPLER_SOBOL ? "PHIP_SAMPLER_SOBOL" : "PHIP_SAMPLER_STRATIFIED";
-        if (direct) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
+        if (direct && p->sampler == PHIP_SAMPLER_STRATIFIED) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
         const DevScene &D0 = sc->devs[0]->dev;
         if (p->sampler == PHIP_SAMPLER_SOBOL) {
             if (!p->sobol_matrices || p->sobol_dimensions < 8) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_matrices / sobol_dimensions (the reference plugin's direction numbers) are required");
             if (p->sobol_log_resolution > 26) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_log_resolution out of range");
-            if (p->rr_depth < 2) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: rrDepth must be at least 2 (the dimension bookkeeping of sobol.cpp:241-242 is restated for that case)");
+            if (!direct && p->rr_depth < 2) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: rrDepth must be at least 2 (the dimension bookkeeping of sobol.cpp:241-242 is restated for that case)");
+            if (direct && (p->emitter_samples > 1 || p->bsdf_samples > 1) && p->sobol_log_resolution < 2)
+                throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sample arrays of `direct` need a film of more than two pixels per side (SobolSampler::generate enumerates them per pixel: sobol.cpp:182,190)");
             if (p->sobol_log_resolution > 1 && (!p->sobol_vdc || !p->sobol_vdc_inv)) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_vdc / sobol_vdc_inv are required when the film is enumerated per pixel");
             if (sc->descCopy.film.crop_offset_x != 0 || sc->descCopy.film.crop_offset_y != 0) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: the crop window must start at the film's origin");
             uint32_t need = 0; { uint32_t side = (uint32_t) std::max(D0.film.width, D0.film.height), r = 1; while (r < side) { r <<= 1; ++need; } }
@@ -1290,7 +1296,20 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             const int reach = (int) std::floor(D.film.radius + 0.5f);
             const int acc = (sppDone > 0 || accumulate) ? 1 : 0;
             const char *fv = getenv("PHIP_FILM_V1");                  /* experiment hook: the round-2 tiled kernel */
-            if (qmc)
+            const bool splat = reach <= 2 && tileShift >= 4 && bs == (1 << tileShift) && nLocalTiles > 0 && !getenv("PHIP_FILM_GATHER");     /* PHIP_FILM_GATHER: the tiled gathers of rounds 2 / 3 (A/B) */
+            if (splat) {
+                /* round 4: one pass over L with the footprint sums in registers, then an ordered merge of the 16 x 16 patch images (k_film.h) */
+                const int r = std::max(reach, 1), cells = (16 + 2 * r) * (16 + 2 * r) * 5;
+                const unsigned nPatches = (unsigned) nLocalTiles << (2 * (tileShift - 4));
+                if (sd.patchImg.n < (size_t) nPatches * cells) sd.patchImg.alloc((size_t) nPatches * cells);
+                const float4 *Lc = (const float4 *) sd.L.p;
+                if (r == 1) { if (qmc) hipLaunchKernelGGL((k_film_splat<1, true>), dim3(nPatches), dim3(256), 0, stream, D, rc, Lc, sd.patchImg.p, sd.invalid.p);
+                              else hipLaunchKernelGGL((k_film_splat<1, false>), dim3(nPatches), dim3(256), 0, stream, D, rc, Lc, sd.patchImg.p, sd.invalid.p);
+                              hipLaunchKernelGGL(k_film_merge<1>, fg, block, 0, stream, D, rc, (const float *) sd.patchImg.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut, acc); }
+                else        { if (qmc) hipLaunchKernelGGL((k_film_splat<2, true>), dim3(nPatches), dim3(256), 0, stream, D, rc, Lc, sd.patchImg.p, sd.invalid.p);
+                              else hipLaunchKernelGGL((k_film_splat<2, false>), dim3(nPatches), dim3(256), 0, stream, D, rc, Lc, sd.patchImg.p, sd.invalid.p);
+                              hipLaunchKernelGGL(k_film_merge<2>, fg, block, 0, stream, D, rc, (const float *) sd.patchImg.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut, acc); }
+            } else if (qmc)
                 hipLaunchKernelGGL(k_film<true>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
                                    acc, sd.invalid.p);
             else if (reach <= 2 && bs >= FILM_TILE + 2 * std::max(reach, 1) && !getenv("PHIP_FILM_GENERIC") && !(fv && atoi(fv))) {

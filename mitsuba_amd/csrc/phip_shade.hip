@@ -1,6 +1,6 @@
 /*
  * phip_shade.hip -- the shading kernels of the wavefront path: k_shade<materials, strictNormals, features> (k_shade.h) and
- * k_shade_direct<materials, features> (k_shade_direct.h), 40 instantiations.  Compiled once per feature set
+ * k_shade_direct<materials, features> (k_shade_direct.h), 44 instantiations.  Compiled once per feature set
  * (-DSHADE_FEAT=0..3: bit 0 = environment emitter, bit 1 = bitmap textures; 8 and 11: bit 3 = the QMC samplers, without / with both other features)
  * so that the objects build in parallel;
  * phip.hip dispatches on the scene's feature set (phipLaunchShade / phipLaunchShadeDirect).  See phip_common.h.
@@ -36,11 +36,7 @@ void SHADE_CAT(phipLaunchShadeF, SHADE_FEAT)(bool strictNormals, int materialMas
 
 void SHADE_CAT(phipLaunchShadeDirectF, SHADE_FEAT)(int materialMask, dim3 grid, hipStream_t stream,
                                                    const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
-#if SHADE_FEAT >= 8
-    throw std::runtime_error("the QMC samplers are built for the `path` integrator only");      /* (validateParams refuses it before) */
-#else
     /* `direct`: leaf BSDF models = diffuse only / all, strictNormals at run time */
     static const ShadeKernel table[2] = { k_shade_direct<0, SHADE_FEAT>, k_shade_direct<MM_ALL, SHADE_FEAT> };
     hipLaunchKernelGGL(table[(materialMask & MM_ALL) ? 1 : 0], grid, dim3(BLOCK), 0, stream, S, P, rc, L);
-#endif
 }

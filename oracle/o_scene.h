@@ -427,6 +427,8 @@ struct SampleSource {
     Vec2 single[2];
     void generateDirectArrays(size_t sampleCount, size_t emitterSamples, size_t bsdfSamples) {
         dirEmitterSamples = emitterSamples;
+        if (qmc == 3 && rinv->hammersley && (emitterSamples > 1 || bsdfSamples > 1))
+            throw std::runtime_error("request2DArray(): Not supported for the Hammersley QMC sequence!");       /* hammersley.cpp:293-300 */
         if (ctr) return;
         const size_t n[2] = { emitterSamples, bsdfSamples };
         for (int w = 0; w < 2; ++w) {
@@ -447,6 +449,24 @@ struct SampleSource {
     size_t dirEmitterSamples = 1;      /* (set by generateDirectArrays: which request / array the BSDF samples are depends on it) */
     Vec2 directSample(int which, size_t i, size_t count) const {
         if (!ctr) return count > 1 ? arrays[which][(size_t) sample * count + i] : single[which];
+        if (sequence()) {
+            /* sobol.cpp:170-196 / halton.cpp:274-328 (generate) and :238-257 / :352-384 (next2D).  More than one sample of a kind: requested array a
+               (direct.cpp:139-146: the emitter array first) owns dimensions 5 + 2 a and 6 + 2 a; its element sample * count + i is the point of
+               "sample j of this pixel", j = sample * count + i -- sobol::look_up(j, pixel), m_offset + j * m_stride.  A single sample: the next 2D
+               request -- dimensions (2, 3) for the emitter sample (the camera sample took 0 and 1); for the BSDF sample (2, 3) when the emitter
+               samples were an array, else m_dimension is 4 and next2D() moves on to the end of the arrays' range, 5 with no array requested: (5, 6) */
+            const uint32_t E = (uint32_t) dirEmitterSamples;
+            float f[4]; block(1 + (uint32_t) i, f);
+            const Vec2 fallback = which == 0 ? Vec2(f[0], f[1]) : Vec2(f[2], f[3]);
+            if (count > 1) {
+                const uint32_t dim = 5u + 2u * (which ? (E > 1 ? 1u : 0u) : 0u);
+                const uint32_t j = sample * (uint32_t) count + (uint32_t) i;
+                const uint64_t idx = qmc == 1 ? sobol->lookUp(j, px, py) : rinv->sampleIndex(j, px, py);
+                if (dim + 1 >= seqDims()) return fallback;
+                return Vec2(seqSample(idx, dim), seqSample(idx, dim + 1));
+            }
+            return sobol2D(which == 0 ? 2u : (E > 1 ? 2u : 5u), fallback);
+        }
         if (ld) {
             /* more than one sample of a kind: a requested 2D array (direct.cpp:139-146, the emitter array first) = ONE scrambled
                sequence of sampleCount * count points in a random order (ldsampler.cpp:193-197); a single one: the sample's next 2D request */

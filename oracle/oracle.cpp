@@ -98,7 +98,8 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
                 throw std::runtime_error("PHIP_SAMPLER_LD: on the counter stream, power-of-two sample count");
         }
         if (isQmc(p->sampler)) {
-            if (sampler_mode != 0 || p->integrator != PHIP_INTEGRATOR_PATH) throw std::runtime_error("the QMC samplers: `path`, counter-stream mode");
+            if (sampler_mode != 0) throw std::runtime_error("the QMC samplers: counter-stream mode");
+            if (p->integrator != PHIP_INTEGRATOR_PATH && p->sampler == PHIP_SAMPLER_STRATIFIED) throw std::runtime_error("PHIP_SAMPLER_STRATIFIED: `path` only");
             setQmc(scene, p, rp.qmc, rp.sobol, rp.stRes, rp.rinv);
         }
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;

@@ -111,6 +111,19 @@ def test_qmc_samplers_of_the_scene_reach_the_device(phip, ref, oracle, gauss):
             print("%s, %s: path_hip inside Mitsuba vs harness rel L2 %.3e; vs the reference's own path + %s on the CPU rel L2 %.3e" % (name, sampler, r, sampler, rc))
             assert r < 1e-5
             assert rc <= (0.6 if sampler == "stratified" else 1e-3), rc
+        # `direct` on the deterministic samplers: sample arrays (shadingSamples 3) and single samples -- direct_hip inside Mitsuba = the reference's direct + sampler on the CPU
+        from mitsuba_amd.integrator import DirectHIP
+        for sampler, kw, (e, b) in (("sobol", dict(sobol=sobol_tables(w, h)), (3, 3)), ("halton", dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1)), (2, 1)),
+                                    ("hammersley", dict(sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=qmc_tables(-1)), (1, 1))):
+            pd = A.default_render_params(spp=8, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=e, bsdf_samples=b)
+            img, sec = rs.render_job(pd, threads=2, plugin="direct_hip", sampler=sampler)
+            film = HDRFilm(gs.width, gs.height)
+            assert DirectHIP(emitterSamples=e, bsdfSamples=b).render(gs, film, 8, **kw)
+            r = rel_l2(img, film.develop())
+            cpu, _ = rs.render_job(pd, threads=4, sampler=sampler)
+            rc = rel_l2(img, cpu)
+            print("%s, %s: direct_hip (%d, %d) inside Mitsuba vs harness rel L2 %.3e; vs the reference's own direct + %s on the CPU rel L2 %.3e" % (name, sampler, e, b, r, sampler, rc))
+            assert r < 1e-5 and rc <= 1e-3, (r, rc)
         rs.close(); gs.close()
 
 

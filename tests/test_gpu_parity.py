@@ -610,7 +610,7 @@ def test_sobol_and_stratified_samplers_match_oracle(gpu, phip, oracle, gauss):
     with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sampler=A.PHIP_SAMPLER_SOBOL)
     with pytest.raises(PhipError): PathHIP(rrDepth=1).render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(32, 32))
     with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 8, sampler=A.PHIP_SAMPLER_STRATIFIED)
-    with pytest.raises(PhipError): DirectHIP().render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(32, 32))
+    with pytest.raises(PhipError): DirectHIP().render(gs, HDRFilm(32, 32), 16, sampler=A.PHIP_SAMPLER_STRATIFIED)
     gs.close()
 
 
@@ -657,5 +657,37 @@ def test_halton_and_hammersley_samplers_match_oracle(gpu, phip, oracle, gauss):
         # errors: no tables, rrDepth 1, `direct`
         with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sampler=kind)
         with pytest.raises(PhipError): PathHIP(rrDepth=1).render(gs, HDRFilm(32, 32), 16, **kw)
-        with pytest.raises(PhipError): DirectHIP().render(gs, HDRFilm(32, 32), 16, **kw)
+    # hammersley has no sample arrays (hammersley.cpp:293-300)
+    with pytest.raises(PhipError): DirectHIP(emitterSamples=2, bsdfSamples=1).render(gs, HDRFilm(32, 32), 16, sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=qmc_tables(-1))
+    gs.close()
+
+
+def test_direct_with_the_qmc_samplers_matches_oracle(gpu, phip, oracle, gauss):
+    """`direct` on the reference's sequence samplers (the oracle is pinned to Mitsuba's own `direct` + `sobol` / `halton` / `hammersley`:
+    tests/test_ref_pin.py::test_direct_with_the_reference_qmc_samplers_is_reproduced_bit_for_bit): sample arrays (dimensions 5.. of "sample j of
+    the pixel") and single samples (dimensions (2, 3), then (5, 6)) in every combination, per-sample radiance bit-identical; scenes with microfacet /
+    dielectric BSDFs, an environment map and textures (the QMC build of k_shade_direct with both features); progressive passes"""
+    import ref_scenes as RS
+    from conftest import sobol_tables, qmc_tables
+    from test_golden import _golden_mip, G
+    from mitsuba_amd.integrator import Scene, DirectHIP, HDRFilm
+    fixture = np.load(os.path.join(G, "ref_renders.npz"))
+    scenes = [(S.cornell_box(40, 36, gauss).desc(), 1.0), (RS.zoo(gauss, None).desc(), 0.9999),
+              (RS.envmap(gauss, _golden_mip(fixture, "envmap")).desc(), 0.999), (RS.textures(gauss, _golden_mip(fixture, "textures")).desc(), 0.999)]
+    for desc, mi in scenes:
+        w, h = desc.film.crop_width, desc.film.crop_height
+        for e, b in ((1, 1), (3, 2), (0, 2), (4, 1)):
+            compare_render(gpu, oracle, desc, 4, min_identical=mi, integrator=DirectHIP, render_kw=dict(sobol=sobol_tables(w, h)), emitterSamples=e, bsdfSamples=b)
+            compare_render(gpu, oracle, desc, 4, min_identical=mi, integrator=DirectHIP, render_kw=dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(7)), emitterSamples=e, bsdfSamples=b)
+        compare_render(gpu, oracle, desc, 4, min_identical=mi, integrator=DirectHIP, render_kw=dict(sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=qmc_tables(-1)), emitterSamples=1, bsdfSamples=1)
+    # two passes of 4 of 8 samples = one render of 8 (array element k * count + i with k the sample's global number)
+    desc = S.cornell_box(32, 32, gauss).desc()
+    gs = Scene(desc); integ = DirectHIP(emitterSamples=3, bsdfSamples=2)
+    for kw in (dict(sobol=sobol_tables(32, 32)), dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1))):
+        whole = HDRFilm(32, 32); assert integ.render(gs, whole, 8, **kw)
+        parts = HDRFilm(32, 32); assert integ.render(gs, parts, 4, sample_offset=0, sample_total=8, **kw)
+        p = integ.params(gs, 4, flags=A.PHIP_FLAG_ACCUMULATE, sample_offset=4, sample_total=8, **kw)
+        acc = parts.storage.copy(); st = A.phip_stats()
+        assert phip.phip_render(gs._h, C.byref(p), acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
+        assert rel_l2(acc, whole.storage) < 1e-6
     gs.close()

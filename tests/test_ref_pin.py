@@ -396,6 +396,36 @@ def test_sobol_sampler_of_the_reference_is_reproduced_bit_for_bit(ref, olibm):
         assert (smp.view(np.uint32) == osmp.view(np.uint32)).all(), (name, float((smp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean()))
 
 
+def test_direct_with_the_reference_qmc_samplers_is_reproduced_bit_for_bit(ref, olibm):
+    """SURVEY 8(f) row 4, the rest of it: the reference's OWN `direct` integrator with its OWN `sobol` / `halton` / `hammersley` plugins against the
+    restatement.  `direct` requests sample ARRAYS for more than one shading sample of a kind (direct.cpp:139-146): the samplers fill them in
+    generate() from dimensions 5.. of the points "sample j of this pixel" (sobol.cpp:170-196, halton.cpp:274-328), single samples are the next 2D
+    requests -- (2, 3), then (5, 6): dimension 4 is never handed out.  hammersley has no arrays (hammersley.cpp:293-300): single samples only."""
+    from mitsuba_amd._ffi import PhipError  # noqa: F401
+    gauss_libm = olibm.gaussian_filter(0.5, libm=True)
+    for name, build in (("cornell", lambda: S.cornell_box(24, 20, gauss_libm)), ("zoo", lambda: RS.zoo(gauss_libm, None)), ("glass", lambda: RS.glass(gauss_libm, None))):
+        desc = build().desc()
+        rs = ref.RefScene(desc); osc = olibm.OracleScene(desc, libm=True)
+        w, h = desc.film.crop_width, desc.film.crop_height
+        for e, b, spp in ((1, 1, 4), (3, 2, 4), (0, 2, 3), (2, 0, 4), (1, 5, 2), (4, 1, 4)):
+            for smp_name, kw in (("sobol", dict(sobol=ref.sobol_tables(w, h))), ("halton", dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=ref.qmc_tables(-1, 256))),
+                                 ("halton", dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=ref.qmc_tables(7, 256), seed=9)),
+                                 ("hammersley", dict(sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=ref.qmc_tables(-1, 256)))):
+                if smp_name == "hammersley" and (e > 1 or b > 1):
+                    continue
+                p = A.default_render_params(spp=spp, block_size=256, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=e, bsdf_samples=b, **kw)
+                _, rsmp = rs.render(p, sampler=smp_name)
+                _, osmp, _ = osc.render(p, threads=1, want_samples=True)
+                assert rsmp[..., :3].mean() > 0.005, (name, smp_name, e, b)
+                same = (rsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1)
+                assert same.all(), (name, smp_name, e, b, float(same.mean()))
+        # hammersley refuses sample arrays, like the plugin
+        p = A.default_render_params(spp=4, block_size=256, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=1, sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=ref.qmc_tables(-1, 256))
+        with pytest.raises(RuntimeError):
+            osc.render(p, threads=1, want_samples=True)
+        rs.close(); osc.close()
+
+
 def test_stratified_construction_on_the_reference(ref, olibm):
     """PHIP_SAMPLER_STRATIFIED: the reference's `path` consuming the addressable stratified construction through the glue sampler
     (ref_glue/ctr_sampler.cpp, `stratified` mode: it calls nothing of the oracle) equals the restatement sample for sample; and the

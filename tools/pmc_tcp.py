@@ -54,7 +54,9 @@ def main():
     roof = None
     if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
         roof = json.load(open(sys.argv[4])).get("peak_lane_random_16B")
-    json.dump({"workload": tag, "source": "rocprofv3 --kernel-trace --pmc (tools/pmc_mem.sh), MI355X", "definition": __doc__, "vmem_roof_lane_loads_per_s": roof, "kernels": res},
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mitsuba_amd import _ffi as _ffi_id
+    json.dump({"build_id": _ffi_id.built_id(os.environ.get("PHIP_LIB")), "workload": tag, "source": "rocprofv3 --kernel-trace --pmc (tools/pmc_mem.sh), MI355X", "definition": __doc__, "vmem_roof_lane_loads_per_s": roof, "kernels": res},
               open(out, "w"), indent=1)
     for k, r in sorted(res.items(), key=lambda kv: -kv[1]["avg_launch_ms"] * kv[1]["launches"]):
         print(k, {x: r[x] for x in ("avg_launch_ms", "vmem_wave_instructions", "clk_per_wave_instruction_per_cu", "lines_per_instruction", "l1_hit_rate", "l2_hit_rate", "td_busy_frac", "issue_frac")})

@@ -36,7 +36,9 @@ def run(counter, tag, cmd):
     return agg, n
 
 
-res = {"workload": bench_name, "scene_key": workload, "spp_override": spp or None, "pool_slots_override": os.environ.get("PHIP_POOL"),
+sys.path.insert(0, ROOT)
+from mitsuba_amd import _ffi as _ffi_id  # noqa: E402  (the id compiled into the library that is being profiled: read from the file, no GPU call)
+res = {"build_id": _ffi_id.built_id(os.environ.get("PHIP_LIB")), "workload": bench_name, "scene_key": workload, "spp_override": spp or None, "pool_slots_override": os.environ.get("PHIP_POOL"),
        "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB",
        "note": "per-launch figures: the path pool must have the size of the full job (8 M slots for jobs >= 256 M samples, else 4 M) -- set PHIP_POOL when spp is reduced"}
 cf, _ = run("FETCH_SIZE", "cal_fetch", cal_cmd)

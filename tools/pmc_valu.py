@@ -69,6 +69,9 @@ for k, c in sorted(agg.items()):
             n = base(name)[1]
             e[name.lower() + "_per_launch"] = round(c[name] / max(n, 1), 1)
     res[k] = e
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mitsuba_amd import _ffi as _ffi_id  # noqa: E402
+res["build_id"] = _ffi_id.built_id(os.environ.get("PHIP_LIB"))       # the library the counters were taken on (bench.py flags a mismatch)
 txt = json.dumps(res, indent=1)
 print(txt)
 if out:
