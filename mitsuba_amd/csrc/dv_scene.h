@@ -85,7 +85,7 @@ struct DevEnvMap {
 
 struct DevScene {
     const float4 *nodes; const float4 *tris; const float4 *triShade;
-    uint32_t flatMode;                                      /* layout of flatLeaves: 1 = (min, ref)(max, 0) per leaf; 2 = packed planes + record masks, padded to four entries (traverseFlat2) */
+    uint32_t flatMode;                                      /* layout of flatLeaves: 1 = (min, ref)(max, 0) per leaf; 2 = packed planes + record masks (traverseFlat2) */
     const float4 *flatLeaves; uint32_t nFlatLeaves;         /* k_mega: the leaves of a tree of <= FLAT_LEAVES_MAX leaves as a flat table (k_traverse.h: traverseFlat); 0: walk the BVH4 */
     const uint4 *wnodes; uint32_t wideNodeCache;             /* big scenes: the compressed 8-wide tree (k_wide.h); tris is then in ITS leaf order and nodes is unused */
     const DevMaterial *materials; uint32_t nMaterials;

@@ -45,7 +45,10 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                                                                    125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
 #define MEGA_COUNT(row, amount) ldsCount[row][threadIdx.x] += (uint32_t) (amount)
 #if MEGA_REGEN_QUEUE
-    __shared__ uint32_t ldsRegen[BLOCK / 64][11][64];           /* per wave: 64 prepared camera samples (o, mint | d, maxt | id, pixel, k), one word per entry and row */
+    constexpr int RQ_ROWS = QMC ? 13 : 11;
+    __shared__ uint32_t ldsRegen[BLOCK / 64][RQ_ROWS][64];      /* per wave: 64 prepared camera samples (o, mint | d, maxt | id, pixel, k [| the sample's sequence index: QMC]), one word per entry and row */
+    __shared__ uint32_t ldsSeq[QMC ? BLOCK / 64 : 1][2][64];    /* QMC: per lane, the sequence index of the path's sample -- shadeVertex draws every number of the path from it; deriving it anew at every
+                                                                   request (sobol::look_up: ~30 table rows) was a third of the QMC kernel's sampling cost */
 #endif
     /* dynamic LDS: [traversal stack | all nodes | all Wald records] (setupTraversal) [shading records | emitter table | materials],
        sized for THIS scene (megaLdsBytes) so that as many blocks as the registers allow fit a CU */
@@ -141,6 +144,10 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                     q[0 * 64] = pm_to_bits(o.x); q[1 * 64] = pm_to_bits(o.y); q[2 * 64] = pm_to_bits(o.z); q[3 * 64] = pm_to_bits(mint);
                     q[4 * 64] = pm_to_bits(d.x); q[5 * 64] = pm_to_bits(d.y); q[6 * 64] = pm_to_bits(d.z); q[7 * 64] = pm_to_bits(maxt);
                     q[8 * 64] = (uint32_t) id; q[9 * 64] = pixel; q[10 * 64] = k;
+                    if (QMC) {
+                        const uint64_t sidx = isSequenceSampler(rc.sampler) ? seqIndex(rc, k, px, py) : 0ull;
+                        q[11 * 64] = (uint32_t) sidx; q[12 * 64] = (uint32_t) (sidx >> 32);
+                    }
                 }
                 qHead = 0u; qCount = (uint32_t) __popcll(vmask);
                 next = (end - next < 64ull) ? end : next + 64ull;
@@ -152,6 +159,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 v.rayO = make_float4(pm_from_bits(q[0 * 64]), pm_from_bits(q[1 * 64]), pm_from_bits(q[2 * 64]), pm_from_bits(q[3 * 64]));
                 v.rayD = make_float4(pm_from_bits(q[4 * 64]), pm_from_bits(q[5 * 64]), pm_from_bits(q[6 * 64]), pm_from_bits(q[7 * 64]));
                 v.id = q[8 * 64]; v.pixel = q[9 * 64]; v.k = q[10 * 64];
+                if (QMC) { ldsSeq[waveInBlock][0][lane] = q[11 * 64]; ldsSeq[waveInBlock][1][lane] = q[12 * 64]; }
                 v.thr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
                 v.mis = make_float2(0.0f, 0.0f);
                 v.state = 1u | F_ALIVE | F_EMITTED | F_FIRST;
@@ -238,7 +246,11 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         if (alive) {
             uint32_t nv = 0;
             bool newRay;
-            const LRegister acc{ accum };
+#if MEGA_REGEN_QUEUE
+            const LRegister acc{ accum, (QMC && isSequenceSampler(rc.sampler)) ? &ldsSeq[QMC ? waveInBlock : 0][0][lane] : nullptr };
+#else
+            const LRegister acc{ accum, nullptr };
+#endif
             ended = shadeVertex<MM, STRICT, QMC ? 8 : 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
             if (ended) MEGA_COUNT(MC_VERTICES, nv);
         }

@@ -165,9 +165,15 @@ struct LGlobal {
     __device__ __forceinline__ float4 load(uint32_t id) const { return L[id]; }
     __device__ __forceinline__ void store(uint32_t id, const float4 &l) const { L[id] = l; }
     __device__ __forceinline__ float4 rayO(const PathVertex &) const { return P.rayO[slot]; }
+    /* the sample's index in the sequence (sobol / halton / hammersley): re-derived from (sample, pixel) at every request */
+    __device__ __forceinline__ uint64_t seqIdx(const RenderConst &rc, const PathVertex &v, uint32_t width) const { return seqIndex(rc, v.k, v.pixel % width, v.pixel / width); }
 };
 struct LRegister {
     float4 &acc;
+    const uint32_t *seq;        /* QMC: the lane's two LDS words holding the sample's sequence index, computed once when the camera sample was prepared (k_mega.h) */
+    __device__ __forceinline__ uint64_t seqIdx(const RenderConst &rc, const PathVertex &v, uint32_t width) const {
+        return seq ? ((uint64_t) seq[0] | ((uint64_t) seq[64] << 32)) : seqIndex(rc, v.k, v.pixel % width, v.pixel / width);
+    }
     __device__ __forceinline__ float4 load(uint32_t) const { return acc; }
     __device__ __forceinline__ void store(uint32_t, const float4 &l) const { acc = l; }
     __device__ __forceinline__ float4 rayO(const PathVertex &v) const { return v.rayO; }
@@ -267,7 +273,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                     const uint32_t j = depth - 1u - (uint32_t) rc.rrDepth, kq = 2u * (depth - 1u) - (flags >> NS_SHIFT);
                     if (isSequenceSampler(rc.sampler)) {
                         const uint32_t dim = 2u * (1u + kq) + j + 1u;      /* (+ 1: SobolSampler::next2D skips dimension 4, see the vertex's requests below) */
-                        if (dim < seqDims(rc)) rr = seqSample(rc, seqIndex(rc, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width), dim);
+                        if (dim < seqDims(rc)) rr = seqSample(rc, acc.seqIdx(rc, v, (uint32_t) S.film.width), dim);
                     } else if (rc.sampler == PHIP_SAMPLER_STRATIFIED && j < ST_DIMENSIONS)
                         rr = stPoint1D(v.pixel, v.k, j, rc.seed, rc.stRes, rr);
                 }
@@ -323,7 +329,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             if (QMC && isSequenceSampler(rc.sampler)) {
                 /* SobolSampler::next2D (sobol.cpp:238-257): the requests of this vertex start at dimension 2 (1 + k0) + the 1D requests made so far
                    (one Russian-roulette request behind every vertex from rrDepth on: max(0, depth - rrDepth)) */
-                const uint64_t idx = seqIndex(rc, v.k, v.pixel % (uint32_t) S.film.width, v.pixel / (uint32_t) S.film.width);
+                const uint64_t idx = acc.seqIdx(rc, v, (uint32_t) S.film.width);
                 const uint32_t nDims = seqDims(rc);
                 /* ... and the sampler never hands out dimension 4 to a 2D request (sobol.cpp:241-242: the test for the dimensions reserved to sample
                    arrays, [5, 5) when none is requested, fires for m_dimension == 4): the sample's third 2D request starts there -- no 1D request

@@ -266,8 +266,7 @@ __device__ __forceinline__ bool traverseFlat(const DevScene &S, lds_cf4 *flat, u
  *   A = (min.x, max.x, min.y, max.y)   B = (min.z, max.z, bits(mask of the leaf's records), 0)
  * so that (a) the two planes of an axis are one packed multiply-add (v_pk_fma_f32), and (b) pass 1 yields a bit mask of RECORDS: pass 2
  * is `while (mask) test record ffs(mask)` -- no leaf reference to fetch and decode between records, a record referenced by two leaves is
- * tested once.  The table is padded to a multiple of four entries with empty record masks (pass 1 is unrolled by four: eight LDS
- * broadcasts in flight instead of a wait per leaf).  The Wald test is branch-free here (waldIntersectSel: the axis permutation as twelve
+ * tested once.  Pass 1 takes the entries four at a time (eight LDS broadcasts in flight instead of a wait per leaf), the rest one by one.  The Wald test is branch-free here (waldIntersectSel: the axis permutation as twelve
  * selects instead of three divergent branches -- inside traverseFlat the exec-mask bookkeeping was 40 scalar instructions per record).
  * Same arithmetic on the same operands, so (t, u, v, prim) are the same bits; records in index order instead of leaf order: winsTie. */
 #ifndef MEGA_WALD_PAIR
@@ -291,21 +290,28 @@ __device__ __forceinline__ bool waldIntersectSel(const float4 &a, const float4 &
 }
 
 template <bool SHADOW>
-__device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat /* a multiple of four */, lds_cf4 *tris, const V3 &o, const V3 &d, const V3 &rcp,
+__device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds_cf4 *tris, const V3 &o, const V3 &d, const V3 &rcp,
                                               float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
     const f2v rx = { rcp.x, rcp.x }, ry = { rcp.y, rcp.y }, rz = { rcp.z, rcp.z };
     const f2v ox = { -(o.x * rcp.x), -(o.x * rcp.x) }, oy = { -(o.y * rcp.y), -(o.y * rcp.y) }, oz = { -(o.z * rcp.z), -(o.z * rcp.z) };
     uint32_t mask = 0;
-    for (uint32_t c4 = 0; c4 < nFlat; c4 += 4) {
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const f4v A = flat[2 * (c4 + j)], B = flat[2 * (c4 + j) + 1];
-            const f2v x = __builtin_elementwise_fma(A.xy, rx, ox), y = __builtin_elementwise_fma(A.zw, ry, oy), z = __builtin_elementwise_fma(B.xy, rz, oz);
-            const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), mint));
-            const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), maxt));
-            mask |= (tn <= tf) ? pm_to_bits(B.z) : 0u;
+#define FLAT2_BOX(c_)                                                                                                                  \
+        {                                                                                                                              \
+            const f4v A = flat[2 * (c_)], B = flat[2 * (c_) + 1];                                                                      \
+            const f2v x = __builtin_elementwise_fma(A.xy, rx, ox), y = __builtin_elementwise_fma(A.zw, ry, oy), z = __builtin_elementwise_fma(B.xy, rz, oz); \
+            const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), mint));                             \
+            const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), maxt));                             \
+            mask |= (tn <= tf) ? pm_to_bits(B.z) : 0u;                                                                                 \
         }
+    /* groups of four entries (eight LDS broadcasts in flight), then the rest one by one: the Cornell box has 17 leaves -- padded to 20 it paid for three
+       boxes no ray can enter, 15 % of a pass that is a third of the traversal */
+    const uint32_t nFlat4 = nFlat & ~3u;
+    for (uint32_t c4 = 0; c4 < nFlat4; c4 += 4) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) FLAT2_BOX(c4 + j)
     }
+    for (uint32_t c = nFlat4; c < nFlat; ++c) FLAT2_BOX(c)
+#undef FLAT2_BOX
     ++nodeVisits;
     bool found = false;
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;

@@ -742,7 +742,6 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                     packed.push_back(make_float4(mn.x, mx.x, mn.y, mx.y));
                     packed.push_back(make_float4(mn.z, mx.z, pm_from_bits(bits), 0.0f));
                 }
-                while ((packed.size() / 2) % 4) { packed.push_back(make_float4(0, 0, 0, 0)); packed.push_back(make_float4(0, 0, 0, 0)); }
                 flat.swap(packed); D.flatMode = 2;
             }
             sd.flatLeaves.upload(flat.data(), flat.size());
