@@ -164,7 +164,7 @@ def time_workload(workload, steps, warmup, rank, world, local, devices, D, torch
         assert ok
         D.reduce_film(film, dst=0)
         if rank == 0:
-            D.film_to_host(film, host.ptr)
+            scene.film_to_host(film.data_ptr(), host.ptr)        # the merged frame to the pinned host frame (the master's film->put)
         return integ.stats
 
     def step_resident():

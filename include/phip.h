@@ -361,6 +361,11 @@ int  phip_render(phip_scene *scene, const phip_render_params *params,
 int  phip_render_device(phip_scene *scene, const phip_render_params *params,
                         void *d_out_rgbaw, phip_stats *out_stats);
 
+/* (ABI 7) A device-resident frame of this scene's crop size -- phip_render_device's output, e.g. after the caller's own RCCL reduce of
+   per-process films (bench.py --gpus N under torchrun) -- to host memory, the way phip_render delivers it: one asynchronous copy into pinned
+   memory, staged chunks into pageable memory.  The reference's analogue is the master's film->put (src/librender/renderproc.cpp:142-149). */
+int  phip_film_to_host(phip_scene *scene, const void *d_rgbaw, float *out_rgbaw);
+
 /* Per-sample radiance of the last render with PHIP_FLAG_SAMPLE_BUFFER: n = crop_w*crop_h*spp
    entries of (R,G,B,alpha) ordered [y][x][sample].  Test/diagnostic hook. */
 int  phip_get_samples(phip_scene *scene, float *out_rgba, size_t n_samples);

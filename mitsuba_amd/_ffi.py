@@ -134,6 +134,7 @@ def lib():
     L.phip_develop.argtypes = [fp, C.c_size_t, fp]
     L.phip_scene_accel_info.argtypes = [C.c_void_p, C.POINTER(A.phip_accel_info)]
     L.phip_gaussian_filter.argtypes = [C.c_float, fp, fp]
+    L.phip_film_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.phip_host_alloc.restype = C.c_void_p
     L.phip_host_alloc.argtypes = [C.c_size_t]
     L.phip_host_free.argtypes = [C.c_void_p]; L.phip_host_free.restype = None

@@ -130,7 +130,7 @@ __host__ __device__ __forceinline__ uint32_t spreadBits(uint32_t x) {
     return x;
 }
 
-/* ---- the sample stream: what the `c`-th request of a sample returns.  PHIP_SAMPLER_CTR: words of pcg4d blocks;
+/* ---- the sample stream (HISTORY.md 3.5): what the `c`-th request of a sample returns.  PHIP_SAMPLER_CTR: words of pcg4d blocks;
  *      PHIP_SAMPLER_LD: the first LD_DIMENSIONS 2D requests (the pixel jitter is request 0) and 1D requests of a sample come from
  *      scrambled (0,2)-sequences, later ones from the counter stream -- next1D / next2D of ldsampler.cpp:212-226 ---- */
 /* The reference's deterministic sequence samplers (sobol, halton, hammersley) share their consumption: a point index per (pixel, sample), one

@@ -100,7 +100,7 @@ struct TraceSource {
 };
 
 /* L[id] += c for an unoccluded NEE entry (no other lane touches L[id] during the ray kernels).  Measured alternatives,
- * both reverted: three fire-and-forget float atomics (+1..3 % on the big scenes, but the Cornell shadow
+ * both reverted (HISTORY.md 3.4): three fire-and-forget float atomics (+1..3 % on the big scenes, but the Cornell shadow
  * kernel doubled), a per-slot accumulator flushed once per sample (k_shade then pays for it).  Scenes that fit LDS avoid
  * the read-modify-write altogether: k_mega keeps the accumulator in a register. */
 __device__ __forceinline__ void addRadiance(float4 *L, uint32_t id, const float4 &c) {

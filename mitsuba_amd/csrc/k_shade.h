@@ -303,7 +303,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
         }
         V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
         if (!terminate) {
-            /* the parity stream is consumed in CALL ORDER, like a Sampler: the k-th 2D request after the pixel jitter is
+            /* the parity stream is consumed in CALL ORDER, like a Sampler (HISTORY.md 3.5): the k-th 2D request after the pixel jitter is
                pair k & 1 (.xy / .zw) of block 1 + 2 (k >> 1).  A vertex with a smooth BSDF makes two requests (emitter sample, BSDF
                sample), a vertex without one; k0 = 2 (depth - 1) - ns is this vertex's first, ns = the non-smooth vertices so far
                (bits 26..31 of the state word, modulo 64).  All-smooth paths: k0 is even and both pairs come from one block. */

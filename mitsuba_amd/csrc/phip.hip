@@ -1713,6 +1713,19 @@ int phip_render(phip_scene *scene, const phip_render_params *params, float *out_
     }
 }
 
+int phip_film_to_host(phip_scene *scene, const void *d_rgbaw, float *out_rgbaw) {
+    if (!scene || !d_rgbaw || !out_rgbaw) return setErr(PHIP_ERR_INVALID, "NULL argument");
+    try {
+        SceneDev &sd = *scene->devs[0];
+        HIP_TRY(hipSetDevice(sd.device));
+        HIP_TRY(hipDeviceSynchronize());                       /* the frame may have been written on another stream (an RCCL reduce) */
+        filmToHost(sd, out_rgbaw, (const float *) d_rgbaw, (size_t) sd.dev.film.width * sd.dev.film.height * 5 * sizeof(float));
+        return PHIP_OK;
+    } catch (const std::exception &e) {
+        return setErr(PHIP_ERR_DEVICE, e.what());
+    }
+}
+
 int phip_get_samples(phip_scene *scene, float *out_rgba, size_t n_samples) {
     if (!scene || !out_rgba) return setErr(PHIP_ERR_INVALID, "NULL argument");
     SceneDev &sd = *scene->devs[0];

@@ -86,6 +86,12 @@ class Scene:
         if rc != 0:
             raise _ffi.PhipError(rc, "phip_scene_replicate")
 
+    def film_to_host(self, d_ptr, host_ptr):
+        """a device-resident frame (render_device's output, e.g. after an RCCL reduce) to host memory, as phip_render delivers it"""
+        rc = self._L.phip_film_to_host(self._h, C.c_void_p(d_ptr), C.c_void_p(host_ptr))
+        if rc != 0:
+            raise _ffi.PhipError(rc, "phip_film_to_host")
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.phip_scene_destroy(self._h)

@@ -114,7 +114,7 @@ struct DirectSamplingRecord {
 
 /* Sample source: the reference consumes one sequential stream per worker (`sfmt` mode); the
  * parity stream (`ctr`) is addressed by (pixel, sample, dimension block) so CPU and GPU see the
- * same numbers regardless of scheduling.  Block layout (shared with the HIP kernels):
+ * same numbers regardless of scheduling.  Block layout (shared with the HIP kernels; HISTORY.md 3.5):
  *   block 0              : (jitter.x, jitter.y, -, -)
  *   block 1 + 2*(k>>1)   : pair k & 1 = the k-th 2D request after the jitter (= (emitter.xy, bsdf.xy) of depth k/2+1 without dielectrics)
  *   block 2 + 2*(d-1)    : (rr, -, -, -)
@@ -131,7 +131,7 @@ inline float u32ToFloat(uint32_t u) {
     uint32_t b = (u >> 9) | 0x3f800000u; float f; memcpy(&f, &b, 4); return f - 1.0f;
 }
 
-/* ---- PHIP_SAMPLER_LD: ldsampler.cpp's construction on the counter-based generator.  Points: core/qmc.h:43-59,82-87 ---- */
+/* ---- PHIP_SAMPLER_LD (HISTORY.md 3.5): ldsampler.cpp's construction on the counter-based generator.  Points: core/qmc.h:43-59,82-87 ---- */
 inline float radicalInverse2Single(uint32_t n, uint32_t scramble) {
     n = __builtin_bswap32(n);
     n = ((n & 0x0f0f0f0f) << 4) | ((n & 0xf0f0f0f0) >> 4);
@@ -358,7 +358,7 @@ struct SampleSource {
         pcg4d(v);
         for (int i = 0; i < 4; ++i) out[i] = u32ToFloat(v[i]);
     }
-    /* ctr mode, `path`: the stream is defined by CALL ORDER, like a Sampler is consumed: the k-th 2D request after
+    /* ctr mode, `path`: the stream is defined by CALL ORDER, like a Sampler is consumed (HISTORY.md 3.5): the k-th 2D request after
        the pixel jitter (k = 0, 1, ...) is pair k & 1 (.xy / .zw) of block 1 + 2 (k >> 1).  A vertex with a smooth BSDF makes two
        requests (emitter sample, BSDF sample), a vertex without (dielectric) one: k = 2 (depth - 1) - ns at the start of vertex
        `depth`, ns = non-smooth vertices so far (modulo 64: six bits of device state). */

@@ -2,7 +2,7 @@
  * ORACLE -- TEST INFRASTRUCTURE ONLY.
  *
  * ctr_sampler.cpp: a Sampler plugin FOR THE REFERENCE ("ctr", oracle/_ref/plugins/ctr.so) that hands the reference's own
- * integrators the counter-based parity stream of DESIGN.md 3.5 -- pcg4d(pixel, sampleIndex, block, seed) -- so that the
+ * integrators the counter-based parity stream of HISTORY.md 3.5 -- pcg4d(pixel, sampleIndex, block, seed) -- so that the
  * reference's `path` / `direct` and the GPU consume THE SAME random numbers and their images can be compared directly
  * (tests/test_gpu_dropin.py).  The stream is defined by CALL ORDER, which is all a sampler sees:
  *   `path`:   2D request 0 of a sample = the pixel jitter (block 0 .xy, integrator.cpp:171); 2D request 1 + k = pair k & 1 (.xy / .zw)
@@ -13,7 +13,7 @@
  *   `direct`: the sample counts tell which 2D calls are single samples (direct.cpp:212-216,251-255); arrays as in generate().
  * Nothing about the scene is needed (round 1 needed the oracle's per-sample smooth-vertex masks for scenes with dielectrics).
  * ld = true (`path` only): PHIP_SAMPLER_LD -- the first four 2D and the first four 1D requests of a sample are points of scrambled
- * (0,2)-sequences in a keyed order (include/phip.h), made with the reference's own qmc.h functions.
+ * (0,2)-sequences in a keyed order (include/phip.h, HISTORY.md 3.5), made with the reference's own qmc.h functions.
  */
 #include <mitsuba/render/sampler.h>
 #include <mitsuba/render/scene.h>

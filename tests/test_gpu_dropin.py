@@ -217,7 +217,7 @@ def test_random_scenes_gpu_against_the_reference_on_the_same_samples(phip, ref, 
     """(opt-in; written at the very end of round 1 and not yet run to completion on a GPU box -- the same comparison on fixed
     scenes is test_gpu_against_the_reference_on_the_same_samples above)
     the fuzz scenes (ref_scenes.random_scene, with the reference's own MIP pyramids): GPU against Mitsuba's `path` /
-    `direct` fed with the parity stream, sample by sample.  Only glibc's rounding separates the two:
+    `direct` fed with the parity stream, sample by sample.  Only glibc's rounding separates the two (HISTORY.md 3.6):
     nearly all samples agree to the last bit, the rest to ~1e-6, a handful of paths per scene at most take another branch"""
     import ref_scenes as RS
     from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm

@@ -53,7 +53,7 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
     same = (gsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1)
     if desc.n_triangles <= 512 and not same.all():
         # the oracle's kd-tree (= the reference's) and a BVH may disagree on a ray through an edge: an exact-distance tie decided by
-        # the kd-tree's leaf order, or a silhouette hit lost at a split plane (~1e-7 of the samples).  path_hip returns
+        # the kd-tree's leaf order, or a silhouette hit lost at a split plane (HISTORY.md 2.1: ~1e-7 of the samples).  path_hip returns
         # the structure-independent answer, so the bar applies against the oracle answering ray queries by a sweep over all triangles
         assert same.mean() >= min(min_identical, 0.9999), "only %.5f%% of the samples are bit-identical to the kd-tree oracle" % (100 * same.mean())
         osc.set_bruteforce(True)
@@ -63,7 +63,7 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
         # big scenes (a sweep over 250 k triangles per ray for every sample is out of reach): the FEW samples on which path_hip and the
         # kd-tree oracle differ are re-evaluated one by one with the oracle answering its ray queries by that sweep -- each must then
         # be path_hip's value bit for bit: what separates the two is the reference's kd-tree (a silhouette hit lost at a split plane, an
-        # exact-distance tie decided by leaf order: DESIGN.md 2.1), not the renderer
+        # exact-distance tie decided by leaf order: HISTORY.md 2.1), not the renderer
         idx = np.argwhere(~same)
         osc.set_bruteforce(True)
         n_equal = sum(int((osc.path_sample(p, int(x), int(y), int(k)).view(np.uint32) == gsmp[y, x, k].view(np.uint32)).all()) for y, x, k in idx)

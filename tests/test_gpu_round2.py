@@ -224,3 +224,24 @@ def test_rccl_calls_of_the_merge_on_the_devices_that_are_there(gpu, phip):
     n = phip.phip_debug_rccl_selftest(8, 1 << 20)
     assert n >= 1, phip.phip_last_error()
     assert n == min(8, phip.phip_device_count())
+
+
+def test_frame_reaches_pinned_and_pageable_host_memory_alike(gpu, phip, gauss):
+    """ABI 7: phip_render delivers the frame into pinned memory (phip_host_alloc: one asynchronous copy) and into pageable memory (staged chunks) -- the same
+    bits, a film larger than the 4 MB staging chunk incl. a ragged last chunk; phip_film_to_host does the same for a device-resident frame (what the
+    per-process multi-GPU path copies after its reduce); stats.d2h_ms is reported inside render_ms"""
+    import torch
+    from mitsuba_amd.integrator import PinnedFilm
+    w, h = 701, 333                                               # 701 x 333 x 20 B = 4.67 MB: two chunks, the second ragged
+    sc = gpu.Scene(S.cornell_box(w, h, gauss).desc()); integ = gpu.PathHIP(maxDepth=4)
+    ref = gpu.HDRFilm(w, h); assert integ.render(sc, ref, 2)
+    pf = PinnedFilm(w, h); assert integ.render_into(sc, pf.ptr, 2)
+    assert integ.stats.d2h_ms > 0 and integ.stats.render_ms >= integ.stats.d2h_ms
+    pageable = np.zeros((h, w, 5), np.float32); assert integ.render_into(sc, pageable.ctypes.data, 2)
+    assert (pf.storage.view(np.uint32) == ref.storage.view(np.uint32)).all() and (pageable.view(np.uint32) == ref.storage.view(np.uint32)).all()
+    dev = torch.zeros((h, w, 5), dtype=torch.float32, device="cuda:0")
+    assert integ.render_device(sc, dev.data_ptr(), 2)
+    out = np.zeros((h, w, 5), np.float32); sc.film_to_host(dev.data_ptr(), out.ctypes.data)
+    pf.storage[...] = 0; sc.film_to_host(dev.data_ptr(), pf.ptr)
+    assert (out.view(np.uint32) == ref.storage.view(np.uint32)).all() and (pf.storage.view(np.uint32) == ref.storage.view(np.uint32)).all()
+    pf.close(); sc.close()

@@ -1,6 +1,6 @@
 """Register budgets of the hot kernels, read from the compiler (hipcc -Rpass-analysis=kernel-resource-usage; cross-compiles, no GPU).
 
-The persistent ray kernel's speed follows its resident waves (4 / 5 / 6 waves per SIMD = 188.7 / 169.1 / 158.9 ms per C3
+The persistent ray kernel's speed follows its resident waves (HISTORY.md 3.4: 4 / 5 / 6 waves per SIMD = 188.7 / 169.1 / 158.9 ms per C3
 frame), so its VGPR count is a design property, not an accident of the compiler: 7 waves per SIMD (round 4) need <= 72 VGPRs and no scratch.  Its SGPR
 count decides how many 256-thread blocks a CU admits (MI355X guide: 82..96 SGPRs -> 7 blocks, whatever the occupancy API answers); the
 persistent grid is sized for WIDE_WAVES blocks per CU, so the count must admit that many or the surplus blocks run in a second round."""
@@ -74,7 +74,7 @@ def test_fused_kernel_keeps_four_waves_without_scratch():
 def test_shading_kernels_of_the_metric_configurations_keep_their_waves():
     """k_shade of scenes without environment emitter / textures (FEAT bits 2 and 4: LDS-addressed tables) runs five waves per SIMD where more than one BSDF
     model is present (SHADE_WAVES_PLAIN; <= 96 VGPRs, its LDS of 28.5 KB admits five blocks per CU) and the lean diffuse instantiation fits 88.  Scratch is
-    bounded: the allocator may park a few dwords outside the vertex's hot path, not more (k_shade forced to more waves with spills lost)."""
+    bounded: the allocator may park a few dwords outside the vertex's hot path, not more (HISTORY.md 3.4: k_shade forced to more waves with spills lost)."""
     flags = next(u[1] for u in _ffi.UNITS if u[2] == "phip_shade0.o")
     res = resources("phip_shade.hip", flags)
     seen = 0
@@ -92,7 +92,7 @@ def test_shading_kernels_of_the_metric_configurations_keep_their_waves():
 
 def test_film_splat_keeps_its_accumulators_in_registers():
     """k_film_splat<2, false> (gaussian / tent defaults, counter stream: the film pass of every configuration of the metric) holds 125 partial sums per thread:
-    two waves per SIMD (256 VGPRs) and no scratch -- a branch around the accumulation or hoisted per-pixel invariants push them into scratch (DESIGN.md 3.3e)"""
+    two waves per SIMD (256 VGPRs) and no scratch -- a branch around the accumulation or hoisted per-pixel invariants push them into scratch (DESIGN.md 3.5)"""
     res = resources("phip.hip")
     k = next(v for name, v in res.items() if name.startswith("_Z12k_film_splatILi2ELb0E"))
     assert k["scratch"] == 0 and k["vgprs"] <= 256, k
