@@ -352,13 +352,43 @@ DV float sobolSample(const SobolTab &T, uint64_t index, uint32_t dimension) {
     const float v = (float) result * (1.0f / 4294967296.0f);
     return 0.99999994f < v ? 0.99999994f : v;            /* std::min(result * 2^-32, ONE_MINUS_EPS_FLT) */
 }
+/* two consecutive dimensions / two pairs of them of ONE point in one pass over the index bits: the reads of all rows are in flight together
+   (a vertex draws its emitter and its BSDF sample from the same point: four chains of round trips become one) */
+DV void sobolSample2(const SobolTab &T, uint64_t index, uint32_t dimension, float &a, float &b) {
+    uint32_t r0 = T.scramble, r1 = T.scramble;
+    const uint32_t *row = T.matrices + dimension * 52u;
+    const uint32_t n = bitLength64(index);
+#pragma unroll 8
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t v0 = row[i], v1 = row[52u + i];
+        const bool bit = ((index >> i) & 1ull) != 0;
+        r0 ^= bit ? v0 : 0u; r1 ^= bit ? v1 : 0u;
+    }
+    const float f0 = (float) r0 * (1.0f / 4294967296.0f), f1 = (float) r1 * (1.0f / 4294967296.0f);
+    a = 0.99999994f < f0 ? 0.99999994f : f0; b = 0.99999994f < f1 ? 0.99999994f : f1;
+}
+DV void sobolSample2x2(const SobolTab &T, uint64_t index, uint32_t dimA, uint32_t dimB, float out[4]) {
+    uint32_t r0 = T.scramble, r1 = T.scramble, r2 = T.scramble, r3 = T.scramble;
+    const uint32_t *rowA = T.matrices + dimA * 52u, *rowB = T.matrices + dimB * 52u;
+    const uint32_t n = bitLength64(index);
+#pragma unroll 4                                                 /* (16 reads in flight; 32 put the QMC build of k_mega 100 B into scratch) */
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t v0 = rowA[i], v1 = rowA[52u + i], v2 = rowB[i], v3 = rowB[52u + i];
+        const bool bit = ((index >> i) & 1ull) != 0;
+        r0 ^= bit ? v0 : 0u; r1 ^= bit ? v1 : 0u; r2 ^= bit ? v2 : 0u; r3 ^= bit ? v3 : 0u;
+    }
+    const uint32_t r[4] = { r0, r1, r2, r3 };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float f = (float) r[k] * (1.0f / 4294967296.0f); out[k] = 0.99999994f < f ? 0.99999994f : f; }
+}
 /* the camera sample: SobolSampler::next2D at dimension 0 (sobol.cpp:244-247) -> the jitter renderBlock adds to the pixel (integrator.cpp:171) */
 DV void sobolCameraSample(const SobolTab &T, uint32_t sampleIndex, uint32_t px, uint32_t py, float &jx, float &jy) {
     const uint64_t idx = sobolSampleIndex(T, sampleIndex, px, py);
     if (idx != (uint64_t) sampleIndex) {
-        jx = sobolSample(T, idx, 0u) * T.resolution - (float) (int) px;
-        jy = sobolSample(T, idx, 1u) * T.resolution - (float) (int) py;
-    } else { jx = sobolSample(T, idx, 0u); jy = sobolSample(T, idx, 1u); }
+        float a, b; sobolSample2(T, idx, 0u, a, b);
+        jx = a * T.resolution - (float) (int) px;
+        jy = b * T.resolution - (float) (int) py;
+    } else sobolSample2(T, idx, 0u, jx, jy);
 }
 
 /* ---- PHIP_SAMPLER_HALTON / _HAMMERSLEY: the reference's radical-inverse samplers as they stand (src/samplers/halton.cpp, hammersley.cpp).  The

@@ -335,11 +335,21 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                    arrays, [5, 5) when none is requested, fires for m_dimension == 4): the sample's third 2D request starts there -- no 1D request
                    can come earlier with rrDepth >= 2 -- so it and every later request is shifted by one */
                 uint32_t dim = 2u * (1u + k0) + (depth > (uint32_t) rc.rrDepth ? depth - (uint32_t) rc.rrDepth : 0u) + (k0 >= 1u ? 1u : 0u);
-                if (smoothVertex) {
-                    if (dim + 1u < nDims) smpEmitter = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
-                    dim += 2u + (k0 == 0u ? 1u : 0u);
+                if (rc.sampler == PHIP_SAMPLER_SOBOL) {
+                    /* both requests of the vertex in one pass over the index bits (dv_math.h: sobolSample2x2); a request beyond the table keeps the counter stream's numbers */
+                    const uint32_t dimE = dim, dimB = smoothVertex ? dim + 2u + (k0 == 0u ? 1u : 0u) : dim;
+                    const bool okE = smoothVertex && dimE + 1u < nDims, okB = dimB + 1u < nDims;
+                    float q[4];
+                    sobolSample2x2(rc.sobol, idx, okE ? dimE : 0u, okB ? dimB : 0u, q);
+                    if (okE) smpEmitter = V2(q[0], q[1]);
+                    if (okB) smpBSDF = V2(q[2], q[3]);
+                } else {
+                    if (smoothVertex) {
+                        if (dim + 1u < nDims) smpEmitter = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
+                        dim += 2u + (k0 == 0u ? 1u : 0u);
+                    }
+                    if (dim + 1u < nDims) smpBSDF = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
                 }
-                if (dim + 1u < nDims) smpBSDF = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
             } else if (QMC && rc.sampler == PHIP_SAMPLER_STRATIFIED) {
                 /* 2D requests k0 + 1 (and k0 + 2 at a smooth vertex) of the sample: the first ST_DIMENSIONS are stratified, jittered by the counter stream's own numbers */
                 const uint32_t q = k0 + 1u;

@@ -1660,6 +1660,10 @@ static void filmToHost(SceneDev &sd, float *dst, const float *dFilm, size_t byte
         HIP_TRY(hipStreamSynchronize(sd.stream));
         return;
     }
+    if (bytes <= ((size_t) 256 << 10)) {                       /* a small frame: not worth 8 MB of pinned staging (their allocation is 8 ms) */
+        HIP_TRY(hipMemcpy(dst, dFilm, bytes, hipMemcpyDeviceToHost));
+        return;
+    }
     for (int i = 0; i < 2; ++i) {
         if (!sd.stage[i]) HIP_TRY(hipHostMalloc((void **) &sd.stage[i], FILM_STAGE_BYTES, hipHostMallocDefault));
         if (!sd.stageDone[i]) HIP_TRY(hipEventCreateWithFlags(&sd.stageDone[i], hipEventDisableTiming));
