@@ -35,7 +35,8 @@ def _sources():
 # objects of libphip.so: (source, extra flags, object name) -- see csrc/phip_common.h
 # phip_mega.hip is compiled without MachineLICM: hoisting the double-precision polynomial constants of phip_fmath.h (two VGPRs each,
 # 64-bit literals cannot be encoded) out of k_mega's persistent loop cost ~40 VGPRs -- 168 instead of 128, i.e. 3 instead of 4 waves per SIMD
-UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", ["-mllvm", "-disable-machine-licm"], "phip_mega.o")] + \
+MEGA_FLAGS = ["-mllvm", "-disable-machine-licm"]
+UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", MEGA_FLAGS, "phip_mega.o")] + \
         [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f], "phip_shade%d.o" % f) for f in (0, 1, 2, 3, 8, 11)]
 
 

@@ -33,6 +33,9 @@
 #ifndef MEGA_CLIP_SEL
 #define MEGA_CLIP_SEL 1              /* the scene-box clip without control flow (k_clip.h: clipToSceneSel) */
 #endif
+#ifndef MEGA_BALANCE
+#define MEGA_BALANCE 1               /* FLAT == 2: the Wald tests of a traversal are dealt over the lanes of the wave (k_traverse.h: traverseFlat2W) instead of looping per lane */
+#endif
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
@@ -68,8 +71,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 
     const uint32_t waveId = blockIdx.x * (BLOCK / 64) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = __lane_id();
     unsigned long long next = 0, end = 0;                       /* the wave's chunk of sample ids (wave-uniform) */
-#if MEGA_REGEN_QUEUE
     const uint32_t waveInBlock = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const WaveBalance wb = waveBalanceAt(g_smem, waveInBlock);  /* FLAT == 2 && MEGA_BALANCE: over the traversal stack, which the flat table does not use (phip.hip sizes it) */
+#if MEGA_REGEN_QUEUE
     uint32_t qHead = 0, qCount = 0;                             /* the wave's queue of prepared camera samples (wave-uniform) */
 #endif
     bool exhausted = rc.totalIds == 0;
@@ -223,6 +227,19 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 
         /* ---- closest hit ---- */
         { PF_BEGIN
+        if (FLAT == 2 && MEGA_BALANCE) {                        /* every lane takes part: the tests of the wave's rays are dealt over its lanes */
+            const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
+            float mint, maxt;
+            TravResult r;
+            uint32_t nNode = 0, nTri = 0;
+            V3 rcp;
+            const bool go = alive & clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp);
+            traverseFlat2W<false>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
+            if (alive) {
+                v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+                MEGA_COUNT(MC_RAYS, 1); MEGA_COUNT(MC_NODE, nNode); MEGA_COUNT(MC_TRI, nTri);
+            }
+        } else
         if (alive) {
             const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
             float mint, maxt;
@@ -242,6 +259,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         /* ---- the vertex: emitter hit / Russian roulette / emission / NEE sample / BSDF sample ---- */
         bool pushShadow = false, ended = false;
         ShadowEntry sh;
+        if (FLAT == 2 && MEGA_BALANCE) sh.e0 = sh.e1 = make_float4(0, 0, 0, 0);   /* every lane clips "its" entry (a lane without one takes no part in the result) */
         { PF_BEGIN
         if (alive) {
             uint32_t nv = 0;
@@ -258,6 +276,19 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         PF_END(2, __ballot(alive)) }
         /* ---- shadow ray of the NEE sample; unoccluded: the contribution joins the accumulator (path.cpp:187-199) ---- */
         { PF_BEGIN
+        if (FLAT == 2 && MEGA_BALANCE) {
+            const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
+            float mint, maxt;
+            TravResult r;
+            uint32_t nNode = 0, nTri = 0;
+            V3 rcp;
+            const bool go = pushShadow & clipToSceneSel<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp);
+            const bool occluded = traverseFlat2W<true>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
+            if (pushShadow) {
+                MEGA_COUNT(MC_SH_RAYS, 1); MEGA_COUNT(MC_SH_NODE, nNode); MEGA_COUNT(MC_SH_TRI, nTri);
+                if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
+            }
+        } else
         if (pushShadow) {
             const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
             float mint, maxt;

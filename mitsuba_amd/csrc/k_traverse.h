@@ -372,5 +372,122 @@ __device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds
     return found;
 }
 
+/* traverseFlat2 with pass 2 DEALT OVER THE WAVE (k_mega, MEGA_BALANCE).  The per-lane loop above runs for the wave's slowest lane -- about
+ * eight Wald tests where the average ray needs 3.1, and in the shadow phase 30 of 64 lanes have no ray at all.  Here the (ray, record) pairs
+ * of the whole wave are written to a work list in LDS and every lane tests one pair per step, whoever the ray belongs to:
+ *   1. a prefix sum of popcount(mask) over the wave (six DPP steps) gives every lane its segment of the list; it writes (lane << 5 | record)
+ *      per set bit -- a loop of the slowest lane's length, but of seven instructions, not seventy;
+ *   2. ceil(pairs / 64) steps: entry -> the owner's ray through ds_bpermute (eight dwords), the record from LDS, the same Wald test on the
+ *      same operands, against the owner's ORIGINAL interval (the sequential loop's shrinking maxt only rejects candidates that lose anyway);
+ *      closest hit: LDS min of (bits(t) << 32 | (0x7FFFFFF - prim) << 5 | record) on the owner's slot -- the smallest t, at equal t the
+ *      highest triangle index: winsTie, independent of the order; shadow ray: LDS min of the record index (the sequential loop stops at the
+ *      first hit in index order: the work counter stays what it was);
+ *   3. the owner reads its slot and repeats the winning test with its own registers for (t, u, v): same operands, same bits.
+ * A work list of BAL_CAP pairs; a wave with more (never seen on the Cornell box: 64 x 3.1) goes round again with the lanes that did not fit.
+ * Every lane of the wave must call, converged; `go` = this lane has a ray.  The buffers lie over the traversal stack (unused by the flat table). */
+#define BAL_CAP 512u
+#define BAL_WAVE_BYTES (64u * 8u + BAL_CAP * 2u)                          /* slots, work list */
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+struct WaveBalance { lds_u64 *slot; lds_u16 *list; };
+__device__ __forceinline__ WaveBalance waveBalanceAt(unsigned char *smem, uint32_t waveInBlock) {
+    unsigned char *p = smem + waveInBlock * BAL_WAVE_BYTES;
+    WaveBalance wb; wb.slot = (lds_u64 *) p; wb.list = (lds_u16 *) (p + 64u * 8u);
+    return wb;
+}
+#define BAL_SYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }    /* DS operations of a wave execute in order: this only pins the compiler's order */
+
+template <bool SHADOW>
+__device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, lds_cf4 *tris, const WaveBalance &wb, uint32_t lane, bool go,
+                                               const V3 &o, const V3 &d, const V3 &rcp, float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
+    const f2v rx = { rcp.x, rcp.x }, ry = { rcp.y, rcp.y }, rz = { rcp.z, rcp.z };
+    const f2v ox = { -(o.x * rcp.x), -(o.x * rcp.x) }, oy = { -(o.y * rcp.y), -(o.y * rcp.y) }, oz = { -(o.z * rcp.z), -(o.z * rcp.z) };
+    uint32_t mask = 0;
+#define FLAT2_BOX(c_)                                                                                                                  \
+        {                                                                                                                              \
+            const f4v A = flat[2 * (c_)], B = flat[2 * (c_) + 1];                                                                      \
+            const f2v x = __builtin_elementwise_fma(A.xy, rx, ox), y = __builtin_elementwise_fma(A.zw, ry, oy), z = __builtin_elementwise_fma(B.xy, rz, oz); \
+            const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), mint));                             \
+            const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), maxt));                             \
+            mask |= (tn <= tf) ? pm_to_bits(B.z) : 0u;                                                                                 \
+        }
+    const uint32_t nFlat4 = nFlat & ~3u;
+    for (uint32_t c4 = 0; c4 < nFlat4; c4 += 4) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) FLAT2_BOX(c4 + j)
+    }
+    for (uint32_t c = nFlat4; c < nFlat; ++c) FLAT2_BOX(c)
+#undef FLAT2_BOX
+    mask = go ? mask : 0u;                                       /* (a lane without a ray ran pass 1 on whatever its registers held) */
+    nodeVisits += go ? 1u : 0u;
+    const uint32_t mask0 = mask;
+
+    if (SHADOW) *(lds_u32 *) (wb.slot + lane) = 0xFFFFFFFFu; else wb.slot[lane] = ~0ull;
+    while (__ballot(mask != 0u)) {
+        /* list segments in lane order: an inclusive scan of the pair counts over the wave (every lane is active here: plain DPP, the
+           sequence the compiler itself emits for wave-aggregated atomics -- four shifts inside the rows of 16, then two row broadcasts) */
+        const uint32_t pc = (uint32_t) __popc(mask);
+        uint32_t incl = pc;
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+        /* the lanes whose segment ends inside the list (a prefix of the wave, never empty: a lane has at most 32 pairs) write it and are done */
+        const bool fits = incl <= BAL_CAP;
+        const uint32_t nFit = (uint32_t) __popcll(__ballot(fits));
+        const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) (nFit - 1u));
+        if (pc && fits) {
+            const uint32_t tag = lane << 5;
+            lds_u16 *w = wb.list + (incl - pc);
+            do {
+                *w++ = (uint16_t) (tag | (uint32_t) __builtin_ctz(mask));
+                mask &= mask - 1u;
+            } while (mask);
+        }
+        BAL_SYNC()
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t i = base + lane;
+            const uint32_t item = wb.list[i];                    /* (entries behind `total` hold stale pairs: tested, not committed) */
+            const uint32_t owner = (item >> 5) & 63u, rec = item & 31u;
+            const int src = (int) (owner << 2);
+            const V3 po(pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.x))), pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.y))),
+                        pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.z))));
+            const V3 pd(pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.x))), pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.y))),
+                        pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.z))));
+            const float pmint = pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(mint)));
+            const float pmaxt = pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(maxt)));
+            lds_cf4 *t_ = tris + 3 * rec;
+            const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
+            float tu, tv, tt;
+            const bool hit = (i < total) & waldIntersectSel(a, b, c, po, pd, pmint, pmaxt, tu, tv, tt);
+            if (hit) {
+                if (SHADOW) __hip_atomic_fetch_min((lds_u32 *) (wb.slot + owner), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_min(wb.slot + owner, ((unsigned long long) pm_to_bits(tt) << 32) | (unsigned long long) (((0x7FFFFFFu - pm_to_bits(c.z)) << 5) | rec),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        BAL_SYNC()
+    }
+    res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+    if (SHADOW) {
+        const uint32_t first = *(lds_u32 *) (wb.slot + lane);
+        const bool found = first != 0xFFFFFFFFu;
+        triTests += (uint32_t) __popc(found ? (mask0 & ((2u << (first & 31u)) - 1u)) : mask0);
+        return found;
+    } else {
+        const unsigned long long best = wb.slot[lane];
+        const bool found = best != ~0ull;
+        triTests += (uint32_t) __popc(mask0);
+        lds_cf4 *t_ = tris + 3 * ((uint32_t) best & 31u);
+        const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
+        float tu, tv, tt;
+        waldIntersectSel(a, b, c, o, d, mint, maxt, tu, tv, tt);
+        res.t = found ? tt : res.t; res.u = found ? tu : res.u; res.v = found ? tv : res.v; res.prim = found ? pm_to_bits(c.z) : res.prim;
+        return found;
+    }
+}
+
 /* the block's dynamic LDS: traversal stack + node / record cache (setupTraversal) */
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];

@@ -743,6 +743,8 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                     packed.push_back(make_float4(mn.z, mx.z, pm_from_bits(bits), 0.0f));
                 }
                 flat.swap(packed); D.flatMode = 2;
+                /* k_mega deals the Wald tests over the wave through LDS buffers that lie over the (then unused) traversal stack (k_traverse.h: traverseFlat2W) */
+                D.stackDepth = std::max<uint32_t>(D.stackDepth, ((BLOCK / 64) * BAL_WAVE_BYTES + BLOCK * sizeof(uint32_t) - 1) / (BLOCK * sizeof(uint32_t)));
             }
             sd.flatLeaves.upload(flat.data(), flat.size());
             D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
