@@ -289,12 +289,44 @@ __device__ __forceinline__ bool waldIntersectSel(const float4 &a, const float4 &
     return (k < 3u) & !(t < mint) & !(t > maxt) & (u >= 0) & (v >= 0) & (u + v <= 1.0f);
 }
 
-template <bool SHADOW>
-__device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds_cf4 *tris, const V3 &o, const V3 &d, const V3 &rcp,
-                                              float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
+
+/* Pass 1 of the packed flat table (DevScene::flatMode 2): the bit mask of the Wald records whose leaf box the ray enters.  Two forms of the
+ * table, a compile-time choice shared with the host code that packs it (phip.hip):
+ *   MEGA_FLAT_CH = 0: entry = (min.x, max.x, min.y, max.y) (min.z, max.z, bits(records), 0): an axis is one v_pk_fma_f32, then the pair is
+ *      ordered with a min and a max -- 15.3 VALU per box;
+ *   MEGA_FLAT_CH = 1: entry = (c.x, c.y, c.z, 0) (h.x, h.y, h.z, bits(records)), centre and half extent: with c' = c * rcp - o * rcp the slab
+ *      distances of an axis are c' -+ h * |rcp| -- ALREADY ordered, one v_pk_fma_f32 whose source modifiers negate h for the low half and
+ *      replicate h, |rcp| and c' into both halves (inline assembly: the compiler does not form them) -- 11.3 VALU per box.  The two forms
+ *      round differently; the test only has to be conservative, and the host pads h for it (phip.hip). */
+#ifndef MEGA_FLAT_CH
+#define MEGA_FLAT_CH 1
+#endif
+__device__ __forceinline__ uint32_t flat2Pass1(lds_cf4 *flat, uint32_t nFlat, const V3 &o, const V3 &rcp, float mint, float maxt) {
+    uint32_t mask = 0;
+#if MEGA_FLAT_CH
+    const f2v rxy = { rcp.x, rcp.y }, oxy = { -(o.x * rcp.x), -(o.y * rcp.y) };
+    const f2v rz2 = { rcp.z, 0.0f }, oz2 = { -(o.z * rcp.z), 0.0f };
+    f2v axy = { fabsf(rcp.x), fabsf(rcp.y) }, az2 = { fabsf(rcp.z), 0.0f };
+    asm("" : "+v"(axy), "+v"(az2));                   /* (opaque: otherwise the two v_and are rematerialised inside the loop) */
+    /* the orderings in assembly as well: on values that come out of inline assembly fmaxf / fminf first canonicalise every operand (v_max_f32 x, x, x) */
+#define FLAT2_BOX(c_)                                                                                                                  \
+        {                                                                                                                              \
+            const f4v A = flat[2 * (c_)], B = flat[2 * (c_) + 1];                                                                      \
+            const f2v cxy = __builtin_elementwise_fma(A.xy, rxy, oxy), cz = __builtin_elementwise_fma(A.zw, rz2, oz2);                 \
+            f2v tx, ty, tz;                           /* (near, far) = (c' - h |r|, c' + h |r|) */                                      \
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_lo:[1,0,0]" : "=v"(tx) : "v"(B.xy), "v"(axy), "v"(cxy));            \
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,1,1] neg_lo:[1,0,0]" : "=v"(ty) : "v"(B.xy), "v"(axy), "v"(cxy)); \
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_lo:[1,0,0]" : "=v"(tz) : "v"(B.zw), "v"(az2), "v"(cz));             \
+            float tn, tf;                                                                                                              \
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(tx.x), "v"(ty.x), "v"(mint));                                              \
+            asm("v_max_f32 %0, %1, %2" : "=v"(tn) : "v"(tn), "v"(tz.x));                                                               \
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(tx.y), "v"(ty.y), "v"(maxt));                                              \
+            asm("v_min_f32 %0, %1, %2" : "=v"(tf) : "v"(tf), "v"(tz.y));                                                               \
+            mask |= (tn <= tf) ? pm_to_bits(B.w) : 0u;                                                                                 \
+        }
+#else
     const f2v rx = { rcp.x, rcp.x }, ry = { rcp.y, rcp.y }, rz = { rcp.z, rcp.z };
     const f2v ox = { -(o.x * rcp.x), -(o.x * rcp.x) }, oy = { -(o.y * rcp.y), -(o.y * rcp.y) }, oz = { -(o.z * rcp.z), -(o.z * rcp.z) };
-    uint32_t mask = 0;
 #define FLAT2_BOX(c_)                                                                                                                  \
         {                                                                                                                              \
             const f4v A = flat[2 * (c_)], B = flat[2 * (c_) + 1];                                                                      \
@@ -303,6 +335,7 @@ __device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds
             const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), maxt));                             \
             mask |= (tn <= tf) ? pm_to_bits(B.z) : 0u;                                                                                 \
         }
+#endif
     /* groups of four entries (eight LDS broadcasts in flight), then the rest one by one: the Cornell box has 17 leaves -- padded to 20 it paid for three
        boxes no ray can enter, 15 % of a pass that is a third of the traversal */
     const uint32_t nFlat4 = nFlat & ~3u;
@@ -312,6 +345,13 @@ __device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds
     }
     for (uint32_t c = nFlat4; c < nFlat; ++c) FLAT2_BOX(c)
 #undef FLAT2_BOX
+    return mask;
+}
+
+template <bool SHADOW>
+__device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds_cf4 *tris, const V3 &o, const V3 &d, const V3 &rcp,
+                                              float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
+    uint32_t mask = flat2Pass1(flat, nFlat, o, rcp, mint, maxt);
     ++nodeVisits;
     bool found = false;
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
@@ -400,24 +440,7 @@ __device__ __forceinline__ WaveBalance waveBalanceAt(unsigned char *smem, uint32
 template <bool SHADOW>
 __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, lds_cf4 *tris, const WaveBalance &wb, uint32_t lane, bool go,
                                                const V3 &o, const V3 &d, const V3 &rcp, float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
-    const f2v rx = { rcp.x, rcp.x }, ry = { rcp.y, rcp.y }, rz = { rcp.z, rcp.z };
-    const f2v ox = { -(o.x * rcp.x), -(o.x * rcp.x) }, oy = { -(o.y * rcp.y), -(o.y * rcp.y) }, oz = { -(o.z * rcp.z), -(o.z * rcp.z) };
-    uint32_t mask = 0;
-#define FLAT2_BOX(c_)                                                                                                                  \
-        {                                                                                                                              \
-            const f4v A = flat[2 * (c_)], B = flat[2 * (c_) + 1];                                                                      \
-            const f2v x = __builtin_elementwise_fma(A.xy, rx, ox), y = __builtin_elementwise_fma(A.zw, ry, oy), z = __builtin_elementwise_fma(B.xy, rz, oz); \
-            const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), mint));                             \
-            const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), maxt));                             \
-            mask |= (tn <= tf) ? pm_to_bits(B.z) : 0u;                                                                                 \
-        }
-    const uint32_t nFlat4 = nFlat & ~3u;
-    for (uint32_t c4 = 0; c4 < nFlat4; c4 += 4) {
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) FLAT2_BOX(c4 + j)
-    }
-    for (uint32_t c = nFlat4; c < nFlat; ++c) FLAT2_BOX(c)
-#undef FLAT2_BOX
+    uint32_t mask = flat2Pass1(flat, nFlat, o, rcp, mint, maxt);
     mask = go ? mask : 0u;                                       /* (a lane without a ray ran pass 1 on whatever its registers held) */
     nodeVisits += go ? 1u : 0u;
     const uint32_t mask0 = mask;

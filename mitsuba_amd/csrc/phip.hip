@@ -739,8 +739,24 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                     const uint32_t r = ~pm_to_bits(mn.w), first = r >> 3, count = (r & 7u) + 1u;
                     uint32_t bits = 0;
                     for (uint32_t i = 0; i < count; ++i) bits |= 1u << firstCopy[first + i];
+#if MEGA_FLAT_CH
+                    /* centre / half extent (k_traverse.h: flat2Pass1).  c -+ h must cover the (padded) box whatever the rounding of c, and the
+                       distances c' -+ h |rcp| are rounded differently from the plane form the pad of bvh.h was sized for (two roundings of
+                       magnitude |c rcp| + |o rcp| instead of one): h gets the rounding of c and another 4e-6 of the scene's extent on top */
+                    const float ext = std::max(sc->bvh.tightMax[0] - sc->bvh.tightMin[0], std::max(sc->bvh.tightMax[1] - sc->bvh.tightMin[1], sc->bvh.tightMax[2] - sc->bvh.tightMin[2]));
+                    float c[3], h[3];
+                    const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
+                    for (int a = 0; a < 3; ++a) {
+                        c[a] = (float) (0.5 * ((double) lo[a] + (double) hi[a]));
+                        const double need = std::max((double) c[a] - (double) lo[a], (double) hi[a] - (double) c[a]);
+                        h[a] = std::nextafter((float) need, INFINITY) + 2.4e-7f * std::fabs(c[a]) + 4e-6f * ext;
+                    }
+                    packed.push_back(make_float4(c[0], c[1], c[2], 0.0f));
+                    packed.push_back(make_float4(h[0], h[1], h[2], pm_from_bits(bits)));
+#else
                     packed.push_back(make_float4(mn.x, mx.x, mn.y, mx.y));
                     packed.push_back(make_float4(mn.z, mx.z, pm_from_bits(bits), 0.0f));
+#endif
                 }
                 flat.swap(packed); D.flatMode = 2;
                 /* k_mega deals the Wald tests over the wave through LDS buffers that lie over the (then unused) traversal stack (k_traverse.h: traverseFlat2W) */
