@@ -426,6 +426,11 @@ __device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds
  * A work list of BAL_CAP pairs; a wave with more (never seen on the Cornell box: 64 x 3.1) goes round again with the lanes that did not fit.
  * Every lane of the wave must call, converged; `go` = this lane has a ray.  The buffers lie over the traversal stack (unused by the flat table). */
 #define BAL_CAP 512u
+#ifndef BAL_ILP
+#define BAL_ILP 1                        /* pairs per lane and step of the test loop (BAL_CAP is a multiple of 64 * BAL_ILP).  Measured: 1 / 2 / 4 = 53.0 / 56.0 / 59.8 ms
+                                            per C2 frame (profiles/r04_gpu_call_m_*): the list's tail is rounded up to whole steps, and wider steps waste more tests than their
+                                            interleaving hides */
+#endif
 #define BAL_WAVE_BYTES (64u * 8u + BAL_CAP * 2u)                          /* slots, work list */
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
@@ -470,26 +475,34 @@ __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, ld
             } while (mask);
         }
         BAL_SYNC()
-        for (uint32_t base = 0; base < total; base += 64u) {
-            const uint32_t i = base + lane;
-            const uint32_t item = wb.list[i];                    /* (entries behind `total` hold stale pairs: tested, not committed) */
-            const uint32_t owner = (item >> 5) & 63u, rec = item & 31u;
-            const int src = (int) (owner << 2);
-            const V3 po(pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.x))), pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.y))),
-                        pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.z))));
-            const V3 pd(pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.x))), pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.y))),
-                        pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.z))));
-            const float pmint = pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(mint)));
-            const float pmaxt = pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(maxt)));
-            lds_cf4 *t_ = tris + 3 * rec;
-            const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
-            float tu, tv, tt;
-            const bool hit = (i < total) & waldIntersectSel(a, b, c, po, pd, pmint, pmaxt, tu, tv, tt);
-            if (hit) {
-                if (SHADOW) __hip_atomic_fetch_min((lds_u32 *) (wb.slot + owner), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else __hip_atomic_fetch_min(wb.slot + owner, ((unsigned long long) pm_to_bits(tt) << 32) | (unsigned long long) (((0x7FFFFFFu - pm_to_bits(c.z)) << 5) | rec),
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        /* one pair per lane and step (BAL_ILP of them interleaved measured slower, see above) */
+        for (uint32_t base = 0; base < total; base += 64u * BAL_ILP) {
+            bool hit[BAL_ILP]; uint32_t own[BAL_ILP], lo[BAL_ILP], hi[BAL_ILP];
+#pragma unroll
+            for (uint32_t j = 0; j < BAL_ILP; ++j) {             /* the tests, free of control flow so that the compiler interleaves them ... */
+                const uint32_t i = base + 64u * j + lane;
+                const uint32_t item = wb.list[i];                /* (entries behind `total` hold stale pairs: tested, not committed) */
+                const uint32_t owner = (item >> 5) & 63u, rec = item & 31u;
+                const int src = (int) (owner << 2);
+                const V3 po(pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.x))), pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.y))),
+                            pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.z))));
+                const V3 pd(pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.x))), pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.y))),
+                            pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(d.z))));
+                const float pmint = pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(mint)));
+                const float pmaxt = pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(maxt)));
+                lds_cf4 *t_ = tris + 3 * rec;
+                const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
+                float tu, tv, tt;
+                hit[j] = (i < total) & waldIntersectSel(a, b, c, po, pd, pmint, pmaxt, tu, tv, tt);
+                own[j] = owner; hi[j] = pm_to_bits(tt);
+                lo[j] = SHADOW ? rec : (((0x7FFFFFFu - pm_to_bits(c.z)) << 5) | rec);
             }
+#pragma unroll
+            for (uint32_t j = 0; j < BAL_ILP; ++j)               /* ... then the commits */
+                if (hit[j]) {
+                    if (SHADOW) __hip_atomic_fetch_min((lds_u32 *) (wb.slot + own[j]), lo[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_min(wb.slot + own[j], ((unsigned long long) hi[j] << 32) | (unsigned long long) lo[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
         }
         BAL_SYNC()
     }
