@@ -19,7 +19,7 @@
  */
 
 #ifndef WIDE_STACK_LDS
-#define WIDE_STACK_LDS 9                 /* 8-byte entries per lane in LDS (18 KB per block of 256) */
+#define WIDE_STACK_LDS 6                 /* 8-byte entries per lane in LDS (12 KB per block of 256; nine until the triangle rounds of WIDE_DEAL took 6 KB per block: measured the same, 153.2 ms per C3 frame either way) */
 #endif
 #ifndef WIDE_BLOCK
 #define WIDE_BLOCK 256                   /* threads per block of k_rays_w.  Measured (round 2): ONE block of 1024 per CU, whose LDS then holds a single copy of the
@@ -100,6 +100,10 @@ typedef WideStackT<BLOCK> WideStack;
 __host__ __device__ __forceinline__ size_t wideLdsBytes(uint32_t nodeCache, uint32_t blockThreads) {
     return (size_t) WIDE_STACK_LDS * blockThreads * sizeof(uint2) + (size_t) nodeCache * 5 * sizeof(uint4);
 }
+#ifndef WIDE_DEAL
+#define WIDE_DEAL 1
+#endif
+__host__ __device__ __forceinline__ size_t wideDealBytes(uint32_t blockThreads) { return WIDE_DEAL ? (size_t) (blockThreads / 64u) * (64u * 8u + 64u * 8u + 256u * 2u) : 0; }   /* k_rays_w: WD_WAVE_BYTES per wave */
 __host__ __device__ __forceinline__ uint32_t wideRaycastCache(uint32_t nodeCache) { return nodeCache < WIDE_NODE_CACHE_RAYCAST ? nodeCache : WIDE_NODE_CACHE_RAYCAST; }
 
 /* carve the block's dynamic LDS and stage the top of the tree (all threads of the block must call) */
@@ -372,7 +376,169 @@ enum { WW_RAYS = 0, WW_STEPS, WW_SH_RAYS, WW_SH_STEPS, WW_COUNT };     /* 64-bit
 #endif
 #define WIDE_FLAT 1                      /* ONE loop (refill test, then one traversal iteration of the live lanes) instead of a traversal loop nested in a refill loop */
 #endif
-#if WIDE_FLAT
+#ifndef WIDE_DEAL
+#define WIDE_DEAL 1                      /* the triangle tests of an iteration dealt over the lanes of the wave (0: the flat loop, one record per lane and iteration) */
+#endif
+#if WIDE_DEAL
+/* The flat loop below tests ONE Wald record per lane and iteration: a ray that entered leaves with four triangles stays four iterations
+ * before it may take its next node step, while every iteration executes the node block AND the triangle block for whoever needs them
+ * (tools/wave_sim.py: 45 of 64 lanes in a node block, 21 in a triangle block).  Here the pending (ray, record) pairs of the whole wave go
+ * to a work list in LDS and every lane tests one pair per step, as k_mega does (k_traverse.h: traverseFlat2W): all the triangles a ray has
+ * pending are decided in the iteration that found them, the wave needs a fifth fewer iterations for the same rays (simulated), i.e. a
+ * fifth fewer executions of both blocks -- on a kernel bound by the number of vector-memory instructions it issues.
+ *   - list entry = any-hit flag << 11 | owner lane << 5 | bit of the owner's triangle group; the tester fetches the owner's ray and group
+ *     base with ds_bpermute, the record from memory, and runs the same Wald test on the same operands against the owner's CURRENT interval;
+ *   - closest hit: LDS min of (bits(t) << 32 | (0x3FFFFFFF - prim) << 2 | class) on the owner's slot -- smallest t, at equal t the highest
+ *     triangle index (winsTie), whatever the order; the lane whose key stands in the slot after the step writes (u, v) beside it;
+ *     any hit: LDS min of the group bit (the sequential loop stops at the first hit in bit order: the work counter stays what it was);
+ *   - the slot is the ray's result: (t, u, v, prim) leave the registers, the owner only pulls its new maxt after a round.
+ * The rays' step sequences are unchanged (all records of a group, then the next node), hence so are results and counters. */
+#ifndef WD_THRESHOLD
+#define WD_THRESHOLD 32u                 /* pairs that must be pending before a round runs (0: every iteration that has any).  Ray kernel, C3 at 64 spp / C4 at 128 spp:
+                                            flat loop 153.4 / 318.5 ms -- dealt, threshold 0: 148.3 / 306.7 -- 24: 143.6 / 293.4 -- 40: 143.7 / 292.9 -- 56: 149.0 / 302.2 */
+#endif
+#ifndef WD_REFILL
+#define WD_REFILL 8                      /* idle lanes at which the wave fetches new rays (the flat loop: REFILL_LANES = 16; here 8 / 16 / 24 measured 140.5 / 142.0 / 149.0 ms per C3 frame) */
+#endif
+#define WD_CAP 256u                      /* list entries per wave (a multiple of 64); lanes whose pairs do not fit wait for the next iteration */
+#define WD_WAVE_BYTES (64u * 8u + 64u * 8u + WD_CAP * 2u)
+typedef __attribute__((address_space(3))) uint16_t lds_w16;
+typedef __attribute__((address_space(3))) unsigned long long lds_w64;
+typedef __attribute__((address_space(3))) uint32_t lds_w32;
+#define WD_SYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideStackT<WIDE_BLOCK> &stack, ShadowSourceDyn &ss, TraceSourceDyn &ts,
+                                                       unsigned long long *wc /* LDS: WC_COUNT counters of this wave */, unsigned char *dealLds /* WD_WAVE_BYTES of this wave */) {
+    lds_w64 *slot = (lds_w64 *) dealLds; lds_u2 *uvs = (lds_u2 *) (dealLds + 64u * 8u); lds_w16 *list = (lds_w16 *) (dealLds + 2u * 64u * 8u);
+    const uint32_t lane = __lane_id();
+    bool active = false, shadow = false;
+    uint32_t handle = 0, steps = 0;
+    WideRay ray; ray.o = ray.d = ray.rcp = V3(0.0f); ray.mint = ray.maxt = 0; ray.octinv4 = 0;
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const bool moreS = ss.more(), moreAny = moreS || ts.more();              /* wave-uniform */
+        if (moreAny) {
+            if (__popcll(idle) >= WD_REFILL) {
+                const uint32_t h = moreS ? ss.assign(!active, idle) : ts.assign(!active, idle);
+                if (!active && h != INVALID_RAY) {
+                    V3 o, d; float mint, maxt;                   /* (already clipped to the scene box) */
+                    const bool ok = moreS ? ss.load(h, o, d, mint, maxt) : ts.load(h, o, d, mint, maxt);
+                    if (ok) {
+                        const unsigned long long got = __ballot(1);
+                        if (lane == (uint32_t) __ffsll((long long) got) - 1u) wc[moreS ? WW_SH_RAYS : WW_RAYS] += (uint32_t) __popcll(got);
+                        TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+                        if (maxt > mint) {
+                            wideRaySetup(ray, o, d, V3(slabRcpFast(d.x), slabRcpFast(d.y), slabRcpFast(d.z)), mint, maxt);
+                            ng = wideRootGroup(); tg = make_uint2(0u, 0u);
+                            stack.sp = 0; handle = h; shadow = moreS; active = true; steps = 0;
+                            slot[lane] = ~0ull;
+                        } else if (moreS) {
+                            ss.commit(h, false, res);
+                        } else {
+                            ts.commit(h, false, res);
+                        }
+                    }
+                }
+            }
+        } else if (idle == ~0ull) break;
+        if (active && tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps)
+
+        /* ---- the triangle round: every lane takes part ---- */
+        const uint32_t pending = active ? tg.y : 0u;
+        const uint32_t pc = (uint32_t) __popc(pending);
+        bool mine = false;                                       /* this lane's group is decided in this round */
+        if (__ballot(pc != 0u)) {                                /* (wave-uniform) */
+        uint32_t incl = pc;
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+        incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+        /* a round costs its instructions whatever the number of pairs: it is held back while few pairs are pending and enough other lanes have node
+           steps to take (tools/wave_sim.py, dealt + threshold) */
+        const uint32_t nPairs = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+        const bool roundNow = WD_THRESHOLD == 0u || nPairs >= WD_THRESHOLD || 2u * (uint32_t) __popcll(__ballot(pc != 0u)) >= (uint32_t) __popcll(__ballot(active));
+        if (nPairs && roundNow) {                                /* (wave-uniform) */
+            const bool fits = incl <= WD_CAP;                    /* a prefix of the lanes, never empty: a group has at most 24 records */
+            const uint32_t nFit = (uint32_t) __popcll(__ballot(fits));
+            const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) (nFit - 1u));
+            mine = pc != 0u && fits;
+            if (mine) {
+                const uint32_t tag = (shadow ? 0x800u : 0u) | (lane << 5);
+                lds_w16 *w = list + (incl - pc);
+                uint32_t m = pending;
+                do { *w++ = (uint16_t) (tag | (uint32_t) __builtin_ctz(m)); m &= m - 1u; } while (m);
+            }
+            WD_SYNC()
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t i = base + lane;
+                const uint32_t item = list[i];                   /* (behind `total`: stale entries, fetched -- every lane must be active in a ds_bpermute, a
+                                                                    disabled SOURCE lane reads as zero -- and not tested) */
+                const uint32_t owner = (item >> 5) & 63u, bit = item & 31u;
+                const bool anyHit = (item & 0x800u) != 0u;
+                const int src = (int) (owner << 2);
+#define WD_FETCH(x) pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(x)))
+                const V3 po(WD_FETCH(ray.o.x), WD_FETCH(ray.o.y), WD_FETCH(ray.o.z)), pd(WD_FETCH(ray.d.x), WD_FETCH(ray.d.y), WD_FETCH(ray.d.z));
+                const float pmint = WD_FETCH(ray.mint), pmaxt = WD_FETCH(ray.maxt);
+#undef WD_FETCH
+                const uint32_t tbase = (uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) tg.x);
+                if (i < total) {                                 /* (only the last step of a round is partial) */
+                    WIDE_LOAD_TRI(S, tbase + bit, a, b, c)
+                    float tu, tv, tt;
+                    if (waldIntersectSel(a, b, c, po, pd, pmint, pmaxt, tu, tv, tt)) {
+                        const unsigned long long key = anyHit ? (unsigned long long) bit
+                            : (((unsigned long long) pm_to_bits(tt) << 32) | (unsigned long long) (((HIT_PRIM_MASK - pm_to_bits(c.z)) << 2) | (pm_to_bits(c.w) & 3u)));
+                        __hip_atomic_fetch_min(slot + owner, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (!anyHit && slot[owner] == key) { u2v q; q.x = pm_to_bits(tu); q.y = pm_to_bits(tv); uvs[owner] = q; }
+                    }
+                }
+            }
+            WD_SYNC()
+        }
+        }
+        if (active) {
+            bool finished = false;
+            if (mine) {
+                const unsigned long long best = slot[lane];
+                if (shadow) {
+                    const bool occ = best != ~0ull;
+                    steps += (uint32_t) __popc(occ ? (tg.y & ((2u << ((uint32_t) best & 31u)) - 1u)) : tg.y) << 16;
+                    finished = occ;
+                } else {
+                    steps += pc << 16;
+                    if (best != ~0ull) ray.maxt = pm_from_bits((uint32_t) (best >> 32));
+                }
+                tg.y = 0u;
+            }
+            if (!finished && tg.y == 0u && !(ng.y & 0xff000000u)) {
+                if (stack.sp == 0) finished = true;
+                else {
+                    const uint2 e = stack.pop();
+                    if (e.y & 0xff000000u) ng = e; else { tg = e; ng = make_uint2(0u, 0u); }
+                }
+            }
+            if (finished) {
+                const unsigned long long best = slot[lane];
+                TravResult res; res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
+                if (shadow) ss.commit(handle, best != ~0ull, res);
+                else {
+                    if (best != ~0ull) {
+                        const u2v q = uvs[lane];
+                        const uint32_t lo = (uint32_t) best;
+                        res.t = pm_from_bits((uint32_t) (best >> 32)); res.u = pm_from_bits(q.x); res.v = pm_from_bits(q.y);
+                        res.prim = (HIT_PRIM_MASK - (lo >> 2)) | ((lo & 3u) << HIT_CLASS_SHIFT);
+                    }
+                    ts.commit(handle, false, res);
+                }
+                /* node steps (low word) and triangle tests (high word) of the ray in ONE 64-bit LDS add */
+                atomicAdd(&wc[shadow ? WW_SH_STEPS : WW_STEPS], (unsigned long long) (steps & 0xFFFFu) | ((unsigned long long) (steps >> 16) << 32));
+                active = false;
+            }
+        }
+    }
+}
+#elif WIDE_FLAT
 /* The loop is flat: every pass tests the refill condition (two scalar instructions on the ballot of the idle lanes) and then runs one
    traversal iteration -- one node step, one triangle test, one pop -- for the lanes that have a ray.  The nested form (an inner loop the
    live lanes stay in until enough of them have finished) made the compiler keep two register images of the lane state, one per loop,
@@ -562,7 +728,11 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_WAVES) void k_rays_w(DevScene S, P
     ss.q.init(drawCounters, blockIdx.x % RAY_SHARDS, nBlk, waveId, nWavesGrid);
     ts.q.init(drawCounters + RAY_SHARDS * RAY_SHARD_STRIDE, blockIdx.x % RAY_SHARDS, nChunk, waveId, nWavesGrid);
     ss.start(); ts.start();
+#if WIDE_DEAL
+    persistentTraverseWide(S, stk, ss, ts, wcnt[wave], g_smem + wideLdsBytes(S.wideNodeCache, WIDE_BLOCK) + wave * WD_WAVE_BYTES);
+#else
     persistentTraverseWide(S, stk, ss, ts, wcnt[wave]);
+#endif
     if (__lane_id() == 0) {
         const unsigned long long v[6] = { wcnt[wave][WW_RAYS], wcnt[wave][WW_STEPS] & 0xFFFFFFFFull, wcnt[wave][WW_STEPS] >> 32,
                                           wcnt[wave][WW_SH_RAYS], wcnt[wave][WW_SH_STEPS] & 0xFFFFFFFFull, wcnt[wave][WW_SH_STEPS] >> 32 };

@@ -1122,7 +1122,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     const dim3 pgrid = persistentGrid((const void *) k_shadow_p, TRACE_WAVES);
     const dim3 pgridTrace = persistentGrid(sc->bvh.nNodes >= 64 ? (const void *) k_trace_p<false> : (const void *) k_trace_p<true>, TRACE_P_WAVES);
     /* k_rays_w: blocks of WIDE_BLOCK threads with their own LDS plan (one block per CU holds 800 nodes of the tree) */
-    const size_t wideLds = sc->wide ? wideLdsBytes(D.wideNodeCache, WIDE_BLOCK) : 0;
+    const size_t wideLds = sc->wide ? wideLdsBytes(D.wideNodeCache, WIDE_BLOCK) + wideDealBytes(WIDE_BLOCK) : 0;
     dim3 pgridRays = persistentGrid((const void *) k_rays_p, RAYS_WAVES);
     if (sc->wide) {
         if (wideLds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) k_rays_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int) wideLds));

@@ -50,7 +50,8 @@ def test_ray_kernel_of_the_big_scenes_fits_seven_waves_per_simd():
     assert k["vgprs"] <= 512 // waves // 8 * 8, k                  # 72: the allocation granule is 8 registers
     assert blocks_per_cu_by_sgprs(k["sgprs"]) >= waves, k           # the persistent grid is sized for `waves` blocks per CU
     stack = int(re.search(r"#define WIDE_STACK_LDS (\d+)", src).group(1)); cache = int(re.search(r"#define WIDE_NODE_CACHE_MAX (\d+)", src).group(1))
-    assert waves * (stack * 8 * 256 + cache * 80 + k["lds"]) <= 160 * 1024      # ... and their LDS (stack + node cache + counters) fits the CU
+    deal = 4 * (64 * 8 + 64 * 8 + 256 * 2) if re.search(r"#define WIDE_DEAL 1", src) else 0      # WD_WAVE_BYTES per wave: slots, (u, v), work list
+    assert waves * (stack * 8 * 256 + cache * 80 + deal + k["lds"]) <= 160 * 1024      # ... and their LDS (stack + node cache + triangle rounds + counters) fits the CU
     # the standalone ray cast of phip_trace on the same tree
     rc = next(v for name, v in res.items() if name.startswith("_Z11k_raycast_w"))
     assert rc["scratch"] == 0 and rc["vgprs"] <= 80, rc
