@@ -316,7 +316,15 @@ struct SobolTab {
     const uint64_t *vdc, *vdcInv;       /* rows [m - 1] of vdc_sobol_matrices / vdc_sobol_matrices_inv */
     uint32_t dims, logRes, scramble;    /* m_scramble truncated to 32 bits (sobolseq.h:86: sampleSingle(index, dimension, (uint32_t) scramble)) */
     float resolution;                   /* 2^logRes */
+    /* byte tables (device only; built by phip.hip, NULL on the host side of the CPU tests): entry [dimension][b][v] = the XOR of the rows 8 b + j over
+       the set bits j of v -- the contribution of byte b of the index.  A number is then 4 look-ups for a 28-bit index (C2: 2 x 10 bits of pixel, 8 of
+       sample) instead of 28 row reads and 28 selects; XOR is associative, so it is the same number.  vdcBt / vdcInvBt: the same for the two
+       enumeration rows (64-bit entries). */
+    const uint32_t *matBt;              /* dims x SOBOL_BT_BYTES x 256 */
+    const uint64_t *vdcBt, *vdcInvBt;   /* 4 x 256 (the frame has 32 bits), SOBOL_BT_BYTES x 256 */
 };
+#define SOBOL_BT_BYTES 7u               /* ceil(52 / 8): bytes of the index that have rows */
+DV uint32_t byteLength64(uint64_t v) { return v ? (71u - (uint32_t) __builtin_clzll((unsigned long long) v)) >> 3 : 0u; }
 /* The loops of sobolseq.h are `for (; bits; bits >>= 1, ++c) if (bits & 1) acc ^= table[c]`: a table read behind a branch behind a shift, one
    memory round trip per bit -- ~28 dependent round trips per number drawn (C2 with <sampler type="sobol"/>: 158.8 ms per frame in k_mega, 173 ms in
    the film pass that re-derives the pixel jitter).  XOR does not care about order and a zero changes nothing, so every row up to the highest set
@@ -328,6 +336,17 @@ DV uint64_t sobolLookUp(const SobolTab &T, uint32_t frame, uint32_t px, uint32_t
     const uint32_t m = T.logRes, m2 = m << 1;
     uint64_t index = (uint64_t) frame << m2;
     uint64_t delta = 0;
+    if (T.vdcBt) {
+        const uint64_t *t = T.vdcBt;
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) delta ^= t[b * 256u + ((frame >> (8u * b)) & 255u)];      /* (entry [b][0] = 0) */
+        const uint64_t scr = (uint64_t) (T.scramble >> (32u - m));
+        const uint64_t bb = ((((uint64_t) px ^ scr) << m) | ((uint64_t) py ^ scr)) ^ delta;
+        const uint32_t nb = byteLength64(bb);
+        const uint64_t *ti = T.vdcInvBt;
+        for (uint32_t b = 0; b < nb; ++b) index ^= ti[b * 256u + (uint32_t) ((bb >> (8u * b)) & 255ull)];
+        return index;
+    }
     const uint32_t nf = bitLength32(frame);
 #pragma unroll 8
     for (uint32_t c = 0; c < nf; ++c) { const uint64_t v = T.vdc[c]; delta ^= ((frame >> c) & 1u) ? v : 0ull; }
@@ -345,6 +364,13 @@ DV uint64_t sobolSampleIndex(const SobolTab &T, uint32_t sampleIndex, uint32_t p
 /* sobol::sampleSingle, sobolseq.h:42-58 */
 DV float sobolSample(const SobolTab &T, uint64_t index, uint32_t dimension) {
     uint32_t result = T.scramble;
+    if (T.matBt) {
+        const uint32_t *t = T.matBt + (size_t) dimension * (SOBOL_BT_BYTES * 256u);
+        const uint32_t nb = byteLength64(index);
+        for (uint32_t b = 0; b < nb; ++b) result ^= t[b * 256u + (uint32_t) ((index >> (8u * b)) & 255ull)];
+        const float v = (float) result * (1.0f / 4294967296.0f);
+        return 0.99999994f < v ? 0.99999994f : v;
+    }
     const uint32_t *row = T.matrices + dimension * 52u;
     const uint32_t n = bitLength64(index);
 #pragma unroll 8
@@ -356,6 +382,17 @@ DV float sobolSample(const SobolTab &T, uint64_t index, uint32_t dimension) {
    (a vertex draws its emitter and its BSDF sample from the same point: four chains of round trips become one) */
 DV void sobolSample2(const SobolTab &T, uint64_t index, uint32_t dimension, float &a, float &b) {
     uint32_t r0 = T.scramble, r1 = T.scramble;
+    if (T.matBt) {
+        const uint32_t *t = T.matBt + (size_t) dimension * (SOBOL_BT_BYTES * 256u);
+        const uint32_t nb = byteLength64(index);
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint32_t e = i * 256u + (uint32_t) ((index >> (8u * i)) & 255ull);
+            r0 ^= t[e]; r1 ^= t[SOBOL_BT_BYTES * 256u + e];
+        }
+        const float f0 = (float) r0 * (1.0f / 4294967296.0f), f1 = (float) r1 * (1.0f / 4294967296.0f);
+        a = 0.99999994f < f0 ? 0.99999994f : f0; b = 0.99999994f < f1 ? 0.99999994f : f1;
+        return;
+    }
     const uint32_t *row = T.matrices + dimension * 52u;
     const uint32_t n = bitLength64(index);
 #pragma unroll 8
@@ -369,6 +406,18 @@ DV void sobolSample2(const SobolTab &T, uint64_t index, uint32_t dimension, floa
 }
 DV void sobolSample2x2(const SobolTab &T, uint64_t index, uint32_t dimA, uint32_t dimB, float out[4]) {
     uint32_t r0 = T.scramble, r1 = T.scramble, r2 = T.scramble, r3 = T.scramble;
+    if (T.matBt) {
+        const uint32_t *ta = T.matBt + (size_t) dimA * (SOBOL_BT_BYTES * 256u), *tb = T.matBt + (size_t) dimB * (SOBOL_BT_BYTES * 256u);
+        const uint32_t nb = byteLength64(index);
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint32_t e = i * 256u + (uint32_t) ((index >> (8u * i)) & 255ull);
+            r0 ^= ta[e]; r1 ^= ta[SOBOL_BT_BYTES * 256u + e]; r2 ^= tb[e]; r3 ^= tb[SOBOL_BT_BYTES * 256u + e];
+        }
+        const uint32_t r[4] = { r0, r1, r2, r3 };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float f = (float) r[k] * (1.0f / 4294967296.0f); out[k] = 0.99999994f < f ? 0.99999994f : f; }
+        return;
+    }
     const uint32_t *rowA = T.matrices + dimA * 52u, *rowB = T.matrices + dimB * 52u;
     const uint32_t n = bitLength64(index);
 #pragma unroll 4                                                 /* (16 reads in flight; 32 put the QMC build of k_mega 100 B into scratch) */

@@ -171,7 +171,7 @@ struct SceneDev {
     DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
-    DevBuf<uint32_t> sobolMat; DevBuf<unsigned long long> sobolVdc; uint64_t sobolKey = 0; uint32_t sobolLogRes = 0;    /* PHIP_SAMPLER_SOBOL: the plugin's tables */
+    DevBuf<uint32_t> sobolMat, sobolBt; DevBuf<unsigned long long> sobolVdc, sobolVdcBt; uint64_t sobolKey = 0; uint32_t sobolLogRes = 0;    /* PHIP_SAMPLER_SOBOL: the plugin's tables */
     DevBuf<uint32_t> rinvPrimes, rinvOffsets; DevBuf<uint16_t> rinvPerm; uint64_t rinvKey = 0;   /* PHIP_SAMPLER_HALTON / _HAMMERSLEY: primes + permutations */
     uint32_t rinvInvPerm2 = 0x4u, rinvInvPerm3 = 0x24u;                                                                         /* inverse permutations of bases 2 and 3, two bits per digit */
     DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
@@ -1007,6 +1007,30 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             if (p->sobol_log_resolution > 1)
                 for (int i = 0; i < PHIP_SOBOL_MATRIX_SIZE; ++i) { v[i] = p->sobol_vdc[i]; v[PHIP_SOBOL_MATRIX_SIZE + i] = p->sobol_vdc_inv[i]; }
             sd.sobolVdc.upload(v.data(), v.size());
+            /* byte tables (dv_math.h: SobolTab::matBt): entry [v] of byte b = entry [v without its lowest set bit] ^ row 8 b + that bit */
+            {
+                std::vector<uint32_t> bt((size_t) p->sobol_dimensions * SOBOL_BT_BYTES * 256u, 0u);
+                for (size_t d = 0; d < (size_t) p->sobol_dimensions; ++d)
+                    for (uint32_t b = 0; b < SOBOL_BT_BYTES; ++b) {
+                        uint32_t *t = &bt[(d * SOBOL_BT_BYTES + b) * 256u];
+                        for (uint32_t x = 1; x < 256u; ++x) {
+                            const uint32_t j = 8u * b + (uint32_t) __builtin_ctz(x);
+                            t[x] = t[x & (x - 1u)] ^ (j < (uint32_t) PHIP_SOBOL_MATRIX_SIZE ? p->sobol_matrices[d * PHIP_SOBOL_MATRIX_SIZE + j] : 0u);
+                        }
+                    }
+                sd.sobolBt.upload(bt.data(), bt.size());
+                std::vector<unsigned long long> vb((4u + SOBOL_BT_BYTES) * 256u, 0ull);
+                for (uint32_t b = 0; b < 4u + SOBOL_BT_BYTES; ++b) {
+                    const unsigned long long *rows = b < 4u ? &v[0] : &v[PHIP_SOBOL_MATRIX_SIZE];
+                    const uint32_t bb = b < 4u ? b : b - 4u;
+                    unsigned long long *t = &vb[(size_t) b * 256u];
+                    for (uint32_t x = 1; x < 256u; ++x) {
+                        const uint32_t j = 8u * bb + (uint32_t) __builtin_ctz(x);
+                        t[x] = t[x & (x - 1u)] ^ (j < (uint32_t) PHIP_SOBOL_MATRIX_SIZE ? rows[j] : 0ull);
+                    }
+                }
+                sd.sobolVdcBt.upload(vb.data(), vb.size());
+            }
             sd.sobolKey = key; sd.sobolLogRes = p->sobol_log_resolution;
         }
     }
@@ -1164,6 +1188,10 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             rc.sobol.matrices = sd.sobolMat.p; rc.sobol.vdc = (const uint64_t *) sd.sobolVdc.p; rc.sobol.vdcInv = (const uint64_t *) sd.sobolVdc.p + PHIP_SOBOL_MATRIX_SIZE;
             rc.sobol.dims = p->sobol_dimensions; rc.sobol.logRes = p->sobol_log_resolution; rc.sobol.scramble = (uint32_t) p->sobol_scramble;
             rc.sobol.resolution = (float) (1u << p->sobol_log_resolution);
+            if (!getenv("PHIP_SOBOL_BITWISE")) {                /* (A/B: the row-by-row loops of sobolseq.h) */
+                rc.sobol.matBt = sd.sobolBt.p;
+                rc.sobol.vdcBt = (const uint64_t *) sd.sobolVdcBt.p; rc.sobol.vdcInvBt = (const uint64_t *) sd.sobolVdcBt.p + 4u * 256u;
+            }
         } else if (p->sampler == PHIP_SAMPLER_STRATIFIED) {
             const unsigned n = (unsigned) (p->sample_total > 0 ? p->sample_total : p->spp);
             unsigned r = 1; while (r * r < n) ++r;
