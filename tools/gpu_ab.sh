@@ -3,7 +3,7 @@
 # tools/build_variant.sh (same sources, extra -D flags), each on the workloads below.  Extra environment for a row: A/B rows of the form
 # "label VAR=value ..." in the AB_ENV variable, separated by ';' (e.g. AB_ENV="nosort PHIP_SHADE_SORT=0;pool8M PHIP_POOL=8388608").
 #   WORKLOADS="atrium 64;glass 128;cornell 256" bash tools/gpu_ab.sh
-# (round 3's one-off experiment scripts gpu_r3a..q.sh were folded into this one; their outputs are profiles/r03_gpu_call_*.log)
+# (round 3's one-off experiment scripts gpu_r3a..q.sh were folded into this one; their outputs are profiles/r03_gpu_call_logs.txt)
 b=$PWD/mitsuba_amd/_build
 WORKLOADS=${WORKLOADS:-"atrium 64;glass 128"}
 run() { # label env...
