@@ -321,9 +321,9 @@ struct SobolTab {
        sample) instead of 28 row reads and 28 selects; XOR is associative, so it is the same number.  vdcBt / vdcInvBt: the same for the two
        enumeration rows (64-bit entries). */
     const uint32_t *matBt;              /* dims x SOBOL_BT_BYTES x 256 */
-    const uint64_t *vdcBt, *vdcInvBt;   /* 4 x 256 (the frame has 32 bits), SOBOL_BT_BYTES x 256 */
+    const uint64_t *vdcBt, *vdcInvBt;   /* 4 x 256 (the frame has 32 bits), 7 x 256 (a pixel code has at most 52 bits) */
 };
-#define SOBOL_BT_BYTES 7u               /* ceil(52 / 8): bytes of the index that have rows */
+#define SOBOL_BT_BYTES 8u               /* every byte of a 64-bit index (rows 52 .. 63 of a dimension are, as in sobolseq.h, the first rows of the next one) */
 DV uint32_t byteLength64(uint64_t v) { return v ? (71u - (uint32_t) __builtin_clzll((unsigned long long) v)) >> 3 : 0u; }
 /* The loops of sobolseq.h are `for (; bits; bits >>= 1, ++c) if (bits & 1) acc ^= table[c]`: a table read behind a branch behind a shift, one
    memory round trip per bit -- ~28 dependent round trips per number drawn (C2 with <sampler type="sobol"/>: 158.8 ms per frame in k_mega, 173 ms in

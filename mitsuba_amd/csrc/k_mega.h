@@ -9,7 +9,8 @@
  * Here a lane owns one path from the camera sample to its end:
  *
  *   loop:  lanes without a path draw the next sample id of the wave's chunk (same-lane regeneration, integrator.cpp:157-183)
- *          closest hit   (traverse<false>, k_traverse.h: the same per-lane BVH4 state machine, nodes + records from LDS)
+ *          closest hit   (k_traverse.h: trees of <= 32 records -- the Cornell box -- as a flat table of leaf boxes tested in one uniform pass, the Wald
+ *                         tests of the wave's rays dealt over its lanes (traverseFlat2W); larger trees: the per-lane BVH4 state machine, all from LDS)
  *          shadeVertex   (k_shade.h: the same statement of path.cpp:119-300 the wavefront kernel runs)
  *          shadow ray    (traverse<true>); an unoccluded entry adds its contribution to the lane's accumulator REGISTER
  *          a finished path stores its (R,G,B,alpha) once: L[id] = acc

@@ -10,7 +10,8 @@
  * Compressed Wide BVHs", HPG 2017) costs five load instructions and replaces ~2.3 BVH4 nodes: fewer bytes AND fewer
  * dependent round trips per ray, paid for with ALU work there is room for.
  *
- * Per-lane state machine, as in k_traverse.h: one node step and one triangle test per loop iteration.  The traversal stack
+ * Per-lane state machine, as in k_traverse.h: one node step per loop iteration; the triangle tests the lanes of a wave have pending are dealt
+ * over the whole wave (round 4: persistentTraverseWide under WIDE_DEAL, below; k_raycast_w keeps one test per lane and iteration).  The traversal stack
  * holds GROUPS, 8 bytes each: a node group (childBase, hit bits 24..31 | imask) or a triangle group (triBase, hit bits 0..23),
  * so a node pushes at most one entry however many of its children are hit and the stack is as deep as the tree (LDS:
  * WIDE_STACK_LDS entries per lane, the rest spills to HBM).  Children are visited in the order slot ^ rayOctant, which the

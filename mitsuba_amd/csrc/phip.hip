@@ -776,6 +776,33 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     *sc->cancelFlag = 0;
 }
 
+
+/* Byte tables of the Sobol' direction numbers (dv_math.h: SobolTab::matBt / vdcBt / vdcInvBt): entry [v] of byte b = the XOR of the rows 8 b + j over the
+   set bits j of v, built as entry [v without its lowest set bit] ^ row 8 b + that bit.  `rows2` = the two enumeration rows (vdc, then vdc_inv), 52 words each. */
+static void buildSobolByteTables(const uint32_t *matrices, size_t dims, const unsigned long long *rows2, std::vector<uint32_t> &bt, std::vector<unsigned long long> &vb) {
+    bt.assign(dims * SOBOL_BT_BYTES * 256u, 0u);
+    for (size_t d = 0; d < dims; ++d)
+        for (uint32_t b = 0; b < SOBOL_BT_BYTES; ++b) {
+            uint32_t *t = &bt[(d * SOBOL_BT_BYTES + b) * 256u];
+            for (uint32_t x = 1; x < 256u; ++x) {
+                const uint32_t j = 8u * b + (uint32_t) __builtin_ctz(x);
+                /* (sampleSingle indexes matrices[i + dimension * 52] for every set bit i of the index: above bit 51 that is the next dimension's rows) */
+                const size_t row = d * PHIP_SOBOL_MATRIX_SIZE + j;
+                t[x] = t[x & (x - 1u)] ^ (row < dims * PHIP_SOBOL_MATRIX_SIZE ? matrices[row] : 0u);
+            }
+        }
+    vb.assign((4u + 7u) * 256u, 0ull);
+    for (uint32_t b = 0; b < 4u + 7u; ++b) {
+        const unsigned long long *rows = b < 4u ? rows2 : rows2 + PHIP_SOBOL_MATRIX_SIZE;
+        const uint32_t bb = b < 4u ? b : b - 4u;
+        unsigned long long *t = &vb[(size_t) b * 256u];
+        for (uint32_t x = 1; x < 256u; ++x) {
+            const uint32_t j = 8u * bb + (uint32_t) __builtin_ctz(x);
+            t[x] = t[x & (x - 1u)] ^ (j < (uint32_t) PHIP_SOBOL_MATRIX_SIZE ? rows[j] : 0ull);
+        }
+    }
+}
+
 /* 64-bit content key of a caller's table (word-wise multiply-xorshift; ~2 GB/s: 0.1 ms for the Sobol direction numbers) */
 static uint64_t contentHash(const void *data, size_t bytes, uint64_t h) {
     const unsigned char *b = (const unsigned char *) data;
@@ -1007,29 +1034,10 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             if (p->sobol_log_resolution > 1)
                 for (int i = 0; i < PHIP_SOBOL_MATRIX_SIZE; ++i) { v[i] = p->sobol_vdc[i]; v[PHIP_SOBOL_MATRIX_SIZE + i] = p->sobol_vdc_inv[i]; }
             sd.sobolVdc.upload(v.data(), v.size());
-            /* byte tables (dv_math.h: SobolTab::matBt): entry [v] of byte b = entry [v without its lowest set bit] ^ row 8 b + that bit */
             {
-                std::vector<uint32_t> bt((size_t) p->sobol_dimensions * SOBOL_BT_BYTES * 256u, 0u);
-                for (size_t d = 0; d < (size_t) p->sobol_dimensions; ++d)
-                    for (uint32_t b = 0; b < SOBOL_BT_BYTES; ++b) {
-                        uint32_t *t = &bt[(d * SOBOL_BT_BYTES + b) * 256u];
-                        for (uint32_t x = 1; x < 256u; ++x) {
-                            const uint32_t j = 8u * b + (uint32_t) __builtin_ctz(x);
-                            t[x] = t[x & (x - 1u)] ^ (j < (uint32_t) PHIP_SOBOL_MATRIX_SIZE ? p->sobol_matrices[d * PHIP_SOBOL_MATRIX_SIZE + j] : 0u);
-                        }
-                    }
-                sd.sobolBt.upload(bt.data(), bt.size());
-                std::vector<unsigned long long> vb((4u + SOBOL_BT_BYTES) * 256u, 0ull);
-                for (uint32_t b = 0; b < 4u + SOBOL_BT_BYTES; ++b) {
-                    const unsigned long long *rows = b < 4u ? &v[0] : &v[PHIP_SOBOL_MATRIX_SIZE];
-                    const uint32_t bb = b < 4u ? b : b - 4u;
-                    unsigned long long *t = &vb[(size_t) b * 256u];
-                    for (uint32_t x = 1; x < 256u; ++x) {
-                        const uint32_t j = 8u * bb + (uint32_t) __builtin_ctz(x);
-                        t[x] = t[x & (x - 1u)] ^ (j < (uint32_t) PHIP_SOBOL_MATRIX_SIZE ? rows[j] : 0ull);
-                    }
-                }
-                sd.sobolVdcBt.upload(vb.data(), vb.size());
+                std::vector<uint32_t> bt; std::vector<unsigned long long> vb;
+                buildSobolByteTables(p->sobol_matrices, (size_t) p->sobol_dimensions, v.data(), bt, vb);
+                sd.sobolBt.upload(bt.data(), bt.size()); sd.sobolVdcBt.upload(vb.data(), vb.size());
             }
             sd.sobolKey = key; sd.sobolLogRes = p->sobol_log_resolution;
         }

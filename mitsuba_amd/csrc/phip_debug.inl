@@ -103,6 +103,31 @@ void phip_debug_host_ld_point(uint32_t pixel, uint32_t sample, uint32_t dim, uin
     ldPoint(pixel, sample, dim, seed, mask, out2[0], out2[1]);
 }
 
+/* PHIP_SAMPLER_SOBOL on the host: index of sample `sample[i]` of pixel (px[i], py[i]) (SobolSampler::setSampleIndex) and its number in dimension dim[i], with the
+   row loops of sobolseq.h (byte_tables = 0) or through the byte tables phip_render builds from the same direction numbers (byte_tables = 1: the device's path) --
+   the code the kernels compile (dv_math.h) */
+int phip_debug_host_sobol(const uint32_t *matrices, uint32_t dims, const unsigned long long *vdc, const unsigned long long *vdc_inv, uint32_t log_res, uint32_t scramble,
+                          int byte_tables, size_t n, const uint32_t *sample, const uint32_t *px, const uint32_t *py, const uint32_t *dim,
+                          unsigned long long *out_index, float *out_value, float *out_pair2x2 /* 4 n: dimensions dim, dim + 1, dim + 2, dim + 3 in one pass */) {
+    std::vector<unsigned long long> rows(2 * PHIP_SOBOL_MATRIX_SIZE, 0ull);
+    if (log_res > 1u) for (int i = 0; i < PHIP_SOBOL_MATRIX_SIZE; ++i) { rows[i] = vdc[i]; rows[PHIP_SOBOL_MATRIX_SIZE + i] = vdc_inv[i]; }
+    std::vector<uint32_t> bt; std::vector<unsigned long long> vb;
+    SobolTab T; memset(&T, 0, sizeof(T));
+    T.matrices = matrices; T.vdc = (const uint64_t *) rows.data(); T.vdcInv = (const uint64_t *) rows.data() + PHIP_SOBOL_MATRIX_SIZE;
+    T.dims = dims; T.logRes = log_res; T.scramble = scramble; T.resolution = (float) (1u << log_res);
+    if (byte_tables) {
+        buildSobolByteTables(matrices, dims, rows.data(), bt, vb);
+        T.matBt = bt.data(); T.vdcBt = (const uint64_t *) vb.data(); T.vdcInvBt = (const uint64_t *) vb.data() + 4u * 256u;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (dim[i] + 5u >= dims) return setErr(PHIP_ERR_INVALID, "dimension out of range");      /* (an index above 2^52 reads on into the next dimension, as sobolseq.h does) */
+        const uint64_t idx = sobolSampleIndex(T, sample[i], px[i], py[i]);
+        out_index[i] = idx; out_value[i] = sobolSample(T, idx, dim[i]);
+        if (out_pair2x2) sobolSample2x2(T, idx, dim[i], dim[i] + 2u, out_pair2x2 + 4 * i);
+    }
+    return PHIP_OK;
+}
+
 /* Wald records + BVH statistics of a triangle soup, built exactly like phip_scene_create does (no GPU needed) */
 int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles,
                               phip_accel_info *info, float *scene_box6) {

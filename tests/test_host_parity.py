@@ -206,3 +206,41 @@ def test_cdf_sample_small_tables_equal_the_search(phip):
                                          out.ctypes.data_as(C.POINTER(C.c_uint32)))
             want = np.array([reference(cdf, n, v) for v in vals], np.uint32)
             assert (out == want).all(), (n, cdf[:n + 1], vals[out != want], out[out != want], want[out != want])
+
+
+def test_sobol_byte_tables_equal_the_row_loops(phip):
+    """PHIP_SAMPLER_SOBOL: the device draws its numbers through 256-entry XOR tables per byte of the index (dv_math.h: SobolTab::matBt, built by the host from the
+    plugin's direction numbers).  The same functions compiled for the host, with and without the tables, on the same random requests: every index of the pixel
+    enumeration (sobol::look_up) and every number bit for bit; and the number against a direct restatement of sobol::sampleSingle (sobolseq.h:42-58) in numpy."""
+    from conftest import sobol_tables
+    rng = np.random.default_rng(11)
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    for (w, h), scramble in (((1024, 1024), 0), ((1920, 1080), 0x9E3779B9), ((2, 2), 0), ((4096, 2160), 123456789)):
+        mat, vdc, vdc_inv, m = sobol_tables(w, h, dimensions=128)
+        n = 20000
+        sample = rng.integers(0, 1 << 12, n).astype(np.uint32); sample[:64] = np.arange(64)
+        sample[64:96] = (1 << np.arange(32, dtype=np.uint64)).astype(np.uint32)                    # every byte of the frame number
+        px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32)
+        dim = rng.integers(0, 120, n).astype(np.uint32)
+        res = []
+        for bt in (0, 1):
+            idx = np.zeros(n, np.uint64); val = np.zeros(n, np.float32); quad = np.zeros((n, 4), np.float32)
+            rc = phip.phip_debug_host_sobol(mat.ctypes.data_as(u32p), len(mat) // 52, vdc.ctypes.data_as(u64p), vdc_inv.ctypes.data_as(u64p), m, scramble, bt, n,
+                                            sample.ctypes.data_as(u32p), px.ctypes.data_as(u32p), py.ctypes.data_as(u32p), dim.ctypes.data_as(u32p),
+                                            idx.ctypes.data_as(u64p), fp(val), fp(quad))
+            assert rc == 0
+            res.append((idx, val, quad))
+        assert (res[0][0] == res[1][0]).all()
+        assert (res[0][1].view(np.uint32) == res[1][1].view(np.uint32)).all()
+        assert (res[0][2].view(np.uint32) == res[1][2].view(np.uint32)).all()
+        assert (res[1][2][:, 0].view(np.uint32) == res[1][1].view(np.uint32)).all()                # the 2 x 2 form starts at the same dimension
+        # sampleSingle restated: XOR of the rows of the set index bits, scaled by 2^-32, clamped below 1
+        idx = res[0][0]
+        acc = np.full(n, scramble, np.uint32)
+        for bit in range(64):                                                                     # (above bit 51 sampleSingle reads on into the next dimension's rows)
+            on = ((idx >> np.uint64(bit)) & np.uint64(1)).astype(bool)
+            acc[on] ^= mat[dim[on].astype(np.int64) * 52 + bit]
+        expect = np.minimum((acc.astype(np.float32) * np.float32(1.0 / 4294967296.0)), np.float32(0.99999994))
+        assert (expect.view(np.uint32) == res[1][1].view(np.uint32)).all()
+        if m > 1:
+            assert len(np.unique(idx)) > n // 2 and (idx >> np.uint64(2 * m) == sample).all()      # look_up keeps the frame number in the bits above the pixel

@@ -19,4 +19,5 @@ for name,kw in (("ctr",{}),("sobol",dict(sobol=sobol_tables(w,h))),("halton",dic
     st=integ.stats
     print(json.dumps({"sampler":name,"fused":st.fused,"Msamples/s":round(w*h*spp/1e6/dt,1),"wall_ms":round(dt*1e3,2),"fused_kernel_ms":round(st.fused_kernel_ms,2),"film_ms":round(st.film_kernel_ms,2),"d2h_ms":round(st.d2h_ms,3)}))
 PY
+timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_direct.py -m gpu -q -k "sobol or sampler or qmc or cornell_render" 2>&1 | grep -v "version\|Hostname\|Librccl" | tail -3 | tee $out/pytest_samplers.txt
 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $out/smoke.txt
