@@ -76,6 +76,75 @@ def simulate(seqs, policy, refill=16, lanes=64, cost_n=5, cost_t=4):
             "mem_instr_per_ray": round(mem / len(seqs), 2)}
 
 
+# ---- round 4: the triangle tests of an iteration DEALT over the wave (k_wide.h: WIDE_DEAL).  A lane's run of consecutive triangle steps (the records of the
+#      leaves its last node step hit) is decided in one round; a round costs ceil(pairs / 64) executions of the triangle block.  simulate_dealt_thr holds a
+#      round back until `thr` pairs are pending or no lane has a node step to take. ----
+def simulate_dealt(seqs, refill=16, lanes=64, cost_n=5, cost_t=3):
+    it = iter(seqs); cur=[None]*lanes; pos=[0]*lanes
+    nexec=texec=nlane=tlane=iters=0; more=True
+    while True:
+        idle=[i for i in range(lanes) if cur[i] is None]
+        if more and (len(idle)>=refill or len(idle)==lanes):
+            for i in idle:
+                s=next(it,None)
+                if s is None: more=False; break
+                cur[i]=s; pos[i]=0
+        active=[i for i in range(lanes) if cur[i] is not None]
+        if not active:
+            if not more: break
+            continue
+        iters+=1
+        cn=[i for i in active if pos[i]<len(cur[i]) and cur[i][pos[i]]==1]
+        if cn:
+            nexec+=1; nlane+=len(cn)
+            for i in cn: pos[i]+=1
+        tot=0
+        for i in active:
+            r=0
+            while pos[i]+r<len(cur[i]) and cur[i][pos[i]+r]==2: r+=1
+            pos[i]+=r; tot+=r
+        if tot:
+            b=-(-tot//lanes); texec+=b; tlane+=tot
+        for i in active:
+            if pos[i]>=len(cur[i]): cur[i]=None
+    mem=nexec*cost_n+texec*cost_t
+    return {"iters":iters,"node_blocks":nexec,"tri_blocks":texec,"node_lanes/blk":round(nlane/max(nexec,1),1),"tri_lanes/blk":round(tlane/max(texec,1),1),"mem_instr_per_ray":round(mem/len(seqs),2)}
+
+
+def simulate_dealt_thr(seqs, thr, refill=16, lanes=64, cost_n=5, cost_t=3):
+    it = iter(seqs); cur=[None]*lanes; pos=[0]*lanes
+    nexec=texec=nlane=tlane=iters=0; more=True
+    while True:
+        idle=[i for i in range(lanes) if cur[i] is None]
+        if more and (len(idle)>=refill or len(idle)==lanes):
+            for i in idle:
+                s=next(it,None)
+                if s is None: more=False; break
+                cur[i]=s; pos[i]=0
+        active=[i for i in range(lanes) if cur[i] is not None]
+        if not active:
+            if not more: break
+            continue
+        iters+=1
+        cn=[i for i in active if pos[i]<len(cur[i]) and cur[i][pos[i]]==1]
+        if cn:
+            nexec+=1; nlane+=len(cn)
+            for i in cn: pos[i]+=1
+        runs={}
+        tot=0
+        for i in active:
+            r=0
+            while pos[i]+r<len(cur[i]) and cur[i][pos[i]+r]==2: r+=1
+            if r: runs[i]=r; tot+=r
+        nodework=sum(1 for i in active if i not in runs and pos[i]<len(cur[i]))
+        if tot and (tot>=thr or nodework==0):
+            for i,r in runs.items(): pos[i]+=r
+            b=-(-tot//lanes); texec+=b; tlane+=tot
+        for i in active:
+            if pos[i]>=len(cur[i]): cur[i]=None
+    mem=nexec*cost_n+texec*cost_t
+    return {"iters":iters,"node_blocks":nexec,"tri_blocks":texec,"node_lanes/blk":round(nlane/max(nexec,1),1),"tri_lanes/blk":round(tlane/max(texec,1),1),"mem_instr_per_ray":round(mem/len(seqs),2)}
+
 if __name__ == "__main__":
     scene = sys.argv[1] if len(sys.argv) > 1 else "atrium"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
@@ -94,6 +163,10 @@ if __name__ == "__main__":
     for name, pol in pols.items():
         for refill in (16, 32):
             print("%-58s refill %2d: %s" % (name, refill, simulate(seqs, pol, refill=refill)))
+    print("-- triangle tests dealt over the wave (round 4)")
+    print("dealt, a round whenever pairs are pending: %s" % simulate_dealt(seqs))
+    for thr in (16, 32, 48, 64):
+        print("dealt, rounds held back until %2d pairs: %s" % (thr, simulate_dealt_thr(seqs, thr)))
     print("-- refill threshold sweep (both blocks every iteration)")
     for refill in (1, 4, 8, 16, 24):
         print("refill %2d: %s" % (refill, simulate(seqs, pols["both every iteration (shipping)"], refill=refill)))
