@@ -691,3 +691,71 @@ def test_direct_with_the_qmc_samplers_matches_oracle(gpu, phip, oracle, gauss):
         assert phip.phip_render(gs._h, C.byref(p), acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
         assert rel_l2(acc, whole.storage) < 1e-6
     gs.close()
+
+
+def _sheets_scene(gauss, w=96, h=96):
+    """15 diffuse sheets one behind the other (30 triangles, staggered so that camera rays end on different ones) and a two-triangle light in front of
+    them: a tree of at most 32 Wald records in at most 32 leaves, i.e. the fused kernel's flat table -- and EVERY ray enters (nearly) every leaf box."""
+    sb = S.SceneBuilder()
+    rng = np.random.default_rng(3)
+    for i in range(15):
+        m = sb.diffuse(tuple(rng.uniform(0.3, 0.8, 3)))
+        s = 100.0 - 5.0 * i
+        ox, oy = 14.0 * (i % 4) - 20.0, 9.0 * (i % 3) - 9.0
+        z = 10.0 * i
+        sb.quad((ox - s, oy - s, z), (ox + s, oy - s, z), (ox + s, oy + s, z), (ox - s, oy + s, z), m, facing=(0, 0, -1))
+    black = sb.diffuse((0, 0, 0))
+    sb.quad((-60, 130, -150), (60, 130, -150), (60, 170, -120), (-60, 170, -120), black, facing=(0, -1, 1), radiance=(30.0, 25.0, 20.0))
+    sb.perspective((0, 0, -260), (0, 0, 0), (0, 1, 0), 50.0, near=1.0, far=1e4)
+    sb.hdrfilm(w, h, gauss)
+    return sb
+
+
+def test_fused_kernel_work_list_overflow_matches_oracle(gpu, oracle, gauss):
+    """k_mega deals the Wald tests of a wave through a work list of 512 (ray, record) pairs (k_traverse.h: traverseFlat2W); the Cornell box never fills it
+    (64 x 3.1).  Here every ray enters the boxes of ~30 records: ~1900 pairs per wave, four rounds with the lanes that did not fit -- closest hits, shadow rays
+    and their work counters must be what the per-lane loop and the oracle give."""
+    from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
+    sb = _sheets_scene(gauss)
+    desc = sb.desc()
+    assert desc.n_triangles == 32
+    same, r = compare_render(gpu, oracle, desc, 16, min_identical=1.0, maxDepth=6)
+    assert same == 1.0
+    # the scene took the fused kernel (compare_render then also held it against the wavefront kernels), and a ray tests many records
+    gs = Scene(desc); integ = PathHIP(maxDepth=6); film = HDRFilm(gs.width, gs.height)
+    assert integ.render(gs, film, 4)
+    st = integ.stats
+    # (5 tests per ray on average -- 330 pairs per wave; the camera rays of a wave, which all enter every box from the front, bring ~1900)
+    assert st.fused and st.closest_triangle_tests >= 4 * st.closest_rays, (st.fused, st.closest_triangle_tests, st.closest_rays)
+    gs.close()
+
+
+def test_ray_kernel_work_list_overflow_matches_oracle(gpu, oracle, gauss):
+    """k_rays_w deals the triangle tests of an iteration through a work list of 256 pairs per wave (k_wide.h: WIDE_DEAL); lanes whose pairs do not fit wait
+    for the next iteration.  A haystack of long overlapping triangles (every leaf group holds many records, every ray enters many leaves) overflows it all the
+    time; results and per-sample radiance must still be the oracle's."""
+    rng = np.random.default_rng(17)
+    n = 3000
+    c = rng.uniform(-3.0, 3.0, (n, 1, 3))
+    axis = rng.normal(size=(n, 1, 3)); axis /= np.linalg.norm(axis, axis=-1, keepdims=True)
+    t = np.array([-9.0, 9.0, 0.0]).reshape(1, 3, 1)
+    side = rng.normal(scale=0.6, size=(n, 3, 3))
+    P = (c + t * axis + side).astype(np.float32).reshape(-1, 3)          # needles ~18 long, ~1 wide, through a ball of radius 3
+    T = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    sb = S.SceneBuilder()
+    sb.mesh(P, T, sb.twosided(sb.diffuse((0.6, 0.55, 0.5))))
+    black = sb.diffuse((0, 0, 0))
+    sb.quad((-8, 14, -8), (8, 14, -8), (8, 14, 8), (-8, 14, 8), black, facing=(0, -1, 0), radiance=(12.0, 11.0, 10.0))
+    sb.perspective((0, 2, -26), (0, 0, 0), (0, 1, 0), 40.0, near=0.1, far=1e3)
+    sb.hdrfilm(64, 48, gauss)
+    desc = sb.desc()
+    from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
+    gs = Scene(desc)
+    info = gs.accel_info().as_dict()
+    assert info["node_bytes"] == 80, info                                 # the compressed wide tree, i.e. k_rays_w
+    integ = PathHIP(maxDepth=5); film = HDRFilm(gs.width, gs.height)
+    assert integ.render(gs, film, 2)
+    st = integ.stats
+    assert not st.fused and st.closest_triangle_tests >= 12 * st.closest_rays, (st.closest_triangle_tests, st.closest_rays)
+    gs.close()
+    compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=5)
