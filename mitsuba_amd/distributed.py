@@ -39,6 +39,11 @@ def reduce_film(film, dst=0):
     """In-place SUM-reduce of a (H,W,5) float32 tensor onto rank `dst` (ncclReduce on GPUs)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+        if film.is_cuda:
+            # A "synchronous" collective of the nccl backend only makes torch's CURRENT STREAM wait for it; the host returns at once.  What follows here
+            # runs on the library's own streams (phip_film_to_host: the merged frame's D2H; the next phip_render_device: it overwrites `film`), which
+            # know nothing of torch's -- so the host waits for the reduce before it hands the buffer on.
+            torch.cuda.current_stream(film.device).synchronize()
     return film
 
 
