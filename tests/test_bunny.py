@@ -120,3 +120,48 @@ def test_bunny_through_the_reference_obj_loader_and_the_shim(phip, gauss, bunny,
     assert abs(img.mean() - cpu.mean()) / cpu.mean() < 0.08
     rs.close(); gs.close()
     del full
+
+
+def test_bunny_through_the_reference_ply_loader_equals_the_mesh(gauss, bunny, tmp_path):
+    """data/tests/bunny.ply is a PLY file; the reference reads such assets with src/shapes/ply.cpp, whose parser is written against Boost.MPL's lambda
+    machinery (oracle/ref_shims/boost/mpl/vector.hpp restates the forms it uses).  The fixture's mesh written as PLY -- ascii and binary_little_endian, as
+    ply.cpp's callbacks expect it: float x y z per vertex, a uchar-counted int list per face -- and loaded by the reference's own plugin answers the 40 000
+    chords of the benchmark exactly as the reference answered them on the original file (CPU only: ShapeKDTree::rayIntersect on the loaded TriMesh)."""
+    from oracle import ref_ffi
+    if not ref_ffi.available() or not os.path.exists(os.path.join(os.path.dirname(ref_ffi.LIB), "plugins", "ply.so")):
+        pytest.skip("oracle/_ref (reference build with the ply loader) is not present")
+    from mitsuba_amd import scene as S
+    V, F = bunny["V"].astype("<f4"), bunny["F"].astype("<i4")
+    head = "ply\nformat %s 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n"
+    asc = tmp_path / "bunny_ascii.ply"
+    with open(asc, "w") as f:
+        f.write(head % ("ascii", len(V), len(F)))
+        for v in V:
+            f.write("%.9g %.9g %.9g\n" % (v[0], v[1], v[2]))
+        for t in F:
+            f.write("3 %d %d %d\n" % (t[0], t[1], t[2]))
+    binf = tmp_path / "bunny_binary.ply"
+    with open(binf, "wb") as f:
+        f.write((head % ("binary_little_endian", len(V), len(F))).encode())
+        f.write(V.tobytes())
+        rec = np.zeros(len(F), dtype=[("n", "u1"), ("i", "<i4", 3)]); rec["n"] = 3; rec["i"] = F
+        f.write(rec.tobytes())
+    for path in (asc, binf):
+        # the benchmark's scene is the bunny alone (make_golden_bunny.bunny_scene adds nothing else that a chord could hit first? it does: shape ids are
+        # checked below) -- here: an empty description + the file, so every hit is on the loaded mesh
+        sb = S.SceneBuilder()
+        mat = sb.diffuse((0.5, 0.5, 0.5))
+        # (a scene without emitter gets the reference's default sunsky, a plugin this build does not have: a millimetre of light a kilometre away)
+        sb.quad((1000, 1000, 1000), (1000.001, 1000, 1000), (1000.001, 1000.001, 1000), (1000, 1000.001, 1000), sb.diffuse((0, 0, 0)), radiance=(1.0, 1.0, 1.0))
+        sb.perspective((-0.05, 0.18, 0.32), (-0.017, 0.10, 0.0), (0, 1, 0), 40.0)
+        sb.hdrfilm(16, 16, gauss)
+        rs = ref_ffi.RefScene(sb.desc(), shape_files=[("ply", str(path), mat)])
+        h = rs.trace(bunny["rays"])
+        hits = h[0] if isinstance(h, tuple) else h
+        t = np.asarray(hits)[:, 0]
+        on_bunny = np.isfinite(bunny["t"]) & (bunny["shape"] == 0)
+        assert np.isfinite(t[on_bunny]).all(), path
+        assert (t[on_bunny].view(np.uint32) == bunny["t"][on_bunny].view(np.uint32)).all(), path      # the same distances, bit for bit
+        miss = ~np.isfinite(bunny["t"])
+        assert (~np.isfinite(t[miss])).all(), path
+        rs.close()
