@@ -76,22 +76,31 @@ def test_phip_trace_on_the_bunny_equals_the_reference(phip, gauss, bunny):
 
 
 @pytest.mark.gpu
-def test_bunny_through_the_reference_obj_loader_and_the_shim(phip, gauss, bunny, tmp_path):
-    """a real asset, loaded by the reference's own mesh-loader plugin (src/shapes/obj.cpp), flattened by the path_hip shim and
+@pytest.mark.parametrize("loader", ["obj", "ply"])
+def test_bunny_through_the_reference_obj_loader_and_the_shim(phip, gauss, bunny, tmp_path, loader):
+    """a real asset, loaded by the reference's own mesh-loader plugins (src/shapes/obj.cpp, src/shapes/ply.cpp), flattened by the path_hip shim and
     rendered on the GPU, against the same mesh handed to the library directly"""
     from oracle import ref_ffi
-    if not ref_ffi.available() or not ref_ffi.have_shims() or not os.path.exists(os.path.join(os.path.dirname(ref_ffi.LIB), "plugins", "obj.so")):
-        pytest.skip("oracle/_ref (reference build + plugin shims + obj loader) is not present")
+    if not ref_ffi.available() or not ref_ffi.have_shims() or not os.path.exists(os.path.join(os.path.dirname(ref_ffi.LIB), "plugins", loader + ".so")):
+        pytest.skip("oracle/_ref (reference build + plugin shims + %s loader) is not present" % loader)
     if phip.phip_device_count() <= 0:
         pytest.fail("no HIP device visible")
     from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
     V, F = bunny["V"], bunny["F"]
-    obj = tmp_path / "bunny.obj"
-    with open(obj, "w") as f:
-        for v in V:
-            f.write("v %.9g %.9g %.9g\n" % (v[0], v[1], v[2]))
-        for t in F:
-            f.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
+    obj = tmp_path / ("bunny." + loader)
+    if loader == "obj":
+        with open(obj, "w") as f:
+            for v in V:
+                f.write("v %.9g %.9g %.9g\n" % (v[0], v[1], v[2]))
+            for t in F:
+                f.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
+    else:
+        with open(obj, "wb") as f:
+            f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nelement face %d\n"
+                     "property list uchar int vertex_indices\nend_header\n" % (len(V), len(F))).encode())
+            f.write(V.astype("<f4").tobytes())
+            rec = np.zeros(len(F), dtype=[("n", "u1"), ("i", "<i4", 3)]); rec["n"] = 3; rec["i"] = F
+            f.write(rec.tobytes())
     w, h, spp = 96, 96, 16
     full = bunny["scene"](V, F, gauss, w, h)                    # shapes: bunny, floor, light
     # the same scene with the bunny coming from the file: the description holds floor + light, the loader adds the mesh LAST
@@ -104,7 +113,7 @@ def test_bunny_through_the_reference_obj_loader_and_the_shim(phip, gauss, bunny,
     sb.perspective((-0.05, 0.18, 0.32), (-0.017, 0.10, 0.0), (0, 1, 0), 40.0)
     sb.hdrfilm(w, h, gauss)
     partial = sb.desc()
-    rs = ref_ffi.RefScene(partial, shape_files=[("obj", str(obj), bunny_mat)])
+    rs = ref_ffi.RefScene(partial, shape_files=[(loader, str(obj), bunny_mat)])
     p = A.default_render_params(spp=spp, max_depth=6)
     img, sec = rs.render_job(p, threads=2, plugin="path_hip")  # Mitsuba: obj.so -> Scene -> path_hip.so -> libphip.so -> GPU
     sb.mesh(V, F, bunny_mat)                                    # the direct version: same shapes, same order
@@ -113,7 +122,7 @@ def test_bunny_through_the_reference_obj_loader_and_the_shim(phip, gauss, bunny,
     assert PathHIP(maxDepth=6).render(gs, film, spp)
     direct = film.develop()
     r = rel_l2(img, direct)
-    print("bunny through obj.so + path_hip.so vs direct: rel L2 %.3e (%.2f s)" % (r, sec))
+    print("bunny through %s.so + path_hip.so vs direct: rel L2 %.3e (%.2f s)" % (loader, r, sec))
     assert np.isfinite(img).all() and img.max() > 0
     assert r < 1e-4
     cpu, _ = rs.render_job(p, threads=8)                        # the reference's CPU path on the loaded asset
