@@ -246,6 +246,15 @@ void oracle_ld_point(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t see
     SampleSource s; s.pixel = pixel; s.sample = sample; s.seed = seed; s.ld = true; s.ldMask = mask;
     const Vec2 p = s.ldPoint(dim); out2[0] = p.x; out2[1] = p.y;
 }
+/* dimension `dim` of point `index` of the Halton / Hammersley sequence as RinvTables::sample draws it (halton.cpp:343-350, hammersley.cpp:235-243);
+   perm = NULL: no scrambling.  Pinned on the reference's own known answers (src/tests/test_samplers.cpp:33-77) by tests/test_golden.py. */
+float oracle_rinv_sample(const uint32_t *primes, uint32_t dims, const uint16_t *perm, int hammersley, uint64_t sample_count, uint64_t index, uint32_t dim) {
+    RinvTables T; T.primes = primes; T.perm = perm; T.dims = dims; T.hammersley = hammersley != 0;
+    size_t off = 0; T.permOffset.resize(dims);
+    for (uint32_t d = 0; d < dims; ++d) { T.permOffset[d] = off; off += primes[d]; }
+    if (hammersley) T.factor = (float) 1.0f / (float) sample_count;       /* hammersley.cpp:97 before setFilmResolution: m_factor = 1 / sampleCount */
+    return T.sample(index, dim);
+}
 void oracle_ctr_block(uint32_t pixel, uint32_t sample, uint32_t block, uint32_t seed, float *out4) {
     SampleSource s; s.pixel = pixel; s.sample = sample; s.seed = seed; s.block(block, out4);
 }

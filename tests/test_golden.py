@@ -87,3 +87,29 @@ def test_reference_render_fixture(oracle, name, build, kw):
     same = (samples.view(np.uint32) == ref_s.view(np.uint32)).all(-1).mean()
     assert same == 1.0, "%.4f%% of the samples are bit-identical to the reference (max abs diff %.3e)" % (100 * same, np.abs(samples - ref_s).max())
     assert np.array_equal(film.view(np.uint32), ref_f.view(np.uint32))
+
+
+def test_halton_and_hammersley_known_answers(oracle):
+    """The reference's own known answers for its radical-inverse samplers (src/tests/test_samplers.cpp:33-77: MATLAB's haltonset(5), the first five
+    points; Hammersley with sampleCount = 5: i / 5 in front of the same columns), to the test's own tolerance of 1e-7.  They are the UNSCRAMBLED sequence
+    (`scramble` = 0); the plugins' default, Faure's permutations, is pinned on the plugins themselves in tests/test_ref_pin.py."""
+    import ctypes as C
+    import numpy as np
+    from conftest import qmc_tables
+    L = oracle.lib()
+    primes, perm = qmc_tables(0)
+    assert perm is None and list(primes[:5]) == [2, 3, 5, 7, 11]
+    pp = primes.ctypes.data_as(C.POINTER(C.c_uint32))
+    halton = np.array([[0, 0, 0, 0, 0],
+                       [0.500000000000000, 0.333333333333333, 0.200000000000000, 0.142857142857143, 0.090909090909091],
+                       [0.250000000000000, 0.666666666666667, 0.400000000000000, 0.285714285714286, 0.181818181818182],
+                       [0.750000000000000, 0.111111111111111, 0.600000000000000, 0.428571428571429, 0.272727272727273],
+                       [0.125000000000000, 0.444444444444444, 0.800000000000000, 0.571428571428571, 0.363636363636364]])
+    got = np.array([[L.oracle_rinv_sample(pp, len(primes), None, 0, 1, i, j) for j in range(5)] for i in range(5)])
+    assert np.abs(got - halton).max() <= 1e-7
+    hamm = np.concatenate([np.arange(5).reshape(5, 1) / 5.0, halton], axis=1)
+    got = np.array([[L.oracle_rinv_sample(pp, len(primes), None, 1, 5, i, j) for j in range(6)] for i in range(5)])
+    assert np.abs(got - hamm).max() <= 1e-7
+    # test03_radicalInverseIncr: the van der Corput sequence, exactly
+    for i in range(20):
+        assert L.oracle_rinv_sample(pp, len(primes), None, 0, 1, i, 0) == int(format(i, "b")[::-1], 2) / float(1 << max(i.bit_length(), 1)) or i == 0
