@@ -327,6 +327,36 @@ void oracle_sample_emitter(void *scene_, const float *ref3, const float *refN3, 
     }
 }
 
+/* Emitter::sampleDirect / pdfDirect of the scene's ENVIRONMENT emitter (constant.cpp / envmap.cpp:516-556), solid-angle measure, no visibility test: the pair
+   the reference's test_chisquare::test03_EmitterDirect holds against each other (test_chisquare.cpp:575-618).  sample: d3 + pdf; pdf of given directions. */
+int oracle_env_sample_direct(void *scene_, const float *ref3, size_t n, const float *sample2, float *d3, float *pdf, float *value3) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    if (scene.envEmitter < 0) return -1;
+    const phip_emitter &em = scene.emitters[scene.envEmitter];
+    for (size_t i = 0; i < n; ++i) {
+        DirectSamplingRecord dRec;
+        dRec.ref = Vec3(ref3[0], ref3[1], ref3[2]); dRec.refN = Vec3(0.0f, 0.0f, 0.0f);
+        dRec.emitter = scene.envEmitter; dRec.pdf = 0; dRec.measure = EInvalidMeasure;
+        const Vec2 sample(sample2[2 * i], sample2[2 * i + 1]);
+        const Spectrum value = em.type == PHIP_EMITTER_ENVMAP ? scene.envmapSampleDirect(dRec, sample) : scene.constantSampleDirect(em, dRec, sample);
+        for (int k = 0; k < 3; ++k) { d3[3 * i + k] = dRec.pdf != 0 ? dRec.d[k] : 0.0f; value3[3 * i + k] = value[k]; }
+        pdf[i] = dRec.pdf;
+    }
+    return 0;
+}
+int oracle_env_pdf_direct(void *scene_, const float *ref3, size_t n, const float *d3, float *pdf) {
+    const Scene &scene = *static_cast<Scene *>(scene_);
+    if (scene.envEmitter < 0) return -1;
+    const phip_emitter &em = scene.emitters[scene.envEmitter];
+    for (size_t i = 0; i < n; ++i) {
+        DirectSamplingRecord dRec;
+        dRec.ref = Vec3(ref3[0], ref3[1], ref3[2]); dRec.refN = Vec3(0.0f, 0.0f, 0.0f);
+        dRec.d = Vec3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]); dRec.emitter = scene.envEmitter; dRec.measure = ESolidAngle; dRec.dist = 1.0f; dRec.n = -dRec.d;
+        pdf[i] = em.type == PHIP_EMITTER_ENVMAP ? scene.envmapPdfDirect(dRec) : scene.constantPdfDirect(dRec);
+    }
+    return 0;
+}
+
 /* MipMap::eval on explicit inputs (mipmap.h:629-728) */
 int oracle_mip_eval(const phip_texture *t, size_t n, const float *uv2, const float *d0, const float *d1, float *out3) {
     try {

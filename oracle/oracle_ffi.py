@@ -52,6 +52,8 @@ def lib(libm=False):
     L.oracle_sfmt_floats.argtypes = [C.c_uint64, C.c_int, C.c_size_t, fp]
     L.oracle_ctr_block.argtypes = [u32, u32, u32, u32, fp]
     L.oracle_ld_point.argtypes = [u32, u32, u32, u32, u32, fp]
+    L.oracle_env_sample_direct.argtypes = [C.c_void_p, fp, C.c_size_t, fp, fp, fp, fp]
+    L.oracle_env_pdf_direct.argtypes = [C.c_void_p, fp, C.c_size_t, fp, fp]
     L.oracle_rinv_sample.argtypes = [C.POINTER(C.c_uint32), u32, C.POINTER(C.c_uint16), C.c_int, C.c_uint64, C.c_uint64, u32]; L.oracle_rinv_sample.restype = C.c_float
     L.oracle_clipped_aabb.argtypes = [fp, fp, fp]
     L.oracle_bsdf_sample.argtypes = [C.c_void_p, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]

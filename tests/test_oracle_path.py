@@ -440,3 +440,46 @@ def test_every_c2_sample_that_differs_from_the_kd_tree_is_a_kd_tree_artifact(ora
         assert np.array_equal(sw, np.array(r["gpu"], np.float32)), r
         assert not np.array_equal(kd, sw)
     sc.close()
+
+
+def test_environment_emitters_sample_direct_matches_pdf_chi_square(oracle, gauss):
+    """The reference's test_chisquare::test03_EmitterDirect (test_chisquare.cpp:575-618; data/tests/test_emitter.xml holds environment emitters only):
+    chi-square (10 x 20 bins in (theta, phi), significance 0.01 / number of tests) that Emitter::sampleDirect draws directions with the density
+    pdfDirect reports, from a reference point at the origin -- for the `envmap` emitter (hierarchical row / column CDFs + tent within the texel,
+    envmap.cpp:516-556, 573-644; a smooth map and a rotated one) and for `constant` (uniform sphere)."""
+    import ctypes as C
+    from test_oracle_bsdf import chi2_test, SIGNIFICANCE
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    L = oracle.lib()
+    h, w = 32, 64
+    T, P = np.meshgrid((np.arange(h) + 0.5) / h * np.pi, (np.arange(w) + 0.5) / w * 2 * np.pi, indexing="ij")
+    lum = 1.0 + 0.7 * np.cos(2 * P) * np.sin(T) + 0.5 * np.cos(T) + 2.5 * np.exp(-((T - 0.9) ** 2 + (P - 2.0) ** 2) / 0.18)
+    tex = np.stack([lum, 0.8 * lum, 0.6 * lum], -1).astype(np.float32)
+    c, s = np.cos(0.7), np.sin(0.7)
+    R = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], np.float32) @ np.array([[1, 0, 0, 0], [0, 0.8, -0.6, 0], [0, 0.6, 0.8, 0], [0, 0, 0, 1]], np.float32)
+    cases = [("envmap", lambda sb: sb.envmap(tex)), ("envmap rotated", lambda sb: sb.envmap(tex, scale=0.5, to_world=R)), ("constant", lambda sb: sb.constant((1.0, 2.0, 3.0)))]
+    rng = np.random.default_rng(2024)
+    n = 400000
+    for name, env in cases:
+        sb = S.SceneBuilder(); m = sb.diffuse((0.5, 0.5, 0.5))
+        sb.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), m, facing=(0, 0, -1))
+        env(sb)
+        sb.perspective((0, 0, -6), (0, 0, 0), (0, 1, 0), 45.0); sb.hdrfilm(8, 8, gauss)
+        sc = oracle.OracleScene(sb.desc())
+        ref = np.zeros(3, np.float32)
+        smp = np.minimum(rng.random((n, 2)).astype(np.float32), np.float32(1) - np.float32(2 ** -24))
+        d = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32); val = np.zeros((n, 3), np.float32)
+        assert L.oracle_env_sample_direct(sc.h, fp(ref), n, fp(smp), fp(d), fp(pdf), fp(val)) == 0
+
+        def pdf_fn(dirs):
+            out = np.zeros(len(dirs), np.float32)
+            assert L.oracle_env_pdf_direct(sc.h, fp(ref), len(dirs), fp(np.ascontiguousarray(dirs, np.float32)), fp(out)) == 0
+            return out
+        pval, mass = chi2_test(d, pdf_fn, n)
+        assert pval > SIGNIFICANCE / len(cases), (name, pval)
+        assert abs(mass - (pdf > 0).mean()) < 1e-2, (name, mass)                     # the density integrates to the fraction of successful samples
+        ok = pdf > 0
+        # sampleDirect's pdf is pdfDirect of the direction it returns (up to the round trip direction -> (u, v) -> texel weights near texel borders and the poles)
+        rel = np.abs(pdf_fn(d[ok]) - pdf[ok]) / pdf[ok]
+        assert np.quantile(rel, 0.999) < 1e-3, (name, np.quantile(rel, 0.999), rel.max())    # (at the poles 1 / sin(theta) makes single samples differ by more)
+        sc.close()
