@@ -142,6 +142,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) vmask, 0u));
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
                     const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
+                    if (QMC && rc.jitter) rc.jitter[id] = make_float2(jit.x, jit.y);      /* for the film pass (64 consecutive ids: one 512-byte store per wave) */
                     const float sx = (float) px + jit.x, sy = (float) py + jit.y;
                     V3 o, d; float mint, maxt;
                     cameraRay(S.cam, sx, sy, o, d, mint, maxt);
@@ -206,6 +207,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 if (decodeId(rc, S.film, id, px, py, k)) {      /* ids outside the crop window (edge blocks) are consumed and skipped */
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
                     const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
+                    if (QMC && rc.jitter) rc.jitter[id] = make_float2(jit.x, jit.y);
                     const float sx = (float) px + jit.x, sy = (float) py + jit.y;
                     V3 o, d; float mint, maxt;
                     cameraRay(S.cam, sx, sy, o, d, mint, maxt);
