@@ -1,22 +1,10 @@
-out=gpurun_out/r4x; mkdir -p $out
-timeout 200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_direct.py -m gpu -q -k "sobol or sampler or qmc or halton" 2>&1 | grep -v "version\|Hostname\|Librccl" | tail -4 | tee $out/pytest.txt
-python - <<'PY' 2>&1 | tee $out/c2_samplers_candidates.txt
-import sys, time, json, os
-sys.path.insert(0, "tests")
-from conftest import sobol_tables, qmc_tables
-from mitsuba_amd import _ffi, _abi as A, scene as S
-from mitsuba_amd.integrator import Scene, PathHIP, PinnedFilm
-w=h=1024; spp=256
-sc=Scene(S.cornell_box(w,h,_ffi.gaussian_filter()).desc()); integ=PathHIP(maxDepth=-1); film=PinnedFilm(w,h)
-for name,kw,env in (("sobol",dict(sobol=sobol_tables(w,h)),None),("sobol-nojitterbuf",dict(sobol=sobol_tables(w,h)),"1"),("halton",dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1)),None),("halton-nojitterbuf",dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1)),"1")):
-    if env: os.environ["PHIP_NO_JITTER_BUFFER"]=env
-    else: os.environ.pop("PHIP_NO_JITTER_BUFFER",None)
-    kw.setdefault("flags", A.PHIP_FLAG_KERNEL_TIMING)
-    integ.render_into(sc, film.ptr, 4, **kw)
-    integ.render_into(sc, film.ptr, spp, **kw)
-    t=time.perf_counter(); integ.render_into(sc, film.ptr, spp, **kw); dt=time.perf_counter()-t
-    st=integ.stats
-    print(json.dumps({"sampler":name,"Msamples/s":round(w*h*spp/1e6/dt,1),"wall_ms":round(dt*1e3,2),"fused_kernel_ms":round(st.fused_kernel_ms,2),"film_ms":round(st.film_kernel_ms,2)}))
-PY
-SPP=64 python tools/gpu_scenes.py atrium4k 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('atrium4k 64spp', d['Msamples/s'], d['kernel_ms'], d['iters'])" | tee $out/pool.txt
+#!/bin/bash
+# branch r5-candidates: parity of the fused kernel, then the branch build against main's library (mitsuba_amd/_build/libphip_main.so), interleaved
+out=gpurun_out/r4y; mkdir -p $out
+b=$PWD/mitsuba_amd/_build
+timeout 200 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "cornell or c1_config or block_sizes or ragged or overflow or sobol" 2>&1 | grep -v "version\|Hostname\|Librccl" | tail -3 | tee $out/pytest.txt
+row() { env "${@:2}" SPP=256 REPEAT=3 python tools/gpu_scenes.py cornell 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-8s fused %6.2f ms  film %4.2f  wall %6.1f  %7.1f Msamples/s' % ('$1', d['kernel_ms']['fused_kernel_ms'], d['kernel_ms']['film_kernel_ms'], d['wall_ms'], d['Msamples/s']))"; }
+row warm X=1 > /dev/null 2>&1
+for i in 1 2 3; do row branch X=1; row main PHIP_LIB=$b/libphip_main.so; done 2>/dev/null | tee $out/ab.txt
