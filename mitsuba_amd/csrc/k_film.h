@@ -47,13 +47,13 @@ __global__ __launch_bounds__(BLOCK) void k_film(DevScene S, RenderConst rc, cons
             const uint32_t m = spreadBits((uint32_t) (sx - offX)) | (spreadBits((uint32_t) (sy - offY)) << 1);
             const uint32_t pixel = (uint32_t) sy * (uint32_t) F.width + (uint32_t) sx;
             for (uint32_t k = 0; k < rc.sppPass; ++k) {
-                const V2 jit = streamJitter<QMC>(rc, pixel, k + rc.sppFirst, (uint32_t) F.width);
+                const unsigned long long id = (((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m;
+                const V2 jit = filmJitter<QMC>(rc, id, pixel, k + rc.sppFirst, (uint32_t) F.width);
                 const float px = (float) sx + jit.x, py = (float) sy + jit.y;
                 const float posx = px - 0.5f - (float) (offX - F.border), posy = py - 0.5f - (float) (offY - F.border);
                 const int minx = max((int) ceilf(posx - F.radius), 0), maxx = min((int) floorf(posx + F.radius), bw - 1);
                 const int miny = max((int) ceilf(posy - F.radius), 0), maxy = min((int) floorf(posy + F.radius), bh - 1);
                 if (dx < minx || dx > maxx || dy < miny || dy > maxy) continue;
-                const unsigned long long id = (((unsigned long long) ts * rc.sppPass + k) << (2 * rc.tileShift)) | m;
                 const float4 v = L[id];
                 /* validity check of ImageBlock::put: reject non-finite / negative samples (imageblock.h:148-151) */
                 if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w)) || v.x < 0 || v.y < 0 || v.z < 0 || v.w < 0) {
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(256, FILM_SPLAT_WAVES) void k_film_splat(DevScene S
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" : "+v"(sx), "+v"(sy), "+v"(pixel));
 #endif
-                const V2 jit = streamJitter<QMC>(rc, pixel, k + rc.sppFirst, (uint32_t) F.width);
+                /* (sequence samplers: the jitter the path kernel stored for this sample id, behind the sample itself; a padding sample reads the pass's first) */
+                const V2 jit = filmJitter<QMC>(rc, (unsigned long long) (src - L) + (size_t) (live ? k : 0u) * stride, pixel, k + rc.sppFirst, (uint32_t) F.width);
                 const float px = (float) sx + jit.x, py = (float) sy + jit.y;
                 const float posx = px - 0.5f - (float) gx, posy = py - 0.5f - (float) gy;             /* block-bitmap coordinates */
                 /* validity check of ImageBlock::put (imageblock.h:148-151).  No branch around the 125 accumulators (the two paths' copies of them do not fit

@@ -49,8 +49,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                                                                    125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
 #define MEGA_COUNT(row, amount) ldsCount[row][threadIdx.x] += (uint32_t) (amount)
 #if MEGA_REGEN_QUEUE
-    constexpr int RQ_ROWS = QMC ? 13 : 11;
-    __shared__ uint32_t ldsRegen[BLOCK / 64][RQ_ROWS][64];      /* per wave: 64 prepared camera samples (o, mint | d, maxt | id, pixel, k [| the sample's sequence index: QMC]), one word per entry and row */
+    constexpr int RQ_ROWS = QMC ? 10 : 8;
+    __shared__ uint32_t ldsRegen[BLOCK / 64][RQ_ROWS][64];      /* per wave: 64 prepared camera samples (mint | d, maxt | id, pixel, k [| the sample's sequence index: QMC]), one word per entry and row;
+                                                                   the origin of a pinhole camera's rays is the same for every sample (camO below) */
     __shared__ uint32_t ldsSeq[QMC ? BLOCK / 64 : 1][2][64];    /* QMC: per lane, the sequence index of the path's sample -- shadeVertex draws every number of the path from it; deriving it anew at every
                                                                    request (sobol::look_up: ~30 table rows) was a third of the QMC kernel's sampling cost */
 #endif
@@ -76,6 +77,8 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     const WaveBalance wb = waveBalanceAt(g_smem, waveInBlock);  /* FLAT == 2 && MEGA_BALANCE: over the traversal stack, which the flat table does not use (phip.hip sizes it) */
 #if MEGA_REGEN_QUEUE
     uint32_t qHead = 0, qCount = 0;                             /* the wave's queue of prepared camera samples (wave-uniform) */
+    V3 camO;                                                    /* the origin cameraRay returns for every sample (dv_scene.h: the camera-to-world translation, by its own expression) */
+    { V3 d_; float mn_, mx_; cameraRay(S.cam, 0.5f, 0.5f, camO, d_, mn_, mx_); }
 #endif
     bool exhausted = rc.totalIds == 0;
 
@@ -142,16 +145,17 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) vmask, 0u));
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
                     const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
+                    if (QMC && rc.jitter) rc.jitter[id] = make_float2(jit.x, jit.y);      /* for the film pass (64 consecutive ids: one 512-byte store per wave) */
                     const float sx = (float) px + jit.x, sy = (float) py + jit.y;
                     V3 o, d; float mint, maxt;
                     cameraRay(S.cam, sx, sy, o, d, mint, maxt);
                     uint32_t *q = &ldsRegen[waveInBlock][0][pos];
-                    q[0 * 64] = pm_to_bits(o.x); q[1 * 64] = pm_to_bits(o.y); q[2 * 64] = pm_to_bits(o.z); q[3 * 64] = pm_to_bits(mint);
-                    q[4 * 64] = pm_to_bits(d.x); q[5 * 64] = pm_to_bits(d.y); q[6 * 64] = pm_to_bits(d.z); q[7 * 64] = pm_to_bits(maxt);
-                    q[8 * 64] = (uint32_t) id; q[9 * 64] = pixel; q[10 * 64] = k;
+                    q[0 * 64] = pm_to_bits(mint);
+                    q[1 * 64] = pm_to_bits(d.x); q[2 * 64] = pm_to_bits(d.y); q[3 * 64] = pm_to_bits(d.z); q[4 * 64] = pm_to_bits(maxt);
+                    q[5 * 64] = (uint32_t) id; q[6 * 64] = pixel; q[7 * 64] = k;
                     if (QMC) {
                         const uint64_t sidx = isSequenceSampler(rc.sampler) ? seqIndex(rc, k, px, py) : 0ull;
-                        q[11 * 64] = (uint32_t) sidx; q[12 * 64] = (uint32_t) (sidx >> 32);
+                        q[8 * 64] = (uint32_t) sidx; q[9 * 64] = (uint32_t) (sidx >> 32);
                     }
                 }
                 qHead = 0u; qCount = (uint32_t) __popcll(vmask);
@@ -161,10 +165,10 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) want, 0u));
             if (!alive && rank < qCount) {
                 const uint32_t *q = &ldsRegen[waveInBlock][0][qHead + rank];
-                v.rayO = make_float4(pm_from_bits(q[0 * 64]), pm_from_bits(q[1 * 64]), pm_from_bits(q[2 * 64]), pm_from_bits(q[3 * 64]));
-                v.rayD = make_float4(pm_from_bits(q[4 * 64]), pm_from_bits(q[5 * 64]), pm_from_bits(q[6 * 64]), pm_from_bits(q[7 * 64]));
-                v.id = q[8 * 64]; v.pixel = q[9 * 64]; v.k = q[10 * 64];
-                if (QMC) { ldsSeq[waveInBlock][0][lane] = q[11 * 64]; ldsSeq[waveInBlock][1][lane] = q[12 * 64]; }
+                v.rayO = make_float4(camO.x, camO.y, camO.z, pm_from_bits(q[0 * 64]));
+                v.rayD = make_float4(pm_from_bits(q[1 * 64]), pm_from_bits(q[2 * 64]), pm_from_bits(q[3 * 64]), pm_from_bits(q[4 * 64]));
+                v.id = q[5 * 64]; v.pixel = q[6 * 64]; v.k = q[7 * 64];
+                if (QMC) { ldsSeq[waveInBlock][0][lane] = q[8 * 64]; ldsSeq[waveInBlock][1][lane] = q[9 * 64]; }
                 v.thr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
                 v.mis = make_float2(0.0f, 0.0f);
                 v.state = 1u | F_ALIVE | F_EMITTED | F_FIRST;
@@ -206,6 +210,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 if (decodeId(rc, S.film, id, px, py, k)) {      /* ids outside the crop window (edge blocks) are consumed and skipped */
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
                     const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
+                    if (QMC && rc.jitter) rc.jitter[id] = make_float2(jit.x, jit.y);
                     const float sx = (float) px + jit.x, sy = (float) py + jit.y;
                     V3 o, d; float mint, maxt;
                     cameraRay(S.cam, sx, sy, o, d, mint, maxt);

@@ -114,6 +114,7 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         decodeId(rc, S.film, newId, px, py, k);
         const uint32_t pixel = py * (uint32_t) S.film.width + px;
         const V2 jit = streamJitter<QMC>(rc, pixel, k, (uint32_t) S.film.width);
+        if (QMC && rc.jitter) rc.jitter[newId] = make_float2(jit.x, jit.y);      /* for the film pass */
         const float sx = (float) px + jit.x, sy = (float) py + jit.y;
         V3 o, d; float mint, maxt;
         cameraRay(S.cam, sx, sy, o, d, mint, maxt);
@@ -215,7 +216,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                         /* the camera ray is the one ray with differentials: filtered lookup, envmap.cpp:395-407.
                            Its sample position is recomputed from the counter stream (a rare branch) */
                         const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
-                        const V2 hc = streamJitter<QMC>(rc, v.pixel, v.k, (uint32_t) S.film.width);
+                        const V2 hc = filmJitter<QMC>(rc, v.id, v.pixel, v.k, (uint32_t) S.film.width);
                         V3 rx, ry;
                         cameraRayDifferentials(S.cam, (float) px + hc.x, (float) py + hc.y, rx, ry);
                         rx = rayD + (rx - rayD) * rc.diffScaleFactor;
@@ -371,7 +372,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
                 if (firstVertex) {
                     const uint32_t px = v.pixel % (uint32_t) S.film.width, py = v.pixel / (uint32_t) S.film.width;
-                    const V2 hc = streamJitter<QMC>(rc, v.pixel, v.k, (uint32_t) S.film.width);
+                    const V2 hc = filmJitter<QMC>(rc, v.id, v.pixel, v.k, (uint32_t) S.film.width);
                     V3 rx, ry;
                     cameraRayDifferentials(S.cam, (float) px + hc.x, (float) py + hc.y, rx, ry);
                     rx = rayD + (rx - rayD) * rc.diffScaleFactor;

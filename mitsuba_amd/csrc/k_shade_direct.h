@@ -53,7 +53,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
 
         /* the camera ray of this sample: direction, differentials (integrator.cpp:171-181) */
         const uint32_t px = info.y % (uint32_t) S.film.width, py = info.y / (uint32_t) S.film.width;
-        const V2 hc = streamJitter<QMC>(rc, info.y, info.z, (uint32_t) S.film.width);
+        const V2 hc = filmJitter<QMC>(rc, id, info.y, info.z, (uint32_t) S.film.width);      /* (sequence samplers: read back, the regeneration stored it) */
         const float sx = (float) px + hc.x, sy = (float) py + hc.y;
         V3 camD;
         if (first) {

@@ -518,8 +518,14 @@ __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, ld
         triTests += (uint32_t) __popc(mask0);
         lds_cf4 *t_ = tris + 3 * ((uint32_t) best & 31u);
         const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
-        float tu, tv, tt;
-        waldIntersectSel(a, b, c, o, d, mint, maxt, tu, tv, tt);
+        /* t is the key's high word (the tester's quotient, bit for bit); (u, v) follow from it as in the Wald test -- no division, no o_k / d_k selects */
+        const float tt = pm_from_bits((uint32_t) (best >> 32));
+        const uint32_t k = pm_to_bits(a.x);
+        const bool k0 = k == 0, k2 = k == 2;
+        const float o_u = k0 ? o.y : (k2 ? o.x : o.z), o_v = k0 ? o.z : (k2 ? o.y : o.x);
+        const float d_u = k0 ? d.y : (k2 ? d.x : d.z), d_v = k0 ? d.z : (k2 ? d.y : d.x);
+        const float hu = o_u + tt * d_u - b.x, hv = o_v + tt * d_v - b.y;
+        const float tu = hv * b.z + hu * b.w, tv = hu * c.x + hv * c.y;
         res.t = found ? tt : res.t; res.u = found ? tu : res.u; res.v = found ? tv : res.v; res.prim = found ? pm_to_bits(c.z) : res.prim;
         return found;
     }

@@ -168,6 +168,7 @@ struct SceneDev {
     DevScene dev;
     /* ---- render-time buffers (grown on demand, reused between calls) ---- */
     DevBuf<float4> rayO, rayD, hit, thr, camHit, shadow, L, sampleOut;
+    DevBuf<float2> jitter;                                                                     /* sequence samplers: the camera sample's pixel jitter per sample id (RenderConst::jitter) */
     DevBuf<uint4> info; DevBuf<uint32_t> state; DevBuf<float2> mis;
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
@@ -999,10 +1000,11 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     hipStream_t stream = (p->n_devices <= 1) ? (hipStream_t) p->stream : nullptr;    /* a caller's stream belongs to one device */
     if (!stream) { if (!sd.stream) HIP_TRY(hipStreamCreate(&sd.stream)); stream = sd.stream; }
 
-    /* passes: bound the per-sample buffer (16 B per sample id) */
+    /* passes: bound the per-sample buffer (16 B per sample id; 24 B with the jitter the sequence samplers keep for the film pass) */
+    const bool keepJitter = (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY) && !getenv("PHIP_NO_JITTER_BUFFER");
     const unsigned long long tilePixels = (unsigned long long) bs * bs;
     const unsigned long long maxIdsPerPass = (1ull << 32) - 1;                 /* sample ids are 32-bit in the slot state */
-    unsigned long long budgetIds = (24ull << 30) / 16;                        /* 24 GiB of sample buffer */
+    unsigned long long budgetIds = (24ull << 30) / (keepJitter ? 24 : 16);    /* 24 GiB of sample buffer */
     if (const char *e = getenv("PHIP_MAX_PASS_SAMPLES")) budgetIds = std::max(1ull, strtoull(e, nullptr, 10));   /* test hook: force several passes */
     unsigned long long idsPerSpp = (unsigned long long) nLocalTiles * tilePixels;
     uint32_t sppPerPass = (uint32_t) p->spp;
@@ -1017,6 +1019,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
 
     const unsigned long long idsFirstPass = idsPerSpp * sppPerPass;
     if (sd.L.n < idsFirstPass) sd.L.alloc((size_t) idsFirstPass);
+    if (keepJitter && sd.jitter.n < idsFirstPass) sd.jitter.alloc((size_t) idsFirstPass);
 
     /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
     const bool rinv = p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY;
@@ -1093,7 +1096,9 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
            work queue is empty: ~0.15 ms per launch on the 250 k-triangle scenes, 14 % of a launch over 4 M slots, 7 % over 8 M.  A bigger
            pool means fewer, longer launches: atrium 1920x1080x64 spp 427 / 454 / 470 / 470 Msamples/s with 4 / 8 / 16 / 32 M slots, the
            glass room at 512 spp 480 / 496 / 505 with 8 / 16 / 32 M -- so the pool grows with the job (about 0.14 KB of HBM per slot). */
-        const unsigned long long poolCap = idsFirstPass >= (512ull << 20) ? (1ull << 25) : idsFirstPass >= (64ull << 20) ? (1ull << 24)
+        /* (round 4, after the ray kernel's triangle rounds: 8 / 16 / 32 / 64 M slots on the 4K slice (531 M ids) 610 / 636 / 646 / 657 Msamples/s, C4 at 512 spp (1062 M ids)
+           flat at 64 M and -2 % at 128 M, C3 (133 M ids) flat from 16 M on: jobs of more than 256 M ids get 64 M slots) */
+        const unsigned long long poolCap = idsFirstPass > (256ull << 20) ? (1ull << 26) : idsFirstPass >= (64ull << 20) ? (1ull << 24)
                                          : idsFirstPass >= (16ull << 20) ? (1ull << 23) : (1ull << 22);
         capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
         {   /* ... and with the memory that is there: the pool's state is ~144 B per slot; it may take a quarter of what is free now (a
@@ -1248,6 +1253,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         }
         rc.envFiltered = (sc->envLevelCount > 1 && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND)) ? 1u : 0u;
         rc.staticIds = 0; rc.shardIds = 0; rc.dynCounter = sd.dynCounter.p; rc.blockShard = sd.blockShard.p;
+        rc.jitter = keepJitter ? sd.jitter.p : nullptr;
         HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), stream));
         uint32_t iter = 0;
 
