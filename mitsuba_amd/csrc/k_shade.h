@@ -366,7 +366,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
             dRec.pdf = 0; dRec.emitter = -1;
             BsdfCtx bctx = bsdfResolve(materials, its);
-            if (TEX && leafIsTextured(*bctx.leaf)) {
+            if (TEX && bctx.textured) {
                 /* texture->eval(its) of the BSDF's bitmap children: unfiltered level-0 lookup, except at the first vertex, whose UV partials come
                    from the camera-ray differentials (Intersection::getBSDF(ray) -> computePartials, records.inl:69-75) */
                 float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;

@@ -100,7 +100,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             if (!terminate) {
                 const V3 refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;     /* DirectSamplingRecord(its), records.inl:146-153 */
                 BsdfCtx bctx = bsdfResolve(materials, its);
-                if (TEX && leafIsTextured(*bctx.leaf)) {
+                if (TEX && bctx.textured) {
                     /* its.getBSDF(ray): every query at the camera vertex sees the UV partials of the camera-ray differentials */
                     float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
                     V3 rx, ry;

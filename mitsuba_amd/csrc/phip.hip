@@ -428,7 +428,14 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
        functions the kernel would run, so precomputing them does not change a single bit */
     bool anyTexcoords = false;
     for (uint32_t i = 0; i < d.n_shapes; ++i) anyTexcoords |= d.shapes[i].has_texcoords != 0;
-    const uint32_t stride = anyTexcoords ? TRISHADE_FLOAT4S_UV : TRISHADE_FLOAT4S;
+    /* material heads behind r5 (dv_scene.h): every scene except the candidates of the fused kernel, which stages 96-byte records in LDS and reads
+       its materials from LDS anyway */
+    bool nonDiffuse = false;
+    for (const DevMaterial &m : mats) nonDiffuse |= m.type == PHIP_BSDF_ROUGHCONDUCTOR || m.type == PHIP_BSDF_DIELECTRIC;
+    const bool fusedCandidate = !nonDiffuse && d.n_textures == 0 && envEmitter < 0 && !anyTexcoords && d.n_triangles <= MEGA_TRISHADE_MAX;
+    const bool heads = !fusedCandidate && !getenv("PHIP_NO_HEADS");
+    const uint32_t headAt = heads ? (uint32_t) TRISHADE_FLOAT4S : 0u, uvAt = TRISHADE_FLOAT4S + (heads ? TRISHADE_FLOAT4S_HEAD : 0);
+    const uint32_t stride = uvAt + (anyTexcoords ? 3u : 0u);
     std::vector<float4> ts((size_t) stride * d.n_triangles, make_float4(0, 0, 0, 0));
     for (uint32_t i = 0; i < d.n_triangles; ++i) {
         const DevShape &sh = shapes[triShape[i]];
@@ -461,9 +468,9 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                     dpdv = (side1 * (-dUV2.x) + side2 * dUV1.x) * invDet;
                 }
             }
-            r[6] = make_float4(t0[0], t0[1], t1[0], t1[1]);
-            r[7] = make_float4(t2[0], t2[1], dpdu.x, dpdu.y);
-            r[8] = make_float4(dpdu.z, dpdv.x, dpdv.y, dpdv.z);
+            r[uvAt] = make_float4(t0[0], t0[1], t1[0], t1[1]);
+            r[uvAt + 1] = make_float4(t2[0], t2[1], dpdu.x, dpdu.y);
+            r[uvAt + 2] = make_float4(dpdu.z, dpdv.x, dpdv.y, dpdv.z);
         }
         V3 a, b, c;
         if (sh.hasNormals) {
@@ -473,6 +480,20 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         } else {
             Frame f; triShadingFrame(triFaceNormal(side1, side2), dpdu, f);
             a = f.n; b = f.s; c = f.t;
+        }
+        if (heads) {
+            const DevMaterial &F = mats[front], &B = mats[back];
+            auto plainDiffuse = [](const DevMaterial &l) { return l.type == PHIP_BSDF_DIFFUSE && l.reflTexture == 0; };
+            auto plainDielectric = [](const DevMaterial &l) { return l.type == PHIP_BSDF_DIELECTRIC && l.reflTexture == 0 && l.transTexture == 0; };
+            if (front == back && (plainDiffuse(F) || plainDielectric(F))) {
+                flags |= TS_HEAD_FULL;
+                r[headAt] = make_float4(F.refl[0], F.refl[1], F.refl[2], pm_from_bits(F.type));
+                r[headAt + 1] = make_float4(F.trans[0], F.trans[1], F.trans[2], F.eta[0]);
+            } else if (front != back && plainDiffuse(F) && plainDiffuse(B)) {
+                flags |= TS_HEAD_SPLIT;
+                r[headAt] = make_float4(F.refl[0], F.refl[1], F.refl[2], pm_from_bits(F.type));
+                r[headAt + 1] = make_float4(B.refl[0], B.refl[1], B.refl[2], pm_from_bits(B.type));
+            }
         }
         r[0] = make_float4(p0.x, p0.y, p0.z, pm_from_bits(front));
         r[1] = make_float4(p1.x, p1.y, p1.z, pm_from_bits(back));
@@ -499,7 +520,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                 memcpy(&(*recs)[r + 11], &c, 4);
             }
     }
-    if (ts.empty()) sd.triShade.alloc(TRISHADE_FLOAT4S_UV); else sd.triShade.upload(ts.data(), ts.size());
+    if (ts.empty()) sd.triShade.alloc(TRISHADE_FLOAT4S_UV + TRISHADE_FLOAT4S_HEAD); else sd.triShade.upload(ts.data(), ts.size());
     if (texTexels.empty()) sd.texTexels.alloc(1); else sd.texTexels.upload(texTexels.data(), texTexels.size());
     if (texDesc.empty()) sd.texDesc.alloc(1); else sd.texDesc.upload(texDesc.data(), texDesc.size());
     sc->hasTextures = d.n_textures > 0; sc->triShadeStride = stride;
@@ -575,7 +596,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     memset(&D, 0, sizeof(D));
     D.nodes = sd.nodes.p; D.tris = sd.tris.p; D.triShade = sd.triShade.p;
     D.materials = sd.materials.p; D.nMaterials = (uint32_t) mats.size();
-    D.texTexels = sd.texTexels.p; D.textures = sd.texDesc.p; D.triShadeStride = sc->triShadeStride;
+    D.texTexels = sd.texTexels.p; D.textures = sd.texDesc.p; D.triShadeStride = sc->triShadeStride; D.triShadeHead = headAt; D.triShadeUv = uvAt;
     D.emitterTab = sd.emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
     D.envEmitter = envEmitter;
@@ -1101,11 +1122,16 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         const unsigned long long poolCap = idsFirstPass > (256ull << 20) ? (1ull << 26) : idsFirstPass >= (64ull << 20) ? (1ull << 24)
                                          : idsFirstPass >= (16ull << 20) ? (1ull << 23) : (1ull << 22);
         capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
-        {   /* ... and with the memory that is there: the pool's state is ~144 B per slot; it may take a quarter of what is free now (a
-               shared or partitioned GPU, n_devices replicas), never less than the 4 M slots every job ran with before the pool grew */
+        /* traversal-stack overflow: SPILL_DEPTH words per LANE of a ray kernel -- the wide tree is only walked by persistent grids
+           (at most 8 resident blocks of 256 per CU), the BVH4 also by one-lane-per-slot launches */
+        const bool canSpill = sc->wide ? (int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS : 3 * ((int) sc->bvh.maxDepth - 1) + 1 > (int) D.stackDepth;
+        const bool persistentOnly = sc->wide || (sc->traversal == 2 && sc->bvh.nNodes >= 64 && !getenv("PHIP_MERGED"));
+        {   /* ... and with the memory that is there: the pool's state is ~144 B per slot (+ 384 B of spill stack where every slot is a lane that can
+               spill); it may take a quarter of what is free now (a shared or partitioned GPU, n_devices replicas), never less than the 4 M slots
+               every job ran with before the pool grew */
             size_t freeB = 0, totalB = 0;
             if (sd.rayO.n < capacity && hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-                unsigned long long fit = (unsigned long long) (freeB / 4) / 144ull;
+                unsigned long long fit = (unsigned long long) (freeB / 4) / (144ull + ((!persistentOnly && canSpill) ? (unsigned long long) SPILL_DEPTH * 4ull : 0ull));
                 while (capacity > (1u << 22) && capacity > fit) capacity >>= 1;
             }
         }
@@ -1118,14 +1144,12 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             sd.mis.alloc(capacity); sd.info.alloc(capacity); sd.state.alloc(capacity); sd.shadow.alloc(3 * (size_t) capacity);
             sd.shadowCount.alloc(nBlocks); sd.blockDead.alloc(nBlocks); sd.blockShard.alloc(nBlocks);
         }
-        {   /* traversal-stack overflow: SPILL_DEPTH words per LANE of a ray kernel -- the wide tree is only walked by persistent grids
-               (at most 8 resident blocks of 256 per CU), the BVH4 also by one-lane-per-slot launches */
-            const bool canSpill = sc->wide ? (int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS : 3 * ((int) sc->bvh.maxDepth - 1) + 1 > (int) D.stackDepth;
-            const bool persistentOnly = sc->wide || (sc->traversal == 2 && sc->bvh.nNodes >= 64 && !getenv("PHIP_MERGED"));
-            /* (every block is handed spill + blockIdx * WIDE_BLOCK * SPILL_DEPTH, so the buffer covers the whole grid also when the host's depth bound
-               says that no lane can reach it: 200 MB of 288 GB against a silent out-of-bounds write should that hand-derived bound ever be off) */
-            (void) canSpill;
-            const size_t spillLanes = persistentOnly ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : laneCap;
+        {   /* persistent grids (at most 8 resident blocks of 256 per CU): the buffer always covers the whole grid, also when the host's depth bound says
+               that no lane can reach it -- 200 MB of 288 GB against a silent out-of-bounds write should that hand-derived bound ever be off.  One lane
+               per slot (BVH4 trees of < 64 nodes: small scenes with non-diffuse materials, every `direct` render of a small scene): 384 B per SLOT of a
+               pool of up to 64 M slots is 3..25 GB for a stack that is at most ~20 entries deep on such a tree -- there the bound decides, as before
+               round 4; when it says "can spill" the full size is allocated AND priced in the free-memory guard above */
+            const size_t spillLanes = persistentOnly ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : (canSpill ? laneCap : (size_t) WIDE_BLOCK);
             if (sd.spill.n < spillLanes * SPILL_DEPTH) sd.spill.alloc(spillLanes * SPILL_DEPTH);
         }
         if (sd.stat.n < (size_t) ST_COUNT * nWaves) sd.stat.alloc((size_t) ST_COUNT * nWaves);
