@@ -48,14 +48,18 @@ WORKLOADS = {
     "atrium_3840x2160_64spp_md8": ("atrium", 3840, 2160, 64, 8),                      # 1/16 of C5's samples per pixel: its single-GPU rate
     # the `direct` integrator on the same scenes
     "cornell_1024x1024_256spp_direct": ("cornell_box", 1024, 1024, 256, "direct:1"),
+    # the small scene that is NOT the benchmark: the same box with a rough-copper and a glass block (all three leaf BSDF models; wavefront kernels)
+    "cornell_mixed_1024x1024_256spp": ("cornell_mixed", 1024, 1024, 256, -1),
     "atrium_1920x1080_64spp_direct4": ("atrium", 1920, 1080, 64, "direct:4"),
 }
 HEADLINE = "cornell_1024x1024_256spp"
-EXTRA_SINGLE_GPU = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8"]
+EXTRA_SINGLE_GPU = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8",
+                    "cornell_mixed_1024x1024_256spp", "cornell_1024x1024_256spp_direct"]
 MULTI_GPU_JOB = "atrium_3840x2160_1024spp_md8"
 MULTI_GPU_SLICE = "atrium_3840x2160_64spp_md8"        # the same job at 1/16 of the samples per pixel: its single-GPU rate
 MULTI_GPU_MAX_STEPS = 3
-CPU_BASELINE_EXTRA = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8"]      # every workload of the line gets a bounded CPU figure of its own
+CPU_BASELINE_EXTRA = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8",
+                      "cornell_mixed_1024x1024_256spp", "cornell_1024x1024_256spp_direct"]      # every workload of the line gets a bounded CPU figure of its own
 
 
 def make_integrator(md):
@@ -348,8 +352,9 @@ def main():
     rank, world, local = D.init_from_env()
     in_library = world == 1 and args.gpus > 1          # no torchrun: the library's own multi-device path
     if world != args.gpus and not in_library:
-        if rank == 0:
-            print("bench.py: WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (world, args.gpus, args.gpus), file=sys.stderr)
+        # a line whose n_gpus is not the --gpus that was asked for would be read as that N's measurement: refuse
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: launch with `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d`"
+                         % (world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: path_hip has no CPU fallback")
     if in_library and torch.cuda.device_count() < args.gpus:

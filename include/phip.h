@@ -399,7 +399,8 @@ typedef struct phip_accel_info {
     float    sah_cost;
     float    build_ms;
     uint32_t fits_lds;       /* 1: tree, records, emitter table and materials fit the fused kernel's LDS plan (k_mega) */
-    uint32_t reserved;
+    uint32_t fused_traversal; /* how k_mega traverses the scene: 0 = it walks the BVH4, 1 = flat table of leaf boxes, 2 / 3 = packed table with masks of
+                                 <= 32 / <= 64 Wald records, tests dealt over the wave (was `reserved`, always 0, before round 5: same layout) */
 } phip_accel_info;
 int  phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out);
 

@@ -143,7 +143,7 @@ class phip_hit(C.Structure):
 class phip_accel_info(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_triangle_refs", C.c_uint32),
                 ("max_depth", C.c_uint32), ("node_bytes", C.c_uint32), ("triangle_bytes", C.c_uint32),
-                ("sah_cost", C.c_float), ("build_ms", C.c_float), ("fits_lds", C.c_uint32), ("reserved", C.c_uint32)]
+                ("sah_cost", C.c_float), ("build_ms", C.c_float), ("fits_lds", C.c_uint32), ("fused_traversal", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -155,11 +155,13 @@ DV void triShadingFrame(const V3 &shN, const V3 &side1, Frame &f) {
 }
 
 /* skdtree.h:343-428 with BarycentricPos = true, no UV tangents, no texcoords */
+/* HEADS: the kernel reads the material heads of the records (the wavefront kernels; k_mega's scenes have none: compiled out) */
+template <bool HEADS = false>
 DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float cu, float cv, float t, Isect &its) {
     const float4 *r = S.triShade + (size_t) S.triShadeStride * prim;
     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
     float4 h0 = make_float4(0, 0, 0, 0), h1 = h0;
-    if (S.triShadeHead) { h0 = r[S.triShadeHead]; h1 = r[S.triShadeHead + 1]; }     /* (scene-uniform: requested with the six above) */
+    if (HEADS && S.triShadeHead) { h0 = r[S.triShadeHead]; h1 = r[S.triShadeHead + 1]; }     /* (scene-uniform: requested with the six above) */
     const V3 b(1 - cu - cv, cu, cv);
     const V3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
     its.p = p0 * b.x + p1 * b.y + p2 * b.z;
@@ -187,8 +189,10 @@ DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float
     its.wi = its.sh.toLocal(-rayD);
     its.t = t; its.prim = prim;
     /* the head of the side the ray arrived on (the twosided adapter's choice, bsdfResolve below) */
-    const bool flipSplit = (its.flags & TS_HEAD_SPLIT) && cosTheta(its.wi) < 0;
-    its.head0 = flipSplit ? h1 : h0; its.head1 = h1;
+    if (HEADS) {
+        const bool flipSplit = (its.flags & TS_HEAD_SPLIT) && cosTheta(its.wi) < 0;
+        its.head0 = flipSplit ? h1 : h0; its.head1 = h1;
+    }
 }
 
 /* Intersection::computePartials, intersection.cpp:5-76 (rxOrigin = ryOrigin = rayO: pinhole camera) */
@@ -853,7 +857,7 @@ struct LeafVarying { V3 albedo; float alphaU, alphaV; V3 trans; };   /* the spat
 template <int MM> DV V3 leafEvalPdf(uint32_t type, const DevMaterial &M, const LeafVarying &lv, const V3 &wi, const V3 &wo, float &pdf) {
     const V3 &albedo = lv.albedo;
     pdf = 0.0f;
-    if (type == PHIP_BSDF_DIFFUSE) {
+    if (MM == 0 || type == PHIP_BSDF_DIFFUSE) {              /* (MM == 0: the scene's leaves are all diffuse -- `type` is not even fetched) */
         if (cosTheta(wi) <= 0 || cosTheta(wo) <= 0) return V3(0.0f);
         pdf = PT_INV_PI * cosTheta(wo);
         return albedo * (PT_INV_PI * cosTheta(wo));
@@ -878,7 +882,7 @@ template <int MM> DV V3 leafEvalPdf(uint32_t type, const DevMaterial &M, const L
 template <int MM> DV V3 leafSample(uint32_t type, float eta0, const DevMaterial &M, const LeafVarying &lv, const V3 &wi, const V2 &smp, BSDFSample &bs) {
     const V3 &albedo = lv.albedo;
     bs.eta = 1.0f; bs.delta = false; bs.pdf = 0.0f; bs.wo = V3(0.0f);
-    if (type == PHIP_BSDF_DIFFUSE) {
+    if (MM == 0 || type == PHIP_BSDF_DIFFUSE) {
         if (cosTheta(wi) <= 0) return V3(0.0f);
         bs.wo = squareToCosineHemisphere(smp);
         bs.pdf = PT_INV_PI * cosTheta(bs.wo);
@@ -942,12 +946,13 @@ DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
     return c;
 }
 /* same, from a shading record (front/back already are the nested models) */
+template <bool HEADS = false>
 DV BsdfCtx bsdfResolve(const DevMaterial *materials, const Isect &its) {
     BsdfCtx c; c.wi = its.wi;
     c.flip = (its.flags & TS_TWOSIDED) && cosTheta(its.wi) < 0;
     c.leaf = materials + (c.flip ? its.back : its.front);
     if (c.flip) c.wi.z = -its.wi.z;
-    if (its.flags & (TS_HEAD_SPLIT | TS_HEAD_FULL)) {       /* an untextured diffuse / dielectric leaf: everything arrived with the shading record */
+    if (HEADS && (its.flags & (TS_HEAD_SPLIT | TS_HEAD_FULL))) {       /* an untextured diffuse / dielectric leaf: everything arrived with the shading record */
         c.type = pm_to_bits(its.head0.w); c.eta0 = its.head1.w; c.textured = false;
         c.v.albedo = xyz(its.head0); c.v.trans = xyz(its.head1); c.v.alphaU = c.v.alphaV = 0.0f;
     } else

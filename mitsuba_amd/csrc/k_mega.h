@@ -42,7 +42,7 @@
 
 enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
 
-template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2) */,
+template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2), 3: the same with 33..64 records (two-word masks; MEGA_BALANCE only) */,
           bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
     __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
                                                                    no wait -- and the three that count lanes as ballots in SGPRs: 66.9 vs 66.5 ms per C2 frame and
@@ -74,7 +74,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     const uint32_t waveId = blockIdx.x * (BLOCK / 64) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = __lane_id();
     unsigned long long next = 0, end = 0;                       /* the wave's chunk of sample ids (wave-uniform) */
     const uint32_t waveInBlock = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const WaveBalance wb = waveBalanceAt(g_smem, waveInBlock);  /* FLAT == 2 && MEGA_BALANCE: over the traversal stack, which the flat table does not use (phip.hip sizes it) */
+    const WaveBalance wb = waveBalanceAt(g_smem, waveInBlock);  /* FLAT >= 2 && MEGA_BALANCE: over the traversal stack, which the flat table does not use (phip.hip sizes it) */
 #if MEGA_REGEN_QUEUE
     uint32_t qHead = 0, qCount = 0;                             /* the wave's queue of prepared camera samples (wave-uniform) */
     V3 camO;                                                    /* the origin cameraRay returns for every sample (dv_scene.h: the camera-to-world translation, by its own expression) */
@@ -233,14 +233,14 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 
         /* ---- closest hit ---- */
         { PF_BEGIN
-        if (FLAT == 2 && MEGA_BALANCE) {                        /* every lane takes part: the tests of the wave's rays are dealt over its lanes */
+        if (FLAT >= 2 && MEGA_BALANCE) {                        /* every lane takes part: the tests of the wave's rays are dealt over its lanes */
             const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
             float mint, maxt;
             TravResult r;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
             const bool go = alive & clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp);
-            traverseFlat2W<false>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
+            traverseFlat2W<false, FLAT == 3>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
             if (alive) {
                 v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
                 MEGA_COUNT(MC_RAYS, 1); MEGA_COUNT(MC_NODE, nNode); MEGA_COUNT(MC_TRI, nTri);
@@ -265,7 +265,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         /* ---- the vertex: emitter hit / Russian roulette / emission / NEE sample / BSDF sample ---- */
         bool pushShadow = false, ended = false;
         ShadowEntry sh;
-        if (FLAT == 2 && MEGA_BALANCE) sh.e0 = sh.e1 = make_float4(0, 0, 0, 0);   /* every lane clips "its" entry (a lane without one takes no part in the result) */
+        if (FLAT >= 2 && MEGA_BALANCE) sh.e0 = sh.e1 = make_float4(0, 0, 0, 0);   /* every lane clips "its" entry (a lane without one takes no part in the result) */
         { PF_BEGIN
         if (alive) {
             uint32_t nv = 0;
@@ -282,14 +282,14 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         PF_END(2, __ballot(alive)) }
         /* ---- shadow ray of the NEE sample; unoccluded: the contribution joins the accumulator (path.cpp:187-199) ---- */
         { PF_BEGIN
-        if (FLAT == 2 && MEGA_BALANCE) {
+        if (FLAT >= 2 && MEGA_BALANCE) {
             const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
             float mint, maxt;
             TravResult r;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
             const bool go = pushShadow & clipToSceneSel<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp);
-            const bool occluded = traverseFlat2W<true>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
+            const bool occluded = traverseFlat2W<true, FLAT == 3>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
             if (pushShadow) {
                 MEGA_COUNT(MC_SH_RAYS, 1); MEGA_COUNT(MC_SH_NODE, nNode); MEGA_COUNT(MC_SH_TRI, nTri);
                 if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }

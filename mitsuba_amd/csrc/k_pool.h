@@ -68,6 +68,7 @@ enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_T
                                         with it on the kernel needs 168 VGPRs (3 waves: measured 2020 vs 2171 Msamples/s at 4 waves even with 148 B of scratch) */
 #endif
 #define FLAT_LEAVES_MAX 32           /* k_mega: trees of at most this many leaves are traversed as a flat table of leaf boxes (one bit per leaf) */
+#define FLAT2_LEAVES_MAX 64          /* ... of the packed table with record masks (flatMode 2 / 3: at most 32 / 64 Wald records, the mask is over records, not leaves) */
 #define MEGA_TRISHADE_MAX 96         /* k_mega: shading records staged in LDS (9 KB) */
 #define DYN_SHARDS 8                    /* one dynamic-sample counter per XCD-sized group of blocks */
 #define DYN_STRIDE 16                   /* unsigned long longs between counters (128 B) */

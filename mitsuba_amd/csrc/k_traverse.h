@@ -301,8 +301,13 @@ __device__ __forceinline__ bool waldIntersectSel(const float4 &a, const float4 &
 #ifndef MEGA_FLAT_CH
 #define MEGA_FLAT_CH 1
 #endif
-__device__ __forceinline__ uint32_t flat2Pass1(lds_cf4 *flat, uint32_t nFlat, const V3 &o, const V3 &rcp, float mint, float maxt) {
-    uint32_t mask = 0;
+#ifndef MEGA_BALANCE
+#define MEGA_BALANCE 1               /* k_mega, packed flat table: the Wald tests of a traversal are dealt over the lanes of the wave (traverseFlat2W below) instead of looping per lane */
+#endif
+/* R64 (DevScene::flatMode 3, trees of 33..64 Wald records): the record mask has a second word, kept in the centre's spare word (A.w) */
+template <bool R64 = false>
+__device__ __forceinline__ uint32_t flat2Pass1(lds_cf4 *flat, uint32_t nFlat, const V3 &o, const V3 &rcp, float mint, float maxt, uint32_t *maskHi = nullptr) {
+    uint32_t mask = 0, hi = 0;
 #if MEGA_FLAT_CH
     const f2v rxy = { rcp.x, rcp.y }, oxy = { -(o.x * rcp.x), -(o.y * rcp.y) };
     const f2v rz2 = { rcp.z, 0.0f }, oz2 = { -(o.z * rcp.z), 0.0f };
@@ -323,6 +328,7 @@ __device__ __forceinline__ uint32_t flat2Pass1(lds_cf4 *flat, uint32_t nFlat, co
             asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(tx.y), "v"(ty.y), "v"(maxt));                                              \
             asm("v_min_f32 %0, %1, %2" : "=v"(tf) : "v"(tf), "v"(tz.y));                                                               \
             mask |= (tn <= tf) ? pm_to_bits(B.w) : 0u;                                                                                 \
+            if (R64) hi |= (tn <= tf) ? pm_to_bits(A.w) : 0u;                                                                          \
         }
 #else
     const f2v rx = { rcp.x, rcp.x }, ry = { rcp.y, rcp.y }, rz = { rcp.z, rcp.z };
@@ -345,13 +351,14 @@ __device__ __forceinline__ uint32_t flat2Pass1(lds_cf4 *flat, uint32_t nFlat, co
     }
     for (uint32_t c = nFlat4; c < nFlat; ++c) FLAT2_BOX(c)
 #undef FLAT2_BOX
+    if (R64) *maskHi = hi;
     return mask;
 }
 
 template <bool SHADOW>
 __device__ __forceinline__ bool traverseFlat2(lds_cf4 *flat, uint32_t nFlat, lds_cf4 *tris, const V3 &o, const V3 &d, const V3 &rcp,
                                               float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
-    uint32_t mask = flat2Pass1(flat, nFlat, o, rcp, mint, maxt);
+    uint32_t mask = flat2Pass1<false>(flat, nFlat, o, rcp, mint, maxt);
     ++nodeVisits;
     bool found = false;
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
@@ -442,19 +449,32 @@ __device__ __forceinline__ WaveBalance waveBalanceAt(unsigned char *smem, uint32
 }
 #define BAL_SYNC() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }    /* DS operations of a wave execute in order: this only pins the compiler's order */
 
-template <bool SHADOW>
+/* R64: up to 64 records (a two-word mask; list entry = lane << 6 | record, key = ... (0x3FFFFFF - prim) << 6 | record) -- round 5: a scene of 33..64 records
+   (a Cornell box with a third block) used to leave the dealt traversal for the per-lane leaf table */
+template <bool R64> struct RecMask;
+template <> struct RecMask<false> { typedef uint32_t T; static __device__ __forceinline__ uint32_t popc(T m) { return (uint32_t) __popc(m); }
+                                    static __device__ __forceinline__ uint32_t ctz(T m) { return (uint32_t) __builtin_ctz(m); }
+                                    static __device__ __forceinline__ T upTo(uint32_t i) { return (2u << i) - 1u; } };
+template <> struct RecMask<true>  { typedef unsigned long long T; static __device__ __forceinline__ uint32_t popc(T m) { return (uint32_t) __popcll(m); }
+                                    static __device__ __forceinline__ uint32_t ctz(T m) { return (uint32_t) __builtin_ctzll(m); }
+                                    static __device__ __forceinline__ T upTo(uint32_t i) { return i >= 63u ? ~0ull : (2ull << i) - 1ull; } };
+template <bool SHADOW, bool R64 = false>
 __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, lds_cf4 *tris, const WaveBalance &wb, uint32_t lane, bool go,
                                                const V3 &o, const V3 &d, const V3 &rcp, float mint, float maxt, TravResult &res, uint32_t &nodeVisits, uint32_t &triTests) {
-    uint32_t mask = flat2Pass1(flat, nFlat, o, rcp, mint, maxt);
-    mask = go ? mask : 0u;                                       /* (a lane without a ray ran pass 1 on whatever its registers held) */
+    typedef RecMask<R64> RM; typedef typename RM::T Mask;
+    constexpr uint32_t RB = R64 ? 6u : 5u, RMSK = (1u << RB) - 1u;     /* bits of a record index */
+    uint32_t maskHi = 0;
+    const uint32_t maskLo = flat2Pass1<R64>(flat, nFlat, o, rcp, mint, maxt, &maskHi);
+    Mask mask = R64 ? (Mask) (((unsigned long long) maskHi << 32) | maskLo) : (Mask) maskLo;
+    mask = go ? mask : (Mask) 0;                                 /* (a lane without a ray ran pass 1 on whatever its registers held) */
     nodeVisits += go ? 1u : 0u;
-    const uint32_t mask0 = mask;
+    const Mask mask0 = mask;
 
     if (SHADOW) *(lds_u32 *) (wb.slot + lane) = 0xFFFFFFFFu; else wb.slot[lane] = ~0ull;
-    while (__ballot(mask != 0u)) {
+    while (__ballot(mask != 0)) {
         /* list segments in lane order: an inclusive scan of the pair counts over the wave (every lane is active here: plain DPP, the
            sequence the compiler itself emits for wave-aggregated atomics -- four shifts inside the rows of 16, then two row broadcasts) */
-        const uint32_t pc = (uint32_t) __popc(mask);
+        const uint32_t pc = RM::popc(mask);
         uint32_t incl = pc;
         incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
         incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
@@ -462,15 +482,15 @@ __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, ld
         incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
         incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
         incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
-        /* the lanes whose segment ends inside the list (a prefix of the wave, never empty: a lane has at most 32 pairs) write it and are done */
+        /* the lanes whose segment ends inside the list (a prefix of the wave, never empty: a lane has at most 64 pairs) write it and are done */
         const bool fits = incl <= BAL_CAP;
         const uint32_t nFit = (uint32_t) __popcll(__ballot(fits));
         const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) (nFit - 1u));
         if (pc && fits) {
-            const uint32_t tag = lane << 5;
+            const uint32_t tag = lane << RB;
             lds_u16 *w = wb.list + (incl - pc);
             do {
-                *w++ = (uint16_t) (tag | (uint32_t) __builtin_ctz(mask));
+                *w++ = (uint16_t) (tag | RM::ctz(mask));
                 mask &= mask - 1u;
             } while (mask);
         }
@@ -482,7 +502,7 @@ __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, ld
             for (uint32_t j = 0; j < BAL_ILP; ++j) {             /* the tests, free of control flow so that the compiler interleaves them ... */
                 const uint32_t i = base + 64u * j + lane;
                 const uint32_t item = wb.list[i];                /* (entries behind `total` hold stale pairs: tested, not committed) */
-                const uint32_t owner = (item >> 5) & 63u, rec = item & 31u;
+                const uint32_t owner = (item >> RB) & 63u, rec = item & RMSK;
                 const int src = (int) (owner << 2);
                 const V3 po(pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.x))), pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.y))),
                             pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(src, (int) pm_to_bits(o.z))));
@@ -495,7 +515,7 @@ __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, ld
                 float tu, tv, tt;
                 hit[j] = (i < total) & waldIntersectSel(a, b, c, po, pd, pmint, pmaxt, tu, tv, tt);
                 own[j] = owner; hi[j] = pm_to_bits(tt);
-                lo[j] = SHADOW ? rec : (((0x7FFFFFFu - pm_to_bits(c.z)) << 5) | rec);
+                lo[j] = SHADOW ? rec : ((((0xFFFFFFFFu >> RB) - pm_to_bits(c.z)) << RB) | rec);
             }
 #pragma unroll
             for (uint32_t j = 0; j < BAL_ILP; ++j)               /* ... then the commits */
@@ -510,13 +530,13 @@ __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, ld
     if (SHADOW) {
         const uint32_t first = *(lds_u32 *) (wb.slot + lane);
         const bool found = first != 0xFFFFFFFFu;
-        triTests += (uint32_t) __popc(found ? (mask0 & ((2u << (first & 31u)) - 1u)) : mask0);
+        triTests += RM::popc(found ? (Mask) (mask0 & RM::upTo(first & RMSK)) : mask0);
         return found;
     } else {
         const unsigned long long best = wb.slot[lane];
         const bool found = best != ~0ull;
-        triTests += (uint32_t) __popc(mask0);
-        lds_cf4 *t_ = tris + 3 * ((uint32_t) best & 31u);
+        triTests += RM::popc(mask0);
+        lds_cf4 *t_ = tris + 3 * ((uint32_t) best & RMSK);
         const float4 a = ldsLoad4(t_), b = ldsLoad4(t_ + 1), c = ldsLoad4(t_ + 2);
         /* t is the key's high word (the tester's quotient, bit for bit); (u, v) follow from it as in the Wald test -- no division, no o_k / d_k selects */
         const float tt = pm_from_bits((uint32_t) (best >> 32));

@@ -49,6 +49,12 @@
 #ifndef WIDE_PROFILE
 #define WIDE_PROFILE 0
 #endif
+#ifndef WIDE_CULL
+#define WIDE_CULL 0                      /* experiment (round 5): a node group carries, in the 16 free bits of its hit word, the entry distance (rounded down to
+                                            bfloat16) of the child that is visited SECOND; when the group is popped and a hit found meanwhile lies in front of it, that child
+                                            is skipped without fetching its node.  (The entry distance of the node that pushed the group cannot cull: every hit found between
+                                            push and pop lies inside that node.)  ~30 VALU per node step with two or more inner hits, closest-hit rays only. */
+#endif
 #ifndef WIDE_WAVES
 #define WIDE_WAVES 7                     /* waves per SIMD of k_rays_w = blocks of 256 per CU.  Round 3: 74 VGPRs (flat loop, wave-uniform state in SGPRs, stack
                                             addresses rebuilt from the lane index: see persistentTraverseWide), six waves -- measured C3 / C4 at 128 spp, ray-kernel
@@ -134,7 +140,10 @@ DV float ubyte(uint32_t v, int k) { return (float) ((v >> (8 * k)) & 0xffu); }  
 
 /* One node: slab test of the eight quantised child boxes.  Returns the hit bits: 24..31 inner children in traversal order
    (highest bit = first), 0..23 the leaf triangles of the hit leaves. */
-DV uint32_t wideNodeHits(const uint4 &n0, const uint4 &n1, const uint4 &n2, const uint4 &n3, const uint4 &n4, const WideRay &r) {
+/* WIDE_CULL: *second = (priority << 16 | bfloat16(entry distance, rounded down)) of the hit inner child that is visited SECOND (0: fewer than two) -- the two
+   largest keys of the eight children, kept with a max and a median per child */
+DV uint32_t wideNodeHits(const uint4 &n0, const uint4 &n1, const uint4 &n2, const uint4 &n3, const uint4 &n4, const WideRay &r, uint32_t *second = nullptr) {
+    uint32_t key1 = 0, key2 = 0;
     /* child box plane = p + q * 2^(e-127): t = q * (2^e * rcp) + (p - o) * rcp */
     const float sx = pm_from_bits((n0.w & 0xffu) << 23) * r.rcp.x, sy = pm_from_bits(((n0.w >> 8) & 0xffu) << 23) * r.rcp.y,
                 sz = pm_from_bits(((n0.w >> 16) & 0xffu) << 23) * r.rcp.z;
@@ -174,8 +183,19 @@ DV uint32_t wideNodeHits(const uint4 &n0, const uint4 &n1, const uint4 &n2, cons
             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, r.maxt));
             const uint32_t bits = (childBits4 >> (8 * k)) & 0xffu, idx = (bitIndex4 >> (8 * k)) & 0xffu;
             hits |= (tn <= tf) ? (bits << idx) : 0u;
+#if WIDE_CULL
+            if (second) {
+                const uint32_t key = (tn <= tf && idx >= 24u) ? ((idx << 16) | (pm_to_bits(tn) >> 16)) : 0u;     /* (tn >= mint >= 0: truncation rounds down) */
+                const uint32_t lo = key1 < key ? key1 : key, hi2 = key2 > lo ? key2 : lo;
+                key2 = hi2; key1 = key1 > key ? key1 : key;
+            }
+#endif
         }
     }
+#if WIDE_CULL
+    if (second) *second = key2;
+#endif
+    (void) key1; (void) key2;
     return hits;
 }
 
@@ -217,10 +237,21 @@ __device__ __forceinline__ uint4 ldsLoadU4(lds_cu4 *p) { const u4v v = *p; retur
         const uint32_t idx_ = (ng).x + (uint32_t) __popc((ng).y & ((1u << slot_) - 1u) & 0xffu);      \
         WIDE_LOAD_NODE(stack, S, idx_, n0, n1, n2, n3, n4)                                            \
         ++nodeVisits;                                                                                 \
-        const uint32_t hits_ = wideNodeHits(n0, n1, n2, n3, n4, ray);                                 \
-        (ng) = make_uint2(n1.x, (hits_ & 0xff000000u) | (n0.w >> 24));                                \
+        uint32_t second_ = 0u;                                                                        \
+        const uint32_t hits_ = wideNodeHits(n0, n1, n2, n3, n4, ray, (WIDE_CULL && wideCullOn) ? &second_ : nullptr); \
+        (ng) = make_uint2(n1.x, (hits_ & 0xff000000u) | (n0.w >> 24) | ((second_ & 0xffffu) << 8));   \
         (tg) = make_uint2(n1.y, hits_ & 0x00ffffffu);                                                 \
     }
+#if WIDE_CULL
+/* a popped node group: skip its next child when that child's entry lies behind the closest hit so far; the bound has then served */
+#define WIDE_CULL_POP(e, ray)                                                                         \
+        {                                                                                             \
+            if (pm_from_bits(((e).y & 0x00ffff00u) << 8) > (ray).maxt) (e).y &= ~(0x80000000u >> __clz((int) (e).y)); \
+            (e).y &= 0xff0000ffu;                                                                     \
+        }
+#else
+#define WIDE_CULL_POP(e, ray)
+#endif
 
 /* the root: node 0 is entered as the only child of a virtual group (child base 0, no inner slots below it: rank 0) */
 __device__ __forceinline__ uint2 wideRootGroup() { return make_uint2(0u, 0x80000000u); }
@@ -233,6 +264,7 @@ __device__ __forceinline__ bool traverseWide(const DevScene &S, const V3 &o, con
     stack.sp = 0;
     uint2 ng = wideRootGroup(), tg = make_uint2(0u, 0u);
     bool found = false;
+    constexpr bool wideCullOn = false; (void) wideCullOn;        /* (WIDE_CULL: the persistent kernel only) */
     res.prim = PHIP_NO_HIT; res.t = INFINITY; res.u = res.v = 0;
     for (;;) {
         if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, nodeVisits)
@@ -442,7 +474,7 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                 }
             }
         } else if (idle == ~0ull) break;
-        if (active && tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps)
+        if (active && tg.y == 0u && (ng.y & 0xff000000u)) { constexpr bool wideCullOn = true; (void) wideCullOn; WIDE_NODE_STEP(stack, S, ray, ng, tg, steps) }   /* (any-hit rays carry the bound too: their interval never shrinks, so it never culls -- a lane-varying switch costs more) */
 
         /* ---- the triangle round: every lane takes part ---- */
         const uint32_t pending = active ? tg.y : 0u;
@@ -515,8 +547,8 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
             if (!finished && tg.y == 0u && !(ng.y & 0xff000000u)) {
                 if (stack.sp == 0) finished = true;
                 else {
-                    const uint2 e = stack.pop();
-                    if (e.y & 0xff000000u) ng = e; else { tg = e; ng = make_uint2(0u, 0u); }
+                    uint2 e = stack.pop();
+                    if (e.y & 0xff000000u) { WIDE_CULL_POP(e, ray) ng = e; } else { tg = e; ng = make_uint2(0u, 0u); }
                 }
             }
             if (finished) {

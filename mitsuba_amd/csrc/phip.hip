@@ -729,7 +729,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
        every leaf box in one uniform pass instead of walking the 7-node tree (k_traverse.h: traverseFlat).  Entry = (min.xyz, bits(leaf
        reference)) (max.xyz, 0), boxes as the BVH4 nodes hold them (padded). */
     D.nFlatLeaves = 0; D.flatMode = 0; sd.flatLeaves.alloc(2); D.flatLeaves = sd.flatLeaves.p;
-    if (sc->fitsLds && sc->bvh.nLeaves <= FLAT_LEAVES_MAX && !getenv("PHIP_NO_FLAT")) {
+    if (sc->fitsLds && sc->bvh.nLeaves <= FLAT2_LEAVES_MAX && !getenv("PHIP_NO_FLAT")) {
         std::vector<float4> flat;
         if (sc->bvh.rootRef < 0) {                         /* a single leaf: its box is the scene's */
             flat.push_back(make_float4(sc->bvh.tightMin[0] - 1.0f, sc->bvh.tightMin[1] - 1.0f, sc->bvh.tightMin[2] - 1.0f, pm_from_bits((uint32_t) sc->bvh.rootRef)));
@@ -743,47 +743,52 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                 flat.push_back(make_float4(nd[12 + c], nd[16 + c], nd[20 + c], 0.0f));
             }
         }
-        if (flat.size() / 2 <= FLAT_LEAVES_MAX) {
-            D.flatMode = 1;
-            /* at most 32 Wald records: the packed form with record masks (k_traverse.h: traverseFlat2).  A leaf reference is
-               ~((first record << 3) | records - 1); a triangle referenced by several leaves (spatial splits) has one record per
-               reference -- the copies carry the same 12 words, so only the first copy's bit is set */
-            const size_t nRec = sc->bvh.tris.size() / 12;
-            if (nRec <= 32 && !getenv("PHIP_NO_FLAT2")) {
-                std::vector<uint32_t> firstCopy(nRec);
-                for (size_t i = 0; i < nRec; ++i) {
-                    firstCopy[i] = (uint32_t) i;
-                    for (size_t j = 0; j < i; ++j) if (!memcmp(&sc->bvh.tris[12 * i], &sc->bvh.tris[12 * j], 48)) { firstCopy[i] = (uint32_t) j; break; }
-                }
-                std::vector<float4> packed;
-                for (size_t l = 0; l < flat.size() / 2; ++l) {
-                    const float4 mn = flat[2 * l], mx = flat[2 * l + 1];
-                    const uint32_t r = ~pm_to_bits(mn.w), first = r >> 3, count = (r & 7u) + 1u;
-                    uint32_t bits = 0;
-                    for (uint32_t i = 0; i < count; ++i) bits |= 1u << firstCopy[first + i];
-#if MEGA_FLAT_CH
-                    /* centre / half extent (k_traverse.h: flat2Pass1).  c -+ h must cover the (padded) box whatever the rounding of c, and the
-                       distances c' -+ h |rcp| are rounded differently from the plane form the pad of bvh.h was sized for (two roundings of
-                       magnitude |c rcp| + |o rcp| instead of one): h gets the rounding of c and another 4e-6 of the scene's extent on top */
-                    const float ext = std::max(sc->bvh.tightMax[0] - sc->bvh.tightMin[0], std::max(sc->bvh.tightMax[1] - sc->bvh.tightMin[1], sc->bvh.tightMax[2] - sc->bvh.tightMin[2]));
-                    float c[3], h[3];
-                    const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
-                    for (int a = 0; a < 3; ++a) {
-                        c[a] = (float) (0.5 * ((double) lo[a] + (double) hi[a]));
-                        const double need = std::max((double) c[a] - (double) lo[a], (double) hi[a] - (double) c[a]);
-                        h[a] = std::nextafter((float) need, INFINITY) + 2.4e-7f * std::fabs(c[a]) + 4e-6f * ext;
-                    }
-                    packed.push_back(make_float4(c[0], c[1], c[2], 0.0f));
-                    packed.push_back(make_float4(h[0], h[1], h[2], pm_from_bits(bits)));
-#else
-                    packed.push_back(make_float4(mn.x, mx.x, mn.y, mx.y));
-                    packed.push_back(make_float4(mn.z, mx.z, pm_from_bits(bits), 0.0f));
-#endif
-                }
-                flat.swap(packed); D.flatMode = 2;
-                /* k_mega deals the Wald tests over the wave through LDS buffers that lie over the (then unused) traversal stack (k_traverse.h: traverseFlat2W) */
-                D.stackDepth = std::max<uint32_t>(D.stackDepth, ((BLOCK / 64) * BAL_WAVE_BYTES + BLOCK * sizeof(uint32_t) - 1) / (BLOCK * sizeof(uint32_t)));
+        /* at most 32 Wald records: the packed form with record masks (k_traverse.h: traverseFlat2).  A leaf reference is
+           ~((first record << 3) | records - 1); a triangle referenced by several leaves (spatial splits) has one record per
+           reference -- the copies carry the same 12 words, so only the first copy's bit is set.
+           Round 5: 33..64 records keep the packed form with a two-word mask (flatMode 3; the centre / half-extent table of the dealt
+           traversal only -- the high word rides in the centre's spare word) */
+        const size_t nRec = sc->bvh.tris.size() / 12;
+        const size_t packedMax = (MEGA_FLAT_CH && MEGA_BALANCE && !getenv("PHIP_NO_FLAT3")) ? 64 : 32;
+        if (flat.size() / 2 <= FLAT2_LEAVES_MAX && nRec <= packedMax && !getenv("PHIP_NO_FLAT2")) {
+            std::vector<uint32_t> firstCopy(nRec);
+            for (size_t i = 0; i < nRec; ++i) {
+                firstCopy[i] = (uint32_t) i;
+                for (size_t j = 0; j < i; ++j) if (!memcmp(&sc->bvh.tris[12 * i], &sc->bvh.tris[12 * j], 48)) { firstCopy[i] = (uint32_t) j; break; }
             }
+            std::vector<float4> packed;
+            for (size_t l = 0; l < flat.size() / 2; ++l) {
+                const float4 mn = flat[2 * l], mx = flat[2 * l + 1];
+                const uint32_t r = ~pm_to_bits(mn.w), first = r >> 3, count = (r & 7u) + 1u;
+                unsigned long long bits64 = 0;
+                for (uint32_t i = 0; i < count; ++i) bits64 |= 1ull << firstCopy[first + i];
+                const uint32_t bits = (uint32_t) bits64, bitsHi = (uint32_t) (bits64 >> 32);
+#if MEGA_FLAT_CH
+                /* centre / half extent (k_traverse.h: flat2Pass1).  c -+ h must cover the (padded) box whatever the rounding of c, and the
+                   distances c' -+ h |rcp| are rounded differently from the plane form the pad of bvh.h was sized for (two roundings of
+                   magnitude |c rcp| + |o rcp| instead of one): h gets the rounding of c and another 4e-6 of the scene's extent on top */
+                const float ext = std::max(sc->bvh.tightMax[0] - sc->bvh.tightMin[0], std::max(sc->bvh.tightMax[1] - sc->bvh.tightMin[1], sc->bvh.tightMax[2] - sc->bvh.tightMin[2]));
+                float c[3], h[3];
+                const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
+                for (int a = 0; a < 3; ++a) {
+                    c[a] = (float) (0.5 * ((double) lo[a] + (double) hi[a]));
+                    const double need = std::max((double) c[a] - (double) lo[a], (double) hi[a] - (double) c[a]);
+                    h[a] = std::nextafter((float) need, INFINITY) + 2.4e-7f * std::fabs(c[a]) + 4e-6f * ext;
+                }
+                packed.push_back(make_float4(c[0], c[1], c[2], pm_from_bits(bitsHi)));
+                packed.push_back(make_float4(h[0], h[1], h[2], pm_from_bits(bits)));
+#else
+                (void) bitsHi;
+                packed.push_back(make_float4(mn.x, mx.x, mn.y, mx.y));
+                packed.push_back(make_float4(mn.z, mx.z, pm_from_bits(bits), 0.0f));
+#endif
+            }
+            flat.swap(packed); D.flatMode = nRec <= 32 ? 2 : 3;
+            /* k_mega deals the Wald tests over the wave through LDS buffers that lie over the (then unused) traversal stack (k_traverse.h: traverseFlat2W) */
+            D.stackDepth = std::max<uint32_t>(D.stackDepth, ((BLOCK / 64) * BAL_WAVE_BYTES + BLOCK * sizeof(uint32_t) - 1) / (BLOCK * sizeof(uint32_t)));
+        } else if (flat.size() / 2 <= FLAT_LEAVES_MAX)
+            D.flatMode = 1;
+        if (D.flatMode) {
             sd.flatLeaves.upload(flat.data(), flat.size());
             D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
         }
@@ -1090,6 +1095,14 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         sd.rinvKey = rinvKey;
     }
     if (const char *e = getenv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
+    /* resident blocks of the fused kernel for THIS render (the QMC build has ~15 KB more static LDS than the plan of fitsLds priced at scene
+       creation): when none fits a compute unit the render runs on the wavefront kernels, as it did before the samplers moved to k_mega */
+    int megaPerCU = 0;
+    if (fused) {
+        megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, qmc, megaLdsBytesOf(D)));
+        if (const char *e = getenv("PHIP_MEGA_BLOCKS")) megaPerCU = std::max(1, std::min(megaPerCU, atoi(e)));
+        if (megaPerCU <= 0) fused = false;
+    }
     sd.fused = fused;
 
     phip_stats st; memset(&st, 0, sizeof(st));
@@ -1198,11 +1211,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     /* fused path: resident grid and per-wave statistics rows */
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
     if (fused) {
-        const size_t megaLds = megaLdsBytesOf(D);
-        int perCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, qmc, megaLds));
-        if (const char *e = getenv("PHIP_MEGA_BLOCKS")) perCU = std::max(1, std::min(perCU, atoi(e)));
-        if (perCU <= 0) throw std::runtime_error("k_mega does not fit a compute unit");
-        megaGrid = dim3((unsigned) (nCU * perCU));
+        megaGrid = dim3((unsigned) (nCU * megaPerCU));
         M.nWaves = megaGrid.x * (BLOCK / 64);
         if (sd.stat.n < (size_t) ST_COUNT * M.nWaves) sd.stat.alloc((size_t) ST_COUNT * M.nWaves);
         M.stat = sd.stat.p; M.nextId = sd.megaNext.p;
@@ -1895,7 +1904,7 @@ int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
     out->max_depth = scene->bvh.maxDepth; out->node_bytes = 128; out->triangle_bytes = 48;
     out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
     if (scene->wide) { out->n_nodes = scene->bvh.nWNodes; out->max_depth = scene->bvh.wMaxDepth; out->node_bytes = 80; out->sah_cost = scene->bvh.wSahCost; }
-    out->fits_lds = scene->fitsLds ? 1u : 0u; out->reserved = 0;
+    out->fits_lds = scene->fitsLds ? 1u : 0u; out->fused_traversal = scene->fitsLds ? scene->devs[0]->dev.flatMode : 0u;
     return PHIP_OK;
 }
 

@@ -13,6 +13,7 @@ typedef void (*MegaKernel)(DevScene, MegaParams, RenderConst, float4 *);
    more than 256 VGPRs (measured: 256 + scratch at 2 waves per SIMD), and the scenes of that kind that fit LDS are test
    scenes, not workloads -- they keep the wavefront kernels. */
 template <bool QMC> static MegaKernel megaKernelOf(bool strictNormals, int flat) {
+    if (flat == 3) return MEGA_BALANCE ? (strictNormals ? k_mega<0, true, 3, QMC> : k_mega<0, false, 3, QMC>) : nullptr;
     if (flat == 2) return strictNormals ? k_mega<0, true, 2, QMC> : k_mega<0, false, 2, QMC>;
     if (flat) return strictNormals ? k_mega<0, true, 1, QMC> : k_mega<0, false, 1, QMC>;
     return strictNormals ? k_mega<0, true, 0, QMC> : k_mega<0, false, 0, QMC>;

@@ -302,7 +302,9 @@ def _rgb(v):
 # ==========================================================================================
 #  C1 / C2: the Cornell box (classic measured data, units of mm)
 # ==========================================================================================
-def cornell_box(width, height, filter_table, light_scale=1.0, sb=None):
+def cornell_box(width, height, filter_table, light_scale=1.0, sb=None, short_bsdf=None, tall_bsdf=None, extra_blocks=0):
+    """short_bsdf / tall_bsdf: callables sb -> material id for the two blocks (default: the white diffuse of the room);
+    extra_blocks: further small white blocks on the floor in front of the two (10 triangles each)"""
     sb = sb or SceneBuilder()
     white = sb.diffuse((0.725, 0.71, 0.68))
     red = sb.diffuse((0.63, 0.065, 0.05))
@@ -319,7 +321,7 @@ def cornell_box(width, height, filter_table, light_scale=1.0, sb=None):
     sb.quad((343.0, 548.7, 227.0), (343.0, 548.7, 332.0), (213.0, 548.7, 332.0), (213.0, 548.7, 227.0), light_bsdf,
             facing=(0, -1, 0), radiance=tuple(light_scale * c for c in (17.0, 12.0, 4.0)))
 
-    def box(top, h):
+    def box(top, h, white=white):
         """top: 4 corner (x,z) pairs of the top face, counter-clockwise seen from above"""
         top = [np.array([x, h, z], np.float32) for x, z in top]
         bot = [np.array([p[0], 0.0, p[2]], np.float32) for p in top]
@@ -331,13 +333,24 @@ def cornell_box(width, height, filter_table, light_scale=1.0, sb=None):
             mid = (top[i] + top[j] + bot[i] + bot[j]) / 4.0
             sb.quad(top[i], bot[i], bot[j], top[j], white, facing=mid - cx)
 
-    box([(130.0, 65.0), (82.0, 225.0), (240.0, 272.0), (290.0, 114.0)], 165.0)     # short box
-    box([(423.0, 247.0), (265.0, 296.0), (314.0, 456.0), (472.0, 406.0)], 330.0)   # tall box
+    box([(130.0, 65.0), (82.0, 225.0), (240.0, 272.0), (290.0, 114.0)], 165.0, short_bsdf(sb) if short_bsdf else white)     # short box
+    box([(423.0, 247.0), (265.0, 296.0), (314.0, 456.0), (472.0, 406.0)], 330.0, tall_bsdf(sb) if tall_bsdf else white)   # tall box
+    for i in range(extra_blocks):                                                    # (33..64-record scenes: VERDICT r4 item 3b)
+        x0, z0, s_, h_ = 330.0 + 70.0 * (i % 3), 40.0 + 75.0 * (i // 3), 50.0, 60.0 + 25.0 * i
+        box([(x0 + s_, z0), (x0, z0 + 0.3 * s_), (x0 + 0.3 * s_, z0 + 1.3 * s_), (x0 + 1.3 * s_, z0 + s_)], h_)
 
     sb.perspective(origin=(278.0, 273.0, -800.0), target=(278.0, 273.0, -799.0), up=(0, 1, 0),
                    fov_x_deg=39.3077, near=10.0, far=2800.0)
     sb.hdrfilm(width, height, filter_table)
     return sb
+
+
+def cornell_mixed(width, height, filter_table, light_scale=1.0, sb=None):
+    """The Cornell box of C2 with one block of rough copper (two-sided, Beckmann alpha 0.1) and one of glass (bk7): the same 32
+    triangles, all three leaf BSDF models of the path -- the small scene that is NOT the benchmark."""
+    return cornell_box(width, height, filter_table, light_scale, sb,
+                       short_bsdf=lambda b: b.twosided(b.roughconductor(CU_ETA, CU_K, alpha=0.1)),
+                       tall_bsdf=lambda b: b.dielectric())
 
 
 # ==========================================================================================

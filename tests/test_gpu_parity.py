@@ -693,16 +693,16 @@ def test_direct_with_the_qmc_samplers_matches_oracle(gpu, phip, oracle, gauss):
     gs.close()
 
 
-def _sheets_scene(gauss, w=96, h=96):
+def _sheets_scene(gauss, w=96, h=96, n=15):
     """15 diffuse sheets one behind the other (30 triangles, staggered so that camera rays end on different ones) and a two-triangle light in front of
     them: a tree of at most 32 Wald records in at most 32 leaves, i.e. the fused kernel's flat table -- and EVERY ray enters (nearly) every leaf box."""
     sb = S.SceneBuilder()
     rng = np.random.default_rng(3)
-    for i in range(15):
+    for i in range(n):
         m = sb.diffuse(tuple(rng.uniform(0.3, 0.8, 3)))
-        s = 100.0 - 5.0 * i
+        s = 100.0 - 75.0 * i / n
         ox, oy = 14.0 * (i % 4) - 20.0, 9.0 * (i % 3) - 9.0
-        z = 10.0 * i
+        z = 150.0 * i / n
         sb.quad((ox - s, oy - s, z), (ox + s, oy - s, z), (ox + s, oy + s, z), (ox - s, oy + s, z), m, facing=(0, 0, -1))
     black = sb.diffuse((0, 0, 0))
     sb.quad((-60, 130, -150), (60, 130, -150), (60, 170, -120), (-60, 170, -120), black, facing=(0, -1, 1), radiance=(30.0, 25.0, 20.0))
@@ -728,6 +728,42 @@ def test_fused_kernel_work_list_overflow_matches_oracle(gpu, oracle, gauss):
     # (5 tests per ray on average -- 330 pairs per wave; the camera rays of a wave, which all enter every box from the front, bring ~1900)
     assert st.fused and st.closest_triangle_tests >= 4 * st.closest_rays, (st.fused, st.closest_triangle_tests, st.closest_rays)
     gs.close()
+
+
+@pytest.mark.parametrize("extra", [1, 3])
+def test_cornell_with_33_to_64_records_keeps_the_dealt_traversal(gpu, oracle, gauss, extra):
+    """Round 5: a Cornell box with a third (.. fifth) block has 42 (.. 62) Wald records; trees of up to 64 records keep the fused kernel's
+    packed leaf table with record masks -- two words -- and the Wald tests dealt over the wave (k_traverse.h: traverseFlat2W<.., R64>; phip_accel_info.fused_traversal == 3).
+    Per-sample identity with the oracle, and (compare_render) fused == wavefront."""
+    from mitsuba_amd.integrator import Scene
+    desc = S.cornell_box(96, 96, gauss, extra_blocks=extra).desc()
+    assert 32 < desc.n_triangles <= 64
+    gs = Scene(desc); info = gs.accel_info().as_dict(); gs.close()
+    assert info["fits_lds"] == 1 and info["fused_traversal"] == 3, info
+    for cfg in (dict(maxDepth=-1), dict(maxDepth=5, strictNormals=True)):
+        same, r = compare_render(gpu, oracle, desc, 8, min_identical=1.0, **cfg)
+        assert same == 1.0
+
+
+def test_fused_kernel_64_record_work_list_overflow_matches_oracle(gpu, oracle, gauss):
+    """the overflow scene of the test above with 64 sheets: every record bit of BOTH mask words set for the camera rays, ~3800 pairs per wave"""
+    sb = _sheets_scene(gauss, n=31)
+    desc = sb.desc()
+    assert desc.n_triangles == 64
+    from mitsuba_amd.integrator import Scene
+    gs = Scene(desc); info = gs.accel_info().as_dict(); gs.close()
+    assert info["fused_traversal"] == 3, info
+    same, r = compare_render(gpu, oracle, desc, 8, min_identical=1.0, maxDepth=6)
+    assert same == 1.0
+
+
+def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
+    """bench.py's `cornell_mixed_*` workload: the Cornell box with a rough-copper and a glass block -- 32 triangles, all three leaf BSDF
+    models; the wavefront kernels with the material heads of the shading records (dielectric: head, copper: material table)"""
+    desc = S.cornell_mixed(128, 128, gauss).desc()
+    for cfg in (dict(maxDepth=-1), dict(maxDepth=8, strictNormals=True)):
+        same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, **cfg)
+        print("cornell_mixed %s: identical %.6f rel L2 %.3e" % (cfg, same, r))
 
 
 def test_ray_kernel_work_list_overflow_matches_oracle(gpu, oracle, gauss):

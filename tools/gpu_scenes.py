@@ -7,11 +7,14 @@ from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
 
 ft = _ffi.gaussian_filter()
 cfgs = {"cornell": ("cornell_box", 1024, 1024, 64, -1), "atrium": ("atrium", 1920, 1080, 16, 8), "glass": ("glass_room", 1920, 1080, 32, 16),
-        "atrium4k": ("atrium", 3840, 2160, 16, 8)}
+        "atrium4k": ("atrium", 3840, 2160, 16, 8),
+        "cmixed": ("cornell_mixed", 1024, 1024, 64, -1),                       # the Cornell box with a copper and a glass block (wavefront kernels)
+        "c42": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 1}),       # 42 / 62 Wald records: the two-word record masks of the fused kernel
+        "c62": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 3})}
 for key in sys.argv[1:] or cfgs:
-    name, w, h, spp, md = cfgs[key]
+    name, w, h, spp, md = cfgs[key][:5]
     spp = int(os.environ.get("SPP", spp))
-    sb = getattr(S, name)(w, h, ft)
+    sb = getattr(S, name)(w, h, ft, **(cfgs[key][5] if len(cfgs[key]) > 5 else {}))
     t = time.time(); sc = Scene(sb.desc()); tb = time.time() - t
     integ = PathHIP(maxDepth=md); film = HDRFilm(w, h)
     if not os.environ.get("NOWARM"):
