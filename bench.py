@@ -217,6 +217,9 @@ def dominant_kernel(r):
         leaves = r["accel"]["n_leaves"]
         tree = ("the tree's %d leaves as a flat table of boxes (one uniform pass), " % leaves) if leaves <= 32 else ("BVH4 (%d nodes), " % nodes)
         return "k_mega", "whole path in one persistent kernel: " + tree + "Wald + shading records, emitters, materials in LDS", a["fused_kernel_ms"], max(int(a["iterations"]), 1)
+    if a.get("vertex_traced"):
+        return ("k_shade_trace", "one path vertex + its shadow ray + the next ray per slot and launch; the tree's %d leaves as a packed table of boxes, Wald records, "
+                "emitters, materials in LDS, path state streamed through HBM once per vertex" % r["accel"]["n_leaves"], a["shade_kernel_ms"], max(int(a["iterations"]), 1))
     merged = a["shadow_kernel_ms"] == 0 and a["shadow_rays"] > 0        # closest-hit + any-hit rays in one persistent launch (big trees)
     wide = r["accel"]["node_bytes"] == 80                                # ... over the compressed 8-wide BVH
     rays = "k_rays_w" if wide else "k_rays_p"
@@ -291,7 +294,7 @@ def roofline(r):
         per_node = VMEM_LOADS_PER_NODE.get(r["accel"]["node_bytes"], 7)
         loads = per_node * (a["closest_node_visits"] + a["shadow_node_visits"]) + VMEM_LOADS_PER_TRI * (a["closest_triangle_tests"] + a["shadow_triangle_tests"]) \
             + VMEM_LOADS_PER_RAY * (a["closest_rays"] + a["shadow_rays"])
-    elif name == "k_mega":
+    elif name in ("k_mega", "k_shade_trace"):
         loads = 0.0                  # nodes, records, tables and stack live in LDS; one 16-byte store per sample
     else:
         loads = None

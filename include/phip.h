@@ -318,7 +318,8 @@ typedef struct phip_stats {
     uint64_t shadow_triangle_tests;
     uint64_t invalid_samples;        /* rejected by the ImageBlock::put validity check        */
     uint32_t iterations;             /* wavefront iterations = launches of each kernel        */
-    uint32_t reserved;
+    uint32_t vertex_traced;          /* 1: the iterations ran k_shade_trace -- vertex, shadow ray and next ray of a slot in ONE kernel per iteration (small scenes
+                                        that are not k_mega's: <= 64 Wald records, any material); trace / shadow ms are then 0.  (`reserved`, always 0, before round 5) */
     double   render_ms;              /* host wall clock of the call                           */
     double   trace_kernel_ms;        /* sum of HIP-event durations of the closest-hit kernel  */
     double   shadow_kernel_ms;       /* ... of the any-hit kernel                             */

@@ -121,7 +121,7 @@ class phip_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("path_vertices", C.c_uint64), ("closest_node_visits", C.c_uint64), ("closest_triangle_tests", C.c_uint64),
                 ("shadow_node_visits", C.c_uint64), ("shadow_triangle_tests", C.c_uint64),
-                ("invalid_samples", C.c_uint64), ("iterations", C.c_uint32), ("reserved", C.c_uint32),
+                ("invalid_samples", C.c_uint64), ("iterations", C.c_uint32), ("vertex_traced", C.c_uint32),
                 ("render_ms", C.c_double), ("trace_kernel_ms", C.c_double), ("shadow_kernel_ms", C.c_double),
                 ("shade_kernel_ms", C.c_double), ("film_kernel_ms", C.c_double),
                 ("algorithmic_bytes", C.c_double), ("trace_kernel_bytes", C.c_double),

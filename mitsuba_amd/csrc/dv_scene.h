@@ -92,8 +92,7 @@ struct DevScene {
     const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;
     const float4 *texTexels; const DevMipLevels *textures;   /* bitmap textures: all pyramids in one texel array + one descriptor each */
-    uint32_t triShadeStride;             /* float4s per shading record: 6 (+ 2 with material heads) (+ 3 when a mesh has texture coordinates) */
-    uint32_t triShadeHead, triShadeUv;   /* index of the two-float4 material head inside a record (0: the records have none) / of the three float4s of texture coordinates */
+    uint32_t triShadeStride;             /* float4s per shading record: 6, or 9 when a mesh has texture coordinates */
     int32_t envEmitter; float envCenter[3]; float envRadius;   /* environment emitter (or -1) and its m_sceneBSphere */
     DevEnvMap env;
     int32_t rootRef; uint32_t nTriangles;
@@ -113,17 +112,11 @@ struct DevScene {
  *   vertex normals: r3 = (n0, flags)           r4 = (n1, -)       r5 = (n2, -)
  * frontLeaf/backLeaf = the one-sided model seen from either side (the twosided adapter's nested ids, or
  * the material itself twice). */
-enum { TS_VERTEX_NORMALS = 1, TS_TWOSIDED = 2, TS_MF_SMOOTH = 4, TS_TRANS_OR_BACK = 8, TS_TEXCOORDS = 16,
-       TS_HEAD_SPLIT = 32, TS_HEAD_FULL = 64 };
+enum { TS_VERTEX_NORMALS = 1, TS_TWOSIDED = 2, TS_MF_SMOOTH = 4, TS_TRANS_OR_BACK = 8, TS_TEXCOORDS = 16 };
 #define TRISHADE_FLOAT4S 6
-/* Material heads (round 5; scenes that do not run the fused kernel): k_shade's vertex was three DEPENDENT memory round trips -- slot state ->
-   shading record -> material -- in a kernel that waits on memory two thirds of its time.  The record now carries, behind r5, what the
-   vertex needs of its leaf BSDF when that is little, so that record and material arrive together (two round trips):
-     TS_HEAD_FULL   front == back leaf, an untextured diffuse or dielectric: h0 = (reflectance, bits(type))  h1 = (transmittance, eta)
-     TS_HEAD_SPLIT  two different untextured diffuse leaves (twosided):     h0 = (front reflectance, bits(type))  h1 = (back ..., bits(type))
-   neither flag: rough conductors (eleven more parameters) and textured leaves read the material table as before -- on the atrium 8 % of
-   the vertices, which the lane deal of k_shade has gathered into waves of their own.  With the heads a record is 128 B: one cache line. */
-#define TRISHADE_FLOAT4S_HEAD 2
+/* (Round 5 measured "material heads": two more float4s per record carrying the leaf BSDF's parameters, so that record and material arrive in ONE round
+   trip instead of two.  k_shade got SLOWER -- atrium 63.5 -> 66.4 ms per frame, glass room 119.6 -> 129.7, profiles/r05_gpu_call_a_*: the kernel is bound
+   by the number of vector-memory instructions and lines it moves (texture-data path 83 % busy), not by the length of its dependency chain; removed.) */
 /* meshes with texture coordinates append three float4s: r6 = (uv0, uv1), r7 = (uv2, dpdu.xy), r8 = (dpdu.z, dpdv) with
    dpdu / dpdv = TriMesh::computeUVTangents (trimesh.cpp:683-735; they replace side1 / side2 in the shading frame,
    skdtree.h:373-380) */
@@ -132,7 +125,6 @@ enum { TS_VERTEX_NORMALS = 1, TS_TWOSIDED = 2, TS_MF_SMOOTH = 4, TS_TRANS_OR_BAC
 struct Isect {
     V3 p; Frame sh; V3 geoN; V3 wi; float t; uint32_t prim;
     uint32_t front, back, flags; int32_t emitter;
-    float4 head0, head1;                /* material head of the side the ray arrived on (TS_HEAD_*): (reflectance, bits(type)) (transmittance, eta) */
     V2 uv; V3 dpdu, dpdv;               /* filled for triangles with texture coordinates (TS_TEXCOORDS) */
 };
 
@@ -155,13 +147,9 @@ DV void triShadingFrame(const V3 &shN, const V3 &side1, Frame &f) {
 }
 
 /* skdtree.h:343-428 with BarycentricPos = true, no UV tangents, no texcoords */
-/* HEADS: the kernel reads the material heads of the records (the wavefront kernels; k_mega's scenes have none: compiled out) */
-template <bool HEADS = false>
 DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float cu, float cv, float t, Isect &its) {
     const float4 *r = S.triShade + (size_t) S.triShadeStride * prim;
     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
-    float4 h0 = make_float4(0, 0, 0, 0), h1 = h0;
-    if (HEADS && S.triShadeHead) { h0 = r[S.triShadeHead]; h1 = r[S.triShadeHead + 1]; }     /* (scene-uniform: requested with the six above) */
     const V3 b(1 - cu - cv, cu, cv);
     const V3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
     its.p = p0 * b.x + p1 * b.y + p2 * b.z;
@@ -169,7 +157,7 @@ DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float
     its.flags = pm_to_bits(r3.w);
     V3 dpdu = p1 - p0;                                   /* side1, skdtree.h:378-379 */
     if (its.flags & TS_TEXCOORDS) {                      /* vertexTangents + texture coordinates, skdtree.h:373-377,397-404 */
-        const float4 r6 = r[S.triShadeUv], r7 = r[S.triShadeUv + 1], r8 = r[S.triShadeUv + 2];
+        const float4 r6 = r[6], r7 = r[7], r8 = r[8];
         its.uv = V2(r6.x * b.x + r6.z * b.y + r7.x * b.z, r6.y * b.x + r6.w * b.y + r7.y * b.z);
         its.dpdu = V3(r7.z, r7.w, r8.x); its.dpdv = V3(r8.y, r8.z, r8.w);
         dpdu = its.dpdu;
@@ -188,11 +176,6 @@ DV void fillIntersection(const DevScene &S, const V3 &rayD, uint32_t prim, float
     }
     its.wi = its.sh.toLocal(-rayD);
     its.t = t; its.prim = prim;
-    /* the head of the side the ray arrived on (the twosided adapter's choice, bsdfResolve below) */
-    if (HEADS) {
-        const bool flipSplit = (its.flags & TS_HEAD_SPLIT) && cosTheta(its.wi) < 0;
-        its.head0 = flipSplit ? h1 : h0; its.head1 = h1;
-    }
 }
 
 /* Intersection::computePartials, intersection.cpp:5-76 (rxOrigin = ryOrigin = rayO: pinhole camera) */
@@ -928,8 +911,7 @@ template <int MM> DV V3 leafSample(uint32_t type, float eta0, const DevMaterial 
    cosTheta(wi) > 0 and sample for cosTheta(wi) >= 0; at exactly 0 every wrapped model's eval/pdf is zero
    on either side, so one rule serves all three.) */
 struct BsdfCtx { const DevMaterial *leaf; V3 wi; bool flip;
-                 uint32_t type; float eta0;     /* the leaf's model and (dielectric) its relative index of refraction, by VALUE: they come from the shading record's
-                                                   material head when it has one -- the table is then not read at all (rough conductors read the rest through `leaf`) */
+                 uint32_t type; float eta0;     /* the leaf's model and (dielectric) its relative index of refraction, by value (a diffuse-only build never fetches `type`: leafEvalPdf) */
                  bool textured;
                  LeafVarying v; /* reflectance (diffuse) / specularReflectance (dielectric, roughconductor), roughness, specularTransmittance at this vertex:
                                    the constants, or the texture values k_shade puts here */
@@ -946,17 +928,12 @@ DV BsdfCtx bsdfResolve(const DevScene &S, const DevMaterial &M, const V3 &wi) {
     return c;
 }
 /* same, from a shading record (front/back already are the nested models) */
-template <bool HEADS = false>
 DV BsdfCtx bsdfResolve(const DevMaterial *materials, const Isect &its) {
     BsdfCtx c; c.wi = its.wi;
     c.flip = (its.flags & TS_TWOSIDED) && cosTheta(its.wi) < 0;
     c.leaf = materials + (c.flip ? its.back : its.front);
     if (c.flip) c.wi.z = -its.wi.z;
-    if (HEADS && (its.flags & (TS_HEAD_SPLIT | TS_HEAD_FULL))) {       /* an untextured diffuse / dielectric leaf: everything arrived with the shading record */
-        c.type = pm_to_bits(its.head0.w); c.eta0 = its.head1.w; c.textured = false;
-        c.v.albedo = xyz(its.head0); c.v.trans = xyz(its.head1); c.v.alphaU = c.v.alphaV = 0.0f;
-    } else
-        c.constants();
+    c.constants();
     return c;
 }
 /* The textured parameters of the vertex's leaf model: texture->eval(its) of every `bitmap` child (reflectance / specularReflectance,

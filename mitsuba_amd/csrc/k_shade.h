@@ -28,7 +28,8 @@ template <bool QMC = false>
 __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool &P, const RenderConst &rc, uint32_t *waveCnt,
                                               const uint32_t slot, const bool inRange, uint4 info, const bool alive, bool needNew,
                                               const bool pushShadow, const float4 sh0, const float4 sh1, const float4 sh2,
-                                              const unsigned long long vertices, const unsigned long long done) {
+                                              const unsigned long long vertices, const unsigned long long done,
+                                              float4 *outRo = nullptr, float4 *outRd = nullptr, bool *outAlive = nullptr /* k_shade_trace: the camera ray a regenerated slot starts with, and whether the slot has a ray to trace */) {
     /* ---- shadow queue: compact this block's entries to the front of its own region (no global atomics) ---- */
     uint32_t shadowTotal = 0;
     {
@@ -122,6 +123,7 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         if (S.preclip) preclipRay(S, ro, rd);
         P.rayO[slot] = ro;
         P.rayD[slot] = rd;
+        if (outRo) { *outRo = ro; *outRd = rd; }
         P.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         P.mis[slot] = make_float2(0.0f, 0.0f);
         info = make_uint4((uint32_t) newId, pixel, k, 1u | F_ALIVE | F_EMITTED | F_FIRST | (dynamicId ? F_DYNAMIC : 0u));
@@ -129,6 +131,7 @@ __device__ __forceinline__ void shadeEpilogue(const DevScene &S, const PathPool 
         P.state[slot] = info.w;
         nowAlive = true;
     }
+    if (outAlive) *outAlive = nowAlive;
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;      /* the wave's position in the grid (NOT slot >> 6: k_shade may have permuted the block's slots) */
     /* a slot still waiting for a dynamic sample id counts as live for the termination test */
     const bool live = nowAlive || (inRange && info.w == F_DYNAMIC);
@@ -184,13 +187,13 @@ struct LRegister {
    next ray; v.state is updated whenever the path goes on.  A shadow-queue entry is returned in sh when pushShadow.
    FEAT: bit 0 = the scene has an environment emitter (constant / envmap), bit 1 = it has bitmap textures, bit 2 (k_shade only) = the
    emitter table and the materials are known to fit LDS (the kernel then reads them with ds_read instead of flat loads), bit 4 (k_shade only) =
-   the emitter table fits LDS, the materials stay in memory; bit 5 = the shading records may carry material heads (dv_scene.h; every wavefront kernel); MM: leaf BSDF models
+   the emitter table fits LDS, the materials stay in memory; MM: leaf BSDF models
    present in the scene; STRICT: strictNormals (a compile-time switch: without it the geometric normal is dead after
    fillIntersection and the diffuse-only instantiation fits 80 VGPRs = 6 waves per SIMD) */
 template <int MM, bool STRICT, int FEAT, typename LAcc>
 __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab &T, const DevMaterial *materials, const RenderConst &rc,
                                             PathVertex &v, const LAcc &acc, bool &newRay, bool &pushShadow, ShadowEntry &sh, uint32_t &vertices) {
-    constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0, QMC = (FEAT & 8) != 0, HEADS = (FEAT & 32) != 0;
+    constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0, QMC = (FEAT & 8) != 0;
     const uint32_t prim = pm_to_bits(v.hit.w);
     const V3 rayD(v.rayD.x, v.rayD.y, v.rayD.z);
     V3 thr(v.thr.x, v.thr.y, v.thr.z);
@@ -240,7 +243,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
         if (haveAdd) acc.store(id, l);
     } else {
         Isect its;
-        fillIntersection<HEADS>(S, rayD, prim, v.hit.y, v.hit.z, v.hit.x, its);
+        fillIntersection(S, rayD, prim, v.hit.y, v.hit.z, v.hit.x, its);
         /* the accumulator is zero until the sample's first vertex writes it, and later vertices only touch it when they
            hit an emitter: no unconditional 64-byte-sector read per vertex (LGlobal) */
         if (flags & F_FIRST) {
@@ -365,7 +368,7 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             dRec.ref = its.p;
             dRec.refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;
             dRec.pdf = 0; dRec.emitter = -1;
-            BsdfCtx bctx = bsdfResolve<HEADS>(materials, its);
+            BsdfCtx bctx = bsdfResolve(materials, its);
             if (TEX && bctx.textured) {
                 /* texture->eval(its) of the BSDF's bitmap children: unfiltered level-0 lookup, except at the first vertex, whose UV partials come
                    from the camera-ray differentials (Intersection::getBSDF(ray) -> computePartials, records.inl:69-75) */
@@ -547,7 +550,7 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
         v.id = info.x; v.pixel = info.y; v.k = info.z; v.state = info.w;
         bool newRay; uint32_t nv = 0;
         const LGlobal acc{ L, P, slot };
-        if (shadeVertex<MM, STRICT, FEAT | 32>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv)) {
+        if (shadeVertex<MM, STRICT, FEAT>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv)) {
             vertices = nv; done = 1;
             needNew = true;
         } else {

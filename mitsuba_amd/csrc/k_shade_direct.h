@@ -82,7 +82,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             }
         } else {
             Isect its;
-            fillIntersection<true>(S, camD, prim, camHit.y, camHit.z, camHit.x, its);
+            fillIntersection(S, camD, prim, camHit.y, camHit.z, camHit.x, its);
             if (first) {
                 P.camHit[slot] = camHit;
                 l.w = 1.0f;                                      /* alpha, records.inl:117-144 */
@@ -99,7 +99,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             V3 shD(0.0f), shC(0.0f); float shMaxt = 0;
             if (!terminate) {
                 const V3 refN = (its.flags & TS_TRANS_OR_BACK) ? V3(0.0f) : its.sh.n;     /* DirectSamplingRecord(its), records.inl:146-153 */
-                BsdfCtx bctx = bsdfResolve<true>(materials, its);
+                BsdfCtx bctx = bsdfResolve(materials, its);
                 if (TEX && bctx.textured) {
                     /* its.getBSDF(ray): every query at the camera vertex sees the UV partials of the camera-ray differentials */
                     float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;

@@ -212,6 +212,7 @@ struct phip_scene {
     bool hasTextures = false; uint32_t triShadeStride = TRISHADE_FLOAT4S;
     int envLevelCount = 0;           /* MIP levels of the envmap (0: no envmap) */
     int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
+    bool flatTrace = false;          /* not a scene of k_mega, but its tree is the packed leaf table (<= 64 Wald records) and emitter table + materials fit LDS: k_shade_trace */
     bool wide = false;               /* the ray kernels walk the compressed 8-wide BVH (trees of >= 64 BVH4 nodes; PHIP_WIDE=0 keeps the BVH4) */
     bool fitsLds = false;            /* tree, Wald records, shading records, emitter table and materials fit the fused kernel's LDS plan */
     std::vector<std::unique_ptr<SceneDev>> devs;
@@ -428,14 +429,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
        functions the kernel would run, so precomputing them does not change a single bit */
     bool anyTexcoords = false;
     for (uint32_t i = 0; i < d.n_shapes; ++i) anyTexcoords |= d.shapes[i].has_texcoords != 0;
-    /* material heads behind r5 (dv_scene.h): every scene except the candidates of the fused kernel, which stages 96-byte records in LDS and reads
-       its materials from LDS anyway */
-    bool nonDiffuse = false;
-    for (const DevMaterial &m : mats) nonDiffuse |= m.type == PHIP_BSDF_ROUGHCONDUCTOR || m.type == PHIP_BSDF_DIELECTRIC;
-    const bool fusedCandidate = !nonDiffuse && d.n_textures == 0 && envEmitter < 0 && !anyTexcoords && d.n_triangles <= MEGA_TRISHADE_MAX;
-    const bool heads = !fusedCandidate && !getenv("PHIP_NO_HEADS");
-    const uint32_t headAt = heads ? (uint32_t) TRISHADE_FLOAT4S : 0u, uvAt = TRISHADE_FLOAT4S + (heads ? TRISHADE_FLOAT4S_HEAD : 0);
-    const uint32_t stride = uvAt + (anyTexcoords ? 3u : 0u);
+    const uint32_t stride = anyTexcoords ? TRISHADE_FLOAT4S_UV : TRISHADE_FLOAT4S;
     std::vector<float4> ts((size_t) stride * d.n_triangles, make_float4(0, 0, 0, 0));
     for (uint32_t i = 0; i < d.n_triangles; ++i) {
         const DevShape &sh = shapes[triShape[i]];
@@ -468,9 +462,9 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                     dpdv = (side1 * (-dUV2.x) + side2 * dUV1.x) * invDet;
                 }
             }
-            r[uvAt] = make_float4(t0[0], t0[1], t1[0], t1[1]);
-            r[uvAt + 1] = make_float4(t2[0], t2[1], dpdu.x, dpdu.y);
-            r[uvAt + 2] = make_float4(dpdu.z, dpdv.x, dpdv.y, dpdv.z);
+            r[6] = make_float4(t0[0], t0[1], t1[0], t1[1]);
+            r[7] = make_float4(t2[0], t2[1], dpdu.x, dpdu.y);
+            r[8] = make_float4(dpdu.z, dpdv.x, dpdv.y, dpdv.z);
         }
         V3 a, b, c;
         if (sh.hasNormals) {
@@ -480,20 +474,6 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         } else {
             Frame f; triShadingFrame(triFaceNormal(side1, side2), dpdu, f);
             a = f.n; b = f.s; c = f.t;
-        }
-        if (heads) {
-            const DevMaterial &F = mats[front], &B = mats[back];
-            auto plainDiffuse = [](const DevMaterial &l) { return l.type == PHIP_BSDF_DIFFUSE && l.reflTexture == 0; };
-            auto plainDielectric = [](const DevMaterial &l) { return l.type == PHIP_BSDF_DIELECTRIC && l.reflTexture == 0 && l.transTexture == 0; };
-            if (front == back && (plainDiffuse(F) || plainDielectric(F))) {
-                flags |= TS_HEAD_FULL;
-                r[headAt] = make_float4(F.refl[0], F.refl[1], F.refl[2], pm_from_bits(F.type));
-                r[headAt + 1] = make_float4(F.trans[0], F.trans[1], F.trans[2], F.eta[0]);
-            } else if (front != back && plainDiffuse(F) && plainDiffuse(B)) {
-                flags |= TS_HEAD_SPLIT;
-                r[headAt] = make_float4(F.refl[0], F.refl[1], F.refl[2], pm_from_bits(F.type));
-                r[headAt + 1] = make_float4(B.refl[0], B.refl[1], B.refl[2], pm_from_bits(B.type));
-            }
         }
         r[0] = make_float4(p0.x, p0.y, p0.z, pm_from_bits(front));
         r[1] = make_float4(p1.x, p1.y, p1.z, pm_from_bits(back));
@@ -520,7 +500,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                 memcpy(&(*recs)[r + 11], &c, 4);
             }
     }
-    if (ts.empty()) sd.triShade.alloc(TRISHADE_FLOAT4S_UV + TRISHADE_FLOAT4S_HEAD); else sd.triShade.upload(ts.data(), ts.size());
+    if (ts.empty()) sd.triShade.alloc(TRISHADE_FLOAT4S_UV); else sd.triShade.upload(ts.data(), ts.size());
     if (texTexels.empty()) sd.texTexels.alloc(1); else sd.texTexels.upload(texTexels.data(), texTexels.size());
     if (texDesc.empty()) sd.texDesc.alloc(1); else sd.texDesc.upload(texDesc.data(), texDesc.size());
     sc->hasTextures = d.n_textures > 0; sc->triShadeStride = stride;
@@ -596,7 +576,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     memset(&D, 0, sizeof(D));
     D.nodes = sd.nodes.p; D.tris = sd.tris.p; D.triShade = sd.triShade.p;
     D.materials = sd.materials.p; D.nMaterials = (uint32_t) mats.size();
-    D.texTexels = sd.texTexels.p; D.textures = sd.texDesc.p; D.triShadeStride = sc->triShadeStride; D.triShadeHead = headAt; D.triShadeUv = uvAt;
+    D.texTexels = sd.texTexels.p; D.textures = sd.texDesc.p; D.triShadeStride = sc->triShadeStride;
     D.emitterTab = sd.emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
     D.nEmitters = d.n_emitters; D.emitterNormalization = emNorm;
     D.envEmitter = envEmitter;
@@ -721,15 +701,17 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     sc->descCopy.shapes = nullptr; sc->descCopy.materials = nullptr; sc->descCopy.emitters = nullptr;
     /* the fused kernel's LDS plan (k_mega.h): the whole tree, every Wald and shading record, the emitter table and the
        materials in LDS, a stack that cannot spill; diffuse materials only (phip_mega.hip) */
+    /* (treeInLds: the whole tree and every Wald record are staged in LDS and the stack cannot spill -- also true of small scenes with glass, copper,
+       textures or an environment emitter, which k_shade_trace serves on the same packed leaf table: k_shade_trace.h) */
+    const bool treeInLds = D.nodeCache == sc->bvh.nNodes && D.triCache == sc->bvh.tris.size() / 12 && 3 * ((int) sc->bvh.maxDepth - 1) + 1 <= (int) D.stackDepth;
     sc->fitsLds = sc->materialMask == 0 && !sc->hasTextures && envEmitter < 0 && stride == TRISHADE_FLOAT4S
-        && D.nodeCache == sc->bvh.nNodes && D.triCache == sc->bvh.tris.size() / 12 && d.n_triangles <= MEGA_TRISHADE_MAX
-        && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX
-        && 3 * ((int) sc->bvh.maxDepth - 1) + 1 <= (int) D.stackDepth;
+        && treeInLds && d.n_triangles <= MEGA_TRISHADE_MAX
+        && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX;
     /* ... and, for trees of at most FLAT_LEAVES_MAX leaves (the Cornell box: 17), the leaves as a flat table: the fused kernel tests
        every leaf box in one uniform pass instead of walking the 7-node tree (k_traverse.h: traverseFlat).  Entry = (min.xyz, bits(leaf
        reference)) (max.xyz, 0), boxes as the BVH4 nodes hold them (padded). */
     D.nFlatLeaves = 0; D.flatMode = 0; sd.flatLeaves.alloc(2); D.flatLeaves = sd.flatLeaves.p;
-    if (sc->fitsLds && sc->bvh.nLeaves <= FLAT2_LEAVES_MAX && !getenv("PHIP_NO_FLAT")) {
+    if (treeInLds && !sc->wide && sc->bvh.nLeaves <= FLAT2_LEAVES_MAX && !getenv("PHIP_NO_FLAT")) {
         std::vector<float4> flat;
         if (sc->bvh.rootRef < 0) {                         /* a single leaf: its box is the scene's */
             flat.push_back(make_float4(sc->bvh.tightMin[0] - 1.0f, sc->bvh.tightMin[1] - 1.0f, sc->bvh.tightMin[2] - 1.0f, pm_from_bits((uint32_t) sc->bvh.rootRef)));
@@ -786,13 +768,14 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
             flat.swap(packed); D.flatMode = nRec <= 32 ? 2 : 3;
             /* k_mega deals the Wald tests over the wave through LDS buffers that lie over the (then unused) traversal stack (k_traverse.h: traverseFlat2W) */
             D.stackDepth = std::max<uint32_t>(D.stackDepth, ((BLOCK / 64) * BAL_WAVE_BYTES + BLOCK * sizeof(uint32_t) - 1) / (BLOCK * sizeof(uint32_t)));
-        } else if (flat.size() / 2 <= FLAT_LEAVES_MAX)
+        } else if (sc->fitsLds && flat.size() / 2 <= FLAT_LEAVES_MAX)
             D.flatMode = 1;
         if (D.flatMode) {
             sd.flatLeaves.upload(flat.data(), flat.size());
             D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
         }
     }
+    sc->flatTrace = !sc->fitsLds && D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !getenv("PHIP_NO_SHADE_TRACE");
     sd.counters.alloc(1);
     sd.invalid.alloc(1);
     sd.dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
@@ -868,6 +851,17 @@ static void phipLaunchShade(int feat, bool strictNormals, int materialMask, dim3
         case 8: phipLaunchShadeF8(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         case 11: phipLaunchShadeF11(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
         default: phipLaunchShadeF3(strictNormals, materialMask, grid, stream, S, P, rc, L); break;
+    }
+}
+static void phipLaunchShadeTrace(int feat, bool strictNormals, int materialMask, dim3 grid, size_t lds, hipStream_t stream,
+                                 const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
+    switch (feat & 11) {
+        case 0: phipLaunchShadeTraceF0(strictNormals, materialMask, grid, lds, stream, S, P, rc, L); break;
+        case 1: phipLaunchShadeTraceF1(strictNormals, materialMask, grid, lds, stream, S, P, rc, L); break;
+        case 2: phipLaunchShadeTraceF2(strictNormals, materialMask, grid, lds, stream, S, P, rc, L); break;
+        case 8: phipLaunchShadeTraceF8(strictNormals, materialMask, grid, lds, stream, S, P, rc, L); break;
+        case 11: phipLaunchShadeTraceF11(strictNormals, materialMask, grid, lds, stream, S, P, rc, L); break;
+        default: phipLaunchShadeTraceF3(strictNormals, materialMask, grid, lds, stream, S, P, rc, L); break;
     }
 }
 static void phipLaunchShadeDirect(int feat, int materialMask, dim3 grid, hipStream_t stream,
@@ -1327,15 +1321,20 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             bool drainingSeen = false;                          /* a termination test has counted fewer live slots than the pool holds: blocks may have retired */
             /* environment emitter, bitmap textures; 8: the QMC samplers (two builds: the plain one, and one with both other features) */
             const int feat0 = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0), feat = qmc ? (feat0 ? 11 : 8) : feat0;
+            const bool shadeTrace = sc->flatTrace && !direct && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
+            const size_t shadeTraceLds = (size_t) (BLOCK / 64) * BAL_WAVE_BYTES + (size_t) D.nFlatLeaves * 2 * sizeof(float4) + (size_t) D.triCache * 3 * sizeof(float4);
             while (!done) {
                 const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
                 rc.countAlive = check ? 1 : 0;
                 rc.draining = drainingSeen ? 1u : 0u;
                 if (timing) evShade.record(stream);
                 if (direct) phipLaunchShadeDirect(feat, sc->materialMask, grid, stream, D, P, rc, sd.L.p);
+                else if (shadeTrace) phipLaunchShadeTrace(feat, rc.strictNormals != 0, sc->materialMask, grid, shadeTraceLds, stream, D, P, rc, sd.L.p);
                 else phipLaunchShade(feat, rc.strictNormals != 0, sc->materialMask, grid, stream, D, P, rc, sd.L.p);
                 if (timing) evShade.record(stream);
-                if (merged) {
+                if (shadeTrace) {
+                    /* (the vertex kernel traced both rays of the iteration itself: k_shade_trace.h) */
+                } else if (merged) {
                     if (timing) evTrace.record(stream);
                     if (sc->wide) {
                         /* k_rays_w draws its chunks from sharded counters */
@@ -1444,6 +1443,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     st.trace_kernel_ms = evTrace.sumPairs(); st.shadow_kernel_ms = evShadow.sumPairs();
     st.shade_kernel_ms = evShade.sumPairs(); st.film_kernel_ms = evFilm.sumPairs(); st.fused_kernel_ms = evFused.sumPairs();
     st.fused = fused ? 1u : 0u; st.n_devices = 1;
+    st.vertex_traced = (!fused && sc->flatTrace && !direct && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED)) ? 1u : 0u;
     st.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
     algorithmicBytes(merged, st, (double) W * H, sc->wide);
     if (stats) *stats = st;
@@ -1616,7 +1616,7 @@ static int renderMultiDevice(phip_scene *sc, const phip_render_params *p, float 
             t.trace_kernel_ms = std::max(t.trace_kernel_ms, a.trace_kernel_ms); t.shadow_kernel_ms = std::max(t.shadow_kernel_ms, a.shadow_kernel_ms);
             t.shade_kernel_ms = std::max(t.shade_kernel_ms, a.shade_kernel_ms); t.film_kernel_ms = std::max(t.film_kernel_ms, a.film_kernel_ms);
             t.fused_kernel_ms = std::max(t.fused_kernel_ms, a.fused_kernel_ms);
-            t.algorithmic_bytes += a.algorithmic_bytes; t.trace_kernel_bytes += a.trace_kernel_bytes; t.fused |= a.fused;
+            t.algorithmic_bytes += a.algorithmic_bytes; t.trace_kernel_bytes += a.trace_kernel_bytes; t.fused |= a.fused; t.vertex_traced |= a.vertex_traced;
         }
         t.n_devices = (uint32_t) n;
         t.reduce_ms = std::chrono::duration<double, std::milli>(clk::now() - tr0).count();

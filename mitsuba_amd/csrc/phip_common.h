@@ -45,7 +45,9 @@ using namespace pt;
     void phipLaunchShadeF##n(bool strictNormals, int materialMask, dim3 grid, hipStream_t stream,                          \
                              const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);                      \
     void phipLaunchShadeDirectF##n(int materialMask, dim3 grid, hipStream_t stream,                                        \
-                                   const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);
+                                   const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);                \
+    void phipLaunchShadeTraceF##n(bool strictNormals, int materialMask, dim3 grid, size_t ldsBytes, hipStream_t stream,    \
+                                  const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);
 PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3) PHIP_DECLARE_SHADE(8) PHIP_DECLARE_SHADE(11)
 #undef PHIP_DECLARE_SHADE
 /* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */

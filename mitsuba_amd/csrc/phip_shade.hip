@@ -6,8 +6,10 @@
  * phip.hip dispatches on the scene's feature set (phipLaunchShade / phipLaunchShadeDirect).  See phip_common.h.
  */
 #include "phip_common.h"
+#include "k_traverse.h"
 #include "k_shade.h"
 #include "k_shade_direct.h"
+#include "k_shade_trace.h"
 
 #ifndef SHADE_FEAT
 #error "compile with -DSHADE_FEAT=0..3, 8 or 11"
@@ -39,4 +41,18 @@ void SHADE_CAT(phipLaunchShadeDirectF, SHADE_FEAT)(int materialMask, dim3 grid, 
     /* `direct`: leaf BSDF models = diffuse only / all, strictNormals at run time */
     static const ShadeKernel table[2] = { k_shade_direct<0, SHADE_FEAT>, k_shade_direct<MM_ALL, SHADE_FEAT> };
     hipLaunchKernelGGL(table[(materialMask & MM_ALL) ? 1 : 0], grid, dim3(BLOCK), 0, stream, S, P, rc, L);
+}
+
+/* k_shade_trace (k_shade_trace.h): scenes on the packed leaf table (<= 64 Wald records) that k_mega does not serve; `path` only */
+void SHADE_CAT(phipLaunchShadeTraceF, SHADE_FEAT)(bool strictNormals, int materialMask, dim3 grid, size_t ldsBytes, hipStream_t stream,
+                                                  const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L) {
+#if SHADE_FEAT == 0
+    /* (phip.hip takes this path only when emitter table and materials fit LDS: the LDS-addressed tables, FEAT bit 2) */
+#define TRACE_ROW(S_) { k_shade_trace<0, S_, 4>, k_shade_trace<MM_ROUGH, S_, 4>, k_shade_trace<MM_DIELECTRIC, S_, 4>, k_shade_trace<MM_ALL, S_, 4> }
+#else
+#define TRACE_ROW(S_) { k_shade_trace<0, S_, SHADE_FEAT>, k_shade_trace<MM_ROUGH, S_, SHADE_FEAT>, k_shade_trace<MM_DIELECTRIC, S_, SHADE_FEAT>, k_shade_trace<MM_ALL, S_, SHADE_FEAT> }
+#endif
+    static const ShadeKernel table[2][4] = { TRACE_ROW(false), TRACE_ROW(true) };
+#undef TRACE_ROW
+    hipLaunchKernelGGL(table[strictNormals ? 1 : 0][materialMask & MM_ALL], grid, dim3(BLOCK), ldsBytes, stream, S, P, rc, L);
 }

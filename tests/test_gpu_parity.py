@@ -83,11 +83,12 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
     assert abs(int(st.closest_rays) - int(ost.closest_rays)) <= max(4, 1e-4 * ost.closest_rays)
     assert abs(int(st.path_vertices) - int(ost.path_vertices)) <= max(4, 1e-4 * ost.path_vertices)
     assert st.invalid_samples == ost.invalid_samples
-    if st.fused:
-        # the scene fits LDS, so the fused kernel (k_mega) rendered it: the wavefront kernels must give the same bits
+    if st.fused or st.vertex_traced:
+        # the scene fits LDS, so the fused kernel (k_mega) rendered it -- or its tree is the packed leaf table and k_shade_trace ran the iterations:
+        # the wavefront kernels (k_shade -> k_shadow_p -> k_trace) must give the same bits
         film2 = HDRFilm(gs.width, gs.height)
         assert integ.render(gs, film2, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_NO_FUSED, **render_kw)
-        assert not integ.stats.fused
+        assert not integ.stats.fused and not integ.stats.vertex_traced
         wsmp = integ.samples(gs, spp)
         assert (wsmp.view(np.uint32) == gsmp.view(np.uint32)).all(), "fused and wavefront paths differ"
         assert (film2.storage.view(np.uint32) == film.storage.view(np.uint32)).all()
@@ -759,8 +760,13 @@ def test_fused_kernel_64_record_work_list_overflow_matches_oracle(gpu, oracle, g
 
 def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
     """bench.py's `cornell_mixed_*` workload: the Cornell box with a rough-copper and a glass block -- 32 triangles, all three leaf BSDF
-    models; the wavefront kernels with the material heads of the shading records (dielectric: head, copper: material table)"""
+    models; a tree of 32 Wald records, so k_shade_trace (one kernel per iteration: vertex + shadow ray + next ray on the packed leaf table in LDS)"""
+    from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
     desc = S.cornell_mixed(128, 128, gauss).desc()
+    gs = Scene(desc); integ = PathHIP(maxDepth=6); film = HDRFilm(gs.width, gs.height)
+    assert integ.render(gs, film, 2)
+    assert integ.stats.vertex_traced == 1 and integ.stats.fused == 0 and integ.stats.trace_kernel_ms == 0, integ.stats.as_dict()
+    gs.close()
     for cfg in (dict(maxDepth=-1), dict(maxDepth=8, strictNormals=True)):
         same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, **cfg)
         print("cornell_mixed %s: identical %.6f rel L2 %.3e" % (cfg, same, r))

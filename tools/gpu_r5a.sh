@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call a: (1) material heads in the shading records (k_shade: two dependent round trips instead of three) against PHIP_NO_HEADS=1, and the
+# round 5, GPU call a (made on commit 973d15f: the material heads it measures were REMOVED afterwards, PHIP_NO_HEADS no longer exists): (1) material heads in the shading records (k_shade: two dependent round trips instead of three) against PHIP_NO_HEADS=1, and the
 # k_rays_w variants built by tools/build_variant.sh -- `cull` (-DWIDE_CULL=1: popped node groups skip a child whose entry lies behind the hit),
 # `b768c292w6` / `b1024c585w4` (blocks of 768 / 1024 lanes sharing an LDS cache of 292 / 585 top-of-tree nodes, read with ds_read_b128) -- on C3 / C4;
 # (2) the small scenes: C2, the 42- / 62-record boxes (two-word record masks; PHIP_NO_FLAT3=1 = the per-lane leaf table they used before), the mixed box;
