@@ -466,6 +466,51 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
     return t;
 }
 
+/* Scenes with more than one BSDF model: on the atrium 8 % of the vertices lie on copper, so nearly every wave ran the
+   microfacet code -- the longest branch of the vertex by far -- for its two or three conductor lanes (round 2: lane
+   utilisation 0.27).  Which LANE shades which of the block's 256 slots is free (all state is addressed by slot), so the
+   slots are dealt to the lanes by the class the ray kernel left in the hit record (k_pool.h): diffuse, rough conductor,
+   dielectric, then the slots without a live path (they regenerate).  A wave runs the microfacet code only if it got
+   conductor vertices (VALU instructions per launch -40 %, lane utilisation 0.29 -> 0.53).  Every lane fetches the state of
+   ITS slot (coalesced, one round trip, as without the deal) and hands it to the lane that shades it through LDS.  Results
+   cannot change: every slot is shaded by exactly one lane with the same code.  (All threads of the block call; two barriers.) */
+#define SHADE_DEAL_BYTES (BLOCK * (16 + 16 + 16 + 16 + 8 + 4))
+__device__ __forceinline__ void dealSlotsByClass(unsigned char *xbuf /* SHADE_DEAL_BYTES of LDS, 16-byte aligned */, uint32_t (*clsCnt)[BLOCK / 64] /* LDS: [4][BLOCK / 64] */,
+                                                 const PathPool &P, uint4 &info, PathVertex &v, uint32_t &slot, bool &inRange) {
+    uint4 *xInfo = (uint4 *) xbuf;
+    float4 *xHit = (float4 *) (xInfo + BLOCK), *xRayD = xHit + BLOCK, *xThr = xRayD + BLOCK;
+    float2 *xMis = (float2 *) (xThr + BLOCK);
+    uint32_t *xSlot = (uint32_t *) (xMis + BLOCK);
+    uint32_t cls = 3u;
+    if (inRange && (info.w & F_ALIVE)) {
+        const uint32_t w = pm_to_bits(v.hit.w);
+        if (w != PHIP_NO_HIT) cls = w >> HIT_CLASS_SHIFT;       /* (a path that left the scene ends here: with the idle slots) */
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = __lane_id();
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) rank = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) clsCnt[c][wave] = (uint32_t) __popcll(m);
+    }
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c)
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) {
+            const uint32_t n = clsCnt[c][w];
+            if (c < cls || (c == cls && w < wave)) base += n;
+        }
+    const uint32_t dst = base + rank;
+    xInfo[dst] = info; xHit[dst] = v.hit; xRayD[dst] = v.rayD; xThr[dst] = v.thr; xMis[dst] = v.mis; xSlot[dst] = slot;
+    __syncthreads();
+    info = xInfo[threadIdx.x]; v.hit = xHit[threadIdx.x]; v.rayD = xRayD[threadIdx.x]; v.thr = xThr[threadIdx.x]; v.mis = xMis[threadIdx.x];
+    slot = xSlot[threadIdx.x];
+    inRange = slot < P.capacity;
+}
+
 template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM == 0 ? SHADE_WAVES_LEAN : ((FEAT & 3) == 0 ? SHADE_WAVES_PLAIN : SHADE_WAVES)) void k_shade(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
     __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
@@ -495,47 +540,9 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
         tab.T.t = ldsEm; tab.materials = S.materials;
     }
     if (MM != 0 && SHADE_SORT && S.shadeSort) {                 /* (block-uniform) */
-        /* Scenes with more than one BSDF model: on the atrium 8 % of the vertices lie on copper, so nearly every wave ran the
-           microfacet code -- the longest branch of the vertex by far -- for its two or three conductor lanes (round 2: lane
-           utilisation 0.27).  Which LANE shades which of the block's 256 slots is free (all state is addressed by slot), so the
-           slots are dealt to the lanes by the class the ray kernel left in the hit record (k_pool.h): diffuse, rough conductor,
-           dielectric, then the slots without a live path (they regenerate).  A wave runs the microfacet code only if it got
-           conductor vertices (VALU instructions per launch -40 %, lane utilisation 0.29 -> 0.53).  Every lane fetches the state of
-           ITS slot (coalesced, one round trip, as without the deal) and hands it to the lane that shades it through LDS.  Results
-           cannot change: every slot is shaded by exactly one lane with the same code. */
-        __shared__ uint4 xInfo[BLOCK];
-        __shared__ float4 xHit[BLOCK], xRayD[BLOCK], xThr[BLOCK];
-        __shared__ float2 xMis[BLOCK];
-        __shared__ uint32_t xSlot[BLOCK];
+        __shared__ __align__(16) unsigned char xbuf[SHADE_DEAL_BYTES];
         __shared__ uint32_t clsCnt[4][BLOCK / 64];
-        uint32_t cls = 3u;
-        if (inRange && (info.w & F_ALIVE)) {
-            const uint32_t w = pm_to_bits(v.hit.w);
-            if (w != PHIP_NO_HIT) cls = w >> HIT_CLASS_SHIFT;       /* (a path that left the scene ends here: with the idle slots) */
-        }
-        const uint32_t wave = threadIdx.x >> 6, lane = __lane_id();
-        uint32_t rank = 0;
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) {
-            const unsigned long long m = __ballot(cls == c);
-            if (cls == c) rank = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) clsCnt[c][wave] = (uint32_t) __popcll(m);
-        }
-        __syncthreads();
-        uint32_t base = 0;
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c)
-#pragma unroll
-            for (uint32_t w = 0; w < BLOCK / 64; ++w) {
-                const uint32_t n = clsCnt[c][w];
-                if (c < cls || (c == cls && w < wave)) base += n;
-            }
-        const uint32_t dst = base + rank;
-        xInfo[dst] = info; xHit[dst] = v.hit; xRayD[dst] = v.rayD; xThr[dst] = v.thr; xMis[dst] = v.mis; xSlot[dst] = slot;
-        __syncthreads();
-        info = xInfo[threadIdx.x]; v.hit = xHit[threadIdx.x]; v.rayD = xRayD[threadIdx.x]; v.thr = xThr[threadIdx.x]; v.mis = xMis[threadIdx.x];
-        slot = xSlot[threadIdx.x];
-        inRange = slot < P.capacity;
+        dealSlotsByClass(xbuf, clsCnt, P, info, v, slot, inRange);
     }
     v.hit.w = pm_from_bits(hitPrim(pm_to_bits(v.hit.w)));       /* (the class bits have served: k_pool.h) */
     if (!inRange) info = make_uint4(0, 0, 0, 0);

@@ -13,7 +13,7 @@
  * same order, the shadow ray's contribution joins L[id] after the vertex's own terms as k_shadow_p's read-modify-write did: same bits.
  */
 #ifndef SHADE_TRACE_WAVES
-#define SHADE_TRACE_WAVES 4
+#define SHADE_TRACE_WAVES 5              /* 96 VGPRs (4: 99..110).  Mixed Cornell box, 4 M slots: 1643 -> 1759 Msamples/s (profiles/r05_gpu_call_e_*) */
 #endif
 
 /* Radiance policy: the vertex's additions are held back until its shadow ray is decided, then written once (LGlobal wrote L[id] in k_shade and k_shadow_p
@@ -26,17 +26,16 @@ struct LPending {
     __device__ __forceinline__ uint64_t seqIdx(const RenderConst &rc, const PathVertex &v, uint32_t width) const { return seqIndex(rc, v.k, v.pixel % width, v.pixel / width); }
 };
 
-__host__ __device__ __forceinline__ size_t shadeTraceLdsBytes(const DevScene &S) {
-    return (size_t) (BLOCK / 64) * BAL_WAVE_BYTES + (size_t) S.nFlatLeaves * 2 * sizeof(float4) + (size_t) S.triCache * 3 * sizeof(float4);
-}
-
 template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_TRACE_WAVES) void k_shade_trace(DevScene S, PathPool P, RenderConst rc, float4 *L) {
     __shared__ uint32_t waveCnt[BLOCK / 64];
-    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
-    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
+    /* one buffer, two uses: the class deal's slot exchange at the head of the block (scenes with more than one BSDF model), then -- behind a barrier -- the
+       slots and work lists of the dealt traversals */
+    __shared__ __align__(16) unsigned char xbuf[MM != 0 ? SHADE_DEAL_BYTES : (BLOCK / 64) * BAL_WAVE_BYTES];
+    static_assert(SHADE_DEAL_BYTES >= (BLOCK / 64) * BAL_WAVE_BYTES, "the traversal buffers lie over the exchange buffer");
+    __shared__ uint32_t clsCnt[4][BLOCK / 64];
     if (rc.draining && P.blockDead[blockIdx.x]) return;         /* (block-uniform) */
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;      /* (the pool's capacity is a multiple of BLOCK: every lane has a slot) */
-    const bool inRange = slot < P.capacity;
+    uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;            /* (the pool's capacity is a multiple of BLOCK: every lane has a slot) */
+    bool inRange = slot < P.capacity;
     const uint32_t lslot = inRange ? slot : 0u;
     uint4 info = P.info[lslot];
     info.w = P.state[lslot];
@@ -45,15 +44,19 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, SHA
     v.rayD = P.rayD[lslot];
     v.thr = P.thr[lslot];
     v.mis = P.mis[lslot];
+    /* dynamic LDS: [the packed leaf table][the Wald records][emitter table][materials] (the host checked that both tables fit: phip.hip, flatTrace) */
+    float4 *ldsFlat = (float4 *) g_smem, *ldsTris = ldsFlat + 2u * S.nFlatLeaves;
+    float *ldsEm = (float *) (ldsTris + 3u * S.triCache);
+    DevMaterial *ldsMat = (DevMaterial *) (ldsEm + ((S.emitterTabSize + 3u) & ~3u));
     ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
-    if (FEAT & 4) { tab.T.t = ldsEm; tab.materials = ldsMat; }
-    /* dynamic LDS: [per wave: slots + work list of the dealt Wald tests][the packed leaf table][the Wald records] */
-    float4 *ldsFlat = (float4 *) (g_smem + (size_t) (BLOCK / 64) * BAL_WAVE_BYTES), *ldsTris = ldsFlat + 2u * S.nFlatLeaves;
+    tab.T.t = ldsEm; tab.materials = ldsMat;
     for (uint32_t i = threadIdx.x; i < 2u * S.nFlatLeaves; i += BLOCK) ldsFlat[i] = S.flatLeaves[i];
     for (uint32_t i = threadIdx.x; i < 3u * S.triCache; i += BLOCK) ldsTris[i] = S.tris[i];
     lds_cf4 *flat = (lds_cf4 *) ldsFlat, *tris = (lds_cf4 *) ldsTris;
     const uint32_t lane = __lane_id();
-    const WaveBalance wb = waveBalanceAt(g_smem, (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)));
+    const WaveBalance wb = waveBalanceAt(xbuf, (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)));
+    /* the lane deal by BSDF model (k_shade.h: dealSlotsByClass): the class is what THIS kernel left in the hit word when it traced the ray */
+    if (MM != 0 && SHADE_SORT && S.shadeSort) dealSlotsByClass(xbuf, clsCnt, P, info, v, slot, inRange);
     v.hit.w = pm_from_bits(hitPrim(pm_to_bits(v.hit.w)));
     if (!inRange) info = make_uint4(0, 0, 0, 0);
     __syncthreads();                                            /* LDS tables are complete */
@@ -103,7 +106,7 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, SHA
         float mint, maxt; V3 rcp; TravResult r;
         const bool go = nowAlive & clipToSceneSel<false>(S, o, d, ro.w, rd.w, mint, maxt, rcp);
         traverseFlat2W<false, true>(flat, S.nFlatLeaves, tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
-        if (nowAlive) P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+        if (nowAlive) P.hit[slot] = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim == PHIP_NO_HIT ? r.prim : (r.prim | (r.cls << HIT_CLASS_SHIFT))));
     }
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
     waveStat(P, ST_CLOSEST_RAYS, waveId, nowAlive ? 1ull : 0ull);

@@ -49,6 +49,13 @@ __host__ __device__ __forceinline__ size_t megaLdsBytesOf(const DevScene &S) {
          + (size_t) S.nMaterials * sizeof(DevMaterial) + 16 /* alignment of the next array */ + (size_t) S.nFlatLeaves * 2 * sizeof(float4);
 }
 
+/* k_shade_trace (k_shade_trace.h), dynamic LDS of a block: the packed leaf table, the Wald records, the emitter table and the materials -- sized for THIS scene (the static 8.5 KB of k_shade's
+   two tables would cost a block of occupancy; the work lists of the dealt traversals live in the static exchange buffer) */
+__host__ __device__ __forceinline__ size_t shadeTraceLdsBytes(const DevScene &S) {
+    return (size_t) S.nFlatLeaves * 2 * sizeof(float4) + (size_t) S.triCache * 3 * sizeof(float4) + (size_t) ((S.emitterTabSize + 3u) & ~3u) * sizeof(float)
+         + (size_t) S.nMaterials * sizeof(DevMaterial);
+}
+
 /* carve the block's dynamic LDS and stage the cached geometry (all threads of the block must call) */
 __device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char *smem, uint32_t *spill, TravStack &stk) {
     uint32_t *stack = (uint32_t *) smem;
@@ -547,6 +554,7 @@ __device__ __forceinline__ bool traverseFlat2W(lds_cf4 *flat, uint32_t nFlat, ld
         const float hu = o_u + tt * d_u - b.x, hv = o_v + tt * d_v - b.y;
         const float tu = hv * b.z + hu * b.w, tv = hu * c.x + hv * c.y;
         res.t = found ? tt : res.t; res.u = found ? tu : res.u; res.v = found ? tv : res.v; res.prim = found ? pm_to_bits(c.z) : res.prim;
+        res.cls = found ? (pm_to_bits(c.w) & 3u) : 0u;           /* the record's shade class (k_shade_trace passes it on in the hit word: k_pool.h) */
         return found;
     }
 }

@@ -776,6 +776,8 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         }
     }
     sc->flatTrace = !sc->fitsLds && D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !getenv("PHIP_NO_SHADE_TRACE");
+    /* ... whose lanes are dealt by BSDF model where there is more than one (the kernel traces its own rays and leaves the class in the hit word) */
+    if (sc->flatTrace && sc->materialMask != 0) { D.shadeSort = 1u; if (const char *e = getenv("PHIP_SHADE_SORT")) D.shadeSort = atoi(e) != 0 ? 1u : 0u; }
     sd.counters.alloc(1);
     sd.invalid.alloc(1);
     sd.dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
@@ -1098,6 +1100,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         if (megaPerCU <= 0) fused = false;
     }
     sd.fused = fused;
+    /* ... or k_shade_trace: the scene's tree is the packed leaf table, but k_mega does not serve it (glass / copper / textures / environment emitter) */
+    const bool shadeTrace = !fused && sc->flatTrace && !direct && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
 
     phip_stats st; memset(&st, 0, sizeof(st));
     const bool timing = (p->flags & PHIP_FLAG_KERNEL_TIMING) != 0;
@@ -1126,7 +1130,11 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
            glass room at 512 spp 480 / 496 / 505 with 8 / 16 / 32 M -- so the pool grows with the job (about 0.14 KB of HBM per slot). */
         /* (round 4, after the ray kernel's triangle rounds: 8 / 16 / 32 / 64 M slots on the 4K slice (531 M ids) 610 / 636 / 646 / 657 Msamples/s, C4 at 512 spp (1062 M ids)
            flat at 64 M and -2 % at 128 M, C3 (133 M ids) flat from 16 M on: jobs of more than 256 M ids get 64 M slots) */
-        const unsigned long long poolCap = idsFirstPass > (256ull << 20) ? (1ull << 26) : idsFirstPass >= (64ull << 20) ? (1ull << 24)
+        /* (round 5: k_shade_trace has no persistent ray kernel whose drain a big pool amortises -- what a big pool costs it is the tail of the pass, the launches
+           in which the long paths of a few slots finish: mixed Cornell box at 256 spp with 1 / 2 / 4 / 8 / 16 M slots 1518 / 1617 / 1643 / 1596 / 1450 Msamples/s,
+           profiles/r05_gpu_call_e_*) */
+        const unsigned long long poolCap = shadeTrace ? (1ull << 22)
+                                         : idsFirstPass > (256ull << 20) ? (1ull << 26) : idsFirstPass >= (64ull << 20) ? (1ull << 24)
                                          : idsFirstPass >= (16ull << 20) ? (1ull << 23) : (1ull << 22);
         capacity = (uint32_t) std::min<unsigned long long>(std::max<unsigned long long>(idsFirstPass, BLOCK), poolCap);
         /* traversal-stack overflow: SPILL_DEPTH words per LANE of a ray kernel -- the wide tree is only walked by persistent grids
@@ -1321,8 +1329,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             bool drainingSeen = false;                          /* a termination test has counted fewer live slots than the pool holds: blocks may have retired */
             /* environment emitter, bitmap textures; 8: the QMC samplers (two builds: the plain one, and one with both other features) */
             const int feat0 = (D.envEmitter >= 0 ? 1 : 0) | (sc->hasTextures ? 2 : 0), feat = qmc ? (feat0 ? 11 : 8) : feat0;
-            const bool shadeTrace = sc->flatTrace && !direct && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
-            const size_t shadeTraceLds = (size_t) (BLOCK / 64) * BAL_WAVE_BYTES + (size_t) D.nFlatLeaves * 2 * sizeof(float4) + (size_t) D.triCache * 3 * sizeof(float4);
+            const size_t shadeTraceLds = shadeTraceLdsBytes(D);
             while (!done) {
                 const bool check = ((iter + 1) & 7) == 0 || rc.totalIds <= (unsigned long long) capacity * 4;
                 rc.countAlive = check ? 1 : 0;
@@ -1443,7 +1450,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     st.trace_kernel_ms = evTrace.sumPairs(); st.shadow_kernel_ms = evShadow.sumPairs();
     st.shade_kernel_ms = evShade.sumPairs(); st.film_kernel_ms = evFilm.sumPairs(); st.fused_kernel_ms = evFused.sumPairs();
     st.fused = fused ? 1u : 0u; st.n_devices = 1;
-    st.vertex_traced = (!fused && sc->flatTrace && !direct && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED)) ? 1u : 0u;
+    st.vertex_traced = shadeTrace ? 1u : 0u;
     st.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
     algorithmicBytes(merged, st, (double) W * H, sc->wide);
     if (stats) *stats = st;
