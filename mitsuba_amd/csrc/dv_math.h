@@ -20,6 +20,19 @@
 #include "../../include/phip_fmath.h"
 
 #define DV __host__ __device__ __forceinline__
+/* PHIP_EXPERIMENTS (tools/build_variant.sh -DPHIP_EXPERIMENTS=1): the alternatives that were measured against the product -- earlier kernel generations,
+   algorithm-selecting environment variables -- are compiled in; the shipped library carries one algorithm per job and reads no environment beyond the
+   documented knobs */
+#ifndef PHIP_EXPERIMENTS
+#define PHIP_EXPERIMENTS 0
+#endif
+/* the Sobol' row loops of sobolseq.h (one table read per index bit): the device code of the product draws through the byte tables only; the host keeps both
+   forms (tests/test_host_parity.py holds them against each other) */
+#if defined(__HIP_DEVICE_COMPILE__) && !PHIP_EXPERIMENTS
+#define SOBOL_ROW_LOOPS 0
+#else
+#define SOBOL_ROW_LOOPS 1
+#endif
 
 /* float -> int the way the reference's hardware does it (x86 cvttss2si: NaN and out-of-range values give INT_MIN, the
    "integer indefinite" -- e.g. floorToInt(NaN) < 0 sends MIPMap::eval down its bilinear branch, mipmap.h:657-662); AMD's
@@ -336,7 +349,7 @@ DV uint64_t sobolLookUp(const SobolTab &T, uint32_t frame, uint32_t px, uint32_t
     const uint32_t m = T.logRes, m2 = m << 1;
     uint64_t index = (uint64_t) frame << m2;
     uint64_t delta = 0;
-    if (T.vdcBt) {
+    if (!SOBOL_ROW_LOOPS || T.vdcBt) {
         const uint64_t *t = T.vdcBt;
 #pragma unroll
         for (uint32_t b = 0; b < 4u; ++b) delta ^= t[b * 256u + ((frame >> (8u * b)) & 255u)];      /* (entry [b][0] = 0) */
@@ -364,7 +377,7 @@ DV uint64_t sobolSampleIndex(const SobolTab &T, uint32_t sampleIndex, uint32_t p
 /* sobol::sampleSingle, sobolseq.h:42-58 */
 DV float sobolSample(const SobolTab &T, uint64_t index, uint32_t dimension) {
     uint32_t result = T.scramble;
-    if (T.matBt) {
+    if (!SOBOL_ROW_LOOPS || T.matBt) {
         const uint32_t *t = T.matBt + (size_t) dimension * (SOBOL_BT_BYTES * 256u);
         const uint32_t nb = byteLength64(index);
         for (uint32_t b = 0; b < nb; ++b) result ^= t[b * 256u + (uint32_t) ((index >> (8u * b)) & 255ull)];
@@ -382,7 +395,7 @@ DV float sobolSample(const SobolTab &T, uint64_t index, uint32_t dimension) {
    (a vertex draws its emitter and its BSDF sample from the same point: four chains of round trips become one) */
 DV void sobolSample2(const SobolTab &T, uint64_t index, uint32_t dimension, float &a, float &b) {
     uint32_t r0 = T.scramble, r1 = T.scramble;
-    if (T.matBt) {
+    if (!SOBOL_ROW_LOOPS || T.matBt) {
         const uint32_t *t = T.matBt + (size_t) dimension * (SOBOL_BT_BYTES * 256u);
         const uint32_t nb = byteLength64(index);
         for (uint32_t i = 0; i < nb; ++i) {
@@ -406,7 +419,7 @@ DV void sobolSample2(const SobolTab &T, uint64_t index, uint32_t dimension, floa
 }
 DV void sobolSample2x2(const SobolTab &T, uint64_t index, uint32_t dimA, uint32_t dimB, float out[4]) {
     uint32_t r0 = T.scramble, r1 = T.scramble, r2 = T.scramble, r3 = T.scramble;
-    if (T.matBt) {
+    if (!SOBOL_ROW_LOOPS || T.matBt) {
         const uint32_t *ta = T.matBt + (size_t) dimA * (SOBOL_BT_BYTES * 256u), *tb = T.matBt + (size_t) dimB * (SOBOL_BT_BYTES * 256u);
         const uint32_t nb = byteLength64(index);
         for (uint32_t i = 0; i < nb; ++i) {
@@ -456,7 +469,19 @@ struct RinvTab {
     uint32_t invPerm2, invPerm3;        /* inverse permutations of bases 2 and 3, two bits per digit (identity without scrambling) */
     uint32_t sampleCount;               /* hammersley: m_sampleCount (of the whole render) */
     float factor;                       /* hammersley: m_factor */
+    /* Multi-digit tables (round 5; NULL: the digit-by-digit loops).  The radical inverse is a chain of DEPENDENT steps, one per digit of the index
+       (23 for base 2 on C2), each a division by a run-time prime; the Faure permutation is per base, so the permuted value of a chunk of k digits is
+       ONE look-up (base 2: 10 digits per chunk, 3: 6, 5: 4, 7: 3, 11..31: 2, larger: 1), and the division by the chunk size b^k a multiply-high with a
+       correction.  Built by the host for the first RINV_TAB_DIMS dimensions (phip.hip: buildRinvTables):
+         dimInfo[8 d ..]  base, B = base^k, k | first chunk entry << 8, floor(2^32 / B) + 1, bits(1 / base), bits(radical * perm[0] / (1 - radical)), -, -
+         chunk[..]        per value c of a chunk: V_full (the k digits of c, least significant first, as value = value * base + perm[digit]) |
+                          V_sig << 10 (the same over the SIGNIFICANT digits of c only: the top chunk of an index) | number of significant digits << 20
+         fac[34 d + m]    radical^m as the loop computes it (m sequential float multiplications), pw[11 d + n] = base^n */
+    const uint32_t *dimInfo, *chunk, *pw; const float *fac; uint32_t tabDims;
 };
+#define RINV_TAB_DIMS 128u
+#define RINV_FAC_STRIDE 34u
+#define RINV_PW_STRIDE 11u
 /* inverseScrambledRadicalInverse, halton.cpp:198-211 / hammersley.cpp:165-178 */
 DV uint32_t rinvInverse(uint32_t base, uint32_t inverse, uint32_t digits, uint32_t invPerm) {
     uint32_t index = 0;
@@ -485,7 +510,37 @@ DV uint64_t rinvSampleIndex(const RinvTab &T, uint32_t k, uint32_t px, uint32_t 
 }
 /* radicalInverseFast / scrambledRadicalInverseFast, qmc.cpp:141-166,169-1198,1201-2230 (the macros RINV / SCRAMBLED_RINV: integer digits, one
    float factor): bit for bit */
+/* floor(n / B) and the remainder by M = floor(2^32 / B) + 1: n M / 2^32 = n / B + n d / 2^32 with 0 < d <= 1, so the multiply-high is the quotient or one
+   more; one more shows as a remainder that wrapped below zero (>= 2^32 - B >= B in unsigned arithmetic, whether or not q B itself overflowed) */
+DV void rinvDivMod(uint32_t n, uint32_t B, uint32_t M, uint32_t &q, uint32_t &c) {
+    q = (uint32_t) (((uint64_t) n * (uint64_t) M) >> 32);
+    c = n - q * B;
+    if (c >= B) { q -= 1u; c += B; }
+}
+/* (Measured and not kept, profiles/r05_gpu_call_g_*: a straight-line form that derives up to four chunks and the top chunk's digit count by integer
+   arithmetic alone and requests all look-ups together -- two memory round trips per number instead of one per chunk: k_mega with `halton` 1.600 x the counter
+   stream's time against 1.585 x for this loop; the extra divisions cost what the parallel loads save.) */
+DV float rinvRadicalInverseTab(const RinvTab &T, uint32_t baseIndex, uint32_t i32) {
+    const uint32_t *di = T.dimInfo + 8u * baseIndex;
+    const uint32_t B = di[1], k = di[2] & 0xffu, M = di[3];
+    const float tail = pm_from_bits(di[5]);                 /* radical * perm[0] / (1 - radical) (0 without scrambling) */
+    const uint32_t *tab = T.chunk + (di[2] >> 8);
+    uint64_t value = 0;
+    uint32_t digits = 0;
+    while (i32 >= B) {                                      /* a full chunk: k digits, leading zeros included */
+        uint32_t q, c; rinvDivMod(i32, B, M, q, c);
+        value = value * B + (uint64_t) (tab[c] & 0x3ffu);
+        digits += k; i32 = q;
+    }
+    const uint32_t e = tab[i32], n = e >> 20;               /* the top chunk: its significant digits only (the loops stop when nothing is left) */
+    value = value * T.pw[RINV_PW_STRIDE * baseIndex + n] + (uint64_t) ((e >> 10) & 0x3ffu);
+    digits += n;
+    const float factor = T.fac[RINV_FAC_STRIDE * baseIndex + digits];
+    const float inverse = T.perm ? factor * ((float) value + tail) : (float) value * factor;
+    return 0.99999994f < inverse ? 0.99999994f : inverse;
+}
 DV float rinvRadicalInverse(const RinvTab &T, uint32_t baseIndex, uint64_t index) {
+    if (T.dimInfo && baseIndex < T.tabDims && !(index >> 32)) return rinvRadicalInverseTab(T, baseIndex, (uint32_t) index);
     const uint32_t base = T.primes[baseIndex];
     const float radical = 1.0f / (float) (int) base;
     const uint16_t *perm = T.perm ? T.perm + T.permOffset[baseIndex] : nullptr;

@@ -173,6 +173,7 @@ struct SceneDev {
     DevBuf<Counters> counters;
     DevBuf<uint32_t> tileOrigin, shadowCount, blockDead, spill, blockShard; DevBuf<int32_t> tileSlot;
     DevBuf<uint32_t> sobolMat, sobolBt; DevBuf<unsigned long long> sobolVdc, sobolVdcBt; uint64_t sobolKey = 0; uint32_t sobolLogRes = 0;    /* PHIP_SAMPLER_SOBOL: the plugin's tables */
+    DevBuf<uint32_t> rinvDimInfo, rinvChunk, rinvPw; DevBuf<float> rinvFac; uint32_t rinvTabDims = 0;   /* ... and their multi-digit tables (buildRinvTables) */
     DevBuf<uint32_t> rinvPrimes, rinvOffsets; DevBuf<uint16_t> rinvPerm; uint64_t rinvKey = 0;   /* PHIP_SAMPLER_HALTON / _HAMMERSLEY: primes + permutations */
     uint32_t rinvInvPerm2 = 0x4u, rinvInvPerm3 = 0x24u;                                                                         /* inverse permutations of bases 2 and 3, two bits per digit */
     DevBuf<unsigned long long> dynCounter, stat, invalid, megaNext;
@@ -815,6 +816,38 @@ static void buildSobolByteTables(const uint32_t *matrices, size_t dims, const un
     }
 }
 
+/* Multi-digit tables of the radical inverses (dv_math.h: RinvTab::dimInfo / chunk / fac / pw) for the leading dimensions whose base is below 1024 (at most
+   RINV_TAB_DIMS): the permuted value of every chunk of k digits, the float factors radical^m as the digit loop multiplies them up, the powers base^n */
+static uint32_t buildRinvTables(const uint32_t *primes, const uint16_t *perm /* concatenated, or NULL */, const uint32_t *permOffset, uint32_t dims,
+                                std::vector<uint32_t> &dimInfo, std::vector<uint32_t> &chunk, std::vector<float> &fac, std::vector<uint32_t> &pw) {
+    uint32_t nd = 0;
+    while (nd < dims && nd < RINV_TAB_DIMS && primes[nd] < 1024u) ++nd;
+    dimInfo.assign((size_t) 8 * nd, 0u); chunk.clear(); fac.assign((size_t) RINV_FAC_STRIDE * nd, 0.0f); pw.assign((size_t) RINV_PW_STRIDE * nd, 0u);
+    for (uint32_t d = 0; d < nd; ++d) {
+        const uint32_t base = primes[d];
+        const uint16_t *P = perm ? perm + permOffset[d] : nullptr;
+        uint32_t k = 1, B = base;
+        while ((unsigned long long) B * base <= 1024ull && k < RINV_PW_STRIDE - 1u) { B *= base; ++k; }
+        const uint32_t first = (uint32_t) chunk.size();
+        dimInfo[8 * d] = base; dimInfo[8 * d + 1] = B; dimInfo[8 * d + 2] = k | (first << 8);
+        dimInfo[8 * d + 3] = (uint32_t) ((1ull << 32) / B) + 1u;
+        for (uint32_t c = 0; c < B; ++c) {
+            uint32_t vFull = 0, vSig = 0, n = 0, t = c;
+            for (uint32_t j = 0; j < k; ++j) { const uint32_t digit = t % base; t /= base; vFull = vFull * base + (P ? (uint32_t) P[digit] : digit); }
+            for (t = c; t; t /= base, ++n) { const uint32_t digit = t % base; vSig = vSig * base + (P ? (uint32_t) P[digit] : digit); }
+            chunk.push_back(vFull | (vSig << 10) | (n << 20));
+        }
+        const float radical = 1.0f / (float) (int) base;
+        const float tail = P ? radical * (float) (int) P[0] / (1.0f - radical) : 0.0f;        /* the constant of scrambledRadicalInverse, by its own expression */
+        dimInfo[8 * d + 4] = pm_to_bits(radical); dimInfo[8 * d + 5] = pm_to_bits(tail);
+        float f = 1.0f;
+        for (uint32_t m = 0; m < RINV_FAC_STRIDE; ++m) { fac[(size_t) RINV_FAC_STRIDE * d + m] = f; f *= radical; }
+        uint32_t pwr = 1;
+        for (uint32_t n = 0; n <= k; ++n) { pw[(size_t) RINV_PW_STRIDE * d + n] = pwr; pwr *= base; }
+    }
+    return nd;
+}
+
 /* 64-bit content key of a caller's table (word-wise multiply-xorshift; ~2 GB/s: 0.1 ms for the Sobol direction numbers) */
 static uint64_t contentHash(const void *data, size_t bytes, uint64_t h) {
     const unsigned char *b = (const unsigned char *) data;
@@ -1088,6 +1121,11 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             for (uint32_t i = 0; i < 2; ++i) sd.rinvInvPerm2 |= i << (2u * p2[i]);          /* invPerm[perm[i]] = i (faure.cpp: invertPermutation) */
             for (uint32_t i = 0; i < 3; ++i) sd.rinvInvPerm3 |= i << (2u * p3[i]);
         }
+        {
+            std::vector<uint32_t> di, ch, pw; std::vector<float> fc;
+            sd.rinvTabDims = buildRinvTables(p->qmc_primes, p->qmc_permutations, off.data(), p->qmc_dimensions, di, ch, fc, pw);
+            if (sd.rinvTabDims) { sd.rinvDimInfo.upload(di.data(), di.size()); sd.rinvChunk.upload(ch.data(), ch.size()); sd.rinvFac.upload(fc.data(), fc.size()); sd.rinvPw.upload(pw.data(), pw.size()); }
+        }
         sd.rinvKey = rinvKey;
     }
     if (const char *e = getenv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
@@ -1236,7 +1274,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             rc.sobol.matrices = sd.sobolMat.p; rc.sobol.vdc = (const uint64_t *) sd.sobolVdc.p; rc.sobol.vdcInv = (const uint64_t *) sd.sobolVdc.p + PHIP_SOBOL_MATRIX_SIZE;
             rc.sobol.dims = p->sobol_dimensions; rc.sobol.logRes = p->sobol_log_resolution; rc.sobol.scramble = (uint32_t) p->sobol_scramble;
             rc.sobol.resolution = (float) (1u << p->sobol_log_resolution);
-            if (!getenv("PHIP_SOBOL_BITWISE")) {                /* (A/B: the row-by-row loops of sobolseq.h) */
+            if (!(PHIP_EXPERIMENTS && getenv("PHIP_SOBOL_BITWISE"))) {      /* (experiment builds, A/B: the row-by-row loops of sobolseq.h -- the product's device code has the byte tables only) */
                 rc.sobol.matBt = sd.sobolBt.p;
                 rc.sobol.vdcBt = (const uint64_t *) sd.sobolVdcBt.p; rc.sobol.vdcInvBt = (const uint64_t *) sd.sobolVdcBt.p + 4u * 256u;
             }
@@ -1250,6 +1288,9 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             RinvTab &T = rc.rinv;
             T.primes = sd.rinvPrimes.p; T.perm = p->qmc_permutations ? sd.rinvPerm.p : nullptr; T.permOffset = sd.rinvOffsets.p; T.dims = p->qmc_dimensions;
             T.invPerm2 = sd.rinvInvPerm2; T.invPerm3 = sd.rinvInvPerm3;
+            if (sd.rinvTabDims && !getenv("PHIP_RINV_DIGITWISE")) {     /* (A/B: the digit-by-digit loops of qmc.cpp) */
+                T.dimInfo = sd.rinvDimInfo.p; T.chunk = sd.rinvChunk.p; T.fac = sd.rinvFac.p; T.pw = sd.rinvPw.p; T.tabDims = sd.rinvTabDims;
+            }
             const uint32_t res[2] = { (uint32_t) D.film.width, (uint32_t) D.film.height };
             T.sampleCount = (uint32_t) (p->sample_total > 0 ? p->sample_total : p->spp);
             if (p->sampler == PHIP_SAMPLER_HALTON) {

@@ -128,6 +128,22 @@ int phip_debug_host_sobol(const uint32_t *matrices, uint32_t dims, const unsigne
     return PHIP_OK;
 }
 
+/* the radical inverses of PHIP_SAMPLER_HALTON / _HAMMERSLEY (dv_math.h: rinvRadicalInverse) on the host: digit by digit (tables = 0: the loops of qmc.cpp) or
+   through the multi-digit tables the render uploads (buildRinvTables) -- tests/test_host_parity.py holds the two against each other and against numpy */
+int phip_debug_host_rinv(const uint32_t *primes, const uint16_t *perm, uint32_t dims, int tables, size_t n, const unsigned long long *index, const uint32_t *dim, float *out) {
+    std::vector<uint32_t> off(dims); size_t total = 0;
+    for (uint32_t d = 0; d < dims; ++d) { off[d] = (uint32_t) total; total += primes[d]; }
+    RinvTab T; memset(&T, 0, sizeof(T));
+    T.primes = primes; T.perm = perm; T.permOffset = off.data(); T.dims = dims;
+    std::vector<uint32_t> di, ch, pw; std::vector<float> fc;
+    if (tables) { T.tabDims = buildRinvTables(primes, perm, off.data(), dims, di, ch, fc, pw); T.dimInfo = di.data(); T.chunk = ch.data(); T.fac = fc.data(); T.pw = pw.data(); }
+    for (size_t i = 0; i < n; ++i) {
+        if (dim[i] >= dims) return setErr(PHIP_ERR_INVALID, "dimension out of range");
+        out[i] = rinvRadicalInverse(T, dim[i], index[i]);
+    }
+    return PHIP_OK;
+}
+
 /* Wald records + BVH statistics of a triangle soup, built exactly like phip_scene_create does (no GPU needed) */
 int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles,
                               phip_accel_info *info, float *scene_box6) {

@@ -244,3 +244,44 @@ def test_sobol_byte_tables_equal_the_row_loops(phip):
         assert (expect.view(np.uint32) == res[1][1].view(np.uint32)).all()
         if m > 1:
             assert len(np.unique(idx)) > n // 2 and (idx >> np.uint64(2 * m) == sample).all()      # look_up keeps the frame number in the bits above the pixel
+
+
+def test_radical_inverse_tables_equal_the_digit_loops(phip):
+    """PHIP_SAMPLER_HALTON / _HAMMERSLEY (round 5): the device draws its radical inverses through multi-digit tables (dv_math.h: RinvTab::chunk, built by the host:
+    the permuted value of a chunk of k digits is one look-up, the division by base^k a multiply-high with a correction).  The same functions compiled for the
+    host, with and without the tables, on random indices of every dimension -- and the digit loop against scrambledRadicalInverse (qmc.cpp:99-112) in numpy."""
+    from conftest import qmc_tables
+    rng = np.random.default_rng(23)
+    u32p, u64p, u16p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint16)
+    for scramble in (-1, 7, 0):
+        primes, perm = qmc_tables(scramble, dimensions=64)
+        primes = np.ascontiguousarray(primes, np.uint32)
+        n = 60000
+        index = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+        index[:4000] = np.arange(4000)                                                             # the first points, the empty index
+        index[4000:8000] = rng.integers(0, 1 << 23, 4000, dtype=np.uint64)                          # C2's range (31104 x 256)
+        for j, b in enumerate((2, 3, 5, 7, 11, 1024, 729, 625, 343, 121)):                          # multiples and neighbours of the chunk sizes
+            index[8000 + 40 * j:8000 + 40 * j + 40] = (np.arange(1, 41, dtype=np.uint64) * np.uint64(b ** (1 + j % 3))) + np.uint64(j % 2) - np.uint64(j % 3 == 2)
+        index[9000:9064] = (np.uint64(1) << np.arange(64, dtype=np.uint64))                         # ... incl. indices above 2^32 (the digit loops serve those)
+        index[9064:9100] = np.uint64(0xFFFFFFFF) - np.arange(36, dtype=np.uint64)
+        dim = rng.integers(0, len(primes), n).astype(np.uint32); dim[:4000] = np.arange(4000) % len(primes)
+        res = []
+        for tables in (0, 1):
+            out = np.zeros(n, np.float32)
+            rc = phip.phip_debug_host_rinv(primes.ctypes.data_as(u32p), perm.ctypes.data_as(u16p) if perm is not None else None, len(primes), tables, n,
+                                           index.ctypes.data_as(u64p), dim.ctypes.data_as(u32p), fp(out))
+            assert rc == 0
+            res.append(out)
+        assert (res[0].view(np.uint32) == res[1].view(np.uint32)).all(), np.argwhere(res[0] != res[1])[:10]
+        assert (res[0] >= 0).all() and (res[0] < 1).all()
+        # the definition (qmc.cpp:99-112, float accumulation) agrees to rounding: the Fast forms sum integer digits and scale once
+        off = np.concatenate(([0], np.cumsum(primes.astype(np.int64))[:-1])).astype(np.int64)
+        sel = np.arange(0, 3000)
+        for i in sel[::7]:
+            b = int(primes[dim[i]]); radical = 1.0 / b; inv = 0.0; digit = radical; t = int(index[i])
+            P = (lambda d: int(perm[off[dim[i]] + d])) if perm is not None else (lambda d: d)
+            while t:
+                inv += digit * P(t % b); digit *= radical; t //= b
+            if perm is not None:
+                inv += digit * P(0) / (1 - radical)
+            assert abs(min(inv, 0.99999994) - float(res[0][i])) <= 2e-6, (i, b, index[i], inv, res[0][i])
