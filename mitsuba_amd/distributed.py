@@ -23,7 +23,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PHIP_DIST_BACKEND=gloo: the per-process protocol on device tensors without RCCL (gloo stages them through the host) -- how the two-rank test
+            # runs on a box with ONE GPU, where a RCCL clique of two ranks on the same device is refused (tests/test_gpu_round2.py)
+            backend = os.environ.get("PHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -35,6 +35,37 @@ def build(quiet=True):
         raise RuntimeError("reference build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
     if not quiet:
         print(r.stdout[-2000:])
+    pin_libm()
+
+
+PINNED = os.path.join(HERE, "_ref", "pinned_libm")
+
+
+def pin_libm():
+    """oracle/_ref/pinned_libm/libm.so.6 = the libm of the container that BUILT the reference, + its glibc version.  The arbiter of
+    the full-size test (tests/test_gpu_dropin.py) is Mitsuba with glibc's <= 1-ulp transcendentals; its subprocess puts this directory first on
+    LD_LIBRARY_PATH, so that the comparison runs against the SAME libm on every GPU lease (the directory travels with the snapshot like the other built
+    files).  Static linking is not an option: glibc's libm.a is not position independent."""
+    import ctypes
+    import shutil
+    src = None
+    for line in open("/proc/self/maps"):
+        if "/libm.so" in line or "/libm-" in line:
+            src = line.split()[-1]
+            break
+    if src is None:
+        ctypes.CDLL("libm.so.6")
+        for line in open("/proc/self/maps"):
+            if "/libm.so" in line or "/libm-" in line:
+                src = line.split()[-1]
+                break
+    if src is None:
+        return
+    os.makedirs(PINNED, exist_ok=True)
+    shutil.copy2(os.path.realpath(src), os.path.join(PINNED, "libm.so.6"))
+    ver = ctypes.CDLL(None).gnu_get_libc_version
+    ver.restype = ctypes.c_char_p
+    open(os.path.join(PINNED, "glibc_version.txt"), "w").write(ver().decode() + "\n")
 
 
 def build_shims():

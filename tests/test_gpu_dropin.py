@@ -256,6 +256,10 @@ def _fullsize(tmp_path, keys, preload):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
+    # the arbiter's libm is the one of the container that built oracle/_ref (oracle/ref_ffi.py: pin_libm), on every lease: VERDICT r4, item 7
+    pinned = os.path.join(root, "oracle", "_ref", "pinned_libm")
+    if os.path.exists(os.path.join(pinned, "libm.so.6")):
+        env["LD_LIBRARY_PATH"] = pinned + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
     if preload:
         r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "crm"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
@@ -282,6 +286,14 @@ def test_baseline_configs_at_full_size_against_the_reference(phip, ref, gauss, t
     stock = _fullsize(tmp_path, keys + ["C2sobol"], preload=False)
     # C2 with <sampler type="sobol"/>: the reference's own sampler plugin on the CPU side, its direction numbers on the GPU side -- no parity
     # sampler anywhere, the image the reference renders for that scene file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pinned = os.path.join(root, "oracle", "_ref", "pinned_libm")
+    if os.path.exists(os.path.join(pinned, "libm.so.6")):
+        built_with = open(os.path.join(pinned, "glibc_version.txt")).read().strip()
+        for name, r in stock.items():
+            assert os.path.realpath(r["libm_mapped"]) == os.path.realpath(os.path.join(pinned, "libm.so.6")), r["libm_mapped"]
+        print("the reference's libm: %s (glibc %s of the container that built oracle/_ref; this box runs glibc %s)"
+              % (os.path.relpath(pinned, root), built_with, next(iter(stock.values()))["glibc_version"]))
     for name, r in stock.items():
         print("%s vs Mitsuba 0.6 (glibc): rel L2 %.3e, %.4f %% of the pixels differ by more than 1e-3; GPU %.3f s, reference %.1f s on %d threads"
               % (name, r["rel_l2"], 100 * r["pixels_differing_by_more_than_1e-3"], r["gpu_seconds"], r["reference_seconds"], r["reference_threads"]))

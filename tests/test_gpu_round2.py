@@ -217,6 +217,31 @@ def test_bench_two_gpus(gpu, phip, launcher):
     assert d["config"]["workload"] == "cornell_256x256_16spp_md4"
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_on_one_gpu_run_the_per_process_protocol(gpu, phip, tmp_path, world):
+    """bench.py's N > 1 step (phip_render_device of the rank's shard -> reduce_film -> phip_film_to_host on rank 0) executed by `world`
+    processes that SHARE GPU 0, the device tensors reduced by gloo through the host (a RCCL clique of two ranks on one device is refused): the order of the
+    library's streams and the collective on one film buffer -- the bug class of 5f696ea, found by reading in round 4 -- is run by a machine.  Three steps back
+    to back (the next render overwrites the buffer the previous step reduced and copied out); every merged frame equals the unsharded render of its seed."""
+    import socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "result.txt"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PHIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "_dist_gpu_worker.py"), str(out), "3"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=540)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    w, steps, err, total = out.read_text().split()
+    assert int(w) == world and int(steps) == 3
+    assert float(err) < 1e-6, err                               # shards merged in another order of additions than the unsharded film: last bits only
+    assert int(total) == 640 * 360 * 8                          # every sample of the (last) frame rendered by exactly one rank
+
+
 def test_rccl_calls_of_the_merge_on_the_devices_that_are_there(gpu, phip):
     """ncclCommInitAll / ncclGroupStart / ncclReduce / ncclGroupEnd as renderMultiDevice issues them, bound through the same dlopen,
     on a clique of the visible devices (one device is a valid clique: the only way these calls run on a single-GPU box)"""

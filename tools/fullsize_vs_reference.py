@@ -5,6 +5,7 @@ parity-stream sampler) -- developed images, relative L2.
     LD_PRELOAD=$PWD/oracle/_build/libcrm.so python tools/fullsize_vs_reference.py ...  the same against the reference with the
         correctly rounded transcendentals of include/phip_fmath.h in place of glibc's (oracle/ref_glue/crlibm_shim.cpp)"""
 import json
+import ctypes
 import os
 import sys
 import time
@@ -18,6 +19,10 @@ from oracle import ref_ffi as R                               # noqa: E402
 
 gauss = _ffi.gaussian_filter(0.5)
 out = {}
+# which libm answers the reference's transcendentals in this process (tests/test_gpu_dropin.py puts oracle/_ref/pinned_libm first on LD_LIBRARY_PATH)
+LIBM_MAPPED = next((line.split()[-1] for line in open("/proc/self/maps") if "/libm.so" in line or "/libm-" in line), "?")
+_v = ctypes.CDLL(None).gnu_get_libc_version; _v.restype = ctypes.c_char_p
+GLIBC_VERSION = _v().decode()
 from oracle import oracle_ffi as O                             # noqa: E402
 for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1024, 1024, 256, -1),
                                    ("C2sobol cornell 1024x1024x256, the reference's own sobol sampler on both sides", S.cornell_box, 1024, 1024, 256, -1),
@@ -48,7 +53,8 @@ for name, build, w, h, spp, md in (("C2 cornell 1024x1024x256", S.cornell_box, 1
     big = float((np.abs(g - cpu) > 1e-3 * np.maximum(1.0, np.abs(cpu))).any(-1).mean())
     out[name] = {"gpu_seconds": round(tg, 3), "reference_seconds": round(sec, 1), "reference_threads": os.cpu_count(), "rel_l2": rel,
                  "pixels_differing_by_more_than_1e-3": big, "speedup": round(sec / tg, 1),
-                 "reference_libm": "phip_fmath.h (LD_PRELOAD libcrm.so)" if "libcrm" in os.environ.get("LD_PRELOAD", "") else "glibc"}
+                 "reference_libm": "phip_fmath.h (LD_PRELOAD libcrm.so)" if "libcrm" in os.environ.get("LD_PRELOAD", "") else "glibc",
+                 "libm_mapped": LIBM_MAPPED, "glibc_version": GLIBC_VERSION}
     print(name, out[name], flush=True)
     rs.close(); gs.close()
 os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)
