@@ -16,6 +16,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def phip():
     """libphip.so (built in-tree if needed).  Loads without a GPU; compute calls need one."""
+    # torch brings its own copy of the HIP runtime: when libphip.so (linked against /opt/rocm's) has touched the GPU first, torch's later initialisation finds
+    # "No HIP GPUs" -- the tests that hand torch tensors to the library then depend on the order they run in.  Initialise torch's side first.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     from mitsuba_amd import _ffi
     _ffi.build()
     return _ffi.lib()
