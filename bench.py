@@ -416,13 +416,16 @@ def main():
             out["requested"] = {"steps": args.steps, "warmup": args.warmup}
             out["roofline"]["scope"] = "the dominant kernel of ONE rank's share of the job (rank 0): the N-GPU line prices no collective -- the film reduce is reduce_ms of the library path / inside ms_per_step here"
             out["cpu_baseline_note"] = "no CPU baseline on the N > 1 line (the N = 1 line carries one per workload)"
-            sbal, ssrc = profile_json("shard_balance", "")
+            sbal, ssrc = profile_json("shard_balance", headline)      # the prediction taken on THIS job's shape (round 5: the whole 1024-spp job, not its 64-spp slice)
+            if sbal is None:
+                sbal, ssrc = profile_json("shard_balance", "")
             pred = ((sbal or {}).get("N") or {}).get(str(n_gpus))
             if pred:
                 out["predicted_scaling_efficiency"] = pred.get("predicted_scaling_efficiency")
                 out["prediction"] = {"source": ssrc, "max_over_mean_shard_time": pred.get("max_over_mean"), "loss_to_imbalance": pred.get("loss_to_imbalance"),
                                      "loss_to_fixed_costs": pred.get("loss_to_fixed_costs"), "reduce_s_estimate": pred.get("reduce_s_estimate"),
-                                     "note": "tools/shard_balance.py: the N shards of the job's 64-spp slice rendered one after another on ONE GPU; efficiency = T(1) / (N (max shard time + ring reduce at 153 GB/s per link))"}
+                                     "workload": (sbal or {}).get("workload"),
+                                     "note": "tools/shard_balance.py: the N shards of the named workload rendered one after another on ONE GPU; efficiency = T(1) / (N (max shard time + ring reduce at 153 GB/s per link))"}
             if single:
                 out["single_gpu_same_job"] = single
                 out["scaling_efficiency"] = round(s["value"] / (n_gpus * single["value"]), 4)

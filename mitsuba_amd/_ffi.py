@@ -36,8 +36,11 @@ def _sources():
 # phip_mega.hip is compiled without MachineLICM: hoisting the double-precision polynomial constants of phip_fmath.h (two VGPRs each,
 # 64-bit literals cannot be encoded) out of k_mega's persistent loop cost ~40 VGPRs -- 168 instead of 128, i.e. 3 instead of 4 waves per SIMD
 MEGA_FLAGS = ["-mllvm", "-disable-machine-licm"]
-UNITS = [("phip.hip", [], "phip.o"), ("phip_mega.hip", MEGA_FLAGS, "phip_mega.o")] + \
-        [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f], "phip_shade%d.o" % f) for f in (0, 1, 2, 3, 8, 11)]
+# phip_shade.hip: once per feature set and part (see its header): 24 objects; the heavy ones (textures: bit 1 of the feature set) first, so that the
+# longest compiles start when the pool does
+SHADE_FEATS, SHADE_PARTS = (11, 3, 2, 1, 8, 0), (0, 1, 3, 2)
+UNITS = [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f, "-DSHADE_PART=%d" % q], "phip_shade%d_%d.o" % (f, q)) for f in SHADE_FEATS for q in SHADE_PARTS] + \
+        [("phip_mega.hip", MEGA_FLAGS, "phip_mega.o"), ("phip.hip", [], "phip.o")]
 
 
 def source_id():
@@ -81,18 +84,22 @@ def build(force=False, verbose=False):
 def _build_locked(sid, out_lib, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", "").split()
-    procs = []
+    cmds = []
     for src, extra, obj in UNITS:
         if src == "phip.hip":
             extra = extra + ['-DPHIP_BUILD_ID="%s"' % sid]
-        cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj + ".tmp.o")]
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for cmd, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
-        if verbose:
-            print(" ".join(cmd)); print(out)
+        cmds.append([hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj + ".tmp.o")])
+    # as many compilers at a time as there are cores, in the order of UNITS (longest first)
+    import concurrent.futures
+    def run(cmd):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return cmd, r.returncode, r.stdout
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(2, os.cpu_count() or 4)) as pool:
+        for cmd, rc, out in pool.map(run, cmds):
+            if rc != 0:
+                raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+            if verbose:
+                print(" ".join(cmd)); print(out)
     for _, _, obj in UNITS:
         os.replace(os.path.join(BUILD, obj + ".tmp.o"), os.path.join(BUILD, obj))
     tmp = out_lib + ".tmp.%d" % os.getpid()

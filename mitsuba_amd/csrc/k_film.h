@@ -209,6 +209,7 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled(DevScene S, RenderConst rc
     if (invalid) atomicAdd(invalidCount, invalid);
 }
 
+#if PHIP_EXPERIMENTS      /* (superseded by the splat below for every case it served; kept for A/B builds: PHIP_FILM_GATHER=1) */
 /* ---- round 3: the tiled gather for the reference's default filters (reach R = 1 or 2 pixels: box, tent, gaussian stddev 0.5) ----
  * Same arithmetic per (sample, pixel) pair and the same order of additions as k_film_tiled, restructured around what round 2's
  * counters showed (53 % of the wave cycles waiting at 3.7 waves per SIMD, 37 KB of LDS per block, two barriers per sample index):
@@ -354,6 +355,8 @@ __global__ __launch_bounds__(BLOCK) void k_film_tiled2(DevScene S, RenderConst r
     }
     if (invalid) atomicAdd(invalidCount, invalid);
 }
+
+#endif  /* PHIP_EXPERIMENTS */
 
 /* ---- round 4: the film as a SPLAT in registers + an ordered merge (filters of reach R <= 2: every default of the reference) ----
  * The gathers above read each staged sample 25 times out of LDS (one per destination pixel under its footprint), stage 1.56 source

@@ -136,6 +136,7 @@ struct ShadowSource {
     }
 };
 
+#if PHIP_EXPERIMENTS      /* the BVH4 ray kernels of rounds 1-2 for big trees (the product walks the compressed wide tree: k_wide.h); A/B builds only */
 #ifndef TRACE_P_WAVES
 #define TRACE_P_WAVES 5
 #endif
@@ -247,6 +248,8 @@ template <bool TYPED> __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_
     waveStat(P, ST_TRI, waveId, triTests);
 }
 
+#endif  /* PHIP_EXPERIMENTS */
+
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, PathPool P, float4 *L) {
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
     waveStat(P, ST_TRI, waveId, triTests);
 }
 
+#if PHIP_EXPERIMENTS      /* one lane per shadow-queue entry (PHIP_TRAVERSAL=lane) */
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathPool P, float4 *L) {
     if (P.blockDead[blockIdx.x]) return;
     TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
@@ -313,6 +317,8 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathP
         waveStat(P, ST_SH_TRI, waveId, triTests);
     }
 }
+
+#endif
 
 /* standalone ray casts for phip_trace */
 __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {

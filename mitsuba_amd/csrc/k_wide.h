@@ -571,6 +571,8 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
         }
     }
 }
+#elif !PHIP_EXPERIMENTS
+#error "WIDE_DEAL=0 (the flat / nested loops of rounds 2-3) is an experiment build: add -DPHIP_EXPERIMENTS=1"
 #elif WIDE_FLAT
 /* The loop is flat: every pass tests the refill condition (two scalar instructions on the ballot of the idle lanes) and then runs one
    traversal iteration -- one node step, one triangle test, one pop -- for the lanes that have a ray.  The nested form (an inner loop the

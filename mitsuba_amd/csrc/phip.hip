@@ -47,6 +47,11 @@
 /* ======================================================================================
  *  error handling
  * ====================================================================================== */
+/* Environment: the shipped library reads PHIP_DEBUG_TIMING (host-side phase times on stderr), PHIP_MAX_PASS_SAMPLES (the sample-buffer budget: the tests force several
+   passes with it) and the builder parameters PHIP_BVH_* (bvh.h) -- nothing that selects an algorithm.  Every switch an A/B row of profiles/ was made with is
+   read by experiment builds only (-DPHIP_EXPERIMENTS=1, tools/build_variant.sh): in the product expEnv() is a constant and its names are not even
+   in the binary. */
+static inline const char *expEnv(const char *name) { return PHIP_EXPERIMENTS ? getenv(name) : nullptr; }
 static thread_local std::string g_err;
 static int setErr(int code, const std::string &msg) { g_err = msg; return code; }
 
@@ -505,9 +510,9 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (texTexels.empty()) sd.texTexels.alloc(1); else sd.texTexels.upload(texTexels.data(), texTexels.size());
     if (texDesc.empty()) sd.texDesc.alloc(1); else sd.texDesc.upload(texDesc.data(), texDesc.size());
     sc->hasTextures = d.n_textures > 0; sc->triShadeStride = stride;
-    if (const char *e = getenv("PHIP_TRAVERSAL")) sc->traversal = strcmp(e, "lane") == 0 ? 0 : 2;
+    if (const char *e = expEnv("PHIP_TRAVERSAL")) sc->traversal = strcmp(e, "lane") == 0 ? 0 : 2;
     sc->wide = sc->traversal == 2 && sc->bvh.nWNodes > 0 && sc->bvh.nNodes >= 64;
-    if (const char *e = getenv("PHIP_WIDE")) sc->wide = sc->wide && atoi(e) != 0;
+    if (const char *e = expEnv("PHIP_WIDE")) sc->wide = sc->wide && atoi(e) != 0;
     /* the stack of the structure that is going to be walked: three pushes per BVH4 level (the wide tree's group stack is checked below) */
     if (!sc->wide && 3 * sc->bvh.maxDepth + 2 > STACK_DEPTH + SPILL_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
     if (sc->wide) {
@@ -533,7 +538,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         if (m.type == PHIP_BSDF_ROUGHCONDUCTOR) sc->materialMask |= MM_ROUGH;
         if (m.type == PHIP_BSDF_DIELECTRIC) sc->materialMask |= MM_DIELECTRIC;
     }
-    if (const char *e = getenv("PHIP_SHADE_GENERIC")) if (atoi(e)) sc->materialMask = MM_ALL;
+    if (const char *e = expEnv("PHIP_SHADE_GENERIC")) if (atoi(e)) sc->materialMask = MM_ALL;
     /* packed emitter table (dv_scene.h: EmitterTab) */
     std::vector<float> tab(ecdf);
     tab.resize(ecdf.size() + (size_t) EM_STRIDE * d.n_emitters, 0.0f);
@@ -674,18 +679,18 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     D.stackDepth = (uint32_t) std::min<int>(STACK_DEPTH, std::max<int>(4, 3 * ((int) sc->bvh.maxDepth - 1) + 1));
     D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, NODE_CACHE_MAX);
     D.triCache = (sc->bvh.tris.size() / 12 <= TRI_CACHE_MAX) ? (uint32_t) (sc->bvh.tris.size() / 12) : 0u;
-    if (const char *e = getenv("PHIP_NODE_CACHE")) D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, (uint32_t) atoi(e));
+    if (const char *e = expEnv("PHIP_NODE_CACHE")) D.nodeCache = std::min<uint32_t>(sc->bvh.nNodes, (uint32_t) atoi(e));
     if (D.nodeCache == 0) D.triCache = 0;
     D.wnodes = sd.wnodes.p; D.wideNodeCache = 0;
     D.preclip = sc->wide ? 1u : 0u;                          /* k_rays_w traverses rays the shading kernels have clipped (k_clip.h) */
     /* the lane deal of k_shade pays where the expensive model is rare: rough conductors (microfacet sampling: atrium, 8 % of the vertices,
        k_shade -7 %); on a diffuse + dielectric mix the extra round trip costs more than the cheap Fresnel branch (glass room: +8 %) */
     D.shadeSort = (sc->wide && (sc->materialMask & MM_ROUGH)) ? 1u : 0u;
-    if (const char *e = getenv("PHIP_SHADE_SORT")) D.shadeSort = D.shadeSort && atoi(e) != 0;       /* experiment hook */
+    if (const char *e = expEnv("PHIP_SHADE_SORT")) D.shadeSort = D.shadeSort && atoi(e) != 0;       /* experiment hook */
     if (sc->wide) {
         D.nodeCache = 0; D.triCache = 0;
         D.wideNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, WIDE_NODE_CACHE_MAX);
-        if (const char *e = getenv("PHIP_NODE_CACHE")) D.wideNodeCache = std::min<uint32_t>(D.wideNodeCache, (uint32_t) atoi(e));
+        if (const char *e = expEnv("PHIP_NODE_CACHE")) D.wideNodeCache = std::min<uint32_t>(D.wideNodeCache, (uint32_t) atoi(e));
         if ((int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS + SPILL_DEPTH / 2) throw std::runtime_error("wide BVH too deep for the traversal stack");
     }
     for (int a = 0; a < 3; ++a) { D.sceneMin[a] = sc->bvh.sceneMin[a]; D.sceneMax[a] = sc->bvh.sceneMax[a]; }
@@ -712,7 +717,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
        every leaf box in one uniform pass instead of walking the 7-node tree (k_traverse.h: traverseFlat).  Entry = (min.xyz, bits(leaf
        reference)) (max.xyz, 0), boxes as the BVH4 nodes hold them (padded). */
     D.nFlatLeaves = 0; D.flatMode = 0; sd.flatLeaves.alloc(2); D.flatLeaves = sd.flatLeaves.p;
-    if (treeInLds && !sc->wide && sc->bvh.nLeaves <= FLAT2_LEAVES_MAX && !getenv("PHIP_NO_FLAT")) {
+    if (treeInLds && !sc->wide && sc->bvh.nLeaves <= FLAT2_LEAVES_MAX && !expEnv("PHIP_NO_FLAT")) {
         std::vector<float4> flat;
         if (sc->bvh.rootRef < 0) {                         /* a single leaf: its box is the scene's */
             flat.push_back(make_float4(sc->bvh.tightMin[0] - 1.0f, sc->bvh.tightMin[1] - 1.0f, sc->bvh.tightMin[2] - 1.0f, pm_from_bits((uint32_t) sc->bvh.rootRef)));
@@ -732,8 +737,8 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
            Round 5: 33..64 records keep the packed form with a two-word mask (flatMode 3; the centre / half-extent table of the dealt
            traversal only -- the high word rides in the centre's spare word) */
         const size_t nRec = sc->bvh.tris.size() / 12;
-        const size_t packedMax = (MEGA_FLAT_CH && MEGA_BALANCE && !getenv("PHIP_NO_FLAT3")) ? 64 : 32;
-        if (flat.size() / 2 <= FLAT2_LEAVES_MAX && nRec <= packedMax && !getenv("PHIP_NO_FLAT2")) {
+        const size_t packedMax = (MEGA_FLAT_CH && MEGA_BALANCE && !expEnv("PHIP_NO_FLAT3")) ? 64 : 32;
+        if (flat.size() / 2 <= FLAT2_LEAVES_MAX && nRec <= packedMax && !expEnv("PHIP_NO_FLAT2")) {
             std::vector<uint32_t> firstCopy(nRec);
             for (size_t i = 0; i < nRec; ++i) {
                 firstCopy[i] = (uint32_t) i;
@@ -776,9 +781,9 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
             D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
         }
     }
-    sc->flatTrace = !sc->fitsLds && D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !getenv("PHIP_NO_SHADE_TRACE");
+    sc->flatTrace = !sc->fitsLds && D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !expEnv("PHIP_NO_SHADE_TRACE");
     /* ... whose lanes are dealt by BSDF model where there is more than one (the kernel traces its own rays and leaves the class in the hit word) */
-    if (sc->flatTrace && sc->materialMask != 0) { D.shadeSort = 1u; if (const char *e = getenv("PHIP_SHADE_SORT")) D.shadeSort = atoi(e) != 0 ? 1u : 0u; }
+    if (sc->flatTrace && sc->materialMask != 0) { D.shadeSort = 1u; if (const char *e = expEnv("PHIP_SHADE_SORT")) D.shadeSort = atoi(e) != 0 ? 1u : 0u; }
     sd.counters.alloc(1);
     sd.invalid.alloc(1);
     sd.dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
@@ -1056,7 +1061,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     if (!stream) { if (!sd.stream) HIP_TRY(hipStreamCreate(&sd.stream)); stream = sd.stream; }
 
     /* passes: bound the per-sample buffer (16 B per sample id; 24 B with the jitter the sequence samplers keep for the film pass) */
-    const bool keepJitter = (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY) && !getenv("PHIP_NO_JITTER_BUFFER");
+    const bool keepJitter = (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY) && !expEnv("PHIP_NO_JITTER_BUFFER");
     const unsigned long long tilePixels = (unsigned long long) bs * bs;
     const unsigned long long maxIdsPerPass = (1ull << 32) - 1;                 /* sample ids are 32-bit in the slot state */
     unsigned long long budgetIds = (24ull << 30) / (keepJitter ? 24 : 16);    /* 24 GiB of sample buffer */
@@ -1128,13 +1133,13 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         }
         sd.rinvKey = rinvKey;
     }
-    if (const char *e = getenv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
+    if (const char *e = expEnv("PHIP_MEGA")) fused = fused && atoi(e) != 0;            /* experiment hook: PHIP_MEGA=0 forces the wavefront kernels */
     /* resident blocks of the fused kernel for THIS render (the QMC build has ~15 KB more static LDS than the plan of fitsLds priced at scene
        creation): when none fits a compute unit the render runs on the wavefront kernels, as it did before the samplers moved to k_mega */
     int megaPerCU = 0;
     if (fused) {
         megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, qmc, megaLdsBytesOf(D)));
-        if (const char *e = getenv("PHIP_MEGA_BLOCKS")) megaPerCU = std::max(1, std::min(megaPerCU, atoi(e)));
+        if (const char *e = expEnv("PHIP_MEGA_BLOCKS")) megaPerCU = std::max(1, std::min(megaPerCU, atoi(e)));
         if (megaPerCU <= 0) fused = false;
     }
     sd.fused = fused;
@@ -1178,7 +1183,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         /* traversal-stack overflow: SPILL_DEPTH words per LANE of a ray kernel -- the wide tree is only walked by persistent grids
            (at most 8 resident blocks of 256 per CU), the BVH4 also by one-lane-per-slot launches */
         const bool canSpill = sc->wide ? (int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS : 3 * ((int) sc->bvh.maxDepth - 1) + 1 > (int) D.stackDepth;
-        const bool persistentOnly = sc->wide || (sc->traversal == 2 && sc->bvh.nNodes >= 64 && !getenv("PHIP_MERGED"));
+        const bool persistentOnly = sc->wide || (sc->traversal == 2 && sc->bvh.nNodes >= 64 && !expEnv("PHIP_MERGED"));
         {   /* ... and with the memory that is there: the pool's state is ~144 B per slot (+ 384 B of spill stack where every slot is a lane that can
                spill); it may take a quarter of what is free now (a shared or partitioned GPU, n_devices replicas), never less than the 4 M slots
                every job ran with before the pool grew */
@@ -1189,7 +1194,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             }
         }
         capacity = (capacity + BLOCK - 1) / BLOCK * BLOCK;
-        if (const char *e = getenv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
+        if (const char *e = expEnv("PHIP_POOL")) { capacity = (uint32_t) std::max(BLOCK, atoi(e)) / BLOCK * BLOCK; }
         const size_t laneCap = ((size_t) capacity + WIDE_BLOCK - 1) / WIDE_BLOCK * WIDE_BLOCK;      /* k_rays_w runs whole blocks of WIDE_BLOCK lanes */
         nWaves = (uint32_t) (laneCap / 64); nBlocks = capacity / BLOCK;
         if (sd.rayO.n < capacity) {
@@ -1213,7 +1218,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         /* big trees: closest-hit and any-hit rays share one persistent launch (measured +2..4 % on the 250k-triangle scenes;
            on small trees the plain per-slot closest-hit launch wins, so the kernels stay separate there) */
         merged = sc->traversal == 2 && sc->bvh.nNodes >= 64;
-        if (const char *e = getenv("PHIP_MERGED")) merged = sc->traversal == 2 && atoi(e) != 0;
+        if (const char *e = expEnv("PHIP_MERGED")) merged = sc->traversal == 2 && atoi(e) != 0;
         if (sc->wide) merged = true;                             /* the wide tree has the merged kernel only */
     }
     sd.mergedRays = merged;
@@ -1234,10 +1239,16 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     };
     const dim3 grid((capacity + BLOCK - 1) / BLOCK);
     const dim3 pgrid = persistentGrid((const void *) k_shadow_p, TRACE_WAVES);
+#if PHIP_EXPERIMENTS
     const dim3 pgridTrace = persistentGrid(sc->bvh.nNodes >= 64 ? (const void *) k_trace_p<false> : (const void *) k_trace_p<true>, TRACE_P_WAVES);
+#endif
     /* k_rays_w: blocks of WIDE_BLOCK threads with their own LDS plan (one block per CU holds 800 nodes of the tree) */
     const size_t wideLds = sc->wide ? wideLdsBytes(D.wideNodeCache, WIDE_BLOCK) + wideDealBytes(WIDE_BLOCK) : 0;
-    dim3 pgridRays = persistentGrid((const void *) k_rays_p, RAYS_WAVES);
+#if PHIP_EXPERIMENTS
+    dim3 pgridRays = persistentGrid((const void *) k_rays_p, RAYS_WAVES);       /* (PHIP_WIDE=0: the BVH4 ray kernels of rounds 1-2 on the big scenes) */
+#else
+    dim3 pgridRays(1);
+#endif
     if (sc->wide) {
         if (wideLds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) k_rays_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int) wideLds));
         int n = 0;
@@ -1246,7 +1257,9 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         if (n <= 0) n = 1;
         pgridRays = dim3((unsigned) std::max(1, std::min<int>(nCU * n, (int) ((capacity + WIDE_BLOCK - 1) / WIDE_BLOCK))));
     }
-    const bool forcePersist = getenv("PHIP_TRACE_PERSIST") != nullptr;   /* experiment hook */
+#if PHIP_EXPERIMENTS
+    const bool forcePersist = expEnv("PHIP_TRACE_PERSIST") != nullptr;
+#endif
 
     /* fused path: resident grid and per-wave statistics rows */
     dim3 megaGrid(1); MegaParams M; memset(&M, 0, sizeof(M));
@@ -1274,7 +1287,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             rc.sobol.matrices = sd.sobolMat.p; rc.sobol.vdc = (const uint64_t *) sd.sobolVdc.p; rc.sobol.vdcInv = (const uint64_t *) sd.sobolVdc.p + PHIP_SOBOL_MATRIX_SIZE;
             rc.sobol.dims = p->sobol_dimensions; rc.sobol.logRes = p->sobol_log_resolution; rc.sobol.scramble = (uint32_t) p->sobol_scramble;
             rc.sobol.resolution = (float) (1u << p->sobol_log_resolution);
-            if (!(PHIP_EXPERIMENTS && getenv("PHIP_SOBOL_BITWISE"))) {      /* (experiment builds, A/B: the row-by-row loops of sobolseq.h -- the product's device code has the byte tables only) */
+            if (!(PHIP_EXPERIMENTS && expEnv("PHIP_SOBOL_BITWISE"))) {      /* (experiment builds, A/B: the row-by-row loops of sobolseq.h -- the product's device code has the byte tables only) */
                 rc.sobol.matBt = sd.sobolBt.p;
                 rc.sobol.vdcBt = (const uint64_t *) sd.sobolVdcBt.p; rc.sobol.vdcInvBt = (const uint64_t *) sd.sobolVdcBt.p + 4u * 256u;
             }
@@ -1288,7 +1301,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             RinvTab &T = rc.rinv;
             T.primes = sd.rinvPrimes.p; T.perm = p->qmc_permutations ? sd.rinvPerm.p : nullptr; T.permOffset = sd.rinvOffsets.p; T.dims = p->qmc_dimensions;
             T.invPerm2 = sd.rinvInvPerm2; T.invPerm3 = sd.rinvInvPerm3;
-            if (sd.rinvTabDims && !getenv("PHIP_RINV_DIGITWISE")) {     /* (A/B: the digit-by-digit loops of qmc.cpp) */
+            if (sd.rinvTabDims && !expEnv("PHIP_RINV_DIGITWISE")) {     /* (A/B: the digit-by-digit loops of qmc.cpp) */
                 T.dimInfo = sd.rinvDimInfo.p; T.chunk = sd.rinvChunk.p; T.fac = sd.rinvFac.p; T.pw = sd.rinvPw.p; T.tabDims = sd.rinvTabDims;
             }
             const uint32_t res[2] = { (uint32_t) D.film.width, (uint32_t) D.film.height };
@@ -1351,7 +1364,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             {
                 const unsigned long long perSlot = rc.totalIds / capacity;
                 unsigned long long staticPerSlot = perSlot - perSlot / 4;
-                if (const char *e = getenv("PHIP_STATIC_PERCENT")) staticPerSlot = perSlot * (unsigned long long) atoi(e) / 100;
+                if (const char *e = expEnv("PHIP_STATIC_PERCENT")) staticPerSlot = perSlot * (unsigned long long) atoi(e) / 100;
                 rc.staticIds = staticPerSlot * capacity;
                 const unsigned long long dyn = rc.totalIds - rc.staticIds;
                 rc.shardIds = (dyn + DYN_SHARDS - 1) / DYN_SHARDS;
@@ -1390,17 +1403,24 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                         HIP_TRY(hipMemsetAsync(sd.drawCounters.p, 0, 2 * RAY_SHARDS * RAY_SHARD_STRIDE * sizeof(unsigned int), stream));
                         hipLaunchKernelGGL(k_rays_w, pgridRays, dim3(WIDE_BLOCK), wideLds, stream, D, P, sd.L.p, sd.drawCounters.p);
                     }
+#if PHIP_EXPERIMENTS
                     else hipLaunchKernelGGL(k_rays_p, pgridRays, block, ldsBytes, stream, D, P, sd.L.p);
+#endif
                     if (timing) evTrace.record(stream);
                 } else {
                     if (timing) evShadow.record(stream);
-                    if (sc->traversal == 2) hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sd.L.p);
-                    else hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sd.L.p);
+#if PHIP_EXPERIMENTS
+                    if (sc->traversal != 2) hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sd.L.p); else
+#endif
+                    hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sd.L.p);
                     if (timing) evShadow.record(stream);
                     if (timing) evTrace.record(stream);
+#if PHIP_EXPERIMENTS
                     if (sc->traversal == 2 && sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p<false>, pgridTrace, block, ldsBytes, stream, D, P);
                     else if (sc->traversal == 2 && forcePersist) hipLaunchKernelGGL(k_trace_p<true>, pgridTrace, block, ldsBytes, stream, D, P);
-                    else hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);     /* tiny trees: the plain per-slot launch wins (measured) */
+                    else
+#endif
+                    hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);     /* tiny trees (the only ones off the wide tree): the plain per-slot launch wins (measured) */
                     if (timing) evTrace.record(stream);
                 }
                 ++iter;
@@ -1434,8 +1454,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             const dim3 fg((W + 15) / 16, (H + 15) / 16);
             const int reach = (int) std::floor(D.film.radius + 0.5f);
             const int acc = (sppDone > 0 || accumulate) ? 1 : 0;
-            const char *fv = getenv("PHIP_FILM_V1");                  /* experiment hook: the round-2 tiled kernel */
-            const bool splat = reach <= 2 && tileShift >= 4 && bs == (1 << tileShift) && nLocalTiles > 0 && !getenv("PHIP_FILM_GATHER");     /* PHIP_FILM_GATHER: the tiled gathers of rounds 2 / 3 (A/B) */
+            const char *fv = expEnv("PHIP_FILM_V1"); (void) fv;       /* experiment hook: the round-2 tiled kernel */
+            const bool splat = reach <= 2 && tileShift >= 4 && bs == (1 << tileShift) && nLocalTiles > 0 && !expEnv("PHIP_FILM_GATHER");     /* PHIP_FILM_GATHER: the tiled gathers of rounds 2 / 3 (A/B) */
             if (splat) {
                 /* round 4: one pass over L with the footprint sums in registers, then an ordered merge of the 16 x 16 patch images (k_film.h) */
                 const int r = std::max(reach, 1), cells = (16 + 2 * r) * (16 + 2 * r) * 5;
@@ -1451,12 +1471,15 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             } else if (qmc)
                 hipLaunchKernelGGL(k_film<true>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
                                    acc, sd.invalid.p);
-            else if (reach <= 2 && bs >= FILM_TILE + 2 * std::max(reach, 1) && !getenv("PHIP_FILM_GENERIC") && !(fv && atoi(fv))) {
+#if PHIP_EXPERIMENTS
+            else if (reach <= 2 && bs >= FILM_TILE + 2 * std::max(reach, 1) && !expEnv("PHIP_FILM_GENERIC") && !(fv && atoi(fv))) {
                 if (reach <= 1)
                     hipLaunchKernelGGL(k_film_tiled2<1>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut, acc, sd.invalid.p);
                 else
                     hipLaunchKernelGGL(k_film_tiled2<2>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut, acc, sd.invalid.p);
-            } else if (reach <= FILM_MAX_REACH && !getenv("PHIP_FILM_GENERIC"))
+            }
+#endif
+            else if (reach <= FILM_MAX_REACH && !expEnv("PHIP_FILM_GENERIC"))
                 if (reach <= 2)
                     hipLaunchKernelGGL(k_film_tiled<2>, fg, block, 0, stream, D, rc, (const float4 *) sd.L.p, (const int32_t *) sd.tileSlot.p, tilesX, dOut,
                                        acc, sd.invalid.p, reach);

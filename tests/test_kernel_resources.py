@@ -77,8 +77,9 @@ def test_shading_kernels_of_the_metric_configurations_keep_their_waves():
     """k_shade of scenes without environment emitter / textures (FEAT bits 2 and 4: LDS-addressed tables) runs five waves per SIMD where more than one BSDF
     model is present (SHADE_WAVES_PLAIN; <= 96 VGPRs, its LDS of 28.5 KB admits five blocks per CU) and the lean diffuse instantiation fits 88.  Scratch is
     bounded: the allocator may park a few dwords outside the vertex's hot path, not more (HISTORY.md 3.4: k_shade forced to more waves with spills lost)."""
-    flags = next(u[1] for u in _ffi.UNITS if u[2] == "phip_shade0.o")
-    res = resources("phip_shade.hip", flags)
+    res = {}
+    for part in (0, 1):                                             # k_shade without / with strictNormals: two objects of the feature set
+        res.update(resources("phip_shade.hip", next(u[1] for u in _ffi.UNITS if u[2] == "phip_shade0_%d.o" % part)))
     seen = 0
     for name, v in res.items():
         m = re.match(r"_Z7k_shadeILi(\d)ELb([01])ELi(\d+)E", name)
@@ -100,3 +101,15 @@ def test_film_splat_keeps_its_accumulators_in_registers():
     assert k["scratch"] == 0 and k["vgprs"] <= 256, k
     k1 = next(v for name, v in res.items() if name.startswith("_Z12k_film_splatILi1ELb0E"))
     assert k1["scratch"] == 0, k1
+
+
+def test_vertex_and_rays_kernel_of_the_small_scenes_keeps_five_waves():
+    """k_shade_trace (round 5: vertex + shadow ray + next ray per slot and launch, scenes on the packed leaf table that k_mega does not serve): 96 VGPRs = five
+    waves per SIMD (measured +7 % over four on the mixed Cornell box), its static LDS -- the exchange buffer of the class deal, which the dealt traversals
+    reuse -- leaves room for five blocks per CU beside ~6 KB of tables"""
+    res = resources("phip_shade.hip", next(u[1] for u in _ffi.UNITS if u[2] == "phip_shade0_3.o"))
+    ks = {n: v for n, v in res.items() if n.startswith("_Z13k_shade_trace")}
+    assert len(ks) == 4, list(ks)
+    for name, v in ks.items():
+        assert v["vgprs"] <= 96 and v["scratch"] <= 48, (name, v)
+        assert 5 * (v["lds"] + 8 * 1024) <= 160 * 1024, (name, v)
