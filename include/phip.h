@@ -238,7 +238,10 @@ typedef enum phip_sampler_kind {
 /* which SamplingIntegrator::Li the call evaluates */
 typedef enum phip_integrator_kind {
     PHIP_INTEGRATOR_PATH = 0,    /* MIPathTracer, src/integrators/path/path.cpp:119-300                                     */
-    PHIP_INTEGRATOR_DIRECT = 1   /* MIDirectIntegrator, src/integrators/direct/direct.cpp:149-312 (max_depth / rr_depth unused) */
+    PHIP_INTEGRATOR_DIRECT = 1,  /* MIDirectIntegrator, src/integrators/direct/direct.cpp:149-312 (max_depth / rr_depth unused) */
+    PHIP_INTEGRATOR_VOLPATH_SIMPLE = 2   /* SimpleVolumetricPathTracer on a scene WITHOUT participating media, src/integrators/path/volpath_simple.cpp:88-318: the path tracer
+                                            without multiple importance sampling (parameters as PHIP_INTEGRATOR_PATH).  Media are not part of the scene description: the
+                                            plugin shim refuses a scene that has any (mitsuba_amd/plugin/volpath_simple_hip.cpp) */
 } phip_integrator_kind;
 
 #define PHIP_MAX_DEVICES 16

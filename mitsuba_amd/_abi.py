@@ -18,7 +18,7 @@ PHIP_SAMPLER_STRATIFIED = 3
 PHIP_SAMPLER_HALTON = 4
 PHIP_SAMPLER_HAMMERSLEY = 5
 PHIP_SOBOL_MATRIX_SIZE = 52
-PHIP_INTEGRATOR_PATH, PHIP_INTEGRATOR_DIRECT = 0, 1
+PHIP_INTEGRATOR_PATH, PHIP_INTEGRATOR_DIRECT, PHIP_INTEGRATOR_VOLPATH_SIMPLE = 0, 1, 2
 PHIP_FLAG_KERNEL_TIMING = 1
 PHIP_FLAG_SAMPLE_BUFFER = 2
 PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND = 4

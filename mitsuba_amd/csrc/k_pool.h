@@ -102,6 +102,7 @@ struct RenderConst {
     int emitterSamples, bsdfSamples;
     float fracLum, fracBSDF, weightLum, weightBSDF;
     uint32_t envFiltered;             /* camera rays that miss use the envmap's EWA lookup (pyramid present) */
+    uint32_t volpath;                 /* PHIP_INTEGRATOR_VOLPATH_SIMPLE: shadeVertex runs volpath_simple's loop (k_shade.h) */
     const uint32_t *tileOrigin;       /* per local tile: x | y << 16 (crop-relative) */
     uint32_t countAlive;              /* this iteration records the number of live slots */
     uint32_t draining;                /* some slots of the pool have died (the host has seen a live count below the capacity): the shading kernels test their block's retired flag before anything else */

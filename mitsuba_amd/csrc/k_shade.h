@@ -14,6 +14,9 @@ __device__ __forceinline__ float miWeight(float pdfA, float pdfB) {
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
+#ifndef SHADE_STAGE_DUMMY
+#define SHADE_STAGE_DUMMY 0         /* A/B: 1 = the FEAT-16 kernels (materials in memory) issue the two look-alike staging loads of the materials as before round 5 */
+#endif
 #ifndef SHADE_WAVES_PLAIN
 #define SHADE_WAVES_PLAIN 5         /* scenes with more than one BSDF model but no environment emitter and no textures (the other instantiations spill
                                        100-200 B per lane at this bound): 95-102 VGPRs without the bound, 96 + 12..28 B of scratch with it.  The kernel waits
@@ -205,11 +208,43 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
     bool haveAdd = false;                  /* radiance to add to the sample's accumulator (in reference order) */
     float4 l = make_float4(0, 0, 0, 0);
     newRay = false; pushShadow = false;
+    /* VP: the sibling integrator `volpath_simple` on a scene without media (src/integrators/path/volpath_simple.cpp:88-318; round 5): the same
+       loop without multiple importance sampling -- emitted radiance counts at the first vertex and behind a delta bounce only (:186-188, 246-255), the emitter
+       sample is weighted by the BSDF value alone (:207-227), Russian roulette is evaluated before the loop looks at the next hit (:282-292).  A uniform branch. */
+    const bool VP = rc.volpath != 0;
+    /* Russian roulette: the end of a loop iteration (path.cpp:278-286 = volpath_simple.cpp:282-292), evaluated by the vertex the iteration's ray arrived at */
+    auto russianRoulette = [&]() {
+        if (depth++ >= (uint32_t) rc.rrDepth) {
+            float q = smin(thr.maxc() * eta * eta, 0.95f);
+            /* the (depth - 1 - rrDepth)-th 1D request of the sample (path.cpp:283) */
+            float rr;
+            if (rc.sampler == PHIP_SAMPLER_LD && depth - 1u - (uint32_t) rc.rrDepth < LD_DIMENSIONS) {
+                float unused; ldPoint(v.pixel, v.k, 2u * (depth - 1u - (uint32_t) rc.rrDepth) + 1u, rc.seed, rc.ldMask, rr, unused);
+            } else
+                rr = u32ToFloat(pcg4d(v.pixel, v.k, 2 + 2 * (depth - 2), rc.seed).x);
+            if (QMC) {
+                /* the (depth - 1 - rrDepth)-th 1D request of the sample.  sobol: its dimension is two per 2D request made so far (the camera
+                   sample and the kq requests of the vertices behind) plus one per earlier 1D request (SobolSampler::next1D, sobol.cpp:226-236) */
+                const uint32_t j = depth - 1u - (uint32_t) rc.rrDepth, kq = 2u * (depth - 1u) - (flags >> NS_SHIFT);
+                if (isSequenceSampler(rc.sampler)) {
+                    const uint32_t dim = 2u * (1u + kq) + j + 1u;      /* (+ 1: SobolSampler::next2D skips dimension 4, see the vertex's requests below) */
+                    if (dim < seqDims(rc)) rr = seqSample(rc, acc.seqIdx(rc, v, (uint32_t) S.film.width), dim);
+                } else if (rc.sampler == PHIP_SAMPLER_STRATIFIED && j < ST_DIMENSIONS)
+                    rr = stPoint1D(v.pixel, v.k, j, rc.seed, rc.stRes, rr);
+            }
+            if (rr >= q)
+                terminate = true;
+            else
+                thr = thr / q;
+        }
+    };
 
     if (prim == PHIP_NO_HIT) {
+        bool live = true;
+        if (VP && !(flags & F_FIRST)) { russianRoulette(); live = !terminate; }     /* volpath_simple.cpp:282-292 runs before :172-183 sees the miss (path.cpp:233-248 breaks first) */
         terminate = true;
         if (flags & F_FIRST) haveAdd = true;   /* a camera ray that leaves the scene: the sample is (0,0,0, alpha 0) -- written, so the buffer needs no clear */
-        if (ENV && S.envEmitter >= 0) {     /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
+        if (ENV && S.envEmitter >= 0 && live) {     /* environment emitter: path.cpp:136-143 (camera ray) / 233-265 (BSDF-sampled ray) */
             const float *em = emitterRecord(T, (uint32_t) S.envEmitter);
             const V3 value = (pm_to_bits(em[EM_TYPE]) == PHIP_EMITTER_ENVMAP) ? envmapEval(S.env, rayD) : rgb(em + EM_RADIANCE);
             if (flags & F_FIRST) {
@@ -227,6 +262,14 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                         bg = envmapEvalDiff(S.env, rayD, rx, ry);
                     }
                     l.x += bg.x; l.y += bg.y; l.z += bg.z;
+                }
+            } else if (VP) {
+                /* volpath_simple.cpp:172-183: throughput * evalEnvironment(ray), when this ray may see emitters at all */
+                if ((flags & F_EMITTED) && (!rc.hideEmitters || (flags & F_SCATTERED))) {
+                    const V3 c = thr * value;
+                    l = acc.load(id);
+                    l.x += c.x; l.y += c.y; l.z += c.z;
+                    haveAdd = true;
                 }
             } else {
                 const float4 ro = acc.rayO(v);
@@ -251,7 +294,10 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             haveAdd = true;
         } else {
             /* ---- tail of the previous loop iteration, path.cpp:257-286 ---- */
-            if (its.emitter >= 0) {
+            if (VP) {
+                /* (the head below adds the emitter's radiance with weight one when F_EMITTED says so; the accumulator is read there) */
+                if (its.emitter >= 0 && (flags & F_EMITTED)) l = acc.load(id);
+            } else if (its.emitter >= 0) {
                 l = acc.load(id);
                 const float *em = emitterRecord(T, (uint32_t) its.emitter);
                 V3 value = (dot(its.sh.n, -rayD) <= 0) ? V3(0.0f) : rgb(em + EM_RADIANCE);
@@ -262,30 +308,8 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 l.x += c.x; l.y += c.y; l.z += c.z;
                 haveAdd = true;
             }
-            flags &= ~F_EMITTED;
-            if (depth++ >= (uint32_t) rc.rrDepth) {
-                float q = smin(thr.maxc() * eta * eta, 0.95f);
-                /* the (depth - 1 - rrDepth)-th 1D request of the sample (path.cpp:283) */
-                float rr;
-                if (rc.sampler == PHIP_SAMPLER_LD && depth - 1u - (uint32_t) rc.rrDepth < LD_DIMENSIONS) {
-                    float unused; ldPoint(v.pixel, v.k, 2u * (depth - 1u - (uint32_t) rc.rrDepth) + 1u, rc.seed, rc.ldMask, rr, unused);
-                } else
-                    rr = u32ToFloat(pcg4d(v.pixel, v.k, 2 + 2 * (depth - 2), rc.seed).x);
-                if (QMC) {
-                    /* the (depth - 1 - rrDepth)-th 1D request of the sample.  sobol: its dimension is two per 2D request made so far (the camera
-                       sample and the kq requests of the vertices behind) plus one per earlier 1D request (SobolSampler::next1D, sobol.cpp:226-236) */
-                    const uint32_t j = depth - 1u - (uint32_t) rc.rrDepth, kq = 2u * (depth - 1u) - (flags >> NS_SHIFT);
-                    if (isSequenceSampler(rc.sampler)) {
-                        const uint32_t dim = 2u * (1u + kq) + j + 1u;      /* (+ 1: SobolSampler::next2D skips dimension 4, see the vertex's requests below) */
-                        if (dim < seqDims(rc)) rr = seqSample(rc, acc.seqIdx(rc, v, (uint32_t) S.film.width), dim);
-                    } else if (rc.sampler == PHIP_SAMPLER_STRATIFIED && j < ST_DIMENSIONS)
-                        rr = stPoint1D(v.pixel, v.k, j, rc.seed, rc.stRes, rr);
-                }
-                if (rr >= q)
-                    terminate = true;
-                else
-                    thr = thr / q;
-            }
+            if (!VP) flags &= ~F_EMITTED;           /* rRec.type = ERadianceNoEmission (volpath_simple: the previous vertex decided, see below) */
+            russianRoulette();
         }
         const bool firstVertex = (flags & F_FIRST) != 0;
         flags &= ~F_FIRST;
@@ -301,7 +325,10 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 l.x += c.x; l.y += c.y; l.z += c.z;
                 haveAdd = true;
             }
-            if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
+            if (VP) {
+                if (STRICT && dot(rayD, its.geoN) * cosTheta(its.wi) > 0)      /* volpath_simple.cpp:194-198: wiDotGeoN * wiDotShN < 0 with wiDotGeoN = -dot(n, d) */
+                    terminate = true;
+            } else if (((int) depth >= rc.maxDepth && rc.maxDepth > 0)
                 || (STRICT && dot(rayD, its.geoN) * cosTheta(its.wi) >= 0))
                 terminate = true;
         }
@@ -311,7 +338,10 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                pair k & 1 (.xy / .zw) of block 1 + 2 (k >> 1).  A vertex with a smooth BSDF makes two requests (emitter sample, BSDF
                sample), a vertex without one; k0 = 2 (depth - 1) - ns is this vertex's first, ns = the non-smooth vertices so far
                (bits 26..31 of the state word, modulo 64).  All-smooth paths: k0 is even and both pairs come from one block. */
-            const bool smoothVertex = (its.flags & TS_MF_SMOOTH) != 0;
+            /* volpath_simple: at depth == maxDepth the query is EEmittedRadiance alone (:239-261 on the vertex before, :103-104 for maxDepth 1): no emitter sample is
+               drawn there, the vertex makes the BSDF request only */
+            const bool directHere = !(VP && rc.maxDepth > 0 && (int) depth >= rc.maxDepth);
+            const bool smoothVertex = (its.flags & TS_MF_SMOOTH) != 0 && directHere;
             const uint32_t k0 = 2u * (depth - 1u) - (flags >> NS_SHIFT);
             U4 h = pcg4d(v.pixel, v.k, 1 + 2 * (k0 >> 1), rc.seed);
             if (k0 & 1u) {
@@ -385,15 +415,15 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                 }
                 bsdfTextures(S, bctx, its.uv, firstVertex, dudx, dudy, dvdx, dvdy);
             }
-            if (its.flags & TS_MF_SMOOTH) {
+            if (smoothVertex) {
                 V3 value = sampleEmitterDirect<ENV>(S, T, dRec, smpEmitter);
                 if (dRec.pdf != 0 && !value.isZero()) {
                     const V3 wo = its.sh.toLocal(dRec.d);
                     float bPdf;
                     const V3 bsdfVal = bsdfEvalPdf<MM>(bctx, wo, bPdf);
                     if (!bsdfVal.isZero() && (!STRICT || dot(its.geoN, dRec.d) * cosTheta(wo) > 0)) {
-                        const float weight = miWeight(dRec.pdf, bPdf);
-                        shC = thr * value * bsdfVal * weight;
+                        if (VP) shC = thr * value * bsdfVal;        /* volpath_simple.cpp:223-225: no MIS */
+                        else { const float weight = miWeight(dRec.pdf, bPdf); shC = thr * value * bsdfVal * weight; }
                         shD = dRec.d; shMaxt = dRec.dist * (1 - PT_SHADOW_EPSILON);
                         pushShadow = true;
                     }
@@ -405,10 +435,19 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
             if (bsdfWeight.isZero()) {
                 terminate = true;
             } else {
+                bool goOn = true;
+                if (VP) {
+                    /* volpath_simple.cpp:239-261: indirect illumination while depth + 1 < maxDepth; emitted radiance behind a delta bounce while depth < maxDepth
+                       and this vertex was asked for direct illumination; nothing of either: the path ends before the ray is traced */
+                    const bool indirect = (int) depth + 1 < rc.maxDepth || rc.maxDepth < 0;
+                    const bool emittedNext = ((int) depth < rc.maxDepth || rc.maxDepth < 0) && directHere && bs.delta;
+                    goOn = indirect || emittedNext;
+                    flags = emittedNext ? (flags | F_EMITTED) : (flags & ~F_EMITTED);
+                }
                 flags |= F_SCATTERED;
                 const V3 wo = its.sh.toWorld(bs.wo);
                 const float woDotGeoN = dot(its.geoN, wo);
-                if (STRICT && woDotGeoN * cosTheta(bs.wo) <= 0) {
+                if (!goOn || (STRICT && woDotGeoN * cosTheta(bs.wo) <= 0)) {
                     terminate = true;
                 } else {
                     v.rayO = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON);
@@ -438,8 +477,11 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
 /* small scene tables are staged in LDS: the emitter table (selection CDF -> emitter -> area CDF is a chain of
    dependent lookups per NEE sample) and the materials (all threads of the block must call; no barrier inside) */
 struct ShadeTables { EmitterTab T; const DevMaterial *materials; };
+/* MATS = false: the caller knows that the materials stay in memory (k_shade with FEAT bit 4: scenes of many materials, the atrium) -- the two look-alike loads
+   that keep the staging branch-free are then two vector-memory instructions per lane for nothing, in a kernel that is bound by their number */
+template <bool MATS = true>
 __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float *ldsEm, DevMaterial *ldsMat) {
-    const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = S.nMaterials <= MATERIAL_LDS_MAX;
+    const bool emInLds = S.emitterTabSize <= EMITTER_LDS_FLOATS, matInLds = MATS && S.nMaterials <= MATERIAL_LDS_MAX;
     /* Both tables are requested before either is stored: ONE memory round trip at the head of a block (the kernels that call this are
        latency bound), not one per table and per loop iteration.  A thread covers the whole staged range with one float4 of the emitter
        table (the host pads it to whole float4s; EMITTER_LDS_FLOATS / 4 = BLOCK) and MAT_F4 of the materials. */
@@ -453,7 +495,8 @@ __device__ __forceinline__ ShadeTables stageShadeTables(const DevScene &S, float
     const uint32_t lastE = nE4 ? nE4 - 1u : 0u, lastM = nM4 ? nM4 - 1u : 0u;
     float4 e = srcE[threadIdx.x < lastE ? threadIdx.x : lastE];
     static_assert(MAT_F4 == 2, "two float4s of the materials per thread (m0, m1)");
-    float4 m0 = srcM[threadIdx.x < lastM ? threadIdx.x : lastM], m1 = srcM[threadIdx.x + BLOCK < lastM ? threadIdx.x + BLOCK : lastM];
+    float4 m0 = make_float4(0, 0, 0, 0), m1 = m0;
+    if (MATS) { m0 = srcM[threadIdx.x < lastM ? threadIdx.x : lastM]; m1 = srcM[threadIdx.x + BLOCK < lastM ? threadIdx.x + BLOCK : lastM]; }
     /* the values are "used" HERE, all at once: without this the compiler sinks every load into the predicated block of its store (load,
        wait, store -- one round trip per table) */
     asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w), "+v"(m0.x), "+v"(m0.y), "+v"(m0.z), "+v"(m0.w), "+v"(m1.x), "+v"(m1.y), "+v"(m1.z), "+v"(m1.w));
@@ -530,7 +573,7 @@ template <int MM, bool STRICT, int FEAT> __global__ __launch_bounds__(BLOCK, MM 
     v.rayD = P.rayD[lslot];
     v.thr = P.thr[lslot];
     v.mis = P.mis[lslot];
-    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    ShadeTables tab = stageShadeTables<(FEAT & 16) == 0 || SHADE_STAGE_DUMMY>(S, ldsEm, ldsMat);
     if (FEAT & 4) { tab.T.t = ldsEm; tab.materials = ldsMat; }     /* the host checked that both tables fit: LDS addressing (ds_read), no flat loads */
     else if (FEAT & 16) {
         /* the emitter table fits, the materials do not (the atrium: 252 materials = 24 KB): the emitter look-ups -- two dozen per NEE sample --

@@ -951,7 +951,7 @@ static bool cancelRequested(const phip_scene *sc) { return __atomic_load_n(sc->c
 
 static void validateParams(const phip_scene *sc, const phip_render_params *p) {
     if (p->spp <= 0) throw std::invalid_argument("spp must be > 0");
-    if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::invalid_argument("unknown integrator kind");
+    if (p->integrator > PHIP_INTEGRATOR_VOLPATH_SIMPLE) throw std::invalid_argument("unknown integrator kind");
     const bool direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
     if (!direct) {
         if (p->rr_depth <= 0) throw std::invalid_argument("'rrDepth' must be set to a value greater than zero!");                       /* integrator.cpp:219-220 */
@@ -1341,6 +1341,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             rc.weightBSDF = rc.weightLum = 1.0f; rc.fracBSDF = rc.fracLum = 0.5f;
         }
         rc.envFiltered = (sc->envLevelCount > 1 && !(p->flags & PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND)) ? 1u : 0u;
+        rc.volpath = p->integrator == PHIP_INTEGRATOR_VOLPATH_SIMPLE ? 1u : 0u;
         rc.staticIds = 0; rc.shardIds = 0; rc.dynCounter = sd.dynCounter.p; rc.blockShard = sd.blockShard.p;
         rc.jitter = keepJitter ? sd.jitter.p : nullptr;
         HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), stream));

@@ -252,3 +252,14 @@ class DirectHIP(PathHIP):
         p.emitter_samples = self.m_emitterSamples
         p.bsdf_samples = self.m_bsdfSamples
         return p
+
+
+class VolPathSimpleHIP(PathHIP):
+    """`volpath_simple_hip` integrator: SimpleVolumetricPathTracer (src/integrators/path/volpath_simple.cpp:88-318) on a scene without participating media --
+    the `path` loop without multiple importance sampling, same parameters (MonteCarloIntegrator: maxDepth, rrDepth, strictNormals, hideEmitters).  The scene
+    description has no media; the Mitsuba plugin shim (mitsuba_amd/plugin/volpath_simple_hip.cpp) refuses a scene that has any."""
+
+    def params(self, scene, spp, seed=0, shard_index=0, shard_count=1, flags=0, stream=None, **extra):
+        p = super().params(scene, spp, seed, shard_index, shard_count, flags, stream, **extra)
+        p.integrator = A.PHIP_INTEGRATOR_VOLPATH_SIMPLE
+        return p

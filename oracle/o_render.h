@@ -19,6 +19,7 @@
  */
 #pragma once
 #include "o_direct.h"
+#include "o_volpath.h"
 #include <thread>
 #include <atomic>
 #include <mutex>
@@ -227,6 +228,7 @@ struct RenderParams {
     int spp = 4, blockSize = 32, threads = 1;
     IntegratorParams ip;
     bool direct = false;                 /* MIDirectIntegrator instead of MIPathTracer */
+    bool volpath = false;                /* SimpleVolumetricPathTracer on a media-free scene (o_volpath.h) */
     DirectParams dp;
     bool ctr = true; uint32_t seed = 0;
     int shardIndex = 0, shardCount = 1;
@@ -298,7 +300,8 @@ inline RenderResult render(const Scene &scene, const RenderParams &rp, float *fi
                     Float alpha;
                     pc.smoothMask = 0;
                     Spectrum spec = rp.direct ? directLi(scene, rp.dp, ray, smp, alpha, &pc, rx, ry)
-                                              : pathLi(scene, rp.ip, ray, smp, alpha, &pc, &rx, &ry);
+                                  : rp.volpath ? volpathSimpleLi(scene, rp.ip, ray, smp, alpha, &pc, &rx, &ry)
+                                               : pathLi(scene, rp.ip, ray, smp, alpha, &pc, &rx, &ry);
                     Float temp[5] = { spec[0], spec[1], spec[2], alpha, 1.0f };
                     if (!blk.put(samplePos, temp)) pc.invalidSamples++;
                     if (maskOut) maskOut[((size_t) py * f.crop_width + px) * rp.spp + j] = pc.smoothMask;

@@ -99,11 +99,12 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
         }
         if (isQmc(p->sampler)) {
             if (sampler_mode != 0) throw std::runtime_error("the QMC samplers: counter-stream mode");
-            if (p->integrator != PHIP_INTEGRATOR_PATH && p->sampler == PHIP_SAMPLER_STRATIFIED) throw std::runtime_error("PHIP_SAMPLER_STRATIFIED: `path` only");
+            if (p->integrator == PHIP_INTEGRATOR_DIRECT && p->sampler == PHIP_SAMPLER_STRATIFIED) throw std::runtime_error("PHIP_SAMPLER_STRATIFIED: `path` only");
             setQmc(scene, p, rp.qmc, rp.sobol, rp.stRes, rp.rinv);
         }
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;
-        if (p->integrator > PHIP_INTEGRATOR_DIRECT) throw std::runtime_error("unknown integrator");
+        rp.volpath = p->integrator == PHIP_INTEGRATOR_VOLPATH_SIMPLE;
+        if (p->integrator > PHIP_INTEGRATOR_VOLPATH_SIMPLE) throw std::runtime_error("unknown integrator");
         if (rp.direct) {
             if (p->emitter_samples < 0 || p->bsdf_samples < 0) throw std::runtime_error("direct: negative sample count");
             rp.dp.emitterSamples = (size_t) p->emitter_samples; rp.dp.bsdfSamples = (size_t) p->bsdf_samples;

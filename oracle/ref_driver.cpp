@@ -447,7 +447,7 @@ int ref_render(void *h, const phip_render_params *p, float *out_samples, float *
         const Vector2i size = film->getCropSize();
         if (size.x > 255 || size.y > 255) throw std::runtime_error("ref_render: at most 255 x 255 pixels (one image block)");
 
-        Properties ip(p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path");
+        Properties ip(p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : p->integrator == PHIP_INTEGRATOR_VOLPATH_SIMPLE ? "volpath_simple" : "path");
         if (p->integrator == PHIP_INTEGRATOR_DIRECT) {
             ip.setSize("emitterSamples", (size_t) p->emitter_samples); ip.setSize("bsdfSamples", (size_t) p->bsdf_samples);
         } else {
@@ -532,7 +532,7 @@ int ref_render_job_plugin(void *h, const phip_render_params *p, const char *inte
                 sched->registerWorker(new LocalWorker(i, formatString("wrk%i", i)));
             sched->start();
         }
-        Properties ip(integrator_plugin ? integrator_plugin : (p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : "path"));
+        Properties ip(integrator_plugin ? integrator_plugin : (p->integrator == PHIP_INTEGRATOR_DIRECT ? "direct" : p->integrator == PHIP_INTEGRATOR_VOLPATH_SIMPLE ? "volpath_simple" : "path"));
         if (p->integrator == PHIP_INTEGRATOR_DIRECT) {
             ip.setSize("emitterSamples", (size_t) p->emitter_samples); ip.setSize("bsdfSamples", (size_t) p->bsdf_samples);
         } else {

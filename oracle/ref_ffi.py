@@ -77,7 +77,7 @@ def build_shims():
 
 
 def have_shims():
-    return all(os.path.exists(os.path.join(HERE, "_ref", "plugins", n + ".so")) for n in ("path_hip", "direct_hip"))
+    return all(os.path.exists(os.path.join(HERE, "_ref", "plugins", n + ".so")) for n in ("path_hip", "direct_hip", "volpath_simple_hip"))
 
 
 def lib():

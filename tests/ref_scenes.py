@@ -260,7 +260,7 @@ def random_scene(gauss, seed, res=(24, 16), mip=None):
     return sb, kw
 
 
-PATH, DIRECT = A.PHIP_INTEGRATOR_PATH, A.PHIP_INTEGRATOR_DIRECT
+PATH, DIRECT, VOLPATH = A.PHIP_INTEGRATOR_PATH, A.PHIP_INTEGRATOR_DIRECT, A.PHIP_INTEGRATOR_VOLPATH_SIMPLE
 
 # (case name, scene builder, render parameters)
 CASES = [
@@ -286,6 +286,20 @@ CASES = [
     ("textures_direct", textures, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=2)),
     ("roughness_maps_path", roughness_maps, dict(spp=2, max_depth=8)),
     ("roughness_maps_direct", roughness_maps, dict(spp=1, integrator=DIRECT, emitter_samples=2, bsdf_samples=2)),
+    # round 5: the sibling integrator `volpath_simple` on media-free scenes (src/integrators/path/volpath_simple.cpp)
+    ("cornell_volpath", cornell, dict(spp=4, max_depth=-1, integrator=VOLPATH)),
+    ("cornell_volpath_rr2", cornell, dict(spp=2, max_depth=-1, rr_depth=2, integrator=VOLPATH)),
+    ("cornell_volpath_md1", cornell, dict(spp=2, max_depth=1, integrator=VOLPATH)),
+    ("cornell_volpath_md2", cornell, dict(spp=2, max_depth=2, integrator=VOLPATH)),
+    ("cornell_volpath_md3", cornell, dict(spp=2, max_depth=3, integrator=VOLPATH)),
+    ("cornell_volpath_hide_strict", cornell, dict(spp=2, max_depth=6, hide_emitters=1, strict_normals=1, integrator=VOLPATH)),
+    ("zoo_volpath", zoo, dict(spp=2, max_depth=8, integrator=VOLPATH)),
+    ("zoo_volpath_strict", zoo, dict(spp=1, max_depth=4, strict_normals=1, integrator=VOLPATH)),
+    ("glass_volpath", glass, dict(spp=2, max_depth=16, integrator=VOLPATH)),
+    ("const_env_volpath", const_env, dict(spp=2, max_depth=6, rr_depth=2, integrator=VOLPATH)),
+    ("const_env_volpath_hide", const_env, dict(spp=1, max_depth=4, hide_emitters=1, strict_normals=1, integrator=VOLPATH)),
+    ("envmap_volpath", envmap, dict(spp=2, max_depth=6, integrator=VOLPATH)),
+    ("textures_volpath", textures, dict(spp=2, max_depth=6, integrator=VOLPATH)),
 ]
 
 

@@ -57,10 +57,11 @@ def test_path_hip_plugin_inside_the_reference(phip, ref, oracle, gauss):
 
 
 def check_scene(ref, name, desc):
-    from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+    from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, VolPathSimpleHIP, HDRFilm
     rs = ref.RefScene(desc)
     gs = Scene(desc)
     for plugin, Integ, kw, rkw, sampler in (("path_hip", PathHIP, dict(maxDepth=6), dict(max_depth=6), "independent"),
+                                           ("volpath_simple_hip", VolPathSimpleHIP, dict(maxDepth=6), dict(max_depth=6, integrator=A.PHIP_INTEGRATOR_VOLPATH_SIMPLE), "independent"),
                                            ("path_hip", PathHIP, dict(maxDepth=6), dict(max_depth=6), "ldsampler"),
                                            ("direct_hip", DirectHIP, dict(emitterSamples=2, bsdfSamples=2),
                                             dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2), "independent"),
@@ -80,8 +81,9 @@ def check_scene(ref, name, desc):
         cpu, _ = rs.render_job(p, threads=8, sampler=sampler)                # the reference's own integrator (and sampler) on the CPU
         dm = abs(img.mean() - cpu.mean()) / cpu.mean()
         print("    vs the reference's CPU %s: mean differs by %.2f %%, rel L2 %.2f" % (plugin.replace("_hip", ""), 100 * dm, rel_l2(img, cpu)))
-        assert dm < 0.08                                                     # small, noisy images (32 spp)
-        assert rel_l2(img, cpu) < 0.6                                        # two independent 32-spp renders
+        noisy = plugin == "volpath_simple_hip"                               # (no multiple importance sampling: fireflies on the atrium's copper at 32 spp)
+        assert dm < (0.12 if noisy else 0.08)                                # small, noisy images (32 spp)
+        assert rel_l2(img, cpu) < (1.2 if noisy else 0.6)                    # two independent 32-spp renders
     rs.close(); gs.close()
 
 

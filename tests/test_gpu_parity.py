@@ -772,6 +772,39 @@ def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
         print("cornell_mixed %s: identical %.6f rel L2 %.3e" % (cfg, same, r))
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(maxDepth=-1), dict(maxDepth=1), dict(maxDepth=2), dict(maxDepth=3), dict(maxDepth=-1, rrDepth=2),
+    dict(maxDepth=6, strictNormals=True), dict(maxDepth=5, hideEmitters=True),
+])
+def test_volpath_simple_cornell_matches_oracle(gpu, oracle, gauss, cfg):
+    """Round 5: the sibling integrator `volpath_simple` on media-free scenes -- PHIP_INTEGRATOR_VOLPATH_SIMPLE, a uniform
+    branch of shadeVertex -- on the fused kernel (and, through compare_render, the wavefront kernels): per-sample identity with the oracle's restatement of
+    volpath_simple.cpp:88-318, which tests/test_ref_pin.py pins on the reference's own plugin"""
+    from mitsuba_amd.integrator import VolPathSimpleHIP
+    desc = S.cornell_box(96, 96, gauss).desc()
+    compare_render(gpu, oracle, desc, 8, integrator=VolPathSimpleHIP, **cfg)
+
+
+def test_volpath_simple_materials_emitters_textures_match_oracle(gpu, oracle, gauss):
+    """... on glass and copper (emitted radiance behind delta bounces: the mixed Cornell box, k_shade_trace), on the big-scene kernels (atrium, glass room), under
+    a constant environment with hideEmitters, on bitmap textures"""
+    from mitsuba_amd.integrator import VolPathSimpleHIP
+    import ref_scenes as RS
+    from test_golden import _golden_mip, G
+    fixture = np.load(os.path.join(G, "ref_renders.npz"))
+    mip_of = lambda scene: _golden_mip(fixture, scene)
+    for name, desc, spp, kw in (("cornell_mixed", S.cornell_mixed(96, 96, gauss).desc(), 8, dict(maxDepth=-1)),
+                                ("cornell_mixed md 4 strict", S.cornell_mixed(96, 96, gauss).desc(), 8, dict(maxDepth=4, strictNormals=True)),
+                                ("atrium", S.atrium(160, 90, gauss).desc(), 4, dict(maxDepth=8)),
+                                ("glass room", S.glass_room(160, 90, gauss).desc(), 4, dict(maxDepth=16)),
+                                ("constant environment", RS.const_env(gauss, None).desc(), 8, dict(maxDepth=6, rrDepth=2)),
+                                ("constant environment, hidden", RS.const_env(gauss, None).desc(), 8, dict(maxDepth=4, hideEmitters=True, strictNormals=True)),
+                                ("envmap", RS.envmap(gauss, mip_of("envmap")).desc(), 4, dict(maxDepth=6)),
+                                ("textures", RS.textures(gauss, mip_of("textures")).desc(), 4, dict(maxDepth=6))):
+        same, r = compare_render(gpu, oracle, desc, spp, min_identical=0.999, integrator=VolPathSimpleHIP, **kw)
+        print("volpath_simple, %s: identical %.6f rel L2 %.3e" % (name, same, r))
+
+
 def test_ray_kernel_work_list_overflow_matches_oracle(gpu, oracle, gauss):
     """k_rays_w deals the triangle tests of an iteration through a work list of 256 pairs per wave (k_wide.h: WIDE_DEAL); lanes whose pairs do not fit wait
     for the next iteration.  A haystack of long overlapping triangles (every leaf group holds many records, every ray enters many leaves) overflows it all the
