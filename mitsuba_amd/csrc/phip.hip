@@ -975,7 +975,8 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
             if (p->qmc_permutations[2] > 2 || p->qmc_permutations[3] > 2 || p->qmc_permutations[4] > 2) throw std::invalid_argument(std::string(name) + ": the permutation of base 3 is not one of {0, 1, 2}");
         }
         if (!direct && p->rr_depth < 2) throw std::invalid_argument(std::string(name) + ": rrDepth must be at least 2 (the dimension bookkeeping of halton.cpp:364-366 is restated for that case)");
-        if (sc->descCopy.film.crop_offset_x != 0 || sc->descCopy.film.crop_offset_y != 0) throw std::invalid_argument(std::string(name) + ": the crop window must start at the film's origin");
+        /* (a crop window anywhere on the film: the image blocks, and with them the pixel positions the sampler's generate() sees, are relative to the crop
+           window -- renderproc.cpp:163-164 starts them at (0, 0) -- so the crop offset never reaches the sequence: nothing to restate, nothing to refuse) */
         const unsigned long long n = (unsigned long long) (p->sample_total > 0 ? p->sample_total : p->spp);
         if (n >= (1ull << 17)) throw std::invalid_argument(std::string(name) + ": at most 131071 samples per pixel (32-bit pixel offsets)");
     }
@@ -990,7 +991,6 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
             if (direct && (p->emitter_samples > 1 || p->bsdf_samples > 1) && p->sobol_log_resolution < 2)
                 throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sample arrays of `direct` need a film of more than two pixels per side (SobolSampler::generate enumerates them per pixel: sobol.cpp:182,190)");
             if (p->sobol_log_resolution > 1 && (!p->sobol_vdc || !p->sobol_vdc_inv)) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_vdc / sobol_vdc_inv are required when the film is enumerated per pixel");
-            if (sc->descCopy.film.crop_offset_x != 0 || sc->descCopy.film.crop_offset_y != 0) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: the crop window must start at the film's origin");
             uint32_t need = 0; { uint32_t side = (uint32_t) std::max(D0.film.width, D0.film.height), r = 1; while (r < side) { r <<= 1; ++need; } }
             if (p->sobol_log_resolution != need) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_log_resolution must be log2 of the crop window's larger side rounded up to a power of two (sobol.cpp:147-157)");
         } else {

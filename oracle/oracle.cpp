@@ -55,7 +55,6 @@ static bool isQmc(uint32_t s) { return s == PHIP_SAMPLER_SOBOL || s == PHIP_SAMP
 static void setQmc(const Scene &scene, const phip_render_params *p, int &qmc, SobolTables &sob, uint32_t &stRes, RinvTables &rinv) {
     if (p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY) {
         if (!p->qmc_primes || p->qmc_dimensions < 8) throw std::runtime_error("PHIP_SAMPLER_HALTON / _HAMMERSLEY: tables missing");
-        if (scene.film.crop_offset_x != 0 || scene.film.crop_offset_y != 0) throw std::runtime_error("PHIP_SAMPLER_HALTON / _HAMMERSLEY: crop window at the origin");
         if (p->rr_depth < 2) throw std::runtime_error("PHIP_SAMPLER_HALTON / _HAMMERSLEY: rrDepth >= 2");
         qmc = 3; rinv.primes = p->qmc_primes; rinv.perm = p->qmc_permutations; rinv.dims = p->qmc_dimensions;
         rinv.permOffset.assign(p->qmc_dimensions, 0);
@@ -64,7 +63,6 @@ static void setQmc(const Scene &scene, const phip_render_params *p, int &qmc, So
         rinv.setFilmResolution(scene.film.crop_width, scene.film.crop_height, (size_t) (p->sample_total > 0 ? p->sample_total : p->spp));
     } else if (p->sampler == PHIP_SAMPLER_SOBOL) {
         if (!p->sobol_matrices || (p->sobol_log_resolution > 1 && (!p->sobol_vdc || !p->sobol_vdc_inv))) throw std::runtime_error("PHIP_SAMPLER_SOBOL: tables missing");
-        if (scene.film.crop_offset_x != 0 || scene.film.crop_offset_y != 0) throw std::runtime_error("PHIP_SAMPLER_SOBOL: crop window at the origin");
         if (p->rr_depth < 2) throw std::runtime_error("PHIP_SAMPLER_SOBOL: rrDepth >= 2");
         qmc = 1; sob.matrices = p->sobol_matrices; sob.vdc = p->sobol_vdc; sob.vdcInv = p->sobol_vdc_inv; sob.dims = p->sobol_dimensions;
         sob.logRes = p->sobol_log_resolution; sob.scramble = p->sobol_scramble; sob.resolution = (float) (1u << p->sobol_log_resolution);

@@ -615,6 +615,18 @@ def test_sobol_and_stratified_samplers_match_oracle(gpu, phip, oracle, gauss):
     gs.close()
 
 
+def test_qmc_samplers_on_a_crop_window_off_the_films_origin_match_oracle(gpu, oracle, gauss):
+    """round 5: the sequence samplers on a crop window that does not start at the film's origin (refused until then; the reference's blocks and sampler positions are
+    relative to the crop window: tests/test_ref_pin.py::test_qmc_samplers_on_a_crop_window_off_the_films_origin)"""
+    from conftest import sobol_tables, qmc_tables
+    sb = S.cornell_box(160, 120, gauss)
+    sb.hdrfilm(160, 120, gauss, crop=(61, 35, 48, 40))
+    desc = sb.desc()
+    for kw in (dict(sobol=sobol_tables(48, 40)), dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1)), dict(sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=qmc_tables(-1))):
+        same, r = compare_render(gpu, oracle, desc, 8, min_identical=1.0, render_kw=kw, maxDepth=6)
+        assert same == 1.0
+
+
 def test_halton_and_hammersley_samplers_match_oracle(gpu, phip, oracle, gauss):
     """PHIP_SAMPLER_HALTON / _HAMMERSLEY (the reference's `halton` / `hammersley` plugins restated: tests/test_ref_pin.py pins the oracle to Mitsuba's own
     `path` + those plugins): per-sample radiance bit-identical to the oracle -- Faure permutations, none, pseudorandom ones; microfacet, dielectric,

@@ -396,6 +396,27 @@ def test_sobol_sampler_of_the_reference_is_reproduced_bit_for_bit(ref, olibm):
         assert (smp.view(np.uint32) == osmp.view(np.uint32)).all(), (name, float((smp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean()))
 
 
+def test_qmc_samplers_on_a_crop_window_off_the_films_origin(ref, olibm):
+    """Round 5 (VERDICT r4 item 4 of "what's missing"): a crop window that does not start at the film's origin.  The reference's image blocks -- and with them the
+    pixel positions its samplers' generate() sees -- are relative to the crop window (renderproc.cpp:163-164 starts them at (0, 0)), the resolution the sequences
+    are partitioned over is the crop size (integrator.cpp:40-41): the crop OFFSET never reaches sobol.cpp:170-196 / halton.cpp:274-328.  So there is nothing to
+    restate -- only a refusal to drop; the reference's own `path` + `sobol` / `halton` / `hammersley` on such a window, bit for bit."""
+    gauss_libm = olibm.gaussian_filter(0.5, libm=True)
+    sb = S.cornell_box(96, 80, gauss_libm)
+    sb.hdrfilm(96, 80, gauss_libm, crop=(37, 22, 24, 20))
+    desc = sb.desc()
+    rs = ref.RefScene(desc); osc = olibm.OracleScene(desc, libm=True)
+    for sampler, kw in (("sobol", dict(sobol=ref.sobol_tables(24, 20))),
+                        ("halton", dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=ref.qmc_tables(-1, 256), seed=0)),
+                        ("hammersley", dict(sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=ref.qmc_tables(-1, 256), seed=0))):
+        p = A.default_render_params(spp=4, max_depth=6, block_size=256, **kw)
+        _, smp = rs.render(p, sampler=sampler)
+        _, osmp, _ = osc.render(p, want_samples=True)
+        assert smp[..., :3].mean() > 0.01
+        assert (smp.view(np.uint32) == osmp.view(np.uint32)).all(), (sampler, float((smp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean()))
+    rs.close(); osc.close()
+
+
 def test_direct_with_the_reference_qmc_samplers_is_reproduced_bit_for_bit(ref, olibm):
     """SURVEY 8(f) row 4, the rest of it: the reference's OWN `direct` integrator with its OWN `sobol` / `halton` / `hammersley` plugins against the
     restatement.  `direct` requests sample ARRAYS for more than one shading sample of a kind (direct.cpp:139-146): the samplers fill them in
