@@ -308,7 +308,9 @@ typedef struct phip_render_params {
 #define PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND 4   /* directly visible envmap pixels: unfiltered level-0 lookup instead of the reference's EWA filter (deviation!) */
 #define PHIP_FLAG_ACCUMULATE 8      /* add to the film of the previous call instead of overwriting it (progressive rendering) */
 #define PHIP_FLAG_ALIAS_DEVICES 16  /* devices[] may name one GPU several times (exercises the multi-device path on a 1-GPU box) */
-#define PHIP_FLAG_NO_FUSED 32       /* never use the fused single-kernel path (k_mega) -- A/B and parity tests of the wavefront kernels on small scenes */
+#define PHIP_FLAG_NO_FUSED 32       /* never use the fused single-kernel path (k_mega) nor the one-kernel iterations (k_shade_trace) -- A/B and parity tests of the wavefront kernels on small scenes */
+#define PHIP_FLAG_NO_MEGA 64        /* not k_mega, but k_shade_trace where the scene admits it (a small scene with glass / copper runs k_mega since round 5: how the tests still reach
+                                       k_shade_trace on it; the kernel's own clients are small scenes with textures or an environment emitter) */
 
 typedef struct phip_stats {
     uint64_t samples;                /* camera samples rendered by this call                  */

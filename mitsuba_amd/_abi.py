@@ -25,6 +25,7 @@ PHIP_FLAG_ENVMAP_BILINEAR_BACKGROUND = 4
 PHIP_FLAG_ACCUMULATE = 8
 PHIP_FLAG_ALIAS_DEVICES = 16
 PHIP_FLAG_NO_FUSED = 32
+PHIP_FLAG_NO_MEGA = 64
 PHIP_NO_HIT = 0xFFFFFFFF
 
 

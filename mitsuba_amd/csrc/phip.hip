@@ -218,6 +218,7 @@ struct phip_scene {
     bool hasTextures = false; uint32_t triShadeStride = TRISHADE_FLOAT4S;
     int envLevelCount = 0;           /* MIP levels of the envmap (0: no envmap) */
     int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
+    bool flatTraceToo = false;       /* a scene of k_mega that k_shade_trace could serve as well (PHIP_FLAG_NO_MEGA) */
     bool flatTrace = false;          /* not a scene of k_mega, but its tree is the packed leaf table (<= 64 Wald records) and emitter table + materials fit LDS: k_shade_trace */
     bool wide = false;               /* the ray kernels walk the compressed 8-wide BVH (trees of >= 64 BVH4 nodes; PHIP_WIDE=0 keeps the BVH4) */
     bool fitsLds = false;            /* tree, Wald records, shading records, emitter table and materials fit the fused kernel's LDS plan */
@@ -710,9 +711,12 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     /* (treeInLds: the whole tree and every Wald record are staged in LDS and the stack cannot spill -- also true of small scenes with glass, copper,
        textures or an environment emitter, which k_shade_trace serves on the same packed leaf table: k_shade_trace.h) */
     const bool treeInLds = D.nodeCache == sc->bvh.nNodes && D.triCache == sc->bvh.tris.size() / 12 && 3 * ((int) sc->bvh.maxDepth - 1) + 1 <= (int) D.stackDepth;
-    sc->fitsLds = sc->materialMask == 0 && !sc->hasTextures && envEmitter < 0 && stride == TRISHADE_FLOAT4S
+    /* (leaf BSDF models: any -- round 5 -- when the tree is the packed leaf table; diffuse only for the trees the fused kernel walks or sweeps leaf by leaf: decided
+       below, once the table is built) */
+    const bool fitsLdsBase = !sc->hasTextures && envEmitter < 0 && stride == TRISHADE_FLOAT4S
         && treeInLds && d.n_triangles <= MEGA_TRISHADE_MAX
         && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX;
+    sc->fitsLds = fitsLdsBase && sc->materialMask == 0;
     /* ... and, for trees of at most FLAT_LEAVES_MAX leaves (the Cornell box: 17), the leaves as a flat table: the fused kernel tests
        every leaf box in one uniform pass instead of walking the 7-node tree (k_traverse.h: traverseFlat).  Entry = (min.xyz, bits(leaf
        reference)) (max.xyz, 0), boxes as the BVH4 nodes hold them (padded). */
@@ -781,9 +785,11 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
             D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
         }
     }
-    sc->flatTrace = !sc->fitsLds && D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !expEnv("PHIP_NO_SHADE_TRACE");
+    if (fitsLdsBase && sc->materialMask != 0 && D.flatMode >= 2 && !expEnv("PHIP_NO_MEGA_MATERIALS")) sc->fitsLds = true;
+    const bool traceable = D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !expEnv("PHIP_NO_SHADE_TRACE");
+    sc->flatTrace = !sc->fitsLds && traceable; sc->flatTraceToo = sc->fitsLds && traceable;
     /* ... whose lanes are dealt by BSDF model where there is more than one (the kernel traces its own rays and leaves the class in the hit word) */
-    if (sc->flatTrace && sc->materialMask != 0) { D.shadeSort = 1u; if (const char *e = expEnv("PHIP_SHADE_SORT")) D.shadeSort = atoi(e) != 0 ? 1u : 0u; }
+    if ((sc->flatTrace || sc->flatTraceToo) && sc->materialMask != 0) { D.shadeSort = 1u; if (const char *e = expEnv("PHIP_SHADE_SORT")) D.shadeSort = atoi(e) != 0 ? 1u : 0u; }
     sd.counters.alloc(1);
     sd.invalid.alloc(1);
     sd.dynCounter.alloc(DYN_SHARDS * DYN_STRIDE);
@@ -1084,7 +1090,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
     const bool rinv = p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY;
     const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED || rinv;     /* served by the wavefront kernels compiled with FEAT bit 3 */
-    bool fused = !direct && sc->fitsLds && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
+    bool fused = !direct && sc->fitsLds && sc->traversal == 2 && !(p->flags & (PHIP_FLAG_NO_FUSED | PHIP_FLAG_NO_MEGA));
     if (qmc && p->sampler == PHIP_SAMPLER_SOBOL) {
         /* the plugin's tables, uploaded once per (pointer, size): ~210 KB of direction numbers + the two 52-word enumeration rows */
         const size_t nm = (size_t) p->sobol_dimensions * PHIP_SOBOL_MATRIX_SIZE;
@@ -1144,7 +1150,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     }
     sd.fused = fused;
     /* ... or k_shade_trace: the scene's tree is the packed leaf table, but k_mega does not serve it (glass / copper / textures / environment emitter) */
-    const bool shadeTrace = !fused && sc->flatTrace && !direct && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
+    const bool shadeTrace = !fused && (sc->flatTrace || sc->flatTraceToo) && !direct && sc->traversal == 2 && !(p->flags & PHIP_FLAG_NO_FUSED);
 
     phip_stats st; memset(&st, 0, sizeof(st));
     const bool timing = (p->flags & PHIP_FLAG_KERNEL_TIMING) != 0;

@@ -9,18 +9,23 @@
 
 typedef void (*MegaKernel)(DevScene, MegaParams, RenderConst, float4 *);
 
-/* Only the diffuse instantiation exists: with the microfacet / dielectric code inlined next to the traversal the kernel needs
-   more than 256 VGPRs (measured: 256 + scratch at 2 waves per SIMD), and the scenes of that kind that fit LDS are test
-   scenes, not workloads -- they keep the wavefront kernels. */
-template <bool QMC> static MegaKernel megaKernelOf(bool strictNormals, int flat) {
+/* Leaf BSDF models: diffuse only (every traversal form), or all three (round 5) on the packed leaf table -- the Cornell box with a glass and a copper block.
+   (Round 2 measured "more than 256 VGPRs" for the microfacet / dielectric code next to the traversal; since then the traversal became the dealt table pass,
+   the work counters moved to LDS and the camera samples to a queue: k_mega<MM_ALL, false, 2, false> builds at 128 VGPRs with 16 B of scratch, four waves.)
+   A scene with glass but no copper runs the build that also knows copper: one more material set, not three. */
+template <bool QMC> static MegaKernel megaKernelOf(int materialMask, bool strictNormals, int flat) {
+    if (materialMask & MM_ALL) {
+        if (flat == 3) return MEGA_BALANCE ? (strictNormals ? k_mega<MM_ALL, true, 3, QMC> : k_mega<MM_ALL, false, 3, QMC>) : nullptr;
+        if (flat == 2) return strictNormals ? k_mega<MM_ALL, true, 2, QMC> : k_mega<MM_ALL, false, 2, QMC>;
+        return nullptr;
+    }
     if (flat == 3) return MEGA_BALANCE ? (strictNormals ? k_mega<0, true, 3, QMC> : k_mega<0, false, 3, QMC>) : nullptr;
     if (flat == 2) return strictNormals ? k_mega<0, true, 2, QMC> : k_mega<0, false, 2, QMC>;
     if (flat) return strictNormals ? k_mega<0, true, 1, QMC> : k_mega<0, false, 1, QMC>;
     return strictNormals ? k_mega<0, true, 0, QMC> : k_mega<0, false, 0, QMC>;
 }
 static MegaKernel megaKernel(int materialMask, bool strictNormals, int flat, bool qmc) {
-    if (materialMask & MM_ALL) return nullptr;
-    return qmc ? megaKernelOf<true>(strictNormals, flat) : megaKernelOf<false>(strictNormals, flat);
+    return qmc ? megaKernelOf<true>(materialMask, strictNormals, flat) : megaKernelOf<false>(materialMask, strictNormals, flat);
 }
 
 int phipMegaBlocksPerCU(int materialMask, bool strictNormals, int flat, bool qmc, size_t ldsBytes) {

