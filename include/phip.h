@@ -217,19 +217,21 @@ typedef enum phip_sampler_kind {
                                 loaded plugin, the test harness out of oracle/_ref/plugins/sobol.so or the fixture tests/golden/sobol_tables.npz made from it).
                                 Requests beyond sobol_dimensions fall back to the counter stream (the reference stops with an error there).
                                 The film's crop window must start at the origin. */
-    , PHIP_SAMPLER_STRATIFIED = 3 /* (ABI 6, `path` only) the construction of `stratified` (src/samplers/stratified.cpp:147-200): the first 4 2D
+    , PHIP_SAMPLER_STRATIFIED = 3 /* (ABI 6; every integrator since round 5) the construction of `stratified` (src/samplers/stratified.cpp:147-200): the first 4 2D
                                 requests of a sample (the pixel jitter is the first) and its first 4 1D requests are jittered points of a
                                 res x res (res^2 x 1) grid whose cells the samples of a pixel visit in a random order per dimension, later
                                 requests are independent -- with the order a keyed permutation (as PHIP_SAMPLER_LD) and the jitter the
                                 counter stream's number for that request, instead of the worker's sequential Random.  The sample count of
-                                the render must be a perfect square (stratified.cpp:64-72 rounds it up). */
-    , PHIP_SAMPLER_HALTON = 4     /* (ABI 6, `path` only) the reference's `halton` sampler as it stands (src/samplers/halton.cpp): sample k of pixel (x, y) is
+                                the render must be a perfect square (stratified.cpp:64-72 rounds it up).  With PHIP_INTEGRATOR_DIRECT a sample array of
+                                more than one shading sample per kind is one Latin hypercube over all its entries (stratified.cpp:160-164), single samples
+                                are the sample's next 2D requests. */
+    , PHIP_SAMPLER_HALTON = 4     /* (ABI 6; `direct` too since round 4) the reference's `halton` sampler as it stands (src/samplers/halton.cpp): sample k of pixel (x, y) is
                                 point offset(x mod 128, y mod 128) + stride * k of the Halton sequence (Gruenschloss' enumeration over bases 2 and 3,
                                 halton.cpp:244-296: stride = 2^a 3^b, the offset by the Chinese remainder theorem), dimension d is the (scrambled) radical
                                 inverse in the d-th prime (qmc.cpp:141-166); dimensions are consumed exactly as by PHIP_SAMPLER_SOBOL (the same bookkeeping,
                                 incl. the 2D request that skips dimension 4).  The primes and the digit permutations (Faure's by default, `scramble` = -1;
                                 none for 0; pseudorandom ones otherwise) are DATA: phip_render_params.qmc_*. */
-    , PHIP_SAMPLER_HAMMERSLEY = 5 /* (ABI 6, `path` only) the reference's `hammersley` sampler (src/samplers/hammersley.cpp): dimension 0 is index * 1 / (sampleCount
+    , PHIP_SAMPLER_HAMMERSLEY = 5 /* (ABI 6; `direct` with single shading samples since round 4) the reference's `hammersley` sampler (src/samplers/hammersley.cpp): dimension 0 is index * 1 / (sampleCount
                                 resX resY), dimension d > 0 the radical inverse in the (d-1)-th prime, index = offset(x mod 128, y mod 128) + resY * k
                                 (hammersley.cpp:181-222); the rest as PHIP_SAMPLER_HALTON.  The sample count is that of the whole render (`sample_total`). */
 } phip_sampler_kind;

@@ -594,6 +594,15 @@ DV void stPoint2D(uint32_t pixel, uint32_t k, uint32_t q, uint32_t seed, uint32_
     const float inv = 1.0f / (float) (int) res;
     x = ((float) (int) (c % res) + u1) * inv; y = ((float) (int) (c / res) + u2) * inv;       /* stratified.cpp:181-189 */
 }
+/* `direct` with more than one sample of a kind: the requested 2D array a (direct.cpp:139-146) is a Latin hypercube over ALL its sampleCount * count entries
+   (stratified.cpp:160-164 -> latinHypercube, src/libcore/qmc.cpp: entry i of a dimension starts as (i + xi) / N, then each dimension is shuffled on its own): entry
+   e = k * count + i holds the stratum a keyed permutation of e gives it, per dimension, jittered by the counter stream's numbers for that entry */
+DV void stArrayPoint(uint32_t pixel, uint32_t a, uint32_t e, uint32_t total, uint32_t seed, float u1, float u2, float &x, float &y) {
+    const U4 h = pcg4d(pixel, 0x200u + a, 0x5354u /* 'ST' */, seed);
+    const float delta = 1.0f / (float) (size_t) total;
+    x = ((float) (int) ldPermuteAny(e, total, h.x) + u1) * delta;
+    y = ((float) (int) ldPermuteAny(e, total, h.y) + u2) * delta;
+}
 DV float stPoint1D(uint32_t pixel, uint32_t k, uint32_t j, uint32_t seed, uint32_t res, float u) {
     const uint32_t c = stCell(pixel, k, 2u * j + 1u, seed, res * res);
     return ((float) (int) c + u) * (1.0f / (float) (size_t) (res * res));                      /* stratified.cpp:170-173 */

@@ -212,7 +212,17 @@ __device__ __forceinline__ V2 streamDirectSample(const RenderConst &rc, uint32_t
         return V2(x, y);
     }
     const U4 h = pcg4d(pixel, k, 1 + i, rc.seed);
-    return which ? V2(u32ToFloat(h.z), u32ToFloat(h.w)) : V2(u32ToFloat(h.x), u32ToFloat(h.y));
+    const V2 u = which ? V2(u32ToFloat(h.z), u32ToFloat(h.w)) : V2(u32ToFloat(h.x), u32ToFloat(h.y));
+    if (QMC && rc.sampler == PHIP_SAMPLER_STRATIFIED) {
+        /* round 5: `stratified` with `direct`.  More than one sample of a kind: a requested array = one Latin hypercube over its stRes^2 * count entries
+           (stArrayPoint); a single one: the sample's next 2D request (the camera sample was request 0) -- one cell of the stRes x stRes grid, as for `path` */
+        const uint32_t E = (uint32_t) rc.emitterSamples, B = (uint32_t) rc.bsdfSamples, count = which ? B : E, n = rc.stRes * rc.stRes;
+        float x, y;
+        if (count > 1) stArrayPoint(pixel, which ? (E > 1 ? 1u : 0u) : 0u, (k % n) * count + i, n * count, rc.seed, u.x, u.y, x, y);
+        else stPoint2D(pixel, k, which ? (E > 1 ? 1u : 2u) : 1u, rc.seed, rc.stRes, u.x, u.y, x, y);
+        return V2(x, y);
+    }
+    return u;
 }
 
 /* sample id -> (local tile, sample-in-pass, pixel); ids are tile-major, then sample, then the

@@ -988,7 +988,6 @@ static void validateParams(const phip_scene *sc, const phip_render_params *p) {
     }
     if (p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED) {
         const char *name = p->sampler == PHIP_SAMPLER_SOBOL ? "PHIP_SAMPLER_SOBOL" : "PHIP_SAMPLER_STRATIFIED";
-        if (direct && p->sampler == PHIP_SAMPLER_STRATIFIED) throw std::invalid_argument(std::string(name) + ": served for the `path` integrator only");
         const DevScene &D0 = sc->devs[0]->dev;
         if (p->sampler == PHIP_SAMPLER_SOBOL) {
             if (!p->sobol_matrices || p->sobol_dimensions < 8) throw std::invalid_argument("PHIP_SAMPLER_SOBOL: sobol_matrices / sobol_dimensions (the reference plugin's direction numbers) are required");

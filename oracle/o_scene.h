@@ -481,7 +481,22 @@ struct SampleSource {
             return ldPoint(2u * (which ? (E > 1 ? 1u : 2u) : 1u));
         }
         float f[4]; block(1 + (uint32_t) i, f);
-        return which == 0 ? Vec2(f[0], f[1]) : Vec2(f[2], f[3]);
+        const Vec2 u = which == 0 ? Vec2(f[0], f[1]) : Vec2(f[2], f[3]);
+        if (qmc == 2) {
+            /* `stratified` with `direct` (round 5): an array of more than one sample per kind is ONE Latin hypercube over its sampleCount * count entries
+               (stratified.cpp:160-164 -> latinHypercube, qmc.cpp: (i + xi) / N per dimension, each dimension shuffled on its own) -- entry e = sample * count + i
+               gets, per dimension, the stratum a keyed permutation assigns it; a single sample is the sample's next 2D request (stratified.cpp:177-189) */
+            const uint32_t E = (uint32_t) dirEmitterSamples, n = stRes * stRes;
+            if (count > 1) {
+                const uint32_t a = which ? (E > 1 ? 1u : 0u) : 0u, total = n * (uint32_t) count, e = (sample % n) * (uint32_t) count + (uint32_t) i;
+                uint32_t h[4] = { pixel, 0x200u + a, 0x5354u, seed };
+                pcg4d(h);
+                const float delta = 1.0f / (Float) (size_t) total;
+                return Vec2(((Float) (int) ldPermuteAny(e, total, h[0]) + u.x) * delta, ((Float) (int) ldPermuteAny(e, total, h[1]) + u.y) * delta);
+            }
+            return stPoint2D(which ? (E > 1 ? 1u : 2u) : 1u, u);
+        }
+        return u;
     }
 };
 

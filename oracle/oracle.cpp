@@ -97,7 +97,6 @@ int oracle_render_masks(void *scene_, const phip_render_params *p, int threads, 
         }
         if (isQmc(p->sampler)) {
             if (sampler_mode != 0) throw std::runtime_error("the QMC samplers: counter-stream mode");
-            if (p->integrator == PHIP_INTEGRATOR_DIRECT && p->sampler == PHIP_SAMPLER_STRATIFIED) throw std::runtime_error("PHIP_SAMPLER_STRATIFIED: `path` only");
             setQmc(scene, p, rp.qmc, rp.sobol, rp.stRes, rp.rinv);
         }
         rp.direct = p->integrator == PHIP_INTEGRATOR_DIRECT;

@@ -64,7 +64,9 @@ public:
             for (size_t j = 0; j < m_sampleCount; ++j)
                 for (size_t i = 0; i < m_req2D[a]; ++i) {
                     float f[4]; block((uint32_t) j, 1 + (uint32_t) i, f);
-                    m_sampleArrays2D[a][j * m_req2D[a] + i] = emitter ? Point2(f[0], f[1]) : Point2(f[2], f[3]);
+                    const Point2 u = emitter ? Point2(f[0], f[1]) : Point2(f[2], f[3]);
+                    /* PHIP_SAMPLER_STRATIFIED (round 5): the array is one Latin hypercube over its sampleCount * count entries (stratified.cpp:160-164) */
+                    m_sampleArrays2D[a][j * m_req2D[a] + i] = m_stratified ? stArrayPoint((uint32_t) a, (uint32_t) ((j % ((size_t) m_stRes * m_stRes)) * m_req2D[a] + i), (uint32_t) ((size_t) m_stRes * m_stRes * m_req2D[a]), u) : u;
                 }
         }
         m_sampleIndex = 0; m_dimension1DArray = m_dimension2DArray = 0;
@@ -79,13 +81,14 @@ public:
         if (m_ld && call < 4) return ldPoint(2 * call);                                             /* ldsampler.cpp:218-224 */
         if (call == 0) {                                                                            /* integrator.cpp:171 */
             block((uint32_t) m_sampleIndex, 0, f);
-            return (m_stratified && !m_direct) ? stPoint2D(0, f[0], f[1]) : Point2(f[0], f[1]);
+            return m_stratified ? stPoint2D(0, f[0], f[1]) : Point2(f[0], f[1]);
         }
         if (m_direct) {
             /* direct.cpp:212-216: a single emitter sample (also drawn when emitterSamples == 0); :251-255 the same for the BSDF */
             const bool emitterCall = (m_emitterSamples <= 1) && call == 1;
             block((uint32_t) m_sampleIndex, 1, f);
-            return emitterCall ? Point2(f[0], f[1]) : Point2(f[2], f[3]);
+            const Point2 u = emitterCall ? Point2(f[0], f[1]) : Point2(f[2], f[3]);
+            return (m_stratified && call < 4) ? stPoint2D(call, u.x, u.y) : u;                       /* stratified.cpp:177-189: the sample's request number `call` */
         }
         /* `path`: 2D request 1 + k of the sample */
         const uint32_t k = call - 1;
@@ -115,6 +118,15 @@ private:
         v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
         const uint32_t n = m_stRes * m_stRes;
         return permuteAny((uint32_t) m_sampleIndex % n, n, v[0]);
+    }
+    Point2 stArrayPoint(uint32_t a, uint32_t e, uint32_t total, const Point2 &u) const {
+        uint32_t v[4] = { m_pixel, 0x200u + a, 0x5354u, m_seed };
+        for (int i = 0; i < 4; ++i) v[i] = v[i] * 1664525u + 1013904223u;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
+        v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+        const Float delta = 1 / (Float) (size_t) total;
+        return Point2(((Float) (int) permuteAny(e, total, v[0]) + u.x) * delta, ((Float) (int) permuteAny(e, total, v[1]) + u.y) * delta);
     }
     Point2 stPoint2D(uint32_t q, Float u1, Float u2) const {
         const uint32_t c = stCell(2 * q);

@@ -607,13 +607,16 @@ def test_sobol_and_stratified_samplers_match_oracle(gpu, phip, oracle, gauss):
         acc = parts.storage.copy(); st = A.phip_stats()
         assert phip.phip_render(gs._h, C.byref(p), acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)) == 0
         assert rel_l2(acc, whole.storage) < 1e-6
-    # errors: a wrong resolution, no tables, rrDepth 1 (sobol.cpp:241-242 is restated for rrDepth >= 2), a stratified count that is no square, `direct`
+    # errors: a wrong resolution, no tables, rrDepth 1 (sobol.cpp:241-242 is restated for rrDepth >= 2), a stratified count that is no square
     with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(64, 64))
     with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 16, sampler=A.PHIP_SAMPLER_SOBOL)
     with pytest.raises(PhipError): PathHIP(rrDepth=1).render(gs, HDRFilm(32, 32), 16, sobol=sobol_tables(32, 32))
     with pytest.raises(PhipError): integ.render(gs, HDRFilm(32, 32), 8, sampler=A.PHIP_SAMPLER_STRATIFIED)
-    with pytest.raises(PhipError): DirectHIP().render(gs, HDRFilm(32, 32), 16, sampler=A.PHIP_SAMPLER_STRATIFIED)
     gs.close()
+    # round 5: `stratified` with `direct` -- single samples (the sample's next 2D requests) and sample arrays (one Latin hypercube per array)
+    for desc, spp, e, b in ((S.cornell_box(48, 40, gauss).desc(), 16, 1, 1), (S.cornell_box(48, 40, gauss).desc(), 4, 3, 2), (S.cornell_mixed(48, 40, gauss).desc(), 9, 2, 1),
+                            (S.atrium(64, 36, gauss, detail=0.3).desc(), 4, 2, 2), (S.cornell_box(32, 32, gauss).desc(), 4, 0, 3)):
+        compare_render(gpu, oracle, desc, spp, min_identical=0.999, integrator=DirectHIP, render_kw=dict(sampler=A.PHIP_SAMPLER_STRATIFIED, seed=3), emitterSamples=e, bsdfSamples=b)
 
 
 def test_qmc_samplers_on_a_crop_window_off_the_films_origin_match_oracle(gpu, oracle, gauss):

@@ -476,6 +476,37 @@ def test_stratified_construction_on_the_reference(ref, olibm):
     assert mse(ours) < 1.25 * mse(own) and mse(ours) < mse(ind)
 
 
+def test_stratified_construction_with_direct_on_the_reference(ref, olibm):
+    """Round 5 (the last piece of SURVEY 8(f) row 4): PHIP_SAMPLER_STRATIFIED with `direct`.  More than one shading sample of a kind is a requested 2D array
+    (direct.cpp:139-146), which the reference's `stratified` fills with ONE Latin hypercube over all sampleCount x count entries (stratified.cpp:160-164 ->
+    latinHypercube); a single one is the sample's next 2D request (one cell of the sampleCount grid).  The reference's OWN `direct` consuming the addressable
+    construction through the glue sampler equals the restatement sample for sample, and the construction converges like the reference's own `direct` + `stratified`."""
+    gauss_libm = olibm.gaussian_filter(0.5, libm=True)
+    desc = S.cornell_box(24, 20, gauss_libm).desc()
+    rs = ref.RefScene(desc); osc = olibm.OracleScene(desc, libm=True)
+    for spp, e, b in ((4, 1, 1), (4, 3, 2), (16, 2, 1), (9, 1, 4), (4, 0, 3), (4, 2, 0)):
+        p = A.default_render_params(spp=spp, block_size=256, integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=e, bsdf_samples=b); p.sampler = A.PHIP_SAMPLER_STRATIFIED
+        _, smp = rs.render(p, sampler="ctr")
+        _, osmp, _ = osc.render(p, want_samples=True)
+        assert smp[..., :3].mean() > 0.01
+        assert (smp.view(np.uint32) == osmp.view(np.uint32)).all(), (spp, e, b, float((smp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean()))
+    rs.close(); osc.close()
+    # convergence: direct lighting of the Cornell box, 16 spp x (2 emitter + 2 BSDF samples): ours within 25 % of the reference's own stratified, better than independent
+    desc = S.cornell_box(32, 32, gauss_libm).desc()
+    rs = ref.RefScene(desc)
+    kw = dict(integrator=A.PHIP_INTEGRATOR_DIRECT, emitter_samples=2, bsdf_samples=2)
+    truth, _ = rs.render_job(A.default_render_params(spp=4096, **kw), threads=os.cpu_count(), sampler="independent")
+    def mae(img): return float(np.abs(img - truth).mean())
+    p16 = A.default_render_params(spp=16, **kw)
+    own, _ = rs.render_job(p16, threads=2, sampler="stratified")
+    ind, _ = rs.render_job(p16, threads=2, sampler="independent")
+    ps = A.default_render_params(spp=16, **kw); ps.sampler = A.PHIP_SAMPLER_STRATIFIED
+    ours, _ = rs.render_job(ps, threads=2, sampler="ctr")
+    rs.close()
+    print("direct, mean abs error at 16 spp: stratified construction %.3e, the reference's stratified %.3e, independent %.3e" % (mae(ours), mae(own), mae(ind)))
+    assert mae(ours) < 1.25 * mae(own) and mae(ours) < mae(ind)
+
+
 def test_halton_and_hammersley_samplers_of_the_reference_are_reproduced_bit_for_bit(ref, olibm):
     """PHIP_SAMPLER_HALTON / _HAMMERSLEY: the reference's OWN `path` with its OWN `halton` / `hammersley` sampler plugins (Gruenschloss' enumeration of the
     points per pixel over bases 2 and 3 / of the Hammersley set, the scrambled radical inverses of qmc.cpp:141-166, pixel positions modulo 128, the
