@@ -760,12 +760,16 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                    distances c' -+ h |rcp| are rounded differently from the plane form the pad of bvh.h was sized for (two roundings of
                    magnitude |c rcp| + |o rcp| instead of one): h gets the rounding of c and another 4e-6 of the scene's extent on top */
                 const float ext = std::max(sc->bvh.tightMax[0] - sc->bvh.tightMin[0], std::max(sc->bvh.tightMax[1] - sc->bvh.tightMin[1], sc->bvh.tightMax[2] - sc->bvh.tightMin[2]));
+                const float camPos[3] = { d.camera.to_world[3], d.camera.to_world[7], d.camera.to_world[11] };
                 float c[3], h[3];
                 const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
                 for (int a = 0; a < 3; ++a) {
                     c[a] = (float) (0.5 * ((double) lo[a] + (double) hi[a]));
                     const double need = std::max((double) c[a] - (double) lo[a], (double) hi[a] - (double) c[a]);
-                    h[a] = std::nextafter((float) need, INFINITY) + 2.4e-7f * std::fabs(c[a]) + 4e-6f * ext;
+                    /* ... and the rounding of o rcp, which grows with the ORIGIN's magnitude (two roundings of |o rcp| move a plane by ~2^-23 |o|): the only rays
+                       that start outside the scene box are the camera's, so the camera position pays for it (a camera 60 scene extents away used to lose
+                       leaf boxes; tests/test_gpu_parity.py: far camera) */
+                    h[a] = std::nextafter((float) need, INFINITY) + 2.4e-7f * std::fabs(c[a]) + 4e-6f * ext + 4.8e-7f * std::fabs(camPos[a]);
                 }
                 packed.push_back(make_float4(c[0], c[1], c[2], pm_from_bits(bitsHi)));
                 packed.push_back(make_float4(h[0], h[1], h[2], pm_from_bits(bits)));
@@ -1874,7 +1878,10 @@ int phip_render(phip_scene *scene, const phip_render_params *params, float *out_
         int rc = renderImpl(scene, params, sd.film.p, out_stats);
         if (rc != PHIP_OK) return rc;
         const auto t0 = std::chrono::steady_clock::now();
-        filmToHost(sd, out_rgbaw, sd.film.p, n * sizeof(float));
+        {
+            std::lock_guard<std::mutex> lock(scene->renderLock);         /* (the staging buffers and the stream of the delivery are the scene's: ADVICE r4) */
+            filmToHost(sd, out_rgbaw, sd.film.p, n * sizeof(float));
+        }
         if (out_stats) {
             out_stats->d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             out_stats->render_ms += out_stats->d2h_ms;
@@ -1892,8 +1899,16 @@ int phip_film_to_host(phip_scene *scene, const void *d_rgbaw, float *out_rgbaw) 
     try {
         SceneDev &sd = *scene->devs[0];
         HIP_TRY(hipSetDevice(sd.device));
-        HIP_TRY(hipDeviceSynchronize());                       /* the frame may have been written on another stream (an RCCL reduce) */
-        filmToHost(sd, out_rgbaw, (const float *) d_rgbaw, (size_t) sd.dev.film.width * sd.dev.film.height * 5 * sizeof(float));
+        const size_t bytes = (size_t) sd.dev.film.width * sd.dev.film.height * 5 * sizeof(float);
+        /* the frame has to be device memory of the scene's first device (a pointer of another GPU, or a host pointer, used to be trusted) */
+        hipPointerAttribute_t attr; memset(&attr, 0, sizeof(attr));
+        if (hipPointerGetAttributes(&attr, d_rgbaw) != hipSuccess) { (void) hipGetLastError(); return setErr(PHIP_ERR_INVALID, "phip_film_to_host: d_rgbaw is not a device pointer"); }
+        if (attr.type != hipMemoryTypeDevice || attr.device != sd.device)
+            return setErr(PHIP_ERR_INVALID, "phip_film_to_host: d_rgbaw must be device memory of the scene's device");
+        /* the staging buffers and the stream are the scene's: one delivery at a time, and not while a render of the scene uses them (phip_render's own copy) */
+        std::lock_guard<std::mutex> lock(scene->renderLock);
+        HIP_TRY(hipDeviceSynchronize());                       /* the frame may have been written on another stream (an RCCL reduce on torch's) */
+        filmToHost(sd, out_rgbaw, (const float *) d_rgbaw, bytes);
         return PHIP_OK;
     } catch (const std::exception &e) {
         return setErr(PHIP_ERR_DEVICE, e.what());

@@ -774,6 +774,50 @@ def test_fused_kernel_64_record_work_list_overflow_matches_oracle(gpu, oracle, g
     assert same == 1.0
 
 
+def test_deep_wide_tree_spills_its_group_stack(gpu, oracle, gauss):
+    """k_rays_w keeps WIDE_STACK_LDS = 6 group entries per lane in LDS and spills deeper ones to HBM.  A scene whose SAH tree is a long spine -- triangles
+    of geometrically growing size along a line, each enclosing box containing all the smaller ones -- makes the wide tree far deeper than six levels: closest hits
+    (phip_trace, against a sweep over all triangles) and a render (k_rays_w: per-sample identity with the oracle) go through the spill path."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    i = np.arange(n)
+    size = 1e-3 * 1.0035 ** i                                    # seven orders of magnitude of triangle sizes
+    centre = np.stack([size * 3.0, np.zeros(n), size * 3.0], 1)    # ... strung out along a diagonal, the big ones far from the small ones
+    tri = rng.normal(size=(n, 3, 3)) * size[:, None, None] * 0.7 + centre[:, None, :]
+    P = tri.reshape(-1, 3).astype(np.float32)
+    T = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    sb = S.SceneBuilder()
+    sb.mesh(P, T, sb.twosided(sb.diffuse((0.7, 0.6, 0.5))))
+    ext = float(np.abs(P).max())
+    black = sb.diffuse((0, 0, 0))
+    sb.quad((-ext, 2 * ext, -ext), (ext, 2 * ext, -ext), (ext, 2 * ext, ext), (-ext, 2 * ext, ext), black, facing=(0, -1, 0), radiance=(8.0, 8.0, 8.0))
+    sb.perspective((0.3 * ext, 0.5 * ext, -2.0 * ext), (0.3 * ext, 0.0, 0.3 * ext), (0, 1, 0), 50.0, near=1e-4 * ext, far=10 * ext)
+    sb.hdrfilm(64, 48, gauss)
+    desc = sb.desc()
+    gs = gpu.Scene(desc); osc = oracle.OracleScene(desc)
+    info = gs.accel_info().as_dict()
+    assert info["node_bytes"] == 80 and info["max_depth"] >= 10, info          # the wide tree, deeper than the LDS part of the stack
+    rays = random_rays(rng, 40000, -0.2 * ext, 1.2 * ext, mint=0.0)
+    rays[:20000, :3] *= 0.01                                     # half of them among the small triangles
+    gh, go, _ = gs.rayIntersect(rays, True, True)
+    bh, _, _ = osc.trace(rays, True, False, bruteforce=True)
+    assert (gh.view(np.uint32) == bh.view(np.uint32)).all(axis=1).mean() > 0.9999
+    oh, oo, _ = osc.trace(rays, True, True)
+    assert (go == oo).mean() > 0.9999
+    gs.close(); osc.close()
+    compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=5)
+
+
+def test_far_camera_keeps_every_leaf_box_of_the_flat_table(gpu, oracle, gauss):
+    """the fused kernel's pass 1 computes slab distances as c rcp - o rcp, whose cancellation error grows with |o|; a camera hundreds of scene extents
+    away (a telephoto view of the Cornell box) must not lose leaf boxes -- the host pads the table's half extents for the camera position (phip.hip)"""
+    for dist, fov in ((60.0, 1.0), (400.0, 0.15), (3000.0, 0.02)):
+        sb = S.cornell_box(64, 64, gauss)
+        sb.perspective(origin=(278.0, 273.0, -560.0 * dist), target=(278.0, 273.0, 0.0), up=(0, 1, 0), fov_x_deg=fov, near=10.0, far=560.0 * dist * 2.0)
+        same, r = compare_render(gpu, oracle, sb.desc(), 8, min_identical=0.9999, maxDepth=5)
+        print("camera %g scene extents away: identical %.6f rel L2 %.3e" % (dist, same, r))
+
+
 def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
     """bench.py's `cornell_mixed_*` workload: the Cornell box with a rough-copper and a glass block -- 32 triangles, all three leaf BSDF
     models; a tree of 32 Wald records, so k_shade_trace (one kernel per iteration: vertex + shadow ray + next ray on the packed leaf table in LDS)"""
