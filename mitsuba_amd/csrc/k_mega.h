@@ -1,6 +1,7 @@
 /*
  * k_mega.h -- k_mega: the whole path of MIPathTracer::Li in ONE persistent kernel, for scenes whose acceleration structure,
- * Wald records, shading records, emitter table and materials all fit in LDS (the Cornell box of BASELINE.json configs[1]).
+ * Wald records, shading records, emitter table and materials all fit in LDS (the Cornell box of BASELINE.json configs[1]; since round 5 also with glass and
+ * copper blocks: every leaf BSDF model, on the packed leaf table of at most 64 Wald records -- phip_mega.hip).
  *
  * The wavefront design (k_shade -> k_shadow_p -> k_trace, state streamed through HBM between three kernels per iteration)
  * exists to keep traversal kernels small when every node fetch is an HBM/L2 round trip.  When the geometry is a few KB in

@@ -2,32 +2,36 @@
  * phip.hip -- MI355X (gfx950) path tracer behind the C ABI of include/phip.h: host side + ray and film kernels.
  *
  * Replaces the reference's per-block CPU loop (SamplingIntegrator::renderBlock ->
- * MIPathTracer::Li, src/librender/integrator.cpp:140-188, src/integrators/path/path.cpp:119-300).
- * Two device paths share one statement of the integrator (shadeVertex, k_shade.h) and one traversal (k_traverse.h):
+ * MIPathTracer::Li, src/librender/integrator.cpp:140-188, src/integrators/path/path.cpp:119-300; the sibling integrators `direct` and -- on scenes
+ * without media -- `volpath_simple`).  Three device paths share one statement of the integrator (shadeVertex, k_shade.h):
  *
- *   wavefront (any scene): a pool of path slots lives in HBM as SoA arrays; every iteration runs
- *       shade -> shadow rays -> closest-hit rays   over the pool, a final film kernel develops the per-sample accumulators
- *   fused (scenes that fit LDS, diffuse materials -- the Cornell box of BASELINE.json configs[1]): k_mega keeps a path in
- *       registers from the camera sample to its end; HBM sees one 16-byte store per sample (k_mega.h)
+ *   wavefront (big scenes): a pool of path slots lives in HBM as SoA arrays; every iteration runs k_shade (one vertex per slot) and k_rays_w
+ *       (persistent waves over the compressed 8-wide BVH: the closest-hit and the any-hit rays of the iteration), a final film pass develops the
+ *       per-sample accumulators
+ *   fused (scenes whose tree, records, emitter table and materials fit LDS -- the Cornell box of BASELINE.json configs[1], with any of the three leaf
+ *       BSDF models when the tree is the packed leaf table of <= 64 Wald records): k_mega keeps a path in registers from the camera sample to its end;
+ *       HBM sees one 16-byte store per sample (k_mega.h)
+ *   vertex-traced (small scenes k_mega does not serve: bitmap textures, an environment emitter): k_shade_trace -- the wavefront's pool, but ONE kernel per
+ *       iteration that shades a slot's vertex and traces its shadow ray and its next ray on the packed leaf table in LDS (k_shade_trace.h)
  *
- * libphip.so is three translation units (phip_common.h).  Kernels and where they live:
- *   k_pool.h      PathPool (HBM layout of the slots), slot flags, RenderConst, per-wave statistics
- *   k_traverse.h  per-lane BVH4 traversal as a state machine (one node step + one Wald test per
- *                 iteration), LDS-staged stacks and top-of-tree cache                  [this unit, phip_mega.hip]
- *   k_rays.h      k_trace / k_shadow (one lane per slot, small scenes), k_trace_p / k_shadow_p / k_rays_p (persistent
- *                 waves with refill; k_rays_p casts the closest-hit and the any-hit rays of an iteration in one launch),
- *                 k_raycast (phip_trace)                                                     [this unit]
- *   k_wide.h      the same ray kernels over the compressed 8-wide BVH (80-byte nodes, quantised child boxes) that the big
- *                 scenes use: k_rays_w, k_raycast_w                                            [this unit]
- *   k_shade.h     shadeVertex + k_shade<materials, strictNormals, features>: emitter-hit / environment MIS term, Russian
- *                 roulette, emission, NEE sample (self-contained shadow-queue entry, block-compacted), BSDF sample -> next
- *                 ray in place; a path that ends is replaced by the SAME lane in the same launch (static sample schedule
- *                 + dynamic tail).  Radiance accumulates in L[sampleId] in the reference's order.   [phip_shade.hip]
- *   k_shade_direct.h  MIDirectIntegrator::Li on the same pool                                     [phip_shade.hip]
- *   k_mega.h      the fused kernel                                                                [phip_mega.hip]
- *   k_film.h      k_film_tiled / k_film: gather of the filtered samples per pixel (ImageBlock::put,
- *                 include/mitsuba/render/imageblock.h:124-204) -- no float atomics, deterministic;
- *                 k_reduce_stats, k_export_samples                                             [this unit]
+ * libphip.so is 26 objects of three sources (phip_common.h).  Kernels and where they live:
+ *   k_pool.h      PathPool (HBM layout of the slots), slot flags, RenderConst, per-wave statistics, the sample streams' entry points
+ *   k_traverse.h  per-lane BVH4 traversal as a state machine, the flat / packed leaf tables of the LDS-resident trees with the Wald tests dealt over
+ *                 the wave (traverseFlat2W), LDS-staged stacks and top-of-tree cache                     [this unit, phip_mega.hip, phip_shade.hip]
+ *   k_rays.h      k_trace / k_shadow_p (BVH4: trees of fewer than 64 nodes rendered by `direct` or with PHIP_FLAG_NO_FUSED), k_raycast (phip_trace);
+ *                 experiment builds also carry the BVH4 ray kernels of rounds 1-2 for big trees                  [this unit]
+ *   k_wide.h      the ray kernels over the compressed 8-wide BVH (80-byte nodes, quantised child boxes) that the big scenes use: k_rays_w
+ *                 (triangle tests dealt over the wave), k_raycast_w                                               [this unit]
+ *   k_shade.h     shadeVertex + k_shade<materials, strictNormals, features>: emitter-hit / environment MIS term, Russian roulette, emission, NEE sample
+ *                 (self-contained shadow-queue entry, block-compacted), BSDF sample -> next ray in place; a path that ends is replaced by the SAME
+ *                 lane in the same launch (static sample schedule + dynamic tail).  Radiance accumulates in L[sampleId] in the reference's
+ *                 order.  volpath_simple is a uniform branch of shadeVertex.                                      [phip_shade.hip]
+ *   k_shade_direct.h  MIDirectIntegrator::Li on the same pool                                                     [phip_shade.hip]
+ *   k_shade_trace.h   the one-kernel iterations of the small scenes                                               [phip_shade.hip]
+ *   k_mega.h      the fused kernel                                                                                [phip_mega.hip]
+ *   k_film.h      k_film_splat + k_film_merge (filters of reach <= 2 pixels: register accumulators, no float atomics, deterministic), k_film_tiled /
+ *                 k_film (wider filters, small blocks): ImageBlock::put, include/mitsuba/render/imageblock.h:124-204;
+ *                 k_reduce_stats, k_export_samples                                                                [this unit]
  *
  * This file: error handling, scene validation and upload (BVH build via bvh.h, camera set-up), replication of the scene to
  * further GPUs, the render loop, the multi-device orchestration (one host thread + stream per GPU, ncclReduce of the

@@ -2,10 +2,10 @@
  * phip_common.h -- what every translation unit of libphip.so starts with: HIP, the C ABI, the device scene layout and
  * shading functions (dv_scene.h), the path-pool layout (k_pool.h), the error macro.
  *
- * libphip.so is built from three sources (eight objects) so that they compile in parallel (the shading kernels are 40
- * template instantiations):
+ * libphip.so is built from three sources (26 objects) so that they compile in parallel:
  *   phip.hip        host side (scene build, render loop, multi-device orchestration, C ABI) + traversal and film kernels
- *   phip_shade.hip  k_shade / k_shade_direct instantiations behind phipLaunchShadeF<n> (compiled six times, -DSHADE_FEAT=0..3, 8 and 11: the QMC samplers)
+ *   phip_shade.hip  k_shade / k_shade_direct / k_shade_trace instantiations behind phipLaunchShade*F<n> -- compiled per feature set (-DSHADE_FEAT=0..3, 8 and 11:
+ *                   environment emitter, bitmap textures, the QMC samplers) and per part (-DSHADE_PART=0..3), 24 objects: see its header
  *   phip_mega.hip   k_mega instantiations behind phipLaunchMega
  * No device function is called across units (everything on the device side is inline in headers), so no -fgpu-rdc.
  */
