@@ -156,6 +156,7 @@ def lib():
     u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.phip_debug_host_sobol.argtypes = [u32p, u32, u64p, u64p, u32, u32, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p, u64p, fp, fp]
     L.phip_debug_host_rinv.argtypes = [u32p, C.POINTER(C.c_uint16), u32, C.c_int, C.c_size_t, u64p, u32p, fp]
+    L.phip_debug_host_rinv2.argtypes = [u32p, C.POINTER(C.c_uint16), u32, C.c_int, C.c_size_t, u64p, u32p, fp]
     L.phip_debug_host_cdf_sample.argtypes = [fp, u32, fp, C.c_size_t, C.POINTER(C.c_uint32)]; L.phip_debug_host_cdf_sample.restype = None
     L.phip_debug_host_mip_eval.argtypes = [C.POINTER(A.phip_texture), C.c_size_t, fp, fp, fp, fp]
     L.phip_debug_host_build_bvh.argtypes = [fp, u32, C.POINTER(C.c_uint32), u32, C.POINTER(A.phip_accel_info), fp]

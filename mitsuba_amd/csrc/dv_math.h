@@ -566,6 +566,31 @@ DV float rinvRadicalInverse(const RinvTab &T, uint32_t baseIndex, uint64_t index
     else inverse = (float) value * factor;
     return 0.99999994f < inverse ? 0.99999994f : inverse;    /* std::min(inverse, ONE_MINUS_EPS) */
 }
+/* Two consecutive dimensions of ONE point (a 2D request) in one interleaved pass: the chunk loops of the two bases advance together, so their look-ups -- two
+   descriptors, then two table entries per level, then the two factors -- are in flight at the same time instead of one behind the other (the radical inverse
+   is a chain of dependent L1 / L2 round trips at four waves per SIMD: latency, not bandwidth).  The same arithmetic per base as rinvRadicalInverseTab. */
+DV void rinvRadicalInverseTab2(const RinvTab &T, uint32_t b0, uint32_t i32, float &r0, float &r1) {
+    const uint32_t *di0 = T.dimInfo + 8u * b0, *di1 = di0 + 8u;
+    const uint32_t B0 = di0[1], k0 = di0[2] & 0xffu, M0 = di0[3], B1 = di1[1], k1 = di1[2] & 0xffu, M1 = di1[3];
+    const float tail0 = pm_from_bits(di0[5]), tail1 = pm_from_bits(di1[5]);
+    const uint32_t *tab0 = T.chunk + (di0[2] >> 8), *tab1 = T.chunk + (di1[2] >> 8);
+    uint64_t v0 = 0, v1 = 0;
+    uint32_t dg0 = 0, dg1 = 0, i0 = i32, i1 = i32;
+    while (i0 >= B0 || i1 >= B1) {                          /* a full chunk of whichever base still has one (the other keeps its state: selects, no branch) */
+        const bool a0 = i0 >= B0, a1 = i1 >= B1;
+        uint32_t q0, c0, q1, c1;
+        rinvDivMod(i0, B0, M0, q0, c0); rinvDivMod(i1, B1, M1, q1, c1);
+        const uint32_t e0 = tab0[a0 ? c0 : 0u], e1 = tab1[a1 ? c1 : 0u];
+        v0 = a0 ? v0 * B0 + (uint64_t) (e0 & 0x3ffu) : v0; dg0 += a0 ? k0 : 0u; i0 = a0 ? q0 : i0;
+        v1 = a1 ? v1 * B1 + (uint64_t) (e1 & 0x3ffu) : v1; dg1 += a1 ? k1 : 0u; i1 = a1 ? q1 : i1;
+    }
+    const uint32_t e0 = tab0[i0], e1 = tab1[i1], n0 = e0 >> 20, n1 = e1 >> 20;
+    const uint32_t p0 = T.pw[RINV_PW_STRIDE * b0 + n0], p1 = T.pw[RINV_PW_STRIDE * (b0 + 1u) + n1];
+    const float f0 = T.fac[RINV_FAC_STRIDE * b0 + dg0 + n0], f1 = T.fac[RINV_FAC_STRIDE * (b0 + 1u) + dg1 + n1];
+    v0 = v0 * p0 + (uint64_t) ((e0 >> 10) & 0x3ffu); v1 = v1 * p1 + (uint64_t) ((e1 >> 10) & 0x3ffu);
+    const float x0 = T.perm ? f0 * ((float) v0 + tail0) : (float) v0 * f0, x1 = T.perm ? f1 * ((float) v1 + tail1) : (float) v1 * f1;
+    r0 = 0.99999994f < x0 ? 0.99999994f : x0; r1 = 0.99999994f < x1 ? 0.99999994f : x1;
+}
 /* dimension `dimension` of point `index`: nextFloat, halton.cpp:343-350 / hammersley.cpp:235-243 */
 DV float rinvSample(const RinvTab &T, uint64_t index, uint32_t dimension) {
     if (T.hammersley) {
@@ -573,6 +598,12 @@ DV float rinvSample(const RinvTab &T, uint64_t index, uint32_t dimension) {
         return rinvRadicalInverse(T, dimension - 1u, index);
     }
     return rinvRadicalInverse(T, dimension, index);
+}
+/* dimensions `dimension`, `dimension` + 1 of point `index` (a 2D request behind the camera sample: dimension >= 2) */
+DV void rinvSample2(const RinvTab &T, uint64_t index, uint32_t dimension, float &a, float &b) {
+    const uint32_t b0 = dimension - T.hammersley;           /* hammersley: its dimension d > 0 is the radical inverse in prime d - 1 */
+    if (T.dimInfo && dimension >= 1u && b0 + 1u < T.tabDims && !(index >> 32)) { rinvRadicalInverseTab2(T, b0, (uint32_t) index, a, b); return; }
+    a = rinvSample(T, index, dimension); b = rinvSample(T, index, dimension + 1u);
 }
 /* the camera sample: next2D at dimension 0, halton.cpp:375-378 / hammersley.cpp:271-274 */
 DV void rinvCameraSample(const RinvTab &T, uint32_t sampleIndex, uint32_t px, uint32_t py, float &jx, float &jy) {

@@ -148,6 +148,12 @@ __device__ __forceinline__ uint64_t seqIndex(const RenderConst &rc, uint32_t k, 
 __device__ __forceinline__ float seqSample(const RenderConst &rc, uint64_t idx, uint32_t dim) {
     return rc.sampler == PHIP_SAMPLER_SOBOL ? sobolSample(rc.sobol, idx, dim) : rinvSample(rc.rinv, idx, dim);
 }
+/* a 2D request: dimensions dim, dim + 1 of the point */
+__device__ __forceinline__ V2 seqSample2(const RenderConst &rc, uint64_t idx, uint32_t dim) {
+    float a, b;
+    if (rc.sampler == PHIP_SAMPLER_SOBOL) sobolSample2(rc.sobol, idx, dim, a, b); else rinvSample2(rc.rinv, idx, dim, a, b);
+    return V2(a, b);
+}
 /* dimensions the tables hold (hammersley: its dimension d > 0 uses prime d - 1) */
 __device__ __forceinline__ uint32_t seqDims(const RenderConst &rc) {
     return rc.sampler == PHIP_SAMPLER_SOBOL ? rc.sobol.dims : rc.rinv.dims + rc.rinv.hammersley;
@@ -201,7 +207,7 @@ __device__ __forceinline__ V2 streamDirectSample(const RenderConst &rc, uint32_t
             dim = which == 0 ? 2u : (E > 1u ? 2u : 5u);
             idx = seqIndex(rc, k, px, py);
         }
-        if (dim + 1u < seqDims(rc)) return V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
+        if (dim + 1u < seqDims(rc)) return seqSample2(rc, idx, dim);
         /* (beyond the tables -- the reference stops with an error there -- the counter stream below) */
     }
     if (rc.sampler == PHIP_SAMPLER_LD) {

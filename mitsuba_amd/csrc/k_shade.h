@@ -379,10 +379,10 @@ __device__ __forceinline__ bool shadeVertex(const DevScene &S, const EmitterTab 
                     if (okB) smpBSDF = V2(q[2], q[3]);
                 } else {
                     if (smoothVertex) {
-                        if (dim + 1u < nDims) smpEmitter = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
+                        if (dim + 1u < nDims) smpEmitter = seqSample2(rc, idx, dim);
                         dim += 2u + (k0 == 0u ? 1u : 0u);
                     }
-                    if (dim + 1u < nDims) smpBSDF = V2(seqSample(rc, idx, dim), seqSample(rc, idx, dim + 1u));
+                    if (dim + 1u < nDims) smpBSDF = seqSample2(rc, idx, dim);
                 }
             } else if (QMC && rc.sampler == PHIP_SAMPLER_STRATIFIED) {
                 /* 2D requests k0 + 1 (and k0 + 2 at a smooth vertex) of the sample: the first ST_DIMENSIONS are stratified, jittered by the counter stream's own numbers */

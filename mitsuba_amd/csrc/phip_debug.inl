@@ -144,6 +144,21 @@ int phip_debug_host_rinv(const uint32_t *primes, const uint16_t *perm, uint32_t 
     return PHIP_OK;
 }
 
+/* ... and the interleaved form of a 2D request (rinvSample2: dimensions dim, dim + 1 in one pass; hammersley = 1: dimension d is the radical inverse in prime d - 1) */
+int phip_debug_host_rinv2(const uint32_t *primes, const uint16_t *perm, uint32_t dims, int hammersley, size_t n, const unsigned long long *index, const uint32_t *dim, float *out2) {
+    std::vector<uint32_t> off(dims); size_t total = 0;
+    for (uint32_t d = 0; d < dims; ++d) { off[d] = (uint32_t) total; total += primes[d]; }
+    RinvTab T; memset(&T, 0, sizeof(T));
+    T.primes = primes; T.perm = perm; T.permOffset = off.data(); T.dims = dims; T.hammersley = hammersley ? 1u : 0u; T.factor = 1.0f;
+    std::vector<uint32_t> di, ch, pw; std::vector<float> fc;
+    T.tabDims = buildRinvTables(primes, perm, off.data(), dims, di, ch, fc, pw); T.dimInfo = di.data(); T.chunk = ch.data(); T.fac = fc.data(); T.pw = pw.data();
+    for (size_t i = 0; i < n; ++i) {
+        if (dim[i] < 1u || dim[i] + 1u >= dims) return setErr(PHIP_ERR_INVALID, "dimension out of range");
+        rinvSample2(T, index[i], dim[i], out2[2 * i], out2[2 * i + 1]);
+    }
+    return PHIP_OK;
+}
+
 /* Wald records + BVH statistics of a triangle soup, built exactly like phip_scene_create does (no GPU needed) */
 int phip_debug_host_build_bvh(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles,
                               phip_accel_info *info, float *scene_box6) {

@@ -274,6 +274,17 @@ def test_radical_inverse_tables_equal_the_digit_loops(phip):
             res.append(out)
         assert (res[0].view(np.uint32) == res[1].view(np.uint32)).all(), np.argwhere(res[0] != res[1])[:10]
         assert (res[0] >= 0).all() and (res[0] < 1).all()
+        # the interleaved 2D form (dimensions d, d + 1 in one pass: what a path vertex's 2D requests call), halton and hammersley numbering
+        for ham in (0, 1):
+            d2 = np.clip(dim, 1 + ham, len(primes) - 2).astype(np.uint32)
+            out2 = np.zeros((n, 2), np.float32)
+            assert phip.phip_debug_host_rinv2(primes.ctypes.data_as(u32p), perm.ctypes.data_as(u16p) if perm is not None else None, len(primes), ham, n,
+                                              index.ctypes.data_as(u64p), d2.ctypes.data_as(u32p), fp(out2)) == 0
+            for col in (0, 1):
+                single = np.zeros(n, np.float32); base = (d2 + col - ham).astype(np.uint32)
+                assert phip.phip_debug_host_rinv(primes.ctypes.data_as(u32p), perm.ctypes.data_as(u16p) if perm is not None else None, len(primes), 0, n,
+                                                 index.ctypes.data_as(u64p), base.ctypes.data_as(u32p), fp(single)) == 0
+                assert (single.view(np.uint32) == out2[:, col].view(np.uint32)).all(), (ham, col)
         # the definition (qmc.cpp:99-112, float accumulation) agrees to rounding: the Fast forms sum integer digits and scale once
         off = np.concatenate(([0], np.cumsum(primes.astype(np.int64))[:-1])).astype(np.int64)
         sel = np.arange(0, 3000)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5, GPU call g: C2 with the reference's samplers -- Halton / Hammersley through the multi-digit radical-inverse tables (PHIP_RINV_DIGITWISE=1: the digit
-# loops), the QMC build of k_mega without the Sobol' row loops (no scratch); sampler parity  -> gpurun_out/r5g/
+# round 5, GPU call g: C2 with the reference's samplers -- Halton / Hammersley through the multi-digit radical-inverse tables (the digit loops: an experiment
+# build with PHIP_RINV_DIGITWISE=1; the A/B row of profiles/r05_gpu_call_g_c2_samplers_rinv_tables.txt was made before the switch left the product), the QMC build of k_mega without the Sobol' row loops (no scratch); sampler parity  -> gpurun_out/r5g/
 mkdir -p gpurun_out/r5g
 o=gpurun_out/r5g
 rm -f mitsuba_amd/_build/libphip_*.so
@@ -13,7 +13,6 @@ from mitsuba_amd.integrator import Scene, PathHIP, PinnedFilm
 w=h=1024; spp=256
 sc=Scene(S.cornell_box(w,h,_ffi.gaussian_filter()).desc()); integ=PathHIP(maxDepth=-1); film=PinnedFilm(w,h)
 rows=(("ctr",{},{}),("sobol",dict(sobol=sobol_tables(w,h)),{}),("halton",dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1)),{}),
-      ("halton_digitwise",dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1)),{"PHIP_RINV_DIGITWISE":"1"}),
       ("hammersley",dict(sampler=A.PHIP_SAMPLER_HAMMERSLEY, qmc=qmc_tables(-1)),{}),("ctr",{},{}))
 for name,kw,env in rows:
     os.environ.update(env)
