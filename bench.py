@@ -250,6 +250,7 @@ def roofline(r):
              own TA / TCP / TCC counters (tools/pmc_tcp.py -> profiles/r03_tcp_*.json)"""
     name, desc, kms, launches = dominant_kernel(r)
     a = r["agg"]
+    nodes = r["accel"]["n_nodes"]
     avg_ms = kms / launches if launches else 0.0
     traffic, tsrc = profile_json("traffic", r["workload"])
     valu, vsrc = profile_json("valu", r["workload"])
@@ -290,7 +291,7 @@ def roofline(r):
                        "definition": "frac = SQ_THREAD_CYCLES_VALU / (256 CU x 4 SIMD x 32 lanes x cycles); issue_frac = SQ_INSTS_VALU x 2 / (1024 x cycles)"}
     # vector-memory path: lane-level load requests against the measured roof
     peak = ((vroof or {}).get("peak_lane_random_16B") or {}).get("16KB_L1")
-    if name in ("k_rays_w", "k_rays_p", "k_trace_p", "k_trace") and kms > 0:
+    if name in ("k_rays_w", "k_rays_p", "k_trace_p", "k_trace") and kms > 0 and (r["accel"]["node_bytes"] == 80 or nodes >= 64):      # (a tree staged in LDS makes no vector-memory requests for its nodes and records)
         per_node = VMEM_LOADS_PER_NODE.get(r["accel"]["node_bytes"], 7)
         loads = per_node * (a["closest_node_visits"] + a["shadow_node_visits"]) + VMEM_LOADS_PER_TRI * (a["closest_triangle_tests"] + a["shadow_triangle_tests"]) \
             + VMEM_LOADS_PER_RAY * (a["closest_rays"] + a["shadow_rays"])
