@@ -38,6 +38,13 @@
 #ifndef MEGA_BALANCE
 #define MEGA_BALANCE 1               /* FLAT == 2: the Wald tests of a traversal are dealt over the lanes of the wave (k_traverse.h: traverseFlat2W) instead of looping per lane */
 #endif
+#ifndef MEGA_CLASS_DEAL
+#define MEGA_CLASS_DEAL 1            /* MM != 0 (scenes with glass / copper: k_mega<MM_ALL>): before the vertex phase the paths of the BLOCK are dealt to its lanes by the BSDF
+                                        model of the surface they hit (an exchange of the path state through LDS), so that a wave runs the microfacet code only if it got
+                                        copper vertices.  Without it nearly every wave of the mixed Cornell box ran all three models for its few copper and glass lanes:
+                                        lane utilisation 0.41 against 0.77 on the all-diffuse box, 2.25 x the VALU instructions for 1.17 x the vertices
+                                        (profiles/r05_valu_cornell_mixed_*) */
+#endif
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
@@ -45,6 +52,7 @@ enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_
 
 template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2), 3: the same with 33..64 records (two-word masks; MEGA_BALANCE only) */,
           bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+    __shared__ uint32_t ldsClsCnt[4][BLOCK / 64];                 /* MEGA_CLASS_DEAL: lanes per BSDF model and wave */
     __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
                                                                    no wait -- and the three that count lanes as ballots in SGPRs: 66.9 vs 66.5 ms per C2 frame and
                                                                    125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
@@ -230,9 +238,12 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         }
 #endif
         PF_END(0, pfWant_) }
-        if (!__any(alive)) break;
+        if (MM != 0 && MEGA_CLASS_DEAL && FLAT >= 2 && MEGA_BALANCE) {
+            if (!__syncthreads_or(alive ? 1 : 0)) break;        /* (the waves of a block meet at barriers below: they leave the loop together) */
+        } else if (!__any(alive)) break;
 
         /* ---- closest hit ---- */
+        uint32_t hitCls = 0;                                    /* shade class of the record hit (the Wald record's 12th word: 0 diffuse, 1 rough conductor, 2 dielectric) */
         { PF_BEGIN
         if (FLAT >= 2 && MEGA_BALANCE) {                        /* every lane takes part: the tests of the wave's rays are dealt over its lanes */
             const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
@@ -244,6 +255,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             traverseFlat2W<false, FLAT == 3>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
             if (alive) {
                 v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+                hitCls = r.cls;
                 MEGA_COUNT(MC_RAYS, 1); MEGA_COUNT(MC_NODE, nNode); MEGA_COUNT(MC_TRI, nTri);
             }
         } else
@@ -263,6 +275,62 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         }
 
         PF_END(1, __ballot(alive)) }
+        /* ---- the paths of the block dealt to its lanes by BSDF model (MEGA_CLASS_DEAL above) ---- */
+        if (MM != 0 && MEGA_CLASS_DEAL && FLAT >= 2 && MEGA_BALANCE) {
+            /* order: rough conductors, dielectrics, diffuse surfaces (and rays that left the scene), lanes without a path -- the expensive models end up in the
+               first wave(s), the idle lanes in the last (which then prepares its camera samples 64 at a time) */
+            const uint32_t key = !alive ? 3u : ((pm_to_bits(v.hit.w) == PHIP_NO_HIT || hitCls == 0u) ? 2u : (hitCls == 1u ? 0u : 1u));
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                const unsigned long long m = __ballot(key == c);
+                if (key == c) rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+                if (lane == 0) ldsClsCnt[c][waveInBlock] = (uint32_t) __popcll(m);
+            }
+            __syncthreads();
+            uint32_t base = 0, special = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c)
+#pragma unroll
+                for (uint32_t w = 0; w < BLOCK / 64; ++w) {
+                    const uint32_t n = ldsClsCnt[c][w];
+                    if (c < key || (c == key && w < waveInBlock)) base += n;
+                    if (c < 2u) special += n;
+                }
+            /* block-uniform: nothing to separate in a pass whose vertices are all diffuse.  (Skipping the exchange also when copper and glass already lie in as
+               few waves as they fill changes nothing: profiles/r05_gpu_call_p_*) */
+            if (special) {
+                const uint32_t dst = base + rank;
+                uint32_t *x = (uint32_t *) g_smem;               /* [MEGA_DEAL_DWORDS][BLOCK], over the traversal stack / work lists (unused between traversals) */
+#define XPUT(j, val) x[(j) * BLOCK + dst] = (val)
+#define XGET(j) x[(j) * BLOCK + threadIdx.x]
+                XPUT(0, pm_to_bits(v.hit.x)); XPUT(1, pm_to_bits(v.hit.y)); XPUT(2, pm_to_bits(v.hit.z)); XPUT(3, pm_to_bits(v.hit.w));
+                XPUT(4, pm_to_bits(v.rayD.x)); XPUT(5, pm_to_bits(v.rayD.y)); XPUT(6, pm_to_bits(v.rayD.z));
+                XPUT(7, pm_to_bits(v.thr.x)); XPUT(8, pm_to_bits(v.thr.y)); XPUT(9, pm_to_bits(v.thr.z)); XPUT(10, pm_to_bits(v.thr.w));
+                __syncthreads();
+                v.hit = make_float4(pm_from_bits(XGET(0)), pm_from_bits(XGET(1)), pm_from_bits(XGET(2)), pm_from_bits(XGET(3)));
+                v.rayD = make_float4(pm_from_bits(XGET(4)), pm_from_bits(XGET(5)), pm_from_bits(XGET(6)), v.rayD.w);
+                v.thr = make_float4(pm_from_bits(XGET(7)), pm_from_bits(XGET(8)), pm_from_bits(XGET(9)), pm_from_bits(XGET(10)));
+                __syncthreads();
+                XPUT(0, pm_to_bits(v.mis.x)); XPUT(1, pm_to_bits(v.mis.y)); XPUT(2, v.id); XPUT(3, v.pixel); XPUT(4, v.k | (alive ? 0x80000000u : 0u)); XPUT(5, v.state);
+                XPUT(6, pm_to_bits(accum.x)); XPUT(7, pm_to_bits(accum.y)); XPUT(8, pm_to_bits(accum.z)); XPUT(9, pm_to_bits(accum.w));
+#if MEGA_REGEN_QUEUE
+                if (QMC) { XPUT(10, ldsSeq[QMC ? waveInBlock : 0][0][lane]); XPUT(11, ldsSeq[QMC ? waveInBlock : 0][1][lane]); }
+#endif
+                __syncthreads();
+                v.mis = make_float2(pm_from_bits(XGET(0)), pm_from_bits(XGET(1))); v.id = XGET(2); v.pixel = XGET(3);
+                { const uint32_t ka = XGET(4); v.k = ka & 0x7FFFFFFFu; alive = (ka >> 31) != 0u; }
+                v.state = XGET(5);
+                accum = make_float4(pm_from_bits(XGET(6)), pm_from_bits(XGET(7)), pm_from_bits(XGET(8)), pm_from_bits(XGET(9)));
+#if MEGA_REGEN_QUEUE
+                if (QMC) { ldsSeq[QMC ? waveInBlock : 0][0][lane] = XGET(10); ldsSeq[QMC ? waveInBlock : 0][1][lane] = XGET(11); }
+#endif
+#undef XPUT
+#undef XGET
+                __syncthreads();                                /* the region goes back to the traversals' work lists */
+            }
+        }
+
         /* ---- the vertex: emitter hit / Russian roulette / emission / NEE sample / BSDF sample ---- */
         bool pushShadow = false, ended = false;
         ShadowEntry sh;

@@ -40,6 +40,8 @@ struct TravStack {
     __device__ __forceinline__ uint32_t popLds() { --sp; return lds[sp * BLOCK]; }    /* the caller knows that nothing spilled */
 };
 
+/* k_mega<MM_ALL> (MEGA_CLASS_DEAL): dwords per lane and exchange round; the region [0, 12 KB) of the dynamic LDS, over the traversal stack (phip.hip sizes it) */
+#define MEGA_DEAL_DWORDS 12u
 /* bytes of dynamic LDS setupTraversal() uses; k_mega appends its shading tables (megaLdsBytesOf) */
 __host__ __device__ __forceinline__ size_t traversalLdsBytesOf(const DevScene &S) {
     return (size_t) S.stackDepth * BLOCK * sizeof(uint32_t) + (size_t) S.nodeCache * NODE_LDS_STRIDE * sizeof(float4) + (size_t) S.triCache * 3 * sizeof(float4);

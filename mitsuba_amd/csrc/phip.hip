@@ -793,7 +793,11 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
             D.flatLeaves = sd.flatLeaves.p; D.nFlatLeaves = (uint32_t) (flat.size() / 2);
         }
     }
-    if (fitsLdsBase && sc->materialMask != 0 && D.flatMode >= 2 && !expEnv("PHIP_NO_MEGA_MATERIALS")) sc->fitsLds = true;
+    if (fitsLdsBase && sc->materialMask != 0 && D.flatMode >= 2 && !expEnv("PHIP_NO_MEGA_MATERIALS")) {
+        sc->fitsLds = true;
+        /* k_mega<MM_ALL> deals the block's paths by BSDF model through MEGA_DEAL_DWORDS x BLOCK dwords of LDS that lie over the traversal stack (k_mega.h) */
+        D.stackDepth = std::max<uint32_t>(D.stackDepth, MEGA_DEAL_DWORDS);
+    }
     const bool traceable = D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !expEnv("PHIP_NO_SHADE_TRACE");
     sc->flatTrace = !sc->fitsLds && traceable; sc->flatTraceToo = sc->fitsLds && traceable;
     /* ... whose lanes are dealt by BSDF model where there is more than one (the kernel traces its own rays and leaves the class in the hit word) */
