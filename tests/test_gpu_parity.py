@@ -837,6 +837,28 @@ def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
         same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, render_kw=dict(flags_extra=A.PHIP_FLAG_NO_MEGA), **cfg)
 
 
+def test_cornell_mixed_paths_change_lanes_not_values(gpu, gauss):
+    """k_mega<MM_ALL> deals the block's paths to its lanes by BSDF model before every vertex (MEGA_CLASS_DEAL: the path state -- the QMC build's sequence
+    index included -- changes lanes through LDS).  At a size where every lane carries ~16 paths one after another (regeneration into lanes that just received
+    another lane's path), every sample of the frame is bit-identical to the three-kernel iterations, whatever the sampler"""
+    from conftest import sobol_tables, qmc_tables
+    from mitsuba_amd.integrator import Scene, PathHIP, VolPathSimpleHIP, HDRFilm
+    w = h = 512; spp = 16
+    gs = Scene(S.cornell_mixed(w, h, gauss).desc())
+    for name, cls, kw in (("ctr", PathHIP, {}), ("sobol", PathHIP, dict(sobol=sobol_tables(w, h))), ("halton", PathHIP, dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1))),
+                          ("volpath_simple", VolPathSimpleHIP, {})):
+        integ = cls(maxDepth=-1); film = HDRFilm(w, h); film2 = HDRFilm(w, h)
+        assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER, **kw)
+        assert integ.stats.fused == 1, name
+        a = integ.samples(gs, spp).copy(); va = integ.stats.path_vertices
+        assert integ.render(gs, film2, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_NO_FUSED, **kw)
+        assert integ.stats.fused == 0 and integ.stats.vertex_traced == 0, name
+        b = integ.samples(gs, spp)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all(), (name, float((a.view(np.uint32) != b.view(np.uint32)).any(axis=-1).mean()))
+        assert (film.storage.view(np.uint32) == film2.storage.view(np.uint32)).all() and va == integ.stats.path_vertices
+    gs.close()
+
+
 @pytest.mark.parametrize("cfg", [
     dict(maxDepth=-1), dict(maxDepth=1), dict(maxDepth=2), dict(maxDepth=3), dict(maxDepth=-1, rrDepth=2),
     dict(maxDepth=6, strictNormals=True), dict(maxDepth=5, hideEmitters=True),
