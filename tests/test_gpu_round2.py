@@ -21,7 +21,7 @@ def gpu(phip):
     return integrator
 
 
-def test_fused_kernel_is_chosen_for_lds_resident_diffuse_scenes_only(gpu, gauss):
+def test_fused_kernel_is_chosen_for_lds_resident_scenes_only(gpu, gauss):
     cb = gpu.Scene(S.cornell_box(64, 64, gauss).desc())
     assert cb.accel_info().fits_lds == 1
     integ = gpu.PathHIP(maxDepth=5)
@@ -32,11 +32,15 @@ def test_fused_kernel_is_chosen_for_lds_resident_diffuse_scenes_only(gpu, gauss)
     assert integ.stats.fused == 0 and integ.stats.iterations > 1
     d = gpu.DirectHIP()
     assert d.render(cb, gpu.HDRFilm(64, 64), 4) and d.stats.fused == 0      # `direct` stays on the wavefront kernels
-    sb = S.cornell_box(64, 64, gauss)
-    P, T, N = S.sphere_mesh((200, 300, 200), 45.0, 4, 3)
-    sb.mesh(P, T, sb.dielectric(1.33, 1.0), normals=N)
-    glass = gpu.Scene(sb.desc())
-    assert glass.accel_info().fits_lds == 0                                  # dielectric / microfacet models keep the wavefront kernels
+    for nu, nv, fits in ((4, 3, 1), (12, 8, 0)):
+        sb = S.cornell_box(64, 64, gauss)
+        P, T, N = S.sphere_mesh((200, 300, 200), 45.0, nu, nv)
+        sb.mesh(P, T, sb.dielectric(1.33, 1.0), normals=N)
+        glass = gpu.Scene(sb.desc())
+        # round 5: dielectric / microfacet models ride the fused kernel on the packed leaf table (<= 64 Wald records); beyond it they keep the wavefront kernels
+        assert glass.accel_info().fits_lds == fits, (len(T), glass.accel_info().as_dict())
+        assert integ.render(glass, gpu.HDRFilm(64, 64), 4) and integ.stats.fused == fits
+        glass.close()
     big = gpu.Scene(S.atrium(64, 36, gauss).desc())
     assert big.accel_info().fits_lds == 0
 
