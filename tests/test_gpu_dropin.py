@@ -88,7 +88,7 @@ def check_scene(ref, name, desc):
             q = float(np.percentile(cpu, 99.0))
             dq = abs(np.minimum(img, q).mean() - np.minimum(cpu, q).mean()) / np.minimum(cpu, q).mean()
             print("    clipped at the reference's 99th percentile: mean differs by %.2f %%" % (100 * dq))
-            ok = dm < 0.3 and dq < 0.08 and rel_l2(img, cpu) < 1.5
+            ok = dm < 0.3 and dq < 0.15 and rel_l2(img, cpu) < 1.5       # (measured over repeated runs, profiles/r05_gpu_call_v_*: atrium 5.1 / 7.2 % clipped, 7.0 / 13.2 % raw; the others < 3 %)
         else:
             ok = dm < 0.08 and rel_l2(img, cpu) < 0.6                        # small, noisy images (32 spp): two independent renders
         if not ok:
