@@ -353,6 +353,18 @@ def cornell_mixed(width, height, filter_table, light_scale=1.0, sb=None):
                        tall_bsdf=lambda b: b.dielectric())
 
 
+def cornell_spheres(width, height, filter_table, nlon=24, nlat=12, materials=True, sb=None):
+    """The Cornell box with a glass and a rough-copper sphere (`materials=False`: two diffuse spheres), tessellated nlon x nlat: 32 + 2 * 2 * nlon * (nlat - 1)
+    triangles -- the mid-sized scenes between the LDS-resident boxes and the atrium (1 k / 4.5 k / 18 k triangles at 24 x 12 / 48 x 24 / 96 x 48): the wavefront
+    kernels on a tree that lives in L2."""
+    sb = cornell_box(width, height, filter_table, sb=sb)
+    P, T, N = sphere_mesh((185, 120, 170), 70.0, nlon, nlat)
+    sb.mesh(P, T, sb.dielectric(1.5, 1.0) if materials else sb.diffuse((0.6, 0.6, 0.6)), normals=N)
+    P, T, N = sphere_mesh((370, 330, 350), 60.0, nlon, nlat)
+    sb.mesh(P, T, sb.twosided(sb.roughconductor(CU_ETA, CU_K, alpha=0.15)) if materials else sb.diffuse((0.7, 0.5, 0.3)), normals=N)
+    return sb
+
+
 # ==========================================================================================
 #  procedural meshes
 # ==========================================================================================

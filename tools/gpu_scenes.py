@@ -10,7 +10,12 @@ cfgs = {"cornell": ("cornell_box", 1024, 1024, 64, -1), "atrium": ("atrium", 192
         "atrium4k": ("atrium", 3840, 2160, 16, 8),
         "cmixed": ("cornell_mixed", 1024, 1024, 64, -1),                       # the Cornell box with a copper and a glass block (wavefront kernels)
         "c42": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 1}),       # 42 / 62 Wald records: the two-word record masks of the fused kernel
-        "c62": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 3})}
+        "c62": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 3}),
+        # the mid-sized scenes: the Cornell box with a glass and a copper sphere (or two diffuse ones) of 1 k / 4.5 k / 18 k triangles: a tree that lives in L2
+        "sph1k": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 24, "nlat": 12}), "sph5k": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 48, "nlat": 24}),
+        "sph18k": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 96, "nlat": 48}),
+        "sph1kd": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 24, "nlat": 12, "materials": False}),
+        "sph18kd": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 96, "nlat": 48, "materials": False})}
 for key in sys.argv[1:] or cfgs:
     name, w, h, spp, md = cfgs[key][:5]
     spp = int(os.environ.get("SPP", spp))
