@@ -89,7 +89,16 @@ def _build_locked(sid, out_lib, verbose):
         if src == "phip.hip":
             extra = extra + ['-DPHIP_BUILD_ID="%s"' % sid]
         cmds.append([hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj + ".tmp.o")])
-    # as many compilers at a time as there are cores, in the order of UNITS (longest first)
+    # as many compilers at a time as there are cores, longest unit first (measured seconds per feature set and part; the order of UNITS is part of the build id,
+    # the order of submission is not)
+    feat_cost = {11: 55.0, 3: 41.0, 2: 29.0, 1: 14.0, 8: 9.0, 0: 11.0}
+    def cost(cmd):
+        name = os.path.basename(cmd[-1])
+        if name.startswith("phip_shade"):
+            f, q = name[len("phip_shade"):].split(".")[0].split("_")
+            return feat_cost.get(int(f), 20.0) * (0.42 if q == "2" else 1.0)
+        return 31.0 if name.startswith("phip_mega") else 14.0
+    cmds.sort(key=cost, reverse=True)
     import concurrent.futures
     def run(cmd):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
