@@ -2,7 +2,8 @@
 """Phase profile of k_mega's persistent loop from a -DMEGA_PROFILE=1 build (tools/build_variant.sh prof with MEGA_FLAGS):
 the work-counter rows of phip_stats carry wave-clock ticks and active-lane counts per phase instead (k_mega.h, end of the kernel).
 
-    PHIP_LIB=mitsuba_amd/_build/libphip_prof.so SPP=64 python tools/mega_profile.py [out.json]
+    PHIP_LIB=mitsuba_amd/_build/libphip_prof.so SPP=64 [SCENE=cornell_mixed] python tools/mega_profile.py [out.json]
+(the exchange of MEGA_CLASS_DEAL lies between the closest-hit and the vertex phase and is in neither: it is what the four shares leave of the kernel's time)
 """
 import json
 import os
@@ -14,7 +15,8 @@ from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
 
 spp = int(os.environ.get("SPP", 64))
 w = h = 1024
-sc = Scene(S.cornell_box(w, h, _ffi.gaussian_filter()).desc())
+scene = os.environ.get("SCENE", "cornell_box")
+sc = Scene(getattr(S, scene)(w, h, _ffi.gaussian_filter()).desc())
 integ = PathHIP(maxDepth=-1); film = HDRFilm(w, h)
 integ.render(sc, film, 1)
 integ.render(sc, film, spp)
@@ -24,7 +26,7 @@ lanes = [None, st["shadow_node_visits"], st["shadow_triangle_tests"], st["path_v
 iters = st["samples"]
 tot = float(sum(ticks))
 names = ["regeneration", "closest hit", "vertex", "shadow ray"]
-out = {"spp": spp, "wave_iterations": iters, "fused_kernel_ms": st["fused_kernel_ms"], "lib": os.environ.get("PHIP_LIB", "")}
+out = {"scene": scene, "spp": spp, "wave_iterations": iters, "fused_kernel_ms": st["fused_kernel_ms"], "lib": os.environ.get("PHIP_LIB", "")}
 for i, n in enumerate(names):
     out[n] = {"share": round(ticks[i] / tot, 4), "ticks_per_iteration": round(ticks[i] * 256.0 / max(iters, 1), 1),
               "lanes_per_iteration": round(lanes[i] / max(iters, 1), 2) if lanes[i] is not None else None}
