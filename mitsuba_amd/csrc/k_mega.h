@@ -45,6 +45,34 @@
                                         lane utilisation 0.41 against 0.77 on the all-diffuse box, 2.25 x the VALU instructions for 1.17 x the vertices
                                         (profiles/r05_valu_cornell_mixed_*) */
 #endif
+#ifndef MEGA_MB_DIAG
+#define MEGA_MB_DIAG 0
+#endif
+#ifndef MEGA_MAILBOX
+#define MEGA_MAILBOX 1               /* MM != 0, counter stream (round 5's last step; the QMC build keeps MEGA_CLASS_DEAL: its static LDS leaves no room): wave 0 of the block SERVES the
+                                        rough-conductor vertices.  The other waves (clients) hand a path that hit copper to a 64-entry mailbox in LDS (S-box: each client owns a
+                                        third of it) and start another path; the server takes the vertices out when MEGA_MB_THRESH of them wait (or some have waited for
+                                        MEGA_MB_PATIENCE of its passes), shades them, traces their shadow rays and hands the continued paths back through a second mailbox (R-box),
+                                        from which the clients fill their free lanes before they take camera samples.  Between batches the server starts camera samples 64 at a
+                                        time and hands their continuations over as well: it holds no path between passes.  No block barrier: the microfacet code runs for
+                                        near-full waves, once per batch instead of once per pass, and nobody waits for the wave that runs it.  Mixed Cornell box 2427 -> 3070
+                                        Msamples/s, copper block only 2694 -> 3484, glass block only 3360 -> 3479, every sample bit-identical (profiles/r05_gpu_call_mb_*).
+                                        Glass vertices stay with the clients (MEGA_MB_CLASSES bit 1): batching them too is slower than not batching at all (2378) */
+#endif
+#ifndef MEGA_MB_CLASSES
+#define MEGA_MB_CLASSES 1            /* shade classes the clients hand over: bit 0 rough conductor, bit 1 dielectric */
+#endif
+#ifndef MEGA_MB_THRESH
+#define MEGA_MB_THRESH 40            /* 24 .. 48 and patience 3 .. 10 measure the same (81.6 - 82.9 ms per frame) */
+#endif
+#ifndef MEGA_MB_PATIENCE
+#define MEGA_MB_PATIENCE 6
+#endif
+#define MB_NS 64u                    /* entries of the S-box (dynamic LDS, behind the work lists) and of the R-box (static: what four blocks per CU leave) */
+#define MB_NR 48u
+#define MB_DW 22u                    /* dwords per mailbox entry (S-box: hit 4, direction 3, throughput 4, MIS 2, id, pixel, k, state, accumulator 4 = 21; R-box: origin + mint 4,
+                                        direction + maxt 4 instead of hit and direction = 22) */
+static_assert((BLOCK / 64u) * BAL_WAVE_BYTES + MB_DW * MB_NS * sizeof(uint32_t) <= MEGA_DEAL_DWORDS * BLOCK * sizeof(uint32_t), "the S-box lies behind the work lists in the region phip.hip sizes with MEGA_DEAL_DWORDS");
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
@@ -52,7 +80,12 @@ enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_
 
 template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2), 3: the same with 33..64 records (two-word masks; MEGA_BALANCE only) */,
           bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+    constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;     /* (the QMC build's static LDS leaves no room for the R-box at four blocks per CU) */
+    constexpr bool DEAL = MM != 0 && FLAT >= 2 && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;
     __shared__ uint32_t ldsClsCnt[4][BLOCK / 64];                 /* MEGA_CLASS_DEAL: lanes per BSDF model and wave */
+    __shared__ uint32_t mbR[MAILBOX ? MB_DW * MB_NR : 1u];        /* MEGA_MAILBOX: the R-box, [MB_DW][MB_NR]; the S-box lies in the dynamic LDS behind the traversals' work lists (phip.hip sizes the region) */
+    __shared__ uint32_t mbState[MAILBOX ? MB_NS + MB_NR : 1u];   /* entry states, S-box then R-box: 0 empty, 2 full, 3 being read (R-box: three consumers claim by compare-and-swap) */
+    __shared__ int mbLive;                                        /* sample ids drawn by the block's waves that have not ended as a sample yet (queued camera samples and paths, wherever they are) */
     __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
                                                                    no wait -- and the three that count lanes as ballots in SGPRs: 66.9 vs 66.5 ms per C2 frame and
                                                                    125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
@@ -78,6 +111,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     lds_cf4 *flat = (lds_cf4 *) ldsFlat;
     for (uint32_t i = threadIdx.x; i < S.nTriangles * TRISHADE_FLOAT4S; i += BLOCK) ldsTriShade[i] = S.triShade[i];
     S.triShade = ldsTriShade;                                   /* (generic pointer into LDS: six loads per vertex, not the inner loop) */
+    if (MAILBOX) { if (threadIdx.x < MB_NS + MB_NR) mbState[threadIdx.x] = 0u; if (threadIdx.x == 0u) mbLive = 0; }
     TravStack stk; setupTraversal(S, g_smem, nullptr, stk);     /* stack + all nodes + all Wald records in LDS (barrier inside); the host checked that nothing can spill */
 
     const uint32_t waveId = blockIdx.x * (BLOCK / 64) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = __lane_id();
@@ -90,6 +124,27 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     { V3 d_; float mn_, mx_; cameraRay(S.cam, 0.5f, 0.5f, camO, d_, mn_, mx_); }
 #endif
     bool exhausted = rc.totalIds == 0;
+    /* MEGA_MAILBOX */
+    uint32_t *mbS = (uint32_t *) (g_smem + (BLOCK / 64u) * BAL_WAVE_BYTES);      /* the S-box, [MB_DW][64], behind the four waves' work lists */
+    const bool server = MAILBOX && waveInBlock == 0u;
+    bool haveHit = false;                                       /* server: the lane's path came out of the S-box with its hit */
+    uint32_t idleSpins = 0, patience = 0;
+    bool mbTimedOut = false;
+#if MEGA_MB_DIAG
+    uint32_t dgDeposit = 0, dgLocal = 0, dgWithdrawn = 0, dgKept = 0, dgServerPass = 0, dgClientPass = 0, dgRefill = 0, dgServerRegen = 0;
+#endif
+    /* the k-th lane that `wants` gets the index of the k-th entry that is `avail` (lane l looks at entry l); through the wave's slot array, free between traversals */
+    auto mbAssign = [&](bool wants, bool avail, uint32_t &e) -> bool {
+        const unsigned long long am = __ballot(avail), wm = __ballot(wants);
+        lds_u32 *map = (lds_u32 *) wb.slot;
+        if (avail) map[__builtin_amdgcn_mbcnt_hi((uint32_t) (am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) am, 0u))] = lane;
+        BAL_SYNC();
+        const uint32_t rw = __builtin_amdgcn_mbcnt_hi((uint32_t) (wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) wm, 0u));
+        const bool got = wants && rw < (uint32_t) __popcll(am);
+        e = got ? map[rw] : 0u;
+        BAL_SYNC();
+        return got;
+    };
 
     bool alive = false;
     PathVertex v; v.id = v.pixel = v.k = v.state = 0;
@@ -114,6 +169,58 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 #if MEGA_PROFILE
         const unsigned long long pfWant_ = __ballot(!alive);
 #endif
+        bool skipRegen = false;
+        if (MAILBOX) {
+            haveHit = false;
+            if (__any(!alive)) {
+                if (server) {
+                    /* the server's free lanes take the copper vertices out of the S-box (the only consumer: no claim needed) */
+                    const uint32_t stt = __hip_atomic_load(&mbState[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t nFull = (uint32_t) __popcll(__ballot(stt == 2u));
+                    bool waiting = nFull != 0u;
+                    if (waiting && nFull < (uint32_t) MEGA_MB_THRESH && !exhausted && ++patience <= (uint32_t) MEGA_MB_PATIENCE) waiting = false;      /* not a full wave yet: camera samples meanwhile */
+                    if (waiting) patience = 0u;
+                    skipRegen = waiting;
+                    uint32_t e;
+                    if (waiting && mbAssign(!alive, stt == 2u, e)) {
+                        const uint32_t *x = mbS + e;
+                        v.hit = make_float4(pm_from_bits(x[0 * MB_NS]), pm_from_bits(x[1 * MB_NS]), pm_from_bits(x[2 * MB_NS]), pm_from_bits(x[3 * MB_NS]));
+                        v.rayD = make_float4(pm_from_bits(x[4 * MB_NS]), pm_from_bits(x[5 * MB_NS]), pm_from_bits(x[6 * MB_NS]), 0.0f);
+                        v.thr = make_float4(pm_from_bits(x[7 * MB_NS]), pm_from_bits(x[8 * MB_NS]), pm_from_bits(x[9 * MB_NS]), pm_from_bits(x[10 * MB_NS]));
+                        v.mis = make_float2(pm_from_bits(x[11 * MB_NS]), pm_from_bits(x[12 * MB_NS]));
+                        v.id = x[13 * MB_NS]; v.pixel = x[14 * MB_NS]; v.k = x[15 * MB_NS]; v.state = x[16 * MB_NS];
+                        accum = make_float4(pm_from_bits(x[17 * MB_NS]), pm_from_bits(x[18 * MB_NS]), pm_from_bits(x[19 * MB_NS]), pm_from_bits(x[20 * MB_NS]));
+                        alive = true; haveHit = true;
+#if MEGA_MB_DIAG
+                        ++dgWithdrawn;
+#endif
+                        __hip_atomic_store(&mbState[e], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+                    /* a client's free lanes take continued paths out of the R-box (three consumers: claim by compare-and-swap) before they take camera samples */
+                    const uint32_t stt = lane < MB_NR ? __hip_atomic_load(&mbState[MB_NS + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
+                    uint32_t e;
+                    if (__any(stt == 2u)) {
+                        bool got = mbAssign(!alive, stt == 2u, e);
+                        if (got) got = atomicCAS(&mbState[MB_NS + e], 2u, 3u) == 2u;
+                        if (got) {
+                            const uint32_t *x = mbR + e;
+                            v.rayO = make_float4(pm_from_bits(x[0 * MB_NR]), pm_from_bits(x[1 * MB_NR]), pm_from_bits(x[2 * MB_NR]), pm_from_bits(x[3 * MB_NR]));
+                            v.rayD = make_float4(pm_from_bits(x[4 * MB_NR]), pm_from_bits(x[5 * MB_NR]), pm_from_bits(x[6 * MB_NR]), pm_from_bits(x[7 * MB_NR]));
+                            v.thr = make_float4(pm_from_bits(x[8 * MB_NR]), pm_from_bits(x[9 * MB_NR]), pm_from_bits(x[10 * MB_NR]), pm_from_bits(x[11 * MB_NR]));
+                            v.mis = make_float2(pm_from_bits(x[12 * MB_NR]), pm_from_bits(x[13 * MB_NR]));
+                            v.id = x[14 * MB_NR]; v.pixel = x[15 * MB_NR]; v.k = x[16 * MB_NR]; v.state = x[17 * MB_NR];
+                            accum = make_float4(pm_from_bits(x[18 * MB_NR]), pm_from_bits(x[19 * MB_NR]), pm_from_bits(x[20 * MB_NR]), pm_from_bits(x[21 * MB_NR]));
+                            alive = true;
+#if MEGA_MB_DIAG
+                            ++dgRefill;
+#endif
+                            __hip_atomic_store(&mbState[MB_NS + e], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+        }
         /* ---- regeneration: lanes without a path start the next camera sample (integrator.cpp:157-183) ---- */
 #if MEGA_REGEN_QUEUE
         /* Camera samples are prepared 64 at a time by ALL lanes of the wave (id decode, pixel jitter, camera ray: ~670 instructions) into a
@@ -121,7 +228,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
            loop for the ~18 lanes (28 %) whose paths had just ended: 14 % of the kernel's time at a quarter of the lanes. */
         for (;;) {
             const unsigned long long want = __ballot(!alive);
-            if (!want) break;
+            if (!want || (MAILBOX && skipRegen)) break;
             if (qCount == 0u) {
                 if (exhausted) break;
                 if (next >= end) {                              /* draw a chunk (wave-uniform branch) */
@@ -134,6 +241,12 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                             const unsigned long long share = (rc.totalIds - seen) / (2ull * M.nWaves);
                             chunk = (uint32_t) (share > MEGA_CHUNK_MAX ? MEGA_CHUNK_MAX : (share < MEGA_CHUNK_MIN ? MEGA_CHUNK_MIN : share));
                             chunk &= ~63u;
+                            if (MAILBOX) {
+                                /* the ids are counted as the block's BEFORE they are drawn (and what the draw does not grant is taken back below): a wave that finds
+                                   the supply exhausted by this very draw must not read mbLive without it */
+                                atomicAdd(&mbLive, (int) chunk);
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            }
                             base = atomicAdd(M.nextId, (unsigned long long) chunk);
                         } else {
                             base = rc.totalIds;
@@ -143,6 +256,10 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                     chunk = __builtin_amdgcn_readfirstlane(chunk);
                     next = ((unsigned long long) bhi << 32) | blo;
                     end = next + chunk; if (end > rc.totalIds) end = rc.totalIds;
+                    if (MAILBOX && lane == 0u && chunk) {       /* every granted id ends as a sample or is skipped below */
+                        const unsigned long long granted = end > next ? end - next : 0ull;
+                        if (granted < chunk) atomicSub(&mbLive, (int) (chunk - granted));
+                    }
                     if (next >= end) { exhausted = true; break; }
                 }
                 /* the next 64 ids of the chunk, one per lane (ids outside the crop window -- edge blocks -- are consumed and skipped) */
@@ -150,6 +267,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 uint32_t px = 0, py = 0, k = 0;
                 const bool valid = id < end && decodeId(rc, S.film, id, px, py, k);
                 const unsigned long long vmask = __ballot(valid);
+                if (MAILBOX) { const int skipped = __popcll(__ballot(id < end && !valid)); if (skipped && lane == 0u) atomicSub(&mbLive, skipped); }
                 if (valid) {
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t) (vmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) vmask, 0u));
                     const uint32_t pixel = py * (uint32_t) S.film.width + px;
@@ -238,8 +356,18 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         }
 #endif
         PF_END(0, pfWant_) }
-        if (MM != 0 && MEGA_CLASS_DEAL && FLAT >= 2 && MEGA_BALANCE) {
+        if (DEAL) {
             if (!__syncthreads_or(alive ? 1 : 0)) break;        /* (the waves of a block meet at barriers below: they leave the loop together) */
+        } else if (MAILBOX) {
+            if (!__any(alive)) {
+                /* nothing in this wave's lanes: done when no id is left anywhere AND every id the block's waves drew has ended as a sample (a path may sit in a
+                   mailbox or in another wave and come here yet); until then look into the mailboxes again.  The wait is bounded: no bug may hang the device */
+                if (exhausted && qCount == 0u && __hip_atomic_load(&mbLive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= 0) break;
+                if (++idleSpins > (1u << 22)) { mbTimedOut = true; break; }      /* (the host refuses the frame: phip.hip) */
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            idleSpins = 0;
         } else if (!__any(alive)) break;
 
         /* ---- closest hit ---- */
@@ -251,9 +379,10 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             TravResult r;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
-            const bool go = alive & clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp);
+            const bool trace = alive && !(MAILBOX && haveHit);
+            const bool go = trace & clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp);
             traverseFlat2W<false, FLAT == 3>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
-            if (alive) {
+            if (trace) {
                 v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
                 hitCls = r.cls;
                 MEGA_COUNT(MC_RAYS, 1); MEGA_COUNT(MC_NODE, nNode); MEGA_COUNT(MC_TRI, nTri);
@@ -275,8 +404,42 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         }
 
         PF_END(1, __ballot(alive)) }
+        /* ---- MEGA_MAILBOX: a client hands the paths that hit copper to the server (if its third of the S-box has room: otherwise it shades them itself) ---- */
+        if (MAILBOX && !server) {
+            const bool special = alive && pm_to_bits(v.hit.w) != PHIP_NO_HIT && hitCls != 0u && ((MEGA_MB_CLASSES >> (hitCls - 1u)) & 1u);
+            if (__any(special)) {
+                /* the wave's own third of the S-box: clients that run in step would pick the same free entries otherwise, and all but one lose the claim */
+                const uint32_t stt = __hip_atomic_load(&mbState[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                uint32_t e;
+                const bool got = mbAssign(special, stt == 0u && (lane * 3u) / MB_NS == waveInBlock - 1u, e);
+                if (got) {
+                    uint32_t *x = mbS + e;
+                    x[0 * MB_NS] = pm_to_bits(v.hit.x); x[1 * MB_NS] = pm_to_bits(v.hit.y); x[2 * MB_NS] = pm_to_bits(v.hit.z); x[3 * MB_NS] = pm_to_bits(v.hit.w);
+                    x[4 * MB_NS] = pm_to_bits(v.rayD.x); x[5 * MB_NS] = pm_to_bits(v.rayD.y); x[6 * MB_NS] = pm_to_bits(v.rayD.z);
+                    x[7 * MB_NS] = pm_to_bits(v.thr.x); x[8 * MB_NS] = pm_to_bits(v.thr.y); x[9 * MB_NS] = pm_to_bits(v.thr.z); x[10 * MB_NS] = pm_to_bits(v.thr.w);
+                    x[11 * MB_NS] = pm_to_bits(v.mis.x); x[12 * MB_NS] = pm_to_bits(v.mis.y);
+                    x[13 * MB_NS] = v.id; x[14 * MB_NS] = v.pixel; x[15 * MB_NS] = v.k; x[16 * MB_NS] = v.state;
+                    x[17 * MB_NS] = pm_to_bits(accum.x); x[18 * MB_NS] = pm_to_bits(accum.y); x[19 * MB_NS] = pm_to_bits(accum.z); x[20 * MB_NS] = pm_to_bits(accum.w);
+                    __hip_atomic_store(&mbState[e], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    alive = false;
+#if MEGA_MB_DIAG
+                    ++dgDeposit;
+#endif
+                }
+#if MEGA_MB_DIAG
+                if (special && alive) ++dgLocal;
+#endif
+            }
+#if MEGA_MB_DIAG
+            if (lane == 0u) ++dgClientPass;
+#endif
+        }
+#if MEGA_MB_DIAG
+        if (MAILBOX && server && lane == 0u) ++dgServerPass;
+        if (MAILBOX && server && alive && !haveHit && (v.state & F_FIRST)) ++dgServerRegen;
+#endif
         /* ---- the paths of the block dealt to its lanes by BSDF model (MEGA_CLASS_DEAL above) ---- */
-        if (MM != 0 && MEGA_CLASS_DEAL && FLAT >= 2 && MEGA_BALANCE) {
+        if (DEAL) {
             /* order: rough conductors, dielectrics, diffuse surfaces (and rays that left the scene), lanes without a path -- the expensive models end up in the
                first wave(s), the idle lanes in the last (which then prepares its camera samples 64 at a time) */
             const uint32_t key = !alive ? 3u : ((pm_to_bits(v.hit.w) == PHIP_NO_HIT || hitCls == 0u) ? 2u : (hitCls == 1u ? 0u : 1u));
@@ -385,6 +548,29 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             MEGA_COUNT(MC_SAMPLES, 1);
             alive = false;
         }
+        if (MAILBOX) {
+            const int nEnded = __popcll(__ballot(ended));
+            if (nEnded && lane == 0u) atomicSub(&mbLive, nEnded);
+            if (server && __any(alive)) {
+                /* the server hands every continued path back (the only producer of the R-box: no claim); what finds no room stays and is traced here in the next pass */
+                const uint32_t stt = lane < MB_NR ? __hip_atomic_load(&mbState[MB_NS + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
+                uint32_t e;
+                if (mbAssign(alive, stt == 0u, e)) {
+                    uint32_t *x = mbR + e;
+                    x[0 * MB_NR] = pm_to_bits(v.rayO.x); x[1 * MB_NR] = pm_to_bits(v.rayO.y); x[2 * MB_NR] = pm_to_bits(v.rayO.z); x[3 * MB_NR] = pm_to_bits(v.rayO.w);
+                    x[4 * MB_NR] = pm_to_bits(v.rayD.x); x[5 * MB_NR] = pm_to_bits(v.rayD.y); x[6 * MB_NR] = pm_to_bits(v.rayD.z); x[7 * MB_NR] = pm_to_bits(v.rayD.w);
+                    x[8 * MB_NR] = pm_to_bits(v.thr.x); x[9 * MB_NR] = pm_to_bits(v.thr.y); x[10 * MB_NR] = pm_to_bits(v.thr.z); x[11 * MB_NR] = pm_to_bits(v.thr.w);
+                    x[12 * MB_NR] = pm_to_bits(v.mis.x); x[13 * MB_NR] = pm_to_bits(v.mis.y);
+                    x[14 * MB_NR] = v.id; x[15 * MB_NR] = v.pixel; x[16 * MB_NR] = v.k; x[17 * MB_NR] = v.state;
+                    x[18 * MB_NR] = pm_to_bits(accum.x); x[19 * MB_NR] = pm_to_bits(accum.y); x[20 * MB_NR] = pm_to_bits(accum.z); x[21 * MB_NR] = pm_to_bits(accum.w);
+                    __hip_atomic_store(&mbState[MB_NS + e], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    alive = false;
+                }
+#if MEGA_MB_DIAG
+                if (alive) ++dgKept;
+#endif
+            }
+        }
     }
 #if MEGA_PROFILE
     if (lane == 0) {      /* rows: closest rays / nodes / tris / shadow rays = ticks of the four phases; shadow nodes / tris / vertices = lanes x 1 of phases 1..3; samples stay */
@@ -398,10 +584,14 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     }
 #endif
 
+#if MEGA_MB_DIAG
+    ldsCount[MC_NODE][threadIdx.x] = dgDeposit; ldsCount[MC_TRI][threadIdx.x] = dgLocal; ldsCount[MC_SH_NODE][threadIdx.x] = dgWithdrawn; ldsCount[MC_SH_TRI][threadIdx.x] = dgKept;
+    ldsCount[MC_RAYS][threadIdx.x] = dgServerPass; ldsCount[MC_SH_RAYS][threadIdx.x] = dgClientPass; ldsCount[MC_VERTICES][threadIdx.x] = dgRefill + (dgServerRegen << 0) * 0u; ldsCount[MC_SAMPLES][threadIdx.x] = dgServerRegen;
+#endif
     /* per-wave statistics (one owner per entry, no atomics) */
     PathPool P; P.stat = M.stat; P.nWaves = M.nWaves;
     const int rows[MC_COUNT] = { ST_SAMPLES, ST_VERTICES, ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
 #pragma unroll
-    for (int i = 0; i < MC_COUNT; ++i) waveStat(P, rows[i], waveId, ldsCount[i][threadIdx.x]);
+    for (int i = 0; i < MC_COUNT; ++i) waveStat(P, rows[i], waveId, ldsCount[i][threadIdx.x] + ((MAILBOX && i == MC_SAMPLES && mbTimedOut && lane == 0u) ? (1ull << 62) : 0ull));
 }
 

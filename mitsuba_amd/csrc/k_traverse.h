@@ -40,7 +40,8 @@ struct TravStack {
     __device__ __forceinline__ uint32_t popLds() { --sp; return lds[sp * BLOCK]; }    /* the caller knows that nothing spilled */
 };
 
-/* k_mega<MM_ALL> (MEGA_CLASS_DEAL): dwords per lane and exchange round; the region [0, 12 KB) of the dynamic LDS, over the traversal stack (phip.hip sizes it) */
+/* k_mega<MM_ALL>: the region [0, 12 KB) of the dynamic LDS, over the traversal stack (phip.hip sizes it) -- MEGA_CLASS_DEAL (QMC build): dwords per lane and exchange round;
+   MEGA_MAILBOX: the four waves' work lists (6 KB), then the S-box */
 #define MEGA_DEAL_DWORDS 12u
 /* bytes of dynamic LDS setupTraversal() uses; k_mega appends its shading tables (megaLdsBytesOf) */
 __host__ __device__ __forceinline__ size_t traversalLdsBytesOf(const DevScene &S) {

@@ -795,7 +795,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     }
     if (fitsLdsBase && sc->materialMask != 0 && D.flatMode >= 2 && !expEnv("PHIP_NO_MEGA_MATERIALS")) {
         sc->fitsLds = true;
-        /* k_mega<MM_ALL> deals the block's paths by BSDF model through MEGA_DEAL_DWORDS x BLOCK dwords of LDS that lie over the traversal stack (k_mega.h) */
+        /* k_mega<MM_ALL> keeps its mailbox of copper vertices (QMC build: the exchange buffer of its class deal) in MEGA_DEAL_DWORDS x BLOCK dwords of LDS that lie over the traversal stack (k_mega.h) */
         D.stackDepth = std::max<uint32_t>(D.stackDepth, MEGA_DEAL_DWORDS);
     }
     const bool traceable = D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !expEnv("PHIP_NO_SHADE_TRACE");
@@ -1158,6 +1158,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, qmc, megaLdsBytesOf(D)));
         if (const char *e = expEnv("PHIP_MEGA_BLOCKS")) megaPerCU = std::max(1, std::min(megaPerCU, atoi(e)));
         if (megaPerCU <= 0) fused = false;
+        if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "[phip] k_mega: %d blocks per CU with %zu bytes of dynamic LDS\n", megaPerCU, megaLdsBytesOf(D));
     }
     sd.fused = fused;
     /* ... or k_shade_trace: the scene's tree is the packed leaf table, but k_mega does not serve it (glass / copper / textures / environment emitter) */
@@ -1519,6 +1520,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         HIP_TRY(hipMemcpyAsync(&hc, sd.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
+        /* (k_mega's mailbox protocol bounds its waits; a wave that gave up poisons its sample count: k_mega.h) */
+        if (fused && hc.total[ST_SAMPLES] > rc.totalIds) throw std::runtime_error("internal error: k_mega's mailbox protocol timed out (samples are missing from the frame)");
         st.samples += hc.total[ST_SAMPLES]; st.closest_rays += hc.total[ST_CLOSEST_RAYS]; st.shadow_rays += hc.total[ST_SHADOW_RAYS];
         st.path_vertices += hc.total[ST_VERTICES]; st.closest_node_visits += hc.total[ST_NODE]; st.closest_triangle_tests += hc.total[ST_TRI];
         st.shadow_node_visits += hc.total[ST_SH_NODE]; st.shadow_triangle_tests += hc.total[ST_SH_TRI];

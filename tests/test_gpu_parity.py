@@ -835,12 +835,16 @@ def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
         print("cornell_mixed %s: identical %.6f rel L2 %.3e" % (cfg, same, r))
         # ... == k_shade_trace (PHIP_FLAG_NO_MEGA; compare_render again holds it against the three-kernel iterations)
         same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, render_kw=dict(flags_extra=A.PHIP_FLAG_NO_MEGA), **cfg)
+    # a ragged film: the edge blocks' ids outside the image are drawn and skipped (k_mega's count of the block's live ids must take them back, or its waves never leave)
+    same, r = compare_render(gpu, oracle, S.cornell_mixed(100, 70, gauss).desc(), 6, min_identical=0.9999, maxDepth=-1)
+    same, r = compare_render(gpu, oracle, S.cornell_mixed(100, 70, gauss).desc(), 2, min_identical=0.9999, maxDepth=3, render_kw=dict(block_size=16))
 
 
 def test_cornell_mixed_paths_change_lanes_not_values(gpu, gauss):
-    """k_mega<MM_ALL> deals the block's paths to its lanes by BSDF model before every vertex (MEGA_CLASS_DEAL: the path state -- the QMC build's sequence
-    index included -- changes lanes through LDS).  At a size where every lane carries ~16 paths one after another (regeneration into lanes that just received
-    another lane's path), every sample of the frame is bit-identical to the three-kernel iterations, whatever the sampler"""
+    """In k_mega<MM_ALL> paths change lanes and waves through LDS: with the counter stream a path that hits copper goes to the block's serving wave through a
+    mailbox and comes back through another (MEGA_MAILBOX); the QMC build deals the block's paths to its lanes by BSDF model before every vertex (MEGA_CLASS_DEAL:
+    the sequence index travels along).  At a size where every lane carries ~16 paths one after another, every sample of the frame is bit-identical to the
+    three-kernel iterations, whatever the sampler and the integrator -- and none is lost (the statistics count them)"""
     from conftest import sobol_tables, qmc_tables
     from mitsuba_amd.integrator import Scene, PathHIP, VolPathSimpleHIP, HDRFilm
     w = h = 512; spp = 16
@@ -855,7 +859,7 @@ def test_cornell_mixed_paths_change_lanes_not_values(gpu, gauss):
         assert integ.stats.fused == 0 and integ.stats.vertex_traced == 0, name
         b = integ.samples(gs, spp)
         assert (a.view(np.uint32) == b.view(np.uint32)).all(), (name, float((a.view(np.uint32) != b.view(np.uint32)).any(axis=-1).mean()))
-        assert (film.storage.view(np.uint32) == film2.storage.view(np.uint32)).all() and va == integ.stats.path_vertices
+        assert (film.storage.view(np.uint32) == film2.storage.view(np.uint32)).all() and va == integ.stats.path_vertices and integ.stats.samples == w * h * spp
     gs.close()
 
 

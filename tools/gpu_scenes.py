@@ -12,6 +12,8 @@ cfgs = {"cornell": ("cornell_box", 1024, 1024, 64, -1), "atrium": ("atrium", 192
         "c42": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 1}),       # 42 / 62 Wald records: the two-word record masks of the fused kernel
         "c62": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 3}),
         # the mid-sized scenes: the Cornell box with a glass and a copper sphere (or two diffuse ones) of 1 k / 4.5 k / 18 k triangles: a tree that lives in L2
+        "cglass": ("cornell_box", 1024, 1024, 64, -1, {"tall_bsdf": lambda b: b.dielectric()}),            # the box with a glass block only / a copper block only
+        "ccopper": ("cornell_box", 1024, 1024, 64, -1, {"short_bsdf": lambda b: b.twosided(b.roughconductor(S.CU_ETA, S.CU_K, alpha=0.1))}),
         "sph1k": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 24, "nlat": 12}), "sph5k": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 48, "nlat": 24}),
         "sph18k": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 96, "nlat": 48}),
         "sph1kd": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 24, "nlat": 12, "materials": False}),
