@@ -837,7 +837,6 @@ def test_cornell_mixed_matches_oracle(gpu, oracle, gauss):
         same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, render_kw=dict(flags_extra=A.PHIP_FLAG_NO_MEGA), **cfg)
     # a ragged film: the edge blocks' ids outside the image are drawn and skipped (k_mega's count of the block's live ids must take them back, or its waves never leave)
     same, r = compare_render(gpu, oracle, S.cornell_mixed(100, 70, gauss).desc(), 6, min_identical=0.9999, maxDepth=-1)
-    same, r = compare_render(gpu, oracle, S.cornell_mixed(100, 70, gauss).desc(), 2, min_identical=0.9999, maxDepth=3, render_kw=dict(block_size=16))
 
 
 def test_cornell_mixed_paths_change_lanes_not_values(gpu, gauss):
