@@ -175,11 +175,11 @@ print(integ.stats.samples)
 # ---- throughput floors: a change that halves a workload must not pass the suite ---------------------------------------------------------
 def test_throughput_floors_of_the_bench_workloads(gpu, gauss):
     """Coarse, box-tolerant floors on the single-GPU workloads of bench.py, one timed frame each after a warm-up frame (the frame into page-locked host memory:
-    bench.py's `value`): about 70 % of what round 5 measured (C2 4750, mixed Cornell box 2360, C3 650, C4 at 128 spp 640, Msamples/s; the boxes of the pool
+    bench.py's `value`): about 65-70 % of what round 5 measured (C2 4440-4750, mixed Cornell box 3050, C3 640, C4 at 128 spp 640, Msamples/s; the boxes of the pool
     differ by +- 3-7 %).  Not a benchmark -- bench.py is -- but no functional test notices a kernel that became twice as slow."""
     import time
     from mitsuba_amd.integrator import Scene, PathHIP, PinnedFilm
-    floors = (("cornell_box", 1024, 1024, 256, -1, 3300.0), ("cornell_mixed", 1024, 1024, 256, -1, 1600.0),
+    floors = (("cornell_box", 1024, 1024, 256, -1, 3300.0), ("cornell_mixed", 1024, 1024, 256, -1, 2000.0),
               ("atrium", 1920, 1080, 64, 8, 450.0), ("glass_room", 1920, 1080, 128, 16, 440.0))
     for name, w, h, spp, md, floor in floors:
         sc = Scene(getattr(S, name)(w, h, gauss).desc()); integ = PathHIP(maxDepth=md); film = PinnedFilm(w, h)
