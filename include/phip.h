@@ -313,6 +313,9 @@ typedef struct phip_render_params {
 #define PHIP_FLAG_NO_FUSED 32       /* never use the fused single-kernel path (k_mega) nor the one-kernel iterations (k_shade_trace) -- A/B and parity tests of the wavefront kernels on small scenes */
 #define PHIP_FLAG_NO_MEGA 64        /* not k_mega, but k_shade_trace where the scene admits it (a small scene with glass / copper runs k_mega since round 5: how the tests still reach
                                        k_shade_trace on it; the kernel's own clients are small scenes with textures or an environment emitter) */
+#define PHIP_FLAG_FUSED_ANY 128     /* the fused kernel on EVERY scene it admits (round 6: k_mega walks the 8-wide tree from memory, phip_accel_info.fused_traversal 4 / 5) -- by default
+                                       only trees of at most PHIP_FUSED_WIDE_MAX_NODES wide nodes run it, the wavefront kernels are faster beyond; parity tests and A/B */
+#define PHIP_FUSED_WIDE_MAX_NODES 4096
 
 typedef struct phip_stats {
     uint64_t samples;                /* camera samples rendered by this call                  */
@@ -408,7 +411,8 @@ typedef struct phip_accel_info {
     float    build_ms;
     uint32_t fits_lds;       /* 1: tree, records, emitter table and materials fit the fused kernel's LDS plan (k_mega) */
     uint32_t fused_traversal; /* how k_mega traverses the scene: 0 = it walks the BVH4, 1 = flat table of leaf boxes, 2 / 3 = packed table with masks of
-                                 <= 32 / <= 64 Wald records, tests dealt over the wave (was `reserved`, always 0, before round 5: same layout) */
+                                 <= 32 / <= 64 Wald records, tests dealt over the wave (was `reserved`, always 0, before round 5: same layout); round 6, fits_lds = 0:
+                                 4 / 5 = k_mega can walk the compressed 8-wide tree from memory (materials in LDS / in memory; PHIP_FLAG_FUSED_ANY) */
 } phip_accel_info;
 int  phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out);
 

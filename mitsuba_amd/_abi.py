@@ -26,6 +26,8 @@ PHIP_FLAG_ACCUMULATE = 8
 PHIP_FLAG_ALIAS_DEVICES = 16
 PHIP_FLAG_NO_FUSED = 32
 PHIP_FLAG_NO_MEGA = 64
+PHIP_FLAG_FUSED_ANY = 128
+PHIP_FUSED_WIDE_MAX_NODES = 4096
 PHIP_NO_HIT = 0xFFFFFFFF
 
 

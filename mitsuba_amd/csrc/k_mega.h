@@ -48,6 +48,13 @@
 #ifndef MEGA_MB_DIAG
 #define MEGA_MB_DIAG 0
 #endif
+#ifndef MEGA_POOL
+#define MEGA_POOL 1                  /* FLAT >= 4 (the tree in memory): the wave's rays are traversed through ONE shared stack of node visits, any lane takes any ray's (k_wide_wave.h:
+                                        traceWidePool); 0: every lane walks its own ray (traceWideW, with MEGA_JOINT) */
+#endif
+#ifndef MEGA_JOINT
+#define MEGA_JOINT 1                 /* FLAT >= 4 (the tree in memory): the shadow ray of a vertex and the next ray of its path share ONE traversal phase (k_wide_wave.h) */
+#endif
 #ifndef MEGA_MAILBOX
 #define MEGA_MAILBOX 1               /* MM != 0, counter stream (round 5's last step; the QMC build keeps MEGA_CLASS_DEAL: its static LDS leaves no room): wave 0 of the block SERVES the
                                         rough-conductor vertices.  The other waves (clients) hand a path that hit copper to a 64-entry mailbox in LDS (S-box: each client owns a
@@ -68,28 +75,41 @@
 #ifndef MEGA_MB_PATIENCE
 #define MEGA_MB_PATIENCE 6
 #endif
-#define MB_NS 64u                    /* entries of the S-box (dynamic LDS, behind the work lists) and of the R-box (static: what four blocks per CU leave) */
+/* MB_NS = 64 entries of the S-box (dynamic LDS, behind the work lists; k_pool.h) and MB_NR of the R-box (static: what four blocks per CU leave) */
 #define MB_NR 48u
-#define MB_DW 22u                    /* dwords per mailbox entry (S-box: hit 4, direction 3, throughput 4, MIS 2, id, pixel, k, state, accumulator 4 = 21; R-box: origin + mint 4,
+/* MB_DW = 22 (k_pool.h): dwords per mailbox entry (S-box: hit 4, direction 3, throughput 4, MIS 2, id, pixel, k, state, accumulator 4 = 21; R-box: origin + mint 4,
                                         direction + maxt 4 instead of hit and direction = 22) */
+static_assert(MEGA_DEAL_DWORDS * sizeof(uint32_t) == WIDE_STACK_LDS * sizeof(uint2), "FLAT >= 4: the class deal's exchange buffer lies over the group stack");
+static_assert(MEGA_DEAL_DWORDS * BLOCK * sizeof(uint32_t) <= (BLOCK / 64u) * WP_WAVE_BYTES, "FLAT >= 4, MEGA_POOL: ... over the waves' round buffers (slots, ray table, pair list: free between traversals)");
 static_assert((BLOCK / 64u) * BAL_WAVE_BYTES + MB_DW * MB_NS * sizeof(uint32_t) <= MEGA_DEAL_DWORDS * BLOCK * sizeof(uint32_t), "the S-box lies behind the work lists in the region phip.hip sizes with MEGA_DEAL_DWORDS");
 #define MEGA_CHUNK_MAX 4096u
 #define MEGA_CHUNK_MIN 64u
 
 enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_NODE, MC_SH_TRI, MC_COUNT };
 
-template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2), 3: the same with 33..64 records (two-word masks; MEGA_BALANCE only) */,
+template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2), 3: the same with 33..64 records (two-word masks; MEGA_BALANCE only);
+                                           round 6 -- 4: the compressed 8-wide tree in L2 / HBM (k_wide_wave.h: traceWideW), emitter table and materials in LDS, 5: the same with the materials in memory */,
           bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+    constexpr bool WIDE = FLAT >= 4;                            /* the tree, its Wald records and the shading records stay in memory: a lane still owns its path from the camera sample to its last vertex */
     constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;     /* (the QMC build's static LDS leaves no room for the R-box at four blocks per CU) */
     constexpr bool DEAL = MM != 0 && FLAT >= 2 && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;
     __shared__ uint32_t ldsClsCnt[4][BLOCK / 64];                 /* MEGA_CLASS_DEAL: lanes per BSDF model and wave */
     __shared__ uint32_t mbR[MAILBOX ? MB_DW * MB_NR : 1u];        /* MEGA_MAILBOX: the R-box, [MB_DW][MB_NR]; the S-box lies in the dynamic LDS behind the traversals' work lists (phip.hip sizes the region) */
     __shared__ uint32_t mbState[MAILBOX ? MB_NS + MB_NR : 1u];   /* entry states, S-box then R-box: 0 empty, 2 full, 3 being read (R-box: three consumers claim by compare-and-swap) */
     __shared__ int mbLive;                                        /* sample ids drawn by the block's waves that have not ended as a sample yet (queued camera samples and paths, wherever they are) */
-    __shared__ uint32_t ldsCount[MC_COUNT][BLOCK];              /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
+    /* WIDE: per-wave counters instead (WCNT: lanes are counted as ballots, node steps and triangle tests by the traversal as k_rays_w does) -- the 8 KB are a fifth
+       of what a block may take at four blocks per CU once stack, node cache and round buffers are in */
+    constexpr bool WCNT = WIDE && !MEGA_PROFILE && !MEGA_MB_DIAG;
+    __shared__ uint32_t ldsCount[WCNT ? 1 : MC_COUNT][WCNT ? 1 : BLOCK];   /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
                                                                    no wait -- and the three that count lanes as ballots in SGPRs: 66.9 vs 66.5 ms per C2 frame and
                                                                    125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
 #define MEGA_COUNT(row, amount) ldsCount[row][threadIdx.x] += (uint32_t) (amount)
+    enum { WC_SAMPLES = 0, WC_VERTICES, WC_RAYS, WC_STEPS, WC_SH_RAYS, WC_SH_STEPS, WC_COUNT };      /* WC_STEPS: node steps | triangle tests << 32 (k_wide_wave.h) */
+    __shared__ unsigned long long wcnt[WIDE ? BLOCK / 64 : 1][WC_COUNT];
+    /* JOINT (WIDE): the shadow ray of a vertex is traced TOGETHER with the next ray of its path, in the traversal phase of the next pass (traceWideW: a lane brings two rays) --
+       one wait for the wave's slowest lane per vertex instead of two.  A path that ended with its shadow ray pending parks its accumulator here and frees the lane */
+    constexpr bool POOL = WIDE && MEGA_POOL;
+    constexpr bool JOINT = WIDE && MEGA_JOINT;
 #if MEGA_REGEN_QUEUE
     constexpr int RQ_ROWS = QMC ? 10 : 8;
     __shared__ uint32_t ldsRegen[BLOCK / 64][RQ_ROWS][64];      /* per wave: 64 prepared camera samples (mint | d, maxt | id, pixel, k [| the sample's sequence index: QMC]), one word per entry and row;
@@ -99,25 +119,39 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 #endif
     /* dynamic LDS: [traversal stack | all nodes | all Wald records] (setupTraversal) [shading records | emitter table | materials],
        sized for THIS scene (megaLdsBytes) so that as many blocks as the registers allow fit a CU */
+    /* WIDE: [group stack | top-of-tree node cache] (setupWide) [the four waves' round buffers | S-box] [emitter table | materials (FLAT 4)] (k_wide_wave.h: megaWideLdsBytesOf) */
+    constexpr uint32_t WAVE_BYTES = POOL ? WP_WAVE_BYTES : WD_WAVE_BYTES;      /* the waves' round buffers (their first 512 bytes: the result slots, which serve mbAssign between traversals) */
+    unsigned char *wideDeal = g_smem + (POOL ? widePoolDealOffset(M.nodeCache) : megaWideDealOffset(M.nodeCache));
     float4 *ldsTriShade = (float4 *) (g_smem + traversalLdsBytesOf(S));
-    float *ldsEm = (float *) (ldsTriShade + (size_t) S.nTriangles * TRISHADE_FLOAT4S);
+    float *ldsEm = WIDE ? (float *) (wideDeal + (BLOCK / 64u) * WAVE_BYTES + (MAILBOX ? MB_DW * MB_NS * sizeof(uint32_t) : 0u))
+                        : (float *) (ldsTriShade + (size_t) S.nTriangles * TRISHADE_FLOAT4S);
     DevMaterial *ldsMat = (DevMaterial *) (ldsEm + ((S.emitterTabSize + 3u) & ~3u));
-    ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    ShadeTables tab = stageShadeTables<FLAT != 5>(S, ldsEm, ldsMat);
     /* the host chose this kernel because every table fits (phip.hip: fitsLds): no run-time choice between the LDS copy and HBM, so that
        the compiler can address the tables as LDS (ds_read) instead of through flat loads, which occupy the texture addresser */
-    tab.T.t = ldsEm; tab.materials = ldsMat;
+    tab.T.t = ldsEm; tab.materials = FLAT == 5 ? S.materials : ldsMat;
     float4 *ldsFlat = (float4 *) (((uintptr_t) (ldsMat + S.nMaterials) + 15u) & ~(uintptr_t) 15u);      /* FLAT: the table of leaf boxes (traverseFlat) */
-    if (FLAT) for (uint32_t i = threadIdx.x; i < 2u * S.nFlatLeaves; i += BLOCK) ldsFlat[i] = S.flatLeaves[i];
-    lds_cf4 *flat = (lds_cf4 *) ldsFlat;
-    for (uint32_t i = threadIdx.x; i < S.nTriangles * TRISHADE_FLOAT4S; i += BLOCK) ldsTriShade[i] = S.triShade[i];
-    S.triShade = ldsTriShade;                                   /* (generic pointer into LDS: six loads per vertex, not the inner loop) */
+    if (FLAT && !WIDE) for (uint32_t i = threadIdx.x; i < 2u * S.nFlatLeaves; i += BLOCK) ldsFlat[i] = S.flatLeaves[i];
+    lds_cf4 *flat = (lds_cf4 *) ldsFlat; (void) flat;
+    if (!WIDE) {
+        for (uint32_t i = threadIdx.x; i < S.nTriangles * TRISHADE_FLOAT4S; i += BLOCK) ldsTriShade[i] = S.triShade[i];
+        S.triShade = ldsTriShade;                               /* (generic pointer into LDS: six loads per vertex, not the inner loop) */
+    }
     if (MAILBOX) { if (threadIdx.x < MB_NS + MB_NR) mbState[threadIdx.x] = 0u; if (threadIdx.x == 0u) mbLive = 0; }
-    TravStack stk; setupTraversal(S, g_smem, nullptr, stk);     /* stack + all nodes + all Wald records in LDS (barrier inside); the host checked that nothing can spill */
+    TravStack stk; stk.tris = nullptr;
+    WideStackT<BLOCK> wstk; WidePool wpool;
+    if (POOL) setupWidePool(S, M.nodeCache, g_smem, M.spill + (size_t) blockIdx.x * BLOCK * SPILL_DEPTH, (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), wpool);   /* the waves' task stacks (LDS, HBM spill behind them) + the top of the tree (barrier inside) */
+    else if (WIDE) setupWide<BLOCK>(S, M.nodeCache, g_smem, M.spill + (size_t) blockIdx.x * BLOCK * SPILL_DEPTH, wstk);     /* group stack (LDS, HBM spill behind it) + the top of the tree (barrier inside) */
+    else setupTraversal(S, g_smem, nullptr, stk);               /* stack + all nodes + all Wald records in LDS (barrier inside); the host checked that nothing can spill */
 
     const uint32_t waveId = blockIdx.x * (BLOCK / 64) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = __lane_id();
     unsigned long long next = 0, end = 0;                       /* the wave's chunk of sample ids (wave-uniform) */
     const uint32_t waveInBlock = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const WaveBalance wb = waveBalanceAt(g_smem, waveInBlock);  /* FLAT >= 2 && MEGA_BALANCE: over the traversal stack, which the flat table does not use (phip.hip sizes it) */
+    /* FLAT 2 / 3 && MEGA_BALANCE: over the traversal stack, which the flat table does not use (phip.hip sizes it); WIDE: the wave's round buffers (the slots serve mbAssign between traversals) */
+    unsigned char *const waveDeal = wideDeal + waveInBlock * WAVE_BYTES;
+    WaveBalance wb = waveBalanceAt(g_smem, waveInBlock);
+    if (WIDE) { wb.slot = (lds_u64 *) waveDeal; wb.list = (lds_u16 *) (waveDeal + 2u * 64u * 8u); }
+    bool poolOverflow = false;                                  /* POOL: a task stack ran out of LDS + spill (the host refuses the frame, as for a mailbox time-out) */
 #if MEGA_REGEN_QUEUE
     uint32_t qHead = 0, qCount = 0;                             /* the wave's queue of prepared camera samples (wave-uniform) */
     V3 camO;                                                    /* the origin cameraRay returns for every sample (dv_scene.h: the camera-to-world translation, by its own expression) */
@@ -125,7 +159,8 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 #endif
     bool exhausted = rc.totalIds == 0;
     /* MEGA_MAILBOX */
-    uint32_t *mbS = (uint32_t *) (g_smem + (BLOCK / 64u) * BAL_WAVE_BYTES);      /* the S-box, [MB_DW][64], behind the four waves' work lists */
+    uint32_t *mbS = WIDE ? (uint32_t *) (wideDeal + (BLOCK / 64u) * WAVE_BYTES)
+                         : (uint32_t *) (g_smem + (BLOCK / 64u) * BAL_WAVE_BYTES);      /* the S-box, [MB_DW][64], behind the four waves' work lists */
     const bool server = MAILBOX && waveInBlock == 0u;
     bool haveHit = false;                                       /* server: the lane's path came out of the S-box with its hit */
     uint32_t idleSpins = 0, patience = 0;
@@ -150,8 +185,15 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     PathVertex v; v.id = v.pixel = v.k = v.state = 0;
     v.hit = v.rayO = v.rayD = v.thr = make_float4(0, 0, 0, 0); v.mis = make_float2(0, 0);
     float4 accum = make_float4(0, 0, 0, 0);
+    if (!WCNT) {
 #pragma unroll
-    for (int i = 0; i < MC_COUNT; ++i) ldsCount[i][threadIdx.x] = 0;
+        for (int i = 0; i < MC_COUNT; ++i) ldsCount[WCNT ? 0 : i][WCNT ? 0 : threadIdx.x] = 0;
+    }
+    unsigned long long *const wc = wcnt[WIDE ? waveInBlock : 0u];
+    if (WIDE && lane < (uint32_t) WC_COUNT) wc[lane] = 0ull;      /* (every wave its own row: no barrier needed) */
+    bool cPush = false, cPend = false;                          /* JOINT: a shadow ray waits for the next traversal phase; its path ended at that vertex (accumulator parked) */
+    float4 cPark = make_float4(0, 0, 0, 0);                     /* (registers: 4 KB of LDS per block would cost the fourth block of a CU) */
+    ShadowEntry cSh; cSh.e0 = cSh.e1 = cSh.e2 = make_float4(0, 0, 0, 0);
 
 #if MEGA_PROFILE
     unsigned long long pfT[4] = { 0, 0, 0, 0 }, pfL[4] = { 0, 0, 0, 0 }, pfIter = 0;      /* regeneration, closest hit, vertex, shadow ray */
@@ -357,9 +399,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 #endif
         PF_END(0, pfWant_) }
         if (DEAL) {
-            if (!__syncthreads_or(alive ? 1 : 0)) break;        /* (the waves of a block meet at barriers below: they leave the loop together) */
+            if (!__syncthreads_or((alive || (JOINT && cPush)) ? 1 : 0)) break;        /* (the waves of a block meet at barriers below: they leave the loop together) */
         } else if (MAILBOX) {
-            if (!__any(alive)) {
+            if (!__any(alive || (JOINT && cPush))) {
                 /* nothing in this wave's lanes: done when no id is left anywhere AND every id the block's waves drew has ended as a sample (a path may sit in a
                    mailbox or in another wave and come here yet); until then look into the mailboxes again.  The wait is bounded: no bug may hang the device */
                 if (exhausted && qCount == 0u && __hip_atomic_load(&mbLive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= 0) break;
@@ -368,11 +410,43 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 continue;
             }
             idleSpins = 0;
-        } else if (!__any(alive)) break;
+        } else if (!__any(alive || (JOINT && cPush))) break;
 
         /* ---- closest hit ---- */
         uint32_t hitCls = 0;                                    /* shade class of the record hit (the Wald record's 12th word: 0 diffuse, 1 rough conductor, 2 dielectric) */
         { PF_BEGIN
+        if (WIDE) {                                             /* every lane takes part (k_wide_wave.h) */
+            const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
+            float mint, maxt;
+            TravResult r;
+            V3 rcp;
+            const bool trace = alive && !(MAILBOX && haveHit);
+            const bool go = trace & clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp);
+            /* JOINT: ... and the shadow ray of the vertex this lane shaded in the previous pass (its own path's, or that of the path that ended there) */
+            const V3 so(cSh.e0.x, cSh.e0.y, cSh.e0.z), sd(cSh.e1.x, cSh.e1.y, cSh.e1.z);
+            float smint = 0.0f, smaxt = 0.0f; bool goS = false;
+            if (JOINT) { V3 srcp; goS = cPush & clipToSceneSel<true>(S, so, sd, PT_EPSILON, cSh.e0.w, smint, smaxt, srcp); }
+            bool occluded = false;
+            if (POOL) traceWidePool<JOINT, true>(S, wpool, lane, goS, so, sd, smint, smaxt, go, o, d, mint, maxt, occluded, r, wc + WC_SH_STEPS, wc + WC_STEPS, poolOverflow);
+            else traceWideW<JOINT, true>(S, wstk, waveDeal, lane, goS, so, sd, smint, smaxt, go, o, d, mint, maxt, occluded, r, wc + WC_SH_STEPS, wc + WC_STEPS);
+            if (trace) {
+                v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
+                hitCls = r.cls;
+            }
+            { const uint32_t n_ = (uint32_t) __popcll(__ballot(trace)); if (lane == 0u) wc[WC_RAYS] += n_; }
+            if (JOINT) {
+                /* the shadow ray's verdict (path.cpp:187-199): the contribution joins the path's accumulator -- the register if the path goes on in this lane, the parked one
+                   if it ended at that vertex, which is then the sample's value */
+                if (cPush && !occluded) {
+                    if (cPend) { cPark.x += cSh.e2.x; cPark.y += cSh.e2.y; cPark.z += cSh.e2.z; }
+                    else { accum.x += cSh.e2.x; accum.y += cSh.e2.y; accum.z += cSh.e2.z; }
+                }
+                if (cPend) L[pm_to_bits(cSh.e2.w)] = cPark;
+                const uint32_t nS_ = (uint32_t) __popcll(__ballot(cPush)), nE_ = (uint32_t) __popcll(__ballot(cPend));
+                if (lane == 0u) { wc[WC_SH_RAYS] += nS_; wc[WC_SAMPLES] += nE_; }
+                cPush = false; cPend = false;
+            }
+        } else
         if (FLAT >= 2 && MEGA_BALANCE) {                        /* every lane takes part: the tests of the wave's rays are dealt over its lanes */
             const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
             float mint, maxt;
@@ -464,7 +538,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                few waves as they fill changes nothing: profiles/r05_gpu_call_p_*) */
             if (special) {
                 const uint32_t dst = base + rank;
-                uint32_t *x = (uint32_t *) g_smem;               /* [MEGA_DEAL_DWORDS][BLOCK], over the traversal stack / work lists (unused between traversals) */
+                uint32_t *x = POOL ? (uint32_t *) wideDeal : (uint32_t *) g_smem;               /* [MEGA_DEAL_DWORDS][BLOCK], over the traversal stack / work lists (POOL: the waves' round buffers), unused between traversals */
 #define XPUT(j, val) x[(j) * BLOCK + dst] = (val)
 #define XGET(j) x[(j) * BLOCK + threadIdx.x]
                 XPUT(0, pm_to_bits(v.hit.x)); XPUT(1, pm_to_bits(v.hit.y)); XPUT(2, pm_to_bits(v.hit.z)); XPUT(3, pm_to_bits(v.hit.w));
@@ -497,7 +571,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         /* ---- the vertex: emitter hit / Russian roulette / emission / NEE sample / BSDF sample ---- */
         bool pushShadow = false, ended = false;
         ShadowEntry sh;
-        if (FLAT >= 2 && MEGA_BALANCE) sh.e0 = sh.e1 = make_float4(0, 0, 0, 0);   /* every lane clips "its" entry (a lane without one takes no part in the result) */
+        if ((FLAT >= 2 && MEGA_BALANCE) || WIDE) sh.e0 = sh.e1 = make_float4(0, 0, 0, 0);   /* every lane clips "its" entry (a lane without one takes no part in the result) */
         { PF_BEGIN
         if (alive) {
             uint32_t nv = 0;
@@ -508,12 +582,36 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             const LRegister acc{ accum, nullptr };
 #endif
             ended = shadeVertex<MM, STRICT, QMC ? 8 : 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
-            if (ended) MEGA_COUNT(MC_VERTICES, nv);
+            if (ended) { if (WCNT) atomicAdd(&wc[WC_VERTICES], (unsigned long long) nv); else MEGA_COUNT(MC_VERTICES, nv); }
         }
 
         PF_END(2, __ballot(alive)) }
         /* ---- shadow ray of the NEE sample; unoccluded: the contribution joins the accumulator (path.cpp:187-199) ---- */
         { PF_BEGIN
+        if (JOINT && !server) {
+            /* the shadow ray waits for the traversal phase of the next pass.  A path that ended here frees the lane now: without a shadow ray its accumulator is the sample;
+               with one the accumulator is parked until the ray is decided */
+            cPush = pushShadow; cSh = sh;
+            if (ended) {
+                if (pushShadow) { cPark = accum; cPend = true; }
+                else L[v.id] = accum;
+                alive = false;
+            }
+            const uint32_t n_ = (uint32_t) __popcll(__ballot(ended && !pushShadow));
+            if (lane == 0u) wc[WC_SAMPLES] += n_;
+        } else
+        if (WIDE) {
+            const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
+            float mint, maxt;
+            TravResult r;
+            V3 rcp;
+            const bool go = pushShadow & clipToSceneSel<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp);
+            bool occluded;
+            if (POOL) traceWidePool<true, false>(S, wpool, lane, go, o, d, mint, maxt, false, o, d, 0.0f, 0.0f, occluded, r, wc + WC_SH_STEPS, wc + WC_STEPS, poolOverflow);
+            else traceWideW<true, false>(S, wstk, waveDeal, lane, go, o, d, mint, maxt, false, o, d, 0.0f, 0.0f, occluded, r, wc + WC_SH_STEPS, wc + WC_STEPS);
+            if (pushShadow && !occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
+            { const uint32_t n_ = (uint32_t) __popcll(__ballot(pushShadow)); if (lane == 0u) wc[WC_SH_RAYS] += n_; }
+        } else
         if (FLAT >= 2 && MEGA_BALANCE) {
             const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
             float mint, maxt;
@@ -543,11 +641,12 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
         }
 
         PF_END(3, __ballot(pushShadow)) }
-        if (ended) {
+        if (ended && !(JOINT && !server)) {                  /* (JOINT: stored or parked above) */
             L[v.id] = accum;
-            MEGA_COUNT(MC_SAMPLES, 1);
+            if (!WCNT) MEGA_COUNT(MC_SAMPLES, 1);
             alive = false;
         }
+        if (WCNT && !(JOINT && !server)) { const uint32_t n_ = (uint32_t) __popcll(__ballot(ended)); if (lane == 0u) wc[WC_SAMPLES] += n_; }
         if (MAILBOX) {
             const int nEnded = __popcll(__ballot(ended));
             if (nEnded && lane == 0u) atomicSub(&mbLive, nEnded);
@@ -592,6 +691,15 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     PathPool P; P.stat = M.stat; P.nWaves = M.nWaves;
     const int rows[MC_COUNT] = { ST_SAMPLES, ST_VERTICES, ST_CLOSEST_RAYS, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_TRI };
 #pragma unroll
-    for (int i = 0; i < MC_COUNT; ++i) waveStat(P, rows[i], waveId, ldsCount[i][threadIdx.x] + ((MAILBOX && i == MC_SAMPLES && mbTimedOut && lane == 0u) ? (1ull << 62) : 0ull));
+    for (int i = 0; i < MC_COUNT; ++i) {
+        unsigned long long val = 0ull;
+        if (WCNT) {
+            if (lane == 0u)
+                val = i == MC_SAMPLES ? wc[WC_SAMPLES] : i == MC_VERTICES ? wc[WC_VERTICES] : i == MC_RAYS ? wc[WC_RAYS] : i == MC_NODE ? (wc[WC_STEPS] & 0xFFFFFFFFull)
+                    : i == MC_TRI ? (wc[WC_STEPS] >> 32) : i == MC_SH_RAYS ? wc[WC_SH_RAYS] : i == MC_SH_NODE ? (wc[WC_SH_STEPS] & 0xFFFFFFFFull) : (wc[WC_SH_STEPS] >> 32);
+        } else val = ldsCount[WCNT ? 0 : i][WCNT ? 0 : threadIdx.x];
+        const bool poison = (MAILBOX && mbTimedOut) || (POOL && __any(poolOverflow));
+        waveStat(P, rows[i], waveId, val + ((i == MC_SAMPLES && poison && lane == 0u) ? (1ull << 62) : 0ull));
+    }
 }
 

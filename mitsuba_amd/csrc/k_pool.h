@@ -67,6 +67,17 @@ enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_T
 #define MEGA_WAVES 4                 /* k_mega: waves per SIMD (= blocks of 256 per CU): 128 VGPRs, no scratch -- with MachineLICM off for that unit (_ffi.py);
                                         with it on the kernel needs 168 VGPRs (3 waves: measured 2020 vs 2171 Msamples/s at 4 waves even with 148 B of scratch) */
 #endif
+#ifndef MEGA_MAILBOX
+#define MEGA_MAILBOX 1               /* k_mega<MM_ALL>, counter stream: a serving wave behind two LDS mailboxes (k_mega.h) */
+#endif
+#define MB_NS 64u                    /* entries of the S-box (dynamic LDS) and dwords per entry: the host sizes k_mega's launch with them */
+#define MB_DW 22u
+#ifndef MEGA_POOL
+#define MEGA_POOL 1                  /* k_mega<.., FLAT >= 4, ..>: one shared task stack per wave (k_wide_wave.h: traceWidePool); the host sizes the launch's LDS by it */
+#endif
+#ifndef MEGA_WIDE_NODE_CACHE
+#define MEGA_WIDE_NODE_CACHE 48u     /* k_mega<.., FLAT >= 4, ..>: top-of-tree nodes (BFS order) a block stages in LDS (80 B each) */
+#endif
 #define FLAT_LEAVES_MAX 32           /* k_mega: trees of at most this many leaves are traversed as a flat table of leaf boxes (one bit per leaf) */
 #define FLAT2_LEAVES_MAX 64          /* ... of the packed table with record masks (flatMode 2 / 3: at most 32 / 64 Wald records, the mask is over records, not leaves) */
 #define MEGA_TRISHADE_MAX 96         /* k_mega: shading records staged in LDS (9 KB) */
@@ -79,6 +90,9 @@ struct MegaParams {
     const int *cancel;               /* host-pinned flag polled when a wave draws a chunk of ids (phip_cancel) */
     unsigned long long *stat;        /* ST_COUNT rows of nWaves entries */
     uint32_t nWaves;
+    /* k_mega<.., FLAT >= 4, ..> (the tree in memory: k_wide_wave.h) */
+    uint32_t nodeCache;              /* top-of-tree nodes (BFS order) every block stages in LDS */
+    uint32_t *spill;                 /* overflow of the group stacks: SPILL_DEPTH words per lane of the grid */
 };
 
 struct Counters {

@@ -43,6 +43,7 @@
 #include "k_traverse.h"
 #include "k_rays.h"
 #include "k_wide.h"
+#include "k_wide_wave.h"
 #include "k_film.h"
 #include <dlfcn.h>
 #include <map>
@@ -226,6 +227,7 @@ struct phip_scene {
     bool flatTrace = false;          /* not a scene of k_mega, but its tree is the packed leaf table (<= 64 Wald records) and emitter table + materials fit LDS: k_shade_trace */
     bool wide = false;               /* the ray kernels walk the compressed 8-wide BVH (trees of >= 64 BVH4 nodes; PHIP_WIDE=0 keeps the BVH4) */
     bool fitsLds = false;            /* tree, Wald records, shading records, emitter table and materials fit the fused kernel's LDS plan */
+    int fusedWide = 0;               /* round 6: 4 / 5 = the fused kernel walks the 8-wide tree from memory (k_mega<.., FLAT 4 / 5, ..>: emitter table in LDS; materials in LDS / in memory) */
     std::vector<std::unique_ptr<SceneDev>> devs;
     int *cancelFlag = nullptr;       /* host-pinned (portable, mapped): phip_cancel writes it, host loops and k_mega poll it */
     std::mutex renderLock;
@@ -798,6 +800,11 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
         /* k_mega<MM_ALL> keeps its mailbox of copper vertices (QMC build: the exchange buffer of its class deal) in MEGA_DEAL_DWORDS x BLOCK dwords of LDS that lie over the traversal stack (k_mega.h) */
         D.stackDepth = std::max<uint32_t>(D.stackDepth, MEGA_DEAL_DWORDS);
     }
+    /* round 6: the fused kernel on a tree that does not fit LDS (k_wide_wave.h) -- every scene on the 8-wide tree whose emitter table fits LDS and that needs none of the
+       feature sets k_mega is not compiled with (bitmap textures, an environment emitter) */
+    sc->fusedWide = (sc->wide && !sc->hasTextures && envEmitter < 0 && stride == TRISHADE_FLOAT4S && tab.size() <= EMITTER_LDS_FLOATS
+                     && sc->bvh.wtris.size() / 12 < WP_TRI_MAX && !expEnv("PHIP_NO_MEGA_WIDE"))
+                  ? (mats.size() <= MATERIAL_LDS_MAX ? 4 : 5) : 0;
     const bool traceable = D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !expEnv("PHIP_NO_SHADE_TRACE");
     sc->flatTrace = !sc->fitsLds && traceable; sc->flatTraceToo = sc->fitsLds && traceable;
     /* ... whose lanes are dealt by BSDF model where there is more than one (the kernel traces its own rays and leaves the class in the hit word) */
@@ -1101,7 +1108,11 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
     const bool rinv = p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY;
     const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED || rinv;     /* served by the wavefront kernels compiled with FEAT bit 3 */
-    bool fused = !direct && sc->fitsLds && sc->traversal == 2 && !(p->flags & (PHIP_FLAG_NO_FUSED | PHIP_FLAG_NO_MEGA));
+    /* (the fused kernel on the 8-wide tree: by default where it is faster than the wavefront kernels -- trees that live in L2, DESIGN.md 3.3 -- with PHIP_FLAG_FUSED_ANY wherever it can run) */
+    const bool wideFused = sc->fusedWide && (sc->bvh.nWNodes <= PHIP_FUSED_WIDE_MAX_NODES || (p->flags & PHIP_FLAG_FUSED_ANY));
+    bool fused = !direct && (sc->fitsLds || wideFused) && sc->traversal == 2 && !(p->flags & (PHIP_FLAG_NO_FUSED | PHIP_FLAG_NO_MEGA));
+    const int megaFlat = sc->fitsLds ? (D.nFlatLeaves ? (int) D.flatMode : 0) : sc->fusedWide;      /* k_mega's traversal form (k_mega.h) */
+    const bool megaWide = megaFlat >= 4;
     if (qmc && p->sampler == PHIP_SAMPLER_SOBOL) {
         /* the plugin's tables, uploaded once per (pointer, size): ~210 KB of direction numbers + the two 52-word enumeration rows */
         const size_t nm = (size_t) p->sobol_dimensions * PHIP_SOBOL_MATRIX_SIZE;
@@ -1154,11 +1165,23 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     /* resident blocks of the fused kernel for THIS render (the QMC build has ~15 KB more static LDS than the plan of fitsLds priced at scene
        creation): when none fits a compute unit the render runs on the wavefront kernels, as it did before the samplers moved to k_mega */
     int megaPerCU = 0;
+    uint32_t megaNodeCache = 0; size_t megaLds = 0;
     if (fused) {
-        megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, D.nFlatLeaves ? (int) D.flatMode : 0, qmc, megaLdsBytesOf(D)));
+        if (megaWide) {
+            /* the top of the tree every block stages (BFS order); the mailbox build (all leaf BSDF models, counter stream) has the S-box behind the round buffers */
+            megaNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, MEGA_WIDE_NODE_CACHE);
+            if (const char *e = expEnv("PHIP_MEGA_NODE_CACHE")) megaNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, (uint32_t) atoi(e));
+            const bool mailbox = sc->materialMask != 0 && !qmc && MEGA_MAILBOX;
+            megaLds = MEGA_POOL ? megaWidePoolLdsBytesOf(D, megaNodeCache, mailbox, megaFlat == 4, MB_DW * MB_NS * sizeof(uint32_t))
+                                : megaWideLdsBytesOf(D, megaNodeCache, mailbox, megaFlat == 4, MB_DW * MB_NS * sizeof(uint32_t));
+            megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCUWide(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaLds));
+        } else {
+            megaLds = megaLdsBytesOf(D);
+            megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaLds));
+        }
         if (const char *e = expEnv("PHIP_MEGA_BLOCKS")) megaPerCU = std::max(1, std::min(megaPerCU, atoi(e)));
         if (megaPerCU <= 0) fused = false;
-        if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "[phip] k_mega: %d blocks per CU with %zu bytes of dynamic LDS\n", megaPerCU, megaLdsBytesOf(D));
+        if (getenv("PHIP_DEBUG_TIMING")) fprintf(stderr, "[phip] k_mega (traversal form %d): %d blocks per CU with %zu bytes of dynamic LDS\n", megaFlat, megaPerCU, megaLds);
     }
     sd.fused = fused;
     /* ... or k_shade_trace: the scene's tree is the packed leaf table, but k_mega does not serve it (glass / copper / textures / environment emitter) */
@@ -1286,6 +1309,12 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         M.nWaves = megaGrid.x * (BLOCK / 64);
         if (sd.stat.n < (size_t) ST_COUNT * M.nWaves) sd.stat.alloc((size_t) ST_COUNT * M.nWaves);
         M.stat = sd.stat.p; M.nextId = sd.megaNext.p;
+        M.nodeCache = megaNodeCache; M.spill = nullptr;
+        if (megaWide) {     /* the group stacks' overflow behind their six LDS entries: the buffer always covers the grid, as for k_rays_w (a silent out-of-bounds write otherwise) */
+            const size_t spillLanes = (size_t) megaGrid.x * BLOCK;
+            if (sd.spill.n < spillLanes * SPILL_DEPTH) sd.spill.alloc(spillLanes * SPILL_DEPTH);
+            M.spill = sd.spill.p;
+        }
         int *dflag = nullptr; HIP_TRY(hipHostGetDevicePointer((void **) &dflag, sc->cancelFlag, 0));
         M.cancel = dflag;
         P.stat = sd.stat.p; P.nWaves = M.nWaves;               /* k_reduce_stats reads these two */
@@ -1371,7 +1400,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipMemsetAsync(sd.stat.p, 0, (size_t) ST_COUNT * M.nWaves * sizeof(unsigned long long), stream));
             if (rc.totalIds) {
                 if (timing) evFused.record(stream);
-                phipLaunchMega(sc->materialMask, p->strict_normals != 0, qmc, megaGrid, megaLdsBytesOf(D), stream, D, M, rc, sd.L.p);
+                if (megaWide) phipLaunchMegaWide(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaGrid, megaLds, stream, D, M, rc, sd.L.p);
+                else phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaGrid, megaLds, stream, D, M, rc, sd.L.p);
                 if (timing) evFused.record(stream);
                 iter = 1;
             }
@@ -1521,7 +1551,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         /* (k_mega's mailbox protocol bounds its waits; a wave that gave up poisons its sample count: k_mega.h) */
-        if (fused && hc.total[ST_SAMPLES] > rc.totalIds) throw std::runtime_error("internal error: k_mega's mailbox protocol timed out (samples are missing from the frame)");
+        if (fused && hc.total[ST_SAMPLES] > rc.totalIds) throw std::runtime_error(megaWide && sc->materialMask == 0 ? "internal error: k_mega's task stack overflowed (LDS + spill buffer)"
+                                                                                       : "internal error: k_mega's mailbox protocol timed out or its task stack overflowed (samples are missing from the frame)");
         st.samples += hc.total[ST_SAMPLES]; st.closest_rays += hc.total[ST_CLOSEST_RAYS]; st.shadow_rays += hc.total[ST_SHADOW_RAYS];
         st.path_vertices += hc.total[ST_VERTICES]; st.closest_node_visits += hc.total[ST_NODE]; st.closest_triangle_tests += hc.total[ST_TRI];
         st.shadow_node_visits += hc.total[ST_SH_NODE]; st.shadow_triangle_tests += hc.total[ST_SH_TRI];
@@ -2007,7 +2038,7 @@ int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
     out->max_depth = scene->bvh.maxDepth; out->node_bytes = 128; out->triangle_bytes = 48;
     out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
     if (scene->wide) { out->n_nodes = scene->bvh.nWNodes; out->max_depth = scene->bvh.wMaxDepth; out->node_bytes = 80; out->sah_cost = scene->bvh.wSahCost; }
-    out->fits_lds = scene->fitsLds ? 1u : 0u; out->fused_traversal = scene->fitsLds ? scene->devs[0]->dev.flatMode : 0u;
+    out->fits_lds = scene->fitsLds ? 1u : 0u; out->fused_traversal = scene->fitsLds ? scene->devs[0]->dev.flatMode : (uint32_t) scene->fusedWide;
     return PHIP_OK;
 }
 

@@ -6,7 +6,7 @@
  *   phip.hip        host side (scene build, render loop, multi-device orchestration, C ABI) + traversal and film kernels
  *   phip_shade.hip  k_shade / k_shade_direct / k_shade_trace instantiations behind phipLaunchShade*F<n> -- compiled per feature set (-DSHADE_FEAT=0..3, 8 and 11:
  *                   environment emitter, bitmap textures, the QMC samplers) and per part (-DSHADE_PART=0..3), 24 objects: see its header
- *   phip_mega.hip   k_mega instantiations behind phipLaunchMega
+ *   phip_mega.hip   k_mega instantiations behind phipLaunchMega (-DMEGA_PART=0: scenes in LDS) / phipLaunchMegaWide (-DMEGA_PART=1: the 8-wide tree in memory)
  * No device function is called across units (everything on the device side is inline in headers), so no -fgpu-rdc.
  */
 #pragma once
@@ -50,7 +50,11 @@ using namespace pt;
                                   const DevScene &S, const PathPool &P, const RenderConst &rc, float4 *L);
 PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_SHADE(3) PHIP_DECLARE_SHADE(8) PHIP_DECLARE_SHADE(11)
 #undef PHIP_DECLARE_SHADE
-/* k_mega<materials, strictNormals> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS */
-int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, int flat /* 0 / DevScene::flatMode */, bool qmc, size_t ldsBytes);
-void phipLaunchMega(int materialMask, bool strictNormals, bool qmc, dim3 grid, size_t ldsBytes, hipStream_t stream,
+/* k_mega<materials, strictNormals, traversal form> (phip_mega.hip): blocks of BLOCK threads that fit one CU with ldsBytes of dynamic LDS.
+   flat 0 .. 3 (0 / DevScene::flatMode: scenes that fit LDS) live in the object compiled with -DMEGA_PART=0, flat 4 / 5 (the 8-wide tree in memory) in -DMEGA_PART=1 */
+int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, int flat, bool qmc, size_t ldsBytes);
+void phipLaunchMega(int materialMask, bool strictNormals, int flat, bool qmc, dim3 grid, size_t ldsBytes, hipStream_t stream,
                     const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);
+int  phipMegaBlocksPerCUWide(int materialMask, bool strictNormals, int flat, bool qmc, size_t ldsBytes);
+void phipLaunchMegaWide(int materialMask, bool strictNormals, int flat, bool qmc, dim3 grid, size_t ldsBytes, hipStream_t stream,
+                        const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);

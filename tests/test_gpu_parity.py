@@ -95,6 +95,19 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
         assert (film2.storage.view(np.uint32) == film.storage.view(np.uint32)).all()
         assert integ.stats.samples == st.samples and integ.stats.path_vertices == st.path_vertices
         assert integ.stats.closest_rays == st.closest_rays and integ.stats.shadow_rays == st.shadow_rays
+    ai = gs.accel_info()
+    from mitsuba_amd.integrator import DirectHIP
+    if not st.fused and ai.fused_traversal >= 4 and not isinstance(integ, DirectHIP) and not (flags_extra & (A.PHIP_FLAG_NO_FUSED | A.PHIP_FLAG_NO_MEGA)):
+        # round 6: the scene's tree is past the size where the fused kernel is the default (PHIP_FUSED_WIDE_MAX_NODES), but k_mega can walk it from memory
+        # (k_wide_wave.h): the same bits, the same counters
+        film3 = HDRFilm(gs.width, gs.height)
+        assert integ.render(gs, film3, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_FUSED_ANY | flags_extra, **render_kw)
+        assert integ.stats.fused
+        fsmp = integ.samples(gs, spp)
+        assert (fsmp.view(np.uint32) == gsmp.view(np.uint32)).all(), "the fused kernel on the 8-wide tree and the wavefront kernels differ"
+        assert (film3.storage.view(np.uint32) == film.storage.view(np.uint32)).all()
+        assert integ.stats.samples == st.samples and integ.stats.path_vertices == st.path_vertices
+        assert integ.stats.closest_rays == st.closest_rays and integ.stats.shadow_rays == st.shadow_rays
     gs.close(); osc.close()
     return same.mean(), r
 
@@ -919,8 +932,38 @@ def test_ray_kernel_work_list_overflow_matches_oracle(gpu, oracle, gauss):
     info = gs.accel_info().as_dict()
     assert info["node_bytes"] == 80, info                                 # the compressed wide tree, i.e. k_rays_w
     integ = PathHIP(maxDepth=5); film = HDRFilm(gs.width, gs.height)
-    assert integ.render(gs, film, 2)
+    assert integ.render(gs, film, 2, flags=A.PHIP_FLAG_NO_FUSED)
     st = integ.stats
     assert not st.fused and st.closest_triangle_tests >= 12 * st.closest_rays, (st.closest_triangle_tests, st.closest_rays)
+    # round 6: a tree of this size runs the fused kernel by default -- its triangle rounds are the same rounds on the same 256-entry list (k_wide_wave.h)
+    assert integ.render(gs, film, 2)
+    assert integ.stats.fused and integ.stats.closest_triangle_tests >= 12 * integ.stats.closest_rays, (integ.stats.closest_triangle_tests, integ.stats.closest_rays)
     gs.close()
     compare_render(gpu, oracle, desc, 4, min_identical=0.999, maxDepth=5)
+
+
+def test_cornell_spheres_run_the_fused_kernel_on_the_wide_tree(gpu, oracle, gauss):
+    """Round 6: the scenes between the LDS-resident boxes and the atrium -- the Cornell box with two tessellated spheres, 1 k triangles, a tree of
+    ~110 compressed 8-wide nodes that lives in L2 -- run k_mega with the tree in memory (phip_accel_info.fused_traversal 4; k_wide_wave.h): a lane owns its path,
+    the wave's rays walk the tree with the group stack in LDS and their Wald tests dealt over the wave.  Every sample bit-identical to the oracle AND to the
+    wavefront kernels (compare_render renders both), counters included; diffuse spheres and glass + copper (the mailbox build), strictNormals, a ragged film,
+    the reference's sobol / halton streams (the QMC builds: the class deal instead of the mailboxes), volpath_simple."""
+    from conftest import sobol_tables, qmc_tables
+    from mitsuba_amd.integrator import Scene, PathHIP, VolPathSimpleHIP, HDRFilm
+    for materials in (False, True):
+        desc = S.cornell_spheres(96, 96, gauss, materials=materials).desc()
+        gs = Scene(desc); ai = gs.accel_info(); integ = PathHIP(maxDepth=6); film = HDRFilm(gs.width, gs.height)
+        assert ai.fits_lds == 0 and ai.fused_traversal == 4 and ai.n_nodes <= A.PHIP_FUSED_WIDE_MAX_NODES, (ai.fits_lds, ai.fused_traversal, ai.n_nodes)
+        assert integ.render(gs, film, 2)
+        assert integ.stats.fused == 1 and integ.stats.trace_kernel_ms == 0 and integ.stats.iterations == 1, integ.stats.as_dict()
+        assert integ.render(gs, film, 2, flags=A.PHIP_FLAG_NO_FUSED)
+        assert integ.stats.fused == 0 and integ.stats.iterations > 1
+        gs.close()
+        for cfg in (dict(maxDepth=-1), dict(maxDepth=7, strictNormals=True), dict(maxDepth=2), dict(maxDepth=5, hideEmitters=True)):
+            same, r = compare_render(gpu, oracle, desc, 8, min_identical=0.9999, **cfg)
+            print("cornell_spheres(materials=%s) %s: identical %.6f rel L2 %.3e" % (materials, cfg, same, r))
+        compare_render(gpu, oracle, desc, 4, min_identical=0.9999, render_kw=dict(sobol=sobol_tables(96, 96)), maxDepth=8)
+        compare_render(gpu, oracle, desc, 4, min_identical=0.9999, render_kw=dict(sampler=A.PHIP_SAMPLER_HALTON, qmc=qmc_tables(-1)), maxDepth=8)
+        compare_render(gpu, oracle, desc, 4, min_identical=0.9999, integrator=VolPathSimpleHIP, maxDepth=8)
+    # a ragged film (ids outside the image are drawn and skipped), finer spheres (4.5 k triangles)
+    compare_render(gpu, oracle, S.cornell_spheres(100, 70, gauss, nlon=48, nlat=24).desc(), 4, min_identical=0.9999, maxDepth=-1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an alternative libphip (same sources, extra flags) next to the product for A/B runs on the GPU box:
-#   [MAIN_FLAGS=..] [MEGA_FLAGS=..] [SHADE_FLAGS=..] tools/build_variant.sh <tag> [flags for every unit...]
+#   [MAIN_FLAGS=..] [MEGA_FLAGS=..] [MEGAW_FLAGS=..] [SHADE_FLAGS=..] tools/build_variant.sh <tag> [flags for every unit...]
 #   ->  mitsuba_amd/_build/libphip_<tag>.so   (load it with PHIP_LIB=...)
 # Units whose flags equal the product's are not recompiled (the product's objects are linked).  Experiment builds (the measured alternatives of DESIGN.md 9:
 # earlier kernel generations, algorithm-selecting environment variables) add -DPHIP_EXPERIMENTS=1 to every unit:  tools/build_variant.sh exp -DPHIP_EXPERIMENTS=1
@@ -15,7 +15,9 @@ for f in 11 3 2 1 8 0; do for q in 0 1 3 2; do
   if [ -n "$SHADE_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F $SHADE_FLAGS "$@" -DSHADE_FEAT=$f -DSHADE_PART=$q -c $c/phip_shade.hip -o $b/phip_shade${f}_${q}_$tag.o & objs="$objs $b/phip_shade${f}_${q}_$tag.o"; throttle
   else objs="$objs $b/phip_shade${f}_$q.o"; fi
 done; done
-if [ -n "$MEGA_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F ${MEGA_FLAGS:-$PROD_MEGA} "$@" -c $c/phip_mega.hip -o $b/phip_mega_$tag.o & objs="$objs $b/phip_mega_$tag.o"; throttle; else objs="$objs $b/phip_mega.o"; fi
+# phip_mega.hip is two objects: -DMEGA_PART=0 (scenes in LDS) and -DMEGA_PART=1 (the 8-wide tree in memory); MEGAW_FLAGS = flags for the second one only
+if [ -n "$MEGA_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F ${MEGA_FLAGS:-$PROD_MEGA} "$@" -DMEGA_PART=0 -c $c/phip_mega.hip -o $b/phip_mega_$tag.o & objs="$objs $b/phip_mega_$tag.o"; throttle; else objs="$objs $b/phip_mega.o"; fi
+if [ -n "$MEGA_FLAGS$MEGAW_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F ${MEGA_FLAGS:-$PROD_MEGA} $MEGAW_FLAGS "$@" -DMEGA_PART=1 -c $c/phip_mega.hip -o $b/phip_megaw_$tag.o & objs="$objs $b/phip_megaw_$tag.o"; throttle; else objs="$objs $b/phip_megaw.o"; fi
 if [ -n "$MAIN_FLAGS$*" ]; then /opt/rocm/bin/hipcc $F $MAIN_FLAGS "$@" -DPHIP_BUILD_ID="\"variant-$tag\"" -c $c/phip.hip -o $b/phip_$tag.o & objs="$objs $b/phip_$tag.o"; else objs="$objs $b/phip.o"; fi
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $b/libphip_$tag.so $objs -ldl

@@ -25,10 +25,11 @@ for key in sys.argv[1:] or cfgs:
     t = time.time(); sc = Scene(sb.desc()); tb = time.time() - t
     integ = PathHIP(maxDepth=md); film = HDRFilm(w, h)
     if not os.environ.get("NOWARM"):
-        integ.render(sc, film, 1)
+        integ.render(sc, film, 1, flags=int(os.environ.get("FLAGS", "0"), 0))
     for _ in range(int(os.environ.get("REPEAT", 1)) - 1):
-        integ.render(sc, film, spp)
-    t = time.time(); integ.render(sc, film, spp, flags=0 if os.environ.get('NOTIMING') else A.PHIP_FLAG_KERNEL_TIMING); dt = time.time() - t
+        integ.render(sc, film, spp, flags=int(os.environ.get("FLAGS", "0"), 0))
+    extra = int(os.environ.get("FLAGS", "0"), 0)       # e.g. FLAGS=0: PHIP_FLAG_NO_FUSED (the wavefront kernels on a scene of k_mega)
+    t = time.time(); integ.render(sc, film, spp, flags=extra | (0 if os.environ.get('NOTIMING') else A.PHIP_FLAG_KERNEL_TIMING)); dt = time.time() - t
     st = integ.stats.as_dict()
     n = w * h * spp
     print(json.dumps({"scene": key, "tris": sb.n_triangles, "accel": sc.accel_info().as_dict(), "scene_create_s": round(tb, 3), "spp": spp, "Msamples/s": round(n / 1e6 / dt, 1),

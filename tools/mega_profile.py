@@ -16,7 +16,7 @@ from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
 spp = int(os.environ.get("SPP", 64))
 w = h = 1024
 scene = os.environ.get("SCENE", "cornell_box")
-sc = Scene(getattr(S, scene)(w, h, _ffi.gaussian_filter()).desc())
+sc = Scene(getattr(S, scene)(w, h, _ffi.gaussian_filter(), **json.loads(os.environ.get("SCENE_KW", "{}"))).desc())      # e.g. SCENE=cornell_spheres SCENE_KW='{"materials": false}'
 integ = PathHIP(maxDepth=-1); film = HDRFilm(w, h)
 integ.render(sc, film, 1)
 integ.render(sc, film, spp)
