@@ -91,7 +91,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                                            round 6 -- 4: the compressed 8-wide tree in L2 / HBM (k_wide_wave.h: traceWideW), emitter table and materials in LDS, 5: the same with the materials in memory */,
           bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
     constexpr bool WIDE = FLAT >= 4;                            /* the tree, its Wald records and the shading records stay in memory: a lane still owns its path from the camera sample to its last vertex */
-    constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;     /* (the QMC build's static LDS leaves no room for the R-box at four blocks per CU) */
+    /* (the QMC build's static LDS leaves no room for the R-box at four blocks per CU; nor does the LDS of the tree-in-memory builds: there the mailboxes' 10 KB cost the fourth
+       block, and the class deal at four blocks measures 3 % faster than the mailboxes at three -- profiles/r06_gpu_call_i_*) */
+    constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && !WIDE && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;
     constexpr bool DEAL = MM != 0 && FLAT >= 2 && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;
     __shared__ uint32_t ldsClsCnt[4][BLOCK / 64];                 /* MEGA_CLASS_DEAL: lanes per BSDF model and wave */
     __shared__ uint32_t mbR[MAILBOX ? MB_DW * MB_NR : 1u];        /* MEGA_MAILBOX: the R-box, [MB_DW][MB_NR]; the S-box lies in the dynamic LDS behind the traversals' work lists (phip.hip sizes the region) */

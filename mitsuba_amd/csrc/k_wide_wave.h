@@ -244,6 +244,7 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
     if (goC) poolWrite(nS0 + __builtin_amdgcn_mbcnt_hi((uint32_t) (gc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) gc, 0u)), make_uint2(0u, 0x80000000u | lane));
     uint32_t nNodeS = 0, nNodeC = 0, nTriS = 0, nTriC = 0;      /* (wave-uniform) */
     const uint32_t room = WP_CAP + wp.spillCap;
+    uint32_t nQ = 0;                                            /* (ray, record) pairs that wait in the queue (wave-uniform) */
     WD_SYNC()
 #define WP_BPERM(srcLane4, x) pm_from_bits((uint32_t) __builtin_amdgcn_ds_bpermute(srcLane4, (int) pm_to_bits(x)))
     /* the ray of a task (every lane must execute: ds_bpermute): origin, direction, interval */
@@ -259,7 +260,7 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
             }                                                                                                                     \
             pmaxt = pm_from_bits((uint32_t) (wp.slot[(ray)] >> 32));                                                              \
         }
-    while (count) {
+    while (count | nQ) {
         /* ---- pop: the top n tasks, one per lane (fewer when the stack could not take eight children and a triangle group of each) ---- */
         uint32_t n = count < 64u ? count : 64u;
         if (count + 9u * n > room) { const uint32_t fit = room > count ? (room - count) / 9u : 0u; n = fit < 1u ? 1u : (fit < n ? fit : n); }
@@ -285,9 +286,9 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
             const unsigned long long nv = __ballot(isNode && live), sv = __ballot((ray & 64u) != 0u);
             nNodeS += (uint32_t) __popcll(nv & sv); nNodeC += (uint32_t) __popcll(nv & ~sv);
         }
-        /* ---- the triangle round: the pairs of the whole wave, one per lane and step ---- */
+        /* ---- the leaf triangles hit join the wave's queue of (ray, record) pairs ---- */
         const uint32_t pc = (uint32_t) __popc(pending);
-        bool keep = false;                                       /* this lane's group goes back on the stack */
+        bool keep = false;                                       /* this lane's group goes back on the stack (the queue is full) */
         if (__ballot(pc != 0u)) {                                /* (wave-uniform) */
             uint32_t incl = pc;
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
@@ -296,41 +297,18 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
-            const bool fits = incl <= WP_PAIRS;                  /* a prefix of the lanes, never empty: a group has at most 24 records */
+            const bool fits = nQ + incl <= WP_PAIRS;             /* a prefix of the lanes (fewer than 64 pairs wait from the last iteration, a group has at most 24 records: never empty) */
             const uint32_t nFit = (uint32_t) __popcll(__ballot(fits));
-            const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) (nFit - 1u));
             keep = pc != 0u && !fits;
             if (pc != 0u && fits) {
                 const uint32_t tag = ray << 25;
-                lds_w32 *w = wp.pairs + (incl - pc);
+                lds_w32 *w = wp.pairs + nQ + (incl - pc);
                 uint32_t m = pending;
                 do { *w++ = tag | (tbase + (uint32_t) __builtin_ctz(m)); m &= m - 1u; } while (m);
             }
-            WD_SYNC()
-            for (uint32_t base = 0; base < total; base += 64u) {
-                const uint32_t i = base + lane;
-                const uint32_t item = wp.pairs[i];               /* (behind `total`: stale entries, fetched -- every lane must be active in a ds_bpermute -- and not tested) */
-                const uint32_t tray = item >> 25;
-                WP_FETCH_RAY(tray, to, td, tmint, tmaxt)
-                const bool test = i < total;                     /* (only the last step of a round is partial) */
-                if (HAVE_S && HAVE_C) nTriS += (uint32_t) __popcll(__ballot(test && (tray & 64u) != 0u));
-                if (test) {
-                    WIDE_LOAD_TRI(S, item & (WP_TRI_MAX - 1u), a, b, c)
-                    float tu, tv, tt;
-                    if (waldIntersectSel(a, b, c, to, td, tmint, tmaxt, tu, tv, tt)) {
-                        if (HAVE_S && (!HAVE_C || (tray & 64u))) wp.slot[tray] = WP_OCCLUDED;
-                        else {
-                            const unsigned long long key = ((unsigned long long) pm_to_bits(tt) << 32) | (unsigned long long) (((HIT_PRIM_MASK - pm_to_bits(c.z)) << 2) | (pm_to_bits(c.w) & 3u));
-                            __hip_atomic_fetch_min(wp.slot + tray, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (wp.slot[tray] == key) { u2v q; q.x = pm_to_bits(tu); q.y = pm_to_bits(tv); wp.uvs[tray] = q; }
-                        }
-                    }
-                }
-            }
-            if (HAVE_S && HAVE_C) nTriC += total; else if (HAVE_S) nTriS += total; else nTriC += total;     /* (joint: nTriC counts both kinds, corrected below) */
-            WD_SYNC()
+            nQ += (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) (nFit - 1u));
         }
-        /* ---- push: the inner children hit, far to near (the nearest on top), and a triangle group that waits for the next round ---- */
+        /* ---- push: the inner children hit, far to near (the nearest on top), and a triangle group the queue had no room for ---- */
         const uint32_t k = (uint32_t) __popc(inner) + (keep ? 1u : 0u);
         if (__ballot(k != 0u)) {                                 /* (wave-uniform) */
             uint32_t incl = k;
@@ -349,6 +327,39 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
             }
             if (keep) poolWrite(pos, make_uint2(tbase, pending | (ray << 24)));
             count += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+        }
+        WD_SYNC()
+        /* ---- the triangle steps: one pair per lane; only FULL steps while node visits are left (a step costs its ~100 instructions whatever the number of its pairs:
+                the remainder waits for the pairs of the next iteration), everything when the stack is empty ---- */
+        const uint32_t nTest = count ? (nQ & ~63u) : nQ;
+        if (nTest) {                                             /* (wave-uniform) */
+            for (uint32_t base = 0; base < nTest; base += 64u) {
+                const uint32_t i = base + lane;
+                const uint32_t item = wp.pairs[i];               /* (behind nQ: stale entries, fetched -- every lane must be active in a ds_bpermute -- and not tested) */
+                const uint32_t tray = item >> 25;
+                WP_FETCH_RAY(tray, to, td, tmint, tmaxt)
+                const bool test = i < nTest;                     /* (only the last step of the traversal is partial) */
+                if (HAVE_S && HAVE_C) nTriS += (uint32_t) __popcll(__ballot(test && (tray & 64u) != 0u));
+                if (test) {
+                    WIDE_LOAD_TRI(S, item & (WP_TRI_MAX - 1u), a, b, c)
+                    float tu, tv, tt;
+                    if (waldIntersectSel(a, b, c, to, td, tmint, tmaxt, tu, tv, tt)) {
+                        if (HAVE_S && (!HAVE_C || (tray & 64u))) wp.slot[tray] = WP_OCCLUDED;
+                        else {
+                            const unsigned long long key = ((unsigned long long) pm_to_bits(tt) << 32) | (unsigned long long) (((HIT_PRIM_MASK - pm_to_bits(c.z)) << 2) | (pm_to_bits(c.w) & 3u));
+                            __hip_atomic_fetch_min(wp.slot + tray, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (wp.slot[tray] == key) { u2v q; q.x = pm_to_bits(tu); q.y = pm_to_bits(tv); wp.uvs[tray] = q; }
+                        }
+                    }
+                }
+            }
+            if (HAVE_S && HAVE_C) nTriC += nTest; else if (HAVE_S) nTriS += nTest; else nTriC += nTest;     /* (joint: nTriC counts both kinds, corrected below) */
+            /* the pairs that wait move to the front of the queue */
+            const uint32_t rest = nQ - nTest;
+            const uint32_t moved = lane < rest ? wp.pairs[nTest + lane] : 0u;
+            WD_SYNC()
+            if (lane < rest) wp.pairs[lane] = moved;
+            nQ = rest;
             WD_SYNC()
         }
     }

@@ -1171,7 +1171,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             /* the top of the tree every block stages (BFS order); the mailbox build (all leaf BSDF models, counter stream) has the S-box behind the round buffers */
             megaNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, MEGA_WIDE_NODE_CACHE);
             if (const char *e = expEnv("PHIP_MEGA_NODE_CACHE")) megaNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, (uint32_t) atoi(e));
-            const bool mailbox = sc->materialMask != 0 && !qmc && MEGA_MAILBOX;
+            const bool mailbox = false;     /* (the tree-in-memory builds deal their paths by BSDF model; the mailboxes' LDS would cost the fourth block of a CU: k_mega.h) */
             megaLds = MEGA_POOL ? megaWidePoolLdsBytesOf(D, megaNodeCache, mailbox, megaFlat == 4, MB_DW * MB_NS * sizeof(uint32_t))
                                 : megaWideLdsBytesOf(D, megaNodeCache, mailbox, megaFlat == 4, MB_DW * MB_NS * sizeof(uint32_t));
             megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCUWide(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaLds));
