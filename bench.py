@@ -51,15 +51,19 @@ WORKLOADS = {
     # the small scene that is NOT the benchmark: the same box with a rough-copper and a glass block (all three leaf BSDF models; wavefront kernels)
     "cornell_mixed_1024x1024_256spp": ("cornell_mixed", 1024, 1024, 256, -1),
     "atrium_1920x1080_64spp_direct4": ("atrium", 1920, 1080, 64, "direct:4"),
+    # round 6: the scenes between the LDS-resident boxes and the atrium -- the Cornell box with a glass and a rough-copper sphere (or two diffuse
+    # spheres) of 1 k triangles: a tree of ~110 compressed 8-wide nodes that lives in L2; the fused kernel walks it from memory (k_mega, traversal form 4)
+    "cornell_spheres_1k_1024x1024_64spp": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 24, "nlat": 12, "materials": True}),
+    "cornell_spheres_1k_diffuse_1024x1024_64spp": ("cornell_spheres", 1024, 1024, 64, -1, {"nlon": 24, "nlat": 12, "materials": False}),
 }
 HEADLINE = "cornell_1024x1024_256spp"
 EXTRA_SINGLE_GPU = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8",
-                    "cornell_mixed_1024x1024_256spp", "cornell_1024x1024_256spp_direct"]
+                    "cornell_mixed_1024x1024_256spp", "cornell_1024x1024_256spp_direct",
+                    "cornell_spheres_1k_1024x1024_64spp", "cornell_spheres_1k_diffuse_1024x1024_64spp"]
 MULTI_GPU_JOB = "atrium_3840x2160_1024spp_md8"
 MULTI_GPU_SLICE = "atrium_3840x2160_64spp_md8"        # the same job at 1/16 of the samples per pixel: its single-GPU rate
 MULTI_GPU_MAX_STEPS = 3
-CPU_BASELINE_EXTRA = ["atrium_1920x1080_64spp_md8", "glassroom_1920x1080_512spp_md16", "atrium_3840x2160_64spp_md8",
-                      "cornell_mixed_1024x1024_256spp", "cornell_1024x1024_256spp_direct"]      # every workload of the line gets a bounded CPU figure of its own
+CPU_BASELINE_EXTRA = list(EXTRA_SINGLE_GPU)      # every workload of the line gets a bounded CPU figure of its own
 
 
 def make_integrator(md):
@@ -80,8 +84,8 @@ def oracle_params(md, spp):
 
 def build_desc(workload):
     from mitsuba_amd import _ffi, scene as S
-    name, w, h, spp, md = WORKLOADS[workload]
-    sb = getattr(S, name)(w, h, _ffi.gaussian_filter(0.5))
+    name, w, h, spp, md = WORKLOADS[workload][:5]
+    sb = getattr(S, name)(w, h, _ffi.gaussian_filter(0.5), **(WORKLOADS[workload][5] if len(WORKLOADS[workload]) > 5 else {}))
     return sb.desc(), w, h, spp, md, sb.n_triangles
 
 
@@ -95,7 +99,7 @@ def profile_json(kind, workload):
     return None, None
 
 
-def cpu_baseline(workload, seconds_target=10.0):
+def cpu_baseline(workload, seconds_target=10.0, single_core_seconds=4.0):
     """The CPU baseline on a bounded sample of the same workload (same scene / film / integrator, reduced spp):
     the REFERENCE ITSELF when oracle/_ref is there (its own libcore + librender + plugins, compiled from /root/reference by
     oracle/Makefile.ref in the build container; the prebuilt files travel with the repository snapshot) -- its complete
@@ -135,7 +139,44 @@ def cpu_baseline(workload, seconds_target=10.0):
            "sample": "%s at %d spp (%d samples, %.1f s; %s)" % (workload, s, w * h * s, dt1, what)}
     if st and st.get("st") is not None:
         out["mrays_per_s"] = round((st["st"].closest_rays + st["st"].shadow_rays) / 1e6 / dt1, 3)
+    # the single-core rate beside it.  The reference's Scheduler keeps the workers its first job registered, so the one-worker job runs in a process of
+    # its own (this file with --cpu-single-core): the same scene, camera and integrator on a film of 1/8 x 1/8 of the pixels
+    if single_core_seconds > 0:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-single-core", workload, "--cpu-seconds", str(single_core_seconds)],
+                               capture_output=True, text=True, timeout=120)
+            out["single_core"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            out["single_core"] = {"value": None, "error": repr(e)}
     return out
+
+
+def cpu_single_core(workload, seconds_target):
+    """one worker of the reference (or of the oracle port) on the workload's scene at 1/8 x 1/8 of its film: prints one JSON object"""
+    from mitsuba_amd import _ffi, scene as S
+    name, w, h, spp, md = WORKLOADS[workload][:5]
+    w8, h8 = max(32, w // 8), max(32, h // 8)
+    desc = getattr(S, name)(w8, h8, _ffi.gaussian_filter(0.5), **(WORKLOADS[workload][5] if len(WORKLOADS[workload]) > 5 else {})).desc()
+    try:
+        from oracle import ref_ffi as R
+        if not os.path.exists(R.LIB):
+            raise RuntimeError("oracle/_ref is not built")
+        rs = R.RefScene(desc)
+        run = lambda s: rs.render_job(oracle_params(md, s), threads=1, want_image=False)[1]
+        kind = "reference"
+    except Exception:
+        from oracle import oracle_ffi as O
+        osc = O.OracleScene(desc)
+
+        def run(s):
+            t = time.time(); osc.render(oracle_params(md, s), threads=1); return time.time() - t
+        kind = "port"
+    dt0 = max(run(1), 1e-3)
+    s = int(max(1, min(spp, round(seconds_target / dt0))))
+    dt1 = run(s) if s != 1 else dt0
+    print(json.dumps({"value": round(w8 * h8 * s / 1e6 / dt1, 5), "unit": "Msamples/s", "cores": 1, "kind": kind,
+                      "sample": "%s on a %dx%d film at %d spp, one worker (%d samples, %.1f s)" % (workload, w8, h8, s, w8 * h8 * s, dt1)}))
 
 
 def time_workload(workload, steps, warmup, rank, world, local, devices, D, torch):
@@ -183,8 +224,11 @@ def time_workload(workload, steps, warmup, rank, world, local, devices, D, torch
     D.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     agg = {}
+    step_s = []                                          # wall time of every timed step on this rank (a step returns with the frame in host memory: it is synchronous)
     for _ in range(steps):
+        ts = time.perf_counter()
         st = step()
+        step_s.append(time.perf_counter() - ts)
         for k, v in st.as_dict().items():
             agg[k] = agg.get(k, 0) + v
     D.barrier(); torch.cuda.synchronize()
@@ -206,13 +250,16 @@ def time_workload(workload, steps, warmup, rank, world, local, devices, D, torch
         host.close()
     return {"workload": workload, "scene": WORKLOADS[workload][0], "triangles": ntris, "W": W, "H": H, "spp": spp, "integrator": integ_name,
             "accel": accel, "agg": agg, "dt": dt, "steps": steps, "warmup": warmup, "samples": total_samples, "rays": total_rays,
-            "scene_create_ms": t_create * 1e3, "d2h_ms": agg.get("d2h_ms", 0.0) / max(steps, 1), "dt_resident_per_step": dt_res}
+            "scene_create_ms": t_create * 1e3, "d2h_ms": agg.get("d2h_ms", 0.0) / max(steps, 1), "dt_resident_per_step": dt_res, "step_s": step_s}
 
 
 def dominant_kernel(r):
     """(name, description, kernel ms over the timed steps, launches) of the kernel that takes most of the frame"""
     a = r["agg"]
     nodes = r["accel"]["n_nodes"]
+    if a["fused"] and r["accel"].get("fused_traversal", 0) >= 4:
+        return ("k_mega", "whole path in one persistent kernel, the compressed 8-wide tree (%d nodes of 80 B) and its 48-B Wald records walked from L2 through one shared task "
+                "stack per wave in LDS; emitter table%s in LDS" % (nodes, " and materials" if r["accel"]["fused_traversal"] == 4 else ""), a["fused_kernel_ms"], max(int(a["iterations"]), 1))
     if a["fused"]:
         leaves = r["accel"]["n_leaves"]
         tree = ("the tree's %d leaves as a flat table of boxes (one uniform pass), " % leaves) if leaves <= 32 else ("BVH4 (%d nodes), " % nodes)
@@ -323,13 +370,39 @@ def roofline(r):
     fr = {k: v for k, v in fr.items() if v is not None}
     out["bound"] = max(fr, key=fr.get) if fr else "hbm"
     out["fractions"] = fr
+    # ... and the SURVEY 8(d) figure as it is defined, beside the measured one: ALGORITHMIC bytes per launch / launch time / 8 TB/s.  It exceeds 1 where the bytes the
+    # model counts (node and record fetches, ray / hit state) never reach the HBM pins; served_by names what delivers them instead
+    if avg_ms > 0:
+        out["frac_algorithmic"] = round(alg_per_launch / 1e9 / (avg_ms / 1e3) / HBM_PEAK_GBS, 4)
+        wide_fused = name == "k_mega" and r["accel"].get("fused_traversal", 0) >= 4
+        out["served_by"] = ("lds" if (name in ("k_mega", "k_shade_trace") and not wide_fused) else
+                            "lds+l2" if wide_fused else
+                            "l1+l2+mall" if name in ("k_rays_w", "k_rays_p", "k_trace_p", "k_trace", "k_shadow_p") else "hbm")
+        out["frac_algorithmic_note"] = ("algorithmic_bytes_per_launch / avg_launch_ms / 8 TB/s (SURVEY 8(d)); > 1 means the byte model's traffic is served by `served_by`, "
+                                        "not by HBM: the measured HBM fraction is `frac`")
+    # the roof that binds this kernel, as a fraction of what that roof delivers: the texture-data path's model for the ray kernels (their line mix at their hit rates),
+    # useful lane-operations / lane-slots for the kernels that live in registers and LDS, the measured HBM fraction for the streaming kernels
+    if name in ("k_rays_w", "k_rays_p") and (out.get("vmem") or {}).get("model_frac") is not None:
+        out["frac_bound"], out["bound_roof"] = out["vmem"]["model_frac"], "texture-data path (vmem.model_frac: allowed / measured clk per wave instruction for the kernel's line mix)"
+    elif name in ("k_mega", "k_shade_trace") and (out.get("valu") or {}).get("frac") is not None:
+        out["frac_bound"], out["bound_roof"] = out["valu"]["frac"], "VALU (valu.frac: active lane-operations / lane-slots; issue slots busy: valu.issue_frac)"
+    elif out.get("frac") is not None:
+        out["frac_bound"], out["bound_roof"] = max(fr.values()), "the largest measured fraction (%s)" % out["bound"]
     return out
 
 
 def summary(r, world):
     a = r["agg"]
     msps = r["samples"] / 1e6 / r["dt"]
-    return {"value": round(msps, 3), "unit": "Msamples/s", "ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "steps": r["steps"], "warmup": r["warmup"],
+    ss = sorted(r.get("step_s") or [])
+    spread = None
+    if ss:
+        n1 = r["samples"] / r["steps"] / 1e6
+        med = ss[len(ss) // 2] if len(ss) % 2 else 0.5 * (ss[len(ss) // 2 - 1] + ss[len(ss) // 2])
+        spread = {"ms_min": round(ss[0] * 1e3, 3), "ms_median": round(med * 1e3, 3), "ms_max": round(ss[-1] * 1e3, 3),
+                  "value_best_step": round(n1 / ss[0], 3), "value_median_step": round(n1 / med, 3), "value_worst_step": round(n1 / ss[-1], 3),
+                  "note": "wall time of the individual timed steps on rank 0 (a step returns with the frame in host memory); `value` is all steps / the bracketed time"}
+    return {"value": round(msps, 3), "unit": "Msamples/s", "ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "steps": r["steps"], "warmup": r["warmup"], "step_spread": spread,
             "mrays_per_s": round(r["rays"] / 1e6 / r["dt"], 1), "mean_path_length": round(a["path_vertices"] / max(a["samples"], 1), 3),
             "scene": r["scene"], "triangles": r["triangles"], "width": r["W"], "height": r["H"], "spp": r["spp"], "integrator": r["integrator"],
             "fused_kernel": bool(a["fused"]), "bvh_build_ms": round(r["accel"].get("build_ms", 0.0), 1), "scene_create_ms": round(r.get("scene_create_ms", 0.0), 1),
@@ -347,8 +420,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS), help="time only this workload (default: the driver contract, see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-single-core", default=None, choices=list(WORKLOADS), help="(helper process of cpu_baseline) time ONE CPU worker on this workload and print one JSON object")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--full-c5", action="store_true", help="N = 1: also time the whole 1024-spp 4K job (configs[4]) on one GPU, one step (~13 s): the same-build denominator of an N-GPU line")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the C3 / C4 / C5-slice workloads")
     args = ap.parse_args()
+    if args.cpu_single_core:
+        cpu_single_core(args.cpu_single_core, args.cpu_seconds)
+        return
 
     import torch
     from mitsuba_amd import _ffi, distributed as D
@@ -393,8 +472,8 @@ def main():
     main_r = time_workload(headline, steps, warmup, rank, world, local, devices, D, torch)
     extras = {}
     if n_gpus == 1 and not args.workload and not args.no_extra:
-        for w in EXTRA_SINGLE_GPU:
-            extras[w] = time_workload(w, min(args.steps, 3), 1, rank, world, local, devices, D, torch)
+        for w in EXTRA_SINGLE_GPU + ([MULTI_GPU_JOB] if args.full_c5 else []):
+            extras[w] = time_workload(w, 1 if w == MULTI_GPU_JOB else min(args.steps, 3), 1 if w != MULTI_GPU_JOB else 0, rank, world, local, devices, D, torch)
 
     if rank == 0:
         s = summary(main_r, world)
@@ -408,7 +487,7 @@ def main():
                        "parallelism": ("one fixed job: 32x32 blocks dealt round-robin in spiral order over %d GPU(s), " % n_gpus) +
                                       ("one host thread per GPU inside libphip + ncclReduce(sum) of the film" if in_library else
                                        "one process per GPU + RCCL reduce(sum) of the film") if n_gpus > 1 else "1 GPU"},
-            "frame_ms": s["ms_per_step"], "mrays_per_s": s["mrays_per_s"], "mean_path_length": s["mean_path_length"],
+            "frame_ms": s["ms_per_step"], "step_spread": s["step_spread"], "mrays_per_s": s["mrays_per_s"], "mean_path_length": s["mean_path_length"],
             "fused_kernel": s["fused_kernel"], "roofline": s["roofline"],
             "build": {"library": _ffi.lib().phip_version().decode(), "id": _ffi.lib().phip_build_id().decode(),
                       "note": "id = hash of mitsuba_amd/csrc + include + compile flags, compiled into libphip.so and checked against the sources when it is loaded"},

@@ -85,7 +85,10 @@ def _build_locked(sid, out_lib, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", "").split()
     cmds = []
-    for src, extra, obj in UNITS:
+    # an alternative build (PHIP_BUILD_OUTPUT) keeps objects of its own: tools/build_variant.sh links the PRODUCT's objects by name
+    sfx = "" if os.path.abspath(out_lib) == os.path.abspath(LIB) else "-" + os.path.splitext(os.path.basename(out_lib))[0]
+    units = [(src, extra, obj[:-2] + sfx + ".o") for src, extra, obj in UNITS]
+    for src, extra, obj in units:
         if src == "phip.hip":
             extra = extra + ['-DPHIP_BUILD_ID="%s"' % sid]
         cmds.append([hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj + ".tmp.o")])
@@ -109,10 +112,10 @@ def _build_locked(sid, out_lib, verbose):
                 raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
             if verbose:
                 print(" ".join(cmd)); print(out)
-    for _, _, obj in UNITS:
+    for _, _, obj in units:
         os.replace(os.path.join(BUILD, obj + ".tmp.o"), os.path.join(BUILD, obj))
     tmp = out_lib + ".tmp.%d" % os.getpid()
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [os.path.join(BUILD, u[2]) for u in UNITS] + ["-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [os.path.join(BUILD, u[2]) for u in units] + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)

@@ -48,6 +48,10 @@
 #ifndef MEGA_MB_DIAG
 #define MEGA_MB_DIAG 0
 #endif
+#ifndef MEGA_MB_FAULT
+#define MEGA_MB_FAULT 0              /* fault injection (tests/test_gpu_dropin.py builds it): the first wave of the grid reports that it gave up -- the host must then re-render the pass on the
+                                        wavefront kernels and deliver the same frame (phip.hip) */
+#endif
 #ifndef MEGA_POOL
 #define MEGA_POOL 1                  /* FLAT >= 4 (the tree in memory): the wave's rays are traversed through ONE shared stack of node visits, any lane takes any ray's (k_wide_wave.h:
                                         traceWidePool); 0: every lane walks its own ray (traceWideW, with MEGA_JOINT) */
@@ -165,7 +169,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                          : (uint32_t *) (g_smem + (BLOCK / 64u) * BAL_WAVE_BYTES);      /* the S-box, [MB_DW][64], behind the four waves' work lists */
     const bool server = MAILBOX && waveInBlock == 0u;
     bool haveHit = false;                                       /* server: the lane's path came out of the S-box with its hit */
-    uint32_t idleSpins = 0, patience = 0;
+    uint32_t idleSpins = 0, patience = 0, idleSig = 0;
     bool mbTimedOut = false;
 #if MEGA_MB_DIAG
     uint32_t dgDeposit = 0, dgLocal = 0, dgWithdrawn = 0, dgKept = 0, dgServerPass = 0, dgClientPass = 0, dgRefill = 0, dgServerRegen = 0;
@@ -246,7 +250,10 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                     uint32_t e;
                     if (__any(stt == 2u)) {
                         bool got = mbAssign(!alive, stt == 2u, e);
-                        if (got) got = atomicCAS(&mbState[MB_NS + e], 2u, 3u) == 2u;
+                        if (got) {      /* (an ACQUIRE claim -- ADVICE r5: an entry refilled between the load above and the claim must not have its payload read before the server's release store) */
+                            uint32_t expect = 2u;
+                            got = __hip_atomic_compare_exchange_strong(&mbState[MB_NS + e], &expect, 3u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                         if (got) {
                             const uint32_t *x = mbR + e;
                             v.rayO = make_float4(pm_from_bits(x[0 * MB_NR]), pm_from_bits(x[1 * MB_NR]), pm_from_bits(x[2 * MB_NR]), pm_from_bits(x[3 * MB_NR]));
@@ -406,8 +413,18 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             if (!__any(alive || (JOINT && cPush))) {
                 /* nothing in this wave's lanes: done when no id is left anywhere AND every id the block's waves drew has ended as a sample (a path may sit in a
                    mailbox or in another wave and come here yet); until then look into the mailboxes again.  The wait is bounded: no bug may hang the device */
-                if (exhausted && qCount == 0u && __hip_atomic_load(&mbLive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= 0) break;
-                if (++idleSpins > (1u << 22)) { mbTimedOut = true; break; }      /* (the host refuses the frame: phip.hip) */
+                const int live_ = __hip_atomic_load(&mbLive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (exhausted && qCount == 0u && live_ <= 0) break;
+                /* the bound is on waiting WITHOUT PROGRESS (a wall-clock bound alone could trip under counter passes, a debugger, or one very long last path): the
+                   count of the block's live ids and the pattern of full mailbox entries are the protocol's state -- while they move, somebody is working */
+                {
+                    const uint32_t stS_ = __hip_atomic_load(&mbState[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t stR_ = lane < MB_NR ? __hip_atomic_load(&mbState[MB_NS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                    const unsigned long long fs_ = __ballot(stS_ == 2u), fr_ = __ballot(stR_ == 2u);
+                    const uint32_t sig_ = (uint32_t) live_ * 0x9E3779B9u ^ (uint32_t) fs_ ^ (uint32_t) (fs_ >> 32) * 3u ^ (uint32_t) fr_ * 5u ^ (uint32_t) (fr_ >> 32) * 7u;
+                    if (sig_ != idleSig) { idleSig = sig_; idleSpins = 0u; }
+                }
+                if (++idleSpins > (1u << 22)) { mbTimedOut = true; break; }      /* (the host re-renders the pass on the wavefront kernels: phip.hip) */
                 __builtin_amdgcn_s_sleep(8);
                 continue;
             }
@@ -700,7 +717,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                 val = i == MC_SAMPLES ? wc[WC_SAMPLES] : i == MC_VERTICES ? wc[WC_VERTICES] : i == MC_RAYS ? wc[WC_RAYS] : i == MC_NODE ? (wc[WC_STEPS] & 0xFFFFFFFFull)
                     : i == MC_TRI ? (wc[WC_STEPS] >> 32) : i == MC_SH_RAYS ? wc[WC_SH_RAYS] : i == MC_SH_NODE ? (wc[WC_SH_STEPS] & 0xFFFFFFFFull) : (wc[WC_SH_STEPS] >> 32);
         } else val = ldsCount[WCNT ? 0 : i][WCNT ? 0 : threadIdx.x];
-        const bool poison = (MAILBOX && mbTimedOut) || (POOL && __any(poolOverflow));
+        const bool poison = (MAILBOX && mbTimedOut) || (POOL && __any(poolOverflow)) || (MEGA_MB_FAULT && waveId == 0u);
         waveStat(P, rows[i], waveId, val + ((i == MC_SAMPLES && poison && lane == 0u) ? (1ull << 62) : 0ull));
     }
 }

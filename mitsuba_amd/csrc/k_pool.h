@@ -45,7 +45,11 @@ struct PathPool {
     unsigned long long *stat;         /* ST_COUNT arrays of nWaves entries */
     uint32_t *spill;                  /* traversal-stack overflow: SPILL_DEPTH entries per lane */
     uint32_t capacity, nWaves;
+    uint32_t spillLanes;              /* lanes the spill buffer covers (the host sizes it by its bound on the stack depth: phip.hip) */
 };
+/* the spill region of a lane of a BVH4 kernel, or NULL when the host's depth bound said that it cannot spill and the buffer does not cover the lane: a push beyond the LDS
+   entries then traps (TravStack::push) instead of writing out of bounds */
+__device__ __forceinline__ uint32_t *spillOf(const PathPool &P, size_t lane) { return lane < P.spillLanes ? P.spill + lane * 96u /* SPILL_DEPTH */ : nullptr; }
 
 /* The closest-hit record of a slot is (t, u, v, w) with w = bits(prim) | shade class << 30 (PHIP_NO_HIT stays all ones): the ray kernel
  * of the big scenes (k_rays_w) passes on the class it finds in the spare word of the Wald record it hit -- 0 diffuse, 1 rough

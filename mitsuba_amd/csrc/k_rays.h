@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BLOCK, RAYS_WAVES) void k_rays_p(DevScene S, PathPo
     __shared__ uint32_t wcnt[BLOCK / 64][WC_COUNT];
     const uint32_t wave = threadIdx.x >> 6, waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
     if (threadIdx.x < (BLOCK / 64) * WC_COUNT) (&wcnt[0][0])[threadIdx.x] = 0;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);   /* (barrier inside) */
+    TravStack stk; setupTraversal(S, g_smem, spillOf(P, (size_t) blockIdx.x * BLOCK + threadIdx.x), stk);   /* (barrier inside) */
     ShadowSource ss{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
     ss.skipEmpty();
     TraceSource ts{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(BLOCK, RAYS_WAVES) void k_rays_p(DevScene S, PathPo
 
 template <bool TYPED> __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_trace_p(DevScene S, PathPool P) {
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
+    TravStack stk; setupTraversal(S, g_smem, spillOf(P, (size_t) blockIdx.x * BLOCK + threadIdx.x), stk);
     TraceSource src{ P, waveId, 0u, nWavesGrid, (P.capacity + 63u) / 64u };
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     persistentTraverse<false, TYPED>(S, stk, src, nodeVisits, triTests, rays);
@@ -252,7 +252,7 @@ template <bool TYPED> __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_
 
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, PathPool P, float4 *L) {
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
+    TravStack stk; setupTraversal(S, g_smem, spillOf(P, (size_t) blockIdx.x * BLOCK + threadIdx.x), stk);
     ShadowSource src{ P, L, waveId, 0u, 0u, nWavesGrid, P.capacity / BLOCK };
     src.skipEmpty();
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, Pat
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPool P) {
     if (P.blockDead[blockIdx.x]) return;
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) slot * SPILL_DEPTH, stk);
+    TravStack stk; setupTraversal(S, g_smem, spillOf(P, slot), stk);
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     if (slot < P.capacity) {
         if ((P.state[slot] & F_TRACE_MASK) == F_ALIVE) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
 #if PHIP_EXPERIMENTS      /* one lane per shadow-queue entry (PHIP_TRAVERSAL=lane) */
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathPool P, float4 *L) {
     if (P.blockDead[blockIdx.x]) return;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + (size_t) (blockIdx.x * BLOCK + threadIdx.x) * SPILL_DEPTH, stk);
+    TravStack stk; setupTraversal(S, g_smem, spillOf(P, (size_t) blockIdx.x * BLOCK + threadIdx.x), stk);
     const uint32_t n = P.shadowCount[blockIdx.x];            /* entries of this block's slots */
     uint32_t nodeVisits = 0, triTests = 0, rays = 0;
     if (threadIdx.x < n) {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathP
 /* standalone ray casts for phip_trace */
 __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
     const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
-    TravStack stk; setupTraversal(S, g_smem, P.spill + i * SPILL_DEPTH, stk);
+    TravStack stk; setupTraversal(S, g_smem, spillOf(P, i), stk);
     uint32_t nodeVisits = 0, triTests = 0, shNodeVisits = 0, shTriTests = 0;
     if (i < n) {
         const phip_ray ry = rays[i];

@@ -30,7 +30,8 @@ struct TravStack {
     uint32_t nodeCache, triCache;
     int depth, sp;
     __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < depth) lds[sp * BLOCK] = v; else spill[sp - depth] = v;
+        if (sp < depth) lds[sp * BLOCK] = v;
+        else { if (!spill) __builtin_trap(); spill[sp - depth] = v; }     /* (no spill region: the host's depth bound was wrong -- stop, do not write out of bounds) */
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop() {
@@ -107,6 +108,7 @@ __device__ __forceinline__ void setupTraversal(const DevScene &S, unsigned char 
         a = t_[0]; b = t_[1]; c = t_[2];                                                              \
     }
 #define SPILL_DEPTH 96
+static_assert(SPILL_DEPTH == 96, "k_pool.h: spillOf");
 
 
 __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {

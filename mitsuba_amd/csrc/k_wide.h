@@ -330,7 +330,8 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
         } else if (idle == ~0ull) break;
         if (active) {
             /* one node step and one triangle test per iteration */
-            if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps)
+            { constexpr bool wideCullOn = false; (void) wideCullOn;        /* (WIDE_CULL: the dealt loop only -- ADVICE r5: the macro names it in every loop) */
+              if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps) }
             bool finished = false;
             if (tg.y) {
                 const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;
@@ -419,7 +420,8 @@ __device__ __forceinline__ void persistentTraverseWide(const DevScene &S, WideSt
                 if (__builtin_amdgcn_readfirstlane(__lane_id()) == __lane_id()) ++pfIters;
 #endif
                 /* one node step and one triangle test per iteration */
-                if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps)
+                { constexpr bool wideCullOn = false; (void) wideCullOn;
+                  if (tg.y == 0u && (ng.y & 0xff000000u)) WIDE_NODE_STEP(stack, S, ray, ng, tg, steps) }
                 bool finished = false;
                 if (tg.y) {
                     const uint32_t bit = (uint32_t) __ffs((int) tg.y) - 1u;

@@ -1250,6 +1250,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                round 4; when it says "can spill" the full size is allocated AND priced in the free-memory guard above */
             const size_t spillLanes = persistentOnly ? std::min<size_t>(laneCap, (size_t) nCU * 8 * 256) : (canSpill ? laneCap : (size_t) WIDE_BLOCK);
             if (sd.spill.n < spillLanes * SPILL_DEPTH) sd.spill.alloc(spillLanes * SPILL_DEPTH);
+            P.spillLanes = (uint32_t) std::min<size_t>(sd.spill.n / SPILL_DEPTH, 0xFFFFFFFFu);
         }
         if (sd.stat.n < (size_t) ST_COUNT * nWaves) sd.stat.alloc((size_t) ST_COUNT * nWaves);
         if (direct && sd.camHit.n < capacity) sd.camHit.alloc(capacity);
@@ -1406,8 +1407,30 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
                 iter = 1;
             }
             HIP_TRY(hipGetLastError());
+            /* k_mega bounds every wait of its mailbox protocol and the depth of its task stacks; a wave that gave up poisons its sample count (k_mega.h).  Such a pass is
+               incomplete: it is not added to the film -- this pass and the rest of the job run on the kernels that have no such protocol (round 6: degrade, do not fail) */
+            HIP_TRY(hipMemsetAsync(&sd.counters.p->total[ST_SAMPLES], 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(k_reduce_stats, dim3(1, REDUCE_SPLIT), dim3(256), 0, stream, P, sd.counters.p, (int) ST_SAMPLES);
+            HIP_TRY(hipMemcpyAsync(&hc.total[ST_SAMPLES], &sd.counters.p->total[ST_SAMPLES], sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             if (cancelRequested(sc)) cancelled = true;
+            if (!cancelled && hc.total[ST_SAMPLES] > rc.totalIds) {
+                fprintf(stderr, "[phip] warning: the fused kernel gave up on this pass (%s); samples %u.. of the job are rendered by the wavefront kernels\n",
+                        megaWide ? "a task stack outgrew LDS + spill buffer" : "a mailbox wait timed out", (unsigned) (p->sample_offset + sppDone));
+                phip_render_params q = *p;
+                q.flags |= PHIP_FLAG_NO_MEGA | PHIP_FLAG_NO_FUSED;
+                q.sample_total = p->sample_total > 0 ? p->sample_total : p->spp;
+                q.sample_offset = p->sample_offset + (int) sppDone; q.spp = p->spp - (int) sppDone;
+                if (sppDone > 0) q.flags |= PHIP_FLAG_ACCUMULATE;
+                phip_stats st2; memset(&st2, 0, sizeof(st2));
+                const int rc2 = renderOnDevice(sc, sd, &q, shardIndex, shardCount, dOut, &st2);
+                st2.samples += st.samples; st2.closest_rays += st.closest_rays; st2.shadow_rays += st.shadow_rays; st2.path_vertices += st.path_vertices;
+                st2.closest_node_visits += st.closest_node_visits; st2.closest_triangle_tests += st.closest_triangle_tests;
+                st2.shadow_node_visits += st.shadow_node_visits; st2.shadow_triangle_tests += st.shadow_triangle_tests; st2.iterations += st.iterations;
+                st2.render_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+                if (stats) *stats = st2;
+                return rc2;
+            }
         } else {
             /* static share: the first 3/4 of every slot's samples; the remainder is handed out dynamically */
             {
@@ -1550,9 +1573,6 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         HIP_TRY(hipMemcpyAsync(&hc, sd.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
-        /* (k_mega's mailbox protocol bounds its waits; a wave that gave up poisons its sample count: k_mega.h) */
-        if (fused && hc.total[ST_SAMPLES] > rc.totalIds) throw std::runtime_error(megaWide && sc->materialMask == 0 ? "internal error: k_mega's task stack overflowed (LDS + spill buffer)"
-                                                                                       : "internal error: k_mega's mailbox protocol timed out or its task stack overflowed (samples are missing from the frame)");
         st.samples += hc.total[ST_SAMPLES]; st.closest_rays += hc.total[ST_CLOSEST_RAYS]; st.shadow_rays += hc.total[ST_SHADOW_RAYS];
         st.path_vertices += hc.total[ST_VERTICES]; st.closest_node_visits += hc.total[ST_NODE]; st.closest_triangle_tests += hc.total[ST_TRI];
         st.shadow_node_visits += hc.total[ST_SH_NODE]; st.shadow_triangle_tests += hc.total[ST_SH_TRI];
@@ -1751,9 +1771,8 @@ static int renderMultiDevice(phip_scene *sc, const phip_render_params *p, float 
 
 /* Entry of both render functions: validation, the scene's render lock, single- or multi-device dispatch, the sticky
    cancellation flag (consumed by the call that observed it). */
-static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /* device memory on the scene's device */, phip_stats *stats) {
+static int renderLocked(phip_scene *sc, const phip_render_params *p, float *dOut /* device memory on the scene's device */, phip_stats *stats) {      /* (the caller holds sc->renderLock) */
     validateParams(sc, p);
-    std::lock_guard<std::mutex> lock(sc->renderLock);
     int rc;
     if (p->n_devices > 1) {
         rc = renderMultiDevice(sc, p, dOut, stats);
@@ -1767,6 +1786,10 @@ static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut /
         return setErr(PHIP_ERR_CANCELLED, "rendering was cancelled");
     }
     return rc;
+}
+static int renderImpl(phip_scene *sc, const phip_render_params *p, float *dOut, phip_stats *stats) {
+    std::lock_guard<std::mutex> lock(sc->renderLock);
+    return renderLocked(sc, p, dOut, stats);
 }
 
 /* ======================================================================================
@@ -1913,17 +1936,17 @@ int phip_render(phip_scene *scene, const phip_render_params *params, float *out_
         SceneDev &sd = *scene->devs[0];
         HIP_TRY(hipSetDevice(sd.device));
         const size_t n = (size_t) sd.dev.film.width * sd.dev.film.height * 5;
+        /* ONE critical section for the render and the delivery of its frame (the frame lives in the scene-owned sd.film -- with the lock dropped in between, a second
+           thread rendering the same scene could have its frame copied out by this one, or a half-written one) */
+        std::lock_guard<std::mutex> lock(scene->renderLock);
         if (sd.film.n < n) {
             if (params->flags & PHIP_FLAG_ACCUMULATE) return setErr(PHIP_ERR_INVALID, "PHIP_FLAG_ACCUMULATE without a previous phip_render on this scene");
             sd.film.alloc(n);
         }
-        int rc = renderImpl(scene, params, sd.film.p, out_stats);
+        int rc = renderLocked(scene, params, sd.film.p, out_stats);
         if (rc != PHIP_OK) return rc;
         const auto t0 = std::chrono::steady_clock::now();
-        {
-            std::lock_guard<std::mutex> lock(scene->renderLock);         /* (the staging buffers and the stream of the delivery are the scene's: ADVICE r4) */
-            filmToHost(sd, out_rgbaw, sd.film.p, n * sizeof(float));
-        }
+        filmToHost(sd, out_rgbaw, sd.film.p, n * sizeof(float));
         if (out_stats) {
             out_stats->d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             out_stats->render_ms += out_stats->d2h_ms;
@@ -1992,7 +2015,7 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             P.nWaves = (uint32_t) ((m + 63) / 64 + BLOCK / 64);
             stat.alloc((size_t) ST_COUNT * P.nWaves);
             HIP_TRY(hipMemset(stat.p, 0, stat.n * sizeof(unsigned long long)));
-            P.stat = stat.p; P.spill = spill.p;
+            P.stat = stat.p; P.spill = spill.p; P.spillLanes = (uint32_t) (spill.n / SPILL_DEPTH);
             ev.record(0);
             if (scene->wide) hipLaunchKernelGGL(k_raycast_w, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);
             else hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);

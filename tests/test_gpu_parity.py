@@ -967,3 +967,52 @@ def test_cornell_spheres_run_the_fused_kernel_on_the_wide_tree(gpu, oracle, gaus
         compare_render(gpu, oracle, desc, 4, min_identical=0.9999, integrator=VolPathSimpleHIP, maxDepth=8)
     # a ragged film (ids outside the image are drawn and skipped), finer spheres (4.5 k triangles)
     compare_render(gpu, oracle, S.cornell_spheres(100, 70, gauss, nlon=48, nlat=24).desc(), 4, min_identical=0.9999, maxDepth=-1)
+
+
+def test_fused_kernel_that_gives_up_degrades_to_the_wavefront_kernels(gpu, gauss, tmp_path):
+    """k_mega bounds every wait of its mailbox protocol and the depth of its task stacks; a wave that gives up poisons its sample count.  The host
+    used to refuse the frame (a hard error); now it re-renders the pass on the kernels that have no such protocol and logs a warning.  A fault-injection build
+    (-DMEGA_MB_FAULT=1: the first wave of every fused launch reports that it gave up) must deliver the frame of the product build, bit for bit -- on the LDS-resident
+    mixed box (the mailbox build), on the Cornell box (the build of the metric) and on the spheres (the tree in memory), also over several passes."""
+    import subprocess, sys
+    from mitsuba_amd import _ffi
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available: the fault-injection library cannot be built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mitsuba_amd", "_build", "libphip_fault.so")
+    # the whole library with the fault compiled in (the product's objects do not travel to the GPU box: .gpurunignore); _ffi.build skips it when the file is up to date
+    env = dict(os.environ, PHIP_BUILD_OUTPUT=lib, PHIP_EXTRA_HIPCC_FLAGS="-DMEGA_MB_FAULT=1")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from mitsuba_amd import _ffi; print(_ffi.build())" % root], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(lib), r.stdout[-2000:] + r.stderr[-2000:]
+    script = r"""
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np
+from mitsuba_amd import _ffi, _abi as A, scene as S
+from mitsuba_amd.integrator import Scene, PathHIP, HDRFilm
+ft = _ffi.gaussian_filter(0.5)
+out = {}
+for name, sb, spp in (("mixed", S.cornell_mixed(96, 96, ft), 8), ("box", S.cornell_box(64, 64, ft), 8), ("spheres", S.cornell_spheres(96, 96, ft), 4)):
+    gs = Scene(sb.desc()); integ = PathHIP(maxDepth=6); film = HDRFilm(gs.width, gs.height)
+    assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER)
+    out[name + "_samples"] = integ.samples(gs, spp).copy(); out[name + "_film"] = film.storage.copy(); out[name + "_fused"] = np.array([integ.stats.fused, integ.stats.samples])
+    gs.close()
+np.savez(sys.argv[1], **out)
+""" % root
+    multi = {"PHIP_MAX_PASS_SAMPLES": str(96 * 96 * 3)}          # several passes: the continuation of a job whose k-th pass gave up accumulates onto the passes before
+    res = {}
+    for tag, e in (("product", {}), ("fault", {"PHIP_LIB": lib}), ("product_multi", multi), ("fault_multi", dict(multi, PHIP_LIB=lib))):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, **e), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = (np.load(f), r.stderr)
+        assert ("warning: the fused kernel gave up" in r.stderr) == tag.startswith("fault"), (tag, r.stderr[-500:])
+    for a, b, samples in (("product", "fault", True), ("product_multi", "fault_multi", False)):
+        prod, fault = res[a][0], res[b][0]
+        for name in ("mixed", "box", "spheres"):
+            assert prod[name + "_fused"][0] == 1 and fault[name + "_fused"][0] == 0, name                    # the product ran k_mega, the fault build ended on the wavefront kernels
+            assert prod[name + "_fused"][1] == fault[name + "_fused"][1], name                                 # every sample counted once
+            assert (prod[name + "_film"].view(np.uint32) == fault[name + "_film"].view(np.uint32)).all(), (a, name)
+            if samples:
+                assert (prod[name + "_samples"].view(np.uint32) == fault[name + "_samples"].view(np.uint32)).all(), name

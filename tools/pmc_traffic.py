@@ -37,6 +37,13 @@ def run(counter, tag, cmd):
 
 
 sys.path.insert(0, ROOT)
+if os.environ.get("PHIP_POOL"):
+    # the pool-size hook is read by experiment builds only (-DPHIP_EXPERIMENTS=1: expEnv is a constant in the product) -- a run against the product would
+    # record an override that never applied
+    _lib = os.environ.get("PHIP_LIB") or os.path.join(ROOT, "mitsuba_amd", "_build", "libphip.so")
+    if not os.path.exists(_lib) or b"PHIP_POOL" not in open(_lib, "rb").read():
+        sys.exit("pmc_traffic.py: PHIP_POOL is set, but %s does not read it (the product ignores algorithm-selecting environment variables): build an experiment "
+                 "library with `tools/build_variant.sh exp -DPHIP_EXPERIMENTS=1` and pass it as PHIP_LIB, or unset PHIP_POOL" % _lib)
 from mitsuba_amd import _ffi as _ffi_id  # noqa: E402  (the id compiled into the library that is being profiled: read from the file, no GPU call)
 res = {"build_id": _ffi_id.built_id(os.environ.get("PHIP_LIB")), "workload": bench_name, "scene_key": workload, "spp_override": spp or None, "pool_slots_override": os.environ.get("PHIP_POOL"),
        "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB",
