@@ -98,7 +98,8 @@ def _build_locked(sid, out_lib, verbose):
     def cost(cmd):
         name = os.path.basename(cmd[-1])
         if name.startswith("phip_shade"):
-            f, q = name[len("phip_shade"):].split(".")[0].split("_")
+            import re
+            f, q = re.match(r"phip_shade(\d+)_(\d)", name).groups()
             return feat_cost.get(int(f), 20.0) * (0.42 if q == "2" else 1.0)
         return 31.0 if name.startswith("phip_mega") else 14.0
     cmds.sort(key=cost, reverse=True)
