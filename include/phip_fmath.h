@@ -75,7 +75,21 @@ PM_FN float pm_frexpf(float x, int *e) {
     return pm_from_bits(u);
 }
 
-#if !defined(PHIP_FMATH_CEPHES)
+#if defined(PHIP_FMATH_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+/* ======================================================================================
+ *  MEASUREMENT ONLY (round 6, VERDICT r5 item 5: what does exactness cost?): the device's own transcendentals -- v_exp_f32 / v_log_f32 / v_sin_f32 / v_cos_f32 behind
+ *  the __expf / __logf / __sinf / __cosf intrinsics (~1-2 ulp on a reduced range), ocml's acosf / atanf / atan2f / tanf -- instead of the correctly rounded double-
+ *  precision evaluations below.  Built by tools/build_variant.sh with -DPHIP_FMATH_NATIVE; never in the product: results are no longer the oracle's bits.
+ * ====================================================================================== */
+PM_FN void pm_sincosf(float xx, float *s, float *c) { *s = __sinf(xx); *c = __cosf(xx); }
+PM_FN float pm_expf(float x) { return __expf(x); }
+PM_FN float pm_logf(float xx) { return __logf(xx); }
+PM_FN float pm_powf(float x, float y) { return x == 0.0f ? (y > 0.0f ? 0.0f : 1.0f) : __expf(y * __logf(x)); }
+PM_FN float pm_acosf(float x) { return acosf(x); }
+PM_FN float pm_atanf(float xx) { return atanf(xx); }
+PM_FN float pm_atan2f(float y, float x) { return atan2f(y, x); }
+PM_FN float pm_tanf(float xx) { return tanf(xx); }
+#elif !defined(PHIP_FMATH_CEPHES)
 /* ======================================================================================
  *  Default implementation: every function is evaluated in DOUBLE precision from IEEE basic operations (argument
  *  reduction with split constants, Taylor / artanh series of 1/n! and 1/n coefficients taken far enough that the

@@ -171,11 +171,15 @@ struct Builder {
        ~3e-7 x the distance travelled along the axis.  A pad relative to the coordinate alone vanishes for a flat box in the
        plane x = 0 (round 2: ties on such planes were decided by the traversal order), hence the term in the scene's extent. */
     float extent[3] = { 0, 0, 0 };
+    /* ... and, round 6, a term in the CAMERA's position: the slab distance of a plane is (plane - o) * rcp, whose rounding grows with |o|, and the camera's are the only rays that
+       start outside the scene box -- a telephoto view from thousands of scene extents away used to be safe only on the BVH4 of the small scenes, whose kernels left the product
+       when every scene got the wide tree (tests/test_gpu_parity.py: far camera; the packed leaf table pads its half extents the same way, phip.hip) */
+    float camPad[3] = { 0, 0, 0 };
     void pad(Box &b) const {
         /* (the LARGEST extent on every axis: a scene that is flat on one axis -- everything in the plane y = 0 -- must not lose its pad there) */
         const float maxExtent = std::max(extent[0], std::max(extent[1], extent[2]));
         for (int i = 0; i < 3; ++i) {
-            float e = 1e-5f * std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])) + 1e-7f * (b.mx[i] - b.mn[i]) + 2e-6f * maxExtent + 1e-30f;
+            float e = 1e-5f * std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])) + 1e-7f * (b.mx[i] - b.mn[i]) + 2e-6f * maxExtent + camPad[i] + 1e-30f;
             b.mn[i] -= e; b.mx[i] += e;
         }
     }
@@ -589,7 +593,8 @@ struct Reinserter {
 template <typename Children2>
 inline void buildWide(HostBVH &out, int32_t root2, const detail::Box &rootBox, Children2 children2) {
     out.wnodes.clear(); out.wtris.clear(); out.nWNodes = 0; out.wMaxDepth = 0; out.nWTris = 0; out.wSahCost = 0;
-    if (root2 < 0) return;                                   /* a single leaf: small scenes use the BVH4 */
+    /* (root2 < 0: the whole scene is ONE leaf -- round 6: it still gets a wide root whose only children are the pieces of that leaf, because every scene's ray kernels walk
+       the wide tree; the collapse below has nothing to decide then) */
     typedef detail::ChildRef Child;
     struct WChild { Child c; uint32_t firstTri, nTris; };    /* leaf pieces carry their record range (in out.tris) */
     struct Item { int32_t ref2; uint32_t index, depth; detail::Box box; };
@@ -650,7 +655,7 @@ inline void buildWide(HostBVH &out, int32_t root2, const detail::Box &rootBox, C
         out.wMaxDepth = std::max(out.wMaxDepth, it.depth);
         /* the children of this wide node, as the SAH-optimal collapse (cost table below) distributes its 8 slots */
         std::vector<Child> ch;
-        expand(it.ref2, 8, ch);
+        if (it.ref2 < 0) ch.push_back(Child{ it.ref2, it.box }); else expand(it.ref2, 8, ch);
         /* leaf children of more than 3 records are split into pieces of <= 3 (same box) */
         std::vector<WChild> wc;
         for (const Child &c : ch) {
@@ -732,7 +737,7 @@ inline void buildWide(HostBVH &out, int32_t root2, const detail::Box &rootBox, C
     out.wSahCost = (float) (cost + 1.0);
 }
 
-inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t nTris, HostBVH &out) {
+inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t nTris, HostBVH &out, const float *cameraPosition = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
     std::vector<BuildTri> T; T.reserve(nTris);
     detail::Box tight; tight.reset();
@@ -770,6 +775,7 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
     }
     detail::Builder B(T, out, positions, indices);
     for (int a = 0; a < 3; ++a) B.extent[a] = tight.mx[a] - tight.mn[a];
+    if (cameraPosition) for (int a = 0; a < 3; ++a) B.camPad[a] = 4.8e-7f * std::fabs(cameraPosition[a]);
     detail::Box rootBox;
     /* spatial splits for the scenes that use the wide tree (small scenes are laid out for LDS record by record) */
     const char *sp = getenv("PHIP_BVH_SPATIAL");

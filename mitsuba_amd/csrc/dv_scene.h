@@ -87,7 +87,10 @@ struct DevScene {
     const float4 *nodes; const float4 *tris; const float4 *triShade;
     uint32_t flatMode;                                      /* layout of flatLeaves: 1 = (min, ref)(max, 0) per leaf; 2 = packed planes + record masks (traverseFlat2) */
     const float4 *flatLeaves; uint32_t nFlatLeaves;         /* k_mega: the leaves of a tree of <= FLAT_LEAVES_MAX leaves as a flat table (k_traverse.h: traverseFlat); 0: walk the BVH4 */
-    const uint4 *wnodes; uint32_t wideNodeCache;             /* big scenes: the compressed 8-wide tree (k_wide.h); tris is then in ITS leaf order and nodes is unused */
+    const uint4 *wnodes; uint32_t wideNodeCache;             /* the compressed 8-wide tree (k_wide_node.h) and -- wtris -- the Wald records in ITS leaf order.  Scenes past the packed leaf
+                                                                table (more than 64 records) hold nothing else: tris == wtris, nodes unused; the LDS-resident scenes keep the BVH4-ordered
+                                                                records (tris) and the leaf table for k_mega / k_shade_trace beside the wide tree the ray kernels walk (round 6) */
+    const float4 *wtris;
     const DevMaterial *materials; uint32_t nMaterials;
     const float *emitterTab; uint32_t emitterTabSize;       /* EmitterTab layout, floats */
     uint32_t nEmitters; float emitterNormalization;

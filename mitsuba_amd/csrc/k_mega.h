@@ -98,7 +98,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     /* (the QMC build's static LDS leaves no room for the R-box at four blocks per CU; nor does the LDS of the tree-in-memory builds: there the mailboxes' 10 KB cost the fourth
        block, and the class deal at four blocks measures 3 % faster than the mailboxes at three -- profiles/r06_gpu_call_i_*) */
     constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && !WIDE && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;
-    constexpr bool DEAL = MM != 0 && FLAT >= 2 && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;
+    /* (WIDE: neither -- the deal's five block barriers per pass cost more than the divergence they remove once a pass is dominated by a traversal whose length differs from
+       wave to wave: glass + copper spheres 1554 -> 1803, glass room 510 -> 602, atrium 444 -> 457 Msamples/s without it, profiles/r06_gpu_call_n_*) */
+    constexpr bool DEAL = MM != 0 && FLAT >= 2 && !WIDE && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;
     __shared__ uint32_t ldsClsCnt[4][BLOCK / 64];                 /* MEGA_CLASS_DEAL: lanes per BSDF model and wave */
     __shared__ uint32_t mbR[MAILBOX ? MB_DW * MB_NR : 1u];        /* MEGA_MAILBOX: the R-box, [MB_DW][MB_NR]; the S-box lies in the dynamic LDS behind the traversals' work lists (phip.hip sizes the region) */
     __shared__ uint32_t mbState[MAILBOX ? MB_NS + MB_NR : 1u];   /* entry states, S-box then R-box: 0 empty, 2 full, 3 being read (R-box: three consumers claim by compare-and-swap) */

@@ -248,7 +248,8 @@ template <bool TYPED> __global__ __launch_bounds__(BLOCK, TRACE_P_WAVES) void k_
     waveStat(P, ST_TRI, waveId, triTests);
 }
 
-#endif  /* PHIP_EXPERIMENTS */
+/* (round 6: k_shadow_p, k_trace and k_raycast below -- the BVH4 ray kernels of the small scenes -- left the product as well: every scene has the compressed wide tree on
+   the device, and k_rays_w / k_raycast_w are the wavefront path's and phip_trace's only ray kernels) */
 
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow_p(DevScene S, PathPool P, float4 *L) {
     const uint32_t waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWavesGrid = gridDim.x * (BLOCK / 64);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace(DevScene S, PathPo
     waveStat(P, ST_TRI, waveId, triTests);
 }
 
-#if PHIP_EXPERIMENTS      /* one lane per shadow-queue entry (PHIP_TRAVERSAL=lane) */
+/* one lane per shadow-queue entry (PHIP_TRAVERSAL=lane) */
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathPool P, float4 *L) {
     if (P.blockDead[blockIdx.x]) return;
     TravStack stk; setupTraversal(S, g_smem, spillOf(P, (size_t) blockIdx.x * BLOCK + threadIdx.x), stk);
@@ -318,7 +319,6 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_shadow(DevScene S, PathP
     }
 }
 
-#endif
 
 /* standalone ray casts for phip_trace */
 __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *rays, size_t n, phip_hit *hits, uint8_t *occluded, PathPool P) {
@@ -351,4 +351,4 @@ __global__ __launch_bounds__(BLOCK) void k_raycast(DevScene S, const phip_ray *r
     waveStat(P, ST_SH_NODE, waveId, shNodeVisits);
     waveStat(P, ST_SH_TRI, waveId, shTriTests);
 }
-
+#endif  /* PHIP_EXPERIMENTS */

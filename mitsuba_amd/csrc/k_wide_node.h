@@ -205,7 +205,7 @@ __device__ __forceinline__ uint4 ldsLoadU4(lds_cu4 *p) { const u4v v = *p; retur
 #define WIDE_LOAD_TRI(S, idx, a, b, c)                                                                \
     float4 a, b, c;                                                                                   \
     {                                                                                                 \
-        const float4 *t_ = (S).tris + 3 * (size_t) (idx);                                             \
+        const float4 *t_ = (S).wtris + 3 * (size_t) (idx);                                            \
         f4v va_, vb_, vc_;                                                                            \
         asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx4 %2, %3, off offset:32\n\ts_waitcnt vmcnt(0)" \
                      : "=&v"(va_), "=&v"(vb_), "=&v"(vc_) : "v"(t_) : "memory");                       \

@@ -174,6 +174,9 @@ __device__ __forceinline__ void traceWideW(const DevScene &S, WideStackT<BLOCK> 
 #ifndef WP_CAP
 #define WP_CAP 256u                      /* task-stack entries per wave in LDS (8 B each): 8 KB per block -- with 512 the block's LDS (slots, ray table, pair list, node cache, camera-sample queue) costs the fourth block of a CU */
 #endif
+#ifndef WP_NEAR_FIRST
+#define WP_NEAR_FIRST 1                  /* the nearest child of every lane on top of the stack (0: every lane's children together, far to near) */
+#endif
 #define WP_PAIRS 256u                    /* (ray, triangle) pairs per round and wave (4 B each: ray << 25 | record) */
 #define WP_TRI_MAX (1u << 25)            /* records the pair list can address (phip.hip checks) */
 #define WP_WAVE_BYTES (128u * 8u + 64u * 8u + 64u * 32u + WP_PAIRS * 4u)      /* per wave: result slots of 128 rays, (u, v) of the closest hits, the any-hit rays, pair list */
@@ -308,9 +311,15 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
             }
             nQ += (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) (nFit - 1u));
         }
-        /* ---- push: the inner children hit, far to near (the nearest on top), and a triangle group the queue had no room for ---- */
-        const uint32_t k = (uint32_t) __popc(inner) + (keep ? 1u : 0u);
-        if (__ballot(k != 0u)) {                                 /* (wave-uniform) */
+        /* ---- push: the inner children hit.  The NEAREST child of every lane goes to the top segment of the stack, its other children (far to near) and a triangle group the
+                queue had no room for below the top segments of all lanes: the next iteration then pops nearest children of MANY rays rather than all children of a few --
+                depth first, front to back per ray, which is what lets a hit found in the near child reject the far ones (WP_NEAR_FIRST: node visits per closest ray of the
+                atrium 11.3 -> see DESIGN.md 3.4; the per-lane walk makes 10.0) ---- */
+        const uint32_t nInner = (uint32_t) __popc(inner);
+        const bool hasTop = WP_NEAR_FIRST && nInner != 0u;
+        const uint32_t k = nInner - (hasTop ? 1u : 0u) + (keep ? 1u : 0u);
+        const unsigned long long topMask = __ballot(hasTop);
+        if (__ballot(k != 0u) | topMask) {                       /* (wave-uniform) */
             uint32_t incl = k;
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x111, 0xf, 0xf, true);
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x112, 0xf, 0xf, true);
@@ -318,15 +327,22 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x118, 0xf, 0xf, true);
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x142, 0xa, 0xf, false);
             incl += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) incl, 0x143, 0xc, 0xf, false);
+            const uint32_t nRest = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
             uint32_t pos = count + incl - k;
-            uint32_t m = inner;
+            uint32_t m = hasTop ? (inner & ~(0x80000000u >> __clz((int) inner))) : inner;      /* (without the highest bit: the first child in traversal order) */
             while (m) {                                          /* lowest bit = last in traversal order: it goes deepest */
                 const uint32_t bit = (uint32_t) __builtin_ctz(m); m &= m - 1u;
                 const uint32_t slotIdx = (bit - 24u) ^ octant;
                 poolWrite(pos++, make_uint2(childBase + (uint32_t) __popc(imask & ((1u << slotIdx) - 1u)), 0x80000000u | ray));
             }
             if (keep) poolWrite(pos, make_uint2(tbase, pending | (ray << 24)));
-            count += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+            if (hasTop) {
+                const uint32_t bit = 31u - (uint32_t) __clz((int) inner);
+                const uint32_t slotIdx = (bit - 24u) ^ octant;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (topMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) topMask, 0u));
+                poolWrite(count + nRest + rank, make_uint2(childBase + (uint32_t) __popc(imask & ((1u << slotIdx) - 1u)), 0x80000000u | ray));
+            }
+            count += nRest + (uint32_t) __popcll(topMask);
         }
         WD_SYNC()
         /* ---- the triangle steps: one pair per lane; only FULL steps while node visits are left (a step costs its ~100 instructions whatever the number of its pairs:

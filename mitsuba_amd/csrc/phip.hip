@@ -45,6 +45,9 @@
 #include "k_wide.h"
 #include "k_wide_wave.h"
 #include "k_film.h"
+#ifndef PHIP_WIDE_MIN_RECORDS
+#define PHIP_WIDE_MIN_RECORDS 64u    /* scenes of more Wald records than the packed leaf table holds are traversed on the 8-wide tree, whatever their size */
+#endif
 #include <dlfcn.h>
 #include <map>
 #include <rccl/rccl.h>          /* types and prototypes only: librccl is bound with dlopen at the first multi-GPU render */
@@ -169,7 +172,8 @@ void spiralBlocks(int sizeX, int sizeY, int bs, std::vector<std::pair<int, int>>
 struct SceneDev {
     int device = 0;
     /* ---- scene (immutable after build / replication) ---- */
-    DevBuf<float4> nodes, tris, triShade, flatLeaves;
+    DevBuf<float4> nodes, tris, wtris, triShade, flatLeaves;      /* tris: BVH4 leaf order (LDS-resident scenes only), wtris: the wide tree's */
+    bool trisAreWide = false;                                      /* scenes past the packed leaf table: DevScene::tris = wtris */
     DevBuf<uint4> wnodes;                                                                     /* compressed wide BVH (big scenes) */
     DevBuf<DevMaterial> materials;
     DevBuf<float> emitterTab;
@@ -199,12 +203,12 @@ struct SceneDev {
     float *stage[2] = { nullptr, nullptr }; hipEvent_t stageDone[2] = { nullptr, nullptr };
 
     template <typename F> void forEachSceneBuffer(F f) {
-        f(nodes); f(wnodes); f(tris); f(triShade); f(flatLeaves); f(materials); f(emitterTab); f(texTexels); f(texDesc);
+        f(nodes); f(wnodes); f(tris); f(wtris); f(triShade); f(flatLeaves); f(materials); f(emitterTab); f(texTexels); f(texDesc);
         f(envTexels); f(envLevels); f(envCdfRows); f(envCdfCols); f(envRowWeights);
     }
     /* the pointer members of the DevScene (everything else in it is plain data, equal on every device) */
     void bind() {
-        dev.nodes = nodes.p; dev.wnodes = wnodes.p; dev.tris = tris.p; dev.triShade = triShade.p; dev.flatLeaves = flatLeaves.p; dev.materials = materials.p;
+        dev.nodes = nodes.p; dev.wnodes = wnodes.p; dev.wtris = wtris.p; dev.tris = trisAreWide ? wtris.p : tris.p; dev.triShade = triShade.p; dev.flatLeaves = flatLeaves.p; dev.materials = materials.p;
         dev.texTexels = texTexels.p; dev.textures = texDesc.p; dev.emitterTab = emitterTab.p;
         dev.env.texels = envTexels.p; dev.env.levels = envLevels.p; dev.env.cdfRows = envCdfRows.p; dev.env.cdfCols = envCdfCols.p;
         dev.env.rowWeights = envRowWeights.p;
@@ -225,7 +229,8 @@ struct phip_scene {
     int materialMask = MM_ALL;       /* leaf BSDF models present: selects the k_shade instantiation */
     bool flatTraceToo = false;       /* a scene of k_mega that k_shade_trace could serve as well (PHIP_FLAG_NO_MEGA) */
     bool flatTrace = false;          /* not a scene of k_mega, but its tree is the packed leaf table (<= 64 Wald records) and emitter table + materials fit LDS: k_shade_trace */
-    bool wide = false;               /* the ray kernels walk the compressed 8-wide BVH (trees of >= 64 BVH4 nodes; PHIP_WIDE=0 keeps the BVH4) */
+    bool wide = false;               /* the ray kernels walk the compressed 8-wide BVH: every scene since round 6 */
+    bool wideOnly = false;           /* ... and the device holds nothing else (trees of >= 64 BVH4 nodes or more than 64 Wald records): no BVH4, no leaf table, no LDS-resident kernels */
     bool fitsLds = false;            /* tree, Wald records, shading records, emitter table and materials fit the fused kernel's LDS plan */
     int fusedWide = 0;               /* round 6: 4 / 5 = the fused kernel walks the 8-wide tree from memory (k_mega<.., FLAT 4 / 5, ..>: emitter table in LDS; materials in LDS / in memory) */
     std::vector<std::unique_ptr<SceneDev>> devs;
@@ -432,7 +437,10 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     }
 
     /* acceleration structure */
-    buildBVH(d.positions, d.indices, d.n_triangles, sc->bvh);
+    {
+        const float camPos[3] = { d.camera.to_world[3], d.camera.to_world[7], d.camera.to_world[11] };
+        buildBVH(d.positions, d.indices, d.n_triangles, sc->bvh, camPos);
+    }
     if (sc->bvh.tris.size() / 12 >= (1u << 28)) throw std::runtime_error("too many triangle records for the leaf reference encoding");
     if (d.n_triangles > HIT_PRIM_MASK) throw std::runtime_error("too many triangles for the hit record (30-bit primitive index)");
 
@@ -518,13 +526,19 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     if (texDesc.empty()) sd.texDesc.alloc(1); else sd.texDesc.upload(texDesc.data(), texDesc.size());
     sc->hasTextures = d.n_textures > 0; sc->triShadeStride = stride;
     if (const char *e = expEnv("PHIP_TRAVERSAL")) sc->traversal = strcmp(e, "lane") == 0 ? 0 : 2;
-    sc->wide = sc->traversal == 2 && sc->bvh.nWNodes > 0 && sc->bvh.nNodes >= 64;
-    if (const char *e = expEnv("PHIP_WIDE")) sc->wide = sc->wide && atoi(e) != 0;
+    /* the compressed 8-wide tree: every scene the packed leaf table of the LDS-resident kernels does not serve (more than 64 Wald records).  Round 6: it used to start at 64 BVH4
+       nodes; the scenes in between ran the round-1 BVH4 kernels (or, all-diffuse ones, k_mega's BVH4 walk in LDS) -- now they run k_mega on the wide tree / k_rays_w */
+    if (sc->bvh.nWNodes == 0) {      /* a scene without triangles: one node without children (all-zero meta bytes hit nothing) -- the ray kernels need a root to reject */
+        sc->bvh.wnodes.assign(20, 0u); sc->bvh.nWNodes = 1; sc->bvh.wMaxDepth = 1;
+    }
+    sc->wideOnly = sc->traversal == 2 && sc->bvh.nWNodes > 0 && (sc->bvh.nNodes >= 64 || sc->bvh.tris.size() / 12 > PHIP_WIDE_MIN_RECORDS);
+    if (const char *e = expEnv("PHIP_WIDE")) sc->wideOnly = sc->wideOnly && atoi(e) != 0;
+    /* ... and, round 6, EVERY scene has the wide tree on the device: the ray kernels of the wavefront path (k_rays_w) and phip_trace (k_raycast_w) walk nothing else -- the
+       round-1 BVH4 ray kernels are compiled by experiment builds only.  The LDS-resident scenes keep their BVH4-ordered records and leaf table for k_mega / k_shade_trace beside it */
+    sc->wide = sc->traversal == 2 && sc->bvh.nWNodes > 0 && (sc->wideOnly || !(PHIP_EXPERIMENTS && expEnv("PHIP_BVH4_RAYS")));
     /* the stack of the structure that is going to be walked: three pushes per BVH4 level (the wide tree's group stack is checked below) */
     if (!sc->wide && 3 * sc->bvh.maxDepth + 2 > STACK_DEPTH + SPILL_DEPTH) throw std::runtime_error("BVH too deep for the traversal stack");
     if (sc->wide) {
-        /* big scenes: the compressed wide tree and the records in ITS leaf order; the BVH4 stays on the host */
-        sd.nodes.alloc(8);
         if (WIDE_NODE_STRIDE == 5) sd.wnodes.upload((const uint4 *) sc->bvh.wnodes.data(), sc->bvh.wnodes.size() / 4);
         else {                                               /* one node per WIDE_NODE_STRIDE * 16 bytes (a 128-byte line) */
             const size_t n = sc->bvh.wnodes.size() / 20;
@@ -532,11 +546,13 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
             for (size_t i = 0; i < n; ++i) memcpy(&padded[i * WIDE_NODE_STRIDE], &sc->bvh.wnodes[i * 20], 80);
             sd.wnodes.upload(padded.data(), padded.size());
         }
-        sd.tris.upload((const float4 *) sc->bvh.wtris.data(), sc->bvh.wtris.size() / 4);
+        if (sc->bvh.wtris.empty()) sd.wtris.alloc(3); else sd.wtris.upload((const float4 *) sc->bvh.wtris.data(), sc->bvh.wtris.size() / 4);
+    } else { sd.wnodes.alloc(5); sd.wtris.alloc(3); }
+    if (sc->wideOnly) {
+        sd.nodes.alloc(8); sd.tris.alloc(3); sd.trisAreWide = true;      /* (DevScene::tris = wtris: SceneDev::bind) */
     } else {
         if (sc->bvh.nodes.empty()) sd.nodes.alloc(8);
         else sd.nodes.upload((const float4 *) sc->bvh.nodes.data(), sc->bvh.nodes.size() / 4);
-        sd.wnodes.alloc(5);
         sd.tris.upload((const float4 *) sc->bvh.tris.data(), sc->bvh.tris.size() / 4);
     }
     sd.materials.upload(mats.data(), mats.size());
@@ -587,7 +603,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
 
     DevScene &D = sd.dev;
     memset(&D, 0, sizeof(D));
-    D.nodes = sd.nodes.p; D.tris = sd.tris.p; D.triShade = sd.triShade.p;
+    D.nodes = sd.nodes.p; D.wtris = sd.wtris.p; D.tris = sd.trisAreWide ? sd.wtris.p : sd.tris.p; D.triShade = sd.triShade.p;
     D.materials = sd.materials.p; D.nMaterials = (uint32_t) mats.size();
     D.texTexels = sd.texTexels.p; D.textures = sd.texDesc.p; D.triShadeStride = sc->triShadeStride;
     D.emitterTab = sd.emitterTab.p; D.emitterTabSize = (uint32_t) tab.size();
@@ -695,7 +711,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     D.shadeSort = (sc->wide && (sc->materialMask & MM_ROUGH)) ? 1u : 0u;
     if (const char *e = expEnv("PHIP_SHADE_SORT")) D.shadeSort = D.shadeSort && atoi(e) != 0;       /* experiment hook */
     if (sc->wide) {
-        D.nodeCache = 0; D.triCache = 0;
+        if (sc->wideOnly) { D.nodeCache = 0; D.triCache = 0; }
         D.wideNodeCache = std::min<uint32_t>(sc->bvh.nWNodes, WIDE_NODE_CACHE_MAX);
         if (const char *e = expEnv("PHIP_NODE_CACHE")) D.wideNodeCache = std::min<uint32_t>(D.wideNodeCache, (uint32_t) atoi(e));
         if ((int) sc->bvh.wMaxDepth + 2 > WIDE_STACK_LDS + SPILL_DEPTH / 2) throw std::runtime_error("wide BVH too deep for the traversal stack");
@@ -727,7 +743,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
        every leaf box in one uniform pass instead of walking the 7-node tree (k_traverse.h: traverseFlat).  Entry = (min.xyz, bits(leaf
        reference)) (max.xyz, 0), boxes as the BVH4 nodes hold them (padded). */
     D.nFlatLeaves = 0; D.flatMode = 0; sd.flatLeaves.alloc(2); D.flatLeaves = sd.flatLeaves.p;
-    if (treeInLds && !sc->wide && sc->bvh.nLeaves <= FLAT2_LEAVES_MAX && !expEnv("PHIP_NO_FLAT")) {
+    if (treeInLds && !sc->wideOnly && sc->bvh.nLeaves <= FLAT2_LEAVES_MAX && !expEnv("PHIP_NO_FLAT")) {
         std::vector<float4> flat;
         if (sc->bvh.rootRef < 0) {                         /* a single leaf: its box is the scene's */
             flat.push_back(make_float4(sc->bvh.tightMin[0] - 1.0f, sc->bvh.tightMin[1] - 1.0f, sc->bvh.tightMin[2] - 1.0f, pm_from_bits((uint32_t) sc->bvh.rootRef)));
@@ -802,7 +818,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
     }
     /* round 6: the fused kernel on a tree that does not fit LDS (k_wide_wave.h) -- every scene on the 8-wide tree whose emitter table fits LDS and that needs none of the
        feature sets k_mega is not compiled with (bitmap textures, an environment emitter) */
-    sc->fusedWide = (sc->wide && !sc->hasTextures && envEmitter < 0 && stride == TRISHADE_FLOAT4S && tab.size() <= EMITTER_LDS_FLOATS
+    sc->fusedWide = (sc->wideOnly && !sc->hasTextures && envEmitter < 0 && stride == TRISHADE_FLOAT4S && tab.size() <= EMITTER_LDS_FLOATS
                      && sc->bvh.wtris.size() / 12 < WP_TRI_MAX && !expEnv("PHIP_NO_MEGA_WIDE"))
                   ? (mats.size() <= MATERIAL_LDS_MAX ? 4 : 5) : 0;
     const bool traceable = D.flatMode >= 2 && tab.size() <= EMITTER_LDS_FLOATS && mats.size() <= MATERIAL_LDS_MAX && !expEnv("PHIP_NO_SHADE_TRACE");
@@ -894,7 +910,7 @@ static SceneDev *replicateScene(phip_scene *sc, int device) {
     std::unique_ptr<SceneDev> dst(new SceneDev());
     dst->device = device;
     HIP_TRY(hipSetDevice(device));
-    dst->nodes.cloneFrom(src.nodes); dst->wnodes.cloneFrom(src.wnodes); dst->tris.cloneFrom(src.tris); dst->triShade.cloneFrom(src.triShade); dst->flatLeaves.cloneFrom(src.flatLeaves);
+    dst->nodes.cloneFrom(src.nodes); dst->wnodes.cloneFrom(src.wnodes); dst->tris.cloneFrom(src.tris); dst->wtris.cloneFrom(src.wtris); dst->trisAreWide = src.trisAreWide; dst->triShade.cloneFrom(src.triShade); dst->flatLeaves.cloneFrom(src.flatLeaves);
     dst->materials.cloneFrom(src.materials); dst->emitterTab.cloneFrom(src.emitterTab);
     dst->texTexels.cloneFrom(src.texTexels); dst->texDesc.cloneFrom(src.texDesc);
     dst->envTexels.cloneFrom(src.envTexels); dst->envLevels.cloneFrom(src.envLevels);
@@ -1276,12 +1292,12 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, ldsBytes) != hipSuccess || n <= 0) n = 1;
         return std::min(n, wanted);
     };
-    auto persistentGrid = [&](const void *kernel, int blocksPerCU) {
+    [[maybe_unused]] auto persistentGrid = [&](const void *kernel, int blocksPerCU) {
         return dim3((unsigned) std::max(1, std::min<int>(nCU * residentBlocks(kernel, blocksPerCU), (int) ((capacity + BLOCK - 1) / BLOCK))));
     };
     const dim3 grid((capacity + BLOCK - 1) / BLOCK);
-    const dim3 pgrid = persistentGrid((const void *) k_shadow_p, TRACE_WAVES);
 #if PHIP_EXPERIMENTS
+    const dim3 pgrid = persistentGrid((const void *) k_shadow_p, TRACE_WAVES);
     const dim3 pgridTrace = persistentGrid(sc->bvh.nNodes >= 64 ? (const void *) k_trace_p<false> : (const void *) k_trace_p<true>, TRACE_P_WAVES);
 #endif
     /* k_rays_w: blocks of WIDE_BLOCK threads with their own LDS plan (one block per CU holds 800 nodes of the tree) */
@@ -1480,20 +1496,20 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
 #endif
                     if (timing) evTrace.record(stream);
                 } else {
+#if PHIP_EXPERIMENTS      /* the BVH4 ray kernels of round 1 (PHIP_BVH4_RAYS=1 on a small scene, PHIP_WIDE=0 / PHIP_TRAVERSAL=lane): A/B only */
                     if (timing) evShadow.record(stream);
-#if PHIP_EXPERIMENTS
                     if (sc->traversal != 2) hipLaunchKernelGGL(k_shadow, grid, block, ldsBytes, stream, D, P, sd.L.p); else
-#endif
                     hipLaunchKernelGGL(k_shadow_p, pgrid, block, ldsBytes, stream, D, P, sd.L.p);
                     if (timing) evShadow.record(stream);
                     if (timing) evTrace.record(stream);
-#if PHIP_EXPERIMENTS
                     if (sc->traversal == 2 && sc->bvh.nNodes >= 64) hipLaunchKernelGGL(k_trace_p<false>, pgridTrace, block, ldsBytes, stream, D, P);
                     else if (sc->traversal == 2 && forcePersist) hipLaunchKernelGGL(k_trace_p<true>, pgridTrace, block, ldsBytes, stream, D, P);
                     else
-#endif
-                    hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);     /* tiny trees (the only ones off the wide tree): the plain per-slot launch wins (measured) */
+                    hipLaunchKernelGGL(k_trace, grid, block, ldsBytes, stream, D, P);
                     if (timing) evTrace.record(stream);
+#else
+                    throw std::runtime_error("internal error: no ray kernel for this scene (the wide tree is missing)");
+#endif
                 }
                 ++iter;
                 if (check) {
@@ -2018,7 +2034,11 @@ int phip_trace(phip_scene *scene, const phip_ray *rays, size_t n, phip_hit *hits
             P.stat = stat.p; P.spill = spill.p; P.spillLanes = (uint32_t) (spill.n / SPILL_DEPTH);
             ev.record(0);
             if (scene->wide) hipLaunchKernelGGL(k_raycast_w, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);
+#if PHIP_EXPERIMENTS
             else hipLaunchKernelGGL(k_raycast, dim3((unsigned) ((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), traversalLdsBytes(sd.dev), 0, sd.dev, (const phip_ray *) dr.p, m, dh.p, dz.p, P);
+#else
+            else throw std::runtime_error("internal error: no ray kernel for this scene (the wide tree is missing)");
+#endif
             ev.record(0);
             HIP_TRY(hipMemsetAsync(sd.counters.p, 0, sizeof(Counters), 0));
             hipLaunchKernelGGL(k_reduce_stats, dim3(ST_COUNT, REDUCE_SPLIT), dim3(256), 0, 0, P, sd.counters.p, 0);
@@ -2060,7 +2080,7 @@ int phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out) {
     out->n_nodes = scene->bvh.nNodes; out->n_leaves = scene->bvh.nLeaves; out->n_triangle_refs = scene->bvh.nTriRefs;
     out->max_depth = scene->bvh.maxDepth; out->node_bytes = 128; out->triangle_bytes = 48;
     out->sah_cost = scene->bvh.sahCost; out->build_ms = scene->bvh.buildMs;
-    if (scene->wide) { out->n_nodes = scene->bvh.nWNodes; out->max_depth = scene->bvh.wMaxDepth; out->node_bytes = 80; out->sah_cost = scene->bvh.wSahCost; }
+    if (scene->wideOnly) { out->n_nodes = scene->bvh.nWNodes; out->max_depth = scene->bvh.wMaxDepth; out->node_bytes = 80; out->sah_cost = scene->bvh.wSahCost; }
     out->fits_lds = scene->fitsLds ? 1u : 0u; out->fused_traversal = scene->fitsLds ? scene->devs[0]->dev.flatMode : (uint32_t) scene->fusedWide;
     return PHIP_OK;
 }

@@ -29,8 +29,12 @@ template <bool QMC> static MegaKernel megaKernelOf(int materialMask, bool strict
     }
     if (flat == 3) return MEGA_BALANCE ? (strictNormals ? k_mega<0, true, 3, QMC> : k_mega<0, false, 3, QMC>) : nullptr;
     if (flat == 2) return strictNormals ? k_mega<0, true, 2, QMC> : k_mega<0, false, 2, QMC>;
+#if PHIP_EXPERIMENTS      /* the BVH4 walk and the per-lane leaf table in LDS (rounds 2-3): since round 6 every scene past the packed leaf table's 64 records is on the 8-wide tree (FLAT 4 / 5) */
     if (flat) return strictNormals ? k_mega<0, true, 1, QMC> : k_mega<0, false, 1, QMC>;
     return strictNormals ? k_mega<0, true, 0, QMC> : k_mega<0, false, 0, QMC>;
+#else
+    return nullptr;
+#endif
 }
 #define MEGA_ENTRY(name) name
 #else

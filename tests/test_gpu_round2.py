@@ -21,7 +21,7 @@ def gpu(phip):
     return integrator
 
 
-def test_fused_kernel_is_chosen_for_lds_resident_scenes_only(gpu, gauss):
+def test_fused_kernel_is_chosen_for_lds_resident_scenes_and_trees_that_live_in_l2(gpu, gauss):
     cb = gpu.Scene(S.cornell_box(64, 64, gauss).desc())
     assert cb.accel_info().fits_lds == 1
     integ = gpu.PathHIP(maxDepth=5)
@@ -37,9 +37,12 @@ def test_fused_kernel_is_chosen_for_lds_resident_scenes_only(gpu, gauss):
         P, T, N = S.sphere_mesh((200, 300, 200), 45.0, nu, nv)
         sb.mesh(P, T, sb.dielectric(1.33, 1.0), normals=N)
         glass = gpu.Scene(sb.desc())
-        # round 5: dielectric / microfacet models ride the fused kernel on the packed leaf table (<= 64 Wald records); beyond it they keep the wavefront kernels
-        assert glass.accel_info().fits_lds == fits, (len(T), glass.accel_info().as_dict())
-        assert integ.render(glass, gpu.HDRFilm(64, 64), 4) and integ.stats.fused == fits
+        # round 5: dielectric / microfacet models ride the fused kernel on the packed leaf table (<= 64 Wald records); round 6: beyond it the scene gets the compressed
+        # 8-wide tree and the fused kernel walks that from memory (fused_traversal 4) -- the wavefront kernels only with PHIP_FLAG_NO_FUSED, where they are k_shade + k_rays_w
+        ai = glass.accel_info()
+        assert ai.fits_lds == fits and (fits or (ai.fused_traversal == 4 and ai.node_bytes == 80)), (len(T), ai.as_dict())
+        assert integ.render(glass, gpu.HDRFilm(64, 64), 4) and integ.stats.fused == 1
+        assert integ.render(glass, gpu.HDRFilm(64, 64), 4, flags=A.PHIP_FLAG_NO_FUSED) and integ.stats.fused == 0 and integ.stats.iterations > 1
         glass.close()
     big = gpu.Scene(S.atrium(64, 36, gauss).desc())
     assert big.accel_info().fits_lds == 0
@@ -125,6 +128,58 @@ def test_multi_device_render_equals_the_single_device_frame(gpu, phip, gauss, sc
         integ.render(gs, gpu.HDRFilm(w, h), spp, devices=[0, 0])            # listed twice without the alias flag
     with pytest.raises(Exception):
         integ.render(gs, gpu.HDRFilm(w, h), spp, devices=[0, 99], flags=A.PHIP_FLAG_ALIAS_DEVICES)
+
+
+def test_eight_device_aliases_progress_reduce_and_cancel(gpu, phip, gauss):
+    """the in-library multi-device path as an eight-GPU node drives it -- eight host threads, eight streams, eight private films merged on
+    devices[0] -- on the one GPU of this box listed eight times (PHIP_FLAG_ALIAS_DEVICES): the merged frame is the single-device frame, reduce_ms is reported, the
+    progress callback is entered by all eight device threads (one at a time) and never reports more than the job holds, and a cancel request in the middle of the
+    frame ends all eight renders (renderproc.cpp:142-154: the process returns, the frame is not delivered) and leaves the scene usable."""
+    import threading
+    w, h, spp = 256, 160, 8
+    gs = gpu.Scene(S.cornell_spheres(w, h, gauss).desc())              # the fused kernel on the wide tree, eight ways
+    integ = gpu.PathHIP(maxDepth=6)
+    one = gpu.HDRFilm(w, h)
+    assert integ.render(gs, one, spp)
+    samples = integ.stats.samples
+    devs = [0] * 8
+    seen = {}
+    lock = threading.Lock(); inside = [0]; overlap = [0]
+
+    def progress(user, device, done, total):
+        with lock:
+            inside[0] += 1
+            overlap[0] = max(overlap[0], inside[0])
+        seen.setdefault(threading.get_ident(), []).append((device, done, total))
+        with lock:
+            inside[0] -= 1
+
+    multi = gpu.HDRFilm(w, h)
+    assert integ.render(gs, multi, spp, flags=A.PHIP_FLAG_ALIAS_DEVICES, devices=devs, progress=progress)
+    st = integ.stats
+    assert st.n_devices == 8 and st.samples == samples and st.reduce_ms > 0
+    assert rel_l2(multi.storage, one.storage) < 2e-6
+    assert np.abs(multi.storage[..., 4] - one.storage[..., 4]).max() < 1e-4
+    assert len(seen) == 8, len(seen)                                   # every device thread reported
+    assert overlap[0] == 1                                             # ... one at a time (phip_scene::progressLock)
+    for calls in seen.values():
+        assert all(0 <= d <= t for _, d, t in calls) and calls[-1][1] == calls[-1][2]      # a device's last report is its whole share
+    assert sum(calls[-1][2] for calls in seen.values()) == samples
+    # cancel in the middle of a long frame: all eight threads stop, the call reports the cancellation, the next render is whole again
+    big = gpu.Scene(S.cornell_spheres(1024, 1024, gauss).desc())
+    integ2 = gpu.PathHIP(maxDepth=-1)
+    film = gpu.HDRFilm(1024, 1024)
+    assert integ2.render(big, film, 1, flags=A.PHIP_FLAG_ALIAS_DEVICES, devices=devs)
+    integ2._scene = big
+    t = threading.Timer(0.1, integ2.cancel); t.start()
+    ok = integ2.render(big, film, 1024, flags=A.PHIP_FLAG_ALIAS_DEVICES, devices=devs)     # ~1 G samples, eight shards one after another on one GPU: ~0.5 s
+    t.join()
+    assert ok is False
+    again = gpu.HDRFilm(1024, 1024); ref = gpu.HDRFilm(1024, 1024)
+    assert integ2.render(big, again, 2, flags=A.PHIP_FLAG_ALIAS_DEVICES, devices=devs) is True
+    assert integ2.render(big, ref, 2) is True
+    assert rel_l2(again.storage, ref.storage) < 2e-6
+    big.close(); gs.close()
 
 
 def test_scene_replicate(gpu, phip, gauss):

@@ -11,6 +11,8 @@ cfgs = {"cornell": ("cornell_box", 1024, 1024, 64, -1), "atrium": ("atrium", 192
         "cmixed": ("cornell_mixed", 1024, 1024, 64, -1),                       # the Cornell box with a copper and a glass block (wavefront kernels)
         "c42": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 1}),       # 42 / 62 Wald records: the two-word record masks of the fused kernel
         "c62": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 3}),
+        "c82": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 5}),       # 82 records: past the packed leaf table -- the 8-wide tree (round 6; before: k_mega's BVH4 walk in LDS)
+        "c92": ("cornell_box", 1024, 1024, 64, -1, {"extra_blocks": 6}),
         # the mid-sized scenes: the Cornell box with a glass and a copper sphere (or two diffuse ones) of 1 k / 4.5 k / 18 k triangles: a tree that lives in L2
         "cglass": ("cornell_box", 1024, 1024, 64, -1, {"tall_bsdf": lambda b: b.dielectric()}),            # the box with a glass block only / a copper block only
         "ccopper": ("cornell_box", 1024, 1024, 64, -1, {"short_bsdf": lambda b: b.twosided(b.roughconductor(S.CU_ETA, S.CU_K, alpha=0.1))}),
