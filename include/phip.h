@@ -314,7 +314,7 @@ typedef struct phip_render_params {
 #define PHIP_FLAG_NO_MEGA 64        /* not k_mega, but k_shade_trace where the scene admits it (a small scene with glass / copper runs k_mega since round 5: how the tests still reach
                                        k_shade_trace on it; the kernel's own clients are small scenes with textures or an environment emitter) */
 #define PHIP_FLAG_FUSED_ANY 128     /* the fused kernel on EVERY scene it admits (round 6: k_mega walks the 8-wide tree from memory, phip_accel_info.fused_traversal 4 / 5) -- by default
-                                       only trees of at most PHIP_FUSED_WIDE_MAX_NODES wide nodes run it, the wavefront kernels are faster beyond (DESIGN.md 3.3); parity tests and A/B */
+                                       only trees of at most PHIP_FUSED_WIDE_MAX_NODES wide nodes run it, the wavefront kernels are faster beyond (DESIGN.md 3.9); parity tests and A/B */
 #define PHIP_FUSED_WIDE_MAX_NODES 4096
 
 typedef struct phip_stats {

@@ -79,7 +79,7 @@ PM_FN float pm_frexpf(float x, int *e) {
 /* ======================================================================================
  *  MEASUREMENT ONLY (round 6, VERDICT r5 item 5: what does exactness cost?): the device's own transcendentals -- v_exp_f32 / v_log_f32 / v_sin_f32 / v_cos_f32 behind
  *  the __expf / __logf / __sinf / __cosf intrinsics (~1-2 ulp on a reduced range), ocml's acosf / atanf / atan2f / tanf -- instead of the correctly rounded double-
- *  precision evaluations below.  Built by tools/build_variant.sh with -DPHIP_FMATH_NATIVE (DESIGN.md 3.9); never in the product: results are no longer the oracle's bits.
+ *  precision evaluations below.  Built by tools/build_variant.sh with -DPHIP_FMATH_NATIVE (DESIGN.md 3.10); never in the product: results are no longer the oracle's bits.
  * ====================================================================================== */
 PM_FN void pm_sincosf(float xx, float *s, float *c) { *s = __sinf(xx); *c = __cosf(xx); }
 PM_FN float pm_expf(float x) { return __expf(x); }

@@ -314,7 +314,7 @@ __device__ __forceinline__ void traceWidePool(const DevScene &S, const WidePool 
         /* ---- push: the inner children hit.  The NEAREST child of every lane goes to the top segment of the stack, its other children (far to near) and a triangle group the
                 queue had no room for below the top segments of all lanes: the next iteration then pops nearest children of MANY rays rather than all children of a few --
                 depth first, front to back per ray, which is what lets a hit found in the near child reject the far ones (WP_NEAR_FIRST: node visits per closest ray of the
-                atrium 11.3 -> see DESIGN.md 3.4; the per-lane walk makes 10.0) ---- */
+                atrium 11.3 -> 10.9, of the glass room 10.9 -> 10.4; the per-lane walk makes 10.0) ---- */
         const uint32_t nInner = (uint32_t) __popc(inner);
         const bool hasTop = WP_NEAR_FIRST && nInner != 0u;
         const uint32_t k = nInner - (hasTop ? 1u : 0u) + (keep ? 1u : 0u);

@@ -1124,7 +1124,7 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     /* which device path: the fused kernel when the scene fits its LDS plan (decided at scene creation) */
     const bool rinv = p->sampler == PHIP_SAMPLER_HALTON || p->sampler == PHIP_SAMPLER_HAMMERSLEY;
     const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED || rinv;     /* served by the wavefront kernels compiled with FEAT bit 3 */
-    /* (the fused kernel on the 8-wide tree: by default where it is faster than the wavefront kernels -- trees that live in L2, DESIGN.md 3.3 -- with PHIP_FLAG_FUSED_ANY wherever it can run) */
+    /* (the fused kernel on the 8-wide tree: by default where it is faster than the wavefront kernels -- trees that live in L2, DESIGN.md 3.9 -- with PHIP_FLAG_FUSED_ANY wherever it can run) */
     const bool wideFused = sc->fusedWide && (sc->bvh.nWNodes <= PHIP_FUSED_WIDE_MAX_NODES || (p->flags & PHIP_FLAG_FUSED_ANY));
     bool fused = !direct && (sc->fitsLds || wideFused) && sc->traversal == 2 && !(p->flags & (PHIP_FLAG_NO_FUSED | PHIP_FLAG_NO_MEGA));
     const int megaFlat = sc->fitsLds ? (D.nFlatLeaves ? (int) D.flatMode : 0) : sc->fusedWide;      /* k_mega's traversal form (k_mega.h) */

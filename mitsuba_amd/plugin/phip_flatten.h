@@ -142,6 +142,12 @@ inline PhipBitmapInfo phipBitmap(const Texture *t) {
     PhipBitmapInfo i = { b->getMIPMap3(), b->getWrapModeU(), b->getWrapModeV(), b->getMaxAnisotropy(), b->getUVScale(), b->getUVOffset() };
     return i;
 }
+/* (the accessor patch goes through virtual functions of the plugins' own classes: nothing to probe) */
+inline void phipLayoutProbeDiffuse(const BSDF *) { }
+inline void phipLayoutProbeTwoSided(const BSDF *) { }
+inline void phipLayoutProbeRoughConductor(const BSDF *) { }
+inline void phipLayoutProbeDielectric(const BSDF *) { }
+inline void phipLayoutProbeBitmap(const Texture *) { }
 #else
 inline const BSDF *phipNested(const BSDF *b, int i) { return static_cast<const TwoSidedBRDF *>(b)->m_nestedBRDF[i].get(); }
 inline const Texture *phipReflectanceTexture(const BSDF *b) { return static_cast<const SmoothDiffuse *>(b)->m_reflectance.get(); }
@@ -155,6 +161,56 @@ inline PhipBitmapInfo phipBitmap(const Texture *t) {
     const BitmapTexture *b = static_cast<const BitmapTexture *>(t);
     PhipBitmapInfo i = { b->m_mipmap3.get(), b->m_wrapModeU, b->m_wrapModeV, b->m_maxAnisotropy, b->m_uvScale, b->m_uvOffset };
     return i;
+}
+/* -DPHIP_REFERENCE_SOURCES reads members of objects that live in OTHER shared objects (diffuse.so, twosided.so, ...) through the class definitions compiled into this
+   one: the same source files, but nothing in the language checks that both were compiled to the same layout (an ODR / layout hazard with no guard).
+   Two guards (round 6):
+     (a) compile time -- the members the shim reads lie where the reference's sources, as included here, put them: a change of those sources that moves them fails the build
+         of the shim instead of reading garbage (sizes in terms of the public base classes, so that a different Float / Spectrum configuration fails too);
+     (b) run time, per object and before anything is read out of it -- every value the shim is about to take through a private member is ALSO reachable through a public
+         virtual of the base class (BSDF::getDiffuseReflectance / getRoughness, Texture::getResolution / getMaximum, Object::getClass of a nested object): the two ways must
+         agree on a probe intersection, or the plugin that owns the object was built with another layout than this shim and the render is refused (phipLayoutProbe*). */
+static_assert(sizeof(TwoSidedBRDF) == sizeof(BSDF) + 2 * sizeof(ref<BSDF>), "twosided.cpp: TwoSidedBRDF is BSDF + m_nestedBRDF[2]");
+static_assert(sizeof(SmoothDiffuse) == sizeof(BSDF) + sizeof(ref<Texture>), "diffuse.cpp: SmoothDiffuse is BSDF + m_reflectance");
+static_assert(sizeof(ref<Texture>) == sizeof(void *) && sizeof(ref<BSDF>) == sizeof(void *), "ref<T> is one pointer");
+inline Intersection phipProbeIntersection() {
+    Intersection its;
+    its.p = Point(0.0f); its.t = 1.0f; its.uv = Point2(0.37f, 0.61f); its.wi = Vector(0, 0, 1);
+    its.geoFrame = its.shFrame = Frame(Normal(0, 0, 1));
+    its.dudx = its.dudy = its.dvdx = its.dvdy = 0; its.hasUVPartials = false; its.time = 0; its.shape = NULL; its.instance = NULL;
+    return its;
+}
+inline bool phipSameSpectrum(const Spectrum &a, const Spectrum &b) { for (int i = 0; i < SPECTRUM_SAMPLES; ++i) if (!(a[i] == b[i])) return false; return true; }
+inline void phipLayoutProbeDiffuse(const BSDF *b) {
+    const Intersection its = phipProbeIntersection();
+    const Texture *t = phipReflectanceTexture(b);
+    if (!t || !t->getClass()->derivesFrom(MTS_CLASS(Texture)) || !phipSameSpectrum(t->eval(its), b->getDiffuseReflectance(its)))
+        SLog(EError, "path_hip: the 'diffuse' plugin that owns this BSDF was not built from the sources this shim was compiled against (SmoothDiffuse::m_reflectance is not where diffuse.cpp puts it)");
+}
+inline void phipLayoutProbeTwoSided(const BSDF *b) {
+    const Intersection its = phipProbeIntersection();          /* wi.z > 0: TwoSidedBRDF::getDiffuseReflectance asks m_nestedBRDF[0] (twosided.cpp:198-203) */
+    const BSDF *n0 = phipNested(b, 0), *n1 = phipNested(b, 1);
+    if (!n0 || !n1 || !n0->getClass()->derivesFrom(MTS_CLASS(BSDF)) || !n1->getClass()->derivesFrom(MTS_CLASS(BSDF))
+        || !phipSameSpectrum(n0->getDiffuseReflectance(its), b->getDiffuseReflectance(its)) || n0->getRoughness(its, 0) != b->getRoughness(its, 0))
+        SLog(EError, "path_hip: the 'twosided' plugin that owns this BSDF was not built from the sources this shim was compiled against (TwoSidedBRDF::m_nestedBRDF is not where twosided.cpp puts it)");
+}
+inline void phipLayoutProbeRoughConductor(const BSDF *b) {
+    const Intersection its = phipProbeIntersection();          /* RoughConductor::getRoughness = 0.5 (alphaU + alphaV) of the textures' averages (roughconductor.cpp:434-437) */
+    const Texture *tu = phipAlphaTexture(b, 0), *tv = phipAlphaTexture(b, 1), *ts = phipSpecularTexture(b, true);
+    if (!tu || !tv || !ts || !tu->getClass()->derivesFrom(MTS_CLASS(Texture)) || !tv->getClass()->derivesFrom(MTS_CLASS(Texture)) || !ts->getClass()->derivesFrom(MTS_CLASS(Texture))
+        || 0.5f * (tu->eval(its).average() + tv->eval(its).average()) != b->getRoughness(its, 0))
+        SLog(EError, "path_hip: the 'roughconductor' plugin that owns this BSDF was not built from the sources this shim was compiled against (m_alphaU / m_alphaV / m_specularReflectance are not where roughconductor.cpp puts them)");
+}
+inline void phipLayoutProbeDielectric(const BSDF *b) {
+    const Texture *tr = phipSpecularTexture(b, false), *tt = phipTransmittanceTexture(b);
+    if (!tr || !tt || !tr->getClass()->derivesFrom(MTS_CLASS(Texture)) || !tt->getClass()->derivesFrom(MTS_CLASS(Texture)))
+        SLog(EError, "path_hip: the 'dielectric' plugin that owns this BSDF was not built from the sources this shim was compiled against (m_specularReflectance / m_specularTransmittance are not where dielectric.cpp puts them)");
+}
+inline void phipLayoutProbeBitmap(const Texture *t) {
+    const PhipBitmapInfo i = phipBitmap(t);                     /* BitmapTexture::getResolution = the MIP pyramid's level-0 size (bitmap.cpp) */
+    const Vector3i res = t->getResolution();
+    if (!i.mip || i.mip->getWidth() != res.x || i.mip->getHeight() != res.y || !(i.maxAnisotropy >= 0))
+        SLog(EError, "path_hip: the 'bitmap' plugin that owns this texture was not built from the sources this shim was compiled against (BitmapTexture::m_mipmap3 is not where bitmap.cpp puts it)");
 }
 #endif
 #endif
@@ -486,6 +542,7 @@ public:
     uint32_t convertBitmap(const Texture *tex) {
         std::map<const Texture *, uint32_t>::iterator it = m_textureIds.find(tex);
         if (it != m_textureIds.end()) return it->second;
+        phipLayoutProbeBitmap(tex);
         const PhipBitmapInfo info = phipBitmap(tex);
         if (!info.mip) SLog(EError, "path_hip: only RGB bitmap textures are supported");
         phip_texture t; memset(&t, 0, sizeof(t));
@@ -526,6 +583,7 @@ public:
         if (cls == "SmoothDiffuse") {
             m.type = PHIP_BSDF_DIFFUSE;
 #if defined(PHIP_HAVE_INTERNALS)
+            phipLayoutProbeDiffuse(bsdf);
             const Texture *tex = phipReflectanceTexture(bsdf);
             if (tex->getClass()->getName() == "BitmapTexture")
                 m.reflectance_texture = 1 + convertBitmap(tex);
@@ -539,6 +597,9 @@ public:
             rgb(bsdf->getDiffuseReflectance(its), m.reflectance);
 #endif
         } else if (cls == "SmoothDielectric") {
+#if defined(PHIP_HAVE_INTERNALS)
+            phipLayoutProbeDielectric(bsdf);
+#endif
             m.type = PHIP_BSDF_DIELECTRIC; m.eta[0] = bsdf->getEta();
             rgb(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.reflectance);
             specularTexture(bsdf, false, m);
@@ -552,6 +613,9 @@ public:
             }
 #endif
         } else if (cls == "RoughConductor") {
+#if defined(PHIP_HAVE_INTERNALS)
+            phipLayoutProbeRoughConductor(bsdf);
+#endif
             m.type = PHIP_BSDF_ROUGHCONDUCTOR;
             /* roughconductor.cpp:176-190: eta / k from data/ior/<material>.{eta,k}.spd unless given explicitly */
             ref<FileResolver> fResolver = Thread::getThread()->getFileResolver();
@@ -607,6 +671,7 @@ public:
         } else if (cls == "TwoSidedBRDF") {
             /* twosided.cpp keeps its children in m_nestedBRDF[2]; they are reachable as named children */
 #if defined(PHIP_HAVE_INTERNALS)
+            phipLayoutProbeTwoSided(bsdf);
             std::vector<const BSDF *> nested = getNestedBSDFs(bsdf);
             uint32_t a = convertBSDF(nested[0], materials, ids), b = nested.size() > 1 ? convertBSDF(nested[1], materials, ids) : a;
             m.type = PHIP_BSDF_TWOSIDED; m.nested[0] = a; m.nested[1] = b;

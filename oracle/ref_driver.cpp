@@ -31,6 +31,8 @@
 #include <mitsuba/render/renderjob.h>
 #include <mitsuba/render/renderqueue.h>
 #include <chrono>
+#include <atomic>
+#include <mutex>
 #include "phip.h"
 #include <execinfo.h>
 #include <signal.h>
@@ -209,6 +211,19 @@ static void segvHandler(int sig) {
     backtrace_symbols_fd(frames, n, 2);
     _exit(139);
 }
+/* the last warning / error the reference logged (a RenderJob that fails -- e.g. a plugin shim that refuses a scene -- reports through the log only) and how the job ended */
+static std::string g_lastWarning;
+static std::mutex g_logLock;
+class CaptureAppender : public Appender {
+public:
+    void append(ELogLevel level, const std::string &text) { if (level >= EWarn) { std::lock_guard<std::mutex> g(g_logLock); g_lastWarning = text; } }
+    void logProgress(Float, const std::string &, const std::string &, const std::string &, const void *) { }
+};
+class JobStatusListener : public RenderListener {
+public:
+    std::atomic<int> cancelled{0};
+    void finishJobEvent(const RenderJob *, bool c) { if (c) cancelled = 1; }
+};
 
 int ref_init(void) {
     if (g_init) return 0;
@@ -227,6 +242,7 @@ int ref_init(void) {
         Thread::getThread()->getLogger()->setLogLevel(EWarn);
         if (!getenv("REF_DRIVER_VERBOSE"))
             Thread::getThread()->getLogger()->clearAppenders();      /* no progress bars; Log(EError) still throws */
+        Thread::getThread()->getLogger()->addAppender(new CaptureAppender());      /* a RenderJob catches what its integrator throws and only LOGS it (renderjob.cpp:96-120): keep the text */
         g_init = true;
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
@@ -549,12 +565,21 @@ int ref_render_job_plugin(void *h, const phip_render_params *p, const char *inte
         scene->getFilm()->clear();
 
         ref<RenderQueue> queue = new RenderQueue();
+        ref<JobStatusListener> status = new JobStatusListener();
+        queue->registerListener(status);
+        { std::lock_guard<std::mutex> g(g_logLock); g_lastWarning.clear(); }
         ref<RenderJob> job = new RenderJob("rend", scene, queue, -1, -1, -1, false, false);
         const auto t0 = std::chrono::steady_clock::now();
         job->start();
         queue->waitLeft(0);
         queue->join();
+        queue->unregisterListener(status);
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (status->cancelled) {          /* the job ended without a frame: its integrator threw (Log(EError)) or returned false */
+            std::lock_guard<std::mutex> g(g_logLock);
+            g_err = "the render job failed: " + (g_lastWarning.empty() ? std::string("(nothing was logged)") : g_lastWarning);
+            return -2;
+        }
         if (out_rgb) {
             const Vector2i size = scene->getFilm()->getCropSize();
             ref<Bitmap> target = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, size);

@@ -6,7 +6,7 @@
 # The summaries are copied into profiles/ (tracked) by hand afterwards: profiles/<prefix>_*.
 tag=${1:-prof}; out=gpurun_out/$tag; mkdir -p $out; root=$(pwd); prefix=${PREFIX:-r03b}
 if [ -z "$NO_PMC" ]; then
-for w in "cornell 256 cornell_1024x1024_256spp" "atrium 64 atrium_1920x1080_64spp_md8" "glass 512 glassroom_1920x1080_512spp_md16" "atrium4k 64 atrium_3840x2160_64spp_md8" "cmixed 256 cornell_mixed_1024x1024_256spp"; do
+for w in "cornell 256 cornell_1024x1024_256spp" "atrium 64 atrium_1920x1080_64spp_md8" "glass 512 glassroom_1920x1080_512spp_md16" "atrium4k 64 atrium_3840x2160_64spp_md8" "cmixed 256 cornell_mixed_1024x1024_256spp" "sph1k 64 cornell_spheres_1k_1024x1024_64spp" "sph1kd 64 cornell_spheres_1k_diffuse_1024x1024_64spp"; do
   set -- $w
   timeout 900 python tools/pmc_traffic.py $1 $out/traffic_$3.json $2 $3 2>&1 | tail -1
   PMC_GROUPS=1 SPP=$2 bash tools/pmc_sq.sh $1 $out/pmc $3
@@ -23,5 +23,5 @@ d = json.load(open('$out/bench.json'))
 print(d['value'], d['ms_per_step'], {k: v['value'] for k, v in d.get('workloads', {}).items()}, d['roofline']['kernel_ms_per_step'], d['roofline']['bound'], d['roofline'].get('fractions'), (d.get('cpu_baseline') or {}).get('value'))
 PY
 (cd /tmp; export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $root/$out/prof -o bench --output-format csv -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $root/$out/prof_bench.json 2> $root/$out/prof.err)
-f=$(find $out/prof -name "*kernel_trace.csv" | head -1); python tools/rocprof_summary.py $f "bench.py --steps 2 --warmup 1 --no-cpu-baseline (C2 + C3 + C4 + C5 slice + mixed Cornell box + C2 with direct), MI355X" > $out/kernel_stats.md 2>&1; head -16 $out/kernel_stats.md
+f=$(find $out/prof -name "*kernel_trace.csv" | head -1); python tools/rocprof_summary.py $f "bench.py --steps 2 --warmup 1 --no-cpu-baseline (C2 + C3 + C4 + C5 slice + mixed Cornell box + C2 with direct + the two sphere boxes), MI355X" > $out/kernel_stats.md 2>&1; head -16 $out/kernel_stats.md
 rm -rf $out/pmc/*_agent_info.csv $out/pmc/*kernel_trace.csv $out/prof gpurun_out/pmc_traffic
