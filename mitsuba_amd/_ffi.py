@@ -40,7 +40,7 @@ MEGA_FLAGS = ["-mllvm", "-disable-machine-licm"]
 # longest compiles start when the pool does
 SHADE_FEATS, SHADE_PARTS = (11, 3, 2, 1, 8, 0), (0, 1, 3, 2)
 UNITS = [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f, "-DSHADE_PART=%d" % q], "phip_shade%d_%d.o" % (f, q)) for f in SHADE_FEATS for q in SHADE_PARTS] + \
-        [("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=0"], "phip_mega.o"), ("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=1"], "phip_megaw.o"), ("phip.hip", [], "phip.o")]
+        [("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=0"], "phip_mega.o"), ("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=1"], "phip_megaw.o"), ("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=2"], "phip_megad.o"), ("phip.hip", [], "phip.o")]
 
 
 def source_id():

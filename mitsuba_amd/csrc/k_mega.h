@@ -93,14 +93,16 @@ enum { MC_SAMPLES = 0, MC_VERTICES, MC_RAYS, MC_NODE, MC_TRI, MC_SH_RAYS, MC_SH_
 
 template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (traverseFlat), 2: packed table + record masks (traverseFlat2), 3: the same with 33..64 records (two-word masks; MEGA_BALANCE only);
                                            round 6 -- 4: the compressed 8-wide tree in L2 / HBM (k_wide_wave.h: traceWideW), emitter table and materials in LDS, 5: the same with the materials in memory */,
-          bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
+          bool QMC /* the reference's sobol / halton / hammersley / stratified streams (FEAT bit 3 of shadeVertex) */,
+          bool DIRECT = false /* round 6: MIDirectIntegrator::Li (k_shade_direct.h: directVertex) instead of the path tracer's vertex -- a lane owns a CAMERA SAMPLE through its
+                                 emitter and BSDF sampling rounds; the loop, the traversals and the camera-sample queue are the same */> __global__ __launch_bounds__(BLOCK, MEGA_WAVES) void k_mega(DevScene S, MegaParams M, RenderConst rc, float4 *L) {
     constexpr bool WIDE = FLAT >= 4;                            /* the tree, its Wald records and the shading records stay in memory: a lane still owns its path from the camera sample to its last vertex */
     /* (the QMC build's static LDS leaves no room for the R-box at four blocks per CU; nor does the LDS of the tree-in-memory builds: there the mailboxes' 10 KB cost the fourth
        block, and the class deal at four blocks measures 3 % faster than the mailboxes at three -- profiles/r06_gpu_call_i_*) */
-    constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && !WIDE && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;
+    constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && !WIDE && !DIRECT && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;
     /* (WIDE: neither -- the deal's five block barriers per pass cost more than the divergence they remove once a pass is dominated by a traversal whose length differs from
        wave to wave: glass + copper spheres 1554 -> 1803, glass room 510 -> 602, atrium 444 -> 457 Msamples/s without it, profiles/r06_gpu_call_n_*) */
-    constexpr bool DEAL = MM != 0 && FLAT >= 2 && !WIDE && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;
+    constexpr bool DEAL = MM != 0 && FLAT >= 2 && !WIDE && !DIRECT && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;      /* (`direct`: the camera vertex's rounds carry the camera hit along -- no exchange) */
     __shared__ uint32_t ldsClsCnt[4][BLOCK / 64];                 /* MEGA_CLASS_DEAL: lanes per BSDF model and wave */
     __shared__ uint32_t mbR[MAILBOX ? MB_DW * MB_NR : 1u];        /* MEGA_MAILBOX: the R-box, [MB_DW][MB_NR]; the S-box lies in the dynamic LDS behind the traversals' work lists (phip.hip sizes the region) */
     __shared__ uint32_t mbState[MAILBOX ? MB_NS + MB_NR : 1u];   /* entry states, S-box then R-box: 0 empty, 2 full, 3 being read (R-box: three consumers claim by compare-and-swap) */
@@ -193,6 +195,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     PathVertex v; v.id = v.pixel = v.k = v.state = 0;
     v.hit = v.rayO = v.rayD = v.thr = make_float4(0, 0, 0, 0); v.mis = make_float2(0, 0);
     float4 accum = make_float4(0, 0, 0, 0);
+    float4 camHit = make_float4(0, 0, 0, 0);                    /* DIRECT: the camera ray's hit record, kept through the sample's rounds (the wavefront path's PathPool::camHit) */
     if (!WCNT) {
 #pragma unroll
         for (int i = 0; i < MC_COUNT; ++i) ldsCount[WCNT ? 0 : i][WCNT ? 0 : threadIdx.x] = 0;
@@ -441,7 +444,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             float mint, maxt;
             TravResult r;
             V3 rcp;
-            const bool trace = alive && !(MAILBOX && haveHit);
+            const bool trace = alive && !(MAILBOX && haveHit) && !(DIRECT && (v.state & F_NOTRACE));      /* (DIRECT: a round without a BSDF sample has no closest-hit query) */
             const bool go = trace & clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp);
             /* JOINT: ... and the shadow ray of the vertex this lane shaded in the previous pass (its own path's, or that of the path that ended there) */
             const V3 so(cSh.e0.x, cSh.e0.y, cSh.e0.z), sd(cSh.e1.x, cSh.e1.y, cSh.e1.z);
@@ -474,7 +477,7 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             TravResult r;
             uint32_t nNode = 0, nTri = 0;
             V3 rcp;
-            const bool trace = alive && !(MAILBOX && haveHit);
+            const bool trace = alive && !(MAILBOX && haveHit) && !(DIRECT && (v.state & F_NOTRACE));
             const bool go = trace & clipToSceneSel<false>(S, o, d, v.rayO.w, v.rayD.w, mint, maxt, rcp);
             traverseFlat2W<false, FLAT == 3>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
             if (trace) {
@@ -602,7 +605,8 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 #else
             const LRegister acc{ accum, nullptr };
 #endif
-            ended = shadeVertex<MM, STRICT, QMC ? 8 : 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
+            if (DIRECT) ended = directVertex<MM, QMC ? 8 : 0>(S, tab.T, tab.materials, rc, v, camHit, acc, newRay, pushShadow, sh, nv);
+            else ended = shadeVertex<MM, STRICT, QMC ? 8 : 0>(S, tab.T, tab.materials, rc, v, acc, newRay, pushShadow, sh, nv);
             if (ended) { if (WCNT) atomicAdd(&wc[WC_VERTICES], (unsigned long long) nv); else MEGA_COUNT(MC_VERTICES, nv); }
         }
 

@@ -12,35 +12,22 @@
  * Per slot it keeps: camHit (the camera ray's hit record; its direction is recomputed from the sample's counter stream),
  * thr = (bsdfVal, bsdfPdf) of the BSDF sample in flight, F_PREV_DELTA, F_SCATTERED (= a BSDF ray is in flight).
  */
-template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade_direct(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+/* One round of MIDirectIntegrator::Li on the register image of a camera sample -- the statement both device paths compile (round 6): the wavefront kernel
+   k_shade_direct below (state streamed through the pool, radiance accumulated in L[id]) and the fused kernel (k_mega<.., DIRECT>: a lane owns the camera sample, state and
+   accumulator live in registers), so that both produce the same bits.
+     in:   v.hit / v.rayD = the record and direction of the ray that was traced since the last round (the camera ray in the first round, BSDF sample i - 1 afterwards),
+           v.thr = (bsdfVal, bsdfPdf) of that BSDF sample, v.state = (round + 1) | flags, camHit = the camera ray's hit record (written in the first round);
+     out:  returns true when the sample is complete (vertices = 1); newRay: v.rayO / v.rayD / v.thr hold the next BSDF sample's ray (the caller clips / stores it);
+           pushShadow + sh: the round's emitter sample; v.state is updated when the sample goes on (F_NOTRACE: no closest-hit query this round). */
+template <int MM, int FEAT, typename LAcc>
+__device__ __forceinline__ bool directVertex(const DevScene &S, const EmitterTab &T, const DevMaterial *materials, const RenderConst &rc,
+                                             PathVertex &v, float4 &camHit, const LAcc &acc, bool &newRay, bool &pushShadow, ShadowEntry &sh, uint32_t &vertices) {
     constexpr bool ENV = (FEAT & 1) != 0, TEX = (FEAT & 2) != 0, QMC = (FEAT & 8) != 0;
-    __shared__ uint32_t waveCnt[BLOCK / 64];
-    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
-    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
-    if (rc.draining && P.blockDead[blockIdx.x]) return;         /* (block-uniform; see k_shade) */
-    /* slot state and the LDS tables in ONE round trip (see k_shade) */
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    const bool inRange = slot < P.capacity;
-    const uint32_t lslot = inRange ? slot : 0u;
-    uint4 info = P.info[lslot];
-    info.w = P.state[lslot];
-    float4 hit = P.hit[lslot];
-    const float4 rd = P.rayD[lslot];
-    const float4 thr4 = P.thr[lslot];
-    float4 camHit = P.camHit[lslot];
-    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
-    const EmitterTab &T = tab.T;
-    const DevMaterial *materials = tab.materials;
-    hit.w = pm_from_bits(hitPrim(pm_to_bits(hit.w)));           /* (class bits of k_rays_w: k_pool.h) */
-    if (!inRange) info = make_uint4(0, 0, 0, 0);
-    __syncthreads();                                            /* LDS tables are complete */
-    const bool alive = inRange && (info.w & F_ALIVE);
-    bool needNew = inRange && !alive && !(info.w & F_DEAD);
-    unsigned long long vertices = 0, done = 0;
-    bool pushShadow = false;
+    const float4 hit = v.hit, rd = v.rayD, thr4 = v.thr;
+    const uint4 info = make_uint4(v.id, v.pixel, v.k, v.state);
+    newRay = false; pushShadow = false;
     float4 sh0 = make_float4(0, 0, 0, 0), sh1 = sh0, sh2 = sh0;
-
-    if (alive) {
+    {
         const int round = (int) (info.w & DEPTH_MASK) - 1;
         uint32_t flags = info.w & ~DEPTH_MASK;
         const uint32_t id = info.x;
@@ -84,7 +71,6 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
             Isect its;
             fillIntersection(S, camD, prim, camHit.y, camHit.z, camHit.x, its);
             if (first) {
-                P.camHit[slot] = camHit;
                 l.w = 1.0f;                                      /* alpha, records.inl:117-144 */
                 haveAdd = true;
                 if (its.emitter >= 0 && !rc.hideEmitters) {       /* direct.cpp:168-169 */
@@ -141,7 +127,7 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                     if (have) {
                         const float weight = miWeight(thr4.w * rc.fracBSDF, lumPdf * rc.fracLum) * rc.weightBSDF;
                         const V3 c = value * V3(thr4.x, thr4.y, thr4.z) * weight;
-                        l = L[id];
+                        l = acc.load(id);
                         l.x += c.x; l.y += c.y; l.z += c.z;
                         haveAdd = true;
                     }
@@ -177,11 +163,9 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                         const V3 wo = its.sh.toWorld(bs.wo);
                         const float woDotGeoN = dot(its.geoN, wo);
                         if (!(rc.strictNormals && woDotGeoN * cosTheta(bs.wo) <= 0)) {
-                            float4 ro = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON), rdn = make_float4(wo.x, wo.y, wo.z, INFINITY);
-                            if (S.preclip) preclipRay(S, ro, rdn);
-                            P.rayO[slot] = ro;
-                            P.rayD[slot] = rdn;
-                            P.thr[slot] = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bs.pdf);
+                            v.rayO = make_float4(its.p.x, its.p.y, its.p.z, PT_EPSILON); v.rayD = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                            v.thr = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bs.pdf);
+                            newRay = true;
                             flags = bs.delta ? (flags | F_PREV_DELTA) : (flags & ~F_PREV_DELTA);
                             issued = true;
                         }
@@ -197,14 +181,60 @@ template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) voi
                 sh2 = make_float4(shC.x, shC.y, shC.z, pm_from_bits(id));
             }
         }
-        if (haveAdd) L[id] = l;
-        if (terminate) {
-            vertices = 1; done = 1;
+        if (haveAdd) acc.store(id, l);
+        sh.e0 = sh0; sh.e1 = sh1; sh.e2 = sh2;
+        if (terminate) { vertices = 1; return true; }
+        v.state = flags | (uint32_t) (round + 2);
+        return false;
+    }
+}
+
+template <int MM, int FEAT> __global__ __launch_bounds__(BLOCK, SHADE_WAVES) void k_shade_direct(DevScene S, PathPool P, RenderConst rc, float4 *L) {
+    constexpr bool QMC = (FEAT & 8) != 0;
+    __shared__ uint32_t waveCnt[BLOCK / 64];
+    __shared__ __align__(16) float ldsEm[EMITTER_LDS_FLOATS];
+    __shared__ DevMaterial ldsMat[MATERIAL_LDS_MAX];
+    if (rc.draining && P.blockDead[blockIdx.x]) return;         /* (block-uniform; see k_shade) */
+    /* slot state and the LDS tables in ONE round trip (see k_shade) */
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const bool inRange = slot < P.capacity;
+    const uint32_t lslot = inRange ? slot : 0u;
+    uint4 info = P.info[lslot];
+    info.w = P.state[lslot];
+    PathVertex v;
+    v.hit = P.hit[lslot];
+    v.rayD = P.rayD[lslot];
+    v.thr = P.thr[lslot];
+    float4 camHit = P.camHit[lslot];
+    const ShadeTables tab = stageShadeTables(S, ldsEm, ldsMat);
+    v.hit.w = pm_from_bits(hitPrim(pm_to_bits(v.hit.w)));       /* (class bits of k_rays_w: k_pool.h) */
+    if (!inRange) info = make_uint4(0, 0, 0, 0);
+    __syncthreads();                                            /* LDS tables are complete */
+    const bool alive = inRange && (info.w & F_ALIVE);
+    bool needNew = inRange && !alive && !(info.w & F_DEAD);
+    unsigned long long vertices = 0, done = 0;
+    bool pushShadow = false, newRay = false;
+    ShadowEntry sh; sh.e0 = sh.e1 = sh.e2 = make_float4(0, 0, 0, 0);
+
+    if (alive) {
+        v.id = info.x; v.pixel = info.y; v.k = info.z; v.state = info.w;
+        v.rayO = make_float4(0, 0, 0, 0); v.mis = make_float2(0, 0);
+        const bool first = (info.w & F_FIRST) != 0;
+        uint32_t nv = 0;
+        const LGlobal acc{ L, P, slot };
+        if (directVertex<MM, FEAT>(S, tab.T, tab.materials, rc, v, camHit, acc, newRay, pushShadow, sh, nv)) {
+            vertices = nv; done = 1;
             needNew = true;
         } else {
-            info.w = flags | (uint32_t) (round + 2);
+            info.w = v.state;
             P.state[slot] = info.w;
         }
+        if (first && pm_to_bits(camHit.w) != PHIP_NO_HIT) P.camHit[slot] = camHit;
+        if (newRay) {
+            float4 ro = v.rayO, rdn = v.rayD;
+            if (S.preclip) preclipRay(S, ro, rdn);
+            P.rayO[slot] = ro; P.rayD[slot] = rdn; P.thr[slot] = v.thr;
+        }
     }
-    shadeEpilogue<QMC>(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh0, sh1, sh2, vertices, done);
+    shadeEpilogue<QMC>(S, P, rc, waveCnt, slot, inRange, info, alive, needNew, pushShadow, sh.e0, sh.e1, sh.e2, vertices, done);
 }

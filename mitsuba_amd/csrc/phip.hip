@@ -1126,8 +1126,9 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
     const bool qmc = p->sampler == PHIP_SAMPLER_SOBOL || p->sampler == PHIP_SAMPLER_STRATIFIED || rinv;     /* served by the wavefront kernels compiled with FEAT bit 3 */
     /* (the fused kernel on the 8-wide tree: by default where it is faster than the wavefront kernels -- trees that live in L2, DESIGN.md 3.9 -- with PHIP_FLAG_FUSED_ANY wherever it can run) */
     const bool wideFused = sc->fusedWide && (sc->bvh.nWNodes <= PHIP_FUSED_WIDE_MAX_NODES || (p->flags & PHIP_FLAG_FUSED_ANY));
-    bool fused = !direct && (sc->fitsLds || wideFused) && sc->traversal == 2 && !(p->flags & (PHIP_FLAG_NO_FUSED | PHIP_FLAG_NO_MEGA));
+    bool fused = (sc->fitsLds || wideFused) && sc->traversal == 2 && !(p->flags & (PHIP_FLAG_NO_FUSED | PHIP_FLAG_NO_MEGA));
     const int megaFlat = sc->fitsLds ? (D.nFlatLeaves ? (int) D.flatMode : 0) : sc->fusedWide;      /* k_mega's traversal form (k_mega.h) */
+    if (direct && megaFlat < 2) fused = false;      /* (round 6: `direct` rides the fused kernel too -- k_mega<.., DIRECT>, on the packed leaf tables and on the tree in memory) */
     const bool megaWide = megaFlat >= 4;
     if (qmc && p->sampler == PHIP_SAMPLER_SOBOL) {
         /* the plugin's tables, uploaded once per (pointer, size): ~210 KB of direction numbers + the two 52-word enumeration rows */
@@ -1190,10 +1191,12 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             const bool mailbox = false;     /* (the tree-in-memory builds deal their paths by BSDF model; the mailboxes' LDS would cost the fourth block of a CU: k_mega.h) */
             megaLds = MEGA_POOL ? megaWidePoolLdsBytesOf(D, megaNodeCache, mailbox, megaFlat == 4, MB_DW * MB_NS * sizeof(uint32_t))
                                 : megaWideLdsBytesOf(D, megaNodeCache, mailbox, megaFlat == 4, MB_DW * MB_NS * sizeof(uint32_t));
-            megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCUWide(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaLds));
+            megaPerCU = std::min(MEGA_WAVES, direct ? phipMegaBlocksPerCUDirect(sc->materialMask, false, megaFlat, qmc, megaLds)
+                                                    : phipMegaBlocksPerCUWide(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaLds));
         } else {
             megaLds = megaLdsBytesOf(D);
-            megaPerCU = std::min(MEGA_WAVES, phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaLds));
+            megaPerCU = std::min(MEGA_WAVES, direct ? phipMegaBlocksPerCUDirect(sc->materialMask, false, megaFlat, qmc, megaLds)
+                                                    : phipMegaBlocksPerCU(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaLds));
         }
         if (const char *e = expEnv("PHIP_MEGA_BLOCKS")) megaPerCU = std::max(1, std::min(megaPerCU, atoi(e)));
         if (megaPerCU <= 0) fused = false;
@@ -1417,7 +1420,8 @@ static int renderOnDevice(phip_scene *sc, SceneDev &sd, const phip_render_params
             HIP_TRY(hipMemsetAsync(sd.stat.p, 0, (size_t) ST_COUNT * M.nWaves * sizeof(unsigned long long), stream));
             if (rc.totalIds) {
                 if (timing) evFused.record(stream);
-                if (megaWide) phipLaunchMegaWide(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaGrid, megaLds, stream, D, M, rc, sd.L.p);
+                if (direct) phipLaunchMegaDirect(sc->materialMask, false, megaFlat, qmc, megaGrid, megaLds, stream, D, M, rc, sd.L.p);
+                else if (megaWide) phipLaunchMegaWide(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaGrid, megaLds, stream, D, M, rc, sd.L.p);
                 else phipLaunchMega(sc->materialMask, p->strict_normals != 0, megaFlat, qmc, megaGrid, megaLds, stream, D, M, rc, sd.L.p);
                 if (timing) evFused.record(stream);
                 iter = 1;

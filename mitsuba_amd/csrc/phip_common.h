@@ -55,6 +55,9 @@ PHIP_DECLARE_SHADE(0) PHIP_DECLARE_SHADE(1) PHIP_DECLARE_SHADE(2) PHIP_DECLARE_S
 int  phipMegaBlocksPerCU(int materialMask, bool strictNormals, int flat, bool qmc, size_t ldsBytes);
 void phipLaunchMega(int materialMask, bool strictNormals, int flat, bool qmc, dim3 grid, size_t ldsBytes, hipStream_t stream,
                     const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);
+int  phipMegaBlocksPerCUDirect(int materialMask, bool strictNormals, int flat, bool qmc, size_t ldsBytes);      /* -DMEGA_PART=2: `direct`, flat 2 .. 5 */
+void phipLaunchMegaDirect(int materialMask, bool strictNormals, int flat, bool qmc, dim3 grid, size_t ldsBytes, hipStream_t stream,
+                          const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);
 int  phipMegaBlocksPerCUWide(int materialMask, bool strictNormals, int flat, bool qmc, size_t ldsBytes);
 void phipLaunchMegaWide(int materialMask, bool strictNormals, int flat, bool qmc, dim3 grid, size_t ldsBytes, hipStream_t stream,
                         const DevScene &S, const MegaParams &M, const RenderConst &rc, float4 *L);

@@ -2,12 +2,14 @@
  * phip_mega.hip -- k_mega<materials, strictNormals, traversal form, QMC> (k_mega.h): the fused single-kernel path.  Compiled twice (phip_common.h):
  *   -DMEGA_PART=0  scenes that fit LDS: BVH4 walk / leaf tables (FLAT 0 .. 3)
  *   -DMEGA_PART=1  round 6: scenes whose tree stays in memory -- the compressed 8-wide tree walked from L2 (FLAT 4 / 5: k_wide_wave.h)
+ *   -DMEGA_PART=2  round 6: the `direct` integrator in the same kernel (k_mega<.., DIRECT = true>), packed leaf tables and the tree in memory
  */
 #include "phip_common.h"
 #include "k_traverse.h"
 #include "k_wide_node.h"
 #include "k_wide_wave.h"
 #include "k_shade.h"
+#include "k_shade_direct.h"
 #include "k_mega.h"
 
 #ifndef MEGA_PART
@@ -37,6 +39,19 @@ template <bool QMC> static MegaKernel megaKernelOf(int materialMask, bool strict
 #endif
 }
 #define MEGA_ENTRY(name) name
+#elif MEGA_PART == 2
+/* round 6: `direct` in the fused kernel (k_shade_direct.h: directVertex) -- the packed leaf tables of the LDS-resident scenes and the tree in memory; strictNormals is a run-time
+   switch of that integrator (direct.cpp:177-190) */
+template <bool QMC> static MegaKernel megaKernelOf(int materialMask, bool, int flat) {
+    const bool all = (materialMask & MM_ALL) != 0;
+    switch (flat) {
+        case 2: return all ? k_mega<MM_ALL, false, 2, QMC, true> : k_mega<0, false, 2, QMC, true>;
+        case 3: return all ? k_mega<MM_ALL, false, 3, QMC, true> : k_mega<0, false, 3, QMC, true>;
+        case 4: return all ? k_mega<MM_ALL, false, 4, QMC, true> : k_mega<0, false, 4, QMC, true>;
+        case 5: return all ? k_mega<MM_ALL, false, 5, QMC, true> : k_mega<0, false, 5, QMC, true>;
+        default: return nullptr;
+    }
+}
 #else
 /* the tree in memory: 4 = emitter table and materials in LDS, 5 = the materials stay in memory (the atrium's 252) */
 template <bool QMC> static MegaKernel megaKernelOf(int materialMask, bool strictNormals, int flat) {
@@ -49,6 +64,10 @@ template <bool QMC> static MegaKernel megaKernelOf(int materialMask, bool strict
     return strictNormals ? k_mega<0, true, 5, QMC> : k_mega<0, false, 5, QMC>;
 }
 #define MEGA_ENTRY(name) name##Wide
+#endif
+#if MEGA_PART == 2
+#undef MEGA_ENTRY
+#define MEGA_ENTRY(name) name##Direct
 #endif
 static MegaKernel megaKernel(int materialMask, bool strictNormals, int flat, bool qmc) {
     return qmc ? megaKernelOf<true>(materialMask, strictNormals, flat) : megaKernelOf<false>(materialMask, strictNormals, flat);

@@ -102,8 +102,7 @@ def compare_render(gpu, oracle, desc, spp, min_identical=0.9999, integrator=None
         # ... and the wavefront kernels against the oracle on their own
         assert (wsmp.view(np.uint32) == osmp.view(np.uint32)).all(axis=-1).mean() >= min_identical
     ai = gs.accel_info()
-    from mitsuba_amd.integrator import DirectHIP
-    if not st.fused and ai.fused_traversal >= 4 and not isinstance(integ, DirectHIP) and not (flags_extra & (A.PHIP_FLAG_NO_FUSED | A.PHIP_FLAG_NO_MEGA)):
+    if not st.fused and ai.fused_traversal >= 4 and not (flags_extra & (A.PHIP_FLAG_NO_FUSED | A.PHIP_FLAG_NO_MEGA)):
         # round 6: the scene's tree is past the size where the fused kernel is the default (PHIP_FUSED_WIDE_MAX_NODES), but k_mega can walk it from memory
         # (k_wide_wave.h): the same bits, the same counters
         film3 = HDRFilm(gs.width, gs.height)

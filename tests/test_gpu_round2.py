@@ -31,7 +31,8 @@ def test_fused_kernel_is_chosen_for_lds_resident_scenes_and_trees_that_live_in_l
     assert integ.render(cb, gpu.HDRFilm(64, 64), 4, flags=A.PHIP_FLAG_NO_FUSED)
     assert integ.stats.fused == 0 and integ.stats.iterations > 1
     d = gpu.DirectHIP()
-    assert d.render(cb, gpu.HDRFilm(64, 64), 4) and d.stats.fused == 0      # `direct` stays on the wavefront kernels
+    assert d.render(cb, gpu.HDRFilm(64, 64), 4) and d.stats.fused == 1      # round 6: `direct` rides the fused kernel too (k_mega<.., DIRECT>)
+    assert d.render(cb, gpu.HDRFilm(64, 64), 4, flags=A.PHIP_FLAG_NO_FUSED) and d.stats.fused == 0
     for nu, nv, fits in ((4, 3, 1), (12, 8, 0)):
         sb = S.cornell_box(64, 64, gauss)
         P, T, N = S.sphere_mesh((200, 300, 200), 45.0, nu, nv)

@@ -25,7 +25,12 @@ for key in sys.argv[1:] or cfgs:
     spp = int(os.environ.get("SPP", spp))
     sb = getattr(S, name)(w, h, ft, **(cfgs[key][5] if len(cfgs[key]) > 5 else {}))
     t = time.time(); sc = Scene(sb.desc()); tb = time.time() - t
-    integ = PathHIP(maxDepth=md); film = HDRFilm(w, h)
+    if os.environ.get("DIRECT"):       # DIRECT=<shadingSamples>: the `direct` integrator on the same scene
+        from mitsuba_amd.integrator import DirectHIP
+        integ = DirectHIP(shadingSamples=int(os.environ["DIRECT"]))
+    else:
+        integ = PathHIP(maxDepth=md)
+    film = HDRFilm(w, h)
     if not os.environ.get("NOWARM"):
         integ.render(sc, film, 1, flags=int(os.environ.get("FLAGS", "0"), 0))
     for _ in range(int(os.environ.get("REPEAT", 1)) - 1):

@@ -32,7 +32,7 @@ print("| kernel | VGPRs | SGPRs | scratch B/lane | static LDS B/block | waves/SI
 print("|---|---:|---:|---:|---:|---:|---:|")
 flags = [f for f in _ffi.HIPCC_FLAGS if f != "-shared"]
 for src, extra, obj in _ffi.UNITS:
-    if obj not in ("phip.o", "phip_mega.o", "phip_megaw.o", "phip_shade0_0.o", "phip_shade0_1.o", "phip_shade0_2.o", "phip_shade0_3.o"):       # the other shading units are the same kernels with more features compiled in
+    if obj not in ("phip.o", "phip_mega.o", "phip_megaw.o", "phip_megad.o", "phip_shade0_0.o", "phip_shade0_1.o", "phip_shade0_2.o", "phip_shade0_3.o"):       # the other shading units are the same kernels with more features compiled in
         continue
     r = subprocess.run([HIPCC] + flags + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", os.path.join(_ffi.CSRC, src), "-o", os.devnull],
                        capture_output=True, text=True)
