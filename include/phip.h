@@ -416,6 +416,13 @@ typedef struct phip_accel_info {
 } phip_accel_info;
 int  phip_scene_accel_info(const phip_scene *scene, phip_accel_info *out);
 
+/* Utilities for callers that fill a phip_scene_desc without Mitsuba at hand (the test harness, bench.py): the table of the reference's default `gaussian` reconstruction
+ * filter with the given standard deviation -- (radius, PHIP_FILTER_RESOLUTION + 1 values), rfilter.cpp:38-57 + gaussian.cpp:34-57; the Mitsuba shim copies the scene's own
+ * filter instead -- and sizeof of the ABI's structs by index (0 phip_material, 1 phip_shape, 2 phip_emitter, 3 phip_camera, 4 phip_film, 5 phip_scene_desc,
+ * 6 phip_render_params, 7 phip_stats, 8 phip_ray, 9 phip_hit, 10 phip_accel_info), for bindings that mirror them (tests/test_abi.py holds the ctypes mirror against it). */
+void   phip_gaussian_filter(float stddev, float *radius, float *table);
+size_t phip_abi_sizeof(int which);
+
 #ifdef __cplusplus
 }
 #endif

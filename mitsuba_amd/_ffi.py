@@ -16,6 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "libphip.so")
+# the same sources with the test hooks compiled in (phip_debug.inl: host twins of device functions, the fmath probe, the HBM calibration kernels): what tests/ and tools/ reach
+# through lib().phip_debug_*; the product library does not export them
+LIB_DEBUG = os.path.join(BUILD, "libphip_debug.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wall", "-Wno-unused-function"]
@@ -43,6 +46,9 @@ UNITS = [("phip_shade.hip", ["-DSHADE_FEAT=%d" % f, "-DSHADE_PART=%d" % q], "phi
         [("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=0"], "phip_mega.o"), ("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=1"], "phip_megaw.o"), ("phip_mega.hip", MEGA_FLAGS + ["-DMEGA_PART=2"], "phip_megad.o"), ("phip.hip", [], "phip.o")]
 
 
+DEBUG_UNIT = ("phip.hip", ["-DPHIP_DEBUG_HOOKS=1"], "phip_dbg.o")
+
+
 def source_id():
     """Provenance of a build: a hash of every source file and the compile flags.  It is compiled into the library (phip_build_id) so
     that a stale libphip.so -- file times mean nothing after a copy to another machine -- is recognised when it is loaded."""
@@ -50,7 +56,7 @@ def source_id():
     h = hashlib.sha256()
     for s in _sources():
         h.update(os.path.basename(s).encode()); h.update(open(s, "rb").read())
-    h.update(repr((HIPCC_FLAGS, UNITS, os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", ""))).encode())
+    h.update(repr((HIPCC_FLAGS, UNITS, DEBUG_UNIT, os.environ.get("PHIP_EXTRA_HIPCC_FLAGS", ""))).encode())
     return h.hexdigest()[:16]
 
 
@@ -69,14 +75,15 @@ def build(force=False, verbose=False):
     os.makedirs(BUILD, exist_ok=True)
     sid = source_id()
     out_lib = os.environ.get("PHIP_BUILD_OUTPUT", LIB)      # experiment hook: alternative builds next to the product (load with PHIP_LIB)
-    if not force and built_id(out_lib) == sid:
+    alt = os.path.abspath(out_lib) != os.path.abspath(LIB)          # an alternative build (fault injection, small stacks): the product's sources with other flags, no test hooks
+    if not force and built_id(out_lib) == sid and (alt or built_id(LIB_DEBUG) == sid):
         return out_lib
     # several processes may find the library stale at once (ranks of a torchrun job, pytest-xdist workers): one builds, the others
     # wait for the lock and find the fresh file; objects and library are written under temporary names and renamed into place
     import fcntl
     with open(os.path.join(BUILD, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and built_id(out_lib) == sid:
+        if not force and built_id(out_lib) == sid and (alt or built_id(LIB_DEBUG) == sid):
             return out_lib
         return _build_locked(sid, out_lib, verbose)
 
@@ -88,7 +95,8 @@ def _build_locked(sid, out_lib, verbose):
     # an alternative build (PHIP_BUILD_OUTPUT) keeps objects of its own: tools/build_variant.sh links the PRODUCT's objects by name
     sfx = "" if os.path.abspath(out_lib) == os.path.abspath(LIB) else "-" + os.path.splitext(os.path.basename(out_lib))[0]
     units = [(src, extra, obj[:-2] + sfx + ".o") for src, extra, obj in UNITS]
-    for src, extra, obj in units:
+    dbg = None if sfx else DEBUG_UNIT                           # (the hooks: the product build only)
+    for src, extra, obj in units + ([dbg] if dbg else []):
         if src == "phip.hip":
             extra = extra + ['-DPHIP_BUILD_ID="%s"' % sid]
         cmds.append([hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj + ".tmp.o")])
@@ -113,14 +121,18 @@ def _build_locked(sid, out_lib, verbose):
                 raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
             if verbose:
                 print(" ".join(cmd)); print(out)
-    for _, _, obj in units:
+    for _, _, obj in units + ([dbg] if dbg else []):
         os.replace(os.path.join(BUILD, obj + ".tmp.o"), os.path.join(BUILD, obj))
-    tmp = out_lib + ".tmp.%d" % os.getpid()
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [os.path.join(BUILD, u[2]) for u in units] + ["-ldl"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-    os.replace(tmp, out_lib)                                # a concurrent loader sees the old library or the new one, never half of one
+    links = [(out_lib, [u[2] for u in units])]
+    if dbg:
+        links.append((LIB_DEBUG, [dbg[2] if u[0] == "phip.hip" else u[2] for u in units]))
+    for target, objs in links:
+        tmp = target + ".tmp.%d" % os.getpid()
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [os.path.join(BUILD, o) for o in objs] + ["-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        os.replace(tmp, target)                             # a concurrent loader sees the old library or the new one, never half of one
     return out_lib
 
 
@@ -161,6 +173,35 @@ def lib():
     L.phip_host_free.argtypes = [C.c_void_p]; L.phip_host_free.restype = None
     L.phip_abi_sizeof.restype = C.c_size_t
     L.phip_abi_sizeof.argtypes = [C.c_int]
+    _lib = _LibWithHooks(L)
+    return _lib
+
+
+class _LibWithHooks(object):
+    """the product library; attribute look-ups of the test hooks (phip_debug_*) go to libphip_debug.so, which is loaded at the first of them"""
+    def __init__(self, product):
+        object.__setattr__(self, "_product", product)
+
+    def __getattr__(self, name):
+        if name.startswith("phip_debug_"):
+            return getattr(debug_lib(), name)
+        return getattr(object.__getattribute__(self, "_product"), name)
+
+
+_debug = None
+
+
+def debug_lib():
+    """mitsuba_amd/_build/libphip_debug.so: the product's sources + phip_debug.inl (tests / tools only)"""
+    global _debug
+    if _debug is not None:
+        return _debug
+    path = os.environ.get("PHIP_DEBUG_LIB", LIB_DEBUG)
+    if not os.path.exists(path):
+        raise RuntimeError("libphip_debug.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    L = C.CDLL(path)
+    fp, u8p, u32 = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_uint32
+    L.phip_last_error.restype = C.c_char_p
     L.phip_debug_host_bsdf_sample.argtypes = [C.POINTER(A.phip_material), u32, u32, C.c_size_t, fp, fp, fp, fp, fp, u8p]
     L.phip_debug_host_bsdf_eval_pdf.argtypes = [C.POINTER(A.phip_material), u32, u32, C.c_size_t, fp, fp, fp, fp]
     L.phip_debug_host_camera_ray.argtypes = [C.POINTER(A.phip_camera), C.POINTER(A.phip_film), C.c_float, C.c_float, C.POINTER(A.phip_ray)]
@@ -175,7 +216,7 @@ def lib():
     L.phip_debug_host_build_bvh.argtypes = [fp, u32, C.POINTER(C.c_uint32), u32, C.POINTER(A.phip_accel_info), fp]
     L.phip_debug_host_trace_wide.argtypes = [fp, u32, C.POINTER(C.c_uint32), u32, C.POINTER(A.phip_ray), C.c_size_t, C.POINTER(A.phip_hit), C.c_int, C.POINTER(A.phip_accel_info), u8p, u32]
     L.phip_debug_fmath.argtypes = [C.c_int, C.c_int, C.c_size_t, fp, fp, fp]
-    _lib = L
+    _debug = L
     return L
 
 

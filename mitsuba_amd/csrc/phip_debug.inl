@@ -1,49 +1,12 @@
 /*
- * phip_debug.inl -- host-side utility and unit-test entry points of libphip.so.
+ * phip_debug.inl -- unit-test entry points, compiled into libphip_debug.so only (-DPHIP_DEBUG_HOOKS=1; the product library does not carry them).
  *
- * phip_gaussian_filter is a harness utility (the Mitsuba shim copies the table from the
- * scene's ReconstructionFilter instead).  The phip_debug_host_* functions execute the
+ * The phip_debug_host_* functions execute the
  * __host__ __device__ shading functions of dv_math.h / dv_scene.h ON THE HOST so that
  * `-m "not gpu"` tests can compare the product's arithmetic with the oracle bit for bit
  * without a GPU.  They are never reachable from phip_render*: rendering has no CPU fallback.
  */
 extern "C" {
-
-/* rfilter.cpp:38-57 + gaussian.cpp:34-57: (radius, table[32]) of `gaussian` with the given stddev */
-void phip_gaussian_filter(float stddev, float *radius, float *table32) {
-    const float r = 4 * stddev;
-    float sum = 0.0f;
-    const float alpha = -1.0f / (2.0f * stddev * stddev);
-    for (size_t i = 0; i < PHIP_FILTER_RESOLUTION; ++i) {
-        float x = (r * i) / PHIP_FILTER_RESOLUTION;
-        float value = smax(0.0f, pm_expf(alpha * x * x) - pm_expf(alpha * r * r));
-        table32[i] = value;
-        sum += value;
-    }
-    table32[PHIP_FILTER_RESOLUTION] = 0.0f;
-    sum *= 2 * r / PHIP_FILTER_RESOLUTION;
-    const float normalization = 1.0f / sum;
-    for (size_t i = 0; i < PHIP_FILTER_RESOLUTION; ++i)
-        table32[i] *= normalization;
-    *radius = r;
-}
-
-size_t phip_abi_sizeof(int which) {
-    switch (which) {
-        case 0: return sizeof(phip_material);
-        case 1: return sizeof(phip_shape);
-        case 2: return sizeof(phip_emitter);
-        case 3: return sizeof(phip_camera);
-        case 4: return sizeof(phip_film);
-        case 5: return sizeof(phip_scene_desc);
-        case 6: return sizeof(phip_render_params);
-        case 7: return sizeof(phip_stats);
-        case 8: return sizeof(phip_ray);
-        case 9: return sizeof(phip_hit);
-        case 10: return sizeof(phip_accel_info);
-        default: return 0;
-    }
-}
 
 int phip_debug_host_bsdf_sample(const phip_material *materials, uint32_t n_materials, uint32_t material, size_t n,
                                 const float *wi3, const float *sample2, float *wo3, float *weight3, float *pdf, uint8_t *delta) {

@@ -29,6 +29,17 @@ def test_library_exports_every_declared_symbol(phip):
         assert hasattr(phip, f), "libphip.so does not export " + f
 
 
+def test_product_library_does_not_export_the_test_hooks():
+    """round 6 (hygiene): phip_debug_* -- host twins of device functions, the fmath probe, the calibration kernels -- live in libphip_debug.so (the same sources
+    with -DPHIP_DEBUG_HOOKS=1), which only tests/ and tools/ load; the shipped library exports the boundary of include/phip.h and nothing of them"""
+    import subprocess
+    from mitsuba_amd import _ffi
+    out = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB], capture_output=True, text=True).stdout
+    assert "phip_render" in out and "phip_debug_" not in out, [l for l in out.splitlines() if "phip_debug_" in l][:5]
+    dbg = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_DEBUG], capture_output=True, text=True).stdout
+    assert "phip_debug_host_camera_ray" in dbg and "phip_debug_fmath" in dbg
+
+
 def test_struct_sizes_match_ctypes_mirror(phip):
     structs = [A.phip_material, A.phip_shape, A.phip_emitter, A.phip_camera, A.phip_film, A.phip_scene_desc,
                A.phip_render_params, A.phip_stats, A.phip_ray, A.phip_hit, A.phip_accel_info]

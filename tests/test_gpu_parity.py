@@ -1025,3 +1025,46 @@ np.savez(sys.argv[1], **out)
             assert (prod[name + "_film"].view(np.uint32) == fault[name + "_film"].view(np.uint32)).all(), (a, name)
             if samples:
                 assert (prod[name + "_samples"].view(np.uint32) == fault[name + "_samples"].view(np.uint32)).all(), name
+
+
+def test_task_stack_of_the_fused_kernel_spills_to_memory(gpu, gauss, tmp_path):
+    """The shared task stack of a wave (k_wide_wave.h: traceWidePool) holds WP_CAP = 256 entries in LDS; what does not fit goes to the wave's slice of the spill buffer in
+    memory (written by one lane, read by another: agent-scope accesses), and an iteration pops fewer tasks when the stack could not take their children.  A library
+    built with 32-entry stacks (-DWP_CAP=32u: nearly every push of the big scenes spills) must render the frames of the product, bit for bit -- the atrium and the glass
+    room under PHIP_FLAG_FUSED_ANY (ten node visits per ray), the spheres, `direct`."""
+    import subprocess, sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available: the small-stack library cannot be built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mitsuba_amd", "_build", "libphip_cap32.so")
+    env = dict(os.environ, PHIP_BUILD_OUTPUT=lib, PHIP_EXTRA_HIPCC_FLAGS="-DWP_CAP=32u")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from mitsuba_amd import _ffi; print(_ffi.build())" % root], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(lib), r.stdout[-2000:] + r.stderr[-2000:]
+    script = r"""
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np
+from mitsuba_amd import _ffi, _abi as A, scene as S
+from mitsuba_amd.integrator import Scene, PathHIP, DirectHIP, HDRFilm
+ft = _ffi.gaussian_filter(0.5)
+out = {}
+for name, sb, spp, integ in (("atrium", S.atrium(96, 54, ft, detail=0.3), 4, PathHIP(maxDepth=6)), ("glass", S.glass_room(96, 54, ft, detail=0.3), 4, PathHIP(maxDepth=10)),
+                             ("spheres", S.cornell_spheres(96, 96, ft), 4, PathHIP(maxDepth=6)), ("direct", S.cornell_spheres(96, 96, ft), 4, DirectHIP(shadingSamples=2))):
+    gs = Scene(sb.desc()); film = HDRFilm(gs.width, gs.height)
+    assert integ.render(gs, film, spp, flags=A.PHIP_FLAG_SAMPLE_BUFFER | A.PHIP_FLAG_FUSED_ANY)
+    assert integ.stats.fused == 1, name
+    out[name] = integ.samples(gs, spp).copy(); out[name + "_film"] = film.storage.copy()
+    gs.close()
+np.savez(sys.argv[1], **out)
+""" % root
+    res = {}
+    for tag, e in (("product", {}), ("cap32", {"PHIP_LIB": lib})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, **e), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "warning" not in r.stderr, r.stderr[-800:]           # (no pass gave up: the stack spilled, it did not overflow)
+        res[tag] = np.load(f)
+    for name in ("atrium", "glass", "spheres", "direct"):
+        assert (res["product"][name].view(np.uint32) == res["cap32"][name].view(np.uint32)).all(), name
+        assert (res["product"][name + "_film"].view(np.uint32) == res["cap32"][name + "_film"].view(np.uint32)).all(), name
