@@ -52,6 +52,9 @@
 #define MEGA_MB_FAULT 0              /* fault injection (tests/test_gpu_dropin.py builds it): the first wave of the grid reports that it gave up -- the host must then re-render the pass on the
                                         wavefront kernels and deliver the same frame (phip.hip) */
 #endif
+#ifndef MEGA_MAILBOX_QMC
+#define MEGA_MAILBOX_QMC 1           /* the mailboxes in the QMC builds of k_mega<MM_ALL> as well (0: they keep the class deal, as in round 5) */
+#endif
 #ifndef MEGA_POOL
 #define MEGA_POOL 1                  /* FLAT >= 4 (the tree in memory): the wave's rays are traversed through ONE shared stack of node visits, any lane takes any ray's (k_wide_wave.h:
                                         traceWidePool); 0: every lane walks its own ray (traceWideW, with MEGA_JOINT) */
@@ -81,7 +84,7 @@
 #endif
 /* MB_NS = 64 entries of the S-box (dynamic LDS, behind the work lists; k_pool.h) and MB_NR of the R-box (static: what four blocks per CU leave) */
 #define MB_NR 48u
-/* MB_DW = 22 (k_pool.h): dwords per mailbox entry (S-box: hit 4, direction 3, throughput 4, MIS 2, id, pixel, k, state, accumulator 4 = 21; R-box: origin + mint 4,
+/* MB_DW = 24 (k_pool.h): dwords per mailbox entry (S-box: hit 4, direction 3, throughput 4, MIS 2, id, pixel, k, state, accumulator 4 = 21; R-box: origin + mint 4,
                                         direction + maxt 4 instead of hit and direction = 22) */
 static_assert(MEGA_DEAL_DWORDS * sizeof(uint32_t) == WIDE_STACK_LDS * sizeof(uint2), "FLAT >= 4: the class deal's exchange buffer lies over the group stack");
 static_assert(MEGA_DEAL_DWORDS * BLOCK * sizeof(uint32_t) <= (BLOCK / 64u) * WP_WAVE_BYTES, "FLAT >= 4, MEGA_POOL: ... over the waves' round buffers (slots, ray table, pair list: free between traversals)");
@@ -99,23 +102,24 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
     constexpr bool WIDE = FLAT >= 4;                            /* the tree, its Wald records and the shading records stay in memory: a lane still owns its path from the camera sample to its last vertex */
     /* (the QMC build's static LDS leaves no room for the R-box at four blocks per CU; nor does the LDS of the tree-in-memory builds: there the mailboxes' 10 KB cost the fourth
        block, and the class deal at four blocks measures 3 % faster than the mailboxes at three -- profiles/r06_gpu_call_i_*) */
-    constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && !WIDE && !DIRECT && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && !QMC;
+    constexpr bool MAILBOX = MM != 0 && FLAT >= 2 && !WIDE && !DIRECT && MEGA_BALANCE && MEGA_MAILBOX && MEGA_REGEN_QUEUE && (!QMC || MEGA_MAILBOX_QMC);      /* (round 6: the QMC builds too -- their work counters became per-wave ones (WCNT: 8 KB of static LDS), which is the room the R-box needed; the sample's sequence index travels with the path) */
     /* (WIDE: neither -- the deal's five block barriers per pass cost more than the divergence they remove once a pass is dominated by a traversal whose length differs from
        wave to wave: glass + copper spheres 1554 -> 1803, glass room 510 -> 602, atrium 444 -> 457 Msamples/s without it, profiles/r06_gpu_call_n_*) */
     constexpr bool DEAL = MM != 0 && FLAT >= 2 && !WIDE && !DIRECT && MEGA_BALANCE && MEGA_CLASS_DEAL && !MAILBOX;      /* (`direct`: the camera vertex's rounds carry the camera hit along -- no exchange) */
     __shared__ uint32_t ldsClsCnt[4][BLOCK / 64];                 /* MEGA_CLASS_DEAL: lanes per BSDF model and wave */
-    __shared__ uint32_t mbR[MAILBOX ? MB_DW * MB_NR : 1u];        /* MEGA_MAILBOX: the R-box, [MB_DW][MB_NR]; the S-box lies in the dynamic LDS behind the traversals' work lists (phip.hip sizes the region) */
+    __shared__ uint32_t mbR[MAILBOX ? MB_DW * MB_NR : 1u];        /* (MB_DW = 24: the last two words of an entry carry the sample's sequence index in the QMC builds) */
+    __shared__ uint32_t mbR_unused_doc[1];        /* MEGA_MAILBOX: the R-box, [MB_DW][MB_NR]; the S-box lies in the dynamic LDS behind the traversals' work lists (phip.hip sizes the region) */
     __shared__ uint32_t mbState[MAILBOX ? MB_NS + MB_NR : 1u];   /* entry states, S-box then R-box: 0 empty, 2 full, 3 being read (R-box: three consumers claim by compare-and-swap) */
     __shared__ int mbLive;                                        /* sample ids drawn by the block's waves that have not ended as a sample yet (queued camera samples and paths, wherever they are) */
     /* WIDE: per-wave counters instead (WCNT: lanes are counted as ballots, node steps and triangle tests by the traversal as k_rays_w does) -- the 8 KB are a fifth
        of what a block may take at four blocks per CU once stack, node cache and round buffers are in */
-    constexpr bool WCNT = WIDE && !MEGA_PROFILE && !MEGA_MB_DIAG;
+    constexpr bool WCNT = (WIDE || (MAILBOX && QMC)) && !MEGA_PROFILE && !MEGA_MB_DIAG;
     __shared__ uint32_t ldsCount[WCNT ? 1 : MC_COUNT][WCNT ? 1 : BLOCK];   /* work counters: one LDS word per lane and counter instead of eight VGPRs.  (As ds_add_u32 -- no read,
                                                                    no wait -- and the three that count lanes as ballots in SGPRs: 66.9 vs 66.5 ms per C2 frame and
                                                                    125 instead of 116 VGPRs; the seven read-modify-writes per pass overlap with the rest as they are) */
 #define MEGA_COUNT(row, amount) ldsCount[row][threadIdx.x] += (uint32_t) (amount)
     enum { WC_SAMPLES = 0, WC_VERTICES, WC_RAYS, WC_STEPS, WC_SH_RAYS, WC_SH_STEPS, WC_COUNT };      /* WC_STEPS: node steps | triangle tests << 32 (k_wide_wave.h) */
-    __shared__ unsigned long long wcnt[WIDE ? BLOCK / 64 : 1][WC_COUNT];
+    __shared__ unsigned long long wcnt[WCNT || WIDE ? BLOCK / 64 : 1][WC_COUNT];
     /* JOINT (WIDE): the shadow ray of a vertex is traced TOGETHER with the next ray of its path, in the traversal phase of the next pass (traceWideW: a lane brings two rays) --
        one wait for the wave's slowest lane per vertex instead of two.  A path that ended with its shadow ray pending parks its accumulator here and frees the lane */
     constexpr bool POOL = WIDE && MEGA_POOL;
@@ -200,8 +204,19 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
 #pragma unroll
         for (int i = 0; i < MC_COUNT; ++i) ldsCount[WCNT ? 0 : i][WCNT ? 0 : threadIdx.x] = 0;
     }
-    unsigned long long *const wc = wcnt[WIDE ? waveInBlock : 0u];
-    if (WIDE && lane < (uint32_t) WC_COUNT) wc[lane] = 0ull;      /* (every wave its own row: no barrier needed) */
+    unsigned long long *const wc = wcnt[(WCNT || WIDE) ? waveInBlock : 0u];
+    if ((WCNT || WIDE) && lane < (uint32_t) WC_COUNT) wc[lane] = 0ull;      /* (every wave its own row: no barrier needed) */
+    /* WCNT outside the tree-in-memory builds: a per-lane count summed over the wave (six DPP steps), lane 63 adds it to the wave's counter */
+    auto wcAdd = [&](int row, uint32_t perLane, bool shiftHigh) {
+        uint32_t t = perLane;
+        t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x111, 0xf, 0xf, true);
+        t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x112, 0xf, 0xf, true);
+        t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x114, 0xf, 0xf, true);
+        t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x118, 0xf, 0xf, true);
+        t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x142, 0xa, 0xf, false);
+        t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x143, 0xc, 0xf, false);
+        if (lane == 63u) wc[row] += shiftHigh ? ((unsigned long long) t << 32) : (unsigned long long) t;
+    };
     bool cPush = false, cPend = false;                          /* JOINT: a shadow ray waits for the next traversal phase; its path ended at that vertex (accumulator parked) */
     float4 cPark = make_float4(0, 0, 0, 0);                     /* (registers: 4 KB of LDS per block would cost the fourth block of a CU) */
     ShadowEntry cSh; cSh.e0 = cSh.e1 = cSh.e2 = make_float4(0, 0, 0, 0);
@@ -243,6 +258,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                         v.mis = make_float2(pm_from_bits(x[11 * MB_NS]), pm_from_bits(x[12 * MB_NS]));
                         v.id = x[13 * MB_NS]; v.pixel = x[14 * MB_NS]; v.k = x[15 * MB_NS]; v.state = x[16 * MB_NS];
                         accum = make_float4(pm_from_bits(x[17 * MB_NS]), pm_from_bits(x[18 * MB_NS]), pm_from_bits(x[19 * MB_NS]), pm_from_bits(x[20 * MB_NS]));
+#if MEGA_REGEN_QUEUE
+                        if (QMC) { ldsSeq[QMC ? waveInBlock : 0][0][lane] = x[22 * MB_NS]; ldsSeq[QMC ? waveInBlock : 0][1][lane] = x[23 * MB_NS]; }
+#endif
                         alive = true; haveHit = true;
 #if MEGA_MB_DIAG
                         ++dgWithdrawn;
@@ -267,6 +285,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                             v.mis = make_float2(pm_from_bits(x[12 * MB_NR]), pm_from_bits(x[13 * MB_NR]));
                             v.id = x[14 * MB_NR]; v.pixel = x[15 * MB_NR]; v.k = x[16 * MB_NR]; v.state = x[17 * MB_NR];
                             accum = make_float4(pm_from_bits(x[18 * MB_NR]), pm_from_bits(x[19 * MB_NR]), pm_from_bits(x[20 * MB_NR]), pm_from_bits(x[21 * MB_NR]));
+#if MEGA_REGEN_QUEUE
+                            if (QMC) { ldsSeq[QMC ? waveInBlock : 0][0][lane] = x[22 * MB_NR]; ldsSeq[QMC ? waveInBlock : 0][1][lane] = x[23 * MB_NR]; }
+#endif
                             alive = true;
 #if MEGA_MB_DIAG
                             ++dgRefill;
@@ -483,8 +504,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             if (trace) {
                 v.hit = make_float4(r.t, r.u, r.v, pm_from_bits(r.prim));
                 hitCls = r.cls;
-                MEGA_COUNT(MC_RAYS, 1); MEGA_COUNT(MC_NODE, nNode); MEGA_COUNT(MC_TRI, nTri);
+                if (!WCNT) { MEGA_COUNT(MC_RAYS, 1); MEGA_COUNT(MC_NODE, nNode); MEGA_COUNT(MC_TRI, nTri); }
             }
+            if (WCNT) { wcAdd(WC_RAYS, trace ? 1u : 0u, false); wcAdd(WC_STEPS, trace ? nNode : 0u, false); wcAdd(WC_STEPS, trace ? nTri : 0u, true); }
         } else
         if (alive) {
             const V3 o(v.rayO.x, v.rayO.y, v.rayO.z), d(v.rayD.x, v.rayD.y, v.rayD.z);
@@ -518,6 +540,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                     x[11 * MB_NS] = pm_to_bits(v.mis.x); x[12 * MB_NS] = pm_to_bits(v.mis.y);
                     x[13 * MB_NS] = v.id; x[14 * MB_NS] = v.pixel; x[15 * MB_NS] = v.k; x[16 * MB_NS] = v.state;
                     x[17 * MB_NS] = pm_to_bits(accum.x); x[18 * MB_NS] = pm_to_bits(accum.y); x[19 * MB_NS] = pm_to_bits(accum.z); x[20 * MB_NS] = pm_to_bits(accum.w);
+#if MEGA_REGEN_QUEUE
+                    if (QMC) { x[22 * MB_NS] = ldsSeq[QMC ? waveInBlock : 0][0][lane]; x[23 * MB_NS] = ldsSeq[QMC ? waveInBlock : 0][1][lane]; }
+#endif
                     __hip_atomic_store(&mbState[e], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     alive = false;
 #if MEGA_MB_DIAG
@@ -646,9 +671,10 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
             const bool go = pushShadow & clipToSceneSel<true>(S, o, d, PT_EPSILON, sh.e0.w, mint, maxt, rcp);
             const bool occluded = traverseFlat2W<true, FLAT == 3>(flat, S.nFlatLeaves, stk.tris, wb, lane, go, o, d, rcp, mint, maxt, r, nNode, nTri);
             if (pushShadow) {
-                MEGA_COUNT(MC_SH_RAYS, 1); MEGA_COUNT(MC_SH_NODE, nNode); MEGA_COUNT(MC_SH_TRI, nTri);
+                if (!WCNT) { MEGA_COUNT(MC_SH_RAYS, 1); MEGA_COUNT(MC_SH_NODE, nNode); MEGA_COUNT(MC_SH_TRI, nTri); }
                 if (!occluded) { accum.x += sh.e2.x; accum.y += sh.e2.y; accum.z += sh.e2.z; }
             }
+            if (WCNT) { wcAdd(WC_SH_RAYS, pushShadow ? 1u : 0u, false); wcAdd(WC_SH_STEPS, pushShadow ? nNode : 0u, false); wcAdd(WC_SH_STEPS, pushShadow ? nTri : 0u, true); }
         } else
         if (pushShadow) {
             const V3 o(sh.e0.x, sh.e0.y, sh.e0.z), d(sh.e1.x, sh.e1.y, sh.e1.z);
@@ -687,6 +713,9 @@ template <int MM, bool STRICT, int FLAT /* 0: BVH4 walk, 1: flat leaf table (tra
                     x[12 * MB_NR] = pm_to_bits(v.mis.x); x[13 * MB_NR] = pm_to_bits(v.mis.y);
                     x[14 * MB_NR] = v.id; x[15 * MB_NR] = v.pixel; x[16 * MB_NR] = v.k; x[17 * MB_NR] = v.state;
                     x[18 * MB_NR] = pm_to_bits(accum.x); x[19 * MB_NR] = pm_to_bits(accum.y); x[20 * MB_NR] = pm_to_bits(accum.z); x[21 * MB_NR] = pm_to_bits(accum.w);
+#if MEGA_REGEN_QUEUE
+                    if (QMC) { x[22 * MB_NR] = ldsSeq[QMC ? waveInBlock : 0][0][lane]; x[23 * MB_NR] = ldsSeq[QMC ? waveInBlock : 0][1][lane]; }
+#endif
                     __hip_atomic_store(&mbState[MB_NS + e], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     alive = false;
                 }

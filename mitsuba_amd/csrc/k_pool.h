@@ -75,7 +75,7 @@ enum { ST_CLOSEST_RAYS = 0, ST_NODE, ST_TRI, ST_SHADOW_RAYS, ST_SH_NODE, ST_SH_T
 #define MEGA_MAILBOX 1               /* k_mega<MM_ALL>, counter stream: a serving wave behind two LDS mailboxes (k_mega.h) */
 #endif
 #define MB_NS 64u                    /* entries of the S-box (dynamic LDS) and dwords per entry: the host sizes k_mega's launch with them */
-#define MB_DW 22u
+#define MB_DW 24u                    /* (22 words of path state + the sample's 64-bit sequence index, which the QMC builds carry along) */
 #ifndef MEGA_POOL
 #define MEGA_POOL 1                  /* k_mega<.., FLAT >= 4, ..>: one shared task stack per wave (k_wide_wave.h: traceWidePool); the host sizes the launch's LDS by it */
 #endif

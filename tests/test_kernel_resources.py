@@ -72,10 +72,11 @@ def test_fused_kernel_keeps_four_waves_without_scratch():
             # diffuse builds: no scratch with the counter stream; the QMC build on the packed table parks 2 dwords (6 with strictNormals) since the interleaved 2D
             # radical inverse (halton 3001 -> 3226 Msamples/s for them; it was 36-64 B before the device drew Sobol' numbers through the byte tables only -- the row
             # loops' 16 reads in flight were what spilled); BVH4 walk / leaf table: up to 10 dwords.  All-material builds: the microfacet code
-            # beside the traversal and the mailbox protocol parks 10-14 dwords (counter stream; 3-8 before the mailboxes, which are worth +26 % on the mixed box), ~22 with the samplers' tables live -- at four waves per SIMD all the same (measured: the mixed
+            # beside the traversal and the mailbox protocol parks 10-14 dwords (counter stream; 3-8 before the mailboxes, which are worth +26 % on the mixed box), ~27 with the samplers' tables live AND the mailboxes
+            # (round 6: worth +24 % with sobol, +21 % with halton on the mixed box) -- at four waves per SIMD all the same (measured: the mixed
             # Cornell box 2360 Msamples/s on this kernel against 1770 on the one-kernel iterations at five waves)
             strict = re.match(r"_Z6k_megaILi\dELb1E", name) is not None
-            limit = (96 if qmc else 64) if allmat else (((40 if strict else 32) if not packed else (24 if strict else 8)) if qmc else 0)
+            limit = (112 if qmc else 64) if allmat else (((40 if strict else 32) if not packed else (24 if strict else 8)) if qmc else 0)
             assert v["vgprs"] <= 128 and v["scratch"] <= limit, (name, v)
             assert 4 * (v["lds"] + 12 * 1024) <= 160 * 1024, (name, v)      # four blocks per CU with the Cornell box's 11 KB of dynamic LDS (tables, records, flat table)
     assert n == 16                                                  # {diffuse, all materials} x strictNormals x {packed flat table of <= 32 / <= 64 records} x {counter stream, QMC} (round 6: the BVH4 walk and the per-lane leaf table in LDS are experiment builds -- scenes past 64 records are on the 8-wide tree)

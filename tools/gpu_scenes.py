@@ -31,12 +31,17 @@ for key in sys.argv[1:] or cfgs:
     else:
         integ = PathHIP(maxDepth=md)
     film = HDRFilm(w, h)
+    skw = {}
+    if os.environ.get("SAMPLER") in ("sobol", "halton", "hammersley"):       # the reference's QMC samplers (tables: tests/golden, as the tests pass them)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        import conftest as CT
+        skw = dict(sobol=CT.sobol_tables(w, h)) if os.environ["SAMPLER"] == "sobol" else dict(sampler=getattr(A, "PHIP_SAMPLER_" + os.environ["SAMPLER"].upper()), qmc=CT.qmc_tables(-1))
     if not os.environ.get("NOWARM"):
-        integ.render(sc, film, 1, flags=int(os.environ.get("FLAGS", "0"), 0))
+        integ.render(sc, film, 1, flags=int(os.environ.get("FLAGS", "0"), 0), **skw)
     for _ in range(int(os.environ.get("REPEAT", 1)) - 1):
-        integ.render(sc, film, spp, flags=int(os.environ.get("FLAGS", "0"), 0))
+        integ.render(sc, film, spp, flags=int(os.environ.get("FLAGS", "0"), 0), **skw)
     extra = int(os.environ.get("FLAGS", "0"), 0)       # e.g. FLAGS=0: PHIP_FLAG_NO_FUSED (the wavefront kernels on a scene of k_mega)
-    t = time.time(); integ.render(sc, film, spp, flags=extra | (0 if os.environ.get('NOTIMING') else A.PHIP_FLAG_KERNEL_TIMING)); dt = time.time() - t
+    t = time.time(); integ.render(sc, film, spp, flags=extra | (0 if os.environ.get('NOTIMING') else A.PHIP_FLAG_KERNEL_TIMING), **skw); dt = time.time() - t
     st = integ.stats.as_dict()
     n = w * h * spp
     print(json.dumps({"scene": key, "tris": sb.n_triangles, "accel": sc.accel_info().as_dict(), "scene_create_s": round(tb, 3), "spp": spp, "Msamples/s": round(n / 1e6 / dt, 1),
