@@ -13,10 +13,14 @@ steps) -- and the same line carries the other single-GPU configs under "workload
 64 spp, maxDepth 8), C4 (glass room, 1920x1080, 512 spp, maxDepth 16) and a 1/16-spp slice of C5, each timed the same way
 (min(K, 3) steps after one warm-up step).
 
-N > 1 (the driver's SCALE runs): the job is BASELINE.json configs[4] -- the atrium at 3840x2160, 1024 spp -- as ONE FIXED
-JOB split N ways (strong scaling): the 32x32 blocks are dealt round-robin in the reference's spiral order over the ranks
-(one process per GPU), every rank renders its blocks into a private full-frame film, and a single RCCL reduce(SUM) of the
-(R,G,B,alpha,weight) film onto rank 0 closes every step.  `value` = samples of the whole job / max-over-ranks time.
+N > 1 (the driver's SCALE runs): `value` is the SAME config with N x the samples per pixel -- Cornell box, 1024x1024,
+256 N spp -- so that every GPU renders as many samples as the one GPU of the N = 1 line (WEAK scaling: value(N) / value(1)
+is N x the efficiency): the 32x32 blocks are dealt round-robin in the reference's spiral order over the ranks (one process
+per GPU; north_star's "pixel blocks shard across the GPUs"), every rank renders its blocks into a private full-frame film,
+and a single RCCL reduce(SUM) of the (R,G,B,alpha,weight) film onto rank 0 closes every step.  `value` = samples of the whole
+job / max-over-ranks time.  The same line carries BASELINE.json configs[4] -- the atrium at 3840x2160, 1024 spp, ONE FIXED JOB
+split N ways (strong scaling) -- under "workloads", beside the single-GPU rate of that job measured in the same run.
+`--workload X` with N > 1 shards the fixed job X (strong scaling).
 (Launched WITHOUT torchrun, `--gpus N` uses the library's own multi-device path instead: one host thread per GPU inside
 phip_render_device and ncclReduce from C++ -- what the Mitsuba plugin uses.)
 
@@ -299,9 +303,10 @@ def roofline(r):
     a = r["agg"]
     nodes = r["accel"]["n_nodes"]
     avg_ms = kms / launches if launches else 0.0
-    traffic, tsrc = profile_json("traffic", r["workload"])
-    valu, vsrc = profile_json("valu", r["workload"])
-    tcp, csrc = profile_json("tcp", r["workload"])
+    pw = r.get("profile_workload") or r["workload"]      # (the weak-scaling line of N GPUs: a rank's launch is the N = 1 config's launch -- the same number of samples through the same kernel)
+    traffic, tsrc = profile_json("traffic", pw)
+    valu, vsrc = profile_json("valu", pw)
+    tcp, csrc = profile_json("tcp", pw)
     vroof, rsrc = profile_json("vmem_roof", "")
     def by_kernel(table):        # profile keys carry template arguments ("k_mega<0, false>"): match the kernel's base name
         for k, v in (table or {}).items():
@@ -446,7 +451,13 @@ def main():
     n_gpus = args.gpus if in_library else world
     devices = list(range(args.gpus)) if in_library else None
 
-    headline = args.workload or (HEADLINE if n_gpus == 1 else MULTI_GPU_JOB)
+    headline = args.workload or HEADLINE
+    weak = n_gpus > 1 and not args.workload
+    if weak:
+        # the N-GPU line of the metric's config: N x the samples per pixel, the blocks dealt over N GPUs -- every GPU renders what the one GPU of the N = 1 line renders
+        name, w_, h_, spp_, md_ = WORKLOADS[HEADLINE][:5]
+        headline = "cornell_%dx%d_%dspp" % (w_, h_, spp_ * n_gpus)
+        WORKLOADS[headline] = (name, w_, h_, spp_ * n_gpus, md_)
     cpu, cpu_extra = None, {}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(headline)                   # before the GPU phase: the GPU is busy for the rest of the run
@@ -456,37 +467,36 @@ def main():
 
     steps, warmup = args.steps, args.warmup
     single = None
-    if n_gpus > 1:
-        # the multi-GPU job is 8.5 G samples per step (about 17 s on one GPU): a bounded number of steps keeps every N inside the
-        # driver's time limit; the line reports the steps that were timed
-        steps, warmup = min(steps, MULTI_GPU_MAX_STEPS), min(warmup, 1)
-        if not args.workload:
-            # the SAME job on ONE GPU, unsharded, at 1/16 of the samples per pixel (the rate does not depend on the sample count at
-            # this size): the denominator of the scaling efficiency, measured in this very run by rank 0 alone
-            if rank == 0:
-                one = time_workload(MULTI_GPU_SLICE, 1, 1, 0, 1, local, None, D.Solo, torch)
-                single = {"workload": MULTI_GPU_SLICE, "value": round(one["samples"] / 1e6 / one["dt"], 3), "unit": "Msamples/s", "ms_per_step": round(one["dt"] * 1e3, 3),
-                          "note": "rank 0 alone, all blocks, before the timed region; same scene / film / integrator as the job, 64 of its 1024 samples per pixel"}
-            D.barrier()
-
     main_r = time_workload(headline, steps, warmup, rank, world, local, devices, D, torch)
+    if weak:
+        main_r["profile_workload"] = HEADLINE
     extras = {}
     if n_gpus == 1 and not args.workload and not args.no_extra:
         for w in EXTRA_SINGLE_GPU + ([MULTI_GPU_JOB] if args.full_c5 else []):
             extras[w] = time_workload(w, 1 if w == MULTI_GPU_JOB else min(args.steps, 3), 1 if w != MULTI_GPU_JOB else 0, rank, world, local, devices, D, torch)
+    if weak and not args.no_extra:
+        # BASELINE.json configs[4]: the 4K atrium at 1024 spp as ONE FIXED JOB split N ways (strong scaling).  8.5 G samples per step (about 12 s on one GPU): a bounded
+        # number of steps keeps every N inside the driver's time limit.  Its denominator: the SAME job on ONE GPU, unsharded, at 1/16 of the samples per pixel (the rate
+        # does not depend on the sample count at this size: --full-c5 on the N = 1 line times all of it), measured in this very run by rank 0 alone
+        if rank == 0:
+            one = time_workload(MULTI_GPU_SLICE, 1, 1, 0, 1, local, None, D.Solo, torch)
+            single = {"workload": MULTI_GPU_SLICE, "value": round(one["samples"] / 1e6 / one["dt"], 3), "unit": "Msamples/s", "ms_per_step": round(one["dt"] * 1e3, 3),
+                      "note": "rank 0 alone, all blocks, before the timed region; same scene / film / integrator as the job, 64 of its 1024 samples per pixel"}
+        D.barrier()
+        extras[MULTI_GPU_JOB] = time_workload(MULTI_GPU_JOB, min(steps, MULTI_GPU_MAX_STEPS), min(warmup, 1), rank, world, local, devices, D, torch)
 
     if rank == 0:
         s = summary(main_r, world)
         out = {
             "metric": "Msamples/s", "value": s["value"], "unit": "Msamples/s", "n_gpus": n_gpus,
             "steps": steps, "warmup": warmup, "ms_per_step": s["ms_per_step"],
-            # every job of this bench is a FIXED frame: more GPUs split the same blocks (strong scaling), also at N = 1
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the default lines: every GPU renders the samples of the metric's config (N x its samples per pixel on N GPUs: weak scaling); `--workload X`: the fixed job X split N ways
+            "higher_is_better": True, "scaling": "strong" if args.workload else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": headline, "scene": s["scene"], "scene_generator": "mitsuba_amd/scene.py rev 3 (round 3 shrank the atrium's balcony slabs by 3 cm: C3 / C4 / C5 numbers of rounds 1-2 are another scene)", "triangles": s["triangles"], "width": s["width"], "height": s["height"],
                        "spp": s["spp"], "integrator": s["integrator"], "rfilter": "gaussian stddev 0.5", "sampler": "ctr seed 0", "block_size": 32,
-                       "parallelism": ("one fixed job: 32x32 blocks dealt round-robin in spiral order over %d GPU(s), " % n_gpus) +
+                       "parallelism": (("%s: 32x32 blocks dealt round-robin in spiral order over %d GPU(s), " % ("the metric's config at N x its samples per pixel" if weak else "one fixed job", n_gpus)) +
                                       ("one host thread per GPU inside libphip + ncclReduce(sum) of the film" if in_library else
-                                       "one process per GPU + RCCL reduce(sum) of the film") if n_gpus > 1 else "1 GPU"},
+                                       "one process per GPU + RCCL reduce(sum) of the film")) if n_gpus > 1 else "1 GPU"},
             "frame_ms": s["ms_per_step"], "step_spread": s["step_spread"], "mrays_per_s": s["mrays_per_s"], "mean_path_length": s["mean_path_length"],
             "fused_kernel": s["fused_kernel"], "roofline": s["roofline"],
             "build": {"library": _ffi.lib().phip_version().decode(), "id": _ffi.lib().phip_build_id().decode(),
@@ -496,21 +506,9 @@ def main():
             out["requested"] = {"steps": args.steps, "warmup": args.warmup}
             out["roofline"]["scope"] = "the dominant kernel of ONE rank's share of the job (rank 0): the N-GPU line prices no collective -- the film reduce is reduce_ms of the library path / inside ms_per_step here"
             out["cpu_baseline_note"] = "no CPU baseline on the N > 1 line (the N = 1 line carries one per workload)"
-            sbal, ssrc = profile_json("shard_balance", headline)      # the prediction taken on THIS job's shape (round 5: the whole 1024-spp job, not its 64-spp slice)
-            if sbal is None:
-                sbal, ssrc = profile_json("shard_balance", "")
-            pred = ((sbal or {}).get("N") or {}).get(str(n_gpus))
-            if pred:
-                out["predicted_scaling_efficiency"] = pred.get("predicted_scaling_efficiency")
-                out["prediction"] = {"source": ssrc, "max_over_mean_shard_time": pred.get("max_over_mean"), "loss_to_imbalance": pred.get("loss_to_imbalance"),
-                                     "loss_to_fixed_costs": pred.get("loss_to_fixed_costs"), "reduce_s_estimate": pred.get("reduce_s_estimate"),
-                                     "workload": (sbal or {}).get("workload"),
-                                     "note": "tools/shard_balance.py: the N shards of the named workload rendered one after another on ONE GPU; efficiency = T(1) / (N (max shard time + ring reduce at 153 GB/s per link))"}
-            if single:
-                out["single_gpu_same_job"] = single
-                out["scaling_efficiency"] = round(s["value"] / (n_gpus * single["value"]), 4)
-                out["scaling_note"] = ("the N = 1 line of this bench times ANOTHER job (%s, the config the metric is quoted on); the efficiency of this "
-                                       "N-GPU job is value / (N x single_gpu_same_job.value), both measured in this run" % HEADLINE)
+            if weak:
+                out["scaling_note"] = ("weak scaling: %d x the samples per pixel of the N = 1 line's config (%s) on %d GPUs -- value(N) / value(1) / N is the efficiency; "
+                                       "the strong-scaling job of BASELINE.json configs[4] is workloads[%r], its one-GPU rate single_gpu_same_job there" % (n_gpus, HEADLINE, n_gpus, MULTI_GPU_JOB))
         if extras:
             out["workloads"] = {headline: {k: v for k, v in s.items() if k != "roofline"}}
             out["workloads"][headline]["roofline_frac_hbm"] = (s["roofline"] or {}).get("frac")
@@ -518,6 +516,16 @@ def main():
                 out["workloads"][w] = summary(r, world)
                 if w in cpu_extra:
                     out["workloads"][w]["cpu_baseline"] = cpu_extra[w]
+            if weak and MULTI_GPU_JOB in extras:
+                j = out["workloads"][MULTI_GPU_JOB]
+                j["scaling"] = "strong"
+                j["single_gpu_same_job"] = single
+                sbal, ssrc = profile_json("shard_balance", MULTI_GPU_JOB)      # the shard balance taken on THIS job's shape on one GPU (round 5)
+                pred = ((sbal or {}).get("N") or {}).get(str(n_gpus))
+                if pred:
+                    j["shard_balance"] = {"source": ssrc, "max_over_mean_shard_time": pred.get("max_over_mean"), "loss_to_imbalance": pred.get("loss_to_imbalance"),
+                                          "reduce_s_estimate": pred.get("reduce_s_estimate"), "workload": (sbal or {}).get("workload"),
+                                          "note": "tools/shard_balance.py: the N shards of the job rendered one after another on ONE GPU"}
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
 

@@ -68,8 +68,10 @@ def test_librccl_exports_what_the_in_library_merge_binds():
 
 
 def test_bench_multi_gpu_line_fields():
-    """the N > 1 line of bench.py names its job, the bounded step count, and the single-GPU rate of the SAME job (static check of the source:
+    """the N > 1 line of bench.py is the metric's config at N x its samples per pixel (weak scaling) and carries the fixed 4K job with its bounded step count and the
+    single-GPU rate of the SAME job (static check of the source:
     the run itself needs GPUs -- tests/test_gpu_round2.py::test_bench_two_gpus)"""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for key in ("single_gpu_same_job", "scaling_efficiency", "MULTI_GPU_MAX_STEPS", '"scaling": "strong"'):
+    for key in ("single_gpu_same_job", "MULTI_GPU_MAX_STEPS", '"strong" if args.workload else "weak"', "scaling_note"):
         assert key in src, key
+    assert "scaling_efficiency" not in src          # (the driver computes efficiencies from the per-N values; the line carries the values and the one-GPU rate of the strong-scaling job)

@@ -277,6 +277,33 @@ def test_bench_two_gpus(gpu, phip, launcher):
     assert d["config"]["workload"] == "cornell_256x256_16spp_md4"
 
 
+@pytest.mark.timeout(900)
+def test_bench_default_line_of_two_ranks_sharing_one_gpu(gpu, phip):
+    """The line the driver's SCALE run asks for -- `bench.py --gpus 2` with no --workload under two ranks -- executed end to end on a box with ONE GPU: both ranks on
+    GPU 0, the film reduced by gloo through the host (PHIP_DIST_BACKEND=gloo; a RCCL clique of two ranks on one device is refused).  `value` is the metric's config at
+    2 x its samples per pixel (weak scaling: every rank renders the 268 M samples of the N = 1 line), and the fixed 4K job of BASELINE.json configs[4] rides along
+    under "workloads" with the one-GPU rate of the same job.  (Rates of two ranks that share a GPU mean nothing; the counts and the keys are what is checked.)"""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PHIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], cwd=root, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=840) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["workload"] == "cornell_1024x1024_512spp" and d["config"]["spp"] == 512
+    assert "scaling_efficiency" not in d and d["cpu_baseline"] is None
+    assert d["roofline"]["traffic_source"] and "cornell_1024x1024_256spp" in d["roofline"]["traffic_source"]     # a rank's launch is the N = 1 config's launch
+    job = d["workloads"]["atrium_3840x2160_1024spp_md8"]
+    assert job["scaling"] == "strong" and job["value"] > 0 and job["single_gpu_same_job"]["value"] > 0
+    assert job["spp"] == 1024 and job["width"] == 3840
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [2, 3])
 def test_two_ranks_on_one_gpu_run_the_per_process_protocol(gpu, phip, tmp_path, world):
