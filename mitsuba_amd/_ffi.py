@@ -95,8 +95,18 @@ def _build_locked(sid, out_lib, verbose):
     # an alternative build (PHIP_BUILD_OUTPUT) keeps objects of its own: tools/build_variant.sh links the PRODUCT's objects by name
     sfx = "" if os.path.abspath(out_lib) == os.path.abspath(LIB) else "-" + os.path.splitext(os.path.basename(out_lib))[0]
     units = [(src, extra, obj[:-2] + sfx + ".o") for src, extra, obj in UNITS]
+    # PHIP_BUILD_REUSE="phip_shade.hip ...": an alternative build whose extra flags do not concern these sources links the PRODUCT's objects of them (where they exist
+    # and are the current build's: this container; on the GPU box objects do not travel and everything is compiled)
+    reuse = set(os.environ.get("PHIP_BUILD_REUSE", "").split()) if sfx and built_id(LIB) == sid else set()
+    reused = set()
+    for i, (src, extra, obj) in enumerate(units):
+        prod = UNITS[i][2]
+        if src in reuse and os.path.exists(os.path.join(BUILD, prod)) and os.path.getmtime(os.path.join(BUILD, prod)) <= os.path.getmtime(LIB):
+            units[i] = (src, extra, prod); reused.add(prod)
     dbg = None if sfx else DEBUG_UNIT                           # (the hooks: the product build only)
     for src, extra, obj in units + ([dbg] if dbg else []):
+        if obj in reused:
+            continue
         if src == "phip.hip":
             extra = extra + ['-DPHIP_BUILD_ID="%s"' % sid]
         cmds.append([hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", os.path.join(BUILD, obj + ".tmp.o")])
@@ -122,7 +132,8 @@ def _build_locked(sid, out_lib, verbose):
             if verbose:
                 print(" ".join(cmd)); print(out)
     for _, _, obj in units + ([dbg] if dbg else []):
-        os.replace(os.path.join(BUILD, obj + ".tmp.o"), os.path.join(BUILD, obj))
+        if obj not in reused:
+            os.replace(os.path.join(BUILD, obj + ".tmp.o"), os.path.join(BUILD, obj))
     links = [(out_lib, [u[2] for u in units])]
     if dbg:
         links.append((LIB_DEBUG, [dbg[2] if u[0] == "phip.hip" else u[2] for u in units]))
@@ -134,6 +145,26 @@ def _build_locked(sid, out_lib, verbose):
             raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         os.replace(tmp, target)                             # a concurrent loader sees the old library or the new one, never half of one
     return out_lib
+
+
+# The libraries of two GPU tests (tests/test_gpu_parity.py): the product's sources with a fault or a limit compiled in.  __graft_entry__.build() makes them in the build
+# container so that they travel with the snapshot (a whole-library build on the GPU box costs the suite two minutes each); the tests call the same function, which
+# returns at once when the file carries the current build id.
+TEST_VARIANTS = {"fault": "-DMEGA_MB_FAULT=1",       # the first wave of every fused launch reports that it gave up: the frame must come from the re-rendered pass
+                 "cap32": "-DWP_CAP=32u"}            # 32-entry task stacks: nearly every push of a big scene spills to memory
+
+
+def build_test_variant(tag):
+    """mitsuba_amd/_build/libphip_<tag>.so (load it with PHIP_LIB); raises with the compiler's output when the build fails"""
+    import sys
+    out = os.path.join(BUILD, "libphip_%s.so" % tag)
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PHIP_BUILD_OUTPUT=out, PHIP_EXTRA_HIPCC_FLAGS=TEST_VARIANTS[tag], PHIP_BUILD_REUSE="phip_shade.hip")
+    env.pop("PHIP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from mitsuba_amd import _ffi; print(_ffi.build())" % root], env=env, capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(out):
+        raise RuntimeError("building %s failed:\n%s%s" % (out, r.stdout[-2000:], r.stderr[-2000:]))
+    return out
 
 
 def lib():

@@ -989,11 +989,9 @@ def test_fused_kernel_that_gives_up_degrades_to_the_wavefront_kernels(gpu, gauss
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available: the fault-injection library cannot be built")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "mitsuba_amd", "_build", "libphip_fault.so")
-    # the whole library with the fault compiled in (the product's objects do not travel to the GPU box: .gpurunignore); _ffi.build skips it when the file is up to date
-    env = dict(os.environ, PHIP_BUILD_OUTPUT=lib, PHIP_EXTRA_HIPCC_FLAGS="-DMEGA_MB_FAULT=1")
-    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from mitsuba_amd import _ffi; print(_ffi.build())" % root], env=env, capture_output=True, text=True)
-    assert r.returncode == 0 and os.path.exists(lib), r.stdout[-2000:] + r.stderr[-2000:]
+    # the library with the fault compiled in: __graft_entry__.build() made it in the build container and it travelled with the snapshot (the call returns at once when
+    # the file carries the current build id; otherwise it is built here, whole -- the product's objects do not travel to the GPU box: .gpurunignore)
+    lib = _ffi.build_test_variant("fault")
     script = r"""
 import sys, os
 sys.path.insert(0, %r)
@@ -1037,10 +1035,8 @@ def test_task_stack_of_the_fused_kernel_spills_to_memory(gpu, gauss, tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available: the small-stack library cannot be built")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "mitsuba_amd", "_build", "libphip_cap32.so")
-    env = dict(os.environ, PHIP_BUILD_OUTPUT=lib, PHIP_EXTRA_HIPCC_FLAGS="-DWP_CAP=32u")
-    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from mitsuba_amd import _ffi; print(_ffi.build())" % root], env=env, capture_output=True, text=True)
-    assert r.returncode == 0 and os.path.exists(lib), r.stdout[-2000:] + r.stderr[-2000:]
+    from mitsuba_amd import _ffi
+    lib = _ffi.build_test_variant("cap32")        # (prebuilt by __graft_entry__.build(), as the fault-injection library above)
     script = r"""
 import sys, os
 sys.path.insert(0, %r)
