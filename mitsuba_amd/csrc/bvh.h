@@ -775,7 +775,14 @@ inline void buildBVH(const float *positions, const uint32_t *indices, uint32_t n
     }
     detail::Builder B(T, out, positions, indices);
     for (int a = 0; a < 3; ++a) B.extent[a] = tight.mx[a] - tight.mn[a];
-    if (cameraPosition) for (int a = 0; a < 3; ++a) B.camPad[a] = 4.8e-7f * std::fabs(cameraPosition[a]);
+    if (cameraPosition) {
+        /* The camera's rays start outside the scene: with the origin 3000 scene extents away a distance is quantised to an eighth of a scene unit, and the Wald test -- the
+           arbiter: the oracle's sweep over all triangles -- then accepts rays that pass a triangle's silhouette by up to ~4 ulp(|o|) ON ANY AXIS (the plane equation's numerator
+           is rounded at the magnitude of the origin's LARGEST component and divided by the dominant component of the normal; round 6 found one such sample in 32768: the ray
+           0.03 units beside the tall block of the Cornell box).  So every axis is padded by the largest component, not by its own (8 ulp). */
+        const float m = std::max(std::fabs(cameraPosition[0]), std::max(std::fabs(cameraPosition[1]), std::fabs(cameraPosition[2])));
+        for (int a = 0; a < 3; ++a) B.camPad[a] = 4.8e-7f * m;
+    }
     detail::Box rootBox;
     /* spatial splits for the scenes that use the wide tree (small scenes are laid out for LDS record by record) */
     const char *sp = getenv("PHIP_BVH_SPATIAL");

@@ -785,7 +785,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                    distances c' -+ h |rcp| are rounded differently from the plane form the pad of bvh.h was sized for (two roundings of
                    magnitude |c rcp| + |o rcp| instead of one): h gets the rounding of c and another 4e-6 of the scene's extent on top */
                 const float ext = std::max(sc->bvh.tightMax[0] - sc->bvh.tightMin[0], std::max(sc->bvh.tightMax[1] - sc->bvh.tightMin[1], sc->bvh.tightMax[2] - sc->bvh.tightMin[2]));
-                const float camPos[3] = { d.camera.to_world[3], d.camera.to_world[7], d.camera.to_world[11] };
+                const float camMax = std::max(std::fabs(d.camera.to_world[3]), std::max(std::fabs(d.camera.to_world[7]), std::fabs(d.camera.to_world[11])));
                 float c[3], h[3];
                 const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
                 for (int a = 0; a < 3; ++a) {
@@ -794,7 +794,7 @@ static void buildScene(phip_scene *sc, const phip_scene_desc &d) {
                     /* ... and the rounding of o rcp, which grows with the ORIGIN's magnitude (two roundings of |o rcp| move a plane by ~2^-23 |o|): the only rays
                        that start outside the scene box are the camera's, so the camera position pays for it (a camera 60 scene extents away used to lose
                        leaf boxes; tests/test_gpu_parity.py: far camera) */
-                    h[a] = std::nextafter((float) need, INFINITY) + 2.4e-7f * std::fabs(c[a]) + 4e-6f * ext + 4.8e-7f * std::fabs(camPos[a]);
+                    h[a] = std::nextafter((float) need, INFINITY) + 2.4e-7f * std::fabs(c[a]) + 4e-6f * ext + 4.8e-7f * camMax;      /* (the largest component on every axis: bvh.h, buildBVH) */
                 }
                 packed.push_back(make_float4(c[0], c[1], c[2], pm_from_bits(bitsHi)));
                 packed.push_back(make_float4(h[0], h[1], h[2], pm_from_bits(bits)));
